@@ -1,0 +1,139 @@
+"""ctypes mirror of include/ffx.h (structures, prototypes, error handling).
+
+This module only *declares* the C ABI; it loads nothing.  `fireflies_amd._lib` binds it to
+libffx_hip.so (the product).  The test-only CPU oracle binds the same declarations to its own
+shared library (oracle/oracle.py) — both libraries implement the same header.
+"""
+import ctypes as C
+
+FFX_MAX_LEVELS = 96
+FFX_ABI_VERSION = 1
+REDUCE_SUM = 0
+REDUCE_SOFTOR = 1
+
+c_f = C.c_float
+c_i = C.c_int
+c_p = C.c_void_p
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [
+        ("n_tris", C.c_int32),
+        ("n_nodes", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("off_nodes", C.c_uint64),
+        ("off_order", C.c_uint64),
+        ("off_refit", C.c_uint64),
+        ("off_recs", C.c_uint64),
+        ("total_bytes", C.c_uint64),
+        ("level_start", C.c_int32 * (FFX_MAX_LEVELS + 1)),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("to_world", c_f * 16),
+        ("camera_to_sample", c_f * 16),
+        ("near_clip", c_f),
+        ("far_clip", c_f),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+    ]
+
+
+class Projector(C.Structure):
+    _fields_ = [
+        ("to_world", c_f * 16),
+        ("camera_to_sample", c_f * 16),
+        ("scale", c_f),
+        ("color", c_f * 3),
+        ("tex_w", C.c_int32),
+        ("tex_h", C.c_int32),
+        ("tex_channels", C.c_int32),
+        ("enabled", C.c_int32),
+    ]
+
+
+class Spot(C.Structure):
+    _fields_ = [
+        ("to_world", c_f * 16),
+        ("intensity", c_f * 3),
+        ("cutoff_deg", c_f),
+        ("beam_width_deg", c_f),
+        ("enabled", C.c_int32),
+    ]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("cam", Camera),
+        ("proj", Projector),
+        ("spot", Spot),
+        ("shadows", C.c_int32),
+        ("n_shapes", C.c_int32),
+    ]
+
+
+PF = C.POINTER(c_f)
+
+# name -> (restype, argtypes); every symbol include/ffx.h declares
+PROTOTYPES = {
+    "ffx_last_error": (C.c_char_p, []),
+    "ffx_abi_version": (c_i, []),
+    "ffx_backend": (C.c_char_p, []),
+    "ffx_project_rays_fwd": (c_i, [c_p, c_i, PF, c_p, c_p]),
+    "ffx_project_rays_bwd": (c_i, [c_p, c_i, PF, c_p, c_p, c_p]),
+    "ffx_transform_points": (c_i, [c_p, c_i, PF, c_i, c_p, c_p]),
+    "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
+    "ffx_splat_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "ffx_splat_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "ffx_splat_depth_fwd": (c_i, [c_p, c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "ffx_splat_lines_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
+    "ffx_blur_fwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),
+    "ffx_bvh_build_host": (c_i, [c_p, c_i, c_p, c_i, c_p, C.c_size_t, C.POINTER(BvhInfo)]),
+    "ffx_scene_update": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "ffx_trace_primary": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(Camera), c_i, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
+    "ffx_trace_rays": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
+    "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),
+    "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p]),
+}
+
+
+class FFXError(RuntimeError):
+    pass
+
+
+def mat16(m):
+    """row-major 4x4 (anything with 16 floats when flattened) -> (c_float*16)."""
+    flat = [float(v) for row in m for v in (row if hasattr(row, "__len__") else [row])]
+    if len(flat) != 16:
+        raise ValueError("expected a 4x4 matrix")
+    return (c_f * 16)(*flat)
+
+
+class Api:
+    """Pointer-level bindings for one loaded library.  Every method takes raw addresses
+    (ints) for [dev] arguments and raises FFXError with ffx_last_error() on failure."""
+
+    def __init__(self, cdll):
+        self.lib = cdll
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(cdll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        ver = cdll.ffx_abi_version()
+        if ver != FFX_ABI_VERSION:
+            raise FFXError(f"ABI version mismatch: library {ver}, python {FFX_ABI_VERSION}")
+        self.backend = cdll.ffx_backend().decode()
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.ffx_last_error()
+            raise FFXError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(*args), name)

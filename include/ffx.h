@@ -1,0 +1,240 @@
+/* ffx.h — C ABI of the MI355X-native Fireflies hot path.
+ *
+ * The reference (Henningson/Fireflies, pure Python) has no FFI: its hot path sits behind a
+ * Python object protocol (torch ops + Mitsuba's `mi.render` / `scene.ray_intersect` /
+ * `params.update()`).  Each entry point below cites the reference call it replaces
+ * (paths relative to /root/reference).  The reference-side binding a maintainer would add
+ * (ctypes) is shown in INTEGRATION.md.
+ *
+ * Two shared libraries implement exactly this header:
+ *   fireflies_amd/csrc/libffx_hip.so   the product: hand-written HIP kernels for gfx950.
+ *   oracle/_build/libffx_oracle.so      test infrastructure: scalar CPU restatement.
+ *
+ * Conventions
+ *   - every function returns FFX_OK (0) or a negative error code; ffx_last_error() gives a
+ *     thread-local message for the last failure on the calling thread.
+ *   - the caller owns every buffer; the library allocates no device memory.  Pointers marked
+ *     [dev] are device pointers for libffx_hip and host pointers for the oracle; pointers
+ *     marked [host] are always host pointers (small parameter blocks, copied into kernel
+ *     arguments at launch).
+ *   - all calls are asynchronous on `stream` (a hipStream_t; the oracle ignores it).
+ *   - arrays are dense, row-major, C order.  float = IEEE binary32.
+ *   - no global state besides the error string; calls on distinct streams are re-entrant.
+ */
+#ifndef FFX_H
+#define FFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFX_ABI_VERSION 1
+#define FFX_MAX_LEVELS 96
+
+typedef void *ffx_stream; /* hipStream_t */
+
+enum {
+  FFX_OK = 0,
+  FFX_ERR_ARG = -1,         /* bad argument (null pointer, non-positive size, ...) */
+  FFX_ERR_LAUNCH = -2,      /* HIP launch / runtime failure */
+  FFX_ERR_UNSUPPORTED = -3, /* valid request this build cannot serve */
+  FFX_ERR_NOMEM = -4        /* caller-provided buffer too small */
+};
+
+enum { FFX_REDUCE_SUM = 0, FFX_REDUCE_SOFTOR = 1 };
+
+const char *ffx_last_error(void);
+int ffx_abi_version(void);
+/* "hip-gfx950" for the product, "cpu-oracle" for the oracle. */
+const char *ffx_backend(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  pattern projection.
+ * Replaces Laser.projectRaysToNDC (fireflies/projection/laser.py:262-275) =
+ * transform_points(rays, K @ FLIP_Y) (fireflies/utils/math.py:220-228): q = KF·[r;1],
+ * pts = q.xyz / q.w.  `KF` [host] is the 4x4 row-major product K @ FLIP_Y.
+ * The backward is the autograd of the same expression w.r.t. rays.
+ * ---------------------------------------------------------------------------------------- */
+int ffx_project_rays_fwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/,
+                         float *pts /*[dev][n,3]*/, ffx_stream stream);
+int ffx_project_rays_bwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/,
+                         const float *gpts /*[dev][n,3]*/, float *grays /*[dev][n,3]*/,
+                         ffx_stream stream);
+
+/* transform_points / transform_directions (fireflies/utils/math.py:220-235).
+ * mode 0: homogeneous transform with perspective divide; mode 1: direction (w = 0, no divide). */
+int ffx_transform_points(const float *pts /*[dev][n,3]*/, int n, const float *M /*[host][16]*/,
+                         int mode, float *out /*[dev][n,3]*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  soft point splatting.
+ * texture_size = (size0, size1); point n = (p0, p1) in [0,1]^2; outputs are indexed [i][j]
+ * with i in [0,size1) paired with p1 and j in [0,size0) paired with p0:
+ *     v(n,i,j) = exp(-(((j - p0*size0)^2 + (i - p1*size1)^2) / sigma)^2)
+ * (fireflies/graphics/rasterization.py:7-37; note the d^4/sigma^2 falloff).
+ * ---------------------------------------------------------------------------------------- */
+
+/* rasterize_points (rasterization.py:7-37): dense [n,size1,size0] layers. */
+int ffx_splat_dense_fwd(const float *pts /*[dev][n,2]*/, int n, float sigma, int size0, int size1,
+                        float *out /*[dev][n,size1,size0]*/, ffx_stream stream);
+/* autograd of rasterize_points w.r.t. points for an upstream gradient on the dense layers. */
+int ffx_splat_dense_bwd(const float *pts /*[dev][n,2]*/, int n, float sigma, int size0, int size1,
+                        const float *gout /*[dev][n,size1,size0]*/, float *gpts /*[dev][n,2]*/,
+                        ffx_stream stream);
+
+/* Fused splat + reduce over the point axis, never materialising [n,size1,size0]:
+ *   reduce = FFX_REDUCE_SUM    : sum(rasterize_points(...), 0)        (rasterization.py:160-161)
+ *   reduce = FFX_REDUCE_SOFTOR : 1 - prod(1 - rasterize_points(...))  (rasterization.py:156-157)
+ * half_window < 0  : every term (terms that are exactly 0 in binary32 are skipped, so the
+ *                    result equals the dense reduction up to summation order).
+ * half_window >= 0 : the reference's footprint-limited variants baked_sum / baked_softor
+ *                    (rasterization.py:164-237, 321-392): point n only touches the odd window
+ *                    of half width `half_window` around floor(p*size), with the reference's
+ *                    border clipping; `sigma` is then what those functions call sigma (the
+ *                    caller passes the already squared value, rasterization.py:577).
+ * Output orientation is that of baked_sum / sum(dense): tex[size1][size0].               */
+int ffx_splat_fwd(const float *pts /*[dev][n,2]*/, int n, float sigma, int reduce, int half_window,
+                  int size0, int size1, float *tex /*[dev][size1,size0]*/, ffx_stream stream);
+/* gradient of the fused op w.r.t. points.  `tex` is the forward output (read for softor). */
+int ffx_splat_bwd(const float *pts /*[dev][n,2]*/, int n, float sigma, int reduce, int half_window,
+                  int size0, int size1, const float *tex /*[dev][size1,size0]*/,
+                  const float *gtex /*[dev][size1,size0]*/, float *gpts /*[dev][n,2]*/,
+                  ffx_stream stream);
+
+/* rasterize_depth (rasterization.py:66-104): dense layers normalised by their own maximum and
+ * scaled by depth[n].  Forward only plus gradient w.r.t. (pts, depth). */
+int ffx_splat_depth_fwd(const float *pts /*[dev][n,2]*/, const float *depth /*[dev][n]*/, int n,
+                        float sigma, int size0, int size1, float *out /*[dev][n,size1,size0]*/,
+                        ffx_stream stream);
+
+/* rasterize_lines (rasterization.py:107-153): soft line segments, lines [n,2,2] =
+ * (start,end) x (c0,c1) in [0,1]^2, output [n,size1,size0] (the reference is only
+ * self-consistent for size0 == size1; other sizes follow its broadcasting). */
+int ffx_splat_lines_fwd(const float *lines /*[dev][n,2,2]*/, int n, float sigma, int size0,
+                        int size1, float *out /*[dev][n,size1,size0]*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  texture finalise: separable Gaussian blur, reflect border.
+ * Replaces kornia.filters.gaussian_blur2d(tex, (k,k), (s,s)) at
+ * examples/vocalfold_scene.py:61-63 and main.py:69-71 (k = 5, s = 3).  ksize odd, <= 15.
+ * bwd is the exact transpose (gradient w.r.t. the input).
+ * ---------------------------------------------------------------------------------------- */
+int ffx_blur_fwd(const float *in /*[dev][h,w]*/, int h, int w, int ksize, float blur_sigma,
+                 float *out /*[dev][h,w]*/, ffx_stream stream);
+int ffx_blur_bwd(const float *gout /*[dev][h,w]*/, int h, int w, int ksize, float blur_sigma,
+                 float *gin /*[dev][h,w]*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5 + K6  per-randomisation geometry update.
+ * Replaces Mesh.get_randomized_vertices (fireflies/entity/mesh.py:158-165) +
+ * Scene.update_meshes (fireflies/scene.py:243-251) + the acceleration-structure rebuild
+ * inside mitsuba_params.update() (fireflies/scene.py:384).
+ *
+ * The BVH is an opaque blob in caller memory.  Topology is built once on the host from a
+ * representative pose (ffx_bvh_build_host), uploaded by the caller, and re-fitted on the
+ * device for every randomisation (ffx_scene_update), which also transforms the vertices:
+ *   world vertex of triangle corner = xform[shape] · [src_verts[vert_off[shape] + idx]; 1]
+ * so an animation frame is selected by pointing vert_off[shape] at that frame.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ffx_bvh_info {
+  int32_t n_tris;
+  int32_t n_nodes;
+  int32_t n_levels;  /* refit groups (node heights), <= FFX_MAX_LEVELS */
+  int32_t max_depth; /* traversal stack bound */
+  uint64_t off_nodes; /* byte offsets inside the blob */
+  uint64_t off_order;
+  uint64_t off_refit;
+  uint64_t off_recs;
+  uint64_t total_bytes;
+  int32_t level_start[FFX_MAX_LEVELS + 1]; /* ranges into the refit list, leaves-first */
+} ffx_bvh_info;
+
+/* upper bound of the blob size for n_tris triangles */
+size_t ffx_bvh_blob_bytes(int n_tris);
+/* Host-side topology build (binned SAH).  tris are *global* vertex indices into verts. */
+int ffx_bvh_build_host(const float *verts /*[host][n_verts,3]*/, int n_verts,
+                       const int32_t *tris /*[host][n_tris,3]*/, int n_tris,
+                       void *blob /*[host]*/, size_t blob_bytes, ffx_bvh_info *info /*[host] out*/);
+int ffx_scene_update(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]*/,
+                     const float *src_verts /*[dev][*,3]*/, const int32_t *tris /*[dev][n_tris,3] shape-local*/,
+                     const int32_t *tri_shape /*[dev][n_tris]*/, const int32_t *vert_off /*[dev][n_shapes]*/,
+                     const float *xform /*[dev][n_shapes,16]*/, int n_shapes, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  primary visibility.
+ * Replaces sensor.sample_ray + scene.ray_intersect in fireflies/graphics/depth.py:
+ *   from_camera_non_wrapped (:49-86)  -> jitter = 0
+ *   from_camera             (:128-166) -> jitter = 1
+ *   get_segmentation_from_camera (:89-125) -> shape_out
+ *   cast_laser_id           (:33-46)  -> ffx_trace_rays
+ * Sample index idx = (y*W + x)*spp + s, sample position ((x + jx)/W, (y + jy)/H) with no
+ * half-pixel offset (depth.py:61-69).  t is the distance along the unit ray direction from
+ * the near-plane origin; a miss writes t = 0 (depth.py:84), shape = -1, prim = -1.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ffx_camera {
+  float to_world[16];         /* row-major, camera looks down +z of its local frame */
+  float camera_to_sample[16]; /* mi.perspective_projection(...) matrix */
+  float near_clip, far_clip;
+  int32_t width, height;
+} ffx_camera;
+
+int ffx_trace_primary(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
+                      const ffx_camera *cam /*[host]*/, int spp, int jitter, uint32_t seed,
+                      float *t_out /*[dev][H*W*spp]*/, int32_t *shape_out /*[dev] or NULL*/,
+                      int32_t *prim_out /*[dev] or NULL*/, ffx_stream stream);
+int ffx_trace_rays(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
+                   const float *origins /*[dev][n,3]*/, const float *dirs /*[dev][n,3]*/, int n,
+                   float tmax, float *t_out /*[dev][n]*/, int32_t *shape_out /*[dev] or NULL*/,
+                   int32_t *prim_out /*[dev] or NULL*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8 / K9  render and its adjoint.
+ * Replaces mi.render(scene, spp=...) (examples/vocalfold_scene.py:102, main.py:156) and its
+ * Dr.Jit backward w.r.t. `tex.data` (examples/vocalfold_scene.py:69).  Shading model
+ * (DESIGN.md §4): direct illumination at the primary hit from two delta emitters
+ * (projector with irradiance texture, spot light), Lambert BSDF per shape, optional shadow
+ * rays, box reconstruction filter, counter-based per-sample jitter.
+ * The render is linear in the texture, so the adjoint needs no forward state: it replays
+ * the same samples (same seed) and scatters d(loss)/d(img) through the bilinear weights.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ffx_projector {
+  float to_world[16];
+  float camera_to_sample[16]; /* K_PROJECTOR of examples/vocalfold_scene.py:31-38 */
+  float scale;                /* Mitsuba projector `scale` */
+  float color[3];             /* RGB weight applied to a 1-channel texture */
+  int32_t tex_w, tex_h, tex_channels; /* tex_channels: 1 or 3 */
+  int32_t enabled;
+} ffx_projector;
+
+typedef struct ffx_spot {
+  float to_world[16];
+  float intensity[3];
+  float cutoff_deg, beam_width_deg;
+  int32_t enabled;
+} ffx_spot;
+
+typedef struct ffx_scene_desc {
+  ffx_camera cam;
+  ffx_projector proj;
+  ffx_spot spot;
+  int32_t shadows;  /* trace shadow rays toward both emitters */
+  int32_t n_shapes; /* rows of shape_albedo */
+} ffx_scene_desc;
+
+int ffx_render_fwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
+                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                   const float *tex /*[dev][tex_h,tex_w,tex_channels]*/, int spp, uint32_t seed,
+                   int img_fp16, void *img /*[dev][H,W,3] fp32 or fp16*/, ffx_stream stream);
+/* gtex is ACCUMULATED into (the caller zeroes it). */
+int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
+                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                   int spp, uint32_t seed, const float *gimg /*[dev][H,W,3] fp32*/,
+                   float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFX_H */

@@ -1,0 +1,201 @@
+"""numpy front-end of the CPU oracle (oracle/_build/libffx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — see the header of oracle/ffx_oracle.c.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from fireflies_amd import _abi  # noqa: E402  (ABI declarations only; loads nothing)
+
+LIB_PATH = os.path.join(_HERE, "_build", "libffx_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_api = None
+
+
+def api():
+    global _api
+    if _api is None:
+        build()
+        _api = _abi.Api(C.CDLL(LIB_PATH))
+        assert _api.backend == "cpu-oracle"
+    return _api
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def _m16(m):
+    return (C.c_float * 16)(*np.asarray(m, dtype=np.float32).reshape(16).tolist())
+
+
+# ---------------------------------------------------------------- K1
+def project_rays_fwd(rays, KF):
+    rays = _f32(rays)
+    out = np.empty_like(rays)
+    api().call("ffx_project_rays_fwd", _p(rays), rays.shape[0], _m16(KF), _p(out), None)
+    return out
+
+
+def project_rays_bwd(rays, KF, gpts):
+    rays, gpts = _f32(rays), _f32(gpts)
+    out = np.empty_like(rays)
+    api().call("ffx_project_rays_bwd", _p(rays), rays.shape[0], _m16(KF), _p(gpts), _p(out), None)
+    return out
+
+
+def transform_points(pts, M, mode=0):
+    pts = _f32(pts)
+    out = np.empty_like(pts)
+    api().call("ffx_transform_points", _p(pts), pts.shape[0], _m16(M), mode, _p(out), None)
+    return out
+
+
+# ---------------------------------------------------------------- K2
+def splat_dense_fwd(pts, sigma, size0, size1):
+    pts = _f32(pts)
+    out = np.empty((pts.shape[0], size1, size0), np.float32)
+    api().call("ffx_splat_dense_fwd", _p(pts), pts.shape[0], sigma, size0, size1, _p(out), None)
+    return out
+
+
+def splat_dense_bwd(pts, sigma, size0, size1, gout):
+    pts, gout = _f32(pts), _f32(gout)
+    out = np.empty_like(pts)
+    api().call("ffx_splat_dense_bwd", _p(pts), pts.shape[0], sigma, size0, size1, _p(gout), _p(out), None)
+    return out
+
+
+def splat_fwd(pts, sigma, reduce, half_window, size0, size1):
+    pts = _f32(pts)
+    out = np.empty((size1, size0), np.float32)
+    api().call("ffx_splat_fwd", _p(pts), pts.shape[0], sigma, reduce, half_window, size0, size1, _p(out), None)
+    return out
+
+
+def splat_bwd(pts, sigma, reduce, half_window, size0, size1, tex, gtex):
+    pts, tex, gtex = _f32(pts), _f32(tex), _f32(gtex)
+    out = np.empty_like(pts)
+    api().call("ffx_splat_bwd", _p(pts), pts.shape[0], sigma, reduce, half_window, size0, size1, _p(tex), _p(gtex), _p(out), None)
+    return out
+
+
+def splat_depth_fwd(pts, depth, sigma, size0, size1):
+    pts, depth = _f32(pts), _f32(depth).reshape(-1)
+    out = np.empty((pts.shape[0], size1, size0), np.float32)
+    api().call("ffx_splat_depth_fwd", _p(pts), _p(depth), pts.shape[0], sigma, size0, size1, _p(out), None)
+    return out
+
+
+def splat_lines_fwd(lines, sigma, size0, size1):
+    lines = _f32(lines)
+    out = np.empty((lines.shape[0], size1, size0), np.float32)
+    api().call("ffx_splat_lines_fwd", _p(lines), lines.shape[0], sigma, size0, size1, _p(out), None)
+    return out
+
+
+# ---------------------------------------------------------------- K3
+def blur_fwd(img, ksize=5, sigma=3.0):
+    img = _f32(img)
+    out = np.empty_like(img)
+    api().call("ffx_blur_fwd", _p(img), img.shape[0], img.shape[1], ksize, sigma, _p(out), None)
+    return out
+
+
+def blur_bwd(g, ksize=5, sigma=3.0):
+    g = _f32(g)
+    out = np.empty_like(g)
+    api().call("ffx_blur_bwd", _p(g), g.shape[0], g.shape[1], ksize, sigma, _p(out), None)
+    return out
+
+
+# ---------------------------------------------------------------- K5..K9
+def camera_struct(to_world, camera_to_sample, near, far, width, height):
+    c = _abi.Camera()
+    c.to_world = _m16(to_world)
+    c.camera_to_sample = _m16(camera_to_sample)
+    c.near_clip, c.far_clip, c.width, c.height = near, far, width, height
+    return c
+
+
+class Geometry:
+    """Triangle scene + the oracle's BVH blob (host memory)."""
+
+    def __init__(self, src_verts, tris, tri_shape, vert_off, build_verts=None):
+        """src_verts [*,3] pool, tris [F,3] shape-local indices, tri_shape [F], vert_off [S]."""
+        self.src_verts = _f32(src_verts)
+        self.tris = _i32(tris)
+        self.tri_shape = _i32(tri_shape)
+        self.vert_off = _i32(vert_off)
+        self.n_shapes = self.vert_off.shape[0]
+        F = self.tris.shape[0]
+        glob = self.tris + self.vert_off[self.tri_shape][:, None]
+        glob = _i32(glob)
+        bv = self.src_verts if build_verts is None else _f32(build_verts)
+        nbytes = api().lib.ffx_bvh_blob_bytes(F)
+        self.blob = np.zeros(nbytes, np.uint8)
+        self.info = _abi.BvhInfo()
+        api().call("ffx_bvh_build_host", _p(bv), bv.shape[0], _p(glob), F, _p(self.blob), nbytes, C.byref(self.info))
+        self.update(np.tile(np.eye(4, dtype=np.float32), (self.n_shapes, 1, 1)))
+
+    def update(self, xforms, vert_off=None):
+        if vert_off is not None:
+            self.vert_off = _i32(vert_off)
+        xf = _f32(xforms).reshape(self.n_shapes, 16)
+        api().call(
+            "ffx_scene_update", _p(self.blob), C.byref(self.info), _p(self.src_verts), _p(self.tris), _p(self.tri_shape),
+            _p(self.vert_off), _p(xf), self.n_shapes, None,
+        )
+
+    def trace_primary(self, cam, spp=1, jitter=0, seed=0):
+        n = cam.width * cam.height * spp
+        t = np.empty(n, np.float32)
+        shape = np.empty(n, np.int32)
+        prim = np.empty(n, np.int32)
+        api().call("ffx_trace_primary", _p(self.blob), C.byref(self.info), C.byref(cam), spp, jitter, seed, _p(t), _p(shape), _p(prim), None)
+        return t, shape, prim
+
+    def trace_rays(self, origins, dirs, tmax=3.0e38):
+        o, d = _f32(origins), _f32(dirs)
+        n = o.shape[0]
+        t = np.empty(n, np.float32)
+        shape = np.empty(n, np.int32)
+        prim = np.empty(n, np.int32)
+        api().call("ffx_trace_rays", _p(self.blob), C.byref(self.info), _p(o), _p(d), n, tmax, _p(t), _p(shape), _p(prim), None)
+        return t, shape, prim
+
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False):
+        albedo = _f32(albedo)
+        tex = _f32(tex)
+        H, W = sd.cam.height, sd.cam.width
+        img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
+        api().call("ffx_render_fwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), None)
+        return img
+
+    def render_bwd(self, sd, albedo, spp, seed, gimg):
+        albedo, gimg = _f32(albedo), _f32(gimg)
+        gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        api().call("ffx_render_bwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, _p(gimg), _p(gtex), None)
+        return gtex
