@@ -1,0 +1,82 @@
+// ffx_common.h — shared declarations for libffx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ffx.h"
+
+// ------------------------------------------------------------------ error handling
+void ffx_set_error(const char *fmt, ...);
+#define FFX_FAIL(code, ...)     \
+  do {                          \
+    ffx_set_error(__VA_ARGS__); \
+    return (code);              \
+  } while (0)
+// checks the launch itself (not completion: all calls are asynchronous on the stream)
+#define FFX_CHECK_LAUNCH(what)                                                           \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) FFX_FAIL(FFX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int ffx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ small POD blocks passed by value
+struct Mat4 { float m[16]; };
+
+// ------------------------------------------------------------------ vector helpers (same operation order as oracle/ffx_oracle.c)
+struct v3 { float x, y, z; };
+__host__ __device__ inline v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline float diffprod(float a, float b, float c, float d) { return fmaf(a, b, -(c * d)); }
+__device__ inline v3 vcross(v3 a, v3 b) {
+  return V3(diffprod(a.y, b.z, a.z, b.y), diffprod(a.z, b.x, a.x, b.z), diffprod(a.x, b.y, a.y, b.x));
+}
+__device__ inline float vdot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ inline v3 xf_point(const float *m, v3 p) {
+  return V3(fmaf(m[0], p.x, fmaf(m[1], p.y, fmaf(m[2], p.z, m[3]))), fmaf(m[4], p.x, fmaf(m[5], p.y, fmaf(m[6], p.z, m[7]))),
+            fmaf(m[8], p.x, fmaf(m[9], p.y, fmaf(m[10], p.z, m[11]))));
+}
+__device__ inline v3 xf_dir(const float *m, v3 d) {
+  return V3(fmaf(m[0], d.x, fmaf(m[1], d.y, m[2] * d.z)), fmaf(m[4], d.x, fmaf(m[5], d.y, m[6] * d.z)),
+            fmaf(m[8], d.x, fmaf(m[9], d.y, m[10] * d.z)));
+}
+
+// counter-based per-sample jitter: lowbias32 integer hash
+__host__ __device__ inline uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+// ------------------------------------------------------------------ BVH blob layout
+// 64-byte node holding BOTH children's boxes: one fetch per traversal step.
+// child >= 0: inner node index.  child < 0: leaf, ~child = (first_slot << 3) | (count - 1).
+// An empty child has lo = +inf, hi = -inf and child = FFX_EMPTY_CHILD.
+struct __attribute__((aligned(16))) BvhNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  int32_t c0, c1;
+  int32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
+#define FFX_EMPTY_CHILD ((int32_t)0x80000000)
+#define FFX_LEAF_MAX 4
+
+// 48-byte triangle record in leaf order, written by ffx_scene_update
+struct __attribute__((aligned(16))) TriRec {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  int32_t prim;
+  int32_t shape;
+  float pad;
+};
+static_assert(sizeof(TriRec) == 48, "record must be 48 bytes");
+
+// entry of the refit list (leaves-first by node height)
+struct RefitEntry { int32_t node; };
+
+#define FFX_STACK_DEPTH 48
+
+int ffx_inv4(const float *m, float *out);  // double-precision cofactor inverse (host)

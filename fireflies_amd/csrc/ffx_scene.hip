@@ -1,0 +1,151 @@
+// ffx_scene.hip — K5 + K6: per-randomisation geometry update on the GPU.
+//
+// Replaces Mesh.get_randomized_vertices (fireflies/entity/mesh.py:158-165), Scene.update_meshes
+// (fireflies/scene.py:243-251) and the acceleration-structure rebuild hidden in
+// mitsuba_params.update() (fireflies/scene.py:384).
+//
+//   k_build_records : one lane per leaf slot.  Gathers the triangle's three source vertices
+//                     (animation frame selected by vert_off[shape]), applies the shape's 4x4 and
+//                     writes the 48-byte record {v0, e1, e2, prim, shape} in LEAF order, so that
+//                     traversal reads a leaf's triangles as one contiguous run.  World-space
+//                     vertices are never written back to HBM.
+//   k_refit_level   : nodes grouped by height (leaves-first); a node's child boxes depend only
+//                     on lower groups, so each group is one parallel pass.
+//   k_refit_tail    : every group of <= 1024 nodes is handled by ONE workgroup that walks the
+//                     remaining heights with a workgroup barrier in between (all waves of a
+//                     workgroup share one CU's L1, so workgroup-scope visibility is enough);
+//                     this replaces ~20 tiny dependent launches by one.
+// HBM traffic per update: 12*V (gather, mostly L2 hits: each vertex is shared by ~6 triangles)
+// + 48*F (records out) + 64*N_nodes (nodes in/out).
+#include "ffx_common.h"
+
+#define UPD_BLOCK 256
+#define TAIL_BLOCK 1024
+
+__global__ void __launch_bounds__(UPD_BLOCK)
+    k_build_records(const int32_t *__restrict__ order, TriRec *__restrict__ recs, int n_tris, const float *__restrict__ src_verts,
+                    const int32_t *__restrict__ tris, const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off,
+                    const float *__restrict__ xform, int n_shapes) {
+  int k = blockIdx.x * UPD_BLOCK + threadIdx.x;
+  if (k >= n_tris) return;
+  int prim = order[k];
+  int sh = tri_shape[prim];
+  sh = min(max(sh, 0), n_shapes - 1); // host validated; clamp so a bad id can never fault
+  const float *m = xform + 16 * sh;
+  float mm[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) mm[i] = m[i];
+  int base = vert_off[sh];
+  v3 p[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *sv = src_verts + 3 * ((size_t)base + tris[3 * prim + c]);
+    p[c] = xf_point(mm, V3(sv[0], sv[1], sv[2]));
+  }
+  v3 e1 = vsub(p[1], p[0]), e2 = vsub(p[2], p[0]);
+  float4 *o = reinterpret_cast<float4 *>(recs + k);
+  o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
+  o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+  o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), 0.f);
+}
+
+// conservative box of a leaf's triangles.  The intersection test works on (v0, e1, e2), whose
+// corners v0+e1, v0+e2 are re-rounded here, so the box is widened by a few ulps.
+__device__ __forceinline__ void leaf_box(const TriRec *__restrict__ recs, int32_t code, float lo[3], float hi[3]) {
+  uint32_t lc = (uint32_t)~code;
+  int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+  for (int i = 0; i < count; ++i) {
+    const TriRec &r = recs[first + i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float p0 = r.v0[a], p1 = r.v0[a] + r.e1[a], p2 = r.v0[a] + r.e2[a];
+      float mn = fminf(p0, fminf(p1, p2)), mx = fmaxf(p0, fmaxf(p1, p2));
+      float pad = 4e-7f * fmaxf(fabsf(mn), fabsf(mx));
+      lo[a] = fminf(lo[a], mn - pad);
+      hi[a] = fmaxf(hi[a], mx + pad);
+    }
+  }
+}
+
+__device__ __forceinline__ void child_box(const BvhNode *nodes, const TriRec *__restrict__ recs, int32_t c, float lo[3], float hi[3]) {
+  if (c == FFX_EMPTY_CHILD) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+  } else if (c < 0) {
+    leaf_box(recs, c, lo, hi);
+  } else {
+    const BvhNode &n = nodes[c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(n.lo0[a], n.lo1[a]); hi[a] = fmaxf(n.hi0[a], n.hi1[a]); }
+  }
+}
+
+__device__ __forceinline__ void refit_node(BvhNode *nodes, const TriRec *__restrict__ recs, int id) {
+  BvhNode &n = nodes[id];
+  float lo[3], hi[3];
+  child_box(nodes, recs, n.c0, lo, hi);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { n.lo0[a] = lo[a]; n.hi0[a] = hi[a]; }
+  child_box(nodes, recs, n.c1, lo, hi);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { n.lo1[a] = lo[a]; n.hi1[a] = hi[a]; }
+}
+
+__global__ void __launch_bounds__(UPD_BLOCK)
+    k_refit_level(BvhNode *nodes, const TriRec *__restrict__ recs, const int32_t *__restrict__ refit, int begin, int end) {
+  int i = begin + blockIdx.x * UPD_BLOCK + threadIdx.x;
+  if (i >= end) return;
+  refit_node(nodes, recs, refit[i]);
+}
+
+struct TailLevels { int n; int start[FFX_MAX_LEVELS + 1]; };
+
+__global__ void __launch_bounds__(TAIL_BLOCK) k_refit_tail(BvhNode *nodes, const TriRec *__restrict__ recs, const int32_t *__restrict__ refit, TailLevels lv) {
+  for (int l = 0; l < lv.n; ++l) {
+    int i = lv.start[l] + threadIdx.x;
+    if (i < lv.start[l + 1]) refit_node(nodes, recs, refit[i]);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
+                                const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+  if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
+  if (info->n_tris < 1 || info->n_nodes < 1 || info->n_levels < 1 || info->n_levels > FFX_MAX_LEVELS)
+    FFX_FAIL(FFX_ERR_ARG, "scene_update: bad bvh info");
+  if (info->level_start[info->n_levels] != info->n_nodes) FFX_FAIL(FFX_ERR_ARG, "scene_update: refit list does not cover every node");
+  hipStream_t st = (hipStream_t)s;
+  char *base = (char *)bvh;
+  BvhNode *nodes = (BvhNode *)(base + info->off_nodes);
+  const int32_t *order = (const int32_t *)(base + info->off_order);
+  const int32_t *refit = (const int32_t *)(base + info->off_refit);
+  TriRec *recs = (TriRec *)(base + info->off_recs);
+
+  hipLaunchKernelGGL(k_build_records, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
+                     tri_shape, vert_off, xform, n_shapes);
+  FFX_CHECK_LAUNCH("scene_update/build_records");
+
+  int l = 0;
+  for (; l < info->n_levels; ++l) {
+    int cnt = info->level_start[l + 1] - info->level_start[l];
+    // once this and every later group fit one workgroup, hand the rest to the tail kernel
+    bool tail_ok = true;
+    for (int m = l; m < info->n_levels; ++m)
+      if (info->level_start[m + 1] - info->level_start[m] > TAIL_BLOCK) { tail_ok = false; break; }
+    if (tail_ok) break;
+    hipLaunchKernelGGL(k_refit_level, dim3(ffx_cdiv(cnt, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, nodes, recs, refit, info->level_start[l],
+                       info->level_start[l + 1]);
+    FFX_CHECK_LAUNCH("scene_update/refit_level");
+  }
+  if (l < info->n_levels) {
+    TailLevels lv;
+    lv.n = info->n_levels - l;
+    for (int m = 0; m <= lv.n; ++m) lv.start[m] = info->level_start[l + m];
+    hipLaunchKernelGGL(k_refit_tail, dim3(1), dim3(TAIL_BLOCK), 0, st, nodes, recs, refit, lv);
+    FFX_CHECK_LAUNCH("scene_update/refit_tail");
+  }
+  return FFX_OK;
+}

@@ -1,0 +1,567 @@
+// ffx_splat.hip — K1 (pattern projection), K2 (soft point splatting, forward + gradient),
+// K3 (texture blur) for gfx950.  See include/ffx.h for the reference call each entry replaces
+// and DESIGN.md §5 for the kernel design and roofline of each.
+//
+// All arithmetic follows the operation order of the reference's torch code (separate multiplies
+// and adds; the file is compiled with -ffp-contract=off), so results agree with the reference to
+// the last few ulps of expf.
+#include "ffx_common.h"
+
+#define SPLAT_BLOCK 256
+#define TILE_W 32
+#define TILE_H 8
+#define CAND_MAX 512   // candidates staged per chunk in the fused forward kernel
+#define NEIGH_MAX 2048 // neighbour list capacity of the gradient kernel
+// exp(-q^2) is exactly 0 in binary32 for q^2 > 103.98; 10.3^2 = 106.1 leaves a margin, so culling
+// on q > FFX_QCUT never drops a non-zero term.
+#define FFX_QCUT 10.3f
+
+// ------------------------------------------------------------------------------- helpers
+// value of one splat at texel (fj, fi); rasterization.py:29-35
+__device__ __forceinline__ float splat_val(float fj, float fi, float p0s, float p1s, float sigma, float inv_sigma, float &d, float &yd, float &xd) {
+  yd = fj - p0s;
+  xd = fi - p1s;
+  d = yd * yd + xd * xd;
+  if (d * inv_sigma > FFX_QCUT) return 0.f;
+  float q = d / sigma;
+  return expf(-(q * q));
+}
+// dv/d(p0*size0) = v*4*d*yd/sigma^2 (and xd for the other axis)
+__device__ __forceinline__ float splat_gcoef(float v, float d, float sigma) { return v * 4.0f * d / (sigma * sigma); }
+
+// window of baked_sum/baked_softor along one axis (rasterization.py:180-235); mirrors
+// window_axis() of the oracle.  Returns false if the point contributes nothing on this axis.
+struct Win1 { int lo, hi, off; float pm; };
+__device__ __forceinline__ bool window_axis(float p, int half, int size, Win1 &w) {
+  int fp = 2 * half + 1;
+  int fo = (int)floorf(p - (float)half);
+  int rs = 0, re = fp;
+  if (fo < 0) { rs = -fo; fo = 0; }
+  if (fo + fp >= size) re = size - fo;
+  if (!(rs < re)) return false;
+  w.pm = p - floorf(p) + (float)half;
+  w.lo = fo;
+  w.hi = fo + re - rs;
+  w.off = rs - fo; // dist index a = A + off
+  return true;
+}
+__device__ __forceinline__ float baked_val(int A, int B, const Win1 &w0, const Win1 &w1, float sigma, float &d, float &yd, float &xd) {
+  yd = (float)(A + w0.off) - w0.pm;
+  xd = (float)(B + w1.off) - w1.pm;
+  d = yd * yd + xd * xd;
+  float q = d / sigma;
+  return expf(-(q * q));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// =================================================================================== K1
+__global__ void __launch_bounds__(256) k_project_fwd(const float *__restrict__ rays, int n, Mat4 KF, float *__restrict__ pts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
+  const float *K = KF.m;
+  float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+  float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+  float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
+  float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+  pts[3 * i] = q0 / q3;
+  pts[3 * i + 1] = q1 / q3;
+  pts[3 * i + 2] = q2 / q3;
+}
+
+__global__ void __launch_bounds__(256)
+    k_project_bwd(const float *__restrict__ rays, int n, Mat4 KF, const float *__restrict__ gpts, float *__restrict__ grays) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
+  const float *K = KF.m;
+  float q[4], gq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = K[4 * r] * x + K[4 * r + 1] * y + K[4 * r + 2] * z + K[4 * r + 3];
+  float iw = 1.0f / q[3];
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    gq[k] = gpts[3 * i + k] * iw;
+    acc += gpts[3 * i + k] * q[k];
+  }
+  gq[3] = -acc * iw * iw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) grays[3 * i + c] = gq[0] * K[c] + gq[1] * K[4 + c] + gq[2] * K[8 + c] + gq[3] * K[12 + c];
+}
+
+__global__ void __launch_bounds__(256) k_transform_points(const float *__restrict__ pts, int n, Mat4 M, int mode, float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  const float *K = M.m;
+  if (mode == 0) {
+    float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+    float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+    float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
+    float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+    out[3 * i] = q0 / q3;
+    out[3 * i + 1] = q1 / q3;
+    out[3 * i + 2] = q2 / q3;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out[3 * i + r] = K[4 * r] * x + K[4 * r + 1] * y + K[4 * r + 2] * z;
+  }
+}
+
+// =================================================================================== K2 dense forward
+// rasterize_points: [n,size1,size0] layers.  HBM-write bound (4 B per (point, texel)); each lane
+// produces 4 consecutive texels and issues one 16-byte store when rows are 16-byte aligned.
+// MODE 0: plain; MODE 1: rasterize_depth (divide by the layer maximum, scale by depth).
+template <int MODE>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_splat_dense_fwd(const float *__restrict__ pts, const float *__restrict__ depth, float sigma, int size0, int size1, int w4, int vec_ok,
+                      float *__restrict__ out) {
+  int n = blockIdx.y;
+  long t = (long)blockIdx.x * SPLAT_BLOCK + threadIdx.x;
+  if (t >= (long)w4 * size1) return;
+  int i = (int)(t / w4), j0 = (int)(t % w4) * 4;
+  float p0s = pts[2 * n] * (float)size0, p1s = pts[2 * n + 1] * (float)size1;
+  float inv_sigma = 1.0f / sigma;
+  float scale_den = 1.f, scale_mul = 1.f;
+  if (MODE == 1) {
+    // the layer maximum sits at the texel nearest to the point (v is monotone in each |dist|)
+    float jn = fminf(fmaxf(rintf(p0s), 0.f), (float)(size0 - 1));
+    float in_ = fminf(fmaxf(rintf(p1s), 0.f), (float)(size1 - 1));
+    float yd = jn - p0s, xd = in_ - p1s;
+    float d = yd * yd + xd * xd;
+    float q = d / sigma;
+    scale_den = expf(-(q * q));
+    scale_mul = depth[n];
+  }
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float d, yd, xd;
+    float val = splat_val((float)(j0 + k), (float)i, p0s, p1s, sigma, inv_sigma, d, yd, xd);
+    if (MODE == 1) val = (val / scale_den) * scale_mul;
+    v[k] = val;
+  }
+  float *o = out + ((size_t)n * size1 + i) * size0 + j0;
+  if (vec_ok) {
+    *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (j0 + k < size0) o[k] = v[k];
+  }
+}
+
+// rasterize_lines (rasterization.py:107-153)
+__global__ void __launch_bounds__(SPLAT_BLOCK) k_splat_lines_fwd(const float *__restrict__ lines, float sigma, int size0, int size1, float *__restrict__ out) {
+  int n = blockIdx.y;
+  long t = (long)blockIdx.x * SPLAT_BLOCK + threadIdx.x;
+  if (t >= (long)size0 * size1) return;
+  int a = (int)(t / size0), b = (int)(t % size0);
+  const float eps = 1.1920928955078125e-07f;
+  float sx = lines[4 * n + 0] * (float)size0, sy = lines[4 * n + 1] * (float)size1;
+  float ex = lines[4 * n + 2] * (float)size0, ey = lines[4 * n + 3] * (float)size1;
+  float mx = ex - sx, my = ey - sy;
+  float mm = mx * mx + my * my + eps;
+  float X = (float)b, Y = (float)a;
+  float pax = X - sx, pay = Y - sy, pbx = X - ex, pby = Y - ey;
+  float t0 = (pax * mx + pay * my) / mm;
+  float qx = X - (sx + t0 * mx), qy = Y - (sy + t0 * my);
+  float d0 = (t0 <= 0.f) ? (pax * pax + pay * pay) : 0.f;
+  float d1 = (t0 > 0.f && t0 < 1.f) ? (qx * qx + qy * qy) : 0.f;
+  float d2 = (t0 >= 1.f) ? (pbx * pbx + pby * pby) : 0.f;
+  float dist = d0 + d1 + d2;
+  out[((size_t)n * size1 + a) * size0 + b] = expf(-(dist * dist) / (sigma * sigma));
+}
+
+// =================================================================================== K2 fused forward
+// One workgroup per 32x8 texel tile.  Wave 0 culls the points against the tile (ballot +
+// prefix: the compacted list keeps ascending point order, so every texel accumulates in the
+// same order as torch.sum/prod over dim 0) and stages the survivors in LDS; every lane then
+// reads the staged points as LDS broadcasts.  The [n,size1,size0] tensor never exists.
+template <bool BAKED>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_splat_fused_fwd(const float *__restrict__ pts, int n, float sigma, int reduce, int half_window, int size0, int size1, float *__restrict__ tex) {
+  __shared__ float c_p0[CAND_MAX], c_p1[CAND_MAX];
+  __shared__ int c_lo0[BAKED ? CAND_MAX : 1], c_hi0[BAKED ? CAND_MAX : 1], c_lo1[BAKED ? CAND_MAX : 1], c_hi1[BAKED ? CAND_MAX : 1];
+  __shared__ int c_of0[BAKED ? CAND_MAX : 1], c_of1[BAKED ? CAND_MAX : 1];
+  __shared__ int c_count;
+
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+  const int j = j0 + (tid % TILE_W), i = i0 + (tid / TILE_W);
+  const float inv_sigma = 1.0f / sigma;
+  float acc = (reduce == FFX_REDUCE_SUM) ? 0.f : 1.f;
+
+  for (int chunk = 0; chunk < n; chunk += CAND_MAX) {
+    if (tid < 64) { // wave 0: ordered compaction of this chunk
+      int count = 0;
+      int lim = min(CAND_MAX, n - chunk);
+      for (int base = 0; base < lim; base += 64) {
+        int k = chunk + base + tid;
+        bool keep = false;
+        float p0s = 0.f, p1s = 0.f;
+        Win1 w0, w1;
+        if (base + tid < lim) {
+          p0s = pts[2 * k] * (float)size0;
+          p1s = pts[2 * k + 1] * (float)size1;
+          if (BAKED) {
+            keep = window_axis(p0s, half_window, size0, w0) && window_axis(p1s, half_window, size1, w1);
+            keep = keep && w0.lo < j0 + TILE_W && w0.hi > j0 && w1.lo < i0 + TILE_H && w1.hi > i0;
+          } else {
+            float dx = fmaxf(fmaxf((float)j0 - p0s, p0s - (float)(j0 + TILE_W - 1)), 0.f);
+            float dy = fmaxf(fmaxf((float)i0 - p1s, p1s - (float)(i0 + TILE_H - 1)), 0.f);
+            keep = (dx * dx + dy * dy) * inv_sigma <= FFX_QCUT;
+          }
+        }
+        unsigned long long m = __ballot(keep);
+        int pos = count + __popcll(m & ((1ull << tid) - 1ull));
+        if (keep) {
+          if (BAKED) {
+            c_p0[pos] = w0.pm; c_p1[pos] = w1.pm;
+            c_lo0[pos] = w0.lo; c_hi0[pos] = w0.hi; c_of0[pos] = w0.off;
+            c_lo1[pos] = w1.lo; c_hi1[pos] = w1.hi; c_of1[pos] = w1.off;
+          } else {
+            c_p0[pos] = p0s; c_p1[pos] = p1s;
+          }
+        }
+        count += __popcll(m);
+      }
+      if (tid == 0) c_count = count;
+    }
+    __syncthreads();
+    int cnt = c_count;
+    if (j < size0 && i < size1) {
+      for (int c = 0; c < cnt; ++c) {
+        float v, d, yd, xd;
+        if (BAKED) {
+          if (j < c_lo0[c] || j >= c_hi0[c] || i < c_lo1[c] || i >= c_hi1[c]) continue;
+          Win1 w0, w1;
+          w0.off = c_of0[c]; w0.pm = c_p0[c];
+          w1.off = c_of1[c]; w1.pm = c_p1[c];
+          v = baked_val(j, i, w0, w1, sigma, d, yd, xd);
+        } else {
+          v = splat_val((float)j, (float)i, c_p0[c], c_p1[c], sigma, inv_sigma, d, yd, xd);
+        }
+        if (reduce == FFX_REDUCE_SUM) acc += v; else acc *= (1.0f - v);
+      }
+    }
+    __syncthreads();
+  }
+  if (j < size0 && i < size1) tex[(size_t)i * size0 + j] = (reduce == FFX_REDUCE_SUM) ? acc : (1.0f - acc);
+}
+
+// =================================================================================== K2 gradient
+// One workgroup per point: sweeps only the texels where the point's value is non-zero in
+// binary32 (or the baked window), so the traffic is the footprint of `gtex`, not [n,H,W].
+// softor needs prod_{m != n}(1 - v_m) per texel: the points whose footprint overlaps this one
+// are compacted into LDS once per workgroup.  Per-lane partial sums are reduced with wave
+// shuffles, then across the 4 waves through LDS: one plain store per point, no atomics, and the
+// result is bitwise reproducible.
+// LAYERED: upstream gradient is the dense [n,size1,size0] tensor (rasterize_points backward).
+template <bool BAKED, bool LAYERED>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_splat_bwd(const float *__restrict__ pts, int n, float sigma, int reduce, int half_window, int size0, int size1, const float *__restrict__ gtex,
+                float *__restrict__ gpts) {
+  __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
+  __shared__ int nb_count;
+  __shared__ float red0[SPLAT_BLOCK / 64], red1[SPLAT_BLOCK / 64];
+
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float inv_sigma = 1.0f / sigma;
+  const float p0s = pts[2 * k] * (float)size0, p1s = pts[2 * k + 1] * (float)size1;
+  const float R = sqrtf(FFX_QCUT * sigma) + 1.0f; // radius beyond which v is exactly 0
+  int lo0, hi0, lo1, hi1;                          // texel range (exclusive hi)
+  Win1 w0, w1;
+  bool alive = true;
+  if (BAKED) {
+    alive = window_axis(p0s, half_window, size0, w0) && window_axis(p1s, half_window, size1, w1);
+    lo0 = w0.lo; hi0 = w0.hi; lo1 = w1.lo; hi1 = w1.hi;
+  } else {
+    lo0 = max(0, (int)floorf(p0s - R)); hi0 = min(size0, (int)ceilf(p0s + R) + 1);
+    lo1 = max(0, (int)floorf(p1s - R)); hi1 = min(size1, (int)ceilf(p1s + R) + 1);
+    alive = hi0 > lo0 && hi1 > lo1;
+  }
+  const bool softor = (reduce == FFX_REDUCE_SOFTOR) && !LAYERED;
+  const bool use_list = softor && n <= NEIGH_MAX;
+  if (use_list) {
+    if (tid < 64) {
+      int count = 0;
+      for (int base = 0; base < n; base += 64) {
+        int m = base + tid;
+        bool keep = false;
+        float q0 = 0.f, q1 = 0.f;
+        if (m < n && m != k) {
+          q0 = pts[2 * m] * (float)size0;
+          q1 = pts[2 * m + 1] * (float)size1;
+          if (BAKED) keep = fabsf(q0 - p0s) <= (float)(2 * half_window + 2) && fabsf(q1 - p1s) <= (float)(2 * half_window + 2);
+          else keep = fabsf(q0 - p0s) <= 2.f * R + 2.f && fabsf(q1 - p1s) <= 2.f * R + 2.f;
+        }
+        unsigned long long mk = __ballot(keep);
+        int pos = count + __popcll(mk & ((1ull << tid) - 1ull));
+        if (keep) { nb_p0[pos] = q0; nb_p1[pos] = q1; }
+        count += __popcll(mk);
+      }
+      if (tid == 0) nb_count = count;
+    }
+    __syncthreads();
+  }
+  float a0 = 0.f, a1 = 0.f;
+  if (alive) {
+    const int rw = hi0 - lo0, rh = hi1 - lo1;
+    const float *g = gtex + (LAYERED ? (size_t)k * size0 * size1 : 0);
+    for (int t = tid; t < rw * rh; t += SPLAT_BLOCK) {
+      int j = lo0 + t % rw, i = lo1 + t / rw;
+      float v, d, yd, xd;
+      if (BAKED) v = baked_val(j, i, w0, w1, sigma, d, yd, xd);
+      else v = splat_val((float)j, (float)i, p0s, p1s, sigma, inv_sigma, d, yd, xd);
+      if (v == 0.f) continue;
+      float w = g[(size_t)i * size0 + j];
+      if (softor) {
+        float prod = 1.f;
+        int cnt = use_list ? nb_count : n;
+        for (int c = 0; c < cnt; ++c) {
+          float q0, q1;
+          if (use_list) { q0 = nb_p0[c]; q1 = nb_p1[c]; }
+          else {
+            if (c == k) continue;
+            q0 = pts[2 * c] * (float)size0; q1 = pts[2 * c + 1] * (float)size1;
+          }
+          float vm, dd, y2, x2;
+          if (BAKED) {
+            Win1 u0, u1;
+            if (!window_axis(q0, half_window, size0, u0) || !window_axis(q1, half_window, size1, u1)) continue;
+            if (j < u0.lo || j >= u0.hi || i < u1.lo || i >= u1.hi) continue;
+            vm = baked_val(j, i, u0, u1, sigma, dd, y2, x2);
+          } else {
+            vm = splat_val((float)j, (float)i, q0, q1, sigma, inv_sigma, dd, y2, x2);
+          }
+          prod *= (1.0f - vm);
+        }
+        w *= prod;
+      }
+      float cf = splat_gcoef(v, d, sigma);
+      a0 += w * (cf * yd);
+      a1 += w * (cf * xd);
+    }
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if ((tid & 63) == 0) { red0[tid >> 6] = a0; red1[tid >> 6] = a1; }
+  __syncthreads();
+  if (tid == 0) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < SPLAT_BLOCK / 64; ++w) { s0 += red0[w]; s1 += red1[w]; }
+    gpts[2 * k] = s0 * (float)size0;
+    gpts[2 * k + 1] = s1 * (float)size1;
+  }
+}
+
+// =================================================================================== K3 blur
+// (ksize x ksize) Gaussian, reflect border.  One workgroup per 32x8 output tile, halo staged in LDS.
+struct BlurW { float w[15]; int ksize; };
+__device__ __forceinline__ int reflect_idx(int t, int n) {
+  if (n == 1) return 0;
+  while (t < 0 || t >= n) {
+    if (t < 0) t = -t;
+    if (t >= n) t = 2 * (n - 1) - t;
+  }
+  return t;
+}
+__global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restrict__ in, int h, int w, BlurW bw, float *__restrict__ out) {
+  __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
+  const int r = bw.ksize / 2, tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
+  const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+  for (int t = threadIdx.x; t < tw * th; t += SPLAT_BLOCK) {
+    int ly = t / tw, lx = t % tw;
+    tile[t] = in[(size_t)reflect_idx(y0 + ly - r, h) * w + reflect_idx(x0 + lx - r, w)];
+  }
+  __syncthreads();
+  int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
+  int x = x0 + lx, y = y0 + ly;
+  if (x >= w || y >= h) return;
+  float acc = 0.f;
+  for (int ky = 0; ky < bw.ksize; ++ky) {
+    float row = 0.f;
+    for (int kx = 0; kx < bw.ksize; ++kx) row = fmaf(bw.w[kx], tile[(ly + ky) * tw + lx + kx], row);
+    acc = fmaf(bw.w[ky], row, acc);
+  }
+  out[(size_t)y * w + x] = acc;
+}
+// exact transpose: gin[q] = sum over the padded positions t (|t - image| <= r) that reflect onto q
+// of g_pad[t] = sum_k w[k] * gout[t - k + r], separately per axis.
+__global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restrict__ gout, int h, int w, BlurW bw, float *__restrict__ gin) {
+  int x = blockIdx.x * TILE_W + threadIdx.x % TILE_W, y = blockIdx.y * TILE_H + threadIdx.x / TILE_W;
+  if (x >= w || y >= h) return;
+  const int r = bw.ksize / 2;
+  float acc = 0.f;
+  // candidate padded rows: y itself, then the r rows above the image and the r rows below it
+  for (int a = -1; a < 2 * r; ++a) {
+    int ty = (a < 0) ? y : (a < r ? -(a + 1) : h + (a - r));
+    if (a >= 0 && reflect_idx(ty, h) != y) continue;
+    for (int b = -1; b < 2 * r; ++b) {
+      int tx = (b < 0) ? x : (b < r ? -(b + 1) : w + (b - r));
+      if (b >= 0 && reflect_idx(tx, w) != x) continue;
+      for (int ky = 0; ky < bw.ksize; ++ky) {
+        int py = ty - ky + r;
+        if (py < 0 || py >= h) continue;
+        float row = 0.f;
+        for (int kx = 0; kx < bw.ksize; ++kx) {
+          int px = tx - kx + r;
+          if (px < 0 || px >= w) continue;
+          row = fmaf(bw.w[kx], gout[(size_t)py * w + px], row);
+        }
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    }
+  }
+  gin[(size_t)y * w + x] = acc;
+}
+
+// =================================================================================== host entry points
+static int blur_weights(int ksize, float sg, BlurW &bw) {
+  if (ksize < 1 || ksize > 15 || !(ksize & 1) || !(sg > 0.f)) return 0;
+  int r = ksize / 2;
+  double sum = 0, g[15];
+  for (int k = 0; k < ksize; ++k) {
+    double x = (double)(k - r);
+    g[k] = exp(-(x * x) / (2.0 * (double)sg * (double)sg));
+    bw.w[k] = (float)g[k];
+    sum += g[k];
+  }
+  for (int k = 0; k < ksize; ++k) bw.w[k] = (float)((double)bw.w[k] / sum);
+  for (int k = ksize; k < 15; ++k) bw.w[k] = 0.f;
+  bw.ksize = ksize;
+  return 1;
+}
+
+extern "C" {
+
+int ffx_project_rays_fwd(const float *rays, int n, const float *KF, float *pts, ffx_stream s) {
+  if (!rays || !KF || !pts || n < 0) FFX_FAIL(FFX_ERR_ARG, "project_rays_fwd: bad argument");
+  if (n == 0) return FFX_OK;
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  hipLaunchKernelGGL(k_project_fwd, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, rays, n, m, pts);
+  FFX_CHECK_LAUNCH("project_rays_fwd");
+  return FFX_OK;
+}
+
+int ffx_project_rays_bwd(const float *rays, int n, const float *KF, const float *gpts, float *grays, ffx_stream s) {
+  if (!rays || !KF || !gpts || !grays || n < 0) FFX_FAIL(FFX_ERR_ARG, "project_rays_bwd: bad argument");
+  if (n == 0) return FFX_OK;
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  hipLaunchKernelGGL(k_project_bwd, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, rays, n, m, gpts, grays);
+  FFX_CHECK_LAUNCH("project_rays_bwd");
+  return FFX_OK;
+}
+
+int ffx_transform_points(const float *pts, int n, const float *M, int mode, float *out, ffx_stream s) {
+  if (!pts || !M || !out || n < 0 || (mode != 0 && mode != 1)) FFX_FAIL(FFX_ERR_ARG, "transform_points: bad argument");
+  if (n == 0) return FFX_OK;
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = M[i];
+  hipLaunchKernelGGL(k_transform_points, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, pts, n, m, mode, out);
+  FFX_CHECK_LAUNCH("transform_points");
+  return FFX_OK;
+}
+
+static int dense_fwd_common(const float *pts, const float *depth, int n, float sigma, int size0, int size1, float *out, ffx_stream s, int mode,
+                            const char *what) {
+  if (!pts || !out || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "%s: bad argument", what);
+  if (n == 0) return FFX_OK;
+  if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "%s: more than 65535 points", what);
+  int w4 = (size0 + 3) / 4;
+  int vec_ok = (size0 % 4 == 0) && (((uintptr_t)out & 15) == 0);
+  dim3 grid(ffx_cdiv((long)w4 * size1, SPLAT_BLOCK), n);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_splat_dense_fwd<0>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, depth, sigma, size0, size1, w4, vec_ok, out);
+  else
+    hipLaunchKernelGGL(k_splat_dense_fwd<1>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, depth, sigma, size0, size1, w4, vec_ok, out);
+  FFX_CHECK_LAUNCH(what);
+  return FFX_OK;
+}
+
+int ffx_splat_dense_fwd(const float *pts, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
+  return dense_fwd_common(pts, nullptr, n, sigma, size0, size1, out, s, 0, "splat_dense_fwd");
+}
+
+int ffx_splat_depth_fwd(const float *pts, const float *depth, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
+  if (!depth) FFX_FAIL(FFX_ERR_ARG, "splat_depth_fwd: bad argument");
+  return dense_fwd_common(pts, depth, n, sigma, size0, size1, out, s, 1, "splat_depth_fwd");
+}
+
+int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
+  if (!lines || !out || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_lines_fwd: bad argument");
+  if (n == 0) return FFX_OK;
+  if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "splat_lines_fwd: more than 65535 lines");
+  dim3 grid(ffx_cdiv((long)size0 * size1, SPLAT_BLOCK), n);
+  hipLaunchKernelGGL(k_splat_lines_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, lines, sigma, size0, size1, out);
+  FFX_CHECK_LAUNCH("splat_lines_fwd");
+  return FFX_OK;
+}
+
+int ffx_splat_dense_bwd(const float *pts, int n, float sigma, int size0, int size1, const float *gout, float *gpts, ffx_stream s) {
+  if (!pts || !gout || !gpts || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_dense_bwd: bad argument");
+  if (n == 0) return FFX_OK;
+  hipLaunchKernelGGL((k_splat_bwd<false, true>), dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, FFX_REDUCE_SUM, -1, size0, size1, gout,
+                     gpts);
+  FFX_CHECK_LAUNCH("splat_dense_bwd");
+  return FFX_OK;
+}
+
+int ffx_splat_fwd(const float *pts, int n, float sigma, int reduce, int half_window, int size0, int size1, float *tex, ffx_stream s) {
+  if (!pts || !tex || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_fwd: bad argument");
+  if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FFX_FAIL(FFX_ERR_ARG, "splat_fwd: bad reduce %d", reduce);
+  dim3 grid(ffx_cdiv(size0, TILE_W), ffx_cdiv(size1, TILE_H));
+  if (grid.y > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "splat_fwd: texture too tall");
+  if (half_window >= 0)
+    hipLaunchKernelGGL(k_splat_fused_fwd<true>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, reduce, half_window, size0, size1, tex);
+  else
+    hipLaunchKernelGGL(k_splat_fused_fwd<false>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, reduce, half_window, size0, size1, tex);
+  FFX_CHECK_LAUNCH("splat_fwd");
+  return FFX_OK;
+}
+
+int ffx_splat_bwd(const float *pts, int n, float sigma, int reduce, int half_window, int size0, int size1, const float *tex, const float *gtex,
+                  float *gpts, ffx_stream s) {
+  (void)tex; // the product over the other points is recomputed; the forward output is not needed
+  if (!pts || !gtex || !gpts || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_bwd: bad argument");
+  if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FFX_FAIL(FFX_ERR_ARG, "splat_bwd: bad reduce %d", reduce);
+  if (n == 0) return FFX_OK;
+  if (half_window >= 0)
+    hipLaunchKernelGGL((k_splat_bwd<true, false>), dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, reduce, half_window, size0, size1,
+                       gtex, gpts);
+  else
+    hipLaunchKernelGGL((k_splat_bwd<false, false>), dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, reduce, half_window, size0, size1,
+                       gtex, gpts);
+  FFX_CHECK_LAUNCH("splat_bwd");
+  return FFX_OK;
+}
+
+int ffx_blur_fwd(const float *in, int h, int w, int ksize, float sg, float *out, ffx_stream s) {
+  BlurW bw;
+  if (!in || !out || h <= 0 || w <= 0 || !blur_weights(ksize, sg, bw)) FFX_FAIL(FFX_ERR_ARG, "blur_fwd: bad argument");
+  dim3 grid(ffx_cdiv(w, TILE_W), ffx_cdiv(h, TILE_H));
+  hipLaunchKernelGGL(k_blur_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, in, h, w, bw, out);
+  FFX_CHECK_LAUNCH("blur_fwd");
+  return FFX_OK;
+}
+
+int ffx_blur_bwd(const float *gout, int h, int w, int ksize, float sg, float *gin, ffx_stream s) {
+  BlurW bw;
+  if (!gout || !gin || h <= 0 || w <= 0 || !blur_weights(ksize, sg, bw)) FFX_FAIL(FFX_ERR_ARG, "blur_bwd: bad argument");
+  dim3 grid(ffx_cdiv(w, TILE_W), ffx_cdiv(h, TILE_H));
+  hipLaunchKernelGGL(k_blur_bwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, gout, h, w, bw, gin);
+  FFX_CHECK_LAUNCH("blur_bwd");
+  return FFX_OK;
+}
+
+} // extern "C"

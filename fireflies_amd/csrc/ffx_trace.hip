@@ -1,0 +1,574 @@
+// ffx_trace.hip — K7 (primary visibility), K8 (render), K9 (render adjoint) for gfx950.
+//
+// Replaces sensor.sample_ray + scene.ray_intersect (fireflies/graphics/depth.py:35-46,72-84,
+// 110-125,152-165) and mi.render / its Dr.Jit backward (examples/vocalfold_scene.py:69,102;
+// main.py:156) — all Mitsuba [EXT].  The arithmetic of ray generation, the triangle test and
+// shading follows the same documented operation order as oracle/ffx_oracle.c, so
+// depths and ids agree with the oracle bit for bit apart from rare 1-ulp boundary cases.
+//
+// Execution model: one 64-lane wavefront = one 8x8 pixel tile (a coherent ray
+// packet: the lanes of a wave walk almost the same nodes, so a node or leaf fetch is a handful of
+// distinct 64-byte lines per wave-instruction).  A 256-thread workgroup owns ONE tile; its four
+// waves take every fourth sample, accumulate radiance in registers and combine through LDS:
+// one store per pixel, no atomics in the forward pass.  Per-lane traversal stacks live in LDS
+// (stride = workgroup size, conflict-free).  Workgroups are remapped so that the 1/8 of the
+// grid that shares an XCD (blockIdx % 8) covers a contiguous band of the image and keeps its
+// part of the BVH hot in that XCD's 4 MiB L2.
+#include <string.h>
+
+#include "ffx_common.h"
+
+#define TR_BLOCK 256
+#define RAY_EPS 8.940696716308594e-05f
+#define SHADOW_EPS (10.0f * RAY_EPS)
+
+struct CamK {
+  float s2c[16];
+  float tw[12]; // rows 0..2 of to_world
+  float near_clip, far_clip, inv_w, inv_h;
+  int W, H;
+};
+
+struct ShadeK {
+  CamK cam;
+  int proj_on, spot_on, shadows;
+  float p_w2l[12];
+  float p_c2s[16];
+  float p_pos[3], p_axis[3], p_color[3];
+  float p_scale;
+  int tw, th, tc;
+  float s_w2l[12];
+  float s_pos[3], s_int[3];
+  float cos_cut, cos_beam, cutoff, inv_trans;
+};
+
+struct Hit { float t; int prim, shape, slot; };
+
+// ------------------------------------------------------------------------------------------ traversal
+__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], v3 o, v3 id, float tmin, float tmax, float &tn_out) {
+  float ax = (lo[0] - o.x) * id.x, bx = (hi[0] - o.x) * id.x;
+  float ay = (lo[1] - o.y) * id.y, by = (hi[1] - o.y) * id.y;
+  float az = (lo[2] - o.z) * id.z, bz = (hi[2] - o.z) * id.z;
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f; // 2-ulp widening
+  tf = fminf(tf, tmax);
+  tn_out = tn;
+  return tn <= tf;
+}
+
+// Moller-Trumbore, division-free rejection; identical order to the oracle.
+__device__ __forceinline__ bool tri_hit(const TriRec *__restrict__ rec, v3 o, v3 d, float tmin, float &t_out, int &prim, int &shape) {
+  const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+  float4 a = r4[0], b = r4[1], c = r4[2];
+  v3 v0 = V3(a.x, a.y, a.z), e1 = V3(a.w, b.x, b.y), e2 = V3(b.z, b.w, c.x);
+  v3 pv = vcross(d, e2);
+  float det = vdot(e1, pv);
+  v3 tv = vsub(o, v0);
+  v3 qv = vcross(tv, e1);
+  float U = vdot(tv, pv), Vv = vdot(d, qv), T = vdot(e2, qv);
+  if (det < 0.f) { det = -det; U = -U; Vv = -Vv; T = -T; }
+  if (!(det > 0.f)) return false;
+  if (!(U >= 0.f) || !(Vv >= 0.f) || !(U + Vv <= det)) return false;
+  float t = T / det;
+  if (!(t > tmin)) return false;
+  t_out = t;
+  prim = __float_as_int(c.y);
+  shape = __float_as_int(c.z);
+  return true;
+}
+
+// ANY = false: closest hit in (tmin, tmax], ties broken by the smaller primitive id.
+// ANY = true : returns true as soon as a hit with tmin < t < tmax is found.
+// `stack` points at this lane's first slot; consecutive entries are `stride` ints apart.
+template <bool ANY>
+__device__ __forceinline__ bool traverse(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float tmin, float tmax, Hit &h,
+                                         int *stack, int stride) {
+  h.t = tmax;
+  h.prim = -1;
+  h.shape = -1;
+  h.slot = -1;
+  const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int sp = 0;
+  int cur = 0;
+  while (true) {
+    const float4 *n4 = reinterpret_cast<const float4 *>(nodes + cur);
+    float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
+    int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
+    float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    float t0, t1;
+    bool h0 = (ch.x != FFX_EMPTY_CHILD) && slab(lo0, hi0, o, id, tmin, h.t, t0);
+    bool h1 = (ch.y != FFX_EMPTY_CHILD) && slab(lo1, hi1, o, id, tmin, h.t, t1);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      int c = side ? ch.y : ch.x;
+      bool hs = side ? h1 : h0;
+      if (hs && c < 0) {
+        uint32_t lc = (uint32_t)~c;
+        int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
+        for (int i = 0; i < count; ++i) {
+          float t;
+          int prim, shape;
+          if (tri_hit(recs + first + i, o, d, tmin, t, prim, shape)) {
+            if (ANY) {
+              if (t < tmax) return true;
+            } else if (t <= tmax && (h.prim < 0 || t < h.t || (t == h.t && prim < h.prim))) {
+              h.t = t; h.prim = prim; h.shape = shape; h.slot = first + i;
+            }
+          }
+        }
+        if (side) h1 = false; else h0 = false;
+      }
+    }
+    // a leaf may have shortened the ray: drop inner children that now start behind the hit
+    if (h0 && t0 > h.t) h0 = false;
+    if (h1 && t1 > h.t) h1 = false;
+    if (h0 && h1) {
+      int nearc = ch.x, farc = ch.y;
+      if (t1 < t0) { nearc = ch.y; farc = ch.x; }
+      stack[sp * stride] = farc;
+      ++sp;
+      cur = nearc;
+    } else if (h0) {
+      cur = ch.x;
+    } else if (h1) {
+      cur = ch.y;
+    } else {
+      if (sp == 0) break;
+      --sp;
+      cur = stack[sp * stride];
+    }
+  }
+  return h.prim >= 0;
+}
+
+// ------------------------------------------------------------------------------------------ camera
+__device__ __forceinline__ void sample_jitter(uint32_t seed_key, uint32_t idx, float &jx, float &jy) {
+  uint32_t a = hash32((2u * idx) ^ seed_key), b = hash32((2u * idx + 1u) ^ seed_key);
+  jx = (float)(a >> 8) * (1.0f / 16777216.0f);
+  jy = (float)(b >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ void cam_ray(const CamK &k, float sx, float sy, v3 &o, v3 &d, float &near_t, float &far_t) {
+  const float *m = k.s2c;
+  float qx = fmaf(m[0], sx, fmaf(m[1], sy, m[3]));
+  float qy = fmaf(m[4], sx, fmaf(m[5], sy, m[7]));
+  float qz = fmaf(m[8], sx, fmaf(m[9], sy, m[11]));
+  float qw = fmaf(m[12], sx, fmaf(m[13], sy, m[15]));
+  v3 np = V3(qx / qw, qy / qw, qz / qw);
+  float len = sqrtf(vdot(np, np));
+  v3 dl = V3(np.x / len, np.y / len, np.z / len);
+  d = xf_dir(k.tw, dl);
+  o = V3(k.tw[3], k.tw[7], k.tw[11]);
+  near_t = k.near_clip / dl.z;
+  far_t = k.far_clip / dl.z;
+}
+
+// ------------------------------------------------------------------------------------------ K7 kernels
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_trace_primary(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, int spp, int jitter, uint32_t seed_key, long total,
+                    float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
+  extern __shared__ int s_stack[];
+  long idx = (long)blockIdx.x * TR_BLOCK + threadIdx.x;
+  if (idx >= total) return;
+  long pix = idx / spp;
+  int x = (int)(pix % cam.W), y = (int)(pix / cam.W);
+  float jx = 0.f, jy = 0.f;
+  if (jitter) sample_jitter(seed_key, (uint32_t)idx, jx, jy);
+  v3 o, d;
+  float nt, ft;
+  cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o, d, nt, ft);
+  Hit h;
+  bool hit = traverse<false>(nodes, recs, o, d, nt, ft, h, s_stack + threadIdx.x, TR_BLOCK);
+  t_out[idx] = hit ? (h.t - nt) : 0.f;
+  if (shape_out) shape_out[idx] = h.shape;
+  if (prim_out) prim_out[idx] = h.prim;
+}
+
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_trace_rays(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ org, const float *__restrict__ dir, int n,
+                 float tmax, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
+  extern __shared__ int s_stack[];
+  int i = blockIdx.x * TR_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  Hit h;
+  bool hit = traverse<false>(nodes, recs, V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.f, tmax, h,
+                             s_stack + threadIdx.x, TR_BLOCK);
+  t_out[i] = hit ? h.t : 0.f;
+  if (shape_out) shape_out[i] = h.shape;
+  if (prim_out) prim_out[i] = h.prim;
+}
+
+// ------------------------------------------------------------------------------------------ shading
+struct SampleTerms {
+  int hit, shape, has_proj;
+  int ix0, ix1, iy0, iy1;
+  float wx0, wx1, wy0, wy1;
+  float proj_fac;
+  float spot[3];
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float nt,
+                                             float ft, SampleTerms &st, int *stack, int stride) {
+  Hit h;
+  st.hit = traverse<false>(nodes, recs, o, d, nt, ft, h, stack, stride);
+  st.has_proj = 0;
+  st.proj_fac = 0.f;
+  st.spot[0] = st.spot[1] = st.spot[2] = 0.f;
+  st.shape = h.shape;
+  if (!st.hit) return;
+  const float4 *r4 = reinterpret_cast<const float4 *>(recs + h.slot);
+  float4 ra = r4[0], rb = r4[1], rc = r4[2];
+  v3 P = V3(fmaf(h.t, d.x, o.x), fmaf(h.t, d.y, o.y), fmaf(h.t, d.z, o.z));
+  v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
+  float nl = sqrtf(vdot(ng, ng));
+  if (!(nl > 0.f)) return;
+  ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+  if (vdot(ng, d) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
+  float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
+  float off = (1.0f + pmax) * RAY_EPS;
+  v3 Po = V3(fmaf(off, ng.x, P.x), fmaf(off, ng.y, P.y), fmaf(off, ng.z, P.z));
+
+  if (c.proj_on) {
+    v3 pl = xf_point(c.p_w2l, P);
+    if (pl.z > 0.f) {
+      const float *m = c.p_c2s;
+      float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
+      float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
+      float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
+      float u = qx / qw, v = qy / qw;
+      if (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f) {
+        v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
+        v3 wi = vsub(ppos, P);
+        float d2 = vdot(wi, wi);
+        float dist = sqrtf(d2);
+        wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+        float cos_s = vdot(ng, wi);
+        float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
+        if (cos_s > 0.f && cos_p > 0.f) {
+          bool vis = true;
+          if (c.shadows) {
+            v3 ws = vsub(ppos, Po);
+            float ds = sqrtf(vdot(ws, ws));
+            ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+            Hit hs;
+            vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
+          }
+          if (vis) {
+            st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+            float fx = fmaf(u, (float)c.tw, -0.5f), fy = fmaf(v, (float)c.th, -0.5f);
+            float x0 = floorf(fx), y0 = floorf(fy);
+            float ax = fx - x0, ay = fy - y0;
+            int ix0 = (int)x0, iy0 = (int)y0;
+            st.ix0 = clampi(ix0, 0, c.tw - 1);
+            st.ix1 = clampi(ix0 + 1, 0, c.tw - 1);
+            st.iy0 = clampi(iy0, 0, c.th - 1);
+            st.iy1 = clampi(iy0 + 1, 0, c.th - 1);
+            st.wx0 = 1.0f - ax; st.wx1 = ax;
+            st.wy0 = 1.0f - ay; st.wy1 = ay;
+            st.has_proj = 1;
+          }
+        }
+      }
+    }
+  }
+  if (c.spot_on) {
+    v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
+    v3 wi = vsub(spos, P);
+    float d2 = vdot(wi, wi);
+    float dist = sqrtf(d2);
+    wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+    float cos_s = vdot(ng, wi);
+    if (cos_s > 0.f) {
+      v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
+      float ln = sqrtf(vdot(ll, ll));
+      float cos_t = ll.z / ln;
+      float fall = 0.f;
+      if (cos_t >= c.cos_beam) fall = 1.f;
+      else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
+      if (fall > 0.f) {
+        bool vis = true;
+        if (c.shadows) {
+          v3 ws = vsub(spos, Po);
+          float ds = sqrtf(vdot(ws, ws));
+          ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+          Hit hs;
+          vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
+        }
+        if (vis) {
+          float f = fall * cos_s / d2 * 0.3183098861837907f;
+          st.spot[0] = c.s_int[0] * f;
+          st.spot[1] = c.s_int[1] * f;
+          st.spot[2] = c.s_int[2] * f;
+        }
+      }
+    }
+  }
+}
+
+// blockIdx -> tile with XCD-contiguous bands: workgroups b, b+8, b+16, ... share an XCD (and its
+// L2), so give them neighbouring tiles.  Pure performance: correctness never depends on it.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+  int per = (nblocks + 7) / 8;
+  int t = (b % 8) * per + (b / 8);
+  return t;
+}
+
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_render_fwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
+                 const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int fp16, void *__restrict__ img) {
+  extern __shared__ int s_dyn[];
+  __shared__ float s_red[3][3][64]; // waves 1..3 -> wave 0
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = c.cam.W, H = c.cam.H;
+  int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
+  bool live = tile < n_tiles && px < W && py < H;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  if (live) {
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+    for (int s = wave; s < spp; s += TR_BLOCK / 64) {
+      uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+      float jx, jy;
+      sample_jitter(seed_key, idx, jx, jy);
+      v3 o, d;
+      float nt, ft;
+      cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+      SampleTerms st;
+      shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+      if (!st.hit) continue;
+      float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
+      if (st.has_proj) {
+        const int tc = c.tc;
+        size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
+        size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
+        if (tc == 1) {
+          float tv = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+          r0 += tv * c.p_color[0] * st.proj_fac;
+          r1 += tv * c.p_color[1] * st.proj_fac;
+          r2 += tv * c.p_color[2] * st.proj_fac;
+        } else {
+          float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+          float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
+          float tv2 = st.wy0 * (st.wx0 * tex[o00 + 2] + st.wx1 * tex[o01 + 2]) + st.wy1 * (st.wx0 * tex[o10 + 2] + st.wx1 * tex[o11 + 2]);
+          r0 += tv0 * 1.0f * st.proj_fac;
+          r1 += tv1 * 1.0f * st.proj_fac;
+          r2 += tv2 * 1.0f * st.proj_fac;
+        }
+      }
+      const float *alb = albedo + 3 * st.shape;
+      acc0 += alb[0] * r0;
+      acc1 += alb[1] * r1;
+      acc2 += alb[2] * r2;
+    }
+  }
+  if (wave > 0) {
+    s_red[wave - 1][0][lane] = acc0;
+    s_red[wave - 1][1][lane] = acc1;
+    s_red[wave - 1][2][lane] = acc2;
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      acc0 += s_red[w][0][lane];
+      acc1 += s_red[w][1][lane];
+      acc2 += s_red[w][2][lane];
+    }
+    float inv_spp = 1.0f / (float)spp;
+    size_t o = ((size_t)py * W + px) * 3;
+    if (fp16) {
+      _Float16 *p = (_Float16 *)img;
+      p[o] = (_Float16)(acc0 * inv_spp);
+      p[o + 1] = (_Float16)(acc1 * inv_spp);
+      p[o + 2] = (_Float16)(acc2 * inv_spp);
+    } else {
+      float *p = (float *)img;
+      p[o] = acc0 * inv_spp;
+      p[o + 1] = acc1 * inv_spp;
+      p[o + 2] = acc2 * inv_spp;
+    }
+  }
+}
+
+// K9: replay the same samples, scatter d(loss)/d(img) * d(img)/d(tex) through the bilinear weights.
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_render_bwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
+                 uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
+  extern __shared__ int s_dyn[];
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = c.cam.W, H = c.cam.H;
+  int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
+  if (!(tile < n_tiles && px < W && py < H)) return;
+  const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float g0 = gimg[(size_t)pix * 3], g1 = gimg[(size_t)pix * 3 + 1], g2 = gimg[(size_t)pix * 3 + 2];
+  if (g0 == 0.f && g1 == 0.f && g2 == 0.f) return;
+  const float inv_spp = 1.0f / (float)spp;
+  const int tc = c.tc;
+  for (int s = wave; s < spp; s += TR_BLOCK / 64) {
+    uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+    float jx, jy;
+    sample_jitter(seed_key, idx, jx, jy);
+    v3 o, d;
+    float nt, ft;
+    cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+    SampleTerms st;
+    shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+    if (!st.hit || !st.has_proj) continue;
+    const float *alb = albedo + 3 * st.shape;
+    size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
+    size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
+    if (tc == 1) {
+      float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
+      atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
+      atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
+      atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
+      atomicAdd(gtex + o11, ws * st.wy1 * st.wx1);
+    } else {
+      const float gg[3] = {g0, g1, g2};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
+        atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
+        atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
+        atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
+        atomicAdd(gtex + o11 + ch, ws * st.wy1 * st.wx1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int cam_prepare(const ffx_camera *c, CamK &k) {
+  if (c->width < 1 || c->height < 1) return 0;
+  if (!ffx_inv4(c->camera_to_sample, k.s2c)) return 0;
+  for (int i = 0; i < 12; ++i) k.tw[i] = c->to_world[i];
+  k.near_clip = c->near_clip;
+  k.far_clip = c->far_clip;
+  k.W = c->width;
+  k.H = c->height;
+  k.inv_w = 1.0f / (float)c->width;
+  k.inv_h = 1.0f / (float)c->height;
+  return 1;
+}
+
+static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
+  memset(&c, 0, sizeof c);
+  if (!cam_prepare(&sd->cam, c.cam)) return 0;
+  c.proj_on = sd->proj.enabled;
+  c.spot_on = sd->spot.enabled;
+  c.shadows = sd->shadows;
+  float inv[16];
+  if (c.proj_on) {
+    if (!ffx_inv4(sd->proj.to_world, inv)) return 0;
+    for (int i = 0; i < 12; ++i) c.p_w2l[i] = inv[i];
+    for (int i = 0; i < 16; ++i) c.p_c2s[i] = sd->proj.camera_to_sample[i];
+    c.p_pos[0] = sd->proj.to_world[3]; c.p_pos[1] = sd->proj.to_world[7]; c.p_pos[2] = sd->proj.to_world[11];
+    c.p_axis[0] = sd->proj.to_world[2]; c.p_axis[1] = sd->proj.to_world[6]; c.p_axis[2] = sd->proj.to_world[10];
+    c.p_scale = sd->proj.scale;
+    for (int i = 0; i < 3; ++i) c.p_color[i] = sd->proj.color[i];
+    c.tw = sd->proj.tex_w; c.th = sd->proj.tex_h; c.tc = sd->proj.tex_channels;
+    if (c.tw < 1 || c.th < 1 || (c.tc != 1 && c.tc != 3)) return 0;
+  }
+  if (c.spot_on) {
+    if (!ffx_inv4(sd->spot.to_world, inv)) return 0;
+    for (int i = 0; i < 12; ++i) c.s_w2l[i] = inv[i];
+    c.s_pos[0] = sd->spot.to_world[3]; c.s_pos[1] = sd->spot.to_world[7]; c.s_pos[2] = sd->spot.to_world[11];
+    for (int i = 0; i < 3; ++i) c.s_int[i] = sd->spot.intensity[i];
+    const float deg = 0.017453292519943295f;
+    c.cutoff = sd->spot.cutoff_deg * deg;
+    float beam = sd->spot.beam_width_deg * deg;
+    c.cos_cut = cosf(c.cutoff);
+    c.cos_beam = cosf(beam);
+    c.inv_trans = 1.0f / (c.cutoff - beam);
+  }
+  return 1;
+}
+
+static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }
+
+static int check_info(const ffx_bvh_info *info, const char *what) {
+  if (info->n_tris < 1 || info->n_nodes < 1 || info->max_depth < 1 || info->max_depth > FFX_STACK_DEPTH) {
+    ffx_set_error("%s: bad bvh info (n_tris %d, n_nodes %d, max_depth %d)", what, info->n_tris, info->n_nodes, info->max_depth);
+    return 0;
+  }
+  return 1;
+}
+static inline size_t stack_bytes(const ffx_bvh_info *info) {
+  int depth = info->max_depth < 8 ? 8 : info->max_depth;
+  return (size_t)depth * TR_BLOCK * sizeof(int);
+}
+
+extern "C" {
+
+int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camera *cam, int spp, int jitter, uint32_t seed, float *t_out,
+                      int32_t *shape_out, int32_t *prim_out, ffx_stream s) {
+  if (!bvh || !info || !cam || !t_out || spp < 1) FFX_FAIL(FFX_ERR_ARG, "trace_primary: bad argument");
+  if (!check_info(info, "trace_primary")) return FFX_ERR_ARG;
+  CamK k;
+  if (!cam_prepare(cam, k)) FFX_FAIL(FFX_ERR_ARG, "trace_primary: bad camera");
+  long total = (long)k.W * k.H * spp;
+  if (total >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "trace_primary: more than 2^32 samples");
+  const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
+  const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  hipLaunchKernelGGL(k_trace_primary, dim3(ffx_cdiv(total, TR_BLOCK)), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, k, nodes, recs, spp, jitter,
+                     seed_key_of(seed), total, t_out, shape_out, prim_out);
+  FFX_CHECK_LAUNCH("trace_primary");
+  return FFX_OK;
+}
+
+int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origins, const float *dirs, int n, float tmax, float *t_out,
+                   int32_t *shape_out, int32_t *prim_out, ffx_stream s) {
+  if (!bvh || !info || !origins || !dirs || !t_out || n < 0) FFX_FAIL(FFX_ERR_ARG, "trace_rays: bad argument");
+  if (!check_info(info, "trace_rays")) return FFX_ERR_ARG;
+  if (n == 0) return FFX_OK;
+  const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
+  const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  hipLaunchKernelGGL(k_trace_rays, dim3(ffx_cdiv(n, TR_BLOCK)), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, nodes, recs, origins, dirs, n, tmax,
+                     t_out, shape_out, prim_out);
+  FFX_CHECK_LAUNCH("trace_rays");
+  return FFX_OK;
+}
+
+int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                   uint32_t seed, int img_fp16, void *img, ffx_stream s) {
+  if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
+  if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
+  if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
+  ShadeK c;
+  if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
+  if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
+  const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
+  const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
+  int n_tiles = tiles_x * tiles_y;
+  int grid = ((n_tiles + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
+  hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
+                     seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
+  FFX_CHECK_LAUNCH("render_fwd");
+  return FFX_OK;
+}
+
+int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                   const float *gimg, float *gtex, ffx_stream s) {
+  if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+  if (!sd->proj.enabled) return FFX_OK;
+  if (!check_info(info, "render_bwd")) return FFX_ERR_ARG;
+  ShadeK c;
+  if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
+  if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: more than 2^32 samples");
+  const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
+  const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
+  int n_tiles = tiles_x * tiles_y;
+  int grid = ((n_tiles + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
+                     tiles_x, n_tiles, gimg, gtex);
+  FFX_CHECK_LAUNCH("render_bwd");
+  return FFX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the C ABI (include/ffx.h) — plumbing only.
+
+PyTorch is used for device memory and the current HIP stream; every arithmetic step happens in
+libffx_hip.so.  All functions require contiguous tensors on a HIP device and raise otherwise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import api
+
+REDUCE = {"sum": _abi.REDUCE_SUM, "softor": _abi.REDUCE_SOFTOR}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on a HIP device (got {t.device}); fireflies_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _m16(m):
+    if isinstance(m, torch.Tensor):
+        m = m.detach().cpu().numpy()
+    a = np.asarray(m, dtype=np.float32).reshape(-1)
+    if a.size != 16:
+        raise ValueError("expected a 4x4 matrix")
+    return (C.c_float * 16)(*a.tolist())
+
+
+def _reduce(reduce):
+    if isinstance(reduce, str):
+        return REDUCE[reduce]
+    return int(reduce)
+
+
+# ------------------------------------------------------------------ K1
+def project_rays_fwd(rays, KF):
+    out = torch.empty_like(rays)
+    api().call("ffx_project_rays_fwd", _dev(rays, name="rays"), rays.shape[0], _m16(KF), _dev(out), _stream())
+    return out
+
+
+def project_rays_bwd(rays, KF, gpts):
+    out = torch.empty_like(rays)
+    api().call("ffx_project_rays_bwd", _dev(rays, name="rays"), rays.shape[0], _m16(KF), _dev(gpts, name="gpts"), _dev(out), _stream())
+    return out
+
+
+def transform_points(pts, M, mode=0):
+    out = torch.empty_like(pts)
+    api().call("ffx_transform_points", _dev(pts, name="pts"), pts.shape[0], _m16(M), mode, _dev(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ K2
+def _check_pts(pts):
+    if pts.dim() != 2 or pts.shape[1] != 2:
+        raise ValueError(f"points must be [N,2], got {tuple(pts.shape)}")
+
+
+def splat_dense_fwd(pts, sigma, size0, size1):
+    _check_pts(pts)
+    out = torch.empty((pts.shape[0], size1, size0), dtype=torch.float32, device=pts.device)
+    api().call("ffx_splat_dense_fwd", _dev(pts, name="pts"), pts.shape[0], float(sigma), size0, size1, _dev(out), _stream())
+    return out
+
+
+def splat_dense_bwd(pts, sigma, size0, size1, gout):
+    _check_pts(pts)
+    if tuple(gout.shape) != (pts.shape[0], size1, size0):
+        raise ValueError("gout shape mismatch")
+    out = torch.empty_like(pts)
+    api().call("ffx_splat_dense_bwd", _dev(pts, name="pts"), pts.shape[0], float(sigma), size0, size1, _dev(gout, name="gout"), _dev(out), _stream())
+    return out
+
+
+def splat_fwd(pts, sigma, reduce, half_window, size0, size1):
+    _check_pts(pts)
+    out = torch.empty((size1, size0), dtype=torch.float32, device=pts.device)
+    api().call("ffx_splat_fwd", _dev(pts, name="pts"), pts.shape[0], float(sigma), _reduce(reduce), int(half_window), size0, size1, _dev(out), _stream())
+    return out
+
+
+def splat_bwd(pts, sigma, reduce, half_window, size0, size1, tex, gtex):
+    _check_pts(pts)
+    if tuple(gtex.shape) != (size1, size0):
+        raise ValueError("gtex shape mismatch")
+    out = torch.empty_like(pts)
+    api().call(
+        "ffx_splat_bwd", _dev(pts, name="pts"), pts.shape[0], float(sigma), _reduce(reduce), int(half_window), size0, size1,
+        _dev(tex, name="tex") if tex is not None else None, _dev(gtex, name="gtex"), _dev(out), _stream(),
+    )
+    return out
+
+
+def splat_depth_fwd(pts, depth, sigma, size0, size1):
+    _check_pts(pts)
+    depth = depth.reshape(-1)
+    out = torch.empty((pts.shape[0], size1, size0), dtype=torch.float32, device=pts.device)
+    api().call("ffx_splat_depth_fwd", _dev(pts, name="pts"), _dev(depth, name="depth"), pts.shape[0], float(sigma), size0, size1, _dev(out), _stream())
+    return out
+
+
+def splat_lines_fwd(lines, sigma, size0, size1):
+    if lines.dim() != 3 or tuple(lines.shape[1:]) != (2, 2):
+        raise ValueError("lines must be [N,2,2]")
+    out = torch.empty((lines.shape[0], size1, size0), dtype=torch.float32, device=lines.device)
+    api().call("ffx_splat_lines_fwd", _dev(lines, name="lines"), lines.shape[0], float(sigma), size0, size1, _dev(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ K3
+def blur_fwd(img, ksize=5, sigma=3.0):
+    if img.dim() != 2:
+        raise ValueError("blur expects [H,W]")
+    out = torch.empty_like(img)
+    api().call("ffx_blur_fwd", _dev(img, name="img"), img.shape[0], img.shape[1], ksize, float(sigma), _dev(out), _stream())
+    return out
+
+
+def blur_bwd(g, ksize=5, sigma=3.0):
+    out = torch.empty_like(g)
+    api().call("ffx_blur_bwd", _dev(g, name="g"), g.shape[0], g.shape[1], ksize, float(sigma), _dev(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ K5..K9
+def camera_struct(to_world, camera_to_sample, near, far, width, height):
+    c = _abi.Camera()
+    c.to_world = _m16(to_world)
+    c.camera_to_sample = _m16(camera_to_sample)
+    c.near_clip, c.far_clip, c.width, c.height = float(near), float(far), int(width), int(height)
+    return c
+
+
+class DeviceGeometry:
+    """Triangle soup + BVH blob resident in HBM.
+
+    src_verts [P,3] : vertex pool (all shapes, all animation frames)
+    tris [F,3]      : shape-local vertex indices
+    tri_shape [F]   : shape id per triangle
+    vert_off [S]    : pool offset of each shape's current frame
+    The topology is built once on the host (ffx_bvh_build_host) from `build_verts` (defaults to the
+    pool at the given offsets); `update()` is the per-randomisation device pass (K5+K6).
+    """
+
+    def __init__(self, src_verts, tris, tri_shape, vert_off, device="cuda", build_xforms=None):
+        src = np.ascontiguousarray(src_verts, dtype=np.float32).reshape(-1, 3)
+        tr = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        ts = np.ascontiguousarray(tri_shape, dtype=np.int32).reshape(-1)
+        vo = np.ascontiguousarray(vert_off, dtype=np.int32).reshape(-1)
+        F, S = tr.shape[0], vo.shape[0]
+        if ts.shape[0] != F:
+            raise ValueError("tri_shape must have one entry per triangle")
+        if F < 1 or S < 1:
+            raise ValueError("need at least one triangle and one shape")
+        if ts.min() < 0 or ts.max() >= S:
+            raise ValueError("tri_shape out of range")
+        if tr.min() < 0:
+            raise ValueError("negative vertex index")
+        self.n_tris, self.n_shapes = F, S
+        self.device = torch.device(device)
+        self._max_local = np.zeros(S, np.int64)
+        np.maximum.at(self._max_local, ts, tr.max(axis=1))
+        self._pool_size = src.shape[0]
+        self._check_offsets(vo)
+        # host build from the pose given by the current offsets (+ optional per-shape transforms)
+        glob = (tr + vo[ts][:, None]).astype(np.int32)
+        bverts = src
+        if build_xforms is not None:
+            bx = np.asarray(build_xforms, dtype=np.float32).reshape(S, 4, 4)
+            bverts = src.copy()
+            used = np.unique(glob)
+            owner = np.zeros(src.shape[0], np.int64)
+            owner[glob.reshape(-1)] = np.repeat(ts, 3)
+            v = src[used]
+            m = bx[owner[used]]
+            bverts[used] = np.einsum("nij,nj->ni", m[:, :3, :3], v) + m[:, :3, 3]
+        a = api()
+        nbytes = a.lib.ffx_bvh_blob_bytes(F)
+        blob = np.zeros(nbytes, np.uint8)
+        self.info = _abi.BvhInfo()
+        a.call("ffx_bvh_build_host", bverts.ctypes.data, bverts.shape[0], glob.ctypes.data, F, blob.ctypes.data, nbytes, C.byref(self.info))
+        self.blob = torch.from_numpy(blob[: self.info.total_bytes].copy()).to(self.device)
+        self.src_verts = torch.from_numpy(src).to(self.device)
+        self.tris = torch.from_numpy(tr).to(self.device)
+        self.tri_shape = torch.from_numpy(ts).to(self.device)
+        self.vert_off = torch.from_numpy(vo).to(self.device)
+        self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
+
+    def _check_offsets(self, vo):
+        if (vo < 0).any() or ((vo.astype(np.int64) + self._max_local) >= self._pool_size).any():
+            raise ValueError("vert_off + triangle index exceeds the vertex pool")
+
+    def update(self, xforms, vert_off=None):
+        """K5+K6: xforms [S,4,4] (host or device tensor), optional new frame offsets [S] (host ints)."""
+        if vert_off is not None:
+            vo = np.ascontiguousarray(vert_off, dtype=np.int32).reshape(-1)
+            if vo.shape[0] != self.n_shapes:
+                raise ValueError("vert_off must have one entry per shape")
+            self._check_offsets(vo)
+            self.vert_off = torch.from_numpy(vo).to(self.device, non_blocking=True)
+        xf = xforms if isinstance(xforms, torch.Tensor) else torch.as_tensor(np.asarray(xforms, np.float32))
+        xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
+        self._xf = xf  # keep alive until the stream has consumed it
+        api().call(
+            "ffx_scene_update", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
+            _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),
+        )
+
+    def trace_primary(self, cam, spp=1, jitter=0, seed=0, want_ids=True):
+        n = cam.width * cam.height * spp
+        t = torch.empty(n, dtype=torch.float32, device=self.device)
+        shape = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
+        prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
+        api().call(
+            "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
+            _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(),
+        )
+        return t, shape, prim
+
+    def trace_rays(self, origins, dirs, tmax=3.0e38):
+        n = origins.shape[0]
+        t = torch.empty(n, dtype=torch.float32, device=self.device)
+        shape = torch.empty(n, dtype=torch.int32, device=self.device)
+        prim = torch.empty(n, dtype=torch.int32, device=self.device)
+        api().call(
+            "ffx_trace_rays", _dev(self.blob, torch.uint8), C.byref(self.info), _dev(origins, name="origins"), _dev(dirs, name="dirs"), n, float(tmax),
+            _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(),
+        )
+        return t, shape, prim
+
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False):
+        H, W = sd.cam.height, sd.cam.width
+        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        api().call(
+            "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
+            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(),
+        )
+        return img
+
+    def render_bwd(self, sd, albedo, spp, seed, gimg):
+        gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
+        api().call(
+            "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
+            int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(),
+        )
+        return gtex

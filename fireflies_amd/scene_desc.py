@@ -1,0 +1,52 @@
+"""Builds the C-ABI parameter blocks (include/ffx.h: ffx_camera, ffx_scene_desc) from host data."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def _m16(m):
+    a = np.asarray(m, dtype=np.float32).reshape(-1)
+    if a.size != 16:
+        raise ValueError("expected a 4x4 matrix")
+    return (C.c_float * 16)(*a.tolist())
+
+
+def camera_struct(to_world, camera_to_sample, near, far, width, height):
+    c = _abi.Camera()
+    c.to_world = _m16(to_world)
+    c.camera_to_sample = _m16(camera_to_sample)
+    c.near_clip, c.far_clip, c.width, c.height = float(near), float(far), int(width), int(height)
+    return c
+
+
+def camera_from_sensor(s, to_world=None):
+    return camera_struct(s.to_world if to_world is None else to_world, s.K, s.near, s.far, s.width, s.height)
+
+
+def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shadows=True, cam_to_world=None, proj_to_world=None,
+               spot_to_world=None, spot_intensity=None):
+    """ffx_scene_desc for a scenes.SceneData.  `color` is the RGB weight of a 1-channel projector
+    texture (the reference packs the laser texture into the green channel,
+    examples/vocalfold_scene.py:64-67)."""
+    sd = _abi.SceneDesc()
+    sd.cam = camera_from_sensor(scene.camera, cam_to_world)
+    sd.shadows = int(bool(shadows))
+    sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
+    if scene.projector is not None:
+        p = scene.projector
+        sd.proj.to_world = _m16(p.to_world if proj_to_world is None else proj_to_world)
+        sd.proj.camera_to_sample = _m16(p.K)
+        sd.proj.scale = float(scene.projector_scale)
+        sd.proj.color = (C.c_float * 3)(*[float(v) for v in color])
+        sd.proj.tex_w, sd.proj.tex_h, sd.proj.tex_channels = int(p.width), int(p.height), int(tex_channels)
+        sd.proj.enabled = 1
+    if scene.spot is not None:
+        s = scene.spot
+        sd.spot.to_world = _m16(s.to_world if spot_to_world is None else spot_to_world)
+        inten = s.intensity if spot_intensity is None else spot_intensity
+        sd.spot.intensity = (C.c_float * 3)(*[float(v) for v in inten])
+        sd.spot.cutoff_deg, sd.spot.beam_width_deg = float(s.cutoff_angle), float(s.beam_width)
+        sd.spot.enabled = 1
+    return sd

@@ -593,10 +593,11 @@ int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts
 /* =========================================================================================
  * K7  ray / triangle and traversal.  [EXT: Mitsuba scene.ray_intersect; call sites
  * graphics/depth.py:41,77,115,157]
- * Moller-Trumbore with the documented operation order:
- *   pv = cross(d,e2); det = dot(e1,pv); inv = 1/det; tv = o - v0; u = dot(tv,pv)*inv;
- *   qv = cross(tv,e1); v = dot(d,qv)*inv; t = dot(e2,qv)*inv;
- *   hit iff det != 0, u >= 0, v >= 0, u + v <= 1, tmin < t <= tmax
+ * Moller-Trumbore, division-free rejection, with the documented operation order:
+ *   pv = cross(d,e2); det = dot(e1,pv); tv = o - v0; qv = cross(tv,e1);
+ *   U = dot(tv,pv); V = dot(d,qv); T = dot(e2,qv); if det < 0 negate det,U,V,T;
+ *   hit iff det > 0, U >= 0, V >= 0, U + V <= det, t = T/det, tmin < t <= tmax
+ *   (cross(a,b).x = fma(a.y,b.z,-(a.z*b.y)) etc.; dot = fma(x,x', fma(y,y', z*z')))
  * closest hit: smaller t wins; equal t -> smaller primitive id wins.
  * ========================================================================================= */
 typedef struct { float t; int prim, shape, slot; } hit_t;
@@ -605,15 +606,13 @@ static inline int tri_hit(const orec *r, v3 o, v3 d, float tmin, float *t_out) {
   v3 e1 = V3(r->e1[0], r->e1[1], r->e1[2]), e2 = V3(r->e2[0], r->e2[1], r->e2[2]);
   v3 pv = vcross(d, e2);
   float det = vdot(e1, pv);
-  if (det == 0.f) return 0;
-  float inv = 1.0f / det;
   v3 tv = vsub(o, V3(r->v0[0], r->v0[1], r->v0[2]));
-  float u = vdot(tv, pv) * inv;
-  if (!(u >= 0.f)) return 0;
   v3 qv = vcross(tv, e1);
-  float v = vdot(d, qv) * inv;
-  if (!(v >= 0.f) || !(u + v <= 1.0f)) return 0;
-  float t = vdot(e2, qv) * inv;
+  float U = vdot(tv, pv), Vv = vdot(d, qv), T = vdot(e2, qv);
+  if (det < 0.f) { det = -det; U = -U; Vv = -Vv; T = -T; }
+  if (!(det > 0.f)) return 0;
+  if (!(U >= 0.f) || !(Vv >= 0.f) || !(U + Vv <= det)) return 0;
+  float t = T / det;
   if (!(t > tmin)) return 0;
   *t_out = t;
   return 1;
