@@ -444,6 +444,7 @@ static int blur_weights(int ksize, float sg, BlurW &bw) {
 extern "C" {
 
 int ffx_project_rays_fwd(const float *rays, int n, const float *KF, float *pts, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!rays || !KF || !pts || n < 0) FFX_FAIL(FFX_ERR_ARG, "project_rays_fwd: bad argument");
   if (n == 0) return FFX_OK;
   Mat4 m;
@@ -454,6 +455,7 @@ int ffx_project_rays_fwd(const float *rays, int n, const float *KF, float *pts, 
 }
 
 int ffx_project_rays_bwd(const float *rays, int n, const float *KF, const float *gpts, float *grays, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!rays || !KF || !gpts || !grays || n < 0) FFX_FAIL(FFX_ERR_ARG, "project_rays_bwd: bad argument");
   if (n == 0) return FFX_OK;
   Mat4 m;
@@ -464,6 +466,7 @@ int ffx_project_rays_bwd(const float *rays, int n, const float *KF, const float 
 }
 
 int ffx_transform_points(const float *pts, int n, const float *M, int mode, float *out, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!pts || !M || !out || n < 0 || (mode != 0 && mode != 1)) FFX_FAIL(FFX_ERR_ARG, "transform_points: bad argument");
   if (n == 0) return FFX_OK;
   Mat4 m;
@@ -475,6 +478,7 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
 
 static int dense_fwd_common(const float *pts, const float *depth, int n, float sigma, int size0, int size1, float *out, ffx_stream s, int mode,
                             const char *what) {
+  if (n == 0) return FFX_OK;
   if (!pts || !out || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "%s: bad argument", what);
   if (n == 0) return FFX_OK;
   if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "%s: more than 65535 points", what);
@@ -499,6 +503,7 @@ int ffx_splat_depth_fwd(const float *pts, const float *depth, int n, float sigma
 }
 
 int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!lines || !out || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_lines_fwd: bad argument");
   if (n == 0) return FFX_OK;
   if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "splat_lines_fwd: more than 65535 lines");
@@ -509,6 +514,7 @@ int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int s
 }
 
 int ffx_splat_dense_bwd(const float *pts, int n, float sigma, int size0, int size1, const float *gout, float *gpts, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!pts || !gout || !gpts || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_dense_bwd: bad argument");
   if (n == 0) return FFX_OK;
   hipLaunchKernelGGL((k_splat_bwd<false, true>), dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, pts, n, sigma, FFX_REDUCE_SUM, -1, size0, size1, gout,
@@ -518,7 +524,7 @@ int ffx_splat_dense_bwd(const float *pts, int n, float sigma, int size0, int siz
 }
 
 int ffx_splat_fwd(const float *pts, int n, float sigma, int reduce, int half_window, int size0, int size1, float *tex, ffx_stream s) {
-  if (!pts || !tex || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_fwd: bad argument");
+  if ((!pts && n > 0) || !tex || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_fwd: bad argument");
   if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FFX_FAIL(FFX_ERR_ARG, "splat_fwd: bad reduce %d", reduce);
   dim3 grid(ffx_cdiv(size0, TILE_W), ffx_cdiv(size1, TILE_H));
   if (grid.y > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "splat_fwd: texture too tall");
@@ -533,6 +539,7 @@ int ffx_splat_fwd(const float *pts, int n, float sigma, int reduce, int half_win
 int ffx_splat_bwd(const float *pts, int n, float sigma, int reduce, int half_window, int size0, int size1, const float *tex, const float *gtex,
                   float *gpts, ffx_stream s) {
   (void)tex; // the product over the other points is recomputed; the forward output is not needed
+  if (n == 0) return FFX_OK;
   if (!pts || !gtex || !gpts || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_bwd: bad argument");
   if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FFX_FAIL(FFX_ERR_ARG, "splat_bwd: bad reduce %d", reduce);
   if (n == 0) return FFX_OK;

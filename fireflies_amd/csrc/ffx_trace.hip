@@ -522,6 +522,7 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
 
 int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origins, const float *dirs, int n, float tmax, float *t_out,
                    int32_t *shape_out, int32_t *prim_out, ffx_stream s) {
+  if (n == 0) return FFX_OK;
   if (!bvh || !info || !origins || !dirs || !t_out || n < 0) FFX_FAIL(FFX_ERR_ARG, "trace_rays: bad argument");
   if (!check_info(info, "trace_rays")) return FFX_ERR_ARG;
   if (n == 0) return FFX_OK;

@@ -92,6 +92,7 @@ static int inv4(const float *mf, float *outf) {
  * ========================================================================================= */
 int ffx_project_rays_fwd(const float *rays, int n, const float *KF, float *pts, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!rays || !KF || !pts || n < 0) FAIL(FFX_ERR_ARG, "project_rays_fwd: bad argument");
   for (int i = 0; i < n; ++i) {
     float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
@@ -108,6 +109,7 @@ int ffx_project_rays_fwd(const float *rays, int n, const float *KF, float *pts, 
  * dL/dr_c = sum_r dL/dq_r * KF[r][c]. */
 int ffx_project_rays_bwd(const float *rays, int n, const float *KF, const float *gpts, float *grays, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!rays || !KF || !gpts || !grays || n < 0) FAIL(FFX_ERR_ARG, "project_rays_bwd: bad argument");
   for (int i = 0; i < n; ++i) {
     float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
@@ -129,6 +131,7 @@ int ffx_project_rays_bwd(const float *rays, int n, const float *KF, const float 
 /* transform_points / transform_directions — utils/math.py:220-235 */
 int ffx_transform_points(const float *pts, int n, const float *M, int mode, float *out, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!pts || !M || !out || n < 0) FAIL(FFX_ERR_ARG, "transform_points: bad argument");
   for (int i = 0; i < n; ++i) {
     float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
@@ -163,6 +166,7 @@ static inline float splat_val(float fj, float fi, float p0s, float p1s, float si
 
 int ffx_splat_dense_fwd(const float *pts, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!pts || !out || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_dense_fwd: bad argument");
   for (int k = 0; k < n; ++k) {
     float p0s = pts[2 * k] * (float)size0, p1s = pts[2 * k + 1] * (float)size1;
@@ -182,6 +186,7 @@ static inline void splat_grad(float v, float d, float yd, float xd, float sigma,
 
 int ffx_splat_dense_bwd(const float *pts, int n, float sigma, int size0, int size1, const float *gout, float *gpts, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!pts || !gout || !gpts || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_dense_bwd: bad argument");
   for (int k = 0; k < n; ++k) {
     float p0s = pts[2 * k] * (float)size0, p1s = pts[2 * k + 1] * (float)size1;
@@ -239,7 +244,7 @@ static inline float baked_val(int A, int B, const win1 *w0, const win1 *w1, floa
 
 int ffx_splat_fwd(const float *pts, int n, float sigma, int reduce, int half_window, int size0, int size1, float *tex, ffx_stream s) {
   (void)s;
-  if (!pts || !tex || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_fwd: bad argument");
+  if ((!pts && n > 0) || !tex || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_fwd: bad argument");
   if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FAIL(FFX_ERR_ARG, "splat_fwd: bad reduce %d", reduce);
   size_t T = (size_t)size0 * size1;
   /* accumulate in point order n = 0..N-1 per texel (torch.sum / torch.prod over dim 0) */
@@ -275,6 +280,7 @@ int ffx_splat_bwd(const float *pts, int n, float sigma, int reduce, int half_win
                   const float *gtex, float *gpts, ffx_stream s) {
   (void)s;
   (void)tex;
+  if (n == 0) return FFX_OK;
   if (!pts || !gtex || !gpts || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_bwd: bad argument");
   if (reduce != FFX_REDUCE_SUM && reduce != FFX_REDUCE_SOFTOR) FAIL(FFX_ERR_ARG, "splat_bwd: bad reduce %d", reduce);
   size_t T = (size_t)size0 * size1;
@@ -337,6 +343,7 @@ int ffx_splat_bwd(const float *pts, int n, float sigma, int reduce, int half_win
  * and multiplied by the point's depth (:104). */
 int ffx_splat_depth_fwd(const float *pts, const float *depth, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!pts || !depth || !out || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_depth_fwd: bad argument");
   for (int k = 0; k < n; ++k) {
     float p0s = pts[2 * k] * (float)size0, p1s = pts[2 * k + 1] * (float)size1;
@@ -359,6 +366,7 @@ int ffx_splat_depth_fwd(const float *pts, const float *depth, int n, float sigma
  * distances and are squared again (:153): out = exp(-(dist2^2) / sigma^2). */
 int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int size1, float *out, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!lines || !out || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_lines_fwd: bad argument");
   const float eps = 1.1920928955078125e-07f; /* torch.finfo().eps */
   for (int k = 0; k < n; ++k) {
@@ -756,6 +764,7 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
 int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origins, const float *dirs, int n, float tmax, float *t_out,
                    int32_t *shape_out, int32_t *prim_out, ffx_stream s) {
   (void)s;
+  if (n == 0) return FFX_OK;
   if (!bvh || !info || !origins || !dirs || !t_out || n < 0) FAIL(FFX_ERR_ARG, "trace_rays: bad argument");
   const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
   const orec *recs = (const orec *)((const char *)bvh + info->off_recs);

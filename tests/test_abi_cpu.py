@@ -1,0 +1,128 @@
+"""CPU-side checks of the product library: it loads without a GPU, exports every symbol that
+include/ffx.h declares, refuses non-device tensors loudly, and its host BVH builder emits a
+structurally valid tree.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fireflies_amd import _abi, _lib, ops, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "ffx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ffx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_python_abi_agree():
+    assert _header_symbols() == sorted(_abi.PROTOTYPES)
+
+
+@pytest.mark.parametrize("which", ["hip", "oracle"])
+def test_library_exports_every_symbol(which, oracle):
+    path = _lib.LIB_PATH if which == "hip" else oracle.LIB_PATH
+    assert os.path.exists(path), f"{path} not built"
+    lib = C.CDLL(path)
+    for name in _header_symbols():
+        assert hasattr(lib, name), f"{which}: missing symbol {name}"
+    lib.ffx_backend.restype = C.c_char_p
+    assert lib.ffx_backend().decode() == ("hip-gfx950" if which == "hip" else "cpu-oracle")
+    assert lib.ffx_abi_version() == _abi.FFX_ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    # sizes implied by include/ffx.h (all members are 4- or 8-byte scalars)
+    assert C.sizeof(_abi.Camera) == 4 * (16 + 16 + 2 + 2)
+    assert C.sizeof(_abi.Projector) == 4 * (16 + 16 + 1 + 3 + 4)
+    assert C.sizeof(_abi.Spot) == 4 * (16 + 3 + 2 + 1)
+    assert C.sizeof(_abi.SceneDesc) == C.sizeof(_abi.Camera) + C.sizeof(_abi.Projector) + C.sizeof(_abi.Spot) + 8
+    assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 4  # + tail padding to 8
+
+
+def test_no_cpu_fallback():
+    pts = torch.rand(4, 2)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.splat_fwd(pts, 10.0, "sum", -1, 16, 16)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.project_rays_fwd(torch.rand(4, 3), np.eye(4))
+
+
+def test_error_reporting_through_the_abi():
+    a = _lib.api()
+    info = _abi.BvhInfo()
+    with pytest.raises(_abi.FFXError, match="bad argument"):
+        a.call("ffx_bvh_build_host", None, 0, None, 0, None, 0, C.byref(info))
+    v = np.zeros((3, 3), np.float32)
+    t = np.array([[0, 1, 7]], np.int32)
+    blob = np.zeros(a.lib.ffx_bvh_blob_bytes(1), np.uint8)
+    with pytest.raises(_abi.FFXError, match="out of range"):
+        a.call("ffx_bvh_build_host", v.ctypes.data, 3, t.ctypes.data, 1, blob.ctypes.data, blob.size, C.byref(info))
+    with pytest.raises(_abi.FFXError, match="too small"):
+        a.call("ffx_bvh_build_host", v.ctypes.data, 3, np.array([[0, 1, 2]], np.int32).ctypes.data, 1, blob.ctypes.data, 8, C.byref(info))
+
+
+def _build(verts, tris):
+    a = _lib.api()
+    F = tris.shape[0]
+    n = a.lib.ffx_bvh_blob_bytes(F)
+    blob = np.zeros(n, np.uint8)
+    info = _abi.BvhInfo()
+    a.call("ffx_bvh_build_host", verts.ctypes.data, verts.shape[0], tris.ctypes.data, F, blob.ctypes.data, n, C.byref(info))
+    return blob, info
+
+
+@pytest.mark.parametrize("case", ["single", "leaf", "vocalfold", "degenerate"])
+def test_host_bvh_structure(case):
+    if case == "single":
+        verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+        tris = np.array([[0, 1, 2]], np.int32)
+    elif case == "leaf":
+        verts, tris = scenes.make_plane(1.0, 1.0, 1, 1)
+    elif case == "degenerate":  # every centroid identical -> median fallback must terminate
+        verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+        tris = np.tile(np.array([[0, 1, 2]], np.int32), (300, 1))
+    else:
+        sc = scenes.vocalfold(frames=1)
+        pool, tr, shape, off, stride, nfr, alb = scenes.flatten(sc)
+        verts, tris = pool, (tr + off[shape][:, None]).astype(np.int32)
+    verts = np.ascontiguousarray(verts, np.float32)
+    tris = np.ascontiguousarray(tris, np.int32)
+    blob, info = _build(verts, tris)
+    F = tris.shape[0]
+    assert info.n_tris == F and 1 <= info.n_nodes <= max(1, F)
+    assert info.max_depth <= 48 and info.total_bytes <= blob.size
+    nodes = blob[info.off_nodes : info.off_nodes + 64 * info.n_nodes].view(np.int32).reshape(-1, 16)
+    order = blob[info.off_order : info.off_order + 4 * F].view(np.int32)
+    refit = blob[info.off_refit : info.off_refit + 4 * info.n_nodes].view(np.int32)
+    assert sorted(order.tolist()) == list(range(F))  # a permutation of the triangles
+    assert sorted(refit.tolist()) == list(range(info.n_nodes))
+    assert info.level_start[0] == 0 and info.level_start[info.n_levels] == info.n_nodes
+    # every leaf slot covered exactly once; every inner node referenced exactly once (except root)
+    covered = np.zeros(F, np.int32)
+    refs = np.zeros(info.n_nodes, np.int32)
+    height = np.zeros(info.n_nodes, np.int32)
+    level_of = np.zeros(info.n_nodes, np.int32)
+    for l in range(info.n_levels):
+        level_of[refit[info.level_start[l] : info.level_start[l + 1]]] = l
+    EMPTY = -(2**31)
+    for k in range(info.n_nodes):
+        for c in (int(nodes[k, 12]), int(nodes[k, 13])):
+            if c == EMPTY:
+                continue
+            if c < 0:
+                lc = (~c) & 0xFFFFFFFF
+                first, cnt = lc >> 3, (lc & 7) + 1
+                assert cnt <= 4 and first + cnt <= F
+                covered[first : first + cnt] += 1
+            else:
+                assert 0 < c < info.n_nodes
+                refs[c] += 1
+                assert level_of[c] < level_of[k]  # children are refitted before parents
+    assert (covered == 1).all()
+    assert refs[0] == 0 and (refs[1:] == 1).all()
