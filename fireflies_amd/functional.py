@@ -1,0 +1,114 @@
+"""Differentiable front-ends: PyTorch `autograd.Function`s whose forward and backward are single
+calls into libffx_hip.so.  They replace the autograd graphs that the reference builds out of
+eager torch ops (graphics/rasterization.py, projection/laser.py) and the Dr.Jit AD bridge around
+`mi.render` (graphics/depth.py:9,33,128 show the `dr.wrap_ad` pattern).
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+FLIP_Y = np.diag([1.0, -1.0, 1.0, 1.0]).astype(np.float32)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _ProjectRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays, KF):
+        rays = _c(rays)
+        ctx.save_for_backward(rays)
+        ctx.KF = KF
+        return ops.project_rays_fwd(rays, KF)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rays,) = ctx.saved_tensors
+        return ops.project_rays_bwd(rays, ctx.KF, _c(g)), None
+
+
+def project_rays(rays, KF):
+    """K1: transform_points(rays, K @ FLIP_Y) (projection/laser.py:262-275); KF is a host 4x4."""
+    return _ProjectRays.apply(rays, np.asarray(KF, np.float32))
+
+
+class _RasterizePoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, sigma, size0, size1):
+        pts = _c(pts)
+        ctx.save_for_backward(pts)
+        ctx.args = (sigma, size0, size1)
+        return ops.splat_dense_fwd(pts, sigma, size0, size1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (pts,) = ctx.saved_tensors
+        sigma, size0, size1 = ctx.args
+        return ops.splat_dense_bwd(pts, sigma, size0, size1, _c(g)), None, None, None
+
+
+def rasterize_points_dense(pts, sigma, size0, size1):
+    """dense [N,size1,size0] layers of graphics/rasterization.py:7-37, differentiable in pts."""
+    return _RasterizePoints.apply(pts, float(sigma), int(size0), int(size1))
+
+
+class _Splat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, sigma, reduce, half_window, size0, size1):
+        pts = _c(pts)
+        tex = ops.splat_fwd(pts, sigma, reduce, half_window, size0, size1)
+        ctx.save_for_backward(pts, tex)
+        ctx.args = (sigma, reduce, half_window, size0, size1)
+        return tex
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, tex = ctx.saved_tensors
+        sigma, reduce, half_window, size0, size1 = ctx.args
+        return ops.splat_bwd(pts, sigma, reduce, half_window, size0, size1, tex, _c(g)), None, None, None, None, None
+
+
+def splat(pts, sigma, size0, size1, reduce="sum", half_window=-1):
+    """fused rasterize_points + sum/softor over the point axis -> [size1,size0]."""
+    return _Splat.apply(pts, float(sigma), reduce, int(half_window), int(size0), int(size1))
+
+
+class _Blur(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, ksize, sigma):
+        ctx.args = (ksize, sigma)
+        return ops.blur_fwd(_c(img), ksize, sigma)
+
+    @staticmethod
+    def backward(ctx, g):
+        ksize, sigma = ctx.args
+        return ops.blur_bwd(_c(g), ksize, sigma), None, None
+
+
+def gaussian_blur(img, ksize=5, sigma=3.0):
+    """kornia.filters.gaussian_blur2d(img, (k,k), (s,s)) on a [H,W] tensor (vocalfold_scene.py:61-63)."""
+    return _Blur.apply(img, int(ksize), float(sigma))
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, geom, sd, albedo, spp, seed, fp16):
+        ctx.geom, ctx.sd, ctx.albedo, ctx.spp, ctx.seed = geom, sd, albedo, spp, seed
+        ctx.tex_shape = tex.shape
+        t = _c(tex)
+        if t.dim() == 2:
+            t = t.unsqueeze(-1)
+        return geom.render_fwd(sd, albedo, t, spp, seed, fp16)
+
+    @staticmethod
+    def backward(ctx, g):
+        gtex = ctx.geom.render_bwd(ctx.sd, ctx.albedo, ctx.spp, ctx.seed, _c(g.float()))
+        return gtex.reshape(ctx.tex_shape), None, None, None, None, None, None
+
+
+def render(tex, geom, sd, albedo, spp, seed=0, fp16=False):
+    """K8/K9: image [H,W,3], differentiable w.r.t. the projector texture ([h,w] or [h,w,c]).
+    The geometry must not be re-fitted between forward and backward (the adjoint replays it)."""
+    return _Render.apply(tex, geom, sd, albedo, int(spp), int(seed), bool(fp16))

@@ -1,0 +1,443 @@
+"""`mi` — the slice of the Mitsuba-3 Python protocol that Fireflies talks to, served by the HIP
+path.  Usage: replace `import mitsuba as mi` by `from fireflies_amd import mi`.
+
+What the reference uses: `mi.set_variant`, `mi.traverse(scene)` -> dict-like
+parameters with `.update()` (fireflies/scene.py:94-384), value wrappers `mi.Float`, `mi.Float32`,
+`mi.Transform4f(...).matrix.torch()`, `mi.TensorXf` (scene.py:135,249,257; examples/
+vocalfold_scene.py:69), `scene.sensors()[i].film().size()/crop_size()/crop_offset()`,
+`mi.perspective_projection(...)` (vocalfold_scene.py:24-38) and `mi.render(scene, spp=...)`
+(:102).  Scene *files* (Mitsuba XML) are a later row: scenes come from
+`fireflies_amd.scenes` (procedural) via `mi.load_scene_data`.
+
+Everything numeric lives on the HIP device: `params.update()` runs K5+K6 (ffx_scene_update),
+`mi.render` runs K8 (and K9 under autograd when `tex.data` requires grad).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import functional as Fn
+from . import ops, scene_desc, scenes
+
+_variant = "hip_ad_rgb"
+
+
+def set_variant(name: str) -> None:
+    """Accepted for source compatibility (every example calls mi.set_variant("cuda_ad_rgb"));
+    there is exactly one backend here: HIP on gfx950, fp32, AD w.r.t. the projector texture."""
+    global _variant
+    _variant = name
+
+
+def variant() -> str:
+    return _variant
+
+
+# ----------------------------------------------------------------------------- value wrappers
+class Float(float):
+    def torch(self):
+        return torch.tensor([float(self)])
+
+
+class _ArrayBase:
+    def __init__(self, data, device=None):
+        if isinstance(data, _ArrayBase):
+            data = data.t
+        if not isinstance(data, torch.Tensor):
+            data = torch.as_tensor(np.asarray(data, dtype=np.float32))
+        self.t = data if device is None else data.to(device)
+
+    def torch(self):
+        return self.t
+
+    def numpy(self):
+        return self.t.detach().cpu().numpy()
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    def __getitem__(self, i):
+        return self.t[i]
+
+    def __iter__(self):
+        return iter(self.t)
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    def __repr__(self):
+        return f"{type(self).__name__}(shape={tuple(self.t.shape)})"
+
+
+class Float32(_ArrayBase):
+    """flat float array (mesh `vertex_positions`, scene.py:249)."""
+
+    def __init__(self, data, device=None):
+        super().__init__(data, device)
+        self.t = self.t.reshape(-1)
+
+
+class UInt32(_ArrayBase):
+    def __init__(self, data, device=None):
+        if not isinstance(data, torch.Tensor):
+            data = torch.as_tensor(np.asarray(data, dtype=np.int32))
+        self.t = data.reshape(-1) if device is None else data.reshape(-1).to(device)
+
+
+class Color3f(_ArrayBase):
+    def __init__(self, data, device=None):
+        super().__init__(data, device)
+        self.t = self.t.reshape(-1)[:3]
+
+    def torch(self):
+        return self.t.reshape(1, 3)
+
+
+Vector3f = Color3f
+Point3f = Color3f
+
+
+class TensorXf(_ArrayBase):
+    pass
+
+
+class _Matrix:
+    def __init__(self, m):
+        self.m = m
+
+    def torch(self):
+        return self.m.reshape(1, 4, 4)
+
+    def numpy(self):
+        return self.m.numpy().reshape(1, 4, 4)
+
+
+class Transform4f:
+    def __init__(self, m=None):
+        if m is None:
+            m = torch.eye(4)
+        if isinstance(m, Transform4f):
+            m = m._m
+        if not isinstance(m, torch.Tensor):
+            m = torch.as_tensor(np.asarray(m, dtype=np.float32))
+        self._m = m.detach().to("cpu", torch.float32).reshape(4, 4).clone()
+
+    @property
+    def matrix(self):
+        return _Matrix(self._m)
+
+    def numpy(self):
+        return self._m.numpy()
+
+    def __repr__(self):
+        return f"Transform4f({self._m.tolist()})"
+
+
+class ScalarTransform3f:
+    pass
+
+
+def perspective_projection(film_size, crop_size, crop_offset, fov_x, near_clip, far_clip) -> Transform4f:
+    """camera space -> sample space [0,1]^2 x depth [EXT Mitsuba, SURVEY App. A]:
+    scale(1/rel_size) * translate(-rel_offset) * scale(-0.5, -0.5*aspect, 1) * translate(-1, -1/aspect, 0) * perspective."""
+    fw, fh = float(film_size[0]), float(film_size[1])
+    cw, ch = float(crop_size[0]), float(crop_size[1])
+    ox, oy = float(crop_offset[0]), float(crop_offset[1])
+    aspect = fw / fh
+    c = 1.0 / math.tan(math.radians(float(fov_x)) * 0.5)
+    P = np.array([[c, 0, 0, 0], [0, c, 0, 0], [0, 0, far_clip / (far_clip - near_clip), -near_clip * far_clip / (far_clip - near_clip)], [0, 0, 1, 0]], np.float64)
+    T1 = np.eye(4)
+    T1[0, 3], T1[1, 3] = -1.0, -1.0 / aspect
+    S1 = np.diag([-0.5, -0.5 * aspect, 1.0, 1.0])
+    T2 = np.eye(4)
+    T2[0, 3], T2[1, 3] = -ox / fw, -oy / fh
+    S2 = np.diag([fw / cw, fh / ch, 1.0, 1.0])
+    return Transform4f((S2 @ T2 @ S1 @ T1 @ P).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- scene objects
+class Film:
+    def __init__(self, w, h):
+        self._w, self._h = int(w), int(h)
+
+    def size(self):
+        return [self._w, self._h]
+
+    def crop_size(self):
+        return [self._w, self._h]
+
+    def crop_offset(self):
+        return [0, 0]
+
+
+class Sampler:
+    """`independent`-sampler stand-in: holds the seed that keys the per-sample hash."""
+
+    def __init__(self):
+        self._seed, self._wavefront = 0, 0
+
+    def seed(self, seed, wavefront_size=0):
+        self._seed, self._wavefront = int(seed), int(wavefront_size)
+
+    def wavefront_size(self):
+        return self._wavefront
+
+
+class Sensor:
+    def __init__(self, scene, key):
+        self._scene, self._key = scene, key
+        self._sampler = Sampler()
+
+    def _p(self, k):
+        return self._scene._params[self._key + "." + k]
+
+    def id(self):
+        return self._key
+
+    def film(self):
+        w, h = self._scene._film_size[self._key]
+        return Film(w, h)
+
+    def sampler(self):
+        return self._sampler
+
+    def near_clip(self):
+        return float(self._p("near_clip"))
+
+    def far_clip(self):
+        return float(self._p("far_clip"))
+
+    def x_fov(self):
+        return float(self._p("x_fov"))
+
+    def world_transform(self):
+        return self._p("to_world")
+
+
+class SceneParameters:
+    """dict-like parameter view with Mitsuba-style keys and `.update()` (fireflies/scene.py:94,121,
+    135,249,257,384).  Assignments only record the new value; `update()` pushes everything that
+    changed to the device in one go (K5+K6 for geometry)."""
+
+    def __init__(self, scene):
+        self._scene = scene
+        self._d = {}
+        self._dirty = set()
+
+    def keys(self):
+        return self._d.keys()
+
+    def items(self):
+        return self._d.items()
+
+    def __contains__(self, k):
+        return k in self._d
+
+    def __iter__(self):
+        return iter(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+    def __setitem__(self, k, v):
+        if k not in self._d:
+            raise KeyError(f"unknown scene parameter {k!r}")
+        self._d[k] = v
+        self._dirty.add(k)
+
+    def _init(self, k, v):
+        self._d[k] = v
+
+    def set_mesh_pose(self, name, world, frame=None, vertices=None):
+        """Fast path used by Scene.update_meshes: instead of assigning transformed vertices to
+        `<mesh>.vertex_positions`, hand over the pose; the transform runs inside ffx_scene_update."""
+        self._scene._set_pose(name, world, frame, vertices)
+        self._dirty.add(name + ".__pose__")
+
+    def update(self):
+        self._scene._apply(self._dirty)
+        self._dirty = set()
+
+
+class Scene:
+    """Device-resident scene: geometry pool + BVH blob (ops.DeviceGeometry), per-shape albedo,
+    camera / projector / spot parameter blocks, the projector texture."""
+
+    def __init__(self, data: scenes.SceneData, device="cuda", shadows=True):
+        self.device = torch.device(device)
+        self.data = data
+        pool, tris, tri_shape, off, stride, nfr, alb = scenes.flatten(data)
+        self._base_off, self._stride, self._n_frames = off.copy(), stride, nfr
+        # one extra slot per mesh for caller-supplied vertices (animation functions,
+        # direct `vertex_positions` assignment)
+        extra, self._scratch_off = [], []
+        base = pool.shape[0]
+        for s, m in enumerate(data.meshes):
+            self._scratch_off.append(base)
+            extra.append(m.frames[0])
+            base += m.frames.shape[1]
+        pool = np.concatenate([pool] + extra, 0)
+        self.geom = ops.DeviceGeometry(pool, tris, tri_shape, off, device=self.device)
+        self.mesh_names = [m.name for m in data.meshes]
+        self._mesh_index = {m.name: i for i, m in enumerate(data.meshes)}
+        S = len(data.meshes)
+        self._xforms = torch.eye(4).repeat(S, 1, 1)  # host
+        self._offs = off.copy()
+        self.albedo = torch.from_numpy(alb).to(self.device)
+        self.shadows = shadows
+        self.tex_color = (0.0, 1.0, 0.0)
+        self._film_size = {}
+        self._params = SceneParameters(self)
+        self._build_params()
+        self._sensors = [Sensor(self, data.camera.name)]
+        if data.projector is not None:
+            self._sensors.append(Sensor(self, data.projector.name))
+        self._sd_cache = None
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self):
+        p, d = self._params, self.data
+        for m in d.meshes:
+            p._init(m.name + ".vertex_positions", Float32(torch.from_numpy(m.frames[0].reshape(-1).copy())))
+            p._init(m.name + ".faces", UInt32(m.tris))
+            p._init(m.name + ".vertex_count", int(m.frames.shape[1]))
+            p._init(m.name + ".face_count", int(m.tris.shape[0]))
+        mats = {}
+        for m in d.meshes:
+            mats.setdefault(m.material, []).append(m)
+        self._material_meshes = {k: [self._mesh_index[x.name] for x in v] for k, v in mats.items()}
+        for mat, ms in mats.items():
+            p._init(mat + ".brdf_0.base_color.value", Color3f(torch.tensor(ms[0].albedo, dtype=torch.float32)))
+            p._init(mat + ".brdf_0.specular", Float(0.5))
+            p._init(mat + ".brdf_0.roughness.value", Float(0.5))
+        for s in [d.camera] + ([d.projector] if d.projector is not None else []):
+            p._init(s.name + ".to_world", Transform4f(s.to_world))
+            p._init(s.name + ".x_fov", Float(s.fov_x))
+            p._init(s.name + ".near_clip", Float(s.near))
+            p._init(s.name + ".far_clip", Float(s.far))
+            self._film_size[s.name] = (s.width, s.height)
+        if d.projector is not None:
+            p._init("Projector.to_world", Transform4f(d.projector.to_world))
+            p._init("Projector.scale", Float(d.projector_scale))
+            tex = torch.zeros((d.projector.height, d.projector.width, 3), device=self.device)
+            p._init("tex.data", TensorXf(tex))
+        if d.spot is not None:
+            s = d.spot
+            p._init(s.name + ".to_world", Transform4f(s.to_world))
+            p._init(s.name + ".intensity.value", Color3f(torch.tensor(s.intensity, dtype=torch.float32)))
+            p._init(s.name + ".cutoff_angle", Float(s.cutoff_angle))
+            p._init(s.name + ".beam_width", Float(s.beam_width))
+
+    def sensors(self):
+        return self._sensors
+
+    def shapes(self):
+        return list(self.mesh_names)
+
+    def _set_pose(self, name, world, frame, vertices):
+        i = self._mesh_index[name]
+        w = world.detach().to("cpu", torch.float32) if isinstance(world, torch.Tensor) else torch.as_tensor(np.asarray(world, np.float32))
+        self._xforms[i] = w.reshape(4, 4)
+        if vertices is not None:
+            V = int(self._stride[i])
+            v = vertices.detach().to(self.device, torch.float32).reshape(-1, 3)
+            if v.shape[0] != V:
+                raise ValueError(f"{name}: expected {V} vertices, got {v.shape[0]}")
+            o = self._scratch_off[i]
+            self.geom.src_verts[o : o + V].copy_(v)
+            self._offs[i] = o
+        elif frame is not None:
+            f = int(frame)
+            if not (0 <= f < int(self._n_frames[i])):
+                raise IndexError(f"{name}: frame {f} out of range [0, {int(self._n_frames[i])})")
+            self._offs[i] = self._base_off[i] + f * int(self._stride[i])
+
+    def _apply(self, dirty):
+        geom_dirty = False
+        for k in dirty:
+            base, _, rest = k.partition(".")
+            if rest == "__pose__":
+                geom_dirty = True
+            elif rest == "vertex_positions" and base in self._mesh_index:
+                # generic Mitsuba-style path: the caller transformed the vertices itself
+                v = self._params._d[k]
+                v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v)
+                self._set_pose(base, torch.eye(4), None, v)
+                geom_dirty = True
+            elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
+                c = self._params._d[k]
+                c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3].to(self.device)
+                for i in self._material_meshes[base]:
+                    self.albedo[i] = c
+        if geom_dirty:
+            self.geom.update(self._xforms, self._offs)
+        self._sd_cache = None
+
+    # ------------------------------------------------------------------ render-time blocks
+    def _mat(self, key):
+        v = self._params[key]
+        return v.numpy() if isinstance(v, Transform4f) else np.asarray(v, np.float32).reshape(4, 4)
+
+    def scene_desc(self, tex_channels=3):
+        if self._sd_cache is not None and self._sd_cache[0] == tex_channels:
+            return self._sd_cache[1]
+        d, p = self.data, self._params
+        cam = d.camera
+        sensor = scenes.SensorData(cam.name, self._mat(cam.name + ".to_world"), float(p[cam.name + ".x_fov"]), float(p[cam.name + ".near_clip"]),
+                                   float(p[cam.name + ".far_clip"]), cam.width, cam.height)
+        proj = None
+        if d.projector is not None:
+            pr = d.projector
+            proj = scenes.SensorData(pr.name, self._mat("Projector.to_world"), float(p[pr.name + ".x_fov"]), float(p[pr.name + ".near_clip"]),
+                                     float(p[pr.name + ".far_clip"]), pr.width, pr.height)
+        spot = None
+        if d.spot is not None:
+            s = d.spot
+            inten = p[s.name + ".intensity.value"]
+            inten = inten.t.reshape(-1).tolist() if isinstance(inten, _ArrayBase) else list(inten)
+            spot = scenes.SpotData(s.name, self._mat(s.name + ".to_world"), tuple(float(v) for v in inten), float(p[s.name + ".cutoff_angle"]),
+                                   float(p[s.name + ".beam_width"]))
+        tmp = scenes.SceneData(d.meshes, sensor, proj, spot, float(p["Projector.scale"]) if proj is not None else 1.0)
+        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows)
+        self._sd_cache = (tex_channels, sd)
+        return sd
+
+    def camera_struct(self, index=0):
+        s = self._sensors[index]
+        w, h = self._film_size[s._key]
+        K = perspective_projection((w, h), (w, h), (0, 0), s.x_fov(), s.near_clip(), s.far_clip()).numpy()
+        return scene_desc.camera_struct(self._mat(s._key + ".to_world"), K, s.near_clip(), s.far_clip(), w, h)
+
+
+def load_scene_data(data: scenes.SceneData, device="cuda", shadows=True) -> Scene:
+    return Scene(data, device=device, shadows=shadows)
+
+
+def traverse(scene: Scene) -> SceneParameters:
+    return scene._params
+
+
+def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: int = 0, sensor: int = 0, fp16: bool = False):
+    """mi.render(scene, spp=...) -> [H,W,3] (wrapped; `.torch()` as in examples/vocalfold_scene.py:14).
+    Differentiable w.r.t. `tex.data` when that parameter is a tensor that requires grad."""
+    if sensor != 0:
+        raise NotImplementedError("only sensor 0 renders; further sensors are projector proxies")
+    p = scene._params
+    tex = None
+    ch = 3
+    if scene.data.projector is not None:
+        tex = p["tex.data"]
+        tex = tex.t if isinstance(tex, _ArrayBase) else tex
+        if not isinstance(tex, torch.Tensor):
+            tex = torch.as_tensor(np.asarray(tex, np.float32))
+        if tex.device != scene.device:
+            tex = tex.to(scene.device)  # the reference uploads through numpy (vocalfold_scene.py:69)
+        ch = 1 if tex.dim() == 2 else int(tex.shape[-1])
+    sd = scene.scene_desc(tex_channels=ch)
+    img = Fn.render(tex.float() if tex is not None else torch.zeros((1, 1, 1), device=scene.device), scene.geom, sd, scene.albedo, spp, seed, fp16)
+    return TensorXf(img)

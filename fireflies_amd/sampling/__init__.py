@@ -1,0 +1,8 @@
+from .base import Sampler
+from .gaussian_distribution import GaussianSampler
+from .uniform import UniformSampler
+from .uniform_integer import UniformIntegerSampler
+from .uniform_scalar_to_vec3 import UniformScalarToVec3Sampler
+from .animation import AnimationSampler
+
+__all__ = ["Sampler", "GaussianSampler", "UniformSampler", "UniformIntegerSampler", "UniformScalarToVec3Sampler", "AnimationSampler"]

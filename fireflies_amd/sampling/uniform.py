@@ -1,0 +1,15 @@
+import torch
+
+from . import base
+from ..utils import math as ffmath
+
+
+class UniformSampler(base.Sampler):
+    """fireflies/sampling/uniform.py: train draw = min + rand * (max - min), ONE torch.rand of the
+    bound's shape on the bound's device (utils/math.py:170-175) — this fixes the RNG stream."""
+
+    def __init__(self, min, max, eval_step_size: float = 0.01, device=torch.device("cuda")) -> None:
+        super().__init__(min, max, eval_step_size, device)
+
+    def sample_train(self):
+        return ffmath.randomBetweenTensors(self._min_range, self._max_range)
