@@ -86,6 +86,17 @@ class Mesh(base.Transformable):
         self._animated = True
         self._randomizable = True
 
+    def set_pool_animation(self, n_train: int, n_eval: int, train_start: int = 0, eval_start: int = None) -> None:
+        """Animation frames that already live in the scene's device vertex pool (procedural scenes,
+        fireflies_amd.scenes): frames [train_start, train_start + n_train) are the train set,
+        [eval_start, eval_start + n_eval) the eval set.  Selecting a frame is then a pointer change
+        inside ffx_scene_update — no vertex data moves."""
+        eval_start = train_start + n_train if eval_start is None else eval_start
+        self._pool_frames = {"train": (int(train_start), int(n_train)), "eval": (int(eval_start), int(n_eval))}
+        self._animation_sampler = sampling.AnimationSampler(0, int(n_train), 0, int(n_eval), device=self._device)
+        self._animated = True
+        self._randomizable = True
+
     def add_animation_func(self, func, min_range, max_range) -> None:
         self._animation_func = func
         self._animation_sampler = sampling.UniformSampler(min_range, max_range, device=self._device)
@@ -165,6 +176,10 @@ class Mesh(base.Transformable):
         self._last_time_sample = t
         if self._animation_func is not None:
             return ("func", None, t)
+        pool = getattr(self, "_pool_frames", None)
+        if pool is not None:
+            which = "train" if self._train else "eval"
+            return ("frames", which, int(min(max(int(t), 0), pool[which][1] - 1)))
         if self._anim_data_train is not None and self._anim_data_eval is not None:
             which = "train" if self._train else "eval"
             stack = self._anim_data_train if self._train else self._anim_data_eval

@@ -145,6 +145,27 @@ def camera_struct(to_world, camera_to_sample, near, far, width, height):
     return c
 
 
+class _EventPair:
+    """records a HIP event pair on the current stream around one launch (bench.py's live kernel
+    timing); a no-op when `sink` is None."""
+
+    def __init__(self, sink, name):
+        self.sink, self.name = sink, name
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            self.b.record()
+            self.sink.append((self.name, self.a, self.b))
+        return False
+
+
 class DeviceGeometry:
     """Triangle soup + BVH blob resident in HBM.
 
@@ -172,6 +193,7 @@ class DeviceGeometry:
             raise ValueError("negative vertex index")
         self.n_tris, self.n_shapes = F, S
         self.device = torch.device(device)
+        self.timing = None  # set to a list to collect (name, start_event, end_event) per launch
         self._max_local = np.zeros(S, np.int64)
         np.maximum.at(self._max_local, ts, tr.max(axis=1))
         self._pool_size = src.shape[0]
@@ -215,10 +237,11 @@ class DeviceGeometry:
         xf = xforms if isinstance(xforms, torch.Tensor) else torch.as_tensor(np.asarray(xforms, np.float32))
         xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
         self._xf = xf  # keep alive until the stream has consumed it
-        api().call(
-            "ffx_scene_update", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-            _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),
-        )
+        with self._timed("scene_update"):
+            api().call(
+                "ffx_scene_update", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
+                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),
+            )
 
     def trace_primary(self, cam, spp=1, jitter=0, seed=0, want_ids=True):
         n = cam.width * cam.height * spp
@@ -242,19 +265,24 @@ class DeviceGeometry:
         )
         return t, shape, prim
 
+    def _timed(self, name):
+        return _EventPair(self.timing, name)
+
     def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False):
         H, W = sd.cam.height, sd.cam.width
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
-        api().call(
+        with self._timed("render_fwd"):
+          api().call(
             "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
             _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(),
-        )
+          )
         return img
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
-        api().call(
-            "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
-            int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(),
-        )
+        with self._timed("render_bwd"):
+            api().call(
+                "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
+                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(),
+            )
         return gtex
