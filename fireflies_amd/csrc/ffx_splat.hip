@@ -53,7 +53,7 @@ __device__ __forceinline__ float baked_val(int A, int B, const Win1 &w0, const W
   return expf(-(q * q));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
@@ -261,8 +261,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // binary32 (or the baked window), so the traffic is the footprint of `gtex`, not [n,H,W].
 // softor needs prod_{m != n}(1 - v_m) per texel: the points whose footprint overlaps this one
 // are compacted into LDS once per workgroup.  Per-lane partial sums are reduced with wave
-// shuffles, then across the 4 waves through LDS: one plain store per point, no atomics, and the
-// result is bitwise reproducible.
+// shuffles, then across the 4 waves through LDS (fp64 partial sums): one plain store per point, no
+// atomics, and the result is bitwise reproducible.
 // LAYERED: upstream gradient is the dense [n,size1,size0] tensor (rasterize_points backward).
 template <bool BAKED, bool LAYERED>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
                 float *__restrict__ gpts) {
   __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
   __shared__ int nb_count;
-  __shared__ float red0[SPLAT_BLOCK / 64], red1[SPLAT_BLOCK / 64];
+  __shared__ double red0[SPLAT_BLOCK / 64], red1[SPLAT_BLOCK / 64];
 
   const int k = blockIdx.x, tid = threadIdx.x;
   const float inv_sigma = 1.0f / sigma;
@@ -311,7 +311,9 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     }
     __syncthreads();
   }
-  float a0 = 0.f, a1 = 0.f;
+  // per-texel terms are fp32 like the reference's autograd; their SUM is carried in fp64: these sums
+  // cancel heavily (|terms| ~ 1e-2, result ~ 1e-4) and fp64 adds are cheap on CDNA
+  double a0 = 0.0, a1 = 0.0;
   if (alive) {
     const int rw = hi0 - lo0, rh = hi1 - lo1;
     const float *g = gtex + (LAYERED ? (size_t)k * size0 * size1 : 0);
@@ -346,8 +348,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
         w *= prod;
       }
       float cf = splat_gcoef(v, d, sigma);
-      a0 += w * (cf * yd);
-      a1 += w * (cf * xd);
+      a0 += (double)(w * (cf * yd));
+      a1 += (double)(w * (cf * xd));
     }
   }
   a0 = wave_sum(a0);
@@ -355,11 +357,11 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   if ((tid & 63) == 0) { red0[tid >> 6] = a0; red1[tid >> 6] = a1; }
   __syncthreads();
   if (tid == 0) {
-    float s0 = 0.f, s1 = 0.f;
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int w = 0; w < SPLAT_BLOCK / 64; ++w) { s0 += red0[w]; s1 += red1[w]; }
-    gpts[2 * k] = s0 * (float)size0;
-    gpts[2 * k + 1] = s1 * (float)size1;
+    gpts[2 * k] = (float)s0 * (float)size0;
+    gpts[2 * k + 1] = (float)s1 * (float)size1;
   }
 }
 

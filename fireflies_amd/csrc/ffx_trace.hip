@@ -14,6 +14,7 @@
 // (stride = workgroup size, conflict-free).  Workgroups are remapped so that the 1/8 of the
 // grid that shares an XCD (blockIdx % 8) covers a contiguous band of the image and keeps its
 // part of the BVH hot in that XCD's 4 MiB L2.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ffx_common.h"
@@ -441,6 +442,332 @@ __global__ void __launch_bounds__(TR_BLOCK)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ wave-packet traversal
+// One wavefront = one packet of 64 coherent rays (4x4 pixels x 4 samples, or their shadow rays).
+// Control flow is WAVE-UNIFORM: the packet walks the union of its rays' paths.  Because the node
+// index is uniform, a node / triangle record is fetched ONCE per wave through the scalar cache
+// (s_load) into SGPRs and feeds the per-lane slab / Moller-Trumbore arithmetic as scalar operands;
+// the vector memory pipe is not used at all during traversal.  The traversal stack is a single
+// VGPR addressed with v_writelane / v_readlane (entry i lives in lane i): no LDS, no barriers.
+// Per-lane results are identical to the per-lane traversal (same tests, closest hit with the
+// primitive-id tie-break is order independent).
+// v_writelane_b32: vec[lane] = val (val, lane wave-uniform, in SGPRs).  clang exposes readlane but not
+// writelane; the s_nop covers the "VALU wrote the SGPR used as lane select" hazard, which hipcc
+// cannot see inside an asm statement.
+__device__ __forceinline__ int writelane_i32(int val, int lane, int vec) {
+  // gfx9 VALU ops may read ONE SGPR over the constant bus: the lane select travels in M0
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
+  return vec;
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool traverse_packet(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float tmin, float tmax,
+                                                bool active, Hit &h) {
+  h.t = active ? tmax : -INFINITY; // an inactive lane fails every slab test
+  h.prim = -1;
+  h.shape = -1;
+  h.slot = -1;
+  const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int stack_v = 0;
+  int sp = 0;
+  int cur = 0;
+  bool found = false;
+  while (true) {
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    const BvhNode *n = nodes + cur;
+    const int c0 = __builtin_amdgcn_readfirstlane(n->c0), c1 = __builtin_amdgcn_readfirstlane(n->c1);
+    float t0, t1;
+    bool h0 = (c0 != FFX_EMPTY_CHILD) && slab(n->lo0, n->hi0, o, id, tmin, h.t, t0);
+    bool h1 = (c1 != FFX_EMPTY_CHILD) && slab(n->lo1, n->hi1, o, id, tmin, h.t, t1);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int c = side ? c1 : c0;
+      const bool hs = side ? h1 : h0;
+      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs) != 0ull) {
+        const uint32_t lc = (uint32_t)~c;
+        const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
+        for (int i = 0; i < count; ++i) {
+          if (hs) {
+            float t;
+            int prim, shape;
+            if (tri_hit(recs + first + i, o, d, tmin, t, prim, shape)) {
+              if (ANY) {
+                if (t < tmax) { found = true; h.t = -INFINITY; }
+              } else if (t <= tmax && (h.prim < 0 || t < h.t || (t == h.t && prim < h.prim))) {
+                h.t = t; h.prim = prim; h.shape = shape; h.slot = first + i;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (ANY && __ballot(active && !found) == 0ull) break; // every ray of the packet is decided
+    const bool g0 = h0 && c0 >= 0 && t0 <= h.t, g1 = h1 && c1 >= 0 && t1 <= h.t;
+    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
+    if (m0 != 0ull && m1 != 0ull) {
+      // visit first the child that most rays enter first
+      const int votes1 = __popcll(__ballot(g1 && (!g0 || t1 < t0))), votes0 = __popcll(__ballot(g0 && (!g1 || t0 <= t1)));
+      const int nearc = votes1 > votes0 ? c1 : c0, farc = votes1 > votes0 ? c0 : c1;
+      stack_v = writelane_i32(farc, sp, stack_v);
+      ++sp;
+      cur = nearc;
+    } else if (m0 != 0ull) {
+      cur = c0;
+    } else if (m1 != 0ull) {
+      cur = c1;
+    } else {
+      if (sp == 0) break;
+      --sp;
+      cur = __builtin_amdgcn_readlane(stack_v, sp);
+    }
+  }
+  return ANY ? found : (h.prim >= 0);
+}
+
+// packet version of shade_sample: every lane of the wave reaches every traversal call
+__device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, bool active, v3 o,
+                                                v3 d, float nt, float ft, SampleTerms &st) {
+  Hit h;
+  st.hit = traverse_packet<false>(nodes, recs, o, d, nt, ft, active, h);
+  st.has_proj = 0;
+  st.proj_fac = 0.f;
+  st.spot[0] = st.spot[1] = st.spot[2] = 0.f;
+  st.shape = h.shape;
+  v3 P = V3(0.f, 0.f, 0.f), ng = V3(0.f, 0.f, 1.f), Po = V3(0.f, 0.f, 0.f);
+  bool ok = st.hit != 0;
+  if (ok) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(recs + h.slot);
+    float4 ra = r4[0], rb = r4[1], rc = r4[2];
+    P = V3(fmaf(h.t, d.x, o.x), fmaf(h.t, d.y, o.y), fmaf(h.t, d.z, o.z));
+    ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
+    float nl = sqrtf(vdot(ng, ng));
+    ok = nl > 0.f;
+    if (ok) {
+      ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+      if (vdot(ng, d) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
+      float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
+      float off = (1.0f + pmax) * RAY_EPS;
+      Po = V3(fmaf(off, ng.x, P.x), fmaf(off, ng.y, P.y), fmaf(off, ng.z, P.z));
+    }
+  }
+  // ---- projector
+  bool need_p = false;
+  float pfac = 0.f, u = 0.f, v = 0.f;
+  v3 ws = V3(0.f, 0.f, 1.f);
+  float ds = 1.f;
+  if (c.proj_on && ok) {
+    v3 pl = xf_point(c.p_w2l, P);
+    if (pl.z > 0.f) {
+      const float *m = c.p_c2s;
+      float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
+      float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
+      float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
+      u = qx / qw;
+      v = qy / qw;
+      if (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f) {
+        v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
+        v3 wi = vsub(ppos, P);
+        float d2 = vdot(wi, wi);
+        float dist = sqrtf(d2);
+        wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+        float cos_s = vdot(ng, wi);
+        float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
+        if (cos_s > 0.f && cos_p > 0.f) {
+          need_p = true;
+          pfac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+          ws = vsub(ppos, Po);
+          ds = sqrtf(vdot(ws, ws));
+          ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+        }
+      }
+    }
+  }
+  bool occ_p = false;
+  if (c.shadows && __ballot(need_p) != 0ull) {
+    Hit hs;
+    occ_p = traverse_packet<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), need_p, hs);
+  }
+  if (need_p && !occ_p) {
+    st.proj_fac = pfac;
+    float fx = fmaf(u, (float)c.tw, -0.5f), fy = fmaf(v, (float)c.th, -0.5f);
+    float x0 = floorf(fx), y0 = floorf(fy);
+    float ax = fx - x0, ay = fy - y0;
+    int ix0 = (int)x0, iy0 = (int)y0;
+    st.ix0 = clampi(ix0, 0, c.tw - 1);
+    st.ix1 = clampi(ix0 + 1, 0, c.tw - 1);
+    st.iy0 = clampi(iy0, 0, c.th - 1);
+    st.iy1 = clampi(iy0 + 1, 0, c.th - 1);
+    st.wx0 = 1.0f - ax; st.wx1 = ax;
+    st.wy0 = 1.0f - ay; st.wy1 = ay;
+    st.has_proj = 1;
+  }
+  // ---- spot
+  bool need_s = false;
+  float sfac = 0.f;
+  if (c.spot_on && ok) {
+    v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
+    v3 wi = vsub(spos, P);
+    float d2 = vdot(wi, wi);
+    float dist = sqrtf(d2);
+    wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+    float cos_s = vdot(ng, wi);
+    if (cos_s > 0.f) {
+      v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
+      float ln = sqrtf(vdot(ll, ll));
+      float cos_t = ll.z / ln;
+      float fall = 0.f;
+      if (cos_t >= c.cos_beam) fall = 1.f;
+      else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
+      if (fall > 0.f) {
+        need_s = true;
+        sfac = fall * cos_s / d2 * 0.3183098861837907f;
+        ws = vsub(spos, Po);
+        ds = sqrtf(vdot(ws, ws));
+        ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+      }
+    }
+  }
+  bool occ_s = false;
+  if (c.shadows && __ballot(need_s) != 0ull) {
+    Hit hs;
+    occ_s = traverse_packet<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), need_s, hs);
+  }
+  if (need_s && !occ_s) {
+    st.spot[0] = c.s_int[0] * sfac;
+    st.spot[1] = c.s_int[1] * sfac;
+    st.spot[2] = c.s_int[2] * sfac;
+  }
+}
+
+// packet lane mapping inside an 8x8 tile: wave = 4x4-pixel quadrant, lane = (pixel 0..15, slot 0..3)
+__device__ __forceinline__ void packet_coords(int tile, int tiles_x, int wave, int lane, int &px, int &py, int &slot) {
+  int pl = lane & 15;
+  slot = lane >> 4;
+  px = (tile % tiles_x) * 8 + (wave & 1) * 4 + (pl & 3);
+  py = (tile / tiles_x) * 8 + (wave >> 1) * 4 + (pl >> 2);
+}
+
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
+                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int fp16, void *__restrict__ img) {
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = c.cam.W, H = c.cam.H;
+  int px, py, slot;
+  packet_coords(tile, tiles_x, wave, lane, px, py, slot);
+  const bool live = tile < n_tiles && px < W && py < H;
+  const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  const int passes = (spp + 3) >> 2;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int s = pass * 4 + slot;
+    const bool active = live && s < spp;
+    uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+    float jx, jy;
+    sample_jitter(seed_key, idx, jx, jy);
+    v3 o, d;
+    float nt, ft;
+    cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+    SampleTerms st;
+    shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
+    if (!st.hit) continue;
+    float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
+    if (st.has_proj) {
+      const int tc = c.tc;
+      size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
+      size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
+      if (tc == 1) {
+        float tv = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+        r0 += tv * c.p_color[0] * st.proj_fac;
+        r1 += tv * c.p_color[1] * st.proj_fac;
+        r2 += tv * c.p_color[2] * st.proj_fac;
+      } else {
+        float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+        float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
+        float tv2 = st.wy0 * (st.wx0 * tex[o00 + 2] + st.wx1 * tex[o01 + 2]) + st.wy1 * (st.wx0 * tex[o10 + 2] + st.wx1 * tex[o11 + 2]);
+        r0 += tv0 * 1.0f * st.proj_fac;
+        r1 += tv1 * 1.0f * st.proj_fac;
+        r2 += tv2 * 1.0f * st.proj_fac;
+      }
+    }
+    const float *alb = albedo + 3 * st.shape;
+    acc0 += alb[0] * r0;
+    acc1 += alb[1] * r1;
+    acc2 += alb[2] * r2;
+  }
+  // combine the 4 sample slots of a pixel: lanes l, l+16, l+32, l+48 (fixed order: deterministic)
+  acc0 += __shfl_down(acc0, 32, 64); acc1 += __shfl_down(acc1, 32, 64); acc2 += __shfl_down(acc2, 32, 64);
+  acc0 += __shfl_down(acc0, 16, 64); acc1 += __shfl_down(acc1, 16, 64); acc2 += __shfl_down(acc2, 16, 64);
+  if (lane < 16 && live) {
+    float inv_spp = 1.0f / (float)spp;
+    size_t o = ((size_t)py * W + px) * 3;
+    if (fp16) {
+      _Float16 *p = (_Float16 *)img;
+      p[o] = (_Float16)(acc0 * inv_spp);
+      p[o + 1] = (_Float16)(acc1 * inv_spp);
+      p[o + 2] = (_Float16)(acc2 * inv_spp);
+    } else {
+      float *p = (float *)img;
+      p[o] = acc0 * inv_spp;
+      p[o + 1] = acc1 * inv_spp;
+      p[o + 2] = acc2 * inv_spp;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TR_BLOCK)
+    k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
+                    uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int W = c.cam.W, H = c.cam.H;
+  int px, py, slot;
+  packet_coords(tile, tiles_x, wave, lane, px, py, slot);
+  bool live = tile < n_tiles && px < W && py < H;
+  const uint32_t pix = live ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (live) { g0 = gimg[(size_t)pix * 3]; g1 = gimg[(size_t)pix * 3 + 1]; g2 = gimg[(size_t)pix * 3 + 2]; }
+  live = live && !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
+  if (__ballot(live) == 0ull) return; // wave-uniform exit
+  const float inv_spp = 1.0f / (float)spp;
+  const int tc = c.tc;
+  const int passes = (spp + 3) >> 2;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int s = pass * 4 + slot;
+    const bool active = live && s < spp;
+    uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+    float jx, jy;
+    sample_jitter(seed_key, idx, jx, jy);
+    v3 o, d;
+    float nt, ft;
+    cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+    SampleTerms st;
+    shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
+    if (!st.hit || !st.has_proj) continue;
+    const float *alb = albedo + 3 * st.shape;
+    size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
+    size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
+    if (tc == 1) {
+      float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
+      atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
+      atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
+      atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
+      atomicAdd(gtex + o11, ws * st.wy1 * st.wx1);
+    } else {
+      const float gg[3] = {g0, g1, g2};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
+        atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
+        atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
+        atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
+        atomicAdd(gtex + o11 + ch, ws * st.wy1 * st.wx1);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static int cam_prepare(const ffx_camera *c, CamK &k) {
   if (c->width < 1 || c->height < 1) return 0;
@@ -486,6 +813,16 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
     c.inv_trans = 1.0f / (c.cutoff - beam);
   }
   return 1;
+}
+
+// FFX_TRAVERSAL=lane selects the per-lane (LDS stack) kernels; default: wave-packet kernels
+static int use_packet() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("FFX_TRAVERSAL");
+    mode = (e && strcmp(e, "lane") == 0) ? 0 : 1;
+  }
+  return mode;
 }
 
 static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }
@@ -547,8 +884,12 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
-  hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
-                     seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
+  if (use_packet())
+    hipLaunchKernelGGL(k_render_fwd_pk, dim3(grid), dim3(TR_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), tiles_x,
+                       n_tiles, img_fp16, img);
+  else
+    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
+                       seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
   FFX_CHECK_LAUNCH("render_fwd");
   return FFX_OK;
 }
@@ -566,8 +907,12 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
-                     tiles_x, n_tiles, gimg, gtex);
+  if (use_packet())
+    hipLaunchKernelGGL(k_render_bwd_pk, dim3(grid), dim3(TR_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), tiles_x, n_tiles,
+                       gimg, gtex);
+  else
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
+                       tiles_x, n_tiles, gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd");
   return FFX_OK;
 }

@@ -112,9 +112,11 @@ def test_k2_empty_and_outside(oracle):
 
 
 def _baked_sum_grad_f64(pts, w, S, sig, half):
-    pts, w = pts.astype(np.float64), w.astype(np.float64)
-    gp = np.zeros_like(pts)
-    for k, (p0, p1) in enumerate(pts * S):
+    # positions are the fp32 products p*size, exactly as the reference and the kernels form them
+    scaled = (pts.astype(np.float32) * np.float32(S)).astype(np.float64)
+    w = w.astype(np.float64)
+    gp = np.zeros(pts.shape, np.float64)
+    for k, (p0, p1) in enumerate(scaled):
         f0, f1 = int(np.floor(p0)), int(np.floor(p1))
         A = np.arange(f0 - half, f0 + half + 1)
         B = np.arange(f1 - half, f1 + half + 1)
@@ -142,8 +144,10 @@ def test_k2_baked(oracle, tag):
     # heavily cancelling sum (|terms| ~ 1e-2, result ~ 3e-4; see test_oracle_golden): judge both the
     # kernel and the reference's own fp32 autograd against a float64 evaluation of the same formula
     f64 = _baked_sum_grad_f64(g["in_pts"], g["in_baked_sum_w"], 100, 100.0, 20)
-    assert np.abs(gp - f64).max() <= 2e-5
-    assert np.abs(g["in_baked_sum_gpts"] - f64).max() <= 3e-5
+    # noise floor: 1681 fp32 terms of magnitude <= 5e-2 (rounding ~1e-8 each), summed, times size0 = 100
+    # -> ~4e-5 for ANY fp32-term implementation (oracle: 2.2e-5, reference autograd: 3.5e-5)
+    assert np.abs(gp - f64).max() <= 8e-5
+    assert np.abs(g["in_baked_sum_gpts"] - f64).max() <= 8e-5
     # softor gradient, baked window, vs oracle
     w = np.cos(np.arange(10000, dtype=np.float32) * 0.13).reshape(100, 100)
     tex = ops.splat_fwd(dev(g["bd_pts"]), 100.0, "softor", 25, 100, 100)
