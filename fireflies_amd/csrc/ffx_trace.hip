@@ -46,12 +46,26 @@ struct ShadeK {
 struct Hit { float t; int prim, shape, slot; };
 
 // ------------------------------------------------------------------------------------------ traversal
-__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], v3 o, v3 id, float tmin, float tmax, float &tn_out) {
-  float ax = (lo[0] - o.x) * id.x, bx = (hi[0] - o.x) * id.x;
-  float ay = (lo[1] - o.y) * id.y, by = (hi[1] - o.y) * id.y;
-  float az = (lo[2] - o.z) * id.z, bz = (hi[2] - o.z) * id.z;
-  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f; // 2-ulp widening
+// Ray/box slab test.  t = lo*id - o*id as ONE fma per plane (o*id is per-ray).  The fma form carries an
+// absolute error of a few ulp(o*id), so the interval is widened by `pad` = 2^-20 * max|o*id| (per
+// ray) on top of the 2-ulp relative widening: boxes may only be hit more often, never less, and the
+// triangle test decides.  NaNs (0 * inf) are dropped by v_min/v_max.
+struct RayBox { v3 id, oid; float pad; };
+__device__ __forceinline__ RayBox make_raybox(v3 o, v3 d) {
+  RayBox r;
+  r.id = V3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+  r.oid = V3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
+  float m = fmaxf(fabsf(r.oid.x), fmaxf(fabsf(r.oid.y), fabsf(r.oid.z)));
+  r.pad = (m < 3.0e38f) ? m * 9.5367431640625e-07f : 0.f;
+  return r;
+}
+__device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const RayBox &rb, float tmin, float tmax, float &tn_out) {
+  float ax = fmaf(lo[0], rb.id.x, -rb.oid.x), bx = fmaf(hi[0], rb.id.x, -rb.oid.x);
+  float ay = fmaf(lo[1], rb.id.y, -rb.oid.y), by = fmaf(hi[1], rb.id.y, -rb.oid.y);
+  float az = fmaf(lo[2], rb.id.z, -rb.oid.z), bz = fmaf(hi[2], rb.id.z, -rb.oid.z);
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)) - rb.pad;
+  float tf = fmaf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), 1.0000004f, rb.pad);
+  tn = fmaxf(tn, tmin);
   tf = fminf(tf, tmax);
   tn_out = tn;
   return tn <= tf;
@@ -88,7 +102,7 @@ __device__ __forceinline__ bool traverse(const BvhNode *__restrict__ nodes, cons
   h.prim = -1;
   h.shape = -1;
   h.slot = -1;
-  const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const RayBox rb = make_raybox(o, d);
   int sp = 0;
   int cur = 0;
   while (true) {
@@ -98,8 +112,8 @@ __device__ __forceinline__ bool traverse(const BvhNode *__restrict__ nodes, cons
     float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
     float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
     float t0, t1;
-    bool h0 = (ch.x != FFX_EMPTY_CHILD) && slab(lo0, hi0, o, id, tmin, h.t, t0);
-    bool h1 = (ch.y != FFX_EMPTY_CHILD) && slab(lo1, hi1, o, id, tmin, h.t, t1);
+    bool h0 = (ch.x != FFX_EMPTY_CHILD) && slab(lo0, hi0, rb, tmin, h.t, t0);
+    bool h1 = (ch.y != FFX_EMPTY_CHILD) && slab(lo1, hi1, rb, tmin, h.t, t1);
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       int c = side ? ch.y : ch.x;
@@ -461,6 +475,26 @@ __device__ __forceinline__ int writelane_i32(int val, int lane, int vec) {
   return vec;
 }
 
+// branch-free Moller-Trumbore for the packet path: same arithmetic and acceptance rule as tri_hit(),
+// but every lane evaluates everything and the outcome is a predicate (no exec-mask branching inside
+// the wave-uniform leaf loop).  det == 0 gives inf/NaN in t, which fails the comparisons.
+__device__ __forceinline__ bool tri_test_bf(const float4 a, const float4 b, const float4 c, v3 o, v3 d, float tmin, float &t_out) {
+  v3 v0 = V3(a.x, a.y, a.z), e1 = V3(a.w, b.x, b.y), e2 = V3(b.z, b.w, c.x);
+  v3 pv = vcross(d, e2);
+  float det = vdot(e1, pv);
+  v3 tv = vsub(o, v0);
+  v3 qv = vcross(tv, e1);
+  float U = vdot(tv, pv), Vv = vdot(d, qv), T = vdot(e2, qv);
+  const bool neg = det < 0.f;
+  det = neg ? -det : det;
+  U = neg ? -U : U;
+  Vv = neg ? -Vv : Vv;
+  T = neg ? -T : T;
+  float t = T / det;
+  t_out = t;
+  return (det > 0.f) & (U >= 0.f) & (Vv >= 0.f) & (U + Vv <= det) & (t > tmin);
+}
+
 template <bool ANY>
 __device__ __forceinline__ bool traverse_packet(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float tmin, float tmax,
                                                 bool active, Hit &h) {
@@ -468,50 +502,70 @@ __device__ __forceinline__ bool traverse_packet(const BvhNode *__restrict__ node
   h.prim = -1;
   h.shape = -1;
   h.slot = -1;
-  const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const RayBox rb = make_raybox(o, d);
   int stack_v = 0;
   int sp = 0;
   int cur = 0;
   bool found = false;
   while (true) {
     cur = __builtin_amdgcn_readfirstlane(cur);
-    const BvhNode *n = nodes + cur;
-    const int c0 = __builtin_amdgcn_readfirstlane(n->c0), c1 = __builtin_amdgcn_readfirstlane(n->c1);
+    // ONE 64-byte scalar fetch per node (uniform address -> s_load_dwordx16), no conditional loads
+    const float4 *n4 = reinterpret_cast<const float4 *>(nodes + cur);
+    const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
+    const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
+    const int c0 = ch.x, c1 = ch.y;
+    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
     float t0, t1;
-    bool h0 = (c0 != FFX_EMPTY_CHILD) && slab(n->lo0, n->hi0, o, id, tmin, h.t, t0);
-    bool h1 = (c1 != FFX_EMPTY_CHILD) && slab(n->lo1, n->hi1, o, id, tmin, h.t, t1);
+    const bool h0 = slab(lo0, hi0, rb, tmin, h.t, t0) & (c0 != FFX_EMPTY_CHILD);
+    const bool h1 = slab(lo1, hi1, rb, tmin, h.t, t1) & (c1 != FFX_EMPTY_CHILD);
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int c = side ? c1 : c0;
       const bool hs = side ? h1 : h0;
-      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs) != 0ull) {
+      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs) != 0ull) { // wave-uniform
         const uint32_t lc = (uint32_t)~c;
         const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
-        for (int i = 0; i < count; ++i) {
-          if (hs) {
+        // fetch ALL records of the leaf before testing any (one scalar round trip per leaf, not one
+        // per triangle); slots past `count` are read but masked (the blob keeps FFX_LEAF_MAX records
+        // of tail padding for the last leaf)
+        float4 ra[FFX_LEAF_MAX], rb4[FFX_LEAF_MAX], rc[FFX_LEAF_MAX];
+#pragma unroll
+        for (int i = 0; i < FFX_LEAF_MAX; ++i) {
+          const float4 *r4 = reinterpret_cast<const float4 *>(recs + first + i);
+          ra[i] = r4[0]; rb4[i] = r4[1]; rc[i] = r4[2];
+        }
+#pragma unroll
+        for (int i = 0; i < FFX_LEAF_MAX; ++i) {
+          if (i < count) { // wave-uniform
             float t;
-            int prim, shape;
-            if (tri_hit(recs + first + i, o, d, tmin, t, prim, shape)) {
-              if (ANY) {
-                if (t < tmax) { found = true; h.t = -INFINITY; }
-              } else if (t <= tmax && (h.prim < 0 || t < h.t || (t == h.t && prim < h.prim))) {
-                h.t = t; h.prim = prim; h.shape = shape; h.slot = first + i;
-              }
+            const bool hit = tri_test_bf(ra[i], rb4[i], rc[i], o, d, tmin, t) & hs;
+            const int prim = __float_as_int(rc[i].y), shape = __float_as_int(rc[i].z);
+            if (ANY) {
+              const bool occ = hit & (t < tmax);
+              found = found | occ;
+              h.t = occ ? -INFINITY : h.t;
+            } else {
+              const bool better = hit & (t <= tmax) & ((h.prim < 0) | (t < h.t) | ((t == h.t) & (prim < h.prim)));
+              h.t = better ? t : h.t;
+              h.prim = better ? prim : h.prim;
+              h.shape = better ? shape : h.shape;
+              h.slot = better ? first + i : h.slot;
             }
           }
         }
       }
     }
-    if (ANY && __ballot(active && !found) == 0ull) break; // every ray of the packet is decided
-    const bool g0 = h0 && c0 >= 0 && t0 <= h.t, g1 = h1 && c1 >= 0 && t1 <= h.t;
+    if (ANY && __ballot(active & !found) == 0ull) break; // every ray of the packet is decided
+    const bool g0 = h0 & (c0 >= 0) & (t0 <= h.t), g1 = h1 & (c1 >= 0) & (t1 <= h.t);
     const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
     if (m0 != 0ull && m1 != 0ull) {
       // visit first the child that most rays enter first
-      const int votes1 = __popcll(__ballot(g1 && (!g0 || t1 < t0))), votes0 = __popcll(__ballot(g0 && (!g1 || t0 <= t1)));
-      const int nearc = votes1 > votes0 ? c1 : c0, farc = votes1 > votes0 ? c0 : c1;
-      stack_v = writelane_i32(farc, sp, stack_v);
+      const int votes1 = __popcll(__ballot(g1 & (!g0 | (t1 < t0)))), votes0 = __popcll(__ballot(g0 & (!g1 | (t0 <= t1))));
+      const bool swap = votes1 > votes0;
+      stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
       ++sp;
-      cur = nearc;
+      cur = swap ? c1 : c0;
     } else if (m0 != 0ull) {
       cur = c0;
     } else if (m1 != 0ull) {
@@ -641,128 +695,149 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
 }
 
 // packet lane mapping inside an 8x8 tile: wave = 4x4-pixel quadrant, lane = (pixel 0..15, slot 0..3)
-__device__ __forceinline__ void packet_coords(int tile, int tiles_x, int wave, int lane, int &px, int &py, int &slot) {
-  int pl = lane & 15;
-  slot = lane >> 4;
-  px = (tile % tiles_x) * 8 + (wave & 1) * 4 + (pl & 3);
-  py = (tile / tiles_x) * 8 + (wave >> 1) * 4 + (pl >> 2);
+// Packet kernels: ONE wavefront per workgroup, one 2x2-pixel tile per wavefront (65,536 work items at
+// 512x512).  Tile costs vary by an order of magnitude (rays along the tube vs. rays that leave it), so
+// fine-grained single-wave workgroups let the hardware dispatcher keep every SIMD full to the end; with
+// 4-wave workgroups over 8x8 tiles the measured average residency was 3 of 7 waves per SIMD.
+// PX = 1: the wave walks the 4 pixels of its tile in turn, all 64 lanes = 64 samples of ONE pixel (the
+//         tightest packet: the union of the rays' paths is practically a single ray's path);
+// PX = 2: 4 pixels x 16 sample slots at once.
+#define PK_BLOCK 64
+template <int PX>
+__device__ __forceinline__ void packet_coords(int tile, int tiles_x, int lane, int sub, int &px, int &py, int &slot) {
+  const int bx = (tile % tiles_x) * 2, by = (tile / tiles_x) * 2;
+  if (PX == 2) { px = bx + (lane & 1); py = by + ((lane >> 1) & 1); slot = lane >> 2; }
+  else { px = bx + (sub & 1); py = by + (sub >> 1); slot = lane; }
 }
 
-__global__ void __launch_bounds__(TR_BLOCK)
+template <int PX>
+__global__ void __launch_bounds__(PK_BLOCK)
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
                     const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int fp16, void *__restrict__ img) {
+  constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
-  int px, py, slot;
-  packet_coords(tile, tiles_x, wave, lane, px, py, slot);
-  const bool live = tile < n_tiles && px < W && py < H;
-  const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  const int passes = (spp + 3) >> 2;
-  for (int pass = 0; pass < passes; ++pass) {
-    const int s = pass * 4 + slot;
-    const bool active = live && s < spp;
-    uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
-    float jx, jy;
-    sample_jitter(seed_key, idx, jx, jy);
-    v3 o, d;
-    float nt, ft;
-    cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
-    SampleTerms st;
-    shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
-    if (!st.hit) continue;
-    float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
-    if (st.has_proj) {
-      const int tc = c.tc;
+  const int passes = (spp + SLOTS - 1) / SLOTS;
+  for (int sub = 0; sub < NSUB; ++sub) {
+    int px, py, slot;
+    packet_coords<PX>(tile, tiles_x, lane, sub, px, py, slot);
+    const bool live = tile < n_tiles && px < W && py < H;
+    if (__ballot(live) == 0ull) continue;
+    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int s = pass * SLOTS + slot;
+      const bool active = live && s < spp;
+      uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+      float jx, jy;
+      sample_jitter(seed_key, idx, jx, jy);
+      v3 o, d;
+      float nt, ft;
+      cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+      SampleTerms st;
+      shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
+      if (!st.hit) continue;
+      float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
+      if (st.has_proj) {
+        const int tc = c.tc;
+        size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
+        size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
+        if (tc == 1) {
+          float tv = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+          r0 += tv * c.p_color[0] * st.proj_fac;
+          r1 += tv * c.p_color[1] * st.proj_fac;
+          r2 += tv * c.p_color[2] * st.proj_fac;
+        } else {
+          float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
+          float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
+          float tv2 = st.wy0 * (st.wx0 * tex[o00 + 2] + st.wx1 * tex[o01 + 2]) + st.wy1 * (st.wx0 * tex[o10 + 2] + st.wx1 * tex[o11 + 2]);
+          r0 += tv0 * 1.0f * st.proj_fac;
+          r1 += tv1 * 1.0f * st.proj_fac;
+          r2 += tv2 * 1.0f * st.proj_fac;
+        }
+      }
+      const float *alb = albedo + 3 * st.shape;
+      acc0 += alb[0] * r0;
+      acc1 += alb[1] * r1;
+      acc2 += alb[2] * r2;
+    }
+    // combine the sample slots of a pixel (lanes l, l+NPIX, ...) in a fixed order: deterministic
+#pragma unroll
+    for (int off = 32; off >= NPIX; off >>= 1) {
+      acc0 += __shfl_down(acc0, off, 64);
+      acc1 += __shfl_down(acc1, off, 64);
+      acc2 += __shfl_down(acc2, off, 64);
+    }
+    if (lane < NPIX && live) {
+      float inv_spp = 1.0f / (float)spp;
+      size_t o = ((size_t)py * W + px) * 3;
+      if (fp16) {
+        _Float16 *p = (_Float16 *)img;
+        p[o] = (_Float16)(acc0 * inv_spp);
+        p[o + 1] = (_Float16)(acc1 * inv_spp);
+        p[o + 2] = (_Float16)(acc2 * inv_spp);
+      } else {
+        float *p = (float *)img;
+        p[o] = acc0 * inv_spp;
+        p[o + 1] = acc1 * inv_spp;
+        p[o + 2] = acc2 * inv_spp;
+      }
+    }
+  }
+}
+
+template <int PX>
+__global__ void __launch_bounds__(PK_BLOCK)
+    k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
+                    uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
+  constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & 63;
+  const int W = c.cam.W, H = c.cam.H;
+  const float inv_spp = 1.0f / (float)spp;
+  const int tc = c.tc;
+  const int passes = (spp + SLOTS - 1) / SLOTS;
+  for (int sub = 0; sub < NSUB; ++sub) {
+    int px, py, slot;
+    packet_coords<PX>(tile, tiles_x, lane, sub, px, py, slot);
+    bool live = tile < n_tiles && px < W && py < H;
+    const uint32_t pix = live ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (live) { g0 = gimg[(size_t)pix * 3]; g1 = gimg[(size_t)pix * 3 + 1]; g2 = gimg[(size_t)pix * 3 + 2]; }
+    live = live && !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
+    if (__ballot(live) == 0ull) continue; // wave-uniform
+    for (int pass = 0; pass < passes; ++pass) {
+      const int s = pass * SLOTS + slot;
+      const bool active = live && s < spp;
+      uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
+      float jx, jy;
+      sample_jitter(seed_key, idx, jx, jy);
+      v3 o, d;
+      float nt, ft;
+      cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
+      SampleTerms st;
+      shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
+      if (!st.hit || !st.has_proj) continue;
+      const float *alb = albedo + 3 * st.shape;
       size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
       size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
       if (tc == 1) {
-        float tv = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
-        r0 += tv * c.p_color[0] * st.proj_fac;
-        r1 += tv * c.p_color[1] * st.proj_fac;
-        r2 += tv * c.p_color[2] * st.proj_fac;
+        float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
+        atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
+        atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
+        atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
+        atomicAdd(gtex + o11, ws * st.wy1 * st.wx1);
       } else {
-        float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
-        float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
-        float tv2 = st.wy0 * (st.wx0 * tex[o00 + 2] + st.wx1 * tex[o01 + 2]) + st.wy1 * (st.wx0 * tex[o10 + 2] + st.wx1 * tex[o11 + 2]);
-        r0 += tv0 * 1.0f * st.proj_fac;
-        r1 += tv1 * 1.0f * st.proj_fac;
-        r2 += tv2 * 1.0f * st.proj_fac;
-      }
-    }
-    const float *alb = albedo + 3 * st.shape;
-    acc0 += alb[0] * r0;
-    acc1 += alb[1] * r1;
-    acc2 += alb[2] * r2;
-  }
-  // combine the 4 sample slots of a pixel: lanes l, l+16, l+32, l+48 (fixed order: deterministic)
-  acc0 += __shfl_down(acc0, 32, 64); acc1 += __shfl_down(acc1, 32, 64); acc2 += __shfl_down(acc2, 32, 64);
-  acc0 += __shfl_down(acc0, 16, 64); acc1 += __shfl_down(acc1, 16, 64); acc2 += __shfl_down(acc2, 16, 64);
-  if (lane < 16 && live) {
-    float inv_spp = 1.0f / (float)spp;
-    size_t o = ((size_t)py * W + px) * 3;
-    if (fp16) {
-      _Float16 *p = (_Float16 *)img;
-      p[o] = (_Float16)(acc0 * inv_spp);
-      p[o + 1] = (_Float16)(acc1 * inv_spp);
-      p[o + 2] = (_Float16)(acc2 * inv_spp);
-    } else {
-      float *p = (float *)img;
-      p[o] = acc0 * inv_spp;
-      p[o + 1] = acc1 * inv_spp;
-      p[o + 2] = acc2 * inv_spp;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(TR_BLOCK)
-    k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
-                    uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int W = c.cam.W, H = c.cam.H;
-  int px, py, slot;
-  packet_coords(tile, tiles_x, wave, lane, px, py, slot);
-  bool live = tile < n_tiles && px < W && py < H;
-  const uint32_t pix = live ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  if (live) { g0 = gimg[(size_t)pix * 3]; g1 = gimg[(size_t)pix * 3 + 1]; g2 = gimg[(size_t)pix * 3 + 2]; }
-  live = live && !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
-  if (__ballot(live) == 0ull) return; // wave-uniform exit
-  const float inv_spp = 1.0f / (float)spp;
-  const int tc = c.tc;
-  const int passes = (spp + 3) >> 2;
-  for (int pass = 0; pass < passes; ++pass) {
-    const int s = pass * 4 + slot;
-    const bool active = live && s < spp;
-    uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
-    float jx, jy;
-    sample_jitter(seed_key, idx, jx, jy);
-    v3 o, d;
-    float nt, ft;
-    cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
-    SampleTerms st;
-    shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
-    if (!st.hit || !st.has_proj) continue;
-    const float *alb = albedo + 3 * st.shape;
-    size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
-    size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
-    if (tc == 1) {
-      float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
-      atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
-      atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
-      atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
-      atomicAdd(gtex + o11, ws * st.wy1 * st.wx1);
-    } else {
-      const float gg[3] = {g0, g1, g2};
+        const float gg[3] = {g0, g1, g2};
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
-        atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
-        atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
-        atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
-        atomicAdd(gtex + o11 + ch, ws * st.wy1 * st.wx1);
+        for (int ch = 0; ch < 3; ++ch) {
+          float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
+          atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
+          atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
+          atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
+          atomicAdd(gtex + o11 + ch, ws * st.wy1 * st.wx1);
+        }
       }
     }
   }
@@ -825,6 +900,17 @@ static int use_packet() {
   return mode;
 }
 
+// packet shape: FFX_PACKET = 1 (1 pixel x 64 sample lanes, default) or 2 (2x2 pixels x 16 sample slots)
+static int packet_px() {
+  static int px = -1;
+  if (px < 0) {
+    const char *e = getenv("FFX_PACKET");
+    px = e ? atoi(e) : 1;
+    if (px != 1 && px != 2) px = 1;
+  }
+  return px;
+}
+
 static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }
 
 static int check_info(const ffx_bvh_info *info, const char *what) {
@@ -881,15 +967,23 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  if (use_packet()) {
+    int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
+    int pgrid = ((pn + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
+    if (packet_px() == 1)
+      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+                         pn, img_fp16, img);
+    else
+      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+                         pn, img_fp16, img);
+    FFX_CHECK_LAUNCH("render_fwd");
+    return FFX_OK;
+  }
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
-  int grid = ((n_tiles + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
-  if (use_packet())
-    hipLaunchKernelGGL(k_render_fwd_pk, dim3(grid), dim3(TR_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), tiles_x,
-                       n_tiles, img_fp16, img);
-  else
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
-                       seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
+  int grid = ((n_tiles + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
+                     seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
   FFX_CHECK_LAUNCH("render_fwd");
   return FFX_OK;
 }
@@ -904,15 +998,23 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  if (use_packet()) {
+    int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
+    int pgrid = ((pn + 7) / 8) * 8;
+    if (packet_px() == 1)
+      hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, gimg,
+                         gtex);
+    else
+      hipLaunchKernelGGL(k_render_bwd_pk<2>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, gimg,
+                         gtex);
+    FFX_CHECK_LAUNCH("render_bwd");
+    return FFX_OK;
+  }
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
-  if (use_packet())
-    hipLaunchKernelGGL(k_render_bwd_pk, dim3(grid), dim3(TR_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), tiles_x, n_tiles,
-                       gimg, gtex);
-  else
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
-                       tiles_x, n_tiles, gimg, gtex);
+  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
+                     tiles_x, n_tiles, gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd");
   return FFX_OK;
 }
