@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-steps", action="store_true")
     ap.add_argument("--no-shadows", action="store_true")
+    ap.add_argument("--entity-device", default="cpu", help="device argument of ff.Scene (where the samplers draw): cpu (no sync per draw) or cuda (the reference default)")
     args = ap.parse_args()
 
     rank, world, local = dist.env_rank_world()
@@ -128,7 +129,7 @@ def main():
     W = H = args.res
 
     # ------------------------------------------------------------------ renders/sec
-    wl = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows)
+    wl = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows, entity_device=args.entity_device)
     with torch.no_grad():
         tex = workloads.build_texture(wl).contiguous()
     wl.params["tex.data"] = tex
@@ -159,7 +160,7 @@ def main():
     # ------------------------------------------------------------------ pattern-gradient steps/sec
     grad = {}
     if not args.no_grad_steps:
-        wg = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows)
+        wg = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device)
         opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=world, base_seed=7)
         gevents = []
 
@@ -203,6 +204,7 @@ def main():
             "workload": f"BASELINE configs[2] (renders): procedural animated vocal-fold scene, {bytes_['F']} triangles, {args.grid**2}-point projector, "
                         f"{W}x{H}, {args.spp} spp, shadows {'on' if not args.no_shadows else 'off'}; configs[1] (grad steps): same scene, {args.grad_grid**2}-point pattern",
             "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render [K8]; texture built once before the loop",
+            "entity_device": args.entity_device,
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
         },

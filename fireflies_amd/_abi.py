@@ -96,6 +96,7 @@ PROTOTYPES = {
     "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),
     "ffx_bvh_build_host": (c_i, [c_p, c_i, c_p, c_i, c_p, C.c_size_t, C.POINTER(BvhInfo)]),
     "ffx_scene_update": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "ffx_scene_update_h": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, C.POINTER(C.c_int32), PF, c_i, c_p]),
     "ffx_trace_primary": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(Camera), c_i, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
     "ffx_trace_rays": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),

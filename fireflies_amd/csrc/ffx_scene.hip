@@ -22,20 +22,31 @@
 #define UPD_BLOCK 256
 #define TAIL_BLOCK 1024
 
+// per-shape tables as a kernel argument (ffx_scene_update_h): 32 * (1 + 12) dwords = 1664 B of kernarg
+struct ShapeTabH { int32_t off[FFX_MAX_SHAPES_H]; float m[FFX_MAX_SHAPES_H][12]; };
+
+template <bool HOST_TAB>
 __global__ void __launch_bounds__(UPD_BLOCK)
     k_build_records(const int32_t *__restrict__ order, TriRec *__restrict__ recs, int n_tris, const float *__restrict__ src_verts,
                     const int32_t *__restrict__ tris, const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off,
-                    const float *__restrict__ xform, int n_shapes) {
+                    const float *__restrict__ xform, int n_shapes, ShapeTabH tab) {
   int k = blockIdx.x * UPD_BLOCK + threadIdx.x;
   if (k >= n_tris) return;
   int prim = order[k];
   int sh = tri_shape[prim];
   sh = min(max(sh, 0), n_shapes - 1); // host validated; clamp so a bad id can never fault
-  const float *m = xform + 16 * sh;
   float mm[12];
+  int base;
+  if (HOST_TAB) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) mm[i] = m[i];
-  int base = vert_off[sh];
+    for (int i = 0; i < 12; ++i) mm[i] = tab.m[sh][i];
+    base = tab.off[sh];
+  } else {
+    const float *m = xform + 16 * sh;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) mm[i] = m[i];
+    base = vert_off[sh];
+  }
   v3 p[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -111,9 +122,10 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_refit_tail(BvhNode *nodes, const
   }
 }
 
-extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                                const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
+                             const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s, bool host_tab) {
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
+  if (host_tab && n_shapes > FFX_MAX_SHAPES_H) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_update_h: more than %d shapes", FFX_MAX_SHAPES_H);
   if (info->n_tris < 1 || info->n_nodes < 1 || info->n_levels < 1 || info->n_levels > FFX_MAX_LEVELS)
     FFX_FAIL(FFX_ERR_ARG, "scene_update: bad bvh info");
   if (info->level_start[info->n_levels] != info->n_nodes) FFX_FAIL(FFX_ERR_ARG, "scene_update: refit list does not cover every node");
@@ -124,8 +136,18 @@ extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float
   const int32_t *refit = (const int32_t *)(base + info->off_refit);
   TriRec *recs = (TriRec *)(base + info->off_recs);
 
-  hipLaunchKernelGGL(k_build_records, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
-                     tri_shape, vert_off, xform, n_shapes);
+  ShapeTabH tab;
+  if (host_tab) {
+    for (int i = 0; i < n_shapes; ++i) {
+      tab.off[i] = vert_off[i];
+      for (int j = 0; j < 12; ++j) tab.m[i][j] = xform[16 * i + j];
+    }
+    hipLaunchKernelGGL(k_build_records<true>, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
+                       tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
+  } else {
+    hipLaunchKernelGGL(k_build_records<false>, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
+                       tri_shape, vert_off, xform, n_shapes, tab);
+  }
   FFX_CHECK_LAUNCH("scene_update/build_records");
 
   int l = 0;
@@ -148,4 +170,14 @@ extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float
     FFX_CHECK_LAUNCH("scene_update/refit_tail");
   }
   return FFX_OK;
+}
+
+extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
+                                const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s, false);
+}
+
+extern "C" int ffx_scene_update_h(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
+                                  const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s, true);
 }

@@ -216,6 +216,27 @@ class Sensor:
         return self._p("to_world")
 
 
+class _PinnedRing:
+    """small host->device uploads that never block the host: a ring of pinned staging buffers,
+    each guarded by an event so a slot is only reused after its DMA has been consumed."""
+
+    def __init__(self, shape, depth=8):
+        self.bufs = [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, host_array, dst):
+        k = self.i
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.bufs[k].copy_(torch.as_tensor(host_array, dtype=torch.float32).reshape(self.bufs[k].shape))
+        dst.copy_(self.bufs[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+
 class SceneParameters:
     """dict-like parameter view with Mitsuba-style keys and `.update()` (fireflies/scene.py:94,121,
     135,249,257,384).  Assignments only record the new value; `update()` pushes everything that
@@ -289,6 +310,8 @@ class Scene:
         self._xforms = torch.eye(4).repeat(S, 1, 1)  # host
         self._offs = off.copy()
         self.albedo = torch.from_numpy(alb).to(self.device)
+        self._albedo_host = alb.copy()
+        self._albedo_ring = None
         self.shadows = shadows
         self.tex_color = (0.0, 1.0, 0.0)
         self._film_size = {}
@@ -359,6 +382,7 @@ class Scene:
 
     def _apply(self, dirty):
         geom_dirty = False
+        albedo_dirty = False
         for k in dirty:
             base, _, rest = k.partition(".")
             if rest == "__pose__":
@@ -371,11 +395,17 @@ class Scene:
                 geom_dirty = True
             elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
                 c = self._params._d[k]
-                c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3].to(self.device)
+                c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]
+                c = c.detach().cpu().numpy()
                 for i in self._material_meshes[base]:
-                    self.albedo[i] = c
+                    self._albedo_host[i] = c
+                albedo_dirty = True
         if geom_dirty:
             self.geom.update(self._xforms, self._offs)
+        if albedo_dirty:
+            if self._albedo_ring is None:
+                self._albedo_ring = _PinnedRing(tuple(self._albedo_host.shape))
+            self._albedo_ring.upload(self._albedo_host, self.albedo)
         self._sd_cache = None
 
     # ------------------------------------------------------------------ render-time blocks

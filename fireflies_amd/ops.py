@@ -220,6 +220,8 @@ class DeviceGeometry:
         self.tris = torch.from_numpy(tr).to(self.device)
         self.tri_shape = torch.from_numpy(ts).to(self.device)
         self.vert_off = torch.from_numpy(vo).to(self.device)
+        self._vert_off_host = vo.copy()
+        self._vert_off_dev_stale = False
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
 
     def _check_offsets(self, vo):
@@ -227,17 +229,34 @@ class DeviceGeometry:
             raise ValueError("vert_off + triangle index exceeds the vertex pool")
 
     def update(self, xforms, vert_off=None):
-        """K5+K6: xforms [S,4,4] (host or device tensor), optional new frame offsets [S] (host ints)."""
+        """K5+K6.  xforms [S,4,4]; optional new frame offsets [S] (host ints).
+        Host xforms (CPU tensor / ndarray) with S <= 32 go through ffx_scene_update_h: the tables
+        are kernel arguments, nothing is copied to the device and the call never blocks.  A device
+        tensor of xforms uses ffx_scene_update (device-resident randomisers)."""
         if vert_off is not None:
             vo = np.ascontiguousarray(vert_off, dtype=np.int32).reshape(-1)
             if vo.shape[0] != self.n_shapes:
                 raise ValueError("vert_off must have one entry per shape")
             self._check_offsets(vo)
-            self.vert_off = torch.from_numpy(vo).to(self.device, non_blocking=True)
-        xf = xforms if isinstance(xforms, torch.Tensor) else torch.as_tensor(np.asarray(xforms, np.float32))
-        xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
-        self._xf = xf  # keep alive until the stream has consumed it
+            self._vert_off_host = vo.copy()
+            self._vert_off_dev_stale = True
+        on_device = isinstance(xforms, torch.Tensor) and xforms.is_cuda
         with self._timed("scene_update"):
+            if not on_device and self.n_shapes <= 32:
+                xf = xforms.detach().numpy() if isinstance(xforms, torch.Tensor) else np.asarray(xforms)
+                xf = np.ascontiguousarray(xf, dtype=np.float32).reshape(self.n_shapes, 16)
+                api().call(
+                    "ffx_scene_update_h", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
+                    _dev(self.tri_shape, torch.int32), self._vert_off_host.ctypes.data_as(C.POINTER(C.c_int32)),
+                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(),
+                )
+                return
+            if self._vert_off_dev_stale:
+                self.vert_off = torch.from_numpy(self._vert_off_host).to(self.device)
+                self._vert_off_dev_stale = False
+            xf = xforms if isinstance(xforms, torch.Tensor) else torch.as_tensor(np.asarray(xforms, np.float32))
+            xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
+            self._xf = xf  # keep alive until the stream has consumed it
             api().call(
                 "ffx_scene_update", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                 _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),

@@ -22,14 +22,18 @@ class Workload:
     tex_size: tuple
 
 
-def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50, n_fold=96, tube=(64, 128), shadows=True, randomize=True):
+def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50, n_fold=96, tube=(64, 128), shadows=True, randomize=True,
+              entity_device=None):
     """configs[1]/[2] of BASELINE.json: animated vocal-fold scene (53,248 triangles at the default
     detail), `grid` x `grid` point laser, camera width x height, projector texture tex x tex.
-    Randomisation ranges are those of examples/vocalfold_scene.py:73-92."""
+    Randomisation ranges are those of examples/vocalfold_scene.py:73-92.
+    `entity_device` is the device argument of ff.Scene (where the samplers draw): the reference
+    default is the GPU; "cpu" draws from torch's CPU generator and avoids one device sync per draw."""
+    edev = device if entity_device is None else entity_device
     data = scenes.vocalfold(width=width, height=height, tex=tex, frames=frames, n_fold=n_fold, tube=tube)
     mi_scene = mi.load_scene_data(data, device=device, shadows=shadows)
     params = mi.traverse(mi_scene)
-    ff_scene = Scene(params, device=device)
+    ff_scene = Scene(params, device=edev)
     if randomize:
         larynx, fold = ff_scene.mesh("mesh-Larynx"), ff_scene.mesh("mesh-VocalFold")
         larynx.scale_x(0.8, 1.2)
@@ -40,9 +44,9 @@ def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50,
         fold.set_pool_animation(n_train, max(1, frames - n_train))  # 40 train / 10 eval, cf. main.py:84-85
         from .sampling import UniformScalarToVec3Sampler
 
-        ff_scene.light("emit-Spot").add_vec3_sampler("intensity.value", UniformScalarToVec3Sampler(1.0, 20.0, device=device))
+        ff_scene.light("emit-Spot").add_vec3_sampler("intensity.value", UniformScalarToVec3Sampler(1.0, 20.0, device=edev))
         mat = ff_scene.material("mat-Default OBJ")
-        mat.add_vec3_key("brdf_0.base_color.value", torch.tensor([0.8, 0.14, 0.34], device=device), torch.tensor([0.85, 0.5, 0.44], device=device))
+        mat.add_vec3_key("brdf_0.base_color.value", torch.tensor([0.8, 0.14, 0.34], device=edev), torch.tensor([0.85, 0.5, 0.44], device=edev))
         mat.add_float_key("brdf_0.specular", 0.0, 0.75)
     ff_scene.train()
     proj = mi_scene.sensors()[1]

@@ -163,6 +163,16 @@ int ffx_scene_update(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]
                      const int32_t *tri_shape /*[dev][n_tris]*/, const int32_t *vert_off /*[dev][n_shapes]*/,
                      const float *xform /*[dev][n_shapes,16]*/, int n_shapes, ffx_stream stream);
 
+/* Same pass with the per-shape tables given as HOST arrays (n_shapes <= FFX_MAX_SHAPES_H): they
+ * travel as kernel arguments, so a randomisation enqueues no host-to-device copy and never blocks
+ * the host.  This is what Scene.randomize() uses; the device-pointer form above serves batched,
+ * device-resident randomisers. */
+#define FFX_MAX_SHAPES_H 32
+int ffx_scene_update_h(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]*/,
+                       const float *src_verts /*[dev][*,3]*/, const int32_t *tris /*[dev][n_tris,3] shape-local*/,
+                       const int32_t *tri_shape /*[dev][n_tris]*/, const int32_t *vert_off /*[host][n_shapes]*/,
+                       const float *xform /*[host][n_shapes,16]*/, int n_shapes, ffx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * K7  primary visibility.
  * Replaces sensor.sample_ray + scene.ray_intersect in fireflies/graphics/depth.py:

@@ -598,6 +598,12 @@ int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts
   return FFX_OK;
 }
 
+int ffx_scene_update_h(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
+                       const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+  if (n_shapes > FFX_MAX_SHAPES_H) FAIL(FFX_ERR_UNSUPPORTED, "scene_update_h: more than %d shapes", FFX_MAX_SHAPES_H);
+  return ffx_scene_update(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s); /* host == device here */
+}
+
 /* =========================================================================================
  * K7  ray / triangle and traversal.  [EXT: Mitsuba scene.ray_intersect; call sites
  * graphics/depth.py:41,77,115,157]
