@@ -11,9 +11,12 @@
 // distinct 64-byte lines per wave-instruction).  A 256-thread workgroup owns ONE tile; its four
 // waves take every fourth sample, accumulate radiance in registers and combine through LDS:
 // one store per pixel, no atomics in the forward pass.  Per-lane traversal stacks live in LDS
-// (stride = workgroup size, conflict-free).  Workgroups are remapped so that the 1/8 of the
-// grid that shares an XCD (blockIdx % 8) covers a contiguous band of the image and keeps its
-// part of the BVH hot in that XCD's 4 MiB L2.
+// (stride = workgroup size, conflict-free).  That per-lane design is kept for K7 and as the A/B
+// baseline (FFX_TRAVERSAL=lane); the render kernels default to the wave-PACKET design further down
+// (scalar-cache node fetch, VGPR lane stack, single pixel x 64 samples per wavefront).
+// XCD placement: tiles are dealt to XCDs interleaved (blockIdx order).  Giving each XCD a contiguous
+// band of the image (FFX_XCD_REMAP=1) improves L2 locality but costs 30 % here: tile cost varies by
+// 10x across the image, so whole XCDs idle while the one that owns the vocal folds finishes.
 #include <stdlib.h>
 #include <string.h>
 
@@ -323,20 +326,22 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   }
 }
 
-// blockIdx -> tile with XCD-contiguous bands: workgroups b, b+8, b+16, ... share an XCD (and its
-// L2), so give them neighbouring tiles.  Pure performance: correctness never depends on it.
-__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+// blockIdx -> tile.  Workgroups b, b+8, b+16, ... share an XCD (and its L2).  mode 1 gives each XCD a
+// contiguous 1/8 band of the image (best L2 locality, but bands differ a lot in cost: the XCD that
+// owns the vocal folds finishes last while others idle); mode 0 is the identity (XCDs interleave at
+// tile granularity: balanced; the whole BVH fits every XCD's L2 anyway).  Pure performance.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks, int mode) {
+  if (mode == 0) return b;
   int per = (nblocks + 7) / 8;
-  int t = (b % 8) * per + (b / 8);
-  return t;
+  return (b % 8) * per + (b / 8);
 }
 
 __global__ void __launch_bounds__(TR_BLOCK)
     k_render_fwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
-                 const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int fp16, void *__restrict__ img) {
+                 const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img) {
   extern __shared__ int s_dyn[];
   __shared__ float s_red[3][3][64]; // waves 1..3 -> wave 0
-  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = xcd_remap(blockIdx.x, gridDim.x, remap);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
   int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
@@ -411,9 +416,9 @@ __global__ void __launch_bounds__(TR_BLOCK)
 // K9: replay the same samples, scatter d(loss)/d(img) * d(img)/d(tex) through the bilinear weights.
 __global__ void __launch_bounds__(TR_BLOCK)
     k_render_bwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
-                 uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
+                 uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
   extern __shared__ int s_dyn[];
-  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = xcd_remap(blockIdx.x, gridDim.x, remap);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
   int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
@@ -702,7 +707,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
 // PX = 1: the wave walks the 4 pixels of its tile in turn, all 64 lanes = 64 samples of ONE pixel (the
 //         tightest packet: the union of the rays' paths is practically a single ray's path);
 // PX = 2: 4 pixels x 16 sample slots at once.
-#define PK_BLOCK 64
+#define PK_BLOCK 256 // upper bound; the launch picks 64/128/256 threads = 1/2/4 independent waves per workgroup
 template <int PX>
 __device__ __forceinline__ void packet_coords(int tile, int tiles_x, int lane, int sub, int &px, int &py, int &slot) {
   const int bx = (tile % tiles_x) * 2, by = (tile / tiles_x) * 2;
@@ -713,9 +718,10 @@ __device__ __forceinline__ void packet_coords(int tile, int tiles_x, int lane, i
 template <int PX>
 __global__ void __launch_bounds__(PK_BLOCK)
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
-                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int fp16, void *__restrict__ img) {
+                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img) {
   constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // each wave of the workgroup owns its own tile; the waves never synchronise
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
   const int passes = (spp + SLOTS - 1) / SLOTS;
@@ -790,9 +796,10 @@ __global__ void __launch_bounds__(PK_BLOCK)
 template <int PX>
 __global__ void __launch_bounds__(PK_BLOCK)
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
-                    uint32_t seed_key, int tiles_x, int n_tiles, const float *__restrict__ gimg, float *__restrict__ gtex) {
+                    uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
   constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // each wave of the workgroup owns its own tile; the waves never synchronise
+  const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
   const float inv_spp = 1.0f / (float)spp;
@@ -911,6 +918,27 @@ static int packet_px() {
   return px;
 }
 
+// independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
+// A CU admits at most 16 workgroups, so single-wave workgroups cap residency at 4 waves/SIMD.
+static int packet_waves() {
+  static int w = -1;
+  if (w < 0) {
+    const char *e = getenv("FFX_PACKET_WAVES");
+    w = e ? atoi(e) : 2;
+    if (w != 1 && w != 2 && w != 4) w = 2;
+  }
+  return w;
+}
+
+static int xcd_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char *e = getenv("FFX_XCD_REMAP");
+    m = e ? atoi(e) : 0;
+  }
+  return m;
+}
+
 static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }
 
 static int check_info(const ffx_bvh_info *info, const char *what) {
@@ -969,13 +997,14 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (use_packet()) {
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
-    int pgrid = ((pn + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
+    const int wpb = packet_waves();
+    int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     if (packet_px() == 1)
-      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, img_fp16, img);
+      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+                         pn, xcd_mode(), img_fp16, img);
     else
-      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, img_fp16, img);
+      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+                         pn, xcd_mode(), img_fp16, img);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -983,7 +1012,7 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
   hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
-                     seed_key_of(seed), tiles_x, n_tiles, img_fp16, img);
+                     seed_key_of(seed), tiles_x, n_tiles, xcd_mode(), img_fp16, img);
   FFX_CHECK_LAUNCH("render_fwd");
   return FFX_OK;
 }
@@ -1000,12 +1029,13 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (use_packet()) {
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
-    int pgrid = ((pn + 7) / 8) * 8;
+    const int wpb = packet_waves();
+    int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8;
     if (packet_px() == 1)
-      hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, gimg,
+      hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg,
                          gtex);
     else
-      hipLaunchKernelGGL(k_render_bwd_pk<2>, dim3(pgrid), dim3(PK_BLOCK), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, gimg,
+      hipLaunchKernelGGL(k_render_bwd_pk<2>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg,
                          gtex);
     FFX_CHECK_LAUNCH("render_bwd");
     return FFX_OK;
@@ -1014,7 +1044,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
   hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
-                     tiles_x, n_tiles, gimg, gtex);
+                     tiles_x, n_tiles, xcd_mode(), gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd");
   return FFX_OK;
 }
