@@ -49,26 +49,29 @@ struct ShadeK {
 struct Hit { float t; int prim, shape, slot; };
 
 // ------------------------------------------------------------------------------------------ traversal
-// Ray/box slab test.  t = lo*id - o*id as ONE fma per plane (o*id is per-ray).  The fma form carries an
-// absolute error of a few ulp(o*id), so the interval is widened by `pad` = 2^-20 * max|o*id| (per
-// ray) on top of the 2-ulp relative widening: boxes may only be hit more often, never less, and the
-// triangle test decides.  NaNs (0 * inf) are dropped by v_min/v_max.
-struct RayBox { v3 id, oid; float pad; };
+// Ray/box slab test, t = (plane - o) * (1/d): exact cancellation at the origin, so no absolute pad is
+// needed; the far side is widened by 2 ulp.  A direction component of (nearly) zero is replaced by
+// +-1e-20 FOR THE BOX TEST ONLY: 1/d stays finite, planes the origin lies between give t = -/+ huge
+// (axis imposes no constraint) and planes it lies outside of give same-signed huge values (box
+// rejected).  With 1/0 = inf the products 0*inf = NaN would silently drop the axis and such rays
+// (every pixel-corner ray of the centre row / column when jitter is off) would walk the whole tree.
+struct RayBox { v3 o, id; };
+__device__ __forceinline__ float safe_rcp_dir(float d) {
+  float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+  return __builtin_amdgcn_rcpf(a);
+}
 __device__ __forceinline__ RayBox make_raybox(v3 o, v3 d) {
   RayBox r;
-  r.id = V3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-  r.oid = V3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
-  float m = fmaxf(fabsf(r.oid.x), fmaxf(fabsf(r.oid.y), fabsf(r.oid.z)));
-  r.pad = (m < 3.0e38f) ? m * 9.5367431640625e-07f : 0.f;
+  r.o = o;
+  r.id = V3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
   return r;
 }
 __device__ __forceinline__ bool slab(const float lo[3], const float hi[3], const RayBox &rb, float tmin, float tmax, float &tn_out) {
-  float ax = fmaf(lo[0], rb.id.x, -rb.oid.x), bx = fmaf(hi[0], rb.id.x, -rb.oid.x);
-  float ay = fmaf(lo[1], rb.id.y, -rb.oid.y), by = fmaf(hi[1], rb.id.y, -rb.oid.y);
-  float az = fmaf(lo[2], rb.id.z, -rb.oid.z), bz = fmaf(hi[2], rb.id.z, -rb.oid.z);
-  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)) - rb.pad;
-  float tf = fmaf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), 1.0000004f, rb.pad);
-  tn = fmaxf(tn, tmin);
+  float ax = (lo[0] - rb.o.x) * rb.id.x, bx = (hi[0] - rb.o.x) * rb.id.x;
+  float ay = (lo[1] - rb.o.y) * rb.id.y, by = (hi[1] - rb.o.y) * rb.id.y;
+  float az = (lo[2] - rb.o.z) * rb.id.z, bz = (hi[2] - rb.o.z) * rb.id.z;
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;
   tf = fminf(tf, tmax);
   tn_out = tn;
   return tn <= tf;
