@@ -503,74 +503,126 @@ __device__ __forceinline__ bool tri_test_bf(const float4 a, const float4 b, cons
   return (det > 0.f) & (U >= 0.f) & (Vv >= 0.f) & (U + Vv <= det) & (t > tmin);
 }
 
-template <bool ANY>
-__device__ __forceinline__ bool traverse_packet(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float tmin, float tmax,
-                                                bool active, Hit &h) {
-  h.t = active ? tmax : -INFINITY; // an inactive lane fails every slab test
-  h.prim = -1;
-  h.shape = -1;
-  h.slot = -1;
-  const RayBox rb = make_raybox(o, d);
+// R rays per lane: one packet walk serves 64*R rays.  Every scalar instruction, scalar load and
+// dependent round trip of a traversal step is shared by the R rays of a lane (the scalar unit, one per
+// CU, is the tightest resource of this kernel), while the per-lane VALU work is simply repeated R times
+// with independent data (more ILP per wave).
+template <bool ANY, int R>
+__device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
+                                                const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
+  RayBox rb[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    h[r].t = active[r] ? tmax[r] : -INFINITY; // an inactive ray fails every slab test
+    h[r].prim = -1;
+    h[r].shape = -1;
+    h[r].slot = -1;
+    found[r] = false;
+    rb[r] = make_raybox(o[r], d[r]);
+  }
   int stack_v = 0;
   int sp = 0;
   int cur = 0;
-  bool found = false;
   while (true) {
     cur = __builtin_amdgcn_readfirstlane(cur);
-    // ONE 64-byte scalar fetch per node (uniform address -> s_load_dwordx16), no conditional loads
+    // ONE 64-byte scalar fetch per node (uniform address -> scalar loads), no conditional loads
     const float4 *n4 = reinterpret_cast<const float4 *>(nodes + cur);
     const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
     const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
     const int c0 = ch.x, c1 = ch.y;
     const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
     const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-    float t0, t1;
-    const bool h0 = slab(lo0, hi0, rb, tmin, h.t, t0) & (c0 != FFX_EMPTY_CHILD);
-    const bool h1 = slab(lo1, hi1, rb, tmin, h.t, t1) & (c1 != FFX_EMPTY_CHILD);
+    float t0[R], t1[R];
+    bool h0[R], h1[R];
+    bool any0 = false, any1 = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      h0[r] = slab(lo0, hi0, rb[r], tmin[r], h[r].t, t0[r]) & (c0 != FFX_EMPTY_CHILD);
+      h1[r] = slab(lo1, hi1, rb[r], tmin[r], h[r].t, t1[r]) & (c1 != FFX_EMPTY_CHILD);
+      any0 |= h0[r];
+      any1 |= h1[r];
+    }
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int c = side ? c1 : c0;
-      const bool hs = side ? h1 : h0;
-      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs) != 0ull) { // wave-uniform
+      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(side ? any1 : any0) != 0ull) { // wave-uniform
         const uint32_t lc = (uint32_t)~c;
         const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
-        // fetch ALL records of the leaf before testing any (one scalar round trip per leaf, not one
-        // per triangle); slots past `count` are read but masked (the blob keeps FFX_LEAF_MAX records
-        // of tail padding for the last leaf)
-        float4 ra[FFX_LEAF_MAX], rb4[FFX_LEAF_MAX], rc[FFX_LEAF_MAX];
-#pragma unroll
-        for (int i = 0; i < FFX_LEAF_MAX; ++i) {
+        for (int i = 0; i < count; ++i) {
           const float4 *r4 = reinterpret_cast<const float4 *>(recs + first + i);
-          ra[i] = r4[0]; rb4[i] = r4[1]; rc[i] = r4[2];
-        }
+          const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
+          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
+          const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb4.x, rb4.y), e2 = V3(rb4.z, rb4.w, rc.x);
+          // Moller-Trumbore in three stages with WAVE-UNIFORM early-outs (same arithmetic and acceptance
+          // rule as tri_hit): the rays of a packet nearly always fail together at the first barycentric
+          // test, so the second cross product, two dot products and the IEEE division are skipped for
+          // the whole wave.  (U <= det is implied by V >= 0 and U + V <= det.)
+          bool p1[R], neg[R], any1 = false;
+          float detA[R], Us[R];
+          v3 tv[R];
 #pragma unroll
-        for (int i = 0; i < FFX_LEAF_MAX; ++i) {
-          if (i < count) { // wave-uniform
-            float t;
-            const bool hit = tri_test_bf(ra[i], rb4[i], rc[i], o, d, tmin, t) & hs;
-            const int prim = __float_as_int(rc[i].y), shape = __float_as_int(rc[i].z);
+          for (int r = 0; r < R; ++r) {
+            const v3 pv = vcross(d[r], e2);
+            const float det = vdot(e1, pv);
+            tv[r] = vsub(o[r], v0);
+            const float U = vdot(tv[r], pv);
+            neg[r] = det < 0.f;
+            detA[r] = neg[r] ? -det : det;
+            Us[r] = neg[r] ? -U : U;
+            p1[r] = (side ? h1[r] : h0[r]) & (detA[r] > 0.f) & (Us[r] >= 0.f) & (Us[r] <= detA[r]);
+            any1 |= p1[r];
+          }
+          if (__ballot(any1) == 0ull) continue;
+          bool p2[R], any2 = false;
+          v3 qv[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            qv[r] = vcross(tv[r], e1);
+            const float Vv = vdot(d[r], qv[r]);
+            const float Vs = neg[r] ? -Vv : Vv;
+            p2[r] = p1[r] & (Vs >= 0.f) & (Us[r] + Vs <= detA[r]);
+            any2 |= p2[r];
+          }
+          if (__ballot(any2) == 0ull) continue;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float T = vdot(e2, qv[r]);
+            const float t = (neg[r] ? -T : T) / detA[r];
+            const bool hit = p2[r] & (t > tmin[r]);
             if (ANY) {
-              const bool occ = hit & (t < tmax);
-              found = found | occ;
-              h.t = occ ? -INFINITY : h.t;
+              const bool occ = hit & (t < tmax[r]);
+              found[r] = found[r] | occ;
+              h[r].t = occ ? -INFINITY : h[r].t;
             } else {
-              const bool better = hit & (t <= tmax) & ((h.prim < 0) | (t < h.t) | ((t == h.t) & (prim < h.prim)));
-              h.t = better ? t : h.t;
-              h.prim = better ? prim : h.prim;
-              h.shape = better ? shape : h.shape;
-              h.slot = better ? first + i : h.slot;
+              const bool better = hit & (t <= tmax[r]) & ((h[r].prim < 0) | (t < h[r].t) | ((t == h[r].t) & (prim < h[r].prim)));
+              h[r].t = better ? t : h[r].t;
+              h[r].prim = better ? prim : h[r].prim;
+              h[r].shape = better ? shape : h[r].shape;
+              h[r].slot = better ? first + i : h[r].slot;
             }
           }
         }
       }
     }
-    if (ANY && __ballot(active & !found) == 0ull) break; // every ray of the packet is decided
-    const bool g0 = h0 & (c0 >= 0) & (t0 <= h.t), g1 = h1 & (c1 >= 0) & (t1 <= h.t);
+    if (ANY) {
+      bool undecided = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) undecided |= active[r] & !found[r];
+      if (__ballot(undecided) == 0ull) break; // every ray of the packet is decided
+    }
+    bool g0 = false, g1 = false, first1 = false, first0 = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool a0 = h0[r] & (c0 >= 0) & (t0[r] <= h[r].t), a1 = h1[r] & (c1 >= 0) & (t1[r] <= h[r].t);
+      g0 |= a0;
+      g1 |= a1;
+      first1 |= a1 & (!a0 | (t1[r] < t0[r]));
+      first0 |= a0 & (!a1 | (t0[r] <= t1[r]));
+    }
     const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
     if (m0 != 0ull && m1 != 0ull) {
-      // visit first the child that most rays enter first
-      const int votes1 = __popcll(__ballot(g1 & (!g0 | (t1 < t0)))), votes0 = __popcll(__ballot(g0 & (!g1 | (t0 <= t1))));
-      const bool swap = votes1 > votes0;
+      // visit first the child that most lanes enter first
+      const bool swap = __popcll(__ballot(first1)) > __popcll(__ballot(first0));
       stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
       ++sp;
       cur = swap ? c1 : c0;
@@ -584,269 +636,343 @@ __device__ __forceinline__ bool traverse_packet(const BvhNode *__restrict__ node
       cur = __builtin_amdgcn_readlane(stack_v, sp);
     }
   }
-  return ANY ? found : (h.prim >= 0);
 }
 
-// packet version of shade_sample: every lane of the wave reaches every traversal call
-__device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, bool active, v3 o,
-                                                v3 d, float nt, float ft, SampleTerms &st) {
-  Hit h;
-  st.hit = traverse_packet<false>(nodes, recs, o, d, nt, ft, active, h);
-  st.has_proj = 0;
-  st.proj_fac = 0.f;
-  st.spot[0] = st.spot[1] = st.spot[2] = 0.f;
-  st.shape = h.shape;
-  v3 P = V3(0.f, 0.f, 0.f), ng = V3(0.f, 0.f, 1.f), Po = V3(0.f, 0.f, 0.f);
-  bool ok = st.hit != 0;
-  if (ok) {
-    const float4 *r4 = reinterpret_cast<const float4 *>(recs + h.slot);
-    float4 ra = r4[0], rb = r4[1], rc = r4[2];
-    P = V3(fmaf(h.t, d.x, o.x), fmaf(h.t, d.y, o.y), fmaf(h.t, d.z, o.z));
-    ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
-    float nl = sqrtf(vdot(ng, ng));
-    ok = nl > 0.f;
-    if (ok) {
-      ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
-      if (vdot(ng, d) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
-      float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
-      float off = (1.0f + pmax) * RAY_EPS;
-      Po = V3(fmaf(off, ng.x, P.x), fmaf(off, ng.y, P.y), fmaf(off, ng.z, P.z));
+// per-sample shading state between the three packet walks
+struct ShadePre {
+  bool ok, need_p, need_s;
+  v3 P, ng, Po;
+  float pfac, u, v, sfac;
+  v3 ws_p, ws_s;
+  float ds_p, ds_s;
+};
+
+// packet version of shade_sample for R samples per lane: every lane of the wave reaches every walk
+template <int R>
+__device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const bool (&active)[R],
+                                                const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
+  Hit h[R];
+  bool fnd[R];
+  traverse_packet<false, R>(nodes, recs, o, d, nt, ft, active, h, fnd);
+  ShadePre pre[R];
+  bool any_p = false, any_s = false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    ShadePre &q = pre[r];
+    st[r].hit = h[r].prim >= 0;
+    st[r].has_proj = 0;
+    st[r].proj_fac = 0.f;
+    st[r].spot[0] = st[r].spot[1] = st[r].spot[2] = 0.f;
+    st[r].shape = h[r].shape;
+    q.P = V3(0.f, 0.f, 0.f);
+    q.ng = V3(0.f, 0.f, 1.f);
+    q.Po = V3(0.f, 0.f, 0.f);
+    q.ok = st[r].hit != 0;
+    if (q.ok) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
+      float4 ra = r4[0], rb = r4[1], rc = r4[2];
+      q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
+      v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
+      float nl = sqrtf(vdot(ng, ng));
+      q.ok = nl > 0.f;
+      if (q.ok) {
+        ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+        if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
+        q.ng = ng;
+        float pmax = fmaxf(fabsf(q.P.x), fmaxf(fabsf(q.P.y), fabsf(q.P.z)));
+        float off = (1.0f + pmax) * RAY_EPS;
+        q.Po = V3(fmaf(off, ng.x, q.P.x), fmaf(off, ng.y, q.P.y), fmaf(off, ng.z, q.P.z));
+      }
     }
-  }
-  // ---- projector
-  bool need_p = false;
-  float pfac = 0.f, u = 0.f, v = 0.f;
-  v3 ws = V3(0.f, 0.f, 1.f);
-  float ds = 1.f;
-  if (c.proj_on && ok) {
-    v3 pl = xf_point(c.p_w2l, P);
-    if (pl.z > 0.f) {
-      const float *m = c.p_c2s;
-      float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
-      float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
-      float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
-      u = qx / qw;
-      v = qy / qw;
-      if (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f) {
-        v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
-        v3 wi = vsub(ppos, P);
-        float d2 = vdot(wi, wi);
-        float dist = sqrtf(d2);
-        wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
-        float cos_s = vdot(ng, wi);
-        float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
-        if (cos_s > 0.f && cos_p > 0.f) {
-          need_p = true;
-          pfac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
-          ws = vsub(ppos, Po);
-          ds = sqrtf(vdot(ws, ws));
-          ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+    // ---- projector terms
+    q.need_p = false;
+    q.pfac = 0.f; q.u = 0.f; q.v = 0.f;
+    q.ws_p = V3(0.f, 0.f, 1.f);
+    q.ds_p = 1.f;
+    if (c.proj_on && q.ok) {
+      v3 pl = xf_point(c.p_w2l, q.P);
+      if (pl.z > 0.f) {
+        const float *m = c.p_c2s;
+        float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
+        float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
+        float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
+        q.u = qx / qw;
+        q.v = qy / qw;
+        if (q.u >= 0.f && q.u <= 1.f && q.v >= 0.f && q.v <= 1.f) {
+          v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
+          v3 wi = vsub(ppos, q.P);
+          float d2 = vdot(wi, wi);
+          float dist = sqrtf(d2);
+          wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+          float cos_s = vdot(q.ng, wi);
+          float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
+          if (cos_s > 0.f && cos_p > 0.f) {
+            q.need_p = true;
+            q.pfac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+            v3 ws = vsub(ppos, q.Po);
+            q.ds_p = sqrtf(vdot(ws, ws));
+            q.ws_p = V3(ws.x / q.ds_p, ws.y / q.ds_p, ws.z / q.ds_p);
+          }
         }
       }
     }
-  }
-  bool occ_p = false;
-  if (c.shadows && __ballot(need_p) != 0ull) {
-    Hit hs;
-    occ_p = traverse_packet<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), need_p, hs);
-  }
-  if (need_p && !occ_p) {
-    st.proj_fac = pfac;
-    float fx = fmaf(u, (float)c.tw, -0.5f), fy = fmaf(v, (float)c.th, -0.5f);
-    float x0 = floorf(fx), y0 = floorf(fy);
-    float ax = fx - x0, ay = fy - y0;
-    int ix0 = (int)x0, iy0 = (int)y0;
-    st.ix0 = clampi(ix0, 0, c.tw - 1);
-    st.ix1 = clampi(ix0 + 1, 0, c.tw - 1);
-    st.iy0 = clampi(iy0, 0, c.th - 1);
-    st.iy1 = clampi(iy0 + 1, 0, c.th - 1);
-    st.wx0 = 1.0f - ax; st.wx1 = ax;
-    st.wy0 = 1.0f - ay; st.wy1 = ay;
-    st.has_proj = 1;
-  }
-  // ---- spot
-  bool need_s = false;
-  float sfac = 0.f;
-  if (c.spot_on && ok) {
-    v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
-    v3 wi = vsub(spos, P);
-    float d2 = vdot(wi, wi);
-    float dist = sqrtf(d2);
-    wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
-    float cos_s = vdot(ng, wi);
-    if (cos_s > 0.f) {
-      v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
-      float ln = sqrtf(vdot(ll, ll));
-      float cos_t = ll.z / ln;
-      float fall = 0.f;
-      if (cos_t >= c.cos_beam) fall = 1.f;
-      else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
-      if (fall > 0.f) {
-        need_s = true;
-        sfac = fall * cos_s / d2 * 0.3183098861837907f;
-        ws = vsub(spos, Po);
-        ds = sqrtf(vdot(ws, ws));
-        ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+    // ---- spot terms
+    q.need_s = false;
+    q.sfac = 0.f;
+    q.ws_s = V3(0.f, 0.f, 1.f);
+    q.ds_s = 1.f;
+    if (c.spot_on && q.ok) {
+      v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
+      v3 wi = vsub(spos, q.P);
+      float d2 = vdot(wi, wi);
+      float dist = sqrtf(d2);
+      wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+      float cos_s = vdot(q.ng, wi);
+      if (cos_s > 0.f) {
+        v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
+        float ln = sqrtf(vdot(ll, ll));
+        float cos_t = ll.z / ln;
+        float fall = 0.f;
+        if (cos_t >= c.cos_beam) fall = 1.f;
+        else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
+        if (fall > 0.f) {
+          q.need_s = true;
+          q.sfac = fall * cos_s / d2 * 0.3183098861837907f;
+          v3 ws = vsub(spos, q.Po);
+          q.ds_s = sqrtf(vdot(ws, ws));
+          q.ws_s = V3(ws.x / q.ds_s, ws.y / q.ds_s, ws.z / q.ds_s);
+        }
       }
     }
+    any_p |= q.need_p;
+    any_s |= q.need_s;
   }
-  bool occ_s = false;
-  if (c.shadows && __ballot(need_s) != 0ull) {
-    Hit hs;
-    occ_s = traverse_packet<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), need_s, hs);
+  // ---- shadow walks (wave-uniform decisions)
+  bool occ_p[R], occ_s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) occ_p[r] = occ_s[r] = false;
+  if (c.shadows && __ballot(any_p) != 0ull) {
+    v3 so[R], sdir[R];
+    float s0[R], s1[R];
+    bool act[R];
+    Hit hs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_p; s0[r] = 0.f; s1[r] = pre[r].ds_p * (1.0f - SHADOW_EPS); act[r] = pre[r].need_p; }
+    traverse_packet<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_p);
   }
-  if (need_s && !occ_s) {
-    st.spot[0] = c.s_int[0] * sfac;
-    st.spot[1] = c.s_int[1] * sfac;
-    st.spot[2] = c.s_int[2] * sfac;
+  if (c.shadows && __ballot(any_s) != 0ull) {
+    v3 so[R], sdir[R];
+    float s0[R], s1[R];
+    bool act[R];
+    Hit hs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_s; s0[r] = 0.f; s1[r] = pre[r].ds_s * (1.0f - SHADOW_EPS); act[r] = pre[r].need_s; }
+    traverse_packet<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_s);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const ShadePre &q = pre[r];
+    if (q.need_p && !occ_p[r]) {
+      st[r].proj_fac = q.pfac;
+      float fx = fmaf(q.u, (float)c.tw, -0.5f), fy = fmaf(q.v, (float)c.th, -0.5f);
+      float x0 = floorf(fx), y0 = floorf(fy);
+      float ax = fx - x0, ay = fy - y0;
+      int ix0 = (int)x0, iy0 = (int)y0;
+      st[r].ix0 = clampi(ix0, 0, c.tw - 1);
+      st[r].ix1 = clampi(ix0 + 1, 0, c.tw - 1);
+      st[r].iy0 = clampi(iy0, 0, c.th - 1);
+      st[r].iy1 = clampi(iy0 + 1, 0, c.th - 1);
+      st[r].wx0 = 1.0f - ax; st[r].wx1 = ax;
+      st[r].wy0 = 1.0f - ay; st[r].wy1 = ay;
+      st[r].has_proj = 1;
+    }
+    if (q.need_s && !occ_s[r]) {
+      st[r].spot[0] = c.s_int[0] * q.sfac;
+      st[r].spot[1] = c.s_int[1] * q.sfac;
+      st[r].spot[2] = c.s_int[2] * q.sfac;
+    }
   }
 }
 
-// packet lane mapping inside an 8x8 tile: wave = 4x4-pixel quadrant, lane = (pixel 0..15, slot 0..3)
-// Packet kernels: ONE wavefront per workgroup, one 2x2-pixel tile per wavefront (65,536 work items at
-// 512x512).  Tile costs vary by an order of magnitude (rays along the tube vs. rays that leave it), so
-// fine-grained single-wave workgroups let the hardware dispatcher keep every SIMD full to the end; with
-// 4-wave workgroups over 8x8 tiles the measured average residency was 3 of 7 waves per SIMD.
-// PX = 1: the wave walks the 4 pixels of its tile in turn, all 64 lanes = 64 samples of ONE pixel (the
-//         tightest packet: the union of the rays' paths is practically a single ray's path);
-// PX = 2: 4 pixels x 16 sample slots at once.
+// Packet kernels.  A wavefront owns one 2x2-pixel tile (65,536 work items at 512x512): tile costs vary
+// by an order of magnitude (rays along the tube vs. rays that leave it), so fine-grained, independent
+// waves let the hardware dispatcher keep every SIMD busy to the end.  The 64 lanes are the 64 samples
+// of a pixel; every lane carries R rays = the same sample index of R horizontally adjacent pixels
+// (R = 2: the tile is walked as two pixel pairs; R = 1: as four single pixels).  All 64*R rays of a
+// packet are within a two-pixel frustum, so the union of their paths is practically one ray's path.
 #define PK_BLOCK 256 // upper bound; the launch picks 64/128/256 threads = 1/2/4 independent waves per workgroup
-template <int PX>
-__device__ __forceinline__ void packet_coords(int tile, int tiles_x, int lane, int sub, int &px, int &py, int &slot) {
-  const int bx = (tile % tiles_x) * 2, by = (tile / tiles_x) * 2;
-  if (PX == 2) { px = bx + (lane & 1); py = by + ((lane >> 1) & 1); slot = lane >> 2; }
-  else { px = bx + (sub & 1); py = by + (sub >> 1); slot = lane; }
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
 }
 
-template <int PX>
+template <int R>
+__device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, int (&px)[R], int (&py)[R]) {
+  const int bx = (tile % tiles_x) * 2, by = (tile / tiles_x) * 2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (R == 2) { px[r] = bx + r; py[r] = by + sub; }
+    else { px[r] = bx + (sub & 1); py[r] = by + (sub >> 1); }
+  }
+}
+
+template <int R>
 __global__ void __launch_bounds__(PK_BLOCK)
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
                     const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img) {
-  constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
+  constexpr int NSUB = 4 / R;
   // each wave of the workgroup owns its own tile; the waves never synchronise
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
-  const int passes = (spp + SLOTS - 1) / SLOTS;
+  const int passes = (spp + 63) >> 6;
+  const float inv_spp = 1.0f / (float)spp;
   for (int sub = 0; sub < NSUB; ++sub) {
-    int px, py, slot;
-    packet_coords<PX>(tile, tiles_x, lane, sub, px, py, slot);
-    const bool live = tile < n_tiles && px < W && py < H;
-    if (__ballot(live) == 0ull) continue;
-    const uint32_t pix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    for (int pass = 0; pass < passes; ++pass) {
-      const int s = pass * SLOTS + slot;
-      const bool active = live && s < spp;
-      uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
-      float jx, jy;
-      sample_jitter(seed_key, idx, jx, jy);
-      v3 o, d;
-      float nt, ft;
-      cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
-      SampleTerms st;
-      shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
-      if (!st.hit) continue;
-      float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
-      if (st.has_proj) {
-        const int tc = c.tc;
-        size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
-        size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
-        if (tc == 1) {
-          float tv = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
-          r0 += tv * c.p_color[0] * st.proj_fac;
-          r1 += tv * c.p_color[1] * st.proj_fac;
-          r2 += tv * c.p_color[2] * st.proj_fac;
-        } else {
-          float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
-          float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
-          float tv2 = st.wy0 * (st.wx0 * tex[o00 + 2] + st.wx1 * tex[o01 + 2]) + st.wy1 * (st.wx0 * tex[o10 + 2] + st.wx1 * tex[o11 + 2]);
-          r0 += tv0 * 1.0f * st.proj_fac;
-          r1 += tv1 * 1.0f * st.proj_fac;
-          r2 += tv2 * 1.0f * st.proj_fac;
-        }
-      }
-      const float *alb = albedo + 3 * st.shape;
-      acc0 += alb[0] * r0;
-      acc1 += alb[1] * r1;
-      acc2 += alb[2] * r2;
-    }
-    // combine the sample slots of a pixel (lanes l, l+NPIX, ...) in a fixed order: deterministic
+    int px[R], py[R];
+    packet_pixels<R>(tile, tiles_x, sub, px, py);
+    bool live[R], any_live = false;
+    uint32_t pix[R];
+    float acc[R][3];
 #pragma unroll
-    for (int off = 32; off >= NPIX; off >>= 1) {
-      acc0 += __shfl_down(acc0, off, 64);
-      acc1 += __shfl_down(acc1, off, 64);
-      acc2 += __shfl_down(acc2, off, 64);
+    for (int r = 0; r < R; ++r) {
+      live[r] = tile < n_tiles && px[r] < W && py[r] < H;
+      any_live |= live[r];
+      pix[r] = (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r];
+      acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
     }
-    if (lane < NPIX && live) {
-      float inv_spp = 1.0f / (float)spp;
-      size_t o = ((size_t)py * W + px) * 3;
-      if (fp16) {
-        _Float16 *p = (_Float16 *)img;
-        p[o] = (_Float16)(acc0 * inv_spp);
-        p[o + 1] = (_Float16)(acc1 * inv_spp);
-        p[o + 2] = (_Float16)(acc2 * inv_spp);
-      } else {
-        float *p = (float *)img;
-        p[o] = acc0 * inv_spp;
-        p[o + 1] = acc1 * inv_spp;
-        p[o + 2] = acc2 * inv_spp;
+    if (__ballot(any_live) == 0ull) continue;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int s = pass * 64 + lane;
+      bool active[R];
+      v3 o[R], d[R];
+      float nt[R], ft[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        active[r] = live[r] && s < spp;
+        uint32_t idx = pix[r] * (uint32_t)spp + (uint32_t)s;
+        float jx, jy;
+        sample_jitter(seed_key, idx, jx, jy);
+        cam_ray(c.cam, ((float)px[r] + jx) * c.cam.inv_w, ((float)py[r] + jy) * c.cam.inv_h, o[r], d[r], nt[r], ft[r]);
+      }
+      SampleTerms st[R];
+      shade_sample_pk<R>(c, nodes, recs, active, o, d, nt, ft, st);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!st[r].hit) continue;
+        float r0 = st[r].spot[0], r1 = st[r].spot[1], r2 = st[r].spot[2];
+        if (st[r].has_proj) {
+          const int tc = c.tc;
+          size_t o00 = ((size_t)st[r].iy0 * c.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * c.tw + st[r].ix1) * tc;
+          size_t o10 = ((size_t)st[r].iy1 * c.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * c.tw + st[r].ix1) * tc;
+          const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1, pf = st[r].proj_fac;
+          if (tc == 1) {
+            float tv = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
+            r0 += tv * c.p_color[0] * pf;
+            r1 += tv * c.p_color[1] * pf;
+            r2 += tv * c.p_color[2] * pf;
+          } else {
+            float tv0 = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
+            float tv1 = wy0 * (wx0 * tex[o00 + 1] + wx1 * tex[o01 + 1]) + wy1 * (wx0 * tex[o10 + 1] + wx1 * tex[o11 + 1]);
+            float tv2 = wy0 * (wx0 * tex[o00 + 2] + wx1 * tex[o01 + 2]) + wy1 * (wx0 * tex[o10 + 2] + wx1 * tex[o11 + 2]);
+            r0 += tv0 * 1.0f * pf;
+            r1 += tv1 * 1.0f * pf;
+            r2 += tv2 * 1.0f * pf;
+          }
+        }
+        const float *alb = albedo + 3 * st[r].shape;
+        acc[r][0] += alb[0] * r0;
+        acc[r][1] += alb[1] * r1;
+        acc[r][2] += alb[2] * r2;
+      }
+    }
+    // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a0 = wave_sum64(acc[r][0]), a1 = wave_sum64(acc[r][1]), a2 = wave_sum64(acc[r][2]);
+      if (lane == 0 && live[r]) {
+        size_t o = (size_t)pix[r] * 3;
+        if (fp16) {
+          _Float16 *p = (_Float16 *)img;
+          p[o] = (_Float16)(a0 * inv_spp);
+          p[o + 1] = (_Float16)(a1 * inv_spp);
+          p[o + 2] = (_Float16)(a2 * inv_spp);
+        } else {
+          float *p = (float *)img;
+          p[o] = a0 * inv_spp;
+          p[o + 1] = a1 * inv_spp;
+          p[o + 2] = a2 * inv_spp;
+        }
       }
     }
   }
 }
 
-template <int PX>
+template <int R>
 __global__ void __launch_bounds__(PK_BLOCK)
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
                     uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
-  constexpr int NPIX = PX * PX, SLOTS = 64 / NPIX, NSUB = 4 / NPIX;
-  // each wave of the workgroup owns its own tile; the waves never synchronise
+  constexpr int NSUB = 4 / R;
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H;
   const float inv_spp = 1.0f / (float)spp;
   const int tc = c.tc;
-  const int passes = (spp + SLOTS - 1) / SLOTS;
+  const int passes = (spp + 63) >> 6;
   for (int sub = 0; sub < NSUB; ++sub) {
-    int px, py, slot;
-    packet_coords<PX>(tile, tiles_x, lane, sub, px, py, slot);
-    bool live = tile < n_tiles && px < W && py < H;
-    const uint32_t pix = live ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (live) { g0 = gimg[(size_t)pix * 3]; g1 = gimg[(size_t)pix * 3 + 1]; g2 = gimg[(size_t)pix * 3 + 2]; }
-    live = live && !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
-    if (__ballot(live) == 0ull) continue; // wave-uniform
-    for (int pass = 0; pass < passes; ++pass) {
-      const int s = pass * SLOTS + slot;
-      const bool active = live && s < spp;
-      uint32_t idx = pix * (uint32_t)spp + (uint32_t)s;
-      float jx, jy;
-      sample_jitter(seed_key, idx, jx, jy);
-      v3 o, d;
-      float nt, ft;
-      cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
-      SampleTerms st;
-      shade_sample_pk(c, nodes, recs, active, o, d, nt, ft, st);
-      if (!st.hit || !st.has_proj) continue;
-      const float *alb = albedo + 3 * st.shape;
-      size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
-      size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
-      if (tc == 1) {
-        float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
-        atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
-        atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
-        atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
-        atomicAdd(gtex + o11, ws * st.wy1 * st.wx1);
-      } else {
-        const float gg[3] = {g0, g1, g2};
+    int px[R], py[R];
+    packet_pixels<R>(tile, tiles_x, sub, px, py);
+    bool live[R], any_live = false;
+    uint32_t pix[R];
+    float g[R][3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
-          atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
-          atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
-          atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
-          atomicAdd(gtex + o11 + ch, ws * st.wy1 * st.wx1);
+    for (int r = 0; r < R; ++r) {
+      live[r] = tile < n_tiles && px[r] < W && py[r] < H;
+      pix[r] = live[r] ? (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r] : 0u;
+      g[r][0] = g[r][1] = g[r][2] = 0.f;
+      if (live[r]) { g[r][0] = gimg[(size_t)pix[r] * 3]; g[r][1] = gimg[(size_t)pix[r] * 3 + 1]; g[r][2] = gimg[(size_t)pix[r] * 3 + 2]; }
+      live[r] = live[r] && !(g[r][0] == 0.f && g[r][1] == 0.f && g[r][2] == 0.f);
+      any_live |= live[r];
+    }
+    if (__ballot(any_live) == 0ull) continue; // wave-uniform
+    for (int pass = 0; pass < passes; ++pass) {
+      const int s = pass * 64 + lane;
+      bool active[R];
+      v3 o[R], d[R];
+      float nt[R], ft[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        active[r] = live[r] && s < spp;
+        uint32_t idx = pix[r] * (uint32_t)spp + (uint32_t)s;
+        float jx, jy;
+        sample_jitter(seed_key, idx, jx, jy);
+        cam_ray(c.cam, ((float)px[r] + jx) * c.cam.inv_w, ((float)py[r] + jy) * c.cam.inv_h, o[r], d[r], nt[r], ft[r]);
+      }
+      SampleTerms st[R];
+      shade_sample_pk<R>(c, nodes, recs, active, o, d, nt, ft, st);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!st[r].hit || !st[r].has_proj) continue;
+        const float *alb = albedo + 3 * st[r].shape;
+        size_t o00 = ((size_t)st[r].iy0 * c.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * c.tw + st[r].ix1) * tc;
+        size_t o10 = ((size_t)st[r].iy1 * c.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * c.tw + st[r].ix1) * tc;
+        const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1;
+        if (tc == 1) {
+          float ws = (g[r][0] * alb[0] * c.p_color[0] + g[r][1] * alb[1] * c.p_color[1] + g[r][2] * alb[2] * c.p_color[2]) * st[r].proj_fac * inv_spp;
+          atomicAdd(gtex + o00, ws * wy0 * wx0);
+          atomicAdd(gtex + o01, ws * wy0 * wx1);
+          atomicAdd(gtex + o10, ws * wy1 * wx0);
+          atomicAdd(gtex + o11, ws * wy1 * wx1);
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            float ws = g[r][ch] * alb[ch] * st[r].proj_fac * inv_spp;
+            atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
+            atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
+            atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
+            atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
+          }
         }
       }
     }
@@ -910,15 +1036,15 @@ static int use_packet() {
   return mode;
 }
 
-// packet shape: FFX_PACKET = 1 (1 pixel x 64 sample lanes, default) or 2 (2x2 pixels x 16 sample slots)
-static int packet_px() {
-  static int px = -1;
-  if (px < 0) {
-    const char *e = getenv("FFX_PACKET");
-    px = e ? atoi(e) : 1;
-    if (px != 1 && px != 2) px = 1;
+// rays per lane of the packet kernels: FFX_RAYS = 1 or 2 (default)
+static int packet_rays() {
+  static int r = -1;
+  if (r < 0) {
+    const char *e = getenv("FFX_RAYS");
+    r = e ? atoi(e) : 2;
+    if (r != 1 && r != 2) r = 2;
   }
-  return px;
+  return r;
 }
 
 // independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
@@ -1002,7 +1128,7 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
-    if (packet_px() == 1)
+    if (packet_rays() == 1)
       hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
                          pn, xcd_mode(), img_fp16, img);
     else
@@ -1034,7 +1160,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8;
-    if (packet_px() == 1)
+    if (packet_rays() == 1)
       hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg,
                          gtex);
     else
