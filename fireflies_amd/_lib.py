@@ -12,7 +12,8 @@ from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libffx_hip.so")
+# FFX_LIB lets an experiment load an alternative BUILD of the same HIP library (never another backend)
+LIB_PATH = os.environ.get("FFX_LIB", os.path.join(CSRC, "libffx_hip.so"))
 
 _api = None
 

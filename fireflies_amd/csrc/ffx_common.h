@@ -61,7 +61,9 @@ struct __attribute__((aligned(16))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "node must be 64 bytes");
 #define FFX_EMPTY_CHILD ((int32_t)0x80000000)
+#ifndef FFX_LEAF_MAX
 #define FFX_LEAF_MAX 4
+#endif
 
 // 48-byte triangle record in leaf order, written by ffx_scene_update
 struct __attribute__((aligned(16))) TriRec {

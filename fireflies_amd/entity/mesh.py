@@ -23,13 +23,9 @@ def load_obj_vertices(path: str) -> torch.Tensor:
     """All `v x y z` records of a Wavefront OBJ file, in file order ([V,3] float32).
     Stands in for pywavefront.Wavefront(...).vertices (mesh.py:173-179; pywavefront is not a
     dependency here)."""
-    out = []
-    with open(path, "r") as f:
-        for line in f:
-            if line.startswith("v "):
-                p = line.split()
-                out.append((float(p[1]), float(p[2]), float(p[3])))
-    return torch.tensor(out, dtype=torch.float32).reshape(-1, 3)
+    from ..loaders import load_obj
+
+    return torch.from_numpy(load_obj(path)[0])
 
 
 class Mesh(base.Transformable):

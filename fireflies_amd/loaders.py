@@ -1,0 +1,210 @@
+"""Scene-file readers (host side): a subset of the Mitsuba-3 XML format and Wavefront OBJ.
+
+SURVEY §8(f) f4: the reference loads its scenes with `mi.load_file("…/vocalfold.xml")`
+(examples/vocalfold_scene.py:20-22) and its animation frames with pywavefront
+(fireflies/entity/mesh.py:167-181).  Neither Mitsuba nor pywavefront is a dependency here; this
+module reads what those scene files contain so that `mi.load_file(path)` keeps working:
+
+  <sensor type="perspective">   fov, near_clip, far_clip, <transform name="to_world">, <film> width/height
+  <shape type="obj"|"ply">       filename (OBJ only; PLY raises), optional to_world (baked into the vertices),
+                                 nested or referenced <bsdf> (diffuse reflectance / principled base_color)
+  <emitter type="spot">          intensity, cutoff_angle, beam_width, to_world
+  <emitter type="projector">     irradiance texture (id "tex"), scale, fov, to_world
+  <transform>                    <matrix value="16 floats">, <lookat origin target up>, <translate>, <scale>,
+                                 <rotate x|y|z angle>  (applied in document order, like Mitsuba)
+  <default name value>, $name substitution, <integer|float|string|rgb|boolean name value>
+
+Anything else is ignored with a warning; nothing here touches the GPU.
+"""
+import os
+import re
+import warnings
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from . import scenes
+
+
+# ----------------------------------------------------------------------------- OBJ
+def load_obj(path):
+    """-> (vertices [V,3] float32, triangles [F,3] int32).  Faces with more than three corners are
+    fan-triangulated; `v/vt/vn` corner syntax and negative (relative) indices are handled."""
+    verts, tris = [], []
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    tris.append((idx[0], idx[k], idx[k + 1]))
+    v = np.asarray(verts, np.float32).reshape(-1, 3)
+    t = np.asarray(tris, np.int32).reshape(-1, 3)
+    if t.size and (t.min() < 0 or t.max() >= v.shape[0]):
+        raise ValueError(f"{path}: face index out of range")
+    return v, t
+
+
+def save_obj(path, verts, tris):
+    with open(path, "w") as f:
+        for v in np.asarray(verts):
+            f.write(f"v {v[0]:.9g} {v[1]:.9g} {v[2]:.9g}\n")
+        for t in np.asarray(tris):
+            f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+
+
+def load_obj_sequence(directory):
+    """all *.obj of a directory in sorted order -> frames [T,V,3] (same topology assumed) and the
+    triangles of the first file (fireflies/entity/mesh.py:167-181)."""
+    files = sorted(f for f in os.listdir(directory) if f.endswith(".obj"))
+    if not files:
+        raise FileNotFoundError(f"no .obj files in {directory}")
+    frames, tris = [], None
+    for f in files:
+        v, t = load_obj(os.path.join(directory, f))
+        if tris is None:
+            tris = t
+        elif v.shape != frames[0].shape:
+            raise ValueError(f"{f}: vertex count differs from the first frame")
+        frames.append(v)
+    return np.stack(frames), tris
+
+
+# ----------------------------------------------------------------------------- XML helpers
+def _floats(s):
+    return [float(x) for x in re.split(r"[,\s]+", s.strip()) if x]
+
+
+def _rot(axis, deg):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    c, s = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    m = np.eye(4)
+    m[:3, :3] = np.eye(3) * c + s * K + (1 - c) * np.outer(a, a)
+    return m
+
+
+def _transform(node):
+    m = np.eye(4)
+    if node is None:
+        return m.astype(np.float32)
+    for op in node:
+        if op.tag == "matrix":
+            t = np.asarray(_floats(op.get("value")), np.float64).reshape(4, 4)
+        elif op.tag == "lookat":
+            t = scenes.look_at(_floats(op.get("origin")), _floats(op.get("target")), _floats(op.get("up", "0,1,0"))).astype(np.float64)
+        elif op.tag == "translate":
+            t = np.eye(4)
+            t[:3, 3] = _floats(op.get("value")) if op.get("value") else [float(op.get(k, 0)) for k in "xyz"]
+        elif op.tag == "scale":
+            v = _floats(op.get("value")) if op.get("value") else [float(op.get(k, 1)) for k in "xyz"]
+            v = v * 3 if len(v) == 1 else v
+            t = np.diag([v[0], v[1], v[2], 1.0])
+        elif op.tag == "rotate":
+            axis = _floats(op.get("value")) if op.get("value") else [float(op.get(k, 0)) for k in "xyz"]
+            t = _rot(axis, float(op.get("angle")))
+        else:
+            warnings.warn(f"transform op <{op.tag}> ignored")
+            continue
+        m = t @ m  # later operations are applied after earlier ones
+    return m.astype(np.float32)
+
+
+def _props(node):
+    out = {}
+    for c in node:
+        if c.tag in ("float", "integer", "string", "boolean") and c.get("name"):
+            v = c.get("value")
+            out[c.get("name")] = float(v) if c.tag == "float" else int(v) if c.tag == "integer" else (v == "true") if c.tag == "boolean" else v
+        elif c.tag in ("rgb", "spectrum") and c.get("name"):
+            v = _floats(c.get("value"))
+            out[c.get("name")] = tuple(v * 3 if len(v) == 1 else v[:3])
+    return out
+
+
+def _child(node, tag, name=None):
+    for c in node:
+        if c.tag == tag and (name is None or c.get("name") == name):
+            return c
+    return None
+
+
+def _albedo_of(bsdf, bsdfs):
+    if bsdf is None:
+        return (0.5, 0.5, 0.5), "mat-Default"
+    if bsdf.tag == "ref":
+        ref = bsdfs.get(bsdf.get("id"))
+        if ref is None:
+            raise ValueError(f"unknown bsdf reference {bsdf.get('id')}")
+        return _albedo_of(ref, bsdfs)[0], bsdf.get("id")
+    inner = bsdf
+    while inner.get("type") in ("twosided", "bumpmap", "normalmap", "mask") and _child(inner, "bsdf") is not None:
+        inner = _child(inner, "bsdf")
+    p = _props(inner)
+    col = p.get("reflectance", p.get("base_color", p.get("diffuse_reflectance", (0.5, 0.5, 0.5))))
+    if inner.get("type") not in ("diffuse", "principled"):
+        warnings.warn(f"bsdf type {inner.get('type')!r} is rendered as Lambert with its base colour (DESIGN.md §4.3)")
+    return tuple(col), bsdf.get("id") or "mat-Default"
+
+
+def load_mitsuba_xml(path):
+    """-> scenes.SceneData.  Sensor 0 is the camera; a second perspective sensor, if present, is the
+    projector proxy whose film size is the projector texture size (examples/vocalfold_scene.py:24-38)."""
+    text = open(path, "r").read()
+    defaults = dict(re.findall(r'<default\s+name="([^"]+)"\s+value="([^"]*)"', text))
+    for k, v in defaults.items():
+        text = text.replace("$" + k, v)
+    root = ET.fromstring(text)
+    base = os.path.dirname(os.path.abspath(path))
+    bsdfs = {b.get("id"): b for b in root.iter("bsdf") if b.get("id")}
+    sensors, meshes, spot, projector, proj_scale = [], [], None, None, 1.0
+    for node in root:
+        if node.tag == "sensor":
+            if node.get("type") != "perspective":
+                warnings.warn(f"sensor type {node.get('type')!r} ignored")
+                continue
+            p = _props(node)
+            film = _child(node, "film")
+            fp = _props(film) if film is not None else {}
+            name = node.get("id") or ("PerspectiveCamera" if not sensors else f"PerspectiveCamera_{len(sensors)}")
+            sensors.append(scenes.SensorData(name, _transform(_child(node, "transform", "to_world")), float(p.get("fov", 45.0)), float(p.get("near_clip", 0.01)),
+                                             float(p.get("far_clip", 1e4)), int(fp.get("width", 768)), int(fp.get("height", 576))))
+        elif node.tag == "shape":
+            if node.get("type") != "obj":
+                raise NotImplementedError(f"shape type {node.get('type')!r}: only OBJ meshes are read")
+            p = _props(node)
+            v, t = load_obj(os.path.join(base, p["filename"]))
+            M = _transform(_child(node, "transform", "to_world"))
+            v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+            alb, mat = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
+            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat))
+        elif node.tag == "emitter":
+            p = _props(node)
+            tw = _transform(_child(node, "transform", "to_world"))
+            if node.get("type") == "spot":
+                inten = p.get("intensity", (1.0, 1.0, 1.0))
+                inten = (inten,) * 3 if isinstance(inten, float) else inten
+                cutoff = float(p.get("cutoff_angle", 20.0))
+                spot = scenes.SpotData(node.get("id") or "emit-Spot", tw, tuple(inten), cutoff, float(p.get("beam_width", cutoff * 0.75)))
+            elif node.get("type") == "projector":
+                projector = (tw, float(p.get("fov", 45.0)))
+                proj_scale = float(p.get("scale", 1.0))
+            else:
+                warnings.warn(f"emitter type {node.get('type')!r} ignored")
+    if not sensors:
+        raise ValueError(f"{path}: no perspective sensor")
+    if not meshes:
+        raise ValueError(f"{path}: no shapes")
+    proj = None
+    if projector is not None:
+        proxy = sensors[1] if len(sensors) > 1 else None
+        w, h = (proxy.width, proxy.height) if proxy is not None else (500, 500)
+        proj = scenes.SensorData(proxy.name if proxy is not None else "PerspectiveCamera_1", projector[0], proxy.fov_x if proxy is not None else projector[1],
+                                 proxy.near if proxy is not None else 0.01, proxy.far if proxy is not None else 1e4, w, h)
+    return scenes.SceneData(meshes, sensors[0], proj, spot, proj_scale, notes={"source": path})

@@ -448,6 +448,14 @@ def load_scene_data(data: scenes.SceneData, device="cuda", shadows=True) -> Scen
     return Scene(data, device=device, shadows=shadows)
 
 
+def load_file(path, device="cuda", shadows=True, **_ignored) -> Scene:
+    """mi.load_file(path[, parallel=False]) (examples/vocalfold_scene.py:22, main.py:29): reads the
+    Mitsuba-XML subset and OBJ meshes described in fireflies_amd/loaders.py."""
+    from . import loaders
+
+    return Scene(loaders.load_mitsuba_xml(path), device=device, shadows=shadows)
+
+
 def traverse(scene: Scene) -> SceneParameters:
     return scene._params
 
