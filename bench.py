@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-steps", action="store_true")
     ap.add_argument("--no-shadows", action="store_true")
+    ap.add_argument("--workload", default="vocalfold", choices=["vocalfold", "colon"],
+                    help="vocalfold = BASELINE configs[1]/[2] (the metric's configuration); colon = configs[4] "
+                         "(use --res 1024 --spp 256 --grid 32 --fp16)")
+    ap.add_argument("--fp16", action="store_true", help="fp16 radiance buffer (config 5)")
     ap.add_argument("--entity-device", default="cpu", help="device argument of ff.Scene (where the samplers draw): cpu (no sync per draw) or cuda (the reference default)")
     args = ap.parse_args()
 
@@ -147,7 +151,8 @@ def main():
     W = H = args.res
 
     # ------------------------------------------------------------------ renders/sec
-    wl = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows, entity_device=args.entity_device)
+    make = workloads.vocalfold if args.workload == "vocalfold" else workloads.colon
+    wl = make(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows, entity_device=args.entity_device)
     with torch.no_grad():
         tex = workloads.build_texture(wl).contiguous()
     wl.params["tex.data"] = tex
@@ -159,7 +164,7 @@ def main():
         torch.manual_seed(seed)
         random.seed(seed)
         wl.ff_scene.randomize()
-        return mi.render(wl.mi_scene, spp=args.spp, seed=seed)
+        return mi.render(wl.mi_scene, spp=args.spp, seed=seed, fp16=args.fp16)
 
     events = []
 
@@ -173,12 +178,12 @@ def main():
     renders_per_sec = world * args.steps / t_render
     k8_ms, k8_n = _kernel_ms(events, "render_fwd")
     upd_ms, _ = _kernel_ms(events, "scene_update")
-    bytes_ = algorithmic_bytes(wl, W, H)
+    bytes_ = algorithmic_bytes(wl, W, H, fp16=args.fp16)
 
     # ------------------------------------------------------------------ pattern-gradient steps/sec
     grad = {}
     if not args.no_grad_steps:
-        wg = workloads.vocalfold(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device)
+        wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device)
         opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=world, base_seed=7)
         gevents = []
 
@@ -217,11 +222,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not args.fp16 else "f32 (f16 film)",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2] (renders): procedural animated vocal-fold scene, {bytes_['F']} triangles, {args.grid**2}-point projector, "
-                        f"{W}x{H}, {args.spp} spp, shadows {'on' if not args.no_shadows else 'off'}; configs[1] (grad steps): same scene, {args.grad_grid**2}-point pattern",
+            "workload": (f"BASELINE configs[2] (renders): procedural animated vocal-fold scene, {bytes_['F']} triangles, {args.grid**2}-point projector, "
+                         f"{W}x{H}, {args.spp} spp, shadows {'on' if not args.no_shadows else 'off'}; configs[1] (grad steps): same scene, {args.grad_grid**2}-point pattern")
+            if args.workload == "vocalfold" else
+            (f"BASELINE configs[4]: procedural colon scene, {bytes_['F']} triangles, {args.grid**2}-point projector, {W}x{H}, {args.spp} spp, "
+             f"{'fp16' if args.fp16 else 'fp32'} radiance buffer"),
             "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render [K8]; texture built once before the loop",
             "entity_device": args.entity_device,
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,

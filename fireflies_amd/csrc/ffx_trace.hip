@@ -1027,45 +1027,30 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
 }
 
 // FFX_TRAVERSAL=lane selects the per-lane (LDS stack) kernels; default: wave-packet kernels
+// (the knobs are read at every launch: cheap, and lets one process exercise every variant)
 static int use_packet() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char *e = getenv("FFX_TRAVERSAL");
-    mode = (e && strcmp(e, "lane") == 0) ? 0 : 1;
-  }
-  return mode;
+  const char *e = getenv("FFX_TRAVERSAL");
+  return (e && strcmp(e, "lane") == 0) ? 0 : 1;
 }
 
 // rays per lane of the packet kernels: FFX_RAYS = 1 or 2 (default)
 static int packet_rays() {
-  static int r = -1;
-  if (r < 0) {
-    const char *e = getenv("FFX_RAYS");
-    r = e ? atoi(e) : 2;
-    if (r != 1 && r != 2) r = 2;
-  }
-  return r;
+  const char *e = getenv("FFX_RAYS");
+  int r = e ? atoi(e) : 2;
+  return (r == 1 || r == 2) ? r : 2;
 }
 
 // independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
 // A CU admits at most 16 workgroups, so single-wave workgroups cap residency at 4 waves/SIMD.
 static int packet_waves() {
-  static int w = -1;
-  if (w < 0) {
-    const char *e = getenv("FFX_PACKET_WAVES");
-    w = e ? atoi(e) : 2;
-    if (w != 1 && w != 2 && w != 4) w = 2;
-  }
-  return w;
+  const char *e = getenv("FFX_PACKET_WAVES");
+  int w = e ? atoi(e) : 2;
+  return (w == 1 || w == 2 || w == 4) ? w : 2;
 }
 
 static int xcd_mode() {
-  static int m = -1;
-  if (m < 0) {
-    const char *e = getenv("FFX_XCD_REMAP");
-    m = e ? atoi(e) : 0;
-  }
-  return m;
+  const char *e = getenv("FFX_XCD_REMAP");
+  return e ? (atoi(e) != 0) : 0;
 }
 
 static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }

@@ -1,0 +1,98 @@
+"""Image post-processing of the dataset path — same classes as
+fireflies/postprocessing/*: a probability-gated chain of blur / silhouette / noise.
+
+The reference runs these on the HOST with numpy, kornia and cv2 on images that were copied back
+from the GPU (main.py:138-160).  Here an image that is a HIP tensor stays on the device (the blur
+is the K3 kernel); a numpy image is accepted too and a numpy image is returned, like the reference.
+The python-`random` draws happen in the same order (gate, then the function's own draws).
+"""
+import random
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def _to_device(image):
+    if isinstance(image, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).cuda(), True
+    return image.float().contiguous(), False
+
+
+def _back(t, was_numpy):
+    return t.cpu().numpy() if was_numpy else t
+
+
+class BasePostProcessingFunction:
+    def __init__(self, probability: float):
+        self._probability = probability
+
+    def apply(self, image):
+        """base.py:10-14: applied with probability `probability` (one random.uniform draw)."""
+        if random.uniform(0, 1) < self._probability:
+            return self.post_process(image)
+        return image
+
+    def post_process(self, image):
+        raise NotImplementedError
+
+
+class PostProcessor:
+    def __init__(self, post_process_funcs):
+        self._post_process_functs = post_process_funcs
+
+    def post_process(self, image):
+        out = image.copy() if isinstance(image, np.ndarray) else image.clone()
+        for func in self._post_process_functs:
+            out = func.apply(out)
+        return out
+
+
+class GaussianBlur(BasePostProcessingFunction):
+    """gauss_blur.py:7-28: kornia.filters.gaussian_blur2d(image, kernel_size, sigma) on a [H,W] image."""
+
+    def __init__(self, kernel_size, sigma, probability: float):
+        super().__init__(probability)
+        if kernel_size[0] != kernel_size[1] or sigma[0] != sigma[1]:
+            raise NotImplementedError("only square kernels (all call sites of the reference use them)")
+        self._kernel_size, self._sigma = kernel_size, sigma
+
+    def post_process(self, image):
+        t, was_np = _to_device(image)
+        return _back(ops.blur_fwd(t, int(self._kernel_size[0]), float(self._sigma[0])), was_np)
+
+
+class WhiteNoise(BasePostProcessingFunction):
+    """white_noise.py:5-20: image + N(mean, std), clipped to [0,1] (device RNG here, numpy's there)."""
+
+    def __init__(self, mean: float, std: float, probability: float):
+        super().__init__(probability)
+        self._mean, self._std = mean, std
+
+    def post_process(self, image):
+        t, was_np = _to_device(image)
+        noise = torch.randn_like(t) * self._std + self._mean
+        return _back(torch.clamp(t + noise, 0, 1), was_np)
+
+
+class ApplySilhouette(BasePostProcessingFunction):
+    """apply_silhouette.py:10-40: multiply by a blurred filled circle (endoscope vignette); centre and
+    radius drawn with random.randint in the reference's order (cc_x, cc_y, radius)."""
+
+    def __init__(self, probability: float = 2.0):
+        super().__init__(probability)
+
+    def post_process(self, image):
+        t, was_np = _to_device(image)
+        cc_x = random.randint(100, 200)
+        cc_y = random.randint(200, 300)
+        radius = random.randint(170, 230)
+        h, w = t.shape[-2], t.shape[-1]
+        yy, xx = torch.meshgrid(torch.arange(h, device=t.device), torch.arange(w, device=t.device), indexing="ij")
+        mask = (((xx - cc_x) ** 2 + (yy - cc_y) ** 2) <= radius * radius).float().contiguous()
+        mask = ops.blur_fwd(mask, 11, 5.0)
+        return _back(t * mask, was_np)
+
+
+__all__ = ["BasePostProcessingFunction", "PostProcessor", "GaussianBlur", "WhiteNoise", "ApplySilhouette"]

@@ -57,6 +57,30 @@ def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50,
     return Workload(data, mi_scene, params, ff_scene, laser, K, 10.0, (tex, tex))
 
 
+def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=True, randomize=True, entity_device=None):
+    """configs[4] of BASELINE.json: colon-endoscopy scene (524,288 triangles), 1024x1024, 1024-point
+    pattern (32 x 32), texture 1024^2; render with spp = 256 and fp16=True for the full configuration."""
+    edev = device if entity_device is None else entity_device
+    data = scenes.colon(width=width, height=height, tex=tex)
+    mi_scene = mi.load_scene_data(data, device=device, shadows=shadows)
+    params = mi.traverse(mi_scene)
+    ff_scene = Scene(params, device=edev)
+    if randomize:
+        mesh = ff_scene.mesh("mesh-Colon")
+        mesh.scale_x(0.9, 1.1)
+        mesh.rotate_z(-0.05, 0.05)
+        from .sampling import UniformScalarToVec3Sampler
+
+        ff_scene.light("emit-Spot").add_vec3_sampler("intensity.value", UniformScalarToVec3Sampler(2.0, 10.0, device=edev))
+    ff_scene.train()
+    proj = mi_scene.sensors()[1]
+    x_fov, near, far = params[proj.id() + ".x_fov"], params[proj.id() + ".near_clip"], params[proj.id() + ".far_clip"]
+    K = mi.perspective_projection(proj.film().size(), proj.film().crop_size(), proj.film().crop_offset(), x_fov, near, far).matrix.torch()[0]
+    rays = Laser.generate_uniform_rays(0.0275 * 18 / grid * 1.8, grid, grid, device=device)
+    laser = Laser(ff_scene._projector, rays, K, x_fov, near, far, device=device)
+    return Workload(data, mi_scene, params, ff_scene, laser, K, 10.0, (tex, tex))
+
+
 def build_texture(wl: Workload, reduce="sum", blur=True):
     """the laser texture as in examples/vocalfold_scene.py:56-67, kept 1-channel (green weight
     lives in the scene description) and on the device."""

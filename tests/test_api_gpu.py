@@ -317,3 +317,29 @@ def test_cfg5_colon_half_million_triangles_fp16(oracle):
     lhs = float(((f32 - base).double() * g.double()).sum())
     rhs = float((tex_big.double() * gtex.double()).sum())
     assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs))
+
+
+def test_postprocessing_chain_on_device(oracle):
+    """dataset path: same classes / gating / draw order as fireflies/postprocessing/*."""
+    import fireflies_amd.postprocessing as pp
+
+    img = torch.rand(512, 512, device=DEV)
+    blur = pp.GaussianBlur((3, 3), (5, 5), 2.0)
+    np.testing.assert_array_equal(blur.apply(img).cpu().numpy(), oracle.blur_fwd(img.cpu().numpy(), 3, 5.0))
+    assert torch.equal(pp.GaussianBlur((3, 3), (5, 5), -1.0).apply(img), img)  # gate closed
+    random.seed(5)
+    sil = pp.ApplySilhouette().apply(img)
+    random.seed(5)
+    random.uniform(0, 1)
+    cx, cy, r = random.randint(100, 200), random.randint(200, 300), random.randint(170, 230)
+    assert float(sil[cy, cx]) == pytest.approx(float(img[cy, cx]), rel=1e-5)  # inside the circle
+    far = (cx + r + 40 < 512) and float(sil[cy, min(cx + r + 40, 511)]) or 0.0
+    assert far == 0.0
+    torch.manual_seed(0)
+    noisy = pp.WhiteNoise(0.0, 0.05, 2.0).apply(img)
+    assert 0.03 < float((noisy - img).std()) < 0.06 and float(noisy.min()) >= 0 and float(noisy.max()) <= 1
+    chain = pp.PostProcessor([pp.GaussianBlur((3, 3), (5, 5), 0.5), pp.ApplySilhouette(), pp.WhiteNoise(0.0, 0.05, 0.5)])
+    out = chain.post_process(img)
+    assert out.shape == img.shape and out.is_cuda and torch.isfinite(out).all()
+    out_np = chain.post_process(img.cpu().numpy())  # numpy in -> numpy out, like the reference
+    assert isinstance(out_np, np.ndarray) and out_np.shape == (512, 512)

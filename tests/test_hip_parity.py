@@ -398,3 +398,32 @@ def test_k7_axis_parallel_rays_are_not_pathological():
     d = dev(np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]], np.float32))
     t, s, p = gd.trace_rays(o, d)
     assert int(s[1]) >= 0 and float(t[1]) > 0  # the off-axis ray hits a fold
+
+
+@pytest.mark.parametrize("env", [{"FFX_TRAVERSAL": "lane"}, {"FFX_RAYS": "1"}, {"FFX_RAYS": "2"}, {"FFX_RAYS": "1", "FFX_XCD_REMAP": "1", "FFX_PACKET_WAVES": "4"},
+                                 {"FFX_RAYS": "2", "FFX_PACKET_WAVES": "1"}])
+def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
+    """the per-lane kernels, the wave-packet kernels with 1 and 2 rays per lane, and the launch-shape
+    knobs all compute the same image and the same texture gradient (odd film size, spp not a multiple
+    of 64, both shadow settings)."""
+    for k in ("FFX_TRAVERSAL", "FFX_RAYS", "FFX_XCD_REMAP", "FFX_PACKET_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = scenes.vocalfold(width=45, height=37, tex=64, frames=3, n_fold=20, tube=(20, 24))
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 8))
+    tex = _tex(sc, 1)
+    rng = np.random.default_rng(2)
+    gimg = rng.standard_normal((37, 45, 3)).astype(np.float32)
+    for shadows, spp in ((True, 5), (False, 70)):
+        sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=shadows)
+        img_d = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=21))
+        img_o = go.render_fwd(sd, alb, host(tex), spp, seed=21)
+        scale = float(img_o.max())
+        err = np.abs(img_d - img_o)
+        assert scale > 0.02 and (err > 1e-4 * scale).mean() <= 1e-3 and err.max() <= 0.25 * scale, env
+        gt_d = host(gd.render_bwd(sd, dev(alb), spp, 21, dev(gimg)))
+        gt_o = go.render_bwd(sd, alb, spp, 21, gimg)
+        gs = float(np.abs(gt_o).max())
+        gerr = np.abs(gt_d - gt_o)
+        assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs, env
