@@ -1048,6 +1048,13 @@ static int packet_waves() {
   return (w == 1 || w == 2 || w == 4) ? w : 2;
 }
 
+// experiment knob: dynamic LDS bytes per workgroup of the packet kernels (unused by the kernel; it only
+// lowers occupancy so that latency- and throughput-bound behaviour can be told apart)
+static size_t dummy_lds() {
+  const char *e = getenv("FFX_DUMMY_LDS");
+  return e ? (size_t)atol(e) : 0;
+}
+
 static int xcd_mode() {
   const char *e = getenv("FFX_XCD_REMAP");
   return e ? (atoi(e) != 0) : 0;
@@ -1114,10 +1121,10 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     if (packet_rays() == 1)
-      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
                          pn, xcd_mode(), img_fp16, img);
     else
-      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
+      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
                          pn, xcd_mode(), img_fp16, img);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
