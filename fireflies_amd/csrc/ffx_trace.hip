@@ -638,6 +638,165 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
   }
 }
 
+// ------------------------------------------------------------------------------------------ packed fp32, 2 rays per lane
+// On MI355X a plain v_fma_f32 issues at ~4 cycles per wave64 instruction; only PACKED fp32
+// (v_pk_add/mul/fma_f32) reaches the vector peak (profiles/r1_valu_issue_rates.txt), and this kernel is
+// VALU-issue bound.  With two rays per lane every subtract / multiply / fma of the slab and triangle
+// tests is ONE packed instruction on the pair (ray0, ray1); the uniform node plane or triangle
+// component sits in an SGPR and is broadcast to both halves through op_sel (no splat moves).
+// Each element is computed exactly like the scalar code (same operations, same order, IEEE fp32).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct v3p { f2 x, y, z; };
+__device__ __forceinline__ f2 splat2(float s) { return (f2){s, s}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 diffprod2(f2 a, f2 b, f2 c, f2 d) { return fma2(a, b, -(c * d)); }
+__device__ __forceinline__ f2 vdot2(const v3p &a, const v3p &b) { return fma2(a.x, b.x, fma2(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ v3p vcross2(const v3p &a, const v3p &b) {
+  v3p r;
+  r.x = diffprod2(a.y, b.z, a.z, b.y);
+  r.y = diffprod2(a.z, b.x, a.x, b.z);
+  r.z = diffprod2(a.x, b.y, a.y, b.x);
+  return r;
+}
+__device__ __forceinline__ v3p pack3(v3 a, v3 b) { v3p r; r.x = (f2){a.x, b.x}; r.y = (f2){a.y, b.y}; r.z = (f2){a.z, b.z}; return r; }
+__device__ __forceinline__ v3p splat3(v3 a) { v3p r; r.x = splat2(a.x); r.y = splat2(a.y); r.z = splat2(a.z); return r; }
+
+// slab test of one (uniform) box against the two rays of the lane; same formula as slab()
+__device__ __forceinline__ void slab2(const float lo[3], const float hi[3], const v3p &o, const v3p &id, f2 tmin, f2 tmax, f2 &tn, bool &hit0, bool &hit1) {
+  const f2 ax = (splat2(lo[0]) - o.x) * id.x, bx = (splat2(hi[0]) - o.x) * id.x;
+  const f2 ay = (splat2(lo[1]) - o.y) * id.y, by = (splat2(hi[1]) - o.y) * id.y;
+  const f2 az = (splat2(lo[2]) - o.z) * id.z, bz = (splat2(hi[2]) - o.z) * id.z;
+  f2 tf;
+  tn.x = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), tmin.x));
+  tn.y = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), tmin.y));
+  tf.x = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
+  tf.y = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+  tf = tf * splat2(1.0000004f);
+  tf.x = fminf(tf.x, tmax.x);
+  tf.y = fminf(tf.y, tmax.y);
+  hit0 = tn.x <= tf.x;
+  hit1 = tn.y <= tf.y;
+}
+
+template <bool ANY>
+__device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o_)[2], const v3 (&d_)[2],
+                                                 const float (&tmin_)[2], const float (&tmax_)[2], const bool (&active)[2], Hit (&h)[2], bool (&found)[2]) {
+  const v3p o = pack3(o_[0], o_[1]), d = pack3(d_[0], d_[1]);
+  v3p id;
+  id.x = (f2){safe_rcp_dir(d_[0].x), safe_rcp_dir(d_[1].x)};
+  id.y = (f2){safe_rcp_dir(d_[0].y), safe_rcp_dir(d_[1].y)};
+  id.z = (f2){safe_rcp_dir(d_[0].z), safe_rcp_dir(d_[1].z)};
+  const f2 tmin = {tmin_[0], tmin_[1]};
+  f2 ht = {active[0] ? tmax_[0] : -INFINITY, active[1] ? tmax_[1] : -INFINITY}; // an inactive ray fails every slab test
+#pragma unroll
+  for (int r = 0; r < 2; ++r) { h[r].prim = -1; h[r].shape = -1; h[r].slot = -1; found[r] = false; }
+  int stack_v = 0;
+  int sp = 0;
+  int cur = 0;
+  while (true) {
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    const float4 *n4 = reinterpret_cast<const float4 *>(nodes + cur);
+    const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
+    const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
+    const int c0 = ch.x, c1 = ch.y;
+    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    f2 t0, t1;
+    bool h0[2], h1[2];
+    slab2(lo0, hi0, o, id, tmin, ht, t0, h0[0], h0[1]);
+    slab2(lo1, hi1, o, id, tmin, ht, t1, h1[0], h1[1]);
+    const bool v0 = c0 != FFX_EMPTY_CHILD, v1 = c1 != FFX_EMPTY_CHILD;
+    h0[0] &= v0; h0[1] &= v0; h1[0] &= v1; h1[1] &= v1;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int c = side ? c1 : c0;
+      const bool hs0 = side ? h1[0] : h0[0], hs1 = side ? h1[1] : h0[1];
+      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs0 | hs1) != 0ull) { // wave-uniform
+        const uint32_t lc = (uint32_t)~c;
+        const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
+        for (int i = 0; i < count; ++i) {
+          const float4 *r4 = reinterpret_cast<const float4 *>(recs + first + i);
+          const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
+          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
+          const v3p v0p = splat3(V3(ra.x, ra.y, ra.z)), e1 = splat3(V3(ra.w, rb4.x, rb4.y)), e2 = splat3(V3(rb4.z, rb4.w, rc.x));
+          // stage 1 (packed): pv = d x e2, det = e1 . pv, tv = o - v0, U = tv . pv
+          const v3p pv = vcross2(d, e2);
+          const f2 det = vdot2(e1, pv);
+          v3p tv;
+          tv.x = o.x - v0p.x; tv.y = o.y - v0p.y; tv.z = o.z - v0p.z;
+          const f2 U = vdot2(tv, pv);
+          const bool n0 = det.x < 0.f, n1 = det.y < 0.f;
+          const f2 detA = {n0 ? -det.x : det.x, n1 ? -det.y : det.y};
+          const f2 Us = {n0 ? -U.x : U.x, n1 ? -U.y : U.y};
+          const bool p10 = hs0 & (detA.x > 0.f) & (Us.x >= 0.f) & (Us.x <= detA.x);
+          const bool p11 = hs1 & (detA.y > 0.f) & (Us.y >= 0.f) & (Us.y <= detA.y);
+          if (__ballot(p10 | p11) == 0ull) continue;
+          // stage 2 (packed): qv = tv x e1, V = d . qv
+          const v3p qv = vcross2(tv, e1);
+          const f2 Vv = vdot2(d, qv);
+          const f2 Vs = {n0 ? -Vv.x : Vv.x, n1 ? -Vv.y : Vv.y};
+          const f2 UV = Us + Vs;
+          const bool p20 = p10 & (Vs.x >= 0.f) & (UV.x <= detA.x);
+          const bool p21 = p11 & (Vs.y >= 0.f) & (UV.y <= detA.y);
+          if (__ballot(p20 | p21) == 0ull) continue;
+          // stage 3: T = e2 . qv, t = T / det (IEEE division, per element)
+          const f2 T = vdot2(e2, qv);
+          const float tt[2] = {(n0 ? -T.x : T.x) / detA.x, (n1 ? -T.y : T.y) / detA.y};
+          const bool p2[2] = {p20, p21};
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const float t = tt[r];
+            const float cur_t = r ? ht.y : ht.x;
+            const bool hit = p2[r] & (t > tmin_[r]);
+            bool upd;
+            if (ANY) {
+              upd = hit & (t < tmax_[r]);
+              found[r] = found[r] | upd;
+            } else {
+              upd = hit & (t <= tmax_[r]) & ((h[r].prim < 0) | (t < cur_t) | ((t == cur_t) & (prim < h[r].prim)));
+              h[r].prim = upd ? prim : h[r].prim;
+              h[r].shape = upd ? shape : h[r].shape;
+              h[r].slot = upd ? first + i : h[r].slot;
+            }
+            const float nt = ANY ? -INFINITY : t;
+            if (r) ht.y = upd ? nt : ht.y; else ht.x = upd ? nt : ht.x;
+          }
+        }
+      }
+    }
+    if (ANY && __ballot((active[0] & !found[0]) | (active[1] & !found[1])) == 0ull) break; // every ray is decided
+    const bool a00 = h0[0] & (c0 >= 0) & (t0.x <= ht.x), a01 = h0[1] & (c0 >= 0) & (t0.y <= ht.y);
+    const bool a10 = h1[0] & (c1 >= 0) & (t1.x <= ht.x), a11 = h1[1] & (c1 >= 0) & (t1.y <= ht.y);
+    const unsigned long long m0 = __ballot(a00 | a01), m1 = __ballot(a10 | a11);
+    if (m0 != 0ull && m1 != 0ull) {
+      const bool first1 = (a10 & (!a00 | (t1.x < t0.x))) | (a11 & (!a01 | (t1.y < t0.y)));
+      const bool first0 = (a00 & (!a10 | (t0.x <= t1.x))) | (a01 & (!a11 | (t0.y <= t1.y)));
+      const bool swap = __popcll(__ballot(first1)) > __popcll(__ballot(first0));
+      stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
+      ++sp;
+      cur = swap ? c1 : c0;
+    } else if (m0 != 0ull) {
+      cur = c0;
+    } else if (m1 != 0ull) {
+      cur = c1;
+    } else {
+      if (sp == 0) break;
+      --sp;
+      cur = __builtin_amdgcn_readlane(stack_v, sp);
+    }
+  }
+  h[0].t = ht.x;
+  h[1].t = ht.y;
+}
+
+// dispatch: the packed implementation for 2 rays per lane, the generic one otherwise
+template <bool ANY, int R>
+__device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
+                                                    const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
+  if constexpr (R == 2) traverse_packet2<ANY>(nodes, recs, o, d, tmin, tmax, active, h, found);
+  else traverse_packet<ANY, R>(nodes, recs, o, d, tmin, tmax, active, h, found);
+}
+
 // per-sample shading state between the three packet walks
 struct ShadePre {
   bool ok, need_p, need_s;
@@ -653,7 +812,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
                                                 const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
   Hit h[R];
   bool fnd[R];
-  traverse_packet<false, R>(nodes, recs, o, d, nt, ft, active, h, fnd);
+  traverse_packet_any<false, R>(nodes, recs, o, d, nt, ft, active, h, fnd);
   ShadePre pre[R];
   bool any_p = false, any_s = false;
 #pragma unroll
@@ -758,7 +917,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_p; s0[r] = 0.f; s1[r] = pre[r].ds_p * (1.0f - SHADOW_EPS); act[r] = pre[r].need_p; }
-    traverse_packet<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_p);
+    traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_p);
   }
   if (c.shadows && __ballot(any_s) != 0ull) {
     v3 so[R], sdir[R];
@@ -767,7 +926,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_s; s0[r] = 0.f; s1[r] = pre[r].ds_s * (1.0f - SHADOW_EPS); act[r] = pre[r].need_s; }
-    traverse_packet<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_s);
+    traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_s);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1033,11 +1192,12 @@ static int use_packet() {
   return (e && strcmp(e, "lane") == 0) ? 0 : 1;
 }
 
-// rays per lane of the packet kernels: FFX_RAYS = 1 or 2 (default)
+// rays per lane of the packet kernels: FFX_RAYS = 1 (default) or 2 (packed-fp32 variant; measured
+// 2.14 ms vs 1.93 ms for K8: hipcc needs s_mov/s_nop sequences around SGPR-operand packed ops)
 static int packet_rays() {
   const char *e = getenv("FFX_RAYS");
-  int r = e ? atoi(e) : 2;
-  return (r == 1 || r == 2) ? r : 2;
+  int r = e ? atoi(e) : 1;
+  return (r == 1 || r == 2) ? r : 1;
 }
 
 // independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
