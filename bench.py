@@ -194,17 +194,23 @@ def main():
         t_grad = _bracket(grad_step, args.steps, args.warmup, dev)
         wg.mi_scene.geom.timing = None
         torch.cuda.synchronize()
-        k9_ms, _ = _kernel_ms(gevents, "render_bwd")
+        k9_ms, _ = _kernel_ms(gevents, "render_bwd")  # re-tracing adjoint (only above FFX_CACHE_LIMIT_GB)
+        k9c_ms, _ = _kernel_ms(gevents, "render_bwd_cached")
         k8g_ms, _ = _kernel_ms(gevents, "render_fwd")
         bg = algorithmic_bytes(wg, W, H)
+        # streaming adjoint: reads the 16-byte record of every sample + d(loss)/d(img), writes gtex once
+        bytes_k9c = 16 * W * H * args.spp + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
         grad = {
             "grad_steps_per_sec": args.steps / t_grad,
             "grad_samples_per_sec": world * args.steps / t_grad,
             "grad_ms_per_step": 1e3 * t_grad / args.steps,
             "grad_config": {"points": args.grad_grid**2, "samples_per_step": world, "samples_per_rank": 1},
-            "grad_kernels_ms": {"render_fwd": k8g_ms, "render_bwd": k9_ms},
-            "render_bwd_roofline": None if k9_ms is None else {"bound": "hbm", "achieved": bg["render_bwd"] / (k9_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                                               "unit": "GB/s", "frac": bg["render_bwd"] / (k9_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+            "grad_kernels_ms": {"render_fwd(+cache write)": k8g_ms, "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
+            "render_bwd_cached_roofline": None if k9c_ms is None else {
+                "kernel": "k_render_bwd_cached (streams the per-sample records written by K8)", "bound": "hbm",
+                "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
+                "traffic": (pmc_traffic("k_render_bwd_cached") or {}).get("bytes")},
         }
 
     if rank != 0:

@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
 // ------------------------------------------------------------------------------------------ shading
 struct SampleTerms {
   int hit, shape, has_proj;
+  int ubx, uby; // unclamped bilinear base texel (for the per-sample cache)
   int ix0, ix1, iy0, iy1;
   float wx0, wx1, wy0, wy1;
   float proj_fac;
@@ -283,6 +284,7 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
             float x0 = floorf(fx), y0 = floorf(fy);
             float ax = fx - x0, ay = fy - y0;
             int ix0 = (int)x0, iy0 = (int)y0;
+            st.ubx = ix0; st.uby = iy0;
             st.ix0 = clampi(ix0, 0, c.tw - 1);
             st.ix1 = clampi(ix0 + 1, 0, c.tw - 1);
             st.iy0 = clampi(iy0, 0, c.th - 1);
@@ -937,6 +939,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
       float x0 = floorf(fx), y0 = floorf(fy);
       float ax = fx - x0, ay = fy - y0;
       int ix0 = (int)x0, iy0 = (int)y0;
+      st[r].ubx = ix0; st[r].uby = iy0;
       st[r].ix0 = clampi(ix0, 0, c.tw - 1);
       st[r].ix1 = clampi(ix0 + 1, 0, c.tw - 1);
       st[r].iy0 = clampi(iy0, 0, c.th - 1);
@@ -980,7 +983,8 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, in
 template <int R>
 __global__ void __launch_bounds__(PK_BLOCK)
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
-                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img) {
+                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img,
+                    uint4 *__restrict__ cache) {
   constexpr int NSUB = 4 / R;
   // each wave of the workgroup owns its own tile; the waves never synchronise
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1017,6 +1021,18 @@ __global__ void __launch_bounds__(PK_BLOCK)
       }
       SampleTerms st[R];
       shade_sample_pk<R>(c, nodes, recs, active, o, d, nt, ft, st);
+      if (cache) {
+        // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!active[r]) continue;
+          uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+          if (st[r].hit && st[r].has_proj)
+            rec = make_uint4((uint32_t)(st[r].ubx + 1) | ((uint32_t)(st[r].uby + 1) << 12) | ((uint32_t)st[r].shape << 24), __float_as_uint(st[r].wx1),
+                             __float_as_uint(st[r].wy1), __float_as_uint(st[r].proj_fac));
+          cache[(size_t)pix[r] * (size_t)spp + (size_t)s] = rec;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit) continue;
@@ -1133,6 +1149,100 @@ __global__ void __launch_bounds__(PK_BLOCK)
             atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
           }
         }
+      }
+    }
+  }
+}
+
+// K9 from the per-sample cache: a pure streaming kernel.  Each lane reads one 16-byte record (1 KiB per
+// wave-instruction, coalesced) and rebuilds the 4 bilinear taps.  The 64 lanes of a wave are 64
+// consecutive samples — at spp >= 64 all of ONE pixel — so their taps fall on a handful of texels:
+// issuing them as global float atomics serialises on the same addresses (measured 0.65 ms, 5 % of the
+// HBM rate).  Instead every wave accumulates into a private 16x16-texel LDS tile placed at the wave's
+// tap bounding box (ds_add_f32), then flushes ONE global atomic per touched texel.  Waves whose taps
+// span more than 16x16 texels (low spp, grazing projections) fall back to direct atomics.
+struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; };
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+    k_render_bwd_cached(const uint4 *__restrict__ cache, long total, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
+                        float *__restrict__ gtex) {
+  __shared__ float s_tile[4][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float *tile = s_tile[wave];
+  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) { // wave-uniform trip count
+    const long idx = base + threadIdx.x;
+    bool active = idx < total;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (active) rec = cache[idx];
+    const float fac = __uint_as_float(rec.w);
+    active = active && fac != 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (active) {
+      const long pix = idx / p.spp;
+      g0 = gimg[pix * 3]; g1 = gimg[pix * 3 + 1]; g2 = gimg[pix * 3 + 2];
+      active = !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
+    }
+    if (__ballot(active) == 0ull) continue;
+    const int ix0 = (int)(rec.x & 0xfffu) - 1, iy0 = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
+    const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
+    const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
+    const float wx0 = 1.0f - ax, wx1 = ax, wy0 = 1.0f - ay, wy1 = ay;
+    if (p.tc == 1) {
+      float ws = 0.f;
+      if (active) {
+        const float *alb = albedo + 3 * shape;
+        ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * fac * p.inv_spp;
+      }
+      const int minx = wave_min_i(active ? x0 : 0x7fffffff), maxx = wave_max_i(active ? x1 : -1);
+      const int miny = wave_min_i(active ? y0 : 0x7fffffff), maxy = wave_max_i(active ? y1 : -1);
+      const int bw = maxx - minx + 1, bh = maxy - miny + 1;
+      if (bw <= 16 && bh <= 16) { // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[lane + 64 * k] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+          atomicAdd(&tile[(y0 - miny) * 16 + (x0 - minx)], ws * wy0 * wx0);
+          atomicAdd(&tile[(y0 - miny) * 16 + (x1 - minx)], ws * wy0 * wx1);
+          atomicAdd(&tile[(y1 - miny) * 16 + (x0 - minx)], ws * wy1 * wx0);
+          atomicAdd(&tile[(y1 - miny) * 16 + (x1 - minx)], ws * wy1 * wx1);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = lane + 64 * k, ty = e >> 4, tx = e & 15;
+          const float v = tile[e];
+          if (v != 0.f && tx < bw && ty < bh) atomicAdd(gtex + (size_t)(miny + ty) * p.tw + (minx + tx), v);
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else if (active) {
+        atomicAdd(gtex + (size_t)y0 * p.tw + x0, ws * wy0 * wx0);
+        atomicAdd(gtex + (size_t)y0 * p.tw + x1, ws * wy0 * wx1);
+        atomicAdd(gtex + (size_t)y1 * p.tw + x0, ws * wy1 * wx0);
+        atomicAdd(gtex + (size_t)y1 * p.tw + x1, ws * wy1 * wx1);
+      }
+    } else if (active) {
+      const float *alb = albedo + 3 * shape;
+      const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3;
+      const size_t o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
+      const float gg[3] = {g0, g1, g2};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float ws = gg[ch] * alb[ch] * fac * p.inv_spp;
+        atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
+        atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
+        atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
+        atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
       }
     }
   }
@@ -1266,8 +1376,8 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
   return FFX_OK;
 }
 
-int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
-                   uint32_t seed, int img_fp16, void *img, ffx_stream s) {
+static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                           uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
@@ -1276,16 +1386,18 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
-  if (use_packet()) {
+  if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
+    FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
+  if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     if (packet_rays() == 1)
       hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, xcd_mode(), img_fp16, img);
+                         pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
     else
       hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, xcd_mode(), img_fp16, img);
+                         pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -1295,6 +1407,35 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
                      seed_key_of(seed), tiles_x, n_tiles, xcd_mode(), img_fp16, img);
   FFX_CHECK_LAUNCH("render_fwd");
+  return FFX_OK;
+}
+
+int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                   uint32_t seed, int img_fp16, void *img, ffx_stream s) {
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, nullptr, s);
+}
+
+size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * 16; }
+
+int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                         uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
+  if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
+  if (((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache must be 16-byte aligned");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, cache, s);
+}
+
+int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {
+  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!sd->proj.enabled) return FFX_OK;
+  BwdP p;
+  p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
+  if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || sd->cam.width < 1 || sd->cam.height < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad scene description");
+  for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];
+  p.inv_spp = 1.0f / (float)spp;
+  long total = (long)sd->cam.width * sd->cam.height * spp;
+  int grid = (int)((total + 255) / 256 < 256 * 32 ? (total + 255) / 256 : 256 * 32); // <= 32 workgroups per CU, grid-stride
+  hipLaunchKernelGGL(k_render_bwd_cached, dim3(grid), dim3(256), 0, (hipStream_t)s, (const uint4 *)cache, total, p, gimg, shape_albedo, gtex);
+  FFX_CHECK_LAUNCH("render_bwd_cached");
   return FFX_OK;
 }
 

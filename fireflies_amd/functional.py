@@ -3,6 +3,8 @@ calls into libffx_hip.so.  They replace the autograd graphs that the reference b
 eager torch ops (graphics/rasterization.py, projection/laser.py) and the Dr.Jit AD bridge around
 `mi.render` (graphics/depth.py:9,33,128 show the `dr.wrap_ad` pattern).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -92,6 +94,10 @@ def gaussian_blur(img, ksize=5, sigma=3.0):
     return _Blur.apply(img, int(ksize), float(sigma))
 
 
+# renders whose per-sample cache would exceed this many bytes fall back to the re-tracing adjoint
+CACHE_LIMIT_BYTES = int(float(os.environ.get("FFX_CACHE_LIMIT_GB", "32")) * (1 << 30))
+
+
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tex, geom, sd, albedo, spp, seed, fp16):
@@ -100,15 +106,29 @@ class _Render(torch.autograd.Function):
         t = _c(tex)
         if t.dim() == 2:
             t = t.unsqueeze(-1)
-        return geom.render_fwd(sd, albedo, t, spp, seed, fp16)
+        ctx.cache = None
+        if tex.requires_grad and sd.proj.enabled:
+            nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp)
+            if nbytes <= CACHE_LIMIT_BYTES:
+                # store 16 B per sample now instead of re-tracing the scene in backward
+                ctx.cache = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        return geom.render_fwd(sd, albedo, t, spp, seed, fp16, cache=ctx.cache)
 
     @staticmethod
     def backward(ctx, g):
-        gtex = ctx.geom.render_bwd(ctx.sd, ctx.albedo, ctx.spp, ctx.seed, _c(g.float()))
+        g = _c(g.float())
+        if ctx.cache is not None:
+            gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g)
+            ctx.cache = None
+        else:  # replays the geometry: it must not have been re-fitted since the forward pass
+            gtex = ctx.geom.render_bwd(ctx.sd, ctx.albedo, ctx.spp, ctx.seed, g)
         return gtex.reshape(ctx.tex_shape), None, None, None, None, None, None
 
 
 def render(tex, geom, sd, albedo, spp, seed=0, fp16=False):
     """K8/K9: image [H,W,3], differentiable w.r.t. the projector texture ([h,w] or [h,w,c]).
-    The geometry must not be re-fitted between forward and backward (the adjoint replays it)."""
+    When the texture requires grad the forward kernel also stores a 16-byte record per sample
+    (268 MB at 512x512x64) and the adjoint is a streaming pass over those records; beyond
+    FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
+    forward and backward)."""
     return _Render.apply(tex, geom, sd, albedo, int(spp), int(seed), bool(fp16))

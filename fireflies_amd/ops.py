@@ -136,6 +136,10 @@ def blur_bwd(g, ksize=5, sigma=3.0):
     return out
 
 
+def render_cache_bytes(width, height, spp):
+    return int(api().lib.ffx_render_cache_bytes(int(width), int(height), int(spp)))
+
+
 # ------------------------------------------------------------------ K5..K9
 def camera_struct(to_world, camera_to_sample, near, far, width, height):
     c = _abi.Camera()
@@ -287,15 +291,35 @@ class DeviceGeometry:
     def _timed(self, name):
         return _EventPair(self.timing, name)
 
-    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False):
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None):
+        """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
+        16-byte record per sample for render_bwd_cached."""
         H, W = sd.cam.height, sd.cam.width
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        if cache is not None:
+            if cache.numel() < W * H * int(spp) * 16:
+                raise ValueError("cache tensor too small")
+            with self._timed("render_fwd"):
+                api().call(
+                    "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
+                    _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype),
+                    _dev(cache, torch.uint8, "cache"), _stream(),
+                )
+            return img
         with self._timed("render_fwd"):
           api().call(
             "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
             _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(),
           )
         return img
+
+    def render_bwd_cached(self, sd, albedo, cache, spp, gimg):
+        """K9 from the per-sample cache written by render_fwd(..., cache=...): a streaming kernel, no BVH."""
+        gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
+        with self._timed("render_bwd_cached"):
+            api().call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
+                       _dev(gimg, name="gimg"), _dev(gtex), _stream())
+        return gtex
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)

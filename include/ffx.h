@@ -244,6 +244,27 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                    int spp, uint32_t seed, const float *gimg /*[dev][H,W,3] fp32*/,
                    float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K8 + K9 with a per-sample cache (store instead of re-trace).
+ * ffx_render_fwd_cache = ffx_render_fwd that additionally writes one 16-byte record per sample
+ * (index (y*W + x)*spp + s):  word0 = (ix0+1) | (iy0+1) << 12 | shape << 24  (unclamped bilinear base
+ * texel, projector textures up to 4094^2, up to 255 shapes), then the bilinear fractions ax, ay and
+ * the geometric factor `fac` (0 when the sample receives no projector light).
+ * ffx_render_bwd_cached streams those records and scatters d(loss)/d(img) * albedo * fac / spp
+ * through the bilinear weights into gtex (accumulated; the caller zeroes it).  It needs neither the
+ * BVH nor the camera: the geometry may be re-fitted between the forward and the backward pass.
+ * HBM traffic per render: 16 B/sample written by the forward, read once by the adjoint
+ * (268 MB at 512x512x64) instead of re-running the whole traversal.
+ * ---------------------------------------------------------------------------------------- */
+size_t ffx_render_cache_bytes(int width, int height, int spp);
+int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
+                         const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                         const float *tex /*[dev]*/, int spp, uint32_t seed, int img_fp16,
+                         void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes*/, ffx_stream stream);
+int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                          const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
+                          float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -835,7 +835,7 @@ static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 
 /* per-sample shading terms: projector texel footprint (4 bilinear taps with weights) and the
  * scalar factor multiplying the texture value, plus the spot contribution. */
-typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; float wx[2], wy[2]; float proj_fac; float spot_rgb[3]; } sample_terms;
+typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, uby; float wx[2], wy[2]; float proj_fac; float spot_rgb[3]; } sample_terms;
 
 static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *recs, v3 o, v3 d, float nt, float ft, sample_terms *st) {
   hit_t h;
@@ -888,6 +888,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
             float x0 = floorf(fx), y0 = floorf(fy);
             float ax = fx - x0, ay = fy - y0;
             int ix0 = (int)x0, iy0 = (int)y0;
+            st->ubx = ix0; st->uby = iy0;
             int ix1 = ix0 + 1, iy1 = iy0 + 1;
             ix0 = clampi(ix0, 0, c->tw - 1);
             ix1 = clampi(ix1, 0, c->tw - 1);
@@ -955,9 +956,10 @@ static inline uint16_t f32_to_f16(float f) {
   return h;
 }
 
-int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
-                   uint32_t seed, int img_fp16, void *img, ffx_stream s) {
-  (void)s;
+typedef struct { uint32_t w0; float ax, ay, fac; } crec; /* per-sample cache record, include/ffx.h */
+
+static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                           uint32_t seed, int img_fp16, void *img, crec *cache) {
   if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   shade_ctx c;
@@ -979,6 +981,14 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
       cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
       sample_terms st;
       shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
+      if (cache) {
+        crec *cr = &cache[idx];
+        cr->w0 = 0; cr->ax = 0.f; cr->ay = 0.f; cr->fac = 0.f;
+        if (st.hit && st.has_proj) {
+          cr->w0 = (uint32_t)(st.ubx + 1) | ((uint32_t)(st.uby + 1) << 12) | ((uint32_t)st.shape << 24);
+          cr->ax = st.wx[1]; cr->ay = st.wy[1]; cr->fac = st.proj_fac;
+        }
+      }
       if (!st.hit) continue;
       const float *alb = shape_albedo + 3 * st.shape;
       float rgb[3] = {st.spot_rgb[0], st.spot_rgb[1], st.spot_rgb[2]};
@@ -1000,6 +1010,52 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
       else ((float *)img)[(size_t)pix * 3 + ch] = v;
     }
   }
+  return FFX_OK;
+}
+
+int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                   uint32_t seed, int img_fp16, void *img, ffx_stream s) {
+  (void)s;
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, NULL);
+}
+
+size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * 16; }
+
+int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                         uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
+  (void)s;
+  if (!cache) FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, (crec *)cache);
+}
+
+/* adjoint from the per-sample records: same weights, same clamping as the forward lookup */
+int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {
+  (void)s;
+  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!sd->proj.enabled) return FFX_OK;
+  int W = sd->cam.width, H = sd->cam.height, tw = sd->proj.tex_w, th = sd->proj.tex_h, tc = sd->proj.tex_channels;
+  const crec *cr = (const crec *)cache;
+  float inv_spp = 1.0f / (float)spp;
+  size_t nt_ = (size_t)tw * th * tc;
+  double *acc = (double *)calloc(nt_, sizeof(double));
+  for (long idx = 0; idx < (long)W * H * spp; ++idx) {
+    const crec *r = &cr[idx];
+    if (r->fac == 0.f) continue;
+    const float *g = gimg + (size_t)(idx / spp) * 3;
+    int ix0 = (int)(r->w0 & 0xfffu) - 1, iy0 = (int)((r->w0 >> 12) & 0xfffu) - 1, shape = (int)(r->w0 >> 24);
+    int ix[2] = {clampi(ix0, 0, tw - 1), clampi(ix0 + 1, 0, tw - 1)}, iy[2] = {clampi(iy0, 0, th - 1), clampi(iy0 + 1, 0, th - 1)};
+    float wx[2] = {1.0f - r->ax, r->ax}, wy[2] = {1.0f - r->ay, r->ay};
+    const float *alb = shape_albedo + 3 * shape;
+    for (int tch = 0; tch < tc; ++tch) {
+      float wsum;
+      if (tc == 3) wsum = g[tch] * alb[tch] * r->fac * inv_spp;
+      else wsum = (g[0] * alb[0] * sd->proj.color[0] + g[1] * alb[1] * sd->proj.color[1] + g[2] * alb[2] * sd->proj.color[2]) * r->fac * inv_spp;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) acc[((size_t)iy[a] * tw + ix[b]) * tc + tch] += (double)(wsum * wy[a] * wx[b]);
+    }
+  }
+  for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
+  free(acc);
   return FFX_OK;
 }
 

@@ -194,6 +194,21 @@ class Geometry:
         api().call("ffx_render_fwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), None)
         return img
 
+    def render_fwd_cache(self, sd, albedo, tex, spp, seed=0, fp16=False):
+        albedo, tex = _f32(albedo), _f32(tex)
+        H, W = sd.cam.height, sd.cam.width
+        img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
+        cache = np.zeros(api().lib.ffx_render_cache_bytes(W, H, spp), np.uint8)
+        api().call("ffx_render_fwd_cache", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(cache), None)
+        return img, cache
+
+    @staticmethod
+    def render_bwd_cached(sd, albedo, cache, spp, gimg):
+        albedo, gimg = _f32(albedo), _f32(gimg)
+        gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        api().call("ffx_render_bwd_cached", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(gimg), _p(gtex), None)
+        return gtex
+
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         albedo, gimg = _f32(albedo), _f32(gimg)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)

@@ -427,3 +427,37 @@ def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
         gs = float(np.abs(gt_o).max())
         gerr = np.abs(gt_d - gt_o)
         assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs, env
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
+    """store-instead-of-retrace: the forward writes a 16-byte record per sample, the adjoint streams
+    them.  Same image as the plain forward (bitwise), same records as the oracle's, same gradient as
+    the re-tracing adjoint and as the oracle; and it survives a re-fit between forward and backward."""
+    sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    xf = _rand_xforms(2, 5)
+    go, gd, alb = _pair(oracle, sc, frame=2, xforms=xf)
+    sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True)
+    tex = _tex(sc, ch)
+    spp = 9
+    nbytes = ops.render_cache_bytes(52, 44, spp)
+    assert nbytes == 52 * 44 * spp * 16
+    cache = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    img_c = gd.render_fwd(sd, dev(alb), tex, spp, seed=3, cache=cache)
+    assert torch.equal(img_c, gd.render_fwd(sd, dev(alb), tex, spp, seed=3))
+    img_o, cache_o = go.render_fwd_cache(sd, alb, host(tex), spp, seed=3)
+    rec_d = host(cache).view(np.uint32).reshape(-1, 4)
+    rec_o = cache_o.view(np.uint32).reshape(-1, 4)
+    same = (rec_d == rec_o).all(axis=1)
+    assert same.mean() > 0.999  # identical operation order; ulp-level edge flips aside
+    rng = np.random.default_rng(0)
+    gimg = rng.standard_normal((44, 52, 3)).astype(np.float32)
+    g_retrace = host(gd.render_bwd(sd, dev(alb), spp, 3, dev(gimg)))
+    gd.update(_rand_xforms(2, 99))  # re-fit to another pose: the cached adjoint must not care
+    g_cached = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg)))
+    g_oracle = go.render_bwd_cached(sd, alb, cache_o, spp, gimg)
+    scale = float(np.abs(g_oracle).max())
+    assert scale > 0
+    for a, b in ((g_cached, g_retrace), (g_cached, g_oracle), (g_oracle, go.render_bwd(sd, alb, spp, 3, gimg))):
+        err = np.abs(a - b)
+        assert (err > 1e-3 * scale).mean() <= 1e-3 and err.max() <= 0.1 * scale
