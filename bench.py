@@ -67,14 +67,17 @@ def _kernel_ms(events, name):
     return (sum(ms) / len(ms), len(ms)) if ms else (None, 0)
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, tag="r"):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
     FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  None if no profile is present."""
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+    # "<round>_pmc_summary.json" = render bracket only, "<round>grad_pmc_summary.json" = gradient bracket
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = [f for f in files if os.path.basename(f).split("_")[0].endswith("grad") == (tag == "grad")]
+    for f in files:
         try:
             d = json.load(open(f))
         except Exception:
@@ -132,6 +135,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU-oracle baseline render (64 = the full workload, no scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-steps", action="store_true")
+    ap.add_argument("--no-render-steps", action="store_true", help="profiling aid: skip the render bracket (prints a reduced line)")
     ap.add_argument("--no-shadows", action="store_true")
     ap.add_argument("--workload", default="vocalfold", choices=["vocalfold", "colon"],
                     help="vocalfold = BASELINE configs[1]/[2] (the metric's configuration); colon = configs[4] "
@@ -172,7 +176,7 @@ def main():
         geom.timing = events if i >= args.warmup else None
         return render_step(i)
 
-    t_render = _bracket(timed_render_step, args.steps, args.warmup, dev)
+    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, args.warmup if not args.no_render_steps else 0, dev)
     geom.timing = None
     torch.cuda.synchronize()
     renders_per_sec = world * args.steps / t_render
@@ -210,7 +214,7 @@ def main():
                 "kernel": "k_render_bwd_cached (streams the per-sample records written by K8)", "bound": "hbm",
                 "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
-                "traffic": (pmc_traffic("k_render_bwd_cached") or {}).get("bytes")},
+                "traffic": (pmc_traffic("k_render_bwd_cached", "grad") or {}).get("bytes")},
         }
 
     if rank != 0:
