@@ -176,13 +176,16 @@ __device__ __forceinline__ void cam_ray(const CamK &k, float sx, float sy, v3 &o
   float qy = fmaf(m[4], sx, fmaf(m[5], sy, m[7]));
   float qz = fmaf(m[8], sx, fmaf(m[9], sy, m[11]));
   float qw = fmaf(m[12], sx, fmaf(m[13], sy, m[15]));
-  v3 np = V3(qx / qw, qy / qw, qz / qw);
-  float len = sqrtf(vdot(np, np));
-  v3 dl = V3(np.x / len, np.y / len, np.z / len);
+  // one IEEE reciprocal + multiplies instead of a division per component (same order as the oracle)
+  const float iw = 1.0f / qw;
+  v3 np = V3(qx * iw, qy * iw, qz * iw);
+  const float il = 1.0f / sqrtf(vdot(np, np));
+  v3 dl = V3(np.x * il, np.y * il, np.z * il);
   d = xf_dir(k.tw, dl);
   o = V3(k.tw[3], k.tw[7], k.tw[11]);
-  near_t = k.near_clip / dl.z;
-  far_t = k.far_clip / dl.z;
+  const float idz = 1.0f / dl.z;
+  near_t = k.near_clip * idz;
+  far_t = k.far_clip * idz;
 }
 
 // ------------------------------------------------------------------------------------------ K7 kernels
@@ -247,7 +250,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
   float nl = sqrtf(vdot(ng, ng));
   if (!(nl > 0.f)) return;
-  ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+  const float inl = 1.0f / nl;
+  ng = V3(ng.x * inl, ng.y * inl, ng.z * inl);
   if (vdot(ng, d) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
   float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
   float off = (1.0f + pmax) * RAY_EPS;
@@ -260,13 +264,14 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
       float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
       float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
       float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
-      float u = qx / qw, v = qy / qw;
+      const float iqw = 1.0f / qw;
+      float u = qx * iqw, v = qy * iqw;
       if (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f) {
         v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
         v3 wi = vsub(ppos, P);
         float d2 = vdot(wi, wi);
-        float dist = sqrtf(d2);
-        wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+        const float idist = 1.0f / sqrtf(d2);
+        wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
         float cos_s = vdot(ng, wi);
         float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
         if (cos_s > 0.f && cos_p > 0.f) {
@@ -274,7 +279,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           if (c.shadows) {
             v3 ws = vsub(ppos, Po);
             float ds = sqrtf(vdot(ws, ws));
-            ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+            const float ids = 1.0f / ds;
+            ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
             Hit hs;
             vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
           }
@@ -301,8 +307,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
     v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
     v3 wi = vsub(spos, P);
     float d2 = vdot(wi, wi);
-    float dist = sqrtf(d2);
-    wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+    const float idist = 1.0f / sqrtf(d2);
+    wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
     float cos_s = vdot(ng, wi);
     if (cos_s > 0.f) {
       v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
@@ -316,7 +322,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         if (c.shadows) {
           v3 ws = vsub(spos, Po);
           float ds = sqrtf(vdot(ws, ws));
-          ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+          const float ids = 1.0f / ds;
+          ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           Hit hs;
           vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
         }
@@ -837,7 +844,8 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
       float nl = sqrtf(vdot(ng, ng));
       q.ok = nl > 0.f;
       if (q.ok) {
-        ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+        const float inl = 1.0f / nl;
+        ng = V3(ng.x * inl, ng.y * inl, ng.z * inl);
         if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
         q.ng = ng;
         float pmax = fmaxf(fabsf(q.P.x), fmaxf(fabsf(q.P.y), fabsf(q.P.z)));
@@ -857,14 +865,15 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
         float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
         float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
         float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
-        q.u = qx / qw;
-        q.v = qy / qw;
+        const float iqw = 1.0f / qw;
+        q.u = qx * iqw;
+        q.v = qy * iqw;
         if (q.u >= 0.f && q.u <= 1.f && q.v >= 0.f && q.v <= 1.f) {
           v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
           v3 wi = vsub(ppos, q.P);
           float d2 = vdot(wi, wi);
-          float dist = sqrtf(d2);
-          wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+          const float idist = 1.0f / sqrtf(d2);
+          wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float cos_s = vdot(q.ng, wi);
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
           if (cos_s > 0.f && cos_p > 0.f) {
@@ -872,7 +881,8 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
             q.pfac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
             v3 ws = vsub(ppos, q.Po);
             q.ds_p = sqrtf(vdot(ws, ws));
-            q.ws_p = V3(ws.x / q.ds_p, ws.y / q.ds_p, ws.z / q.ds_p);
+            const float ids = 1.0f / q.ds_p;
+            q.ws_p = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           }
         }
       }
@@ -886,8 +896,8 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
       v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
       v3 wi = vsub(spos, q.P);
       float d2 = vdot(wi, wi);
-      float dist = sqrtf(d2);
-      wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+      const float idist = 1.0f / sqrtf(d2);
+      wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
       float cos_s = vdot(q.ng, wi);
       if (cos_s > 0.f) {
         v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
@@ -901,7 +911,8 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
           q.sfac = fall * cos_s / d2 * 0.3183098861837907f;
           v3 ws = vsub(spos, q.Po);
           q.ds_s = sqrtf(vdot(ws, ws));
-          q.ws_s = V3(ws.x / q.ds_s, ws.y / q.ds_s, ws.z / q.ds_s);
+          const float ids = 1.0f / q.ds_s;
+          q.ws_s = V3(ws.x * ids, ws.y * ids, ws.z * ids);
         }
       }
     }

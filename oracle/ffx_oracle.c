@@ -731,12 +731,15 @@ static inline void cam_ray(const cam_ctx *k, float sx, float sy, v3 *d, float *n
   float qy = fmaf(m[4], sx, fmaf(m[5], sy, m[7]));
   float qz = fmaf(m[8], sx, fmaf(m[9], sy, m[11]));
   float qw = fmaf(m[12], sx, fmaf(m[13], sy, m[15]));
-  v3 np = V3(qx / qw, qy / qw, qz / qw);
-  float len = sqrtf(vdot(np, np));
-  v3 dl = V3(np.x / len, np.y / len, np.z / len);
+  /* one IEEE reciprocal + multiplies per normalisation (the HIP kernels follow the same order) */
+  const float iw = 1.0f / qw;
+  v3 np = V3(qx * iw, qy * iw, qz * iw);
+  const float il = 1.0f / sqrtf(vdot(np, np));
+  v3 dl = V3(np.x * il, np.y * il, np.z * il);
   *d = xf_dir(k->to_world, dl);
-  *near_t = k->near_clip / dl.z;
-  *far_t = k->far_clip / dl.z;
+  const float idz = 1.0f / dl.z;
+  *near_t = k->near_clip * idz;
+  *far_t = k->far_clip * idz;
 }
 
 int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camera *cam, int spp, int jitter, uint32_t seed, float *t_out,
@@ -851,7 +854,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
   v3 ng = vcross(V3(r->e1[0], r->e1[1], r->e1[2]), V3(r->e2[0], r->e2[1], r->e2[2]));
   float nl = sqrtf(vdot(ng, ng));
   if (!(nl > 0.f)) return;
-  ng = V3(ng.x / nl, ng.y / nl, ng.z / nl);
+  const float inl = 1.0f / nl;
+  ng = V3(ng.x * inl, ng.y * inl, ng.z * inl);
   if (vdot(ng, d) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z); /* face the viewer */
   float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
   float off = (1.0f + pmax) * RAY_EPS;
@@ -864,12 +868,13 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
       float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
       float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
       float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
-      float u = qx / qw, v = qy / qw;
+      const float iqw = 1.0f / qw;
+      float u = qx * iqw, v = qy * iqw;
       if (u >= 0.f && u <= 1.f && v >= 0.f && v <= 1.f) {
         v3 wi = vsub(c->p_pos, P);
         float d2 = vdot(wi, wi);
-        float dist = sqrtf(d2);
-        wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+        const float idist = 1.0f / sqrtf(d2);
+        wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
         float cos_s = vdot(ng, wi);
         float cos_p = -vdot(c->p_axis, wi);
         if (cos_s > 0.f && cos_p > 0.f) {
@@ -877,7 +882,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
           if (c->shadows) {
             v3 ws = vsub(c->p_pos, Po);
             float ds = sqrtf(vdot(ws, ws));
-            ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+            const float ids = 1.0f / ds;
+            ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
             vis = !occluded(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS));
           }
           if (vis) {
@@ -905,8 +911,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
   if (c->spot_on) {
     v3 wi = vsub(c->s_pos, P);
     float d2 = vdot(wi, wi);
-    float dist = sqrtf(d2);
-    wi = V3(wi.x / dist, wi.y / dist, wi.z / dist);
+    const float idist = 1.0f / sqrtf(d2);
+    wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
     float cos_s = vdot(ng, wi);
     if (cos_s > 0.f) {
       v3 ll = xf_dir(c->s_w2l, V3(-wi.x, -wi.y, -wi.z));
@@ -920,7 +926,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         if (c->shadows) {
           v3 ws = vsub(c->s_pos, Po);
           float ds = sqrtf(vdot(ws, ws));
-          ws = V3(ws.x / ds, ws.y / ds, ws.z / ds);
+          const float ids = 1.0f / ds;
+          ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           vis = !occluded(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS));
         }
         if (vis) {
