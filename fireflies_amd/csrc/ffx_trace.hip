@@ -992,7 +992,8 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, in
 }
 
 template <int R>
-__global__ void __launch_bounds__(PK_BLOCK)
+// 1 ray per lane fits 64 VGPRs / 96 SGPRs (32 B of scratch): 8 waves per SIMD instead of 7 (measured -4 %)
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 3, R == 1 ? 8 : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
                     const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img,
                     uint4 *__restrict__ cache) {
@@ -1096,7 +1097,7 @@ __global__ void __launch_bounds__(PK_BLOCK)
 }
 
 template <int R>
-__global__ void __launch_bounds__(PK_BLOCK)
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 3, R == 1 ? 8 : 4)))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
                     uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
   constexpr int NSUB = 4 / R;
