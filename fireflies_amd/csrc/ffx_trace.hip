@@ -474,6 +474,12 @@ __global__ void __launch_bounds__(TR_BLOCK)
 }
 
 
+// wave ballot of a predicate: the compiler's builtin reads the lane mask directly, whereas HIP's
+// __ballot(int) materialises 0/1 in a VGPR and compares it again (two VALU instructions per call)
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// popcount of a lane mask as a 32-bit SCALAR (the compiler widens a comparison of two popcountll
+// results to 64 bits, which has no scalar compare and lands on the VALU)
+__device__ __forceinline__ int wpop(unsigned long long m) { int r; asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(m) : "scc"); return r; }
 // ------------------------------------------------------------------------------------------ wave-packet traversal
 // One wavefront = one packet of 64 coherent rays (4x4 pixels x 4 samples, or their shadow rays).
 // Control flow is WAVE-UNIFORM: the packet walks the union of its rays' paths.  Because the node
@@ -554,7 +560,7 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int c = side ? c1 : c0;
-      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(side ? any1 : any0) != 0ull) { // wave-uniform
+      if (c < 0 && c != FFX_EMPTY_CHILD && wballot(side ? any1 : any0) != 0ull) { // wave-uniform
         const uint32_t lc = (uint32_t)~c;
         const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
         for (int i = 0; i < count; ++i) {
@@ -581,7 +587,7 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
             p1[r] = (side ? h1[r] : h0[r]) & (detA[r] > 0.f) & (Us[r] >= 0.f) & (Us[r] <= detA[r]);
             any1 |= p1[r];
           }
-          if (__ballot(any1) == 0ull) continue;
+          if (wballot(any1) == 0ull) continue;
           bool p2[R], any2 = false;
           v3 qv[R];
 #pragma unroll
@@ -592,7 +598,7 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
             p2[r] = p1[r] & (Vs >= 0.f) & (Us[r] + Vs <= detA[r]);
             any2 |= p2[r];
           }
-          if (__ballot(any2) == 0ull) continue;
+          if (wballot(any2) == 0ull) continue;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const float T = vdot(e2, qv[r]);
@@ -617,7 +623,7 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
       bool undecided = false;
 #pragma unroll
       for (int r = 0; r < R; ++r) undecided |= active[r] & !found[r];
-      if (__ballot(undecided) == 0ull) break; // every ray of the packet is decided
+      if (wballot(undecided) == 0ull) break; // every ray of the packet is decided
     }
     bool g0 = false, g1 = false, first1 = false, first0 = false;
 #pragma unroll
@@ -628,10 +634,10 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
       first1 |= a1 & (!a0 | (t1[r] < t0[r]));
       first0 |= a0 & (!a1 | (t0[r] <= t1[r]));
     }
-    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
+    const unsigned long long m0 = wballot(g0), m1 = wballot(g1);
     if (m0 != 0ull && m1 != 0ull) {
       // visit first the child that most lanes enter first
-      const bool swap = __popcll(__ballot(first1)) > __popcll(__ballot(first0));
+      const bool swap = wpop(wballot(first1)) > wpop(wballot(first0));
       stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
       ++sp;
       cur = swap ? c1 : c0;
@@ -644,6 +650,202 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
       --sp;
       cur = __builtin_amdgcn_readlane(stack_v, sp);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ octant-specialised packet walk
+// All rays of a one-pixel packet (and of its shadow packets) almost always share the signs of their
+// direction components.  Then, per axis, which of the two box planes is entered first is known for the
+// whole packet, and the slab test needs neither min/max nor a subtract:
+//     t_near[a] = near_plane[a] * id[a] - oidN[a]        t_far[a] = far_plane[a] * id[a] - oidF[a]
+// one v_fma_f32 per plane with the node plane as the SGPR operand: 12 VALU per box instead of 27
+// (3 v_mov + 6 sub + 6 mul + 6 min/max + ...).  oid = o*id; the fma form loses the exact cancellation
+// of (plane - o)*id, so its rounding error |oid|*2^-24 is covered by a per-axis pad e = |oid|*2^-22
+// folded into the two constants oidN = oid + e (entry can only move earlier) and oidF = oid - e (exit
+// only later): boxes are hit at least as often as in exact arithmetic, and the triangle test — which
+// alone decides the result — is unchanged.  The loop is compiled once per octant (OCT bit a set =
+// direction component a negative) and selected per walk by a wave-uniform switch; packets with mixed
+// signs take the generic loop.
+#ifndef FFX_OCTANT_LOOPS
+#define FFX_OCTANT_LOOPS 1
+#endif
+#ifndef FFX_PK1_WAVES
+#define FFX_PK1_WAVES 8 // resident waves per SIMD the 1-ray packet kernels are register-budgeted for
+#endif
+__device__ __forceinline__ constexpr bool octant_loops() { return FFX_OCTANT_LOOPS != 0; }
+struct RayOct { v3 id, oidN, oidF; };
+__device__ __forceinline__ RayOct make_rayoct(v3 o, v3 d) {
+  RayOct r;
+  r.id = V3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
+  const v3 oid = V3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
+  const float k = 2.384185791015625e-07f; // 2^-22
+  const v3 e = V3(fabsf(oid.x) * k, fabsf(oid.y) * k, fabsf(oid.z) * k);
+  r.oidN = V3(oid.x + e.x, oid.y + e.y, oid.z + e.z);
+  r.oidF = V3(oid.x - e.x, oid.y - e.y, oid.z - e.z);
+  return r;
+}
+// Predicates are kept as explicit 64-bit lane masks: v_cmp writes them straight into an SGPR pair,
+// they are combined on the scalar ALU, tested with s_cmp (no ballot) and consumed by v_cndmask through
+// inverse_ballot.  (A `bool` that is not itself a compare costs v_cndmask + v_cmp_ne per ballot.)
+typedef unsigned long long wmask;
+__device__ __forceinline__ wmask m_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }  // ordered <
+__device__ __forceinline__ wmask m_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }  // ordered <=
+__device__ __forceinline__ wmask m_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }  // ordered >
+__device__ __forceinline__ wmask m_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3); }  // ordered >=
+__device__ __forceinline__ wmask m_eq(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 1); }  // ordered ==
+__device__ __forceinline__ wmask m_ult(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+template <typename T>
+__device__ __forceinline__ T msel(wmask m, T a, T b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
+// min/max without the sNaN-quieting v_max(x,x) the compiler puts in front of fminf/fmaxf operands it
+// cannot prove canonical (the loop-carried hit distance): inputs here are never NaN
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <int OCT>
+__device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], const RayOct &rb, float tmin, float tmax, float &tn_out) {
+  const float nx = (OCT & 1) ? hi[0] : lo[0], fx = (OCT & 1) ? lo[0] : hi[0];
+  const float ny = (OCT & 2) ? hi[1] : lo[1], fy = (OCT & 2) ? lo[1] : hi[1];
+  const float nz = (OCT & 4) ? hi[2] : lo[2], fz = (OCT & 4) ? lo[2] : hi[2];
+  const float tn = vmax2(vmax3(fmaf(nx, rb.id.x, -rb.oidN.x), fmaf(ny, rb.id.y, -rb.oidN.y), fmaf(nz, rb.id.z, -rb.oidN.z)), tmin);
+  const float tf = vmin2(vmin3(fmaf(fx, rb.id.x, -rb.oidF.x), fmaf(fy, rb.id.y, -rb.oidF.y), fmaf(fz, rb.id.z, -rb.oidF.z)) * 1.0000004f, tmax);
+  tn_out = tn;
+  return m_le(tn, tf);
+}
+
+// The scalar ALU issues at the same rate as the VALU (one instruction per SIMD per 4 cycles), so the
+// uniform bookkeeping is written to stay short: 32-bit byte offsets for node / record addressing, a
+// fast path for nodes whose children are both inner nodes (no leaf or empty-child logic at all), and
+// nested uniform branches instead of combined predicates.
+template <bool ANY, int OCT>
+__device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const RayOct &rb, v3 o, v3 d, float tmin,
+                                                    float tmax, wmask active, Hit &h, bool &found) {
+  h.t = msel(active, tmax, -INFINITY); // an inactive ray fails every slab test
+  h.prim = -1;
+  h.shape = -1;
+  h.slot = -1;
+  wmask occluded = 0; // ANY: rays that have found an occluder
+  int stack_v = 0;
+  int sp = 0;
+  int cur = 0; // wave-uniform throughout: node fetches are scalar loads
+  const char *nbase = reinterpret_cast<const char *>(nodes);
+  const char *rbase = reinterpret_cast<const char *>(recs);
+  while (true) {
+    const float4 *n4 = reinterpret_cast<const float4 *>(nbase + ((uint32_t)cur << 6));
+    const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
+    const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
+    const int c0 = ch.x, c1 = ch.y;
+    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    float t0, t1;
+    // both slabs unconditionally (one 64-byte fetch, no dependent branch)
+    wmask g0 = slab_oct<OCT>(lo0, hi0, rb, tmin, h.t, t0);
+    wmask g1 = slab_oct<OCT>(lo1, hi1, rb, tmin, h.t, t1);
+    if ((c0 | c1) < 0) { // a leaf or an empty child on at least one side
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int c = side ? c1 : c0;
+        if (c >= 0) continue;
+        const wmask hs = side ? g1 : g0;
+        if (side) g1 = 0ull; else g0 = 0ull; // never descended into
+        if (c == FFX_EMPTY_CHILD) continue;
+        if (hs == 0ull) continue;
+        const uint32_t lc = (uint32_t)~c;
+        const uint32_t first = lc >> 3, count = (lc & 7u) + 1u;
+        uint32_t roff = first * 48u;
+        for (uint32_t i = 0; i < count; ++i, roff += 48u) {
+          const float4 *r4 = reinterpret_cast<const float4 *>(rbase + roff);
+          const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
+          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
+          const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb4.x, rb4.y), e2 = V3(rb4.z, rb4.w, rc.x);
+          // staged Moller-Trumbore with wave-uniform early-outs (same arithmetic and acceptance rule as tri_hit)
+          const v3 pv = vcross(d, e2);
+          const float det = vdot(e1, pv);
+          const v3 tv = vsub(o, v0);
+          const float U = vdot(tv, pv);
+          const wmask neg = m_lt(det, 0.f);
+          const float detA = fabsf(det);
+          const float Us = msel(neg, -U, U);
+          const wmask p1 = hs & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
+          if (p1 == 0ull) continue;
+          const v3 qv = vcross(tv, e1);
+          const float Vv = vdot(d, qv);
+          const float Vs = msel(neg, -Vv, Vv);
+          const wmask p2 = p1 & m_ge(Vs, 0.f) & m_le(Us + Vs, detA);
+          if (p2 == 0ull) continue;
+          const float T = vdot(e2, qv);
+          const float t = msel(neg, -T, T) / detA;
+          const wmask hit = p2 & m_gt(t, tmin);
+          if (ANY) {
+            const wmask occ = hit & m_lt(t, tmax);
+            occluded |= occ;
+            h.t = msel(occ, -INFINITY, h.t);
+          } else {
+            // h.t <= tmax always and h.prim == -1 (the largest unsigned) until the first hit, so
+            // (t <= tmax) & (no hit yet | t < h.t | (t == h.t & prim < h.prim)) reduces to:
+            const wmask better = hit & (m_lt(t, h.t) | (m_eq(t, h.t) & m_ult((uint32_t)prim, (uint32_t)h.prim)));
+            h.t = msel(better, t, h.t);
+            h.prim = msel(better, prim, h.prim);
+            h.shape = msel(better, shape, h.shape);
+            h.slot = msel(better, (int)(first + i), h.slot);
+          }
+        }
+      }
+      if (ANY && (active & ~occluded) == 0ull) break; // every ray of the packet is decided
+      // the hit distance may have shrunk: re-test the (at most one) remaining inner child
+      if (g0 != 0ull) g0 &= m_le(t0, h.t);
+      if (g1 != 0ull) g1 &= m_le(t1, h.t);
+    }
+    if (g0 != 0ull) {
+      if (g1 != 0ull) {
+        // both: visit first the child that most lanes enter first, push the other
+        const wmask lt = m_lt(t1, t0);
+        const bool swap = wpop(g1 & (~g0 | lt)) > wpop(g0 & ~(g1 & lt));
+        stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
+        ++sp;
+        cur = swap ? c1 : c0;
+      } else {
+        cur = c0;
+      }
+    } else if (g1 != 0ull) {
+      cur = c1;
+    } else {
+      if (sp == 0) break;
+      --sp;
+      cur = __builtin_amdgcn_readlane(stack_v, sp);
+    }
+  }
+  found = __builtin_amdgcn_inverse_ballot_w64(occluded);
+}
+
+// one ray per lane: pick the octant loop if the packet's active rays agree on their direction signs
+template <bool ANY>
+__device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[1], const v3 (&d)[1],
+                                                 const float (&tmin)[1], const float (&tmax)[1], const bool (&active)[1], Hit (&h)[1], bool (&found)[1]) {
+  const wmask am = wballot(active[0]);
+  if (am == 0ull) { // nothing to trace
+    h[0].t = -INFINITY; h[0].prim = -1; h[0].shape = -1; h[0].slot = -1; found[0] = false;
+    return;
+  }
+  const RayOct rb = make_rayoct(o[0], d[0]);
+  // octant from the reciprocals actually used (a clamped -0.0 component counts as negative)
+  const uint32_t oct = (__float_as_uint(rb.id.x) >> 31) | ((__float_as_uint(rb.id.y) >> 31) << 1) | ((__float_as_uint(rb.id.z) >> 31) << 2);
+  const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readlane((int)oct, __builtin_ctzll(am)); // octant of the first active lane
+  const bool uniform = (am & __builtin_amdgcn_uicmp(oct, oct0, 33)) == 0ull;
+  if (uniform) {
+    switch (oct0) { // wave-uniform
+      case 0: traverse_packet_oct<ANY, 0>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 1: traverse_packet_oct<ANY, 1>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 2: traverse_packet_oct<ANY, 2>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 3: traverse_packet_oct<ANY, 3>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 4: traverse_packet_oct<ANY, 4>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 5: traverse_packet_oct<ANY, 5>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 6: traverse_packet_oct<ANY, 6>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      default: traverse_packet_oct<ANY, 7>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+    }
+  } else {
+    traverse_packet<ANY, 1>(nodes, recs, o, d, tmin, tmax, active, h, found);
   }
 }
 
@@ -720,7 +922,7 @@ __device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nod
     for (int side = 0; side < 2; ++side) {
       const int c = side ? c1 : c0;
       const bool hs0 = side ? h1[0] : h0[0], hs1 = side ? h1[1] : h0[1];
-      if (c < 0 && c != FFX_EMPTY_CHILD && __ballot(hs0 | hs1) != 0ull) { // wave-uniform
+      if (c < 0 && c != FFX_EMPTY_CHILD && wballot(hs0 | hs1) != 0ull) { // wave-uniform
         const uint32_t lc = (uint32_t)~c;
         const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
         for (int i = 0; i < count; ++i) {
@@ -739,7 +941,7 @@ __device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nod
           const f2 Us = {n0 ? -U.x : U.x, n1 ? -U.y : U.y};
           const bool p10 = hs0 & (detA.x > 0.f) & (Us.x >= 0.f) & (Us.x <= detA.x);
           const bool p11 = hs1 & (detA.y > 0.f) & (Us.y >= 0.f) & (Us.y <= detA.y);
-          if (__ballot(p10 | p11) == 0ull) continue;
+          if (wballot(p10 | p11) == 0ull) continue;
           // stage 2 (packed): qv = tv x e1, V = d . qv
           const v3p qv = vcross2(tv, e1);
           const f2 Vv = vdot2(d, qv);
@@ -747,7 +949,7 @@ __device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nod
           const f2 UV = Us + Vs;
           const bool p20 = p10 & (Vs.x >= 0.f) & (UV.x <= detA.x);
           const bool p21 = p11 & (Vs.y >= 0.f) & (UV.y <= detA.y);
-          if (__ballot(p20 | p21) == 0ull) continue;
+          if (wballot(p20 | p21) == 0ull) continue;
           // stage 3: T = e2 . qv, t = T / det (IEEE division, per element)
           const f2 T = vdot2(e2, qv);
           const float tt[2] = {(n0 ? -T.x : T.x) / detA.x, (n1 ? -T.y : T.y) / detA.y};
@@ -773,14 +975,14 @@ __device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nod
         }
       }
     }
-    if (ANY && __ballot((active[0] & !found[0]) | (active[1] & !found[1])) == 0ull) break; // every ray is decided
+    if (ANY && wballot((active[0] & !found[0]) | (active[1] & !found[1])) == 0ull) break; // every ray is decided
     const bool a00 = h0[0] & (c0 >= 0) & (t0.x <= ht.x), a01 = h0[1] & (c0 >= 0) & (t0.y <= ht.y);
     const bool a10 = h1[0] & (c1 >= 0) & (t1.x <= ht.x), a11 = h1[1] & (c1 >= 0) & (t1.y <= ht.y);
-    const unsigned long long m0 = __ballot(a00 | a01), m1 = __ballot(a10 | a11);
+    const unsigned long long m0 = wballot(a00 | a01), m1 = wballot(a10 | a11);
     if (m0 != 0ull && m1 != 0ull) {
       const bool first1 = (a10 & (!a00 | (t1.x < t0.x))) | (a11 & (!a01 | (t1.y < t0.y)));
       const bool first0 = (a00 & (!a10 | (t0.x <= t1.x))) | (a01 & (!a11 | (t0.y <= t1.y)));
-      const bool swap = __popcll(__ballot(first1)) > __popcll(__ballot(first0));
+      const bool swap = wpop(wballot(first1)) > wpop(wballot(first0));
       stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
       ++sp;
       cur = swap ? c1 : c0;
@@ -803,6 +1005,7 @@ template <bool ANY, int R>
 __device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
                                                     const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
   if constexpr (R == 2) traverse_packet2<ANY>(nodes, recs, o, d, tmin, tmax, active, h, found);
+  else if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, recs, o, d, tmin, tmax, active, h, found);
   else traverse_packet<ANY, R>(nodes, recs, o, d, tmin, tmax, active, h, found);
 }
 
@@ -923,7 +1126,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
   bool occ_p[R], occ_s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) occ_p[r] = occ_s[r] = false;
-  if (c.shadows && __ballot(any_p) != 0ull) {
+  if (c.shadows && wballot(any_p) != 0ull) {
     v3 so[R], sdir[R];
     float s0[R], s1[R];
     bool act[R];
@@ -932,7 +1135,7 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
     for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_p; s0[r] = 0.f; s1[r] = pre[r].ds_p * (1.0f - SHADOW_EPS); act[r] = pre[r].need_p; }
     traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_p);
   }
-  if (c.shadows && __ballot(any_s) != 0ull) {
+  if (c.shadows && wballot(any_s) != 0ull) {
     v3 so[R], sdir[R];
     float s0[R], s1[R];
     bool act[R];
@@ -993,7 +1196,7 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, in
 
 template <int R>
 // 1 ray per lane fits 64 VGPRs / 96 SGPRs (32 B of scratch): 8 waves per SIMD instead of 7 (measured -4 %)
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 3, R == 1 ? 8 : 4)))
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
                     const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img,
                     uint4 *__restrict__ cache) {
@@ -1017,7 +1220,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       pix[r] = (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r];
       acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
     }
-    if (__ballot(any_live) == 0ull) continue;
+    if (wballot(any_live) == 0ull) continue;
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -1097,7 +1300,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 }
 
 template <int R>
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 3, R == 1 ? 8 : 4)))
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
                     uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
   constexpr int NSUB = 4 / R;
@@ -1122,7 +1325,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       live[r] = live[r] && !(g[r][0] == 0.f && g[r][1] == 0.f && g[r][2] == 0.f);
       any_live |= live[r];
     }
-    if (__ballot(any_live) == 0ull) continue; // wave-uniform
+    if (wballot(any_live) == 0ull) continue; // wave-uniform
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -1205,7 +1408,7 @@ __global__ void __launch_bounds__(256)
       g0 = gimg[pix * 3]; g1 = gimg[pix * 3 + 1]; g2 = gimg[pix * 3 + 2];
       active = !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
     }
-    if (__ballot(active) == 0ull) continue;
+    if (wballot(active) == 0ull) continue;
     const int ix0 = (int)(rec.x & 0xfffu) - 1, iy0 = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
     const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
     const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
