@@ -703,13 +703,30 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm
 __device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// Box test of the octant loops: one v_fma_f32 per plane with the node plane as the SGPR operand.
+// Per plane the ray carries a multiplier and a constant,
+//     entered-first plane:  m = id[a],      c = oidN[a]
+//     left-last plane:      m = id[a] * k,  c = oidF[a] * k      (k = 1 + 3*2^-23, the far-side widening)
+// which of lo/hi is which is fixed by the octant at compile time.  (v_pk_fma_f32 with the node planes
+// as an SGPR pair was measured: it occupies ~1.5 issue slots on gfx950 and needs three more VGPRs, and
+// the kernel got 8% slower — profiles/r1_issue_mix.txt.)
+struct RaySlab { v3 id, idk, cN, cF; };
+__device__ __forceinline__ RaySlab make_rayslab(const RayOct &rb) {
+  const float k = 1.0000004f;
+  RaySlab r;
+  r.id = rb.id;
+  r.idk = V3(rb.id.x * k, rb.id.y * k, rb.id.z * k);
+  r.cN = rb.oidN;
+  r.cF = V3(rb.oidF.x * k, rb.oidF.y * k, rb.oidF.z * k);
+  return r;
+}
 template <int OCT>
-__device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], const RayOct &rb, float tmin, float tmax, float &tn_out) {
+__device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], const RaySlab &rs, float tmin, float tmax, float &tn_out) {
   const float nx = (OCT & 1) ? hi[0] : lo[0], fx = (OCT & 1) ? lo[0] : hi[0];
   const float ny = (OCT & 2) ? hi[1] : lo[1], fy = (OCT & 2) ? lo[1] : hi[1];
   const float nz = (OCT & 4) ? hi[2] : lo[2], fz = (OCT & 4) ? lo[2] : hi[2];
-  const float tn = vmax2(vmax3(fmaf(nx, rb.id.x, -rb.oidN.x), fmaf(ny, rb.id.y, -rb.oidN.y), fmaf(nz, rb.id.z, -rb.oidN.z)), tmin);
-  const float tf = vmin2(vmin3(fmaf(fx, rb.id.x, -rb.oidF.x), fmaf(fy, rb.id.y, -rb.oidF.y), fmaf(fz, rb.id.z, -rb.oidF.z)) * 1.0000004f, tmax);
+  const float tn = vmax2(vmax3(fmaf(nx, rs.id.x, -rs.cN.x), fmaf(ny, rs.id.y, -rs.cN.y), fmaf(nz, rs.id.z, -rs.cN.z)), tmin);
+  const float tf = vmin2(vmin3(fmaf(fx, rs.idk.x, -rs.cF.x), fmaf(fy, rs.idk.y, -rs.cF.y), fmaf(fz, rs.idk.z, -rs.cF.z)), tmax);
   tn_out = tn;
   return m_le(tn, tf);
 }
@@ -718,6 +735,13 @@ __device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], 
 // uniform bookkeeping is written to stay short: 32-bit byte offsets for node / record addressing, a
 // fast path for nodes whose children are both inner nodes (no leaf or empty-child logic at all), and
 // nested uniform branches instead of combined predicates.
+#ifdef FFX_STATS
+// debug build only (-DFFX_STATS): per-launch totals of packet walks / node steps / triangle tests
+__device__ unsigned long long g_ffx_stats[16];
+#define FFX_STAT(i) do { if (threadIdx.x % 64 == 0) atomicAdd(&g_ffx_stats[i], 1ull); } while (0)
+#else
+#define FFX_STAT(i) do { } while (0)
+#endif
 template <bool ANY, int OCT>
 __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const RayOct &rb, v3 o, v3 d, float tmin,
                                                     float tmax, wmask active, Hit &h, bool &found) {
@@ -731,18 +755,22 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
   int cur = 0; // wave-uniform throughout: node fetches are scalar loads
   const char *nbase = reinterpret_cast<const char *>(nodes);
   const char *rbase = reinterpret_cast<const char *>(recs);
+  const RaySlab rs = make_rayslab(rb);
+  FFX_STAT(ANY ? 4 : 0);
   while (true) {
+    FFX_STAT(ANY ? 5 : 1);
     const float4 *n4 = reinterpret_cast<const float4 *>(nbase + ((uint32_t)cur << 6));
     const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
     const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
     const int c0 = ch.x, c1 = ch.y;
-    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
     float t0, t1;
     // both slabs unconditionally (one 64-byte fetch, no dependent branch)
-    wmask g0 = slab_oct<OCT>(lo0, hi0, rb, tmin, h.t, t0);
-    wmask g1 = slab_oct<OCT>(lo1, hi1, rb, tmin, h.t, t1);
+    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    wmask g0 = slab_oct<OCT>(lo0, hi0, rs, tmin, h.t, t0);
+    wmask g1 = slab_oct<OCT>(lo1, hi1, rs, tmin, h.t, t1);
     if ((c0 | c1) < 0) { // a leaf or an empty child on at least one side
+      FFX_STAT(ANY ? 12 : 8);
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         const int c = side ? c1 : c0;
@@ -755,6 +783,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
         const uint32_t first = lc >> 3, count = (lc & 7u) + 1u;
         uint32_t roff = first * 48u;
         for (uint32_t i = 0; i < count; ++i, roff += 48u) {
+          FFX_STAT(ANY ? 6 : 2);
           const float4 *r4 = reinterpret_cast<const float4 *>(rbase + roff);
           const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
           const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
@@ -769,6 +798,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
           const float Us = msel(neg, -U, U);
           const wmask p1 = hs & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
           if (p1 == 0ull) continue;
+          FFX_STAT(ANY ? 7 : 3);
           const v3 qv = vcross(tv, e1);
           const float Vv = vdot(d, qv);
           const float Vs = msel(neg, -Vv, Vv);
@@ -800,6 +830,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
     if (g0 != 0ull) {
       if (g1 != 0ull) {
         // both: visit first the child that most lanes enter first, push the other
+        FFX_STAT(ANY ? 13 : 9);
         const wmask lt = m_lt(t1, t0);
         const bool swap = wpop(g1 & (~g0 | lt)) > wpop(g0 & ~(g1 & lt));
         stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
@@ -812,6 +843,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
       cur = c1;
     } else {
       if (sp == 0) break;
+      FFX_STAT(ANY ? 14 : 10);
       --sp;
       cur = __builtin_amdgcn_readlane(stack_v, sp);
     }
@@ -1039,6 +1071,9 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
     q.ng = V3(0.f, 0.f, 1.f);
     q.Po = V3(0.f, 0.f, 0.f);
     q.ok = st[r].hit != 0;
+#ifdef FFX_EXPERIMENT_PRIMARY_ONLY // timing experiment: ray generation + primary walk only
+    q.ok = false;
+#endif
     if (q.ok) {
       const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
       float4 ra = r4[0], rb = r4[1], rc = r4[2];
@@ -1182,6 +1217,45 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
+}
+
+// K7 on the packet traversal.  A wavefront owns a compact block of bw x bh pixels with spp_w samples
+// each (bw * bh * spp_w = 64): 8x8 pixels at 1 spp ... one pixel at >= 64 spp (then it loops over the
+// pixel's samples 64 at a time).  Sample index and jitter are those of k_trace_primary.
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(FFX_PK1_WAVES, FFX_PK1_WAVES)))
+    k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, int spp, int jitter, uint32_t seed_key, int bw_log2,
+                       int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
+  const int blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (blk >= n_blocks) return; // whole wave
+  const int lane = threadIdx.x & 63;
+  const int ppw_log2 = bw_log2 + bh_log2; // pixels per wave (log2)
+  const int spp_w = 64 >> ppw_log2;       // samples of one pixel handled per pass
+  const int pl = lane >> (6 - ppw_log2);  // pixel of the block (0 when the wave is a single pixel)
+  const int sl = lane & (spp_w - 1);      // sample slot within the pass
+  const int x = ((blk % blocks_x) << bw_log2) + (pl & ((1 << bw_log2) - 1));
+  const int y = ((blk / blocks_x) << bh_log2) + (pl >> bw_log2);
+  const bool in_img = x < cam.W && y < cam.H;
+  const uint32_t pix = (uint32_t)y * (uint32_t)cam.W + (uint32_t)x;
+  const int passes = (spp + spp_w - 1) / spp_w;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int sidx = pass * spp_w + sl;
+    const bool active[1] = {in_img && sidx < spp};
+    const uint32_t idx = pix * (uint32_t)spp + (uint32_t)sidx;
+    float jx = 0.f, jy = 0.f;
+    if (jitter) sample_jitter(seed_key, idx, jx, jy);
+    v3 o[1], d[1];
+    float nt[1], ft[1];
+    cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o[0], d[0], nt[0], ft[0]);
+    Hit h[1];
+    bool fnd[1];
+    traverse_packet_any<false, 1>(nodes, recs, o, d, nt, ft, active, h, fnd);
+    if (active[0]) {
+      const bool hit = h[0].prim >= 0;
+      t_out[idx] = hit ? (h[0].t - nt[0]) : 0.f;
+      if (shape_out) shape_out[idx] = h[0].shape;
+      if (prim_out) prim_out[idx] = h[0].prim;
+    }
+  }
 }
 
 template <int R>
@@ -1559,6 +1633,16 @@ static inline size_t stack_bytes(const ffx_bvh_info *info) {
   return (size_t)depth * TR_BLOCK * sizeof(int);
 }
 
+#ifdef FFX_STATS
+extern "C" int ffx_debug_stats(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ffx_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 extern "C" {
 
 int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camera *cam, int spp, int jitter, uint32_t seed, float *t_out,
@@ -1571,6 +1655,19 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
   if (total >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "trace_primary: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  if (use_packet()) {
+    // pixels per wave: 64 / spp when spp divides 64 (a compact bw x bh block), else one pixel per wave
+    int ppw_log2 = 0;
+    if (spp < 64 && 64 % spp == 0)
+      while ((spp << (ppw_log2 + 1)) <= 64) ++ppw_log2;
+    const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
+    const int blocks_x = ffx_cdiv(k.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(k.H, 1 << bh_log2);
+    const int wpb = packet_waves();
+    hipLaunchKernelGGL(k_trace_primary_pk, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, spp, jitter, seed_key_of(seed),
+                       bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+    FFX_CHECK_LAUNCH("trace_primary");
+    return FFX_OK;
+  }
   hipLaunchKernelGGL(k_trace_primary, dim3(ffx_cdiv(total, TR_BLOCK)), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, k, nodes, recs, spp, jitter,
                      seed_key_of(seed), total, t_out, shape_out, prim_out);
   FFX_CHECK_LAUNCH("trace_primary");

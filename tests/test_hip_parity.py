@@ -239,6 +239,22 @@ def test_k7_trace_primary(oracle, cfg):
     assert (host(td)[miss] == 0).all() and (host(pd)[miss] == -1).all()
 
 
+@pytest.mark.parametrize("spp", [1, 3, 16, 64, 70])
+def test_k7_packet_layouts(oracle, spp, monkeypatch):
+    """Every wave layout of the packet K7 kernel (8x8 pixels x 1 sample ... 1 pixel x 64 samples,
+    a sample count that does not divide 64, more than one pass) and the per-lane kernel give the
+    oracle's hits at an image size that is not a multiple of the pixel block."""
+    sc = scenes.vocalfold(width=52, height=37, tex=64, frames=3, n_fold=16, tube=(24, 24))
+    go, gd, _ = _pair(oracle, sc, frame=1, xforms=_rand_xforms(len(sc.meshes), 4))
+    cam = scene_desc.camera_from_sensor(sc.camera)
+    to, so, po = go.trace_primary(cam, spp, 1, seed=3)
+    for mode in ("packet", "lane"):
+        monkeypatch.setenv("FFX_TRAVERSAL", mode)
+        td, sd_, pd = gd.trace_primary(cam, spp, 1, seed=3)
+        assert td.shape[0] == 52 * 37 * spp
+        _cmp_hits(td, sd_, pd, to, so, po, f"spp={spp} {mode}")
+
+
 def test_k7_trace_rays_laser(oracle):
     sc = scenes.vocalfold(width=64, height=64, frames=2, n_fold=32, tube=(32, 32))
     go, gd, _ = _pair(oracle, sc, frame=1)
