@@ -1051,12 +1051,24 @@ struct ShadePre {
 };
 
 // packet version of shade_sample for R samples per lane: every lane of the wave reaches every walk
+// The scene constants (ShadeK, ~100 dwords) are the first kernel argument of the render kernels.  Read
+// through `c` the compiler loads them all up front and, out of SGPRs, parks them in VGPR lanes
+// (v_writelane / v_readlane: ~480 spill instructions on the VALU, the unit that bounds these kernels).
+// kernarg_shade() hands out the same constants through a pointer the compiler cannot see through, so
+// each phase re-reads what it needs with scalar loads from the kernarg segment (no VALU work at all).
+__device__ __forceinline__ const ShadeK &kernarg_shade() {
+  const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const ShadeK *)p;
+}
+
 template <int R>
-__device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const bool (&active)[R],
+__device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const bool (&active)[R],
                                                 const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
   Hit h[R];
   bool fnd[R];
   traverse_packet_any<false, R>(nodes, recs, o, d, nt, ft, active, h, fnd);
+  const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
   bool any_p = false, any_s = false;
 #pragma unroll
@@ -1179,28 +1191,29 @@ __device__ __forceinline__ void shade_sample_pk(const ShadeK &c, const BvhNode *
     for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_s; s0[r] = 0.f; s1[r] = pre[r].ds_s * (1.0f - SHADOW_EPS); act[r] = pre[r].need_s; }
     traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_s);
   }
+  const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const ShadePre &q = pre[r];
     if (q.need_p && !occ_p[r]) {
       st[r].proj_fac = q.pfac;
-      float fx = fmaf(q.u, (float)c.tw, -0.5f), fy = fmaf(q.v, (float)c.th, -0.5f);
+      float fx = fmaf(q.u, (float)c2.tw, -0.5f), fy = fmaf(q.v, (float)c2.th, -0.5f);
       float x0 = floorf(fx), y0 = floorf(fy);
       float ax = fx - x0, ay = fy - y0;
       int ix0 = (int)x0, iy0 = (int)y0;
       st[r].ubx = ix0; st[r].uby = iy0;
-      st[r].ix0 = clampi(ix0, 0, c.tw - 1);
-      st[r].ix1 = clampi(ix0 + 1, 0, c.tw - 1);
-      st[r].iy0 = clampi(iy0, 0, c.th - 1);
-      st[r].iy1 = clampi(iy0 + 1, 0, c.th - 1);
+      st[r].ix0 = clampi(ix0, 0, c2.tw - 1);
+      st[r].ix1 = clampi(ix0 + 1, 0, c2.tw - 1);
+      st[r].iy0 = clampi(iy0, 0, c2.th - 1);
+      st[r].iy1 = clampi(iy0 + 1, 0, c2.th - 1);
       st[r].wx0 = 1.0f - ax; st[r].wx1 = ax;
       st[r].wy0 = 1.0f - ay; st[r].wy1 = ay;
       st[r].has_proj = 1;
     }
     if (q.need_s && !occ_s[r]) {
-      st[r].spot[0] = c.s_int[0] * q.sfac;
-      st[r].spot[1] = c.s_int[1] * q.sfac;
-      st[r].spot[2] = c.s_int[2] * q.sfac;
+      st[r].spot[0] = c2.s_int[0] * q.sfac;
+      st[r].spot[1] = c2.s_int[1] * q.sfac;
+      st[r].spot[2] = c2.s_int[2] * q.sfac;
     }
   }
 }
@@ -1278,7 +1291,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   // each wave of the workgroup owns its own tile; the waves never synchronise
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int W = c.cam.W, H = c.cam.H;
+  const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
   const int passes = (spp + 63) >> 6;
   const float inv_spp = 1.0f / (float)spp;
   for (int sub = 0; sub < NSUB; ++sub) {
@@ -1300,16 +1313,17 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       bool active[R];
       v3 o[R], d[R];
       float nt[R], ft[R];
+      const CamK &cam = kernarg_shade().cam; // phase: ray generation
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         active[r] = live[r] && s < spp;
         uint32_t idx = pix[r] * (uint32_t)spp + (uint32_t)s;
         float jx, jy;
         sample_jitter(seed_key, idx, jx, jy);
-        cam_ray(c.cam, ((float)px[r] + jx) * c.cam.inv_w, ((float)py[r] + jy) * c.cam.inv_h, o[r], d[r], nt[r], ft[r]);
+        cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(c, nodes, recs, active, o, d, nt, ft, st);
+      shade_sample_pk<R>(nodes, recs, active, o, d, nt, ft, st);
       if (cache) {
         // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
 #pragma unroll
@@ -1322,20 +1336,21 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
           cache[(size_t)pix[r] * (size_t)spp + (size_t)s] = rec;
         }
       }
+      const ShadeK &ct = kernarg_shade(); // phase: texture gather and accumulation
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit) continue;
         float r0 = st[r].spot[0], r1 = st[r].spot[1], r2 = st[r].spot[2];
         if (st[r].has_proj) {
-          const int tc = c.tc;
-          size_t o00 = ((size_t)st[r].iy0 * c.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * c.tw + st[r].ix1) * tc;
-          size_t o10 = ((size_t)st[r].iy1 * c.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * c.tw + st[r].ix1) * tc;
+          const int tc = ct.tc;
+          size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
+          size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
           const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1, pf = st[r].proj_fac;
           if (tc == 1) {
             float tv = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
-            r0 += tv * c.p_color[0] * pf;
-            r1 += tv * c.p_color[1] * pf;
-            r2 += tv * c.p_color[2] * pf;
+            r0 += tv * ct.p_color[0] * pf;
+            r1 += tv * ct.p_color[1] * pf;
+            r2 += tv * ct.p_color[2] * pf;
           } else {
             float tv0 = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
             float tv1 = wy0 * (wx0 * tex[o00 + 1] + wx1 * tex[o01 + 1]) + wy1 * (wx0 * tex[o10 + 1] + wx1 * tex[o11 + 1]);
@@ -1380,9 +1395,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   constexpr int NSUB = 4 / R;
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int W = c.cam.W, H = c.cam.H;
+  const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy; see kernarg_shade)
   const float inv_spp = 1.0f / (float)spp;
-  const int tc = c.tc;
   const int passes = (spp + 63) >> 6;
   for (int sub = 0; sub < NSUB; ++sub) {
     int px[R], py[R];
@@ -1405,25 +1419,28 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       bool active[R];
       v3 o[R], d[R];
       float nt[R], ft[R];
+      const CamK &cam = kernarg_shade().cam; // phase: ray generation
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         active[r] = live[r] && s < spp;
         uint32_t idx = pix[r] * (uint32_t)spp + (uint32_t)s;
         float jx, jy;
         sample_jitter(seed_key, idx, jx, jy);
-        cam_ray(c.cam, ((float)px[r] + jx) * c.cam.inv_w, ((float)py[r] + jy) * c.cam.inv_h, o[r], d[r], nt[r], ft[r]);
+        cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(c, nodes, recs, active, o, d, nt, ft, st);
+      shade_sample_pk<R>(nodes, recs, active, o, d, nt, ft, st);
+      const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
+      const int tc = ct.tc;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit || !st[r].has_proj) continue;
         const float *alb = albedo + 3 * st[r].shape;
-        size_t o00 = ((size_t)st[r].iy0 * c.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * c.tw + st[r].ix1) * tc;
-        size_t o10 = ((size_t)st[r].iy1 * c.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * c.tw + st[r].ix1) * tc;
+        size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
+        size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
         const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1;
         if (tc == 1) {
-          float ws = (g[r][0] * alb[0] * c.p_color[0] + g[r][1] * alb[1] * c.p_color[1] + g[r][2] * alb[2] * c.p_color[2]) * st[r].proj_fac * inv_spp;
+          float ws = (g[r][0] * alb[0] * ct.p_color[0] + g[r][1] * alb[1] * ct.p_color[1] + g[r][2] * alb[2] * ct.p_color[2]) * st[r].proj_fac * inv_spp;
           atomicAdd(gtex + o00, ws * wy0 * wx0);
           atomicAdd(gtex + o01, ws * wy0 * wx1);
           atomicAdd(gtex + o10, ws * wy1 * wx0);
