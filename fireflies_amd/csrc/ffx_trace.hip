@@ -497,6 +497,17 @@ __device__ __forceinline__ int writelane_i32(int val, int lane, int vec) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
   return vec;
 }
+// the same, updating the stack register in place (no copy of the whole VGPR around the push)
+__device__ __forceinline__ void push_lane(int &vec, int val, int lane) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
+}
+// dst = mask ? v : dst, in place (keeps a loop-carried value in one register across the branch that updates it)
+__device__ __forceinline__ void msel_into(float &dst, unsigned long long mask, float v) {
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(v), "s"(mask));
+}
+__device__ __forceinline__ void msel_into(int &dst, unsigned long long mask, int v) {
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(v), "s"(mask));
+}
 
 // branch-free Moller-Trumbore for the packet path: same arithmetic and acceptance rule as tri_hit(),
 // but every lane evaluates everything and the outcome is a predicate (no exec-mask branching inside
@@ -810,15 +821,15 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
           if (ANY) {
             const wmask occ = hit & m_lt(t, tmax);
             occluded |= occ;
-            h.t = msel(occ, -INFINITY, h.t);
+            msel_into(h.t, occ, -INFINITY);
           } else {
             // h.t <= tmax always and h.prim == -1 (the largest unsigned) until the first hit, so
             // (t <= tmax) & (no hit yet | t < h.t | (t == h.t & prim < h.prim)) reduces to:
             const wmask better = hit & (m_lt(t, h.t) | (m_eq(t, h.t) & m_ult((uint32_t)prim, (uint32_t)h.prim)));
-            h.t = msel(better, t, h.t);
-            h.prim = msel(better, prim, h.prim);
-            h.shape = msel(better, shape, h.shape);
-            h.slot = msel(better, (int)(first + i), h.slot);
+            msel_into(h.t, better, t);
+            msel_into(h.prim, better, prim);
+            msel_into(h.shape, better, shape);
+            msel_into(h.slot, better, (int)(first + i));
           }
         }
       }
@@ -833,7 +844,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
         FFX_STAT(ANY ? 13 : 9);
         const wmask lt = m_lt(t1, t0);
         const bool swap = wpop(g1 & (~g0 | lt)) > wpop(g0 & ~(g1 & lt));
-        stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
+        push_lane(stack_v, swap ? c0 : c1, sp);
         ++sp;
         cur = swap ? c1 : c0;
       } else {
@@ -1051,6 +1062,28 @@ struct ShadePre {
 };
 
 // packet version of shade_sample for R samples per lane: every lane of the wave reaches every walk
+// Reciprocal, quotient and square root of the shading terms: the hardware seed (v_rcp / v_sqrt / v_rsq,
+// 1 ulp) plus one fma Newton step.  The result equals the correctly rounded IEEE value except in rare
+// last-bit cases (Markstein), at 3 / 5 / 7 VALU instructions instead of the 10 / 10 / 14 of the
+// compiler's IEEE expansions (which also cover denormal and overflow ranges that cannot occur here:
+// arguments are lengths and depths of visible surface points).  Ray generation and the triangle test
+// keep the IEEE forms: they decide WHICH primitive is hit.
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+__device__ __forceinline__ float div_nr(float a, float b) {
+  const float r = rcp_nr(b);
+  const float q = a * r;
+  return fmaf(fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+  const float s1 = fmaf(fmaf(-s, s, x), h, s);
+  return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
+}
+
 // The scene constants (ShadeK, ~100 dwords) are the first kernel argument of the render kernels.  Read
 // through `c` the compiler loads them all up front and, out of SGPRs, parks them in VGPR lanes
 // (v_writelane / v_readlane: ~480 spill instructions on the VALU, the unit that bounds these kernels).
@@ -1091,10 +1124,10 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       float4 ra = r4[0], rb = r4[1], rc = r4[2];
       q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
       v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
-      float nl = sqrtf(vdot(ng, ng));
+      float nl = sqrt_nr(vdot(ng, ng));
       q.ok = nl > 0.f;
       if (q.ok) {
-        const float inl = 1.0f / nl;
+        const float inl = rcp_nr(nl);
         ng = V3(ng.x * inl, ng.y * inl, ng.z * inl);
         if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
         q.ng = ng;
@@ -1115,23 +1148,23 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         float qx = fmaf(m[0], pl.x, fmaf(m[1], pl.y, fmaf(m[2], pl.z, m[3])));
         float qy = fmaf(m[4], pl.x, fmaf(m[5], pl.y, fmaf(m[6], pl.z, m[7])));
         float qw = fmaf(m[12], pl.x, fmaf(m[13], pl.y, fmaf(m[14], pl.z, m[15])));
-        const float iqw = 1.0f / qw;
+        const float iqw = rcp_nr(qw);
         q.u = qx * iqw;
         q.v = qy * iqw;
         if (q.u >= 0.f && q.u <= 1.f && q.v >= 0.f && q.v <= 1.f) {
           v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
           v3 wi = vsub(ppos, q.P);
           float d2 = vdot(wi, wi);
-          const float idist = 1.0f / sqrtf(d2);
+          const float idist = rcp_nr(sqrt_nr(d2));
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float cos_s = vdot(q.ng, wi);
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
           if (cos_s > 0.f && cos_p > 0.f) {
             q.need_p = true;
-            q.pfac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+            q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p) * cos_s;
             v3 ws = vsub(ppos, q.Po);
-            q.ds_p = sqrtf(vdot(ws, ws));
-            const float ids = 1.0f / q.ds_p;
+            q.ds_p = sqrt_nr(vdot(ws, ws));
+            const float ids = rcp_nr(q.ds_p);
             q.ws_p = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           }
         }
@@ -1146,22 +1179,22 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
       v3 wi = vsub(spos, q.P);
       float d2 = vdot(wi, wi);
-      const float idist = 1.0f / sqrtf(d2);
+      const float idist = rcp_nr(sqrt_nr(d2));
       wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
       float cos_s = vdot(q.ng, wi);
       if (cos_s > 0.f) {
         v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
-        float ln = sqrtf(vdot(ll, ll));
-        float cos_t = ll.z / ln;
+        float ln = sqrt_nr(vdot(ll, ll));
+        float cos_t = div_nr(ll.z, ln);
         float fall = 0.f;
         if (cos_t >= c.cos_beam) fall = 1.f;
         else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
         if (fall > 0.f) {
           q.need_s = true;
-          q.sfac = fall * cos_s / d2 * 0.3183098861837907f;
+          q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
           v3 ws = vsub(spos, q.Po);
-          q.ds_s = sqrtf(vdot(ws, ws));
-          const float ids = 1.0f / q.ds_s;
+          q.ds_s = sqrt_nr(vdot(ws, ws));
+          const float ids = rcp_nr(q.ds_s);
           q.ws_s = V3(ws.x * ids, ws.y * ids, ws.z * ids);
         }
       }
