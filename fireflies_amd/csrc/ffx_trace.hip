@@ -681,7 +681,10 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
 #define FFX_OCTANT_LOOPS 1
 #endif
 #ifndef FFX_PK1_WAVES
-#define FFX_PK1_WAVES 8 // resident waves per SIMD the 1-ray packet kernels are register-budgeted for
+// resident waves per SIMD the 1-ray packet kernels are register-budgeted for.  7 -> 72 VGPRs / 94 SGPRs:
+// no spills at all (8 -> 64 / 78: a dozen VGPR spills per pixel = ~240 MB of scratch write-back per
+// render for 1% more speed; 6 is 6% slower)
+#define FFX_PK1_WAVES 7
 #endif
 __device__ __forceinline__ constexpr bool octant_loops() { return FFX_OCTANT_LOOPS != 0; }
 struct RayOct { v3 id, oidN, oidF; };
@@ -797,7 +800,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
           FFX_STAT(ANY ? 6 : 2);
           const float4 *r4 = reinterpret_cast<const float4 *>(rbase + roff);
           const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
-          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
+          const int prim = __float_as_int(rc.y); // (the shape id is read back from the record: h.slot)
           const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb4.x, rb4.y), e2 = V3(rb4.z, rb4.w, rc.x);
           // staged Moller-Trumbore with wave-uniform early-outs (same arithmetic and acceptance rule as tri_hit)
           const v3 pv = vcross(d, e2);
@@ -828,7 +831,6 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
             const wmask better = hit & (m_lt(t, h.t) | (m_eq(t, h.t) & m_ult((uint32_t)prim, (uint32_t)h.prim)));
             msel_into(h.t, better, t);
             msel_into(h.prim, better, prim);
-            msel_into(h.shape, better, shape);
             msel_into(h.slot, better, (int)(first + i));
           }
         }
@@ -1111,7 +1113,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     st[r].has_proj = 0;
     st[r].proj_fac = 0.f;
     st[r].spot[0] = st[r].spot[1] = st[r].spot[2] = 0.f;
-    st[r].shape = h[r].shape;
+    st[r].shape = -1; // read from the hit's triangle record below (the octant loops do not carry it)
     q.P = V3(0.f, 0.f, 0.f);
     q.ng = V3(0.f, 0.f, 1.f);
     q.Po = V3(0.f, 0.f, 0.f);
@@ -1122,6 +1124,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     if (q.ok) {
       const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
       float4 ra = r4[0], rb = r4[1], rc = r4[2];
+      st[r].shape = __float_as_int(rc.z);
       q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
       v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
       float nl = sqrt_nr(vdot(ng, ng));
@@ -1298,7 +1301,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     if (active[0]) {
       const bool hit = h[0].prim >= 0;
       t_out[idx] = hit ? (h[0].t - nt[0]) : 0.f;
-      if (shape_out) shape_out[idx] = h[0].shape;
+      if (shape_out) shape_out[idx] = hit ? recs[h[0].slot].shape : -1;
       if (prim_out) prim_out[idx] = h[0].prim;
     }
   }
@@ -1315,12 +1318,15 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, in
 }
 
 template <int R>
-// 1 ray per lane fits 64 VGPRs / 96 SGPRs (32 B of scratch): 8 waves per SIMD instead of 7 (measured -4 %)
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
                     const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img,
                     uint4 *__restrict__ cache) {
   constexpr int NSUB = 4 / R;
+  // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
+  // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
+  // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
+  __shared__ float s_acc[R][3][PK_BLOCK];
   // each wave of the workgroup owns its own tile; the waves never synchronise
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1332,13 +1338,12 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     packet_pixels<R>(tile, tiles_x, sub, px, py);
     bool live[R], any_live = false;
     uint32_t pix[R];
-    float acc[R][3];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       live[r] = tile < n_tiles && px[r] < W && py[r] < H;
       any_live |= live[r];
       pix[r] = (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r];
-      acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+      s_acc[r][0][threadIdx.x] = s_acc[r][1][threadIdx.x] = s_acc[r][2][threadIdx.x] = 0.f;
     }
     if (wballot(any_live) == 0ull) continue;
     for (int pass = 0; pass < passes; ++pass) {
@@ -1394,15 +1399,15 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
           }
         }
         const float *alb = albedo + 3 * st[r].shape;
-        acc[r][0] += alb[0] * r0;
-        acc[r][1] += alb[1] * r1;
-        acc[r][2] += alb[2] * r2;
+        s_acc[r][0][threadIdx.x] += alb[0] * r0;
+        s_acc[r][1][threadIdx.x] += alb[1] * r1;
+        s_acc[r][2][threadIdx.x] += alb[2] * r2;
       }
     }
     // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float a0 = wave_sum64(acc[r][0]), a1 = wave_sum64(acc[r][1]), a2 = wave_sum64(acc[r][2]);
+      float a0 = wave_sum64(s_acc[r][0][threadIdx.x]), a1 = wave_sum64(s_acc[r][1][threadIdx.x]), a2 = wave_sum64(s_acc[r][2][threadIdx.x]);
       if (lane == 0 && live[r]) {
         size_t o = (size_t)pix[r] * 3;
         if (fp16) {
