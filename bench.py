@@ -246,7 +246,7 @@ def main():
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
         },
         "roofline": {
-            "kernel": "k_render_fwd (ffx_render_fwd, K8)",
+            "kernel": "k_render_fwd_pk<1> (ffx_render_fwd, K8)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -258,7 +258,7 @@ def main():
             "avg_kernel_ms": k8_ms,
             "launches_timed": k8_n,
             "note": "by design NOT HBM-bound: samples are reduced in registers, so compulsory traffic is ~6 MB per render; the kernel is "
-                    "bound by BVH-traversal latency / VALU (SURVEY 8d). rays/s is the meaningful secondary figure.",
+                    "VALU-issue bound (SQ counters in profiles/r1_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
         },
         "kernels_ms": {"scene_update(K5+K6, all launches)": upd_ms, "render_fwd(K8)": k8_ms},
