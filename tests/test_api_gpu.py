@@ -239,6 +239,25 @@ def test_pattern_optimizer_runs_and_respects_constraints():
     np.testing.assert_allclose(losses, losses2, rtol=1e-4, atol=1e-6)
 
 
+def test_pattern_optimizer_explicit_adjoints_match_autograd():
+    """`step` (adjoint kernels called directly) and `step_autograd` (the same pipeline on
+    torch.autograd) follow the same trajectory; a generic task loss goes through autograd for the
+    loss only.  K9 accumulates with float atomics, hence a tolerance instead of bit equality."""
+    def custom(img):
+        return (img[..., 1] - 0.05).square().mean() + 0.1 * img[..., 0].mean()
+
+    for loss_fn in (None, custom):
+        runs = []
+        for which in ("step", "step_autograd"):
+            wl = _small()
+            kw = {} if loss_fn is None else {"loss_fn": loss_fn}
+            opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, samples_per_step=2, base_seed=5, **kw)
+            losses = [float(getattr(opt, which)()["loss"]) for _ in range(3)]
+            runs.append((losses, wl.laser._rays.detach().clone()))
+        np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(runs[0][1], runs[1][1], rtol=1e-5, atol=2e-6)
+
+
 def test_laser_yaml_roundtrip(tmp_path):
     wl = _small(randomize=False)
     f = tmp_path / "laser.yaml"
