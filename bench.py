@@ -88,6 +88,28 @@ def pmc_traffic(kernel_prefix, tag="r"):
     return best
 
 
+def valu_issue(kernel_substr, kernel_ms):
+    """Secondary, compute-side view of the dominant kernel (it is VALU-issue bound, which the contract's
+    hbm|mfma roofline cannot express): wave-level VALU instructions per launch from the committed SQ
+    counter pass (profiles/*_sq_instruction_mix.json, vocal-fold workload) over the live kernel time,
+    against 1024 SIMDs x one wave64 instruction per 4 cycles at the 2.4 GHz nominal clock."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_instruction_mix.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if kernel_substr in k and "SQ_INSTS_VALU" in v:
+                n = v["SQ_INSTS_VALU"]["mean"]
+                peak = 1024 * 2.4e9 / 4
+                ach = n / (kernel_ms * 1e-3)
+                return {"valu_wave_instr_per_launch": n, "achieved_Ginstr_per_s": ach / 1e9, "peak_Ginstr_per_s": peak / 1e9, "frac": ach / peak,
+                        "source": os.path.basename(f)}
+    return None
+
+
 def algorithmic_bytes(wl, width, height, fp16=False):
     """K8 render_fwd  B = G + 4*T + 3*s_r*W*H,  G = 12*V + 12*F + 32*N_nodes
     (V = vertices of one pose, F = triangles, N_nodes = BVH nodes, T = texels of the 1-channel
@@ -257,6 +279,7 @@ def main():
             "algorithmic_bytes_per_launch": bytes_["render_fwd"],
             "avg_kernel_ms": k8_ms,
             "launches_timed": k8_n,
+            "valu_issue": valu_issue("k_render_fwd_pk", k8_ms) if args.workload == "vocalfold" and W == 512 and args.spp == 64 else None,
             "note": "by design NOT HBM-bound: samples are reduced in registers, so compulsory traffic is ~6 MB per render; the kernel is "
                     "VALU-issue bound (SQ counters in profiles/r1_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),

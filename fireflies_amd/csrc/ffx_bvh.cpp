@@ -184,7 +184,7 @@ const char *ffx_backend(void) { return "hip-gfx950"; }
 
 size_t ffx_bvh_blob_bytes(int n_tris) {
   size_t f = n_tris < 1 ? 1 : (size_t)n_tris;
-  return 64 + f * sizeof(BvhNode) + f * 4 + f * 4 + 64 + (f + FFX_LEAF_MAX) * sizeof(TriRec) + 64;
+  return 64 + f * sizeof(BvhNode) + f * 4 + f * 4 + 64 + (f + FFX_LEAF_MAX) * sizeof(TriRec) + 64 + FFX_N_APEX * (size_t)ffx_apex_stride(n_tris < 1 ? 1 : n_tris);
 }
 
 int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int n_tris, void *blob, size_t blob_bytes, ffx_bvh_info *info) {
@@ -238,6 +238,8 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   off = (off + 63) & ~(uint64_t)63;
   info->off_recs = off;
   off += ((uint64_t)n_tris + FFX_LEAF_MAX) * sizeof(TriRec); // tail padding: leaf fetches always read FFX_LEAF_MAX records
+  off = (off + 63) & ~(uint64_t)63;
+  off += FFX_N_APEX * ffx_apex_stride(n_tris); // apex-record areas (ffx_common.h), zero until a render call fills them
   info->total_bytes = off;
   if (off > blob_bytes) FFX_FAIL(FFX_ERR_NOMEM, "bvh_build_host: internal size error");
   if (info->max_depth > FFX_STACK_DEPTH) FFX_FAIL(FFX_ERR_UNSUPPORTED, "bvh_build_host: tree depth %d exceeds the traversal stack", info->max_depth);

@@ -76,6 +76,26 @@ struct __attribute__((aligned(16))) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "record must be 48 bytes");
 
+// 48-byte APEX record: a triangle as seen from a fixed ray origin ("apex") o — the camera position for
+// primary rays, an emitter position for shadow rays (which are traced from the emitter towards the
+// surface).  With tv = o - v0 the Moller-Trumbore scalars of a ray (o, d) are three dot products,
+//     det = d . A,  U = d . B,  V = d . C,  t = T / det      A = e2 x e1, B = e2 x tv, C = tv x e1, T = e2 . C
+// (DESIGN.md §4.1).  Written per render call by k_apex_records into the apex areas at the end of the
+// blob; the oracle computes the same four quantities in the same order on the fly.
+struct __attribute__((aligned(16))) TriApex {
+  float A[3];
+  float B[3];
+  float C[3];
+  float T;
+  int32_t prim;
+  int32_t shape;
+};
+static_assert(sizeof(TriApex) == 48, "apex record must be 48 bytes");
+#define FFX_N_APEX 3 // 0 camera, 1 projector, 2 spot
+// byte stride of one apex area / offset of area k (they are the last FFX_N_APEX areas of the blob)
+static inline uint64_t ffx_apex_stride(int n_tris) { return ((((uint64_t)n_tris + FFX_LEAF_MAX) * 48u) + 63u) & ~(uint64_t)63; }
+static inline uint64_t ffx_apex_offset(const ffx_bvh_info *info, int k) { return info->total_bytes - (uint64_t)(FFX_N_APEX - k) * ffx_apex_stride(info->n_tris); }
+
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };
 

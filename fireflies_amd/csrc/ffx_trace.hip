@@ -98,10 +98,41 @@ __device__ __forceinline__ bool tri_hit(const TriRec *__restrict__ rec, v3 o, v3
   return true;
 }
 
+// The same test for rays that share their origin with a whole batch (primary rays: the camera; shadow
+// rays: the emitter they are traced from): Moller-Trumbore's scalars as three dot products with the
+// triangle's APEX vectors (ffx_common.h).  The apex vectors are formed here in the same order as in
+// k_apex_records and the oracle, so all three produce identical bits.
+struct ApexVec { v3 A, B, C; float T; };
+__device__ __forceinline__ ApexVec apex_vectors(v3 v0, v3 e1, v3 e2, v3 o) {
+  ApexVec a;
+  a.A = vcross(e2, e1);
+  const v3 tv = vsub(o, v0);
+  a.B = vcross(e2, tv);
+  a.C = vcross(tv, e1);
+  a.T = vdot(e2, a.C);
+  return a;
+}
+__device__ __forceinline__ bool tri_hit_apex(const TriRec *__restrict__ rec, v3 o, v3 d, float tmin, float &t_out, int &prim, int &shape) {
+  const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+  float4 a = r4[0], b = r4[1], c = r4[2];
+  const ApexVec av = apex_vectors(V3(a.x, a.y, a.z), V3(a.w, b.x, b.y), V3(b.z, b.w, c.x), o);
+  float det = vdot(d, av.A), U = vdot(d, av.B), Vv = vdot(d, av.C), T = av.T;
+  if (det < 0.f) { det = -det; U = -U; Vv = -Vv; T = -T; }
+  if (!(det > 0.f)) return false;
+  if (!(U >= 0.f) || !(Vv >= 0.f) || !(U + Vv <= det)) return false;
+  float t = T / det;
+  if (!(t > tmin)) return false;
+  t_out = t;
+  prim = __float_as_int(c.y);
+  shape = __float_as_int(c.z);
+  return true;
+}
+
 // ANY = false: closest hit in (tmin, tmax], ties broken by the smaller primitive id.
 // ANY = true : returns true as soon as a hit with tmin < t < tmax is found.
 // `stack` points at this lane's first slot; consecutive entries are `stride` ints apart.
-template <bool ANY>
+// APEX: the ray origin is a batch-wide apex (see tri_hit_apex); false for arbitrary rays.
+template <bool ANY, bool APEX>
 __device__ __forceinline__ bool traverse(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float tmin, float tmax, Hit &h,
                                          int *stack, int stride) {
   h.t = tmax;
@@ -130,7 +161,7 @@ __device__ __forceinline__ bool traverse(const BvhNode *__restrict__ nodes, cons
         for (int i = 0; i < count; ++i) {
           float t;
           int prim, shape;
-          if (tri_hit(recs + first + i, o, d, tmin, t, prim, shape)) {
+          if (APEX ? tri_hit_apex(recs + first + i, o, d, tmin, t, prim, shape) : tri_hit(recs + first + i, o, d, tmin, t, prim, shape)) {
             if (ANY) {
               if (t < tmax) return true;
             } else if (t <= tmax && (h.prim < 0 || t < h.t || (t == h.t && prim < h.prim))) {
@@ -203,7 +234,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
   float nt, ft;
   cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o, d, nt, ft);
   Hit h;
-  bool hit = traverse<false>(nodes, recs, o, d, nt, ft, h, s_stack + threadIdx.x, TR_BLOCK);
+  bool hit = traverse<false, true>(nodes, recs, o, d, nt, ft, h, s_stack + threadIdx.x, TR_BLOCK);
   t_out[idx] = hit ? (h.t - nt) : 0.f;
   if (shape_out) shape_out[idx] = h.shape;
   if (prim_out) prim_out[idx] = h.prim;
@@ -216,8 +247,8 @@ __global__ void __launch_bounds__(TR_BLOCK)
   int i = blockIdx.x * TR_BLOCK + threadIdx.x;
   if (i >= n) return;
   Hit h;
-  bool hit = traverse<false>(nodes, recs, V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.f, tmax, h,
-                             s_stack + threadIdx.x, TR_BLOCK);
+  bool hit = traverse<false, false>(nodes, recs, V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), 0.f, tmax, h,
+                                    s_stack + threadIdx.x, TR_BLOCK);
   t_out[i] = hit ? h.t : 0.f;
   if (shape_out) shape_out[i] = h.shape;
   if (prim_out) prim_out[i] = h.prim;
@@ -238,7 +269,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float nt,
                                              float ft, SampleTerms &st, int *stack, int stride) {
   Hit h;
-  st.hit = traverse<false>(nodes, recs, o, d, nt, ft, h, stack, stride);
+  st.hit = traverse<false, true>(nodes, recs, o, d, nt, ft, h, stack, stride);
   st.has_proj = 0;
   st.proj_fac = 0.f;
   st.spot[0] = st.spot[1] = st.spot[2] = 0.f;
@@ -276,13 +307,9 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
         if (cos_s > 0.f && cos_p > 0.f) {
           bool vis = true;
-          if (c.shadows) {
-            v3 ws = vsub(ppos, Po);
-            float ds = sqrtf(vdot(ws, ws));
-            const float ids = 1.0f / ds;
-            ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
+          if (c.shadows) { // traced FROM the emitter (the batch's apex) to the lifted surface point: t in (0, 1 - eps)
             Hit hs;
-            vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
+            vis = !traverse<true, true>(nodes, recs, ppos, vsub(Po, ppos), 0.f, 1.0f - SHADOW_EPS, hs, stack, stride);
           }
           if (vis) {
             st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
@@ -320,12 +347,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
       if (fall > 0.f) {
         bool vis = true;
         if (c.shadows) {
-          v3 ws = vsub(spos, Po);
-          float ds = sqrtf(vdot(ws, ws));
-          const float ids = 1.0f / ds;
-          ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           Hit hs;
-          vis = !traverse<true>(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS), hs, stack, stride);
+          vis = !traverse<true, true>(nodes, recs, spos, vsub(Po, spos), 0.f, 1.0f - SHADOW_EPS, hs, stack, stride);
         }
         if (vis) {
           float f = fall * cos_s / d2 * 0.3183098861837907f;
@@ -534,7 +557,7 @@ __device__ __forceinline__ bool tri_test_bf(const float4 a, const float4 b, cons
 // CU, is the tightest resource of this kernel), while the per-lane VALU work is simply repeated R times
 // with independent data (more ILP per wave).
 template <bool ANY, int R>
-__device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
+__device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
                                                 const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
   RayBox rb[R];
 #pragma unroll
@@ -577,21 +600,20 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
         for (int i = 0; i < count; ++i) {
           const float4 *r4 = reinterpret_cast<const float4 *>(recs + first + i);
           const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
-          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
-          const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb4.x, rb4.y), e2 = V3(rb4.z, rb4.w, rc.x);
-          // Moller-Trumbore in three stages with WAVE-UNIFORM early-outs (same arithmetic and acceptance
-          // rule as tri_hit): the rays of a packet nearly always fail together at the first barycentric
-          // test, so the second cross product, two dot products and the IEEE division are skipped for
-          // the whole wave.  (U <= det is implied by V >= 0 and U + V <= det.)
+          const int prim = __float_as_int(rc.z), shape = __float_as_int(rc.w);
+          // apex record: det = d.A, U = d.B, V = d.C, t = T/det (ffx_common.h)
+          const v3 A = V3(ra.x, ra.y, ra.z), B = V3(ra.w, rb4.x, rb4.y), C = V3(rb4.z, rb4.w, rc.x);
+          const float Tq = rc.y;
+          // three stages with WAVE-UNIFORM early-outs (same arithmetic and acceptance rule as
+          // tri_hit_apex): the rays of a packet nearly always fail together at the first barycentric
+          // test, so the remaining dot product and the IEEE division are skipped for the whole wave.
+          // (U <= det is implied by V >= 0 and U + V <= det.)
           bool p1[R], neg[R], any1 = false;
           float detA[R], Us[R];
-          v3 tv[R];
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const v3 pv = vcross(d[r], e2);
-            const float det = vdot(e1, pv);
-            tv[r] = vsub(o[r], v0);
-            const float U = vdot(tv[r], pv);
+            const float det = vdot(d[r], A);
+            const float U = vdot(d[r], B);
             neg[r] = det < 0.f;
             detA[r] = neg[r] ? -det : det;
             Us[r] = neg[r] ? -U : U;
@@ -600,11 +622,9 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
           }
           if (wballot(any1) == 0ull) continue;
           bool p2[R], any2 = false;
-          v3 qv[R];
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            qv[r] = vcross(tv[r], e1);
-            const float Vv = vdot(d[r], qv[r]);
+            const float Vv = vdot(d[r], C);
             const float Vs = neg[r] ? -Vv : Vv;
             p2[r] = p1[r] & (Vs >= 0.f) & (Us[r] + Vs <= detA[r]);
             any2 |= p2[r];
@@ -612,8 +632,7 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
           if (wballot(any2) == 0ull) continue;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            const float T = vdot(e2, qv[r]);
-            const float t = (neg[r] ? -T : T) / detA[r];
+            const float t = (neg[r] ? -Tq : Tq) / detA[r];
             const bool hit = p2[r] & (t > tmin[r]);
             if (ANY) {
               const bool occ = hit & (t < tmax[r]);
@@ -757,7 +776,7 @@ __device__ unsigned long long g_ffx_stats[16];
 #define FFX_STAT(i) do { } while (0)
 #endif
 template <bool ANY, int OCT>
-__device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const RayOct &rb, v3 o, v3 d, float tmin,
+__device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const RayOct &rb, v3 d, float tmin,
                                                     float tmax, wmask active, Hit &h, bool &found) {
   h.t = msel(active, tmax, -INFINITY); // an inactive ray fails every slab test
   h.prim = -1;
@@ -800,25 +819,23 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
           FFX_STAT(ANY ? 6 : 2);
           const float4 *r4 = reinterpret_cast<const float4 *>(rbase + roff);
           const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
-          const int prim = __float_as_int(rc.y); // (the shape id is read back from the record: h.slot)
-          const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb4.x, rb4.y), e2 = V3(rb4.z, rb4.w, rc.x);
-          // staged Moller-Trumbore with wave-uniform early-outs (same arithmetic and acceptance rule as tri_hit)
-          const v3 pv = vcross(d, e2);
-          const float det = vdot(e1, pv);
-          const v3 tv = vsub(o, v0);
-          const float U = vdot(tv, pv);
+          const int prim = __float_as_int(rc.z); // (the shape id is read back through h.slot)
+          // apex record: det = d.A, U = d.B, V = d.C, t = T/det; staged with wave-uniform early-outs
+          // (same arithmetic and acceptance rule as tri_hit_apex)
+          const v3 A = V3(ra.x, ra.y, ra.z), B = V3(ra.w, rb4.x, rb4.y), C = V3(rb4.z, rb4.w, rc.x);
+          const float det = vdot(d, A);
+          const float U = vdot(d, B);
           const wmask neg = m_lt(det, 0.f);
           const float detA = fabsf(det);
           const float Us = msel(neg, -U, U);
           const wmask p1 = hs & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
           if (p1 == 0ull) continue;
           FFX_STAT(ANY ? 7 : 3);
-          const v3 qv = vcross(tv, e1);
-          const float Vv = vdot(d, qv);
+          const float Vv = vdot(d, C);
           const float Vs = msel(neg, -Vv, Vv);
           const wmask p2 = p1 & m_ge(Vs, 0.f) & m_le(Us + Vs, detA);
           if (p2 == 0ull) continue;
-          const float T = vdot(e2, qv);
+          const float T = rc.y;
           const float t = msel(neg, -T, T) / detA;
           const wmask hit = p2 & m_gt(t, tmin);
           if (ANY) {
@@ -866,7 +883,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
 
 // one ray per lane: pick the octant loop if the packet's active rays agree on their direction signs
 template <bool ANY>
-__device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[1], const v3 (&d)[1],
+__device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[1], const v3 (&d)[1],
                                                  const float (&tmin)[1], const float (&tmax)[1], const bool (&active)[1], Hit (&h)[1], bool (&found)[1]) {
   const wmask am = wballot(active[0]);
   if (am == 0ull) { // nothing to trace
@@ -880,178 +897,27 @@ __device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nod
   const bool uniform = (am & __builtin_amdgcn_uicmp(oct, oct0, 33)) == 0ull;
   if (uniform) {
     switch (oct0) { // wave-uniform
-      case 0: traverse_packet_oct<ANY, 0>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 1: traverse_packet_oct<ANY, 1>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 2: traverse_packet_oct<ANY, 2>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 3: traverse_packet_oct<ANY, 3>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 4: traverse_packet_oct<ANY, 4>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 5: traverse_packet_oct<ANY, 5>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 6: traverse_packet_oct<ANY, 6>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      default: traverse_packet_oct<ANY, 7>(nodes, recs, rb, o[0], d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 0: traverse_packet_oct<ANY, 0>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 1: traverse_packet_oct<ANY, 1>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 2: traverse_packet_oct<ANY, 2>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 3: traverse_packet_oct<ANY, 3>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 4: traverse_packet_oct<ANY, 4>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 5: traverse_packet_oct<ANY, 5>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 6: traverse_packet_oct<ANY, 6>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      default: traverse_packet_oct<ANY, 7>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
     }
   } else {
     traverse_packet<ANY, 1>(nodes, recs, o, d, tmin, tmax, active, h, found);
   }
 }
 
-// ------------------------------------------------------------------------------------------ packed fp32, 2 rays per lane
-// On MI355X a plain v_fma_f32 issues at ~4 cycles per wave64 instruction; only PACKED fp32
-// (v_pk_add/mul/fma_f32) reaches the vector peak (profiles/r1_valu_issue_rates.txt), and this kernel is
-// VALU-issue bound.  With two rays per lane every subtract / multiply / fma of the slab and triangle
-// tests is ONE packed instruction on the pair (ray0, ray1); the uniform node plane or triangle
-// component sits in an SGPR and is broadcast to both halves through op_sel (no splat moves).
-// Each element is computed exactly like the scalar code (same operations, same order, IEEE fp32).
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct v3p { f2 x, y, z; };
-__device__ __forceinline__ f2 splat2(float s) { return (f2){s, s}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 diffprod2(f2 a, f2 b, f2 c, f2 d) { return fma2(a, b, -(c * d)); }
-__device__ __forceinline__ f2 vdot2(const v3p &a, const v3p &b) { return fma2(a.x, b.x, fma2(a.y, b.y, a.z * b.z)); }
-__device__ __forceinline__ v3p vcross2(const v3p &a, const v3p &b) {
-  v3p r;
-  r.x = diffprod2(a.y, b.z, a.z, b.y);
-  r.y = diffprod2(a.z, b.x, a.x, b.z);
-  r.z = diffprod2(a.x, b.y, a.y, b.x);
-  return r;
-}
-__device__ __forceinline__ v3p pack3(v3 a, v3 b) { v3p r; r.x = (f2){a.x, b.x}; r.y = (f2){a.y, b.y}; r.z = (f2){a.z, b.z}; return r; }
-__device__ __forceinline__ v3p splat3(v3 a) { v3p r; r.x = splat2(a.x); r.y = splat2(a.y); r.z = splat2(a.z); return r; }
-
-// slab test of one (uniform) box against the two rays of the lane; same formula as slab()
-__device__ __forceinline__ void slab2(const float lo[3], const float hi[3], const v3p &o, const v3p &id, f2 tmin, f2 tmax, f2 &tn, bool &hit0, bool &hit1) {
-  const f2 ax = (splat2(lo[0]) - o.x) * id.x, bx = (splat2(hi[0]) - o.x) * id.x;
-  const f2 ay = (splat2(lo[1]) - o.y) * id.y, by = (splat2(hi[1]) - o.y) * id.y;
-  const f2 az = (splat2(lo[2]) - o.z) * id.z, bz = (splat2(hi[2]) - o.z) * id.z;
-  f2 tf;
-  tn.x = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), tmin.x));
-  tn.y = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), tmin.y));
-  tf.x = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
-  tf.y = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
-  tf = tf * splat2(1.0000004f);
-  tf.x = fminf(tf.x, tmax.x);
-  tf.y = fminf(tf.y, tmax.y);
-  hit0 = tn.x <= tf.x;
-  hit1 = tn.y <= tf.y;
-}
-
-template <bool ANY>
-__device__ __forceinline__ void traverse_packet2(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o_)[2], const v3 (&d_)[2],
-                                                 const float (&tmin_)[2], const float (&tmax_)[2], const bool (&active)[2], Hit (&h)[2], bool (&found)[2]) {
-  const v3p o = pack3(o_[0], o_[1]), d = pack3(d_[0], d_[1]);
-  v3p id;
-  id.x = (f2){safe_rcp_dir(d_[0].x), safe_rcp_dir(d_[1].x)};
-  id.y = (f2){safe_rcp_dir(d_[0].y), safe_rcp_dir(d_[1].y)};
-  id.z = (f2){safe_rcp_dir(d_[0].z), safe_rcp_dir(d_[1].z)};
-  const f2 tmin = {tmin_[0], tmin_[1]};
-  f2 ht = {active[0] ? tmax_[0] : -INFINITY, active[1] ? tmax_[1] : -INFINITY}; // an inactive ray fails every slab test
-#pragma unroll
-  for (int r = 0; r < 2; ++r) { h[r].prim = -1; h[r].shape = -1; h[r].slot = -1; found[r] = false; }
-  int stack_v = 0;
-  int sp = 0;
-  int cur = 0;
-  while (true) {
-    cur = __builtin_amdgcn_readfirstlane(cur);
-    const float4 *n4 = reinterpret_cast<const float4 *>(nodes + cur);
-    const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
-    const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
-    const int c0 = ch.x, c1 = ch.y;
-    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-    f2 t0, t1;
-    bool h0[2], h1[2];
-    slab2(lo0, hi0, o, id, tmin, ht, t0, h0[0], h0[1]);
-    slab2(lo1, hi1, o, id, tmin, ht, t1, h1[0], h1[1]);
-    const bool v0 = c0 != FFX_EMPTY_CHILD, v1 = c1 != FFX_EMPTY_CHILD;
-    h0[0] &= v0; h0[1] &= v0; h1[0] &= v1; h1[1] &= v1;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int c = side ? c1 : c0;
-      const bool hs0 = side ? h1[0] : h0[0], hs1 = side ? h1[1] : h0[1];
-      if (c < 0 && c != FFX_EMPTY_CHILD && wballot(hs0 | hs1) != 0ull) { // wave-uniform
-        const uint32_t lc = (uint32_t)~c;
-        const int first = (int)(lc >> 3), count = (int)(lc & 7u) + 1;
-        for (int i = 0; i < count; ++i) {
-          const float4 *r4 = reinterpret_cast<const float4 *>(recs + first + i);
-          const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
-          const int prim = __float_as_int(rc.y), shape = __float_as_int(rc.z);
-          const v3p v0p = splat3(V3(ra.x, ra.y, ra.z)), e1 = splat3(V3(ra.w, rb4.x, rb4.y)), e2 = splat3(V3(rb4.z, rb4.w, rc.x));
-          // stage 1 (packed): pv = d x e2, det = e1 . pv, tv = o - v0, U = tv . pv
-          const v3p pv = vcross2(d, e2);
-          const f2 det = vdot2(e1, pv);
-          v3p tv;
-          tv.x = o.x - v0p.x; tv.y = o.y - v0p.y; tv.z = o.z - v0p.z;
-          const f2 U = vdot2(tv, pv);
-          const bool n0 = det.x < 0.f, n1 = det.y < 0.f;
-          const f2 detA = {n0 ? -det.x : det.x, n1 ? -det.y : det.y};
-          const f2 Us = {n0 ? -U.x : U.x, n1 ? -U.y : U.y};
-          const bool p10 = hs0 & (detA.x > 0.f) & (Us.x >= 0.f) & (Us.x <= detA.x);
-          const bool p11 = hs1 & (detA.y > 0.f) & (Us.y >= 0.f) & (Us.y <= detA.y);
-          if (wballot(p10 | p11) == 0ull) continue;
-          // stage 2 (packed): qv = tv x e1, V = d . qv
-          const v3p qv = vcross2(tv, e1);
-          const f2 Vv = vdot2(d, qv);
-          const f2 Vs = {n0 ? -Vv.x : Vv.x, n1 ? -Vv.y : Vv.y};
-          const f2 UV = Us + Vs;
-          const bool p20 = p10 & (Vs.x >= 0.f) & (UV.x <= detA.x);
-          const bool p21 = p11 & (Vs.y >= 0.f) & (UV.y <= detA.y);
-          if (wballot(p20 | p21) == 0ull) continue;
-          // stage 3: T = e2 . qv, t = T / det (IEEE division, per element)
-          const f2 T = vdot2(e2, qv);
-          const float tt[2] = {(n0 ? -T.x : T.x) / detA.x, (n1 ? -T.y : T.y) / detA.y};
-          const bool p2[2] = {p20, p21};
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const float t = tt[r];
-            const float cur_t = r ? ht.y : ht.x;
-            const bool hit = p2[r] & (t > tmin_[r]);
-            bool upd;
-            if (ANY) {
-              upd = hit & (t < tmax_[r]);
-              found[r] = found[r] | upd;
-            } else {
-              upd = hit & (t <= tmax_[r]) & ((h[r].prim < 0) | (t < cur_t) | ((t == cur_t) & (prim < h[r].prim)));
-              h[r].prim = upd ? prim : h[r].prim;
-              h[r].shape = upd ? shape : h[r].shape;
-              h[r].slot = upd ? first + i : h[r].slot;
-            }
-            const float nt = ANY ? -INFINITY : t;
-            if (r) ht.y = upd ? nt : ht.y; else ht.x = upd ? nt : ht.x;
-          }
-        }
-      }
-    }
-    if (ANY && wballot((active[0] & !found[0]) | (active[1] & !found[1])) == 0ull) break; // every ray is decided
-    const bool a00 = h0[0] & (c0 >= 0) & (t0.x <= ht.x), a01 = h0[1] & (c0 >= 0) & (t0.y <= ht.y);
-    const bool a10 = h1[0] & (c1 >= 0) & (t1.x <= ht.x), a11 = h1[1] & (c1 >= 0) & (t1.y <= ht.y);
-    const unsigned long long m0 = wballot(a00 | a01), m1 = wballot(a10 | a11);
-    if (m0 != 0ull && m1 != 0ull) {
-      const bool first1 = (a10 & (!a00 | (t1.x < t0.x))) | (a11 & (!a01 | (t1.y < t0.y)));
-      const bool first0 = (a00 & (!a10 | (t0.x <= t1.x))) | (a01 & (!a11 | (t0.y <= t1.y)));
-      const bool swap = wpop(wballot(first1)) > wpop(wballot(first0));
-      stack_v = writelane_i32(swap ? c0 : c1, sp, stack_v);
-      ++sp;
-      cur = swap ? c1 : c0;
-    } else if (m0 != 0ull) {
-      cur = c0;
-    } else if (m1 != 0ull) {
-      cur = c1;
-    } else {
-      if (sp == 0) break;
-      --sp;
-      cur = __builtin_amdgcn_readlane(stack_v, sp);
-    }
-  }
-  h[0].t = ht.x;
-  h[1].t = ht.y;
-}
-
-// dispatch: the packed implementation for 2 rays per lane, the generic one otherwise
+// dispatch: the octant loops for one ray per lane, the generic loop otherwise.  All packet walks are
+// APEX walks (their rays share the origin o_apex whose records `arecs` were written by k_apex_records).
 template <bool ANY, int R>
-__device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
+__device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ arecs, const v3 (&o)[R], const v3 (&d)[R],
                                                     const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
-  if constexpr (R == 2) traverse_packet2<ANY>(nodes, recs, o, d, tmin, tmax, active, h, found);
-  else if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, recs, o, d, tmin, tmax, active, h, found);
-  else traverse_packet<ANY, R>(nodes, recs, o, d, tmin, tmax, active, h, found);
+  if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, arecs, o, d, tmin, tmax, active, h, found);
+  else traverse_packet<ANY, R>(nodes, arecs, o, d, tmin, tmax, active, h, found);
 }
 
 // per-sample shading state between the three packet walks
@@ -1059,8 +925,6 @@ struct ShadePre {
   bool ok, need_p, need_s;
   v3 P, ng, Po;
   float pfac, u, v, sfac;
-  v3 ws_p, ws_s;
-  float ds_p, ds_s;
 };
 
 // packet version of shade_sample for R samples per lane: every lane of the wave reaches every walk
@@ -1098,11 +962,12 @@ __device__ __forceinline__ const ShadeK &kernarg_shade() {
 }
 
 template <int R>
-__device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const bool (&active)[R],
-                                                const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
+__device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
+                                                uint32_t astride, const bool (&active)[R], const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R],
+                                                const float (&ft)[R], SampleTerms (&st)[R]) {
   Hit h[R];
   bool fnd[R];
-  traverse_packet_any<false, R>(nodes, recs, o, d, nt, ft, active, h, fnd);
+  traverse_packet_any<false, R>(nodes, arecs, o, d, nt, ft, active, h, fnd); // apex 0: the camera
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
   bool any_p = false, any_s = false;
@@ -1142,8 +1007,6 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     // ---- projector terms
     q.need_p = false;
     q.pfac = 0.f; q.u = 0.f; q.v = 0.f;
-    q.ws_p = V3(0.f, 0.f, 1.f);
-    q.ds_p = 1.f;
     if (c.proj_on && q.ok) {
       v3 pl = xf_point(c.p_w2l, q.P);
       if (pl.z > 0.f) {
@@ -1165,10 +1028,6 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           if (cos_s > 0.f && cos_p > 0.f) {
             q.need_p = true;
             q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p) * cos_s;
-            v3 ws = vsub(ppos, q.Po);
-            q.ds_p = sqrt_nr(vdot(ws, ws));
-            const float ids = rcp_nr(q.ds_p);
-            q.ws_p = V3(ws.x * ids, ws.y * ids, ws.z * ids);
           }
         }
       }
@@ -1176,8 +1035,6 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     // ---- spot terms
     q.need_s = false;
     q.sfac = 0.f;
-    q.ws_s = V3(0.f, 0.f, 1.f);
-    q.ds_s = 1.f;
     if (c.spot_on && q.ok) {
       v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
       v3 wi = vsub(spos, q.P);
@@ -1195,37 +1052,38 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         if (fall > 0.f) {
           q.need_s = true;
           q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
-          v3 ws = vsub(spos, q.Po);
-          q.ds_s = sqrt_nr(vdot(ws, ws));
-          const float ids = rcp_nr(q.ds_s);
-          q.ws_s = V3(ws.x * ids, ws.y * ids, ws.z * ids);
         }
       }
     }
     any_p |= q.need_p;
     any_s |= q.need_s;
   }
-  // ---- shadow walks (wave-uniform decisions)
+  // ---- shadow walks (wave-uniform decisions).  A shadow ray is traced FROM the emitter — the apex its
+  // triangle records were prepared for — to the lifted surface point: o = emitter, d = Po - emitter,
+  // occluded iff some triangle is hit at 0 < t < 1 - eps.  No normalisation, and the packet's rays share
+  // their origin exactly.
   bool occ_p[R], occ_s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) occ_p[r] = occ_s[r] = false;
   if (c.shadows && wballot(any_p) != 0ull) {
+    const v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
     v3 so[R], sdir[R];
     float s0[R], s1[R];
     bool act[R];
     Hit hs[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_p; s0[r] = 0.f; s1[r] = pre[r].ds_p * (1.0f - SHADOW_EPS); act[r] = pre[r].need_p; }
-    traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_p);
+    for (int r = 0; r < R; ++r) { so[r] = ppos; sdir[r] = vsub(pre[r].Po, ppos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_p; }
+    traverse_packet_any<true, R>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride), so, sdir, s0, s1, act, hs, occ_p);
   }
   if (c.shadows && wballot(any_s) != 0ull) {
+    const v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
     v3 so[R], sdir[R];
     float s0[R], s1[R];
     bool act[R];
     Hit hs[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { so[r] = pre[r].Po; sdir[r] = pre[r].ws_s; s0[r] = 0.f; s1[r] = pre[r].ds_s * (1.0f - SHADOW_EPS); act[r] = pre[r].need_s; }
-    traverse_packet_any<true, R>(nodes, recs, so, sdir, s0, s1, act, hs, occ_s);
+    for (int r = 0; r < R; ++r) { so[r] = spos; sdir[r] = vsub(pre[r].Po, spos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_s; }
+    traverse_packet_any<true, R>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride), so, sdir, s0, s1, act, hs, occ_s);
   }
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
 #pragma unroll
@@ -1272,7 +1130,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // each (bw * bh * spp_w = 64): 8x8 pixels at 1 spp ... one pixel at >= 64 spp (then it loops over the
 // pixel's samples 64 at a time).  Sample index and jitter are those of k_trace_primary.
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(FFX_PK1_WAVES, FFX_PK1_WAVES)))
-    k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, int spp, int jitter, uint32_t seed_key, int bw_log2,
+    k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, int spp, int jitter,
+                       uint32_t seed_key, int bw_log2,
                        int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
   const int blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (blk >= n_blocks) return; // whole wave
@@ -1297,7 +1156,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o[0], d[0], nt[0], ft[0]);
     Hit h[1];
     bool fnd[1];
-    traverse_packet_any<false, 1>(nodes, recs, o, d, nt, ft, active, h, fnd);
+    traverse_packet_any<false, 1>(nodes, arecs, o, d, nt, ft, active, h, fnd);
     if (active[0]) {
       const bool hit = h[0].prim >= 0;
       t_out[idx] = hit ? (h[0].t - nt[0]) : 0.f;
@@ -1319,9 +1178,9 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, in
 
 template <int R>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
-    k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
-                    const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img,
-                    uint4 *__restrict__ cache) {
+    k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
+                    const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16,
+                    void *__restrict__ img, uint4 *__restrict__ cache) {
   constexpr int NSUB = 4 / R;
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
@@ -1361,7 +1220,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(nodes, recs, active, o, d, nt, ft, st);
+      shade_sample_pk<R>(nodes, recs, arecs, astride, active, o, d, nt, ft, st);
       if (cache) {
         // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
 #pragma unroll
@@ -1428,8 +1287,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 
 template <int R>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
-    k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
-                    uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
+    k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
+                    const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg,
+                    float *__restrict__ gtex) {
   constexpr int NSUB = 4 / R;
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1467,7 +1327,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(nodes, recs, active, o, d, nt, ft, st);
+      shade_sample_pk<R>(nodes, recs, arecs, astride, active, o, d, nt, ft, st);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
@@ -1639,19 +1499,34 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   return 1;
 }
 
+// Apex records (ffx_common.h): one lane per leaf slot writes the triangle's (A, B, C, T) for each of the
+// requested apexes.  Runs in front of every packet render / trace launch on the same stream: the apex
+// areas at the end of the blob are scratch owned by the most recent call (calls that share a blob must
+// be stream-ordered, as they already are for the records themselves).  53 k triangles x 3 apexes: 7.7 MB.
+struct ApexK { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; };
+__global__ void __launch_bounds__(256)
+    k_apex_records(const TriRec *__restrict__ recs, int n_tris, ApexK ak, TriApex *__restrict__ out, uint32_t astride) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_tris) return;
+  const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
+  const float4 a = r4[0], b = r4[1], c = r4[2];
+  const v3 v0 = V3(a.x, a.y, a.z), e1 = V3(a.w, b.x, b.y), e2 = V3(b.z, b.w, c.x);
+#pragma unroll
+  for (int j = 0; j < FFX_N_APEX; ++j) {
+    if (!ak.on[j]) continue;
+    const ApexVec av = apex_vectors(v0, e1, e2, V3(ak.o[j][0], ak.o[j][1], ak.o[j][2]));
+    float4 *o4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(out) + (size_t)j * astride) + 3 * (size_t)k;
+    o4[0] = make_float4(av.A.x, av.A.y, av.A.z, av.B.x);
+    o4[1] = make_float4(av.B.y, av.B.z, av.C.x, av.C.y);
+    o4[2] = make_float4(av.C.z, av.T, c.y, c.z); // prim, shape as in TriRec
+  }
+}
+
 // FFX_TRAVERSAL=lane selects the per-lane (LDS stack) kernels; default: wave-packet kernels
 // (the knobs are read at every launch: cheap, and lets one process exercise every variant)
 static int use_packet() {
   const char *e = getenv("FFX_TRAVERSAL");
   return (e && strcmp(e, "lane") == 0) ? 0 : 1;
-}
-
-// rays per lane of the packet kernels: FFX_RAYS = 1 (default) or 2 (packed-fp32 variant; measured
-// 2.14 ms vs 1.93 ms for K8: hipcc needs s_mov/s_nop sequences around SGPR-operand packed ops)
-static int packet_rays() {
-  const char *e = getenv("FFX_RAYS");
-  int r = e ? atoi(e) : 1;
-  return (r == 1 || r == 2) ? r : 1;
 }
 
 // independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
@@ -1667,6 +1542,34 @@ static int packet_waves() {
 static size_t dummy_lds() {
   const char *e = getenv("FFX_DUMMY_LDS");
   return e ? (size_t)atol(e) : 0;
+}
+
+// fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
+static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *cam_to_world, const ffx_scene_desc *sd, const TriApex **arecs,
+                       uint32_t *astride, hipStream_t s) {
+  ApexK ak;
+  memset(&ak, 0, sizeof ak);
+  ak.on[0] = 1;
+  ak.o[0][0] = cam_to_world[3]; ak.o[0][1] = cam_to_world[7]; ak.o[0][2] = cam_to_world[11];
+  if (sd && sd->proj.enabled) {
+    ak.on[1] = 1;
+    ak.o[1][0] = sd->proj.to_world[3]; ak.o[1][1] = sd->proj.to_world[7]; ak.o[1][2] = sd->proj.to_world[11];
+  }
+  if (sd && sd->spot.enabled) {
+    ak.on[2] = 1;
+    ak.o[2][0] = sd->spot.to_world[3]; ak.o[2][1] = sd->spot.to_world[7]; ak.o[2][2] = sd->spot.to_world[11];
+  }
+  const uint64_t stride = ffx_apex_stride(info->n_tris);
+  if (info->total_bytes < info->off_recs + FFX_N_APEX * stride || stride >= (1ull << 32)) {
+    ffx_set_error("blob has no apex areas (built by another library version?)");
+    return 0;
+  }
+  TriApex *out = (TriApex *)((char *)bvh + ffx_apex_offset(info, 0));
+  const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride);
+  *arecs = out;
+  *astride = (uint32_t)stride;
+  return 1;
 }
 
 static int xcd_mode() {
@@ -1718,8 +1621,11 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
     const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
     const int blocks_x = ffx_cdiv(k.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(k.H, 1 << bh_log2);
     const int wpb = packet_waves();
-    hipLaunchKernelGGL(k_trace_primary_pk, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, spp, jitter, seed_key_of(seed),
-                       bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+    const TriApex *arecs;
+    uint32_t astride;
+    if (!launch_apex(bvh, info, cam->to_world, nullptr, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    hipLaunchKernelGGL(k_trace_primary_pk, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, spp, jitter,
+                       seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
     FFX_CHECK_LAUNCH("trace_primary");
     return FFX_OK;
   }
@@ -1759,12 +1665,11 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
-    if (packet_rays() == 1)
-      hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
-    else
-      hipLaunchKernelGGL(k_render_fwd_pk<2>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp, seed_key_of(seed), ptx,
-                         pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
+    const TriApex *arecs;
+    uint32_t astride;
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, shape_albedo, tex, spp,
+                       seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -1820,12 +1725,11 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8;
-    if (packet_rays() == 1)
-      hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg,
-                         gtex);
-    else
-      hipLaunchKernelGGL(k_render_bwd_pk<2>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg,
-                         gtex);
+    const TriApex *arecs;
+    uint32_t astride;
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, shape_albedo, spp, seed_key_of(seed), ptx,
+                       pn, xcd_mode(), gimg, gtex);
     FFX_CHECK_LAUNCH("render_bwd");
     return FFX_OK;
   }

@@ -152,7 +152,10 @@ typedef struct ffx_bvh_info {
   int32_t level_start[FFX_MAX_LEVELS + 1]; /* ranges into the refit list, leaves-first */
 } ffx_bvh_info;
 
-/* upper bound of the blob size for n_tris triangles */
+/* upper bound of the blob size for n_tris triangles.  The blob ends with scratch areas ("apex records",
+ * DESIGN.md 4.1) that ffx_trace_primary / ffx_render_* rewrite on every call on their stream: calls that
+ * share a blob must be stream-ordered, and the blob they take as `const void *` is const in its
+ * topology and triangle records only. */
 size_t ffx_bvh_blob_bytes(int n_tris);
 /* Host-side topology build (binned SAH).  tris are *global* vertex indices into verts. */
 int ffx_bvh_build_host(const float *verts /*[host][n_verts,3]*/, int n_verts,

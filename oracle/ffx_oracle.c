@@ -632,6 +632,28 @@ static inline int tri_hit(const orec *r, v3 o, v3 d, float tmin, float *t_out) {
   return 1;
 }
 
+/* The same test for rays that share their origin with a whole batch (the camera for primary rays, the
+ * emitter for shadow rays, which are traced from the emitter towards the surface): Moller-Trumbore's
+ * scalars as three dot products with the triangle's apex vectors,
+ *     det = d.A, U = d.B, V = d.C, t = T/det      A = e2 x e1, B = e2 x tv, C = tv x e1, T = e2.C, tv = o - v0.
+ * The HIP library precomputes (A, B, C, T) per (triangle, apex) in this operation order (k_apex_records). */
+static inline int tri_hit_apex(const orec *r, v3 o, v3 d, float tmin, float *t_out) {
+  v3 e1 = V3(r->e1[0], r->e1[1], r->e1[2]), e2 = V3(r->e2[0], r->e2[1], r->e2[2]);
+  v3 A = vcross(e2, e1);
+  v3 tv = vsub(o, V3(r->v0[0], r->v0[1], r->v0[2]));
+  v3 B = vcross(e2, tv);
+  v3 Cv = vcross(tv, e1);
+  float T = vdot(e2, Cv);
+  float det = vdot(d, A), U = vdot(d, B), Vv = vdot(d, Cv);
+  if (det < 0.f) { det = -det; U = -U; Vv = -Vv; T = -T; }
+  if (!(det > 0.f)) return 0;
+  if (!(U >= 0.f) || !(Vv >= 0.f) || !(U + Vv <= det)) return 0;
+  float t = T / det;
+  if (!(t > tmin)) return 0;
+  *t_out = t;
+  return 1;
+}
+
 static inline int box_hit(const onode *nd, v3 o, v3 id, float tmin, float tmax) {
   float t0 = tmin, t1 = tmax;
   const float oo[3] = {o.x, o.y, o.z}, ii[3] = {id.x, id.y, id.z};
@@ -646,7 +668,8 @@ static inline int box_hit(const onode *nd, v3 o, v3 id, float tmin, float tmax) 
   return t0 <= t1;
 }
 
-static void closest_hit(const onode *nodes, const orec *recs, v3 o, v3 d, float tmin, float tmax, hit_t *h) {
+/* apex != 0: o is a batch-wide ray origin (tri_hit_apex); 0: arbitrary rays (tri_hit) */
+static void closest_hit(const onode *nodes, const orec *recs, v3 o, v3 d, float tmin, float tmax, int apex, hit_t *h) {
   h->t = tmax;
   h->prim = -1;
   h->shape = -1;
@@ -661,7 +684,7 @@ static void closest_hit(const onode *nodes, const orec *recs, v3 o, v3 d, float 
       for (int i = 0; i < nd->count; ++i) {
         const orec *r = &recs[nd->first + i];
         float t;
-        if (tri_hit(r, o, d, tmin, &t)) {
+        if (apex ? tri_hit_apex(r, o, d, tmin, &t) : tri_hit(r, o, d, tmin, &t)) {
           if (t <= tmax && (h->prim < 0 || t < h->t || (t == h->t && r->prim < h->prim))) {
             h->t = t; h->prim = r->prim; h->shape = r->shape; h->slot = nd->first + i;
           }
@@ -674,7 +697,7 @@ static void closest_hit(const onode *nodes, const orec *recs, v3 o, v3 d, float 
   }
 }
 
-/* any hit with tmin < t < tmax */
+/* any hit with tmin < t < tmax; o is the apex of the shadow rays (the emitter) */
 static int occluded(const onode *nodes, const orec *recs, v3 o, v3 d, float tmin, float tmax) {
   v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int stack[128], sp = 0;
@@ -685,7 +708,7 @@ static int occluded(const onode *nodes, const orec *recs, v3 o, v3 d, float tmin
     if (nd->left < 0) {
       for (int i = 0; i < nd->count; ++i) {
         float t;
-        if (tri_hit(&recs[nd->first + i], o, d, tmin, &t) && t < tmax) return 1;
+        if (tri_hit_apex(&recs[nd->first + i], o, d, tmin, &t) && t < tmax) return 1;
       }
     } else {
       stack[sp++] = nd->left;
@@ -761,7 +784,7 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
     float nt, ft;
     cam_ray(&k, ((float)x + jx) * k.inv_w, ((float)y + jy) * k.inv_h, &d, &nt, &ft);
     hit_t h;
-    closest_hit(nodes, recs, k.o, d, nt, ft, &h);
+    closest_hit(nodes, recs, k.o, d, nt, ft, 1, &h);
     t_out[idx] = (h.prim >= 0) ? (h.t - nt) : 0.f; /* depth.py:81-84 */
     if (shape_out) shape_out[idx] = h.shape;
     if (prim_out) prim_out[idx] = h.prim;
@@ -781,7 +804,7 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
   for (int i = 0; i < n; ++i) {
     hit_t h;
     closest_hit(nodes, recs, V3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), V3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), 0.f,
-                tmax, &h);
+                tmax, 0, &h);
     t_out[i] = (h.prim >= 0) ? h.t : 0.f;
     if (shape_out) shape_out[i] = h.shape;
     if (prim_out) prim_out[i] = h.prim;
@@ -842,7 +865,7 @@ typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, ub
 
 static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *recs, v3 o, v3 d, float nt, float ft, sample_terms *st) {
   hit_t h;
-  closest_hit(nodes, recs, o, d, nt, ft, &h);
+  closest_hit(nodes, recs, o, d, nt, ft, 1, &h);
   st->hit = h.prim >= 0;
   st->has_proj = 0;
   st->proj_fac = 0.f;
@@ -879,13 +902,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         float cos_p = -vdot(c->p_axis, wi);
         if (cos_s > 0.f && cos_p > 0.f) {
           int vis = 1;
-          if (c->shadows) {
-            v3 ws = vsub(c->p_pos, Po);
-            float ds = sqrtf(vdot(ws, ws));
-            const float ids = 1.0f / ds;
-            ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
-            vis = !occluded(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS));
-          }
+          if (c->shadows) /* traced FROM the emitter to the lifted surface point: 0 < t < 1 - eps */
+            vis = !occluded(nodes, recs, c->p_pos, vsub(Po, c->p_pos), 0.f, 1.0f - SHADOW_EPS);
           if (vis) {
             /* irradiance texture * pi*scale / (z_l^2 * cos_p) [EXT Mitsuba projector], Lambert
                albedo/pi * cos_s: pi cancels */
@@ -923,13 +941,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
       else if (cos_t > c->cos_cut) fall = (c->cutoff - acosf(cos_t)) * c->inv_trans;
       if (fall > 0.f) {
         int vis = 1;
-        if (c->shadows) {
-          v3 ws = vsub(c->s_pos, Po);
-          float ds = sqrtf(vdot(ws, ws));
-          const float ids = 1.0f / ds;
-          ws = V3(ws.x * ids, ws.y * ids, ws.z * ids);
-          vis = !occluded(nodes, recs, Po, ws, 0.f, ds * (1.0f - SHADOW_EPS));
-        }
+        if (c->shadows) vis = !occluded(nodes, recs, c->s_pos, vsub(Po, c->s_pos), 0.f, 1.0f - SHADOW_EPS);
         if (vis) {
           float f = fall * cos_s / d2 * 0.3183098861837907f; /* Lambert 1/pi */
           for (int ch = 0; ch < 3; ++ch) st->spot_rgb[ch] = c->s_int[ch] * f;
