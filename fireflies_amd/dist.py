@@ -25,7 +25,17 @@ def init(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        td.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this driver
+        kw = {}
+        if backend == "nccl":
+            # one process per GPU: bind the communicator to this rank's device up front
+            n = max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local % n)
+            kw["device_id"] = torch.device("cuda", local % n)
+        try:
+            td.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:  # torch without the device_id argument
+            td.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -39,7 +49,10 @@ def rank():
 
 def barrier():
     if td.is_initialized():
-        td.barrier()
+        if td.get_backend() == "nccl":
+            td.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            td.barrier()
 
 
 def sample_ids(n_samples: int, rank_: int, world: int):
