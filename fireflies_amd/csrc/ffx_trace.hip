@@ -552,10 +552,10 @@ __device__ __forceinline__ bool tri_test_bf(const float4 a, const float4 b, cons
   return (det > 0.f) & (U >= 0.f) & (Vv >= 0.f) & (U + Vv <= det) & (t > tmin);
 }
 
-// R rays per lane: one packet walk serves 64*R rays.  Every scalar instruction, scalar load and
-// dependent round trip of a traversal step is shared by the R rays of a lane (the scalar unit, one per
-// CU, is the tightest resource of this kernel), while the per-lane VALU work is simply repeated R times
-// with independent data (more ILP per wave).
+// Generic packet walk (min/max slab test, no assumption on direction signs) for R rays per lane.  The
+// kernels instantiate R = 1 only — a packed two-rays-per-lane variant was measured slower and removed —
+// and reach this loop for the rare packets whose rays disagree on a direction sign; everything else
+// takes the octant loops below.  Same apex triangle test, same results.
 template <bool ANY, int R>
 __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[R], const v3 (&d)[R],
                                                 const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
@@ -1115,9 +1115,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 // Packet kernels.  A wavefront owns one 2x2-pixel tile (65,536 work items at 512x512): tile costs vary
 // by an order of magnitude (rays along the tube vs. rays that leave it), so fine-grained, independent
 // waves let the hardware dispatcher keep every SIMD busy to the end.  The 64 lanes are the 64 samples
-// of a pixel; every lane carries R rays = the same sample index of R horizontally adjacent pixels
-// (R = 2: the tile is walked as two pixel pairs; R = 1: as four single pixels).  All 64*R rays of a
-// packet are within a two-pixel frustum, so the union of their paths is practically one ray's path.
+// of a pixel and the tile is walked as four single pixels (R = 1; the template parameter remains from
+// a two-pixels-per-lane experiment).  All 64 rays of a packet are within a one-pixel frustum, so the
+// union of their paths is practically one ray's path.
 #define PK_BLOCK 256 // upper bound; the launch picks 64/128/256 threads = 1/2/4 independent waves per workgroup
 
 __device__ __forceinline__ float wave_sum64(float v) {
