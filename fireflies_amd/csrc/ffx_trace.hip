@@ -721,6 +721,9 @@ __device__ __forceinline__ RayOct make_rayoct(v3 o, v3 d) {
 // they are combined on the scalar ALU, tested with s_cmp (no ballot) and consumed by v_cndmask through
 // inverse_ballot.  (A `bool` that is not itself a compare costs v_cndmask + v_cmp_ne per ballot.)
 typedef unsigned long long wmask;
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wmask m_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }  // ordered <
 __device__ __forceinline__ wmask m_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }  // ordered <=
 __device__ __forceinline__ wmask m_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }  // ordered >
@@ -792,17 +795,20 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
   FFX_STAT(ANY ? 4 : 0);
   while (true) {
     FFX_STAT(ANY ? 5 : 1);
-    const float4 *n4 = reinterpret_cast<const float4 *>(nbase + ((uint32_t)cur << 6));
-    const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];
-    const int4 ch = *reinterpret_cast<const int4 *>(n4 + 3);
-    const int c0 = ch.x, c1 = ch.y;
+    // the whole 64-byte node with ONE scalar load (s_load_dwordx16); the empty asm makes all 16 dwords
+    // live, otherwise the compiler fetches the 14 it needs with three loads (x8 + x4 + x2) — and scalar
+    // loads share the issue port that co-limits this loop
+    const v16i nd = *reinterpret_cast<const v16i *>(nbase + ((uint32_t)cur << 6));
+    asm volatile("" ::"s"(nd));
+    const int c0 = nd.sc, c1 = nd.sd;
     float t0, t1;
-    // both slabs unconditionally (one 64-byte fetch, no dependent branch)
-    const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-    const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+    const float lo0[3] = {__int_as_float(nd.s0), __int_as_float(nd.s1), __int_as_float(nd.s2)};
+    const float hi0[3] = {__int_as_float(nd.s3), __int_as_float(nd.s4), __int_as_float(nd.s5)};
+    const float lo1[3] = {__int_as_float(nd.s6), __int_as_float(nd.s7), __int_as_float(nd.s8)};
+    const float hi1[3] = {__int_as_float(nd.s9), __int_as_float(nd.sa), __int_as_float(nd.sb)};
     wmask g0 = slab_oct<OCT>(lo0, hi0, rs, tmin, h.t, t0);
     wmask g1 = slab_oct<OCT>(lo1, hi1, rs, tmin, h.t, t1);
-    if ((c0 | c1) < 0) { // a leaf or an empty child on at least one side
+    if (__builtin_expect((c0 | c1) < 0, 0)) { // a leaf or an empty child on at least one side (2 of 27 steps)
       FFX_STAT(ANY ? 12 : 8);
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
@@ -817,12 +823,16 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
         uint32_t roff = first * 48u;
         for (uint32_t i = 0; i < count; ++i, roff += 48u) {
           FFX_STAT(ANY ? 6 : 2);
-          const float4 *r4 = reinterpret_cast<const float4 *>(rbase + roff);
-          const float4 ra = r4[0], rb4 = r4[1], rc = r4[2];
-          const int prim = __float_as_int(rc.z); // (the shape id is read back through h.slot)
+          // the 48-byte apex record with two scalar loads (x8 + x4) issued together, instead of four staged ones
+          const v8i r8 = *reinterpret_cast<const v8i *>(rbase + roff);
+          const v4i r4 = *reinterpret_cast<const v4i *>(rbase + roff + 32);
+          asm volatile("" ::"s"(r8), "s"(r4));
+          const int prim = r4.z; // (the shape id is read back through h.slot)
           // apex record: det = d.A, U = d.B, V = d.C, t = T/det; staged with wave-uniform early-outs
           // (same arithmetic and acceptance rule as tri_hit_apex)
-          const v3 A = V3(ra.x, ra.y, ra.z), B = V3(ra.w, rb4.x, rb4.y), C = V3(rb4.z, rb4.w, rc.x);
+          const v3 A = V3(__int_as_float(r8.s0), __int_as_float(r8.s1), __int_as_float(r8.s2));
+          const v3 B = V3(__int_as_float(r8.s3), __int_as_float(r8.s4), __int_as_float(r8.s5));
+          const v3 C = V3(__int_as_float(r8.s6), __int_as_float(r8.s7), __int_as_float(r4.x));
           const float det = vdot(d, A);
           const float U = vdot(d, B);
           const wmask neg = m_lt(det, 0.f);
@@ -835,7 +845,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
           const float Vs = msel(neg, -Vv, Vv);
           const wmask p2 = p1 & m_ge(Vs, 0.f) & m_le(Us + Vs, detA);
           if (p2 == 0ull) continue;
-          const float T = rc.y;
+          const float T = __int_as_float(r4.y);
           const float t = msel(neg, -T, T) / detA;
           const wmask hit = p2 & m_gt(t, tmin);
           if (ANY) {
