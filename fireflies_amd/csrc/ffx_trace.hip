@@ -721,6 +721,9 @@ __device__ __forceinline__ RayOct make_rayoct(v3 o, v3 d) {
 // they are combined on the scalar ALU, tested with s_cmp (no ballot) and consumed by v_cndmask through
 // inverse_ballot.  (A `bool` that is not itself a compare costs v_cndmask + v_cmp_ne per ballot.)
 typedef unsigned long long wmask;
+// hides a uniform mask from common-subexpression elimination: the compiler otherwise evaluates one
+// `g != 0` for two branches up front and keeps the outcome as s_cselect'ed lane masks (4 extra SALU)
+__device__ __forceinline__ wmask launder_mask(wmask m) { asm("" : "+s"(m)); return m; }
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -879,7 +882,7 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
       } else {
         cur = c0;
       }
-    } else if (g1 != 0ull) {
+    } else if (launder_mask(g1) != 0ull) { // (laundered: tested here, not hoisted above the g0 branch as a lane mask)
       cur = c1;
     } else {
       if (sp == 0) break;
