@@ -706,10 +706,13 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
 #define FFX_PK1_WAVES 7
 #endif
 __device__ __forceinline__ constexpr bool octant_loops() { return FFX_OCTANT_LOOPS != 0; }
+// `scale` = 1/tmax of the ray: the octant box test works in units of the ray's own parameter range, so
+// every distance it compares lies in [0, 1] (see slab_oct).  The scale multiplies 1/d once, hence enters
+// plane*m and o*m alike: a purely relative change of the results, no new cancellation error.
 struct RayOct { v3 id, oidN, oidF; };
-__device__ __forceinline__ RayOct make_rayoct(v3 o, v3 d) {
+__device__ __forceinline__ RayOct make_rayoct(v3 o, v3 d, float scale) {
   RayOct r;
-  r.id = V3(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
+  r.id = V3(safe_rcp_dir(d.x) * scale, safe_rcp_dir(d.y) * scale, safe_rcp_dir(d.z) * scale);
   const v3 oid = V3(o.x * r.id.x, o.y * r.id.y, o.z * r.id.z);
   const float k = 2.384185791015625e-07f; // 2^-22
   const v3 e = V3(fabsf(oid.x) * k, fabsf(oid.y) * k, fabsf(oid.z) * k);
@@ -740,6 +743,8 @@ __device__ __forceinline__ T msel(wmask m, T a, T b) { return __builtin_amdgcn_i
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max3 with the VOP3 clamp bit: the result is clamped to [0, 1] at no cost
+__device__ __forceinline__ float vmax3_sat(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // Box test of the octant loops: one v_fma_f32 per plane with the node plane as the SGPR operand.
@@ -759,13 +764,18 @@ __device__ __forceinline__ RaySlab make_rayslab(const RayOct &rb) {
   r.cF = V3(rb.oidF.x * k, rb.oidF.y * k, rb.oidF.z * k);
   return r;
 }
+// Distances are in units of the ray's parameter range (RayOct::scale), so a box can only matter if it is
+// entered within [0, 1): the lower bound max(tn, tmin) becomes the free `clamp` bit of v_max3_f32 (the
+// near clip distance is tiny: boxes nearer than it cost a visit at most, the triangle test still
+// enforces t > tmin), and the upper bound is the scaled hit distance `hts` <= 0.9990002 (so an entry
+// distance clamped down to 1 still fails).  10 VALU per box.
 template <int OCT>
-__device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], const RaySlab &rs, float tmin, float tmax, float &tn_out) {
+__device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], const RaySlab &rs, float hts, float &tn_out) {
   const float nx = (OCT & 1) ? hi[0] : lo[0], fx = (OCT & 1) ? lo[0] : hi[0];
   const float ny = (OCT & 2) ? hi[1] : lo[1], fy = (OCT & 2) ? lo[1] : hi[1];
   const float nz = (OCT & 4) ? hi[2] : lo[2], fz = (OCT & 4) ? lo[2] : hi[2];
-  const float tn = vmax2(vmax3(fmaf(nx, rs.id.x, -rs.cN.x), fmaf(ny, rs.id.y, -rs.cN.y), fmaf(nz, rs.id.z, -rs.cN.z)), tmin);
-  const float tf = vmin2(vmin3(fmaf(fx, rs.idk.x, -rs.cF.x), fmaf(fy, rs.idk.y, -rs.cF.y), fmaf(fz, rs.idk.z, -rs.cF.z)), tmax);
+  const float tn = vmax3_sat(fmaf(nx, rs.id.x, -rs.cN.x), fmaf(ny, rs.id.y, -rs.cN.y), fmaf(nz, rs.id.z, -rs.cN.z));
+  const float tf = vmin2(vmin3(fmaf(fx, rs.idk.x, -rs.cF.x), fmaf(fy, rs.idk.y, -rs.cF.y), fmaf(fz, rs.idk.z, -rs.cF.z)), hts);
   tn_out = tn;
   return m_le(tn, tf);
 }
@@ -782,9 +792,13 @@ __device__ unsigned long long g_ffx_stats[16];
 #define FFX_STAT(i) do { } while (0)
 #endif
 template <bool ANY, int OCT>
-__device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const RayOct &rb, v3 d, float tmin,
-                                                    float tmax, wmask active, Hit &h, bool &found) {
+__device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const RayOct &rb, float scale, v3 d,
+                                                    float tmin, float tmax, wmask active, Hit &h, bool &found) {
   h.t = msel(active, tmax, -INFINITY); // an inactive ray fails every slab test
+  // the hit distance in box-test units, widened by 2 ulp (a box touching the current hit must still be
+  // entered: an equal-t triangle with a smaller id may be inside); refreshed after every leaf
+  const float sw = scale * 1.0000002f;
+  float hts = h.t * sw;
   h.prim = -1;
   h.shape = -1;
   h.slot = -1;
@@ -809,8 +823,8 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
     const float hi0[3] = {__int_as_float(nd.s3), __int_as_float(nd.s4), __int_as_float(nd.s5)};
     const float lo1[3] = {__int_as_float(nd.s6), __int_as_float(nd.s7), __int_as_float(nd.s8)};
     const float hi1[3] = {__int_as_float(nd.s9), __int_as_float(nd.sa), __int_as_float(nd.sb)};
-    wmask g0 = slab_oct<OCT>(lo0, hi0, rs, tmin, h.t, t0);
-    wmask g1 = slab_oct<OCT>(lo1, hi1, rs, tmin, h.t, t1);
+    wmask g0 = slab_oct<OCT>(lo0, hi0, rs, hts, t0);
+    wmask g1 = slab_oct<OCT>(lo1, hi1, rs, hts, t1);
     if (__builtin_expect((c0 | c1) < 0, 0)) { // a leaf or an empty child on at least one side (2 of 27 steps)
       FFX_STAT(ANY ? 12 : 8);
 #pragma unroll
@@ -867,8 +881,9 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
       }
       if (ANY && (active & ~occluded) == 0ull) break; // every ray of the packet is decided
       // the hit distance may have shrunk: re-test the (at most one) remaining inner child
-      if (g0 != 0ull) g0 &= m_le(t0, h.t);
-      if (g1 != 0ull) g1 &= m_le(t1, h.t);
+      hts = h.t * sw;
+      if (g0 != 0ull) g0 &= m_le(t0, hts);
+      if (g1 != 0ull) g1 &= m_le(t1, hts);
     }
     if (g0 != 0ull) {
       if (g1 != 0ull) {
@@ -903,21 +918,24 @@ __device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nod
     h[0].t = -INFINITY; h[0].prim = -1; h[0].shape = -1; h[0].slot = -1; found[0] = false;
     return;
   }
-  const RayOct rb = make_rayoct(o[0], d[0]);
+  // unit of the box test: tmax maps to 0.999, so an entry distance beyond the ray's range — which the
+  // clamp turns into exactly 1 — stays above the scaled hit distance and the box is rejected
+  const float scale = 0.999f * __builtin_amdgcn_rcpf(tmax[0]);
+  const RayOct rb = make_rayoct(o[0], d[0], scale);
   // octant from the reciprocals actually used (a clamped -0.0 component counts as negative)
   const uint32_t oct = (__float_as_uint(rb.id.x) >> 31) | ((__float_as_uint(rb.id.y) >> 31) << 1) | ((__float_as_uint(rb.id.z) >> 31) << 2);
   const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readlane((int)oct, __builtin_ctzll(am)); // octant of the first active lane
   const bool uniform = (am & __builtin_amdgcn_uicmp(oct, oct0, 33)) == 0ull;
   if (uniform) {
     switch (oct0) { // wave-uniform
-      case 0: traverse_packet_oct<ANY, 0>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 1: traverse_packet_oct<ANY, 1>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 2: traverse_packet_oct<ANY, 2>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 3: traverse_packet_oct<ANY, 3>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 4: traverse_packet_oct<ANY, 4>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 5: traverse_packet_oct<ANY, 5>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      case 6: traverse_packet_oct<ANY, 6>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
-      default: traverse_packet_oct<ANY, 7>(nodes, recs, rb, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 0: traverse_packet_oct<ANY, 0>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 1: traverse_packet_oct<ANY, 1>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 2: traverse_packet_oct<ANY, 2>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 3: traverse_packet_oct<ANY, 3>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 4: traverse_packet_oct<ANY, 4>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 5: traverse_packet_oct<ANY, 5>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      case 6: traverse_packet_oct<ANY, 6>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
+      default: traverse_packet_oct<ANY, 7>(nodes, recs, rb, scale, d[0], tmin[0], tmax[0], am, h[0], found[0]); break;
     }
   } else {
     traverse_packet<ANY, 1>(nodes, recs, o, d, tmin, tmax, active, h, found);
