@@ -47,19 +47,30 @@ def _max_over_ranks(x, device):
 
 
 def _bracket(fn, steps, warmup, device):
-    """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides."""
+    """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides.
+    The cyclic garbage collector is paused over the timed steps, as timeit does: a generation-2 pass
+    over the scene graphs built during set-up stalls the host for ~70 ms (seen once per ~200 steps),
+    which is 60 steps' worth of GPU work."""
+    import gc
+
     for i in range(warmup):
         fn(i)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        fn(warmup + i)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    return _max_over_ranks(time.perf_counter() - t0, device)
+    gc.collect()
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    return _max_over_ranks(dt, device)
 
 
 def _kernel_ms(events, name):
@@ -148,8 +159,8 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)  # ~0.1 s per bracket: long enough for the clocks to settle
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--grid", type=int, default=16, help="laser grid (grid x grid points) for renders; 256 points by default")
@@ -194,16 +205,24 @@ def main():
 
     events = []
 
+    # Per-launch HIP event pairs are recorded for at most TIMED_STEPS steps of a bracket and resolved
+    # right after it: hundreds of unresolved timing events slow every later launch of the process down
+    # (measured: the gradient bracket ran at half speed after 600 of them).
+    TIMED_STEPS = 24
+
+    w_render = 0 if args.no_render_steps else args.warmup
+
     def timed_render_step(i):
-        geom.timing = events if i >= args.warmup else None
+        geom.timing = events if w_render <= i < w_render + TIMED_STEPS else None
         return render_step(i)
 
-    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, args.warmup if not args.no_render_steps else 0, dev)
+    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev)
     geom.timing = None
     torch.cuda.synchronize()
     renders_per_sec = world * args.steps / t_render
     k8_ms, k8_n = _kernel_ms(events, "render_fwd")
     upd_ms, _ = _kernel_ms(events, "scene_update")
+    events.clear()
     bytes_ = algorithmic_bytes(wl, W, H, fp16=args.fp16)
 
     # ------------------------------------------------------------------ pattern-gradient steps/sec
@@ -214,7 +233,7 @@ def main():
         gevents = []
 
         def grad_step(i):
-            wg.mi_scene.geom.timing = gevents if i >= args.warmup else None
+            wg.mi_scene.geom.timing = gevents if args.warmup <= i < args.warmup + TIMED_STEPS else None
             return opt.step()
 
         t_grad = _bracket(grad_step, args.steps, args.warmup, dev)
@@ -223,6 +242,7 @@ def main():
         k9_ms, _ = _kernel_ms(gevents, "render_bwd")  # re-tracing adjoint (only above FFX_CACHE_LIMIT_GB)
         k9c_ms, _ = _kernel_ms(gevents, "render_bwd_cached")
         k8g_ms, _ = _kernel_ms(gevents, "render_fwd")
+        gevents.clear()
         bg = algorithmic_bytes(wg, W, H)
         # streaming adjoint: reads the 16-byte record of every sample + d(loss)/d(img), writes gtex once
         bytes_k9c = 16 * W * H * args.spp + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
@@ -284,7 +304,7 @@ def main():
                     "VALU-issue bound (SQ counters in profiles/r1_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
         },
-        "kernels_ms": {"scene_update(K5+K6, all launches)": upd_ms, "render_fwd(K8)": k8_ms},
+        "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_ms},
     }
     out.update(grad)
     if not args.no_cpu_baseline and world == 1:

@@ -4,6 +4,7 @@ PyTorch is used for device memory and the current HIP stream; every arithmetic s
 libffx_hip.so.  All functions require contiguous tensors on a HIP device and raise otherwise.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -219,7 +220,17 @@ class DeviceGeometry:
         blob = np.zeros(nbytes, np.uint8)
         self.info = _abi.BvhInfo()
         a.call("ffx_bvh_build_host", bverts.ctypes.data, bverts.shape[0], glob.ctypes.data, F, blob.ctypes.data, nbytes, C.byref(self.info))
-        self.blob = torch.from_numpy(blob[: self.info.total_bytes].copy()).to(self.device)
+        # Two copies of the blob: update() re-fits the one that is NOT being read, on a side stream, while
+        # the render kernels of the previous step are still running on the caller's stream (the refit is
+        # five small dependent launches, ~55 us with the GPU otherwise idle; overlapped it costs nothing).
+        # FFX_ASYNC_UPDATE=0 falls back to one blob, everything on the caller's stream.
+        b0 = torch.from_numpy(blob[: self.info.total_bytes].copy()).to(self.device)
+        self._async = self.device.type == "cuda" and os.environ.get("FFX_ASYNC_UPDATE", "1") != "0"
+        self._blobs = [b0, b0.clone()] if self._async else [b0]
+        self._cur = 0
+        self._side = torch.cuda.Stream(self.device) if self._async else None
+        self._upd_done = [None, None]   # event: the refit of blob i has been enqueued up to here (side stream)
+        self._last_use = [None, None]   # event: the last reader of blob i (caller's stream)
         self.src_verts = torch.from_numpy(src).to(self.device)
         self.tris = torch.from_numpy(tr).to(self.device)
         self.tri_shape = torch.from_numpy(ts).to(self.device)
@@ -227,6 +238,24 @@ class DeviceGeometry:
         self._vert_off_host = vo.copy()
         self._vert_off_dev_stale = False
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
+
+    @property
+    def blob(self):
+        """the blob the next render / trace call will read (ordered after its refit on the current stream)"""
+        self._acquire()
+        return self._blobs[self._cur]
+
+    def _acquire(self):
+        ev = self._upd_done[self._cur] if self._async else None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def _release(self):
+        if self._async:
+            ev = self._last_use[self._cur]
+            if ev is None:
+                ev = self._last_use[self._cur] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
 
     def _check_offsets(self, vo):
         if (vo < 0).any() or ((vo.astype(np.int64) + self._max_local) >= self._pool_size).any():
@@ -245,12 +274,31 @@ class DeviceGeometry:
             self._vert_off_host = vo.copy()
             self._vert_off_dev_stale = True
         on_device = isinstance(xforms, torch.Tensor) and xforms.is_cuda
+        if not self._async:
+            self._update_into(self._blobs[0], xforms, on_device)
+            return
+        nxt = 1 - self._cur
+        main = torch.cuda.current_stream(self.device)
+        if self._last_use[nxt] is not None:
+            self._side.wait_event(self._last_use[nxt])  # its last reader must be done before it is overwritten
+        if on_device:
+            self._side.wait_stream(main)  # the tables were produced on the caller's stream
+            xforms.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            self._update_into(self._blobs[nxt], xforms, on_device)
+            ev = self._upd_done[nxt]
+            if ev is None:
+                ev = self._upd_done[nxt] = torch.cuda.Event()
+            ev.record(self._side)
+        self._cur = nxt
+
+    def _update_into(self, blob, xforms, on_device):
         with self._timed("scene_update"):
             if not on_device and self.n_shapes <= 32:
                 xf = xforms.detach().numpy() if isinstance(xforms, torch.Tensor) else np.asarray(xforms)
                 xf = np.ascontiguousarray(xf, dtype=np.float32).reshape(self.n_shapes, 16)
                 api().call(
-                    "ffx_scene_update_h", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
+                    "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                     _dev(self.tri_shape, torch.int32), self._vert_off_host.ctypes.data_as(C.POINTER(C.c_int32)),
                     xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(),
                 )
@@ -262,7 +310,7 @@ class DeviceGeometry:
             xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
             self._xf = xf  # keep alive until the stream has consumed it
             api().call(
-                "ffx_scene_update", _dev(self.blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
+                "ffx_scene_update", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                 _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),
             )
 
@@ -275,6 +323,7 @@ class DeviceGeometry:
             "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
             _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(),
         )
+        self._release()
         return t, shape, prim
 
     def trace_rays(self, origins, dirs, tmax=3.0e38):
@@ -286,6 +335,7 @@ class DeviceGeometry:
             "ffx_trace_rays", _dev(self.blob, torch.uint8), C.byref(self.info), _dev(origins, name="origins"), _dev(dirs, name="dirs"), n, float(tmax),
             _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(),
         )
+        self._release()
         return t, shape, prim
 
     def _timed(self, name):
@@ -305,12 +355,14 @@ class DeviceGeometry:
                     _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype),
                     _dev(cache, torch.uint8, "cache"), _stream(),
                 )
+            self._release()
             return img
         with self._timed("render_fwd"):
           api().call(
             "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
             _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(),
           )
+        self._release()
         return img
 
     def render_bwd_cached(self, sd, albedo, cache, spp, gimg):
@@ -328,4 +380,5 @@ class DeviceGeometry:
                 "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
                 int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(),
             )
+        self._release()
         return gtex

@@ -291,9 +291,12 @@ def test_k5k6_update_is_idempotent_and_tracks_frames(oracle):
                 ref = host(td).copy()
             else:
                 np.testing.assert_array_equal(host(td), ref)  # same pose -> same bits after other poses
-    blob1 = gd.blob.clone()
+    # refit is a pure function of (pose, topology): nodes + records are identical after a repeated update
+    # (which lands in the other of the two blobs; the apex areas behind the records are per-call scratch)
+    geo = int(gd.info.off_recs) + 48 * int(gd.info.n_tris)
+    blob1 = gd.blob[:geo].clone()
     gd.update(xf, offs)
-    assert torch.equal(blob1, gd.blob)  # refit is a pure function of (pose, topology)
+    assert torch.equal(blob1, gd.blob[:geo])
 
 
 # ------------------------------------------------------------------ K8 / K9
