@@ -299,6 +299,35 @@ def test_k5k6_update_is_idempotent_and_tracks_frames(oracle):
     assert torch.equal(blob1, gd.blob[:geo])
 
 
+def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
+    """update() re-fits the blob that is not being read, on a side stream, while earlier traces may still
+    be running; a burst of (update, trace) pairs without any host sync must give exactly what the
+    single-blob, single-stream path gives for every pose."""
+    sc = scenes.vocalfold(width=96, height=96, frames=6, n_fold=24, tube=(24, 32))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    cam = scene_desc.camera_from_sensor(sc.camera)
+    poses = []
+    rng = np.random.default_rng(4)
+    for i in range(12):
+        offs = off.copy()
+        offs[1] = off[1] + int(rng.integers(0, nfr[1])) * stride[1]
+        poses.append((_rand_xforms(2, 100 + i), offs))
+    monkeypatch.setenv("FFX_ASYNC_UPDATE", "1")
+    ga = ops.DeviceGeometry(pool, tris, shape, off)
+    assert ga._async and len(ga._blobs) == 2
+    outs = []
+    for xf, offs in poses:  # no synchronisation anywhere in this loop
+        ga.update(xf, offs)
+        outs.append(ga.trace_primary(cam, 4, 1, seed=9))
+    monkeypatch.setenv("FFX_ASYNC_UPDATE", "0")
+    gs = ops.DeviceGeometry(pool, tris, shape, off)
+    assert not gs._async
+    for (xf, offs), (t, s_, p) in zip(poses, outs):
+        gs.update(xf, offs)
+        t2, s2, p2 = gs.trace_primary(cam, 4, 1, seed=9)
+        assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
+
+
 # ------------------------------------------------------------------ K8 / K9
 def _tex(sc, ch=1, seed=0):
     rng = np.random.default_rng(seed)
