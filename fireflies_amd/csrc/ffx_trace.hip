@@ -1560,12 +1560,14 @@ static int use_packet() {
   return (e && strcmp(e, "lane") == 0) ? 0 : 1;
 }
 
-// independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1, 2 (default) or 4.
-// A CU admits at most 16 workgroups, so single-wave workgroups cap residency at 4 waves/SIMD.
+// independent waves per workgroup of the packet kernels: FFX_PACKET_WAVES = 1 (default), 2 or 4.
+// The waves of a workgroup never cooperate, so the smallest workgroup gives the dispatcher the finest
+// grain (measured 1 / 2 / 4 waves: 0.882 / 0.891 / 0.951 ms per step on the vocal fold, 16.2 / 16.5 /
+// 17.4 ms on the colon).
 static int packet_waves() {
   const char *e = getenv("FFX_PACKET_WAVES");
-  int w = e ? atoi(e) : 2;
-  return (w == 1 || w == 2 || w == 4) ? w : 2;
+  int w = e ? atoi(e) : 1;
+  return (w == 1 || w == 2 || w == 4) ? w : 1;
 }
 
 // experiment knob: dynamic LDS bytes per workgroup of the packet kernels (unused by the kernel; it only
