@@ -1211,19 +1211,22 @@ template <int R>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16,
-                    void *__restrict__ img, uint4 *__restrict__ cache) {
+                    void *__restrict__ img, uint4 *__restrict__ cache, int ppw) {
   constexpr int NSUB = 4 / R;
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
   // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
   __shared__ float s_acc[R][3][PK_BLOCK];
   // each wave of the workgroup owns its own tile; the waves never synchronise
-  const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // a wave walks `ppw` (1, 2 or 4) of its tile's four pixels; 4 / ppw waves share a tile
+  const int wv = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wpt = NSUB / ppw;
+  const int tile = wv / wpt, sub0 = (wv % wpt) * ppw;
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
   const int passes = (spp + 63) >> 6;
   const float inv_spp = 1.0f / (float)spp;
-  for (int sub = 0; sub < NSUB; ++sub) {
+  for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
     packet_pixels<R>(tile, tiles_x, sub, px, py);
     bool live[R], any_live = false;
@@ -1570,6 +1573,15 @@ static int packet_waves() {
   return (w == 1 || w == 2 || w == 4) ? w : 1;
 }
 
+// pixels of its 2x2 tile a wave of k_render_fwd_pk walks: FFX_PIXELS_PER_WAVE = 1, 2 (default) or 4.
+// Measured 4 / 2 / 1: 1133 / 1180 / 1165 renders/s (vocal fold), 62.0 / 62.6 / 62.2 (colon): shorter
+// waves even out the tail of the launch, one pixel per wave pays the wave start-up four times.
+static int pixels_per_wave() {
+  const char *e = getenv("FFX_PIXELS_PER_WAVE");
+  int w = e ? atoi(e) : 2;
+  return (w == 1 || w == 2 || w == 4) ? w : 2;
+}
+
 // experiment knob: dynamic LDS bytes per workgroup of the packet kernels (unused by the kernel; it only
 // lowers occupancy so that latency- and throughput-bound behaviour can be told apart)
 static size_t dummy_lds() {
@@ -1697,12 +1709,13 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
     int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
     const int wpb = packet_waves();
-    int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
+    const int ppw = pixels_per_wave();
+    int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
     hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, shape_albedo, tex, spp,
-                       seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache);
+                       seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
