@@ -1442,33 +1442,37 @@ __global__ void __launch_bounds__(256)
         const float *alb = albedo + 3 * shape;
         ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * fac * p.inv_spp;
       }
-      const int minx = wave_min_i(active ? x0 : 0x7fffffff), maxx = wave_max_i(active ? x1 : -1);
-      const int miny = wave_min_i(active ? y0 : 0x7fffffff), maxy = wave_max_i(active ? y1 : -1);
-      const int bw = maxx - minx + 1, bh = maxy - miny + 1;
-      if (bw <= 16 && bh <= 16) { // wave-uniform
+      // The 64 lanes of a wave are (almost always) the 64 samples of one pixel: their taps fall on a
+      // handful of neighbouring texels.  They are summed in a private 16x16 LDS tile centred on the first
+      // active lane's tap (no wave-wide min/max reductions: those cost 24 cross-lane LDS operations per
+      // iteration) and flushed with one global atomic per touched texel; a tap outside the tile — a wave
+      // that straddles pixels far apart in the texture — goes to memory directly.
+      const unsigned long long am = wballot(active);
+      const int fl = __builtin_ctzll(am);
+      const int minx = __builtin_amdgcn_readlane(x0, fl) - 7, miny = __builtin_amdgcn_readlane(y0, fl) - 7;
+      const bool in_tile = active && x0 >= minx && x1 <= minx + 15 && y0 >= miny && y1 <= miny + 15;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tile[lane + 64 * k] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        if (active) {
-          atomicAdd(&tile[(y0 - miny) * 16 + (x0 - minx)], ws * wy0 * wx0);
-          atomicAdd(&tile[(y0 - miny) * 16 + (x1 - minx)], ws * wy0 * wx1);
-          atomicAdd(&tile[(y1 - miny) * 16 + (x0 - minx)], ws * wy1 * wx0);
-          atomicAdd(&tile[(y1 - miny) * 16 + (x1 - minx)], ws * wy1 * wx1);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = lane + 64 * k, ty = e >> 4, tx = e & 15;
-          const float v = tile[e];
-          if (v != 0.f && tx < bw && ty < bh) atomicAdd(gtex + (size_t)(miny + ty) * p.tw + (minx + tx), v);
-        }
-        __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < 4; ++k) tile[lane + 64 * k] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+      if (in_tile) {
+        atomicAdd(&tile[(y0 - miny) * 16 + (x0 - minx)], ws * wy0 * wx0);
+        atomicAdd(&tile[(y0 - miny) * 16 + (x1 - minx)], ws * wy0 * wx1);
+        atomicAdd(&tile[(y1 - miny) * 16 + (x0 - minx)], ws * wy1 * wx0);
+        atomicAdd(&tile[(y1 - miny) * 16 + (x1 - minx)], ws * wy1 * wx1);
       } else if (active) {
         atomicAdd(gtex + (size_t)y0 * p.tw + x0, ws * wy0 * wx0);
         atomicAdd(gtex + (size_t)y0 * p.tw + x1, ws * wy0 * wx1);
         atomicAdd(gtex + (size_t)y1 * p.tw + x0, ws * wy1 * wx0);
         atomicAdd(gtex + (size_t)y1 * p.tw + x1, ws * wy1 * wx1);
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane + 64 * k, ty = e >> 4, tx = e & 15;
+        const float v = tile[e];
+        if (v != 0.f) atomicAdd(gtex + (size_t)(miny + ty) * p.tw + (minx + tx), v); // only cells with in-range taps are non-zero
+      }
+      __builtin_amdgcn_wave_barrier();
     } else if (active) {
       const float *alb = albedo + 3 * shape;
       const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3;
