@@ -267,3 +267,49 @@ def test_scene_update_transform_and_frames(oracle):
     S = np.diag([1.0, 1.0, 0.5, 1.0]).astype(np.float32)
     g.update(S[None], off)
     np.testing.assert_allclose(g.trace_primary(cam)[0].reshape(8, 8), (1.0 - s.near) / dl[..., 2], rtol=2e-6)
+
+
+def _hash32(x):
+    x = np.asarray(x, np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def test_apex_form_agrees_with_the_general_triangle_test(oracle):
+    """Primary rays are intersected with the apex form of Moller-Trumbore (three dot products with
+    per-triangle vectors), arbitrary rays with the textbook form.  The two are
+    independent formulations inside the oracle: on the same (jittered: DESIGN.md 4.2) rays they must
+    find the same primitive, up to rays that graze an edge, at the same distance."""
+    sc = scenes.vocalfold(width=40, height=32, tex=32, frames=2, n_fold=16, tube=(16, 24))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    geo = oracle.Geometry(pool, tris, shape, off)
+    s = sc.camera
+    seed = 5
+    t_a, s_a, p_a = geo.trace_primary(scene_desc.camera_from_sensor(s), 1, 1, seed)
+    # the same rays, built here in float64 and handed over as arbitrary rays
+    W, H = s.width, s.height
+    idx = np.arange(W * H, dtype=np.uint64)
+    key = _hash32(np.uint64(seed + 0x9E3779B9))
+    jx = (_hash32((2 * idx) ^ key) >> 8).astype(np.float64) / 16777216.0
+    jy = (_hash32((2 * idx + 1) ^ key) >> 8).astype(np.float64) / 16777216.0
+    sx = ((idx % W).astype(np.float64) + jx) / W
+    sy = ((idx // W).astype(np.float64) + jy) / H
+    Kinv = np.linalg.inv(s.K.astype(np.float64))
+    q = np.stack([sx, sy, np.zeros_like(sx), np.ones_like(sx)], -1) @ Kinv.T
+    dl = q[:, :3] / q[:, 3:]
+    dl /= np.linalg.norm(dl, axis=-1, keepdims=True)
+    tw = np.asarray(s.to_world, np.float64)
+    d = (dl @ tw[:3, :3].T).astype(np.float32)
+    o = np.tile(tw[:3, 3][None], (d.shape[0], 1)).astype(np.float32)
+    t_g, s_g, p_g = geo.trace_rays(o, d)
+    hit = p_a >= 0
+    assert hit.mean() > 0.5
+    same = (p_a == p_g) & (s_a == s_g)
+    assert same.mean() > 0.995, f"{1 - same.mean():.3%} of the rays hit a different primitive"
+    near_t = s.near / dl[:, 2]  # trace_primary reports t from the near plane
+    both = same & hit
+    np.testing.assert_allclose(t_a[both] + near_t[both], t_g[both], rtol=2e-5, atol=2e-5)
