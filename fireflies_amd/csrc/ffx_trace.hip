@@ -532,26 +532,6 @@ __device__ __forceinline__ void msel_into(int &dst, unsigned long long mask, int
   asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(v), "s"(mask));
 }
 
-// branch-free Moller-Trumbore for the packet path: same arithmetic and acceptance rule as tri_hit(),
-// but every lane evaluates everything and the outcome is a predicate (no exec-mask branching inside
-// the wave-uniform leaf loop).  det == 0 gives inf/NaN in t, which fails the comparisons.
-__device__ __forceinline__ bool tri_test_bf(const float4 a, const float4 b, const float4 c, v3 o, v3 d, float tmin, float &t_out) {
-  v3 v0 = V3(a.x, a.y, a.z), e1 = V3(a.w, b.x, b.y), e2 = V3(b.z, b.w, c.x);
-  v3 pv = vcross(d, e2);
-  float det = vdot(e1, pv);
-  v3 tv = vsub(o, v0);
-  v3 qv = vcross(tv, e1);
-  float U = vdot(tv, pv), Vv = vdot(d, qv), T = vdot(e2, qv);
-  const bool neg = det < 0.f;
-  det = neg ? -det : det;
-  U = neg ? -U : U;
-  Vv = neg ? -Vv : Vv;
-  T = neg ? -T : T;
-  float t = T / det;
-  t_out = t;
-  return (det > 0.f) & (U >= 0.f) & (Vv >= 0.f) & (U + Vv <= det) & (t > tmin);
-}
-
 // Generic packet walk (min/max slab test, no assumption on direction signs) for R rays per lane.  The
 // kernels instantiate R = 1 only — a packed two-rays-per-lane variant was measured slower and removed —
 // and reach this loop for the rare packets whose rays disagree on a direction sign; everything else
@@ -740,9 +720,7 @@ template <typename T>
 __device__ __forceinline__ T msel(wmask m, T a, T b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
 // min/max without the sNaN-quieting v_max(x,x) the compiler puts in front of fminf/fmaxf operands it
 // cannot prove canonical (the loop-carried hit distance): inputs here are never NaN
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // max3 with the VOP3 clamp bit: the result is clamped to [0, 1] at no cost
 __device__ __forceinline__ float vmax3_sat(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -1400,17 +1378,6 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 // tap bounding box (ds_add_f32), then flushes ONE global atomic per touched texel.  Waves whose taps
 // span more than 16x16 texels (low spp, grazing projections) fall back to direct atomics.
 struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; };
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 __global__ void __launch_bounds__(256)
     k_render_bwd_cached(const uint4 *__restrict__ cache, long total, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
