@@ -114,6 +114,33 @@ __global__ void __launch_bounds__(256) k_transform_points(const float *__restric
   }
 }
 
+// clamp_to_fov + normalize_rays in one launch (the pattern has 64..1024 rays: launch-bound; as separate
+// torch ops this was 13 launches per optimiser step)
+__global__ void __launch_bounds__(256) k_clamp_to_fov(float *__restrict__ rays, int n, Mat4 KF, Mat4 KI, float lo, float hi, int n_norm) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
+  const float *K = KF.m;
+  float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+  float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+  float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
+  float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+  float px = q0 / q3, py = q1 / q3, pz = q2 / q3;
+  px = fminf(fmaxf(px, lo), hi);
+  py = fminf(fmaxf(py, lo), hi);
+  const float *I = KI.m;
+  float w0 = I[0] * px + I[1] * py + I[2] * pz + I[3];
+  float w1 = I[4] * px + I[5] * py + I[6] * pz + I[7];
+  float w2 = I[8] * px + I[9] * py + I[10] * pz + I[11];
+  float w3 = I[12] * px + I[13] * py + I[14] * pz + I[15];
+  x = w0 / w3; y = w1 / w3; z = w2 / w3;
+  for (int k = 0; k < n_norm; ++k) {
+    float nrm = sqrtf(x * x + y * y + z * z);
+    x /= nrm; y /= nrm; z /= nrm;
+  }
+  rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
+}
+
 // =================================================================================== K2 dense forward
 // rasterize_points: [n,size1,size0] layers.  HBM-write bound (4 B per (point, texel)); each lane
 // produces 4 consecutive texels and issues one 16-byte store when rows are 16-byte aligned.
@@ -475,6 +502,16 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
   for (int i = 0; i < 16; ++i) m.m[i] = M[i];
   hipLaunchKernelGGL(k_transform_points, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, pts, n, m, mode, out);
   FFX_CHECK_LAUNCH("transform_points");
+  return FFX_OK;
+}
+
+int ffx_clamp_to_fov(float *rays, int n, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {
+  if (n == 0) return FFX_OK;
+  if (!rays || !KF || !KF_inv || n < 0 || n_normalize < 0 || !(lo <= hi)) FFX_FAIL(FFX_ERR_ARG, "clamp_to_fov: bad argument");
+  Mat4 a, b;
+  for (int i = 0; i < 16; ++i) { a.m[i] = KF[i]; b.m[i] = KF_inv[i]; }
+  hipLaunchKernelGGL(k_clamp_to_fov, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, rays, n, a, b, lo, hi, n_normalize);
+  FFX_CHECK_LAUNCH("clamp_to_fov");
   return FFX_OK;
 }
 

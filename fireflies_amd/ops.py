@@ -65,6 +65,12 @@ def transform_points(pts, M, mode=0):
     return out
 
 
+def clamp_to_fov_(rays, KF, KF_inv, lo, hi, n_normalize=1):
+    """in place: Laser.clamp_to_fov (+ n_normalize - 1 further normalisations) in one launch"""
+    api().call("ffx_clamp_to_fov", _dev(rays, name="rays"), rays.shape[0], _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), _stream())
+    return rays
+
+
 # ------------------------------------------------------------------ K2
 def _check_pts(pts):
     if pts.dim() != 2 or pts.shape[1] != 2:

@@ -160,8 +160,7 @@ class PatternOptimizer:
             loss = loss + reg
         rays.grad = grad
         self.opt.step()
-        self.laser.clamp_to_fov()
-        self.laser.normalize_rays()
+        self.laser.clamp_to_fov(then_normalize=True)  # clamp_to_fov() + normalize_rays() in one launch
         self.step_index += 1
         return {"loss": loss}
 

@@ -139,10 +139,18 @@ class Laser(camera.Camera):
         return None
 
     @torch.no_grad()
-    def clamp_to_fov(self, clamp_val: float = 0.95, epsilon: float = 0.0001) -> None:
+    def clamp_to_fov(self, clamp_val: float = 0.95, epsilon: float = 0.0001, then_normalize: bool = False) -> None:
+        """project, clamp the screen position to [1 - clamp_val, clamp_val], un-project, normalise
+        (laser.py:199-206) — one launch, in place.  then_normalize=True also applies the
+        normalize_rays() that the training loops call right after (laser.py:254-255)."""
+        if self._rays.is_cuda and self._rays.is_contiguous():
+            ops.clamp_to_fov_(self._rays.detach(), self._KF, self._KF_inv, 1 - clamp_val, clamp_val, 2 if then_normalize else 1)
+            return
         ndc = ops.project_rays_fwd(self._rays.detach().contiguous(), self._KF)
         ndc[:, 0:2] = torch.clamp(ndc[:, 0:2], 1 - clamp_val, clamp_val)
         self._rays[:] = _unit(self.projectNDCPointsToWorld(ndc))
+        if then_normalize:
+            self.normalize_rays()
 
     @torch.no_grad()
     def _respawn(self, out_of_bounds) -> None:

@@ -69,6 +69,14 @@ int ffx_project_rays_bwd(const float *rays /*[dev][n,3]*/, int n, const float *K
 int ffx_transform_points(const float *pts /*[dev][n,3]*/, int n, const float *M /*[host][16]*/,
                          int mode, float *out /*[dev][n,3]*/, ffx_stream stream);
 
+/* Constraint projection of the pattern after an optimiser step, in place:
+ * Laser.clamp_to_fov (fireflies/projection/laser.py:199-206): ndc = transform_points(rays, KF);
+ * ndc.xy = clamp(ndc.xy, lo, hi); rays = normalize(transform_points(ndc, KF_inv)); followed by
+ * n_normalize - 1 further normalisations (Laser.normalize_rays, laser.py:254-255; the training loops
+ * call both).  lo = 1 - clamp_val, hi = clamp_val. */
+int ffx_clamp_to_fov(float *rays /*[dev][n,3] in/out*/, int n, const float *KF /*[host][16]*/,
+                     const float *KF_inv /*[host][16]*/, float lo, float hi, int n_normalize, ffx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  soft point splatting.
  * texture_size = (size0, size1); point n = (p0, p1) in [0,1]^2; outputs are indexed [i][j]

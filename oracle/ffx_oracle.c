@@ -148,6 +148,30 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
   return FFX_OK;
 }
 
+/* Laser.clamp_to_fov + Laser.normalize_rays (fireflies/projection/laser.py:199-206,254-255):
+ * project with KF, clamp the screen xy to [lo, hi], un-project with KF_inv, normalise n_normalize times */
+int ffx_clamp_to_fov(float *rays, int n, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {
+  (void)s;
+  if (n == 0) return FFX_OK;
+  if (!rays || !KF || !KF_inv || n < 0 || n_normalize < 0 || !(lo <= hi)) FAIL(FFX_ERR_ARG, "clamp_to_fov: bad argument");
+  for (int i = 0; i < n; ++i) {
+    float x = rays[3 * i], y = rays[3 * i + 1], z = rays[3 * i + 2];
+    float q[4], w[4];
+    for (int r = 0; r < 4; ++r) q[r] = KF[4 * r] * x + KF[4 * r + 1] * y + KF[4 * r + 2] * z + KF[4 * r + 3];
+    float px = q[0] / q[3], py = q[1] / q[3], pz = q[2] / q[3];
+    px = fminf(fmaxf(px, lo), hi);
+    py = fminf(fmaxf(py, lo), hi);
+    for (int r = 0; r < 4; ++r) w[r] = KF_inv[4 * r] * px + KF_inv[4 * r + 1] * py + KF_inv[4 * r + 2] * pz + KF_inv[4 * r + 3];
+    x = w[0] / w[3]; y = w[1] / w[3]; z = w[2] / w[3];
+    for (int k = 0; k < n_normalize; ++k) {
+      float nrm = sqrtf(x * x + y * y + z * z);
+      x /= nrm; y /= nrm; z /= nrm;
+    }
+    rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
+  }
+  return FFX_OK;
+}
+
 /* =========================================================================================
  * K2  rasterize_points — graphics/rasterization.py:7-37
  *   points*texture_size (:18); y = j index over size0, x = i index over size1 (:21-27);

@@ -73,6 +73,12 @@ def transform_points(pts, M, mode=0):
     return out
 
 
+def clamp_to_fov(rays, KF, KF_inv, lo, hi, n_normalize=1):
+    out = _f32(rays).copy()
+    api().call("ffx_clamp_to_fov", _p(out), out.shape[0], _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), None)
+    return out
+
+
 # ---------------------------------------------------------------- K2
 def splat_dense_fwd(pts, sigma, size0, size1):
     pts = _f32(pts)

@@ -328,6 +328,20 @@ def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
         assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
 
 
+def test_clamp_to_fov_matches_oracle(oracle):
+    K = scenes.perspective_projection(64, 64, 30.0, 0.01, 100.0).astype(np.float64)
+    KF = (K @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    KI = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    rng = np.random.default_rng(8)
+    r = rng.standard_normal((333, 3)).astype(np.float32)
+    r[:, 2] = -np.abs(r[:, 2]) - 1.5
+    for nn in (1, 2):
+        d = dev(r.copy())
+        out = host(ops.clamp_to_fov_(d, KF, KI, 0.05, 0.95, nn))
+        np.testing.assert_allclose(out, oracle.clamp_to_fov(r, KF, KI, 0.05, 0.95, nn), rtol=0, atol=3e-7)
+    assert ops.clamp_to_fov_(torch.empty((0, 3), device="cuda"), KF, KI, 0.05, 0.95).shape == (0, 3)
+
+
 # ------------------------------------------------------------------ K8 / K9
 def _tex(sc, ch=1, seed=0):
     rng = np.random.default_rng(seed)

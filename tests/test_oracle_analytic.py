@@ -313,3 +313,37 @@ def test_apex_form_agrees_with_the_general_triangle_test(oracle):
     near_t = s.near / dl[:, 2]  # trace_primary reports t from the near plane
     both = same & hit
     np.testing.assert_allclose(t_a[both] + near_t[both], t_g[both], rtol=2e-5, atol=2e-5)
+
+
+def test_clamp_to_fov_properties(oracle):
+    """Laser.clamp_to_fov + normalize_rays (laser.py:199-206,254-255): rays inside the frustum only get
+    re-normalised, rays outside land on the clamp boundary, all come back with unit length; checked
+    against a float64 restatement."""
+    K = scenes.perspective_projection(64, 64, 30.0, 0.01, 100.0).astype(np.float64)
+    KF = K @ np.diag([1.0, -1.0, 1.0, 1.0])
+    KI = np.linalg.inv(KF)
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal((200, 3))
+    r[:, 2] = -np.abs(r[:, 2]) - 1.5  # rays are stored with z = -1 (laser.py:31-33); some leave the 30 deg frustum
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    lo, hi = 0.05, 0.95
+
+    def ref(r64):
+        q = np.c_[r64, np.ones(len(r64))] @ KF.T
+        p = q[:, :3] / q[:, 3:]
+        p[:, :2] = np.clip(p[:, :2], lo, hi)
+        w = np.c_[p, np.ones(len(p))] @ KI.T
+        w = w[:, :3] / w[:, 3:]
+        return w / np.linalg.norm(w, axis=1, keepdims=True)
+
+    out = oracle.clamp_to_fov(r.astype(np.float32), KF.astype(np.float32), KI.astype(np.float32), lo, hi, 2)
+    np.testing.assert_allclose(out, ref(r), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=3e-7)
+    q = np.c_[out.astype(np.float64), np.ones(len(out))] @ KF.T
+    xy = q[:, :2] / q[:, 3:]
+    assert xy.min() >= lo - 1e-5 and xy.max() <= hi + 1e-5
+    q0 = np.c_[r, np.ones(len(r))] @ KF.T
+    inside = ((q0[:, :2] / q0[:, 3:] > lo) & (q0[:, :2] / q0[:, 3:] < hi)).all(axis=1)
+    assert 10 < inside.sum() < 190
+    np.testing.assert_allclose(out[inside], r[inside], atol=3e-6)  # untouched apart from rounding
+    assert oracle.clamp_to_fov(np.zeros((0, 3), np.float32), KF.astype(np.float32), KI.astype(np.float32), lo, hi).shape == (0, 3)
