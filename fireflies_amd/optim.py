@@ -144,11 +144,15 @@ class PatternOptimizer:
             gts = ops.blur_bwd(gtex, self.blur[0], self.blur[1]) if self.blur else gtex
             gp = ops.splat_bwd(pts, self.sigma, "sum", -1, s0, s1, tsum, gts)
             grays = ops.project_rays_bwd(rd, KF, torch.nn.functional.pad(gp, (0, 1)))
-        flat = torch.cat([grays.reshape(-1), loss_sum.reshape(1)])
-        dist.allreduce_sum_(flat)
-        flat /= float(S)
-        grad = flat[:-1].reshape(rays.shape).clone()
-        loss = flat[-1]
+        if w > 1:
+            flat = torch.cat([grays.reshape(-1), loss_sum.reshape(1)])
+            dist.allreduce_sum_(flat)
+            flat /= float(S)
+            grad = flat[:-1].reshape(rays.shape).clone()
+            loss = flat[-1]
+        else:  # nothing to exchange: skip the pack / unpack launches
+            grad = grays if S == 1 else grays / float(S)
+            loss = loss_sum if S == 1 else loss_sum / float(S)
         if self.reg_weight > 0:  # identical on every rank (depends on the pattern only)
             tsor = ops.splat_fwd(pts, self.sigma, "softor", -1, s0, s1)
             diff = tsor - tsum
