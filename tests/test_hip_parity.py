@@ -1,6 +1,8 @@
 """GPU parity tests: every HIP entry point of libffx_hip.so is called through the C ABI and
 compared with (a) the golden vectors captured from the reference's torch code and (b) the CPU
 oracle on the same seeded inputs.  Tolerances are stated per test.  Run with `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -506,7 +508,11 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
     assert nbytes == 52 * 44 * spp * 16
     cache = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     img_c = gd.render_fwd(sd, dev(alb), tex, spp, seed=3, cache=cache)
-    assert torch.equal(img_c, gd.render_fwd(sd, dev(alb), tex, spp, seed=3))
+    img_p = gd.render_fwd(sd, dev(alb), tex, spp, seed=3)
+    if os.environ.get("FFX_TRAVERSAL") == "lane":  # the records are always written by the packet kernel
+        torch.testing.assert_close(img_c, img_p, rtol=1e-4, atol=1e-5 * float(img_p.max()))
+    else:
+        assert torch.equal(img_c, img_p)
     img_o, cache_o = go.render_fwd_cache(sd, alb, host(tex), spp, seed=3)
     rec_d = host(cache).view(np.uint32).reshape(-1, 4)
     rec_o = cache_o.view(np.uint32).reshape(-1, 4)
