@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 from fireflies_amd import _abi  # noqa: E402  (ABI declarations only; loads nothing)
 
-LIB_PATH = os.path.join(_HERE, "_build", "libffx_oracle.so")
+# FFX_ORACLE_LIB: use another build of the oracle (e.g. one compiled with -fsanitize=address,undefined)
+LIB_PATH = os.environ.get("FFX_ORACLE_LIB") or os.path.join(_HERE, "_build", "libffx_oracle.so")
 
 
 def build(force=False):
