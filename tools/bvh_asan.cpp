@@ -1,0 +1,24 @@
+// Host-side BVH builder under AddressSanitizer / UBSan (CPU only; GPU sanitizers are not available):
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/bvh_asan tools/bvh_asan.cpp fireflies_amd/csrc/ffx_bvh.cpp \&\& ASAN_OPTIONS=detect_leaks=0 /tmp/bvh_asan
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/ffx.h"
+int main() {
+  for (int trial = 0; trial < 6; ++trial) {
+    int F = trial == 0 ? 1 : (trial == 1 ? 5 : 3000 * trial + 7);
+    int V = 3 * F;
+    std::vector<float> v(3 * V);
+    std::vector<int32_t> t(3 * F);
+    srand(trial);
+    for (auto &x : v) x = (float)rand() / RAND_MAX * (trial == 2 ? 0.f : 10.f); // trial 2: all coincident
+    for (int i = 0; i < 3 * F; ++i) t[i] = i;
+    size_t nb = ffx_bvh_blob_bytes(F);
+    std::vector<unsigned char> blob(nb);
+    ffx_bvh_info info;
+    int rc = ffx_bvh_build_host(v.data(), V, t.data(), F, blob.data(), nb, &info);
+    printf("F=%d rc=%d nodes=%d depth=%d total=%llu / %zu\n", F, rc, info.n_nodes, info.max_depth, (unsigned long long)info.total_bytes, nb);
+    if (rc != 0 || info.total_bytes > nb) return 1;
+  }
+  return 0;
+}
