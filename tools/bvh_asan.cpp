@@ -1,5 +1,5 @@
 // Host-side BVH builder under AddressSanitizer / UBSan (CPU only; GPU sanitizers are not available):
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/bvh_asan tools/bvh_asan.cpp fireflies_amd/csrc/ffx_bvh.cpp \&\& ASAN_OPTIONS=detect_leaks=0 /tmp/bvh_asan
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o /tmp/bvh_asan tools/bvh_asan.cpp fireflies_amd/csrc/ffx_bvh.cpp && ASAN_OPTIONS=detect_leaks=0 /tmp/bvh_asan
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
