@@ -365,10 +365,19 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
 // contiguous 1/8 band of the image (best L2 locality, but bands differ a lot in cost: the XCD that
 // owns the vocal folds finishes last while others idle); mode 0 is the identity (XCDs interleave at
 // tile granularity: balanced; the whole BVH fits every XCD's L2 anyway).  Pure performance.
+// mode >= 2: blocked interleave with block size B = mode: within every group of 8*B workgroups, XCD k
+// walks B CONSECUTIVE work items — the waves resident on one CU then work on adjacent pixels and share
+// scalar-cache / L2 lines of the lower tree levels, while the groups stay small enough to balance.
 __device__ __forceinline__ int xcd_remap(int b, int nblocks, int mode) {
   if (mode == 0) return b;
-  int per = (nblocks + 7) / 8;
-  return (b % 8) * per + (b / 8);
+  if (mode == 1) {
+    int per = (nblocks + 7) / 8;
+    return (b % 8) * per + (b / 8);
+  }
+  const int B = mode, G = 8 * B;
+  const int g = b / G, r = b % G;
+  if ((g + 1) * G > nblocks) return b; // ragged last group: identity
+  return g * G + (r % 8) * B + (r / 8);
 }
 
 __global__ void __launch_bounds__(TR_BLOCK)
@@ -1175,9 +1184,17 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
   }
 }
 
+// tile index -> pixel.  tiles_x carries the enumeration: bits 0..23 the number of 2x2-pixel tiles per
+// image row, bits 24..27 tb: tiles are enumerated in square blocks of 2^tb x 2^tb tiles (row-major
+// inside a block, blocks row-major over the image; tb = 0: plain row-major), so that consecutive work
+// items — which the dispatcher hands to neighbouring wave slots — are compact 2-D patches of the image.
 template <int R>
-__device__ __forceinline__ void packet_pixels(int tile, int tiles_x, int sub, int (&px)[R], int (&py)[R]) {
-  const int bx = (tile % tiles_x) * 2, by = (tile / tiles_x) * 2;
+__device__ __forceinline__ void packet_pixels(int tile, int tiles_x_tb, int sub, int (&px)[R], int (&py)[R]) {
+  const int tb = (tiles_x_tb >> 24) & 15, tiles_x = tiles_x_tb & 0xffffff;
+  const int bt1 = (1 << tb) - 1, blocks_x = (tiles_x + bt1) >> tb;
+  const int blk = tile >> (2 * tb), within = tile & ((1 << (2 * tb)) - 1);
+  const int tx = ((blk % blocks_x) << tb) + (within & bt1), ty = ((blk / blocks_x) << tb) + (within >> tb);
+  const int bx = tx * 2, by = ty * 2;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (R == 2) { px[r] = bx + r; py[r] = by + sub; }
@@ -1544,6 +1561,15 @@ static int packet_waves() {
   return (w == 1 || w == 2 || w == 4) ? w : 1;
 }
 
+// log2 of the side (in 2x2-pixel tiles) of the square blocks in which tiles are enumerated: FFX_TILE_BLOCK,
+// default 3 = 16x16-pixel blocks (+1 % on both workloads against row-major; a blocked XCD interleave on
+// top of either enumeration, FFX_XCD_REMAP >= 2, swings between +3 % and -14 % with the image geometry)
+static int tile_block_log2() {
+  const char *e = getenv("FFX_TILE_BLOCK");
+  int t = e ? atoi(e) : 3;
+  return (t < 0 || t > 8) ? 3 : t;
+}
+
 // pixels of its 2x2 tile a wave of k_render_fwd_pk walks: FFX_PIXELS_PER_WAVE = 1, 2 (default) or 4.
 // Measured 4 / 2 / 1: 1133 / 1180 / 1165 renders/s (vocal fold), 62.0 / 62.6 / 62.2 (colon): shorter
 // waves even out the tail of the launch, one pixel per wave pays the wave start-up four times.
@@ -1590,7 +1616,8 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
 
 static int xcd_mode() {
   const char *e = getenv("FFX_XCD_REMAP");
-  return e ? (atoi(e) != 0) : 0;
+  int m = e ? atoi(e) : 0;
+  return m < 0 ? 0 : m;
 }
 
 static inline uint32_t seed_key_of(uint32_t seed) { return hash32(seed + 0x9e3779b9U); }
@@ -1678,7 +1705,10 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
-    int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
+    const int tb = tile_block_log2();
+    int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
+    int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb); // whole blocks; tiles outside the image are skipped
+    ptx |= tb << 24;
     const int wpb = packet_waves();
     const int ppw = pixels_per_wave();
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
@@ -1739,7 +1769,10 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (use_packet()) {
-    int ptx = ffx_cdiv(c.cam.W, 2), pn = ptx * ffx_cdiv(c.cam.H, 2);
+    const int tb = tile_block_log2();
+    int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
+    int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb);
+    ptx |= tb << 24;
     const int wpb = packet_waves();
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8;
     const TriApex *arecs;

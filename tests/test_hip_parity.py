@@ -465,12 +465,12 @@ def test_k7_axis_parallel_rays_are_not_pathological():
 
 
 @pytest.mark.parametrize("env", [{"FFX_TRAVERSAL": "lane"}, {}, {"FFX_XCD_REMAP": "1", "FFX_PACKET_WAVES": "4", "FFX_PIXELS_PER_WAVE": "4"},
-                                 {"FFX_PACKET_WAVES": "2", "FFX_PIXELS_PER_WAVE": "1"}])
+                                 {"FFX_PACKET_WAVES": "2", "FFX_PIXELS_PER_WAVE": "1", "FFX_TILE_BLOCK": "0"}, {"FFX_XCD_REMAP": "16", "FFX_TILE_BLOCK": "2"}])
 def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
     """the per-lane kernels (apex vectors formed per ray), the wave-packet kernels (apex records
     precomputed per render call) and the launch-shape knobs all compute the same image and the same
     texture gradient (odd film size, spp not a multiple of 64, both shadow settings)."""
-    for k in ("FFX_TRAVERSAL", "FFX_XCD_REMAP", "FFX_PACKET_WAVES", "FFX_PIXELS_PER_WAVE"):
+    for k in ("FFX_TRAVERSAL", "FFX_XCD_REMAP", "FFX_PACKET_WAVES", "FFX_PIXELS_PER_WAVE", "FFX_TILE_BLOCK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
