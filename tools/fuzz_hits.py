@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Fuzz: packet K7 / K8 against the CPU oracle over many random poses (run on an MI355X).
+Counts rays whose primitive differs and — the failure a non-conservative box test would cause — rays the
+oracle hits but the GPU misses; and the worst per-pixel radiance difference."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fireflies_amd import ops, scene_desc, scenes  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def main():
+    n_pose = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    rng = np.random.default_rng(123)
+    sc = scenes.vocalfold(width=96, height=80, tex=64, frames=6, n_fold=24, tube=(24, 32))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    gd = ops.DeviceGeometry(pool, tris, shape, off)
+    go = oracle.Geometry(pool, tris, shape, off)
+    cam = scene_desc.camera_from_sensor(sc.camera)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    tex = torch.rand((64, 64, 1), device="cuda")
+    tot = flips = lost = 0
+    worst = 0.0
+    bad_px = 0
+    npx = 0
+    for i in range(n_pose):
+        a = rng.uniform(-0.2, 0.2)
+        R = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+        S = np.diag([rng.uniform(0.6, 1.6), rng.uniform(0.8, 1.2), 1.0, 1.0])
+        T = np.eye(4)
+        T[:3, 3] = rng.uniform(-0.08, 0.08, 3)
+        xf = np.stack([np.eye(4), T @ R @ S]).astype(np.float32)
+        offs = off.copy()
+        offs[1] = off[1] + int(rng.integers(0, nfr[1])) * stride[1]
+        gd.update(xf, offs)
+        go.update(xf, offs)
+        spp = int(rng.choice([1, 4, 64]))
+        td, sd_, pd = gd.trace_primary(cam, spp, 1, seed=i)
+        to, so, po = go.trace_primary(cam, spp, 1, seed=i)
+        pd, sd_ = pd.cpu().numpy(), sd_.cpu().numpy()
+        tot += pd.size
+        flips += int(((pd != po) | (sd_ != so)).sum())
+        lost += int(((pd < 0) & (po >= 0)).sum())
+        img_d = gd.render_fwd(sd, torch.from_numpy(alb).cuda(), tex, 16, seed=i).cpu().numpy()
+        img_o = go.render_fwd(sd, alb, tex.cpu().numpy(), 16, seed=i)
+        err = np.abs(img_d - img_o) / max(float(img_o.max()), 1e-6)
+        worst = max(worst, float(err.max()))
+        bad_px += int((err > 1e-4).sum())
+        npx += err.size
+    print(f"poses {n_pose}: rays {tot}, different primitive {flips} ({flips / tot:.2e}), oracle-hit-but-GPU-miss {lost}")
+    print(f"render: pixels*channels {npx}, |diff| > 1e-4 of scale: {bad_px} ({bad_px / npx:.2e}), worst {worst:.3e} of scale")
+
+
+if __name__ == "__main__":
+    main()
