@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--grid", type=int, default=16, help="laser grid (grid x grid points) for renders; 256 points by default")
     ap.add_argument("--grad-grid", type=int, default=8, help="laser grid of the gradient-step bracket (configs[1]: 64 points)")
     ap.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU-oracle baseline render (64 = the full workload, no scaling)")
+    ap.add_argument("--grad-samples", type=int, default=0, help="scene samples per gradient step over all ranks (0 = one per rank; BASELINE configs[3]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-steps", action="store_true")
     ap.add_argument("--no-render-steps", action="store_true", help="profiling aid: skip the render bracket (prints a reduced line)")
@@ -234,7 +235,8 @@ def main():
     grad = {}
     if not args.no_grad_steps:
         wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device)
-        opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=world, base_seed=7)
+        S = args.grad_samples if args.grad_samples > 0 else world
+        opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=S, base_seed=7)
         gevents = []
 
         def grad_step(i):
@@ -253,9 +255,9 @@ def main():
         bytes_k9c = 16 * W * H * args.spp + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
         grad = {
             "grad_steps_per_sec": args.steps / t_grad,
-            "grad_samples_per_sec": world * args.steps / t_grad,
+            "grad_samples_per_sec": S * args.steps / t_grad,
             "grad_ms_per_step": 1e3 * t_grad / args.steps,
-            "grad_config": {"points": args.grad_grid**2, "samples_per_step": world, "samples_per_rank": 1},
+            "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world))},
             "grad_kernels_ms": {"render_fwd(+cache write)": k8g_ms, "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
             "render_bwd_cached_roofline": None if k9c_ms is None else {
                 "kernel": "k_render_bwd_cached (streams the per-sample records written by K8)", "bound": "hbm",
