@@ -347,3 +347,53 @@ def test_clamp_to_fov_properties(oracle):
     assert 10 < inside.sum() < 190
     np.testing.assert_allclose(out[inside], r[inside], atol=3e-6)  # untouched apart from rounding
     assert oracle.clamp_to_fov(np.zeros((0, 3), np.float32), KF.astype(np.float32), KI.astype(np.float32), lo, hi).shape == (0, 3)
+
+
+def test_pattern_gradient_matches_central_differences(oracle):
+    """The whole chain of the hot path on the oracle: pattern rays -> K1 -> K2 (sum) -> K3 -> K8 -> loss,
+    and its adjoint K9 -> K3^T -> K2-bwd -> K1-bwd, against central differences of the loss with respect
+    to individual ray components.  The render is linear in the texture and visibility does
+    not depend on it, so the only approximation is the finite step in the smooth splat."""
+    sc = scenes.vocalfold(width=40, height=32, tex=48, frames=2, n_fold=12, tube=(16, 16))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    g = oracle.Geometry(pool, tris, shape, off)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    K = sc.projector.K.astype(np.float64)
+    KF = (K @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    a = 0.0275 * 18 / 4
+    gx, gy = np.meshgrid(np.arange(4) - 1.5, np.arange(4) - 1.5, indexing="ij")
+    rays = np.stack([np.tan(gx.reshape(-1) * a), np.tan(gy.reshape(-1) * a), -np.ones(16)], 1)
+    rays = (rays / np.linalg.norm(rays, axis=1, keepdims=True)).astype(np.float32)
+    rng = np.random.default_rng(11)
+    w = rng.random((32, 40, 3)).astype(np.float32)  # loss = sum(w * img)
+    sigma, spp, seed = 10.0, 4, 2
+
+    def tex_of(r):
+        pts = np.ascontiguousarray(oracle.project_rays_fwd(r, KF)[:, :2])
+        tsum = oracle.splat_fwd(pts, sigma, 0, -1, 48, 48)
+        return pts, tsum, oracle.blur_fwd(tsum)
+
+    def loss_of(r):
+        _, _, tex = tex_of(r)
+        img = g.render_fwd(sd, alb, tex[..., None], spp, seed=seed)
+        return float((img.astype(np.float64) * w).sum())
+
+    pts, tsum, tex = tex_of(rays)
+    gtex = g.render_bwd(sd, alb, spp, seed, w)[..., 0]
+    assert np.abs(gtex).sum() > 0
+    gts = oracle.blur_bwd(gtex)
+    gp = oracle.splat_bwd(pts, sigma, 0, -1, 48, 48, tsum, gts)
+    grays = oracle.project_rays_bwd(rays, KF, np.c_[gp, np.zeros(len(gp), np.float32)].astype(np.float32))
+    scale = np.abs(grays).max()
+    assert scale > 0
+    h = 2e-3
+    checked = 0
+    for i in (0, 5, 6, 9, 10, 15):
+        for c in (0, 1):
+            rp, rm = rays.copy(), rays.copy()
+            rp[i, c] += h
+            rm[i, c] -= h
+            fd = (loss_of(rp) - loss_of(rm)) / (2 * h)
+            assert abs(fd - grays[i, c]) <= 0.02 * abs(fd) + 0.01 * scale, (i, c, fd, grays[i, c])
+            checked += 1
+    assert checked == 12
