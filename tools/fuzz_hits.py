@@ -15,8 +15,12 @@ from oracle import oracle  # noqa: E402
 
 def main():
     n_pose = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    which = sys.argv[2] if len(sys.argv) > 2 else "vocalfold"
     rng = np.random.default_rng(123)
-    sc = scenes.vocalfold(width=96, height=80, tex=64, frames=6, n_fold=24, tube=(24, 32))
+    if which == "colon":  # the 524,288-triangle scene of config 5 at a small film
+        sc = scenes.colon(width=96, height=80, tex=64)
+    else:
+        sc = scenes.vocalfold(width=96, height=80, tex=64, frames=6, n_fold=24, tube=(24, 32))
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
     gd = ops.DeviceGeometry(pool, tris, shape, off)
     go = oracle.Geometry(pool, tris, shape, off)
@@ -33,9 +37,10 @@ def main():
         S = np.diag([rng.uniform(0.6, 1.6), rng.uniform(0.8, 1.2), 1.0, 1.0])
         T = np.eye(4)
         T[:3, 3] = rng.uniform(-0.08, 0.08, 3)
-        xf = np.stack([np.eye(4), T @ R @ S]).astype(np.float32)
+        xf = np.stack([np.eye(4)] * (len(off) - 1) + [T @ R @ S]).astype(np.float32)
         offs = off.copy()
-        offs[1] = off[1] + int(rng.integers(0, nfr[1])) * stride[1]
+        if len(off) > 1:
+            offs[1] = off[1] + int(rng.integers(0, nfr[1])) * stride[1]
         gd.update(xf, offs)
         go.update(xf, offs)
         spp = int(rng.choice([1, 4, 64]))
