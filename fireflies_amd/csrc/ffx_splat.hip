@@ -141,6 +141,33 @@ __global__ void __launch_bounds__(256) k_clamp_to_fov(float *__restrict__ rays, 
   rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
 }
 
+// L1Loss(a, b) * weight and its gradient in two launches (sub, abs, mean, mul, sign, mul, neg as torch ops
+// were seven): partial sums per workgroup in a fixed order, then one workgroup adds the <= 256 partials
+__global__ void __launch_bounds__(256) k_l1_partial(const float *__restrict__ a, const float *__restrict__ b, long n, float gscale, float *__restrict__ ws,
+                                                     float *__restrict__ g) {
+  __shared__ float s_part[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    acc += fabsf(d);
+    g[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[1 + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+__global__ void __launch_bounds__(256) k_l1_final(float *__restrict__ ws, int nblocks, float vscale) {
+  __shared__ float s_part[4];
+  float acc = (int)threadIdx.x < nblocks ? ws[1 + threadIdx.x] : 0.f;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[0] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * vscale;
+}
+
 // =================================================================================== K2 dense forward
 // rasterize_points: [n,size1,size0] layers.  HBM-write bound (4 B per (point, texel)); each lane
 // produces 4 consecutive texels and issues one 16-byte store when rows are 16-byte aligned.
@@ -502,6 +529,15 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
   for (int i = 0; i < 16; ++i) m.m[i] = M[i];
   hipLaunchKernelGGL(k_transform_points, dim3(ffx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, pts, n, m, mode, out);
   FFX_CHECK_LAUNCH("transform_points");
+  return FFX_OK;
+}
+
+int ffx_l1_value_grad(const float *a, const float *b, long n, float weight, float *ws, float *g, ffx_stream s) {
+  if (!a || !b || !ws || !g || n < 1) FFX_FAIL(FFX_ERR_ARG, "l1_value_grad: bad argument");
+  int blocks = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  hipLaunchKernelGGL(k_l1_partial, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, n, weight / (float)n, ws, g);
+  hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(256), 0, (hipStream_t)s, ws, blocks, weight / (float)n);
+  FFX_CHECK_LAUNCH("l1_value_grad");
   return FFX_OK;
 }
 

@@ -65,6 +65,14 @@ def transform_points(pts, M, mode=0):
     return out
 
 
+def l1_value_grad(a, b, weight=1.0):
+    """weight * L1Loss(a, b) (a 0-dim view into the workspace) and its gradient with respect to `a`"""
+    ws = torch.empty(257, dtype=torch.float32, device=a.device)
+    g = torch.empty_like(a)
+    api().call("ffx_l1_value_grad", _dev(a, name="a"), _dev(b, name="b"), a.numel(), float(weight), _dev(ws), _dev(g), _stream())
+    return ws[0], g
+
+
 def clamp_to_fov_(rays, KF, KF_inv, lo, hi, n_normalize=1):
     """in place: Laser.clamp_to_fov (+ n_normalize - 1 further normalisations) in one launch"""
     api().call("ffx_clamp_to_fov", _dev(rays, name="rays"), rays.shape[0], _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), _stream())

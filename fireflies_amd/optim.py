@@ -155,11 +155,9 @@ class PatternOptimizer:
             loss = loss_sum if S == 1 else loss_sum / float(S)
         if self.reg_weight > 0:  # identical on every rank (depends on the pattern only)
             tsor = ops.splat_fwd(pts, self.sigma, "softor", -1, s0, s1)
-            diff = tsor - tsum
-            reg = self.reg_weight * diff.abs().mean()
-            gd = torch.sign(diff) * (self.reg_weight / float(diff.numel()))
-            # d reg / d pts through both splats (autograd accumulates the softor branch first)
-            gp = ops.splat_bwd(pts, self.sigma, "softor", -1, s0, s1, tsor, gd) + ops.splat_bwd(pts, self.sigma, "sum", -1, s0, s1, tsum, -gd)
+            # reg = w * L1Loss(softor, sum) and d reg / d softor in two launches; d reg / d sum is its negative
+            reg, gd = ops.l1_value_grad(tsor, tsum, self.reg_weight)
+            gp = ops.splat_bwd(pts, self.sigma, "softor", -1, s0, s1, tsor, gd) - ops.splat_bwd(pts, self.sigma, "sum", -1, s0, s1, tsum, gd)
             grad += ops.project_rays_bwd(rd, KF, torch.nn.functional.pad(gp, (0, 1)))
             loss = loss + reg
         rays.grad = grad

@@ -124,6 +124,13 @@ int ffx_splat_depth_fwd(const float *pts /*[dev][n,2]*/, const float *depth /*[d
 int ffx_splat_lines_fwd(const float *lines /*[dev][n,2,2]*/, int n, float sigma, int size0,
                         int size1, float *out /*[dev][n,size1,size0]*/, ffx_stream stream);
 
+/* Overlap regulariser of the reference's point-pattern loop, L1Loss(softor, sum)
+ * (fireflies/graphics/rasterization.py:579,589-600), with its gradient:
+ *   ws[0] = weight * mean(|a - b|);   g = weight * sign(a - b) / n   (= d ws[0] / d a;  d ws[0] / d b = -g)
+ * ws: [dev][257] floats — [0] the value, [1..256] scratch for the two-pass reduction (fixed order). */
+int ffx_l1_value_grad(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, long n, float weight,
+                      float *ws /*[dev][257]*/, float *g /*[dev][n]*/, ffx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * K3  texture finalise: separable Gaussian blur, reflect border.
  * Replaces kornia.filters.gaussian_blur2d(tex, (k,k), (s,s)) at

@@ -148,6 +148,22 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
   return FFX_OK;
 }
 
+/* overlap regulariser L1Loss(softor, sum) of the reference's point-pattern loop
+ * (fireflies/graphics/rasterization.py:579,589-600) and its gradient */
+int ffx_l1_value_grad(const float *a, const float *b, long n, float weight, float *ws, float *g, ffx_stream s) {
+  (void)s;
+  if (!a || !b || !ws || !g || n < 1) FAIL(FFX_ERR_ARG, "l1_value_grad: bad argument");
+  double acc = 0.0;
+  const float gs = weight / (float)n;
+  for (long i = 0; i < n; ++i) {
+    const float d = a[i] - b[i];
+    acc += fabs((double)d);
+    g[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+  }
+  ws[0] = (float)(acc * (double)gs);
+  return FFX_OK;
+}
+
 /* Laser.clamp_to_fov + Laser.normalize_rays (fireflies/projection/laser.py:199-206,254-255):
  * project with KF, clamp the screen xy to [lo, hi], un-project with KF_inv, normalise n_normalize times */
 int ffx_clamp_to_fov(float *rays, int n, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {

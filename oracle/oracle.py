@@ -74,6 +74,14 @@ def transform_points(pts, M, mode=0):
     return out
 
 
+def l1_value_grad(a, b, weight=1.0):
+    a, b = _f32(a), _f32(b)
+    ws = np.zeros(257, np.float32)
+    g = np.empty_like(a)
+    api().call("ffx_l1_value_grad", _p(a), _p(b), a.size, float(weight), _p(ws), _p(g), None)
+    return float(ws[0]), g
+
+
 def clamp_to_fov(rays, KF, KF_inv, lo, hi, n_normalize=1):
     out = _f32(rays).copy()
     api().call("ffx_clamp_to_fov", _p(out), out.shape[0], _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), None)

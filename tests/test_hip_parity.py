@@ -330,6 +330,18 @@ def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
         assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
 
 
+def test_l1_value_grad_matches_oracle(oracle):
+    rng = np.random.default_rng(6)
+    for shape in ((500, 500), (7, 3), (1, 1)):
+        a = rng.random(shape).astype(np.float32)
+        b = rng.random(shape).astype(np.float32)
+        b.flat[0] = a.flat[0]
+        v, g = ops.l1_value_grad(dev(a), dev(b), 0.1)
+        vo, go = oracle.l1_value_grad(a, b, 0.1)
+        assert abs(float(v) - vo) <= 2e-6 * max(vo, 1e-6)
+        np.testing.assert_array_equal(host(g), go)
+
+
 def test_clamp_to_fov_matches_oracle(oracle):
     K = scenes.perspective_projection(64, 64, 30.0, 0.01, 100.0).astype(np.float64)
     KF = (K @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)

@@ -397,3 +397,16 @@ def test_pattern_gradient_matches_central_differences(oracle):
             assert abs(fd - grays[i, c]) <= 0.02 * abs(fd) + 0.01 * scale, (i, c, fd, grays[i, c])
             checked += 1
     assert checked == 12
+
+
+def test_l1_value_grad(oracle):
+    """weight * L1Loss(a, b) (rasterization.py:579,589-600) and its gradient with respect to a"""
+    rng = np.random.default_rng(2)
+    a = rng.random((37, 53)).astype(np.float32)
+    b = rng.random((37, 53)).astype(np.float32)
+    b[3, 4] = a[3, 4]  # sign(0) = 0 (torch.sign)
+    v, g = oracle.l1_value_grad(a, b, 0.1)
+    d = a.astype(np.float64) - b.astype(np.float64)
+    assert abs(v - 0.1 * np.abs(d).mean()) < 1e-7
+    np.testing.assert_allclose(g, 0.1 * np.sign(d) / d.size, rtol=1e-6, atol=0)
+    assert g[3, 4] == 0.0
