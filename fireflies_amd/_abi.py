@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 1
+FFX_ABI_VERSION = 2
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -28,6 +28,14 @@ class BvhInfo(C.Structure):
         ("off_recs", C.c_uint64),
         ("total_bytes", C.c_uint64),
         ("level_start", C.c_int32 * (FFX_MAX_LEVELS + 1)),
+        ("n_wide", C.c_int32),
+        ("wide_depth", C.c_int32),
+        ("wide_root", C.c_int32),
+        ("wide_pad", C.c_int32),
+        ("off_wnodes", C.c_uint64),
+        ("off_wsrc", C.c_uint64),
+        ("off_tq", C.c_uint64),
+        ("off_whdr", C.c_uint64),
     ]
 
 

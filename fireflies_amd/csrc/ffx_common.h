@@ -96,6 +96,22 @@ static_assert(sizeof(TriApex) == 48, "apex record must be 48 bytes");
 static inline uint64_t ffx_apex_stride(int n_tris) { return ((((uint64_t)n_tris + FFX_LEAF_MAX) * 48u) + 63u) & ~(uint64_t)63; }
 static inline uint64_t ffx_apex_offset(const ffx_bvh_info *info, int k) { return info->total_bytes - (uint64_t)(FFX_N_APEX - k) * ffx_apex_stride(info->n_tris); }
 
+// ------------------------------------------------------------------ 64-wide overlay
+// One child of a wide node, or one triangle of a cluster: a box on the 16-bit grid of the current pose
+// (x = org + q * step per axis; q[0..2] round down, q[3..5] round up, one extra cell of slack each) and
+// a reference.  ref >= 0: wide inner node, (index << 6) | (children - 1).  ref < 0: cluster,
+// ~ref = (first_slot << 6) | (triangles - 1).  In the triangle array `ref` is unused.
+struct __attribute__((aligned(16))) WideChild {
+  uint16_t q[6];
+  int32_t ref;
+};
+static_assert(sizeof(WideChild) == 16, "wide child must be 16 bytes");
+#define FFX_WIDE 64
+#define FFX_WIDE_MAX_DEPTH 6
+// grid header written by the refit: org[3], step[3] (floats)
+struct WideHdr { float org[3]; float step[3]; float pad[10]; };
+static_assert(sizeof(WideHdr) == 64, "wide header must be 64 bytes");
+
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };
 

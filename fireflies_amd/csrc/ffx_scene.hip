@@ -122,6 +122,66 @@ __global__ void __launch_bounds__(TAIL_BLOCK) k_refit_tail(BvhNode *nodes, const
   }
 }
 
+// ---- 64-wide overlay (ffx_common.h): after the binary refit, every box the wave-packet kernels test is
+// re-expressed on a 16-bit grid spanning the scene's bounding box of THIS pose (the root box the refit
+// just produced): triangle boxes in leaf-slot order and the children of the wide inner nodes, each of which
+// is the box of one binary node (wsrc: binary node * 2 + side).  q_lo = floor - 1, q_hi = ceil + 1: the
+// extra cell (1.5e-5 of the scene extent) absorbs every rounding of the de-quantisation in the kernels.
+__device__ __forceinline__ void grid_of_root(const BvhNode *__restrict__ nodes, float org[3], float step[3], float inv[3]) {
+  const BvhNode &n = nodes[0];
+  float ext[3], emax = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = fminf(n.lo0[a], n.lo1[a]), hi = fmaxf(n.hi0[a], n.hi1[a]);
+    org[a] = lo;
+    ext[a] = hi - lo;
+    emax = fmaxf(emax, ext[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float e = fmaxf(ext[a], fmaxf(emax * 1e-6f, 1e-30f)); // a flat scene still gets a non-degenerate grid
+    step[a] = e * (1.0f / 65533.0f);                            // cells 1 .. 65534 span the box: the slack cell never clips
+    inv[a] = 65533.0f / e;
+    org[a] -= step[a];
+  }
+}
+__device__ __forceinline__ void quantise_box(const float lo[3], const float hi[3], const float org[3], const float inv[3], WideChild &c) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ql = floorf((lo[a] - org[a]) * inv[a]) - 1.0f, qh = ceilf((hi[a] - org[a]) * inv[a]) + 1.0f;
+    c.q[a] = (uint16_t)fminf(fmaxf(ql, 0.f), 65535.f);
+    c.q[3 + a] = (uint16_t)fminf(fmaxf(qh, 0.f), 65535.f);
+  }
+}
+__global__ void __launch_bounds__(UPD_BLOCK)
+    k_wide_quant(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, int n_tris, WideChild *__restrict__ tq, WideChild *__restrict__ wn,
+                 const int32_t *__restrict__ wsrc, int n_wchild, WideHdr *__restrict__ hdr) {
+  const int i = blockIdx.x * UPD_BLOCK + threadIdx.x;
+  float org[3], step[3], inv[3];
+  grid_of_root(nodes, org, step, inv);
+  if (i == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { hdr->org[a] = org[a]; hdr->step[a] = step[a]; }
+  }
+  if (i < n_tris) {
+    float lo[3], hi[3];
+    leaf_box(recs, ~(int32_t)((uint32_t)i << 3), lo, hi); // the padded box of the single triangle in slot i
+    WideChild c;
+    quantise_box(lo, hi, org, inv, c);
+    c.ref = 0;
+    tq[i] = c;
+  } else if (i < n_tris + n_wchild) {
+    const int k = i - n_tris;
+    const int src = wsrc[k];
+    if (src < 0) return;
+    const BvhNode &n = nodes[src >> 1];
+    WideChild c = wn[k];
+    if (src & 1) quantise_box(n.lo1, n.hi1, org, inv, c);
+    else quantise_box(n.lo0, n.hi0, org, inv, c);
+    wn[k] = c;
+  }
+}
+
 static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
                              const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s, bool host_tab) {
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
@@ -168,6 +228,13 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
     for (int m = 0; m <= lv.n; ++m) lv.start[m] = info->level_start[l + m];
     hipLaunchKernelGGL(k_refit_tail, dim3(1), dim3(TAIL_BLOCK), 0, st, nodes, recs, refit, lv);
     FFX_CHECK_LAUNCH("scene_update/refit_tail");
+  }
+  if (info->off_tq != 0) { // the 64-wide overlay of the wave-packet kernels
+    const int n_wchild = info->n_wide * FFX_WIDE;
+    hipLaunchKernelGGL(k_wide_quant, dim3(ffx_cdiv((long)info->n_tris + n_wchild, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, nodes, recs, info->n_tris,
+                       (WideChild *)(base + info->off_tq), (WideChild *)(base + info->off_wnodes), (const int32_t *)(base + info->off_wsrc), n_wchild,
+                       (WideHdr *)(base + info->off_whdr));
+    FFX_CHECK_LAUNCH("scene_update/wide_quant");
   }
   return FFX_OK;
 }

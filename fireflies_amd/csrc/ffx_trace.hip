@@ -896,6 +896,317 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
   found = __builtin_amdgcn_inverse_ballot_w64(occluded);
 }
 
+// ------------------------------------------------------------------------------------------ 64-wide packet walk
+// tools/ubench/issue_rates.hip (profiles/r2_issue_rates.txt) measured what bounds the binary packet walk
+// above: on gfx950 a VALU instruction with an SGPR source operand, and every min/max/compare/select,
+// issues once per ~4.3 cycles per SIMD, while mul/add/fma on VGPR operands issue every ~2.3 — and the
+// binary walk's box test is ten 4.3-cycle instructions PER BOX, each computing the same answer in 64 lanes
+// (the rays of a one-pixel packet are practically one ray).  This walk turns the lanes around for the box
+// tests: a node has up to 64 children and LANE j TESTS CHILD j against the packet as a whole,
+//     enter >= max_a (near_plane_a - o_a) * N_a        leave <= min_a (far_plane_a - o_a) * F_a
+// with N_a / F_a the smallest / largest |1/d_a| of the packet's rays (they share their origin o, so the
+// interval test costs exactly what a single ray costs: six fma on VGPR operands + four 4.3-cycle ops for 64
+// boxes).  Triangles sit in clusters of up to 64 consecutive leaf slots whose boxes are tested the same way;
+// only the triangles that survive are tested exactly, with the lanes back on the rays (same apex test, same
+// acceptance rule: results are identical to the binary walk, closest hit with the primitive-id tie-break
+// is order independent).  Boxes live on a 16-bit grid (ffx_common.h: WideChild, 16 B per child: a node is one
+// coalesced 1 KB load); the grid is folded into the packet constants once per walk, so de-quantisation is
+// six integer-to-float conversions per step.  The traversal stack (reference, entry distance) is in LDS.
+struct WideScene { const WideChild *wn; const WideChild *tq; const WideHdr *hdr; int32_t root; };
+#define FFX_WSTACK (63 * FFX_WIDE_MAX_DEPTH + 6)
+// per-walk constants, uniform across the wave: tn_a = fma(q_near_a, mN_a, -kN_a), tf_a = fma(q_far_a, mF_a, -kF_a)
+// (GEN walks only) a second entry term per axis from the FAR plane, tg_a = fma(q_far_a, mG_a, -kG_a): an axis on
+// which the packet's rays disagree in sign has two entry bounds and no exit bound (see make_widepk).
+struct WidePk { v3 mN, kN, mF, kF, mG, kG; wmask neg[3]; };
+
+#define FFX_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), 0xf, 0xf, false))
+// wave-wide min / max of the bit patterns of NON-NEGATIVE floats (they order like unsigned integers): four
+// DPP steps inside each row of 16 lanes (quad swap, quad-pair swap, half-row mirror, row mirror), then the
+// four row results are combined on the scalar ALU.  The result is wave-uniform (SGPR).
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce_nn(uint32_t v) {
+#define FFX_RSTEP(ctrl) { const uint32_t o_ = FFX_DPP(v, ctrl); v = MAX ? (v > o_ ? v : o_) : (v < o_ ? v : o_); }
+  FFX_RSTEP(0xB1)  // quad_perm [1,0,3,2]
+  FFX_RSTEP(0x4E)  // quad_perm [2,3,0,1]
+  FFX_RSTEP(0x141) // row_half_mirror
+  FFX_RSTEP(0x140) // row_mirror
+#undef FFX_RSTEP
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  if (MAX) { const uint32_t x = a > b ? a : b, y = c > e ? c : e; return x > y ? x : y; }
+  const uint32_t x = a < b ? a : b, y = c < e ? c : e;
+  return x < y ? x : y;
+}
+__device__ __forceinline__ uint32_t mbcnt64(wmask m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+__device__ __forceinline__ int wff1(wmask m) { return __builtin_ctzll(m); }
+
+// the packet constants of one walk.  `aid[r]` = |scaled 1/d| of ray r per axis, `oct[r]` its direction signs,
+// `oct0` the packet's octant (signs of its first active ray), `mixed` the axes on which the active rays
+// disagree in sign.  On a mixed axis the packet is a wedge that opens both ways: it reaches a box beyond
+// `lo` no earlier than (lo - o) * min(1/d+) and a box before `hi` no earlier than (o - hi) * min(1/|d-|), and
+// it never leaves the slab for good — two entry bounds, no exit bound.  (Dropping the axis instead is
+// conservative too, but a packet with two mixed axes — a pixel next to the image centre — then walks every
+// box in its depth range: one such wave took 7 ms.)
+template <int R>
+__device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v3 o, const v3 (&aid)[R], const uint32_t (&oct)[R], const wmask (&active)[R],
+                                              uint32_t oct0, uint32_t mixed) {
+  const float org[3] = {hdr->org[0], hdr->org[1], hdr->org[2]}, step[3] = {hdr->step[0], hdr->step[1], hdr->step[2]};
+  const float oo[3] = {o.x, o.y, o.z};
+  float mN[3], kN[3], mF[3], kF[3], mG[3], kG[3];
+  const float k22 = 2.384185791015625e-07f, k21 = 4.76837158203125e-07f, kw = 1.0000004f;
+  WidePk pk;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const bool is_mixed = (mixed >> a) & 1u;
+    // smallest / largest |1/d_a| over the active rays; on a mixed axis: the smallest of each sign
+    uint32_t lo = 0x7f800000u, hi = 0u, lo2 = 0x7f800000u; // +inf, 0, +inf
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t v = __float_as_uint(a == 0 ? aid[r].x : (a == 1 ? aid[r].y : aid[r].z));
+      const wmask negr = __builtin_amdgcn_uicmp((oct[r] >> a) & 1u, 0u, 33);
+      const wmask first = is_mixed ? (active[r] & ~negr) : active[r];
+      const uint32_t vl = msel(first, v, 0x7f800000u), vh = msel(active[r], v, 0u), vl2 = msel(active[r] & negr, v, 0x7f800000u);
+      lo = lo < vl ? lo : vl;
+      hi = hi > vh ? hi : vh;
+      lo2 = lo2 < vl2 ? lo2 : vl2;
+    }
+    const float mn = __uint_as_float(wave_reduce_nn<false>(lo));
+    const bool negd = !is_mixed && ((oct0 >> a) & 1u);
+    pk.neg[a] = negd ? ~0ull : 0ull;
+    const float sN = negd ? -mn : mn;
+    // near side (same padding as make_rayoct: the entry can only move earlier)
+    const float oidn = oo[a] * sN, cN = oidn + fabsf(oidn) * k22;
+    const float gn = org[a] * sN;
+    mN[a] = step[a] * sN;
+    kN[a] = (cN - gn) + (fabsf(cN) + fabsf(gn)) * k21;
+    if (!is_mixed) {
+      // far side, widened (make_rayslab)
+      const float mx = __uint_as_float(wave_reduce_nn<true>(hi));
+      const float sF = negd ? -mx : mx;
+      const float oidf = oo[a] * sF, cF = (oidf - fabsf(oidf) * k22) * kw;
+      const float sFk = sF * kw, gf = org[a] * sFk;
+      mF[a] = step[a] * sFk;
+      kF[a] = (cF - gf) - (fabsf(cF) + fabsf(gf)) * k21;
+      mG[a] = 0.f;
+      kG[a] = 1e30f; // tg_a = -1e30
+    } else {
+      // second entry bound from the far (= hi) plane: (o - x) * m2 = fma(q, -step * m2, -(org * m2 - o * m2))
+      const float m2 = __uint_as_float(wave_reduce_nn<false>(lo2));
+      const float og = oo[a] * m2, gg = org[a] * m2;
+      mG[a] = -(step[a] * m2);
+      kG[a] = (gg - og) + (fabsf(gg) + fabsf(og)) * k21;
+      mF[a] = 0.f;
+      kF[a] = -1e30f; // tf_a = +1e30
+    }
+  }
+  pk.mN = V3(mN[0], mN[1], mN[2]); pk.kN = V3(kN[0], kN[1], kN[2]);
+  pk.mF = V3(mF[0], mF[1], mF[2]); pk.kF = V3(kF[0], kF[1], kF[2]);
+  pk.mG = V3(mG[0], mG[1], mG[2]); pk.kG = V3(kG[0], kG[1], kG[2]);
+  return pk;
+}
+
+template <bool ANY, int OCT, int R>
+__device__ __forceinline__ void traverse_wide_oct(const WideScene &ws, const TriApex *__restrict__ recs, const WidePk &pk, const v3 (&d)[R], const float (&tmin)[R],
+                                                  const float (&tmax)[R], const float (&sw)[R], const wmask (&active)[R], Hit (&h)[R], wmask (&occluded)[R],
+                                                  uint2 *__restrict__ stack) {
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    h[r].t = msel(active[r], tmax[r], -INFINITY);
+    h[r].prim = -1;
+    h[r].shape = -1;
+    h[r].slot = -1;
+    occluded[r] = 0ull;
+  }
+  // the packet's hit distance in box-test units (the largest over its rays: a box matters while ANY ray can
+  // still reach it), as the bit pattern of a non-negative float; refreshed whenever a ray's hit improves
+  auto packet_hts = [&]() -> uint32_t {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = fmaxf(m, h[r].t * sw[r]); // -inf (inactive / occluded) drops out against 0
+    return wave_reduce_nn<true>(__float_as_uint(m));
+  };
+  uint32_t hb = packet_hts();
+  int sp = 0;
+  int32_t cur = ws.root;
+  const char *rbase = reinterpret_cast<const char *>(recs);
+  FFX_STAT(ANY ? 4 : 0);
+  while (true) {
+    FFX_STAT(ANY ? 5 : 1);
+    // ---- fetch: lane j reads child j (inner node) or triangle box first + j (cluster): one 16-byte load per lane
+    const bool is_cluster = cur < 0;
+    const uint32_t code = is_cluster ? (uint32_t)~cur : (uint32_t)cur;
+    const uint32_t base = code >> 6, cnt = (code & 63u) + 1u;
+    const WideChild *src = is_cluster ? ws.tq + base : ws.wn + (size_t)base * FFX_WIDE;
+    const wmask lanes = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+    uint4 q = make_uint4(0xffffffffu, 0x0000ffffu, 0u, 0u);
+    if ((uint32_t)lane < cnt) q = *reinterpret_cast<const uint4 *>(src + lane);
+    const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
+    const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
+    float nx, ny, nz, fx, fy, fz, tn;
+    if constexpr (OCT < 8) { // which plane is entered first is known at compile time
+      nx = (OCT & 1) ? hx : lx; fx = (OCT & 1) ? lx : hx;
+      ny = (OCT & 2) ? hy : ly; fy = (OCT & 2) ? ly : hy;
+      nz = (OCT & 4) ? hz : lz; fz = (OCT & 4) ? lz : hz;
+      tn = vmax3_sat(fmaf(nx, pk.mN.x, -pk.kN.x), fmaf(ny, pk.mN.y, -pk.kN.y), fmaf(nz, pk.mN.z, -pk.kN.z));
+    } else { // generic instance (packets with mixed direction signs): run-time plane choice, second entry terms
+      nx = msel(pk.neg[0], hx, lx); fx = msel(pk.neg[0], lx, hx);
+      ny = msel(pk.neg[1], hy, ly); fy = msel(pk.neg[1], ly, hy);
+      nz = msel(pk.neg[2], hz, lz); fz = msel(pk.neg[2], lz, hz);
+      const float t1 = fmaxf(fmaxf(fmaf(nx, pk.mN.x, -pk.kN.x), fmaf(ny, pk.mN.y, -pk.kN.y)), fmaf(nz, pk.mN.z, -pk.kN.z));
+      const float t2 = fmaxf(fmaxf(fmaf(fx, pk.mG.x, -pk.kG.x), fmaf(fy, pk.mG.y, -pk.kG.y)), fmaf(fz, pk.mG.z, -pk.kG.z));
+      tn = vmax3_sat(t1, t2, t2);
+    }
+    const float tf = vmin2(vmin3(fmaf(fx, pk.mF.x, -pk.kF.x), fmaf(fy, pk.mF.y, -pk.kF.y), fmaf(fz, pk.mF.z, -pk.kF.z)), __uint_as_float(hb));
+    wmask hit = m_le(tn, tf) & lanes;
+    int32_t next = 0;
+    bool have_next = false;
+    if (is_cluster) {
+      FFX_STAT(ANY ? 12 : 8);
+      while (hit != 0ull) {
+        const uint32_t j = (uint32_t)wff1(hit);
+        hit &= hit - 1ull;
+        FFX_STAT(ANY ? 6 : 2);
+        const uint32_t slot = base + j;
+        const uint32_t roff = slot * 48u;
+        const v8i r8 = *reinterpret_cast<const v8i *>(rbase + roff);
+        const v4i r4 = *reinterpret_cast<const v4i *>(rbase + roff + 32);
+        asm volatile("" ::"s"(r8), "s"(r4));
+        const int prim = r4.z;
+        const v3 A = V3(__int_as_float(r8.s0), __int_as_float(r8.s1), __int_as_float(r8.s2));
+        const v3 B = V3(__int_as_float(r8.s3), __int_as_float(r8.s4), __int_as_float(r8.s5));
+        const v3 C = V3(__int_as_float(r8.s6), __int_as_float(r8.s7), __int_as_float(r4.x));
+        const float T = __int_as_float(r4.y);
+        wmask improved = 0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          // apex test, staged with wave-uniform early-outs (identical arithmetic to traverse_packet_oct)
+          const float det = vdot(d[r], A);
+          const float U = vdot(d[r], B);
+          const wmask neg = m_lt(det, 0.f);
+          const float detA = fabsf(det);
+          const float Us = msel(neg, -U, U);
+          const wmask alive = ANY ? (active[r] & ~occluded[r]) : active[r];
+          const wmask p1 = alive & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
+          if (p1 == 0ull) continue;
+          FFX_STAT(ANY ? 7 : 3);
+          const float Vv = vdot(d[r], C);
+          const float Vs = msel(neg, -Vv, Vv);
+          const wmask p2 = p1 & m_ge(Vs, 0.f) & m_le(Us + Vs, detA);
+          if (p2 == 0ull) continue;
+          const float t = msel(neg, -T, T) / detA;
+          const wmask hitm = p2 & m_gt(t, tmin[r]);
+          if (ANY) {
+            const wmask occ = hitm & m_lt(t, tmax[r]);
+            occluded[r] |= occ;
+            msel_into(h[r].t, occ, -INFINITY);
+            improved |= occ;
+          } else {
+            const wmask better = hitm & (m_lt(t, h[r].t) | (m_eq(t, h[r].t) & m_ult((uint32_t)prim, (uint32_t)h[r].prim)));
+            msel_into(h[r].t, better, t);
+            msel_into(h[r].prim, better, prim);
+            msel_into(h[r].slot, better, (int)slot);
+            improved |= better;
+          }
+        }
+        if (improved != 0ull) {
+          if (ANY) {
+            wmask left = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) left |= active[r] & ~occluded[r];
+            if (left == 0ull) return; // every ray of the packet is decided
+          }
+          hb = packet_hts();
+          hit &= m_le(tn, __uint_as_float(hb)); // the remaining triangles of this cluster against the shorter rays
+        }
+      }
+    } else if (hit != 0ull) {
+      FFX_STAT(ANY ? 13 : 9);
+      // descend into the child entered first, push the others with their entry distances
+      const uint32_t tnb = __float_as_uint(tn);
+      int near_lane = wff1(hit);
+      if ((hit & (hit - 1ull)) != 0ull) {
+        const uint32_t mnb = wave_reduce_nn<false>(msel(hit, tnb, 0x40000000u));
+        near_lane = wff1(hit & __builtin_amdgcn_uicmp(tnb, mnb, 32));
+        const wmask others = hit & ~(1ull << near_lane);
+        if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(q.w, tnb);
+        sp += wpop(others);
+      }
+      next = __builtin_amdgcn_readlane((int)q.w, near_lane);
+      have_next = true;
+    }
+    if (!have_next) {
+      // pop: skip entries the rays can no longer reach
+      while (true) {
+        if (sp == 0) return;
+        FFX_STAT(ANY ? 14 : 10);
+        --sp;
+        const uint2 e = stack[sp];
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), etn = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        if (etn <= hb) { next = (int32_t)ref; break; }
+      }
+    }
+    cur = next;
+  }
+}
+
+// wide walk of R rays per lane that share their origin `o` (the apex the records `recs` were prepared for)
+template <bool ANY, int R>
+__device__ __forceinline__ void traverse_wide(const WideScene &ws, const TriApex *__restrict__ recs, v3 o, const v3 (&d)[R], const float (&tmin)[R],
+                                              const float (&tmax)[R], const bool (&act)[R], Hit (&h)[R], bool (&found)[R], uint2 *__restrict__ stack) {
+  wmask active[R], any_active = 0ull;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { active[r] = wballot(act[r]); any_active |= active[r]; }
+  if (any_active == 0ull) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { h[r].t = -INFINITY; h[r].prim = -1; h[r].shape = -1; h[r].slot = -1; found[r] = false; }
+    return;
+  }
+  v3 aid[R];
+  float sw[R];
+  uint32_t oct[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // unit of the box test: tmax maps to 0.999 (traverse_packet1)
+    const float scale = 0.999f * __builtin_amdgcn_rcpf(tmax[r]);
+    const v3 id = V3(safe_rcp_dir(d[r].x) * scale, safe_rcp_dir(d[r].y) * scale, safe_rcp_dir(d[r].z) * scale);
+    oct[r] = (__float_as_uint(id.x) >> 31) | ((__float_as_uint(id.y) >> 31) << 1) | ((__float_as_uint(id.z) >> 31) << 2);
+    aid[r] = V3(fabsf(id.x), fabsf(id.y), fabsf(id.z));
+    sw[r] = scale * 1.0000002f;
+  }
+  // the packet's octant: that of its first active ray; axes on which some active ray disagrees are dropped
+  uint32_t oct0 = 0;
+  {
+    bool got = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (!got && active[r] != 0ull) { oct0 = (uint32_t)__builtin_amdgcn_readlane((int)oct[r], wff1(active[r])); got = true; }
+  }
+  uint32_t mixed = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    wmask dis = 0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dis |= active[r] & __builtin_amdgcn_uicmp((oct[r] >> a) & 1u, (oct0 >> a) & 1u, 33);
+    if (dis != 0ull) mixed |= 1u << a;
+  }
+  const WidePk pk = make_widepk<R>(ws.hdr, o, aid, oct, active, oct0, mixed);
+  wmask occ[R];
+  if (mixed != 0u) traverse_wide_oct<ANY, 8, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack);
+  else switch (oct0) { // wave-uniform
+    case 0: traverse_wide_oct<ANY, 0, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 1: traverse_wide_oct<ANY, 1, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 2: traverse_wide_oct<ANY, 2, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 3: traverse_wide_oct<ANY, 3, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 4: traverse_wide_oct<ANY, 4, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 5: traverse_wide_oct<ANY, 5, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    case 6: traverse_wide_oct<ANY, 6, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+    default: traverse_wide_oct<ANY, 7, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) found[r] = __builtin_amdgcn_inverse_ballot_w64(occ[r]);
+}
+
 // one ray per lane: pick the octant loop if the packet's active rays agree on their direction signs
 template <bool ANY>
 __device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[1], const v3 (&d)[1],
@@ -929,12 +1240,15 @@ __device__ __forceinline__ void traverse_packet1(const BvhNode *__restrict__ nod
   }
 }
 
-// dispatch: the octant loops for one ray per lane, the generic loop otherwise.  All packet walks are
-// APEX walks (their rays share the origin o_apex whose records `arecs` were written by k_apex_records).
-template <bool ANY, int R>
-__device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ arecs, const v3 (&o)[R], const v3 (&d)[R],
-                                                    const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R], Hit (&h)[R], bool (&found)[R]) {
-  if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, arecs, o, d, tmin, tmax, active, h, found);
+// dispatch: WIDE — the 64-wide walk (default); otherwise the binary walks: octant loops for one ray per
+// lane, the generic loop for more.  All packet walks are APEX walks (their rays share the origin o[0] whose
+// records `arecs` were written by k_apex_records).
+template <bool ANY, int R, bool WIDE>
+__device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ arecs, const WideScene &ws, uint2 *__restrict__ stack,
+                                                    const v3 (&o)[R], const v3 (&d)[R], const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R],
+                                                    Hit (&h)[R], bool (&found)[R]) {
+  if constexpr (WIDE) traverse_wide<ANY, R>(ws, arecs, o[0], d, tmin, tmax, active, h, found, stack);
+  else if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, arecs, o, d, tmin, tmax, active, h, found);
   else traverse_packet<ANY, R>(nodes, arecs, o, d, tmin, tmax, active, h, found);
 }
 
@@ -979,13 +1293,13 @@ __device__ __forceinline__ const ShadeK &kernarg_shade() {
   return *(const ShadeK *)p;
 }
 
-template <int R>
+template <int R, bool WIDE>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
-                                                uint32_t astride, const bool (&active)[R], const v3 (&o)[R], const v3 (&d)[R], const float (&nt)[R],
-                                                const float (&ft)[R], SampleTerms (&st)[R]) {
+                                                uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
+                                                const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
   Hit h[R];
   bool fnd[R];
-  traverse_packet_any<false, R>(nodes, arecs, o, d, nt, ft, active, h, fnd); // apex 0: the camera
+  traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
   bool any_p = false, any_s = false;
@@ -1091,7 +1405,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = ppos; sdir[r] = vsub(pre[r].Po, ppos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_p; }
-    traverse_packet_any<true, R>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride), so, sdir, s0, s1, act, hs, occ_p);
+    traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride), ws, stack, so, sdir, s0, s1, act, hs, occ_p);
   }
   if (c.shadows && wballot(any_s) != 0ull) {
     const v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
@@ -1101,7 +1415,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = spos; sdir[r] = vsub(pre[r].Po, spos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_s; }
-    traverse_packet_any<true, R>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride), so, sdir, s0, s1, act, hs, occ_s);
+    traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride), ws, stack, so, sdir, s0, s1, act, hs, occ_s);
   }
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
 #pragma unroll
@@ -1136,7 +1450,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 // of a pixel and the tile is walked as four single pixels (R = 1; the template parameter remains from
 // a two-pixels-per-lane experiment).  All 64 rays of a packet are within a one-pixel frustum, so the
 // union of their paths is practically one ray's path.
-#define PK_BLOCK 256 // upper bound; the launch picks 64/128/256 threads = 1/2/4 independent waves per workgroup
+#define PK_BLOCK 64 // one independent wave per workgroup: the finest grain for the dispatcher (2 / 4 waves measured +1 % / +8 % time)
 
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -1147,10 +1461,12 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // K7 on the packet traversal.  A wavefront owns a compact block of bw x bh pixels with spp_w samples
 // each (bw * bh * spp_w = 64): 8x8 pixels at 1 spp ... one pixel at >= 64 spp (then it loops over the
 // pixel's samples 64 at a time).  Sample index and jitter are those of k_trace_primary.
+template <bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(FFX_PK1_WAVES, FFX_PK1_WAVES)))
-    k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, int spp, int jitter,
-                       uint32_t seed_key, int bw_log2,
+    k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, WideScene ws, int spp,
+                       int jitter, uint32_t seed_key, int bw_log2,
                        int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
+  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   const int blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (blk >= n_blocks) return; // whole wave
   const int lane = threadIdx.x & 63;
@@ -1174,7 +1490,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o[0], d[0], nt[0], ft[0]);
     Hit h[1];
     bool fnd[1];
-    traverse_packet_any<false, 1>(nodes, arecs, o, d, nt, ft, active, h, fnd);
+    traverse_packet_any<false, 1, WIDE>(nodes, arecs, ws, s_wstack, o, d, nt, ft, active, h, fnd);
     if (active[0]) {
       const bool hit = h[0].prim >= 0;
       t_out[idx] = hit ? (h[0].t - nt[0]) : 0.f;
@@ -1202,12 +1518,13 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x_tb, int sub,
   }
 }
 
-template <int R>
+template <int R, bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
-                    const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16,
-                    void *__restrict__ img, uint4 *__restrict__ cache, int ppw) {
+                    WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
+                    int fp16, void *__restrict__ img, uint4 *__restrict__ cache, int ppw) {
   constexpr int NSUB = 4 / R;
+  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
   // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
@@ -1249,7 +1566,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(nodes, recs, arecs, astride, active, o, d, nt, ft, st);
+      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
       if (cache) {
         // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
 #pragma unroll
@@ -1314,12 +1631,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   }
 }
 
-template <int R>
+template <int R, bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
-                    const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg,
-                    float *__restrict__ gtex) {
+                    WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
+                    const float *__restrict__ gimg, float *__restrict__ gtex) {
   constexpr int NSUB = 4 / R;
+  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy; see kernarg_shade)
@@ -1356,7 +1674,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R>(nodes, recs, arecs, astride, active, o, d, nt, ft, st);
+      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
@@ -1555,10 +1873,21 @@ static int use_packet() {
 // The waves of a workgroup never cooperate, so the smallest workgroup gives the dispatcher the finest
 // grain (measured 1 / 2 / 4 waves: 0.882 / 0.891 / 0.951 ms per step on the vocal fold, 16.2 / 16.5 /
 // 17.4 ms on the colon).
-static int packet_waves() {
-  const char *e = getenv("FFX_PACKET_WAVES");
-  int w = e ? atoi(e) : 1;
-  return (w == 1 || w == 2 || w == 4) ? w : 1;
+static int packet_waves() { return 1; }
+
+// FFX_WIDE=0 selects the binary packet walks (A/B baseline); default: the 64-wide walk
+static int use_wide(const ffx_bvh_info *info) {
+  const char *e = getenv("FFX_WIDE");
+  return (e && strcmp(e, "0") == 0) || info->off_tq == 0 ? 0 : 1;
+}
+static WideScene wide_scene(const void *bvh, const ffx_bvh_info *info) {
+  WideScene ws;
+  const char *base = (const char *)bvh;
+  ws.wn = (const WideChild *)(base + info->off_wnodes);
+  ws.tq = (const WideChild *)(base + info->off_tq);
+  ws.hdr = (const WideHdr *)(base + info->off_whdr);
+  ws.root = info->wide_root;
+  return ws;
 }
 
 // log2 of the side (in 2x2-pixel tiles) of the square blocks in which tiles are enumerated: FFX_TILE_BLOCK,
@@ -1667,8 +1996,13 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
     const TriApex *arecs;
     uint32_t astride;
     if (!launch_apex(bvh, info, cam->to_world, nullptr, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
-    hipLaunchKernelGGL(k_trace_primary_pk, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, spp, jitter,
-                       seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+    const WideScene ws = wide_scene(bvh, info);
+    if (use_wide(info))
+      hipLaunchKernelGGL(k_trace_primary_pk<true>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jitter,
+                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+    else
+      hipLaunchKernelGGL(k_trace_primary_pk<false>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jitter,
+                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
     FFX_CHECK_LAUNCH("trace_primary");
     return FFX_OK;
   }
@@ -1715,8 +2049,13 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const TriApex *arecs;
     uint32_t astride;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
-    hipLaunchKernelGGL(k_render_fwd_pk<1>, dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, shape_albedo, tex, spp,
-                       seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
+    const WideScene ws = wide_scene(bvh, info);
+    if (use_wide(info))
+      hipLaunchKernelGGL((k_render_fwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
+    else
+      hipLaunchKernelGGL((k_render_fwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -1778,8 +2117,13 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     const TriApex *arecs;
     uint32_t astride;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
-    hipLaunchKernelGGL(k_render_bwd_pk<1>, dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, shape_albedo, spp, seed_key_of(seed), ptx,
-                       pn, xcd_mode(), gimg, gtex);
+    const WideScene ws = wide_scene(bvh, info);
+    if (use_wide(info))
+      hipLaunchKernelGGL((k_render_bwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, spp,
+                         seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex);
+    else
+      hipLaunchKernelGGL((k_render_bwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, spp,
+                         seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex);
     FFX_CHECK_LAUNCH("render_bwd");
     return FFX_OK;
   }

@@ -98,20 +98,34 @@ def gaussian_blur(img, ksize=5, sigma=3.0):
 CACHE_LIMIT_BYTES = int(float(os.environ.get("FFX_CACHE_LIMIT_GB", "32")) * (1 << 30))
 
 
+def cache_supported(sd, spp):
+    """whether ffx_render_fwd_cache accepts this render (its records pack the texel in 12+12 bits and
+    the shape id in 8) and the cache fits the FFX_CACHE_LIMIT_GB budget"""
+    if not sd.proj.enabled:
+        return False
+    if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255:
+        return False
+    return ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp) <= CACHE_LIMIT_BYTES
+
+
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tex, geom, sd, albedo, spp, seed, fp16):
-        ctx.geom, ctx.sd, ctx.albedo, ctx.spp, ctx.seed = geom, sd, albedo, spp, seed
+        ctx.geom, ctx.sd, ctx.spp, ctx.seed = geom, sd, spp, seed
         ctx.tex_shape = tex.shape
         t = _c(tex)
         if t.dim() == 2:
             t = t.unsqueeze(-1)
         ctx.cache = None
+        ctx.albedo = albedo
         if tex.requires_grad and sd.proj.enabled:
-            nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp)
-            if nbytes <= CACHE_LIMIT_BYTES:
+            # the adjoint needs the albedo as it was at the forward pass (Scene._apply overwrites the
+            # tensor in place on the next randomisation): keep a private copy (3 floats per shape)
+            ctx.albedo = albedo.clone()
+            if cache_supported(sd, spp):
                 # store 16 B per sample now instead of re-tracing the scene in backward
-                ctx.cache = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+                ctx.cache = torch.empty(ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp), dtype=torch.uint8, device=t.device)
+        ctx.pose_version = geom.version
         return geom.render_fwd(sd, albedo, t, spp, seed, fp16, cache=ctx.cache)
 
     @staticmethod
@@ -120,7 +134,13 @@ class _Render(torch.autograd.Function):
         if ctx.cache is not None:
             gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g)
             ctx.cache = None
-        else:  # replays the geometry: it must not have been re-fitted since the forward pass
+        else:  # replays the geometry: it must still be in the pose of the forward pass
+            if ctx.geom.version != ctx.pose_version:
+                raise RuntimeError(
+                    "render backward: the scene was re-fitted (randomize()/update()) between forward and backward and this render "
+                    "uses the re-tracing adjoint (cache over FFX_CACHE_LIMIT_GB, texture > 4094^2 or > 255 shapes): call backward "
+                    "before the next randomisation"
+                )
             gtex = ctx.geom.render_bwd(ctx.sd, ctx.albedo, ctx.spp, ctx.seed, g)
         return gtex.reshape(ctx.tex_shape), None, None, None, None, None, None
 

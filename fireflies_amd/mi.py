@@ -372,7 +372,7 @@ class Scene:
             if v.shape[0] != V:
                 raise ValueError(f"{name}: expected {V} vertices, got {v.shape[0]}")
             o = self._scratch_off[i]
-            self.geom.src_verts[o : o + V].copy_(v)
+            self.geom.write_verts(o, v)  # ordered against the refits on the side stream
             self._offs[i] = o
         elif frame is not None:
             f = int(frame)

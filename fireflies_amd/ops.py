@@ -15,8 +15,9 @@ from ._lib import api
 REDUCE = {"sum": _abi.REDUCE_SUM, "softor": _abi.REDUCE_SOFTOR}
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """the caller's current HIP stream on `device` (default: the current device)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _dev(t, dtype=torch.float32, name="tensor"):
@@ -251,6 +252,10 @@ class DeviceGeometry:
         self.vert_off = torch.from_numpy(vo).to(self.device)
         self._vert_off_host = vo.copy()
         self._vert_off_dev_stale = False
+        self._pool_written = None  # event: the last write_verts() into the vertex pool (caller's stream)
+        self.version = 0           # bumped by every update(): functional._Render pins the pose it traced
+        if self._async:  # blob copies / uploads above were enqueued on the caller's stream
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
 
     @property
@@ -271,6 +276,29 @@ class DeviceGeometry:
                 ev = self._last_use[self._cur] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
 
+    def write_verts(self, offset, verts):
+        """copy caller-supplied vertices [V,3] into the pool at `offset` (animation functions, direct
+        `vertex_positions` assignment).  Ordered against the refits on the side stream in both
+        directions: the copy waits for every enqueued refit (one may still be reading this slot), and
+        the next update() waits for the copy."""
+        main = torch.cuda.current_stream(self.device)
+        if self._async:
+            for ev in self._upd_done:
+                if ev is not None:
+                    main.wait_event(ev)
+        self.src_verts[offset : offset + verts.shape[0]].copy_(verts)
+        if self._async:
+            if self._pool_written is None:
+                self._pool_written = torch.cuda.Event()
+            self._pool_written.record(main)
+
+    def _call(self, name, *args):
+        """a launch on this geometry's device (which need not be the current one)"""
+        if self.device.index is None or torch.cuda.current_device() == self.device.index:
+            return api().call(name, *args)
+        with torch.cuda.device(self.device):
+            return api().call(name, *args)
+
     def _check_offsets(self, vo):
         if (vo < 0).any() or ((vo.astype(np.int64) + self._max_local) >= self._pool_size).any():
             raise ValueError("vert_off + triangle index exceeds the vertex pool")
@@ -288,6 +316,7 @@ class DeviceGeometry:
             self._vert_off_host = vo.copy()
             self._vert_off_dev_stale = True
         on_device = isinstance(xforms, torch.Tensor) and xforms.is_cuda
+        self.version += 1
         if not self._async:
             self._update_into(self._blobs[0], xforms, on_device)
             return
@@ -295,6 +324,8 @@ class DeviceGeometry:
         main = torch.cuda.current_stream(self.device)
         if self._last_use[nxt] is not None:
             self._side.wait_event(self._last_use[nxt])  # its last reader must be done before it is overwritten
+        if self._pool_written is not None:
+            self._side.wait_event(self._pool_written)  # caller-supplied vertices must have landed in the pool
         if on_device:
             self._side.wait_stream(main)  # the tables were produced on the caller's stream
             xforms.record_stream(self._side)
@@ -311,10 +342,10 @@ class DeviceGeometry:
             if not on_device and self.n_shapes <= 32:
                 xf = xforms.detach().numpy() if isinstance(xforms, torch.Tensor) else np.asarray(xforms)
                 xf = np.ascontiguousarray(xf, dtype=np.float32).reshape(self.n_shapes, 16)
-                api().call(
+                self._call(
                     "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                     _dev(self.tri_shape, torch.int32), self._vert_off_host.ctypes.data_as(C.POINTER(C.c_int32)),
-                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(),
+                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(self.device),
                 )
                 return
             if self._vert_off_dev_stale:
@@ -323,9 +354,9 @@ class DeviceGeometry:
             xf = xforms if isinstance(xforms, torch.Tensor) else torch.as_tensor(np.asarray(xforms, np.float32))
             xf = xf.to(device=self.device, dtype=torch.float32).reshape(self.n_shapes, 16).contiguous()
             self._xf = xf  # keep alive until the stream has consumed it
-            api().call(
+            self._call(
                 "ffx_scene_update", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(),
+                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(self.device),
             )
 
     def trace_primary(self, cam, spp=1, jitter=0, seed=0, want_ids=True):
@@ -333,9 +364,9 @@ class DeviceGeometry:
         t = torch.empty(n, dtype=torch.float32, device=self.device)
         shape = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
-        api().call(
+        self._call(
             "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
-            _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(),
+            _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self.device),
         )
         self._release()
         return t, shape, prim
@@ -345,9 +376,9 @@ class DeviceGeometry:
         t = torch.empty(n, dtype=torch.float32, device=self.device)
         shape = torch.empty(n, dtype=torch.int32, device=self.device)
         prim = torch.empty(n, dtype=torch.int32, device=self.device)
-        api().call(
+        self._call(
             "ffx_trace_rays", _dev(self.blob, torch.uint8), C.byref(self.info), _dev(origins, name="origins"), _dev(dirs, name="dirs"), n, float(tmax),
-            _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(),
+            _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(self.device),
         )
         self._release()
         return t, shape, prim
@@ -364,17 +395,17 @@ class DeviceGeometry:
             if cache.numel() < W * H * int(spp) * 16:
                 raise ValueError("cache tensor too small")
             with self._timed("render_fwd"):
-                api().call(
+                self._call(
                     "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
                     _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype),
-                    _dev(cache, torch.uint8, "cache"), _stream(),
+                    _dev(cache, torch.uint8, "cache"), _stream(self.device),
                 )
             self._release()
             return img
         with self._timed("render_fwd"):
-          api().call(
+          self._call(
             "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
-            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(),
+            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(self.device),
           )
         self._release()
         return img
@@ -383,16 +414,16 @@ class DeviceGeometry:
         """K9 from the per-sample cache written by render_fwd(..., cache=...): a streaming kernel, no BVH."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         with self._timed("render_bwd_cached"):
-            api().call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
-                       _dev(gimg, name="gimg"), _dev(gtex), _stream())
+            self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
+                       _dev(gimg, name="gimg"), _dev(gtex), _stream(self.device))
         return gtex
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         with self._timed("render_bwd"):
-            api().call(
+            self._call(
                 "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
-                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(),
+                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self.device),
             )
         self._release()
         return gtex

@@ -122,8 +122,8 @@ class PatternOptimizer:
             random.seed(seed)
             self.ff_scene.randomize()
             sd = ms.scene_desc(tex_channels=1)
-            nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, self.spp) if sd.proj.enabled else 0
-            use_cache = 0 < nbytes <= Fn.CACHE_LIMIT_BYTES
+            use_cache = Fn.cache_supported(sd, self.spp)
+            nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, self.spp) if use_cache else 0
             if use_cache and (self._cache is None or self._cache.numel() != nbytes):
                 self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
             img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None)

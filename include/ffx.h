@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 1
+#define FFX_ABI_VERSION 2
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -165,6 +165,17 @@ typedef struct ffx_bvh_info {
   uint64_t off_recs;
   uint64_t total_bytes;
   int32_t level_start[FFX_MAX_LEVELS + 1]; /* ranges into the refit list, leaves-first */
+  /* 64-wide overlay of the same tree for the wave-packet kernels: inner nodes of up to
+   * 64 children with 16-bit quantised boxes, triangles grouped in clusters of up to 64 consecutive leaf
+   * slots.  All zero in a blob written by the oracle (which walks its own binary tree). */
+  int32_t n_wide;     /* wide inner nodes (0: the whole scene is one cluster) */
+  int32_t wide_depth; /* wide inner levels above the clusters */
+  int32_t wide_root;  /* reference of the root: >= 0 wide node, < 0 cluster code */
+  int32_t wide_pad;
+  uint64_t off_wnodes; /* n_wide x 64 x 16 B child records */
+  uint64_t off_wsrc;   /* n_wide x 64 x int32: where each child's box lives in the binary tree */
+  uint64_t off_tq;     /* n_tris x 16 B quantised triangle boxes, leaf-slot order */
+  uint64_t off_whdr;   /* 64 B: quantisation grid of the current pose */
 } ffx_bvh_info;
 
 /* upper bound of the blob size for n_tris triangles.  The blob ends with scratch areas ("apex records",

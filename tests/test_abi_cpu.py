@@ -42,7 +42,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.Projector) == 4 * (16 + 16 + 1 + 3 + 4)
     assert C.sizeof(_abi.Spot) == 4 * (16 + 3 + 2 + 1)
     assert C.sizeof(_abi.SceneDesc) == C.sizeof(_abi.Camera) + C.sizeof(_abi.Projector) + C.sizeof(_abi.Spot) + 8
-    assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 4  # + tail padding to 8
+    # 4 ints, 5 offsets, level_start, 4 ints of the wide overlay (+ 4 bytes of padding to 8), 4 offsets
+    assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 16 + 4 + 4 * 8
 
 
 def test_no_cpu_fallback():
@@ -126,3 +127,38 @@ def test_host_bvh_structure(case):
                 assert level_of[c] < level_of[k]  # children are refitted before parents
     assert (covered == 1).all()
     assert refs[0] == 0 and (refs[1:] == 1).all()
+    # ---- the 64-wide overlay: clusters reachable from wide_root tile the leaf slots exactly once, every
+    # wide node is referenced once, every child knows the binary node whose box it mirrors
+    nw = info.n_wide
+    wn = blob[info.off_wnodes : info.off_wnodes + 1024 * nw].view(np.int32).reshape(nw, 64, 4)
+    wsrc = blob[info.off_wsrc : info.off_wsrc + 256 * nw].view(np.int32).reshape(nw, 64)
+    wcov = np.zeros(F, np.int32)
+    wrefs = np.zeros(max(nw, 1), np.int32)
+    depth_seen = 0
+
+    def visit(ref, depth):
+        nonlocal depth_seen
+        if ref < 0:
+            code = (~ref) & 0xFFFFFFFF
+            first, cnt = code >> 6, (code & 63) + 1
+            assert first + cnt <= F
+            wcov[first : first + cnt] += 1
+            return
+        idx, cnt = ref >> 6, (ref & 63) + 1
+        assert 0 <= idx < nw and 2 <= cnt <= 64
+        wrefs[idx] += 1
+        depth_seen = max(depth_seen, depth + 1)
+        for j in range(64):
+            if j < cnt:
+                src = int(wsrc[idx, j])
+                assert 0 <= src < 2 * info.n_nodes
+                visit(int(wn[idx, j, 3]), depth + 1)
+            else:
+                assert int(wsrc[idx, j]) == -1
+
+    visit(int(info.wide_root), 0)
+    assert (wcov == 1).all()
+    assert nw == 0 or (wrefs == 1).all()
+    assert depth_seen == info.wide_depth <= 6
+    assert (info.n_wide == 0) == (F <= 64)
+    assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + 16 * F <= info.off_whdr
