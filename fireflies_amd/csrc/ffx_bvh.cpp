@@ -189,8 +189,10 @@ inline int32_t leaf_code(int first, int count) { return ~(int32_t)(((uint32_t)fi
 // binary tree.  Typical fill: ~45 of 64 (53 k triangles: 1 198 clusters, 27 + 1 wide nodes).
 struct WideNode { std::vector<int> kids; int bnode = -1; };
 
-inline int32_t cluster_code(int first, int count) { return ~(int32_t)(((uint32_t)first << 6) | (uint32_t)(count - 1)); }
-inline int32_t wide_ref(int index, int count) { return (int32_t)(((uint32_t)index << 6) | (uint32_t)(count - 1)); }
+// reference = cluster << 31 | element << 6 | (count - 1): `element` indexes the array of 16-byte WideChild
+// elements that starts at off_wnodes — wide node w is elements [64 w, 64 w + count), the cluster of leaf slots
+// [first, first + count) is elements [tq0 + first, ...) with tq0 = 64 * n_wide
+inline int32_t wide_elem_ref(bool cluster, uint32_t element, int count) { return (int32_t)((cluster ? 0x80000000u : 0u) | (element << 6) | (uint32_t)(count - 1)); }
 
 // returns the wide nodes (children = build-node ids of their items), `wide_of[b]` = wide node rooted at
 // build node b (-1: b is a cluster root or not an item) and the number of layers
@@ -320,13 +322,13 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   if (wide_depth > FFX_WIDE_MAX_DEPTH) FFX_FAIL(FFX_ERR_UNSUPPORTED, "bvh_build_host: wide tree depth %d exceeds %d", wide_depth, FFX_WIDE_MAX_DEPTH);
   info->n_wide = (int32_t)wide.size();
   info->wide_depth = wide_depth;
-  info->off_wnodes = off;
+  info->off_wnodes = off; // wide nodes and triangle boxes form ONE array of 16-byte elements (see wide_elem_ref)
   off += (uint64_t)wide.size() * FFX_WIDE * sizeof(WideChild);
-  info->off_wsrc = off;
-  off += (uint64_t)wide.size() * FFX_WIDE * 4;
-  off = (off + 63) & ~(uint64_t)63;
   info->off_tq = off;
   off += (uint64_t)n_tris * sizeof(WideChild);
+  off = (off + 63) & ~(uint64_t)63;
+  info->off_wsrc = off;
+  off += (uint64_t)wide.size() * FFX_WIDE * 4;
   off = (off + 63) & ~(uint64_t)63;
   info->off_whdr = off;
   off += 64;
@@ -380,11 +382,13 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   // (binary node index * 2 + side of the child's parent; -1 for unused lanes)
   WideChild *wn = (WideChild *)((char *)blob + info->off_wnodes);
   int32_t *wsrc = (int32_t *)((char *)blob + info->off_wsrc);
+  const uint32_t tq0 = (uint32_t)wide.size() * FFX_WIDE;
+  if ((uint64_t)tq0 + (uint64_t)n_tris >= (1u << 25)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "bvh_build_host: more than 2^25 wide elements");
   if (wide.empty()) {
-    info->wide_root = cluster_code(0, n_tris);
+    info->wide_root = wide_elem_ref(true, tq0, n_tris);
   } else {
     const int wroot = wide_of[root];
-    info->wide_root = wide_ref(wroot, (int)wide[wroot].kids.size());
+    info->wide_root = wide_elem_ref(false, (uint32_t)wroot * FFX_WIDE, (int)wide[wroot].kids.size());
     for (size_t w = 0; w < wide.size(); ++w) {
       const std::vector<int> &kids = wide[w].kids;
       for (int j = 0; j < FFX_WIDE; ++j) {
@@ -396,7 +400,7 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
         if (j >= (int)kids.size()) continue;
         const BuildNode &k = b.nodes[kids[j]];
         const int kw = wide_of[kids[j]];
-        c.ref = kw >= 0 ? wide_ref(kw, (int)wide[kw].kids.size()) : cluster_code(k.sfirst, k.scount);
+        c.ref = kw >= 0 ? wide_elem_ref(false, (uint32_t)kw * FFX_WIDE, (int)wide[kw].kids.size()) : wide_elem_ref(true, tq0 + (uint32_t)k.sfirst, k.scount);
         wsrc[w * FFX_WIDE + j] = b.nodes[k.parent].out_index * 2 + k.side;
       }
     }

@@ -99,8 +99,9 @@ static inline uint64_t ffx_apex_offset(const ffx_bvh_info *info, int k) { return
 // ------------------------------------------------------------------ 64-wide overlay
 // One child of a wide node, or one triangle of a cluster: a box on the 16-bit grid of the current pose
 // (x = org + q * step per axis; q[0..2] round down, q[3..5] round up, one extra cell of slack each) and
-// a reference.  ref >= 0: wide inner node, (index << 6) | (children - 1).  ref < 0: cluster,
-// ~ref = (first_slot << 6) | (triangles - 1).  In the triangle array `ref` is unused.
+// a reference: cluster << 31 | element << 6 | (count - 1), where `element` indexes the ONE array of 16-byte
+// elements formed by the wide nodes (64 each) followed by the triangle boxes in leaf-slot order.  In the
+// triangle part `ref` is unused.
 struct __attribute__((aligned(16))) WideChild {
   uint16_t q[6];
   int32_t ref;

@@ -773,10 +773,28 @@ __device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], 
 // nested uniform branches instead of combined predicates.
 #ifdef FFX_STATS
 // debug build only (-DFFX_STATS): per-launch totals of packet walks / node steps / triangle tests
-__device__ unsigned long long g_ffx_stats[16];
+__device__ unsigned long long g_ffx_stats[32];
 #define FFX_STAT(i) do { if (threadIdx.x % 64 == 0) atomicAdd(&g_ffx_stats[i], 1ull); } while (0)
+#define FFX_STAT_MAX(i, v) do { if (threadIdx.x % 64 == 0) atomicMax(&g_ffx_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define FFX_STAT(i) do { } while (0)
+#define FFX_STAT_MAX(i, v) do { } while (0)
+#endif
+#ifdef FFX_TIMERS // separate debug build (-DFFX_TIMERS): the counters above perturb the timing by two orders of magnitude
+// phase timers (shader clock, s_memtime): FFX_TSTART(t); ... FFX_TSTOP(t, slot) adds the elapsed cycles of this wave to slot
+// (accumulated per workgroup in LDS and flushed once at the end of the kernel: a global atomic per stamp
+// would sit in front of every s_waitcnt vmcnt(0) of the walk and measure itself)
+__device__ unsigned long long g_ffx_tim[32];
+static __shared__ unsigned long long s_ffx_tim[32];
+#define FFX_TSTART(t) unsigned long long t = __builtin_amdgcn_s_memtime()
+#define FFX_TSTOP(t, i) do { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x % 64 == 0) s_ffx_tim[i] += t_now_ - t; t = t_now_; } while (0)
+#define FFX_TINIT() do { if (threadIdx.x < 32) s_ffx_tim[threadIdx.x] = 0ull; __builtin_amdgcn_wave_barrier(); } while (0)
+#define FFX_TFLUSH() do { __builtin_amdgcn_wave_barrier(); if (threadIdx.x < 32 && s_ffx_tim[threadIdx.x] != 0ull) atomicAdd(&g_ffx_tim[threadIdx.x], s_ffx_tim[threadIdx.x]); } while (0)
+#else
+#define FFX_TSTART(t) do { } while (0)
+#define FFX_TSTOP(t, i) do { } while (0)
+#define FFX_TINIT() do { } while (0)
+#define FFX_TFLUSH() do { } while (0)
 #endif
 template <bool ANY, int OCT>
 __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const RayOct &rb, float scale, v3 d,
@@ -912,30 +930,39 @@ __device__ __forceinline__ void traverse_packet_oct(const BvhNode *__restrict__ 
 // is order independent).  Boxes live on a 16-bit grid (ffx_common.h: WideChild, 16 B per child: a node is one
 // coalesced 1 KB load); the grid is folded into the packet constants once per walk, so de-quantisation is
 // six integer-to-float conversions per step.  The traversal stack (reference, entry distance) is in LDS.
-struct WideScene { const WideChild *wn; const WideChild *tq; const WideHdr *hdr; int32_t root; };
+// `elems`: the wide nodes (64 children each) followed by the triangle boxes in leaf-slot order — ONE array of
+// 16-byte elements, so that a reference (cluster << 31 | element << 6 | count - 1) addresses both kinds alike;
+// `tq0` = element index of leaf slot 0.
+struct WideScene { const WideChild *elems; const WideHdr *hdr; int32_t root; uint32_t tq0; };
 #define FFX_WSTACK (63 * FFX_WIDE_MAX_DEPTH + 6)
 // per-walk constants, uniform across the wave: tn_a = fma(q_near_a, mN_a, -kN_a), tf_a = fma(q_far_a, mF_a, -kF_a)
 // (GEN walks only) a second entry term per axis from the FAR plane, tg_a = fma(q_far_a, mG_a, -kG_a): an axis on
 // which the packet's rays disagree in sign has two entry bounds and no exit bound (see make_widepk).
 struct WidePk { v3 mN, kN, mF, kF, mG, kG; wmask neg[3]; };
 
-#define FFX_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), 0xf, 0xf, false))
 // wave-wide min / max of the bit patterns of NON-NEGATIVE floats (they order like unsigned integers): four
-// DPP steps inside each row of 16 lanes (quad swap, quad-pair swap, half-row mirror, row mirror), then the
-// four row results are combined on the scalar ALU.  The result is wave-uniform (SGPR).
+// fused DPP steps inside each row of 16 lanes (quad swap, quad-pair swap, half-row mirror, row mirror: one
+// VALU instruction each; the s_nop covers the "VALU wrote the VGPR a DPP op reads" hazard the compiler
+// cannot see inside an asm statement), then the four row results are combined on the scalar ALU.
+#define FFX_DPP_STEP(OP, CTRL) asm("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ uint32_t smin_u32(uint32_t a, uint32_t b) { uint32_t r; asm("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ uint32_t smax_u32(uint32_t a, uint32_t b) { uint32_t r; asm("s_max_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
 template <bool MAX>
 __device__ __forceinline__ uint32_t wave_reduce_nn(uint32_t v) {
-#define FFX_RSTEP(ctrl) { const uint32_t o_ = FFX_DPP(v, ctrl); v = MAX ? (v > o_ ? v : o_) : (v < o_ ? v : o_); }
-  FFX_RSTEP(0xB1)  // quad_perm [1,0,3,2]
-  FFX_RSTEP(0x4E)  // quad_perm [2,3,0,1]
-  FFX_RSTEP(0x141) // row_half_mirror
-  FFX_RSTEP(0x140) // row_mirror
-#undef FFX_RSTEP
+  if (MAX) {
+    FFX_DPP_STEP("v_max_u32_dpp", "quad_perm:[1,0,3,2]");
+    FFX_DPP_STEP("v_max_u32_dpp", "quad_perm:[2,3,0,1]");
+    FFX_DPP_STEP("v_max_u32_dpp", "row_half_mirror");
+    FFX_DPP_STEP("v_max_u32_dpp", "row_mirror");
+  } else {
+    FFX_DPP_STEP("v_min_u32_dpp", "quad_perm:[1,0,3,2]");
+    FFX_DPP_STEP("v_min_u32_dpp", "quad_perm:[2,3,0,1]");
+    FFX_DPP_STEP("v_min_u32_dpp", "row_half_mirror");
+    FFX_DPP_STEP("v_min_u32_dpp", "row_mirror");
+  }
   const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
   const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-  if (MAX) { const uint32_t x = a > b ? a : b, y = c > e ? c : e; return x > y ? x : y; }
-  const uint32_t x = a < b ? a : b, y = c < e ? c : e;
-  return x < y ? x : y;
+  return MAX ? smax_u32(smax_u32(a, b), smax_u32(c, e)) : smin_u32(smin_u32(a, b), smin_u32(c, e));
 }
 __device__ __forceinline__ uint32_t mbcnt64(wmask m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ int wff1(wmask m) { return __builtin_ctzll(m); }
@@ -949,7 +976,8 @@ __device__ __forceinline__ int wff1(wmask m) { return __builtin_ctzll(m); }
 // box in its depth range: one such wave took 7 ms.)
 template <int R>
 __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v3 o, const v3 (&aid)[R], const uint32_t (&oct)[R], const wmask (&active)[R],
-                                              uint32_t oct0, uint32_t mixed) {
+                                              uint32_t oct0, uint32_t mixed, float &spread) {
+  float dmax_all = 0.f, dspread = 0.f; // largest |d_a| and largest (max |d_a| - min |d_a|) over the axes, in units of 1/scale
   const float org[3] = {hdr->org[0], hdr->org[1], hdr->org[2]}, step[3] = {hdr->step[0], hdr->step[1], hdr->step[2]};
   const float oo[3] = {o.x, o.y, o.z};
   float mN[3], kN[3], mF[3], kF[3], mG[3], kG[3];
@@ -982,6 +1010,9 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
     if (!is_mixed) {
       // far side, widened (make_rayslab)
       const float mx = __uint_as_float(wave_reduce_nn<true>(hi));
+      const float dhi = __builtin_amdgcn_rcpf(mn), dlo = __builtin_amdgcn_rcpf(mx); // |d_a| range of the packet
+      dmax_all = fmaxf(dmax_all, dhi);
+      dspread = fmaxf(dspread, dhi - dlo);
       const float sF = negd ? -mx : mx;
       const float oidf = oo[a] * sF, cF = (oidf - fabsf(oidf) * k22) * kw;
       const float sFk = sF * kw, gf = org[a] * sFk;
@@ -1002,14 +1033,21 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
   pk.mN = V3(mN[0], mN[1], mN[2]); pk.kN = V3(kN[0], kN[1], kN[2]);
   pk.mF = V3(mF[0], mF[1], mF[2]); pk.kF = V3(kF[0], kF[1], kF[2]);
   pk.mG = V3(mG[0], mG[1], mG[2]); pk.kG = V3(kG[0], kG[1], kG[2]);
+  spread = dspread * __builtin_amdgcn_rcpf(dmax_all);
   return pk;
 }
 
+// returns false if the walk was abandoned because it exceeded its budget of steps / exact tests (the caller
+// then repeats it on the binary walk, whose per-ray box tests cope with incoherent packets)
+#ifndef FFX_WIDE_MAX_WORK
+#define FFX_WIDE_MAX_WORK 96 // steps + exact triangle tests of one walk (typical: 7 + 7; measured 24 / 48 / 64 / 96 / 192: 0.77 / 0.70 / 0.65 / 0.65 / 0.65 ms vocal fold, 4.2 / 3.5 / 3.4 / 3.3 / 3.3 ms colon)
+#endif
 template <bool ANY, int OCT, int R>
-__device__ __forceinline__ void traverse_wide_oct(const WideScene &ws, const TriApex *__restrict__ recs, const WidePk &pk, const v3 (&d)[R], const float (&tmin)[R],
+__device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const TriApex *__restrict__ recs, const WidePk &pk, const v3 (&d)[R], const float (&tmin)[R],
                                                   const float (&tmax)[R], const float (&sw)[R], const wmask (&active)[R], Hit (&h)[R], wmask (&occluded)[R],
                                                   uint2 *__restrict__ stack) {
-  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t lane16 = (threadIdx.x & 63u) << 4;
+  int budget = FFX_WIDE_MAX_WORK;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     h[r].t = msel(active[r], tmax[r], -INFINITY);
@@ -1029,18 +1067,29 @@ __device__ __forceinline__ void traverse_wide_oct(const WideScene &ws, const Tri
   uint32_t hb = packet_hts();
   int sp = 0;
   int32_t cur = ws.root;
+  const char *ebase = reinterpret_cast<const char *>(ws.elems);
   const char *rbase = reinterpret_cast<const char *>(recs);
   FFX_STAT(ANY ? 4 : 0);
-  while (true) {
+#ifdef FFX_STATS
+  unsigned n_steps = 0, n_tris = 0;
+#endif
+  FFX_TSTART(tw);
+  for (;;) {
+    if (--budget < 0) return false;
     FFX_STAT(ANY ? 5 : 1);
-    // ---- fetch: lane j reads child j (inner node) or triangle box first + j (cluster): one 16-byte load per lane
-    const bool is_cluster = cur < 0;
-    const uint32_t code = is_cluster ? (uint32_t)~cur : (uint32_t)cur;
-    const uint32_t base = code >> 6, cnt = (code & 63u) + 1u;
-    const WideChild *src = is_cluster ? ws.tq + base : ws.wn + (size_t)base * FFX_WIDE;
-    const wmask lanes = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
-    uint4 q = make_uint4(0xffffffffu, 0x0000ffffu, 0u, 0u);
-    if ((uint32_t)lane < cnt) q = *reinterpret_cast<const uint4 *>(src + lane);
+#ifdef FFX_STATS
+    ++n_steps;
+    FFX_STAT_MAX(ANY ? 15 : 11, ((unsigned long long)n_steps << 32) | n_tris);
+    if (n_steps == 13) FFX_STAT(ANY ? 28 : 24); // walks with more than 12 steps, and the steps beyond
+    if (n_steps > 12) FFX_STAT(ANY ? 29 : 25);
+#endif
+    // ---- fetch: lane j reads child j of an inner node or box j of a cluster: one 16-byte load per lane, no
+    // divergence (lanes beyond the count re-read the last element and are masked out of the result)
+    const uint32_t cnt1 = (uint32_t)cur & 63u;
+    const uint32_t eoff = ((uint32_t)cur & 0x7fffffc0u) >> 2; // element index * 16
+    const uint32_t lo16 = lane16 < (cnt1 << 4) ? lane16 : (cnt1 << 4);
+    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16);
+    const wmask lanes = ~0ull >> (63u - cnt1);
     const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
     const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
     float nx, ny, nz, fx, fy, fz, tn;
@@ -1059,15 +1108,27 @@ __device__ __forceinline__ void traverse_wide_oct(const WideScene &ws, const Tri
     }
     const float tf = vmin2(vmin3(fmaf(fx, pk.mF.x, -pk.kF.x), fmaf(fy, pk.mF.y, -pk.kF.y), fmaf(fz, pk.mF.z, -pk.kF.z)), __uint_as_float(hb));
     wmask hit = m_le(tn, tf) & lanes;
-    int32_t next = 0;
-    bool have_next = false;
-    if (is_cluster) {
+    FFX_TSTOP(tw, ANY ? 8 : 0);
+    if (cur < 0) {
+      // ---- cluster: the surviving triangles are tested exactly, lanes back on the rays
       FFX_STAT(ANY ? 12 : 8);
+      const uint32_t slot0 = (eoff >> 4) - ws.tq0;
+#ifdef FFX_EXP_ANY_NOTRIS // timing experiment: any-hit walks without the exact triangle tests
+      if (ANY) hit = 0ull;
+#endif
       while (hit != 0ull) {
         const uint32_t j = (uint32_t)wff1(hit);
         hit &= hit - 1ull;
+        --budget;
         FFX_STAT(ANY ? 6 : 2);
-        const uint32_t slot = base + j;
+#ifdef FFX_STATS
+        ++n_tris;
+        if (n_tris == 17) FFX_STAT(ANY ? 20 : 16);  // walks with more than 16 exact tests ...
+        if (n_tris > 16) FFX_STAT(ANY ? 21 : 17);   // ... and the tests beyond the 16th
+        if (n_tris == 65) FFX_STAT(ANY ? 22 : 18);
+        if (n_tris > 64) FFX_STAT(ANY ? 23 : 19);
+#endif
+        const uint32_t slot = slot0 + j;
         const uint32_t roff = slot * 48u;
         const v8i r8 = *reinterpret_cast<const v8i *>(rbase + roff);
         const v4i r4 = *reinterpret_cast<const v4i *>(rbase + roff + 32);
@@ -1114,46 +1175,64 @@ __device__ __forceinline__ void traverse_wide_oct(const WideScene &ws, const Tri
             wmask left = 0ull;
 #pragma unroll
             for (int r = 0; r < R; ++r) left |= active[r] & ~occluded[r];
-            if (left == 0ull) return; // every ray of the packet is decided
+            if (left == 0ull) { FFX_TSTOP(tw, ANY ? 9 : 1); return true; } // every ray of the packet is decided
+            // (the undecided rays keep their full length: the packet's hit distance does not change)
+          } else {
+            hb = packet_hts();
+            hit &= m_le(tn, __uint_as_float(hb)); // the remaining triangles of this cluster against the shorter rays
           }
-          hb = packet_hts();
-          hit &= m_le(tn, __uint_as_float(hb)); // the remaining triangles of this cluster against the shorter rays
         }
       }
+      FFX_TSTOP(tw, ANY ? 9 : 1);
     } else if (hit != 0ull) {
       FFX_STAT(ANY ? 13 : 9);
-      // descend into the child entered first, push the others with their entry distances
-      const uint32_t tnb = __float_as_uint(tn);
-      int near_lane = wff1(hit);
-      if ((hit & (hit - 1ull)) != 0ull) {
-        const uint32_t mnb = wave_reduce_nn<false>(msel(hit, tnb, 0x40000000u));
-        near_lane = wff1(hit & __builtin_amdgcn_uicmp(tnb, mnb, 32));
-        const wmask others = hit & ~(1ull << near_lane);
-        if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(q.w, tnb);
-        sp += wpop(others);
+      // ---- inner node: descend into the child entered first, push the others with their entry distances.
+      // key = entry distance (6 low mantissa bits dropped: it only orders and culls, conservatively) | lane
+      const uint32_t key = (__float_as_uint(tn) & ~63u) | (threadIdx.x & 63u);
+      if ((hit & (hit - 1ull)) == 0ull) { // a single child
+        cur = __builtin_amdgcn_readlane((int)q.w, wff1(hit));
+        FFX_TSTOP(tw, ANY ? 10 : 2);
+        continue;
       }
-      next = __builtin_amdgcn_readlane((int)q.w, near_lane);
-      have_next = true;
+#ifdef FFX_EXP_LANE_ORDER // experiment: descend in lane order instead of nearest-first
+      const uint32_t near_lane = (uint32_t)wff1(hit);
+#else
+      const uint32_t near_lane = wave_reduce_nn<false>(msel(hit, key, 0xffffffffu)) & 63u;
+#endif
+      const wmask others = hit & ~(1ull << near_lane);
+      if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(q.w, key);
+      sp += wpop(others);
+      cur = __builtin_amdgcn_readlane((int)q.w, (int)near_lane);
+      FFX_TSTOP(tw, ANY ? 10 : 2);
+      continue;
     }
-    if (!have_next) {
-      // pop: skip entries the rays can no longer reach
-      while (true) {
-        if (sp == 0) return;
-        FFX_STAT(ANY ? 14 : 10);
-        --sp;
-        const uint2 e = stack[sp];
-        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), etn = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
-        if (etn <= hb) { next = (int32_t)ref; break; }
-      }
+    // ---- pop: skip entries the rays can no longer reach
+    for (;;) {
+      if (sp == 0) { FFX_TSTOP(tw, ANY ? 11 : 3); return true; }
+      FFX_STAT(ANY ? 14 : 10);
+      --sp;
+      const uint2 e = stack[sp];
+      const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), etn = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y) & ~63u;
+      if (etn <= hb) { cur = (int32_t)ref; break; }
     }
-    cur = next;
+    FFX_TSTOP(tw, ANY ? 11 : 3);
   }
 }
 
-// wide walk of R rays per lane that share their origin `o` (the apex the records `recs` were prepared for)
+// wide walk of R rays per lane that share their origin `o` (the apex the records `recs` were prepared for).
+// Packets the interval test is bad at go to the binary walk instead (its box tests are per ray): packets whose
+// rays disagree on a direction sign, packets whose directions spread more than FFX_WIDE_FAT of their length
+// (the samples of a pixel on a depth discontinuity, seen from an emitter: a fan whose bounding wedge
+// contains hundreds of boxes no ray comes near — colon, 1024^2: 15.9 ms with every packet on the wide walk,
+// 4.2 ms on the binary walk), and walks that exceed FFX_WIDE_MAX_WORK.  Results are identical either way.
+#ifndef FFX_WIDE_FAT
+#define FFX_WIDE_FAT 0.02f
+#endif
 template <bool ANY, int R>
-__device__ __forceinline__ void traverse_wide(const WideScene &ws, const TriApex *__restrict__ recs, v3 o, const v3 (&d)[R], const float (&tmin)[R],
-                                              const float (&tmax)[R], const bool (&act)[R], Hit (&h)[R], bool (&found)[R], uint2 *__restrict__ stack) {
+__device__ __forceinline__ void traverse_wide(const WideScene &ws, const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[R],
+                                              const v3 (&d)[R], const float (&tmin)[R], const float (&tmax)[R], const bool (&act)[R], Hit (&h)[R], bool (&found)[R],
+                                              uint2 *__restrict__ stack) {
+  FFX_TSTART(ts);
   wmask active[R], any_active = 0ull;
 #pragma unroll
   for (int r = 0; r < R; ++r) { active[r] = wballot(act[r]); any_active |= active[r]; }
@@ -1174,7 +1253,7 @@ __device__ __forceinline__ void traverse_wide(const WideScene &ws, const TriApex
     aid[r] = V3(fabsf(id.x), fabsf(id.y), fabsf(id.z));
     sw[r] = scale * 1.0000002f;
   }
-  // the packet's octant: that of its first active ray; axes on which some active ray disagrees are dropped
+  // the packet's octant: that of its first active ray
   uint32_t oct0 = 0;
   {
     bool got = false;
@@ -1182,29 +1261,34 @@ __device__ __forceinline__ void traverse_wide(const WideScene &ws, const TriApex
     for (int r = 0; r < R; ++r)
       if (!got && active[r] != 0ull) { oct0 = (uint32_t)__builtin_amdgcn_readlane((int)oct[r], wff1(active[r])); got = true; }
   }
-  uint32_t mixed = 0;
+  wmask dis = 0ull;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    wmask dis = 0ull;
+  for (int r = 0; r < R; ++r) dis |= active[r] & __builtin_amdgcn_uicmp(oct[r], oct0, 33);
+  bool done = false;
+  if (dis == 0ull) {
+    float spread;
+    const WidePk pk = make_widepk<R>(ws.hdr, o[0], aid, oct, active, oct0, 0u, spread);
+    FFX_TSTOP(ts, ANY ? 12 : 4);
+    if (spread <= FFX_WIDE_FAT) {
+      wmask occ[R];
+      switch (oct0) { // wave-uniform
+        case 0: done = traverse_wide_oct<ANY, 0, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 1: done = traverse_wide_oct<ANY, 1, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 2: done = traverse_wide_oct<ANY, 2, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 3: done = traverse_wide_oct<ANY, 3, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 4: done = traverse_wide_oct<ANY, 4, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 5: done = traverse_wide_oct<ANY, 5, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        case 6: done = traverse_wide_oct<ANY, 6, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+        default: done = traverse_wide_oct<ANY, 7, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+      }
 #pragma unroll
-    for (int r = 0; r < R; ++r) dis |= active[r] & __builtin_amdgcn_uicmp((oct[r] >> a) & 1u, (oct0 >> a) & 1u, 33);
-    if (dis != 0ull) mixed |= 1u << a;
+      for (int r = 0; r < R; ++r) found[r] = __builtin_amdgcn_inverse_ballot_w64(occ[r]);
+    }
   }
-  const WidePk pk = make_widepk<R>(ws.hdr, o, aid, oct, active, oct0, mixed);
-  wmask occ[R];
-  if (mixed != 0u) traverse_wide_oct<ANY, 8, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack);
-  else switch (oct0) { // wave-uniform
-    case 0: traverse_wide_oct<ANY, 0, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 1: traverse_wide_oct<ANY, 1, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 2: traverse_wide_oct<ANY, 2, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 3: traverse_wide_oct<ANY, 3, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 4: traverse_wide_oct<ANY, 4, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 5: traverse_wide_oct<ANY, 5, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    case 6: traverse_wide_oct<ANY, 6, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
-    default: traverse_wide_oct<ANY, 7, R>(ws, recs, pk, d, tmin, tmax, sw, active, h, occ, stack); break;
+  if (!done) {
+    FFX_STAT(ANY ? 30 : 26);
+    traverse_packet<ANY, R>(nodes, recs, o, d, tmin, tmax, act, h, found); // binary walk, per-ray box tests
   }
-#pragma unroll
-  for (int r = 0; r < R; ++r) found[r] = __builtin_amdgcn_inverse_ballot_w64(occ[r]);
 }
 
 // one ray per lane: pick the octant loop if the packet's active rays agree on their direction signs
@@ -1247,7 +1331,7 @@ template <bool ANY, int R, bool WIDE>
 __device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ arecs, const WideScene &ws, uint2 *__restrict__ stack,
                                                     const v3 (&o)[R], const v3 (&d)[R], const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R],
                                                     Hit (&h)[R], bool (&found)[R]) {
-  if constexpr (WIDE) traverse_wide<ANY, R>(ws, arecs, o[0], d, tmin, tmax, active, h, found, stack);
+  if constexpr (WIDE) traverse_wide<ANY, R>(ws, nodes, arecs, o, d, tmin, tmax, active, h, found, stack);
   else if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, arecs, o, d, tmin, tmax, active, h, found);
   else traverse_packet<ANY, R>(nodes, arecs, o, d, tmin, tmax, active, h, found);
 }
@@ -1525,6 +1609,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                     int fp16, void *__restrict__ img, uint4 *__restrict__ cache, int ppw) {
   constexpr int NSUB = 4 / R;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
+  FFX_TINIT();
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
   // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
@@ -1556,6 +1641,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       bool active[R];
       v3 o[R], d[R];
       float nt[R], ft[R];
+      FFX_TSTART(tk);
       const CamK &cam = kernarg_shade().cam; // phase: ray generation
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -1565,8 +1651,10 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         sample_jitter(seed_key, idx, jx, jy);
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
+      FFX_TSTOP(tk, 16);
       SampleTerms st[R];
       shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
+      FFX_TSTOP(tk, 17);
       if (cache) {
         // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
 #pragma unroll
@@ -1629,6 +1717,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       }
     }
   }
+  FFX_TFLUSH();
 }
 
 template <int R, bool WIDE>
@@ -1883,10 +1972,10 @@ static int use_wide(const ffx_bvh_info *info) {
 static WideScene wide_scene(const void *bvh, const ffx_bvh_info *info) {
   WideScene ws;
   const char *base = (const char *)bvh;
-  ws.wn = (const WideChild *)(base + info->off_wnodes);
-  ws.tq = (const WideChild *)(base + info->off_tq);
+  ws.elems = (const WideChild *)(base + info->off_wnodes);
   ws.hdr = (const WideHdr *)(base + info->off_whdr);
   ws.root = info->wide_root;
+  ws.tq0 = (uint32_t)((info->off_tq - info->off_wnodes) / sizeof(WideChild));
   return ws;
 }
 
@@ -1964,10 +2053,22 @@ static inline size_t stack_bytes(const ffx_bvh_info *info) {
 }
 
 #ifdef FFX_STATS
-extern "C" int ffx_debug_stats(unsigned long long *out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ffx_stats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+#endif
+#ifdef FFX_TIMERS
+extern "C" int ffx_debug_timers(unsigned long long *out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_ffx_tim), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_tim), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+#ifdef FFX_STATS
+extern "C" int ffx_debug_stats(unsigned long long *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ffx_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_stats), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;

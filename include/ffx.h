@@ -170,11 +170,11 @@ typedef struct ffx_bvh_info {
    * slots.  All zero in a blob written by the oracle (which walks its own binary tree). */
   int32_t n_wide;     /* wide inner nodes (0: the whole scene is one cluster) */
   int32_t wide_depth; /* wide inner levels above the clusters */
-  int32_t wide_root;  /* reference of the root: >= 0 wide node, < 0 cluster code */
+  int32_t wide_root;  /* reference of the root: cluster << 31 | element << 6 | (count - 1), elements of 16 B from off_wnodes */
   int32_t wide_pad;
   uint64_t off_wnodes; /* n_wide x 64 x 16 B child records */
   uint64_t off_wsrc;   /* n_wide x 64 x int32: where each child's box lives in the binary tree */
-  uint64_t off_tq;     /* n_tris x 16 B quantised triangle boxes, leaf-slot order */
+  uint64_t off_tq;     /* n_tris x 16 B quantised triangle boxes, leaf-slot order; = off_wnodes + n_wide * 1024 */
   uint64_t off_whdr;   /* 64 B: quantisation grid of the current pose */
 } ffx_bvh_info;
 

@@ -136,15 +136,20 @@ def test_host_bvh_structure(case):
     wrefs = np.zeros(max(nw, 1), np.int32)
     depth_seen = 0
 
+    tq0 = 64 * nw
+    assert info.off_tq == info.off_wnodes + 16 * tq0
+
     def visit(ref, depth):
         nonlocal depth_seen
-        if ref < 0:
-            code = (~ref) & 0xFFFFFFFF
-            first, cnt = code >> 6, (code & 63) + 1
-            assert first + cnt <= F
+        ref &= 0xFFFFFFFF
+        cluster, elem, cnt = ref >> 31, (ref >> 6) & 0x1FFFFFF, (ref & 63) + 1
+        if cluster:
+            first = elem - tq0
+            assert 0 <= first and first + cnt <= F
             wcov[first : first + cnt] += 1
             return
-        idx, cnt = ref >> 6, (ref & 63) + 1
+        assert elem % 64 == 0
+        idx = elem // 64
         assert 0 <= idx < nw and 2 <= cnt <= 64
         wrefs[idx] += 1
         depth_seen = max(depth_seen, depth + 1)
@@ -161,4 +166,4 @@ def test_host_bvh_structure(case):
     assert nw == 0 or (wrefs == 1).all()
     assert depth_seen == info.wide_depth <= 6
     assert (info.n_wide == 0) == (F <= 64)
-    assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + 16 * F <= info.off_whdr
+    assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + 16 * F <= info.off_wsrc

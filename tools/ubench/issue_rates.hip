@@ -166,6 +166,23 @@
 #define K_SCMP(i) "s_cmp_lg_u64 s[36:37], 0\n"
 #define K_BCNT(i) "s_bcnt1_i32_b64 " T(i) ", s[36:37]\n"
 #define K_SNOP(i) "s_nop 0\n"
+#define K_DPP_MIN(i) "v_min_u32_dpp " D(i) ", " A(i) ", " B(i) " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define K_DPP_MIRROR(i) "v_min_u32_dpp " D(i) ", " A(i) ", " B(i) " row_mirror row_mask:0xf bank_mask:0xf\n"
+#define K_DPP_MOV(i) "v_mov_b32_dpp " D(i) ", " A(i) " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define K_MIN_U32(i) "v_min_u32 " D(i) ", " A(i) ", " B(i) "\n"
+#define K_SDWA_CVT(i) "v_cvt_f32_u32_sdwa " D(i) ", " A(i) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define K_CVT_U32(i) "v_cvt_f32_u32 " D(i) ", " A(i) "\n"
+#define K_CVT_UBYTE(i) "v_cvt_f32_ubyte1 " D(i) ", " A(i) "\n"
+#define K_AND_OR(i) "v_and_or_b32 " D(i) ", " A(i) ", " B(i) ", " A(i) "\n"
+#define K_MBCNT(i) "v_mbcnt_lo_u32_b32 " D(i) ", s36, " A(i) "\n"
+#define K_LSHL_ADD(i) "v_lshl_add_u32 " D(i) ", " A(i) ", 3, " B(i) "\n"
+#define K_SNOP1(i) "s_nop 1\n"
+// the DPP reduction step as used in the kernels: s_nop 1 + one dependent DPP op
+#define K_DPP_CHAIN(i) "s_nop 1\n v_min_u32_dpp v32, v32, v32 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+// readlane feeding a scalar op (the VALU -> SGPR -> SALU path of the cross-row combine)
+#define K_RL_SMIN(i) "v_readlane_b32 " T(i) ", " A(i) ", 16\n s_min_u32 s40, s40, " T(i) "\n"
+// v_cmp -> SGPR pair -> s_and -> s_cmp -> (not taken) branch: the uniform decision chain of the walks
+#define K_CMP_BR(i) "v_cmp_le_f32 s[40:41], " A(i) ", " B(i) "\n s_and_b64 s[42:43], s[40:41], s[38:39]\n s_cmp_lg_u64 s[42:43], 0\n s_cbranch_scc0 1f\n"
 // VALU/SALU interleave
 #define K_MIX11(i) "v_fma_f32 " D(i) ", s36, " B(i) ", " A(i) "\n" "s_and_b64 " S(i) ", s[36:37], s[38:39]\n"
 #define K_MIX21(i) "v_fma_f32 " D(i) ", s36, " B(i) ", " A(i) "\n" "v_mul_f32 " D(i) ", s36, " B(i) "\n" "s_and_b64 " S(i) ", s[36:37], s[38:39]\n"
@@ -238,6 +255,20 @@ KERNEL(k_mix12, X4(K_MIX12))
 KERNEL(k_dep_fma, X4(K_DEP_FMA))
 KERNEL(k_dep_mul, X4(K_DEP_MUL))
 KERNEL(k_br_nt, "s_cmp_lg_u32 0, 0\n" X4(K_BR_NT))
+KERNEL(k_dpp_min, X4(K_DPP_MIN))
+KERNEL(k_dpp_mirror, X4(K_DPP_MIRROR))
+KERNEL(k_dpp_mov, X4(K_DPP_MOV))
+KERNEL(k_min_u32, X4(K_MIN_U32))
+KERNEL(k_sdwa_cvt, X4(K_SDWA_CVT))
+KERNEL(k_cvt_u32, X4(K_CVT_U32))
+KERNEL(k_cvt_ubyte, X4(K_CVT_UBYTE))
+KERNEL(k_and_or, X4(K_AND_OR))
+KERNEL(k_mbcnt, X4(K_MBCNT))
+KERNEL(k_lshl_add, X4(K_LSHL_ADD))
+KERNEL(k_snop1, X4(K_SNOP1))
+KERNEL(k_dpp_chain, X4(K_DPP_CHAIN))
+KERNEL(k_rl_smin, X4(K_RL_SMIN))
+KERNEL(k_cmp_br, X4(K_CMP_BR))
 
 // scalar loads from a 4 KB table (scalar-cache hits): 16 x s_load_dwordx16 per iteration, drained once per iteration
 __global__ void __launch_bounds__(64) k_sload16(float *out, Stamp *st, int iters, const int *tab) {
@@ -311,11 +342,14 @@ static void time_one(const char *name, int n_per_iter, int waves_per_simd, F lau
   hipEventDestroy(b);
 }
 
+static const char *g_filter = nullptr;
 #define RUN(K, NAME, N)                                                                                                             \
+  if (!g_filter || strstr(NAME, g_filter))                                                                                           \
   for (int w : {1, 2, 4, 7, 8})                                                                                                      \
     time_one(NAME, N, w, [&](int blocks, size_t lds, int iters) { hipLaunchKernelGGL(K, dim3(blocks), dim3(64), lds, 0, d_out, d_st, iters); });
 
 int main(int argc, char **argv) {
+  if (argc > 1) g_filter = argv[1];
   hipMalloc(&d_out, 1024);
   hipMalloc(&d_st, sizeof(Stamp));
   int h_tab[64 * 16];
@@ -354,6 +388,20 @@ int main(int argc, char **argv) {
   RUN(k_dep_fma, "v_fma_f32 dependent chain", 64)
   RUN(k_dep_mul, "v_mul_f32 dependent chain", 64)
   RUN(k_br_nt, "s_cbranch_scc1 not taken", 65)
+  RUN(k_dpp_min, "v_min_u32_dpp quad_perm (indep.)", 64)
+  RUN(k_dpp_mirror, "v_min_u32_dpp row_mirror (indep.)", 64)
+  RUN(k_dpp_mov, "v_mov_b32_dpp quad_perm", 64)
+  RUN(k_min_u32, "v_min_u32 (VOP2)", 64)
+  RUN(k_sdwa_cvt, "v_cvt_f32_u32_sdwa WORD_1", 64)
+  RUN(k_cvt_u32, "v_cvt_f32_u32", 64)
+  RUN(k_cvt_ubyte, "v_cvt_f32_ubyte1", 64)
+  RUN(k_and_or, "v_and_or_b32", 64)
+  RUN(k_mbcnt, "v_mbcnt_lo_u32_b32 (SGPR mask)", 64)
+  RUN(k_lshl_add, "v_lshl_add_u32", 64)
+  RUN(k_snop1, "s_nop 1", 64)
+  RUN(k_dpp_chain, "s_nop 1 + dependent v_min_u32_dpp (pair)", 64)
+  RUN(k_rl_smin, "v_readlane -> s_min_u32 (pair)", 64)
+  RUN(k_cmp_br, "v_cmp->s_and->s_cmp->branch (4 instr)", 64)
   for (int w : {1, 2, 4, 7, 8})
     time_one("s_load_dwordx16 (scalar-cache hits)", 16, w,
              [&](int blocks, size_t lds, int iters) { hipLaunchKernelGGL(k_sload16, dim3(blocks), dim3(64), lds, 0, d_out, d_st, iters, d_tab); });

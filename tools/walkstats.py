@@ -19,7 +19,7 @@ def main():
     with torch.no_grad():
         wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
     lib = _lib.api().lib
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     for seed in range(3):
         wl.ff_scene.randomize()
         mi.render(wl.mi_scene, spp=spp, seed=seed)
