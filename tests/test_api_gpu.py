@@ -258,6 +258,104 @@ def test_pattern_optimizer_explicit_adjoints_match_autograd():
         torch.testing.assert_close(runs[0][1], runs[1][1], rtol=1e-5, atol=2e-6)
 
 
+def _oracle_step_gradient(oracle, wl, opt_kwargs, S, step=0):
+    """d loss / d rays and the loss of ONE PatternOptimizer step, chained through the oracle: per sample k the
+    scene is randomised under dist.sample_seed(base, step, S, k), rendered and differentiated (K8 / K9) by the
+    oracle, then K3^T, K2-bwd, K1-bwd and the overlap regulariser — the arithmetic of optim.PatternOptimizer.step
+    restated with the oracle's entry points."""
+    from fireflies_amd import dist
+
+    rays = wl.laser._rays.detach().cpu().numpy().copy()
+    KF = wl.laser._KF
+    s0, s1 = opt_kwargs["tex_size"]
+    sigma, spp, reg_w, base = opt_kwargs["sigma"], opt_kwargs["spp"], opt_kwargs["reg_weight"], opt_kwargs["base_seed"]
+    ndc = oracle.project_rays_fwd(rays, KF)
+    pts = np.ascontiguousarray(ndc[:, :2])
+    tsum = oracle.splat_fwd(pts, sigma, 0, -1, s0, s1)
+    tex = oracle.blur_fwd(tsum)
+    gtex = np.zeros_like(tex)
+    loss = 0.0
+    H, W = wl.mi_scene.scene_desc(tex_channels=1).cam.height, wl.mi_scene.scene_desc(tex_channels=1).cam.width
+    gimg = np.zeros((H, W, 3), np.float32)
+    gimg[..., 1] = -1.0 / float(H * W)  # d coverage_loss / d img
+    for k in range(S):
+        seed = dist.sample_seed(base, step, S, k)
+        torch.manual_seed(seed)
+        random.seed(seed)
+        wl.ff_scene.randomize()
+        go = _oracle_pose(oracle, wl)
+        sd = wl.mi_scene.scene_desc(tex_channels=1)
+        alb = wl.mi_scene.albedo.cpu().numpy()
+        img = go.render_fwd(sd, alb, tex, spp, seed=seed)
+        loss += float(-img[..., 1].mean())
+        gtex += go.render_bwd(sd, alb, spp, seed, gimg)[..., 0]
+    gts = oracle.blur_bwd(gtex)
+    gp = oracle.splat_bwd(pts, sigma, 0, -1, s0, s1, tsum, gts)
+    grad = oracle.project_rays_bwd(rays, KF, np.concatenate([gp, np.zeros((pts.shape[0], 1), np.float32)], 1)) / float(S)
+    loss /= float(S)
+    if reg_w > 0:
+        tsor = oracle.splat_fwd(pts, sigma, 1, -1, s0, s1)
+        reg, gd = oracle.l1_value_grad(tsor, tsum, reg_w)
+        gp = oracle.splat_bwd(pts, sigma, 1, -1, s0, s1, tsor, gd) - oracle.splat_bwd(pts, sigma, 0, -1, s0, s1, tsum, gd)
+        grad = grad + oracle.project_rays_bwd(rays, KF, np.concatenate([gp, np.zeros((pts.shape[0], 1), np.float32)], 1))
+        loss += float(reg)
+    return grad, loss
+
+
+@pytest.mark.parametrize("S", [4, 32])
+def test_multi_sample_step_matches_oracle(oracle, S):
+    """BASELINE configs[3] on one GPU: a PatternOptimizer step over S randomised scene samples (4 = one
+    rank's share of the 8-GPU split, 32 = the whole step) gives the pattern gradient and loss of the oracle
+    chained over the same per-sample seeds (dist.sample_seed) — not merely of its own autograd twin."""
+    kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=11)
+    wl = _small()
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, samples_per_step=S, **kw)
+    out = opt.step()
+    got = wl.laser._rays.grad.detach().cpu().numpy()
+    wl2 = _small()  # same scene, fresh samplers: the oracle replays the randomisations
+    ref, ref_loss = _oracle_step_gradient(oracle, wl2, kw, S)
+    assert np.abs(ref).max() > 0
+    np.testing.assert_allclose(got, ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
+    assert float(out["loss"]) == pytest.approx(ref_loss, rel=2e-4, abs=1e-6)
+    # second step: the sample seeds advance with the step index
+    before = wl.laser._rays.detach().clone()
+    opt.step()
+    assert opt.step_index == 2 and not torch.equal(before, wl.laser._rays.detach())
+
+
+def test_two_rank_rccl_step_matches_one_rank(tmp_path):
+    """BASELINE configs[3]'s exchange on real RCCL: two fresh processes (one per GPU, torch.distributed
+    backend "nccl" = RCCL) run the same 4-sample step, each on its share {k : k mod 2 = rank}; after the ONE
+    all-reduce of the flat [3N+1] buffer both hold the gradient of a single process that ran all four."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path)]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert all(o["world"] == 2 and o["backend"] == "nccl" for o in outs) and {o["device"] for o in outs} == {0, 1}
+    # single process, all four samples
+    kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21)
+    wl = _small()
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, samples_per_step=4, **kw)
+    out = opt.step()
+    ref = wl.laser._rays.grad.detach().cpu().numpy()
+    for o in outs:
+        np.testing.assert_allclose(np.asarray(o["grad"], np.float32), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+        assert o["loss"] == pytest.approx(float(out["loss"]), rel=1e-4)
+        np.testing.assert_allclose(np.asarray(o["rays"], np.float32), wl.laser._rays.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(np.asarray(outs[0]["grad"]), np.asarray(outs[1]["grad"]))  # replicated optimiser state
+
+
 def test_laser_yaml_roundtrip(tmp_path):
     wl = _small(randomize=False)
     f = tmp_path / "laser.yaml"

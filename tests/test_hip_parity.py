@@ -180,6 +180,21 @@ def test_k3_blur(oracle):
     np.testing.assert_array_equal(host(ops.blur_fwd(dev(a), 9, 2.0)), oracle.blur_fwd(a, 9, 2.0))
 
 
+def _assert_image_close(img_d, img_o, spp, frac=2e-4, rel=1e-4, what=""):
+    """radiance: `rel` of the image scale per pixel (fp32 reassociation of the sample sum, ulp-level libm
+    differences) for all but `frac` of the pixels; and NO pixel may be off by more than what one or two
+    samples whose hit or shadow test flips at an edge can cause: a sample carries 1/spp of its pixel, and
+    a single sample is at most ~1.5x the brightest pixel mean, so the bound is 1.5 * scale / spp (it was a
+    flat 0.2 * scale: at 64 spp this is 8x tighter)."""
+    scale = float(img_o.max())
+    assert scale > 0, what
+    err = np.abs(img_d.astype(np.float64) - img_o.astype(np.float64))
+    bad = float((err > rel * scale).mean())
+    assert bad <= frac, f"{what}: {bad:.2e} of the pixel channels differ by more than {rel:g} of the scale"
+    assert err.max() <= 1.5 * scale / spp, f"{what}: worst pixel off by {err.max() / scale:.3f} of the scale (bound {1.5 / spp:.3f})"
+    return scale, err
+
+
 # ------------------------------------------------------------------ K5..K7
 def _pair(oracle, sc, frame=0, xforms=None):
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
@@ -330,6 +345,37 @@ def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
         assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
 
 
+def test_async_update_with_caller_supplied_vertices(monkeypatch):
+    """the animation path (`<mesh>.vertex_positions` assignment, add_animation_func, OBJ sequences): Scene
+    copies the caller's vertices into a scratch slot of the vertex pool on the caller's stream while the
+    refit runs on a side stream.  A burst of (new vertices, update, trace) without any host sync must see,
+    for every pose, exactly the vertices of that pose — i.e. what the single-stream path computes."""
+    from fireflies_amd import mi
+
+    def run(async_flag):
+        monkeypatch.setenv("FFX_ASYNC_UPDATE", async_flag)
+        sc = scenes.vocalfold(width=96, height=96, frames=2, n_fold=24, tube=(24, 32))
+        ms = mi.load_scene_data(sc)
+        assert ms.geom._async == (async_flag == "1")
+        params = mi.traverse(ms)
+        cam = ms.camera_struct(0)
+        base = torch.from_numpy(sc.meshes[1].frames[0]).to("cuda")
+        outs = []
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for i in range(10):  # no synchronisation anywhere in this loop
+            v = base * (1.0 + 0.3 * torch.rand((), device="cuda", generator=g)) + 0.05 * torch.randn(3, device="cuda", generator=g)
+            params[sc.meshes[1].name + ".vertex_positions"] = mi.Float32(v.reshape(-1))
+            params.update()
+            outs.append(ms.geom.trace_primary(cam, 2, 1, seed=i))
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run("1"), run("0")
+    for (t1, s1, p1), (t2, s2, p2) in zip(a, b):
+        assert torch.equal(t1, t2) and torch.equal(s1, s2) and torch.equal(p1, p2)
+    assert not torch.equal(a[0][0], a[1][0])  # the poses really differ
+
+
 def test_l1_value_grad_matches_oracle(oracle):
     rng = np.random.default_rng(6)
     for shape in ((500, 500), (7, 3), (1, 1)):
@@ -377,13 +423,7 @@ def test_k8_render_forward(oracle, shadows, ch):
     img_d = host(gd.render_fwd(sd, dev(alb), tex, 8, seed=11))
     img_o = go.render_fwd(sd, alb, host(tex), 8, seed=11)
     assert img_o.max() > 0.05
-    # radiance: 1e-4 relative to the image scale per pixel (fp32 reassociation of the sample sum and
-    # ulp-level libm differences); a sample whose hit flips at an edge moves a pixel by <= 1/spp of
-    # its range, so a handful of outliers are tolerated and bounded separately
-    scale = float(img_o.max())
-    err = np.abs(img_d - img_o)
-    assert (err > 1e-4 * scale).mean() <= 2e-4
-    assert err.max() <= 0.2 * scale
+    scale, _ = _assert_image_close(img_d, img_o, 8, what=f"shadows={shadows} ch={ch}")
     # fp16 film (config 5): converted once at the store
     img_h = host(gd.render_fwd(sd, dev(alb), tex, 8, seed=11, fp16=True)).astype(np.float32)
     np.testing.assert_allclose(img_h, img_d, rtol=1e-3, atol=1e-4 * scale)
@@ -395,10 +435,8 @@ def test_k8_hello_world_plumbing(oracle):
     sd = scene_desc.scene_desc(sc, shadows=True)
     img_d = host(gd.render_fwd(sd, dev(alb), None, 16, seed=0))
     img_o = go.render_fwd(sd, alb, np.zeros((1, 1), np.float32), 16, seed=0)
-    scale = float(img_o.max())
+    scale, _ = _assert_image_close(img_d, img_o, 16, frac=1e-3, what="hello_world")
     assert scale > 0.01
-    err = np.abs(img_d - img_o)
-    assert (err > 1e-4 * scale).mean() <= 1e-3 and err.max() <= 0.2 * scale
 
 
 @pytest.mark.parametrize("ch", [1, 3])
@@ -447,6 +485,47 @@ def test_k8k9_full_size_properties():
     assert abs(float(img.mean()) - float(img_b.mean())) < 2e-3 * float(img.mean())
 
 
+def test_full_size_parity_with_the_oracle_at_512x512x64(oracle):
+    """BASELINE size against the oracle itself (not only properties): three randomised poses of the 53,248
+    triangle vocal fold at 512x512, 64 spp — 50 M primary rays.  Primitive and shape ids must agree on EVERY
+    ray (a box test that is not conservative shows up as a hit the oracle finds and the GPU misses), the
+    image within 1e-4 of its scale with no pixel off by more than two flipped samples' worth."""
+    sc = scenes.vocalfold()
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    gd = ops.DeviceGeometry(pool, tris, shape, off)
+    go = oracle.Geometry(pool, tris, shape, off)
+    cam = scene_desc.camera_from_sensor(sc.camera)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    tex = _tex(sc)
+    rng = np.random.default_rng(77)
+    total = flips = lost = 0
+    for i in range(3):
+        a = rng.uniform(-0.2, 0.2)
+        R = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+        S = np.diag([rng.uniform(0.6, 1.6), rng.uniform(0.8, 1.2), 1.0, 1.0])
+        T = np.eye(4)
+        T[:3, 3] = rng.uniform(-0.08, 0.08, 3)
+        xf = np.stack([np.eye(4), T @ R @ S]).astype(np.float32)
+        offs = off.copy()
+        offs[1] = off[1] + int(rng.integers(0, nfr[1])) * stride[1]
+        gd.update(xf, offs)
+        go.update(xf, offs)
+        td, sd_, pd = gd.trace_primary(cam, 64, 1, seed=i)
+        to, so, po = go.trace_primary(cam, 64, 1, seed=i)
+        pd, sd_ = host(pd), host(sd_)
+        total += pd.size
+        flips += int(((pd != po) | (sd_ != so)).sum())
+        lost += int(((pd < 0) & (po >= 0)).sum())
+        same = pd == po
+        np.testing.assert_allclose(host(td)[same], to[same], rtol=1e-5, atol=1e-6)
+        img_d = host(gd.render_fwd(sd, dev(alb), tex, 64, seed=i))
+        img_o = go.render_fwd(sd, alb, host(tex), 64, seed=i)
+        _assert_image_close(img_d, img_o, 64, what=f"pose {i}")
+    assert total == 3 * 512 * 512 * 64
+    assert lost == 0, f"{lost} rays hit in the oracle and missed on the GPU"
+    assert flips <= 2, f"{flips} of {total} rays hit a different primitive"
+
+
 def test_k7_axis_parallel_rays_are_not_pathological():
     """Un-jittered pixel-corner rays of the centre row / column have a direction component of exactly
     0.  The box test must still reject boxes the origin lies outside of on that axis; when it did not
@@ -476,13 +555,14 @@ def test_k7_axis_parallel_rays_are_not_pathological():
     assert int(s[1]) >= 0 and float(t[1]) > 0  # the off-axis ray hits a fold
 
 
-@pytest.mark.parametrize("env", [{"FFX_TRAVERSAL": "lane"}, {}, {"FFX_XCD_REMAP": "1", "FFX_PACKET_WAVES": "4", "FFX_PIXELS_PER_WAVE": "4"},
-                                 {"FFX_PACKET_WAVES": "2", "FFX_PIXELS_PER_WAVE": "1", "FFX_TILE_BLOCK": "0"}, {"FFX_XCD_REMAP": "16", "FFX_TILE_BLOCK": "2"}])
+@pytest.mark.parametrize("env", [{"FFX_TRAVERSAL": "lane"}, {}, {"FFX_WIDE": "0"}, {"FFX_XCD_REMAP": "1", "FFX_PIXELS_PER_WAVE": "4"},
+                                 {"FFX_WIDE": "0", "FFX_PIXELS_PER_WAVE": "1", "FFX_TILE_BLOCK": "0"}, {"FFX_XCD_REMAP": "16", "FFX_TILE_BLOCK": "2"}])
 def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
     """the per-lane kernels (apex vectors formed per ray), the wave-packet kernels (apex records
-    precomputed per render call) and the launch-shape knobs all compute the same image and the same
+    precomputed per render call) on the 64-wide walk (default) and on the binary walk (FFX_WIDE=0), and the
+    launch-shape knobs all compute the same image and the same
     texture gradient (odd film size, spp not a multiple of 64, both shadow settings)."""
-    for k in ("FFX_TRAVERSAL", "FFX_XCD_REMAP", "FFX_PACKET_WAVES", "FFX_PIXELS_PER_WAVE", "FFX_TILE_BLOCK"):
+    for k in ("FFX_TRAVERSAL", "FFX_WIDE", "FFX_XCD_REMAP", "FFX_PIXELS_PER_WAVE", "FFX_TILE_BLOCK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -495,9 +575,8 @@ def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
         sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=shadows)
         img_d = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=21))
         img_o = go.render_fwd(sd, alb, host(tex), spp, seed=21)
-        scale = float(img_o.max())
-        err = np.abs(img_d - img_o)
-        assert scale > 0.02 and (err > 1e-4 * scale).mean() <= 1e-3 and err.max() <= 0.25 * scale, env
+        scale, _ = _assert_image_close(img_d, img_o, spp, frac=1e-3, what=str(env))
+        assert scale > 0.02
         gt_d = host(gd.render_bwd(sd, dev(alb), spp, 21, dev(gimg)))
         gt_o = go.render_bwd(sd, alb, spp, 21, gimg)
         gs = float(np.abs(gt_o).max())
