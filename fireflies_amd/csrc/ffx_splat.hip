@@ -233,6 +233,68 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_splat_lines_fwd(const float *__
   out[((size_t)n * size1 + a) * size0 + b] = expf(-(dist * dist) / (sigma * sigma));
 }
 
+// autograd of rasterize_lines w.r.t. the segment end points: one workgroup per segment walks the layer,
+// per texel  g * d out / d dist2 * d dist2 / d (start, end)  with out = exp(-dist2^2 / sigma^2); fp64 partial
+// sums, wave shuffles -> LDS -> one store per coordinate: no atomics, reproducible.
+__global__ void __launch_bounds__(1024) k_splat_lines_bwd(const float *__restrict__ lines, float sigma, int size0, int size1, const float *__restrict__ gout,
+                                                         float *__restrict__ glines) {
+  __shared__ double s_part[16][4];
+  const int n = blockIdx.x;
+  const float eps = 1.1920928955078125e-07f;
+  const float sx = lines[4 * n + 0] * (float)size0, sy = lines[4 * n + 1] * (float)size1;
+  const float ex = lines[4 * n + 2] * (float)size0, ey = lines[4 * n + 3] * (float)size1;
+  const float mx = ex - sx, my = ey - sy;
+  const float mm = mx * mx + my * my + eps;
+  const float inv_s2 = 1.0f / (sigma * sigma);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0}; // d/d(sx, sy, ex, ey) in texel units
+  const long total = (long)size0 * size1;
+  const float *g = gout + (size_t)n * total;
+  for (long t = threadIdx.x; t < total; t += 1024) {
+    const float go = g[t];
+    if (go == 0.f) continue;
+    const int a = (int)(t / size0), b = (int)(t % size0);
+    const float X = (float)b, Y = (float)a;
+    const float pax = X - sx, pay = Y - sy, pbx = X - ex, pby = Y - ey;
+    const float t0 = (pax * mx + pay * my) / mm;
+    float dist, dsx, dsy, dex, dey; // dist2 and its derivatives
+    if (t0 <= 0.f) {
+      dist = pax * pax + pay * pay;
+      dsx = -2.f * pax; dsy = -2.f * pay; dex = 0.f; dey = 0.f;
+    } else if (t0 < 1.f) {
+      const float qx = X - (sx + t0 * mx), qy = Y - (sy + t0 * my);
+      dist = qx * qx + qy * qy;
+      // d dist2 = -2 q.dS - 2 t0 q.dm - 2 (q.m) dt0,  dt0 = (-m.dS + pa.dm) / mm - 2 t0 (m.dm) / mm,  dm = dE - dS
+      const float qm = (qx * mx + qy * my) / mm;
+      // coefficient vectors of dt0:  w.r.t. S: (-m - pa + 2 t0 m) / mm ; w.r.t. E: (pa - 2 t0 m) / mm   (the 1/mm is in qm)
+      const float cSx = -mx - pax + 2.f * t0 * mx, cSy = -my - pay + 2.f * t0 * my;
+      const float cEx = pax - 2.f * t0 * mx, cEy = pay - 2.f * t0 * my;
+      dsx = -2.f * qx + 2.f * t0 * qx - 2.f * qm * cSx;
+      dsy = -2.f * qy + 2.f * t0 * qy - 2.f * qm * cSy;
+      dex = -2.f * t0 * qx - 2.f * qm * cEx;
+      dey = -2.f * t0 * qy - 2.f * qm * cEy;
+    } else {
+      dist = pbx * pbx + pby * pby;
+      dsx = 0.f; dsy = 0.f; dex = -2.f * pbx; dey = -2.f * pby;
+    }
+    const float o = expf(-(dist * dist) * inv_s2);
+    const double k = (double)go * (double)(o * (-2.f * dist * inv_s2));
+    acc[0] += k * dsx; acc[1] += k * dsy; acc[2] += k * dex; acc[3] += k * dey;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    for (int off = 32; off >= 1; off >>= 1) acc[c] += __shfl_down(acc[c], off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0)
+    for (int c = 0; c < 4; ++c) s_part[wave][c] = acc[c];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0.0;
+    for (int w = 0; w < 16; ++w) v += s_part[w][threadIdx.x];
+    // chain through the scaling of the end points by the texture size (rasterization.py:122-123)
+    glines[4 * n + threadIdx.x] = (float)(v * (double)((threadIdx.x & 1) ? size1 : size0));
+  }
+}
+
 // =================================================================================== K2 fused forward
 // One workgroup per 32x8 texel tile.  Wave 0 culls the points against the tile (ballot +
 // prefix: the compacted list keeps ascending point order, so every texel accumulates in the
@@ -585,6 +647,14 @@ int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int s
   dim3 grid(ffx_cdiv((long)size0 * size1, SPLAT_BLOCK), n);
   hipLaunchKernelGGL(k_splat_lines_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, lines, sigma, size0, size1, out);
   FFX_CHECK_LAUNCH("splat_lines_fwd");
+  return FFX_OK;
+}
+
+int ffx_splat_lines_bwd(const float *lines, int n, float sigma, int size0, int size1, const float *gout, float *glines, ffx_stream s) {
+  if (n == 0) return FFX_OK;
+  if (!lines || !gout || !glines || n < 0 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f)) FFX_FAIL(FFX_ERR_ARG, "splat_lines_bwd: bad argument");
+  hipLaunchKernelGGL(k_splat_lines_bwd, dim3(n), dim3(1024), 0, (hipStream_t)s, lines, sigma, size0, size1, gout, glines);
+  FFX_CHECK_LAUNCH("splat_lines_bwd");
   return FFX_OK;
 }
 

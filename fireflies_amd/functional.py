@@ -56,6 +56,27 @@ def rasterize_points_dense(pts, sigma, size0, size1):
     return _RasterizePoints.apply(pts, float(sigma), int(size0), int(size1))
 
 
+class _RasterizeLines(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lines, sigma, size0, size1):
+        lines = _c(lines.float())
+        ctx.save_for_backward(lines)
+        ctx.args = (sigma, size0, size1)
+        return ops.splat_lines_fwd(lines, sigma, size0, size1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (lines,) = ctx.saved_tensors
+        sigma, size0, size1 = ctx.args
+        return ops.splat_lines_bwd(lines, sigma, size0, size1, _c(g.float())), None, None, None
+
+
+def rasterize_lines(lines, sigma, size0, size1):
+    """soft line segments [N,2,2] -> [N,size1,size0] (graphics/rasterization.py:107-153), differentiable in the
+    segments (the reference optimises them through it, :645-743)."""
+    return _RasterizeLines.apply(lines, float(sigma), int(size0), int(size1))
+
+
 class _Splat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, sigma, reduce, half_window, size0, size1):

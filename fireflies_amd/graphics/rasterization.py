@@ -113,10 +113,11 @@ def rasterize_depth(points, depth_vals, sigma: float, texture_size, device=None)
 
 
 def rasterize_lines(lines, sigma: float, texture_size, device=None):
-    """soft line segments [N,2,2] -> [N,size1,size0] (:107-153).  The reference scales its INPUT in
-    place (:122-123); this does not mutate the argument."""
+    """soft line segments [N,2,2] -> [N,size1,size0] (:107-153), differentiable w.r.t. the segments like the
+    reference's torch expression (its line-regularisation loop optimises them, :645-743).  The reference scales
+    its INPUT in place (:122-123); this does not mutate the argument."""
     s0, s1 = _size(texture_size)
-    return ops.splat_lines_fwd(lines.detach().contiguous().float(), float(sigma), s0, s1)
+    return Fn.rasterize_lines(lines, float(sigma), s0, s1)
 
 
 def subsampled_point_raster(ndc_points, num_subsamples, sigma, sensor_size):

@@ -6,7 +6,7 @@ SURVEY §8(f) f4: the reference loads its scenes with `mi.load_file("…/vocalfo
 module reads what those scene files contain so that `mi.load_file(path)` keeps working:
 
   <sensor type="perspective">   fov, near_clip, far_clip, <transform name="to_world">, <film> width/height
-  <shape type="obj"|"ply">       filename (OBJ only; PLY raises), optional to_world (baked into the vertices),
+  <shape type="obj"|"ply">       filename (Wavefront OBJ; Stanford PLY ascii / binary), optional to_world (baked into the vertices),
                                  nested or referenced <bsdf> (diffuse reflectance / principled base_color)
   <emitter type="spot">          intensity, cutoff_angle, beam_width, to_world
   <emitter type="projector">     irradiance texture (id "tex"), scale, fov, to_world
@@ -48,6 +48,123 @@ def load_obj(path):
     if t.size and (t.min() < 0 or t.max() >= v.shape[0]):
         raise ValueError(f"{path}: face index out of range")
     return v, t
+
+
+# ----------------------------------------------------------------------------- PLY
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4",
+              "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path):
+    """Stanford PLY (ascii, binary_little_endian, binary_big_endian) -> (vertices [V,3] float32, triangles [F,3]
+    int32).  Reads the `vertex` element's x/y/z and the `face` element's index list (vertex_indices /
+    vertex_index), fan-triangulating polygons; other elements and properties are skipped.  `Scene` classifies
+    parameter keys containing "ply" as meshes exactly like "mesh" (fireflies/scene.py:100), and Mitsuba scene
+    files reference PLY shapes as <shape type="ply">."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: unterminated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] == "comment" or tok[0] == "obj_info":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append({"name": tok[1], "count": int(tok[2]), "props": []})
+            elif tok[0] == "property":
+                if tok[1] == "list":
+                    elements[-1]["props"].append(("list", tok[2], tok[3], tok[4]))
+                else:
+                    elements[-1]["props"].append(("scalar", tok[1], tok[2]))
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt!r}")
+        verts, tris = None, []
+        if fmt == "ascii":
+            tokens = iter(f.read().split())
+
+            def scalar(t):
+                v = next(tokens)
+                return float(v) if _PLY_TYPES[t][0] == "f" else int(v)
+
+        else:
+            end = "<" if fmt == "binary_little_endian" else ">"
+
+            def scalar(t):
+                dt = np.dtype(end + _PLY_TYPES[t])
+                return np.frombuffer(f.read(dt.itemsize), dt)[0].item()
+
+        for el in elements:
+            names = [p[-1] for p in el["props"]]
+            all_scalar = all(p[0] == "scalar" for p in el["props"])
+            if el["name"] == "vertex":
+                if not {"x", "y", "z"} <= set(names):
+                    raise ValueError(f"{path}: vertex element without x/y/z")
+                if fmt != "ascii" and all_scalar:  # one structured read
+                    dt = np.dtype([(p[2], end + _PLY_TYPES[p[1]]) for p in el["props"]])
+                    raw = np.frombuffer(f.read(dt.itemsize * el["count"]), dt)
+                    verts = np.stack([raw["x"], raw["y"], raw["z"]], 1).astype(np.float32)
+                else:
+                    rows = np.empty((el["count"], 3), np.float32)
+                    for i in range(el["count"]):
+                        rec = {}
+                        for p in el["props"]:
+                            if p[0] == "scalar":
+                                rec[p[2]] = scalar(p[1])
+                            else:
+                                rec[p[3]] = [scalar(p[2]) for _ in range(int(scalar(p[1])))]
+                        rows[i] = (rec["x"], rec["y"], rec["z"])
+                    verts = rows
+            else:
+                for _ in range(el["count"]):
+                    for p in el["props"]:
+                        if p[0] == "scalar":
+                            scalar(p[1])
+                            continue
+                        idx = [int(scalar(p[2])) for _ in range(int(scalar(p[1])))]
+                        if el["name"] == "face" and p[3] in ("vertex_indices", "vertex_index"):
+                            for k in range(1, len(idx) - 1):
+                                tris.append((idx[0], idx[k], idx[k + 1]))
+    if verts is None:
+        raise ValueError(f"{path}: no vertex element")
+    t = np.asarray(tris, np.int32).reshape(-1, 3)
+    if t.size and (t.min() < 0 or t.max() >= verts.shape[0]):
+        raise ValueError(f"{path}: face index out of range")
+    return verts, t
+
+
+def save_ply(path, verts, tris, binary=True):
+    verts, tris = np.asarray(verts, np.float32), np.asarray(tris, np.int32)
+    head = (f"ply\nformat {'binary_little_endian' if binary else 'ascii'} 1.0\nelement vertex {len(verts)}\nproperty float x\nproperty float y\n"
+            f"property float z\nelement face {len(tris)}\nproperty list uchar int vertex_indices\nend_header\n")
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii"))
+        if binary:
+            f.write(verts.astype("<f4").tobytes())
+            rec = np.empty(len(tris), np.dtype([("n", "u1"), ("i", "<i4", 3)]))
+            rec["n"], rec["i"] = 3, tris
+            f.write(rec.tobytes())
+        else:
+            for v in verts:
+                f.write(f"{v[0]:.9g} {v[1]:.9g} {v[2]:.9g}\n".encode())
+            for t in tris:
+                f.write(f"3 {t[0]} {t[1]} {t[2]}\n".encode())
+
+
+def load_mesh_file(path):
+    """OBJ or PLY by extension"""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".ply":
+        return load_ply(path)
+    if ext == ".obj":
+        return load_obj(path)
+    raise NotImplementedError(f"{path}: only .obj and .ply meshes are read")
 
 
 def save_obj(path, verts, tris):
@@ -176,10 +293,10 @@ def load_mitsuba_xml(path):
             sensors.append(scenes.SensorData(name, _transform(_child(node, "transform", "to_world")), float(p.get("fov", 45.0)), float(p.get("near_clip", 0.01)),
                                              float(p.get("far_clip", 1e4)), int(fp.get("width", 768)), int(fp.get("height", 576))))
         elif node.tag == "shape":
-            if node.get("type") != "obj":
-                raise NotImplementedError(f"shape type {node.get('type')!r}: only OBJ meshes are read")
+            if node.get("type") not in ("obj", "ply"):
+                raise NotImplementedError(f"shape type {node.get('type')!r}: only OBJ and PLY meshes are read")
             p = _props(node)
-            v, t = load_obj(os.path.join(base, p["filename"]))
+            v, t = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]))
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
             alb, mat = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)

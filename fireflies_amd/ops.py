@@ -137,6 +137,14 @@ def splat_lines_fwd(lines, sigma, size0, size1):
     return out
 
 
+def splat_lines_bwd(lines, sigma, size0, size1, gout):
+    if tuple(gout.shape) != (lines.shape[0], size1, size0):
+        raise ValueError("gout shape mismatch")
+    out = torch.empty_like(lines)
+    api().call("ffx_splat_lines_bwd", _dev(lines, name="lines"), lines.shape[0], float(sigma), size0, size1, _dev(gout, name="gout"), _dev(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ K3
 def blur_fwd(img, ksize=5, sigma=3.0):
     if img.dim() != 2:

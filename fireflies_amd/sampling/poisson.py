@@ -1,53 +1,90 @@
 """Bridson Poisson-disk sampling with a spatially varying radius (host, numpy).
 
-Counterpart of fireflies/sampling/poisson.py (`bridson(sampling_map)` -> (count, samples)), used
-only to initialise a blue-noise pattern (projection/laser.py:95-145).  Sequential by nature and
-off the hot path; the sample set depends on the RNG, so there is no golden vector for it — tests
-check the defining property (pairwise distance >= local radius) instead.
+Counterpart of fireflies/sampling/poisson.py:16-116 (`bridson(radius_map)` -> (count, samples)), used only to
+initialise a blue-noise pattern (projection/laser.py:95-145).  Sequential by nature and off the hot path.
+
+The sample set is defined by the random draws, so this follows the reference's draw ORDER and its acceptance
+rule exactly, and by default draws from the same GLOBAL numpy generator (`np.random.seed(s)` reproduces the
+reference's samples: tests/golden/g11_bridson.npz):
+  * first point: two uniforms, (u0 * rows, u1 * cols); the map is indexed [row = coords[0], col = coords[1]];
+  * per round: `randint(len(active))` picks an active point; then k candidates, each consuming a radius draw
+    (uniform in [r, 2r) for "default", normal(1.5 r, 0.2 r) for "normDist") and an angle draw, placed at
+    (+ r sin a, + r cos a); EVERY accepted candidate of the k is kept (the reference does not stop at the first),
+    and the active point is retired only when none of its k candidates was accepted;
+  * acceptance is on the INTEGER occupancy grid (one cell per map entry): a candidate is rejected if any cell in
+    the square of half-width ceil(radius there) around its cell holds a sample — not a Euclidean test.
 """
 import numpy as np
 
 
-def bridson(sampling_map, k: int = 30, rng=None):
-    """sampling_map[x, y] = minimum distance wanted around (x, y).  Returns (n, [[x, y], ...])."""
-    rng = np.random.default_rng() if rng is None else rng
-    W, H = sampling_map.shape
-    rmin = float(sampling_map.min())
-    cell = rmin / np.sqrt(2.0)
-    gw, gh = int(np.ceil(W / cell)), int(np.ceil(H / cell))
-    grid = -np.ones((gw, gh), np.int64)
-    pts = []
+class _GlobalNumpy:
+    """the module-level numpy generator, with the three draws the algorithm needs"""
 
-    def radius(p):
-        return float(sampling_map[min(int(p[0]), W - 1), min(int(p[1]), H - 1)])
+    @staticmethod
+    def random():
+        return np.random.random()
 
-    def fits(p):
-        r = radius(p)
-        reach = int(np.ceil(r / cell))
-        gx, gy = int(p[0] / cell), int(p[1] / cell)
-        for ix in range(max(gx - reach, 0), min(gx + reach + 1, gw)):
-            for iy in range(max(gy - reach, 0), min(gy + reach + 1, gh)):
-                j = grid[ix, iy]
-                if j >= 0 and np.hypot(*(pts[j] - p)) < r:
-                    return False
-        return True
+    @staticmethod
+    def randint(n):
+        return np.random.randint(n)
 
-    first = np.array([rng.uniform(0, W), rng.uniform(0, H)])
-    pts.append(first)
-    grid[int(first[0] / cell), int(first[1] / cell)] = 0
-    active = [0]
+    @staticmethod
+    def normal(mu, sd):
+        return np.random.normal(mu, sd)
+
+
+class _FromGenerator:
+    def __init__(self, g):
+        self.g = g
+
+    def random(self):
+        return self.g.random()
+
+    def randint(self, n):
+        return int(self.g.integers(n))
+
+    def normal(self, mu, sd):
+        return self.g.normal(mu, sd)
+
+
+def bridson(radius, k: int = 30, radiusType: str = "default", rng=None):
+    """radius[row, col] = minimum spacing wanted around that cell.  Returns (n, array [n, 2] of (row, col) positions).
+    `rng`: None = numpy's global generator (like the reference), or a numpy Generator."""
+    if radiusType not in ("default", "normDist"):
+        raise ValueError(f"unknown radiusType {radiusType!r}")
+    draw = _GlobalNumpy if rng is None else _FromGenerator(rng)
+    radius = np.asarray(radius, dtype=np.float64)
+    rows, cols = radius.shape
+    occupied = np.zeros((rows, cols), dtype=bool)
+
+    def cell(p):
+        return int(np.floor(p[0])), int(np.floor(p[1]))
+
+    first = (draw.random() * rows, draw.random() * cols)
+    occupied[cell(first)] = True
+    samples = [np.asarray(first, np.float64)]
+    active = [samples[0]]
     while active:
-        i = active[rng.integers(len(active))]
-        base, r = pts[i], radius(pts[i])
+        pick = draw.randint(len(active))
+        base = active[pick]
+        r_here = radius[cell(base)]
+        accepted_any = False
         for _ in range(k):
-            ang, rad = rng.uniform(0, 2 * np.pi), rng.uniform(r, 2 * r)
-            q = base + rad * np.array([np.cos(ang), np.sin(ang)])
-            if not (0 <= q[0] < W and 0 <= q[1] < H) or not fits(q):
+            dist = r_here * (draw.random() + 1.0) if radiusType == "default" else r_here * draw.normal(1.5, 0.2)
+            ang = 2.0 * np.pi * draw.random()
+            cand = np.array([base[0] + dist * np.sin(ang), base[1] + dist * np.cos(ang)])
+            if not (0.0 <= cand[0] <= rows and 0.0 <= cand[1] <= cols):
                 continue
-            pts.append(q)
-            grid[int(q[0] / cell), int(q[1] / cell)] = len(pts) - 1
-            active.append(len(pts) - 1)
-            break
-        else:
-            active.remove(i)
-    return len(pts), [p.tolist() for p in pts]
+            cr, cc = cell(cand)
+            if cr >= rows or cc >= cols:  # exactly on the far border (the reference raises an IndexError there)
+                continue
+            reach = int(np.ceil(radius[cr, cc]))
+            if occupied[max(cr - reach, 0) : min(cr + reach + 1, rows), max(cc - reach, 0) : min(cc + reach + 1, cols)].any():
+                continue
+            occupied[cr, cc] = True
+            samples.append(cand)
+            active.append(cand)
+            accepted_any = True
+        if not accepted_any:
+            del active[pick]
+    return len(samples), np.asarray(samples)

@@ -123,6 +123,13 @@ int ffx_splat_depth_fwd(const float *pts /*[dev][n,2]*/, const float *depth /*[d
  * self-consistent for size0 == size1; other sizes follow its broadcasting). */
 int ffx_splat_lines_fwd(const float *lines /*[dev][n,2,2]*/, int n, float sigma, int size0,
                         int size1, float *out /*[dev][n,size1,size0]*/, ffx_stream stream);
+/* autograd of rasterize_lines w.r.t. the segments for an upstream gradient on the layers (the reference
+ * optimises segments through it: rasterization.py:645-743).  The three branches of the distance (before the
+ * start, along the segment, past the end; :147-151) are differentiated where they are selected; inside the
+ * segment the derivative of the projection parameter t0 is included, as torch.autograd does. */
+int ffx_splat_lines_bwd(const float *lines /*[dev][n,2,2]*/, int n, float sigma, int size0, int size1,
+                        const float *gout /*[dev][n,size1,size0]*/, float *glines /*[dev][n,2,2]*/,
+                        ffx_stream stream);
 
 /* Overlap regulariser of the reference's point-pattern loop, L1Loss(softor, sum)
  * (fireflies/graphics/rasterization.py:579,589-600), with its gradient:

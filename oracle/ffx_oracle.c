@@ -431,6 +431,56 @@ int ffx_splat_lines_fwd(const float *lines, int n, float sigma, int size0, int s
   return FFX_OK;
 }
 
+/* autograd of rasterize_lines w.r.t. the segments (the loop at rasterization.py:645-743 optimises them through
+ * it): per texel g * d out / d dist2 * d dist2 / d (start, end), out = exp(-dist2^2 / sigma^2); the branch masks
+ * (:147-149) are constants, inside the segment d t0 is included as autograd does.  Sums in double. */
+int ffx_splat_lines_bwd(const float *lines, int n, float sigma, int size0, int size1, const float *gout, float *glines, ffx_stream s) {
+  (void)s;
+  if (n == 0) return FFX_OK;
+  if (!lines || !gout || !glines || n < 0 || size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "splat_lines_bwd: bad argument");
+  const float eps = 1.1920928955078125e-07f;
+  const float inv_s2 = 1.0f / (sigma * sigma);
+  for (int k = 0; k < n; ++k) {
+    float sx = lines[4 * k + 0] * (float)size0, sy = lines[4 * k + 1] * (float)size1;
+    float ex = lines[4 * k + 2] * (float)size0, ey = lines[4 * k + 3] * (float)size1;
+    float mx = ex - sx, my = ey - sy;
+    float mm = mx * mx + my * my + eps;
+    const float *g = gout + (size_t)k * size1 * size0;
+    double acc[4] = {0, 0, 0, 0};
+    for (int a = 0; a < size1; ++a)
+      for (int b = 0; b < size0; ++b) {
+        float go = g[(size_t)a * size0 + b];
+        if (go == 0.f) continue;
+        float X = (float)b, Y = (float)a;
+        float pax = X - sx, pay = Y - sy, pbx = X - ex, pby = Y - ey;
+        float t0 = (pax * mx + pay * my) / mm;
+        float dist, dsx, dsy, dex, dey;
+        if (t0 <= 0.f) {
+          dist = pax * pax + pay * pay;
+          dsx = -2.f * pax; dsy = -2.f * pay; dex = 0.f; dey = 0.f;
+        } else if (t0 < 1.f) {
+          float qx = X - (sx + t0 * mx), qy = Y - (sy + t0 * my);
+          dist = qx * qx + qy * qy;
+          float qm = (qx * mx + qy * my) / mm;
+          float cSx = -mx - pax + 2.f * t0 * mx, cSy = -my - pay + 2.f * t0 * my;
+          float cEx = pax - 2.f * t0 * mx, cEy = pay - 2.f * t0 * my;
+          dsx = -2.f * qx + 2.f * t0 * qx - 2.f * qm * cSx;
+          dsy = -2.f * qy + 2.f * t0 * qy - 2.f * qm * cSy;
+          dex = -2.f * t0 * qx - 2.f * qm * cEx;
+          dey = -2.f * t0 * qy - 2.f * qm * cEy;
+        } else {
+          dist = pbx * pbx + pby * pby;
+          dsx = 0.f; dsy = 0.f; dex = -2.f * pbx; dey = -2.f * pby;
+        }
+        float o = expf(-(dist * dist) * inv_s2);
+        double kk = (double)go * (double)(o * (-2.f * dist * inv_s2));
+        acc[0] += kk * dsx; acc[1] += kk * dsy; acc[2] += kk * dex; acc[3] += kk * dey;
+      }
+    for (int c = 0; c < 4; ++c) glines[4 * k + c] = (float)(acc[c] * (double)((c & 1) ? size1 : size0));
+  }
+  return FFX_OK;
+}
+
 /* =========================================================================================
  * K3  gaussian_blur2d with reflect border [EXT kornia 0.7.1, call site
  * examples/vocalfold_scene.py:61-63].  Kernel: g[k] = exp(-(k - r)^2 / (2 s^2)), normalised

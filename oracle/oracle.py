@@ -132,6 +132,13 @@ def splat_lines_fwd(lines, sigma, size0, size1):
 
 
 # ---------------------------------------------------------------- K3
+def splat_lines_bwd(lines, sigma, size0, size1, gout):
+    lines, gout = _f32(lines), _f32(gout)
+    out = np.empty_like(lines)
+    api().call("ffx_splat_lines_bwd", _p(lines), lines.shape[0], sigma, size0, size1, _p(gout), _p(out), None)
+    return out
+
+
 def blur_fwd(img, ksize=5, sigma=3.0):
     img = _f32(img)
     out = np.empty_like(img)

@@ -281,18 +281,63 @@ def test_mi_conventions():
     assert isinstance(type(mi.Float(2.0))(3.5), mi.Float) and len(mi.Color3f([1, 2, 3])) == 3
 
 
-def test_bridson_poisson_disk_property():
+def test_bridson_matches_the_reference_draw_for_draw():
+    """sampling/poisson.py:16-116 draws from numpy's GLOBAL generator; under the same np.random.seed the
+    samples are the reference's (tests/golden/g11_bridson.npz, oracle/gen_golden_r2.py): constant and
+    spatially varying radius, k, the normal-distributed radius type, and generate_blue_noise_rays on top."""
     from fireflies_amd.sampling import poisson
 
+    g = load_golden("g11_bridson.npz")
+    for tag in ("const", "small"):
+        np.random.seed(int(g[f"{tag}_seed"]))
+        n, pts = poisson.bridson(np.ones(tuple(g[f"{tag}_shape"])) * float(g[f"{tag}_radius"]))
+        assert n == int(g[f"{tag}_n"])
+        np.testing.assert_array_equal(pts, g[f"{tag}_pts"])
+    np.random.seed(13)
+    n, pts = poisson.bridson(g["vary_map"], k=12)
+    assert n == int(g["vary_n"])
+    np.testing.assert_array_equal(pts, g["vary_pts"])
+    np.random.seed(14)
+    n, pts = poisson.bridson(np.ones((30, 30)) * 4.0, k=20, radiusType="normDist")
+    assert n == int(g["norm_n"])
+    np.testing.assert_array_equal(pts, g["norm_pts"])
+    np.random.seed(21)
+    rays = ff.projection.Laser.generate_blue_noise_rays(32, 24, 16, torch.from_numpy(g["bn_K"]), device=CPU)
+    np.testing.assert_allclose(rays.numpy(), g["bn_rays"], rtol=1e-6, atol=2e-7)
+    # the defining property of the reference's acceptance rule: no two samples within the square of
+    # half-width ceil(r) cells (so their Euclidean distance exceeds ceil(r) - 1)
     rng = np.random.default_rng(0)
     n, pts = poisson.bridson(np.ones((60, 40)) * 6.0, rng=rng)
-    pts = np.asarray(pts)
     assert n == len(pts) > 20
-    d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 1e9
-    assert d.min() >= 6.0 - 1e-9
-    assert (pts[:, 0] >= 0).all() and (pts[:, 0] < 60).all() and (pts[:, 1] < 40).all()
+    cells = np.floor(pts).astype(int)
+    cheb = np.abs(cells[:, None] - cells[None]).max(-1) + np.eye(n, dtype=int) * 10**6
+    assert cheb.min() > 6
+    assert (pts[:, 0] >= 0).all() and (pts[:, 0] <= 60).all() and (pts[:, 1] <= 40).all()
     rays = ff.projection.Laser.generate_blue_noise_rays(100, 100, 16, torch.from_numpy(scenes.perspective_projection(100, 100, 30.0, 0.01, 100.0)), device=CPU)
     assert rays.shape[1] == 3 and (rays[:, 2] < 0).all() and (rays.norm(dim=1) - 1).abs().max() < 1e-5
+
+
+def test_laser_world_space_accessors_have_the_intended_values():
+    """Laser.rays / origin / originPerRay raise AttributeError at the reference's HEAD (laser.py:163-177 read a
+    non-existent attribute); the intended semantics — directions through transform_directions(_rays, world),
+    origin = the projector's world matrix / its translation — are pinned here against utils.math (golden g6)."""
+    tr = ff.entity.Transformable("projector", CPU)
+    world = torch.tensor([[0.0, 0.0, 1.0, 0.3], [0.0, 1.0, 0.0, -0.2], [-1.0, 0.0, 0.0, 1.5], [0.0, 0.0, 0.0, 1.0]])
+    tr.set_world(world)
+    K = torch.from_numpy(scenes.perspective_projection(500, 500, 30.0, 0.01, 100.0))
+    rays = ff.projection.Laser.generate_uniform_rays(0.05, 3, 3, device=CPU)
+    laser = ff.projection.Laser(tr, rays, K, 30.0, 0.01, 100.0, device=CPU)
+    got = laser.rays()
+    np.testing.assert_allclose(got.numpy(), (rays @ world[:3, :3].T).numpy(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(got, ff.utils.math.transform_directions(rays, world))
+    np.testing.assert_allclose(laser.origin().numpy(), world.numpy())
+    op = laser.originPerRay()
+    assert op.shape == rays.shape
+    np.testing.assert_allclose(op.numpy(), np.tile(world[:3, 3].numpy(), (9, 1)))
+    # the central ray (0, 0, -1) of the local frame maps to -(third column of the rotation)
+    np.testing.assert_allclose(got[4].numpy(), -world[:3, 2].numpy(), atol=1e-6)
+    laser.setToWorld(torch.eye(4))
+    np.testing.assert_allclose(laser.rays().numpy(), rays.numpy(), atol=1e-7)
 
 
 def test_laser_static_generators_and_yaml(tmp_path):

@@ -100,6 +100,22 @@ def test_rasterization_api_matches_reference():
     lo = R.rasterize_lines(lines, 3.0, torch.tensor(g5["lines_size"]))
     np.testing.assert_allclose(lo.cpu().numpy(), g5["lines_out"], rtol=1e-5, atol=1e-6)
     assert torch.equal(lines, keep)  # the reference scales its argument in place; this does not
+    # rasterize_lines is differentiable like the reference's torch expression (golden g10 = its autograd)
+    g10 = load_golden("g10_lines_grad.npz")
+    leaf = dev(g10["b_lines"]).requires_grad_(True)
+    lo = R.rasterize_lines(leaf * 1.0, float(g10["b_sigma"]), torch.tensor(g10["b_size"]))
+    (lo * dev(g10["b_w"])).sum().backward()
+    ref = g10["b_glines"]
+    np.testing.assert_allclose(leaf.grad.cpu().numpy(), ref, rtol=1e-4, atol=3e-6 * np.abs(ref).max())
+    # the reference's line-regularisation loss L1(softor, sum) drives the segments apart (rasterization.py:676-691)
+    loc = (torch.rand(12, 2, device=DEV) - 0.5) * 0.2 + 0.5
+    loc.requires_grad_(True)
+    d = torch.tensor([[0.6, 0.8]], device=DEV) * 0.1
+    segs = torch.stack([loc + d, loc - d], dim=1)
+    rl = R.rasterize_lines(segs, 10.0, torch.tensor([64, 64]))
+    loss = torch.nn.functional.l1_loss(R.softor(rl), rl.sum(dim=0))
+    loss.backward()
+    assert loc.grad is not None and torch.isfinite(loc.grad).all() and float(loc.grad.abs().sum()) > 0
     sub = R.subsampled_point_raster(dev(g5["depth_pts"]), 3, 6.0, torch.tensor([32, 32]))
     for i in range(3):
         np.testing.assert_allclose(sub[i].cpu().numpy(), g5[f"subsampled_{i}"], rtol=1e-5, atol=2e-6)

@@ -166,6 +166,21 @@ def test_k2_depth_and_lines(oracle):
     l0, l1 = [int(v) for v in g["lines_size"]]
     out = host(ops.splat_lines_fwd(dev(g["lines_in"]), 3.0, l0, l1))
     np.testing.assert_allclose(out, g["lines_out"], rtol=1e-5, atol=1e-6)
+    # gradient w.r.t. the segments: the reference's autograd (golden g10) and the oracle
+    g10 = load_golden("g10_lines_grad.npz")
+    for t in "abc":
+        s0, s1 = [int(v) for v in g10[f"{t}_size"]]
+        sigma = float(g10[f"{t}_sigma"])
+        gl = host(ops.splat_lines_bwd(dev(g10[f"{t}_lines"]), sigma, s0, s1, dev(g10[f"{t}_w"])))
+        ref = g10[f"{t}_glines"]
+        np.testing.assert_allclose(gl, ref, rtol=1e-4, atol=3e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(gl, oracle.splat_lines_bwd(g10[f"{t}_lines"], sigma, s0, s1, g10[f"{t}_w"]), rtol=2e-5, atol=1e-6 * np.abs(ref).max())
+    rng = np.random.default_rng(3)  # a non-square film and many segments
+    lines = (rng.random((37, 2, 2)) * 1.2 - 0.1).astype(np.float32)
+    w = rng.standard_normal((37, 40, 56)).astype(np.float32)
+    gl = host(ops.splat_lines_bwd(dev(lines), 25.0, 56, 40, dev(w)))
+    ref = oracle.splat_lines_bwd(lines, 25.0, 56, 40, w)
+    np.testing.assert_allclose(gl, ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max())
 
 
 # ------------------------------------------------------------------ K3

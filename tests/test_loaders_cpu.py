@@ -88,3 +88,44 @@ def test_mitsuba_xml_subset(tmp_path):
 
     M = loaders._transform(ET.fromstring('<transform><rotate y="1" angle="90"/></transform>'))
     np.testing.assert_allclose(M[:3, :3] @ np.array([1.0, 0, 0]), [0, 0, -1], atol=1e-6)
+
+
+def test_ply_ascii_binary_and_polygons(tmp_path):
+    """PLY meshes (Scene classifies "ply" keys as meshes like the reference, fireflies/scene.py:100; Mitsuba scene
+    files reference them as <shape type="ply">): ascii and both binary byte orders, extra vertex properties,
+    polygon faces, a leading element that is neither vertex nor face."""
+    v, t = scenes.make_uv_sphere((0.1, -0.2, 0.3), 0.7, 10, 6)
+    for binary in (True, False):
+        f = tmp_path / f"s{int(binary)}.ply"
+        loaders.save_ply(f, v, t, binary=binary)
+        v2, t2 = loaders.load_ply(f)
+        np.testing.assert_allclose(v2, v, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(t2, t)
+        v3, t3 = loaders.load_mesh_file(str(f))
+        assert v3.shape == v.shape and t3.shape == t.shape
+    # hand-written ascii file: normals + colours on the vertices, a quad and a pentagon, a comment, another element first
+    (tmp_path / "q.ply").write_text(
+        "ply\nformat ascii 1.0\ncomment made by hand\nelement material 1\nproperty float shininess\nelement vertex 5\nproperty float x\nproperty float y\n"
+        "property float z\nproperty float nx\nproperty uchar red\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n"
+        "0.5\n0 0 0 0 255\n1 0 0 0 255\n1 1 0 0 255\n0 1 0 0 255\n0.5 1.5 0 0 255\n4 0 1 2 3\n5 0 1 2 4 3\n")
+    vq, tq = loaders.load_ply(tmp_path / "q.ply")
+    assert vq.shape == (5, 3) and tq.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 4], [0, 4, 3]]
+    # big-endian binary with double coordinates and ushort indices
+    import struct
+
+    head = b"ply\nformat binary_big_endian 1.0\nelement vertex 3\nproperty double x\nproperty double y\nproperty double z\nelement face 1\nproperty list uchar ushort vertex_index\nend_header\n"
+    body = b"".join(struct.pack(">ddd", *p) for p in ((0, 0, 0), (1, 0, 0), (0, 2, 0))) + struct.pack(">BHHH", 3, 0, 1, 2)
+    (tmp_path / "b.ply").write_bytes(head + body)
+    vb, tb = loaders.load_ply(tmp_path / "b.ply")
+    np.testing.assert_allclose(vb, [[0, 0, 0], [1, 0, 0], [0, 2, 0]])
+    assert tb.tolist() == [[0, 1, 2]]
+    (tmp_path / "bad.ply").write_text("plx\n")
+    with pytest.raises(ValueError):
+        loaders.load_ply(tmp_path / "bad.ply")
+    # a PLY shape inside a scene file
+    wv, wt = scenes.make_plane(0.0, 1.0, 4, 4)
+    loaders.save_ply(tmp_path / "wall.ply", wv, wt)
+    loaders.save_obj(tmp_path / "quad.obj", *scenes.make_uv_sphere((0.1, 0.05, 4.0), 0.35, 8, 4))
+    (tmp_path / "scene.xml").write_text(XML.replace('<shape type="obj" id="mesh-Wall">', '<shape type="ply" id="mesh-Wall">').replace("wall.obj", "wall.ply"))
+    sc = loaders.load_mitsuba_xml(str(tmp_path / "scene.xml"))
+    assert sc.meshes[0].name == "mesh-Wall" and sc.meshes[0].tris.shape[0] == wt.shape[0]
