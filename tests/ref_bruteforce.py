@@ -1,0 +1,218 @@
+"""Independent brute-force restatement of K7 / K8 / K9 — TEST INFRASTRUCTURE, float64 numpy.
+
+Purpose: the oracle for the Mitsuba half of the path (oracle/ffx_oracle.c) and the HIP
+kernels were written together "in the same operation order", so a shared conceptual error would be invisible to
+every HIP-vs-oracle test.  This module was written from the *published conventions* (SURVEY.md Appendix A,
+DESIGN.md §4) and NOT from ffx_oracle.c: no BVH (every ray against every triangle), the textbook
+Moller-Trumbore test with the ray's own origin (not the apex form), float64 throughout, numpy broadcasting
+instead of loops.  tests/test_bruteforce_cpu.py compares it with the oracle on small scenes: depth, ids,
+radiance and the texture gradient.
+
+What is restated (each with the convention it comes from):
+  * sensor rays [SURVEY App. A `sensor.sample_ray`]: sample position ((x + jx)/W, (y + jy)/H), no half-pixel
+    offset (fireflies/graphics/depth.py:61-69); near-plane point = camera_to_sample^-1 (sx, sy, 0); direction =
+    to_world * normalize(that point); origin = camera position; valid range (near / d_z, far / d_z], reported t
+    measured from the near plane.
+  * jitter: the counter-based hash of DESIGN.md §4.2 (this is OUR definition; it has to be shared for a
+    per-pixel comparison to be possible at all).
+  * closest hit with ties broken by the smaller primitive id.
+  * shading [SURVEY §7.3 / DESIGN §4.3]: direct light at the primary hit, geometric normal faced to the viewer,
+    Lambert; projector = perspective frustum with a bilinear, clamp-to-edge irradiance texture, radiance
+    albedo * tex(uv) * scale / (z_local^2 cos_p) * cos_s inside uv in [0,1]^2; spot = albedo / pi * I * falloff / d^2
+    * cos_s with falloff 1 inside beam_width and linear in the ANGLE down to 0 at the cutoff; shadow rays from
+    the emitter to the surface point lifted by (1 + max|P|) * 1500 * 2^-24 along the normal, occluded by any hit at
+    0 < t < 1 - 10 * 1500 * 2^-24; box reconstruction filter (plain mean over the samples).
+  * adjoint: the render is linear in the texture, so d loss / d tex scatters gimg * albedo * colour * geometric
+    factor / spp through the four bilinear weights.
+"""
+import numpy as np
+
+EPS = 1500.0 * 2.0**-24
+
+
+def _m(x, n):
+    return np.asarray(list(x), np.float64).reshape(n, n)
+
+
+def _hash32(x):
+    x = np.asarray(x, np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def jitter(seed, idx):
+    key = _hash32(np.uint64((seed + 0x9E3779B9) & 0xFFFFFFFF))
+    a = _hash32(((2 * idx) & 0xFFFFFFFF) ^ key)
+    b = _hash32(((2 * idx + 1) & 0xFFFFFFFF) ^ key)
+    return (a >> 8).astype(np.float64) / 16777216.0, (b >> 8).astype(np.float64) / 16777216.0
+
+
+def camera_rays(cam, spp, use_jitter, seed):
+    W, H = cam.width, cam.height
+    idx = np.arange(W * H * spp, dtype=np.uint64)
+    pix = idx // spp
+    x, y = (pix % W).astype(np.float64), (pix // W).astype(np.float64)
+    jx, jy = jitter(seed, idx) if use_jitter else (0.0, 0.0)
+    sx, sy = (x + jx) / W, (y + jy) / H
+    s2c = np.linalg.inv(_m(cam.camera_to_sample, 4))
+    q = np.stack([sx, sy, np.zeros_like(sx), np.ones_like(sx)], 1) @ s2c.T
+    near_p = q[:, :3] / q[:, 3:4]
+    dl = near_p / np.linalg.norm(near_p, axis=1, keepdims=True)
+    tw = _m(cam.to_world, 4)
+    d = dl @ tw[:3, :3].T
+    o = np.broadcast_to(tw[:3, 3], d.shape)
+    return o, d, cam.near_clip / dl[:, 2], cam.far_clip / dl[:, 2]
+
+
+def intersect(o, d, tris, tmin, tmax, chunk=4096):
+    """every ray against every triangle (v0, e1, e2 of shape [F,3]); closest hit in (tmin, tmax], ties -> smaller id.
+    Returns t (inf on a miss) and the primitive id (-1)."""
+    v0, e1, e2 = tris
+    n = o.shape[0]
+    t_best = np.full(n, np.inf)
+    prim = np.full(n, -1, np.int64)
+    for a in range(0, n, chunk):
+        oo, dd = o[a : a + chunk, None, :], d[a : a + chunk, None, :]
+        pv = np.cross(dd, e2[None])
+        det = (e1[None] * pv).sum(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = oo - v0[None]
+            u = (tv * pv).sum(-1) * inv
+            qv = np.cross(tv, e1[None])
+            v = (dd * qv).sum(-1) * inv
+            t = (e2[None] * qv).sum(-1) * inv
+        ok = (det != 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > np.asarray(tmin)[a : a + chunk, None]) & (t <= np.asarray(tmax)[a : a + chunk, None])
+        t = np.where(ok, t, np.inf)
+        tm = t.min(1)
+        first = np.argmax(t == tm[:, None], axis=1)  # smallest primitive id among equal distances
+        hit = np.isfinite(tm)
+        t_best[a : a + chunk] = tm
+        prim[a : a + chunk] = np.where(hit, first, -1)
+    return t_best, prim
+
+
+def any_hit(o, d, tris, tmax, chunk=4096):
+    t, _ = intersect(o, d, tris, np.zeros(o.shape[0]), np.full(o.shape[0], np.nextafter(tmax, 0.0)), chunk)
+    return np.isfinite(t)
+
+
+def world_triangles(verts, tri_idx):
+    p = np.asarray(verts, np.float64)[np.asarray(tri_idx)]
+    return p[:, 0], p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+
+
+def trace_primary(verts, tri_idx, tri_shape, cam, spp, use_jitter, seed):
+    tris = world_triangles(verts, tri_idx)
+    o, d, nt, ft = camera_rays(cam, spp, use_jitter, seed)
+    t, prim = intersect(o, d, tris, nt, ft)
+    hit = prim >= 0
+    return np.where(hit, t - nt, 0.0), np.where(hit, np.asarray(tri_shape)[np.maximum(prim, 0)], -1), prim
+
+
+def _bilinear_setup(u, v, tw, th):
+    fx, fy = u * tw - 0.5, v * th - 0.5
+    x0, y0 = np.floor(fx), np.floor(fy)
+    ax, ay = fx - x0, fy - y0
+    xi0, xi1 = np.clip(x0, 0, tw - 1).astype(int), np.clip(x0 + 1, 0, tw - 1).astype(int)
+    yi0, yi1 = np.clip(y0, 0, th - 1).astype(int), np.clip(y0 + 1, 0, th - 1).astype(int)
+    return (xi0, xi1, yi0, yi1), ((1 - ay) * (1 - ax), (1 - ay) * ax, ay * (1 - ax), ay * ax)
+
+
+def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed):
+    """per sample: hit mask, shape id, projector taps / weights / factor, spot radiance (before albedo)"""
+    tris = world_triangles(verts, tri_idx)
+    v0, e1, e2 = tris
+    o, d, nt, ft = camera_rays(sd.cam, spp, True, seed)
+    t, prim = intersect(o, d, tris, nt, ft)
+    hit = prim >= 0
+    pr = np.maximum(prim, 0)
+    P = o + np.where(hit, t, 0.0)[:, None] * d
+    n = np.cross(e1[pr], e2[pr])
+    nl = np.linalg.norm(n, axis=1, keepdims=True)
+    ok = hit & (nl[:, 0] > 0)
+    n = n / np.where(nl > 0, nl, 1.0)
+    n = np.where(((n * d).sum(1) > 0)[:, None], -n, n)
+    Po = P + n * ((1.0 + np.abs(P).max(1)) * EPS)[:, None]
+    shape = np.where(hit, np.asarray(tri_shape)[pr], -1)
+    out = {"hit": hit, "shape": shape, "pfac": np.zeros(len(P)), "taps": None, "w": None, "spot": np.zeros((len(P), 3))}
+    if sd.proj.enabled:
+        tw = _m(sd.proj.to_world, 4)
+        w2l = np.linalg.inv(tw)
+        pl = P @ w2l[:3, :3].T + w2l[:3, 3]
+        Kp = _m(sd.proj.camera_to_sample, 4)
+        q = np.concatenate([pl, np.ones((len(pl), 1))], 1) @ Kp.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u, v = q[:, 0] / q[:, 3], q[:, 1] / q[:, 3]
+        ppos, axis = tw[:3, 3], tw[:3, 2]
+        wi = ppos - P
+        dist = np.linalg.norm(wi, axis=1)
+        wi = wi / np.where(dist > 0, dist, 1.0)[:, None]
+        cos_s, cos_p = (n * wi).sum(1), -(wi @ axis)
+        lit = ok & (pl[:, 2] > 0) & (u >= 0) & (u <= 1) & (v >= 0) & (v <= 1) & (cos_s > 0) & (cos_p > 0)
+        if sd.shadows and lit.any():
+            sel = np.where(lit)[0]
+            occ = any_hit(np.broadcast_to(ppos, (len(sel), 3)), Po[sel] - ppos, tris, 1.0 - 10.0 * EPS)
+            lit[sel[occ]] = False
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fac = sd.proj.scale / (pl[:, 2] ** 2 * cos_p) * cos_s
+        out["pfac"] = np.where(lit, fac, 0.0)
+        out["taps"], out["w"] = _bilinear_setup(np.where(lit, u, 0.5), np.where(lit, v, 0.5), sd.proj.tex_w, sd.proj.tex_h)
+    if sd.spot.enabled:
+        tw = _m(sd.spot.to_world, 4)
+        spos = tw[:3, 3]
+        wi = spos - P
+        d2 = (wi * wi).sum(1)
+        wi = wi / np.sqrt(np.where(d2 > 0, d2, 1.0))[:, None]
+        cos_s = (n * wi).sum(1)
+        ll = (-wi) @ np.linalg.inv(tw)[:3, :3].T
+        cos_t = ll[:, 2] / np.linalg.norm(ll, axis=1)
+        cutoff, beam = np.deg2rad(sd.spot.cutoff_deg), np.deg2rad(sd.spot.beam_width_deg)
+        ang = np.arccos(np.clip(cos_t, -1, 1))
+        fall = np.where(ang <= beam, 1.0, np.where(ang < cutoff, (cutoff - ang) / (cutoff - beam), 0.0))
+        lit = ok & (cos_s > 0) & (fall > 0)
+        if sd.shadows and lit.any():
+            sel = np.where(lit)[0]
+            occ = any_hit(np.broadcast_to(spos, (len(sel), 3)), Po[sel] - spos, tris, 1.0 - 10.0 * EPS)
+            lit[sel[occ]] = False
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = np.where(lit, fall * cos_s / d2 / np.pi, 0.0)
+        out["spot"] = f[:, None] * np.asarray(list(sd.spot.intensity), np.float64)[None]
+    return out
+
+
+def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed):
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed)
+    W, H = sd.cam.width, sd.cam.height
+    rad = s["spot"].copy()
+    if sd.proj.enabled:
+        tex = np.asarray(tex, np.float64)
+        (x0, x1, y0, y1), (w00, w01, w10, w11) = s["taps"], s["w"]
+        if tex.ndim == 2 or tex.shape[-1] == 1:
+            t2 = tex.reshape(tex.shape[0], tex.shape[1])
+            tv = w00 * t2[y0, x0] + w01 * t2[y0, x1] + w10 * t2[y1, x0] + w11 * t2[y1, x1]
+            rad += (tv * s["pfac"])[:, None] * np.asarray(list(sd.proj.color), np.float64)[None]
+        else:
+            tv = w00[:, None] * tex[y0, x0] + w01[:, None] * tex[y0, x1] + w10[:, None] * tex[y1, x0] + w11[:, None] * tex[y1, x1]
+            rad += tv * s["pfac"][:, None]
+    alb = np.asarray(albedo, np.float64)[np.maximum(s["shape"], 0)]
+    rad = np.where(s["hit"][:, None], rad * alb, 0.0)
+    return rad.reshape(H, W, spp, 3).mean(2)
+
+
+def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg):
+    """d <img, gimg> / d tex for a 1-channel texture"""
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed)
+    g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
+    alb = np.asarray(albedo, np.float64)[np.maximum(s["shape"], 0)]
+    ws = (g * alb * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) * s["pfac"] / spp
+    ws = np.where(s["hit"], ws, 0.0)
+    gt = np.zeros((sd.proj.tex_h, sd.proj.tex_w))
+    (x0, x1, y0, y1), (w00, w01, w10, w11) = s["taps"], s["w"]
+    for (yy, xx), w in (((y0, x0), w00), ((y0, x1), w01), ((y1, x0), w10), ((y1, x1), w11)):
+        np.add.at(gt, (yy, xx), ws * w)
+    return gt
