@@ -202,12 +202,14 @@ def main():
     geom = wl.mi_scene.geom
     base_seed = 1000
 
+    # one seed per rank before the loop (disjoint scene samples per rank), then the reference's loop as it stands —
+    # `ff_scene.randomize(); mi.render(...)` without reseeding (examples/vocalfold_scene.py:100-102)
+    torch.manual_seed(base_seed + rank)
+    random.seed(base_seed + rank)
+
     def render_step(i):
-        seed = base_seed + i * world + rank  # disjoint scene samples per rank
-        torch.manual_seed(seed)
-        random.seed(seed)
         wl.ff_scene.randomize()
-        return mi.render(wl.mi_scene, spp=args.spp, seed=seed, fp16=args.fp16)
+        return mi.render(wl.mi_scene, spp=args.spp, seed=base_seed + i * world + rank, fp16=args.fp16)
 
     events = []
 

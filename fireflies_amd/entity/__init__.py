@@ -1,4 +1,4 @@
-from .base import Transformable
+from .base import DrawBatch, Transformable
 from .mesh import Mesh
 
-__all__ = ["Transformable", "Mesh"]
+__all__ = ["Transformable", "Mesh", "DrawBatch"]

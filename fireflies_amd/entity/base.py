@@ -6,10 +6,13 @@ scripts depend on (pinned by tests/golden/g7):
   * `rotate_z` feeds getPitchTransform (= rotation about Y) and `rotate_y` feeds getYawTransform
     (= rotation about Z) (entity/base.py:194-207); composition is Z @ Y @ X.
 Host/device split (MI355X): the random draws happen on the entity's device with the same
-torch.rand calls as the reference (so a seeded run sees the same stream), but the 4x4 algebra
-is done on the host from ONE `.tolist()` per draw instead of dozens of one-element device
-kernels and per-angle syncs; matrices are handed to the GPU once per randomisation as a single
-[S,16] buffer (Scene.update_meshes -> ffx_scene_update).
+torch.rand calls as the reference (so a seeded run sees the same stream).  randomize() is split in
+two phases: `_draw` issues every sampler call in the reference's order and parks the drawn device
+tensors in a DrawBatch; `_compose` does the 4x4 algebra on the host from the fetched values.  A whole
+Scene.randomize() — or a whole batch of scene samples (Scene.randomize_batch) — therefore costs ONE
+device-to-host transfer instead of one `.tolist()` sync per draw, and that transfer waits only for the
+draws themselves (they run on a side stream), never for the render that is still in flight; matrices
+reach the GPU as kernel arguments of ffx_scene_update_h.
 """
 import torch
 
@@ -17,6 +20,88 @@ from .. import sampling
 from ..utils import math as ffmath
 
 _CPU = torch.device("cpu")
+
+
+class DrawBatch:
+    """device tensors drawn by the samplers of one or more randomisations; `fetch()` brings all of them to
+    the host with one transfer and returns them as lists of Python floats (slot -> values).
+
+    A uniform draw `min + rand * (max - min)` (utils/math.py:170-175: three device ops in the reference) is
+    registered as (rand, min, max): only `torch.rand` — the call that defines the RNG stream — runs on the
+    device, the affine map is evaluated on the host after the transfer with the same float32 multiply and add,
+    so the values are bit-identical."""
+
+    def __init__(self):
+        self._tensors = []
+        self._slots = []  # (first tensor index, kind, repeat)
+
+    def add(self, t) -> int:
+        self._tensors.append(t.detach().reshape(-1))
+        self._slots.append((len(self._tensors) - 1, 0, 1, None, None))
+        return len(self._slots) - 1
+
+    def add_uniform(self, u, lo, hi, repeat: int = 1) -> int:
+        """u: the torch.rand tensor (device); lo / hi: the bounds as float32 numpy arrays (host mirrors kept by the sampler)"""
+        self._tensors.append(u.reshape(-1))
+        self._slots.append((len(self._tensors) - 1, 1, repeat, lo, hi))
+        return len(self._slots) - 1
+
+    def __len__(self):
+        return len(self._slots)
+
+    def fetch(self):
+        return self.start_fetch().finish()
+
+    def start_fetch(self):
+        """enqueue the transfer on the current stream (CUDA entities: an asynchronous copy into pinned memory);
+        `.finish()` on the returned object waits for it and returns the values"""
+        if not self._slots or all(not t.is_cuda for t in self._tensors):
+            return _Pending(self, None, None)
+        dev = next(t.device for t in self._tensors if t.is_cuda)
+        flat = torch.cat([t.to(dev, torch.float32) for t in self._tensors])
+        pool = _PINNED.setdefault(flat.numel(), [])
+        host = pool.pop() if pool else torch.empty(flat.shape, dtype=torch.float32).pin_memory()  # (pinning costs ~50 us: reuse)
+        host.copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _Pending(self, host, ev)
+
+    def _values(self, flat):
+        if not self._slots:
+            return []
+        if flat is None:
+            arrs = [t.to(torch.float32).numpy() for t in self._tensors]
+        else:
+            arrs, k = [], 0
+            for t in self._tensors:
+                arrs.append(flat[k : k + t.numel()])
+                k += t.numel()
+        out = []
+        for first, kind, rep, lo, hi in self._slots:
+            if kind == 0:
+                v = arrs[first]
+            else:
+                v = arrs[first] * (hi - lo) + lo  # float32, one rounding per operation like the torch expression
+            vals = [float(x) for x in v]
+            out.append(vals * rep if rep > 1 else vals)
+        return out
+
+
+_PINNED = {}  # free pinned staging buffers by size
+
+
+class _Pending:
+    def __init__(self, batch, host, event):
+        self.batch, self.host, self.event = batch, host, event
+
+    def finish(self):
+        if self.event is not None:
+            self.event.synchronize()  # the one sync
+            vals = self.batch._values(self.host.numpy())
+            _PINNED.setdefault(self.host.numel(), []).append(self.host)
+            self.host = None
+            return vals
+        return self.batch._values(None)
 
 
 class Transformable:
@@ -31,6 +116,8 @@ class Transformable:
         self._randomized_float_attributes = {}
         self._vec3_attributes = {}
         self._randomized_vec3_attributes = {}
+        self._host_float_attributes = {}  # host copies of the last randomised attributes (what Scene writes back)
+        self._host_vec3_attributes = {}
         zeros = torch.zeros(3, device=self._device)
         self._rotation_sampler = sampling.UniformSampler(zeros.clone(), zeros.clone())
         self._translation_sampler = sampling.UniformSampler(zeros.clone(), zeros.clone())
@@ -46,16 +133,22 @@ class Transformable:
         return self._randomizable
 
     def set_randomizable(self, randomizable: bool) -> None:
+        sampling.base.touch()
         self._randomizable = randomizable
 
     def set_centroid(self, centroid) -> None:
+        sampling.base.touch()
         c = centroid.detach().to(_CPU).reshape(-1)
         self._centroid_mat[0, 3], self._centroid_mat[1, 3], self._centroid_mat[2, 3] = c[0], c[1], c[2]
 
     def get_randomized_vec3_attributes(self) -> dict:
+        if self._randomized_vec3_attributes is None:  # the tensors the reference API hands out, from the host values
+            self._randomized_vec3_attributes = {k: torch.tensor(v) for k, v in self._host_vec3_attributes.items()}
         return self._randomized_vec3_attributes
 
     def get_randomized_float_attributes(self) -> dict:
+        if self._randomized_float_attributes is None:
+            self._randomized_float_attributes = {k: torch.tensor([v]) for k, v in self._host_float_attributes.items()}
         return self._randomized_float_attributes
 
     def vec3_attributes(self) -> dict:
@@ -75,18 +168,22 @@ class Transformable:
 
     # ------------------------------------------------------------------ attribute samplers
     def add_float_sampler(self, key: str, sampler) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._float_attributes[key] = sampler
 
     def add_float_key(self, key: str, min: float, max: float) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._float_attributes[key] = sampling.UniformSampler(min, max, device=self._device)
 
     def add_vec3_key(self, key: str, min, max) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._vec3_attributes[key] = sampling.UniformSampler(min, max, device=self._device)
 
     def add_vec3_sampler(self, key: str, sampler) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._vec3_attributes[key] = sampler
 
@@ -108,20 +205,25 @@ class Transformable:
 
     # ------------------------------------------------------------------ transforms
     def set_world(self, _origin) -> None:
+        sampling.base.touch()
         self._world = _origin.detach().to(_CPU, torch.float32).reshape(4, 4).clone()
         self._randomized_world = self._world.clone()
 
     def setParent(self, parent) -> None:
+        sampling.base.touch()
         self._parent = parent
         parent.setChild(self)
 
     def setChild(self, child) -> None:
+        sampling.base.touch()
         self._child = child
 
     def set_rotation_sampler(self, sampler) -> None:
+        sampling.base.touch()
         self._rotation_sampler = sampler
 
     def set_translation_sampler(self, sampler) -> None:
+        sampling.base.touch()
         self._translation_sampler = sampler
 
     def update_index_from_sampler(self, sampler, min, max, index) -> None:
@@ -129,6 +231,7 @@ class Transformable:
         sampler.get_max()[index] = max
 
     def _axis_range(self, sampler, lo, hi, index):
+        sampling.base.touch()
         self._randomizable = True
         self.update_index_from_sampler(sampler, lo, hi, index)
 
@@ -142,6 +245,7 @@ class Transformable:
         self._axis_range(self._rotation_sampler, min_rot, max_rot, 2)
 
     def rotate(self, min, max) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._rotation_sampler.set_sample_interval(min.to(self._device), max.to(self._device))
 
@@ -155,44 +259,86 @@ class Transformable:
         self._axis_range(self._translation_sampler, min_translation, max_translation, 2)
 
     def translate(self, min, max) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._translation_sampler.set_sample_interval(min.to(self._device), max.to(self._device))
 
-    # ------------------------------------------------------------------ sampling (host 4x4 algebra)
-    def _sample_rotation_host(self):
-        self._sampled_rotation = self._rotation_sampler.sample()
-        rx, ry, rz = (float(v) for v in self._sampled_rotation.reshape(-1).tolist())
+    # ------------------------------------------------------------------ sampling: draw (device) / compose (host)
+    @staticmethod
+    def _rotation_matrix(rx, ry, rz):
         # names as in the reference: the "z" slot uses Pitch (about Y), the "y" slot Yaw (about Z)
         zMat = ffmath.getPitchTransform(rz, _CPU)
         yMat = ffmath.getYawTransform(ry, _CPU)
         xMat = ffmath.getRollTransform(rx, _CPU)
-        return ffmath.toMat4x4(zMat @ yMat @ xMat)
+        m = torch.zeros((4, 4))
+        m[:3, :3] = zMat @ yMat @ xMat
+        m[3, 3] = 1.0
+        return m
 
-    def _sample_translation_host(self):
-        self._random_translation = self._translation_sampler.sample()
-        tx, ty, tz = (float(v) for v in self._random_translation.reshape(-1).tolist())
-        t = torch.eye(4)
-        t[0, 3], t[1, 3], t[2, 3] = tx, ty, tz
+    @staticmethod
+    def _translation_matrix(tx, ty, tz):
+        return torch.tensor([[1.0, 0.0, 0.0, tx], [0.0, 1.0, 0.0, ty], [0.0, 0.0, 1.0, tz], [0.0, 0.0, 0.0, 1.0]])
+
+    def _draw_attributes(self, batch):
+        slots = {"f": {}, "v": {}}
+        for key, sampler in self._float_attributes.items():
+            slots["f"][key] = sampler.draw(batch)
+        for key, sampler in self._vec3_attributes.items():
+            slots["v"][key] = sampler.draw(batch)
+        return slots
+
+    def _compose_attributes(self, slots, values):
+        self._host_float_attributes = {k: values[i][0] for k, i in slots["f"].items()}
+        self._host_vec3_attributes = {k: values[i] for k, i in slots["v"].items()}
+        self._randomized_float_attributes = self._randomized_vec3_attributes = None  # rebuilt on demand (get_randomized_*)
+
+    def _draw(self, batch):
+        """phase 1 of randomize(): the sampler calls of the reference, in its order (translation, rotation,
+        float / vec3 attributes; entity/base.py:220-234).  Returns a ticket for _compose, None if not randomisable."""
+        if not self.randomizable():
+            return None
+        return {"t": self._translation_sampler.draw(batch), "r": self._rotation_sampler.draw(batch), "a": self._draw_attributes(batch)}
+
+    def _compose(self, ticket, values) -> None:
+        """phase 2: (T + centroid) @ R @ world on the host from the fetched draws"""
+        if ticket is None:
+            return
+        t = self._translation_matrix(*values[ticket["t"]])
         self._last_translation = t
-        return t
+        self._last_draw = (values[ticket["t"]], values[ticket["r"]])
+        self._randomized_world = (t + self._centroid_mat) @ self._rotation_matrix(*values[ticket["r"]]) @ self._world
+        self._compose_attributes(ticket["a"], values)
+
+    # the last drawn translation / rotation (attributes of the reference), as tensors on demand
+    @property
+    def _random_translation(self):
+        return torch.tensor(self._last_draw[0]) if getattr(self, "_last_draw", None) else None
+
+    @_random_translation.setter
+    def _random_translation(self, v):
+        self._last_draw = ([float(x) for x in v.reshape(-1).tolist()], (getattr(self, "_last_draw", None) or (None, [0.0, 0.0, 0.0]))[1])
+
+    @property
+    def _sampled_rotation(self):
+        return torch.tensor(self._last_draw[1]) if getattr(self, "_last_draw", None) else None
+
+    @_sampled_rotation.setter
+    def _sampled_rotation(self, v):
+        self._last_draw = ((getattr(self, "_last_draw", None) or ([0.0, 0.0, 0.0], None))[0], [float(x) for x in v.reshape(-1).tolist()])
 
     def sample_rotation(self):
-        return self._sample_rotation_host().to(self._device)
+        self._sampled_rotation = self._rotation_sampler.sample()
+        return self._rotation_matrix(*(float(v) for v in self._sampled_rotation.reshape(-1).tolist())).to(self._device)
 
     def sample_translation(self):
-        return self._sample_translation_host().to(self._device)
-
-    def _sample_attributes(self):
-        for key, sampler in self._float_attributes.items():
-            self._randomized_float_attributes[key] = sampler.sample()
-        for key, sampler in self._vec3_attributes.items():
-            self._randomized_vec3_attributes[key] = sampler.sample()
+        self._random_translation = self._translation_sampler.sample()
+        self._last_translation = self._translation_matrix(*(float(v) for v in self._random_translation.reshape(-1).tolist()))
+        return self._last_translation.to(self._device)
 
     def randomize(self) -> None:
-        if not self.randomizable():
-            return
-        self._randomized_world = (self._sample_translation_host() + self._centroid_mat) @ self._sample_rotation_host() @ self._world
-        self._sample_attributes()
+        batch = DrawBatch()
+        ticket = self._draw(batch)
+        self._compose(ticket, batch.fetch())
 
     def relative(self) -> bool:
         return self._parent is not None

@@ -45,6 +45,7 @@ class Mesh(base.Transformable):
 
     # ------------------------------------------------------------------ scale
     def set_scale_sampler(self, sampler) -> None:
+        sampling.base.touch()
         self._scale_sampler = sampler
 
     def scale_x(self, min_scale: float, max_scale: float) -> None:
@@ -57,6 +58,7 @@ class Mesh(base.Transformable):
         self._axis_range(self._scale_sampler, min_scale, max_scale, 2)
 
     def scale(self, min, max) -> None:
+        sampling.base.touch()
         self._randomizable = True
         self._scale_sampler.set_sample_interval(min.to(self._device), max.to(self._device))
 
@@ -73,6 +75,7 @@ class Mesh(base.Transformable):
 
     def set_animation_frames(self, train_frames, eval_frames=None) -> None:
         """Frame stacks without going through OBJ files (same state as add_*_animation_from_obj)."""
+        sampling.base.touch()
         self._anim_data_train = train_frames.to(self._device)
         self._anim_data_eval = (train_frames if eval_frames is None else eval_frames).to(self._device)
         if self._animation_sampler is None:
@@ -87,6 +90,7 @@ class Mesh(base.Transformable):
         fireflies_amd.scenes): frames [train_start, train_start + n_train) are the train set,
         [eval_start, eval_start + n_eval) the eval set.  Selecting a frame is then a pointer change
         inside ffx_scene_update — no vertex data moves."""
+        sampling.base.touch()
         eval_start = train_start + n_train if eval_start is None else eval_start
         self._pool_frames = {"train": (int(train_start), int(n_train)), "eval": (int(eval_start), int(n_eval))}
         self._animation_sampler = sampling.AnimationSampler(0, int(n_train), 0, int(n_eval), device=self._device)
@@ -94,6 +98,7 @@ class Mesh(base.Transformable):
         self._randomizable = True
 
     def add_animation_func(self, func, min_range, max_range) -> None:
+        sampling.base.touch()
         self._animation_func = func
         self._animation_sampler = sampling.UniformSampler(min_range, max_range, device=self._device)
         self._animated = True
@@ -104,6 +109,7 @@ class Mesh(base.Transformable):
             self._animation_sampler = sampling.AnimationSampler(0, 1, 0, 1, device=self._device)
 
     def add_train_animation_from_obj(self, path: str, min: int = None, max: int = None) -> None:
+        sampling.base.touch()
         self._anim_data_train = self.load_animation(path)
         self._ensure_anim_sampler()
         # the reference ignores `min` (mesh.py:81,88): the interval always starts at 0
@@ -111,6 +117,7 @@ class Mesh(base.Transformable):
         self._animated = True
 
     def add_eval_animation_from_obj(self, path: str, min: int = None, max: int = None) -> None:
+        sampling.base.touch()
         self._anim_data_eval = self.load_animation(path)
         self._ensure_anim_sampler()
         self._animation_sampler.set_eval_interval(0, self._anim_data_eval.shape[0] if max is None else max)
@@ -132,6 +139,7 @@ class Mesh(base.Transformable):
         self._faces = faces.to(self._device)
 
     def set_vertices(self, vertices) -> None:
+        sampling.base.touch()
         self._vertices = vertices.to(self._device)
 
     def faces(self):
@@ -141,21 +149,27 @@ class Mesh(base.Transformable):
         return self._vertices
 
     # ------------------------------------------------------------------ randomisation
-    def _sample_scale_host(self):
+    def sample_scale(self):
         sx, sy, sz = (float(v) for v in self._scale_sampler.sample().reshape(-1).tolist())
         m = torch.eye(4)
         m[0, 0], m[1, 1], m[2, 2] = sx, sy, sz
-        return m
+        return m.to(self._device)
 
-    def sample_scale(self):
-        return self._sample_scale_host().to(self._device)
-
-    def randomize(self) -> None:
+    def _draw(self, batch):
+        """translation, rotation, scale (mesh.py:141-150; float / vec3 attributes are NOT sampled for meshes)"""
         if not self.randomizable():
+            return None
+        return {"t": self._translation_sampler.draw(batch), "r": self._rotation_sampler.draw(batch), "s": self._scale_sampler.draw(batch)}
+
+    def _compose(self, ticket, values) -> None:
+        if ticket is None:
             return
-        self._randomized_world = (
-            (self._sample_translation_host() + self._centroid_mat) @ self._sample_rotation_host() @ self._sample_scale_host() @ self._world
-        )
+        t = self._translation_matrix(*values[ticket["t"]])
+        self._last_translation = t
+        self._last_draw = (values[ticket["t"]], values[ticket["r"]])
+        sx, sy, sz = values[ticket["s"]]
+        sc = torch.tensor([[sx, 0.0, 0.0, 0.0], [0.0, sy, 0.0, 0.0], [0.0, 0.0, sz, 0.0], [0.0, 0.0, 0.0, 1.0]])
+        self._randomized_world = (t + self._centroid_mat) @ self._rotation_matrix(*values[ticket["r"]]) @ sc @ self._world
 
     def load_animation(self, path: str):
         frames = [load_obj_vertices(os.path.join(path, f)) for f in sorted(os.listdir(path)) if f.endswith(".obj")]

@@ -29,8 +29,11 @@ class Material(Transformable):
     def __init__(self, name: str, device=torch.device("cuda")):
         super().__init__(name, device)
 
-    def randomize(self) -> None:
-        self._sample_attributes()
+    def _draw(self, batch):
+        return {"a": self._draw_attributes(batch)}
+
+    def _compose(self, ticket, values) -> None:
+        self._compose_attributes(ticket["a"], values)
 
 
 for _n, _k in [("set_world", "World"), ("setParent", "Relative"), ("setChild", "Relative"), ("rotate_x", "Rotation"), ("rotate_y", "Rotation"),

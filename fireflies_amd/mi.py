@@ -477,5 +477,13 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
             tex = tex.to(scene.device)  # the reference uploads through numpy (vocalfold_scene.py:69)
         ch = 1 if tex.dim() == 2 else int(tex.shape[-1])
     sd = scene.scene_desc(tex_channels=ch)
-    img = Fn.render(tex.float() if tex is not None else torch.zeros((1, 1, 1), device=scene.device), scene.geom, sd, scene.albedo, spp, seed, fp16)
+    if tex is None:
+        tex = torch.zeros((1, 1, 1), device=scene.device)
+    elif tex.dtype != torch.float32:
+        tex = tex.float()
+    if tex.requires_grad and torch.is_grad_enabled():
+        img = Fn.render(tex, scene.geom, sd, scene.albedo, spp, seed, fp16)
+    else:  # nothing to differentiate: straight to the kernel (autograd.Function.apply costs ~80 us of host time per call)
+        t = tex if tex.is_contiguous() else tex.contiguous()
+        img = scene.geom.render_fwd(sd, scene.albedo, t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
     return TensorXf(img)

@@ -15,9 +15,36 @@ from ._lib import api
 REDUCE = {"sum": _abi.REDUCE_SUM, "softor": _abi.REDUCE_SOFTOR}
 
 
+def _dev_index(device=None):
+    if device is None:
+        return torch.cuda.current_device()
+    if isinstance(device, int):
+        return device
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
 def _stream(device=None):
-    """the caller's current HIP stream on `device` (default: the current device)"""
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """the caller's current HIP stream on `device` (default: the current device) as a raw handle.
+    (torch.cuda.current_stream() builds a Stream object through several Python layers: 10 us per call,
+    seven calls per render step; the raw query is one C call.)"""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(_dev_index(device)))
+
+
+_STREAM_OBJECTS = {}
+
+
+def _stream_obj(device=None):
+    """torch Stream object of the caller's current stream (for event record / wait), cached by raw handle"""
+    idx = _dev_index(device)
+    raw = torch._C._cuda_getCurrentRawStream(idx)
+    s = _STREAM_OBJECTS.get((idx, raw))
+    if s is None:
+        s = torch.cuda.current_stream(idx)
+        if len(_STREAM_OBJECTS) > 64:
+            _STREAM_OBJECTS.clear()
+        _STREAM_OBJECTS[(idx, raw)] = s
+    return s
 
 
 def _dev(t, dtype=torch.float32, name="tensor"):
@@ -221,6 +248,7 @@ class DeviceGeometry:
             raise ValueError("negative vertex index")
         self.n_tris, self.n_shapes = F, S
         self.device = torch.device(device)
+        self._didx = _dev_index(self.device) if self.device.type == "cuda" and torch.cuda.is_available() else None
         self.timing = None  # set to a list to collect (name, start_event, end_event) per launch
         self._max_local = np.zeros(S, np.int64)
         np.maximum.at(self._max_local, ts, tr.max(axis=1))
@@ -263,7 +291,7 @@ class DeviceGeometry:
         self._pool_written = None  # event: the last write_verts() into the vertex pool (caller's stream)
         self.version = 0           # bumped by every update(): functional._Render pins the pose it traced
         if self._async:  # blob copies / uploads above were enqueued on the caller's stream
-            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            self._side.wait_stream(_stream_obj(self._didx))
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
 
     @property
@@ -275,21 +303,21 @@ class DeviceGeometry:
     def _acquire(self):
         ev = self._upd_done[self._cur] if self._async else None
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            _stream_obj(self._didx).wait_event(ev)
 
     def _release(self):
         if self._async:
             ev = self._last_use[self._cur]
             if ev is None:
                 ev = self._last_use[self._cur] = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            ev.record(_stream_obj(self._didx))
 
     def write_verts(self, offset, verts):
         """copy caller-supplied vertices [V,3] into the pool at `offset` (animation functions, direct
         `vertex_positions` assignment).  Ordered against the refits on the side stream in both
         directions: the copy waits for every enqueued refit (one may still be reading this slot), and
         the next update() waits for the copy."""
-        main = torch.cuda.current_stream(self.device)
+        main = _stream_obj(self._didx)
         if self._async:
             for ev in self._upd_done:
                 if ev is not None:
@@ -302,7 +330,7 @@ class DeviceGeometry:
 
     def _call(self, name, *args):
         """a launch on this geometry's device (which need not be the current one)"""
-        if self.device.index is None or torch.cuda.current_device() == self.device.index:
+        if self.device.index is None or torch._C._cuda_getDevice() == self.device.index:
             return api().call(name, *args)
         with torch.cuda.device(self.device):
             return api().call(name, *args)
@@ -329,7 +357,7 @@ class DeviceGeometry:
             self._update_into(self._blobs[0], xforms, on_device)
             return
         nxt = 1 - self._cur
-        main = torch.cuda.current_stream(self.device)
+        main = _stream_obj(self._didx)
         if self._last_use[nxt] is not None:
             self._side.wait_event(self._last_use[nxt])  # its last reader must be done before it is overwritten
         if self._pool_written is not None:
@@ -353,7 +381,7 @@ class DeviceGeometry:
                 self._call(
                     "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                     _dev(self.tri_shape, torch.int32), self._vert_off_host.ctypes.data_as(C.POINTER(C.c_int32)),
-                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(self.device),
+                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(self._didx),
                 )
                 return
             if self._vert_off_dev_stale:
@@ -364,7 +392,7 @@ class DeviceGeometry:
             self._xf = xf  # keep alive until the stream has consumed it
             self._call(
                 "ffx_scene_update", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(self.device),
+                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(self._didx),
             )
 
     def trace_primary(self, cam, spp=1, jitter=0, seed=0, want_ids=True):
@@ -374,7 +402,7 @@ class DeviceGeometry:
         prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         self._call(
             "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
-            _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self.device),
+            _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self._didx),
         )
         self._release()
         return t, shape, prim
@@ -386,7 +414,7 @@ class DeviceGeometry:
         prim = torch.empty(n, dtype=torch.int32, device=self.device)
         self._call(
             "ffx_trace_rays", _dev(self.blob, torch.uint8), C.byref(self.info), _dev(origins, name="origins"), _dev(dirs, name="dirs"), n, float(tmax),
-            _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(self.device),
+            _dev(t), _dev(shape, torch.int32), _dev(prim, torch.int32), _stream(self._didx),
         )
         self._release()
         return t, shape, prim
@@ -406,14 +434,14 @@ class DeviceGeometry:
                 self._call(
                     "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
                     _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype),
-                    _dev(cache, torch.uint8, "cache"), _stream(self.device),
+                    _dev(cache, torch.uint8, "cache"), _stream(self._didx),
                 )
             self._release()
             return img
         with self._timed("render_fwd"):
           self._call(
             "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
-            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(self.device),
+            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(self._didx),
           )
         self._release()
         return img
@@ -423,7 +451,7 @@ class DeviceGeometry:
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
-                       _dev(gimg, name="gimg"), _dev(gtex), _stream(self.device))
+                       _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx))
         return gtex
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
@@ -431,7 +459,7 @@ class DeviceGeometry:
         with self._timed("render_bwd"):
             self._call(
                 "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
-                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self.device),
+                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx),
             )
         self._release()
         return gtex

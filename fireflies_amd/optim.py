@@ -62,6 +62,11 @@ class PatternOptimizer:
         self.step_index = 0
         self._cache = None
 
+    def _sample_seeds(self, step):
+        """seeds of this rank's scene samples of optimisation step `step` (dist.sample_seed: independent of the world size)"""
+        S = self.samples_per_step
+        return [dist.sample_seed(self.base_seed, step, S, k) for k in dist.sample_ids(S, dist.rank(), dist.world_size())]
+
     # ------------------------------------------------------------------ texture from the current pattern
     def textures(self):
         pts = self.laser.projectRaysToNDC()[:, 0:2].contiguous()
@@ -116,11 +121,26 @@ class PatternOptimizer:
         tex3 = tex.unsqueeze(-1)
         gtex = None
         loss_sum = torch.zeros((), device=tex.device)
-        for k in dist.sample_ids(S, r, w):
-            seed = dist.sample_seed(self.base_seed, self.step_index, S, k)
-            torch.manual_seed(seed)
-            random.seed(seed)
-            self.ff_scene.randomize()
+        # this rank's scene samples: all their random draws up front (each under its own seed, as
+        # manual_seed(s); randomize() would make them), ONE device-to-host transfer for the lot
+        seeds = self._sample_seeds(self.step_index)
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        appliers = None
+        if ahead is not None and ahead[0] == (self.step_index, tuple(seeds)):
+            try:
+                appliers = ahead[1]()
+            except RuntimeError:  # a sampler range was changed since: draw again
+                appliers = None
+        if appliers is None:
+            appliers = self.ff_scene.randomize_batch(seeds)
+        # the NEXT step's samples are drawn now, ahead of this step's renders: device draws issued behind a
+        # render that fills the GPU only complete when it ends, and waiting for them would serialise host and GPU.
+        # Their seeds are a function of the step index alone; the generators are put back afterwards.
+        if self.ff_scene._draw_stream() is not None:  # (host-side draws of CPU entities have nothing to wait for)
+            nxt = self._sample_seeds(self.step_index + 1)
+            self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
+        for seed, apply_sample in zip(seeds, appliers):
+            apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
             use_cache = Fn.cache_supported(sd, self.spp)
             nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, self.spp) if use_cache else 0

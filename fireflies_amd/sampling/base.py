@@ -10,6 +10,18 @@ They are reproduced (same statements on shared tensors) because existing scripts
 """
 import torch
 
+# bumped by every mutation of a sampler / entity configuration that goes through the API: Scene's pre-drawn
+# randomisation (scene.py: _predraw) is only used if nothing changed since it was drawn
+_MUTATIONS = [0]
+
+
+def touch() -> None:
+    _MUTATIONS[0] += 1
+
+
+def mutation_count() -> int:
+    return _MUTATIONS[0]
+
 
 class Sampler:
     def __init__(self, min, max, eval_step_size: float = 0.01, device=torch.device("cuda")) -> None:
@@ -24,24 +36,31 @@ class Sampler:
     # interval accessors (base.py:32-46); get_min/get_max hand out the live tensors, which the
     # Transformable convenience setters rely on (entity/base.py:146-151)
     def set_sample_interval(self, min, max) -> None:
+        touch()
         self._min_range, self._max_range = min.clone(), max.clone()
 
     def get_min(self):
+        touch()  # hands out the live tensor: the caller may write through it
         return self._min_range
 
     def get_max(self):
+        touch()
         return self._max_range
 
     def set_sample_max(self, max) -> None:
+        touch()
         self._max_range = max.clone()
 
     def set_sample_min(self, min) -> None:
+        touch()
         self._min_range = min.clone()
 
     def train(self) -> None:
+        touch()
         self._train = True
 
     def eval(self) -> None:
+        touch()
         self._train = False
 
     def sample(self):
@@ -49,6 +68,22 @@ class Sampler:
 
     def sample_train(self):
         raise NotImplementedError
+
+    def _host_bounds(self):
+        """float32 numpy mirrors of (min, max), refreshed when the configuration counter moved (one sync then,
+        for device bounds)"""
+        hb = getattr(self, "_hb", None)
+        if hb is None or hb[0] != _MUTATIONS[0]:
+            lo = self._min_range.detach().reshape(-1).to("cpu", torch.float32).numpy().copy()
+            hi = self._max_range.detach().reshape(-1).to("cpu", torch.float32).numpy().copy()
+            hb = self._hb = (_MUTATIONS[0], lo, hi)
+        return hb[1], hb[2]
+
+    def draw(self, batch) -> int:
+        """registers this sampler's next draw in an entity.DrawBatch and returns its slot (the value reaches
+        the host with the batch's single transfer).  Subclasses whose train draw is min + rand * (max - min)
+        register only the rand (see DrawBatch.add_uniform)."""
+        return batch.add(torch.as_tensor(self.sample(), dtype=torch.float32))
 
     def sample_eval(self):
         if bool((self._min_range == self._max_range).all()):

@@ -13,3 +13,11 @@ class UniformSampler(base.Sampler):
 
     def sample_train(self):
         return ffmath.randomBetweenTensors(self._min_range, self._max_range)
+
+    def draw(self, batch) -> int:
+        if not self._train:
+            return super().draw(batch)
+        a, b = self._min_range, self._max_range
+        assert a.size() == b.size() and a.device == b.device
+        lo, hi = self._host_bounds()
+        return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi)  # the same torch.rand call as sample_train

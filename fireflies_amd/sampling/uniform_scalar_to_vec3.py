@@ -12,10 +12,20 @@ class UniformScalarToVec3Sampler(base.Sampler):
         super().__init__(min, max, eval_step_size, device)
 
     def _vec3(self, s):
-        return torch.tensor([s, s, s], device=self._device)
+        # (the reference builds torch.tensor([s, s, s]): three .item() syncs on a device scalar; same values here)
+        s = torch.as_tensor(s, dtype=torch.float32, device=self._device).reshape(-1)[0]
+        return torch.stack([s, s, s])
 
     def sample_train(self):
         return self._vec3(ffmath.randomBetweenTensors(self._min_range, self._max_range))
+
+    def draw(self, batch) -> int:
+        if not self._train:
+            return super().draw(batch)
+        a, b = self._min_range, self._max_range
+        assert a.size() == b.size() and a.device == b.device and a.numel() == 1
+        lo, hi = self._host_bounds()
+        return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi, repeat=3)
 
     def sample_eval(self):
         if bool((self._min_range == self._max_range).all()):

@@ -15,7 +15,7 @@ from typing import List
 
 import torch
 
-from . import emitter, entity, material, mi
+from . import emitter, entity, material, mi, ops
 
 
 class Scene:
@@ -180,7 +180,7 @@ class Scene:
             if not fast:  # foreign parameter object: reference behaviour (scene.py:243-251)
                 p[mesh.name() + ".vertex_positions"] = mi.Float32(mesh.get_randomized_vertices().flatten())
                 continue
-            pick = mesh.sample_animation_index()
+            pick = mesh._pending_pick if hasattr(mesh, "_pending_pick") else mesh.sample_animation_index()
             world = mesh._world_host()
             uncentre = torch.eye(4)
             uncentre[0:3, 3] = -mesh._centroid_mat[0:3, 3]
@@ -198,12 +198,13 @@ class Scene:
 
     def _write_attributes(self, ent) -> None:
         p = self._mitsuba_params
-        for key, value in ent.get_randomized_float_attributes().items():
+        # host copies made by the entity's _compose (one transfer per randomisation, not one sync per attribute)
+        for key, value in ent._host_float_attributes.items():
             full = ent.name() + "." + key
-            p[full] = type(p[full])(value.item())
-        for key, value in ent.get_randomized_vec3_attributes().items():
+            p[full] = type(p[full])(value)
+        for key, value in ent._host_vec3_attributes.items():
             full = ent.name() + "." + key
-            p[full] = type(p[full])(value.tolist())
+            p[full] = type(p[full])(value)
 
     def _write_pose(self, ent) -> None:
         self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f(ent._world_host().tolist())
@@ -235,22 +236,60 @@ class Scene:
 
     # ------------------------------------------------------------------ randomisation
     def randomize_list(self, entity_list: List[entity.Transformable]) -> None:
+        """reference API (scene.py:344-358): parents first, then the child chain — one entity at a time"""
+        for ent in self._chain_order(entity_list):
+            ent.randomize()
+
+    @staticmethod
+    def _chain_order(entity_list):
         for root in [e for e in entity_list if e.parent() is None]:
-            root.randomize()
+            yield root
             child = root.child()
             while child is not None:
-                child.randomize()
+                yield child
                 child = child.child()
 
-    def randomize(self) -> None:
-        self.randomize_list(self._meshes)
-        self.randomize_list(self._lights)
-        self.randomize_list(self._materials)
+    def _draw_order(self):
+        """every entity in the order Scene.randomize visits it (scene.py:360-371)"""
+        yield from self._chain_order(self._meshes)
+        yield from self._chain_order(self._lights)
+        yield from self._chain_order(self._materials)
         if self._camera is not None:
-            self._camera.randomize()
+            yield self._camera
         if self._projector is not None:
-            self._projector.randomize()
-        self.update_meshes()
+            yield self._projector
+
+    def _draw_stream(self):
+        """side stream for the sampler draws of CUDA entities: the device-to-host transfer of the drawn values
+        then waits for the draws only, not for the render still running on the caller's stream.  (The Philox
+        offsets of torch's CUDA generator are tracked on the host: the values do not depend on the stream.)"""
+        dev = torch.device(self._device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(dev, priority=-1)  # high priority: a handful of tiny kernels ahead of the render
+        return self._side
+
+    def _draw_all(self, batch):
+        """phase 1 for one scene sample: all sampler calls, reference order (entities, then the meshes' animation
+        draws, which the reference makes inside update_meshes, scene.py:243-251 -> mesh.py:183-198)"""
+        ents = list(self._draw_order())
+        tickets = [e._draw(batch) for e in ents]
+        picks = [m.sample_animation_index() if m.randomizable() else None for m in self._meshes]
+        return ents, tickets, picks
+
+    def _apply(self, drawn, values) -> None:
+        """phase 2 + push: host algebra, parameter writes, ONE device pass (params.update())"""
+        ents, tickets, picks = drawn
+        for e, t in zip(ents, tickets):
+            e._compose(t, values)
+        for m, pick in zip(self._meshes, picks):
+            m._pending_pick = pick
+        try:
+            self.update_meshes()
+        finally:
+            for m in self._meshes:
+                del m._pending_pick
         if self._camera is not None:
             self.update_camera()
         if self._projector is not None:
@@ -258,3 +297,130 @@ class Scene:
         self.update_lights()
         self.update_materials()
         self._mitsuba_params.update()
+
+    def _fetch(self, batch):
+        side = self._draw_stream()
+        if side is None:
+            return batch.fetch()
+        with torch.cuda.stream(side):
+            return batch.fetch()
+
+    # ---- pre-drawn randomisation (CUDA entities, train mode).
+    # A tiny kernel on ANY stream is not scheduled while a render that fills the GPU is in flight (measured:
+    # ten torch.rand launches on a high-priority side stream complete ~0.6 ms later, when the render ends), so
+    # a randomize() that draws on the device and then waits for the values serialises host and GPU (870
+    # instead of 1 370 renders/s).  Therefore randomize() issues the draws of the NEXT randomisation right
+    # away — before the caller launches this step's render — and rewinds the generators to where they were.
+    # The next call uses those values only if it finds torch's CUDA generator, Python's `random` and the
+    # sampler configuration exactly as this call left them (then it fast-forwards the generators to the state
+    # after the pre-drawn calls): the numbers, and what any other consumer of the generators sees, are those
+    # of the plain sequential program.  Otherwise the pre-drawn values are dropped and the draws are made now.
+    # FFX_PREDRAW=0 switches the mechanism off.  (Caveat: sampler bounds written in place through a tensor
+    # obtained earlier from get_min()/get_max() are not seen by the configuration check.)
+    def _predraw_enabled(self):
+        import os
+
+        return self._draw_stream() is not None and os.environ.get("FFX_PREDRAW", "1") != "0" and all(e._train for e in self._draw_order())
+
+    def _rng_state(self):
+        import random as _random
+
+        return torch.cuda.get_rng_state(torch.device(self._device)), _random.getstate()
+
+    def _set_rng_state(self, st) -> None:
+        import random as _random
+
+        torch.cuda.set_rng_state(st[0], torch.device(self._device))
+        _random.setstate(st[1])
+
+    def _predraw(self) -> None:
+        from .sampling import base as sbase
+
+        side = self._draw_stream()
+        before = self._rng_state()
+        batch = entity.DrawBatch()
+        with torch.cuda.stream(side):
+            drawn = self._draw_all(batch)
+            pending = batch.start_fetch()
+        after = self._rng_state()
+        self._set_rng_state(before)
+        self._pre = {"before": before, "after": after, "drawn": drawn, "pending": pending, "config": sbase.mutation_count()}
+
+    def _take_predrawn(self):
+        from .sampling import base as sbase
+
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is None or pre["config"] != sbase.mutation_count():
+            return None
+        now = self._rng_state()
+        if not torch.equal(now[0], pre["before"][0]) or now[1] != pre["before"][1]:
+            return None
+        self._set_rng_state(pre["after"])
+        return pre["drawn"], pre["pending"].finish()
+
+    def randomize(self) -> None:
+        side = self._draw_stream()
+        got = self._take_predrawn() if side is not None else None
+        if got is None:
+            batch = entity.DrawBatch()
+            if side is None:
+                drawn = self._draw_all(batch)
+            else:
+                with torch.cuda.stream(side):
+                    drawn = self._draw_all(batch)
+            values = self._fetch(batch)
+        else:
+            drawn, values = got
+        if side is not None:
+            ops._stream_obj(side.device).wait_stream(side)  # drawn tensors may be used by animation functions
+            if self._predraw_enabled():
+                self._predraw()
+        self._apply(drawn, values)
+
+    def randomize_batch(self, seeds, lazy: bool = False):
+        """The randomisations of several scene samples (BASELINE configs[3]: the samples of one optimisation step),
+        each drawn under its own seed exactly as `torch.manual_seed(s); random.seed(s); randomize()` would, but
+        with ONE device-to-host transfer for all of them.  Returns one callable per seed; calling it applies that
+        sample (host algebra + parameter writes + params.update()), to be followed by the render of that sample.
+        lazy=True returns a zero-argument function producing that list instead: the draws are enqueued now (put
+        them in front of the renders they must not wait for), the transfer is awaited when it is called, and the
+        generators are left as they were found (the caller is drawing ahead of time)."""
+        import random as _random
+
+        from .sampling import base as sbase
+
+        side = self._draw_stream()
+        keep = None
+        if lazy:
+            keep = (torch.cuda.get_rng_state(torch.device(self._device)) if side is not None else None, torch.get_rng_state(), _random.getstate())
+        batch = entity.DrawBatch()
+        drawn = []
+        for seed in seeds:
+            torch.manual_seed(int(seed))
+            _random.seed(int(seed))
+            if side is None:
+                drawn.append(self._draw_all(batch))
+            else:
+                with torch.cuda.stream(side):
+                    drawn.append(self._draw_all(batch))
+        if side is None:
+            pending = batch.start_fetch()
+        else:
+            with torch.cuda.stream(side):
+                pending = batch.start_fetch()
+        config = sbase.mutation_count()
+        if keep is not None:
+            if keep[0] is not None:
+                torch.cuda.set_rng_state(keep[0], torch.device(self._device))
+            torch.set_rng_state(keep[1])
+            _random.setstate(keep[2])
+
+        def appliers():
+            if sbase.mutation_count() != config:
+                raise RuntimeError("the sampler configuration changed after these scene samples were drawn")
+            values = pending.finish()
+            if side is not None:
+                ops._stream_obj(side.device).wait_stream(side)
+            return [(lambda d=d: self._apply(d, values)) for d in drawn]
+
+        return appliers if lazy else appliers()

@@ -254,6 +254,60 @@ def test_scene_classification_and_randomize_over_generic_params():
     torch.testing.assert_close(a, sc2._mitsuba_params["mesh-Cube.vertex_positions"].torch())
 
 
+def _randomisable_fake_scene():
+    p, _ = _fake_scene_params()
+    sc = ff.Scene(p, device=CPU)
+    mesh = sc.mesh("mesh-Cube")
+    mesh.scale_x(0.5, 2.0)
+    mesh.rotate_y(-0.25, 0.25)
+    mesh.translate_z(-0.3, 0.3)
+    sc.light("emit-Spot").add_vec3_sampler("intensity.value", ff.sampling.UniformScalarToVec3Sampler(1.0, 20.0, device=CPU))
+    sc.material("mat-Default").add_float_key("brdf_0.specular", 0.0, 0.75)
+    sc._camera.translate_x(-0.1, 0.1)
+    sc.train()
+    return p, sc
+
+
+def _snapshot(p):
+    return {k: (v.torch().clone() if hasattr(v, "torch") and not isinstance(v, mi.Float) else (v.matrix.torch().clone() if hasattr(v, "matrix") else float(v)))
+            for k, v in p.items() if k != "tex.data"}
+
+
+def test_randomize_is_one_transfer_and_batches_replay_the_sequential_draws(monkeypatch):
+    """f1: Scene.randomize() draws everything first (reference order) and fetches it with ONE device-to-host
+    transfer (it was one .tolist() per draw); randomize_batch(seeds) draws S scene samples up front under their
+    own seeds — same numbers as S sequential `manual_seed(s); random.seed(s); randomize()` calls — again with one
+    transfer, and applies them one by one."""
+    fetches = []
+    orig = ff.entity.DrawBatch.start_fetch
+    monkeypatch.setattr(ff.entity.DrawBatch, "start_fetch", lambda self: (fetches.append(len(self)), orig(self))[1])
+    seeds = [11, 12, 13, 14]
+    p1, sc1 = _randomisable_fake_scene()
+    seq = []
+    for s_ in seeds:
+        torch.manual_seed(s_)
+        random.seed(s_)
+        sc1.randomize()
+        seq.append(_snapshot(p1))
+    assert len(fetches) == len(seeds) and all(n >= 10 for n in fetches)  # mesh t,r,s + light t,r,2 attrs + material 2 attrs + camera t,r
+    fetches.clear()
+    p2, sc2 = _randomisable_fake_scene()
+    appliers = sc2.randomize_batch(seeds)
+    assert len(fetches) == 1 and len(appliers) == len(seeds)
+    for apply_k, ref in zip(appliers, seq):
+        apply_k()
+        got = _snapshot(p2)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            if isinstance(ref[k], float):
+                assert got[k] == ref[k], k
+            else:
+                torch.testing.assert_close(got[k], ref[k], rtol=0, atol=0, msg=k)
+    assert p2.updates == len(seeds)
+    # the poses of different seeds really differ
+    assert not torch.equal(seq[0]["mesh-Cube.vertex_positions"], seq[1]["mesh-Cube.vertex_positions"])
+
+
 def test_material_has_no_pose_but_warns():
     m = ff.material.Material("mat-X", device=CPU)
     with pytest.warns(UserWarning):

@@ -177,6 +177,48 @@ def test_scene_randomize_render_and_depth_against_oracle(oracle):
     assert tuple(maps.shape) == (3, 56, 64) and float(maps.max()) > 0
 
 
+def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypatch):
+    """f1, reference-default entity device ("cuda"): Scene.randomize() pre-draws the next randomisation before
+    the caller launches its render and rewinds the generators; it may only use those values if nothing touched
+    the generators or the sampler configuration in between.  Same seeds with the mechanism on and off must give
+    the same parameter sequence — including after a foreign draw from torch's CUDA generator, a reseed, a foreign
+    `random` draw and a changed sampler range (each of which must invalidate the pre-drawn values)."""
+    def run(flag):
+        monkeypatch.setenv("FFX_PREDRAW", flag)
+        wl = _small(entity_device="cuda")
+        torch.manual_seed(123)
+        random.seed(123)
+        seq, foreign = [], []
+        for i in range(12):
+            if i == 4:
+                foreign.append(torch.rand(2, device=DEV).cpu())  # somebody else draws from the CUDA generator
+            if i == 6:
+                torch.manual_seed(77)
+            if i == 8:
+                foreign.append(random.random())
+            if i == 10:
+                wl.ff_scene.mesh("mesh-VocalFold").rotate_y(-0.05, 0.4)
+            wl.ff_scene.randomize()
+            img = mi.render(wl.mi_scene, spp=2, seed=i).torch()
+            seq.append((wl.mi_scene._xforms.clone(), list(wl.mi_scene._offs), wl.mi_scene.albedo.cpu().clone(),
+                        wl.params["emit-Spot.intensity.value"].torch().cpu().clone(), img.cpu()))
+        foreign.append(torch.rand(2, device=DEV).cpu())
+        return seq, foreign
+
+    (a, fa), (b, fb) = run("1"), run("0")
+    for k, (x, y) in enumerate(zip(a, b)):
+        torch.testing.assert_close(x[0], y[0], rtol=0, atol=0, msg=f"step {k}: transforms")
+        assert x[1] == y[1], f"step {k}: animation frames"
+        torch.testing.assert_close(x[2], y[2], rtol=0, atol=0, msg=f"step {k}: albedo")
+        torch.testing.assert_close(x[3], y[3], rtol=0, atol=0, msg=f"step {k}: light")
+        assert torch.equal(x[4], y[4]), f"step {k}: image"
+    # the foreign consumers saw the same numbers either way
+    torch.testing.assert_close(fa[0], fb[0], rtol=0, atol=0)
+    assert fa[1] == fb[1]
+    torch.testing.assert_close(fa[2], fb[2], rtol=0, atol=0)
+    assert not torch.equal(a[0][0], a[1][0])
+
+
 def test_generic_vertex_assignment_path(oracle):
     """Mitsuba-style use: assign transformed vertices to `<mesh>.vertex_positions` and update()."""
     wl = _small(randomize=False)
