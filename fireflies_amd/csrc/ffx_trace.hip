@@ -6,14 +6,13 @@
 // shading follows the same documented operation order as oracle/ffx_oracle.c, so
 // depths and ids agree with the oracle bit for bit apart from rare 1-ulp boundary cases.
 //
-// Execution model: one 64-lane wavefront = one 8x8 pixel tile (a coherent ray
-// packet: the lanes of a wave walk almost the same nodes, so a node or leaf fetch is a handful of
-// distinct 64-byte lines per wave-instruction).  A 256-thread workgroup owns ONE tile; its four
-// waves take every fourth sample, accumulate radiance in registers and combine through LDS:
-// one store per pixel, no atomics in the forward pass.  Per-lane traversal stacks live in LDS
-// (stride = workgroup size, conflict-free).  That per-lane design is kept for K7 and as the A/B
-// baseline (FFX_TRAVERSAL=lane); the render kernels default to the wave-PACKET design further down
-// (scalar-cache node fetch, VGPR lane stack, single pixel x 64 samples per wavefront).
+// Execution model.  The render kernels and K7 are WAVE-PACKET kernels: one wavefront = the 64
+// samples of one pixel (or a compact pixel block at low spp), wave-uniform control flow.  Their default
+// traversal is the 64-wide walk (lanes test 64 child boxes of a wide node against the packet as a whole; exact
+// triangle tests with the lanes back on the rays), falling back to the binary packet walk (scalar-cache node
+// fetch, per-ray box tests with the node as SGPR operands, VGPR lane stack) for packets the interval test is bad
+// at.  The per-lane kernels further down (one lane = one ray, LDS stack) serve arbitrary rays (k_trace_rays)
+// and remain as the A/B baseline (FFX_TRAVERSAL=lane).
 // XCD placement: tiles are dealt to XCDs interleaved (blockIdx order).  Giving each XCD a contiguous
 // band of the image (FFX_XCD_REMAP=1) improves L2 locality but costs 30 % here: tile cost varies by
 // 10x across the image, so whole XCDs idle while the one that owns the vocal folds finishes.

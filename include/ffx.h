@@ -20,6 +20,17 @@
  *   - all calls are asynchronous on `stream` (a hipStream_t; the oracle ignores it).
  *   - arrays are dense, row-major, C order.  float = IEEE binary32.
  *   - no global state besides the error string; calls on distinct streams are re-entrant.
+ *   - process environment read by libffx_hip.so at every ffx_trace_primary / ffx_render_* call.  None of these
+ *     changes a result (tests/test_hip_parity.py runs every variant against the oracle); they select between
+ *     equivalent kernels / launch shapes and exist for A/B measurements:
+ *       FFX_TRAVERSAL=lane       per-lane kernels (LDS stack, apex vectors per ray) instead of the wave-packet kernels
+ *       FFX_WIDE=0               wave-packet kernels on the binary walk only (default: 64-wide walk with binary fallback)
+ *       FFX_PIXELS_PER_WAVE=1|2|4  pixels of a 2x2 tile one wavefront renders (default 2)
+ *       FFX_TILE_BLOCK=0..8      log2 side of the square blocks in which tiles are enumerated (default 3)
+ *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs (default 0: interleaved)
+ *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
+ *     The Python host layer reads FFX_LIB (alternative BUILD of this library), FFX_ASYNC_UPDATE=0 (single BVH blob,
+ *     refit on the caller's stream), FFX_CACHE_LIMIT_GB (per-sample adjoint cache budget), FFX_PREDRAW=0.
  */
 #ifndef FFX_H
 #define FFX_H
