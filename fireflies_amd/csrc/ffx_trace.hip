@@ -1601,13 +1601,36 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x_tb, int sub,
   }
 }
 
+// ---- adjoint cache (store instead of re-trace): what K9 needs of a pixel, written by K8.
+// The render is linear in the texture and the 64 samples of a pixel land on a handful of neighbouring texels
+// (measured: 87 % of the lit pixels within 4x4 texels, 99.5 % within 5x5), nearly always on ONE shape, so the
+// adjoint of a pixel is  gtex[T] += (gimg[p] . albedo[shape] (. colour)) / spp * W[T]  with the per-pixel
+// FOOTPRINT  W[T] = sum over its samples of fac * bilinear weight — 25 floats instead of 64 records of 16 B.
+//   [0, 64)              CacheHdr
+//   64 + 128 * pixel     CacheSlot: window origin, shape, the 5x5 footprint
+//   off_arena + 24 * i   CacheStray: single samples that do not fit (outside the window: depth discontinuities,
+//                        grazing surfaces; a second shape in the pixel; later 64-sample passes of a pixel that
+//                        drift), allocated with one atomic per affected wave
+// 39.8 MB at 512x512x64 (was 268 MB), of which K8 writes and K9 reads ~10 MB: unlit pixels carry a header only.
+struct CacheHdr { uint32_t n_stray, cap_stray, dropped, pad[13]; };
+struct __attribute__((aligned(16))) CacheSlot { int16_t x0, y0; uint16_t shape, lit; uint32_t pad[2]; float w[25]; uint32_t pad2[3]; };
+static_assert(sizeof(CacheSlot) == 128, "cache slot must be 128 bytes");
+struct CacheStray { uint32_t pix, xy_shape; float ax, ay, fac; uint32_t pad; }; // xy_shape = x0 | y0 << 12 ... see stray_pack
+static_assert(sizeof(CacheStray) == 24, "stray record must be 24 bytes");
+__host__ __device__ inline size_t cache_stray_capacity(int w, int h, int spp) {
+  const size_t n = (size_t)w * h * spp / 64;
+  return n < 4096 ? 4096 : n;
+}
+
 template <int R, bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    int fp16, void *__restrict__ img, uint4 *__restrict__ cache, int ppw) {
+                    int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw) {
   constexpr int NSUB = 4 / R;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
+  __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
+  static_assert(R == 1, "the adjoint cache is written one pixel at a time");
   FFX_TINIT();
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
@@ -1635,6 +1658,12 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       s_acc[r][0][threadIdx.x] = s_acc[r][1][threadIdx.x] = s_acc[r][2][threadIdx.x] = 0.f;
     }
     if (wballot(any_live) == 0ull) continue;
+    // adjoint cache: window origin (wave-uniform) and shape of this pixel's footprint, -1 until a sample is lit
+    int fox = -1, foy = -1, fshape = -1;
+    if (cache) {
+      if (lane < 32) s_foot[lane] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+    }
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -1655,15 +1684,45 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
       FFX_TSTOP(tk, 17);
       if (cache) {
-        // one 16-byte record per sample; the 64 lanes of a wave write 1 KiB contiguously
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if (!active[r]) continue;
-          uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-          if (st[r].hit && st[r].has_proj)
-            rec = make_uint4((uint32_t)(st[r].ubx + 1) | ((uint32_t)(st[r].uby + 1) << 12) | ((uint32_t)st[r].shape << 24), __float_as_uint(st[r].wx1),
-                             __float_as_uint(st[r].wy1), __float_as_uint(st[r].proj_fac));
-          cache[(size_t)pix[r] * (size_t)spp + (size_t)s] = rec;
+        // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
+        const bool lit = active[0] && st[0].hit && st[0].has_proj;
+        const wmask litm = wballot(lit);
+        if (litm != 0ull) {
+          if (fox < 0) { // first lit samples of the pixel: the window starts at their smallest tap
+            fox = (int)wave_reduce_nn<false>(lit ? (uint32_t)st[0].ix0 : 0xffffffffu);
+            foy = (int)wave_reduce_nn<false>(lit ? (uint32_t)st[0].iy0 : 0xffffffffu);
+            fshape = __builtin_amdgcn_readlane(st[0].shape, wff1(litm));
+          }
+          const bool in_win = lit && st[0].ix0 >= fox && st[0].ix1 <= fox + 4 && st[0].iy0 >= foy && st[0].iy1 <= foy + 4 && st[0].shape == fshape;
+          if (in_win) {
+            const float pf = st[0].proj_fac;
+            const int bx0 = st[0].ix0 - fox, bx1 = st[0].ix1 - fox, by0 = (st[0].iy0 - foy) * 5, by1 = (st[0].iy1 - foy) * 5;
+            atomicAdd(&s_foot[by0 + bx0], pf * st[0].wy0 * st[0].wx0);
+            atomicAdd(&s_foot[by0 + bx1], pf * st[0].wy0 * st[0].wx1);
+            atomicAdd(&s_foot[by1 + bx0], pf * st[0].wy1 * st[0].wx0);
+            atomicAdd(&s_foot[by1 + bx1], pf * st[0].wy1 * st[0].wx1);
+          }
+          const wmask straym = wballot(lit && !in_win);
+          if (straym != 0ull) { // single samples that do not fit the footprint: one allocation per wave
+            CacheHdr *hdr = reinterpret_cast<CacheHdr *>(cache);
+            const uint32_t n = (uint32_t)wpop(straym);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&hdr->n_stray, n);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t cap = hdr->cap_stray;
+            if (base + n <= cap) {
+              if (lit && !in_win) {
+                CacheStray *rec = reinterpret_cast<CacheStray *>(cache + 64 + (size_t)128 * (size_t)W * (size_t)H) + base + mbcnt64(straym);
+                rec->pix = pix[0];
+                rec->xy_shape = (uint32_t)(st[0].ubx + 1) | ((uint32_t)(st[0].uby + 1) << 12) | ((uint32_t)st[0].shape << 24);
+                rec->ax = st[0].wx1;
+                rec->ay = st[0].wy1;
+                rec->fac = st[0].proj_fac;
+              }
+            } else if (lane == 0) {
+              atomicAdd(&hdr->dropped, n); // arena exhausted (never seen: it holds 1/64 of all samples, strays are ~0.1 %)
+            }
+          }
         }
       }
       const ShadeK &ct = kernarg_shade(); // phase: texture gather and accumulation
@@ -1695,6 +1754,16 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         s_acc[r][1][threadIdx.x] += alb[1] * r1;
         s_acc[r][2][threadIdx.x] += alb[2] * r2;
       }
+    }
+    if (cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
+      __builtin_amdgcn_wave_barrier();
+      CacheSlot *slot = reinterpret_cast<CacheSlot *>(cache + 64) + pix[0];
+      if (lane == 0) {
+        slot->x0 = (int16_t)fox; slot->y0 = (int16_t)foy;
+        slot->shape = (uint16_t)(fshape < 0 ? 0 : fshape);
+        slot->lit = fox >= 0 ? 1 : 0;
+      }
+      if (fox >= 0 && lane < 25) slot->w[lane] = s_foot[lane];
     }
     // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
 #pragma unroll
@@ -1793,89 +1862,67 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   }
 }
 
-// K9 from the per-sample cache: a pure streaming kernel.  Each lane reads one 16-byte record (1 KiB per
-// wave-instruction, coalesced) and rebuilds the 4 bilinear taps.  The 64 lanes of a wave are 64
-// consecutive samples — at spp >= 64 all of ONE pixel — so their taps fall on a handful of texels:
-// issuing them as global float atomics serialises on the same addresses (measured 0.65 ms, 5 % of the
-// HBM rate).  Instead every wave accumulates into a private 16x16-texel LDS tile placed at the wave's
-// tap bounding box (ds_add_f32), then flushes ONE global atomic per touched texel.  Waves whose taps
-// span more than 16x16 texels (low spp, grazing projections) fall back to direct atomics.
+// K9 from the adjoint cache.  Part 1: 32 lanes per pixel slot — lane e < 25 scatters footprint weight e scaled by
+// the pixel's  gimg . albedo[shape] (. colour) / spp  with one global float atomic (a lit pixel touches ~16
+// texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
+// pixel slots): one lane per stray sample record, four taps each.
 struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; };
 
 __global__ void __launch_bounds__(256)
-    k_render_bwd_cached(const uint4 *__restrict__ cache, long total, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
+    k_render_bwd_cached(const char *__restrict__ cache, long n_pix, int slot_blocks, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
                         float *__restrict__ gtex) {
-  __shared__ float s_tile[4][256];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float *tile = s_tile[wave];
-  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) { // wave-uniform trip count
-    const long idx = base + threadIdx.x;
-    bool active = idx < total;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    if (active) rec = cache[idx];
-    const float fac = __uint_as_float(rec.w);
-    active = active && fac != 0.f;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (active) {
-      const long pix = idx / p.spp;
-      g0 = gimg[pix * 3]; g1 = gimg[pix * 3 + 1]; g2 = gimg[pix * 3 + 2];
-      active = !(g0 == 0.f && g1 == 0.f && g2 == 0.f);
-    }
-    if (wballot(active) == 0ull) continue;
-    const int ix0 = (int)(rec.x & 0xfffu) - 1, iy0 = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
-    const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
-    const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
-    const float wx0 = 1.0f - ax, wx1 = ax, wy0 = 1.0f - ay, wy1 = ay;
+  if ((int)blockIdx.x < slot_blocks) {
+    const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int e = threadIdx.x & 31;
+    if (pixel >= n_pix) return;
+    const CacheSlot *slot = reinterpret_cast<const CacheSlot *>(cache + 64) + pixel;
+    if (!slot->lit || e >= 25) return;
+    const float w = slot->w[e];
+    if (w == 0.f) return;
+    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+    const float *alb = albedo + 3 * (int)slot->shape;
+    const int x = (int)slot->x0 + e % 5, y = (int)slot->y0 + e / 5;
     if (p.tc == 1) {
-      float ws = 0.f;
-      if (active) {
-        const float *alb = albedo + 3 * shape;
-        ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * fac * p.inv_spp;
-      }
-      // The 64 lanes of a wave are (almost always) the 64 samples of one pixel: their taps fall on a
-      // handful of neighbouring texels.  They are summed in a private 16x16 LDS tile centred on the first
-      // active lane's tap (no wave-wide min/max reductions: those cost 24 cross-lane LDS operations per
-      // iteration) and flushed with one global atomic per touched texel; a tap outside the tile — a wave
-      // that straddles pixels far apart in the texture — goes to memory directly.
-      const unsigned long long am = wballot(active);
-      const int fl = __builtin_ctzll(am);
-      const int minx = __builtin_amdgcn_readlane(x0, fl) - 7, miny = __builtin_amdgcn_readlane(y0, fl) - 7;
-      const bool in_tile = active && x0 >= minx && x1 <= minx + 15 && y0 >= miny && y1 <= miny + 15;
+      const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
+      if (ws != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, ws * w);
+    } else {
+      float *t = gtex + ((size_t)y * p.tw + x) * 3;
+      if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * p.inv_spp * w);
+      if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * p.inv_spp * w);
+      if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * p.inv_spp * w);
+    }
+    return;
+  }
+  const CacheHdr *hdr = reinterpret_cast<const CacheHdr *>(cache);
+  const uint32_t n = min(hdr->n_stray, hdr->cap_stray);
+  const uint32_t i = (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x;
+  if (i >= n) return;
+  const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + 64 + (size_t)128 * (size_t)n_pix)[i];
+  const long pixel = rec.pix;
+  const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+  const int ix0 = (int)(rec.xy_shape & 0xfffu) - 1, iy0 = (int)((rec.xy_shape >> 12) & 0xfffu) - 1, shape = (int)(rec.xy_shape >> 24);
+  const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
+  const float wx0 = 1.0f - rec.ax, wx1 = rec.ax, wy0 = 1.0f - rec.ay, wy1 = rec.ay;
+  const float *alb = albedo + 3 * shape;
+  if (p.tc == 1) {
+    const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * rec.fac * p.inv_spp;
+    if (ws == 0.f) return;
+    atomicAdd(gtex + (size_t)y0 * p.tw + x0, ws * wy0 * wx0);
+    atomicAdd(gtex + (size_t)y0 * p.tw + x1, ws * wy0 * wx1);
+    atomicAdd(gtex + (size_t)y1 * p.tw + x0, ws * wy1 * wx0);
+    atomicAdd(gtex + (size_t)y1 * p.tw + x1, ws * wy1 * wx1);
+  } else {
+    const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3;
+    const size_t o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
+    const float gg[3] = {g0, g1, g2};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tile[lane + 64 * k] = 0.f;
-      __builtin_amdgcn_wave_barrier();
-      if (in_tile) {
-        atomicAdd(&tile[(y0 - miny) * 16 + (x0 - minx)], ws * wy0 * wx0);
-        atomicAdd(&tile[(y0 - miny) * 16 + (x1 - minx)], ws * wy0 * wx1);
-        atomicAdd(&tile[(y1 - miny) * 16 + (x0 - minx)], ws * wy1 * wx0);
-        atomicAdd(&tile[(y1 - miny) * 16 + (x1 - minx)], ws * wy1 * wx1);
-      } else if (active) {
-        atomicAdd(gtex + (size_t)y0 * p.tw + x0, ws * wy0 * wx0);
-        atomicAdd(gtex + (size_t)y0 * p.tw + x1, ws * wy0 * wx1);
-        atomicAdd(gtex + (size_t)y1 * p.tw + x0, ws * wy1 * wx0);
-        atomicAdd(gtex + (size_t)y1 * p.tw + x1, ws * wy1 * wx1);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = lane + 64 * k, ty = e >> 4, tx = e & 15;
-        const float v = tile[e];
-        if (v != 0.f) atomicAdd(gtex + (size_t)(miny + ty) * p.tw + (minx + tx), v); // only cells with in-range taps are non-zero
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else if (active) {
-      const float *alb = albedo + 3 * shape;
-      const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3;
-      const size_t o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
-      const float gg[3] = {g0, g1, g2};
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float ws = gg[ch] * alb[ch] * fac * p.inv_spp;
-        atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
-        atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
-        atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
-        atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
-      }
+    for (int ch = 0; ch < 3; ++ch) {
+      const float ws = gg[ch] * alb[ch] * rec.fac * p.inv_spp;
+      if (ws == 0.f) continue;
+      atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
+      atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
+      atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
+      atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
     }
   }
 }
@@ -2138,6 +2185,12 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
+  if (cache) { // header of the adjoint cache: stray-sample arena empty
+    CacheHdr h;
+    memset(&h, 0, sizeof h);
+    h.cap_stray = (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp);
+    if (hipMemcpyAsync(cache, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)s) != hipSuccess) FFX_FAIL(FFX_ERR_LAUNCH, "render_fwd_cache: header upload failed");
+  }
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
@@ -2152,10 +2205,10 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const WideScene ws = wide_scene(bvh, info);
     if (use_wide(info))
       hipLaunchKernelGGL((k_render_fwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw);
     else
       hipLaunchKernelGGL((k_render_fwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (uint4 *)cache, ppw);
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -2173,7 +2226,10 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, nullptr, s);
 }
 
-size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * 16; }
+size_t ffx_render_cache_bytes(int width, int height, int spp) {
+  if (width < 1 || height < 1 || spp < 1) return 0;
+  return 64 + (size_t)128 * width * height + sizeof(CacheStray) * cache_stray_capacity(width, height, spp);
+}
 
 int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
@@ -2190,9 +2246,10 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || sd->cam.width < 1 || sd->cam.height < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad scene description");
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];
   p.inv_spp = 1.0f / (float)spp;
-  long total = (long)sd->cam.width * sd->cam.height * spp;
-  int grid = (int)((total + 255) / 256 < 256 * 32 ? (total + 255) / 256 : 256 * 32); // <= 32 workgroups per CU, grid-stride
-  hipLaunchKernelGGL(k_render_bwd_cached, dim3(grid), dim3(256), 0, (hipStream_t)s, (const uint4 *)cache, total, p, gimg, shape_albedo, gtex);
+  const long n_pix = (long)sd->cam.width * sd->cam.height;
+  const int slot_blocks = ffx_cdiv(n_pix, 8), stray_blocks = ffx_cdiv((long)cache_stray_capacity(sd->cam.width, sd->cam.height, spp), 256);
+  hipLaunchKernelGGL(k_render_bwd_cached, dim3(slot_blocks + stray_blocks), dim3(256), 0, (hipStream_t)s, (const char *)cache, n_pix, slot_blocks, p, gimg,
+                     shape_albedo, gtex);
   FFX_CHECK_LAUNCH("render_bwd_cached");
   return FFX_OK;
 }

@@ -115,7 +115,7 @@ def gaussian_blur(img, ksize=5, sigma=3.0):
     return _Blur.apply(img, int(ksize), float(sigma))
 
 
-# renders whose per-sample cache would exceed this many bytes fall back to the re-tracing adjoint
+# renders whose adjoint cache would exceed this many bytes fall back to the re-tracing adjoint
 CACHE_LIMIT_BYTES = int(float(os.environ.get("FFX_CACHE_LIMIT_GB", "32")) * (1 << 30))
 
 
@@ -168,8 +168,8 @@ class _Render(torch.autograd.Function):
 
 def render(tex, geom, sd, albedo, spp, seed=0, fp16=False):
     """K8/K9: image [H,W,3], differentiable w.r.t. the projector texture ([h,w] or [h,w,c]).
-    When the texture requires grad the forward kernel also stores a 16-byte record per sample
-    (268 MB at 512x512x64) and the adjoint is a streaming pass over those records; beyond
+    When the texture requires grad the forward kernel also stores each pixel's footprint in the texture
+    (128 B per pixel + a small arena: 40 MB at 512x512x64) and the adjoint scatters those footprints; beyond
     FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
     forward and backward)."""
     return _Render.apply(tex, geom, sd, albedo, int(spp), int(seed), bool(fp16))

@@ -424,11 +424,11 @@ class DeviceGeometry:
 
     def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None):
         """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
-        16-byte record per sample for render_bwd_cached."""
+        footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h)."""
         H, W = sd.cam.height, sd.cam.width
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         if cache is not None:
-            if cache.numel() < W * H * int(spp) * 16:
+            if cache.numel() < render_cache_bytes(W, H, spp):
                 raise ValueError("cache tensor too small")
             with self._timed("render_fwd"):
                 self._call(
@@ -447,7 +447,7 @@ class DeviceGeometry:
         return img
 
     def render_bwd_cached(self, sd, albedo, cache, spp, gimg):
-        """K9 from the per-sample cache written by render_fwd(..., cache=...): a streaming kernel, no BVH."""
+        """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),

@@ -102,7 +102,7 @@ class PatternOptimizer:
         """One optimisation step over `samples_per_step` scene samples (sharded over ranks).
 
         Same arithmetic, kernels and summation order as `step_autograd` (the tests compare the two
-        trajectories), but every adjoint is called directly: K9 on the per-sample records, K3^T, K2-bwd,
+        trajectories), but every adjoint is called directly: K9 on the per-pixel footprints, K3^T, K2-bwd,
         K1-bwd.  The autograd version spends ~1.7 ms of host time per step on graph bookkeeping for
         ~1.2 ms of GPU work; this one keeps the GPU busy."""
         from . import ops

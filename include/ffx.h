@@ -292,16 +292,17 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                    float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
- * K8 + K9 with a per-sample cache (store instead of re-trace).
- * ffx_render_fwd_cache = ffx_render_fwd that additionally writes one 16-byte record per sample
- * (index (y*W + x)*spp + s):  word0 = (ix0+1) | (iy0+1) << 12 | shape << 24  (unclamped bilinear base
- * texel, projector textures up to 4094^2, up to 255 shapes), then the bilinear fractions ax, ay and
- * the geometric factor `fac` (0 when the sample receives no projector light).
- * ffx_render_bwd_cached streams those records and scatters d(loss)/d(img) * albedo * fac / spp
- * through the bilinear weights into gtex (accumulated; the caller zeroes it).  It needs neither the
- * BVH nor the camera: the geometry may be re-fitted between the forward and the backward pass.
- * HBM traffic per render: 16 B/sample written by the forward, read once by the adjoint
- * (268 MB at 512x512x64) instead of re-running the whole traversal.
+ * K8 + K9 with an adjoint cache (store instead of re-trace).
+ * ffx_render_fwd_cache = ffx_render_fwd that additionally writes what the adjoint needs into `cache`, an opaque
+ * caller-owned buffer of ffx_render_cache_bytes(...) bytes that only the library that wrote it can read.
+ * libffx_hip: per pixel the FOOTPRINT of its samples in the projector texture — window origin, shape and 5x5
+ * weights  W[T] = sum_s fac_s * bilinear weight_s(T)  (the render is linear in the texture, the samples of a pixel
+ * land on a handful of texels of one shape) — plus an arena of 24-byte records for the few samples that do not
+ * fit: 39.8 MB at 512x512x64, ~10 MB of it touched.  The oracle keeps one 16-byte record per
+ * sample.  ffx_render_bwd_cached scatters  gimg . albedo (. colour) / spp * W  into gtex (accumulated; the caller
+ * zeroes it).  It needs neither the BVH nor the camera: the geometry may be re-fitted between the forward and the
+ * backward pass (shape_albedo must still hold the forward's values).  Limits: projector textures up to 4094^2,
+ * up to 255 shapes (FFX_ERR_UNSUPPORTED otherwise: use ffx_render_bwd).
  * ---------------------------------------------------------------------------------------- */
 size_t ffx_render_cache_bytes(int width, int height, int spp);
 int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
