@@ -95,6 +95,10 @@ PROTOTYPES = {
     "ffx_transform_points": (c_i, [c_p, c_i, PF, c_i, c_p, c_p]),
     "ffx_l1_value_grad": (c_i, [c_p, c_p, C.c_long, C.c_float, c_p, c_p, c_p]),
     "ffx_clamp_to_fov": (c_i, [c_p, c_i, PF, PF, C.c_float, C.c_float, c_i, c_p]),
+    "ffx_pattern_ws_floats": (C.c_size_t, [c_i, c_i]),
+    "ffx_pattern_fwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
     "ffx_splat_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p, c_p]),

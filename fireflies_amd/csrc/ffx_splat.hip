@@ -481,6 +481,286 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   }
 }
 
+
+// =================================================================================== fused pattern side of an optimisation step
+// The pattern has 64..1024 points and the texture 500^2 texels: every kernel of the pattern side is launch-bound,
+// and as separate entry points one gradient step issued ~30 of them (~0.11 ms next to a 0.75 ms render).  Three
+// launches do the same arithmetic in the same order:
+//   k_pattern_fwd   K1 + K2(sum) + K2(softor) (+ the partial sums of the overlap regulariser L1(softor, sum))
+//   k_pattern_bwd   K2-bwd of the data term, of the regulariser's softor and sum terms, and K1-bwd of both
+//   k_adam_clamp    Adam + Laser.clamp_to_fov + normalize_rays
+__device__ __forceinline__ void project_xy(const float *__restrict__ rays, int k, const float *K, float &p0, float &p1) {
+  const float x = rays[3 * k], y = rays[3 * k + 1], z = rays[3 * k + 2];
+  const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+  const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+  const float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+  p0 = q0 / q3;
+  p1 = q1 / q3;
+}
+
+// one workgroup per 32x8 texel tile, like k_splat_fused_fwd (ordered compaction of the points that reach the tile:
+// every texel adds / multiplies in ascending point order); each texel keeps BOTH reductions of the same splat values.
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_fwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, int want_softor, float *__restrict__ pts,
+                  float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws) {
+  __shared__ float c_p0[CAND_MAX], c_p1[CAND_MAX];
+  __shared__ int c_count;
+  __shared__ float s_part[SPLAT_BLOCK / 64];
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+  const int j = j0 + (tid % TILE_W), i = i0 + (tid / TILE_W);
+  const float inv_sigma = 1.0f / sigma;
+  float acc_s = 0.f, acc_p = 1.f;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int chunk = 0; chunk < n; chunk += CAND_MAX) {
+    if (tid < 64) {
+      int count = 0;
+      const int lim = min(CAND_MAX, n - chunk);
+      for (int base = 0; base < lim; base += 64) {
+        const int k = chunk + base + tid;
+        bool keep = false;
+        float p0s = 0.f, p1s = 0.f;
+        if (base + tid < lim) {
+          float p0, p1;
+          project_xy(rays, k, KF.m, p0, p1);
+          if (first) { pts[2 * k] = p0; pts[2 * k + 1] = p1; }
+          p0s = p0 * (float)size0;
+          p1s = p1 * (float)size1;
+          const float dx = fmaxf(fmaxf((float)j0 - p0s, p0s - (float)(j0 + TILE_W - 1)), 0.f);
+          const float dy = fmaxf(fmaxf((float)i0 - p1s, p1s - (float)(i0 + TILE_H - 1)), 0.f);
+          keep = (dx * dx + dy * dy) * inv_sigma <= FFX_QCUT;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = count + __popcll(m & ((1ull << tid) - 1ull));
+        if (keep) { c_p0[pos] = p0s; c_p1[pos] = p1s; }
+        count += __popcll(m);
+      }
+      if (tid == 0) c_count = count;
+    }
+    __syncthreads();
+    const int cnt = c_count;
+    if (j < size0 && i < size1) {
+      for (int c = 0; c < cnt; ++c) {
+        float d, yd, xd;
+        const float v = splat_val((float)j, (float)i, c_p0[c], c_p1[c], sigma, inv_sigma, d, yd, xd);
+        acc_s += v;
+        acc_p *= (1.0f - v);
+      }
+    }
+    __syncthreads();
+  }
+  float l1 = 0.f;
+  if (j < size0 && i < size1) {
+    tsum[(size_t)i * size0 + j] = acc_s;
+    if (want_softor) {
+      const float so = 1.0f - acc_p;
+      tsor[(size_t)i * size0 + j] = so;
+      l1 = fabsf(so - acc_s);
+    }
+  }
+  if (want_softor) { // partial sum of |softor - sum| of this tile, fixed order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l1 += __shfl_down(l1, o, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = l1;
+    __syncthreads();
+    if (tid == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  }
+}
+
+// one workgroup per point over its non-zero footprint, like k_splat_bwd.  Data term: upstream gts on the SUM
+// texture.  Regulariser w * mean|softor - sum|: upstream gd = w * sign(softor - sum) / T on softor and -gd on
+// sum, i.e. per texel gd * (prod_{m != k}(1 - v_m) - 1) on this point's splat value.  fp64 partial sums; then
+// K1-bwd of both results (the chain through the perspective divide) by one lane.
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
+                  const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
+                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, float loss_div) {
+  __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
+  __shared__ int nb_count;
+  __shared__ double red[4][SPLAT_BLOCK / 64];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float inv_sigma = 1.0f / sigma;
+  float p0, p1;
+  project_xy(rays, k, KF.m, p0, p1);
+  const float p0s = p0 * (float)size0, p1s = p1 * (float)size1;
+  const float R = sqrtf(FFX_QCUT * sigma) + 1.0f;
+  const int lo0 = max(0, (int)floorf(p0s - R)), hi0 = min(size0, (int)ceilf(p0s + R) + 1);
+  const int lo1 = max(0, (int)floorf(p1s - R)), hi1 = min(size1, (int)ceilf(p1s + R) + 1);
+  const bool alive = hi0 > lo0 && hi1 > lo1;
+  const bool reg = reg_weight > 0.f && tsor != nullptr;
+  const bool use_list = reg && n <= NEIGH_MAX;
+  if (use_list) {
+    if (tid < 64) {
+      int count = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int m = base + tid;
+        bool keep = false;
+        float q0 = 0.f, q1 = 0.f;
+        if (m < n && m != k) {
+          float a, b;
+          project_xy(rays, m, KF.m, a, b);
+          q0 = a * (float)size0;
+          q1 = b * (float)size1;
+          keep = fabsf(q0 - p0s) <= 2.f * R + 2.f && fabsf(q1 - p1s) <= 2.f * R + 2.f;
+        }
+        const unsigned long long mk = __ballot(keep);
+        const int pos = count + __popcll(mk & ((1ull << tid) - 1ull));
+        if (keep) { nb_p0[pos] = q0; nb_p1[pos] = q1; }
+        count += __popcll(mk);
+      }
+      if (tid == 0) nb_count = count;
+    }
+    __syncthreads();
+  }
+  const float gscale = reg_weight / ((float)size0 * (float)size1);
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (alive) {
+    const int rw = hi0 - lo0, rh = hi1 - lo1;
+    for (int t = tid; t < rw * rh; t += SPLAT_BLOCK) {
+      const int j = lo0 + t % rw, i = lo1 + t / rw;
+      float d, yd, xd;
+      const float v = splat_val((float)j, (float)i, p0s, p1s, sigma, inv_sigma, d, yd, xd);
+      if (v == 0.f) continue;
+      const size_t T = (size_t)i * size0 + j;
+      const float cf = splat_gcoef(v, d, sigma);
+      if (gts) {
+        const float w = gts[T];
+        a0 += (double)(w * (cf * yd));
+        a1 += (double)(w * (cf * xd));
+      }
+      if (reg) {
+        const float df = tsor[T] - tsum[T];
+        const float gd = df > 0.f ? gscale : (df < 0.f ? -gscale : 0.f);
+        if (gd != 0.f) {
+          float prod = 1.f;
+          const int cnt = use_list ? nb_count : n;
+          for (int c = 0; c < cnt; ++c) {
+            float q0, q1;
+            if (use_list) { q0 = nb_p0[c]; q1 = nb_p1[c]; }
+            else {
+              if (c == k) continue;
+              float a, b;
+              project_xy(rays, c, KF.m, a, b);
+              q0 = a * (float)size0; q1 = b * (float)size1;
+            }
+            float dd, y2, x2;
+            prod *= (1.0f - splat_val((float)j, (float)i, q0, q1, sigma, inv_sigma, dd, y2, x2));
+          }
+          // softor term (gd * prod) and sum term (-gd), each rounded like the separate kernels, summed in fp64
+          b0 += (double)((gd * prod) * (cf * yd)) - (double)(gd * (cf * yd));
+          b1 += (double)((gd * prod) * (cf * xd)) - (double)(gd * (cf * xd));
+        }
+      }
+    }
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); b0 = wave_sum(b0); b1 = wave_sum(b1);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; red[2][tid >> 6] = b0; red[3][tid >> 6] = b1; }
+  __syncthreads();
+  if (tid == 0) {
+    double sres[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      for (int w = 0; w < SPLAT_BLOCK / 64; ++w) sres[c] += red[c][w];
+    // K1-bwd (k_project_bwd) with gpts = (g0, g1, 0)
+    const float x = rays[3 * k], y = rays[3 * k + 1], z = rays[3 * k + 2];
+    const float *K = KF.m;
+    float q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = K[4 * r] * x + K[4 * r + 1] * y + K[4 * r + 2] * z + K[4 * r + 3];
+    const float iw = 1.0f / q[3];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      float *out = part == 0 ? grays_data : grays_reg;
+      if (!out) continue;
+      const float g0 = (float)sres[2 * part] * (float)size0, g1 = (float)sres[2 * part + 1] * (float)size1;
+      float gq[4];
+      gq[0] = g0 * iw;
+      gq[1] = g1 * iw;
+      gq[2] = 0.f * iw;
+      float acc = 0.f;
+      acc += g0 * q[0];
+      acc += g1 * q[1];
+      acc += 0.f * q[2];
+      gq[3] = -acc * iw * iw;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[3 * k + c] = gq[0] * K[c] + gq[1] * K[4 + c] + gq[2] * K[8 + c] + gq[3] * K[12 + c];
+    }
+  }
+  if (k == 0 && reg_value) { // value of the regulariser from the forward's per-tile partial sums (fixed order)
+    float acc = 0.f;
+    for (int t = tid; t < n_ws; t += SPLAT_BLOCK) acc += ws[t];
+    __shared__ float s_v[SPLAT_BLOCK / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) s_v[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      const float rv = reg ? ((s_v[0] + s_v[1]) + (s_v[2] + s_v[3])) * gscale : 0.f;
+      reg_value[0] = rv;
+      if (loss_in) reg_value[1] = loss_in[0] / loss_div + rv; // the step's total loss: data term / S + regulariser
+    }
+  }
+}
+
+// Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the
+// step count kept on the device) followed by Laser.clamp_to_fov + normalize_rays on the updated ray: one launch.
+__global__ void __launch_bounds__(256)
+    k_adam_clamp(float *__restrict__ rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a, float *__restrict__ grad_out,
+                 float *__restrict__ m, float *__restrict__ v, float *__restrict__ step, int n, double lr, double beta1, double beta2, double eps_d, Mat4 KF, Mat4 KI, float lo, float hi, int n_norm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float t = step[0] + 1.0f;
+  if (i < n) {
+    // the scalars as torch forms them: in double from the Python floats, rounded to float where they meet the tensors
+    const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
+    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+    const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float g = grad[3 * i + c];
+      if (grad_out) { // g = grad / S + grad_b, rounded like the two torch ops it replaces; kept as the parameter's .grad
+        if (scale_a != 1.0f) g = g / scale_a;
+        if (grad_b) g = g + grad_b[3 * i + c];
+        grad_out[3 * i + c] = g;
+      }
+      float mm = m[3 * i + c], vv = v[3 * i + c];
+      mm = mm + omb1 * (g - mm);
+      vv = b2 * vv + omb2 * g * g;
+      m[3 * i + c] = mm;
+      v[3 * i + c] = vv;
+      const float denom = sqrtf(vv) / bc2s + eps;
+      r[c] = rays[3 * i + c] - step_size * mm / denom;
+    }
+    float x = r[0], y = r[1], z = r[2];
+    const float *K = KF.m;
+    const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+    const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+    const float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
+    const float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+    float px = q0 / q3, py = q1 / q3, pz = q2 / q3;
+    px = fminf(fmaxf(px, lo), hi);
+    py = fminf(fmaxf(py, lo), hi);
+    const float *I = KI.m;
+    const float w0 = I[0] * px + I[1] * py + I[2] * pz + I[3];
+    const float w1 = I[4] * px + I[5] * py + I[6] * pz + I[7];
+    const float w2 = I[8] * px + I[9] * py + I[10] * pz + I[11];
+    const float w3 = I[12] * px + I[13] * py + I[14] * pz + I[15];
+    x = w0 / w3; y = w1 / w3; z = w2 / w3;
+    for (int k = 0; k < n_norm; ++k) {
+      const float nrm = sqrtf(x * x + y * y + z * z);
+      x /= nrm; y /= nrm; z /= nrm;
+    }
+    rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
+  }
+  // every lane has read the step count: the last workgroup to get here... (one workgroup covers up to 256 rays;
+  // with more rays the count must not be bumped before every workgroup has read it: the host passes it instead)
+  if (gridDim.x == 1) {
+    __syncthreads();
+    if (threadIdx.x == 0) step[0] = t;
+  }
+}
+__global__ void k_bump_step(float *step) { step[0] += 1.0f; }
+
 // =================================================================================== K3 blur
 // (ksize x ksize) Gaussian, reflect border.  One workgroup per 32x8 output tile, halo staged in LDS.
 struct BlurW { float w[15]; int ksize; };
@@ -600,6 +880,53 @@ int ffx_l1_value_grad(const float *a, const float *b, long n, float weight, floa
   hipLaunchKernelGGL(k_l1_partial, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, n, weight / (float)n, ws, g);
   hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(256), 0, (hipStream_t)s, ws, blocks, weight / (float)n);
   FFX_CHECK_LAUNCH("l1_value_grad");
+  return FFX_OK;
+}
+
+
+size_t ffx_pattern_ws_floats(int size0, int size1) {
+  if (size0 < 1 || size1 < 1) return 0;
+  return (size_t)ffx_cdiv(size0, TILE_W) * ffx_cdiv(size1, TILE_H);
+}
+
+int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
+                    float *ws, ffx_stream s) {
+  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)))
+    FFX_FAIL(FFX_ERR_ARG, "pattern_fwd: bad argument");
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  dim3 grid(ffx_cdiv(size0, TILE_W), ffx_cdiv(size1, TILE_H));
+  hipLaunchKernelGGL(k_pattern_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, want_softor, pts, tsum, tsor, ws);
+  FFX_CHECK_LAUNCH("pattern_fwd");
+  return FFX_OK;
+}
+
+int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts,
+                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, float loss_div, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)))
+    FFX_FAIL(FFX_ERR_ARG, "pattern_bwd: bad argument");
+  if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_bwd: more than 65535 points");
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  hipLaunchKernelGGL(k_pattern_bwd, dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws,
+                     (int)ffx_pattern_ws_floats(size0, size1), gts ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in,
+                     loss_div > 0.f ? loss_div : 1.0f);
+  FFX_CHECK_LAUNCH("pattern_bwd");
+  return FFX_OK;
+}
+
+int ffx_adam_clamp_step(float *rays, const float *grad, const float *grad_b, float grad_div, float *grad_out, float *exp_avg, float *exp_avg_sq, float *step, int n,
+                        double lr, double beta1, double beta2, double eps, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {
+  if ((grad_b || grad_div != 1.0f) && !grad_out) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: combining gradients needs grad_out");
+  if (!(grad_div > 0.f)) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: grad_div must be positive");
+  if (!rays || !grad || !exp_avg || !exp_avg_sq || !step || !KF || !KF_inv || n < 1 || n_normalize < 0 || !(lo <= hi)) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: bad argument");
+  Mat4 a, b;
+  for (int i = 0; i < 16; ++i) { a.m[i] = KF[i]; b.m[i] = KF_inv[i]; }
+  const int blocks = ffx_cdiv(n, 256);
+  hipLaunchKernelGGL(k_adam_clamp, dim3(blocks), dim3(256), 0, (hipStream_t)s, rays, grad, grad_b, grad_div, grad_out, exp_avg, exp_avg_sq, step, n, lr, beta1,
+                     beta2, eps, a, b, lo, hi, n_normalize);
+  if (blocks > 1) hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(1), 0, (hipStream_t)s, step);
+  FFX_CHECK_LAUNCH("adam_clamp_step");
   return FFX_OK;
 }
 

@@ -1980,8 +1980,10 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
 // be stream-ordered, as they already are for the records themselves).  53 k triangles x 3 apexes: 7.7 MB.
 struct ApexK { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; };
 __global__ void __launch_bounds__(256)
-    k_apex_records(const TriRec *__restrict__ recs, int n_tris, ApexK ak, TriApex *__restrict__ out, uint32_t astride) {
+    k_apex_records(const TriRec *__restrict__ recs, int n_tris, ApexK ak, TriApex *__restrict__ out, uint32_t astride, uint32_t *__restrict__ cache_hdr,
+                   uint32_t cap_stray) {
   const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k == 0 && cache_hdr) { cache_hdr[0] = 0u; cache_hdr[1] = cap_stray; cache_hdr[2] = 0u; } // adjoint cache: stray arena empty (CacheHdr)
   if (k >= n_tris) return;
   const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
   const float4 a = r4[0], b = r4[1], c = r4[2];
@@ -2052,7 +2054,7 @@ static size_t dummy_lds() {
 
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
 static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *cam_to_world, const ffx_scene_desc *sd, const TriApex **arecs,
-                       uint32_t *astride, hipStream_t s) {
+                       uint32_t *astride, hipStream_t s, void *cache = nullptr, uint32_t cap_stray = 0) {
   ApexK ak;
   memset(&ak, 0, sizeof ak);
   ak.on[0] = 1;
@@ -2072,7 +2074,7 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   }
   TriApex *out = (TriApex *)((char *)bvh + ffx_apex_offset(info, 0));
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
-  hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride);
+  hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
   *arecs = out;
   *astride = (uint32_t)stride;
   return 1;
@@ -2185,12 +2187,6 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
-  if (cache) { // header of the adjoint cache: stray-sample arena empty
-    CacheHdr h;
-    memset(&h, 0, sizeof h);
-    h.cap_stray = (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp);
-    if (hipMemcpyAsync(cache, &h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)s) != hipSuccess) FFX_FAIL(FFX_ERR_LAUNCH, "render_fwd_cache: header upload failed");
-  }
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
@@ -2201,7 +2197,8 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
-    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u))
+      return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
     if (use_wide(info))
       hipLaunchKernelGGL((k_render_fwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,

@@ -107,6 +107,52 @@ def clamp_to_fov_(rays, KF, KF_inv, lo, hi, n_normalize=1):
     return rays
 
 
+# ------------------------------------------------------------------ fused pattern side of an optimisation step
+def pattern_ws_floats(size0, size1):
+    return int(api().lib.ffx_pattern_ws_floats(int(size0), int(size1)))
+
+
+def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True, out=None):
+    """K1 + K2(sum) + K2(softor) + partial sums of L1(softor, sum) in one launch -> (pts [n,2], tsum, tsor, ws).
+    `out`: optional tuple of tensors to reuse."""
+    n = rays.shape[0]
+    if out is None:
+        pts = torch.empty((n, 2), dtype=torch.float32, device=rays.device)
+        tsum = torch.empty((size1, size0), dtype=torch.float32, device=rays.device)
+        tsor = torch.empty((size1, size0), dtype=torch.float32, device=rays.device) if want_softor else None
+        ws = torch.empty(pattern_ws_floats(size0, size1), dtype=torch.float32, device=rays.device) if want_softor else None
+    else:
+        pts, tsum, tsor, ws = out
+    api().call("ffx_pattern_fwd", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), int(bool(want_softor)), _dev(pts), _dev(tsum),
+               _dev(tsor) if want_softor else None, _dev(ws) if want_softor else None, _stream())
+    return pts, tsum, tsor, ws
+
+
+def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, loss_in=None, loss_div=1.0):
+    """K2-bwd of the data term (gts on the sum texture) and of reg_weight * L1(softor, sum), each through K1-bwd, in
+    one launch -> (grays_data or None, grays_reg or None, [2] tensor: regulariser value, and loss_in / loss_div +
+    regulariser if the 0-dim tensor `loss_in` is given)"""
+    n = rays.shape[0]
+    gd = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if gts is not None else None
+    gr = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if reg_weight > 0 else None
+    val = torch.empty(2, dtype=torch.float32, device=rays.device)
+    api().call("ffx_pattern_bwd", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), _dev(tsum, name="tsum"),
+               _dev(tsor, name="tsor") if tsor is not None else None, _dev(gts, name="gts") if gts is not None else None, float(reg_weight),
+               _dev(ws, name="ws") if ws is not None else None, _dev(gd) if gd is not None else None, _dev(gr) if gr is not None else None, _dev(val),
+               _dev(loss_in, name="loss_in") if loss_in is not None else None, float(loss_div), _stream())
+    return gd, gr, val
+
+
+def adam_clamp_step_(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, grad_b=None, grad_div=1.0, grad_out=None):
+    """in place: torch.optim.Adam's update of `rays` followed by Laser.clamp_to_fov + normalisation, one launch.
+    With grad_out the gradient used is grad / grad_div + grad_b (stored in grad_out)."""
+    api().call("ffx_adam_clamp_step", _dev(rays, name="rays"), _dev(grad, name="grad"), _dev(grad_b, name="grad_b") if grad_b is not None else None, float(grad_div),
+               _dev(grad_out, name="grad_out") if grad_out is not None else None, _dev(exp_avg, name="exp_avg"), _dev(exp_avg_sq, name="exp_avg_sq"),
+               _dev(step, name="step"), rays.shape[0], float(lr), float(beta1), float(beta2), float(eps), _m16(KF), _m16(KF_inv), float(lo), float(hi),
+               int(n_normalize), _stream())
+    return rays
+
+
 # ------------------------------------------------------------------ K2
 def _check_pts(pts):
     if pts.dim() != 2 or pts.shape[1] != 2:
@@ -446,9 +492,10 @@ class DeviceGeometry:
         self._release()
         return img
 
-    def render_bwd_cached(self, sd, albedo, cache, spp, gimg):
-        """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH."""
-        gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
+    def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None):
+        """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
+        `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one."""
+        gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
                        _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx))

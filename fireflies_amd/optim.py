@@ -32,19 +32,35 @@ def coverage_loss(img):
 _COVERAGE_GRAD = {}
 
 
-def _coverage_value_and_grad(img):
-    """coverage_loss and its (constant) gradient without an autograd graph."""
+def _coverage_grad(img):
     key = (tuple(img.shape), img.device)
     g = _COVERAGE_GRAD.get(key)
     if g is None:
         g = torch.zeros(img.shape, dtype=torch.float32, device=img.device)
         g[..., 1] = -1.0 / float(img.shape[0] * img.shape[1])
         _COVERAGE_GRAD[key] = g
-    return -img[..., 1].float().mean(), g
+    return g
 
 
-# a task loss may carry `value_and_grad(img) -> (loss, d loss / d img)`; otherwise autograd is used for it
+def _coverage_value_and_grad(img):
+    """coverage_loss and its (constant) gradient without an autograd graph."""
+    return -img[..., 1].float().mean(), _coverage_grad(img)
+
+
+_coverage_value_and_grad.__wrapped_grad__ = _coverage_grad
+
+
+def _coverage_accumulate(img, acc):
+    """acc += coverage_loss(img) (two launches: reduction, subtract) -> its constant gradient"""
+    g = _coverage_value_and_grad.__wrapped_grad__(img)
+    acc.sub_(img[..., 1].mean(dtype=torch.float32))
+    return g
+
+
+# a task loss may carry `value_and_grad(img) -> (loss, d loss / d img)` and `accumulate_value_and_grad(img, acc) -> d loss / d img`
+# (adds the value to the 0-dim tensor `acc`); otherwise autograd is used for it
 coverage_loss.value_and_grad = _coverage_value_and_grad
+coverage_loss.accumulate_value_and_grad = _coverage_accumulate
 
 
 class PatternOptimizer:
@@ -97,14 +113,31 @@ class PatternOptimizer:
         (g,) = torch.autograd.grad(loss, leaf)
         return loss.detach(), g
 
+    def _adam_state(self, rays):
+        """exp_avg / exp_avg_sq / step of torch.optim.Adam for `rays` (created like Adam._init_group does), so that
+        step() and step_autograd() — and anything that inspects self.opt — share one optimiser state"""
+        st = self.opt.state[rays]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=rays.device)
+            st["exp_avg"] = torch.zeros_like(rays, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(rays, memory_format=torch.preserve_format)
+        g = self.opt.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            raise NotImplementedError("PatternOptimizer.step: plain Adam only (use step_autograd for other settings)")
+        if not (isinstance(st["step"], torch.Tensor) and st["step"].is_cuda):
+            st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=rays.device)
+        return st, g
+
     @torch.no_grad()
     def step(self):
         """One optimisation step over `samples_per_step` scene samples (sharded over ranks).
 
         Same arithmetic, kernels and summation order as `step_autograd` (the tests compare the two
-        trajectories), but every adjoint is called directly: K9 on the per-pixel footprints, K3^T, K2-bwd,
-        K1-bwd.  The autograd version spends ~1.7 ms of host time per step on graph bookkeeping for
-        ~1.2 ms of GPU work; this one keeps the GPU busy."""
+        trajectories), but every adjoint is called directly and the pattern side is three fused launches:
+        ffx_pattern_fwd (K1 + K2 sum + K2 softor + the regulariser's partial sums), ffx_pattern_bwd (K2-bwd of the
+        data and regulariser terms + K1-bwd) and ffx_adam_clamp_step (Adam + clamp_to_fov + normalize_rays); K9
+        accumulates every sample's texture gradient into one buffer.  As ~30 separate launches the pattern side
+        cost 0.11 ms per step next to a 0.75 ms render; through torch.autograd the step was host-bound."""
         from . import ops
 
         rays = self.laser._rays
@@ -113,14 +146,19 @@ class PatternOptimizer:
         S = self.samples_per_step
         r, w = dist.rank(), dist.world_size()
         geom, ms = self.mi_scene.geom, self.mi_scene
-        # pattern -> texture (K1, K2, K3)
+        want_reg = self.reg_weight > 0
         rd = rays.detach()
-        pts = ops.project_rays_fwd(rd, KF)[:, 0:2].contiguous()
-        tsum = ops.splat_fwd(pts, self.sigma, "sum", -1, s0, s1)
+        # pattern -> texture (K1, K2, K3)
+        buf = getattr(self, "_pat_buf", None)
+        if buf is None or buf[0].shape[0] != rd.shape[0] or tuple(buf[1].shape) != (s1, s0) or (buf[2] is None) == want_reg:
+            buf = None
+        pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf)
         tex = ops.blur_fwd(tsum, self.blur[0], self.blur[1]) if self.blur else tsum
         tex3 = tex.unsqueeze(-1)
-        gtex = None
-        loss_sum = torch.zeros((), device=tex.device)
+        if getattr(self, "_acc", None) is None or self._acc.numel() != tex3.numel() + 1:
+            self._acc = torch.empty(tex3.numel() + 1, dtype=torch.float32, device=tex.device)  # texture gradient + loss: one fill
+        self._acc.zero_()
+        gtex, loss_sum = self._acc[:-1].view(tex3.shape), self._acc[-1]
         # this rank's scene samples: all their random draws up front (each under its own seed, as
         # manual_seed(s); randomize() would make them), ONE device-to-host transfer for the lot
         seeds = self._sample_seeds(self.step_index)
@@ -139,6 +177,7 @@ class PatternOptimizer:
         if self.ff_scene._draw_stream() is not None:  # (host-side draws of CPU entities have nothing to wait for)
             nxt = self._sample_seeds(self.step_index + 1)
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
+        fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
@@ -147,42 +186,39 @@ class PatternOptimizer:
             if use_cache and (self._cache is None or self._cache.numel() != nbytes):
                 self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
             img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None)
-            with torch.enable_grad():
-                l, gimg = self._loss_and_grad(img)
-            gimg = gimg.float().contiguous()
-            if use_cache:
-                g = geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, gimg)
+            if fast_loss is not None:
+                gimg = fast_loss(img, loss_sum)
             else:
-                g = geom.render_bwd(sd, ms.albedo, self.spp, seed, gimg)
-            g = g.reshape(tex.shape)
-            gtex = g if gtex is None else gtex + g
-            loss_sum = loss_sum + l
-        # back through K3^T, K2-bwd, K1-bwd for this rank's share
-        if gtex is None:
-            grays = torch.zeros_like(rd)
-        else:
-            gts = ops.blur_bwd(gtex, self.blur[0], self.blur[1]) if self.blur else gtex
-            gp = ops.splat_bwd(pts, self.sigma, "sum", -1, s0, s1, tsum, gts)
-            grays = ops.project_rays_bwd(rd, KF, torch.nn.functional.pad(gp, (0, 1)))
+                with torch.enable_grad():
+                    l, gimg = self._loss_and_grad(img)
+                loss_sum += l
+                gimg = gimg.float().contiguous()
+            if use_cache:
+                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, gimg, out=gtex)
+            else:
+                gtex += geom.render_bwd(sd, ms.albedo, self.spp, seed, gimg).reshape(gtex.shape)
+        # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
+        gts = None
+        if seeds:
+            g2 = gtex.reshape(tex.shape)
+            gts = ops.blur_bwd(g2, self.blur[0], self.blur[1]) if self.blur else g2
+        reg_w = self.reg_weight if want_reg else 0.0
+        st, g = self._adam_state(rays)
+        grad = torch.empty_like(rd)
         if w > 1:
-            flat = torch.cat([grays.reshape(-1), loss_sum.reshape(1)])
-            dist.allreduce_sum_(flat)
-            flat /= float(S)
-            grad = flat[:-1].reshape(rays.shape).clone()
-            loss = flat[-1]
-        else:  # nothing to exchange: skip the pack / unpack launches
-            grad = grays if S == 1 else grays / float(S)
-            loss = loss_sum if S == 1 else loss_sum / float(S)
-        if self.reg_weight > 0:  # identical on every rank (depends on the pattern only)
-            tsor = ops.splat_fwd(pts, self.sigma, "softor", -1, s0, s1)
-            # reg = w * L1Loss(softor, sum) and d reg / d softor in two launches; d reg / d sum is its negative
-            reg, gd = ops.l1_value_grad(tsor, tsum, self.reg_weight)
-            gp = ops.splat_bwd(pts, self.sigma, "softor", -1, s0, s1, tsor, gd) - ops.splat_bwd(pts, self.sigma, "sum", -1, s0, s1, tsum, gd)
-            grad += ops.project_rays_bwd(rd, KF, torch.nn.functional.pad(gp, (0, 1)))
-            loss = loss + reg
+            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws)
+            flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), loss_sum.reshape(1)])
+            dist.allreduce_sum_(flat)  # the ONE exchange of a step: [3N + 1] floats
+            gsum = flat[:-1].reshape(rays.shape).contiguous()
+            loss = flat[-1] / float(S) + val[0]
+        else:  # nothing to exchange: the total loss comes out of the backward launch, the gradient parts meet in the update launch
+            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_sum, loss_div=float(S))
+            gsum = gd if gd is not None else torch.zeros_like(rd)
+            loss = val[1]
+        # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()
+        ops.adam_clamp_step_(rd, gsum, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], KF, self.laser._KF_inv,
+                             1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad)
         rays.grad = grad
-        self.opt.step()
-        self.laser.clamp_to_fov(then_normalize=True)  # clamp_to_fov() + normalize_rays() in one launch
         self.step_index += 1
         return {"loss": loss}
 

@@ -150,6 +150,37 @@ int ffx_l1_value_grad(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, 
                       float *ws /*[dev][257]*/, float *g /*[dev][n]*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The pattern side of one optimisation step, fused (the loop of rasterization.py:583-607 with the projector in
+ * front: Laser.projectRaysToNDC laser.py:262-275 -> rasterize_points + sum / softor rasterization.py:7-37,156-161
+ * -> L1Loss(softor, sum) :589-600 -> backward -> Adam -> Laser.clamp_to_fov / normalize_rays laser.py:199-206,
+ * 254-255).  Same arithmetic and summation order as the separate entry points above; a 64..1024-point pattern
+ * makes every one of those launch-bound.
+ *   ffx_pattern_fwd : pts = (KF rays).xy / w;  tsum = sum_n v_n;  tsor = 1 - prod_n (1 - v_n) (if want_softor),
+ *                     ws[ffx_pattern_ws_floats(size0, size1)] = partial sums of |tsor - tsum| (any partition).
+ *   ffx_pattern_bwd : grays_data = d/d rays of <gts, tsum>  (gts = upstream gradient on the SUM texture; NULL: skipped);
+ *                     grays_reg  = d/d rays of reg_weight * mean|tsor - tsum|;  reg_value[0] = that value and, if
+ *                     loss_in is given, reg_value[1] = loss_in[0] / loss_div + reg_value[0] (the step's total loss).
+ *   ffx_adam_clamp_step : g = grad / grad_div + grad_b (grad_b may be NULL; g is stored in grad_out, which may be NULL
+ *                     if there is nothing to combine), then torch.optim.Adam's update of rays with (exp_avg,
+ *                     exp_avg_sq, step [dev][1], incremented; lr / betas / eps as the doubles torch holds), then
+ *                     ffx_clamp_to_fov(rays, ..., n_normalize) — one launch.
+ * ---------------------------------------------------------------------------------------- */
+size_t ffx_pattern_ws_floats(int size0, int size1);
+int ffx_pattern_fwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
+                    int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,
+                    float *tsor /*[dev][size1,size0] or NULL*/, float *ws /*[dev] or NULL*/, ffx_stream stream);
+int ffx_pattern_bwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
+                    const float *tsum /*[dev]*/, const float *tsor /*[dev] or NULL*/, const float *gts /*[dev] or NULL*/,
+                    float reg_weight, const float *ws /*[dev] or NULL*/, float *grays_data /*[dev][n,3] or NULL*/,
+                    float *grays_reg /*[dev][n,3] or NULL*/, float *reg_value /*[dev][2] or NULL*/,
+                    const float *loss_in /*[dev][1] or NULL*/, float loss_div, ffx_stream stream);
+int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[dev][n,3]*/, const float *grad_b /*[dev][n,3] or NULL*/,
+                        float grad_div, float *grad_out /*[dev][n,3] or NULL*/, float *exp_avg /*[dev][n,3]*/,
+                        float *exp_avg_sq /*[dev][n,3]*/, float *step /*[dev][1]*/, int n, double lr, double beta1, double beta2,
+                        double eps, const float *KF /*[host][16]*/, const float *KF_inv /*[host][16]*/, float lo, float hi,
+                        int n_normalize, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * K3  texture finalise: separable Gaussian blur, reflect border.
  * Replaces kornia.filters.gaussian_blur2d(tex, (k,k), (s,s)) at
  * examples/vocalfold_scene.py:61-63 and main.py:69-71 (k = 5, s = 3).  ksize odd, <= 15.

@@ -1210,3 +1210,106 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   free(acc);
   return FFX_OK;
 }
+
+/* =========================================================================================
+ * The pattern side of one optimisation step as ONE call each way (include/ffx.h): restated by composing the entry
+ * points above — which each follow the reference line by line — so that the fused HIP kernels are checked against
+ * the unfused arithmetic.  Adam: torch.optim.Adam (torch/optim/adam.py, _single_tensor_adam / the fused functor):
+ *   m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ * ========================================================================================= */
+size_t ffx_pattern_ws_floats(int size0, int size1) {
+  if (size0 < 1 || size1 < 1) return 0;
+  return (size_t)((size0 + 31) / 32) * (size_t)((size1 + 7) / 8);
+}
+
+int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
+                    float *ws, ffx_stream s) {
+  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)))
+    FAIL(FFX_ERR_ARG, "pattern_fwd: bad argument");
+  float *p3 = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+  if (!p3) FAIL(FFX_ERR_NOMEM, "pattern_fwd: out of memory");
+  int rc = ffx_project_rays_fwd(rays, n, KF, p3, s);
+  for (int i = 0; i < n; ++i) { pts[2 * i] = p3[3 * i]; pts[2 * i + 1] = p3[3 * i + 1]; }
+  free(p3);
+  if (rc) return rc;
+  if ((rc = ffx_splat_fwd(pts, n, sigma, FFX_REDUCE_SUM, -1, size0, size1, tsum, s))) return rc;
+  if (want_softor) {
+    if ((rc = ffx_splat_fwd(pts, n, sigma, FFX_REDUCE_SOFTOR, -1, size0, size1, tsor, s))) return rc;
+    const size_t nw = ffx_pattern_ws_floats(size0, size1), T = (size_t)size0 * size1;
+    double acc = 0.0;
+    for (size_t t = 0; t < T; ++t) acc += fabs((double)(tsor[t] - tsum[t]));
+    for (size_t t = 0; t < nw; ++t) ws[t] = 0.f;
+    ws[0] = (float)acc;
+  }
+  return FFX_OK;
+}
+
+int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts,
+                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, float loss_div, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)))
+    FAIL(FFX_ERR_ARG, "pattern_bwd: bad argument");
+  const size_t T = (size_t)size0 * size1;
+  float *p3 = (float *)malloc(sizeof(float) * 3 * (size_t)n), *pts = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+  float *gp = (float *)malloc(sizeof(float) * 2 * (size_t)n), *gp2 = (float *)malloc(sizeof(float) * 2 * (size_t)n), *g3 = (float *)calloc(3 * (size_t)n, sizeof(float));
+  float *gd = (reg_weight > 0.f) ? (float *)malloc(sizeof(float) * T) : NULL;
+  int rc = FFX_OK;
+  if (!p3 || !pts || !gp || !gp2 || !g3 || (reg_weight > 0.f && !gd)) { rc = FFX_ERR_NOMEM; snprintf(g_err, sizeof g_err, "pattern_bwd: out of memory"); goto done; }
+  if ((rc = ffx_project_rays_fwd(rays, n, KF, p3, s))) goto done;
+  for (int i = 0; i < n; ++i) { pts[2 * i] = p3[3 * i]; pts[2 * i + 1] = p3[3 * i + 1]; }
+  if (gts) {
+    if ((rc = ffx_splat_bwd(pts, n, sigma, FFX_REDUCE_SUM, -1, size0, size1, tsum, gts, gp, s))) goto done;
+    for (int i = 0; i < n; ++i) { g3[3 * i] = gp[2 * i]; g3[3 * i + 1] = gp[2 * i + 1]; g3[3 * i + 2] = 0.f; }
+    if ((rc = ffx_project_rays_bwd(rays, n, KF, g3, grays_data, s))) goto done;
+  }
+  if (reg_weight > 0.f) {
+    const float gs = reg_weight / ((float)size0 * (float)size1);
+    for (size_t t = 0; t < T; ++t) { const float d = tsor[t] - tsum[t]; gd[t] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f); }
+    if ((rc = ffx_splat_bwd(pts, n, sigma, FFX_REDUCE_SOFTOR, -1, size0, size1, tsor, gd, gp, s))) goto done;
+    if ((rc = ffx_splat_bwd(pts, n, sigma, FFX_REDUCE_SUM, -1, size0, size1, tsum, gd, gp2, s))) goto done;
+    for (int i = 0; i < n; ++i) { g3[3 * i] = gp[2 * i] - gp2[2 * i]; g3[3 * i + 1] = gp[2 * i + 1] - gp2[2 * i + 1]; g3[3 * i + 2] = 0.f; }
+    if ((rc = ffx_project_rays_bwd(rays, n, KF, g3, grays_reg, s))) goto done;
+    if (reg_value) {
+      double acc = 0.0;
+      const size_t nw = ffx_pattern_ws_floats(size0, size1);
+      for (size_t t = 0; t < nw; ++t) acc += (double)ws[t];
+      reg_value[0] = (float)(acc * (double)gs);
+    }
+  } else if (reg_value) {
+    reg_value[0] = 0.f;
+  }
+  if (rc == FFX_OK && reg_value && loss_in) reg_value[1] = loss_in[0] / (loss_div > 0.f ? loss_div : 1.0f) + reg_value[0];
+done:
+  free(p3); free(pts); free(gp); free(gp2); free(g3); free(gd);
+  return rc;
+}
+
+int ffx_adam_clamp_step(float *rays, const float *grad, const float *grad_b, float grad_div, float *grad_out, float *exp_avg, float *exp_avg_sq, float *step, int n,
+                        double lr, double beta1_d, double beta2_d, double eps_d, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize,
+                        ffx_stream s) {
+  if ((grad_b || grad_div != 1.0f) && !grad_out) FAIL(FFX_ERR_ARG, "adam_clamp_step: combining gradients needs grad_out");
+  if (!(grad_div > 0.f)) FAIL(FFX_ERR_ARG, "adam_clamp_step: grad_div must be positive");
+  if (!rays || !grad || !exp_avg || !exp_avg_sq || !step || !KF || !KF_inv || n < 1 || n_normalize < 0 || !(lo <= hi)) FAIL(FFX_ERR_ARG, "adam_clamp_step: bad argument");
+  const float t = step[0] + 1.0f;
+  /* the scalars as torch forms them: in double from the Python floats (adam.py: 1 - beta, bias corrections), rounded to
+   * float where they meet the tensors */
+  const float beta2 = (float)beta2_d, omb1 = (float)(1.0 - beta1_d), omb2 = (float)(1.0 - beta2_d), eps = (float)eps_d;
+  const double bc1 = 1.0 - pow(beta1_d, (double)t), bc2 = 1.0 - pow(beta2_d, (double)t);
+  const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
+  for (int i = 0; i < 3 * n; ++i) {
+    float g = grad[i];
+    if (grad_out) {
+      if (grad_div != 1.0f) g = g / grad_div;
+      if (grad_b) g = g + grad_b[i];
+      grad_out[i] = g;
+    }
+    float m = exp_avg[i], v = exp_avg_sq[i];
+    m = m + omb1 * (g - m);
+    v = beta2 * v + omb2 * g * g;
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / bc2s + eps;
+    rays[i] = rays[i] - step_size * m / denom;
+  }
+  step[0] = t;
+  return ffx_clamp_to_fov(rays, n, KF, KF_inv, lo, hi, n_normalize, s);
+}

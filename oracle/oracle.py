@@ -82,6 +82,36 @@ def l1_value_grad(a, b, weight=1.0):
     return float(ws[0]), g
 
 
+def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True):
+    rays = _f32(rays)
+    n = rays.shape[0]
+    pts = np.empty((n, 2), np.float32)
+    tsum = np.empty((size1, size0), np.float32)
+    tsor = np.empty((size1, size0), np.float32) if want_softor else None
+    ws = np.zeros(int(api().lib.ffx_pattern_ws_floats(size0, size1)), np.float32)
+    api().call("ffx_pattern_fwd", _p(rays), n, _m16(KF), float(sigma), size0, size1, int(want_softor), _p(pts), _p(tsum), _p(tsor) if want_softor else None, _p(ws), None)
+    return pts, tsum, tsor, ws
+
+
+def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws):
+    rays = _f32(rays)
+    n = rays.shape[0]
+    gd = np.zeros((n, 3), np.float32)
+    gr = np.zeros((n, 3), np.float32)
+    val = np.zeros(2, np.float32)
+    gts = None if gts is None else _f32(gts)
+    api().call("ffx_pattern_bwd", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(_f32(tsum)), _p(_f32(tsor)) if tsor is not None else None,
+               _p(gts) if gts is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val), None, 1.0, None)
+    return gd, gr, float(val[0])
+
+
+def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1):
+    """in place on rays / exp_avg / exp_avg_sq / step (float32 arrays)"""
+    api().call("ffx_adam_clamp_step", _p(rays), _p(_f32(grad)), None, 1.0, None, _p(exp_avg), _p(exp_avg_sq), _p(step), rays.shape[0], float(lr), float(beta1), float(beta2), float(eps),
+               _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), None)
+    return rays
+
+
 def clamp_to_fov(rays, KF, KF_inv, lo, hi, n_normalize=1):
     out = _f32(rays).copy()
     api().call("ffx_clamp_to_fov", _p(out), out.shape[0], _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), None)

@@ -640,3 +640,62 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
             assert (err > 1e-3 * scale).mean() <= 1e-3 and err.max() <= 0.1 * scale
     # at the BASELINE size the cache is 39.8 MB (one 16-byte record per sample was 268 MB)
     assert ops.render_cache_bytes(512, 512, 64) <= 40 * 10**6
+
+
+# ------------------------------------------------------------------ fused pattern side of an optimisation step
+@pytest.mark.parametrize("n,size,sigma", [(64, (96, 80), 10.0), (256, (500, 500), 10.0), (700, (128, 128), 30.0)])
+def test_fused_pattern_kernels_match_the_unfused_oracle(oracle, n, size, sigma):
+    """ffx_pattern_fwd / ffx_pattern_bwd / ffx_adam_clamp_step (three launches) against the oracle's composition of
+    the separate entry points, which follow the reference line by line (laser.py:262-275, rasterization.py:7-37,
+    156-161,589-600) — and the Adam part against torch.optim.Adam itself."""
+    rng = np.random.default_rng(n)
+    s0, s1 = size
+    g2 = load_golden("g2_projection.npz")
+    KF = (g2["K"] @ FLIP_Y).astype(np.float32)
+    ndc = (rng.random((n, 3)) * np.array([0.9, 0.9, 0.0]) + np.array([0.05, 0.05, -1.0])).astype(np.float32)
+    rays = oracle.transform_points(ndc, np.linalg.inv(KF.astype(np.float64)).astype(np.float32))
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    pts_o, tsum_o, tsor_o, ws_o = oracle.pattern_fwd(rays, KF, sigma, s0, s1, True)
+    pts_d, tsum_d, tsor_d, ws_d = ops.pattern_fwd(dev(rays), KF, sigma, s0, s1, True)
+    np.testing.assert_allclose(host(pts_d), pts_o, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(tsum_d), tsum_o, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(host(tsor_d), tsor_o, rtol=2e-6, atol=1e-6)
+    assert float(host(ws_d).sum()) == pytest.approx(float(ws_o.sum()), rel=1e-5)
+    # the fused forward equals the separate HIP kernels bit for bit (same tiles, same point order)
+    assert torch.equal(tsum_d, ops.splat_fwd(pts_d, sigma, "sum", -1, s0, s1)) and torch.equal(tsor_d, ops.splat_fwd(pts_d, sigma, "softor", -1, s0, s1))
+    gts = rng.standard_normal((s1, s0)).astype(np.float32)
+    for w in (0.1, 0.0):
+        gd_o, gr_o, val_o = oracle.pattern_bwd(rays, KF, sigma, s0, s1, tsum_o, tsor_o, gts, w, ws_o)
+        gd_d, gr_d, val_d = ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_d, tsor_d, dev(gts), w, ws_d)
+        np.testing.assert_allclose(host(gd_d), gd_o, rtol=2e-4, atol=2e-5 * np.abs(gd_o).max())
+        if w > 0:
+            np.testing.assert_allclose(host(gr_d), gr_o, rtol=5e-4, atol=5e-5 * np.abs(gr_o).max())
+            assert float(val_d[0]) == pytest.approx(val_o, rel=1e-5)
+        else:
+            assert gr_d is None and float(val_d[0]) == 0.0
+    # no data term (a rank without samples): only the regulariser
+    gd_d, gr_d, _ = ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_d, tsor_d, None, 0.1, ws_d)
+    assert gd_d is None
+    np.testing.assert_allclose(host(gr_d), gr_o if False else oracle.pattern_bwd(rays, KF, sigma, s0, s1, tsum_o, tsor_o, None, 0.1, ws_o)[1], rtol=5e-4,
+                               atol=5e-5 * np.abs(gr_o).max() if np.abs(gr_o).max() > 0 else 1e-9)
+    # Adam + clamp_to_fov + normalise: three steps against the oracle and against torch.optim.Adam
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    r_d = dev(rays).clone()
+    m_d, v_d, st_d = torch.zeros_like(r_d), torch.zeros_like(r_d), torch.zeros((), device="cuda")
+    r_o, m_o, v_o, st_o = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    r_t = dev(rays).clone().requires_grad_(True)
+    opt = torch.optim.Adam([r_t], lr=5e-3)
+    for k in range(3):
+        g = (rng.standard_normal(rays.shape) * 0.3).astype(np.float32)
+        ops.adam_clamp_step_(r_d, dev(g), m_d, v_d, st_d, 5e-3, 0.9, 0.999, 1e-8, KF, KFi, 0.05, 0.95, 2)
+        oracle.adam_clamp_step(r_o, g, m_o, v_o, st_o, 5e-3, 0.9, 0.999, 1e-8, KF, KFi, 0.05, 0.95, 2)
+        r_t.grad = dev(g)
+        opt.step()
+        with torch.no_grad():
+            ops.clamp_to_fov_(r_t.detach(), KF, KFi, 0.05, 0.95, 2)
+        np.testing.assert_allclose(host(r_d), r_o, rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(host(r_d), host(r_t), rtol=2e-6, atol=2e-7)
+    assert float(st_d) == 3.0 and st_o[0] == 3.0
+    np.testing.assert_allclose(host(m_d), m_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(host(m_d), host(opt.state[r_t]["exp_avg"]), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(host(v_d), host(opt.state[r_t]["exp_avg_sq"]), rtol=1e-6, atol=1e-10)
