@@ -393,6 +393,16 @@ class Scene:
                 v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v)
                 self._set_pose(base, torch.eye(4), None, v)
                 geom_dirty = True
+            elif rest.startswith("brdf_0.") and rest != "brdf_0.base_color.value" and base in self._material_meshes:
+                # principled-BSDF parameters other than the base colour (specular, roughness, clearcoat, ...; the
+                # reference randomises them: main.py:97-107, examples/vocalfold_scene.py:93) are accepted so that
+                # such scripts run, but shading is Lambert: say so once instead of silently ignoring them
+                if not getattr(self, "_warned_bsdf", False):
+                    import warnings
+
+                    warnings.warn(f"{k}: principled-BSDF parameters other than base_color do not affect the render — shading is Lambert "
+                                  "(fireflies_amd DESIGN.md 4.3); further assignments of such parameters are not reported", stacklevel=4)
+                    self._warned_bsdf = True
             elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
                 c = self._params._d[k]
                 c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]

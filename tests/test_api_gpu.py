@@ -219,6 +219,19 @@ def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypat
     assert not torch.equal(a[0][0], a[1][0])
 
 
+def test_principled_parameters_are_accepted_but_reported():
+    """the reference randomises brdf_0.specular / roughness / clearcoat (main.py:97-107, vocalfold_scene.py:93); here
+    they are accepted and shading stays Lambert — which is said out loud (once), not silently ignored."""
+    wl = _small()
+    with pytest.warns(UserWarning, match="shading is Lambert"):
+        wl.ff_scene.randomize()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        wl.ff_scene.randomize()  # reported once per scene
+
+
 def test_generic_vertex_assignment_path(oracle):
     """Mitsuba-style use: assign transformed vertices to `<mesh>.vertex_positions` and update()."""
     wl = _small(randomize=False)
