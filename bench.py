@@ -53,11 +53,14 @@ def _bracket(fn, steps, warmup, device):
     which is 60 steps' worth of GPU work."""
     import gc
 
-    for i in range(warmup):
-        fn(i)
+    # collect BEFORE the warm-up steps: a full collection walks the whole heap and leaves the interpreter's
+    # working set cold in the caches — done after the warm-up it made the first timed step 2x slower on the host
+    # (1.1 instead of 0.5 ms, tools/startprof.py), which a 20-step bracket sees as +3 % per step
     gc.collect()
     gc.disable()
     try:
+        for i in range(warmup):
+            fn(i)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -78,10 +81,18 @@ def _kernel_ms(events, name):
     return (sum(ms) / len(ms), len(ms)) if ms else (None, 0)
 
 
+PROFILED_WORKLOAD = {"workload": "vocalfold", "res": 512, "spp": 64}  # what tools/collect_profiles.sh runs (bench.py defaults)
+
+
+def _is_profiled_workload(args):
+    return args.workload == "vocalfold" and args.res == 512 and args.spp == 64 and not args.fp16 and not args.no_shadows
+
+
 def pmc_traffic(kernel_prefix, tag="r"):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
-    written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  None if no profile is present."""
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at its
+    default workload; FETCH_SIZE doubled as MI355X_MICROARCH.md HBM section prescribes for gfx950).  The caller
+    only asks for the workload those passes ran (PROFILED_WORKLOAD).  None if no profile is present."""
     import glob
 
     best = None
@@ -99,25 +110,47 @@ def pmc_traffic(kernel_prefix, tag="r"):
     return best
 
 
+# cycles per wave64 instruction per SIMD with >= 4 resident waves, the LOWEST figure measured for any member of the
+# class (tools/ubench/issue_rates.hip, profiles/r2_issue_rates.txt; instruction counts fixed by the asm bodies):
+#   fast: v_fma/v_mul/v_add/v_fmac_f32 and v_mov on VGPR operands only .................. 2.27
+#   slow: any VALU op with an SGPR/constant source, min/max/med3, compares, v_cndmask, conversions, integer ops,
+#         DPP, v_readlane/v_writelane, packed fp32 .......................................... 4.09
+#   transcendental (v_rcp/v_rsq/v_sqrt/v_exp/v_log) ............................................ 8.18
+VALU_CYCLES = {"fast": 2.27, "slow": 4.09, "trans": 8.18}
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
 def valu_issue(kernel_substr, kernel_ms):
-    """Secondary, compute-side view of the dominant kernel (it is VALU-issue bound, which the contract's
-    hbm|mfma roofline cannot express): wave-level VALU instructions per launch from the committed SQ
-    counter pass (profiles/*_sq_instruction_mix.json, vocal-fold workload) over the live kernel time,
-    against 1024 SIMDs x one wave64 instruction per 4 cycles at the 2.4 GHz nominal clock."""
+    """Compute-side view of the dominant kernel (it is VALU-issue bound, which the contract's hbm|mfma roofline
+    cannot express).  Ceiling = the time the kernel's OWN instruction mix needs if every instruction issued at the
+    best rate measured for its class: the SQ counters of the newest committed pass (profiles/*_sq_instruction_mix.json,
+    same workload) give wave-level counts per launch; every fma/mul/add is priced as the VGPR-only form (2.27 cycles)
+    although many carry a scalar operand (4.09) — the ceiling is optimistic, so frac = ceiling / live kernel time
+    is a lower bound of the issue utilisation and cannot exceed 1."""
     import glob
 
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_instruction_mix.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_instruction_mix.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         for k, v in d.items():
             if kernel_substr in k and "SQ_INSTS_VALU" in v:
-                n = v["SQ_INSTS_VALU"]["mean"]
-                peak = 1024 * 2.4e9 / 4
-                ach = n / (kernel_ms * 1e-3)
-                return {"valu_wave_instr_per_launch": n, "achieved_Ginstr_per_s": ach / 1e9, "peak_Ginstr_per_s": peak / 1e9, "frac": ach / peak,
-                        "source": os.path.basename(f)}
+                g = lambda c: v.get(c, {}).get("mean", 0.0)  # noqa: E731
+                n = g("SQ_INSTS_VALU")
+                fast = g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32")
+                trans = g("SQ_INSTS_VALU_TRANS_F32")
+                if fast == 0.0:  # a profile without the class counters: price everything at the fast rate
+                    fast, trans = n, 0.0
+                slow = n - fast - trans
+                cyc = fast * VALU_CYCLES["fast"] + slow * VALU_CYCLES["slow"] + trans * VALU_CYCLES["trans"]
+                ceil_ms = 1e3 * cyc / SIMDS / CLOCK_HZ
+                return {"valu_wave_instr_per_launch": n, "fp32_fma_mul_add": fast, "transcendental": trans, "other_valu": slow,
+                        "cycles_per_instr": VALU_CYCLES, "simds": SIMDS, "clock_ghz": CLOCK_HZ / 1e9,
+                        "ceiling_ms": ceil_ms, "kernel_ms": kernel_ms, "frac": ceil_ms / kernel_ms,
+                        "salu_per_launch": g("SQ_INSTS_SALU"), "smem_per_launch": g("SQ_INSTS_SMEM"), "vmem_per_launch": g("SQ_INSTS_VMEM"),
+                        "lds_per_launch": g("SQ_INSTS_LDS"),
+                        "source": f"counts: profiles/{os.path.basename(f)} (committed rocprofv3 --pmc passes, not this run); rates: profiles/r2_issue_rates.txt; time: this run"}
     return None
 
 
@@ -135,9 +168,20 @@ def algorithmic_bytes(wl, width, height, fp16=False):
             "scene_update": 24 * V + 32 * nodes, "G": G, "V": V, "F": F, "nodes": nodes}
 
 
+def _omp_set_threads(n):
+    """the oracle is linked against libgomp: set the team size of its `omp parallel for` loops"""
+    import ctypes
+
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
 def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
-    """CPU oracle (OpenMP over pixels) on the same pose / texture at `cpu_spp` samples per pixel;
-    scaled to the full spp.  Rank 0, N = 1 only."""
+    """CPU oracle on the same pose / texture: all host threads (OpenMP over pixels) at `cpu_spp` samples per pixel,
+    and ONE thread on a smaller bounded sample; both scaled to the full spp.  Rank 0, N = 1 only."""
     from fireflies_amd import scenes
     from oracle import oracle as orc
 
@@ -156,9 +200,25 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
         t_r += time.perf_counter() - t0
         n += 1
     per_render = t_upd + (t_r / n) * (spp_full / cpu_spp)
-    return {"value": 1.0 / per_render, "unit": "renders/sec", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} renders of the same pose at {cpu_spp} of {spp_full} spp ({t_r:.1f} s measured in total, scaled x{spp_full / cpu_spp:g}) + refit "
-                      f"{t_upd * 1e3:.1f} ms; gcc -O2 scalar oracle, OpenMP over pixels on {os.cpu_count()} threads"}
+    out = {"value": 1.0 / per_render, "unit": "renders/sec", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} renders of the same pose at {cpu_spp} of {spp_full} spp ({t_r:.1f} s measured in total, scaled x{spp_full / cpu_spp:g}) + refit "
+                     f"{t_upd * 1e3:.1f} ms; gcc -O2 scalar oracle (a restatement for checking, not a tuned CPU renderer), OpenMP over pixels on {os.cpu_count()} threads",
+           "mitsuba_scalar_rgb": "unavailable (mitsuba 3.5.0 / drjit 0.4.4 are not installed here or on the GPU box and are not part of /root/reference)"}
+    # one thread: a bounded sample (1/16 of the samples per pixel, >= 1), scaled
+    spp1 = max(1, spp_full // 16)
+    if _omp_set_threads(1):
+        try:
+            t0 = time.perf_counter()
+            geo.update(wl.mi_scene._xforms.numpy(), wl.mi_scene._offs)
+            t_upd1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            geo.render_fwd(sd, alb, texh, spp1, seed=seed)
+            t1 = time.perf_counter() - t0
+        finally:
+            _omp_set_threads(os.cpu_count())
+        out["one_thread"] = {"value": 1.0 / (t_upd1 + t1 * spp_full / spp1), "unit": "renders/sec", "cores": 1,
+                             "sample": f"1 render at {spp1} of {spp_full} spp ({t1:.1f} s measured, scaled x{spp_full / spp1:g}) + refit {t_upd1 * 1e3:.1f} ms"}
+    return out
 
 
 def main():
@@ -180,7 +240,7 @@ def main():
                     help="vocalfold = BASELINE configs[1]/[2] (the metric's configuration); colon = configs[4] "
                          "(use --res 1024 --spp 256 --grid 32 --fp16)")
     ap.add_argument("--fp16", action="store_true", help="fp16 radiance buffer (config 5)")
-    ap.add_argument("--entity-device", default="cpu", help="device argument of ff.Scene (where the samplers draw): cpu (no sync per draw) or cuda (the reference default)")
+    ap.add_argument("--entity-device", default="cuda", help="device argument of ff.Scene (where the sampler bounds live and whose generator is used): cuda (the reference default) or cpu")
     args = ap.parse_args()
 
     rank, world, local = dist.env_rank_world()
@@ -213,15 +273,20 @@ def main():
 
     events = []
 
-    # Per-launch HIP event pairs are recorded for at most TIMED_STEPS steps of a bracket and resolved
-    # right after it: hundreds of unresolved timing events slow every later launch of the process down
+    # Per-launch HIP event pairs (on the launch streams) are recorded for every 4th step of a timed bracket, at most
+    # TIMED_STEPS of them, and resolved right after it.  Every pair costs two marker packets around the kernel, which
+    # keep the next step's refit from overlapping it: with all 20 steps of a short bracket instrumented the bracket
+    # itself ran 8 % slower; and hundreds of unresolved timing events slow every later launch of the process down
     # (measured: the gradient bracket ran at half speed after 600 of them).
-    TIMED_STEPS = 24
+    TIMED_STEPS = int(os.environ.get("FFX_BENCH_TIMED_STEPS", "8"))
+
+    def _timed(i, first):
+        return i >= first and (i - first) % 4 == 0 and (i - first) // 4 < TIMED_STEPS
 
     w_render = 0 if args.no_render_steps else args.warmup
 
     def timed_render_step(i):
-        geom.timing = events if w_render <= i < w_render + TIMED_STEPS else None
+        geom.timing = events if _timed(i, w_render) else None
         return render_step(i)
 
     t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev)
@@ -242,7 +307,7 @@ def main():
         gevents = []
 
         def grad_step(i):
-            wg.mi_scene.geom.timing = gevents if args.warmup <= i < args.warmup + TIMED_STEPS else None
+            wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup) else None
             return opt.step()
 
         t_grad = _bracket(grad_step, args.steps, args.warmup, dev)
@@ -265,13 +330,13 @@ def main():
                 "kernel": "k_render_bwd_cached (streams the per-sample records written by K8)", "bound": "hbm",
                 "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
-                "traffic": (pmc_traffic("k_render_bwd_cached", "grad") or {}).get("bytes")},
+                "traffic": (pmc_traffic("k_render_bwd_cached", "grad") or {}).get("bytes") if _is_profiled_workload(args) else None},
         }
 
     if rank != 0:
         return
     achieved = bytes_["render_fwd"] / (k8_ms * 1e-3) / 1e9
-    traffic = pmc_traffic("k_render_fwd_pk")
+    traffic = pmc_traffic("k_render_fwd_pk") if _is_profiled_workload(args) else None  # the committed PMC passes ran the default workload only
     out = {
         "metric": "renders/sec @512x512,64spp vocal-fold (+ pattern-grad-steps/sec in grad_steps_per_sec); HBM GB/s vs peak in roofline",
         "value": renders_per_sec,
@@ -304,13 +369,14 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None if traffic is None else traffic["bytes"],
-            "traffic_source": None if traffic is None else f"profiles/{traffic['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; raw {traffic['raw_bytes']:.0f} B, FETCH_SIZE x2 gfx950 correction)",
+            "traffic_source": ("no committed PMC pass for this workload" if not _is_profiled_workload(args) else None) if traffic is None else
+            f"profiles/{traffic['source']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at this workload, not this run; raw {traffic['raw_bytes']:.0f} B, FETCH_SIZE x2 gfx950 correction)",
             "algorithmic_bytes_per_launch": bytes_["render_fwd"],
             "avg_kernel_ms": k8_ms,
             "launches_timed": k8_n,
-            "valu_issue": valu_issue("k_render_fwd_pk", k8_ms) if args.workload == "vocalfold" and W == 512 and args.spp == 64 else None,
+            "valu_issue": valu_issue("k_render_fwd_pk", k8_ms) if _is_profiled_workload(args) else None,
             "note": "by design NOT HBM-bound: samples are reduced in registers, so compulsory traffic is ~6 MB per render; the kernel is "
-                    "VALU-issue bound (SQ counters in profiles/r1_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
+                    "VALU-issue bound (valu_issue below; SQ counters in profiles/r2_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
         },
         "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_ms},

@@ -37,14 +37,23 @@ class DrawBatch:
 
     def add(self, t) -> int:
         self._tensors.append(t.detach().reshape(-1))
-        self._slots.append((len(self._tensors) - 1, 0, 1, None, None))
+        self._slots.append((len(self._tensors) - 1, 0, 1, None, None, None))
         return len(self._slots) - 1
 
     def add_uniform(self, u, lo, hi, repeat: int = 1) -> int:
         """u: the torch.rand tensor (device); lo / hi: the bounds as float32 numpy arrays (host mirrors kept by the sampler)"""
         self._tensors.append(u.reshape(-1))
-        self._slots.append((len(self._tensors) - 1, 1, repeat, lo, hi))
+        self._slots.append((len(self._tensors) - 1, 1, repeat, lo, hi, None))
         return len(self._slots) - 1
+
+    def add_uniform_host(self, u, lo, hi, repeat: int = 1) -> int:
+        """u: the values of the torch.rand call as a float32 numpy array already on the host
+        (sampling/torch_rng.py: the device generator's Philox stream evaluated natively); nothing to transfer"""
+        self._slots.append((-1, 2, repeat, lo, hi, u))
+        return len(self._slots) - 1
+
+    def needs_transfer(self) -> bool:
+        return any(t.is_cuda for t in self._tensors)
 
     def __len__(self):
         return len(self._slots)
@@ -77,11 +86,12 @@ class DrawBatch:
                 arrs.append(flat[k : k + t.numel()])
                 k += t.numel()
         out = []
-        for first, kind, rep, lo, hi in self._slots:
+        for first, kind, rep, lo, hi, host_u in self._slots:
             if kind == 0:
                 v = arrs[first]
             else:
-                v = arrs[first] * (hi - lo) + lo  # float32, one rounding per operation like the torch expression
+                u = host_u if kind == 2 else arrs[first]
+                v = u * (hi - lo) + lo  # float32, one rounding per operation like the torch expression
             vals = [float(x) for x in v]
             out.append(vals * rep if rep > 1 else vals)
         return out

@@ -1,0 +1,42 @@
+"""The `torch.rand` of a CUDA sampler bound, evaluated on the host (ffx_torch_rand_h, include/ffx.h).
+
+The reference draws `torch.rand(a.shape, device=a.device)` per sampler (fireflies/utils/math.py:170-175)
+and syncs per value (fireflies/scene.py:258-274).  For the default CUDA generator those numbers are a
+pure function of (seed, offset), so the product computes them natively on the host and advances the
+generator's offset by what the device launch would have consumed: same values, same stream for every
+other consumer of the generator, no launch, no transfer, no sync.  FFX_HOST_PHILOX=0 switches back to
+device draws (Scene then pre-draws them on a side stream, scene.py).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_ENABLED = os.environ.get("FFX_HOST_PHILOX", "1") != "0"
+_INC = C.c_uint64(0)
+_BUF = (C.c_float * 256)()
+_FN = None
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def host_rand(numel: int, device):
+    """the `numel` values torch.rand(..., device=device) would return now (float32 numpy array), with the
+    device generator advanced accordingly; None if this draw has to be made on the device."""
+    global _FN
+    if not _ENABLED or numel < 1 or numel > 256 or torch.cuda.is_current_stream_capturing():
+        return None
+    if _FN is None:
+        _FN = _lib.api().lib.ffx_torch_rand_h
+    dev = torch.device(device)
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    off = gen.get_offset()
+    if _FN(gen.initial_seed(), off, numel, _BUF, C.byref(_INC)) != 0:
+        return None
+    gen.set_offset(off + _INC.value)
+    return np.ctypeslib.as_array(_BUF)[:numel].copy()

@@ -1,6 +1,6 @@
 import torch
 
-from . import base
+from . import base, torch_rng
 from ..utils import math as ffmath
 
 
@@ -20,4 +20,8 @@ class UniformSampler(base.Sampler):
         a, b = self._min_range, self._max_range
         assert a.size() == b.size() and a.device == b.device
         lo, hi = self._host_bounds()
+        if a.is_cuda:
+            u = torch_rng.host_rand(a.numel(), a.device)  # the values of that torch.rand call, without the launch
+            if u is not None:
+                return batch.add_uniform_host(u, lo, hi)
         return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi)  # the same torch.rand call as sample_train

@@ -1,6 +1,6 @@
 import torch
 
-from . import base
+from . import base, torch_rng
 from ..utils import math as ffmath
 
 
@@ -25,6 +25,10 @@ class UniformScalarToVec3Sampler(base.Sampler):
         a, b = self._min_range, self._max_range
         assert a.size() == b.size() and a.device == b.device and a.numel() == 1
         lo, hi = self._host_bounds()
+        if a.is_cuda:
+            u = torch_rng.host_rand(1, a.device)
+            if u is not None:
+                return batch.add_uniform_host(u, lo, hi, repeat=3)
         return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi, repeat=3)
 
     def sample_eval(self):

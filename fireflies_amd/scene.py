@@ -15,7 +15,7 @@ from typing import List
 
 import torch
 
-from . import emitter, entity, material, mi, ops
+from . import emitter, entity, material, mi, ops, sampling
 
 
 class Scene:
@@ -358,7 +358,35 @@ class Scene:
         self._set_rng_state(pre["after"])
         return pre["drawn"], pre["pending"].finish()
 
+    def _host_drawable(self) -> bool:
+        """True if every draw of a randomisation can be evaluated on the host (sampling/torch_rng.py): train mode and
+        only uniform samplers with small bounds.  Cached until the sampler configuration changes."""
+        from .sampling import base as sbase
+        from .sampling import torch_rng
+
+        c = getattr(self, "_hd", None)
+        if c is None or c[0] != sbase.mutation_count():
+            ok = torch_rng.enabled() and torch.device(self._device).type == "cuda"
+            if ok:
+                for e in self._draw_order():
+                    if not e.randomizable():
+                        continue
+                    extra = [e._scale_sampler] if hasattr(e, "_scale_sampler") else []  # meshes draw translation, rotation, scale
+                    for smp in list(e._all_samplers()) + extra:
+                        if type(smp) not in (sampling.UniformSampler, sampling.UniformScalarToVec3Sampler) or not smp._train or smp._min_range.numel() > 256:
+                            ok = False
+            c = self._hd = (sbase.mutation_count(), ok)
+        return c[1]
+
     def randomize(self) -> None:
+        if self._host_drawable():
+            # f1: no device work at all for the draws — values from the generator's Philox stream on the host,
+            # 4x4 algebra on the host, matrices as kernel arguments of the one refit pass
+            self._pre = None
+            batch = entity.DrawBatch()
+            drawn = self._draw_all(batch)
+            self._apply(drawn, self._fetch(batch) if batch.needs_transfer() else batch.fetch())
+            return
         side = self._draw_stream()
         got = self._take_predrawn() if side is not None else None
         if got is None:

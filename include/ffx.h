@@ -181,6 +181,23 @@ int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[
                         int n_normalize, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * f1  sampler draws of a scene randomisation, on the host.
+ * Replaces the `torch.rand(a.shape, device=a.device)` inside randomBetweenTensors (fireflies/utils/math.py:170-175),
+ * the call behind every UniformSampler / UniformScalarToVec3Sampler draw (fireflies/sampling/uniform.py:16-19,
+ * uniform_scalar_to_vec3.py) that Transformable.randomize / Mesh.randomize issue per entity
+ * (fireflies/entity/base.py:220-234, entity/mesh.py:141-156), each followed in the reference by a `.tolist()` /
+ * `.item()` device-to-host sync (fireflies/scene.py:258-274).  For a tensor of n <= 256 float32 elements on
+ * PyTorch-ROCm's default CUDA generator with (seed = gen.initial_seed(), offset = gen.get_offset()) the call
+ * writes the n values that torch.rand would have produced on the device (Philox4x32-10, element index =
+ * subsequence, offset / 4 = counter; rocrand's (0, 1] float mapping with torch's 1 -> 0 fold) and the amount
+ * by which the caller must advance the generator offset (gen.set_offset(offset + *offset_increment)).
+ * No device work, no stream.  FFX_ERR_UNSUPPORTED for n > 256 or an offset that is not a multiple of 4
+ * (the caller then draws on the device as the reference does).
+ * ---------------------------------------------------------------------------------------- */
+int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *out /*[host][n]*/,
+                     uint64_t *offset_increment /*[host]*/);
+
+/* ------------------------------------------------------------------------------------------
  * K3  texture finalise: separable Gaussian blur, reflect border.
  * Replaces kornia.filters.gaussian_blur2d(tex, (k,k), (s,s)) at
  * examples/vocalfold_scene.py:61-63 and main.py:69-71 (k = 5, s = 3).  ksize odd, <= 15.

@@ -482,6 +482,48 @@ int ffx_splat_lines_bwd(const float *lines, int n, float sigma, int size0, int s
 }
 
 /* =========================================================================================
+ * f1  torch.rand(shape, device="cuda") of n <= 256 float32 elements on the default CUDA generator of
+ * PyTorch-ROCm (the draw inside randomBetweenTensors, fireflies/utils/math.py:170-175; called by
+ * fireflies/sampling/uniform.py:16-19), restated from the published algorithms [EXT]:
+ *   Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123):
+ *     per round  (c0,c1,c2,c3) <- (hi(M1*c2)^c1^k0, lo(M1*c2), hi(M0*c0)^c3^k1, lo(M0*c0)),
+ *     M0 = 0xD2511F53, M1 = 0xCD9E8D57; key bumped by (0x9E3779B9, 0xBB67AE85) between rounds;
+ *   counter words (offset/4 lo, offset/4 hi, element index, 0), key (seed lo, seed hi) — curand_init(seed,
+ *     subsequence = thread index, offset) as called by ATen's distribution_elementwise_grid_stride_kernel
+ *     (one 256-thread block for n <= 256; element i takes the FIRST output word of thread i);
+ *   float mapping of rocrand (2^-32 + x * 2^-32 evaluated in binary32: (0, 1]) and torch's fold 1 -> 0.
+ * Pinned on the GPU box against torch.rand itself (tests/test_api_gpu.py::test_host_philox_matches_torch_rand).
+ * ========================================================================================= */
+static void philox_mulhilo(unsigned m, unsigned v, unsigned *hi, unsigned *lo) {
+  unsigned long long p = (unsigned long long)m * (unsigned long long)v;
+  *hi = (unsigned)(p >> 32);
+  *lo = (unsigned)(p & 0xffffffffull);
+}
+int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *out, uint64_t *offset_increment) {
+  if (!out || !offset_increment || n <= 0) FAIL(FFX_ERR_ARG, "torch_rand_h: bad argument");
+  if (n > 256) FAIL(FFX_ERR_UNSUPPORTED, "torch_rand_h: more than 256 elements (%d)", n);
+  if (offset % 4 != 0) FAIL(FFX_ERR_UNSUPPORTED, "torch_rand_h: offset not a multiple of 4");
+  for (int i = 0; i < n; ++i) {
+    unsigned c[4] = {(unsigned)((offset / 4) & 0xffffffffull), (unsigned)((offset / 4) >> 32), (unsigned)i, 0u};
+    unsigned k[2] = {(unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32)};
+    for (int round = 0; round < 10; ++round) {
+      unsigned h0, l0, h1, l1;
+      if (round > 0) { k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u; }
+      philox_mulhilo(0xD2511F53u, c[0], &h0, &l0);
+      philox_mulhilo(0xCD9E8D57u, c[2], &h1, &l1);
+      unsigned nc[4] = {h1 ^ c[1] ^ k[0], l1, h0 ^ c[3] ^ k[1], l0};
+      memcpy(c, nc, sizeof c);
+    }
+    float x = (float)c[0];           /* unsigned -> binary32, round to nearest even */
+    float u = ldexpf(1.0f, -32);     /* 2^-32 */
+    u = u + x * ldexpf(1.0f, -32);   /* the product is exact, so a fused or an unfused evaluation agree */
+    out[i] = (u == 1.0f) ? 0.0f : u;
+  }
+  *offset_increment = 4;
+  return FFX_OK;
+}
+
+/* =========================================================================================
  * K3  gaussian_blur2d with reflect border [EXT kornia 0.7.1, call site
  * examples/vocalfold_scene.py:61-63].  Kernel: g[k] = exp(-(k - r)^2 / (2 s^2)), normalised
  * to sum 1; 2-D weight = g[ky]*g[kx]; border index reflect (no edge repeat): -1 -> 1.

@@ -36,6 +36,44 @@ def test_library_exports_every_symbol(which, oracle):
     assert lib.ffx_abi_version() == _abi.FFX_ABI_VERSION
 
 
+@pytest.mark.parametrize("which", ["hip", "oracle"])
+def test_host_philox_known_answers(which, oracle):
+    """ffx_torch_rand_h (a host function in both libraries): Random123's published known-answer vector for
+    Philox-4x32-10 (counter 0, key 0 -> first word 0x6627e8d5) through the float mapping, the 1 -> 0 fold's domain,
+    counter placement (offset / 4 in the low words, element index in the third), and the refusals.  The match
+    with torch.rand itself is a GPU test (tests/test_api_gpu.py::test_host_philox_matches_torch_rand)."""
+    lib = C.CDLL(_lib.LIB_PATH if which == "hip" else oracle.LIB_PATH)
+    fn = lib.ffx_torch_rand_h
+    fn.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    out, inc = (C.c_float * 256)(), C.c_uint64()
+    assert fn(0, 0, 3, out, C.byref(inc)) == 0 and inc.value == 4
+    assert out[0] == np.float32(np.float32(0x6627E8D5) * np.float32(2.0**-32) + np.float32(2.0**-32))
+
+    def philox(ctr, key):  # numpy restatement of the published round function, for the remaining words
+        c, k = [int(x) for x in ctr], [int(x) for x in key]
+        for r in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+            k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+        return c
+
+    assert philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]  # Random123 kat_vectors
+    assert philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    seed, off = (0x299F31D0 << 32) | 0xA4093822, 4 * ((0x05A308D3 << 32) | 0x243F6A88)
+    assert fn(seed, off, 256, out, C.byref(inc)) == 0
+    for i in (0, 1, 2, 100, 255):
+        w = philox([0x243F6A88, 0x05A308D3, i, 0], [0xA4093822, 0x299F31D0])[0]
+        want = np.float32(np.float32(w) * np.float32(2.0**-32) + np.float32(2.0**-32))
+        assert out[i] == (np.float32(0.0) if want == 1.0 else want), i
+    assert all(0.0 <= out[i] < 1.0 for i in range(256))
+    assert fn(0, 0, 257, out, C.byref(inc)) == _abi_err("FFX_ERR_UNSUPPORTED") and fn(0, 2, 3, out, C.byref(inc)) == _abi_err("FFX_ERR_UNSUPPORTED")
+    assert fn(0, 0, 0, out, C.byref(inc)) == _abi_err("FFX_ERR_ARG")
+
+
+def _abi_err(name):
+    return {"FFX_ERR_ARG": -1, "FFX_ERR_LAUNCH": -2, "FFX_ERR_UNSUPPORTED": -3, "FFX_ERR_NOMEM": -4}[name]
+
+
 def test_struct_sizes_match_header():
     # sizes implied by include/ffx.h (all members are 4- or 8-byte scalars)
     assert C.sizeof(_abi.Camera) == 4 * (16 + 16 + 2 + 2)

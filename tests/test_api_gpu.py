@@ -183,8 +183,11 @@ def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypat
     the generators or the sampler configuration in between.  Same seeds with the mechanism on and off must give
     the same parameter sequence — including after a foreign draw from torch's CUDA generator, a reseed, a foreign
     `random` draw and a changed sampler range (each of which must invalidate the pre-drawn values)."""
-    def run(flag):
+    from fireflies_amd.sampling import torch_rng
+
+    def run(flag, host_philox=False):
         monkeypatch.setenv("FFX_PREDRAW", flag)
+        monkeypatch.setattr(torch_rng, "_ENABLED", host_philox)
         wl = _small(entity_device="cuda")
         torch.manual_seed(123)
         random.seed(123)
@@ -205,18 +208,58 @@ def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypat
         foreign.append(torch.rand(2, device=DEV).cpu())
         return seq, foreign
 
-    (a, fa), (b, fb) = run("1"), run("0")
-    for k, (x, y) in enumerate(zip(a, b)):
-        torch.testing.assert_close(x[0], y[0], rtol=0, atol=0, msg=f"step {k}: transforms")
-        assert x[1] == y[1], f"step {k}: animation frames"
-        torch.testing.assert_close(x[2], y[2], rtol=0, atol=0, msg=f"step {k}: albedo")
-        torch.testing.assert_close(x[3], y[3], rtol=0, atol=0, msg=f"step {k}: light")
-        assert torch.equal(x[4], y[4]), f"step {k}: image"
-    # the foreign consumers saw the same numbers either way
-    torch.testing.assert_close(fa[0], fb[0], rtol=0, atol=0)
-    assert fa[1] == fb[1]
-    torch.testing.assert_close(fa[2], fb[2], rtol=0, atol=0)
+    (a, fa), (b, fb), (c, fc) = run("1"), run("0"), run("0", host_philox=True)
+    for (p, fp), what in (((b, fb), "pre-drawn on the device"), ((c, fc), "host Philox (default)")):
+        for k, (x, y) in enumerate(zip(a, p)):
+            torch.testing.assert_close(x[0], y[0], rtol=0, atol=0, msg=f"{what}, step {k}: transforms")
+            assert x[1] == y[1], f"{what}, step {k}: animation frames"
+            torch.testing.assert_close(x[2], y[2], rtol=0, atol=0, msg=f"{what}, step {k}: albedo")
+            torch.testing.assert_close(x[3], y[3], rtol=0, atol=0, msg=f"{what}, step {k}: light")
+            assert torch.equal(x[4], y[4]), f"{what}, step {k}: image"
+        # the foreign consumers saw the same numbers either way
+        torch.testing.assert_close(fa[0], fp[0], rtol=0, atol=0)
+        assert fa[1] == fp[1]
+        torch.testing.assert_close(fa[2], fp[2], rtol=0, atol=0)
     assert not torch.equal(a[0][0], a[1][0])
+
+
+def test_host_philox_matches_torch_rand():
+    """f1: ffx_torch_rand_h (the product's host evaluation of a CUDA sampler draw) against torch.rand itself on this
+    GPU's default generator — values bit for bit and the generator left in the same state — for the shapes the
+    samplers use (1, 3) and the extremes (2, 255, 256), from fresh seeds and in the middle of a stream that other
+    consumers (randn, a large rand, randint) advance by other amounts.  The oracle's independent restatement of
+    the same published algorithm is held to the same numbers."""
+    import ctypes as C
+
+    from fireflies_amd.sampling import torch_rng
+    from oracle import oracle as orc
+
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    olib = orc.api().lib
+    for seed in (0, 1, 1234, 2**40 + 17, 2**63 + 5):
+        torch.manual_seed(seed)
+        for k, n in enumerate((3, 1, 3, 2, 255, 256, 7, 3, 1)):
+            if k == 3:
+                torch.randn(5, device=DEV)
+            if k == 5:
+                torch.rand(100_000, device=DEV)
+            if k == 7:
+                torch.randint(0, 10, (3,), device=DEV)
+            st = gen.get_state().clone()
+            want = torch.rand(n, device=DEV).cpu().numpy()
+            after = gen.get_offset()
+            gen.set_state(st)
+            seed_now, off = gen.initial_seed(), gen.get_offset()
+            got = torch_rng.host_rand(n, DEV)
+            assert got is not None and got.dtype == np.float32
+            assert np.array_equal(got, want), (seed, k, n, got[:4], want[:4])
+            assert gen.get_offset() == after, (seed, k, n)
+            if olib is not None:
+                buf, inc = (C.c_float * n)(), C.c_uint64()
+                assert olib.ffx_torch_rand_h(C.c_uint64(seed_now), C.c_uint64(off), n, buf, C.byref(inc)) == 0
+                assert np.array_equal(np.ctypeslib.as_array(buf), want) and inc.value == after - off
+    # out of its range the host path declines (the sampler then draws on the device)
+    assert torch_rng.host_rand(257, DEV) is None and torch_rng.host_rand(0, DEV) is None
 
 
 def test_principled_parameters_are_accepted_but_reported():
