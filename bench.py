@@ -318,8 +318,14 @@ def main():
         k8g_ms, _ = _kernel_ms(gevents, "render_fwd")
         gevents.clear()
         bg = algorithmic_bytes(wg, W, H)
-        # streaming adjoint: reads the 16-byte record of every sample + d(loss)/d(img), writes gtex once
-        bytes_k9c = 16 * W * H * args.spp + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
+        # streaming adjoint over the per-pixel footprint cache written by K8: the 16-byte header of every
+        # pixel's slot, the 25-float footprint of the LIT pixels, the stray records, d(loss)/d(img); gtex written once.
+        # Lit pixels / strays are counted in the cache the last step left behind.
+        n_lit = n_stray = 0
+        if opt._cache is not None:
+            n_stray = int(opt._cache[:4].view(torch.int32).item())
+            n_lit = int((opt._cache[64:64 + 128 * W * H].view(W * H, 128)[:, 6] != 0).sum().item())
+        bytes_k9c = 16 * W * H + 100 * n_lit + 24 * n_stray + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
         grad = {
             "grad_steps_per_sec": args.steps / t_grad,
             "grad_samples_per_sec": S * args.steps / t_grad,
@@ -327,7 +333,8 @@ def main():
             "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world))},
             "grad_kernels_ms": {"render_fwd(+cache write)": k8g_ms, "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
             "render_bwd_cached_roofline": None if k9c_ms is None else {
-                "kernel": "k_render_bwd_cached (streams the per-sample records written by K8)", "bound": "hbm",
+                "kernel": "k_render_bwd_cached (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",
+                "lit_pixels": n_lit, "stray_samples": n_stray,
                 "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
                 "traffic": (pmc_traffic("k_render_bwd_cached", "grad") or {}).get("bytes") if _is_profiled_workload(args) else None},

@@ -688,10 +688,12 @@ __device__ __forceinline__ void traverse_packet(const BvhNode *__restrict__ node
 #define FFX_OCTANT_LOOPS 1
 #endif
 #ifndef FFX_PK1_WAVES
-// resident waves per SIMD the 1-ray packet kernels are register-budgeted for.  7 -> 72 VGPRs / 94 SGPRs:
-// no spills at all (8 -> 64 / 78: a dozen VGPR spills per pixel = ~240 MB of scratch write-back per
-// render for 1% more speed; 6 is 6% slower)
-#define FFX_PK1_WAVES 7
+// resident waves per SIMD the 1-ray packet kernels are register-budgeted for.  8 -> 64 VGPRs / 78 SGPRs.  With
+// the 64-wide walk the hot loops fit: what spills (9 dwords) are loop-invariant addresses and pixel indices,
+// stored once per wave and reloaded in the per-pixel epilogue.  Measured through the bench loop (tools/k8sweep.sh):
+// 5 / 6 / 7 / 8 waves: 1235 / 1325 / 1376 / 1404 renders/s — the walk waits on one vector load per step, more
+// resident waves hide it.  (The binary walk preferred 7: its spills were inside the node loop.)
+#define FFX_PK1_WAVES 8
 #endif
 __device__ __forceinline__ constexpr bool octant_loops() { return FFX_OCTANT_LOOPS != 0; }
 // `scale` = 1/tmax of the ray: the octant box test works in units of the ray's own parameter range, so

@@ -174,7 +174,7 @@ class PatternOptimizer:
         # the NEXT step's samples are drawn now, ahead of this step's renders: device draws issued behind a
         # render that fills the GPU only complete when it ends, and waiting for them would serialise host and GPU.
         # Their seeds are a function of the step index alone; the generators are put back afterwards.
-        if self.ff_scene._draw_stream() is not None:  # (host-side draws of CPU entities have nothing to wait for)
+        if self.ff_scene._draw_stream() is not None and not self.ff_scene._host_drawable():  # (draws evaluated on the host have nothing to wait for)
             nxt = self._sample_seeds(self.step_index + 1)
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)

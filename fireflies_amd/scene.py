@@ -417,10 +417,11 @@ class Scene:
 
         from .sampling import base as sbase
 
-        side = self._draw_stream()
+        side = None if self._host_drawable() else self._draw_stream()  # host-evaluated draws: no device work to order
         keep = None
         if lazy:
-            keep = (torch.cuda.get_rng_state(torch.device(self._device)) if side is not None else None, torch.get_rng_state(), _random.getstate())
+            on_gpu = torch.device(self._device).type == "cuda" and torch.cuda.is_available()  # (host-evaluated draws advance that generator too)
+            keep = (torch.cuda.get_rng_state(torch.device(self._device)) if on_gpu else None, torch.get_rng_state(), _random.getstate())
         batch = entity.DrawBatch()
         drawn = []
         for seed in seeds:
