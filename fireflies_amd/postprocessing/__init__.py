@@ -64,16 +64,27 @@ class GaussianBlur(BasePostProcessingFunction):
 
 
 class WhiteNoise(BasePostProcessingFunction):
-    """white_noise.py:5-20: image + N(mean, std), clipped to [0,1] (device RNG here, numpy's there)."""
+    """white_noise.py:5-20: image + N(mean, std), clipped to [0,1].  rng="numpy" (default) draws the noise exactly as
+    the reference does — `np.random.normal(ones * mean, ones * std)` from the GLOBAL numpy generator, float64 — so
+    a script seeded with np.random.seed sees the same images (pinned by tests/golden/g12); the draw is host work and
+    one upload per image.  rng="device" draws with torch.randn_like on the image's device instead (no host work,
+    torch's generator: a different stream)."""
 
-    def __init__(self, mean: float, std: float, probability: float):
+    def __init__(self, mean: float, std: float, probability: float, rng: str = "numpy"):
         super().__init__(probability)
-        self._mean, self._std = mean, std
+        if rng not in ("numpy", "device"):
+            raise ValueError("rng must be 'numpy' or 'device'")
+        self._mean, self._std, self._rng = mean, std, rng
 
     def post_process(self, image):
         t, was_np = _to_device(image)
-        noise = torch.randn_like(t) * self._std + self._mean
-        return _back(torch.clamp(t + noise, 0, 1), was_np)
+        if self._rng == "numpy":
+            shape = tuple(t.shape)
+            noise = np.random.normal(np.ones(shape) * self._mean, np.ones(shape) * self._std)  # float64, the reference's call
+            out = (t.double() + torch.from_numpy(noise).to(t.device)).to(t.dtype)  # `image += noise`: one rounding to the image type
+        else:
+            out = t + (torch.randn_like(t) * self._std + self._mean)
+        return _back(torch.clamp(out, 0, 1), was_np)
 
 
 class ApplySilhouette(BasePostProcessingFunction):

@@ -3,10 +3,10 @@ import torch
 
 
 def rayPlane(laserOrigin, laserDirection, planeOrigin, planeNormal):
-    """distance t [N,1] along each ray to the plane (intersections.py:5-11); rays parallel to the
-    plane get denominator 1 like the reference (denom / denom)."""
+    """distance t [N,1] along each ray to the plane (intersections.py:5-11); nearly parallel rays get the
+    reference's `denom / denom`: 1 for a tiny denominator, NaN for an exactly zero one (pinned by golden g12)."""
     denom = torch.sum(planeNormal * laserDirection, dim=1)
-    denom = torch.where(torch.abs(denom) < 0.000001, torch.ones_like(denom), denom)
+    denom = torch.where(torch.abs(denom) < 0.000001, denom / denom, denom)
     t = torch.sum((planeOrigin - laserOrigin) * planeNormal, dim=1) / denom
     return t[:, None]
 

@@ -404,3 +404,17 @@ def test_laser_static_generators_and_yaml(tmp_path):
     # a ray through the screen centre is the optical axis
     c = ff.projection.Laser._unproject(torch.tensor([[0.5, 0.5, -1.0]]), K)
     np.testing.assert_allclose(c.numpy(), [[0, 0, -1]], atol=1e-6)
+
+
+def test_intersection_helpers_match_reference():
+    """fireflies/utils/intersections.py rayPlane / sphereSphere against golden g12 (captured from the reference,
+    oracle/gen_golden_r2b.py) — including the exactly parallel ray, where the reference's `denom / denom` is NaN."""
+    from fireflies_amd.utils import intersections
+
+    g = load_golden("g12_dataset_helpers.npz")
+    t = intersections.rayPlane(torch.from_numpy(g["rp_o"]), torch.from_numpy(g["rp_d"]), torch.from_numpy(g["rp_po"]), torch.from_numpy(g["rp_pn"]))
+    np.testing.assert_array_equal(t.numpy(), g["rp_t"])
+    assert np.isnan(g["rp_t"][3, 0]) and np.isfinite(np.delete(g["rp_t"], 3, axis=0)).all()
+    hit = intersections.sphereSphere(torch.from_numpy(g["ss_a"]), torch.from_numpy(g["ss_ar"]), torch.from_numpy(g["ss_b"]), torch.from_numpy(g["ss_br"]))
+    np.testing.assert_array_equal(hit.numpy(), g["ss_hit"])
+    assert 0 < int(g["ss_hit"].sum()) < g["ss_hit"].size

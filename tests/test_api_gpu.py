@@ -157,6 +157,12 @@ def test_scene_randomize_render_and_depth_against_oracle(oracle):
         np.testing.assert_allclose(d.cpu().numpy(), to, rtol=1e-5, atol=1e-6)
         seg = ff.graphics.depth.get_segmentation_from_camera(wl.mi_scene)
         assert tuple(seg.shape) == (56, 64) and int(seg.max()) >= 1
+        # label image against the oracle's shape ids through the reference's relabelling (depth.py:119-125:
+        # pointer-like ids, `-= min`, `max - ids`; a miss is the null pointer 0)
+        _, so1, _ = go.trace_primary(wl.mi_scene.camera_struct(0), 1, 0, 0)
+        ptr = so1.astype(np.int64) + 1
+        ptr -= ptr.min()
+        np.testing.assert_array_equal(seg.cpu().numpy(), (ptr.max() - ptr).reshape(56, 64))
         dj = ff.graphics.depth.from_camera(wl.mi_scene, spp=2, seed=9)
         tj, _, _ = go.trace_primary(wl.mi_scene.camera_struct(0), 2, 1, 9)
         ok = (dj.cpu().numpy() > 0) == (tj > 0)
@@ -173,8 +179,19 @@ def test_scene_randomize_render_and_depth_against_oracle(oracle):
     # laser rays cast into the scene
     ids = ff.graphics.depth.cast_laser_id(wl.mi_scene, wl.laser.originPerRay(), -wl.laser.rays() * torch.tensor([1.0, -1.0, 1.0], device=DEV))
     assert ids.shape[0] == 36
+    # random_depth_maps (depth.py:169-190): map k is the depth image of the k-th randomised pose — replayed under the
+    # same seeds, pose by pose, against the oracle
+    torch.manual_seed(21)
+    random.seed(21)
     maps = ff.graphics.depth.random_depth_maps(wl.ff_scene, wl.mi_scene, num_maps=3, spp=1)
     assert tuple(maps.shape) == (3, 56, 64) and float(maps.max()) > 0
+    torch.manual_seed(21)
+    random.seed(21)
+    for k in range(3):
+        wl.ff_scene.randomize()
+        tk, _, _ = _oracle_pose(oracle, wl).trace_primary(wl.mi_scene.camera_struct(0), 1, 0, 0)
+        np.testing.assert_allclose(maps[k].cpu().numpy(), tk.reshape(56, 64), rtol=1e-5, atol=1e-6, err_msg=f"depth map {k}")
+    assert not torch.equal(maps[0], maps[1])
 
 
 def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypatch):
@@ -566,8 +583,26 @@ def test_postprocessing_chain_on_device(oracle):
     assert float(sil[cy, cx]) == pytest.approx(float(img[cy, cx]), rel=1e-5)  # inside the circle
     far = (cx + r + 40 < 512) and float(sil[cy, min(cx + r + 40, 511)]) or 0.0
     assert far == 0.0
+    # the whole silhouette image against the same chain on the host: Euclidean disc -> oracle blur (11, 5) -> product
+    # (cv2.circle's rasterisation of the rim and kornia's blur are [EXT]: the disc and K3's kernel are stated, not pinned)
+    yy, xx = np.mgrid[0:512, 0:512]
+    disc = (((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).astype(np.float32)
+    np.testing.assert_allclose(sil.cpu().numpy(), img.cpu().numpy() * oracle.blur_fwd(disc, 11, 5.0), rtol=0, atol=1e-7)
+    # white noise on the reference's numpy stream: golden g12 (values of WhiteNoise.post_process under np.random.seed,
+    # and a three-function chain whose gates consume python `random` in the reference's order)
+    g = load_golden("g12_dataset_helpers.npz")
+    np.random.seed(7)
+    got = pp.WhiteNoise(0.02, 0.1, 1.0).post_process(torch.from_numpy(g["wn_image"]).float().to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), g["wn_out"], rtol=0, atol=2e-7)
+    chain12 = pp.PostProcessor([pp.WhiteNoise(0.0, 0.05, 0.5), pp.WhiteNoise(0.1, 0.02, 0.5), pp.WhiteNoise(-0.05, 0.2, 0.5)])
+    random.seed(11)
+    np.random.seed(12)
+    for k in range(6):
+        out = chain12.post_process(torch.from_numpy(g["wn_image"]).float().to(DEV))
+        np.testing.assert_allclose(out.cpu().numpy(), g["chain_out"][k], rtol=0, atol=4e-7, err_msg=f"chain pass {k}")
+    assert not np.array_equal(g["chain_out"][0], g["chain_out"][1])
     torch.manual_seed(0)
-    noisy = pp.WhiteNoise(0.0, 0.05, 2.0).apply(img)
+    noisy = pp.WhiteNoise(0.0, 0.05, 2.0, rng="device").apply(img)
     assert 0.03 < float((noisy - img).std()) < 0.06 and float(noisy.min()) >= 0 and float(noisy.max()) <= 1
     chain = pp.PostProcessor([pp.GaussianBlur((3, 3), (5, 5), 0.5), pp.ApplySilhouette(), pp.WhiteNoise(0.0, 0.05, 0.5)])
     out = chain.post_process(img)
@@ -601,6 +636,29 @@ def test_pattern_initialisers(oracle):
     phys = laser.rays() * torch.tensor([-1.0, 1.0, -1.0], device=DEV)  # see Laser docstring: physical direction
     mask = le.generate_epipolar_constraints(wl.mi_scene, wl.params, "cpu")
     assert tuple(mask.shape) == (96, 96) and 0 < int(mask.sum()) <= 96 * 96
+    # value checks of the SMARTY chain's pieces: the variance map is the per-pixel std of the depth maps (+ epsilon);
+    # laser_from_ndc_points aims every beam at the point where the camera ray through the chosen pixel meets the plane
+    # at the mean depth — so casting those beams from the laser origin must reproduce those points
+    dm = torch.rand(5, 12, 16)
+    np.testing.assert_allclose(le.probability_distribution_from_depth_maps(dm, 0.01).numpy(), dm.numpy().std(axis=0, ddof=1) + 0.01, rtol=1e-5)
+    np.testing.assert_allclose(le.probability_distribution_from_depth_maps(dm.numpy(), 0.01), dm.numpy().std(axis=0) + 0.01, rtol=1e-6)
+    torch.manual_seed(3)
+    pick = le.points_from_probability_distribution(torch.tensor([[0.0, 1.0, 0.0], [2.0, 0.0, 0.0]]), 2)
+    assert sorted(pick.tolist()) == [1, 3]  # only the non-zero pixels can be drawn, without replacement
+    cam = wl.mi_scene.sensors()[0]
+    depth_maps = torch.full((2, 96, 96), 1.5)
+    chosen = torch.tensor([96 * 10 + 20, 96 * 50 + 48, 96 * 80 + 7])
+    origin = torch.tensor([0.05, -0.02, 0.0])
+    dirs = le.laser_from_ndc_points(cam, origin, depth_maps, chosen, device="cpu")
+    ray_o, ray_d = le.create_rays(cam, chosen)
+    cam_o = cam.world_transform().matrix.torch()[0][:3, 3]
+    _, cam_d = le.get_camera_direction(cam)
+    cam_d = cam_d[0] / cam_d[0].norm()
+    tt = ((cam_o + 1.5 * cam_d - ray_o) @ cam_d) / (ray_d @ cam_d)  # closed form: plane through cam_o + 1.5 d, normal d
+    target = ray_o + ray_d * tt[:, None]
+    want = (target - origin) / (target - origin).norm(dim=1, keepdim=True)
+    np.testing.assert_allclose(dirs.numpy(), want.numpy(), atol=2e-6)
+    assert float((dirs.norm(dim=1) - 1).abs().max()) < 1e-6
     t = intersections.rayPlane(torch.zeros(2, 3), torch.tensor([[0.0, 0, 1], [0, 1, 0]]), torch.tensor([[0.0, 0, 2]]), torch.tensor([[0.0, 0, -1]]))
     assert float(t[0]) == pytest.approx(2.0)
     assert bool(intersections.sphereSphere(torch.zeros(1, 3), torch.tensor([1.0]), torch.tensor([[1.5, 0, 0]]), torch.tensor([1.0])))
