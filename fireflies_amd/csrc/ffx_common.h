@@ -102,11 +102,30 @@ static inline uint64_t ffx_apex_offset(const ffx_bvh_info *info, int k) { return
 // a reference: cluster << 31 | element << 6 | (count - 1), where `element` indexes the ONE array of 16-byte
 // elements formed by the wide nodes (64 each) followed by the triangle boxes in leaf-slot order.  In the
 // triangle part `ref` is unused.
+#ifndef FFX_WIDE_F32
+#define FFX_WIDE_F32 1
+#endif
+#if FFX_WIDE_F32
+// float32 boxes (32-byte elements): the 16-bit grid cost six integer-to-float conversions per step of the walk —
+// conversions issue at the 4-cycle rate, a third of the box test's issue time (tools/ubench/issue_rates.hip) — for
+// half the bytes of a structure that lives in L2 anyway.  WideHdr then holds the identity grid (org 0, step 1).
+struct __attribute__((aligned(16))) WideChild {
+  float lo[3];
+  float hi0;   // hi[0]
+  float hi12[2]; // hi[1], hi[2]
+  int32_t ref;
+  int32_t pad;
+};
+static_assert(sizeof(WideChild) == 32, "wide child must be 32 bytes");
+#define FFX_WIDE_ELEM_SHIFT 5
+#else
 struct __attribute__((aligned(16))) WideChild {
   uint16_t q[6];
   int32_t ref;
 };
 static_assert(sizeof(WideChild) == 16, "wide child must be 16 bytes");
+#define FFX_WIDE_ELEM_SHIFT 4
+#endif
 #define FFX_WIDE 64
 #define FFX_WIDE_MAX_DEPTH 6
 // grid header written by the refit: org[3], step[3] (floats)

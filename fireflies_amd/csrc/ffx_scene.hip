@@ -146,19 +146,31 @@ __device__ __forceinline__ void grid_of_root(const BvhNode *__restrict__ nodes, 
   }
 }
 __device__ __forceinline__ void quantise_box(const float lo[3], const float hi[3], const float org[3], const float inv[3], WideChild &c) {
+#if FFX_WIDE_F32
+  // the boxes as they are (leaf boxes carry the refit's relative padding; the walk's packet constants carry the
+  // padding for its own roundings, make_widepk)
+  c.lo[0] = lo[0]; c.lo[1] = lo[1]; c.lo[2] = lo[2];
+  c.hi0 = hi[0]; c.hi12[0] = hi[1]; c.hi12[1] = hi[2];
+#else
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float ql = floorf((lo[a] - org[a]) * inv[a]) - 1.0f, qh = ceilf((hi[a] - org[a]) * inv[a]) + 1.0f;
     c.q[a] = (uint16_t)fminf(fmaxf(ql, 0.f), 65535.f);
     c.q[3 + a] = (uint16_t)fminf(fmaxf(qh, 0.f), 65535.f);
   }
+#endif
 }
 __global__ void __launch_bounds__(UPD_BLOCK)
     k_wide_quant(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, int n_tris, WideChild *__restrict__ tq, WideChild *__restrict__ wn,
                  const int32_t *__restrict__ wsrc, int n_wchild, WideHdr *__restrict__ hdr) {
   const int i = blockIdx.x * UPD_BLOCK + threadIdx.x;
   float org[3], step[3], inv[3];
+#if FFX_WIDE_F32
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { org[a] = 0.f; step[a] = 1.f; inv[a] = 1.f; }
+#else
   grid_of_root(nodes, org, step, inv);
+#endif
   if (i == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) { hdr->org[a] = org[a]; hdr->step[a] = step[a]; }
@@ -169,6 +181,9 @@ __global__ void __launch_bounds__(UPD_BLOCK)
     WideChild c;
     quantise_box(lo, hi, org, inv, c);
     c.ref = 0;
+#if FFX_WIDE_F32
+    c.pad = 0;
+#endif
     tq[i] = c;
   } else if (i < n_tris + n_wchild) {
     const int k = i - n_tris;

@@ -734,6 +734,8 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm
 // max3 with the VOP3 clamp bit: the result is clamped to [0, 1] at no cost
 __device__ __forceinline__ float vmax3_sat(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// b is wave-uniform (an SGPR): VOP2's first source may be scalar — no v_mov in front of the min
+__device__ __forceinline__ float vmin2_s(float a, uint32_t b_bits) { float r; asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b_bits)); return r; }
 
 // Box test of the octant loops: one v_fma_f32 per plane with the node plane as the SGPR operand.
 // Per plane the ray carries a multiplier and a constant,
@@ -979,7 +981,11 @@ template <int R>
 __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v3 o, const v3 (&aid)[R], const uint32_t (&oct)[R], const wmask (&active)[R],
                                               uint32_t oct0, uint32_t mixed, float &spread) {
   float dmax_all = 0.f, dspread = 0.f; // largest |d_a| and largest (max |d_a| - min |d_a|) over the axes, in units of 1/scale
+#if FFX_WIDE_F32
+  const float org[3] = {0.f, 0.f, 0.f}, step[3] = {1.f, 1.f, 1.f}; // float boxes: no grid to fold in
+#else
   const float org[3] = {hdr->org[0], hdr->org[1], hdr->org[2]}, step[3] = {hdr->step[0], hdr->step[1], hdr->step[2]};
+#endif
   const float oo[3] = {o.x, o.y, o.z};
   float mN[3], kN[3], mF[3], kF[3], mG[3], kG[3];
   const float k22 = 2.384185791015625e-07f, k21 = 4.76837158203125e-07f, kw = 1.0000004f;
@@ -1047,7 +1053,7 @@ template <bool ANY, int OCT, int R>
 __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const TriApex *__restrict__ recs, const WidePk &pk, const v3 (&d)[R], const float (&tmin)[R],
                                                   const float (&tmax)[R], const float (&sw)[R], const wmask (&active)[R], Hit (&h)[R], wmask (&occluded)[R],
                                                   uint2 *__restrict__ stack) {
-  const uint32_t lane16 = (threadIdx.x & 63u) << 4;
+  const uint32_t lane16 = (threadIdx.x & 63u) << FFX_WIDE_ELEM_SHIFT; // byte offset of this lane's element within a node / cluster
   int budget = FFX_WIDE_MAX_WORK;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1087,12 +1093,20 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
     // ---- fetch: lane j reads child j of an inner node or box j of a cluster: one 16-byte load per lane, no
     // divergence (lanes beyond the count re-read the last element and are masked out of the result)
     const uint32_t cnt1 = (uint32_t)cur & 63u;
-    const uint32_t eoff = ((uint32_t)cur & 0x7fffffc0u) >> 2; // element index * 16
-    const uint32_t lo16 = lane16 < (cnt1 << 4) ? lane16 : (cnt1 << 4);
-    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16);
+    const uint32_t eoff = ((uint32_t)cur & 0x7fffffc0u) >> (6 - FFX_WIDE_ELEM_SHIFT); // element index * element size
+    const uint32_t lo16 = lane16 < (cnt1 << FFX_WIDE_ELEM_SHIFT) ? lane16 : (cnt1 << FFX_WIDE_ELEM_SHIFT);
     const wmask lanes = ~0ull >> (63u - cnt1);
+#if FFX_WIDE_F32
+    const float4 qa = *reinterpret_cast<const float4 *>(ebase + eoff + lo16);
+    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16 + 16); // hi.y, hi.z, ref, pad  (q.z = ref)
+    const float lx = qa.x, ly = qa.y, lz = qa.z, hx = qa.w, hy = __uint_as_float(q.x), hz = __uint_as_float(q.y);
+#define FFX_QREF q.z
+#else
+    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16);
     const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
     const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
+#define FFX_QREF q.w
+#endif
     float nx, ny, nz, fx, fy, fz, tn;
     if constexpr (OCT < 8) { // which plane is entered first is known at compile time
       nx = (OCT & 1) ? hx : lx; fx = (OCT & 1) ? lx : hx;
@@ -1107,13 +1121,13 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       const float t2 = fmaxf(fmaxf(fmaf(fx, pk.mG.x, -pk.kG.x), fmaf(fy, pk.mG.y, -pk.kG.y)), fmaf(fz, pk.mG.z, -pk.kG.z));
       tn = vmax3_sat(t1, t2, t2);
     }
-    const float tf = vmin2(vmin3(fmaf(fx, pk.mF.x, -pk.kF.x), fmaf(fy, pk.mF.y, -pk.kF.y), fmaf(fz, pk.mF.z, -pk.kF.z)), __uint_as_float(hb));
+    const float tf = vmin2_s(vmin3(fmaf(fx, pk.mF.x, -pk.kF.x), fmaf(fy, pk.mF.y, -pk.kF.y), fmaf(fz, pk.mF.z, -pk.kF.z)), hb);
     wmask hit = m_le(tn, tf) & lanes;
     FFX_TSTOP(tw, ANY ? 8 : 0);
     if (cur < 0) {
       // ---- cluster: the surviving triangles are tested exactly, lanes back on the rays
       FFX_STAT(ANY ? 12 : 8);
-      const uint32_t slot0 = (eoff >> 4) - ws.tq0;
+      const uint32_t slot0 = (eoff >> FFX_WIDE_ELEM_SHIFT) - ws.tq0;
 #ifdef FFX_EXP_ANY_NOTRIS // timing experiment: any-hit walks without the exact triangle tests
       if (ANY) hit = 0ull;
 #endif
@@ -1191,7 +1205,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       // key = entry distance (6 low mantissa bits dropped: it only orders and culls, conservatively) | lane
       const uint32_t key = (__float_as_uint(tn) & ~63u) | (threadIdx.x & 63u);
       if ((hit & (hit - 1ull)) == 0ull) { // a single child
-        cur = __builtin_amdgcn_readlane((int)q.w, wff1(hit));
+        cur = __builtin_amdgcn_readlane((int)FFX_QREF, wff1(hit));
         FFX_TSTOP(tw, ANY ? 10 : 2);
         continue;
       }
@@ -1201,9 +1215,9 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       const uint32_t near_lane = wave_reduce_nn<false>(msel(hit, key, 0xffffffffu)) & 63u;
 #endif
       const wmask others = hit & ~(1ull << near_lane);
-      if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(q.w, key);
+      if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(FFX_QREF, key);
       sp += wpop(others);
-      cur = __builtin_amdgcn_readlane((int)q.w, (int)near_lane);
+      cur = __builtin_amdgcn_readlane((int)FFX_QREF, (int)near_lane);
       FFX_TSTOP(tw, ANY ? 10 : 2);
       continue;
     }
@@ -1220,6 +1234,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
   }
 }
 
+#undef FFX_QREF
 // wide walk of R rays per lane that share their origin `o` (the apex the records `recs` were prepared for).
 // Packets the interval test is bad at go to the binary walk instead (its box tests are per ray): packets whose
 // rays disagree on a direction sign, packets whose directions spread more than FFX_WIDE_FAT of their length

@@ -168,14 +168,15 @@ def test_host_bvh_structure(case):
     # ---- the 64-wide overlay: clusters reachable from wide_root tile the leaf slots exactly once, every
     # wide node is referenced once, every child knows the binary node whose box it mirrors
     nw = info.n_wide
-    wn = blob[info.off_wnodes : info.off_wnodes + 1024 * nw].view(np.int32).reshape(nw, 64, 4)
+    ESZ = 32  # bytes per wide element: float32 box {lo[3], hi[3]}, ref, pad (ffx_common.h: WideChild)
+    wn = blob[info.off_wnodes : info.off_wnodes + 64 * ESZ * nw].view(np.int32).reshape(nw, 64, ESZ // 4)
     wsrc = blob[info.off_wsrc : info.off_wsrc + 256 * nw].view(np.int32).reshape(nw, 64)
     wcov = np.zeros(F, np.int32)
     wrefs = np.zeros(max(nw, 1), np.int32)
     depth_seen = 0
 
     tq0 = 64 * nw
-    assert info.off_tq == info.off_wnodes + 16 * tq0
+    assert info.off_tq == info.off_wnodes + ESZ * tq0
 
     def visit(ref, depth):
         nonlocal depth_seen
@@ -195,7 +196,7 @@ def test_host_bvh_structure(case):
             if j < cnt:
                 src = int(wsrc[idx, j])
                 assert 0 <= src < 2 * info.n_nodes
-                visit(int(wn[idx, j, 3]), depth + 1)
+                visit(int(wn[idx, j, 6]), depth + 1)
             else:
                 assert int(wsrc[idx, j]) == -1
 
@@ -204,4 +205,4 @@ def test_host_bvh_structure(case):
     assert nw == 0 or (wrefs == 1).all()
     assert depth_seen == info.wide_depth <= 6
     assert (info.n_wide == 0) == (F <= 64)
-    assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + 16 * F <= info.off_wsrc
+    assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + ESZ * F <= info.off_wsrc
