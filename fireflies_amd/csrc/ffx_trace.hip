@@ -1242,7 +1242,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
 // contains hundreds of boxes no ray comes near — colon, 1024^2: 15.9 ms with every packet on the wide walk,
 // 4.2 ms on the binary walk), and walks that exceed FFX_WIDE_MAX_WORK.  Results are identical either way.
 #ifndef FFX_WIDE_FAT
-#define FFX_WIDE_FAT 0.02f
+#define FFX_WIDE_FAT 0.04f
 #endif
 template <bool ANY, int R>
 __device__ __forceinline__ void traverse_wide(const WideScene &ws, const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[R],
@@ -1347,6 +1347,11 @@ template <bool ANY, int R, bool WIDE>
 __device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ nodes, const TriApex *__restrict__ arecs, const WideScene &ws, uint2 *__restrict__ stack,
                                                     const v3 (&o)[R], const v3 (&d)[R], const float (&tmin)[R], const float (&tmax)[R], const bool (&active)[R],
                                                     Hit (&h)[R], bool (&found)[R]) {
+#ifdef FFX_EXP_NOWALK // timing experiment: every ray "hits" leaf slot 0 half-way along its range — what everything but the walks costs
+#pragma unroll
+  for (int r = 0; r < R; ++r) { h[r].t = ANY ? -INFINITY : 0.5f * (tmin[r] + tmax[r]); h[r].prim = ANY ? -1 : 0; h[r].shape = -1; h[r].slot = ANY ? -1 : 0; found[r] = false; }
+  return;
+#endif
   if constexpr (WIDE) traverse_wide<ANY, R>(ws, nodes, arecs, o, d, tmin, tmax, active, h, found, stack);
   else if constexpr (R == 1 && octant_loops()) traverse_packet1<ANY>(nodes, arecs, o, d, tmin, tmax, active, h, found);
   else traverse_packet<ANY, R>(nodes, arecs, o, d, tmin, tmax, active, h, found);

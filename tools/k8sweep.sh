@@ -3,7 +3,7 @@
 # usage (on the GPU box): bash tools/k8sweep.sh "name|ENV=1 ENV2=x" ...   (FFX_LIB etc. go in the env part)
 for spec in "$@"; do
   name=${spec%%|*}; envs=${spec#*|}
-  out=$(env $envs python bench.py --steps 60 --warmup 10 --no-grad-steps --no-cpu-baseline 2>/dev/null | tail -1)
+  out=$(env $envs python bench.py --steps 60 --warmup 10 --no-grad-steps --no-cpu-baseline $K8SWEEP_ARGS 2>/dev/null | tail -1)
   python - "$name" "$out" <<'PY'
 import json, sys
 try:
