@@ -734,6 +734,9 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm
 // max3 with the VOP3 clamp bit: the result is clamped to [0, 1] at no cost
 __device__ __forceinline__ float vmax3_sat(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a * b with b wave-uniform, as ONE v_mul with a scalar operand (written out so that the vectoriser does not pair the
+// multiplies of a pixel's channels into v_pk_mul_f32, whose VGPR copy of b it hoists out of every loop and spills)
+__device__ __forceinline__ float vmul_s(float a, float b_uniform) { float r; asm("v_mul_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b_uniform)); return r; }
 // b is wave-uniform (an SGPR): VOP2's first source may be scalar — no v_mov in front of the min
 __device__ __forceinline__ float vmin2_s(float a, uint32_t b_bits) { float r; asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b_bits)); return r; }
 
@@ -1572,7 +1575,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
                        int jitter, uint32_t seed_key, int bw_log2,
                        int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
-  const int blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // (wave-uniform by construction; readfirstlane tells the compiler, which otherwise carries everything derived from it in VGPRs)
+  const int blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (blk >= n_blocks) return; // whole wave
   const int lane = threadIdx.x & 63;
   const int ppw_log2 = bw_log2 + bh_log2; // pixels per wave (log2)
@@ -1660,13 +1664,14 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   __shared__ float s_acc[R][3][PK_BLOCK];
   // each wave of the workgroup owns its own tile; the waves never synchronise
   // a wave walks `ppw` (1, 2 or 4) of its tile's four pixels; 4 / ppw waves share a tile
-  const int wv = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
   const int wpt = NSUB / ppw;
   const int tile = wv / wpt, sub0 = (wv % wpt) * ppw;
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
   const int passes = (spp + 63) >> 6;
-  const float inv_spp = 1.0f / (float)spp;
+  // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
+  const float inv_spp_u = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(1.0f / (float)spp)));
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
     packet_pixels<R>(tile, tiles_x, sub, px, py);
@@ -1683,7 +1688,11 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     // adjoint cache: window origin (wave-uniform) and shape of this pixel's footprint, -1 until a sample is lit
     int fox = -1, foy = -1, fshape = -1;
     if (cache) {
-      if (lane < 32) s_foot[lane] = 0.f;
+      // (index laundered: the compiler otherwise keeps &s_foot[lane] in a VGPR across the whole kernel — and, at the
+      // 64-VGPR budget, spills it: 256 B of scratch traffic per wave for an address that costs two instructions)
+      int lz = lane;
+      asm volatile("" : "+v"(lz));
+      if (lz < 32) s_foot[lz] = 0.f;
       __builtin_amdgcn_wave_barrier();
     }
     for (int pass = 0; pass < passes; ++pass) {
@@ -1785,7 +1794,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         slot->shape = (uint16_t)(fshape < 0 ? 0 : fshape);
         slot->lit = fox >= 0 ? 1 : 0;
       }
-      if (fox >= 0 && lane < 25) slot->w[lane] = s_foot[lane];
+      int lw = lane;
+      asm volatile("" : "+v"(lw));
+      if (fox >= 0 && lw < 25) slot->w[lw] = s_foot[lw];
     }
     // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
 #pragma unroll
@@ -1795,14 +1806,14 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         size_t o = (size_t)pix[r] * 3;
         if (fp16) {
           _Float16 *p = (_Float16 *)img;
-          p[o] = (_Float16)(a0 * inv_spp);
-          p[o + 1] = (_Float16)(a1 * inv_spp);
-          p[o + 2] = (_Float16)(a2 * inv_spp);
+          p[o] = (_Float16)vmul_s(a0, inv_spp_u);
+          p[o + 1] = (_Float16)vmul_s(a1, inv_spp_u);
+          p[o + 2] = (_Float16)vmul_s(a2, inv_spp_u);
         } else {
           float *p = (float *)img;
-          p[o] = a0 * inv_spp;
-          p[o + 1] = a1 * inv_spp;
-          p[o + 2] = a2 * inv_spp;
+          p[o] = vmul_s(a0, inv_spp_u);
+          p[o + 1] = vmul_s(a1, inv_spp_u);
+          p[o + 2] = vmul_s(a2, inv_spp_u);
         }
       }
     }
@@ -1817,7 +1828,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                     const float *__restrict__ gimg, float *__restrict__ gtex) {
   constexpr int NSUB = 4 / R;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
-  const int tile = xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy; see kernarg_shade)
   const float inv_spp = 1.0f / (float)spp;
