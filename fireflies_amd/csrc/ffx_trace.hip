@@ -970,6 +970,25 @@ __device__ __forceinline__ uint32_t wave_reduce_nn(uint32_t v) {
   const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
   return MAX ? smax_u32(smax_u32(a, b), smax_u32(c, e)) : smin_u32(smin_u32(a, b), smin_u32(c, e));
 }
+// three reductions at once (make_widepk: the three axes).  The chains are interleaved, so that the two instructions
+// between a DPP write and the next DPP read of the same register ARE the wait states the hazard asks for (no s_nop per
+// step), and the rows are combined by row_bcast:15 / row_bcast:31 (rows 1, 3 take lane 15 of the row before; rows 2, 3
+// take lane 31): the wave's result sits in lane 63 — one readlane and no scalar min/max per value.
+// Checked against a shuffle reduction on random data by tools/ubench/reduce3_check.hip.
+#define FFX_R3_STEP(OP, CTRL, MASK)                               \
+  OP " %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+  OP " %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+  OP " %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"
+#define FFX_R3_ALL(OP)                                                                                                                            \
+  "s_nop 1\n\t" FFX_R3_STEP(OP, "quad_perm:[1,0,3,2]", "0xf") FFX_R3_STEP(OP, "quad_perm:[2,3,0,1]", "0xf") FFX_R3_STEP(OP, "row_half_mirror", "0xf") \
+      FFX_R3_STEP(OP, "row_mirror", "0xf") FFX_R3_STEP(OP, "row_bcast:15", "0xa") FFX_R3_STEP(OP, "row_bcast:31", "0xc")
+template <bool MAX>
+__device__ __forceinline__ void wave_reduce3_nn(uint32_t (&v)[3]) {
+  if (MAX) asm(FFX_R3_ALL("v_max_u32_dpp") : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+  else asm(FFX_R3_ALL("v_min_u32_dpp") : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = (uint32_t)__builtin_amdgcn_readlane((int)v[a], 63);
+}
 __device__ __forceinline__ uint32_t mbcnt64(wmask m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ int wff1(wmask m) { return __builtin_ctzll(m); }
 
@@ -993,46 +1012,73 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
   float mN[3], kN[3], mF[3], kF[3], mG[3], kG[3];
   const float k22 = 2.384185791015625e-07f, k21 = 4.76837158203125e-07f, kw = 1.0000004f;
   WidePk pk;
+  // smallest / largest |1/d_a| over the active rays; on a mixed axis: the smallest of each sign
+  uint32_t lo[3], hi[3], lo2[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const bool is_mixed = (mixed >> a) & 1u;
-    // smallest / largest |1/d_a| over the active rays; on a mixed axis: the smallest of each sign
-    uint32_t lo = 0x7f800000u, hi = 0u, lo2 = 0x7f800000u; // +inf, 0, +inf
+    lo[a] = 0x7f800000u; hi[a] = 0u; lo2[a] = 0x7f800000u; // +inf, 0, +inf
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t v = __float_as_uint(a == 0 ? aid[r].x : (a == 1 ? aid[r].y : aid[r].z));
       const wmask negr = __builtin_amdgcn_uicmp((oct[r] >> a) & 1u, 0u, 33);
       const wmask first = is_mixed ? (active[r] & ~negr) : active[r];
       const uint32_t vl = msel(first, v, 0x7f800000u), vh = msel(active[r], v, 0u), vl2 = msel(active[r] & negr, v, 0x7f800000u);
-      lo = lo < vl ? lo : vl;
-      hi = hi > vh ? hi : vh;
-      lo2 = lo2 < vl2 ? lo2 : vl2;
+      lo[a] = lo[a] < vl ? lo[a] : vl;
+      hi[a] = hi[a] > vh ? hi[a] : vh;
+      lo2[a] = lo2[a] < vl2 ? lo2[a] : vl2;
     }
-    const float mn = __uint_as_float(wave_reduce_nn<false>(lo));
+  }
+  if (mixed == 0u) { // (a compile-time constant at the call sites) the three axes in interleaved chains
+    wave_reduce3_nn<false>(lo);
+    wave_reduce3_nn<true>(hi);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = wave_reduce_nn<false>(lo[a]);
+      if ((mixed >> a) & 1u) lo2[a] = wave_reduce_nn<false>(lo2[a]);
+      else hi[a] = wave_reduce_nn<true>(hi[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const bool is_mixed = (mixed >> a) & 1u;
+    const float mn = __uint_as_float(lo[a]);
     const bool negd = !is_mixed && ((oct0 >> a) & 1u);
     pk.neg[a] = negd ? ~0ull : 0ull;
     const float sN = negd ? -mn : mn;
     // near side (same padding as make_rayoct: the entry can only move earlier)
     const float oidn = oo[a] * sN, cN = oidn + fabsf(oidn) * k22;
+#if FFX_WIDE_F32
+    mN[a] = sN;
+    kN[a] = cN + fabsf(cN) * k21;
+#else
     const float gn = org[a] * sN;
     mN[a] = step[a] * sN;
     kN[a] = (cN - gn) + (fabsf(cN) + fabsf(gn)) * k21;
+#endif
     if (!is_mixed) {
       // far side, widened (make_rayslab)
-      const float mx = __uint_as_float(wave_reduce_nn<true>(hi));
+      const float mx = __uint_as_float(hi[a]);
       const float dhi = __builtin_amdgcn_rcpf(mn), dlo = __builtin_amdgcn_rcpf(mx); // |d_a| range of the packet
       dmax_all = fmaxf(dmax_all, dhi);
       dspread = fmaxf(dspread, dhi - dlo);
       const float sF = negd ? -mx : mx;
       const float oidf = oo[a] * sF, cF = (oidf - fabsf(oidf) * k22) * kw;
-      const float sFk = sF * kw, gf = org[a] * sFk;
+      const float sFk = sF * kw;
+#if FFX_WIDE_F32
+      mF[a] = sFk;
+      kF[a] = cF - fabsf(cF) * k21;
+#else
+      const float gf = org[a] * sFk;
       mF[a] = step[a] * sFk;
       kF[a] = (cF - gf) - (fabsf(cF) + fabsf(gf)) * k21;
+#endif
       mG[a] = 0.f;
       kG[a] = 1e30f; // tg_a = -1e30
     } else {
       // second entry bound from the far (= hi) plane: (o - x) * m2 = fma(q, -step * m2, -(org * m2 - o * m2))
-      const float m2 = __uint_as_float(wave_reduce_nn<false>(lo2));
+      const float m2 = __uint_as_float(lo2[a]);
       const float og = oo[a] * m2, gg = org[a] * m2;
       mG[a] = -(step[a] * m2);
       kG[a] = (gg - og) + (fabsf(gg) + fabsf(og)) * k21;
