@@ -970,6 +970,9 @@ __device__ __forceinline__ uint32_t wave_reduce_nn(uint32_t v) {
   const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
   return MAX ? smax_u32(smax_u32(a, b), smax_u32(c, e)) : smin_u32(smin_u32(a, b), smin_u32(c, e));
 }
+#ifndef FFX_WIDE_FAT
+#define FFX_WIDE_FAT 0.04f // see traverse_wide
+#endif
 // three reductions at once (make_widepk: the three axes).  The chains are interleaved, so that the two instructions
 // between a DPP write and the next DPP read of the same register ARE the wait states the hazard asks for (no s_nop per
 // step), and the rows are combined by row_bcast:15 / row_bcast:31 (rows 1, 3 take lane 15 of the row before; rows 2, 3
@@ -1024,14 +1027,48 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
       const wmask negr = __builtin_amdgcn_uicmp((oct[r] >> a) & 1u, 0u, 33);
       const wmask first = is_mixed ? (active[r] & ~negr) : active[r];
       const uint32_t vl = msel(first, v, 0x7f800000u), vh = msel(active[r], v, 0u), vl2 = msel(active[r] & negr, v, 0x7f800000u);
-      lo[a] = lo[a] < vl ? lo[a] : vl;
-      hi[a] = hi[a] > vh ? hi[a] : vh;
-      lo2[a] = lo2[a] < vl2 ? lo2[a] : vl2;
+      if (R == 1) { lo[a] = vl; hi[a] = vh; lo2[a] = vl2; } // (aid is finite: safe_rcp_dir clamps tiny components)
+      else {
+        lo[a] = lo[a] < vl ? lo[a] : vl;
+        hi[a] = hi[a] > vh ? hi[a] : vh;
+        lo2[a] = lo2[a] < vl2 ? lo2[a] : vl2;
+      }
     }
   }
   if (mixed == 0u) { // (a compile-time constant at the call sites) the three axes in interleaved chains
     wave_reduce3_nn<false>(lo);
     wave_reduce3_nn<true>(hi);
+#if FFX_WIDE_F32
+    // Everything from here on is wave-uniform float arithmetic, which this machine can only do on the vector ALU at the
+    // 4-cycle rate of scalar-operand instructions: it is written to be short.  Signs are applied to the bit patterns
+    // (scalar ALU); the two paddings of each side are one fma (2^-20 >= 2^-22 + 2^-21 + the roundings they cover:
+    // of o * m, of m * k and of the box test's own fma); the fat-packet measure
+    //     max_a (1/mn_a - 1/mx_a) / max_a (1/mn_a) <= FAT   <=>   for all a:  M (mx_a - mn_a) <= FAT mn_a mx_a,  M = min_a mn_a
+    // needs no reciprocal.
+    const float PAD = 9.5367431640625e-07f; // 2^-20
+    const float M = fminf(__uint_as_float(lo[0]), fminf(__uint_as_float(lo[1]), __uint_as_float(lo[2])));
+    bool fat = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t sgn = ((oct0 >> a) & 1u) << 31;
+      pk.neg[a] = sgn ? ~0ull : 0ull;
+      const float mn = __uint_as_float(lo[a]), mx = __uint_as_float(hi[a]);
+      fat |= M * (mx - mn) > FFX_WIDE_FAT * (mn * mx);
+      const float sN = __uint_as_float(lo[a] ^ sgn), sFk = __uint_as_float(hi[a] ^ sgn) * kw;
+      const float oidn = oo[a] * sN, oidf = oo[a] * sFk;
+      mN[a] = sN;
+      kN[a] = fmaf(fabsf(oidn), PAD, oidn);   // the entry can only move earlier
+      mF[a] = sFk;
+      kF[a] = fmaf(-fabsf(oidf), PAD, oidf);  // the exit only later (on top of the far-side widening kw)
+      mG[a] = 0.f;
+      kG[a] = 1e30f;
+    }
+    pk.mN = V3(mN[0], mN[1], mN[2]); pk.kN = V3(kN[0], kN[1], kN[2]);
+    pk.mF = V3(mF[0], mF[1], mF[2]); pk.kF = V3(kF[0], kF[1], kF[2]);
+    pk.mG = V3(mG[0], mG[1], mG[2]); pk.kG = V3(kG[0], kG[1], kG[2]);
+    spread = fat ? 1.0f : 0.0f;
+    return pk;
+#endif
   } else {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -1049,14 +1086,9 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
     const float sN = negd ? -mn : mn;
     // near side (same padding as make_rayoct: the entry can only move earlier)
     const float oidn = oo[a] * sN, cN = oidn + fabsf(oidn) * k22;
-#if FFX_WIDE_F32
-    mN[a] = sN;
-    kN[a] = cN + fabsf(cN) * k21;
-#else
     const float gn = org[a] * sN;
     mN[a] = step[a] * sN;
     kN[a] = (cN - gn) + (fabsf(cN) + fabsf(gn)) * k21;
-#endif
     if (!is_mixed) {
       // far side, widened (make_rayslab)
       const float mx = __uint_as_float(hi[a]);
@@ -1065,15 +1097,9 @@ __device__ __forceinline__ WidePk make_widepk(const WideHdr *__restrict__ hdr, v
       dspread = fmaxf(dspread, dhi - dlo);
       const float sF = negd ? -mx : mx;
       const float oidf = oo[a] * sF, cF = (oidf - fabsf(oidf) * k22) * kw;
-      const float sFk = sF * kw;
-#if FFX_WIDE_F32
-      mF[a] = sFk;
-      kF[a] = cF - fabsf(cF) * k21;
-#else
-      const float gf = org[a] * sFk;
+      const float sFk = sF * kw, gf = org[a] * sFk;
       mF[a] = step[a] * sFk;
       kF[a] = (cF - gf) - (fabsf(cF) + fabsf(gf)) * k21;
-#endif
       mG[a] = 0.f;
       kG[a] = 1e30f; // tg_a = -1e30
     } else {
@@ -1120,7 +1146,11 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
     for (int r = 0; r < R; ++r) m = fmaxf(m, h[r].t * sw[r]); // -inf (inactive / occluded) drops out against 0
     return wave_reduce_nn<true>(__float_as_uint(m));
   };
-  uint32_t hb = packet_hts();
+  // before any hit every active ray's distance is its tmax, which the unit of the box test maps to 0.999 * (1 + a few
+  // ulp) by construction (sw = 0.999 / tmax * 1.0000002): a constant just above that is a valid (conservative) packet
+  // bound — and saves the wave-wide maximum at the start of every walk.  It stays below 1, the value the clamp gives
+  // boxes beyond the rays' range.
+  uint32_t hb = __float_as_uint(0.9991f);
   int sp = 0;
   int32_t cur = ws.root;
   const char *ebase = reinterpret_cast<const char *>(ws.elems);
@@ -1290,9 +1320,6 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
 // (the samples of a pixel on a depth discontinuity, seen from an emitter: a fan whose bounding wedge
 // contains hundreds of boxes no ray comes near — colon, 1024^2: 15.9 ms with every packet on the wide walk,
 // 4.2 ms on the binary walk), and walks that exceed FFX_WIDE_MAX_WORK.  Results are identical either way.
-#ifndef FFX_WIDE_FAT
-#define FFX_WIDE_FAT 0.04f
-#endif
 template <bool ANY, int R>
 __device__ __forceinline__ void traverse_wide(const WideScene &ws, const BvhNode *__restrict__ nodes, const TriApex *__restrict__ recs, const v3 (&o)[R],
                                               const v3 (&d)[R], const float (&tmin)[R], const float (&tmax)[R], const bool (&act)[R], Hit (&h)[R], bool (&found)[R],
