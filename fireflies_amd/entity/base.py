@@ -14,6 +14,9 @@ device-to-host transfer instead of one `.tolist()` sync per draw, and that trans
 draws themselves (they run on a side stream), never for the render that is still in flight; matrices
 reach the GPU as kernel arguments of ffx_scene_update_h.
 """
+import math
+
+import numpy as np
 import torch
 
 from .. import sampling
@@ -276,18 +279,25 @@ class Transformable:
     # ------------------------------------------------------------------ sampling: draw (device) / compose (host)
     @staticmethod
     def _rotation_matrix(rx, ry, rz):
-        # names as in the reference: the "z" slot uses Pitch (about Y), the "y" slot Yaw (about Z)
-        zMat = ffmath.getPitchTransform(rz, _CPU)
-        yMat = ffmath.getYawTransform(ry, _CPU)
-        xMat = ffmath.getRollTransform(rx, _CPU)
-        m = torch.zeros((4, 4))
-        m[:3, :3] = zMat @ yMat @ xMat
+        # names as in the reference: the "z" slot uses Pitch (about Y), the "y" slot Yaw (about Z); Z @ Y @ X in float32.
+        # Built with numpy (same float32 products as utils.math.get*Transform + torch.matmul, bit for bit — pinned by
+        # golden g7): a handful of 3x3 tensors from Python lists cost more host time than the whole refit launch.
+        cz, sz = math.cos(rz), math.sin(rz)
+        cy, sy = math.cos(ry), math.sin(ry)
+        cx, sx = math.cos(rx), math.sin(rx)
+        zMat = np.array([[cz, 0, sz], [0, 1, 0], [-sz, 0, cz]], dtype=np.float32)  # getPitchTransform
+        yMat = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]], dtype=np.float32)  # getYawTransform
+        xMat = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=np.float32)  # getRollTransform
+        m = np.zeros((4, 4), dtype=np.float32)
+        m[:3, :3] = (zMat @ yMat) @ xMat
         m[3, 3] = 1.0
-        return m
+        return torch.from_numpy(m)
 
     @staticmethod
     def _translation_matrix(tx, ty, tz):
-        return torch.tensor([[1.0, 0.0, 0.0, tx], [0.0, 1.0, 0.0, ty], [0.0, 0.0, 1.0, tz], [0.0, 0.0, 0.0, 1.0]])
+        m = np.eye(4, dtype=np.float32)
+        m[0, 3], m[1, 3], m[2, 3] = tx, ty, tz
+        return torch.from_numpy(m)
 
     def _draw_attributes(self, batch):
         slots = {"f": {}, "v": {}}
@@ -316,7 +326,8 @@ class Transformable:
         t = self._translation_matrix(*values[ticket["t"]])
         self._last_translation = t
         self._last_draw = (values[ticket["t"]], values[ticket["r"]])
-        self._randomized_world = (t + self._centroid_mat) @ self._rotation_matrix(*values[ticket["r"]]) @ self._world
+        rot = self._rotation_matrix(*values[ticket["r"]])
+        self._randomized_world = torch.from_numpy(((t.numpy() + self._centroid_mat.numpy()) @ rot.numpy()) @ self._world.numpy())
         self._compose_attributes(ticket["a"], values)
 
     # the last drawn translation / rotation (attributes of the reference), as tensors on demand

@@ -12,6 +12,7 @@ ffx_scene_update, which transforms the vertices inside the BVH-refit pass.
 """
 import os
 
+import numpy as np
 import torch
 
 from . import base
@@ -168,8 +169,11 @@ class Mesh(base.Transformable):
         self._last_translation = t
         self._last_draw = (values[ticket["t"]], values[ticket["r"]])
         sx, sy, sz = values[ticket["s"]]
-        sc = torch.tensor([[sx, 0.0, 0.0, 0.0], [0.0, sy, 0.0, 0.0], [0.0, 0.0, sz, 0.0], [0.0, 0.0, 0.0, 1.0]])
-        self._randomized_world = (t + self._centroid_mat) @ self._rotation_matrix(*values[ticket["r"]]) @ sc @ self._world
+        sc = np.zeros((4, 4), dtype=np.float32)
+        sc[0, 0], sc[1, 1], sc[2, 2], sc[3, 3] = sx, sy, sz, 1.0
+        rot = self._rotation_matrix(*values[ticket["r"]])
+        # (numpy: the same float32 products as the torch expression, see Transformable._rotation_matrix)
+        self._randomized_world = torch.from_numpy((((t.numpy() + self._centroid_mat.numpy()) @ rot.numpy()) @ sc) @ self._world.numpy())
 
     def load_animation(self, path: str):
         frames = [load_obj_vertices(os.path.join(path, f)) for f in sorted(os.listdir(path)) if f.endswith(".obj")]
