@@ -699,3 +699,43 @@ def test_fused_pattern_kernels_match_the_unfused_oracle(oracle, n, size, sigma):
     np.testing.assert_allclose(host(m_d), m_o, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(host(m_d), host(opt.state[r_t]["exp_avg"]), rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(host(v_d), host(opt.state[r_t]["exp_avg_sq"]), rtol=1e-6, atol=1e-10)
+
+
+def test_dpp_three_chain_reduction_against_shuffle_reference(tmp_path):
+    """the interleaved DPP / row_bcast wave reduction that make_widepk uses for the packet bounds
+    (ffx_trace.hip: wave_reduce3_nn), compiled as the stand-alone checker tools/ubench/reduce3_check.hip and compared
+    with a plain reduction on random data (4096 waves x 3 chains x min/max).  A wrong bound would make the packet
+    test non-conservative, i.e. missed hits — which the parity tests above would only see where it happens."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "reduce3_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-w", "-o", exe, os.path.join(root, "tools", "ubench", "reduce3_check.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr
+
+
+def test_wide_overlay_builders_give_identical_images(oracle, monkeypatch):
+    """the 64-wide overlay only decides which boxes a packet visits, never what it hits: the three host builders
+    (greedy SAH cut by area — the default —, by triangle count, and the first, layered one; FFX_WIDE_BUILD, read by
+    ffx_bvh_build_host) must render bit-identical images and identical primitive ids — and the same as the oracle."""
+    sc = scenes.vocalfold(width=72, height=64, tex=96, frames=3, n_fold=24, tube=(24, 32))
+    sd = scene_desc.scene_desc(sc, shadows=True)
+    tex = _tex(sc)
+    cam = scene_desc.camera_from_sensor(sc.camera)
+    imgs, prims, shapes_seen = [], [], []
+    for mode in ("area", "count", "layers"):
+        monkeypatch.setenv("FFX_WIDE_BUILD", mode)
+        go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 2))
+        shapes_seen.append((gd.info.n_wide, gd.info.wide_depth))
+        imgs.append(gd.render_fwd(sd, dev(alb), tex, 8, seed=11))
+        prims.append(gd.trace_primary(cam, 4, 1, 5)[2])
+    assert len(set(shapes_seen)) > 1, shapes_seen  # they really are different trees
+    for k in (1, 2):
+        assert torch.equal(imgs[0], imgs[k]) and torch.equal(prims[0], prims[k])
+    _, _, p_o = go.trace_primary(cam, 4, 1, 5)
+    assert (host(prims[0]) == p_o).mean() > 0.9995
