@@ -318,14 +318,14 @@ def main():
         k8g_ms, _ = _kernel_ms(gevents, "render_fwd")
         gevents.clear()
         bg = algorithmic_bytes(wg, W, H)
-        # streaming adjoint over the per-pixel footprint cache written by K8: the 16-byte header of every
-        # pixel's slot, the 25-float footprint of the LIT pixels, the stray records, d(loss)/d(img); gtex written once.
+        # streaming adjoint over the per-pixel footprint cache written by K8: the 8-byte header of every
+        # pixel, the 25-float footprint of the LIT pixels, the stray records, d(loss)/d(img); gtex written once.
         # Lit pixels / strays are counted in the cache the last step left behind.
         n_lit = n_stray = 0
         if opt._cache is not None:
             n_stray = int(opt._cache[:4].view(torch.int32).item())
-            n_lit = int((opt._cache[64:64 + 128 * W * H].view(W * H, 128)[:, 6] != 0).sum().item())
-        bytes_k9c = 16 * W * H + 100 * n_lit + 24 * n_stray + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
+            n_lit = int((opt._cache[64:64 + 8 * W * H].view(W * H, 8)[:, 6] != 0).sum().item())  # CachePix.lit (8-byte headers, dense)
+        bytes_k9c = 8 * W * H + 100 * n_lit + 24 * n_stray + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
         grad = {
             "grad_steps_per_sec": args.steps / t_grad,
             "grad_samples_per_sec": S * args.steps / t_grad,

@@ -1705,15 +1705,21 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x_tb, int sub,
 // (measured: 87 % of the lit pixels within 4x4 texels, 99.5 % within 5x5), nearly always on ONE shape, so the
 // adjoint of a pixel is  gtex[T] += (gimg[p] . albedo[shape] (. colour)) / spp * W[T]  with the per-pixel
 // FOOTPRINT  W[T] = sum over its samples of fac * bilinear weight — 25 floats instead of 64 records of 16 B.
-//   [0, 64)              CacheHdr
-//   64 + 128 * pixel     CacheSlot: window origin, shape, the 5x5 footprint
-//   off_arena + 24 * i   CacheStray: single samples that do not fit (outside the window: depth discontinuities,
-//                        grazing surfaces; a second shape in the pixel; later 64-sample passes of a pixel that
-//                        drift), allocated with one atomic per affected wave
-// 39.8 MB at 512x512x64 (was 268 MB), of which K8 writes and K9 reads ~10 MB: unlit pixels carry a header only.
+//   [0, 64)                        CacheHdr
+//   64 + 8 * pixel                 CachePix: window origin, shape, lit flag — a DENSE array, so that the adjoint reads
+//                                  2 MB of it instead of touching every pixel's footprint
+//   off_foot + 112 * pixel         CacheFoot: the 5x5 footprint (written and read for lit pixels only)
+//   off_arena + 24 * i             CacheStray: single samples that do not fit (outside the window: depth discontinuities,
+//                                  grazing surfaces; a second shape in the pixel; later 64-sample passes of a pixel that
+//                                  drift), allocated with one atomic per affected wave
+// 37.7 MB at 512x512x64 (one 16-byte record per sample was 268 MB), of which K8 writes and K9 reads ~10 MB.
 struct CacheHdr { uint32_t n_stray, cap_stray, dropped, pad[13]; };
-struct __attribute__((aligned(16))) CacheSlot { int16_t x0, y0; uint16_t shape, lit; uint32_t pad[2]; float w[25]; uint32_t pad2[3]; };
-static_assert(sizeof(CacheSlot) == 128, "cache slot must be 128 bytes");
+struct __attribute__((aligned(8))) CachePix { int16_t x0, y0; uint16_t shape, lit; };
+static_assert(sizeof(CachePix) == 8, "cache pixel header must be 8 bytes");
+struct __attribute__((aligned(16))) CacheFoot { float w[25]; uint32_t pad[3]; };
+static_assert(sizeof(CacheFoot) == 112, "cache footprint must be 112 bytes");
+__host__ __device__ inline size_t cache_off_foot(size_t n_pix) { return (64 + 8 * n_pix + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t cache_off_arena(size_t n_pix) { return (cache_off_foot(n_pix) + sizeof(CacheFoot) * n_pix + 127) & ~(size_t)127; }
 struct CacheStray { uint32_t pix, xy_shape; float ax, ay, fac; uint32_t pad; }; // xy_shape = x0 | y0 << 12 ... see stray_pack
 static_assert(sizeof(CacheStray) == 24, "stray record must be 24 bytes");
 __host__ __device__ inline size_t cache_stray_capacity(int w, int h, int spp) {
@@ -1816,7 +1822,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const uint32_t cap = hdr->cap_stray;
             if (base + n <= cap) {
               if (lit && !in_win) {
-                CacheStray *rec = reinterpret_cast<CacheStray *>(cache + 64 + (size_t)128 * (size_t)W * (size_t)H) + base + mbcnt64(straym);
+                CacheStray *rec = reinterpret_cast<CacheStray *>(cache + cache_off_arena((size_t)W * (size_t)H)) + base + mbcnt64(straym);
                 rec->pix = pix[0];
                 rec->xy_shape = (uint32_t)(st[0].ubx + 1) | ((uint32_t)(st[0].uby + 1) << 12) | ((uint32_t)st[0].shape << 24);
                 rec->ax = st[0].wx1;
@@ -1861,15 +1867,16 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     }
     if (cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
       __builtin_amdgcn_wave_barrier();
-      CacheSlot *slot = reinterpret_cast<CacheSlot *>(cache + 64) + pix[0];
       if (lane == 0) {
-        slot->x0 = (int16_t)fox; slot->y0 = (int16_t)foy;
-        slot->shape = (uint16_t)(fshape < 0 ? 0 : fshape);
-        slot->lit = fox >= 0 ? 1 : 0;
+        CachePix hp;
+        hp.x0 = (int16_t)fox; hp.y0 = (int16_t)foy;
+        hp.shape = (uint16_t)(fshape < 0 ? 0 : fshape);
+        hp.lit = fox >= 0 ? 1 : 0;
+        reinterpret_cast<CachePix *>(cache + 64)[pix[0]] = hp; // one 8-byte store
       }
       int lw = lane;
       asm volatile("" : "+v"(lw));
-      if (fox >= 0 && lw < 25) slot->w[lw] = s_foot[lw];
+      if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + cache_off_foot((size_t)W * (size_t)H))[pix[0]].w[lw] = s_foot[lw];
     }
     // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
 #pragma unroll
@@ -1981,13 +1988,13 @@ __global__ void __launch_bounds__(256)
     const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const int e = threadIdx.x & 31;
     if (pixel >= n_pix) return;
-    const CacheSlot *slot = reinterpret_cast<const CacheSlot *>(cache + 64) + pixel;
-    if (!slot->lit || e >= 25) return;
-    const float w = slot->w[e];
+    const CachePix hp = reinterpret_cast<const CachePix *>(cache + 64)[pixel];
+    if (!hp.lit || e >= 25) return;
+    const float w = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix))[pixel].w[e];
     if (w == 0.f) return;
     const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
-    const float *alb = albedo + 3 * (int)slot->shape;
-    const int x = (int)slot->x0 + e % 5, y = (int)slot->y0 + e / 5;
+    const float *alb = albedo + 3 * (int)hp.shape;
+    const int x = (int)hp.x0 + e % 5, y = (int)hp.y0 + e / 5;
     if (p.tc == 1) {
       const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
       if (ws != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, ws * w);
@@ -2003,7 +2010,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t n = min(hdr->n_stray, hdr->cap_stray);
   const uint32_t i = (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x;
   if (i >= n) return;
-  const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + 64 + (size_t)128 * (size_t)n_pix)[i];
+  const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + cache_off_arena((size_t)n_pix))[i];
   const long pixel = rec.pix;
   const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
   const int ix0 = (int)(rec.xy_shape & 0xfffu) - 1, iy0 = (int)((rec.xy_shape >> 12) & 0xfffu) - 1, shape = (int)(rec.xy_shape >> 24);
@@ -2331,7 +2338,7 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
 
 size_t ffx_render_cache_bytes(int width, int height, int spp) {
   if (width < 1 || height < 1 || spp < 1) return 0;
-  return 64 + (size_t)128 * width * height + sizeof(CacheStray) * cache_stray_capacity(width, height, spp);
+  return cache_off_arena((size_t)width * height) + sizeof(CacheStray) * cache_stray_capacity(width, height, spp);
 }
 
 int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,

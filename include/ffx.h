@@ -346,7 +346,7 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
  * libffx_hip: per pixel the FOOTPRINT of its samples in the projector texture — window origin, shape and 5x5
  * weights  W[T] = sum_s fac_s * bilinear weight_s(T)  (the render is linear in the texture, the samples of a pixel
  * land on a handful of texels of one shape) — plus an arena of 24-byte records for the few samples that do not
- * fit: 39.8 MB at 512x512x64, ~10 MB of it touched.  The oracle keeps one 16-byte record per
+ * fit: 37.7 MB at 512x512x64, ~10 MB of it touched.  The oracle keeps one 16-byte record per
  * sample.  ffx_render_bwd_cached scatters  gimg . albedo (. colour) / spp * W  into gtex (accumulated; the caller
  * zeroes it).  It needs neither the BVH nor the camera: the geometry may be re-fitted between the forward and the
  * backward pass (shape_albedo must still hold the forward's values).  Limits: projector textures up to 4094^2,
