@@ -303,7 +303,7 @@ size_t ffx_bvh_blob_bytes(int n_tris) {
   // of more than FFX_WIDE triangles or is the parent of clusters; bounded generously), 64 x (16 + 4) B each
   const size_t wmax = f / 16 + 4;
   return 64 + f * sizeof(BvhNode) + f * 4 + f * 4 + 64 + (f + FFX_LEAF_MAX) * sizeof(TriRec) + 64 + FFX_N_APEX * (size_t)ffx_apex_stride(n_tris < 1 ? 1 : n_tris) +
-         wmax * FFX_WIDE * (sizeof(WideChild) + 4) + f * sizeof(WideChild) + 256;
+         wmax * FFX_WIDE * (sizeof(WideChild) + 4) + (f + FFX_WIDE) * sizeof(WideChild) + 256;
 }
 
 int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int n_tris, void *blob, size_t blob_bytes, ffx_bvh_info *info) {
@@ -395,7 +395,7 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   info->off_wnodes = off; // wide nodes and triangle boxes form ONE array of 16-byte elements (see wide_elem_ref)
   off += (uint64_t)wide.size() * FFX_WIDE * sizeof(WideChild);
   info->off_tq = off;
-  off += (uint64_t)n_tris * sizeof(WideChild);
+  off += ((uint64_t)n_tris + FFX_WIDE) * sizeof(WideChild); // 64 elements of padding: every lane of a cluster step reads one
   off = (off + 63) & ~(uint64_t)63;
   info->off_wsrc = off;
   off += (uint64_t)wide.size() * FFX_WIDE * 4;

@@ -955,20 +955,14 @@ __device__ __forceinline__ uint32_t smin_u32(uint32_t a, uint32_t b) { uint32_t 
 __device__ __forceinline__ uint32_t smax_u32(uint32_t a, uint32_t b) { uint32_t r; asm("s_max_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
 template <bool MAX>
 __device__ __forceinline__ uint32_t wave_reduce_nn(uint32_t v) {
-  if (MAX) {
-    FFX_DPP_STEP("v_max_u32_dpp", "quad_perm:[1,0,3,2]");
-    FFX_DPP_STEP("v_max_u32_dpp", "quad_perm:[2,3,0,1]");
-    FFX_DPP_STEP("v_max_u32_dpp", "row_half_mirror");
-    FFX_DPP_STEP("v_max_u32_dpp", "row_mirror");
-  } else {
-    FFX_DPP_STEP("v_min_u32_dpp", "quad_perm:[1,0,3,2]");
-    FFX_DPP_STEP("v_min_u32_dpp", "quad_perm:[2,3,0,1]");
-    FFX_DPP_STEP("v_min_u32_dpp", "row_half_mirror");
-    FFX_DPP_STEP("v_min_u32_dpp", "row_mirror");
-  }
-  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), e = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-  return MAX ? smax_u32(smax_u32(a, b), smax_u32(c, e)) : smin_u32(smin_u32(a, b), smin_u32(c, e));
+  // ONE asm block (the compiler pads every asm statement with its own hazard nop): four butterfly steps inside the rows,
+  // row_bcast:15 / :31 carry the row results to lane 63 (see wave_reduce3_nn) — one readlane, no scalar min/max
+#define FFX_R1(OP, CTRL, MASK) "s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"
+#define FFX_R1_ALL(OP) FFX_R1(OP, "quad_perm:[1,0,3,2]", "0xf") FFX_R1(OP, "quad_perm:[2,3,0,1]", "0xf") FFX_R1(OP, "row_half_mirror", "0xf") \
+    FFX_R1(OP, "row_mirror", "0xf") FFX_R1(OP, "row_bcast:15", "0xa") FFX_R1(OP, "row_bcast:31", "0xc")
+  if (MAX) asm(FFX_R1_ALL("v_max_u32_dpp") : "+v"(v));
+  else asm(FFX_R1_ALL("v_min_u32_dpp") : "+v"(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 #ifndef FFX_WIDE_FAT
 #define FFX_WIDE_FAT 0.04f // see traverse_wide
@@ -1173,14 +1167,18 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
     // divergence (lanes beyond the count re-read the last element and are masked out of the result)
     const uint32_t cnt1 = (uint32_t)cur & 63u;
     const uint32_t eoff = ((uint32_t)cur & 0x7fffffc0u) >> (6 - FFX_WIDE_ELEM_SHIFT); // element index * element size
-    const uint32_t lo16 = lane16 < (cnt1 << FFX_WIDE_ELEM_SHIFT) ? lane16 : (cnt1 << FFX_WIDE_ELEM_SHIFT);
-    const wmask lanes = ~0ull >> (63u - cnt1);
 #if FFX_WIDE_F32
-    const float4 qa = *reinterpret_cast<const float4 *>(ebase + eoff + lo16);
-    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16 + 16); // hi.y, hi.z, ref, pad  (q.z = ref)
+    // lane j reads element j whatever the count: the unused children of a wide node hold inverted boxes (never hit), a
+    // cluster's run is followed by other triangles' boxes (masked below; the array is padded by 64 elements) — so the
+    // scalar side of the step is three instructions: the lane's byte offset is ONE vector add on a loop-invariant base.
+    const uint32_t voff = eoff + lane16;
+    const float4 qa = *reinterpret_cast<const float4 *>(ebase + voff);
+    const uint4 q = *reinterpret_cast<const uint4 *>(ebase + voff + 16); // hi.y, hi.z, ref, pad  (q.z = ref)
     const float lx = qa.x, ly = qa.y, lz = qa.z, hx = qa.w, hy = __uint_as_float(q.x), hz = __uint_as_float(q.y);
 #define FFX_QREF q.z
 #else
+    const uint32_t lo16 = lane16 < (cnt1 << FFX_WIDE_ELEM_SHIFT) ? lane16 : (cnt1 << FFX_WIDE_ELEM_SHIFT);
+    const wmask lanes = ~0ull >> (63u - cnt1);
     const uint4 q = *reinterpret_cast<const uint4 *>(ebase + eoff + lo16);
     const float lx = (float)(q.x & 0xffffu), ly = (float)(q.x >> 16), lz = (float)(q.y & 0xffffu);
     const float hx = (float)(q.y >> 16), hy = (float)(q.z & 0xffffu), hz = (float)(q.z >> 16);
@@ -1201,9 +1199,16 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       tn = vmax3_sat(t1, t2, t2);
     }
     const float tf = vmin2_s(vmin3(fmaf(fx, pk.mF.x, -pk.kF.x), fmaf(fy, pk.mF.y, -pk.kF.y), fmaf(fz, pk.mF.z, -pk.kF.z)), hb);
+#if FFX_WIDE_F32
+    wmask hit = m_le(tn, tf);
+#else
     wmask hit = m_le(tn, tf) & lanes;
+#endif
     FFX_TSTOP(tw, ANY ? 8 : 0);
     if (cur < 0) {
+#if FFX_WIDE_F32
+      hit &= ~0ull >> (63u - cnt1); // only the cluster's own triangles
+#endif
       // ---- cluster: the surviving triangles are tested exactly, lanes back on the rays
       FFX_STAT(ANY ? 12 : 8);
       const uint32_t slot0 = (eoff >> FFX_WIDE_ELEM_SHIFT) - ws.tq0;
@@ -1212,7 +1217,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
 #endif
       while (hit != 0ull) {
         const uint32_t j = (uint32_t)wff1(hit);
-        hit &= hit - 1ull;
+        asm("s_bitset0_b64 %0, %1" : "+s"(hit) : "s"(j)); // hit &= hit - 1 in one scalar instruction instead of three
         --budget;
         FFX_STAT(ANY ? 6 : 2);
 #ifdef FFX_STATS
@@ -1283,7 +1288,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       // ---- inner node: descend into the child entered first, push the others with their entry distances.
       // key = entry distance (6 low mantissa bits dropped: it only orders and culls, conservatively) | lane
       const uint32_t key = (__float_as_uint(tn) & ~63u) | (threadIdx.x & 63u);
-      if ((hit & (hit - 1ull)) == 0ull) { // a single child
+      if (wpop(hit) == 1) { // a single child
         cur = __builtin_amdgcn_readlane((int)FFX_QREF, wff1(hit));
         FFX_TSTOP(tw, ANY ? 10 : 2);
         continue;
