@@ -1154,8 +1154,15 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
   unsigned n_steps = 0, n_tris = 0;
 #endif
   FFX_TSTART(tw);
-  for (;;) {
-    if (--budget < 0) return false;
+  // ONE loop with ONE exit: every way out of a step (walk complete, every ray decided, budget spent) is folded into the
+  // wave-uniform flag `go`, and every way on (descend, pop) into `nxt`.  Written with returns / continues from inside the
+  // nested loops, the compiler's control-flow structuriser turned the exits into state variables and a dispatch
+  // chain of ~15 scalar instructions and half a dozen branches per step.
+  bool go, completed = true;
+  do {
+    go = true;
+    bool descend = false;
+    int32_t nxt = 0;
     FFX_STAT(ANY ? 5 : 1);
 #ifdef FFX_STATS
     ++n_steps;
@@ -1274,7 +1281,7 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
             wmask left = 0ull;
 #pragma unroll
             for (int r = 0; r < R; ++r) left |= active[r] & ~occluded[r];
-            if (left == 0ull) { FFX_TSTOP(tw, ANY ? 9 : 1); return true; } // every ray of the packet is decided
+            if (left == 0ull) { go = false; hit = 0ull; } // every ray of the packet is decided: leave the cluster, end the walk
             // (the undecided rays keep their full length: the packet's hit distance does not change)
           } else {
             hb = packet_hts();
@@ -1288,34 +1295,35 @@ __device__ __forceinline__ bool traverse_wide_oct(const WideScene &ws, const Tri
       // ---- inner node: descend into the child entered first, push the others with their entry distances.
       // key = entry distance (6 low mantissa bits dropped: it only orders and culls, conservatively) | lane
       const uint32_t key = (__float_as_uint(tn) & ~63u) | (threadIdx.x & 63u);
-      if (wpop(hit) == 1) { // a single child
-        cur = __builtin_amdgcn_readlane((int)FFX_QREF, wff1(hit));
-        FFX_TSTOP(tw, ANY ? 10 : 2);
-        continue;
-      }
-#ifdef FFX_EXP_LANE_ORDER // experiment: descend in lane order instead of nearest-first
-      const uint32_t near_lane = (uint32_t)wff1(hit);
-#else
-      const uint32_t near_lane = wave_reduce_nn<false>(msel(hit, key, 0xffffffffu)) & 63u;
+      uint32_t near_lane = (uint32_t)wff1(hit);
+      if (wpop(hit) != 1) { // several children: nearest first, the others onto the stack
+#ifndef FFX_EXP_LANE_ORDER // (experiment: descend in lane order instead of nearest-first)
+        near_lane = wave_reduce_nn<false>(msel(hit, key, 0xffffffffu)) & 63u;
 #endif
-      const wmask others = hit & ~(1ull << near_lane);
-      if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(FFX_QREF, key);
-      sp += wpop(others);
-      cur = __builtin_amdgcn_readlane((int)FFX_QREF, (int)near_lane);
+        const wmask others = hit & ~(1ull << near_lane);
+        if (__builtin_amdgcn_inverse_ballot_w64(others)) stack[sp + (int)mbcnt64(others)] = make_uint2(FFX_QREF, key);
+        sp += wpop(others);
+      }
+      nxt = __builtin_amdgcn_readlane((int)FFX_QREF, (int)near_lane);
+      descend = true;
       FFX_TSTOP(tw, ANY ? 10 : 2);
-      continue;
     }
-    // ---- pop: skip entries the rays can no longer reach
-    for (;;) {
-      if (sp == 0) { FFX_TSTOP(tw, ANY ? 11 : 3); return true; }
-      FFX_STAT(ANY ? 14 : 10);
-      --sp;
-      const uint2 e = stack[sp];
-      const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), etn = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y) & ~63u;
-      if (etn <= hb) { cur = (int32_t)ref; break; }
+    if (!descend && go) {
+      // ---- pop: skip entries the rays can no longer reach; an empty stack ends the walk
+      go = false;
+      while (sp > 0) {
+        FFX_STAT(ANY ? 14 : 10);
+        --sp;
+        const uint2 e = stack[sp];
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), etn = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y) & ~63u;
+        if (etn <= hb) { nxt = (int32_t)ref; go = true; break; }
+      }
+      FFX_TSTOP(tw, ANY ? 11 : 3);
     }
-    FFX_TSTOP(tw, ANY ? 11 : 3);
-  }
+    if (--budget < 0) { completed = false; go = false; } // (a walk that ends on its last allowed step is repeated by the caller: harmless)
+    cur = nxt;
+  } while (go);
+  return completed;
 }
 
 #undef FFX_QREF
