@@ -1894,7 +1894,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
     // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float a0 = wave_sum64(s_acc[r][0][threadIdx.x]), a1 = wave_sum64(s_acc[r][1][threadIdx.x]), a2 = wave_sum64(s_acc[r][2][threadIdx.x]);
+      // the three channel sums in interleaved DPP chains (FFX_R3_ALL, see wave_reduce3_nn: butterfly inside the rows,
+      // row_bcast to lane 63) — a fixed order, like the 18 ds_bpermute + add pairs of three shuffle trees it replaces
+      float a0 = s_acc[r][0][threadIdx.x], a1 = s_acc[r][1][threadIdx.x], a2 = s_acc[r][2][threadIdx.x];
+      asm(FFX_R3_ALL("v_add_f32_dpp") : "+v"(a0), "+v"(a1), "+v"(a2));
+      a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a0), 63));
+      a1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a1), 63));
+      a2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a2), 63));
       if (lane == 0 && live[r]) {
         size_t o = (size_t)pix[r] * 3;
         if (fp16) {
