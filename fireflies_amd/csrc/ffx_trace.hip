@@ -1774,7 +1774,6 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       live[r] = tile < n_tiles && px[r] < W && py[r] < H;
       any_live |= live[r];
       pix[r] = (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r];
-      s_acc[r][0][threadIdx.x] = s_acc[r][1][threadIdx.x] = s_acc[r][2][threadIdx.x] = 0.f;
     }
     if (wballot(any_live) == 0ull) continue;
     // adjoint cache: window origin (wave-uniform) and shape of this pixel's footprint, -1 until a sample is lit
@@ -1851,7 +1850,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       const ShadeK &ct = kernarg_shade(); // phase: texture gather and accumulation
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (!st[r].hit) continue;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f; // this pass's contribution of the lane's sample
+        if (st[r].hit) {
         float r0 = st[r].spot[0], r1 = st[r].spot[1], r2 = st[r].spot[2];
         if (st[r].has_proj) {
           const int tc = ct.tc;
@@ -1873,9 +1873,37 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
           }
         }
         const float *alb = albedo + 3 * st[r].shape;
-        s_acc[r][0][threadIdx.x] += alb[0] * r0;
-        s_acc[r][1][threadIdx.x] += alb[1] * r1;
-        s_acc[r][2][threadIdx.x] += alb[2] * r2;
+        c0 = alb[0] * r0;
+        c1 = alb[1] * r1;
+        c2 = alb[2] * r2;
+        }
+        // running sums of a pixel that needs several 64-sample passes are parked in LDS between the passes; the
+        // usual single pass never touches it (it had cost 15 LDS operations per pixel)
+        if (pass > 0) { c0 += s_acc[r][0][threadIdx.x]; c1 += s_acc[r][1][threadIdx.x]; c2 += s_acc[r][2][threadIdx.x]; }
+        if (pass + 1 < passes) {
+          s_acc[r][0][threadIdx.x] = c0; s_acc[r][1][threadIdx.x] = c1; s_acc[r][2][threadIdx.x] = c2;
+        } else {
+          // last pass: combine the 64 lanes in a fixed order (deterministic, no atomics) — the three channel sums in
+          // interleaved DPP chains (FFX_R3_ALL, see wave_reduce3_nn: butterfly inside the rows, row_bcast to lane 63)
+          asm(FFX_R3_ALL("v_add_f32_dpp") : "+v"(c0), "+v"(c1), "+v"(c2));
+          const float a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(c0), 63));
+          const float a1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(c1), 63));
+          const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(c2), 63));
+          if (lane == 0 && live[r]) {
+            size_t o = (size_t)pix[r] * 3;
+            if (fp16) {
+              _Float16 *p = (_Float16 *)img;
+              p[o] = (_Float16)vmul_s(a0, inv_spp_u);
+              p[o + 1] = (_Float16)vmul_s(a1, inv_spp_u);
+              p[o + 2] = (_Float16)vmul_s(a2, inv_spp_u);
+            } else {
+              float *p = (float *)img;
+              p[o] = vmul_s(a0, inv_spp_u);
+              p[o + 1] = vmul_s(a1, inv_spp_u);
+              p[o + 2] = vmul_s(a2, inv_spp_u);
+            }
+          }
+        }
       }
     }
     if (cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
@@ -1890,31 +1918,6 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       int lw = lane;
       asm volatile("" : "+v"(lw));
       if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + cache_off_foot((size_t)W * (size_t)H))[pix[0]].w[lw] = s_foot[lw];
-    }
-    // combine the 64 samples of each pixel in a fixed shuffle order: deterministic, no atomics
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // the three channel sums in interleaved DPP chains (FFX_R3_ALL, see wave_reduce3_nn: butterfly inside the rows,
-      // row_bcast to lane 63) — a fixed order, like the 18 ds_bpermute + add pairs of three shuffle trees it replaces
-      float a0 = s_acc[r][0][threadIdx.x], a1 = s_acc[r][1][threadIdx.x], a2 = s_acc[r][2][threadIdx.x];
-      asm(FFX_R3_ALL("v_add_f32_dpp") : "+v"(a0), "+v"(a1), "+v"(a2));
-      a0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a0), 63));
-      a1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a1), 63));
-      a2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a2), 63));
-      if (lane == 0 && live[r]) {
-        size_t o = (size_t)pix[r] * 3;
-        if (fp16) {
-          _Float16 *p = (_Float16 *)img;
-          p[o] = (_Float16)vmul_s(a0, inv_spp_u);
-          p[o + 1] = (_Float16)vmul_s(a1, inv_spp_u);
-          p[o + 2] = (_Float16)vmul_s(a2, inv_spp_u);
-        } else {
-          float *p = (float *)img;
-          p[o] = vmul_s(a0, inv_spp_u);
-          p[o + 1] = vmul_s(a1, inv_spp_u);
-          p[o + 2] = vmul_s(a2, inv_spp_u);
-        }
-      }
     }
   }
   FFX_TFLUSH();
