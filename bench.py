@@ -248,8 +248,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    local = local % max(torch.cuda.device_count(), 1)  # (rehearsals with more ranks than devices share a device)
     torch.cuda.set_device(local)
-    dist.init()
+    dist.init(os.environ.get("FFX_DIST_BACKEND"))  # default: nccl (= RCCL); gloo only for single-GPU rehearsals of the N > 1 path
     dev = torch.device("cuda", local)
     W = H = args.res
 
