@@ -16,7 +16,10 @@ from fireflies_amd.optim import PatternOptimizer  # noqa: E402
 
 def main():
     out = sys.argv[1]
-    rank, world, local = dist.init("nccl")
+    backend = sys.argv[2] if len(sys.argv) > 2 else "nccl"  # "gloo": rehearsal of the same step with both ranks on ONE device
+    if backend != "nccl":
+        torch.cuda.set_device(0)
+    rank, world, local = dist.init(backend)
     dev = torch.cuda.current_device()
     wl = workloads.vocalfold(device="cuda", width=64, height=56, tex=96, grid=6, frames=5, n_fold=20, tube=(20, 24))
     opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=4)

@@ -454,26 +454,30 @@ def test_multi_sample_step_matches_oracle(oracle, S):
     assert opt.step_index == 2 and not torch.equal(before, wl.laser._rays.detach())
 
 
-def test_two_rank_rccl_step_matches_one_rank(tmp_path):
-    """BASELINE configs[3]'s exchange on real RCCL: two fresh processes (one per GPU, torch.distributed
-    backend "nccl" = RCCL) run the same 4-sample step, each on its share {k : k mod 2 = rank}; after the ONE
-    all-reduce of the flat [3N+1] buffer both hold the gradient of a single process that ran all four."""
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_rank_rccl_step_matches_one_rank(tmp_path, backend):
+    """BASELINE configs[3]'s exchange: two fresh processes run the same 4-sample step, each on its share
+    {k : k mod 2 = rank}; after the ONE all-reduce of the flat [3N+1] buffer both hold the gradient of a single
+    process that ran all four.  "nccl": real RCCL, one process per GPU (skipped with fewer than two GPUs);
+    "gloo": the same two-rank step with both ranks on ONE device — the sharding, the seeds, the exchange point and the
+    replicated update are exercised on a one-GPU box too, only the transport differs."""
     import json
     import os
     import subprocess
     import sys
 
-    if torch.cuda.device_count() < 2:
+    if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path)]
+           os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path), backend]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
-    assert all(o["world"] == 2 and o["backend"] == "nccl" for o in outs) and {o["device"] for o in outs} == {0, 1}
+    assert all(o["world"] == 2 and o["backend"] == backend for o in outs)
+    assert {o["device"] for o in outs} == ({0, 1} if backend == "nccl" else {0})
     # single process, all four samples
     kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21)
     wl = _small()
