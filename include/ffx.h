@@ -29,8 +29,13 @@
  *       FFX_TILE_BLOCK=0..8      log2 side of the square blocks in which tiles are enumerated (default 3)
  *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs (default 0: interleaved)
  *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
+ *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
+ *     tests/test_hip_parity.py::test_wide_overlay_builders_give_identical_images):
+ *       FFX_WIDE_BUILD=area|count|layers   builder of the 64-wide overlay (default area: greedy SAH cut)
+ *       FFX_WIDE_CLUSTER=4..64, FFX_WIDE_COST_EXP=x   experiment knobs of that builder (largest cluster; priority area * count^x)
  *     The Python host layer reads FFX_LIB (alternative BUILD of this library), FFX_ASYNC_UPDATE=0 (single BVH blob,
- *     refit on the caller's stream), FFX_CACHE_LIMIT_GB (per-sample adjoint cache budget), FFX_PREDRAW=0.
+ *     refit on the caller's stream), FFX_CACHE_LIMIT_GB (adjoint cache budget), FFX_HOST_PHILOX=0 (sampler draws on the
+ *     device instead of ffx_torch_rand_h) and then FFX_PREDRAW=0; bench.py reads FFX_DIST_BACKEND and FFX_BENCH_TIMED_STEPS.
  */
 #ifndef FFX_H
 #define FFX_H
