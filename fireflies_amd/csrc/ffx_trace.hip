@@ -2001,36 +2001,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 // the pixel's  gimg . albedo[shape] (. colour) / spp  with one global float atomic (a lit pixel touches ~16
 // texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
 // pixel slots): one lane per stray sample record, four taps each.
-struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; };
+struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; };
 
-__global__ void __launch_bounds__(256)
-    k_render_bwd_cached(const char *__restrict__ cache, long n_pix, int slot_blocks, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
-                        float *__restrict__ gtex) {
-  if ((int)blockIdx.x < slot_blocks) {
-    const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int e = threadIdx.x & 31;
-    if (pixel >= n_pix) return;
-    const CachePix hp = reinterpret_cast<const CachePix *>(cache + 64)[pixel];
-    if (!hp.lit || e >= 25) return;
-    const float w = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix))[pixel].w[e];
-    if (w == 0.f) return;
-    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
-    const float *alb = albedo + 3 * (int)hp.shape;
-    const int x = (int)hp.x0 + e % 5, y = (int)hp.y0 + e / 5;
-    if (p.tc == 1) {
-      const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
-      if (ws != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, ws * w);
-    } else {
-      float *t = gtex + ((size_t)y * p.tw + x) * 3;
-      if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * p.inv_spp * w);
-      if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * p.inv_spp * w);
-      if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * p.inv_spp * w);
-    }
-    return;
-  }
+// the stray records of the adjoint cache: thread i replays record i (four bilinear taps each)
+__device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_pix, uint32_t i, const BwdP &p, const float *__restrict__ gimg,
+                                         const float *__restrict__ albedo, float *__restrict__ gtex) {
   const CacheHdr *hdr = reinterpret_cast<const CacheHdr *>(cache);
   const uint32_t n = min(hdr->n_stray, hdr->cap_stray);
-  const uint32_t i = (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x;
   if (i >= n) return;
   const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + cache_off_arena((size_t)n_pix))[i];
   const long pixel = rec.pix;
@@ -2060,6 +2037,95 @@ __global__ void __launch_bounds__(256)
       atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
     }
   }
+}
+
+// K9 for 1-channel textures, tiled: a workgroup owns an 8x8-pixel block of the image.  Neighbouring pixels land on
+// neighbouring texels, so their 5x5 footprints overlap heavily: the plain kernel issued ~900 k contended global float
+// atomics into a 500^2 texture and was bound by them (0.027 ms for 12 MB).  Here the block's footprints are summed
+// in a 32x32-texel LDS tile anchored at the smallest window origin of its lit pixels, and every touched texel gets
+// ONE global atomic; footprint elements that fall outside the tile (a block on a depth discontinuity) go to memory
+// directly.  Summation order inside a block is not fixed (LDS float atomics) — like the global atomics it replaces.
+#define K9_TILE 32
+__global__ void __launch_bounds__(256)
+    k_render_bwd_cached_tiled(const char *__restrict__ cache, BwdP p, int blocks_x, int tile_blocks, const float *__restrict__ gimg,
+                              const float *__restrict__ albedo, float *__restrict__ gtex) {
+  __shared__ float s_tile[K9_TILE * K9_TILE];
+  __shared__ int s_ox, s_oy, s_any;
+  const long n_pix = (long)p.W * p.H;
+  if ((int)blockIdx.x >= tile_blocks) { // the tail of the grid replays the stray records
+    k9_stray(cache, n_pix, (uint32_t)((int)blockIdx.x - tile_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
+    return;
+  }
+  const int bx = (int)blockIdx.x % blocks_x, by = (int)blockIdx.x / blocks_x;
+  const CachePix *hdrs = reinterpret_cast<const CachePix *>(cache + 64);
+  const CacheFoot *foots = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix));
+  if (threadIdx.x == 0) { s_ox = 0x7fffffff; s_oy = 0x7fffffff; s_any = 0; }
+  for (int i = threadIdx.x; i < K9_TILE * K9_TILE; i += 256) s_tile[i] = 0.f;
+  __syncthreads();
+  // pass 1 (threads 0..63, one per pixel): the tile origin
+  if (threadIdx.x < 64) {
+    const int x = bx * 8 + (threadIdx.x & 7), y = by * 8 + (threadIdx.x >> 3);
+    if (x < p.W && y < p.H) {
+      const CachePix hp = hdrs[(long)y * p.W + x];
+      if (hp.lit) { atomicMin(&s_ox, (int)hp.x0); atomicMin(&s_oy, (int)hp.y0); s_any = 1; }
+    }
+  }
+  __syncthreads();
+  if (!s_any) return; // (uniform: nothing lit in this block)
+  const int ox = s_ox, oy = s_oy;
+  // pass 2: 32 lanes per pixel (25 footprint elements), 8 pixels per iteration
+  const int e = threadIdx.x & 31;
+  for (int it = 0; it < 8; ++it) {
+    const int pl = it * 8 + (threadIdx.x >> 5);
+    const int x = bx * 8 + (pl & 7), y = by * 8 + (pl >> 3);
+    if (x >= p.W || y >= p.H || e >= 25) continue;
+    const long pixel = (long)y * p.W + x;
+    const CachePix hp = hdrs[pixel];
+    if (!hp.lit) continue;
+    const float w = foots[pixel].w[e];
+    if (w == 0.f) continue;
+    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+    const float *alb = albedo + 3 * (int)hp.shape;
+    const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
+    if (ws == 0.f) continue;
+    const int tx = (int)hp.x0 + e % 5, ty = (int)hp.y0 + e / 5;
+    const int lx = tx - ox, ly = ty - oy;
+    if (lx < K9_TILE && ly < K9_TILE) atomicAdd(&s_tile[ly * K9_TILE + lx], ws * w); // (lx, ly >= 0 by construction)
+    else atomicAdd(gtex + (size_t)ty * p.tw + tx, ws * w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K9_TILE * K9_TILE; i += 256) {
+    const float v = s_tile[i];
+    if (v != 0.f) atomicAdd(gtex + (size_t)(oy + i / K9_TILE) * p.tw + (ox + i % K9_TILE), v);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_render_bwd_cached(const char *__restrict__ cache, long n_pix, int slot_blocks, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
+                        float *__restrict__ gtex) {
+  if ((int)blockIdx.x < slot_blocks) {
+    const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int e = threadIdx.x & 31;
+    if (pixel >= n_pix) return;
+    const CachePix hp = reinterpret_cast<const CachePix *>(cache + 64)[pixel];
+    if (!hp.lit || e >= 25) return;
+    const float w = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix))[pixel].w[e];
+    if (w == 0.f) return;
+    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+    const float *alb = albedo + 3 * (int)hp.shape;
+    const int x = (int)hp.x0 + e % 5, y = (int)hp.y0 + e / 5;
+    if (p.tc == 1) {
+      const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
+      if (ws != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, ws * w);
+    } else {
+      float *t = gtex + ((size_t)y * p.tw + x) * 3;
+      if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * p.inv_spp * w);
+      if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * p.inv_spp * w);
+      if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * p.inv_spp * w);
+    }
+    return;
+  }
+  k9_stray(cache, n_pix, (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -2379,7 +2445,17 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];
   p.inv_spp = 1.0f / (float)spp;
   const long n_pix = (long)sd->cam.width * sd->cam.height;
-  const int slot_blocks = ffx_cdiv(n_pix, 8), stray_blocks = ffx_cdiv((long)cache_stray_capacity(sd->cam.width, sd->cam.height, spp), 256);
+  p.W = sd->cam.width; p.H = sd->cam.height;
+  const int stray_blocks = ffx_cdiv((long)cache_stray_capacity(sd->cam.width, sd->cam.height, spp), 256);
+  if (p.tc == 1) {
+    // footprints by 8x8-pixel blocks through an LDS tile; the tail of the grid replays the stray records
+    const int blocks_x = ffx_cdiv(p.W, 8), blocks_y = ffx_cdiv(p.H, 8);
+    hipLaunchKernelGGL(k_render_bwd_cached_tiled, dim3(blocks_x * blocks_y + stray_blocks), dim3(256), 0, (hipStream_t)s, (const char *)cache, p, blocks_x,
+                       blocks_x * blocks_y, gimg, shape_albedo, gtex);
+    FFX_CHECK_LAUNCH("render_bwd_cached/tiled");
+    return FFX_OK;
+  }
+  const int slot_blocks = ffx_cdiv(n_pix, 8);
   hipLaunchKernelGGL(k_render_bwd_cached, dim3(slot_blocks + stray_blocks), dim3(256), 0, (hipStream_t)s, (const char *)cache, n_pix, slot_blocks, p, gimg,
                      shape_albedo, gtex);
   FFX_CHECK_LAUNCH("render_bwd_cached");
