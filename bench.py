@@ -110,13 +110,13 @@ def pmc_traffic(kernel_prefix, tag="r"):
     return best
 
 
-# cycles per wave64 instruction per SIMD with >= 4 resident waves, the LOWEST figure measured for any member of the
-# class (tools/ubench/issue_rates.hip, profiles/r2_issue_rates.txt; instruction counts fixed by the asm bodies):
-#   fast: v_fma/v_mul/v_add/v_fmac_f32 and v_mov on VGPR operands only .................. 2.27
+# cycles per wave64 instruction per SIMD: the NOMINAL issue rates, which the microbenchmark (tools/ubench/issue_rates.hip,
+# profiles/r2_issue_rates.txt; instruction counts fixed by the asm bodies; >= 4 resident waves) approaches from above:
+#   fast: v_fma/v_mul/v_add/v_fmac_f32 and v_mov on VGPR operands only ......... 2   (measured 2.17 - 2.47)
 #   slow: any VALU op with an SGPR/constant source, min/max/med3, compares, v_cndmask, conversions, integer ops,
-#         DPP, v_readlane/v_writelane, packed fp32 .......................................... 4.09
-#   transcendental (v_rcp/v_rsq/v_sqrt/v_exp/v_log) ............................................ 8.18
-VALU_CYCLES = {"fast": 2.27, "slow": 4.09, "trans": 8.18}
+#         DPP, v_readlane/v_writelane, packed fp32 ................................. 4   (measured 4.07 - 4.8)
+#   transcendental (v_rcp/v_rsq/v_sqrt/v_exp/v_log) ................................... 8   (measured 8.19 - 9.3)
+VALU_CYCLES = {"fast": 2.0, "slow": 4.0, "trans": 8.0}
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
@@ -124,8 +124,8 @@ def valu_issue(kernel_substr, kernel_ms):
     """Compute-side view of the dominant kernel (it is VALU-issue bound, which the contract's hbm|mfma roofline
     cannot express).  Ceiling = the time the kernel's OWN instruction mix needs if every instruction issued at the
     best rate measured for its class: the SQ counters of the newest committed pass (profiles/*_sq_instruction_mix.json,
-    same workload) give wave-level counts per launch; every fma/mul/add is priced as the VGPR-only form (2.27 cycles)
-    although many carry a scalar operand (4.09) — the ceiling is optimistic, so frac = ceiling / live kernel time
+    same workload) give wave-level counts per launch; every fma/mul/add is priced as the VGPR-only form (2 cycles)
+    although many carry a scalar operand (4) — the ceiling is optimistic, so frac = ceiling / live kernel time
     is a lower bound of the issue utilisation and cannot exceed 1."""
     import glob
 

@@ -1,0 +1,68 @@
+"""bench.py's bookkeeping without a GPU: the compute-side ceiling in the bench line is re-derivable from the committed
+profiles (profiles/r2_sq_instruction_mix.json x the issue rates of profiles/r2_issue_rates.txt), stays <= 1, and the
+PMC traffic figure is only attached to the workload the committed passes ran."""
+import argparse
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_valu_ceiling_is_rederivable_and_below_one(bench):
+    mix = json.load(open(os.path.join(ROOT, "profiles", "r2_sq_instruction_mix.json")))
+    (k8,) = [v for k, v in mix.items() if "k_render_fwd_pk" in k]
+    stats = open(os.path.join(ROOT, "profiles", "r2_kernel_stats.csv")).read()
+    avg_ns = float(re.search(r'k_render_fwd_pk[^\n]*?",\d+,\d+,([0-9.]+),', stats).group(1))
+    vi = bench.valu_issue("k_render_fwd_pk", avg_ns * 1e-6)
+    n = k8["SQ_INSTS_VALU"]["mean"]
+    fast = sum(k8[c]["mean"] for c in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"))
+    trans = k8["SQ_INSTS_VALU_TRANS_F32"]["mean"]
+    cyc = fast * 2.0 + trans * 8.0 + (n - fast - trans) * 4.0
+    assert vi["ceiling_ms"] == pytest.approx(1e3 * cyc / 1024 / 2.4e9, rel=1e-9)
+    assert 0.5 < vi["frac"] <= 1.0, vi  # against the kernel time rocprofv3 recorded in the same profile set
+    assert "r2_sq_instruction_mix.json" in vi["source"]
+    # the scalar side at the measured 4.2 cycles per instruction does not exceed the kernel time either
+    scalar_ms = 1e3 * (k8["SQ_INSTS_SALU"]["mean"] + k8["SQ_INSTS_BRANCH"]["mean"]) * 4.2 / 1024 / 2.4e9
+    assert scalar_ms <= avg_ns * 1e-6 * 1.02
+
+
+def test_issue_rates_file_backs_the_class_rates(bench):
+    txt = open(os.path.join(ROOT, "profiles", "r2_issue_rates.txt")).read()
+
+    def best(label):  # lowest cycles/instr/SIMD over the occupancies >= 4 waves
+        vals = [float(m.group(2)) for m in re.finditer(re.escape(label) + r"\s+W=(\d)\s+[0-9.]+ ms\s+clk [0-9.]+ GHz\s+([0-9.]+) cyc", txt) if int(m.group(1)) >= 4]
+        assert vals, label
+        return min(vals)
+
+    # the nominal rates of the ceiling are never beaten by a measurement (so the ceiling is optimistic, the fraction a lower bound)
+    assert best("v_fma_f32 v,v,v,v") >= bench.VALU_CYCLES["fast"] and best("v_mul_f32 v,v,v (VOP2)") >= bench.VALU_CYCLES["fast"]
+    assert best("v_fma_f32 v,v,v,v") < 2.6  # ... and the fast class really is the 2-cycle class
+    for slow in ("v_fma_f32 v,s,v,v", "v_max3_f32", "v_cmp_le_f32 -> SGPR pair (VOP3)", "v_cndmask_b32 SGPR mask (VOP3)", "v_pk_fma_f32", "v_readlane_b32",
+                 "v_cvt_f32_u32", "v_min_u32 (VOP2)"):
+        assert bench.VALU_CYCLES["slow"] <= best(slow) < 5.0, slow
+    assert best("v_rcp_f32") >= bench.VALU_CYCLES["trans"]
+
+
+def test_traffic_is_keyed_on_the_profiled_workload(bench):
+    ns = argparse.Namespace(workload="vocalfold", res=512, spp=64, fp16=False, no_shadows=False)
+    assert bench._is_profiled_workload(ns)
+    for k, v in (("workload", "colon"), ("res", 1024), ("spp", 256), ("fp16", True), ("no_shadows", True)):
+        other = argparse.Namespace(**{**vars(ns), k: v})
+        assert not bench._is_profiled_workload(other), k
+    t = bench.pmc_traffic("k_render_fwd_pk")
+    assert t is not None and t["source"].startswith("r2_") and t["bytes"] >= t["raw_bytes"] > 5.6e6  # more than the algorithmic 5.6 MB
+    g = bench.pmc_traffic("k_render_bwd_cached", "grad")
+    assert g is not None and g["source"].startswith("r2grad_")
