@@ -2340,6 +2340,16 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
     int ppw_log2 = 0;
     if (spp < 64 && 64 % spp == 0)
       while ((spp << (ppw_log2 + 1)) <= 64) ++ppw_log2;
+    {
+      // ... but never more than 16 pixels (1 spp) / 8 pixels per wave: a smaller block leaves lanes idle, yet it makes
+      // more and thinner packets — fewer exact tests per walk (24 per walk with 8x8-pixel packets) and enough waves to
+      // hide the walk's latency (4096 waves of 64 pixels do not fill the GPU).  Measured at 512^2 (tools/k7time.py):
+      // 1 / 2 / 4 spp 0.118 / 0.105 / 0.095 ms with full waves, 0.071 / 0.056 / 0.057 ms capped; >= 8 spp unchanged.
+      // FFX_K7_PPW_LOG2 overrides the cap (experiment knob).
+      static const int env_cap = getenv("FFX_K7_PPW_LOG2") ? atoi(getenv("FFX_K7_PPW_LOG2")) : -1;
+      const int cap = env_cap >= 0 ? env_cap : (spp == 1 ? 4 : 3);
+      if (ppw_log2 > cap) ppw_log2 = cap;
+    }
     const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
     const int blocks_x = ffx_cdiv(k.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(k.H, 1 << bh_log2);
     const int wpb = packet_waves();

@@ -144,7 +144,7 @@ class _Render(torch.autograd.Function):
             # tensor in place on the next randomisation): keep a private copy (3 floats per shape)
             ctx.albedo = albedo.clone()
             if cache_supported(sd, spp):
-                # store 16 B per sample now instead of re-tracing the scene in backward
+                # store a texture footprint per pixel now instead of re-tracing the scene in backward
                 ctx.cache = torch.empty(ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp), dtype=torch.uint8, device=t.device)
         ctx.pose_version = geom.version
         return geom.render_fwd(sd, albedo, t, spp, seed, fp16, cache=ctx.cache)

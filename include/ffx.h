@@ -29,6 +29,7 @@
  *       FFX_TILE_BLOCK=0..8      log2 side of the square blocks in which tiles are enumerated (default 3)
  *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs (default 0: interleaved)
  *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
+ *       FFX_K7_PPW_LOG2=0..6     cap on log2(pixels per wavefront) of ffx_trace_primary (default 4 at 1 spp, else 3)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
  *     tests/test_hip_parity.py::test_wide_overlay_builders_give_identical_images):
  *       FFX_WIDE_BUILD=area|count|layers   builder of the 64-wide overlay (default area: greedy SAH cut)
