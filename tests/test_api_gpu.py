@@ -240,7 +240,7 @@ def test_cuda_entities_predrawn_randomisation_is_the_sequential_stream(monkeypat
     assert not torch.equal(a[0][0], a[1][0])
 
 
-def test_host_philox_matches_torch_rand():
+def test_host_philox_matches_torch_rand(monkeypatch):
     """f1: ffx_torch_rand_h (the product's host evaluation of a CUDA sampler draw) against torch.rand itself on this
     GPU's default generator — values bit for bit and the generator left in the same state — for the shapes the
     samplers use (1, 3) and the extremes (2, 255, 256), from fresh seeds and in the middle of a stream that other
@@ -251,6 +251,7 @@ def test_host_philox_matches_torch_rand():
     from fireflies_amd.sampling import torch_rng
     from oracle import oracle as orc
 
+    monkeypatch.setattr(torch_rng, "_ENABLED", True)  # (also when the suite runs under FFX_HOST_PHILOX=0)
     gen = torch.cuda.default_generators[torch.cuda.current_device()]
     olib = orc.api().lib
     for seed in (0, 1, 1234, 2**40 + 17, 2**63 + 5):
