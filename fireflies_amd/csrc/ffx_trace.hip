@@ -1490,7 +1490,8 @@ __device__ __forceinline__ const ShadeK &kernarg_shade() {
 template <int R, bool WIDE>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
-                                                const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R]) {
+                                                const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
+                                                const float *__restrict__ tex_probe = nullptr) {
   Hit h[R];
   bool fnd[R];
   traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
@@ -1580,6 +1581,21 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
         }
       }
+    }
+    // A plain forward render (no adjoint cache) does not need the projector's shadow ray where the projector shines
+    // nothing: if the four texels of the sample's bilinear footprint are all exactly zero — most of a dot pattern is —
+    // its contribution is zero whatever the walk finds.  (The cache-writing forward keeps every walk: the ADJOINT of a
+    // dark texel is not zero.)  Same texel arithmetic as the footprint phase below.
+    if (tex_probe && q.need_p) {
+      const float fx = fmaf(q.u, (float)c.tw, -0.5f), fy = fmaf(q.v, (float)c.th, -0.5f);
+      const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
+      const int x0 = clampi(ix0, 0, c.tw - 1), x1 = clampi(ix0 + 1, 0, c.tw - 1), y0 = clampi(iy0, 0, c.th - 1), y1 = clampi(iy0 + 1, 0, c.th - 1);
+      const int tc = c.tc;
+      float m = 0.f;
+      for (int ch = 0; ch < tc; ++ch)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(tex_probe[((size_t)y0 * c.tw + x0) * tc + ch]), fabsf(tex_probe[((size_t)y0 * c.tw + x1) * tc + ch])),
+                           fmaxf(fabsf(tex_probe[((size_t)y1 * c.tw + x0) * tc + ch]), fabsf(tex_probe[((size_t)y1 * c.tw + x1) * tc + ch]))));
+      if (!(m > 0.f)) q.need_p = false; // (NaN texels keep their walk)
     }
     any_p |= q.need_p;
     any_s |= q.need_s;
@@ -1803,7 +1819,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       }
       FFX_TSTOP(tk, 16);
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
+      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, cache ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
