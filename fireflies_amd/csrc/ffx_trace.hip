@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
     }
     float inv_spp = 1.0f / (float)spp;
     size_t o = ((size_t)py * W + px) * 3;
-    if (fp16) {
+    if (fp16 & 1) {
       _Float16 *p = (_Float16 *)img;
       p[o] = (_Float16)(acc0 * inv_spp);
       p[o + 1] = (_Float16)(acc1 * inv_spp);
@@ -1819,7 +1819,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       }
       FFX_TSTOP(tk, 16);
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, cache ? nullptr : tex);
+      // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
+      // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
+      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, (cache && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -1907,7 +1909,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
           const float a2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(c2), 63));
           if (lane == 0 && live[r]) {
             size_t o = (size_t)pix[r] * 3;
-            if (fp16) {
+            if (fp16 & 1) {
               _Float16 *p = (_Float16 *)img;
               p[o] = (_Float16)vmul_s(a0, inv_spp_u);
               p[o + 1] = (_Float16)vmul_s(a1, inv_spp_u);
@@ -2447,7 +2449,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 
 int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                    uint32_t seed, int img_fp16, void *img, ffx_stream s) {
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, nullptr, s);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, nullptr, s);
 }
 
 size_t ffx_render_cache_bytes(int width, int height, int spp) {
@@ -2459,7 +2461,7 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
   if (((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache must be 16-byte aligned");
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, cache, s);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 3, img, cache, s);
 }
 
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {

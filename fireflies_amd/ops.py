@@ -468,9 +468,11 @@ class DeviceGeometry:
     def _timed(self, name):
         return _EventPair(self.timing, name)
 
-    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None):
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False):
         """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
-        footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h)."""
+        footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h).
+        sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
+        not zero (a pattern optimiser's case), dark footprints are skipped."""
         H, W = sd.cam.height, sd.cam.width
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         if cache is not None:
@@ -479,8 +481,8 @@ class DeviceGeometry:
             with self._timed("render_fwd"):
                 self._call(
                     "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
-                    _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype),
-                    _dev(cache, torch.uint8, "cache"), _stream(self._didx),
+                    _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(bool(fp16)) | (2 if sparse_adjoint else 0),
+                    _dev(img, img.dtype), _dev(cache, torch.uint8, "cache"), _stream(self._didx),
                 )
             self._release()
             return img

@@ -185,7 +185,9 @@ class PatternOptimizer:
             nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, self.spp) if use_cache else 0
             if use_cache and (self._cache is None or self._cache.numel() != nbytes):
                 self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
-            img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None)
+            # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
+            # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
+            img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
             if fast_loss is not None:
                 gimg = fast_loss(img, loss_sum)
             else:

@@ -358,6 +358,12 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
  * backward pass (shape_albedo must still hold the forward's values).  Limits: projector textures up to 4094^2,
  * up to 255 shapes (FFX_ERR_UNSUPPORTED otherwise: use ffx_render_bwd).
  * ---------------------------------------------------------------------------------------- */
+#define FFX_RENDER_FP16 1           /* img_fp16 bit 0: fp16 film */
+#define FFX_RENDER_SPARSE_ADJOINT 2 /* img_fp16 bit 1 (ffx_render_fwd_cache only): the caller needs d loss / d tex only at texels whose
+                                       VALUE is not zero — what a pattern optimiser needs, whose gradient flows through the splat that
+                                       produced the texture (rasterization.py:583-607): samples whose four bilinear taps are all exactly
+                                       zero are then neither shadow-traced nor cached.  The image is the same; gtex at zero-valued texels
+                                       is unspecified.  The oracle ignores the bit (it always computes the full gradient). */
 size_t ffx_render_cache_bytes(int width, int height, int spp);
 int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
                          const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,

@@ -1176,7 +1176,7 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   (void)s;
   if (!cache) FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, (crec *)cache);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, (crec *)cache); /* bit 1 (sparse adjoint) ignored: full gradient */
 }
 
 /* adjoint from the per-sample records: same weights, same clamping as the forward lookup */

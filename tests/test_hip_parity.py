@@ -741,3 +741,31 @@ def test_wide_overlay_builders_give_identical_images(oracle, monkeypatch):
         assert torch.equal(imgs[0], imgs[k]) and torch.equal(prims[0], prims[k])
     _, _, p_o = go.trace_primary(cam, 4, 1, 5)
     assert (host(prims[0]) == p_o).mean() > 0.9995
+
+
+def test_sparse_adjoint_agrees_where_the_texture_is_not_zero(oracle):
+    """FFX_RENDER_SPARSE_ADJOINT (include/ffx.h): with a sparse projector texture the cache-writing forward may skip
+    the samples whose four bilinear taps are all exactly zero.  Same image bit for bit; the texture gradient agrees with
+    the full one (and with the oracle's) at every texel whose value is not zero — the only texels a pattern optimiser's
+    chain reads, since a zero texel has no splat within reach of the blur that produced it."""
+    sc = scenes.vocalfold(width=72, height=64, tex=128, frames=3, n_fold=24, tube=(24, 32))
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 8))
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    rng = np.random.default_rng(5)
+    pts = (rng.random((12, 2)) * 0.8 + 0.1).astype(np.float32)  # a dozen dots on 128^2: most texels are exactly zero
+    tex = ops.blur_fwd(ops.splat_fwd(dev(pts), 4.0, "sum", -1, 128, 128)).unsqueeze(-1).contiguous()
+    zero = host(tex)[..., 0] == 0.0
+    assert 0.5 < zero.mean() < 0.99
+    gimg = dev(rng.standard_normal((64, 72, 3)).astype(np.float32))
+    out = {}
+    for sparse in (False, True):
+        cache = torch.zeros(ops.render_cache_bytes(72, 64, 16), dtype=torch.uint8, device="cuda")
+        img = gd.render_fwd(sd, dev(alb), tex, 16, seed=2, cache=cache, sparse_adjoint=sparse)
+        out[sparse] = (img, host(gd.render_bwd_cached(sd, dev(alb), cache, 16, gimg))[..., 0])
+    assert torch.equal(out[False][0], out[True][0])
+    full, sp = out[False][1], out[True][1]
+    scale = float(np.abs(full).max())
+    assert scale > 0 and np.abs(full[zero]).max() > 0  # the full adjoint does reach dark texels ...
+    np.testing.assert_allclose(sp[~zero], full[~zero], rtol=0, atol=1e-3 * scale)  # ... the sparse one agrees everywhere else
+    g_o = go.render_bwd(sd, alb, 16, 2, host(gimg))[..., 0]
+    np.testing.assert_allclose(sp[~zero], g_o[~zero], rtol=0, atol=2e-3 * scale)
