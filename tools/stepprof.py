@@ -12,7 +12,7 @@ from fireflies_amd import workloads  # noqa: E402
 from fireflies_amd.optim import PatternOptimizer  # noqa: E402
 
 dev = torch.device("cuda", 0)
-wg = workloads.vocalfold(device=dev, grid=8, entity_device="cpu")
+wg = workloads.vocalfold(device=dev, grid=8, entity_device=os.environ.get("FFX_ENTITY_DEVICE", "cuda"))
 opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=64, samples_per_step=1, base_seed=7)
 for _ in range(5):
     opt.step()
