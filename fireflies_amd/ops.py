@@ -423,11 +423,17 @@ class DeviceGeometry:
         with self._timed("scene_update"):
             if not on_device and self.n_shapes <= 32:
                 xf = xforms.detach().numpy() if isinstance(xforms, torch.Tensor) else np.asarray(xforms)
-                xf = np.ascontiguousarray(xf, dtype=np.float32).reshape(self.n_shapes, 16)
+                # the host tables go through two persistent ctypes arrays with numpy views on them: `ndarray.ctypes.data_as`
+                # per call cost more than the launch it fed (measured 120 us each inside the optimiser's loop)
+                tabs = getattr(self, "_host_tabs", None)
+                if tabs is None:
+                    xc, oc = (C.c_float * (16 * self.n_shapes))(), (C.c_int32 * self.n_shapes)()
+                    tabs = self._host_tabs = (xc, np.frombuffer(xc, dtype=np.float32).reshape(self.n_shapes, 16), oc, np.frombuffer(oc, dtype=np.int32))
+                tabs[1][...] = np.asarray(xf, dtype=np.float32).reshape(self.n_shapes, 16)
+                tabs[3][...] = self._vert_off_host
                 self._call(
                     "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-                    _dev(self.tri_shape, torch.int32), self._vert_off_host.ctypes.data_as(C.POINTER(C.c_int32)),
-                    xf.ctypes.data_as(C.POINTER(C.c_float)), self.n_shapes, _stream(self._didx),
+                    _dev(self.tri_shape, torch.int32), tabs[2], tabs[0], self.n_shapes, _stream(self._didx),
                 )
                 return
             if self._vert_off_dev_stale:

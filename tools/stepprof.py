@@ -22,7 +22,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "timing":  # bench.py's per-launch event
     wg.mi_scene.geom.timing = []
 ts = []
 t00 = time.perf_counter()
+SYNC = os.environ.get("FFX_HP_SYNC") == "1"  # idle GPU in front of every step: the unthrottled host time of a step
 for i in range(n):
+    if SYNC:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     opt.step()
     ts.append(1e3 * (time.perf_counter() - t0))
