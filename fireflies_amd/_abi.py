@@ -107,6 +107,7 @@ PROTOTYPES = {
     "ffx_splat_lines_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_lines_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
     "ffx_torch_rand_h": (c_i, [C.c_uint64, C.c_uint64, c_i, PF, C.POINTER(C.c_uint64)]),
+    "ffx_torch_rand_batch_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), PF]),
     "ffx_blur_fwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),

@@ -50,3 +50,17 @@ extern "C" int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *ou
   *offset_increment = 4; // ((n - 1) / (256 * 1 * 4) + 1) * 4 engine calls
   return FFX_OK;
 }
+
+// The draws of a whole randomisation — or of the S scene samples of an optimisation step — in ONE call: draw i is the
+// torch.rand of counts[i] elements under (seeds[i], offsets[i]); the values are packed one draw after the other.  The
+// caller has advanced the generator by 4 per draw when it reserved them (what every draw of <= 256 elements consumes).
+extern "C" int ffx_torch_rand_batch_h(int k, const uint64_t *seeds, const uint64_t *offsets, const int32_t *counts, float *out) {
+  if (k < 0 || (k > 0 && (!seeds || !offsets || !counts || !out))) FFX_FAIL(FFX_ERR_ARG, "torch_rand_batch_h: bad argument");
+  for (int i = 0; i < k; ++i) {
+    uint64_t inc = 0;
+    const int rc = ffx_torch_rand_h(seeds[i], offsets[i], counts[i], out, &inc);
+    if (rc != FFX_OK) return rc;
+    out += counts[i];
+  }
+  return FFX_OK;
+}

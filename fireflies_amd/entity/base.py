@@ -37,6 +37,7 @@ class DrawBatch:
     def __init__(self):
         self._tensors = []
         self._slots = []  # (first tensor index, kind, repeat)
+        self.host = sampling.torch_rng.HostDraws()  # draws evaluated on the host: offsets reserved per draw, values in one native call
 
     def add(self, t) -> int:
         self._tensors.append(t.detach().reshape(-1))
@@ -53,6 +54,11 @@ class DrawBatch:
         """u: the values of the torch.rand call as a float32 numpy array already on the host
         (sampling/torch_rng.py: the device generator's Philox stream evaluated natively); nothing to transfer"""
         self._slots.append((-1, 2, repeat, lo, hi, u))
+        return len(self._slots) - 1
+
+    def add_uniform_reserved(self, idx, lo, hi, repeat: int = 1) -> int:
+        """a draw reserved in self.host (HostDraws.reserve): its values are resolved with the batch's other host draws"""
+        self._slots.append((idx, 3, repeat, lo, hi, None))
         return len(self._slots) - 1
 
     def needs_transfer(self) -> bool:
@@ -89,11 +95,12 @@ class DrawBatch:
                 arrs.append(flat[k : k + t.numel()])
                 k += t.numel()
         out = []
+        reserved = self.host.resolve() if self.host.counts else None
         for first, kind, rep, lo, hi, host_u in self._slots:
             if kind == 0:
                 v = arrs[first]
             else:
-                u = host_u if kind == 2 else arrs[first]
+                u = reserved[first] if kind == 3 else (host_u if kind == 2 else arrs[first])
                 v = u * (hi - lo) + lo  # float32, one rounding per operation like the torch expression
             vals = [float(x) for x in v]
             out.append(vals * rep if rep > 1 else vals)

@@ -19,6 +19,7 @@ _ENABLED = os.environ.get("FFX_HOST_PHILOX", "1") != "0"
 _INC = C.c_uint64(0)
 _BUF = (C.c_float * 256)()
 _FN = None
+_GENS = {}  # device (as the samplers hold it) -> its default CUDA generator
 
 
 def enabled() -> bool:
@@ -40,3 +41,50 @@ def host_rand(numel: int, device):
         return None
     gen.set_offset(off + _INC.value)
     return np.ctypeslib.as_array(_BUF)[:numel].copy()
+
+
+class HostDraws:
+    """the host-evaluated draws of one DrawBatch: `reserve` claims the generator's next offsets in program order (so that
+    every other consumer of the generator sees the stream it would have seen), `resolve` computes all values with ONE
+    native call (ffx_torch_rand_batch_h)."""
+
+    __slots__ = ("seeds", "offsets", "counts", "_values")
+
+    def __init__(self):
+        self.seeds, self.offsets, self.counts, self._values = [], [], [], None
+
+    def reserve(self, numel: int, device):
+        """index of the reserved draw, or None if this draw has to be made on the device"""
+        if not _ENABLED or numel < 1 or numel > 256 or torch.cuda.is_current_stream_capturing():
+            return None
+        gen = _GENS.get(device)
+        if gen is None:
+            dev = torch.device(device)
+            gen = _GENS[device] = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        off = gen.get_offset()
+        if off & 3:
+            return None
+        gen.set_offset(off + 4)  # what the launch of a <= 256-element uniform kernel consumes (checked by the tests against torch.rand)
+        self.seeds.append(gen.initial_seed())
+        self.offsets.append(off)
+        self.counts.append(numel)
+        self._values = None
+        return len(self.counts) - 1
+
+    def resolve(self):
+        """list of float32 numpy arrays, one per reserved draw"""
+        if self._values is None:
+            k = len(self.counts)
+            total = sum(self.counts)
+            out = np.empty(total, dtype=np.float32)
+            if k:
+                fn = _lib.api().lib.ffx_torch_rand_batch_h
+                rc = fn(k, (C.c_uint64 * k)(*self.seeds), (C.c_uint64 * k)(*self.offsets), (C.c_int32 * k)(*self.counts), out.ctypes.data_as(C.POINTER(C.c_float)))
+                if rc != 0:
+                    raise RuntimeError("ffx_torch_rand_batch_h failed")
+            vals, p = [], 0
+            for n in self.counts:
+                vals.append(out[p:p + n])
+                p += n
+            self._values = vals
+        return self._values

@@ -21,7 +21,7 @@ class UniformSampler(base.Sampler):
         assert a.size() == b.size() and a.device == b.device
         lo, hi = self._host_bounds()
         if a.is_cuda:
-            u = torch_rng.host_rand(a.numel(), a.device)  # the values of that torch.rand call, without the launch
-            if u is not None:
-                return batch.add_uniform_host(u, lo, hi)
+            idx = batch.host.reserve(a.numel(), a.device)  # that torch.rand call's place in the generator's stream, without the launch
+            if idx is not None:
+                return batch.add_uniform_reserved(idx, lo, hi)
         return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi)  # the same torch.rand call as sample_train

@@ -26,9 +26,9 @@ class UniformScalarToVec3Sampler(base.Sampler):
         assert a.size() == b.size() and a.device == b.device and a.numel() == 1
         lo, hi = self._host_bounds()
         if a.is_cuda:
-            u = torch_rng.host_rand(1, a.device)
-            if u is not None:
-                return batch.add_uniform_host(u, lo, hi, repeat=3)
+            idx = batch.host.reserve(1, a.device)
+            if idx is not None:
+                return batch.add_uniform_reserved(idx, lo, hi, repeat=3)
         return batch.add_uniform(torch.rand(a.shape, device=a.device), lo, hi, repeat=3)
 
     def sample_eval(self):

@@ -202,6 +202,11 @@ int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[
  * ---------------------------------------------------------------------------------------- */
 int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *out /*[host][n]*/,
                      uint64_t *offset_increment /*[host]*/);
+/* The k draws of a whole Scene.randomize() (fireflies/scene.py:360-371) — or of the S scene samples of an optimisation
+ * step — in one call: draw i = ffx_torch_rand_h(seeds[i], offsets[i], counts[i]); values packed draw after draw.  The
+ * caller advanced the generator by 4 per draw when it reserved the offsets. */
+int ffx_torch_rand_batch_h(int k, const uint64_t *seeds /*[host][k]*/, const uint64_t *offsets /*[host][k]*/,
+                           const int32_t *counts /*[host][k]*/, float *out /*[host][sum counts]*/);
 
 /* ------------------------------------------------------------------------------------------
  * K3  texture finalise: separable Gaussian blur, reflect border.

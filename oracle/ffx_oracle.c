@@ -523,6 +523,17 @@ int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *out, uint64_t
   return FFX_OK;
 }
 
+int ffx_torch_rand_batch_h(int k, const uint64_t *seeds, const uint64_t *offsets, const int32_t *counts, float *out) {
+  if (k < 0 || (k > 0 && (!seeds || !offsets || !counts || !out))) FAIL(FFX_ERR_ARG, "torch_rand_batch_h: bad argument");
+  for (int i = 0; i < k; ++i) {
+    uint64_t inc;
+    int rc = ffx_torch_rand_h(seeds[i], offsets[i], counts[i], out, &inc);
+    if (rc != FFX_OK) return rc;
+    out += counts[i];
+  }
+  return FFX_OK;
+}
+
 /* =========================================================================================
  * K3  gaussian_blur2d with reflect border [EXT kornia 0.7.1, call site
  * examples/vocalfold_scene.py:61-63].  Kernel: g[k] = exp(-(k - r)^2 / (2 s^2)), normalised

@@ -68,6 +68,18 @@ def test_host_philox_known_answers(which, oracle):
     assert all(0.0 <= out[i] < 1.0 for i in range(256))
     assert fn(0, 0, 257, out, C.byref(inc)) == _abi_err("FFX_ERR_UNSUPPORTED") and fn(0, 2, 3, out, C.byref(inc)) == _abi_err("FFX_ERR_UNSUPPORTED")
     assert fn(0, 0, 0, out, C.byref(inc)) == _abi_err("FFX_ERR_ARG")
+    # the batched entry point = the single one, draw by draw
+    fb = lib.ffx_torch_rand_batch_h
+    fb.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+    seeds, offs, cnts = (C.c_uint64 * 3)(5, 5, 77), (C.c_uint64 * 3)(0, 4, 1024), (C.c_int32 * 3)(3, 1, 7)
+    packed = (C.c_float * 11)()
+    assert fb(3, seeds, offs, cnts, packed) == 0
+    p = 0
+    for sd_, of_, n in zip(seeds, offs, cnts):
+        assert fn(sd_, of_, n, out, C.byref(inc)) == 0
+        assert [packed[p + i] for i in range(n)] == [out[i] for i in range(n)]
+        p += n
+    assert fb(0, None, None, None, None) == 0 and fb(1, seeds, offs, (C.c_int32 * 1)(300), packed) == _abi_err("FFX_ERR_UNSUPPORTED")
 
 
 def _abi_err(name):

@@ -278,6 +278,25 @@ def test_host_philox_matches_torch_rand(monkeypatch):
                 assert np.array_equal(np.ctypeslib.as_array(buf), want) and inc.value == after - off
     # out of its range the host path declines (the sampler then draws on the device)
     assert torch_rng.host_rand(257, DEV) is None and torch_rng.host_rand(0, DEV) is None
+    # the batched form the samplers use: offsets reserved draw by draw, all values from ONE native call at the end —
+    # interleaved with a device draw that must see the stream position the reserved draws left behind
+    torch.manual_seed(99)
+    st = gen.get_state().clone()
+    sizes = (3, 3, 1, 3, 256, 2)
+    want = [torch.rand(n, device=DEV).cpu().numpy() for n in sizes[:3]] + [torch.randn(4, device=DEV).cpu().numpy()]
+    want += [torch.rand(n, device=DEV).cpu().numpy() for n in sizes[3:]]
+    after = gen.get_offset()
+    gen.set_state(st)
+    hd = torch_rng.HostDraws()
+    ids = [hd.reserve(n, DEV) for n in sizes[:3]]
+    foreign = torch.randn(4, device=DEV).cpu().numpy()
+    ids += [hd.reserve(n, DEV) for n in sizes[3:]]
+    assert None not in ids and gen.get_offset() == after
+    vals = hd.resolve()
+    np.testing.assert_array_equal(foreign, want[3])
+    for k, i in enumerate(ids):
+        assert np.array_equal(vals[i], want[k if k < 3 else k + 1]), k
+    assert hd.reserve(257, DEV) is None
 
 
 def test_principled_parameters_are_accepted_but_reported():
