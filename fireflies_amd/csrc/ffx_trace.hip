@@ -2258,10 +2258,13 @@ static int tile_block_log2() {
 // pixels of its 2x2 tile a wave of k_render_fwd_pk walks: FFX_PIXELS_PER_WAVE = 1, 2 (default) or 4.
 // Measured 4 / 2 / 1: 1133 / 1180 / 1165 renders/s (vocal fold), 62.0 / 62.6 / 62.2 (colon): shorter
 // waves even out the tail of the launch, one pixel per wave pays the wave start-up four times.
-static int pixels_per_wave() {
+// default: one pixel per wave for the plain forward (finest grain: +1-2 %), two for the cache-writing forward (whose
+// per-pixel footprint bookkeeping amortises better: one pixel per wave was 1.5 % slower there); colon: no difference
+static int pixels_per_wave(bool with_cache) {
   const char *e = getenv("FFX_PIXELS_PER_WAVE");
-  int w = e ? atoi(e) : 2;
-  return (w == 1 || w == 2 || w == 4) ? w : 2;
+  const int dflt = with_cache ? 2 : 1;
+  int w = e ? atoi(e) : dflt;
+  return (w == 1 || w == 2 || w == 4) ? w : dflt;
 }
 
 // experiment knob: dynamic LDS bytes per workgroup of the packet kernels (unused by the kernel; it only
@@ -2422,7 +2425,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb); // whole blocks; tiles outside the image are skipped
     ptx |= tb << 24;
     const int wpb = packet_waves();
-    const int ppw = pixels_per_wave();
+    const int ppw = pixels_per_wave(cache != nullptr);
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;

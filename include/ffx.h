@@ -25,7 +25,7 @@
  *     equivalent kernels / launch shapes and exist for A/B measurements:
  *       FFX_TRAVERSAL=lane       per-lane kernels (LDS stack, apex vectors per ray) instead of the wave-packet kernels
  *       FFX_WIDE=0               wave-packet kernels on the binary walk only (default: 64-wide walk with binary fallback)
- *       FFX_PIXELS_PER_WAVE=1|2|4  pixels of a 2x2 tile one wavefront renders (default 2)
+ *       FFX_PIXELS_PER_WAVE=1|2|4  pixels of a 2x2 tile one wavefront renders (default 1; 2 when the adjoint cache is written)
  *       FFX_TILE_BLOCK=0..8      log2 side of the square blocks in which tiles are enumerated (default 3)
  *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs (default 0: interleaved)
  *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
