@@ -60,7 +60,9 @@ class HostDraws:
         gen = _GENS.get(device)
         if gen is None:
             dev = torch.device(device)
-            gen = _GENS[device] = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            if dev.index is not None:  # ("cuda" without an index follows the current device: not cached)
+                _GENS[device] = gen
         off = gen.get_offset()
         if off & 3:
             return None
