@@ -1720,7 +1720,15 @@ __device__ __forceinline__ void packet_pixels(int tile, int tiles_x_tb, int sub,
   const int tb = (tiles_x_tb >> 24) & 15, tiles_x = tiles_x_tb & 0xffffff;
   const int bt1 = (1 << tb) - 1, blocks_x = (tiles_x + bt1) >> tb;
   const int blk = tile >> (2 * tb), within = tile & ((1 << (2 * tb)) - 1);
-  const int tx = ((blk % blocks_x) << tb) + (within & bt1), ty = ((blk / blocks_x) << tb) + (within >> tb);
+  // row / column of the block: an UNSIGNED division through a float reciprocal with one correction step (exact for
+  // the < 2^22 blocks of any film) — the compiler's signed integer division and modulo were ~50 scalar instructions
+  // per wave, a tenth of a one-pixel wave's scalar work
+  uint32_t by_ = (uint32_t)((float)blk * __builtin_amdgcn_rcpf((float)blocks_x));
+  by_ = __builtin_amdgcn_readfirstlane((int)by_);
+  int rem = blk - (int)by_ * blocks_x;
+  if (rem < 0) { --by_; rem += blocks_x; }
+  if (rem >= blocks_x) { ++by_; rem -= blocks_x; }
+  const int tx = (rem << tb) + (within & bt1), ty = ((int)by_ << tb) + (within >> tb);
   const int bx = tx * 2, by = ty * 2;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1760,7 +1768,7 @@ template <int R, bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw) {
+                    int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off) {
   constexpr int NSUB = 4 / R;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
@@ -1773,13 +1781,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
   // each wave of the workgroup owns its own tile; the waves never synchronise
   // a wave walks `ppw` (1, 2 or 4) of its tile's four pixels; 4 / ppw waves share a tile
   const int wv = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
-  const int wpt = NSUB / ppw;
-  const int tile = wv / wpt, sub0 = (wv % wpt) * ppw;
+  const int wpt_log2 = (R == 1) ? (ppw == 1 ? 2 : (ppw == 2 ? 1 : 0)) : 0; // waves per tile = NSUB / ppw, a power of two: shifts, not divisions
+  const int tile = (R == 1) ? (wv >> wpt_log2) : wv / (NSUB / ppw), sub0 = (R == 1) ? (wv & ((1 << wpt_log2) - 1)) * ppw : (wv % (NSUB / ppw)) * ppw;
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
   const int passes = (spp + 63) >> 6;
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
-  const float inv_spp_u = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(1.0f / (float)spp)));
+  const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
     packet_pixels<R>(tile, tiles_x, sub, px, py);
@@ -1852,7 +1860,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             const uint32_t cap = hdr->cap_stray;
             if (base + n <= cap) {
               if (lit && !in_win) {
-                CacheStray *rec = reinterpret_cast<CacheStray *>(cache + cache_off_arena((size_t)W * (size_t)H)) + base + mbcnt64(straym);
+                CacheStray *rec = reinterpret_cast<CacheStray *>(cache + ((size_t)cache_arena_off << 7)) + base + mbcnt64(straym);
                 rec->pix = pix[0];
                 rec->xy_shape = (uint32_t)(st[0].ubx + 1) | ((uint32_t)(st[0].uby + 1) << 12) | ((uint32_t)st[0].shape << 24);
                 rec->ax = st[0].wx1;
@@ -1935,7 +1943,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       }
       int lw = lane;
       asm volatile("" : "+v"(lw));
-      if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + cache_off_foot((size_t)W * (size_t)H))[pix[0]].w[lw] = s_foot[lw];
+      if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + ((size_t)cache_foot_off << 7))[pix[0]].w[lw] = s_foot[lw];
     }
   }
   FFX_TFLUSH();
@@ -2432,12 +2440,14 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u))
       return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
+    // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
+    const uint32_t foot_off = (uint32_t)(cache_off_foot((size_t)c.cam.W * c.cam.H) >> 7), arena_off = (uint32_t)(cache_off_arena((size_t)c.cam.W * c.cam.H) >> 7);
     if (use_wide(info))
       hipLaunchKernelGGL((k_render_fwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw);
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off, arena_off);
     else
       hipLaunchKernelGGL((k_render_fwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw);
+                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off, arena_off);
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
