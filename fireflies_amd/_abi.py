@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 2
+FFX_ABI_VERSION = 3
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -80,7 +80,14 @@ class SceneDesc(C.Structure):
         ("spot", Spot),
         ("shadows", C.c_int32),
         ("n_shapes", C.c_int32),
+        ("mat_stride", C.c_int32),
     ]
+
+
+# material rows (include/ffx.h FFX_MAT_*)
+MAT_STRIDE = 16
+MAT_MODEL, MAT_ROUGHNESS, MAT_ANISOTROPIC, MAT_METALLIC, MAT_SPEC_TRANS, MAT_ETA = 3, 4, 5, 6, 7, 8
+MAT_SPEC_TINT, MAT_SHEEN, MAT_SHEEN_TINT, MAT_FLATNESS, MAT_CLEARCOAT, MAT_CLEARCOAT_GLOSS = 9, 10, 11, 12, 13, 14
 
 
 PF = C.POINTER(c_f)
@@ -119,6 +126,7 @@ PROTOTYPES = {
     "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),
     "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p]),
     "ffx_render_cache_bytes": (C.c_size_t, [c_i, c_i, c_i]),
+    "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p]),
 }

@@ -43,6 +43,8 @@ struct ShadeK {
   float s_w2l[12];
   float s_pos[3], s_int[3];
   float cos_cut, cos_beam, cutoff, inv_trans;
+  int mat_stride;    // floats per row of the material table: 3 (Lambert albedo) or FFX_MAT_STRIDE
+  const float *mats; // the material table (the render calls' shape_albedo)
 };
 
 struct Hit { float t; int prim, shape, slot; };
@@ -254,6 +256,135 @@ __global__ void __launch_bounds__(TR_BLOCK)
 }
 
 // ------------------------------------------------------------------------------------------ shading
+#define FFX_PI_F 3.14159265358979323846f
+// Reciprocal, quotient and square root of the shading terms: the hardware seed (v_rcp / v_sqrt / v_rsq,
+// 1 ulp) plus one fma Newton step.  The result equals the correctly rounded IEEE value except in rare
+// last-bit cases (Markstein), at 3 / 5 / 7 VALU instructions instead of the 10 / 10 / 14 of the
+// compiler's IEEE expansions (which also cover denormal and overflow ranges that cannot occur here:
+// arguments are lengths and depths of visible surface points).  Ray generation and the triangle test
+// keep the IEEE forms: they decide WHICH primitive is hit.
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+__device__ __forceinline__ float div_nr(float a, float b) {
+  const float r = rcp_nr(b);
+  const float q = a * r;
+  return fmaf(fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+  const float s1 = fmaf(fmaf(-s, s, x), h, s);
+  return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
+}
+
+// BSDF of a material row (include/ffx.h FFX_MAT_*, model 1: the reflection side of Mitsuba's `principled`), for the
+// viewer direction wv and the emitter direction wl at a surface with unit normal n facing the viewer:
+//     pi * f(wv, wl) * cos_o = base_color * A + B   per colour channel.
+// Same formulas, in the same order, as material_eval of oracle/ffx_oracle.c (which cites the model's sources);
+// quotients and roots through the Newton-refined hardware seeds above.  The caller handles model 0 (A = cos_o).
+__device__ __forceinline__ float sqrf(float x) { return x * x; }
+__device__ __forceinline__ float schlick_weight(float c) {
+  float m = 1.0f - c;
+  m = fminf(fmaxf(m, 0.f), 1.f);
+  return sqrf(sqrf(m)) * m;
+}
+__device__ __forceinline__ float smith_g1_aniso(v3 v, float v_dot_h, float ax, float ay) {
+  const float xy = sqrf(ax * v.x) + sqrf(ay * v.y);
+  const float tan2 = div_nr(xy, sqrf(v.z));
+  float r = div_nr(2.0f, 1.0f + sqrt_nr(1.0f + tan2));
+  if (xy == 0.f) r = 1.f;
+  if (v_dot_h * v.z <= 0.f) r = 0.f;
+  return r;
+}
+__device__ __forceinline__ float smith_ggx1(v3 v, float v_dot_h, float alpha) {
+  const float a2 = sqrf(alpha), c2 = sqrf(fabsf(v.z));
+  const float tan2 = div_nr(1.0f - c2, c2);
+  float r = div_nr(2.0f, 1.0f + sqrt_nr(1.0f + a2 * tan2));
+  if (v.z == 1.f) r = 1.f;
+  if (v_dot_h * v.z <= 0.f) r = 0.f;
+  return r;
+}
+__device__ __noinline__ void material_eval(const float *__restrict__ m, v3 n, v3 wv, v3 wl, float &A, float &B) {
+  const float cos_i = vdot(n, wv), cos_o = vdot(n, wl);
+  A = 0.f; B = 0.f;
+  if (!(cos_i > 0.f && cos_o > 0.f)) return;
+  const float4 m0 = reinterpret_cast<const float4 *>(m)[0], m1 = reinterpret_cast<const float4 *>(m)[1], m2 = reinterpret_cast<const float4 *>(m)[2],
+               m3 = reinterpret_cast<const float4 *>(m)[3];
+  const float rough = m1.x, aniso = m1.y, metallic = m1.z, spec_trans = m1.w, eta = m2.x, spec_tint = m2.y, sheen = m2.z, sheen_tint = m2.w;
+  const float flat = m3.x, cc = m3.y, ccg = m3.z;
+  const float lum = 0.212671f * m0.x + 0.715160f * m0.y + 0.072169f * m0.z;
+  const float brdf = (1.0f - metallic) * (1.0f - spec_trans);
+  // shading frame: coordinate_system(n)
+  const float sg = copysignf(1.0f, n.z), ca = -rcp_nr(sg + n.z), cb = n.x * n.y * ca;
+  const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+  const v3 wi = V3(vdot(wv, fs), vdot(wv, ft), cos_i), wo = V3(vdot(wl, fs), vdot(wl, ft), cos_o);
+  v3 wh = V3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z);
+  const float ihl = rcp_nr(sqrt_nr(vdot(wh, wh)));
+  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
+  const float ci_h = vdot(wi, wh), co_h = vdot(wo, wh);
+  const bool facing = ci_h * cos_i > 0.f && co_h * cos_o > 0.f;
+  const float r2 = sqrf(rough), aspect = sqrt_nr(1.0f - 0.9f * aniso);
+  const float ax = fmaxf(0.001f, div_nr(r2, aspect)), ay = fmaxf(0.001f, r2 * aspect);
+  const float ieta = rcp_nr(eta);
+  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * sqrf(ieta);
+  const float ct = ct2 > 0.f ? sqrt_nr(ct2) : 0.f; // cosine of the transmitted direction
+  const float sw = schlick_weight(eta > 1.0f ? fabsf(ci_h) : ct);
+  float a = 0.f, b = 0.f;
+  float F_d;
+  {
+    const float c = fabsf(ci_h);
+    const float a_s = div_nr(c - eta * ct, c + eta * ct), a_p = div_nr(ct - eta * c, ct + eta * c);
+    F_d = 0.5f * (a_s * a_s + a_p * a_p);
+    if (eta == 1.0f) F_d = 0.f;
+    else if (c == 0.f) F_d = 1.f;
+  }
+  if (facing && F_d > 0.f) { // main specular reflection lobe
+    const float tmp = sqrf(div_nr(wh.x, ax)) + sqrf(div_nr(wh.y, ay)) + sqrf(wh.z);
+    float D = rcp_nr(FFX_PI_F * (ax * ay) * sqrf(tmp));
+    if (!(D * wh.z > 1e-20f)) D = 0.f;
+    const float G = smith_g1_aniso(wi, ci_h, ax, ay) * smith_g1_aniso(wo, co_h, ax, ay);
+    const float common = div_nr(D * G, 4.0f * cos_i);
+    const float R0 = sqrf(div_nr(eta - 1.0f, eta + 1.0f));
+    float Fa = metallic * (1.0f - sw), Fb = metallic * sw;
+    if (lum > 0.f) Fa += (1.0f - metallic) * spec_tint * div_nr(R0, lum) * (1.0f - sw);
+    else Fb += (1.0f - metallic) * spec_tint * R0 * (1.0f - sw);
+    Fb += (1.0f - metallic) * spec_tint * sw + (1.0f - metallic) * (1.0f - spec_tint) * F_d;
+    a += Fa * common;
+    b += Fb * common;
+  }
+  if (cc > 0.f && facing) { // clearcoat
+    const float Fcc = sw + (1.0f - sw) * 0.04f;
+    const float alpha = 0.1f + (0.001f - 0.1f) * ccg, a2 = sqrf(alpha), c2 = sqrf(wh.z);
+    float Dcc = div_nr(a2 - 1.0f, FFX_PI_F * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
+    if (!(Dcc * wh.z > 1e-20f)) Dcc = 0.f;
+    const float Gcc = smith_ggx1(wi, ci_h, 0.25f) * smith_ggx1(wo, co_h, 0.25f);
+    b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
+  }
+  const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);
+  if (brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
+    const float f_diff = (1.0f - 0.5f * Fi) * (1.0f - 0.5f * Fo);
+    const float Rr = 2.0f * rough * sqrf(co_h);
+    const float f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0f));
+    float dterm = f_diff + f_retro;
+    if (flat > 0.f) {
+      const float Fss90 = Rr * 0.5f;
+      const float Fss = (1.0f + (Fss90 - 1.0f) * Fo) * (1.0f + (Fss90 - 1.0f) * Fi);
+      const float f_ss = 1.25f * (Fss * (rcp_nr(cos_o + cos_i) - 0.5f) + 0.5f);
+      dterm = dterm + (f_ss - dterm) * flat;
+    }
+    a += brdf * cos_o * 0.3183098861837907f * dterm;
+  }
+  if (sheen > 0.f && 1.0f - metallic > 0.f) {
+    const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
+    if (lum > 0.f) { a += div_nr(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
+    else b += sv;
+  }
+  A = a * FFX_PI_F;
+  B = b * FFX_PI_F;
+}
+
 struct SampleTerms {
   int hit, shape, has_proj;
   int ubx, uby; // unclamped bilinear base texel (for the per-sample cache)
@@ -261,6 +392,7 @@ struct SampleTerms {
   float wx0, wx1, wy0, wy1;
   float proj_fac;
   float spot[3];
+  float proj_fac_b, spot_b[3]; // material rows: the part of the BSDF that does not scale with base_color
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -270,8 +402,9 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   Hit h;
   st.hit = traverse<false, true>(nodes, recs, o, d, nt, ft, h, stack, stride);
   st.has_proj = 0;
-  st.proj_fac = 0.f;
+  st.proj_fac = 0.f; st.proj_fac_b = 0.f;
   st.spot[0] = st.spot[1] = st.spot[2] = 0.f;
+  st.spot_b[0] = st.spot_b[1] = st.spot_b[2] = 0.f;
   st.shape = h.shape;
   if (!st.hit) return;
   const float4 *r4 = reinterpret_cast<const float4 *>(recs + h.slot);
@@ -311,7 +444,11 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
             vis = !traverse<true, true>(nodes, recs, ppos, vsub(Po, ppos), 0.f, 1.0f - SHADOW_EPS, hs, stack, stride);
           }
           if (vis) {
-            st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+            float bA = cos_s, bB = 0.f; // Lambert; material rows: pi f cos = base_color * bA + bB
+            if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f)
+              material_eval(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+            st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * bA;
+            st.proj_fac_b = (c.p_scale / (pl.z * pl.z * cos_p)) * bB;
             float fx = fmaf(u, (float)c.tw, -0.5f), fy = fmaf(v, (float)c.th, -0.5f);
             float x0 = floorf(fx), y0 = floorf(fy);
             float ax = fx - x0, ay = fy - y0;
@@ -350,10 +487,16 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           vis = !traverse<true, true>(nodes, recs, spos, vsub(Po, spos), 0.f, 1.0f - SHADOW_EPS, hs, stack, stride);
         }
         if (vis) {
-          float f = fall * cos_s / d2 * 0.3183098861837907f;
+          float bA = cos_s, bB = 0.f;
+          if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f)
+            material_eval(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+          float f = fall * bA / d2 * 0.3183098861837907f, fb = fall * bB / d2 * 0.3183098861837907f;
           st.spot[0] = c.s_int[0] * f;
           st.spot[1] = c.s_int[1] * f;
           st.spot[2] = c.s_int[2] * f;
+          st.spot_b[0] = c.s_int[0] * fb;
+          st.spot_b[1] = c.s_int[1] * fb;
+          st.spot_b[2] = c.s_int[2] * fb;
         }
       }
     }
@@ -403,6 +546,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
       shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
       if (!st.hit) continue;
       float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
+      float b0 = st.spot_b[0], b1 = st.spot_b[1], b2 = st.spot_b[2];
       if (st.has_proj) {
         const int tc = c.tc;
         size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
@@ -412,6 +556,9 @@ __global__ void __launch_bounds__(TR_BLOCK)
           r0 += tv * c.p_color[0] * st.proj_fac;
           r1 += tv * c.p_color[1] * st.proj_fac;
           r2 += tv * c.p_color[2] * st.proj_fac;
+          b0 += tv * c.p_color[0] * st.proj_fac_b;
+          b1 += tv * c.p_color[1] * st.proj_fac_b;
+          b2 += tv * c.p_color[2] * st.proj_fac_b;
         } else {
           float tv0 = st.wy0 * (st.wx0 * tex[o00] + st.wx1 * tex[o01]) + st.wy1 * (st.wx0 * tex[o10] + st.wx1 * tex[o11]);
           float tv1 = st.wy0 * (st.wx0 * tex[o00 + 1] + st.wx1 * tex[o01 + 1]) + st.wy1 * (st.wx0 * tex[o10 + 1] + st.wx1 * tex[o11 + 1]);
@@ -419,12 +566,21 @@ __global__ void __launch_bounds__(TR_BLOCK)
           r0 += tv0 * 1.0f * st.proj_fac;
           r1 += tv1 * 1.0f * st.proj_fac;
           r2 += tv2 * 1.0f * st.proj_fac;
+          b0 += tv0 * 1.0f * st.proj_fac_b;
+          b1 += tv1 * 1.0f * st.proj_fac_b;
+          b2 += tv2 * 1.0f * st.proj_fac_b;
         }
       }
-      const float *alb = albedo + 3 * st.shape;
-      acc0 += alb[0] * r0;
-      acc1 += alb[1] * r1;
-      acc2 += alb[2] * r2;
+      const float *alb = albedo + (size_t)c.mat_stride * st.shape;
+      if (c.mat_stride == 3) {
+        acc0 += alb[0] * r0;
+        acc1 += alb[1] * r1;
+        acc2 += alb[2] * r2;
+      } else {
+        acc0 += alb[0] * r0 + b0;
+        acc1 += alb[1] * r1 + b1;
+        acc2 += alb[2] * r2 + b2;
+      }
     }
   }
   if (wave > 0) {
@@ -481,11 +637,12 @@ __global__ void __launch_bounds__(TR_BLOCK)
     SampleTerms st;
     shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
     if (!st.hit || !st.has_proj) continue;
-    const float *alb = albedo + 3 * st.shape;
+    const float *alb = albedo + (size_t)c.mat_stride * st.shape;
     size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
     size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
     if (tc == 1) {
       float ws = (g0 * alb[0] * c.p_color[0] + g1 * alb[1] * c.p_color[1] + g2 * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
+      if (st.proj_fac_b != 0.f) ws += (g0 * c.p_color[0] + g1 * c.p_color[1] + g2 * c.p_color[2]) * st.proj_fac_b * inv_spp;
       atomicAdd(gtex + o00, ws * st.wy0 * st.wx0);
       atomicAdd(gtex + o01, ws * st.wy0 * st.wx1);
       atomicAdd(gtex + o10, ws * st.wy1 * st.wx0);
@@ -495,6 +652,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float ws = gg[ch] * alb[ch] * st.proj_fac * inv_spp;
+        if (st.proj_fac_b != 0.f) ws += gg[ch] * st.proj_fac_b * inv_spp;
         atomicAdd(gtex + o00 + ch, ws * st.wy0 * st.wx0);
         atomicAdd(gtex + o01 + ch, ws * st.wy0 * st.wx1);
         atomicAdd(gtex + o10 + ch, ws * st.wy1 * st.wx0);
@@ -1451,31 +1609,10 @@ struct ShadePre {
   bool ok, need_p, need_s;
   v3 P, ng, Po;
   float pfac, u, v, sfac;
+  float pfac_b, sfac_b; // material rows only
 };
 
 // packet version of shade_sample for R samples per lane: every lane of the wave reaches every walk
-// Reciprocal, quotient and square root of the shading terms: the hardware seed (v_rcp / v_sqrt / v_rsq,
-// 1 ulp) plus one fma Newton step.  The result equals the correctly rounded IEEE value except in rare
-// last-bit cases (Markstein), at 3 / 5 / 7 VALU instructions instead of the 10 / 10 / 14 of the
-// compiler's IEEE expansions (which also cover denormal and overflow ranges that cannot occur here:
-// arguments are lengths and depths of visible surface points).  Ray generation and the triangle test
-// keep the IEEE forms: they decide WHICH primitive is hit.
-__device__ __forceinline__ float rcp_nr(float x) {
-  const float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(r, fmaf(-x, r, 1.0f), r);
-}
-__device__ __forceinline__ float div_nr(float a, float b) {
-  const float r = rcp_nr(b);
-  const float q = a * r;
-  return fmaf(fmaf(-b, q, a), r, q);
-}
-__device__ __forceinline__ float sqrt_nr(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float h = 0.5f * __builtin_amdgcn_rsqf(x);
-  const float s1 = fmaf(fmaf(-s, s, x), h, s);
-  return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
-}
-
 // The scene constants (ShadeK, ~100 dwords) are the first kernel argument of the render kernels.  Read
 // through `c` the compiler loads them all up front and, out of SGPRs, parks them in VGPR lanes
 // (v_writelane / v_readlane: ~480 spill instructions on the VALU, the unit that bounds these kernels).
@@ -1487,7 +1624,7 @@ __device__ __forceinline__ const ShadeK &kernarg_shade() {
   return *(const ShadeK *)p;
 }
 
-template <int R, bool WIDE>
+template <int R, bool WIDE, bool MAT = false>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
@@ -1503,8 +1640,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     ShadePre &q = pre[r];
     st[r].hit = h[r].prim >= 0;
     st[r].has_proj = 0;
-    st[r].proj_fac = 0.f;
+    st[r].proj_fac = 0.f; st[r].proj_fac_b = 0.f;
     st[r].spot[0] = st[r].spot[1] = st[r].spot[2] = 0.f;
+    st[r].spot_b[0] = st[r].spot_b[1] = st[r].spot_b[2] = 0.f;
     st[r].shape = -1; // read from the hit's triangle record below (the octant loops do not carry it)
     q.P = V3(0.f, 0.f, 0.f);
     q.ng = V3(0.f, 0.f, 1.f);
@@ -1534,6 +1672,15 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     // ---- projector terms
     q.need_p = false;
     q.pfac = 0.f; q.u = 0.f; q.v = 0.f;
+    q.pfac_b = 0.f; q.sfac_b = 0.f;
+    // material rows (MAT): pi f cos = base_color * bA + bB per emitter (material_eval); Lambert: bA = cos_s, bB = 0
+    const float *mrow = nullptr;
+    if constexpr (MAT) {
+      if (q.ok) {
+        mrow = c.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
+        if (mrow[FFX_MAT_MODEL] == 0.f) mrow = nullptr;
+      }
+    }
     if (c.proj_on && q.ok) {
       v3 pl = xf_point(c.p_w2l, q.P);
       if (pl.z > 0.f) {
@@ -1554,7 +1701,15 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
           if (cos_s > 0.f && cos_p > 0.f) {
             q.need_p = true;
-            q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p) * cos_s;
+            if constexpr (MAT) {
+              float bA = cos_s, bB = 0.f;
+              if (mrow) material_eval(mrow, q.ng, V3(-d[r].x, -d[r].y, -d[r].z), wi, bA, bB);
+              const float e = div_nr(c.p_scale, pl.z * pl.z * cos_p);
+              q.pfac = e * bA;
+              q.pfac_b = e * bB;
+            } else {
+              q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p) * cos_s;
+            }
           }
         }
       }
@@ -1578,7 +1733,14 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
         if (fall > 0.f) {
           q.need_s = true;
-          q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
+          if constexpr (MAT) {
+            float bA = cos_s, bB = 0.f;
+            if (mrow) material_eval(mrow, q.ng, V3(-d[r].x, -d[r].y, -d[r].z), wi, bA, bB);
+            q.sfac = div_nr(fall * bA, d2) * 0.3183098861837907f;
+            q.sfac_b = div_nr(fall * bB, d2) * 0.3183098861837907f;
+          } else {
+            q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
+          }
         }
       }
     }
@@ -1633,6 +1795,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     const ShadePre &q = pre[r];
     if (q.need_p && !occ_p[r]) {
       st[r].proj_fac = q.pfac;
+      if constexpr (MAT) st[r].proj_fac_b = q.pfac_b;
       float fx = fmaf(q.u, (float)c2.tw, -0.5f), fy = fmaf(q.v, (float)c2.th, -0.5f);
       float x0 = floorf(fx), y0 = floorf(fy);
       float ax = fx - x0, ay = fy - y0;
@@ -1650,6 +1813,11 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       st[r].spot[0] = c2.s_int[0] * q.sfac;
       st[r].spot[1] = c2.s_int[1] * q.sfac;
       st[r].spot[2] = c2.s_int[2] * q.sfac;
+      if constexpr (MAT) {
+        st[r].spot_b[0] = c2.s_int[0] * q.sfac_b;
+        st[r].spot_b[1] = c2.s_int[1] * q.sfac_b;
+        st[r].spot_b[2] = c2.s_int[2] * q.sfac_b;
+      }
     }
   }
 }
@@ -1757,21 +1925,29 @@ struct __attribute__((aligned(16))) CacheFoot { float w[25]; uint32_t pad[3]; };
 static_assert(sizeof(CacheFoot) == 112, "cache footprint must be 112 bytes");
 __host__ __device__ inline size_t cache_off_foot(size_t n_pix) { return (64 + 8 * n_pix + 127) & ~(size_t)127; }
 __host__ __device__ inline size_t cache_off_arena(size_t n_pix) { return (cache_off_foot(n_pix) + sizeof(CacheFoot) * n_pix + 127) & ~(size_t)127; }
-struct CacheStray { uint32_t pix, xy_shape; float ax, ay, fac; uint32_t pad; }; // xy_shape = x0 | y0 << 12 ... see stray_pack
+struct CacheStray { uint32_t pix, xy_shape; float ax, ay, fac; float fac_b; /* material rows only (else not written) */ }; // xy_shape = x0 | y0 << 12 ... see stray_pack
 static_assert(sizeof(CacheStray) == 24, "stray record must be 24 bytes");
 __host__ __device__ inline size_t cache_stray_capacity(int w, int h, int spp) {
   const size_t n = (size_t)w * h * spp / 64;
   return n < 4096 ? 4096 : n;
 }
+// material rows: a second footprint per pixel (the part of the BSDF that does not scale with base_color), behind the arena
+__host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stray) {
+  return (cache_off_arena(n_pix) + sizeof(CacheStray) * cap_stray + 127) & ~(size_t)127;
+}
 
-template <int R, bool WIDE>
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
+#define FFX_PK_MAT_WAVES 4 // material rows: the BSDF terms need registers (see DESIGN.md 5.1 on occupancy)
+template <int R, bool WIDE, bool MAT>
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off) {
+                    int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
+                    uint32_t cache_foot_b_off) {
   constexpr int NSUB = 4 / R;
+  constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
+  __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
   static_assert(R == 1, "the adjoint cache is written one pixel at a time");
   FFX_TINIT();
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
@@ -1808,6 +1984,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       int lz = lane;
       asm volatile("" : "+v"(lz));
       if (lz < 32) s_foot[lz] = 0.f;
+      if constexpr (MAT) { if (lz < 32) s_foot_b[lz] = 0.f; }
       __builtin_amdgcn_wave_barrier();
     }
     for (int pass = 0; pass < passes; ++pass) {
@@ -1829,7 +2006,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, (cache && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, (cache && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -1849,6 +2026,15 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             atomicAdd(&s_foot[by0 + bx1], pf * st[0].wy0 * st[0].wx1);
             atomicAdd(&s_foot[by1 + bx0], pf * st[0].wy1 * st[0].wx0);
             atomicAdd(&s_foot[by1 + bx1], pf * st[0].wy1 * st[0].wx1);
+            if constexpr (MAT) {
+              const float pb = st[0].proj_fac_b;
+              if (pb != 0.f) {
+                atomicAdd(&s_foot_b[by0 + bx0], pb * st[0].wy0 * st[0].wx0);
+                atomicAdd(&s_foot_b[by0 + bx1], pb * st[0].wy0 * st[0].wx1);
+                atomicAdd(&s_foot_b[by1 + bx0], pb * st[0].wy1 * st[0].wx0);
+                atomicAdd(&s_foot_b[by1 + bx1], pb * st[0].wy1 * st[0].wx1);
+              }
+            }
           }
           const wmask straym = wballot(lit && !in_win);
           if (straym != 0ull) { // single samples that do not fit the footprint: one allocation per wave
@@ -1866,6 +2052,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                 rec->ax = st[0].wx1;
                 rec->ay = st[0].wy1;
                 rec->fac = st[0].proj_fac;
+                if constexpr (MAT) rec->fac_b = st[0].proj_fac_b;
               }
             } else if (lane == 0) {
               atomicAdd(&hdr->dropped, n); // arena exhausted (never seen: it holds 1/64 of all samples, strays are ~0.1 %)
@@ -1879,16 +2066,22 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         float c0 = 0.f, c1 = 0.f, c2 = 0.f; // this pass's contribution of the lane's sample
         if (st[r].hit) {
         float r0 = st[r].spot[0], r1 = st[r].spot[1], r2 = st[r].spot[2];
+        float b0 = st[r].spot_b[0], b1 = st[r].spot_b[1], b2 = st[r].spot_b[2]; // (MAT only: dead otherwise)
         if (st[r].has_proj) {
           const int tc = ct.tc;
           size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
           size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
-          const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1, pf = st[r].proj_fac;
+          const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1, pf = st[r].proj_fac, pb = st[r].proj_fac_b;
           if (tc == 1) {
             float tv = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
             r0 += tv * ct.p_color[0] * pf;
             r1 += tv * ct.p_color[1] * pf;
             r2 += tv * ct.p_color[2] * pf;
+            if constexpr (MAT) {
+              b0 += tv * ct.p_color[0] * pb;
+              b1 += tv * ct.p_color[1] * pb;
+              b2 += tv * ct.p_color[2] * pb;
+            }
           } else {
             float tv0 = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
             float tv1 = wy0 * (wx0 * tex[o00 + 1] + wx1 * tex[o01 + 1]) + wy1 * (wx0 * tex[o10 + 1] + wx1 * tex[o11 + 1]);
@@ -1896,12 +2089,18 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             r0 += tv0 * 1.0f * pf;
             r1 += tv1 * 1.0f * pf;
             r2 += tv2 * 1.0f * pf;
+            if constexpr (MAT) {
+              b0 += tv0 * 1.0f * pb;
+              b1 += tv1 * 1.0f * pb;
+              b2 += tv2 * 1.0f * pb;
+            }
           }
         }
-        const float *alb = albedo + 3 * st[r].shape;
+        const float *alb = albedo + MS * st[r].shape;
         c0 = alb[0] * r0;
         c1 = alb[1] * r1;
         c2 = alb[2] * r2;
+        if constexpr (MAT) { c0 += b0; c1 += b1; c2 += b2; }
         }
         // running sums of a pixel that needs several 64-sample passes are parked in LDS between the passes; the
         // usual single pass never touches it (it had cost 15 LDS operations per pixel)
@@ -1944,13 +2143,16 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
       int lw = lane;
       asm volatile("" : "+v"(lw));
       if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + ((size_t)cache_foot_off << 7))[pix[0]].w[lw] = s_foot[lw];
+      if constexpr (MAT) {
+        if (fox >= 0 && lw < 25) reinterpret_cast<CacheFoot *>(cache + ((size_t)cache_foot_b_off << 7))[pix[0]].w[lw] = s_foot_b[lw];
+      }
     }
   }
   FFX_TFLUSH();
 }
 
-template <int R, bool WIDE>
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R == 1 ? FFX_PK1_WAVES : 3, R == 1 ? FFX_PK1_WAVES : 4)))
+template <int R, bool WIDE, bool MAT>
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     const float *__restrict__ gimg, float *__restrict__ gtex) {
@@ -1992,18 +2194,21 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
+      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit || !st[r].has_proj) continue;
-        const float *alb = albedo + 3 * st[r].shape;
+        const float *alb = albedo + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
         size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
         size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
         const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1;
         if (tc == 1) {
           float ws = (g[r][0] * alb[0] * ct.p_color[0] + g[r][1] * alb[1] * ct.p_color[1] + g[r][2] * alb[2] * ct.p_color[2]) * st[r].proj_fac * inv_spp;
+          if constexpr (MAT) {
+            if (st[r].proj_fac_b != 0.f) ws += (g[r][0] * ct.p_color[0] + g[r][1] * ct.p_color[1] + g[r][2] * ct.p_color[2]) * st[r].proj_fac_b * inv_spp;
+          }
           atomicAdd(gtex + o00, ws * wy0 * wx0);
           atomicAdd(gtex + o01, ws * wy0 * wx1);
           atomicAdd(gtex + o10, ws * wy1 * wx0);
@@ -2012,6 +2217,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
             float ws = g[r][ch] * alb[ch] * st[r].proj_fac * inv_spp;
+            if constexpr (MAT) {
+              if (st[r].proj_fac_b != 0.f) ws += g[r][ch] * st[r].proj_fac_b * inv_spp;
+            }
             atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
             atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
             atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
@@ -2027,7 +2235,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(R
 // the pixel's  gimg . albedo[shape] (. colour) / spp  with one global float atomic (a lit pixel touches ~16
 // texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
 // pixel slots): one lane per stray sample record, four taps each.
-struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; };
+struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; }; // ms: floats per material row (3 / FFX_MAT_STRIDE)
 
 // the stray records of the adjoint cache: thread i replays record i (four bilinear taps each)
 __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_pix, uint32_t i, const BwdP &p, const float *__restrict__ gimg,
@@ -2041,9 +2249,11 @@ __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_
   const int ix0 = (int)(rec.xy_shape & 0xfffu) - 1, iy0 = (int)((rec.xy_shape >> 12) & 0xfffu) - 1, shape = (int)(rec.xy_shape >> 24);
   const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
   const float wx0 = 1.0f - rec.ax, wx1 = rec.ax, wy0 = 1.0f - rec.ay, wy1 = rec.ay;
-  const float *alb = albedo + 3 * shape;
+  const float *alb = albedo + p.ms * shape;
+  const float fac_b = p.ms == 3 ? 0.f : rec.fac_b;
   if (p.tc == 1) {
-    const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * rec.fac * p.inv_spp;
+    float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * rec.fac * p.inv_spp;
+    if (fac_b != 0.f) ws += (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * fac_b * p.inv_spp;
     if (ws == 0.f) return;
     atomicAdd(gtex + (size_t)y0 * p.tw + x0, ws * wy0 * wx0);
     atomicAdd(gtex + (size_t)y0 * p.tw + x1, ws * wy0 * wx1);
@@ -2055,7 +2265,8 @@ __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_
     const float gg[3] = {g0, g1, g2};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float ws = gg[ch] * alb[ch] * rec.fac * p.inv_spp;
+      float ws = gg[ch] * alb[ch] * rec.fac * p.inv_spp;
+      if (fac_b != 0.f) ws += gg[ch] * fac_b * p.inv_spp;
       if (ws == 0.f) continue;
       atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
       atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
@@ -2109,15 +2320,18 @@ __global__ void __launch_bounds__(256)
     const CachePix hp = hdrs[pixel];
     if (!hp.lit) continue;
     const float w = foots[pixel].w[e];
-    if (w == 0.f) continue;
+    const float wb = p.ms == 3 ? 0.f : reinterpret_cast<const CacheFoot *>(cache + p.off_foot_b)[pixel].w[e];
+    if (w == 0.f && wb == 0.f) continue;
     const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
-    const float *alb = albedo + 3 * (int)hp.shape;
+    const float *alb = albedo + p.ms * (int)hp.shape;
     const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
-    if (ws == 0.f) continue;
+    float val = ws * w;
+    if (wb != 0.f) val += (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp * wb;
+    if (val == 0.f) continue;
     const int tx = (int)hp.x0 + e % 5, ty = (int)hp.y0 + e / 5;
     const int lx = tx - ox, ly = ty - oy;
-    if (lx < K9_TILE && ly < K9_TILE) atomicAdd(&s_tile[ly * K9_TILE + lx], ws * w); // (lx, ly >= 0 by construction)
-    else atomicAdd(gtex + (size_t)ty * p.tw + tx, ws * w);
+    if (lx < K9_TILE && ly < K9_TILE) atomicAdd(&s_tile[ly * K9_TILE + lx], val); // (lx, ly >= 0 by construction)
+    else atomicAdd(gtex + (size_t)ty * p.tw + tx, val);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < K9_TILE * K9_TILE; i += 256) {
@@ -2136,18 +2350,21 @@ __global__ void __launch_bounds__(256)
     const CachePix hp = reinterpret_cast<const CachePix *>(cache + 64)[pixel];
     if (!hp.lit || e >= 25) return;
     const float w = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix))[pixel].w[e];
-    if (w == 0.f) return;
+    const float wb = p.ms == 3 ? 0.f : reinterpret_cast<const CacheFoot *>(cache + p.off_foot_b)[pixel].w[e];
+    if (w == 0.f && wb == 0.f) return;
     const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
-    const float *alb = albedo + 3 * (int)hp.shape;
+    const float *alb = albedo + p.ms * (int)hp.shape;
     const int x = (int)hp.x0 + e % 5, y = (int)hp.y0 + e / 5;
     if (p.tc == 1) {
       const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
-      if (ws != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, ws * w);
+      float val = ws * w;
+      if (wb != 0.f) val += (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp * wb;
+      if (val != 0.f) atomicAdd(gtex + (size_t)y * p.tw + x, val);
     } else {
       float *t = gtex + ((size_t)y * p.tw + x) * 3;
-      if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * p.inv_spp * w);
-      if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * p.inv_spp * w);
-      if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * p.inv_spp * w);
+      if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * p.inv_spp * w + g0 * p.inv_spp * wb);
+      if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * p.inv_spp * w + g1 * p.inv_spp * wb);
+      if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * p.inv_spp * w + g2 * p.inv_spp * wb);
     }
     return;
   }
@@ -2174,6 +2391,8 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   c.proj_on = sd->proj.enabled;
   c.spot_on = sd->spot.enabled;
   c.shadows = sd->shadows;
+  c.mat_stride = sd->mat_stride ? sd->mat_stride : 3;
+  if (c.mat_stride != 3 && c.mat_stride != FFX_MAT_STRIDE) return 0;
   float inv[16];
   if (c.proj_on) {
     if (!ffx_inv4(sd->proj.to_world, inv)) return 0;
@@ -2422,6 +2641,9 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
   ShadeK c;
   if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
+  c.mats = shape_albedo;
+  const bool mat = c.mat_stride == FFX_MAT_STRIDE;
+  if (mat && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd: material rows must be 16-byte aligned");
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
@@ -2442,12 +2664,14 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const WideScene ws = wide_scene(bvh, info);
     // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
     const uint32_t foot_off = (uint32_t)(cache_off_foot((size_t)c.cam.W * c.cam.H) >> 7), arena_off = (uint32_t)(cache_off_arena((size_t)c.cam.W * c.cam.H) >> 7);
-    if (use_wide(info))
-      hipLaunchKernelGGL((k_render_fwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off, arena_off);
-    else
-      hipLaunchKernelGGL((k_render_fwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo,
-                         tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off, arena_off);
+    const uint32_t foot_b_off = (uint32_t)(cache_off_foot_b((size_t)c.cam.W * c.cam.H, cache_stray_capacity(c.cam.W, c.cam.H, spp)) >> 7);
+#define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
+  hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
+                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
+                     arena_off, foot_b_off)
+    if (use_wide(info)) { if (mat) FFX_LAUNCH_FWD(true, true); else FFX_LAUNCH_FWD(true, false); }
+    else { if (mat) FFX_LAUNCH_FWD(false, true); else FFX_LAUNCH_FWD(false, false); }
+#undef FFX_LAUNCH_FWD
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -2470,6 +2694,13 @@ size_t ffx_render_cache_bytes(int width, int height, int spp) {
   return cache_off_arena((size_t)width * height) + sizeof(CacheStray) * cache_stray_capacity(width, height, spp);
 }
 
+size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) {
+  if (!sd || sd->cam.width < 1 || sd->cam.height < 1 || spp < 1) return 0;
+  if (sd->mat_stride != FFX_MAT_STRIDE) return ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp);
+  const size_t n_pix = (size_t)sd->cam.width * sd->cam.height;
+  return cache_off_foot_b(n_pix, cache_stray_capacity(sd->cam.width, sd->cam.height, spp)) + sizeof(CacheFoot) * n_pix;
+}
+
 int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
@@ -2487,6 +2718,9 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   p.inv_spp = 1.0f / (float)spp;
   const long n_pix = (long)sd->cam.width * sd->cam.height;
   p.W = sd->cam.width; p.H = sd->cam.height;
+  p.ms = sd->mat_stride ? sd->mat_stride : 3;
+  if (p.ms != 3 && p.ms != FFX_MAT_STRIDE) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad material stride");
+  p.off_foot_b = cache_off_foot_b((size_t)n_pix, cache_stray_capacity(sd->cam.width, sd->cam.height, spp));
   const int stray_blocks = ffx_cdiv((long)cache_stray_capacity(sd->cam.width, sd->cam.height, spp), 256);
   if (p.tc == 1) {
     // footprints by 8x8-pixel blocks through an LDS tile; the tail of the grid replays the stray records
@@ -2510,6 +2744,9 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if (!check_info(info, "render_bwd")) return FFX_ERR_ARG;
   ShadeK c;
   if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
+  c.mats = shape_albedo;
+  const bool mat = c.mat_stride == FFX_MAT_STRIDE;
+  if (mat && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd: material rows must be 16-byte aligned");
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
@@ -2524,12 +2761,12 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     uint32_t astride;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
-    if (use_wide(info))
-      hipLaunchKernelGGL((k_render_bwd_pk<1, true>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, spp,
-                         seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex);
-    else
-      hipLaunchKernelGGL((k_render_bwd_pk<1, false>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, spp,
-                         seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex);
+#define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
+  hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex)
+    if (use_wide(info)) { if (mat) FFX_LAUNCH_BWD(true, true); else FFX_LAUNCH_BWD(true, false); }
+    else { if (mat) FFX_LAUNCH_BWD(false, true); else FFX_LAUNCH_BWD(false, false); }
+#undef FFX_LAUNCH_BWD
     FFX_CHECK_LAUNCH("render_bwd");
     return FFX_OK;
   }

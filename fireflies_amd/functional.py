@@ -126,7 +126,7 @@ def cache_supported(sd, spp):
         return False
     if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255:
         return False
-    return ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp) <= CACHE_LIMIT_BYTES
+    return ops.render_cache_bytes_sd(sd, spp) <= CACHE_LIMIT_BYTES
 
 
 class _Render(torch.autograd.Function):
@@ -141,11 +141,11 @@ class _Render(torch.autograd.Function):
         ctx.albedo = albedo
         if tex.requires_grad and sd.proj.enabled:
             # the adjoint needs the albedo as it was at the forward pass (Scene._apply overwrites the
-            # tensor in place on the next randomisation): keep a private copy (3 floats per shape)
+            # tensor in place on the next randomisation): keep a private copy (3 or 16 floats per shape)
             ctx.albedo = albedo.clone()
             if cache_supported(sd, spp):
                 # store a texture footprint per pixel now instead of re-tracing the scene in backward
-                ctx.cache = torch.empty(ops.render_cache_bytes(sd.cam.width, sd.cam.height, spp), dtype=torch.uint8, device=t.device)
+                ctx.cache = torch.empty(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device=t.device)
         ctx.pose_version = geom.version
         return geom.render_fwd(sd, albedo, t, spp, seed, fp16, cache=ctx.cache)
 

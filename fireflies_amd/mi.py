@@ -309,6 +309,11 @@ class Scene:
         S = len(data.meshes)
         self._xforms = torch.eye(4).repeat(S, 1, 1)  # host
         self._offs = off.copy()
+        # the material table the render kernels take: [S,3] Lambert albedos, or [S,16] material rows (include/ffx.h FFX_MAT_*)
+        # as soon as one mesh carries a principled BSDF (`albedo` keeps its name: column 0..2 is the base colour either way)
+        rows = scenes.material_rows(data)
+        self._mat_stride = 3 if rows is None else scenes.MAT_STRIDE
+        alb = alb if rows is None else rows
         self.albedo = torch.from_numpy(alb).to(self.device)
         self._albedo_host = alb.copy()
         self._albedo_ring = None
@@ -334,10 +339,21 @@ class Scene:
         for m in d.meshes:
             mats.setdefault(m.material, []).append(m)
         self._material_meshes = {k: [self._mesh_index[x.name] for x in v] for k, v in mats.items()}
+        # principled materials expose the plugin's parameters under the names Mitsuba gives them inside the exporter's
+        # `twosided` wrapper (main.py:97-107: "brdf_0.roughness.value", ..., and "brdf_0.specular" without ".value");
+        # diffuse materials keep base_color / specular / roughness so that the reference's scripts run on them
+        self._material_principled = {k: v[0].bsdf is not None for k, v in mats.items()}
         for mat, ms in mats.items():
             p._init(mat + ".brdf_0.base_color.value", Color3f(torch.tensor(ms[0].albedo, dtype=torch.float32)))
-            p._init(mat + ".brdf_0.specular", Float(0.5))
-            p._init(mat + ".brdf_0.roughness.value", Float(0.5))
+            b = dict(scenes.PRINCIPLED_DEFAULTS)
+            b.update(ms[0].bsdf or {})
+            p._init(mat + ".brdf_0.specular", Float(b["specular"]))
+            p._init(mat + ".brdf_0.roughness.value", Float(b["roughness"]))
+            if ms[0].bsdf is not None:
+                for k in scenes.PRINCIPLED_DEFAULTS:
+                    if k not in ("specular", "roughness"):
+                        p._init(mat + f".brdf_0.{k}.value", Float(b[k]))
+                p._init(mat + ".brdf_0.eta", Float(scenes.specular_to_eta(b["specular"]) if "eta" not in (ms[0].bsdf or {}) else ms[0].bsdf["eta"]))
         for s in [d.camera] + ([d.projector] if d.projector is not None else []):
             p._init(s.name + ".to_world", Transform4f(s.to_world))
             p._init(s.name + ".x_fov", Float(s.fov_x))
@@ -394,21 +410,38 @@ class Scene:
                 self._set_pose(base, torch.eye(4), None, v)
                 geom_dirty = True
             elif rest.startswith("brdf_0.") and rest != "brdf_0.base_color.value" and base in self._material_meshes:
-                # principled-BSDF parameters other than the base colour (specular, roughness, clearcoat, ...; the
-                # reference randomises them: main.py:97-107, examples/vocalfold_scene.py:93) are accepted so that
-                # such scripts run, but shading is Lambert: say so once instead of silently ignoring them
-                if not getattr(self, "_warned_bsdf", False):
-                    import warnings
+                # principled-BSDF parameters (specular, roughness, clearcoat, ...; the reference randomises them:
+                # main.py:97-107, examples/vocalfold_scene.py:93)
+                name = rest[len("brdf_0."):]
+                name = name[:-len(".value")] if name.endswith(".value") else name
+                if not self._material_principled.get(base, False):
+                    # a diffuse material has no such parameters in Mitsuba; accepted so that the scripts run — say so once
+                    if not getattr(self, "_warned_bsdf", False):
+                        import warnings
 
-                    warnings.warn(f"{k}: principled-BSDF parameters other than base_color do not affect the render — shading is Lambert "
-                                  "(fireflies_amd DESIGN.md 4.3); further assignments of such parameters are not reported", stacklevel=4)
-                    self._warned_bsdf = True
+                        warnings.warn(f"{k}: material {base!r} is diffuse — principled-BSDF parameters do not affect it "
+                                      "(declare it principled: scenes.MeshData(bsdf={...}) or <bsdf type=\"principled\">); "
+                                      "further assignments of such parameters are not reported", stacklevel=4)
+                        self._warned_bsdf = True
+                    continue
+                v = self._params._d[k]
+                v = float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
+                if name == "specular":  # the plugin re-derives eta from it (principled.cpp parameters_changed)
+                    col, v = scenes.MAT_COLUMN["eta"], scenes.specular_to_eta(v)
+                    self._params._d[base + ".brdf_0.eta"] = Float(v)
+                elif name in scenes.MAT_COLUMN and name != "model":
+                    col = scenes.MAT_COLUMN[name]
+                else:
+                    raise KeyError(f"{k}: not a parameter of the principled BSDF")
+                for i in self._material_meshes[base]:
+                    self._albedo_host[i, col] = v
+                albedo_dirty = True
             elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
                 c = self._params._d[k]
                 c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]
                 c = c.detach().cpu().numpy()
                 for i in self._material_meshes[base]:
-                    self._albedo_host[i] = c
+                    self._albedo_host[i, :3] = c
                 albedo_dirty = True
         if geom_dirty:
             self.geom.update(self._xforms, self._offs)
@@ -443,7 +476,7 @@ class Scene:
             spot = scenes.SpotData(s.name, self._mat(s.name + ".to_world"), tuple(float(v) for v in inten), float(p[s.name + ".cutoff_angle"]),
                                    float(p[s.name + ".beam_width"]))
         tmp = scenes.SceneData(d.meshes, sensor, proj, spot, float(p["Projector.scale"]) if proj is not None else 1.0)
-        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows)
+        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride)
         self._sd_cache = (tex_channels, sd)
         return sd
 

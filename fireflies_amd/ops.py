@@ -237,6 +237,17 @@ def render_cache_bytes(width, height, spp):
     return int(api().lib.ffx_render_cache_bytes(int(width), int(height), int(spp)))
 
 
+def render_cache_bytes_sd(sd, spp):
+    """the adjoint cache of a render of `sd` (larger with material rows: a second footprint per pixel)"""
+    return int(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), int(spp)))
+
+
+def _check_materials(sd, albedo):
+    ms = int(sd.mat_stride) or 3
+    if albedo.dim() != 2 or albedo.shape[1] != ms or albedo.shape[0] < sd.n_shapes:
+        raise ValueError(f"material table {tuple(albedo.shape)} does not match the scene description (n_shapes {sd.n_shapes}, mat_stride {ms})")
+
+
 # ------------------------------------------------------------------ K5..K9
 def camera_struct(to_world, camera_to_sample, near, far, width, height):
     c = _abi.Camera()
@@ -480,9 +491,10 @@ class DeviceGeometry:
         sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
         not zero (a pattern optimiser's case), dark footprints are skipped."""
         H, W = sd.cam.height, sd.cam.width
+        _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         if cache is not None:
-            if cache.numel() < render_cache_bytes(W, H, spp):
+            if cache.numel() < render_cache_bytes_sd(sd, spp):
                 raise ValueError("cache tensor too small")
             with self._timed("render_fwd"):
                 self._call(
@@ -504,6 +516,7 @@ class DeviceGeometry:
         """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
         `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
+        _check_materials(sd, albedo)
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
                        _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx))
@@ -511,6 +524,7 @@ class DeviceGeometry:
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
+        _check_materials(sd, albedo)
         with self._timed("render_bwd"):
             self._call(
                 "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),

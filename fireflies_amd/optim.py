@@ -182,7 +182,7 @@ class PatternOptimizer:
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
             use_cache = Fn.cache_supported(sd, self.spp)
-            nbytes = ops.render_cache_bytes(sd.cam.width, sd.cam.height, self.spp) if use_cache else 0
+            nbytes = ops.render_cache_bytes_sd(sd, self.spp) if use_cache else 0
             if use_cache and (self._cache is None or self._cache.numel() != nbytes):
                 self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero

@@ -26,7 +26,7 @@ def camera_from_sensor(s, to_world=None):
 
 
 def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shadows=True, cam_to_world=None, proj_to_world=None,
-               spot_to_world=None, spot_intensity=None):
+               spot_to_world=None, spot_intensity=None, mat_stride=0):
     """ffx_scene_desc for a scenes.SceneData.  `color` is the RGB weight of a 1-channel projector
     texture (the reference packs the laser texture into the green channel,
     examples/vocalfold_scene.py:64-67)."""
@@ -34,6 +34,7 @@ def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shad
     sd.cam = camera_from_sensor(scene.camera, cam_to_world)
     sd.shadows = int(bool(shadows))
     sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
+    sd.mat_stride = int(mat_stride)  # 0 / 3: the material table is [S,3] Lambert albedos; 16: material rows (scenes.material_rows)
     if scene.projector is not None:
         p = scene.projector
         sd.proj.to_world = _m16(p.to_world if proj_to_world is None else proj_to_world)

@@ -54,6 +54,7 @@ class MeshData:
     tris: np.ndarray  # [F,3] int32, mesh-local
     albedo: tuple = (0.8, 0.8, 0.8)
     material: str = "mat-Default"
+    bsdf: dict = None  # None: diffuse (Lambert); a dict: Mitsuba `principled` parameters by name (missing ones take PRINCIPLED_DEFAULTS)
 
 
 @dataclass
@@ -230,6 +231,45 @@ def colon(width=1024, height=1024, tex=1024, n_around=256, n_along=1024):
     proj = SensorData("PerspectiveCamera_1", look_at((0.2, 0.0, 0.3), (0.35, 0.0, 3.0)), 60.0, 0.01, 100.0, tex, tex)
     spot = SpotData("emit-Spot", look_at((0.0, 0.1, 0.3), (0.35, 0.0, 3.0)), (6.0, 6.0, 6.0), 60.0, 45.0)
     return SceneData([MeshData("mesh-Colon", verts[None], tris, (0.85, 0.45, 0.40))], cam, proj, spot, projector_scale=6.0, notes={"config": "colon"})
+
+
+# ----------------------------------------------------------------------------- materials
+# Mitsuba 3.5 `principled` plugin defaults [EXT: plugin documentation]; `specular` is converted to `eta` the way the plugin does
+PRINCIPLED_DEFAULTS = {"roughness": 0.5, "anisotropic": 0.0, "metallic": 0.0, "spec_trans": 0.0, "specular": 0.5, "spec_tint": 0.0, "sheen": 0.0,
+                       "sheen_tint": 0.0, "flatness": 0.0, "clearcoat": 0.0, "clearcoat_gloss": 0.0}
+# column of each parameter in a material row (include/ffx.h FFX_MAT_*)
+MAT_STRIDE = 16
+MAT_COLUMN = {"model": 3, "roughness": 4, "anisotropic": 5, "metallic": 6, "spec_trans": 7, "eta": 8, "spec_tint": 9, "sheen": 10, "sheen_tint": 11,
+              "flatness": 12, "clearcoat": 13, "clearcoat_gloss": 14}
+
+
+def specular_to_eta(specular):
+    """eta = 2 / (1 - sqrt(0.08 specular)) - 1  [EXT: principled.cpp constructor / parameters_changed]"""
+    return 2.0 / (1.0 - float(np.sqrt(0.08 * float(specular)))) - 1.0
+
+
+def material_row(albedo, bsdf):
+    """one row of the material table (include/ffx.h): [base_color(3), model, roughness, ..., clearcoat_gloss, 0]"""
+    row = np.zeros(MAT_STRIDE, np.float32)
+    row[0:3] = albedo
+    if bsdf is None:
+        row[MAT_COLUMN["eta"]] = 1.0
+        return row
+    p = dict(PRINCIPLED_DEFAULTS)
+    p.update({k: v for k, v in bsdf.items() if k != "eta"})
+    row[MAT_COLUMN["model"]] = 1.0
+    for k, col in MAT_COLUMN.items():
+        if k in p:
+            row[col] = float(p[k])
+    row[MAT_COLUMN["eta"]] = float(bsdf["eta"]) if "eta" in bsdf and "specular" not in bsdf else specular_to_eta(p["specular"])
+    return row
+
+
+def material_rows(scene):
+    """[S,16] material rows, or None if every mesh is diffuse (the renderer then takes the [S,3] albedo table)"""
+    if all(m.bsdf is None for m in scene.meshes):
+        return None
+    return np.stack([material_row(m.albedo, m.bsdf) for m in scene.meshes]).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------- flattening

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 2
+#define FFX_ABI_VERSION 3
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -311,8 +311,8 @@ int ffx_trace_rays(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
  * Replaces mi.render(scene, spp=...) (examples/vocalfold_scene.py:102, main.py:156) and its
  * Dr.Jit backward w.r.t. `tex.data` (examples/vocalfold_scene.py:69).  Shading model
  * (DESIGN.md §4): direct illumination at the primary hit from two delta emitters
- * (projector with irradiance texture, spot light), Lambert BSDF per shape, optional shadow
- * rays, box reconstruction filter, counter-based per-sample jitter.
+ * (projector with irradiance texture, spot light), Lambert or principled BSDF per shape, optional
+ * shadow rays, box reconstruction filter, counter-based per-sample jitter.
  * The render is linear in the texture, so the adjoint needs no forward state: it replays
  * the same samples (same seed) and scatters d(loss)/d(img) through the bilinear weights.
  * ---------------------------------------------------------------------------------------- */
@@ -336,17 +336,47 @@ typedef struct ffx_scene_desc {
   ffx_camera cam;
   ffx_projector proj;
   ffx_spot spot;
-  int32_t shadows;  /* trace shadow rays toward both emitters */
-  int32_t n_shapes; /* rows of shape_albedo */
+  int32_t shadows;    /* trace shadow rays toward both emitters */
+  int32_t n_shapes;   /* rows of shape_albedo */
+  int32_t mat_stride; /* floats per row of shape_albedo: 0 or 3 = Lambert albedo only, FFX_MAT_STRIDE = material rows (below) */
 } ffx_scene_desc;
 
+/* Material rows (mat_stride == FFX_MAT_STRIDE): shape_albedo is then [n_shapes, 16] floats.  Model 1 is the reflection
+ * side of Mitsuba 3.5's `principled` BSDF [EXT: src/bsdfs/principled.cpp eval(), principledhelpers.h,
+ * microfacet.h — Burley 2012/2015; not in /root/reference], evaluated for the two delta emitters:
+ *   value = F_principled D G / (4 cos_i)                       GGX (ax, ay from roughness, anisotropic), Smith G,
+ *                                                              F = (1-m)(1-tint) F_dielectric(eta) + m Schlick(base) + (1-m) tint Schlick(base/lum R0(eta))
+ *         + clearcoat/4 Schlick(0.04) GTR1(lerp(.1,.001,gloss)) G_ggx(0.25) cos_o
+ *         + (1-m)(1-spec_trans) base/pi cos_o lerp(f_diff + f_retro, f_ss, flatness)
+ *         + (1-m) sheen Schlick_w(cos_d) lerp(1, base/lum, sheen_tint) cos_o
+ * in a frame (s, t, n) with n the geometric normal faced to the viewer (two-sided, as the Blender exporter wraps
+ * every material) and (s, t) = Mitsuba's coordinate_system(n) (meshes carry no uv tangents here).  The transmission
+ * lobe of spec_trans is not evaluated (the emitters are on the viewer's side of an opaque surface); spec_trans only
+ * scales the diffuse lobe, as in the reference.  `eta` is what Mitsuba derives from `specular`:
+ * eta = 2 / (1 - sqrt(0.08 specular)) - 1  (specular 0 -> eta 1: no specular lobe at all, as in Mitsuba).
+ * The render stays linear in the texture and affine in base_color, so the adjoint keeps its form. */
+#define FFX_MAT_STRIDE 16
+#define FFX_MAT_BASE_COLOR 0      /* 3 floats; the Lambert albedo for model 0 */
+#define FFX_MAT_MODEL 3           /* 0.0 = Lambert (base_color / pi), 1.0 = principled */
+#define FFX_MAT_ROUGHNESS 4
+#define FFX_MAT_ANISOTROPIC 5
+#define FFX_MAT_METALLIC 6
+#define FFX_MAT_SPEC_TRANS 7
+#define FFX_MAT_ETA 8
+#define FFX_MAT_SPEC_TINT 9
+#define FFX_MAT_SHEEN 10
+#define FFX_MAT_SHEEN_TINT 11
+#define FFX_MAT_FLATNESS 12
+#define FFX_MAT_CLEARCOAT 13
+#define FFX_MAT_CLEARCOAT_GLOSS 14 /* 15: reserved, 0 */
+
 int ffx_render_fwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
-                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                    const float *tex /*[dev][tex_h,tex_w,tex_channels]*/, int spp, uint32_t seed,
                    int img_fp16, void *img /*[dev][H,W,3] fp32 or fp16*/, ffx_stream stream);
 /* gtex is ACCUMULATED into (the caller zeroes it). */
 int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
-                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                   const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                    int spp, uint32_t seed, const float *gimg /*[dev][H,W,3] fp32*/,
                    float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 
@@ -369,12 +399,15 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                                        produced the texture (rasterization.py:583-607): samples whose four bilinear taps are all exactly
                                        zero are then neither shadow-traced nor cached.  The image is the same; gtex at zero-valued texels
                                        is unspecified.  The oracle ignores the bit (it always computes the full gradient). */
-size_t ffx_render_cache_bytes(int width, int height, int spp);
+size_t ffx_render_cache_bytes(int width, int height, int spp); /* Lambert scenes (mat_stride 0 / 3) */
+/* the same for any scene: with material rows the cache holds a second footprint per pixel (the part of the BSDF
+ * that does not scale with base_color): 67.1 MB at 512x512x64 */
+size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd /*[host]*/, int spp);
 int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
-                         const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+                         const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                          const float *tex /*[dev]*/, int spp, uint32_t seed, int img_fp16,
                          void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes*/, ffx_stream stream);
-int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3]*/,
+int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 

@@ -969,6 +969,7 @@ typedef struct {
   /* spot */
   int spot_on; float s_w2l[16]; v3 s_pos; float s_int[3]; float cos_cut, cos_beam, cutoff, inv_trans;
   int shadows;
+  const float *mats; int mat_stride; /* material rows (include/ffx.h) */
 } shade_ctx;
 
 static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
@@ -976,6 +977,9 @@ static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
   c->proj_on = sd->proj.enabled;
   c->spot_on = sd->spot.enabled;
   c->shadows = sd->shadows;
+  c->mats = NULL;
+  c->mat_stride = sd->mat_stride ? sd->mat_stride : 3;
+  if (c->mat_stride != 3 && c->mat_stride != FFX_MAT_STRIDE) return 0;
   if (c->proj_on) {
     if (!inv4(sd->proj.to_world, c->p_w2l)) return 0;
     memcpy(c->p_c2s, sd->proj.camera_to_sample, sizeof c->p_c2s);
@@ -1002,17 +1006,146 @@ static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* -----------------------------------------------------------------------------------------
+ * BSDF of a material row (include/ffx.h FFX_MAT_*), evaluated for the viewer direction wv and the emitter
+ * direction wl (unit, world space) at a surface with unit normal n facing the viewer:
+ *     pi * f(wv, wl) * cos_o  =  base_color * A + B          (per colour channel; A, B scalars)
+ * Model 0: Lambert, A = cos_o, B = 0.  Model 1: Mitsuba 3.5 `principled`, reflection side [EXT: principled.cpp
+ * eval(); principledhelpers.h schlick_weight / calc_schlick / schlick_R0_eta / principled_fresnel / GTR1Isotropic /
+ * smith_ggx1 / clearcoat_G / calc_dist_params; microfacet.h GGX eval + smith_g1; fresnel.h fresnel();
+ * vector.h coordinate_system — restated from the published model (Burley 2012/2015), sources not in /root/reference;
+ * parity unpinned, cross-checked by tests/ref_bruteforce.py].  Reference call sites that set these parameters:
+ * main.py:97-107, examples/vocalfold_scene.py:86-93.
+ * ----------------------------------------------------------------------------------------- */
+#define FFX_PI 3.14159265358979323846f
+static inline float sqrf(float x) { return x * x; }
+static inline float schlick_weight(float c) {
+  float m = 1.0f - c;
+  m = m < 0.f ? 0.f : (m > 1.f ? 1.f : m);
+  return sqrf(sqrf(m)) * m;
+}
+static inline float smith_g1_aniso(v3 v, v3 wh, float ax, float ay) { /* microfacet.h smith_g1 */
+  float xy = sqrf(ax * v.x) + sqrf(ay * v.y);
+  float tan2 = xy / sqrf(v.z);
+  float r = 2.0f / (1.0f + sqrtf(1.0f + tan2));
+  if (xy == 0.f) r = 1.f;
+  if (vdot(v, wh) * v.z <= 0.f) r = 0.f;
+  return r;
+}
+static inline float smith_ggx1(v3 v, v3 wh, float alpha) { /* principledhelpers.h smith_ggx1 */
+  float a2 = sqrf(alpha), c = fabsf(v.z), c2 = sqrf(c);
+  float tan2 = (1.0f - c2) / c2;
+  float r = 2.0f / (1.0f + sqrtf(1.0f + a2 * tan2));
+  if (v.z == 1.f) r = 1.f;
+  if (vdot(v, wh) * v.z <= 0.f) r = 0.f;
+  return r;
+}
+static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, float *A, float *B) {
+  const float cos_i = vdot(n, wv), cos_o = vdot(n, wl);
+  *A = 0.f; *B = 0.f;
+  if (mat_stride != FFX_MAT_STRIDE || m[FFX_MAT_MODEL] == 0.f) { *A = cos_o; return; } /* Lambert: pi * (1/pi) * cos_o */
+  if (!(cos_i > 0.f && cos_o > 0.f)) return;
+  const float rough = m[FFX_MAT_ROUGHNESS], aniso = m[FFX_MAT_ANISOTROPIC], metallic = m[FFX_MAT_METALLIC], spec_trans = m[FFX_MAT_SPEC_TRANS];
+  const float eta = m[FFX_MAT_ETA], spec_tint = m[FFX_MAT_SPEC_TINT], sheen = m[FFX_MAT_SHEEN], sheen_tint = m[FFX_MAT_SHEEN_TINT];
+  const float flat = m[FFX_MAT_FLATNESS], cc = m[FFX_MAT_CLEARCOAT], ccg = m[FFX_MAT_CLEARCOAT_GLOSS];
+  const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
+  const float brdf = (1.0f - metallic) * (1.0f - spec_trans);
+  /* shading frame: coordinate_system(n) (Duff et al.) */
+  const float sg = copysignf(1.0f, n.z), ca = -1.0f / (sg + n.z), cb = n.x * n.y * ca;
+  const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+  const v3 wi = V3(vdot(wv, fs), vdot(wv, ft), cos_i), wo = V3(vdot(wl, fs), vdot(wl, ft), cos_o);
+  v3 wh = V3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z);
+  const float ihl = 1.0f / sqrtf(vdot(wh, wh));
+  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
+  const float ci_h = vdot(wi, wh), co_h = vdot(wo, wh);
+  const int facing = ci_h * cos_i > 0.f && co_h * cos_o > 0.f;
+  /* calc_dist_params */
+  const float r2 = sqrf(rough), aspect = sqrtf(1.0f - 0.9f * aniso);
+  const float ax = fmaxf(0.001f, r2 / aspect), ay = fmaxf(0.001f, r2 * aspect);
+  /* Schlick weight as calc_schlick takes it (cos >= 0: outside) */
+  float sw;
+  if (eta > 1.0f) sw = schlick_weight(fabsf(ci_h));
+  else {
+    float ct2 = 1.0f - (1.0f - ci_h * ci_h) * sqrf(1.0f / eta);
+    sw = schlick_weight(ct2 > 0.f ? sqrtf(ct2) : 0.f);
+  }
+  float a = 0.f, b = 0.f; /* f * cos_o split, without the pi */
+  /* dielectric Fresnel (fresnel.h) */
+  float F_d;
+  {
+    const float eta_ti = 1.0f / eta;
+    const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * (eta_ti * eta_ti);
+    const float c = fabsf(ci_h), ct = ct2 > 0.f ? sqrtf(ct2) : 0.f;
+    const float a_s = (c - eta * ct) / (c + eta * ct), a_p = (ct - eta * c) / (ct + eta * c);
+    F_d = 0.5f * (a_s * a_s + a_p * a_p);
+    if (eta == 1.0f) F_d = 0.f;
+    else if (c == 0.f) F_d = 1.f;
+  }
+  if (facing && F_d > 0.f) { /* main specular reflection lobe */
+    const float tmp = sqrf(wh.x / ax) + sqrf(wh.y / ay) + sqrf(wh.z);
+    float D = 1.0f / (FFX_PI * (ax * ay) * sqrf(tmp));
+    if (!(D * wh.z > 1e-20f)) D = 0.f;
+    const float G = smith_g1_aniso(wi, wh, ax, ay) * smith_g1_aniso(wo, wh, ax, ay);
+    const float common = D * G / (4.0f * cos_i);
+    const float R0 = sqrf((eta - 1.0f) / (eta + 1.0f));
+    float Fa = metallic * (1.0f - sw), Fb = metallic * sw;
+    if (lum > 0.f) Fa += (1.0f - metallic) * spec_tint * (R0 / lum) * (1.0f - sw);
+    else Fb += (1.0f - metallic) * spec_tint * R0 * (1.0f - sw);
+    Fb += (1.0f - metallic) * spec_tint * sw + (1.0f - metallic) * (1.0f - spec_tint) * F_d;
+    a += Fa * common;
+    b += Fb * common;
+  }
+  if (cc > 0.f && facing) { /* clearcoat */
+    const float Fcc = sw + (1.0f - sw) * 0.04f;
+    const float alpha = 0.1f + (0.001f - 0.1f) * ccg, a2 = sqrf(alpha), c2 = sqrf(wh.z);
+    float Dcc = (a2 - 1.0f) / (FFX_PI * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
+    if (!(Dcc * wh.z > 1e-20f)) Dcc = 0.f;
+    const float Gcc = smith_ggx1(wi, wh, 0.25f) * smith_ggx1(wo, wh, 0.25f);
+    b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
+  }
+  const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);
+  if (brdf > 0.f) { /* diffuse + retro-reflection (+ fake subsurface) */
+    const float f_diff = (1.0f - 0.5f * Fi) * (1.0f - 0.5f * Fo);
+    const float Rr = 2.0f * rough * sqrf(co_h);
+    const float f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0f));
+    float dterm = f_diff + f_retro;
+    if (flat > 0.f) {
+      const float Fss90 = Rr / 2.0f;
+      const float Fss = (1.0f + (Fss90 - 1.0f) * Fo) * (1.0f + (Fss90 - 1.0f) * Fi);
+      const float f_ss = 1.25f * (Fss * (1.0f / (cos_o + cos_i) - 0.5f) + 0.5f);
+      dterm = dterm + (f_ss - dterm) * flat;
+    }
+    a += brdf * cos_o * 0.3183098861837907f * dterm;
+  }
+  if (sheen > 0.f && 1.0f - metallic > 0.f) {
+    const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
+    if (lum > 0.f) { a += sv * sheen_tint / lum; b += sv * (1.0f - sheen_tint); }
+    else b += sv;
+  }
+  *A = a * FFX_PI;
+  *B = b * FFX_PI;
+}
+
+/* test hook (not part of include/ffx.h): material_eval for `count` direction triples */
+int ffx_oracle_material_eval(const float *row, int mat_stride, const float *n, const float *wv, const float *wl, int count, float *ab) {
+  for (int i = 0; i < count; ++i)
+    material_eval(row, mat_stride, V3(n[3 * i], n[3 * i + 1], n[3 * i + 2]), V3(wv[3 * i], wv[3 * i + 1], wv[3 * i + 2]),
+                  V3(wl[3 * i], wl[3 * i + 1], wl[3 * i + 2]), &ab[2 * i], &ab[2 * i + 1]);
+  return FFX_OK;
+}
+
 /* per-sample shading terms: projector texel footprint (4 bilinear taps with weights) and the
  * scalar factor multiplying the texture value, plus the spot contribution. */
-typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, uby; float wx[2], wy[2]; float proj_fac; float spot_rgb[3]; } sample_terms;
+typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, uby; float wx[2], wy[2]; float proj_fac, proj_fac_b; float spot_rgb[3], spot_rgb_b[3]; } sample_terms; /* _b: the part that does not scale with base_color */
 
 static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *recs, v3 o, v3 d, float nt, float ft, sample_terms *st) {
   hit_t h;
   closest_hit(nodes, recs, o, d, nt, ft, 1, &h);
   st->hit = h.prim >= 0;
   st->has_proj = 0;
-  st->proj_fac = 0.f;
+  st->proj_fac = 0.f; st->proj_fac_b = 0.f;
   st->spot_rgb[0] = st->spot_rgb[1] = st->spot_rgb[2] = 0.f;
+  st->spot_rgb_b[0] = st->spot_rgb_b[1] = st->spot_rgb_b[2] = 0.f;
   st->shape = h.shape;
   if (!st->hit) return;
   const orec *r = &recs[h.slot];
@@ -1050,7 +1183,10 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
           if (vis) {
             /* irradiance texture * pi*scale / (z_l^2 * cos_p) [EXT Mitsuba projector], Lambert
                albedo/pi * cos_s: pi cancels */
-            st->proj_fac = (c->p_scale / (pl.z * pl.z * cos_p)) * cos_s;
+            float bA, bB;
+            material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ng, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+            st->proj_fac = (c->p_scale / (pl.z * pl.z * cos_p)) * bA; /* Lambert: bA = cos_s */
+            st->proj_fac_b = (c->p_scale / (pl.z * pl.z * cos_p)) * bB;
             float fx = fmaf(u, (float)c->tw, -0.5f), fy = fmaf(v, (float)c->th, -0.5f);
             float x0 = floorf(fx), y0 = floorf(fy);
             float ax = fx - x0, ay = fy - y0;
@@ -1086,8 +1222,11 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         int vis = 1;
         if (c->shadows) vis = !occluded(nodes, recs, c->s_pos, vsub(Po, c->s_pos), 0.f, 1.0f - SHADOW_EPS);
         if (vis) {
-          float f = fall * cos_s / d2 * 0.3183098861837907f; /* Lambert 1/pi */
-          for (int ch = 0; ch < 3; ++ch) st->spot_rgb[ch] = c->s_int[ch] * f;
+          float bA, bB;
+          material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ng, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+          float f = fall * bA / d2 * 0.3183098861837907f; /* Lambert: bA = cos_s, 1/pi */
+          float fb = fall * bB / d2 * 0.3183098861837907f;
+          for (int ch = 0; ch < 3; ++ch) { st->spot_rgb[ch] = c->s_int[ch] * f; st->spot_rgb_b[ch] = c->s_int[ch] * fb; }
         }
       }
     }
@@ -1118,7 +1257,7 @@ static inline uint16_t f32_to_f16(float f) {
   return h;
 }
 
-typedef struct { uint32_t w0; float ax, ay, fac; } crec; /* per-sample cache record, include/ffx.h */
+typedef struct { uint32_t w0; float ax, ay, fac, fac_b; uint32_t pad; } crec; /* per-sample cache record (the oracle's own format), include/ffx.h */
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                            uint32_t seed, int img_fp16, void *img, crec *cache) {
@@ -1126,6 +1265,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
+  c.mats = shape_albedo;
   const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
   const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
   int W = c.cam.W, H = c.cam.H;
@@ -1145,15 +1285,16 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
       if (cache) {
         crec *cr = &cache[idx];
-        cr->w0 = 0; cr->ax = 0.f; cr->ay = 0.f; cr->fac = 0.f;
+        cr->w0 = 0; cr->ax = 0.f; cr->ay = 0.f; cr->fac = 0.f; cr->fac_b = 0.f; cr->pad = 0;
         if (st.hit && st.has_proj) {
           cr->w0 = (uint32_t)(st.ubx + 1) | ((uint32_t)(st.uby + 1) << 12) | ((uint32_t)st.shape << 24);
-          cr->ax = st.wx[1]; cr->ay = st.wy[1]; cr->fac = st.proj_fac;
+          cr->ax = st.wx[1]; cr->ay = st.wy[1]; cr->fac = st.proj_fac; cr->fac_b = st.proj_fac_b;
         }
       }
       if (!st.hit) continue;
-      const float *alb = shape_albedo + 3 * st.shape;
+      const float *alb = shape_albedo + (size_t)c.mat_stride * st.shape;
       float rgb[3] = {st.spot_rgb[0], st.spot_rgb[1], st.spot_rgb[2]};
+      float rgb_b[3] = {st.spot_rgb_b[0], st.spot_rgb_b[1], st.spot_rgb_b[2]};
       if (st.has_proj) {
         for (int ch = 0; ch < 3; ++ch) {
           int tch = (c.tc == 3) ? ch : 0;
@@ -1162,9 +1303,11 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
           float tv = st.wy[0] * (st.wx[0] * t00 + st.wx[1] * t01) + st.wy[1] * (st.wx[0] * t10 + st.wx[1] * t11);
           float col = (c.tc == 3) ? 1.0f : c.p_color[ch];
           rgb[ch] += tv * col * st.proj_fac;
+          rgb_b[ch] += tv * col * st.proj_fac_b;
         }
       }
-      for (int ch = 0; ch < 3; ++ch) acc[ch] += alb[ch] * rgb[ch];
+      if (c.mat_stride == 3) for (int ch = 0; ch < 3; ++ch) acc[ch] += alb[ch] * rgb[ch];
+      else for (int ch = 0; ch < 3; ++ch) acc[ch] += alb[ch] * rgb[ch] + rgb_b[ch];
     }
     for (int ch = 0; ch < 3; ++ch) {
       float v = acc[ch] * inv_spp;
@@ -1181,7 +1324,8 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, NULL);
 }
 
-size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * 16; }
+size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * sizeof(crec); }
+size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) { return sd ? ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp) : 0; }
 
 int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
@@ -1197,21 +1341,26 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   if (!sd->proj.enabled) return FFX_OK;
   int W = sd->cam.width, H = sd->cam.height, tw = sd->proj.tex_w, th = sd->proj.tex_h, tc = sd->proj.tex_channels;
   const crec *cr = (const crec *)cache;
+  const int ms = sd->mat_stride ? sd->mat_stride : 3;
   float inv_spp = 1.0f / (float)spp;
   size_t nt_ = (size_t)tw * th * tc;
   double *acc = (double *)calloc(nt_, sizeof(double));
   for (long idx = 0; idx < (long)W * H * spp; ++idx) {
     const crec *r = &cr[idx];
-    if (r->fac == 0.f) continue;
+    if (r->fac == 0.f && r->fac_b == 0.f) continue;
     const float *g = gimg + (size_t)(idx / spp) * 3;
     int ix0 = (int)(r->w0 & 0xfffu) - 1, iy0 = (int)((r->w0 >> 12) & 0xfffu) - 1, shape = (int)(r->w0 >> 24);
     int ix[2] = {clampi(ix0, 0, tw - 1), clampi(ix0 + 1, 0, tw - 1)}, iy[2] = {clampi(iy0, 0, th - 1), clampi(iy0 + 1, 0, th - 1)};
     float wx[2] = {1.0f - r->ax, r->ax}, wy[2] = {1.0f - r->ay, r->ay};
-    const float *alb = shape_albedo + 3 * shape;
+    const float *alb = shape_albedo + (size_t)ms * shape;
     for (int tch = 0; tch < tc; ++tch) {
       float wsum;
       if (tc == 3) wsum = g[tch] * alb[tch] * r->fac * inv_spp;
       else wsum = (g[0] * alb[0] * sd->proj.color[0] + g[1] * alb[1] * sd->proj.color[1] + g[2] * alb[2] * sd->proj.color[2]) * r->fac * inv_spp;
+      if (r->fac_b != 0.f) { /* the part of the BSDF that does not scale with base_color */
+        if (tc == 3) wsum += g[tch] * r->fac_b * inv_spp;
+        else wsum += (g[0] * sd->proj.color[0] + g[1] * sd->proj.color[1] + g[2] * sd->proj.color[2]) * r->fac_b * inv_spp;
+      }
       for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) acc[((size_t)iy[a] * tw + ix[b]) * tc + tch] += (double)(wsum * wy[a] * wx[b]);
     }
@@ -1228,6 +1377,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if (!sd->proj.enabled) return FFX_OK;
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
+  c.mats = shape_albedo;
   const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
   const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
   int W = c.cam.W, H = c.cam.H;
@@ -1249,11 +1399,15 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
       sample_terms st;
       shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
       if (!st.hit || !st.has_proj) continue;
-      const float *alb = shape_albedo + 3 * st.shape;
+      const float *alb = shape_albedo + (size_t)c.mat_stride * st.shape;
       for (int tch = 0; tch < c.tc; ++tch) {
         float wsum;
         if (c.tc == 3) wsum = g[tch] * alb[tch] * st.proj_fac * inv_spp;
         else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
+        if (st.proj_fac_b != 0.f) {
+          if (c.tc == 3) wsum += g[tch] * st.proj_fac_b * inv_spp;
+          else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * st.proj_fac_b * inv_spp;
+        }
         for (int a = 0; a < 2; ++a)
           for (int b = 0; b < 2; ++b) acc[((size_t)st.iy[a] * c.tw + st.ix[b]) * c.tc + tch] += (double)(wsum * st.wy[a] * st.wx[b]);
       }

@@ -250,7 +250,7 @@ class Geometry:
         albedo, tex = _f32(albedo), _f32(tex)
         H, W = sd.cam.height, sd.cam.width
         img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
-        cache = np.zeros(api().lib.ffx_render_cache_bytes(W, H, spp), np.uint8)
+        cache = np.zeros(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), spp), np.uint8)
         api().call("ffx_render_fwd_cache", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(cache), None)
         return img, cache
 

@@ -22,6 +22,9 @@ What is restated (each with the convention it comes from):
     * cos_s with falloff 1 inside beam_width and linear in the ANGLE down to 0 at the cutoff; shadow rays from
     the emitter to the surface point lifted by (1 + max|P|) * 1500 * 2^-24 along the normal, occluded by any hit at
     0 < t < 1 - 10 * 1500 * 2^-24; box reconstruction filter (plain mean over the samples).
+  * materials: rows of 3 floats are Lambert albedos; rows of 16 floats (include/ffx.h FFX_MAT_*) with model 1 are
+    Mitsuba's `principled` BSDF, written here from the structure of its eval() (Burley 2012 / 2015 and the Mitsuba 3
+    documentation of the plugin) as RGB arithmetic lobe by lobe — not as the oracle's "base_color * A + B" split.
   * adjoint: the render is linear in the texture, so d loss / d tex scatters gimg * albedo * colour * geometric
     factor / spp through the four bilinear weights.
 """
@@ -123,8 +126,115 @@ def _bilinear_setup(u, v, tw, th):
     return (xi0, xi1, yi0, yi1), ((1 - ay) * (1 - ax), (1 - ay) * ax, ay * (1 - ax), ay * ax)
 
 
-def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed):
-    """per sample: hit mask, shape id, projector taps / weights / factor, spot radiance (before albedo)"""
+def _schlick_w(c):
+    return np.clip(1.0 - c, 0.0, 1.0) ** 5
+
+
+def _fresnel_dielectric(c, eta):
+    """unpolarised Fresnel reflectance for a ray arriving from outside (cos >= 0) at relative index eta"""
+    st2 = (1.0 - c * c) / (eta * eta)
+    ct = np.sqrt(np.maximum(1.0 - st2, 0.0))
+    c = np.abs(c)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rs = (c - eta * ct) / (c + eta * ct)
+        rp = (ct - eta * c) / (ct + eta * c)
+    F = 0.5 * (rs * rs + rp * rp)
+    F = np.where(c == 0.0, 1.0, F)
+    return np.where(eta == 1.0, 0.0, F), ct
+
+
+def _onb(n):
+    """Duff et al. 2017, 'Building an Orthonormal Basis, Revisited' (what Mitsuba's coordinate_system uses)"""
+    sg = np.copysign(1.0, n[:, 2])
+    a = -1.0 / (sg + n[:, 2])
+    b = n[:, 0] * n[:, 1] * a
+    s = np.stack([1.0 + sg * n[:, 0] ** 2 * a, sg * b, -sg * n[:, 0]], 1)
+    t = np.stack([b, sg + n[:, 1] ** 2 * a, -n[:, 1]], 1)
+    return s, t
+
+
+def bsdf_cos(rows, n, wv, wl):
+    """f(wv, wl) * cos_o per colour channel, [N,3].  rows [N,3] (Lambert albedo) or [N,16] (material rows)."""
+    rows = np.asarray(rows, np.float64)
+    cos_i, cos_o = (n * wv).sum(1), (n * wl).sum(1)
+    base = rows[:, :3]
+    lambert = base / np.pi * np.maximum(cos_o, 0.0)[:, None]
+    if rows.shape[1] == 3:
+        return lambert
+    model, rough, aniso, metallic, spec_trans, eta, spec_tint, sheen, sheen_tint, flat, cc, ccg = (rows[:, k] for k in range(3, 15))
+    front = (cos_i > 0) & (cos_o > 0)
+    s, t = _onb(n)
+    wi = np.stack([(wv * s).sum(1), (wv * t).sum(1), cos_i], 1)
+    wo = np.stack([(wl * s).sum(1), (wl * t).sum(1), cos_o], 1)
+    wh = wi + wo
+    wh = wh / np.linalg.norm(wh, axis=1, keepdims=True)
+    ih, oh = (wi * wh).sum(1), (wo * wh).sum(1)
+    facing = (ih * cos_i > 0) & (oh * cos_o > 0)
+    lum = base @ np.array([0.212671, 0.715160, 0.072169])
+    tint = np.where((lum > 0)[:, None], base / np.where(lum > 0, lum, 1.0)[:, None], 1.0)
+    value = np.zeros_like(base)
+    # ---- specular reflection: GGX (anisotropic), separable Smith, principled Fresnel
+    aspect = np.sqrt(1.0 - 0.9 * aniso)
+    ax, ay = np.maximum(0.001, rough**2 / aspect), np.maximum(0.001, rough**2 * aspect)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        D = 1.0 / (np.pi * ax * ay * ((wh[:, 0] / ax) ** 2 + (wh[:, 1] / ay) ** 2 + wh[:, 2] ** 2) ** 2)
+        D = np.where(D * wh[:, 2] > 1e-20, D, 0.0)
+
+        def g1(v):
+            xy = (ax * v[:, 0]) ** 2 + (ay * v[:, 1]) ** 2
+            r = 2.0 / (1.0 + np.sqrt(1.0 + xy / v[:, 2] ** 2))
+            r = np.where(xy == 0, 1.0, r)
+            return np.where((v * wh).sum(1) * v[:, 2] <= 0, 0.0, r)
+
+        G = g1(wi) * g1(wo)
+        F_d, cos_t = _fresnel_dielectric(ih, eta)
+        # Schlick weight the way the plugin's Schlick helper picks its cosine: the incident one for eta > 1, else the transmitted
+        sw = np.where(eta > 1.0, _schlick_w(np.abs(ih)), _schlick_w(cos_t))[:, None]
+        R0 = ((eta - 1.0) / (eta + 1.0)) ** 2
+        F_metal = base + (1.0 - base) * sw
+        F0t = tint * R0[:, None]
+        F_tint = F0t + (1.0 - F0t) * sw
+        F = ((1 - metallic) * (1 - spec_tint) * F_d)[:, None] + metallic[:, None] * F_metal + ((1 - metallic) * spec_tint)[:, None] * F_tint
+        spec = F * (D * G / (4.0 * np.abs(cos_i)))[:, None]
+    value += np.where((front & facing & (F_d > 0))[:, None], spec, 0.0)
+    # ---- clearcoat: GTR1, Schlick with R0 = 0.04, GGX G with alpha 0.25
+    with np.errstate(divide="ignore", invalid="ignore"):
+        alpha = 0.1 + (0.001 - 0.1) * ccg
+        a2 = alpha**2
+        Dcc = (a2 - 1.0) / (np.pi * np.log(a2) * (1.0 + (a2 - 1.0) * wh[:, 2] ** 2))
+        Dcc = np.where(Dcc * wh[:, 2] > 1e-20, Dcc, 0.0)
+
+        def g1c(v):
+            c2 = v[:, 2] ** 2
+            r = 2.0 / (1.0 + np.sqrt(1.0 + 0.25**2 * (1.0 - c2) / c2))
+            r = np.where(v[:, 2] == 1.0, 1.0, r)
+            return np.where((v * wh).sum(1) * v[:, 2] <= 0, 0.0, r)
+
+        Fcc = 0.04 + (1.0 - 0.04) * sw[:, 0]
+        coat = cc * 0.25 * Fcc * Dcc * g1c(wi) * g1c(wo) * np.abs(cos_o)
+    value += np.where((front & facing & (cc > 0))[:, None], coat[:, None], 0.0)
+    # ---- diffuse with retro-reflection, flattened toward the Hanrahan-Krueger fake subsurface term
+    brdf = (1 - metallic) * (1 - spec_trans)
+    Fo, Fi = _schlick_w(np.abs(cos_o)), _schlick_w(np.abs(cos_i))
+    f_diff = (1 - 0.5 * Fi) * (1 - 0.5 * Fo)
+    Rr = 2.0 * rough * oh**2
+    f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0))
+    Fss90 = Rr / 2.0
+    Fss = (1 + (Fss90 - 1) * Fo) * (1 + (Fss90 - 1) * Fi)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f_ss = 1.25 * (Fss * (1.0 / (np.abs(cos_o) + np.abs(cos_i)) - 0.5) + 0.5)
+    dterm = (1 - flat) * (f_diff + f_retro) + flat * np.where(flat > 0, f_ss, 0.0)
+    value += np.where((front & (brdf > 0))[:, None], (brdf * np.abs(cos_o) / np.pi * dterm)[:, None] * base, 0.0)
+    # ---- sheen
+    c_sheen = (1 - sheen_tint)[:, None] + sheen_tint[:, None] * tint
+    sh = (sheen * (1 - metallic) * _schlick_w(np.abs(oh)) * np.abs(cos_o))[:, None] * c_sheen
+    value += np.where((front & (sheen > 0) & (1 - metallic > 0))[:, None], sh, 0.0)
+    return np.where((model != 0)[:, None], value, lambert)
+
+
+def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
+    """per sample: hit mask, shape id, projector taps / weights / rgb factor (irradiance scale x BSDF x cos), spot radiance"""
+    mats = np.asarray(mats, np.float64)
     tris = world_triangles(verts, tri_idx)
     v0, e1, e2 = tris
     o, d, nt, ft = camera_rays(sd.cam, spp, True, seed)
@@ -139,7 +249,8 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed):
     n = np.where(((n * d).sum(1) > 0)[:, None], -n, n)
     Po = P + n * ((1.0 + np.abs(P).max(1)) * EPS)[:, None]
     shape = np.where(hit, np.asarray(tri_shape)[pr], -1)
-    out = {"hit": hit, "shape": shape, "pfac": np.zeros(len(P)), "taps": None, "w": None, "spot": np.zeros((len(P), 3))}
+    out = {"hit": hit, "shape": shape, "pfac": np.zeros((len(P), 3)), "taps": None, "w": None, "spot": np.zeros((len(P), 3))}
+    rows = mats[np.maximum(shape, 0)]
     if sd.proj.enabled:
         tw = _m(sd.proj.to_world, 4)
         w2l = np.linalg.inv(tw)
@@ -159,8 +270,9 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed):
             occ = any_hit(np.broadcast_to(ppos, (len(sel), 3)), Po[sel] - ppos, tris, 1.0 - 10.0 * EPS)
             lit[sel[occ]] = False
         with np.errstate(divide="ignore", invalid="ignore"):
-            fac = sd.proj.scale / (pl[:, 2] ** 2 * cos_p) * cos_s
-        out["pfac"] = np.where(lit, fac, 0.0)
+            fac = np.pi * sd.proj.scale / (pl[:, 2] ** 2 * cos_p)  # irradiance scale of the projector (its pi is Lambert's 1/pi)
+            fac = fac[:, None] * bsdf_cos(rows, n, -d, wi)
+        out["pfac"] = np.where(lit[:, None], fac, 0.0)
         out["taps"], out["w"] = _bilinear_setup(np.where(lit, u, 0.5), np.where(lit, v, 0.5), sd.proj.tex_w, sd.proj.tex_h)
     if sd.spot.enabled:
         tw = _m(sd.spot.to_world, 4)
@@ -180,13 +292,13 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed):
             occ = any_hit(np.broadcast_to(spos, (len(sel), 3)), Po[sel] - spos, tris, 1.0 - 10.0 * EPS)
             lit[sel[occ]] = False
         with np.errstate(divide="ignore", invalid="ignore"):
-            f = np.where(lit, fall * cos_s / d2 / np.pi, 0.0)
-        out["spot"] = f[:, None] * np.asarray(list(sd.spot.intensity), np.float64)[None]
+            f = np.where(lit[:, None], (fall / d2)[:, None] * bsdf_cos(rows, n, -d, wi), 0.0)
+        out["spot"] = f * np.asarray(list(sd.spot.intensity), np.float64)[None]
     return out
 
 
 def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed):
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed)
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo)
     W, H = sd.cam.width, sd.cam.height
     rad = s["spot"].copy()
     if sd.proj.enabled:
@@ -195,21 +307,19 @@ def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed):
         if tex.ndim == 2 or tex.shape[-1] == 1:
             t2 = tex.reshape(tex.shape[0], tex.shape[1])
             tv = w00 * t2[y0, x0] + w01 * t2[y0, x1] + w10 * t2[y1, x0] + w11 * t2[y1, x1]
-            rad += (tv * s["pfac"])[:, None] * np.asarray(list(sd.proj.color), np.float64)[None]
+            rad += tv[:, None] * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]
         else:
             tv = w00[:, None] * tex[y0, x0] + w01[:, None] * tex[y0, x1] + w10[:, None] * tex[y1, x0] + w11[:, None] * tex[y1, x1]
-            rad += tv * s["pfac"][:, None]
-    alb = np.asarray(albedo, np.float64)[np.maximum(s["shape"], 0)]
-    rad = np.where(s["hit"][:, None], rad * alb, 0.0)
+            rad += tv * s["pfac"]
+    rad = np.where(s["hit"][:, None], rad, 0.0)
     return rad.reshape(H, W, spp, 3).mean(2)
 
 
 def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg):
     """d <img, gimg> / d tex for a 1-channel texture"""
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed)
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo)
     g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
-    alb = np.asarray(albedo, np.float64)[np.maximum(s["shape"], 0)]
-    ws = (g * alb * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) * s["pfac"] / spp
+    ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) / spp
     ws = np.where(s["hit"], ws, 0.0)
     gt = np.zeros((sd.proj.tex_h, sd.proj.tex_w))
     (x0, x1, y0, y1), (w00, w01, w10, w11) = s["taps"], s["w"]

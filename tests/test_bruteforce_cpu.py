@@ -2,10 +2,12 @@
 float64 brute-force restatement (tests/ref_bruteforce.py: no BVH, textbook Moller-Trumbore, written from
 SURVEY App. A / DESIGN §4 and not from the oracle's source).  Removes the "same author, same mistake" hole between
 the oracle and the HIP kernels; it cannot replace Mitsuba."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
-from fireflies_amd import scene_desc, scenes
+from fireflies_amd import _abi, scene_desc, scenes
 from tests import ref_bruteforce as bf
 
 
@@ -87,3 +89,138 @@ def test_oracle_agrees_with_an_independent_bruteforce_restatement(oracle, which)
         lhs = float(((img_b - base) * gimg).sum())
         rhs = float((tex.astype(np.float64) * gt_b).sum())
         assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1e-12)
+
+
+def material_rows(S, seed, model=1.0, **fixed):
+    """random principled material rows [S,16] over the ranges the reference randomises (main.py:97-107)"""
+    rng = np.random.default_rng(seed)
+    m = np.zeros((S, _abi.MAT_STRIDE), np.float32)
+    m[:, 0:3] = rng.uniform(0.1, 0.9, (S, 3))
+    m[:, _abi.MAT_MODEL] = model
+    m[:, _abi.MAT_ROUGHNESS] = rng.uniform(0.05, 1.0, S)
+    m[:, _abi.MAT_ANISOTROPIC] = rng.uniform(0.0, 1.0, S)
+    m[:, _abi.MAT_METALLIC] = rng.uniform(0.0, 0.5, S)
+    m[:, _abi.MAT_SPEC_TRANS] = rng.uniform(0.0, 0.4, S)
+    specular = rng.uniform(0.05, 1.0, S)
+    m[:, _abi.MAT_ETA] = 2.0 / (1.0 - np.sqrt(0.08 * specular)) - 1.0
+    m[:, _abi.MAT_SPEC_TINT] = rng.uniform(0.0, 1.0, S)
+    m[:, _abi.MAT_SHEEN] = rng.uniform(0.0, 0.5, S)
+    m[:, _abi.MAT_SHEEN_TINT] = rng.uniform(0.0, 1.0, S)
+    m[:, _abi.MAT_FLATNESS] = rng.uniform(0.0, 1.0, S)
+    m[:, _abi.MAT_CLEARCOAT] = rng.uniform(0.0, 1.0, S)
+    m[:, _abi.MAT_CLEARCOAT_GLOSS] = rng.uniform(0.0, 1.0, S)
+    for k, v in fixed.items():
+        m[:, getattr(_abi, "MAT_" + k.upper())] = v
+    return m
+
+
+def _oracle_material_eval(oracle, row, n, wv, wl):
+    fn = oracle.api().lib.ffx_oracle_material_eval
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 1 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    row = np.ascontiguousarray(row, np.float32)
+    n, wv, wl = (np.ascontiguousarray(a, np.float32) for a in (n, wv, wl))
+    ab = np.zeros((n.shape[0], 2), np.float32)
+    assert fn(row.ctypes.data, row.size, n.ctypes.data, wv.ctypes.data, wl.ctypes.data, n.shape[0], ab.ctypes.data) == 0
+    return ab
+
+
+def _dirs(k, seed):
+    rng = np.random.default_rng(seed)
+    n = rng.standard_normal((k, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+
+    def hemi():
+        v = rng.standard_normal((k, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        c = (v * n).sum(1, keepdims=True)
+        v = np.where(c < 0, v - 2 * c * n, v)  # mirrored into the normal's hemisphere
+        return v
+
+    return n.astype(np.float32), hemi().astype(np.float32), hemi().astype(np.float32)
+
+
+def test_principled_bsdf_closed_forms(oracle):
+    """known answers of the principled model at normal incidence and its energy-free limits"""
+    n = np.array([[0.0, 0.0, 1.0]], np.float32)
+    # wi = wo = n: Schlick weights vanish -> diffuse lobe is exactly Lambert's base/pi; the GGX lobe is F0 / (4 pi alpha^2)
+    rough, specular = 0.5, 0.5
+    eta = 2.0 / (1.0 - np.sqrt(0.08 * specular)) - 1.0  # 1.5
+    row = material_rows(1, 0, roughness=rough, anisotropic=0.0, metallic=0.0, spec_trans=0.0, eta=eta, spec_tint=0.0, sheen=0.0, sheen_tint=0.0,
+                        flatness=0.0, clearcoat=0.0, clearcoat_gloss=0.0)[0]
+    ab = _oracle_material_eval(oracle, row, n, n, n)[0]
+    F0 = ((eta - 1) / (eta + 1)) ** 2
+    assert ab[0] == pytest.approx(1.0, rel=1e-6)  # pi * (1/pi) * cos
+    assert ab[1] == pytest.approx(np.pi * F0 / (4 * np.pi * rough**4), rel=1e-5)
+    # specular = 0 -> eta = 1: no specular lobe at all (index-matched), whatever the roughness
+    row0 = row.copy()
+    row0[_abi.MAT_ETA] = 1.0
+    nn, wv, wl = _dirs(64, 1)
+    ab0 = _oracle_material_eval(oracle, row0, nn, wv, wl)
+    assert np.all(ab0[:, 1] == 0)
+    # metallic = 1 kills diffuse and sheen: A carries only base * (1 - Schlick weight) of the metal's Fresnel term
+    rowm = row.copy()
+    rowm[_abi.MAT_METALLIC] = 1.0
+    abm = _oracle_material_eval(oracle, rowm, n, n, n)[0]
+    assert abm[0] == pytest.approx(np.pi / (4 * np.pi * rough**4), rel=1e-5) and abs(abm[1]) < 1e-7
+    # Lambert rows and 3-float rows: A = cos_o, B = 0
+    lam = material_rows(1, 0, model=0.0)[0]
+    abl = _oracle_material_eval(oracle, lam, nn, wv, wl)
+    np.testing.assert_allclose(abl[:, 0], (nn * wl).sum(1), rtol=1e-6, atol=1e-7)
+    assert np.all(abl[:, 1] == 0)
+    # below the horizon on either side: nothing
+    down = -n
+    assert np.all(_oracle_material_eval(oracle, row, n, n, down) == 0) and np.all(_oracle_material_eval(oracle, row, n, down, n) == 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_principled_bsdf_matches_the_rgb_restatement(oracle, seed):
+    """base_color * A + B of the oracle against the lobe-by-lobe RGB evaluation of tests/ref_bruteforce.py (float64)"""
+    k = 4000
+    n, wv, wl = _dirs(k, 10 + seed)
+    fixed = [{}, {"anisotropic": 0.0, "clearcoat": 0.0, "sheen": 0.0, "flatness": 0.0, "spec_tint": 0.0},
+             {"metallic": 0.0, "spec_trans": 0.0}, {"eta": 1.0}][seed]
+    row = material_rows(1, seed, **fixed)[0]
+    ab = _oracle_material_eval(oracle, row, n, wv, wl).astype(np.float64)
+    got = (row[None, :3].astype(np.float64) * ab[:, :1] + ab[:, 1:2]) / np.pi
+    want = bf.bsdf_cos(np.repeat(row[None].astype(np.float64), k, 0), n.astype(np.float64), wv.astype(np.float64), wl.astype(np.float64))
+    assert want.max() > 0.05
+    np.testing.assert_allclose(got, want, rtol=3e-4, atol=1e-6)
+
+
+def test_oracle_render_with_principled_materials_agrees_with_bruteforce(oracle):
+    sc, spp, frame = scenes.vocalfold(width=24, height=24, tex=32, frames=3, n_fold=12, tube=(12, 16)), 4, 1
+    xf = _xf(len(sc.meshes), 3)
+    pool, tris, shape, off, offs, xf, alb, verts, gidx = _world(sc, frame, xf)
+    go = oracle.Geometry(pool, tris, shape, off)
+    go.update(xf, offs)
+    mats = material_rows(len(sc.meshes), 7)
+    mats[-1, _abi.MAT_MODEL] = 0.0  # one Lambert shape among the principled ones
+    rng = np.random.default_rng(1)
+    tex = rng.random((sc.projector.height, sc.projector.width)).astype(np.float32)
+    for shadows in (True, False):
+        sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=shadows)
+        sd.mat_stride = _abi.MAT_STRIDE
+        img_o = go.render_fwd(sd, mats, tex, spp, seed=9)
+        img_b = bf.render_fwd(verts, gidx, shape, sd, mats, tex, spp, 9)
+        scale = float(img_b.max())
+        err = np.abs(img_o - img_b)
+        assert scale > 0.01
+        assert (err > 5e-4 * scale).mean() <= 1e-2 and err.max() <= 1.5 * scale / spp
+        assert abs(float(img_o.mean()) - float(img_b.mean())) <= 2e-3 * float(img_b.mean())
+    # the Lambert image differs: the materials do something
+    sd3 = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    assert np.abs(go.render_fwd(sd3, mats[:, :3].copy(), tex, spp, seed=9) - img_b).max() > 0.02 * scale
+    # K9 (replay and cached) with material rows
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    sd.mat_stride = _abi.MAT_STRIDE
+    gimg = rng.standard_normal((sc.camera.height, sc.camera.width, 3)).astype(np.float32)
+    gt_o = go.render_bwd(sd, mats, spp, 9, gimg)[..., 0]
+    gt_b = bf.render_bwd(verts, gidx, shape, sd, mats, spp, 9, gimg)
+    gs = float(np.abs(gt_b).max())
+    gerr = np.abs(gt_o - gt_b)
+    assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-2 and gerr.max() <= 0.5 * gs
+    img_c, cache = go.render_fwd_cache(sd, mats, tex, spp, seed=9)
+    np.testing.assert_array_equal(img_c, go.render_fwd(sd, mats, tex, spp, seed=9))
+    gt_c = go.render_bwd_cached(sd, mats, cache, spp, gimg)[..., 0]
+    np.testing.assert_allclose(gt_c, gt_o, rtol=1e-5, atol=1e-6 * gs)

@@ -769,3 +769,60 @@ def test_sparse_adjoint_agrees_where_the_texture_is_not_zero(oracle):
     np.testing.assert_allclose(sp[~zero], full[~zero], rtol=0, atol=1e-3 * scale)  # ... the sparse one agrees everywhere else
     g_o = go.render_bwd(sd, alb, 16, 2, host(gimg))[..., 0]
     np.testing.assert_allclose(sp[~zero], g_o[~zero], rtol=0, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("env", [{}, {"FFX_WIDE": "0"}, {"FFX_TRAVERSAL": "lane"}])
+@pytest.mark.parametrize("ch", [1, 3])
+def test_principled_materials_match_the_oracle(oracle, env, ch, monkeypatch):
+    """material rows (include/ffx.h FFX_MAT_*: Mitsuba's `principled` BSDF, reflection side) through every render entry
+    point: forward, re-tracing adjoint, cache-writing forward + cached adjoint (second footprint), fp16 film; one shape
+    stays Lambert.  The oracle's BSDF itself is pinned by tests/test_bruteforce_cpu.py."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    for k in ("FFX_TRAVERSAL", "FFX_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    xf = _rand_xforms(2, 5)
+    go, gd, alb = _pair(oracle, sc, frame=2, xforms=xf)
+    rng = np.random.default_rng(0)
+    gimg = rng.standard_normal((44, 52, 3)).astype(np.float32)
+    tex = _tex(sc, ch)
+    for trial, fixed in enumerate(({}, {"anisotropic": 0.0, "clearcoat": 0.0, "sheen": 0.0, "flatness": 0.0, "metallic": 0.0, "spec_trans": 0.0, "spec_tint": 0.0})):
+        mats = material_rows(2, 11 + trial, **fixed)
+        if trial == 0:
+            mats[0, 3] = 0.0  # a Lambert shape among principled ones
+        for shadows, spp in ((True, 9), (False, 70)):
+            sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=shadows, mat_stride=16)
+            img_o = go.render_fwd(sd, mats, host(tex), spp, seed=3)
+            img_d = host(gd.render_fwd(sd, dev(mats), tex, spp, seed=3))
+            scale, _ = _assert_image_close(img_d, img_o, spp, frac=1e-3, rel=2e-4, what=f"{env} materials")
+            assert scale > 0.02
+            # not the Lambert image
+            sd3 = scene_desc.scene_desc(sc, tex_channels=ch, shadows=shadows)
+            assert np.abs(host(gd.render_fwd(sd3, dev(mats[:, :3].copy()), tex, spp, seed=3)) - img_d).max() > 0.02 * scale
+            g_o = go.render_bwd(sd, mats, spp, 3, gimg)
+            g_d = host(gd.render_bwd(sd, dev(mats), spp, 3, dev(gimg)))
+            gs = float(np.abs(g_o).max())
+            gerr = np.abs(g_d - g_o)
+            assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs
+            # cache-writing forward: same image, cached adjoint = re-tracing adjoint
+            nbytes = ops.render_cache_bytes_sd(sd, spp)
+            assert nbytes > ops.render_cache_bytes(52, 44, spp) + 112 * 52 * 44 - 128
+            cache = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            img_c = gd.render_fwd(sd, dev(mats), tex, spp, seed=3, cache=cache)
+            torch.testing.assert_close(img_c, torch.from_numpy(img_d).cuda(), rtol=1e-4, atol=1e-5 * scale)
+            hdr = host(cache[:12]).view(np.uint32)
+            assert hdr[2] == 0 and hdr[0] <= hdr[1]
+            g_c = host(gd.render_bwd_cached(sd, dev(mats), cache, spp, dev(gimg)))
+            cerr = np.abs(g_c - g_o)
+            assert (cerr > 1e-3 * gs).mean() <= 1e-3 and cerr.max() <= 0.1 * gs
+        # fp16 film
+        sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=16)
+        h_d = host(gd.render_fwd(sd, dev(mats), tex, 9, seed=3, fp16=True)).astype(np.float32)
+        h_o = go.render_fwd(sd, mats, host(tex), 9, seed=3, fp16=True).astype(np.float32)
+        _assert_image_close(h_d, h_o, 9, frac=2e-3, rel=2e-3, what="fp16 materials")
+    # a material table that does not match the scene description is refused
+    with pytest.raises(ValueError):
+        gd.render_fwd(scene_desc.scene_desc(sc, tex_channels=ch, mat_stride=16), dev(alb), tex, 4)
