@@ -240,6 +240,9 @@ def main():
                     help="vocalfold = BASELINE configs[1]/[2] (the metric's configuration); colon = configs[4] "
                          "(use --res 1024 --spp 256 --grid 32 --fp16)")
     ap.add_argument("--fp16", action="store_true", help="fp16 radiance buffer (config 5)")
+    ap.add_argument("--material", default="principled", choices=["principled", "diffuse"],
+                    help="principled (default): the scene's material is Mitsuba's principled BSDF whose parameters the reference randomises "
+                         "(examples/vocalfold_scene.py:86-93, main.py:97-107); diffuse: Lambert only")
     ap.add_argument("--entity-device", default="cuda", help="device argument of ff.Scene (where the sampler bounds live and whose generator is used): cuda (the reference default) or cpu")
     args = ap.parse_args()
 
@@ -256,7 +259,7 @@ def main():
 
     # ------------------------------------------------------------------ renders/sec
     make = workloads.vocalfold if args.workload == "vocalfold" else workloads.colon
-    wl = make(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows, entity_device=args.entity_device)
+    wl = make(device=dev, width=W, height=H, grid=args.grid, shadows=not args.no_shadows, entity_device=args.entity_device, principled=args.material == "principled")
     with torch.no_grad():
         tex = workloads.build_texture(wl).contiguous()
     wl.params["tex.data"] = tex
@@ -302,7 +305,7 @@ def main():
     # ------------------------------------------------------------------ pattern-gradient steps/sec
     grad = {}
     if not args.no_grad_steps:
-        wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device)
+        wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device, principled=args.material == "principled")
         S = args.grad_samples if args.grad_samples > 0 else world
         opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=S, base_seed=7)
         gevents = []
@@ -366,6 +369,8 @@ def main():
              f"{'fp16' if args.fp16 else 'fp32'} radiance buffer"),
             "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render [K8]; texture built once before the loop",
             "entity_device": args.entity_device,
+            "material": ("principled BSDF (Mitsuba's model, reflection side), parameters randomised as the reference's scripts do" if args.material == "principled"
+                         else "diffuse (Lambert)"),
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
         },

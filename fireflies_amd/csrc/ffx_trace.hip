@@ -280,106 +280,151 @@ __device__ __forceinline__ float sqrt_nr(float x) {
 }
 
 // BSDF of a material row (include/ffx.h FFX_MAT_*, model 1: the reflection side of Mitsuba's `principled`), for the
-// viewer direction wv and the emitter direction wl at a surface with unit normal n facing the viewer:
+// viewer direction wv and an emitter direction wl at a surface with unit normal n facing the viewer:
 //     pi * f(wv, wl) * cos_o = base_color * A + B   per colour channel.
-// Same formulas, in the same order, as material_eval of oracle/ffx_oracle.c (which cites the model's sources);
-// quotients and roots through the Newton-refined hardware seeds above.  The caller handles model 0 (A = cos_o).
+// The model is material_eval of oracle/ffx_oracle.c (which cites its sources), arranged for the kernel:
+//   * what depends on the material and the viewer only (MatCtx) is prepared once per sample and shared by both emitters;
+//   * Smith's G1 is taken as 2 c / (c + sqrt(c^2 + xy)) (= 2 / (1 + sqrt(1 + xy / c^2))), so the specular lobe
+//     D G / (4 cos_i) collapses to D cos_o / ((cos_i + s_i)(cos_o + s_o)): one quotient instead of five;
+//   * an isotropic material (anisotropic = 0, the plugin's default) needs no tangent frame at all;
+//   * quotients and roots are the bare hardware seeds (brcp / bdiv / bsqrt below).
+// Equal to the oracle within a few ulp per term (the parity tests state the tolerance).  The caller handles model 0.
 __device__ __forceinline__ float sqrf(float x) { return x * x; }
 __device__ __forceinline__ float schlick_weight(float c) {
   float m = 1.0f - c;
   m = fminf(fmaxf(m, 0.f), 1.f);
   return sqrf(sqrf(m)) * m;
 }
-__device__ __forceinline__ float smith_g1_aniso(v3 v, float v_dot_h, float ax, float ay) {
-  const float xy = sqrf(ax * v.x) + sqrf(ay * v.y);
-  const float tan2 = div_nr(xy, sqrf(v.z));
-  float r = div_nr(2.0f, 1.0f + sqrt_nr(1.0f + tan2));
-  if (xy == 0.f) r = 1.f;
-  if (v_dot_h * v.z <= 0.f) r = 0.f;
-  return r;
-}
-__device__ __forceinline__ float smith_ggx1(v3 v, float v_dot_h, float alpha) {
-  const float a2 = sqrf(alpha), c2 = sqrf(fabsf(v.z));
-  const float tan2 = div_nr(1.0f - c2, c2);
-  float r = div_nr(2.0f, 1.0f + sqrt_nr(1.0f + a2 * tan2));
-  if (v.z == 1.f) r = 1.f;
-  if (v_dot_h * v.z <= 0.f) r = 0.f;
-  return r;
-}
-__device__ __noinline__ void material_eval(const float *__restrict__ m, v3 n, v3 wv, v3 wl, float &A, float &B) {
-  const float cos_i = vdot(n, wv), cos_o = vdot(n, wl);
-  A = 0.f; B = 0.f;
-  if (!(cos_i > 0.f && cos_o > 0.f)) return;
+// reciprocal, quotient and square root inside the BSDF: the bare hardware seeds (1 ulp) — the BSDF scales a sample's
+// radiance, it does not decide what is hit, and the parity tests state its tolerance
+__device__ __forceinline__ float brcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float bdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+struct MatCtx {
+  float cos_i, Fi, s_i;       // viewer side: cosine, Schlick weight, sqrt(cos_i^2 + (ax wi.x)^2 + (ay wi.y)^2)
+  float ax, ay, inv_ax, inv_ay;
+  float rough, metallic, spec_tint, eta, ieta2, R0, tint_a, tint_b; // tint: spec_tint * R0 (/ lum) split into the base_color part and the rest
+  float brdf, flat, cc, cc_a2, sheen_a, sheen_b; // sheen * (1 - metallic) * (tint / lum | 1 - tint)
+  bool aniso;
+  v3 fs, ft, wi; // tangent frame and the viewer in it (anisotropic materials only)
+};
+__device__ __forceinline__ void material_prepare(const float *__restrict__ m, v3 n, v3 wv, MatCtx &k) {
   const float4 m0 = reinterpret_cast<const float4 *>(m)[0], m1 = reinterpret_cast<const float4 *>(m)[1], m2 = reinterpret_cast<const float4 *>(m)[2],
                m3 = reinterpret_cast<const float4 *>(m)[3];
-  const float rough = m1.x, aniso = m1.y, metallic = m1.z, spec_trans = m1.w, eta = m2.x, spec_tint = m2.y, sheen = m2.z, sheen_tint = m2.w;
-  const float flat = m3.x, cc = m3.y, ccg = m3.z;
+  const float aniso = m1.y, spec_trans = m1.w, sheen = m2.z, sheen_tint = m2.w, ccg = m3.z;
+  k.rough = m1.x; k.metallic = m1.z; k.eta = m2.x; k.spec_tint = m2.y; k.flat = m3.x; k.cc = m3.y;
   const float lum = 0.212671f * m0.x + 0.715160f * m0.y + 0.072169f * m0.z;
-  const float brdf = (1.0f - metallic) * (1.0f - spec_trans);
-  // shading frame: coordinate_system(n)
-  const float sg = copysignf(1.0f, n.z), ca = -rcp_nr(sg + n.z), cb = n.x * n.y * ca;
-  const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
-  const v3 wi = V3(vdot(wv, fs), vdot(wv, ft), cos_i), wo = V3(vdot(wl, fs), vdot(wl, ft), cos_o);
-  v3 wh = V3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z);
-  const float ihl = rcp_nr(sqrt_nr(vdot(wh, wh)));
+  const float ilum = lum > 0.f ? brcp(lum) : 0.f;
+  k.brdf = (1.0f - k.metallic) * (1.0f - spec_trans);
+  k.cos_i = vdot(n, wv);
+  k.Fi = schlick_weight(k.cos_i);
+  const float r2 = sqrf(k.rough);
+  k.aniso = aniso != 0.f;
+  float xy;
+  if (k.aniso) {
+    const float aspect = bsqrt(1.0f - 0.9f * aniso);
+    k.ax = fmaxf(0.001f, bdiv(r2, aspect));
+    k.ay = fmaxf(0.001f, r2 * aspect);
+    // shading frame: coordinate_system(n)
+    const float sg = copysignf(1.0f, n.z), ca = -brcp(sg + n.z), cb = n.x * n.y * ca;
+    k.fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x);
+    k.ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+    k.wi = V3(vdot(wv, k.fs), vdot(wv, k.ft), k.cos_i);
+    xy = sqrf(k.ax * k.wi.x) + sqrf(k.ay * k.wi.y);
+  } else {
+    k.ax = k.ay = fmaxf(0.001f, r2);
+    xy = sqrf(k.ax) * fmaxf(1.0f - sqrf(k.cos_i), 0.f);
+  }
+  k.inv_ax = brcp(k.ax);
+  k.inv_ay = k.aniso ? brcp(k.ay) : k.inv_ax;
+  k.s_i = bsqrt(sqrf(k.cos_i) + xy);
+  k.ieta2 = sqrf(brcp(k.eta));
+  k.R0 = sqrf((k.eta - 1.0f) * brcp(k.eta + 1.0f));
+  const float t = (1.0f - k.metallic) * k.spec_tint * k.R0;
+  k.tint_a = lum > 0.f ? t * ilum : 0.f;
+  k.tint_b = lum > 0.f ? 0.f : t;
+  const float sv = sheen * (1.0f - k.metallic);
+  k.sheen_a = lum > 0.f ? sv * sheen_tint * ilum : 0.f;
+  k.sheen_b = lum > 0.f ? sv * (1.0f - sheen_tint) : sv;
+  const float alpha = 0.1f + (0.001f - 0.1f) * ccg;
+  k.cc_a2 = sqrf(alpha);
+}
+__device__ __forceinline__ float ggx1_cc(float c, float c_dot_h) { // smith_ggx1 with alpha = 0.25 (clearcoat)
+  const float c2 = sqrf(c);
+  float r = bdiv(2.0f * c, c + bsqrt(c2 + 0.0625f * (1.0f - c2)));
+  if (c_dot_h * c <= 0.f) r = 0.f;
+  return r;
+}
+__device__ __forceinline__ void material_eval(const MatCtx &k, v3 n, v3 wv, v3 wl, float &A, float &B) {
+  const float cos_i = k.cos_i, cos_o = vdot(n, wl);
+  A = 0.f; B = 0.f;
+  if (!(cos_i > 0.f && cos_o > 0.f)) return;
+  v3 wh = V3(wv.x + wl.x, wv.y + wl.y, wv.z + wl.z); // world space
+  const float ihl = __builtin_amdgcn_rsqf(vdot(wh, wh));
   wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
-  const float ci_h = vdot(wi, wh), co_h = vdot(wo, wh);
-  const bool facing = ci_h * cos_i > 0.f && co_h * cos_o > 0.f;
-  const float r2 = sqrf(rough), aspect = sqrt_nr(1.0f - 0.9f * aniso);
-  const float ax = fmaxf(0.001f, div_nr(r2, aspect)), ay = fmaxf(0.001f, r2 * aspect);
-  const float ieta = rcp_nr(eta);
-  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * sqrf(ieta);
-  const float ct = ct2 > 0.f ? sqrt_nr(ct2) : 0.f; // cosine of the transmitted direction
+  const float ci_h = vdot(wv, wh), co_h = vdot(wl, wh), ch = vdot(n, wh);
+  const bool facing = ci_h > 0.f && co_h > 0.f; // (cos_i, cos_o > 0)
+  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * k.ieta2;
+  const float ct = ct2 > 0.f ? bsqrt(ct2) : 0.f; // cosine of the transmitted direction
+  const float eta = k.eta;
   const float sw = schlick_weight(eta > 1.0f ? fabsf(ci_h) : ct);
   float a = 0.f, b = 0.f;
   float F_d;
   {
     const float c = fabsf(ci_h);
-    const float a_s = div_nr(c - eta * ct, c + eta * ct), a_p = div_nr(ct - eta * c, ct + eta * c);
+    const float ds = c + eta * ct, dp = ct + eta * c, ir = brcp(ds * dp); // one reciprocal for both amplitudes
+    const float a_s = (c - eta * ct) * dp * ir, a_p = (ct - eta * c) * ds * ir;
     F_d = 0.5f * (a_s * a_s + a_p * a_p);
     if (eta == 1.0f) F_d = 0.f;
     else if (c == 0.f) F_d = 1.f;
   }
-  if (facing && F_d > 0.f) { // main specular reflection lobe
-    const float tmp = sqrf(div_nr(wh.x, ax)) + sqrf(div_nr(wh.y, ay)) + sqrf(wh.z);
-    float D = rcp_nr(FFX_PI_F * (ax * ay) * sqrf(tmp));
-    if (!(D * wh.z > 1e-20f)) D = 0.f;
-    const float G = smith_g1_aniso(wi, ci_h, ax, ay) * smith_g1_aniso(wo, co_h, ax, ay);
-    const float common = div_nr(D * G, 4.0f * cos_i);
-    const float R0 = sqrf(div_nr(eta - 1.0f, eta + 1.0f));
-    float Fa = metallic * (1.0f - sw), Fb = metallic * sw;
-    if (lum > 0.f) Fa += (1.0f - metallic) * spec_tint * div_nr(R0, lum) * (1.0f - sw);
-    else Fb += (1.0f - metallic) * spec_tint * R0 * (1.0f - sw);
-    Fb += (1.0f - metallic) * spec_tint * sw + (1.0f - metallic) * (1.0f - spec_tint) * F_d;
+  if (facing && F_d > 0.f) { // main specular reflection lobe: F D G / (4 cos_i)
+    float tmp, xy_o;
+    if (k.aniso) {
+      const float hx = vdot(wh, k.fs), hy = vdot(wh, k.ft), ox = vdot(wl, k.fs), oy = vdot(wl, k.ft);
+      tmp = sqrf(hx * k.inv_ax) + sqrf(hy * k.inv_ay) + sqrf(ch);
+      xy_o = sqrf(k.ax * ox) + sqrf(k.ay * oy);
+    } else {
+      tmp = fmaxf(1.0f - sqrf(ch), 0.f) * sqrf(k.inv_ax) + sqrf(ch);
+      xy_o = sqrf(k.ax) * fmaxf(1.0f - sqrf(cos_o), 0.f);
+    }
+    const float dden = FFX_PI_F * (k.ax * k.ay) * sqrf(tmp);
+    const float s_o = bsqrt(sqrf(cos_o) + xy_o);
+    // D G / (4 cos_i) = cos_o / (dden (cos_i + s_i)(cos_o + s_o))
+    float common = bdiv(cos_o, dden * ((cos_i + k.s_i) * (cos_o + s_o)));
+    if (!(ch > 1e-20f * dden)) common = 0.f; // D * cos_h > 1e-20
+    const float m1 = 1.0f - k.metallic;
+    const float Fa = k.metallic * (1.0f - sw) + k.tint_a * (1.0f - sw);
+    const float Fb = k.metallic * sw + k.tint_b * (1.0f - sw) + m1 * k.spec_tint * sw + m1 * (1.0f - k.spec_tint) * F_d;
     a += Fa * common;
     b += Fb * common;
   }
-  if (cc > 0.f && facing) { // clearcoat
+  if (k.cc > 0.f && facing) { // clearcoat
     const float Fcc = sw + (1.0f - sw) * 0.04f;
-    const float alpha = 0.1f + (0.001f - 0.1f) * ccg, a2 = sqrf(alpha), c2 = sqrf(wh.z);
-    float Dcc = div_nr(a2 - 1.0f, FFX_PI_F * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
-    if (!(Dcc * wh.z > 1e-20f)) Dcc = 0.f;
-    const float Gcc = smith_ggx1(wi, ci_h, 0.25f) * smith_ggx1(wo, co_h, 0.25f);
-    b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
+    const float a2 = k.cc_a2, c2 = sqrf(ch);
+    float Dcc = bdiv(a2 - 1.0f, FFX_PI_F * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
+    if (!(Dcc * ch > 1e-20f)) Dcc = 0.f;
+    const float Gcc = ggx1_cc(cos_i, ci_h) * ggx1_cc(cos_o, co_h);
+    b += k.cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
   }
-  const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);
-  if (brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
+  const float Fo = schlick_weight(cos_o), Fi = k.Fi;
+  if (k.brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
     const float f_diff = (1.0f - 0.5f * Fi) * (1.0f - 0.5f * Fo);
-    const float Rr = 2.0f * rough * sqrf(co_h);
+    const float Rr = 2.0f * k.rough * sqrf(co_h);
     const float f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0f));
     float dterm = f_diff + f_retro;
-    if (flat > 0.f) {
+    if (k.flat > 0.f) {
       const float Fss90 = Rr * 0.5f;
       const float Fss = (1.0f + (Fss90 - 1.0f) * Fo) * (1.0f + (Fss90 - 1.0f) * Fi);
-      const float f_ss = 1.25f * (Fss * (rcp_nr(cos_o + cos_i) - 0.5f) + 0.5f);
-      dterm = dterm + (f_ss - dterm) * flat;
+      const float f_ss = 1.25f * (Fss * (brcp(cos_o + cos_i) - 0.5f) + 0.5f);
+      dterm = dterm + (f_ss - dterm) * k.flat;
     }
-    a += brdf * cos_o * 0.3183098861837907f * dterm;
+    a += k.brdf * cos_o * 0.3183098861837907f * dterm;
   }
-  if (sheen > 0.f && 1.0f - metallic > 0.f) {
-    const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
-    if (lum > 0.f) { a += div_nr(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
-    else b += sv;
+  if (k.sheen_a != 0.f || k.sheen_b != 0.f) {
+    const float sv = schlick_weight(fabsf(co_h)) * cos_o;
+    a += sv * k.sheen_a;
+    b += sv * k.sheen_b;
   }
   A = a * FFX_PI_F;
   B = b * FFX_PI_F;
@@ -445,8 +490,11 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           }
           if (vis) {
             float bA = cos_s, bB = 0.f; // Lambert; material rows: pi f cos = base_color * bA + bB
-            if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f)
-              material_eval(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+            if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
+              MatCtx mk;
+              material_prepare(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), mk);
+              material_eval(mk, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+            }
             st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * bA;
             st.proj_fac_b = (c.p_scale / (pl.z * pl.z * cos_p)) * bB;
             float fx = fmaf(u, (float)c.tw, -0.5f), fy = fmaf(v, (float)c.th, -0.5f);
@@ -488,8 +536,11 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         }
         if (vis) {
           float bA = cos_s, bB = 0.f;
-          if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f)
-            material_eval(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+          if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
+            MatCtx mk;
+            material_prepare(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), mk);
+            material_eval(mk, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+          }
           float f = fall * bA / d2 * 0.3183098861837907f, fb = fall * bB / d2 * 0.3183098861837907f;
           st.spot[0] = c.s_int[0] * f;
           st.spot[1] = c.s_int[1] * f;
@@ -1624,6 +1675,18 @@ __device__ __forceinline__ const ShadeK &kernarg_shade() {
   return *(const ShadeK *)p;
 }
 
+// whether any of the four texels of the bilinear footprint at (u, v) is non-zero (same texel arithmetic as the footprint phase)
+__device__ __forceinline__ bool tex_footprint_lit(const float *__restrict__ tex, int tw, int th, int tc, float u, float v) {
+  const float fx = fmaf(u, (float)tw, -0.5f), fy = fmaf(v, (float)th, -0.5f);
+  const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
+  const int x0 = clampi(ix0, 0, tw - 1), x1 = clampi(ix0 + 1, 0, tw - 1), y0 = clampi(iy0, 0, th - 1), y1 = clampi(iy0 + 1, 0, th - 1);
+  float m = 0.f;
+  for (int ch = 0; ch < tc; ++ch)
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(tex[((size_t)y0 * tw + x0) * tc + ch]), fabsf(tex[((size_t)y0 * tw + x1) * tc + ch])),
+                       fmaxf(fabsf(tex[((size_t)y1 * tw + x0) * tc + ch]), fabsf(tex[((size_t)y1 * tw + x1) * tc + ch]))));
+  return m > 0.f; // (NaN texels: fmaxf drops them — as before, a NaN next to zeros reads as dark)
+}
+
 template <int R, bool WIDE, bool MAT = false>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
@@ -1674,13 +1737,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     q.pfac = 0.f; q.u = 0.f; q.v = 0.f;
     q.pfac_b = 0.f; q.sfac_b = 0.f;
     // material rows (MAT): pi f cos = base_color * bA + bB per emitter (material_eval); Lambert: bA = cos_s, bB = 0
-    const float *mrow = nullptr;
-    if constexpr (MAT) {
-      if (q.ok) {
-        mrow = c.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
-        if (mrow[FFX_MAT_MODEL] == 0.f) mrow = nullptr;
-      }
-    }
+    // (MAT: the BSDF is evaluated AFTER the shadow walks, for the samples the emitters reach — there the walk's registers
+    // are free; before the walks only the geometric factors are formed, and P, ng stay live across them)
     if (c.proj_on && q.ok) {
       v3 pl = xf_point(c.p_w2l, q.P);
       if (pl.z > 0.f) {
@@ -1699,14 +1757,15 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float cos_s = vdot(q.ng, wi);
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
-          if (cos_s > 0.f && cos_p > 0.f) {
+          bool lit = cos_s > 0.f && cos_p > 0.f;
+          if constexpr (MAT) {
+            // (material rows: the texture probe — see below — comes first, it saves the BSDF of a dark footprint too)
+            if (tex_probe && lit) lit = tex_footprint_lit(tex_probe, c.tw, c.th, c.tc, q.u, q.v);
+          }
+          if (lit) {
             q.need_p = true;
             if constexpr (MAT) {
-              float bA = cos_s, bB = 0.f;
-              if (mrow) material_eval(mrow, q.ng, V3(-d[r].x, -d[r].y, -d[r].z), wi, bA, bB);
-              const float e = div_nr(c.p_scale, pl.z * pl.z * cos_p);
-              q.pfac = e * bA;
-              q.pfac_b = e * bB;
+              q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p); // x (bA, bB) after the walks
             } else {
               q.pfac = div_nr(c.p_scale, pl.z * pl.z * cos_p) * cos_s;
             }
@@ -1734,10 +1793,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         if (fall > 0.f) {
           q.need_s = true;
           if constexpr (MAT) {
-            float bA = cos_s, bB = 0.f;
-            if (mrow) material_eval(mrow, q.ng, V3(-d[r].x, -d[r].y, -d[r].z), wi, bA, bB);
-            q.sfac = div_nr(fall * bA, d2) * 0.3183098861837907f;
-            q.sfac_b = div_nr(fall * bB, d2) * 0.3183098861837907f;
+            q.sfac = div_nr(fall, d2) * 0.3183098861837907f; // x (bA, bB) after the walks
           } else {
             q.sfac = div_nr(fall * cos_s, d2) * 0.3183098861837907f;
           }
@@ -1748,16 +1804,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     // nothing: if the four texels of the sample's bilinear footprint are all exactly zero — most of a dot pattern is —
     // its contribution is zero whatever the walk finds.  (The cache-writing forward keeps every walk: the ADJOINT of a
     // dark texel is not zero.)  Same texel arithmetic as the footprint phase below.
-    if (tex_probe && q.need_p) {
-      const float fx = fmaf(q.u, (float)c.tw, -0.5f), fy = fmaf(q.v, (float)c.th, -0.5f);
-      const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
-      const int x0 = clampi(ix0, 0, c.tw - 1), x1 = clampi(ix0 + 1, 0, c.tw - 1), y0 = clampi(iy0, 0, c.th - 1), y1 = clampi(iy0 + 1, 0, c.th - 1);
-      const int tc = c.tc;
-      float m = 0.f;
-      for (int ch = 0; ch < tc; ++ch)
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(tex_probe[((size_t)y0 * c.tw + x0) * tc + ch]), fabsf(tex_probe[((size_t)y0 * c.tw + x1) * tc + ch])),
-                           fmaxf(fabsf(tex_probe[((size_t)y1 * c.tw + x0) * tc + ch]), fabsf(tex_probe[((size_t)y1 * c.tw + x1) * tc + ch]))));
-      if (!(m > 0.f)) q.need_p = false; // (NaN texels keep their walk)
+    if constexpr (!MAT) {
+      if (tex_probe && q.need_p) q.need_p = tex_footprint_lit(tex_probe, c.tw, c.th, c.tc, q.u, q.v);
     }
     any_p |= q.need_p;
     any_s |= q.need_s;
@@ -1792,7 +1840,36 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const ShadePre &q = pre[r];
+    ShadePre &q = pre[r];
+    if constexpr (MAT) {
+      // BSDF of the samples an emitter reaches: pi f cos = base_color * bA + bB (material_eval); Lambert rows: bA = cos_s
+      const bool lit_p = q.need_p && !occ_p[r], lit_s = q.need_s && !occ_s[r];
+      if (lit_p || lit_s) {
+        const float *mrow = c2.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
+        const bool mat_on = mrow[FFX_MAT_MODEL] != 0.f;
+        const v3 wv = V3(-d[r].x, -d[r].y, -d[r].z);
+        MatCtx mk;
+        if (mat_on) material_prepare(mrow, q.ng, wv, mk);
+        if (lit_p) {
+          v3 wi = vsub(V3(c2.p_pos[0], c2.p_pos[1], c2.p_pos[2]), q.P);
+          const float idist = rcp_nr(sqrt_nr(vdot(wi, wi)));
+          wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
+          float bA = vdot(q.ng, wi), bB = 0.f;
+          if (mat_on) material_eval(mk, q.ng, wv, wi, bA, bB);
+          q.pfac_b = q.pfac * bB;
+          q.pfac = q.pfac * bA;
+        }
+        if (lit_s) {
+          v3 wi = vsub(V3(c2.s_pos[0], c2.s_pos[1], c2.s_pos[2]), q.P);
+          const float idist = rcp_nr(sqrt_nr(vdot(wi, wi)));
+          wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
+          float bA = vdot(q.ng, wi), bB = 0.f;
+          if (mat_on) material_eval(mk, q.ng, wv, wi, bA, bB);
+          q.sfac_b = q.sfac * bB;
+          q.sfac = q.sfac * bA;
+        }
+      }
+    }
     if (q.need_p && !occ_p[r]) {
       st[r].proj_fac = q.pfac;
       if constexpr (MAT) st[r].proj_fac_b = q.pfac_b;
@@ -1936,7 +2013,9 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
   return (cache_off_arena(n_pix) + sizeof(CacheStray) * cap_stray + 127) & ~(size_t)127;
 }
 
+#ifndef FFX_PK_MAT_WAVES
 #define FFX_PK_MAT_WAVES 4 // material rows: the BSDF terms need registers (see DESIGN.md 5.1 on occupancy)
+#endif
 template <int R, bool WIDE, bool MAT>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,

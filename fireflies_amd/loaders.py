@@ -7,7 +7,7 @@ module reads what those scene files contain so that `mi.load_file(path)` keeps w
 
   <sensor type="perspective">   fov, near_clip, far_clip, <transform name="to_world">, <film> width/height
   <shape type="obj"|"ply">       filename (Wavefront OBJ; Stanford PLY ascii / binary), optional to_world (baked into the vertices),
-                                 nested or referenced <bsdf> (diffuse reflectance / principled base_color)
+                                 nested or referenced <bsdf>: diffuse reflectance, or principled with its scalar parameters (scenes.PRINCIPLED_DEFAULTS)
   <emitter type="spot">          intensity, cutoff_angle, beam_width, to_world
   <emitter type="projector">     irradiance texture (id "tex"), scale, fov, to_world
   <transform>                    <matrix value="16 floats">, <lookat origin target up>, <translate>, <scale>,
@@ -253,21 +253,28 @@ def _child(node, tag, name=None):
 
 
 def _albedo_of(bsdf, bsdfs):
+    """-> (base colour, material id, principled parameters or None for a diffuse material)"""
     if bsdf is None:
-        return (0.5, 0.5, 0.5), "mat-Default"
+        return (0.5, 0.5, 0.5), "mat-Default", None
     if bsdf.tag == "ref":
         ref = bsdfs.get(bsdf.get("id"))
         if ref is None:
             raise ValueError(f"unknown bsdf reference {bsdf.get('id')}")
-        return _albedo_of(ref, bsdfs)[0], bsdf.get("id")
+        col, _, params = _albedo_of(ref, bsdfs)
+        return col, bsdf.get("id"), params
     inner = bsdf
     while inner.get("type") in ("twosided", "bumpmap", "normalmap", "mask") and _child(inner, "bsdf") is not None:
         inner = _child(inner, "bsdf")
     p = _props(inner)
     col = p.get("reflectance", p.get("base_color", p.get("diffuse_reflectance", (0.5, 0.5, 0.5))))
-    if inner.get("type") not in ("diffuse", "principled"):
+    if isinstance(col, float):
+        col = (col,) * 3
+    params = None
+    if inner.get("type") == "principled":  # the plugin's scalar parameters (textures are not read); `eta` only without `specular`
+        params = {k: float(p[k]) for k in list(scenes.PRINCIPLED_DEFAULTS) + ["eta"] if isinstance(p.get(k), (int, float))}
+    elif inner.get("type") != "diffuse":
         warnings.warn(f"bsdf type {inner.get('type')!r} is rendered as Lambert with its base colour (DESIGN.md §4.3)")
-    return tuple(col), bsdf.get("id") or "mat-Default"
+    return tuple(col), bsdf.get("id") or "mat-Default", params
 
 
 def load_mitsuba_xml(path):
@@ -299,8 +306,8 @@ def load_mitsuba_xml(path):
             v, t = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]))
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
-            alb, mat = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
-            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat))
+            alb, mat, bsdf = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
+            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat, bsdf))
         elif node.tag == "emitter":
             p = _props(node)
             tw = _transform(_child(node, "transform", "to_world"))

@@ -188,8 +188,11 @@ def _fold_lip(side, phase, n=96, R=1.25, z0=5.0, half_len=1.15, g0=0.28):
     return verts, tris
 
 
-def vocalfold(width=512, height=512, tex=500, frames=50, n_fold=96, tube=(64, 128)):
-    """cfg2-4: F = 2*tube[0]*tube[1] + 2 * 2*n_fold^2 = 16384 + 36864 = 53248 triangles."""
+def vocalfold(width=512, height=512, tex=500, frames=50, n_fold=96, tube=(64, 128), principled=True):
+    """cfg2-4: F = 2*tube[0]*tube[1] + 2 * 2*n_fold^2 = 16384 + 36864 = 53248 triangles.
+    The material is a principled BSDF with the plugin's defaults, like the reference's "mat-Default OBJ" whose
+    `brdf_0.specular` examples/vocalfold_scene.py:93 randomises (principled=False: diffuse)."""
+    bsdf = {} if principled else None
     lar_v, lar_t = _tube(tube[0], tube[1], 0.8, 7.5, lambda t, z: 1.25 + 0.08 * np.sin(3 * t) * np.sin(1.3 * z) + 0.05 * np.cos(2.1 * z))
     fold_frames = []
     for k in range(frames):
@@ -203,16 +206,17 @@ def vocalfold(width=512, height=512, tex=500, frames=50, n_fold=96, tube=(64, 12
     spot = SpotData("emit-Spot", look_at((0.0, 0.1, 1.5), (0.0, 0.0, 5.0)), (8.0, 8.0, 8.0), 40.0, 30.0)
     return SceneData(
         [
-            MeshData("mesh-Larynx", lar_v[None], lar_t, (0.80, 0.32, 0.34), "mat-Default OBJ"),
-            MeshData("mesh-VocalFold", np.stack(fold_frames).astype(np.float32), fold_t, (0.85, 0.62, 0.60), "mat-Default OBJ"),
+            MeshData("mesh-Larynx", lar_v[None], lar_t, (0.80, 0.32, 0.34), "mat-Default OBJ", bsdf),
+            MeshData("mesh-VocalFold", np.stack(fold_frames).astype(np.float32), fold_t, (0.85, 0.62, 0.60), "mat-Default OBJ", bsdf),
         ],
         cam, proj, spot, projector_scale=20.0, notes={"config": "vocalfold", "frames": frames},
     )
 
 
 # ----------------------------------------------------------------------------- cfg5
-def colon(width=1024, height=1024, tex=1024, n_around=256, n_along=1024):
-    """cfg5: curved tube with haustral ripples, 2*256*1024 = 524,288 triangles."""
+def colon(width=1024, height=1024, tex=1024, n_around=256, n_along=1024, principled=True):
+    """cfg5: curved tube with haustral ripples, 2*256*1024 = 524,288 triangles; material "mat-Mucosa", a principled BSDF
+    as in the reference's main.py:97-107 (principled=False: diffuse)."""
     th = np.linspace(0, 2 * np.pi, n_around, endpoint=False)
     s = np.linspace(0.0, 1.0, n_along + 1)
     tt, ss = np.meshgrid(th, s, indexing="xy")
@@ -230,7 +234,8 @@ def colon(width=1024, height=1024, tex=1024, n_around=256, n_along=1024):
     cam = SensorData("PerspectiveCamera", look_at((0.0, 0.0, 0.3), (0.35, 0.0, 3.0)), 90.0, 0.01, 100.0, width, height)
     proj = SensorData("PerspectiveCamera_1", look_at((0.2, 0.0, 0.3), (0.35, 0.0, 3.0)), 60.0, 0.01, 100.0, tex, tex)
     spot = SpotData("emit-Spot", look_at((0.0, 0.1, 0.3), (0.35, 0.0, 3.0)), (6.0, 6.0, 6.0), 60.0, 45.0)
-    return SceneData([MeshData("mesh-Colon", verts[None], tris, (0.85, 0.45, 0.40))], cam, proj, spot, projector_scale=6.0, notes={"config": "colon"})
+    return SceneData([MeshData("mesh-Colon", verts[None], tris, (0.85, 0.45, 0.40), "mat-Mucosa", {} if principled else None)], cam, proj, spot,
+                     projector_scale=6.0, notes={"config": "colon"})
 
 
 # ----------------------------------------------------------------------------- materials

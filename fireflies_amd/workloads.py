@@ -23,14 +23,15 @@ class Workload:
 
 
 def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50, n_fold=96, tube=(64, 128), shadows=True, randomize=True,
-              entity_device=None):
+              entity_device=None, principled=True):
     """configs[1]/[2] of BASELINE.json: animated vocal-fold scene (53,248 triangles at the default
     detail), `grid` x `grid` point laser, camera width x height, projector texture tex x tex.
     Randomisation ranges are those of examples/vocalfold_scene.py:73-92.
     `entity_device` is the device argument of ff.Scene (where the samplers draw): the reference
-    default is the GPU; "cpu" draws from torch's CPU generator and avoids one device sync per draw."""
+    default is the GPU; "cpu" draws from torch's CPU generator and avoids one device sync per draw.
+    `principled`: the material is Mitsuba's principled BSDF, whose `specular` the reference randomises (False: diffuse)."""
     edev = device if entity_device is None else entity_device
-    data = scenes.vocalfold(width=width, height=height, tex=tex, frames=frames, n_fold=n_fold, tube=tube)
+    data = scenes.vocalfold(width=width, height=height, tex=tex, frames=frames, n_fold=n_fold, tube=tube, principled=principled)
     mi_scene = mi.load_scene_data(data, device=device, shadows=shadows)
     params = mi.traverse(mi_scene)
     ff_scene = Scene(params, device=edev)
@@ -57,11 +58,11 @@ def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50,
     return Workload(data, mi_scene, params, ff_scene, laser, K, 10.0, (tex, tex))
 
 
-def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=True, randomize=True, entity_device=None):
+def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=True, randomize=True, entity_device=None, principled=True):
     """configs[4] of BASELINE.json: colon-endoscopy scene (524,288 triangles), 1024x1024, 1024-point
     pattern (32 x 32), texture 1024^2; render with spp = 256 and fp16=True for the full configuration."""
     edev = device if entity_device is None else entity_device
-    data = scenes.colon(width=width, height=height, tex=tex)
+    data = scenes.colon(width=width, height=height, tex=tex, principled=principled)
     mi_scene = mi.load_scene_data(data, device=device, shadows=shadows)
     params = mi.traverse(mi_scene)
     ff_scene = Scene(params, device=edev)
@@ -72,6 +73,17 @@ def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=Tru
         from .sampling import UniformScalarToVec3Sampler
 
         ff_scene.light("emit-Spot").add_vec3_sampler("intensity.value", UniformScalarToVec3Sampler(2.0, 10.0, device=edev))
+        if principled:  # the mucosa randomisation of main.py:97-107 (spec_trans scales the diffuse lobe only, include/ffx.h)
+            mat = ff_scene.material("mat-Mucosa")
+            mat.add_float_key("brdf_0.clearcoat.value", 0.0, 1.0)
+            mat.add_float_key("brdf_0.clearcoat_gloss.value", 0.0, 1.0)
+            mat.add_float_key("brdf_0.metallic.value", 0.0, 0.5)
+            mat.add_float_key("brdf_0.specular", 0.0, 1.0)
+            mat.add_float_key("brdf_0.roughness.value", 0.0, 1.0)
+            mat.add_float_key("brdf_0.anisotropic.value", 0.0, 1.0)
+            mat.add_float_key("brdf_0.sheen.value", 0.0, 0.5)
+            mat.add_float_key("brdf_0.spec_trans.value", 0.0, 0.4)
+            mat.add_float_key("brdf_0.flatness.value", 0.0, 1.0)
     ff_scene.train()
     proj = mi_scene.sensors()[1]
     x_fov, near, far = params[proj.id() + ".x_fov"], params[proj.id() + ".near_clip"], params[proj.id() + ".far_clip"]

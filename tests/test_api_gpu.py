@@ -299,17 +299,61 @@ def test_host_philox_matches_torch_rand(monkeypatch):
     assert hd.reserve(257, DEV) is None
 
 
-def test_principled_parameters_are_accepted_but_reported():
-    """the reference randomises brdf_0.specular / roughness / clearcoat (main.py:97-107, vocalfold_scene.py:93); here
-    they are accepted and shading stays Lambert — which is said out loud (once), not silently ignored."""
-    wl = _small()
-    with pytest.warns(UserWarning, match="shading is Lambert"):
-        wl.ff_scene.randomize()
+def test_principled_parameters_reach_the_render(oracle):
+    """the reference randomises brdf_0.specular / roughness / clearcoat ... of a principled material (main.py:97-107,
+    vocalfold_scene.py:93): the parameters land in the material rows the kernels read, `specular` re-derives `eta` like the
+    plugin, and the image is the oracle's for those rows.  A DIFFUSE material has no such parameters: assigning them is
+    reported once instead of being silently ignored."""
+    wl = _small(randomize=False)
+    tex = workloads.build_texture(wl).detach()
+    wl.params["tex.data"] = tex
+    key = "mat-Default OBJ.brdf_0."
+    imgs = {}
+    for specular, rough, coat in ((0.0, 0.5, 0.0), (0.75, 0.3, 0.0), (0.75, 0.3, 0.8)):
+        wl.params[key + "specular"] = mi.Float(specular)
+        wl.params[key + "roughness.value"] = mi.Float(rough)
+        wl.params[key + "clearcoat.value"] = mi.Float(coat)
+        wl.params.update()
+        rows = wl.mi_scene._albedo_host
+        eta = 2.0 / (1.0 - np.sqrt(0.08 * specular)) - 1.0
+        assert rows.shape == (2, 16) and np.all(rows[:, 3] == 1.0)
+        np.testing.assert_allclose(rows[:, 8], eta, rtol=1e-6)
+        np.testing.assert_allclose(rows[:, 4], rough, rtol=1e-6)
+        np.testing.assert_allclose(rows[:, 13], coat, rtol=1e-6)
+        assert abs(float(wl.params[key + "eta"]) - eta) < 1e-5
+        img = mi.render(wl.mi_scene, spp=8, seed=2).torch().cpu().numpy()
+        sd = wl.mi_scene.scene_desc(tex_channels=1)
+        assert sd.mat_stride == 16
+        ref = _oracle_pose(oracle, wl).render_fwd(sd, rows, tex.cpu().numpy(), 8, seed=2)
+        scale = float(ref.max())
+        err = np.abs(img - ref)
+        assert scale > 0.02 and (err > 2e-4 * scale).mean() < 1e-3 and err.max() < 0.2 * scale
+        imgs[(specular, coat)] = img
+    assert np.abs(imgs[(0.75, 0.0)] - imgs[(0.0, 0.0)]).max() > 0.01 * scale
+    assert np.abs(imgs[(0.75, 0.8)] - imgs[(0.75, 0.0)]).max() > 0.001 * scale
+    with pytest.raises(KeyError):
+        wl.params[key + "no_such_lobe.value"] = mi.Float(1.0)
+        wl.params.update()
+    # the differentiable path with material rows: autograd through mi.render = the oracle's adjoint
+    leaf = tex.clone().requires_grad_(True)
+    wl.params["tex.data"] = leaf
+    out = mi.render(wl.mi_scene, spp=8, seed=2).torch()
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    g_o = _oracle_pose(oracle, wl).render_bwd(sd, wl.mi_scene._albedo_host, 8, 2, w.cpu().numpy())[..., 0]
+    gs = float(np.abs(g_o).max())
+    gerr = np.abs(leaf.grad.cpu().numpy().reshape(g_o.shape) - g_o)
+    assert gs > 0 and (gerr > 1e-3 * gs).mean() < 1e-3 and gerr.max() < 0.1 * gs
+    # diffuse material
+    wd = _small(principled=False)
+    assert wd.mi_scene.scene_desc(tex_channels=1).mat_stride == 3 and tuple(wd.mi_scene.albedo.shape) == (2, 3)
+    with pytest.warns(UserWarning, match="is diffuse"):
+        wd.ff_scene.randomize()
     import warnings
 
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        wl.ff_scene.randomize()  # reported once per scene
+        wd.ff_scene.randomize()  # reported once per scene
 
 
 def test_generic_vertex_assignment_path(oracle):
@@ -541,10 +585,12 @@ def test_load_file_xml_obj_renders_like_the_oracle(oracle, tmp_path):
     sc = mi_scene.data
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
     go = oracle.Geometry(pool, tris, shape, off)
-    ref = go.render_fwd(mi_scene.scene_desc(tex_channels=1), alb, tex.cpu().numpy(), 8, seed=2)
+    sd = mi_scene.scene_desc(tex_channels=1)
+    assert sd.mat_stride == 16  # mat-Mucosa is a principled BSDF in the file: material rows (the sphere stays diffuse)
+    ref = go.render_fwd(sd, mi_scene._albedo_host, tex.cpu().numpy(), 8, seed=2)
     scale = float(ref.max())
     err = np.abs(img - ref)
-    assert scale > 0.01 and (err > 1e-4 * scale).mean() < 1e-3 and err.max() < 0.2 * scale
+    assert scale > 0.01 and (err > 2e-4 * scale).mean() < 1e-3 and err.max() < 0.2 * scale
     # the sphere (shape 1) casts a shadow on / occludes the wall: both shapes are visible
     seg = ff.graphics.depth.get_segmentation_from_camera(mi_scene)
     assert len(torch.unique(seg)) >= 2

@@ -7,7 +7,7 @@ from fireflies_amd import loaders, scenes
 XML = """<scene version="3.0.0">
   <default name="spp" value="64"/>
   <default name="res" value="96"/>
-  <bsdf type="twosided" id="mat-Mucosa"><bsdf type="principled"><rgb name="base_color" value="0.8, 0.3, 0.35"/></bsdf></bsdf>
+  <bsdf type="twosided" id="mat-Mucosa"><bsdf type="principled"><rgb name="base_color" value="0.8, 0.3, 0.35"/><float name="roughness" value="0.35"/><float name="specular" value="0.6"/><float name="clearcoat" value="0.25"/></bsdf></bsdf>
   <sensor type="perspective" id="PerspectiveCamera">
     <float name="fov" value="60"/><float name="near_clip" value="0.01"/><float name="far_clip" value="100"/>
     <transform name="to_world"><lookat origin="0,0,1.5" target="0,0,5" up="0,1,0"/></transform>
@@ -77,6 +77,13 @@ def test_mitsuba_xml_subset(tmp_path):
     np.testing.assert_allclose(sc.meshes[0].frames[0], wv * 2 + np.array([0, 0, 6], np.float32), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(sc.meshes[0].albedo, (0.8, 0.3, 0.35))
     assert sc.meshes[0].material == "mat-Mucosa" and sc.meshes[1].albedo == (0.2, 0.2, 0.2)
+    # the principled material keeps its scalar parameters; the diffuse one has none
+    assert sc.meshes[0].bsdf == {"roughness": 0.35, "specular": 0.6, "clearcoat": 0.25} and sc.meshes[1].bsdf is None
+    rows = scenes.material_rows(sc)
+    assert rows.shape == (2, 16) and rows[0, 3] == 1.0 and rows[1, 3] == 0.0
+    np.testing.assert_allclose(rows[0, [4, 13]], [0.35, 0.25], rtol=1e-6)
+    np.testing.assert_allclose(rows[0, 8], 2.0 / (1.0 - np.sqrt(0.08 * 0.6)) - 1.0, rtol=1e-6)
+    np.testing.assert_allclose(rows[1, :3], 0.2, rtol=1e-6)
     assert (sc.camera.width, sc.camera.height, sc.camera.fov_x) == (96, 96, 60.0)
     np.testing.assert_allclose(sc.camera.to_world, scenes.look_at((0, 0, 1.5), (0, 0, 5)), atol=1e-6)
     assert sc.projector.name == "PerspectiveCamera_1" and (sc.projector.width, sc.projector.fov_x) == (128, 30.0)
