@@ -283,7 +283,8 @@ __device__ __forceinline__ float sqrt_nr(float x) {
 // viewer direction wv and an emitter direction wl at a surface with unit normal n facing the viewer:
 //     pi * f(wv, wl) * cos_o = base_color * A + B   per colour channel.
 // The model is material_eval of oracle/ffx_oracle.c (which cites its sources), arranged for the kernel:
-//   * what depends on the material and the viewer only (MatCtx) is prepared once per sample and shared by both emitters;
+//   * the directions are reduced to five cosines (MatGeo) first — for both emitters, so that the surface point, the normal
+//     and the ray die before the lobes are evaluated; the lobes then run one after the other on those scalars;
 //   * Smith's G1 is taken as 2 c / (c + sqrt(c^2 + xy)) (= 2 / (1 + sqrt(1 + xy / c^2))), so the specular lobe
 //     D G / (4 cos_i) collapses to D cos_o / ((cos_i + s_i)(cos_o + s_o)): one quotient instead of five;
 //   * an isotropic material (anisotropic = 0, the plugin's default) needs no tangent frame at all;
@@ -300,54 +301,38 @@ __device__ __forceinline__ float schlick_weight(float c) {
 __device__ __forceinline__ float brcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float bdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-struct MatCtx {
-  float cos_i, Fi, s_i;       // viewer side: cosine, Schlick weight, sqrt(cos_i^2 + (ax wi.x)^2 + (ay wi.y)^2)
-  float ax, ay, inv_ax, inv_ay;
-  float rough, metallic, spec_tint, eta, ieta2, R0, tint_a, tint_b; // tint: spec_tint * R0 (/ lum) split into the base_color part and the rest
-  float brdf, flat, cc, cc_a2, sheen_a, sheen_b; // sheen * (1 - metallic) * (tint / lum | 1 - tint)
-  bool aniso;
-  v3 fs, ft, wi; // tangent frame and the viewer in it (anisotropic materials only)
+// geometry of one (viewer, emitter) pair — all the BSDF needs of the directions, as scalars: five cosines and the three
+// GGX quadratic forms (which take the tangent frame for an anisotropic material: formed here, where the vectors are)
+struct MatGeo {
+  float cos_i, cos_o, ch, ci_h, co_h; // n.wv, n.wl, n.h, wv.h, wl.h
+  float tmp, xy_i, xy_o, axay;        // (hx/ax)^2 + (hy/ay)^2 + hz^2, (ax ix)^2 + (ay iy)^2, the same for wl, ax * ay
 };
-__device__ __forceinline__ void material_prepare(const float *__restrict__ m, v3 n, v3 wv, MatCtx &k) {
-  const float4 m0 = reinterpret_cast<const float4 *>(m)[0], m1 = reinterpret_cast<const float4 *>(m)[1], m2 = reinterpret_cast<const float4 *>(m)[2],
-               m3 = reinterpret_cast<const float4 *>(m)[3];
-  const float aniso = m1.y, spec_trans = m1.w, sheen = m2.z, sheen_tint = m2.w, ccg = m3.z;
-  k.rough = m1.x; k.metallic = m1.z; k.eta = m2.x; k.spec_tint = m2.y; k.flat = m3.x; k.cc = m3.y;
-  const float lum = 0.212671f * m0.x + 0.715160f * m0.y + 0.072169f * m0.z;
-  const float ilum = lum > 0.f ? brcp(lum) : 0.f;
-  k.brdf = (1.0f - k.metallic) * (1.0f - spec_trans);
-  k.cos_i = vdot(n, wv);
-  k.Fi = schlick_weight(k.cos_i);
-  const float r2 = sqrf(k.rough);
-  k.aniso = aniso != 0.f;
-  float xy;
-  if (k.aniso) {
+__device__ __forceinline__ void material_geometry(const float *__restrict__ m, v3 n, v3 wv, v3 wl, MatGeo &g) {
+  g.cos_i = vdot(n, wv);
+  g.cos_o = vdot(n, wl);
+  v3 wh = V3(wv.x + wl.x, wv.y + wl.y, wv.z + wl.z);
+  const float ihl = __builtin_amdgcn_rsqf(vdot(wh, wh));
+  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
+  g.ci_h = vdot(wv, wh);
+  g.co_h = vdot(wl, wh);
+  g.ch = vdot(n, wh);
+  const float r2 = sqrf(m[FFX_MAT_ROUGHNESS]), aniso = m[FFX_MAT_ANISOTROPIC];
+  if (aniso != 0.f) { // calc_dist_params + the shading frame coordinate_system(n)
     const float aspect = bsqrt(1.0f - 0.9f * aniso);
-    k.ax = fmaxf(0.001f, bdiv(r2, aspect));
-    k.ay = fmaxf(0.001f, r2 * aspect);
-    // shading frame: coordinate_system(n)
+    const float ax = fmaxf(0.001f, bdiv(r2, aspect)), ay = fmaxf(0.001f, r2 * aspect);
     const float sg = copysignf(1.0f, n.z), ca = -brcp(sg + n.z), cb = n.x * n.y * ca;
-    k.fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x);
-    k.ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
-    k.wi = V3(vdot(wv, k.fs), vdot(wv, k.ft), k.cos_i);
-    xy = sqrf(k.ax * k.wi.x) + sqrf(k.ay * k.wi.y);
+    const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+    g.tmp = sqrf(bdiv(vdot(wh, fs), ax)) + sqrf(bdiv(vdot(wh, ft), ay)) + sqrf(g.ch);
+    g.xy_i = sqrf(ax * vdot(wv, fs)) + sqrf(ay * vdot(wv, ft));
+    g.xy_o = sqrf(ax * vdot(wl, fs)) + sqrf(ay * vdot(wl, ft));
+    g.axay = ax * ay;
   } else {
-    k.ax = k.ay = fmaxf(0.001f, r2);
-    xy = sqrf(k.ax) * fmaxf(1.0f - sqrf(k.cos_i), 0.f);
+    const float a2 = sqrf(fmaxf(0.001f, r2));
+    g.tmp = bdiv(fmaxf(1.0f - sqrf(g.ch), 0.f), a2) + sqrf(g.ch);
+    g.xy_i = a2 * fmaxf(1.0f - sqrf(g.cos_i), 0.f);
+    g.xy_o = a2 * fmaxf(1.0f - sqrf(g.cos_o), 0.f);
+    g.axay = a2;
   }
-  k.inv_ax = brcp(k.ax);
-  k.inv_ay = k.aniso ? brcp(k.ay) : k.inv_ax;
-  k.s_i = bsqrt(sqrf(k.cos_i) + xy);
-  k.ieta2 = sqrf(brcp(k.eta));
-  k.R0 = sqrf((k.eta - 1.0f) * brcp(k.eta + 1.0f));
-  const float t = (1.0f - k.metallic) * k.spec_tint * k.R0;
-  k.tint_a = lum > 0.f ? t * ilum : 0.f;
-  k.tint_b = lum > 0.f ? 0.f : t;
-  const float sv = sheen * (1.0f - k.metallic);
-  k.sheen_a = lum > 0.f ? sv * sheen_tint * ilum : 0.f;
-  k.sheen_b = lum > 0.f ? sv * (1.0f - sheen_tint) : sv;
-  const float alpha = 0.1f + (0.001f - 0.1f) * ccg;
-  k.cc_a2 = sqrf(alpha);
 }
 __device__ __forceinline__ float ggx1_cc(float c, float c_dot_h) { // smith_ggx1 with alpha = 0.25 (clearcoat)
   const float c2 = sqrf(c);
@@ -355,20 +340,18 @@ __device__ __forceinline__ float ggx1_cc(float c, float c_dot_h) { // smith_ggx1
   if (c_dot_h * c <= 0.f) r = 0.f;
   return r;
 }
-__device__ __forceinline__ void material_eval(const MatCtx &k, v3 n, v3 wv, v3 wl, float &A, float &B) {
-  const float cos_i = k.cos_i, cos_o = vdot(n, wl);
+// the lobes, one after the other, each reading the material values it needs from the row when it needs them (the row is
+// 64 bytes in the vector L1; holding all of it plus the directions in registers cost the kernel two waves of occupancy)
+__device__ __forceinline__ void material_terms(const float *__restrict__ m, const MatGeo &g, float &A, float &B) {
+  const float cos_i = g.cos_i, cos_o = g.cos_o, ch = g.ch, ci_h = g.ci_h, co_h = g.co_h;
   A = 0.f; B = 0.f;
   if (!(cos_i > 0.f && cos_o > 0.f)) return;
-  v3 wh = V3(wv.x + wl.x, wv.y + wl.y, wv.z + wl.z); // world space
-  const float ihl = __builtin_amdgcn_rsqf(vdot(wh, wh));
-  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
-  const float ci_h = vdot(wv, wh), co_h = vdot(wl, wh), ch = vdot(n, wh);
   const bool facing = ci_h > 0.f && co_h > 0.f; // (cos_i, cos_o > 0)
-  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * k.ieta2;
-  const float ct = ct2 > 0.f ? bsqrt(ct2) : 0.f; // cosine of the transmitted direction
-  const float eta = k.eta;
-  const float sw = schlick_weight(eta > 1.0f ? fabsf(ci_h) : ct);
   float a = 0.f, b = 0.f;
+  const float eta = m[FFX_MAT_ETA];
+  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * sqrf(brcp(eta));
+  const float ct = ct2 > 0.f ? bsqrt(ct2) : 0.f; // cosine of the transmitted direction
+  const float sw = schlick_weight(eta > 1.0f ? fabsf(ci_h) : ct);
   float F_d;
   {
     const float c = fabsf(ci_h);
@@ -378,53 +361,55 @@ __device__ __forceinline__ void material_eval(const MatCtx &k, v3 n, v3 wv, v3 w
     if (eta == 1.0f) F_d = 0.f;
     else if (c == 0.f) F_d = 1.f;
   }
+  const float metallic = m[FFX_MAT_METALLIC];
   if (facing && F_d > 0.f) { // main specular reflection lobe: F D G / (4 cos_i)
-    float tmp, xy_o;
-    if (k.aniso) {
-      const float hx = vdot(wh, k.fs), hy = vdot(wh, k.ft), ox = vdot(wl, k.fs), oy = vdot(wl, k.ft);
-      tmp = sqrf(hx * k.inv_ax) + sqrf(hy * k.inv_ay) + sqrf(ch);
-      xy_o = sqrf(k.ax * ox) + sqrf(k.ay * oy);
-    } else {
-      tmp = fmaxf(1.0f - sqrf(ch), 0.f) * sqrf(k.inv_ax) + sqrf(ch);
-      xy_o = sqrf(k.ax) * fmaxf(1.0f - sqrf(cos_o), 0.f);
-    }
-    const float dden = FFX_PI_F * (k.ax * k.ay) * sqrf(tmp);
-    const float s_o = bsqrt(sqrf(cos_o) + xy_o);
+    const float dden = FFX_PI_F * g.axay * sqrf(g.tmp);
+    const float s_i = bsqrt(sqrf(cos_i) + g.xy_i), s_o = bsqrt(sqrf(cos_o) + g.xy_o);
     // D G / (4 cos_i) = cos_o / (dden (cos_i + s_i)(cos_o + s_o))
-    float common = bdiv(cos_o, dden * ((cos_i + k.s_i) * (cos_o + s_o)));
+    float common = bdiv(cos_o, dden * ((cos_i + s_i) * (cos_o + s_o)));
     if (!(ch > 1e-20f * dden)) common = 0.f; // D * cos_h > 1e-20
-    const float m1 = 1.0f - k.metallic;
-    const float Fa = k.metallic * (1.0f - sw) + k.tint_a * (1.0f - sw);
-    const float Fb = k.metallic * sw + k.tint_b * (1.0f - sw) + m1 * k.spec_tint * sw + m1 * (1.0f - k.spec_tint) * F_d;
+    const float spec_tint = m[FFX_MAT_SPEC_TINT], m1 = 1.0f - metallic;
+    float Fa = metallic * (1.0f - sw), Fb = metallic * sw + m1 * spec_tint * sw + m1 * (1.0f - spec_tint) * F_d;
+    if (spec_tint != 0.f) {
+      const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
+      const float t = m1 * spec_tint * sqrf((eta - 1.0f) * brcp(eta + 1.0f)) * (1.0f - sw);
+      if (lum > 0.f) Fa += bdiv(t, lum);
+      else Fb += t;
+    }
     a += Fa * common;
     b += Fb * common;
   }
-  if (k.cc > 0.f && facing) { // clearcoat
+  const float cc = m[FFX_MAT_CLEARCOAT];
+  if (cc > 0.f && facing) { // clearcoat
     const float Fcc = sw + (1.0f - sw) * 0.04f;
-    const float a2 = k.cc_a2, c2 = sqrf(ch);
+    const float alpha = 0.1f + (0.001f - 0.1f) * m[FFX_MAT_CLEARCOAT_GLOSS], a2 = sqrf(alpha), c2 = sqrf(ch);
     float Dcc = bdiv(a2 - 1.0f, FFX_PI_F * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
     if (!(Dcc * ch > 1e-20f)) Dcc = 0.f;
     const float Gcc = ggx1_cc(cos_i, ci_h) * ggx1_cc(cos_o, co_h);
-    b += k.cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
+    b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
   }
-  const float Fo = schlick_weight(cos_o), Fi = k.Fi;
-  if (k.brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
+  const float brdf = (1.0f - metallic) * (1.0f - m[FFX_MAT_SPEC_TRANS]);
+  if (brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
+    const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);
     const float f_diff = (1.0f - 0.5f * Fi) * (1.0f - 0.5f * Fo);
-    const float Rr = 2.0f * k.rough * sqrf(co_h);
+    const float Rr = 2.0f * m[FFX_MAT_ROUGHNESS] * sqrf(co_h);
     const float f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0f));
     float dterm = f_diff + f_retro;
-    if (k.flat > 0.f) {
+    const float flat = m[FFX_MAT_FLATNESS];
+    if (flat > 0.f) {
       const float Fss90 = Rr * 0.5f;
       const float Fss = (1.0f + (Fss90 - 1.0f) * Fo) * (1.0f + (Fss90 - 1.0f) * Fi);
       const float f_ss = 1.25f * (Fss * (brcp(cos_o + cos_i) - 0.5f) + 0.5f);
-      dterm = dterm + (f_ss - dterm) * k.flat;
+      dterm = dterm + (f_ss - dterm) * flat;
     }
-    a += k.brdf * cos_o * 0.3183098861837907f * dterm;
+    a += brdf * cos_o * 0.3183098861837907f * dterm;
   }
-  if (k.sheen_a != 0.f || k.sheen_b != 0.f) {
-    const float sv = schlick_weight(fabsf(co_h)) * cos_o;
-    a += sv * k.sheen_a;
-    b += sv * k.sheen_b;
+  const float sheen = m[FFX_MAT_SHEEN];
+  if (sheen > 0.f && 1.0f - metallic > 0.f) {
+    const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
+    const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2], sheen_tint = m[FFX_MAT_SHEEN_TINT];
+    if (lum > 0.f) { a += bdiv(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
+    else b += sv;
   }
   A = a * FFX_PI_F;
   B = b * FFX_PI_F;
@@ -491,9 +476,10 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           if (vis) {
             float bA = cos_s, bB = 0.f; // Lambert; material rows: pi f cos = base_color * bA + bB
             if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
-              MatCtx mk;
-              material_prepare(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), mk);
-              material_eval(mk, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+              const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
+              MatGeo mg;
+              material_geometry(mrow, ng, V3(-d.x, -d.y, -d.z), wi, mg);
+              material_terms(mrow, mg, bA, bB);
             }
             st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * bA;
             st.proj_fac_b = (c.p_scale / (pl.z * pl.z * cos_p)) * bB;
@@ -537,9 +523,10 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         if (vis) {
           float bA = cos_s, bB = 0.f;
           if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
-            MatCtx mk;
-            material_prepare(c.mats + (size_t)FFX_MAT_STRIDE * h.shape, ng, V3(-d.x, -d.y, -d.z), mk);
-            material_eval(mk, ng, V3(-d.x, -d.y, -d.z), wi, bA, bB);
+            const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
+            MatGeo mg;
+            material_geometry(mrow, ng, V3(-d.x, -d.y, -d.z), wi, mg);
+            material_terms(mrow, mg, bA, bB);
           }
           float f = fall * bA / d2 * 0.3183098861837907f, fb = fall * bB / d2 * 0.3183098861837907f;
           st.spot[0] = c.s_int[0] * f;
@@ -1738,7 +1725,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     q.pfac_b = 0.f; q.sfac_b = 0.f;
     // material rows (MAT): pi f cos = base_color * bA + bB per emitter (material_eval); Lambert: bA = cos_s, bB = 0
     // (MAT: the BSDF is evaluated AFTER the shadow walks, for the samples the emitters reach — there the walk's registers
-    // are free; before the walks only the geometric factors are formed, and P, ng stay live across them)
+    // are free; before the walks only the geometric factors are formed, and P, ng stay live across them.  Parking P and ng
+    // in LDS across the walks reaches 8 waves per SIMD instead of 7 but measured the same: the BSDF's own arithmetic, not
+    // occupancy, is what the material rows cost — K8 0.57 ms against 0.48 ms for a diffuse scene)
     if (c.proj_on && q.ok) {
       v3 pl = xf_point(c.p_w2l, q.P);
       if (pl.z > 0.f) {
@@ -1848,23 +1837,30 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         const float *mrow = c2.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
         const bool mat_on = mrow[FFX_MAT_MODEL] != 0.f;
         const v3 wv = V3(-d[r].x, -d[r].y, -d[r].z);
-        MatCtx mk;
-        if (mat_on) material_prepare(mrow, q.ng, wv, mk);
+        // one emitter after the other: directions -> cosines (MatGeo) -> lobes
         if (lit_p) {
           v3 wi = vsub(V3(c2.p_pos[0], c2.p_pos[1], c2.p_pos[2]), q.P);
-          const float idist = rcp_nr(sqrt_nr(vdot(wi, wi)));
+          const float idist = __builtin_amdgcn_rsqf(vdot(wi, wi));
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float bA = vdot(q.ng, wi), bB = 0.f;
-          if (mat_on) material_eval(mk, q.ng, wv, wi, bA, bB);
+          if (mat_on) {
+            MatGeo g;
+            material_geometry(mrow, q.ng, wv, wi, g);
+            material_terms(mrow, g, bA, bB);
+          }
           q.pfac_b = q.pfac * bB;
           q.pfac = q.pfac * bA;
         }
         if (lit_s) {
           v3 wi = vsub(V3(c2.s_pos[0], c2.s_pos[1], c2.s_pos[2]), q.P);
-          const float idist = rcp_nr(sqrt_nr(vdot(wi, wi)));
+          const float idist = __builtin_amdgcn_rsqf(vdot(wi, wi));
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float bA = vdot(q.ng, wi), bB = 0.f;
-          if (mat_on) material_eval(mk, q.ng, wv, wi, bA, bB);
+          if (mat_on) {
+            MatGeo g;
+            material_geometry(mrow, q.ng, wv, wi, g);
+            material_terms(mrow, g, bA, bB);
+          }
           q.sfac_b = q.sfac * bB;
           q.sfac = q.sfac * bA;
         }
@@ -2014,7 +2010,7 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 }
 
 #ifndef FFX_PK_MAT_WAVES
-#define FFX_PK_MAT_WAVES 4 // material rows: the BSDF terms need registers (see DESIGN.md 5.1 on occupancy)
+#define FFX_PK_MAT_WAVES 7 // material rows: 75 VGPRs (72 at this setting without spills; 8 waves spill 4)
 #endif
 template <int R, bool WIDE, bool MAT>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
