@@ -81,11 +81,12 @@ def _kernel_ms(events, name):
     return (sum(ms) / len(ms), len(ms)) if ms else (None, 0)
 
 
-PROFILED_WORKLOAD = {"workload": "vocalfold", "res": 512, "spp": 64}  # what tools/collect_profiles.sh runs (bench.py defaults)
+PROFILED_WORKLOAD = {"workload": "vocalfold", "res": 512, "spp": 64, "material": "principled"}  # what tools/collect_profiles.sh runs (bench.py defaults)
 
 
 def _is_profiled_workload(args):
-    return args.workload == "vocalfold" and args.res == 512 and args.spp == 64 and not args.fp16 and not args.no_shadows
+    return (args.workload == "vocalfold" and args.res == 512 and args.spp == 64 and not args.fp16 and not args.no_shadows
+            and args.material == PROFILED_WORKLOAD["material"])
 
 
 def pmc_traffic(kernel_prefix, tag="r"):
@@ -375,7 +376,7 @@ def main():
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
         },
         "roofline": {
-            "kernel": "k_render_fwd_pk<1> (ffx_render_fwd, K8)",
+            "kernel": "k_render_fwd_pk<1, wide, %s> (ffx_render_fwd, K8)" % ("material rows" if args.material == "principled" else "albedo"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -57,9 +57,9 @@ def test_issue_rates_file_backs_the_class_rates(bench):
 
 
 def test_traffic_is_keyed_on_the_profiled_workload(bench):
-    ns = argparse.Namespace(workload="vocalfold", res=512, spp=64, fp16=False, no_shadows=False)
+    ns = argparse.Namespace(workload="vocalfold", res=512, spp=64, fp16=False, no_shadows=False, material="principled")
     assert bench._is_profiled_workload(ns)
-    for k, v in (("workload", "colon"), ("res", 1024), ("spp", 256), ("fp16", True), ("no_shadows", True)):
+    for k, v in (("workload", "colon"), ("res", 1024), ("spp", 256), ("fp16", True), ("no_shadows", True), ("material", "diffuse")):
         other = argparse.Namespace(**{**vars(ns), k: v})
         assert not bench._is_profiled_workload(other), k
     t = bench.pmc_traffic("k_render_fwd_pk")
