@@ -118,6 +118,35 @@ def test_error_reporting_through_the_abi():
         a.call("ffx_bvh_build_host", v.ctypes.data, 3, np.array([[0, 1, 2]], np.int32).ctypes.data, 1, blob.ctypes.data, 8, C.byref(info))
 
 
+def test_adjoint_cache_size_follows_the_material_table():
+    """host-side sizing (no GPU work): Lambert scenes keep the 37.7 MB layout at the BASELINE size, material rows add one
+    112-byte footprint per pixel behind the stray arena; the scene-description entry point agrees with the plain one"""
+    a = _lib.api()
+    sd = _abi.SceneDesc()
+    sd.cam.width, sd.cam.height = 512, 512
+    plain = a.lib.ffx_render_cache_bytes(512, 512, 64)
+    assert plain <= 40 * 10**6
+    assert a.lib.ffx_render_cache_bytes_sd(C.byref(sd), 64) == plain
+    sd.mat_stride = 3
+    assert a.lib.ffx_render_cache_bytes_sd(C.byref(sd), 64) == plain
+    sd.mat_stride = _abi.MAT_STRIDE
+    up = lambda v: ((v + 127) // 128) * 128  # noqa: E731
+    assert a.lib.ffx_render_cache_bytes_sd(C.byref(sd), 64) == up(plain) + 112 * 512 * 512
+    assert a.lib.ffx_render_cache_bytes_sd(None, 64) == 0 and a.lib.ffx_render_cache_bytes(0, 4, 4) == 0
+    # the material columns of the Python mirror are the header's
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ffx.h")).read()
+    import re
+
+    for name in ("MODEL", "ROUGHNESS", "ANISOTROPIC", "METALLIC", "SPEC_TRANS", "ETA", "SPEC_TINT", "SHEEN", "SHEEN_TINT", "FLATNESS", "CLEARCOAT",
+                 "CLEARCOAT_GLOSS"):
+        col = int(re.search(rf"#define FFX_MAT_{name} (\d+)", hdr).group(1))
+        assert getattr(_abi, "MAT_" + name) == col
+        from fireflies_amd import scenes
+
+        assert scenes.MAT_COLUMN[name.lower()] == col
+    assert int(re.search(r"#define FFX_MAT_STRIDE (\d+)", hdr).group(1)) == _abi.MAT_STRIDE
+
+
 def _build(verts, tris):
     a = _lib.api()
     F = tris.shape[0]

@@ -1,6 +1,7 @@
 """GPU parity tests: every HIP entry point of libffx_hip.so is called through the C ABI and
 compared with (a) the golden vectors captured from the reference's torch code and (b) the CPU
 oracle on the same seeded inputs.  Tolerances are stated per test.  Run with `-m gpu`."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -826,3 +827,33 @@ def test_principled_materials_match_the_oracle(oracle, env, ch, monkeypatch):
     # a material table that does not match the scene description is refused
     with pytest.raises(ValueError):
         gd.render_fwd(scene_desc.scene_desc(sc, tex_channels=ch, mat_stride=16), dev(alb), tex, 4)
+
+
+def test_principled_materials_mid_size_and_abi_errors(oracle):
+    """material rows at 256x256x64 spp on the full-detail vocal fold (one pixel per wave, the production launch shape) against
+    the oracle, with the reference's vocal-fold randomisation (specular 0 .. 0.75, roughness 0.5); and the C ABI's refusals:
+    an unknown material stride, material rows that are not 16-byte aligned."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    sc = scenes.vocalfold(width=256, height=256, tex=500, frames=4)
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 3))
+    tex = _tex(sc, 1)
+    mats = material_rows(2, 5, anisotropic=0.0, clearcoat=0.0, sheen=0.0, flatness=0.0, metallic=0.0, spec_trans=0.0, spec_tint=0.0, roughness=0.5)
+    mats[:, 8] = [2.0 / (1.0 - np.sqrt(0.08 * s_)) - 1.0 for s_ in (0.0, 0.75)]  # specular 0 (eta 1: no lobe) and 0.75
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16)
+    img_d = host(gd.render_fwd(sd, dev(mats), tex, 64, seed=12))
+    img_o = go.render_fwd(sd, mats, host(tex), 64, seed=12)
+    scale, err = _assert_image_close(img_d, img_o, 64, frac=5e-4, rel=2e-4, what="materials 256x256x64")
+    assert scale > 0.05 and float(err.mean()) < 2e-6 * scale
+    # ---- refusals
+    from fireflies_amd import _lib
+
+    a = _lib.api()
+    img = torch.empty((256, 256, 3), device="cuda")
+    bad = scene_desc.scene_desc(sc, tex_channels=1, mat_stride=5)
+    rc = a.lib.ffx_render_fwd(gd.blob.data_ptr(), C.byref(gd.info), C.byref(bad), dev(mats).data_ptr(), tex.data_ptr(), 4, 0, 0, img.data_ptr(), None)
+    assert rc == -1 and b"scene description" in a.lib.ffx_last_error()
+    shifted = torch.zeros(2 * 16 + 1, device="cuda")[1:]  # 4-byte aligned only
+    rc = a.lib.ffx_render_fwd(gd.blob.data_ptr(), C.byref(gd.info), C.byref(sd), shifted.data_ptr(), tex.data_ptr(), 4, 0, 0, img.data_ptr(), None)
+    assert rc == -1 and b"16-byte aligned" in a.lib.ffx_last_error()
+    torch.cuda.synchronize()
