@@ -15,7 +15,8 @@ def main():
 
     which = sys.argv[1] if len(sys.argv) > 1 else "vocalfold"
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    wl = (workloads.vocalfold if which == "vocalfold" else workloads.colon)(device="cuda", entity_device="cpu")
+    diffuse = len(sys.argv) > 3 and sys.argv[3] == "diffuse"  # (the Lambert kernel; default: the scene's principled material)
+    wl = (workloads.vocalfold if which == "vocalfold" else workloads.colon)(device="cuda", entity_device="cpu", principled=not diffuse)
     with torch.no_grad():
         wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
     lib = _lib.api().lib
