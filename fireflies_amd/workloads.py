@@ -58,11 +58,12 @@ def vocalfold(device="cuda", width=512, height=512, tex=500, grid=16, frames=50,
     return Workload(data, mi_scene, params, ff_scene, laser, K, 10.0, (tex, tex))
 
 
-def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=True, randomize=True, entity_device=None, principled=True):
+def colon(device="cuda", width=1024, height=1024, tex=1024, grid=32, shadows=True, randomize=True, entity_device=None, principled=True,
+          n_around=256, n_along=1024):
     """configs[4] of BASELINE.json: colon-endoscopy scene (524,288 triangles), 1024x1024, 1024-point
     pattern (32 x 32), texture 1024^2; render with spp = 256 and fp16=True for the full configuration."""
     edev = device if entity_device is None else entity_device
-    data = scenes.colon(width=width, height=height, tex=tex, principled=principled)
+    data = scenes.colon(width=width, height=height, tex=tex, principled=principled, n_around=n_around, n_along=n_along)
     mi_scene = mi.load_scene_data(data, device=device, shadows=shadows)
     params = mi.traverse(mi_scene)
     ff_scene = Scene(params, device=edev)

@@ -733,3 +733,33 @@ def test_pattern_initialisers(oracle):
     assert float(t[0]) == pytest.approx(2.0)
     assert bool(intersections.sphereSphere(torch.zeros(1, 3), torch.tensor([1.0]), torch.tensor([[1.5, 0, 0]]), torch.tensor([1.0])))
     assert phys.shape == r.shape
+
+
+def test_colon_workload_with_the_mucosa_randomisation_of_main_py(oracle):
+    """BASELINE configs[4] as the bench builds it (workloads.colon), at a reduced tessellation and film: the nine mucosa
+    parameters main.py:97-107 randomises — clearcoat, clearcoat_gloss, metallic, specular, roughness, anisotropic, sheen,
+    spec_trans, flatness — land in the material row and the image is the oracle's for that row, fp16 film included."""
+    wl = workloads.colon(device=DEV, width=96, height=96, tex=128, grid=6, n_around=32, n_along=64)
+    tex = workloads.build_texture(wl).detach()
+    wl.params["tex.data"] = tex
+    seen = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        random.seed(seed)
+        wl.ff_scene.randomize()
+        row = wl.mi_scene._albedo_host[0].copy()
+        seen.append(row)
+        assert row[3] == 1.0 and 0.0 <= row[5] <= 1.0 and 0.0 <= row[6] <= 0.5 and 0.0 <= row[7] <= 0.4 and 1.0 <= row[8] <= 2.0 / (1.0 - np.sqrt(0.08)) - 1.0 + 1e-5
+        for key, col in (("clearcoat.value", 13), ("clearcoat_gloss.value", 14), ("metallic.value", 6), ("roughness.value", 4), ("anisotropic.value", 5),
+                         ("sheen.value", 10), ("spec_trans.value", 7), ("flatness.value", 12)):
+            assert abs(float(wl.params["mat-Mucosa.brdf_0." + key]) - row[col]) < 1e-6, key
+        sd = wl.mi_scene.scene_desc(tex_channels=1)
+        go = _oracle_pose(oracle, wl)
+        for fp16 in (False, True):
+            img = mi.render(wl.mi_scene, spp=8, seed=seed, fp16=fp16).torch().float().cpu().numpy()
+            ref = go.render_fwd(sd, wl.mi_scene._albedo_host, tex.cpu().numpy(), 8, seed=seed, fp16=fp16).astype(np.float32)
+            scale = float(ref.max())
+            err = np.abs(img - ref)
+            tol = 2e-3 if fp16 else 2e-4
+            assert scale > 0.02 and (err > tol * scale).mean() < 2e-3 and err.max() < 0.2 * scale, (seed, fp16)
+    assert np.abs(seen[0] - seen[1]).max() > 0.05  # the draws differ
