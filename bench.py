@@ -278,15 +278,15 @@ def main():
 
     events = []
 
-    # Per-launch HIP event pairs (on the launch streams) are recorded for every 4th step of a timed bracket, at most
-    # TIMED_STEPS of them, and resolved right after it.  Every pair costs two marker packets around the kernel, which
+    # Per-launch HIP event pairs (on the launch streams) are recorded for every 8th step of a timed bracket, at most
+    # TIMED_STEPS of them (two in a 20-step bracket), and resolved right after it.  Every pair costs two marker packets around the kernel, which
     # keep the next step's refit from overlapping it: with all 20 steps of a short bracket instrumented the bracket
     # itself ran 8 % slower; and hundreds of unresolved timing events slow every later launch of the process down
     # (measured: the gradient bracket ran at half speed after 600 of them).
     TIMED_STEPS = int(os.environ.get("FFX_BENCH_TIMED_STEPS", "8"))
 
-    def _timed(i, first):
-        return i >= first and (i - first) % 4 == 0 and (i - first) // 4 < TIMED_STEPS
+    def _timed(i, first):  # steps 4, 12, 20, ... of a bracket (not its first step, which starts on an idle GPU)
+        return i >= first + 4 and (i - first - 4) % 8 == 0 and (i - first - 4) // 8 < TIMED_STEPS
 
     w_render = 0 if args.no_render_steps else args.warmup
 
