@@ -285,13 +285,14 @@ def main():
     # (measured: the gradient bracket ran at half speed after 600 of them).
     TIMED_STEPS = int(os.environ.get("FFX_BENCH_TIMED_STEPS", "8"))
 
-    def _timed(i, first):  # steps 4, 12, 20, ... of a bracket (not its first step, which starts on an idle GPU)
-        return i >= first + 4 and (i - first - 4) % 8 == 0 and (i - first - 4) // 8 < TIMED_STEPS
+    def _timed(i, first, steps=None):  # steps 4, 12, 20, ... of a bracket (not its first step, which starts on an idle GPU)
+        off = 4 if (steps is None or steps > 4) else 0  # (a bracket of fewer than five steps: its first)
+        return i >= first + off and (i - first - off) % 8 == 0 and (i - first - off) // 8 < TIMED_STEPS
 
     w_render = 0 if args.no_render_steps else args.warmup
 
     def timed_render_step(i):
-        geom.timing = events if _timed(i, w_render) else None
+        geom.timing = events if _timed(i, w_render, args.steps if not args.no_render_steps else 1) else None
         return render_step(i)
 
     t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev)
@@ -312,7 +313,7 @@ def main():
         gevents = []
 
         def grad_step(i):
-            wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup) else None
+            wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup, args.steps) else None
             return opt.step()
 
         t_grad = _bracket(grad_step, args.steps, args.warmup, dev)

@@ -27,7 +27,8 @@
  *       FFX_WIDE=0               wave-packet kernels on the binary walk only (default: 64-wide walk with binary fallback)
  *       FFX_PIXELS_PER_WAVE=1|2|4  pixels of a 2x2 tile one wavefront renders (default 1; 2 when the adjoint cache is written)
  *       FFX_TILE_BLOCK=0..8      log2 side of the square blocks in which tiles are enumerated (default 3)
- *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs (default 0: interleaved)
+ *       FFX_XCD_REMAP=0|1|B      workgroup -> tile mapping across the 8 XCDs: 0 round-robin, 1 one image band per XCD,
+ *                                B >= 2: each XCD takes B consecutive work items of every 8 B (default 128)
  *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
  *       FFX_K7_PPW_LOG2=0..6     cap on log2(pixels per wavefront) of ffx_trace_primary (default 4 at 1 spp, else 3)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
