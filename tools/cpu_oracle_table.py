@@ -24,7 +24,9 @@ def worker():
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
     geo = orc.Geometry(pool, tris, shape, off)
     cam = scene_desc.camera_from_sensor(sc.camera)
-    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    rows = scenes.material_rows(sc)  # the scene's principled material (bench.py's default workload); None: diffuse
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=0 if rows is None else scenes.MAT_STRIDE)
+    alb = alb if rows is None else rows
     one = int(os.environ.get("OMP_NUM_THREADS", "0")) == 1
     spp = 1 if one else 16  # bounded sample; scaled to 64 spp below
     out = {}
@@ -45,9 +47,9 @@ def worker():
     timed("K5+K6 scene_update 53248 tris", lambda: geo.update(xf))
     timed("K7 trace_primary 512x512 x 64 spp", lambda: geo.trace_primary(cam, spp, 1, 3), 64.0 / spp, f"measured at {spp} spp")
     t3 = orc.blur_fwd(tex)[..., None]
-    timed("K8 render_fwd 512x512 x 64 spp shadows", lambda: geo.render_fwd(sd, alb, t3, spp, seed=1), 64.0 / spp, f"measured at {spp} spp")
+    timed("K8 render_fwd 512x512 x 64 spp shadows, principled material", lambda: geo.render_fwd(sd, alb, t3, spp, seed=1), 64.0 / spp, f"measured at {spp} spp")
     gimg = rng.random((512, 512, 3)).astype(np.float32)
-    timed("K9 render_bwd (re-trace) 512x512 x 64 spp", lambda: geo.render_bwd(sd, alb, spp, 1, gimg), 64.0 / spp, f"measured at {spp} spp")
+    timed("K9 render_bwd (re-trace) 512x512 x 64 spp, principled material", lambda: geo.render_bwd(sd, alb, spp, 1, gimg), 64.0 / spp, f"measured at {spp} spp")
     print(json.dumps(out))
 
 
