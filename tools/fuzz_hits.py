@@ -31,6 +31,9 @@ def main():
     worst = 0.0
     bad_px = 0
     npx = 0
+    # the same poses rendered with random principled material rows (include/ffx.h FFX_MAT_*; a fresh table per pose)
+    sdm = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=scenes.MAT_STRIDE)
+    worst_m, bad_m = 0.0, 0
     for i in range(n_pose):
         a = rng.uniform(-0.2, 0.2)
         R = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
@@ -56,8 +59,22 @@ def main():
         worst = max(worst, float(err.max()))
         bad_px += int((err > 1e-4).sum())
         npx += err.size
+        S_ = len(off)
+        mats = np.zeros((S_, scenes.MAT_STRIDE), np.float32)
+        mats[:, 0:3] = rng.uniform(0.1, 0.9, (S_, 3))
+        mats[:, 3] = 1.0
+        for col, (lo, hi) in {4: (0.05, 1.0), 5: (0.0, 1.0), 6: (0.0, 0.5), 7: (0.0, 0.4), 9: (0.0, 1.0), 10: (0.0, 0.5), 11: (0.0, 1.0), 12: (0.0, 1.0),
+                              13: (0.0, 1.0), 14: (0.0, 1.0)}.items():
+            mats[:, col] = rng.uniform(lo, hi, S_)
+        mats[:, 8] = [scenes.specular_to_eta(v) for v in rng.uniform(0.0, 1.0, S_)]
+        im_d = gd.render_fwd(sdm, torch.from_numpy(mats).cuda(), tex, 16, seed=i).cpu().numpy()
+        im_o = go.render_fwd(sdm, mats, tex.cpu().numpy(), 16, seed=i)
+        em = np.abs(im_d - im_o) / max(float(im_o.max()), 1e-6)
+        worst_m = max(worst_m, float(em.max()))
+        bad_m += int((em > 2e-4).sum())
     print(f"poses {n_pose}: rays {tot}, different primitive {flips} ({flips / tot:.2e}), oracle-hit-but-GPU-miss {lost}")
     print(f"render: pixels*channels {npx}, |diff| > 1e-4 of scale: {bad_px} ({bad_px / npx:.2e}), worst {worst:.3e} of scale")
+    print(f"render with random principled material rows: |diff| > 2e-4 of scale: {bad_m} ({bad_m / npx:.2e}), worst {worst_m:.3e} of scale")
 
 
 if __name__ == "__main__":
