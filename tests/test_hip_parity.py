@@ -857,3 +857,38 @@ def test_principled_materials_mid_size_and_abi_errors(oracle):
     rc = a.lib.ffx_render_fwd(gd.blob.data_ptr(), C.byref(gd.info), C.byref(sd), shifted.data_ptr(), tex.data_ptr(), 4, 0, 0, img.data_ptr(), None)
     assert rc == -1 and b"16-byte aligned" in a.lib.ffx_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("ch", [1, 3])
+def test_material_rows_forward_and_adjoint_are_transposes(ch):
+    """independent of the oracle: with material rows the render is still linear in the texture, and both adjoints (cached,
+    re-tracing) are its transpose — <render(tex + d) - render(tex), g> = <d, adjoint(g)> for random d, g (float64 sums)."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    sc = scenes.vocalfold(width=64, height=48, tex=72, frames=3, n_fold=20, tube=(20, 24))
+    S = len(sc.meshes)
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    gd = ops.DeviceGeometry(pool, tris, shape, off)
+    gd.update(_rand_xforms(S, 4))
+    mats = dev(material_rows(S, 21))
+    sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=16)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tex = torch.rand((72, 72, ch), device="cuda", generator=g)
+    d = torch.randn((72, 72, ch), device="cuda", generator=g) * 0.1
+    gimg = torch.randn((48, 64, 3), device="cuda", generator=g)
+    spp = 12
+    base = gd.render_fwd(sd, mats, tex, spp, seed=8).double()
+    pert = gd.render_fwd(sd, mats, tex + d, spp, seed=8).double()
+    lhs = float(((pert - base) * gimg.double()).sum())
+    g_re = gd.render_bwd(sd, mats, spp, 8, gimg).double()
+    cache = torch.zeros(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device="cuda")
+    gd.render_fwd(sd, mats, tex, spp, seed=8, cache=cache)
+    g_ca = gd.render_bwd_cached(sd, mats, cache, spp, gimg).double()
+    for name, gt in (("re-tracing", g_re), ("cached", g_ca)):
+        rhs = float((d.double() * gt).sum())
+        assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs)), (name, lhs, rhs)
+    assert abs(lhs) > 1e-3
+    # linearity itself: render(2 tex) - render(tex) = render(tex) - render(0)
+    zero = gd.render_fwd(sd, mats, torch.zeros_like(tex), spp, seed=8).double()
+    two = gd.render_fwd(sd, mats, 2 * tex, spp, seed=8).double()
+    torch.testing.assert_close(two - base, base - zero, rtol=1e-4, atol=1e-5 * float(base.max()))
