@@ -6,6 +6,11 @@ scene (BASELINE.json metric), one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Without a torchrun environment `--gpus N` (N > 1) makes this process a LAUNCHER: it starts N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per device, backend nccl = RCCL), waits for them and exits with
+the first non-zero code; it never touches a GPU itself and never restarts a rank.  More ranks than devices is refused
+unless FFX_DIST_BACKEND=gloo asks for a single-device rehearsal of the N > 1 path.
+
 A "step" of the headline number is one pass of the render hot path over one randomised scene:
     ff_scene.randomize()  ->  params.update() [K5+K6: vertex transform + BVH refit]
     mi.render(scene, spp) [K8]
@@ -33,8 +38,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fireflies_amd import dist, mi, workloads  # noqa: E402
-from fireflies_amd.optim import PatternOptimizer  # noqa: E402
+dist = mi = workloads = PatternOptimizer = None  # the product, imported by the ranks only (_load_product)
+
+
+def _load_product():
+    """imports fireflies_amd (and with it libffx_hip.so).  Only a RANK does this: the launcher process of
+    `python bench.py --gpus N` (launch_ranks) never loads the HIP library and never touches a GPU."""
+    global dist, mi, workloads, PatternOptimizer
+    from fireflies_amd import dist as _d, mi as _m, workloads as _w
+    from fireflies_amd.optim import PatternOptimizer as _p
+
+    dist, mi, workloads, PatternOptimizer = _d, _m, _w, _p
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -68,6 +82,7 @@ def _bracket(fn, steps, warmup, device):
         for i in range(steps):
             fn(warmup + i)
         torch.cuda.synchronize()
+        _bracket.local_s = time.perf_counter() - t0  # this rank's own K steps (before it waits for the others)
         dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -222,6 +237,84 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment: N fresh child processes, one rank each.
+    This parent makes NO GPU call (torch.cuda.device_count() does not initialise the runtime on this image) and
+    does not import the product; a rank that fails ends the run with its exit code — nothing is restarted."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("FFX_DIST_BACKEND")
+    if n > n_dev and backend != "gloo":
+        raise SystemExit(f"bench.py: --gpus {n} but only {n_dev} device(s) are visible (a single-device rehearsal of the N > 1 path needs FFX_DIST_BACKEND=gloo)")
+    with socket.socket() as so:  # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", FFX_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))  # stdout/stderr inherited: rank 0 prints the line
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def collective_probe(n_points, dev, iters=200):
+    """what the optimisation step's ONE exchange costs on this node: all-reduce(sum) of the flat [3N+1] float buffer
+    (DESIGN 6), mean over `iters` back-to-back calls, max over ranks; plus which device every rank sits on."""
+    import torch.distributed as td
+
+    world = dist.world_size()
+    if world == 1:
+        return None
+    flat = torch.zeros(3 * n_points + 1, dtype=torch.float32, device=dev)
+    for _ in range(20):
+        td.all_reduce(flat)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        td.all_reduce(flat)
+    torch.cuda.synchronize()
+    us = _max_over_ranks((time.perf_counter() - t0) / iters * 1e6, dev)
+    ids = [None] * world
+    props = torch.cuda.get_device_properties(dev)
+    td.all_gather_object(ids, {"rank": dist.rank(), "device": int(torch.cuda.current_device()), "name": props.name,
+                               "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))})
+    return {"world_size": world, "backend": td.get_backend(), "devices": ids, "allreduce_us": us, "allreduce_floats": int(flat.numel()),
+            "launcher": "bench.py (self-launched ranks)" if os.environ.get("FFX_BENCH_LAUNCHED") else "torchrun"}
+
+
+def _gather_floats(x, dev):
+    """[x of rank 0, x of rank 1, ...] on every rank"""
+    import torch.distributed as td
+
+    if dist.world_size() == 1:
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.world_size())]
+    td.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,11 +340,18 @@ def main():
     ap.add_argument("--entity-device", default="cuda", help="device argument of ff.Scene (where the sampler bounds live and whose generator is used): cuda (the reference default) or cpu")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])  # never returns
+    _load_product()
     rank, world, local = dist.env_rank_world()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if world > torch.cuda.device_count() and os.environ.get("FFX_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} device(s) (FFX_DIST_BACKEND=gloo allows a single-device rehearsal)")
     local = local % max(torch.cuda.device_count(), 1)  # (rehearsals with more ranks than devices share a device)
     torch.cuda.set_device(local)
     dist.init(os.environ.get("FFX_DIST_BACKEND"))  # default: nccl (= RCCL); gloo only for single-GPU rehearsals of the N > 1 path
@@ -299,6 +399,8 @@ def main():
     geom.timing = None
     torch.cuda.synchronize()
     renders_per_sec = world * args.steps / t_render
+    per_rank_t = _gather_floats(_bracket.local_s, dev)
+    rccl = collective_probe(args.grad_grid**2, dev)
     k8_ms, k8_n = _kernel_ms(events, "render_fwd")
     upd_ms, _ = _kernel_ms(events, "scene_update")
     events.clear()
@@ -395,7 +497,10 @@ def main():
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
         },
         "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_ms},
+        "rccl": rccl,
     }
+    if rccl is not None:
+        rccl["renders_per_sec_per_rank"] = [args.steps / t for t in per_rank_t]
     out.update(grad)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, tex, args.spp, args.cpu_spp, seed=base_seed)

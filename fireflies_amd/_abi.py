@@ -129,6 +129,7 @@ PROTOTYPES = {
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p]),
+    "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),
 }
 
 

@@ -688,7 +688,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   }
   if (k == 0 && reg_value) { // value of the regulariser from the forward's per-tile partial sums (fixed order)
     float acc = 0.f;
-    for (int t = tid; t < n_ws; t += SPLAT_BLOCK) acc += ws[t];
+    if (reg && ws) // (no regulariser: the forward wrote no partial sums and ws may be NULL)
+      for (int t = tid; t < n_ws; t += SPLAT_BLOCK) acc += ws[t];
     __shared__ float s_v[SPLAT_BLOCK / 64];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -915,7 +916,7 @@ int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int 
   Mat4 m;
   for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
   hipLaunchKernelGGL(k_pattern_bwd, dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws,
-                     (int)ffx_pattern_ws_floats(size0, size1), gts ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in,
+                     ws ? (int)ffx_pattern_ws_floats(size0, size1) : 0, gts ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in,
                      loss_div > 0.f ? loss_div : 1.0f);
   FFX_CHECK_LAUNCH("pattern_bwd");
   return FFX_OK;

@@ -2324,6 +2324,10 @@ struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int 
 __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_pix, uint32_t i, const BwdP &p, const float *__restrict__ gimg,
                                          const float *__restrict__ albedo, float *__restrict__ gtex) {
   const CacheHdr *hdr = reinterpret_cast<const CacheHdr *>(cache);
+  // the forward pass ran out of stray records: the gradient of `dropped` samples is missing.  A wrong gradient must not
+  // look like a right one: poison gtex (NaN) — ffx_render_cache_status tells the host why, which then re-traces
+  // (functional._Render.backward) or raises (optim.PatternOptimizer)
+  if (i == 0 && hdr->dropped != 0u) atomicAdd(gtex, __uint_as_float(0x7fc00000u));
   const uint32_t n = min(hdr->n_stray, hdr->cap_stray);
   if (i >= n) return;
   const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + cache_off_arena((size_t)n_pix))[i];
@@ -2789,6 +2793,15 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
   if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
   if (((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache must be 16-byte aligned");
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 3, img, cache, s);
+}
+
+int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
+  if (!cache || !out3) FFX_FAIL(FFX_ERR_ARG, "render_cache_status: bad argument");
+  CacheHdr h;
+  if (hipMemcpyAsync(&h, cache, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess || hipStreamSynchronize((hipStream_t)s) != hipSuccess)
+    FFX_FAIL(FFX_ERR_LAUNCH, "render_cache_status: reading the cache header failed");
+  out3[0] = h.n_stray; out3[1] = h.cap_stray; out3[2] = h.dropped;
+  return FFX_OK;
 }
 
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {

@@ -201,7 +201,9 @@ class Mesh(base.Transformable):
         return None
 
     def sample_animation(self):
-        pick = self.sample_animation_index()
+        # (inside Scene.randomize the frame was already drawn with the other samplers — scene.Scene._draw_all — and is
+        # waiting in _pending_pick: drawing again would consume a second animation draw per randomisation)
+        pick = self._pending_pick if hasattr(self, "_pending_pick") else self.sample_animation_index()
         if pick is None:
             return self._vertices if not self._animated else None
         if pick[0] == "func":

@@ -119,14 +119,41 @@ def gaussian_blur(img, ksize=5, sigma=3.0):
 CACHE_LIMIT_BYTES = int(float(os.environ.get("FFX_CACHE_LIMIT_GB", "32")) * (1 << 30))
 
 
+# The cache keeps ONE 5x5-texel footprint per pixel; samples outside it go to an arena of 1/64 of all samples.  A projector
+# texture much finer than the camera's pixel footprint makes most samples strays and the arena overflows (the gradient of the
+# dropped samples would be lost: ffx_render_bwd_cached poisons gtex instead, ffx.h).  Expected texels per camera pixel along
+# an axis ~ (texels per projector radian) / (pixels per camera radian) at equal depth; beyond this many the cache is refused
+# up front and the adjoint re-traces.
+# (the 256x256 camera / 500x500 texture of the parity tests is 4.2 and stays well inside the arena; the safety net behind
+# this estimate is the `dropped` count: ffx_render_cache_status, checked by _Render.backward and PatternOptimizer)
+def max_texels_per_pixel():
+    return float(os.environ.get("FFX_CACHE_MAX_TEXELS_PER_PIXEL", "6.0"))
+
+
+def texels_per_pixel(sd):
+    """texels of the projector texture per camera pixel (per axis, at equal distance from both devices, on the optical
+    axes): camera_to_sample[0][0] is 0.5 / tan(fov_x / 2) in sample units per unit tangent for both (mi.perspective_projection)"""
+    kc, kp = abs(float(sd.cam.camera_to_sample[0])), abs(float(sd.proj.camera_to_sample[0]))
+    if kc == 0.0 or kp == 0.0:
+        return float("inf")
+    return (kp * sd.proj.tex_w) / (kc * sd.cam.width)
+
+
 def cache_supported(sd, spp):
     """whether ffx_render_fwd_cache accepts this render (its records pack the texel in 12+12 bits and
-    the shape id in 8) and the cache fits the FFX_CACHE_LIMIT_GB budget"""
+    the shape id in 8), the cache fits the FFX_CACHE_LIMIT_GB budget and a pixel's samples can be expected to
+    stay inside one 5x5-texel footprint"""
     if not sd.proj.enabled:
         return False
     if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255:
         return False
+    if texels_per_pixel(sd) > max_texels_per_pixel():
+        return False
     return ops.render_cache_bytes_sd(sd, spp) <= CACHE_LIMIT_BYTES
+
+
+class CacheOverflowError(RuntimeError):
+    """the adjoint cache's arena of single-sample records filled up: its gradient would have holes"""
 
 
 class _Render(torch.autograd.Function):
@@ -152,10 +179,19 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = _c(g.float())
+        gtex = None
         if ctx.cache is not None:
-            gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g)
+            # (one 64-byte read + stream sync per backward of this generic path; the optimiser's explicit step checks lazily)
+            used, cap, dropped = ops.render_cache_status(ctx.cache)
+            if dropped == 0:
+                gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g)
+            elif ctx.geom.version != ctx.pose_version:
+                raise CacheOverflowError(
+                    f"render backward: the adjoint cache overflowed ({dropped} samples beyond its {cap} single-sample records — a projector "
+                    "texture much finer than the camera's pixels?) and the scene has been re-fitted since the forward pass, so the adjoint "
+                    "cannot re-trace: call backward before the next randomisation, or set FFX_CACHE_LIMIT_GB=0 to always re-trace")
             ctx.cache = None
-        else:  # replays the geometry: it must still be in the pose of the forward pass
+        if gtex is None:  # replays the geometry: it must still be in the pose of the forward pass
             if ctx.geom.version != ctx.pose_version:
                 raise RuntimeError(
                     "render backward: the scene was re-fitted (randomize()/update()) between forward and backward and this render "

@@ -242,6 +242,15 @@ def render_cache_bytes_sd(sd, spp):
     return int(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), int(spp)))
 
 
+def render_cache_status(cache):
+    """(stray records used, arena capacity, dropped samples) of an adjoint cache written by render_fwd(..., cache=...).
+    SYNCHRONISES the current stream (64-byte read).  dropped > 0: the cache is incomplete — ffx_render_bwd_cached then
+    poisons gtex[0] with NaN; use the re-tracing adjoint."""
+    out = (C.c_uint32 * 3)()
+    api().call("ffx_render_cache_status", _dev(cache, torch.uint8, "cache"), out, _stream())
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def _check_materials(sd, albedo):
     ms = int(sd.mat_stride) or 3
     if albedo.dim() != 2 or albedo.shape[1] != ms or albedo.shape[0] < sd.n_shapes:

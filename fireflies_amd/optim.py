@@ -20,6 +20,7 @@ import torch
 
 from . import dist
 from . import functional as Fn
+from .scene import StaleDrawError
 
 
 def coverage_loss(img):
@@ -167,7 +168,7 @@ class PatternOptimizer:
         if ahead is not None and ahead[0] == (self.step_index, tuple(seeds)):
             try:
                 appliers = ahead[1]()
-            except RuntimeError:  # a sampler range was changed since: draw again
+            except StaleDrawError:  # a sampler range was changed since: draw again (anything else — a failed native call, a HIP error — propagates)
                 appliers = None
         if appliers is None:
             appliers = self.ff_scene.randomize_batch(seeds)
@@ -222,7 +223,30 @@ class PatternOptimizer:
                              1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad)
         rays.grad = grad
         self.step_index += 1
+        self._watch_cache()
         return {"loss": loss}
+
+    def _watch_cache(self, every=32):
+        """The adjoint cache is lossy once its arena of single-sample records is full (include/ffx.h
+        ffx_render_cache_status; K9 then poisons the gradient with NaN).  Every `every` steps the 64-byte cache header is
+        copied to pinned host memory behind the step's kernels and inspected once it has landed — the host never waits."""
+        w = getattr(self, "_watch", None)
+        if w is not None and w[1].query():
+            used, cap, dropped = (int(v) for v in w[0][:3].tolist())
+            self._watch = None
+            if dropped:
+                raise Fn.CacheOverflowError(
+                    f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample "
+                    "records: a projector texture much finer than the camera's pixels, or grazing views) — gradients since then carry NaN. "
+                    "Set FFX_CACHE_LIMIT_GB=0 (re-tracing adjoint) or lower FFX_CACHE_MAX_TEXELS_PER_PIXEL.")
+        if getattr(self, "_watch", None) is None and self._cache is not None and (self.step_index - 1) % every == 0:
+            pin = getattr(self, "_watch_pin", None)
+            if pin is None:
+                pin = self._watch_pin = torch.empty(16, dtype=torch.int32, pin_memory=True)
+            pin.copy_(self._cache[:64].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._watch = (pin, ev, self.step_index - 1)
 
     # ------------------------------------------------------------------ the same step through autograd
     def step_autograd(self):

@@ -20,10 +20,54 @@ _INC = C.c_uint64(0)
 _BUF = (C.c_float * 256)()
 _FN = None
 _GENS = {}  # device (as the samplers hold it) -> its default CUDA generator
+_CHECKED_DEVICES = set()  # devices (as the samplers hold them) whose host evaluation has been verified
 
 
 def enabled() -> bool:
     return _ENABLED
+
+
+_VERIFIED = {}  # device index -> bool
+
+
+def verified(device) -> bool:
+    """enabled() AND this process has seen, once per device, that the host evaluation reproduces `torch.rand` on that
+    device bit for bit and leaves the generator at the same offset.  The host path hard-codes what PyTorch-ROCm's uniform
+    kernel does (Philox-4x32-10, +4 offset per launch of <= 256 elements, rocrand's float conversion): a torch / rocrand
+    upgrade that changes any of it would otherwise silently change seeded streams.  On a mismatch the host path is
+    switched off for the process (device draws, as with FFX_HOST_PHILOX=0) with a warning.  The generator is left exactly
+    as it was found."""
+    global _ENABLED
+    if not _ENABLED or not torch.cuda.is_available():
+        return False
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return False
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ok = _VERIFIED.get(idx)
+    if ok is None:
+        gen = torch.cuda.default_generators[idx]
+        state = gen.get_state()
+        try:
+            ok = True
+            gen.manual_seed(0x5EED0FF5E7)
+            for n in (3, 256):
+                off0 = gen.get_offset()
+                want = torch.rand(n, device=torch.device("cuda", idx)).cpu().numpy()
+                off_t = gen.get_offset()
+                gen.set_offset(off0)
+                got = host_rand(n, torch.device("cuda", idx))
+                ok = ok and got is not None and np.array_equal(want, got) and gen.get_offset() == off_t
+        finally:
+            gen.set_state(state)
+        _VERIFIED[idx] = ok
+        if not ok:
+            import warnings
+
+            warnings.warn("fireflies_amd: the host evaluation of torch.rand (ffx_torch_rand_h) does not reproduce this PyTorch build's CUDA "
+                          "uniform kernel; sampler draws fall back to the device (FFX_HOST_PHILOX=0 behaviour)")
+            _ENABLED = False
+    return bool(ok)
 
 
 def host_rand(numel: int, device):
@@ -57,6 +101,10 @@ class HostDraws:
         """index of the reserved draw, or None if this draw has to be made on the device"""
         if not _ENABLED or numel < 1 or numel > 256 or torch.cuda.is_current_stream_capturing():
             return None
+        if device not in _CHECKED_DEVICES:  # first draw on this device in this process: the one-time check against torch.rand
+            if not verified(device):
+                return None
+            _CHECKED_DEVICES.add(device)
         gen = _GENS.get(device)
         if gen is None:
             dev = torch.device(device)

@@ -30,6 +30,12 @@ def _seed_generators(seed: int) -> None:
         torch.cuda.manual_seed_all(seed)  # queued until the device is initialised, as torch.manual_seed would
 
 
+class StaleDrawError(RuntimeError):
+    """scene samples drawn ahead of time (Scene.randomize_batch(lazy=True)) no longer match the sampler configuration:
+    the caller draws again.  Deliberately NOT raised for anything else — a failed native call or a HIP error inside the
+    look-ahead must surface, not be retried."""
+
+
 class Scene:
     MESH_KEYS = ["mesh", "ply"]
     CAM_KEYS = ["camera", "perspective", "perspectivecamera"]
@@ -335,15 +341,29 @@ class Scene:
         return self._draw_stream() is not None and os.environ.get("FFX_PREDRAW", "1") != "0" and all(e._train for e in self._draw_order())
 
     def _rng_state(self):
+        """every generator a sampler may draw from: torch's CUDA and CPU generators (samplers with CPU bounds, a
+        GaussianSampler with a CPU mean), Python's `random` (AnimationSampler) and numpy's global stream (custom samplers)"""
         import random as _random
 
-        return torch.cuda.get_rng_state(torch.device(self._device)), _random.getstate()
+        import numpy as _np
+
+        return torch.cuda.get_rng_state(torch.device(self._device)), _random.getstate(), torch.get_rng_state(), _np.random.get_state()
 
     def _set_rng_state(self, st) -> None:
         import random as _random
 
+        import numpy as _np
+
         torch.cuda.set_rng_state(st[0], torch.device(self._device))
         _random.setstate(st[1])
+        torch.set_rng_state(st[2])
+        _np.random.set_state(st[3])
+
+    @staticmethod
+    def _same_rng_state(a, b) -> bool:
+        na, nb = a[3], b[3]
+        return (torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+                and na[0] == nb[0] and bool((na[1] == nb[1]).all()) and tuple(na[2:]) == tuple(nb[2:]))
 
     def _predraw(self) -> None:
         from .sampling import base as sbase
@@ -364,8 +384,7 @@ class Scene:
         pre, self._pre = getattr(self, "_pre", None), None
         if pre is None or pre["config"] != sbase.mutation_count():
             return None
-        now = self._rng_state()
-        if not torch.equal(now[0], pre["before"][0]) or now[1] != pre["before"][1]:
+        if not self._same_rng_state(self._rng_state(), pre["before"]):
             return None
         self._set_rng_state(pre["after"])
         return pre["drawn"], pre["pending"].finish()
@@ -378,7 +397,7 @@ class Scene:
 
         c = getattr(self, "_hd", None)
         if c is None or c[0] != sbase.mutation_count():
-            ok = torch_rng.enabled() and torch.device(self._device).type == "cuda"
+            ok = torch_rng.verified(self._device)  # (one-time check against torch.rand on this device)
             if ok:
                 for e in self._draw_order():
                     if not e.randomizable():
@@ -458,7 +477,7 @@ class Scene:
 
         def appliers():
             if sbase.mutation_count() != config:
-                raise RuntimeError("the sampler configuration changed after these scene samples were drawn")
+                raise StaleDrawError("the sampler configuration changed after these scene samples were drawn")
             values = pending.finish()
             if side is not None:
                 ops._stream_obj(side.device).wait_stream(side)

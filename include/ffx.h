@@ -244,16 +244,17 @@ typedef struct ffx_bvh_info {
   uint64_t total_bytes;
   int32_t level_start[FFX_MAX_LEVELS + 1]; /* ranges into the refit list, leaves-first */
   /* 64-wide overlay of the same tree for the wave-packet kernels: inner nodes of up to
-   * 64 children with 16-bit quantised boxes, triangles grouped in clusters of up to 64 consecutive leaf
-   * slots.  All zero in a blob written by the oracle (which walks its own binary tree). */
+   * 64 children, triangles grouped in clusters of up to 64 consecutive leaf slots; ONE array of 32-byte
+   * elements {f32 lo[3], f32 hi[3], i32 ref, pad} (16 bytes with 16-bit boxes in a -DFFX_WIDE_F32=0 build).
+   * All zero in a blob written by the oracle (which walks its own binary tree). */
   int32_t n_wide;     /* wide inner nodes (0: the whole scene is one cluster) */
   int32_t wide_depth; /* wide inner levels above the clusters */
-  int32_t wide_root;  /* reference of the root: cluster << 31 | element << 6 | (count - 1), elements of 16 B from off_wnodes */
+  int32_t wide_root;  /* reference of the root: cluster << 31 | element << 6 | (count - 1), elements of 32 B from off_wnodes */
   int32_t wide_pad;
-  uint64_t off_wnodes; /* n_wide x 64 x 16 B child records */
+  uint64_t off_wnodes; /* n_wide x 64 x 32 B child records */
   uint64_t off_wsrc;   /* n_wide x 64 x int32: where each child's box lives in the binary tree */
-  uint64_t off_tq;     /* n_tris x 16 B quantised triangle boxes, leaf-slot order; = off_wnodes + n_wide * 1024 */
-  uint64_t off_whdr;   /* 64 B: quantisation grid of the current pose */
+  uint64_t off_tq;     /* n_tris (+ 64 of padding) x 32 B triangle boxes, leaf-slot order; = off_wnodes + n_wide * 2048 */
+  uint64_t off_whdr;   /* 64 B header of the overlay (the quantisation grid of the current pose in a 16-bit build) */
 } ffx_bvh_info;
 
 /* upper bound of the blob size for n_tris triangles.  The blob ends with scratch areas ("apex records",
@@ -411,6 +412,13 @@ int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[
 int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
+/* The cache is lossy when its arena of single-sample records fills up (a projector texture much finer than the camera's
+ * pixel footprint, grazing views: most samples then miss their pixel's 5x5 window).  Samples beyond the arena are counted
+ * in `dropped` and ffx_render_bwd_cached then poisons gtex[0] with NaN instead of returning a gradient with silent holes.
+ * ffx_render_cache_status reads {records used, arena capacity, dropped} of a cache written by ffx_render_fwd_cache;
+ * it SYNCHRONISES `stream` (a 64-byte device-to-host read).  dropped != 0: fall back to ffx_render_bwd.
+ * (The oracle's cache is one record per sample and never drops: {0, 0, 0}.) */
+int ffx_render_cache_status(const void *cache /*[dev]*/, uint32_t *out3 /*[host][3]*/, ffx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1334,6 +1334,14 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, (crec *)cache); /* bit 1 (sparse adjoint) ignored: full gradient */
 }
 
+/* this cache is one record per sample: nothing is ever dropped */
+int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
+  (void)s;
+  if (!cache || !out3) FAIL(FFX_ERR_ARG, "render_cache_status: bad argument");
+  out3[0] = out3[1] = out3[2] = 0u;
+  return FFX_OK;
+}
+
 /* adjoint from the per-sample records: same weights, same clamping as the forward lookup */
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {
   (void)s;

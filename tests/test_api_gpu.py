@@ -441,11 +441,13 @@ def test_pattern_optimizer_explicit_adjoints_match_autograd():
     def custom(img):
         return (img[..., 1] - 0.05).square().mean() + 0.1 * img[..., 0].mean()
 
-    for loss_fn in (None, custom):
+    # (reg_weight 0: the forward launch writes no softor texture and no partial sums — ffx_pattern_bwd is then called with
+    # ws = NULL and still emits the loss value; the kernel once summed ws regardless)
+    for loss_fn, reg_w in ((None, 0.1), (custom, 0.1), (None, 0.0)):
         runs = []
         for which in ("step", "step_autograd"):
             wl = _small()
-            kw = {} if loss_fn is None else {"loss_fn": loss_fn}
+            kw = {"reg_weight": reg_w} if loss_fn is None else {"loss_fn": loss_fn, "reg_weight": reg_w}
             opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, samples_per_step=2, base_seed=5, **kw)
             losses = [float(getattr(opt, which)()["loss"]) for _ in range(3)]
             runs.append((losses, wl.laser._rays.detach().clone()))
@@ -553,6 +555,41 @@ def test_two_rank_rccl_step_matches_one_rank(tmp_path, backend):
         assert o["loss"] == pytest.approx(float(out["loss"]), rel=1e-4)
         np.testing.assert_allclose(np.asarray(o["rays"], np.float32), wl.laser._rays.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_array_equal(np.asarray(outs[0]["grad"]), np.asarray(outs[1]["grad"]))  # replicated optimiser state
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the launcher starts two fresh rank processes (here both on
+    the one device, transport gloo — FFX_DIST_BACKEND=gloo is the explicit opt-in for that; on a node with >= 2 GPUs the
+    same command runs RCCL, one rank per device) and rank 0's line reports the job: n_gpus 2, two ranks, the [3N+1]
+    all-reduce timed, one rate per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    two_gpus = torch.cuda.device_count() >= 2
+    if not two_gpus:
+        env["FFX_DIST_BACKEND"] = "gloo"
+    else:
+        env.pop("FFX_DIST_BACKEND", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    (line,) = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
+    r = out["rccl"]
+    assert r["world_size"] == 2 and r["backend"] == ("nccl" if two_gpus else "gloo") and r["allreduce_us"] > 0
+    assert [d["rank"] for d in r["devices"]] == [0, 1] and len(r["renders_per_sec_per_rank"]) == 2
+    assert {d["device"] for d in r["devices"]} == ({0, 1} if two_gpus else {0})
+    assert out["grad_config"]["samples_per_step"] == 2 and out["grad_config"]["samples_per_rank"] == 1
+    # without the opt-in, more ranks than devices is refused with a non-zero code and no line
+    if not two_gpus:
+        env.pop("FFX_DIST_BACKEND")
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and bad.stdout.strip() == "" and "only 1 device(s)" in bad.stderr
 
 
 def test_laser_yaml_roundtrip(tmp_path):

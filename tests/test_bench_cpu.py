@@ -66,3 +66,31 @@ def test_traffic_is_keyed_on_the_profiled_workload(bench):
     assert t is not None and t["source"].startswith("r2_") and t["bytes"] >= t["raw_bytes"] > 5.6e6  # more than the algorithmic 5.6 MB
     g = bench.pmc_traffic("k_render_bwd_cached", "grad")
     assert g is not None and g["source"].startswith("r2grad_")
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FFX_DIST_BACKEND")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_self_launcher_refuses_more_ranks_than_devices_and_propagates_failures():
+    """`python bench.py --gpus N` without a torchrun environment starts N rank processes itself (it used to measure ONE
+    GPU and label it n_gpus 1).  On this GPU-less box: more ranks than devices is refused unless FFX_DIST_BACKEND=gloo
+    asks for a rehearsal, and ranks that fail (no HIP device here) end the run with a non-zero code — no line is printed,
+    nothing is restarted."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU box: covered by the -m gpu test")
+    r = _run_bench(["--gpus", "2", "--steps", "2"], {})
+    assert r.returncode != 0 and "only 0 device(s)" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "2", "--steps", "2"], {"FFX_DIST_BACKEND": "gloo"})
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs a HIP device") == 2  # both ranks were started, each failed loudly
+    # inside a torchrun environment the world size must match --gpus
+    r = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
