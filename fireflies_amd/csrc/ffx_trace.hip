@@ -308,6 +308,8 @@ __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(
 struct MatGeo {
   float cos_i, cos_o, ch, ci_h, co_h; // n.wv, n.wl, n.h, wv.h, wl.h
   float tmp, xy_i, xy_o, axay;        // (hx/ax)^2 + (hy/ay)^2 + hz^2, (ax ix)^2 + (ay iy)^2, the same for wl, ax * ay
+  float s2;                           // sin^2(theta_h) = hx^2 + hy^2 — NEVER as 1 - ch^2: near-mirror rows (alpha = 0.0025) and a glossy
+                                      // clearcoat (alpha = 0.001) divide it by alpha^2, which turned the rounding of ch into 0.4 % of a highlight
 };
 __device__ __forceinline__ void material_geometry(const float *__restrict__ m, v3 n, v3 wv, v3 wl, MatGeo &g) {
   g.cos_i = vdot(n, wv);
@@ -324,13 +326,17 @@ __device__ __forceinline__ void material_geometry(const float *__restrict__ m, v
     const float ax = fmaxf(0.001f, bdiv(r2, aspect)), ay = fmaxf(0.001f, r2 * aspect);
     const float sg = copysignf(1.0f, n.z), ca = -brcp(sg + n.z), cb = n.x * n.y * ca;
     const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
-    g.tmp = sqrf(bdiv(vdot(wh, fs), ax)) + sqrf(bdiv(vdot(wh, ft), ay)) + sqrf(g.ch);
+    const float hx = vdot(wh, fs), hy = vdot(wh, ft);
+    g.s2 = sqrf(hx) + sqrf(hy);
+    g.tmp = sqrf(bdiv(hx, ax)) + sqrf(bdiv(hy, ay)) + sqrf(g.ch);
     g.xy_i = sqrf(ax * vdot(wv, fs)) + sqrf(ay * vdot(wv, ft));
     g.xy_o = sqrf(ax * vdot(wl, fs)) + sqrf(ay * vdot(wl, ft));
     g.axay = ax * ay;
   } else {
     const float a2 = sqrf(fmaxf(0.001f, r2));
-    g.tmp = bdiv(fmaxf(1.0f - sqrf(g.ch), 0.f), a2) + sqrf(g.ch);
+    const v3 cx = vcross(n, wh); // |n x h|^2 = sin^2(theta_h), well conditioned at the peak (same order as the oracle's material_geometry)
+    g.s2 = vdot(cx, cx);
+    g.tmp = bdiv(g.s2, a2) + sqrf(g.ch);
     g.xy_i = a2 * fmaxf(1.0f - sqrf(g.cos_i), 0.f);
     g.xy_o = a2 * fmaxf(1.0f - sqrf(g.cos_o), 0.f);
     g.axay = a2;
@@ -385,7 +391,7 @@ __device__ __forceinline__ void material_terms(const float *__restrict__ m, cons
   if (cc > 0.f && facing) { // clearcoat
     const float Fcc = sw + (1.0f - sw) * 0.04f;
     const float alpha = 0.1f + (0.001f - 0.1f) * m[FFX_MAT_CLEARCOAT_GLOSS], a2 = sqrf(alpha), c2 = sqrf(ch);
-    float Dcc = bdiv(a2 - 1.0f, FFX_PI_F * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
+    float Dcc = bdiv(a2 - 1.0f, FFX_PI_F * logf(a2) * (g.s2 + a2 * c2)); // GTR1: 1 + (a2 - 1) cos^2 = sin^2 + a2 cos^2, without the cancellation
     if (!(Dcc * ch > 1e-20f)) Dcc = 0.f;
     const float Gcc = ggx1_cc(cos_i, ci_h) * ggx1_cc(cos_o, co_h);
     b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;

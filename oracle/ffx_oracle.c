@@ -1024,44 +1024,72 @@ static inline float schlick_weight(float c) {
   m = m < 0.f ? 0.f : (m > 1.f ? 1.f : m);
   return sqrf(sqrf(m)) * m;
 }
-static inline float smith_g1_aniso(v3 v, v3 wh, float ax, float ay) { /* microfacet.h smith_g1 */
-  float xy = sqrf(ax * v.x) + sqrf(ay * v.y);
-  float tan2 = xy / sqrf(v.z);
+static inline float smith_g1(float xy, float c, float v_dot_h) { /* microfacet.h smith_g1: xy = (ax v.x)^2 + (ay v.y)^2, c = v.z */
+  float tan2 = xy / sqrf(c);
   float r = 2.0f / (1.0f + sqrtf(1.0f + tan2));
   if (xy == 0.f) r = 1.f;
-  if (vdot(v, wh) * v.z <= 0.f) r = 0.f;
+  if (v_dot_h * c <= 0.f) r = 0.f;
   return r;
 }
-static inline float smith_ggx1(v3 v, v3 wh, float alpha) { /* principledhelpers.h smith_ggx1 */
-  float a2 = sqrf(alpha), c = fabsf(v.z), c2 = sqrf(c);
+static inline float smith_ggx1(float c_in, float v_dot_h, float alpha) { /* principledhelpers.h smith_ggx1, c_in = v.z */
+  float a2 = sqrf(alpha), c = fabsf(c_in), c2 = sqrf(c);
   float tan2 = (1.0f - c2) / c2;
   float r = 2.0f / (1.0f + sqrtf(1.0f + a2 * tan2));
-  if (v.z == 1.f) r = 1.f;
-  if (vdot(v, wh) * v.z <= 0.f) r = 0.f;
+  if (c_in == 1.f) r = 1.f;
+  if (v_dot_h * c_in <= 0.f) r = 0.f;
   return r;
 }
+/* Geometry of a (viewer, emitter) pair.  The half vector is formed in WORLD space and reduced to scalars in the same
+ * operation order as material_geometry of ffx_trace.hip (round 3: the two had formed cos(theta_h) in different frames and
+ * the kernel took sin^2 = 1 - cos^2, which near-mirror rows — alpha = 0.0025 — amplify to 0.4 % of a highlight):
+ *   - sin^2(theta_h) is never 1 - cos^2: isotropic rows take |n x h|^2, anisotropic ones hx^2 + hy^2 in the shading frame
+ *     coordinate_system(n) (Duff et al.); both are well conditioned where the GGX / GTR1 peaks live;
+ *   - isotropic rows need no tangent frame: (hx/a)^2 + (hy/a)^2 = sin^2 / a^2, (a v.x)^2 + (a v.y)^2 = a^2 (1 - cos^2 v). */
+typedef struct { float cos_i, cos_o, ch, ci_h, co_h, s2, tmp, xy_i, xy_o, axay; } mat_geo;
+static void material_geometry(const float *m, v3 n, v3 wv, v3 wl, mat_geo *g) {
+  g->cos_i = vdot(n, wv);
+  g->cos_o = vdot(n, wl);
+  v3 wh = V3(wv.x + wl.x, wv.y + wl.y, wv.z + wl.z);
+  const float ihl = 1.0f / sqrtf(vdot(wh, wh));
+  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
+  g->ci_h = vdot(wv, wh);
+  g->co_h = vdot(wl, wh);
+  g->ch = vdot(n, wh);
+  const float r2 = sqrf(m[FFX_MAT_ROUGHNESS]), aniso = m[FFX_MAT_ANISOTROPIC];
+  if (aniso != 0.f) { /* calc_dist_params + the shading frame */
+    const float aspect = sqrtf(1.0f - 0.9f * aniso);
+    const float ax = fmaxf(0.001f, r2 / aspect), ay = fmaxf(0.001f, r2 * aspect);
+    const float sg = copysignf(1.0f, n.z), ca = -1.0f / (sg + n.z), cb = n.x * n.y * ca;
+    const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+    const float hx = vdot(wh, fs), hy = vdot(wh, ft);
+    g->s2 = sqrf(hx) + sqrf(hy);
+    g->tmp = sqrf(hx / ax) + sqrf(hy / ay) + sqrf(g->ch);
+    g->xy_i = sqrf(ax * vdot(wv, fs)) + sqrf(ay * vdot(wv, ft));
+    g->xy_o = sqrf(ax * vdot(wl, fs)) + sqrf(ay * vdot(wl, ft));
+    g->axay = ax * ay;
+  } else {
+    const float a2 = sqrf(fmaxf(0.001f, r2));
+    const v3 cx = vcross(n, wh);
+    g->s2 = vdot(cx, cx);
+    g->tmp = g->s2 / a2 + sqrf(g->ch);
+    g->xy_i = a2 * fmaxf(1.0f - sqrf(g->cos_i), 0.f);
+    g->xy_o = a2 * fmaxf(1.0f - sqrf(g->cos_o), 0.f);
+    g->axay = a2;
+  }
+}
 static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, float *A, float *B) {
-  const float cos_i = vdot(n, wv), cos_o = vdot(n, wl);
   *A = 0.f; *B = 0.f;
-  if (mat_stride != FFX_MAT_STRIDE || m[FFX_MAT_MODEL] == 0.f) { *A = cos_o; return; } /* Lambert: pi * (1/pi) * cos_o */
+  if (mat_stride != FFX_MAT_STRIDE || m[FFX_MAT_MODEL] == 0.f) { *A = vdot(n, wl); return; } /* Lambert: pi * (1/pi) * cos_o */
+  mat_geo g;
+  material_geometry(m, n, wv, wl, &g);
+  const float cos_i = g.cos_i, cos_o = g.cos_o, ci_h = g.ci_h, co_h = g.co_h;
   if (!(cos_i > 0.f && cos_o > 0.f)) return;
-  const float rough = m[FFX_MAT_ROUGHNESS], aniso = m[FFX_MAT_ANISOTROPIC], metallic = m[FFX_MAT_METALLIC], spec_trans = m[FFX_MAT_SPEC_TRANS];
+  const float rough = m[FFX_MAT_ROUGHNESS], metallic = m[FFX_MAT_METALLIC], spec_trans = m[FFX_MAT_SPEC_TRANS];
   const float eta = m[FFX_MAT_ETA], spec_tint = m[FFX_MAT_SPEC_TINT], sheen = m[FFX_MAT_SHEEN], sheen_tint = m[FFX_MAT_SHEEN_TINT];
   const float flat = m[FFX_MAT_FLATNESS], cc = m[FFX_MAT_CLEARCOAT], ccg = m[FFX_MAT_CLEARCOAT_GLOSS];
   const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
   const float brdf = (1.0f - metallic) * (1.0f - spec_trans);
-  /* shading frame: coordinate_system(n) (Duff et al.) */
-  const float sg = copysignf(1.0f, n.z), ca = -1.0f / (sg + n.z), cb = n.x * n.y * ca;
-  const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
-  const v3 wi = V3(vdot(wv, fs), vdot(wv, ft), cos_i), wo = V3(vdot(wl, fs), vdot(wl, ft), cos_o);
-  v3 wh = V3(wi.x + wo.x, wi.y + wo.y, wi.z + wo.z);
-  const float ihl = 1.0f / sqrtf(vdot(wh, wh));
-  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
-  const float ci_h = vdot(wi, wh), co_h = vdot(wo, wh);
   const int facing = ci_h * cos_i > 0.f && co_h * cos_o > 0.f;
-  /* calc_dist_params */
-  const float r2 = sqrf(rough), aspect = sqrtf(1.0f - 0.9f * aniso);
-  const float ax = fmaxf(0.001f, r2 / aspect), ay = fmaxf(0.001f, r2 * aspect);
   /* Schlick weight as calc_schlick takes it (cos >= 0: outside) */
   float sw;
   if (eta > 1.0f) sw = schlick_weight(fabsf(ci_h));
@@ -1082,10 +1110,9 @@ static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, fl
     else if (c == 0.f) F_d = 1.f;
   }
   if (facing && F_d > 0.f) { /* main specular reflection lobe */
-    const float tmp = sqrf(wh.x / ax) + sqrf(wh.y / ay) + sqrf(wh.z);
-    float D = 1.0f / (FFX_PI * (ax * ay) * sqrf(tmp));
-    if (!(D * wh.z > 1e-20f)) D = 0.f;
-    const float G = smith_g1_aniso(wi, wh, ax, ay) * smith_g1_aniso(wo, wh, ax, ay);
+    float D = 1.0f / (FFX_PI * g.axay * sqrf(g.tmp)); /* microfacet.h GGX eval: tmp = (hx/ax)^2 + (hy/ay)^2 + hz^2 */
+    if (!(D * g.ch > 1e-20f)) D = 0.f;
+    const float G = smith_g1(g.xy_i, cos_i, ci_h) * smith_g1(g.xy_o, cos_o, co_h);
     const float common = D * G / (4.0f * cos_i);
     const float R0 = sqrf((eta - 1.0f) / (eta + 1.0f));
     float Fa = metallic * (1.0f - sw), Fb = metallic * sw;
@@ -1097,10 +1124,11 @@ static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, fl
   }
   if (cc > 0.f && facing) { /* clearcoat */
     const float Fcc = sw + (1.0f - sw) * 0.04f;
-    const float alpha = 0.1f + (0.001f - 0.1f) * ccg, a2 = sqrf(alpha), c2 = sqrf(wh.z);
-    float Dcc = (a2 - 1.0f) / (FFX_PI * logf(a2) * (1.0f + (a2 - 1.0f) * c2));
-    if (!(Dcc * wh.z > 1e-20f)) Dcc = 0.f;
-    const float Gcc = smith_ggx1(wi, wh, 0.25f) * smith_ggx1(wo, wh, 0.25f);
+    const float alpha = 0.1f + (0.001f - 0.1f) * ccg, a2 = sqrf(alpha), c2 = sqrf(g.ch);
+    /* GTR1Isotropic: 1 + (a2 - 1) cos^2 = sin^2 + a2 cos^2, taken in the form that does not cancel at the peak (alpha down to 0.001) */
+    float Dcc = (a2 - 1.0f) / (FFX_PI * logf(a2) * (g.s2 + a2 * c2));
+    if (!(Dcc * g.ch > 1e-20f)) Dcc = 0.f;
+    const float Gcc = smith_ggx1(cos_i, ci_h, 0.25f) * smith_ggx1(cos_o, co_h, 0.25f);
     b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
   }
   const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from fireflies_amd import ops, scenes, scene_desc
-from tests.conftest import load_golden
+from tests.conftest import assert_image_close, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -196,19 +196,7 @@ def test_k3_blur(oracle):
     np.testing.assert_array_equal(host(ops.blur_fwd(dev(a), 9, 2.0)), oracle.blur_fwd(a, 9, 2.0))
 
 
-def _assert_image_close(img_d, img_o, spp, frac=2e-4, rel=1e-4, what=""):
-    """radiance: `rel` of the image scale per pixel (fp32 reassociation of the sample sum, ulp-level libm
-    differences) for all but `frac` of the pixels; and NO pixel may be off by more than what one or two
-    samples whose hit or shadow test flips at an edge can cause: a sample carries 1/spp of its pixel, and
-    a single sample is at most ~1.5x the brightest pixel mean, so the bound is 1.5 * scale / spp (it was a
-    flat 0.2 * scale: at 64 spp this is 8x tighter)."""
-    scale = float(img_o.max())
-    assert scale > 0, what
-    err = np.abs(img_d.astype(np.float64) - img_o.astype(np.float64))
-    bad = float((err > rel * scale).mean())
-    assert bad <= frac, f"{what}: {bad:.2e} of the pixel channels differ by more than {rel:g} of the scale"
-    assert err.max() <= 1.5 * scale / spp, f"{what}: worst pixel off by {err.max() / scale:.3f} of the scale (bound {1.5 / spp:.3f})"
-    return scale, err
+_assert_image_close = assert_image_close  # (tests/conftest.py)
 
 
 # ------------------------------------------------------------------ K5..K7
@@ -537,6 +525,20 @@ def test_full_size_parity_with_the_oracle_at_512x512x64(oracle):
         img_d = host(gd.render_fwd(sd, dev(alb), tex, 64, seed=i))
         img_o = go.render_fwd(sd, alb, host(tex), 64, seed=i)
         _assert_image_close(img_d, img_o, 64, what=f"pose {i}")
+        # ... and the kernel bench.py times: k_render_fwd_pk<1, wide, MATERIAL ROWS>, with the rows the bench's scene carries —
+        # Mitsuba's principled BSDF under the reference's vocal-fold randomisation (examples/vocalfold_scene.py:86-93:
+        # base colour between the two tissue tones, specular 0 .. 0.75; roughness 0.5) — and, on the last pose, near-mirror
+        # rows (roughness 0.05: GGX alpha 0.0025, the case that used to differ by 0.4 % of a highlight)
+        mats = np.zeros((2, 16), np.float32)
+        mats[:, 0:3] = rng.uniform([0.8, 0.14, 0.34], [0.85, 0.5, 0.44], (2, 3))
+        mats[:, 3] = 1.0
+        mats[:, 4] = 0.5 if i < 2 else 0.05
+        spec = rng.uniform(0.0, 0.75, 2)
+        mats[:, 8] = 2.0 / (1.0 - np.sqrt(0.08 * spec)) - 1.0
+        sdm = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16)
+        img_d = host(gd.render_fwd(sdm, dev(mats), tex, 64, seed=i))
+        img_o = go.render_fwd(sdm, mats, host(tex), 64, seed=i)
+        _assert_image_close(img_d, img_o, 64, what=f"pose {i}, material rows")
     assert total == 3 * 512 * 512 * 64
     assert lost == 0, f"{lost} rays hit in the oracle and missed on the GPU"
     assert flips <= 2, f"{flips} of {total} rays hit a different primitive"
@@ -855,7 +857,7 @@ def test_principled_materials_match_the_oracle(oracle, env, ch, monkeypatch):
             sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=shadows, mat_stride=16)
             img_o = go.render_fwd(sd, mats, host(tex), spp, seed=3)
             img_d = host(gd.render_fwd(sd, dev(mats), tex, spp, seed=3))
-            scale, _ = _assert_image_close(img_d, img_o, spp, frac=1e-3, rel=2e-4, what=f"{env} materials")
+            scale, _ = _assert_image_close(img_d, img_o, spp, frac=2e-4, rel=1e-4, what=f"{env} materials")
             assert scale > 0.02
             # not the Lambert image
             sd3 = scene_desc.scene_desc(sc, tex_channels=ch, shadows=shadows)
@@ -900,7 +902,7 @@ def test_principled_materials_mid_size_and_abi_errors(oracle):
     sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16)
     img_d = host(gd.render_fwd(sd, dev(mats), tex, 64, seed=12))
     img_o = go.render_fwd(sd, mats, host(tex), 64, seed=12)
-    scale, err = _assert_image_close(img_d, img_o, 64, frac=5e-4, rel=2e-4, what="materials 256x256x64")
+    scale, err = _assert_image_close(img_d, img_o, 64, frac=2e-4, rel=1e-4, what="materials 256x256x64")
     assert scale > 0.05 and float(err.mean()) < 2e-6 * scale
     # ---- refusals
     from fireflies_amd import _lib
