@@ -96,26 +96,49 @@ def _kernel_ms(events, name):
     return (sum(ms) / len(ms), len(ms)) if ms else (None, 0)
 
 
-PROFILED_WORKLOAD = {"workload": "vocalfold", "res": 512, "spp": 64, "material": "principled"}  # what tools/collect_profiles.sh runs (bench.py defaults)
+# Workloads that tools/collect_profiles.sh has committed rocprofv3 passes for, and the key that names them in profiles/:
+#   profiles/r<N>_*          bench.py's defaults (configs[1]/[2]: vocal fold, 512x512, 64 spp, principled material)
+#   profiles/r<N>colon_*     configs[4] (--workload colon --res 1024 --spp 256 --grid 32 --fp16, principled mucosa)
+# (+ "grad" in front of the underscore for the gradient bracket's PMC passes)
+PROFILED_WORKLOADS = {
+    "": {"workload": "vocalfold", "res": 512, "spp": 64, "fp16": False, "material": "principled"},
+    "colon": {"workload": "colon", "res": 1024, "spp": 256, "fp16": True, "material": "principled"},
+}
+PROFILED_WORKLOAD = PROFILED_WORKLOADS[""]
+
+
+def profile_key(args):
+    """"" / "colon": which committed profile set describes this run's workload; None: none does"""
+    if args.no_shadows:
+        return None
+    for key, w in PROFILED_WORKLOADS.items():
+        if all(getattr(args, k) == v for k, v in w.items()) and (key != "colon" or args.grid == 32):
+            return key
+    return None
 
 
 def _is_profiled_workload(args):
-    return (args.workload == "vocalfold" and args.res == 512 and args.spp == 64 and not args.fp16 and not args.no_shadows
-            and args.material == PROFILED_WORKLOAD["material"])
+    return profile_key(args) == ""
 
 
-def pmc_traffic(kernel_prefix, tag="r"):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
-    written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at its
-    default workload; FETCH_SIZE doubled as MI355X_MICROARCH.md HBM section prescribes for gfx950).  The caller
-    only asks for the workload those passes ran (PROFILED_WORKLOAD).  None if no profile is present."""
+def _profile_files(suffix, key="", grad=False):
+    """committed summaries profiles/r<N><key>[grad]_<suffix>, oldest round first"""
     import glob
+    import re
 
+    pat = re.compile(r"^r(\d+)" + re.escape(key or "") + ("grad" if grad else "") + "_" + re.escape(suffix) + "$")
+    hits = [(int(pat.match(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "*_" + suffix)) if pat.match(os.path.basename(f))]
+    return [f for _, f in sorted(hits)]
+
+
+def pmc_traffic(kernel_prefix, tag="r", key=""):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
+    written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at the workload
+    `key` names; FETCH_SIZE doubled as MI355X_MICROARCH.md HBM section prescribes for gfx950).  The caller
+    only asks for a workload those passes ran (profile_key).  None if no profile is present."""
     best = None
-    # "<round>_pmc_summary.json" = render bracket only, "<round>grad_pmc_summary.json" = gradient bracket
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    files = [f for f in files if os.path.basename(f).split("_")[0].endswith("grad") == (tag == "grad")]
-    for f in files:
+    # "<round><key>_pmc_summary.json" = render bracket only, "<round><key>grad_pmc_summary.json" = gradient bracket
+    for f in _profile_files("pmc_summary.json", key, grad=(tag == "grad")):
         try:
             d = json.load(open(f))
         except Exception:
@@ -136,16 +159,14 @@ VALU_CYCLES = {"fast": 2.0, "slow": 4.0, "trans": 8.0}
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
-def valu_issue(kernel_substr, kernel_ms):
+def valu_issue(kernel_substr, kernel_ms, key=""):
     """Compute-side view of the dominant kernel (it is VALU-issue bound, which the contract's hbm|mfma roofline
     cannot express).  Ceiling = the time the kernel's OWN instruction mix needs if every instruction issued at the
     best rate measured for its class: the SQ counters of the newest committed pass (profiles/*_sq_instruction_mix.json,
     same workload) give wave-level counts per launch; every fma/mul/add is priced as the VGPR-only form (2 cycles)
     although many carry a scalar operand (4) — the ceiling is optimistic, so frac = ceiling / live kernel time
     is a lower bound of the issue utilisation and cannot exceed 1."""
-    import glob
-
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_instruction_mix.json")), reverse=True):
+    for f in reversed(_profile_files("sq_instruction_mix.json", key)):
         try:
             d = json.load(open(f))
         except Exception:
@@ -166,7 +187,7 @@ def valu_issue(kernel_substr, kernel_ms):
                         "ceiling_ms": ceil_ms, "kernel_ms": kernel_ms, "frac": ceil_ms / kernel_ms,
                         "salu_per_launch": g("SQ_INSTS_SALU"), "smem_per_launch": g("SQ_INSTS_SMEM"), "vmem_per_launch": g("SQ_INSTS_VMEM"),
                         "lds_per_launch": g("SQ_INSTS_LDS"),
-                        "source": f"counts: profiles/{os.path.basename(f)} (committed rocprofv3 --pmc passes, not this run); rates: profiles/r2_issue_rates.txt; time: this run"}
+                        "source": f"counts: profiles/{os.path.basename(f)} (committed rocprofv3 --pmc passes of this workload, not this run); rates: profiles/r2_issue_rates.txt; time: this run"}
     return None
 
 
@@ -345,6 +366,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus, sys.argv[1:])  # never returns
     _load_product()
+    pkey = profile_key(args)
     rank, world, local = dist.env_rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -445,13 +467,13 @@ def main():
                 "lit_pixels": n_lit, "stray_samples": n_stray,
                 "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
-                "traffic": (pmc_traffic("k_render_bwd_cached", "grad") or {}).get("bytes") if _is_profiled_workload(args) else None},
+                "traffic": (pmc_traffic("k_render_bwd_cached", "grad", pkey) or {}).get("bytes") if pkey is not None else None},
         }
 
     if rank != 0:
         return
     achieved = bytes_["render_fwd"] / (k8_ms * 1e-3) / 1e9
-    traffic = pmc_traffic("k_render_fwd_pk") if _is_profiled_workload(args) else None  # the committed PMC passes ran the default workload only
+    traffic = pmc_traffic("k_render_fwd_pk", "r", pkey) if pkey is not None else None  # only workloads the committed PMC passes ran
     out = {
         "metric": "renders/sec @512x512,64spp vocal-fold (+ pattern-grad-steps/sec in grad_steps_per_sec); HBM GB/s vs peak in roofline",
         "value": renders_per_sec,
@@ -486,12 +508,12 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None if traffic is None else traffic["bytes"],
-            "traffic_source": ("no committed PMC pass for this workload" if not _is_profiled_workload(args) else None) if traffic is None else
+            "traffic_source": ("no committed PMC pass for this workload" if pkey is None else f"no profiles/r*{pkey}_pmc_summary.json yet") if traffic is None else
             f"profiles/{traffic['source']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at this workload, not this run; raw {traffic['raw_bytes']:.0f} B, FETCH_SIZE x2 gfx950 correction)",
             "algorithmic_bytes_per_launch": bytes_["render_fwd"],
             "avg_kernel_ms": k8_ms,
             "launches_timed": k8_n,
-            "valu_issue": valu_issue("k_render_fwd_pk", k8_ms) if _is_profiled_workload(args) else None,
+            "valu_issue": valu_issue("k_render_fwd_pk", k8_ms, pkey) if pkey is not None else None,
             "note": "by design NOT HBM-bound: samples are reduced in registers, so compulsory traffic is ~6 MB per render; the kernel is "
                     "VALU-issue bound (valu_issue below; SQ counters in profiles/r2_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),

@@ -13,8 +13,12 @@ module reads what those scene files contain so that `mi.load_file(path)` keeps w
   <transform>                    <matrix value="16 floats">, <lookat origin target up>, <translate>, <scale>,
                                  <rotate x|y|z angle>  (applied in document order, like Mitsuba)
   <default name value>, $name substitution, <integer|float|string|rgb|boolean name value>
+  <integrator>                   read for what it implies: direct illumination at the primary hit is what is rendered
+                                 (path / prb / direct with max_depth 2); anything deeper is reported
+  <film> <rfilter>, <sampler>    box filter and independent sampler are what is implemented; others are reported
+  fov_axis                       x (Mitsuba's default), y, smaller, larger, diagonal: converted to the horizontal angle
 
-Anything else is ignored with a warning; nothing here touches the GPU.
+Every node or property that is dropped is reported with a warning (once per kind and file); nothing here touches the GPU.
 """
 import os
 import re
@@ -266,6 +270,10 @@ def _albedo_of(bsdf, bsdfs):
     while inner.get("type") in ("twosided", "bumpmap", "normalmap", "mask") and _child(inner, "bsdf") is not None:
         inner = _child(inner, "bsdf")
     p = _props(inner)
+    for c in inner:
+        if c.tag == "texture" and c.get("name"):
+            warnings.warn(f"bsdf {bsdf.get('id') or inner.get('type')!r}: texture-valued parameter {c.get('name')!r} is not read from the file (bitmap files are not "
+                          "loaded): its default is used — assign params['<mat>.brdf_0.base_color.data'] for a textured base colour")
     col = p.get("reflectance", p.get("base_color", p.get("diffuse_reflectance", (0.5, 0.5, 0.5))))
     if isinstance(col, float):
         col = (col,) * 3
@@ -277,10 +285,80 @@ def _albedo_of(bsdf, bsdfs):
     return tuple(col), bsdf.get("id") or "mat-Default", params
 
 
+_SENSOR_PROPS = {"fov", "fov_axis", "near_clip", "far_clip", "focus_distance", "principal_point_offset_x", "principal_point_offset_y"}
+_FILM_PROPS = {"width", "height", "pixel_format", "component_format", "file_format", "sample_border", "compensate", "crop_offset_x", "crop_offset_y", "crop_width", "crop_height"}
+_SHAPE_PROPS = {"filename", "face_normals", "flip_tex_coords", "flip_normals"}
+_SPOT_PROPS = {"intensity", "cutoff_angle", "beam_width"}
+_PROJ_PROPS = {"fov", "scale", "fov_axis"}
+
+
+def _fov_x(fov, axis, width, height):
+    """the horizontal field of view (degrees) of a perspective sensor whose `fov` is measured along `fov_axis`
+    (Mitsuba: x [default], y, diagonal, smaller, larger)"""
+    if axis in (None, "x"):
+        return float(fov)
+    w, h = float(width), float(height)
+    if axis == "smaller":
+        axis = "x" if w <= h else "y"
+    elif axis == "larger":
+        axis = "x" if w >= h else "y"
+    if axis == "x":
+        return float(fov)
+    t = np.tan(np.deg2rad(float(fov)) * 0.5)
+    if axis == "y":
+        tx = t * w / h
+    elif axis == "diagonal":
+        tx = t * w / np.hypot(w, h)
+    else:
+        raise ValueError(f"unknown fov_axis {axis!r}")
+    return float(np.rad2deg(2.0 * np.arctan(tx)))
+
+
+class _Dropped:
+    """collects what the reader does not honour and reports each kind once"""
+
+    def __init__(self, path):
+        self.path, self.seen = path, set()
+
+    def __call__(self, kind, msg):
+        if kind not in self.seen:
+            self.seen.add(kind)
+            warnings.warn(f"{os.path.basename(self.path)}: {msg}", stacklevel=4)
+
+    def props(self, node, known, what):
+        for c in node:
+            if c.tag in ("float", "integer", "string", "boolean", "rgb", "spectrum", "point", "vector") and c.get("name") and c.get("name") not in known:
+                self((what, c.get("name")), f"{what} property {c.get('name')!r} is ignored")
+
+
+def _check_integrator(node, dropped, notes):
+    """direct illumination at the primary hit from the two delta emitters is what the kernels evaluate: Mitsuba's path / prb
+    with max_depth = 2, or `direct`.  Mitsuba's defaults (max_depth -1 = unbounded) and anything deeper would add indirect
+    light that is not rendered here: say so."""
+    t = node.get("type")
+    p = _props(node)
+    notes["integrator"] = {"type": t, **{k: v for k, v in p.items() if isinstance(v, (int, float, str, bool))}}
+    if t in ("path", "prb", "prb_basic", "volpath", "prbvolpath", "prb_reparam", "direct_reparam", "direct_projective", "prb_projective"):
+        md = int(p.get("max_depth", -1))
+        if md < 0 or md > 2:
+            dropped("integrator.max_depth", f"<integrator type={t!r}> with max_depth {md if md >= 0 else '-1 (unbounded)'}: only direct illumination at the "
+                                            "primary hit is rendered (= max_depth 2); indirect bounces are not")
+        if t.endswith("reparam") or t.endswith("projective"):
+            dropped("integrator.reparam", f"<integrator type={t!r}>: visibility-discontinuity gradients are not computed (gradients flow through the projector texture only)")
+    elif t == "direct":
+        pass
+    elif t in ("aov", "moment", "stokes"):
+        dropped("integrator.type", f"<integrator type={t!r}> wrapper ignored: only the radiance image is rendered")
+    else:
+        dropped("integrator.type", f"<integrator type={t!r}> is not implemented: direct illumination at the primary hit is rendered instead")
+
+
 def load_mitsuba_xml(path):
     """-> scenes.SceneData.  Sensor 0 is the camera; a second perspective sensor, if present, is the
-    projector proxy whose film size is the projector texture size (examples/vocalfold_scene.py:24-38)."""
-    text = open(path, "r").read()
+    projector proxy whose film size is the projector texture size (examples/vocalfold_scene.py:24-38).
+    Whatever the file asks for that is not honoured is reported (warnings.warn), never dropped silently."""
+    with open(path, "r") as f:
+        text = f.read()
     defaults = dict(re.findall(r'<default\s+name="([^"]+)"\s+value="([^"]*)"', text))
     for k, v in defaults.items():
         text = text.replace("$" + k, v)
@@ -288,21 +366,64 @@ def load_mitsuba_xml(path):
     base = os.path.dirname(os.path.abspath(path))
     bsdfs = {b.get("id"): b for b in root.iter("bsdf") if b.get("id")}
     sensors, meshes, spot, projector, proj_scale = [], [], None, None, 1.0
+    dropped = _Dropped(path)
+    notes = {"source": path}
+    have_integrator = False
     for node in root:
         if node.tag == "sensor":
             if node.get("type") != "perspective":
-                warnings.warn(f"sensor type {node.get('type')!r} ignored")
+                dropped(("sensor", node.get("type")), f"sensor type {node.get('type')!r} ignored")
                 continue
             p = _props(node)
+            dropped.props(node, _SENSOR_PROPS, "sensor")
             film = _child(node, "film")
             fp = _props(film) if film is not None else {}
+            width, height = int(fp.get("width", 768)), int(fp.get("height", 576))
+            if film is not None:
+                dropped.props(film, _FILM_PROPS, "film")
+                if film.get("type") not in (None, "hdrfilm"):
+                    dropped(("film", film.get("type")), f"film type {film.get('type')!r}: an hdrfilm-like float RGB image is produced")
+                if any(k in fp for k in ("crop_offset_x", "crop_offset_y", "crop_width", "crop_height")):
+                    dropped("film.crop", "film crop window ignored: the full film is rendered")
+                rf = _child(film, "rfilter")
+                rtype = rf.get("type") if rf is not None else "gaussian"  # Mitsuba's default film filter
+                if rtype != "box" and not sensors:  # (the camera's film; a projector proxy's film is only a texture size)
+                    dropped("rfilter", f"reconstruction filter {rtype!r}{'' if rf is not None else ' (the hdrfilm default)'}: the BOX filter is used — every sample counts "
+                                       "for its own pixel only; Mitsuba's image would be smoother across pixel edges (equal in the mean).  "
+                                       "Declare <rfilter type=\"box\"/> for the like-for-like case")
+                notes.setdefault("rfilter", rtype)
+            for extra in node:
+                if extra.tag == "sampler":
+                    if extra.get("type") not in ("independent",):
+                        dropped("sampler", f"sampler type {extra.get('type')!r}: the independent (counter-based, per-sample hash) sampler is used")
+                    if "sample_count" in _props(extra):
+                        notes.setdefault("sample_count", int(_props(extra)["sample_count"]))
+                elif extra.tag not in ("film", "transform", "float", "integer", "string", "boolean", "ref"):
+                    dropped(("sensor-child", extra.tag), f"<{extra.tag}> inside <sensor> ignored")
+            if "principal_point_offset_x" in p or "principal_point_offset_y" in p:
+                if float(p.get("principal_point_offset_x", 0.0)) != 0.0 or float(p.get("principal_point_offset_y", 0.0)) != 0.0:
+                    dropped("principal_point", "principal_point_offset_x/y ignored: the principal point is the film centre")
             name = node.get("id") or ("PerspectiveCamera" if not sensors else f"PerspectiveCamera_{len(sensors)}")
-            sensors.append(scenes.SensorData(name, _transform(_child(node, "transform", "to_world")), float(p.get("fov", 45.0)), float(p.get("near_clip", 0.01)),
-                                             float(p.get("far_clip", 1e4)), int(fp.get("width", 768)), int(fp.get("height", 576))))
+            sensors.append(scenes.SensorData(name, _transform(_child(node, "transform", "to_world")), _fov_x(p.get("fov", 45.0), p.get("fov_axis"), width, height),
+                                             float(p.get("near_clip", 0.01)), float(p.get("far_clip", 1e4)), width, height))
+        elif node.tag == "integrator":
+            have_integrator = True
+            _check_integrator(node, dropped, notes)
+        elif node.tag in ("bsdf", "default"):
+            pass  # top-level BSDF definitions are resolved through <ref>; <default> was substituted above
+        elif node.tag == "texture":
+            dropped("texture", "top-level <texture> ignored: textures as BSDF parameter values are set through params['<mat>.brdf_0.base_color.data'] (mi.py), "
+                               "bitmap files are not read")
         elif node.tag == "shape":
             if node.get("type") not in ("obj", "ply"):
                 raise NotImplementedError(f"shape type {node.get('type')!r}: only OBJ and PLY meshes are read")
             p = _props(node)
+            dropped.props(node, _SHAPE_PROPS, "shape")
+            for extra in node:
+                if extra.tag == "emitter":
+                    dropped("area-emitter", "area emitter on a shape ignored: only the delta emitters (projector, spot) illuminate the scene")
+                elif extra.tag in ("medium", "sensor"):
+                    dropped(("shape-child", extra.tag), f"<{extra.tag}> inside <shape> ignored")
             v, t = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]))
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
@@ -312,15 +433,23 @@ def load_mitsuba_xml(path):
             p = _props(node)
             tw = _transform(_child(node, "transform", "to_world"))
             if node.get("type") == "spot":
+                dropped.props(node, _SPOT_PROPS, "spot emitter")
+                if _child(node, "texture") is not None:
+                    dropped("spot.texture", "spot emitter texture ignored: a plain spot light is rendered")
                 inten = p.get("intensity", (1.0, 1.0, 1.0))
                 inten = (inten,) * 3 if isinstance(inten, float) else inten
                 cutoff = float(p.get("cutoff_angle", 20.0))
                 spot = scenes.SpotData(node.get("id") or "emit-Spot", tw, tuple(inten), cutoff, float(p.get("beam_width", cutoff * 0.75)))
             elif node.get("type") == "projector":
-                projector = (tw, float(p.get("fov", 45.0)))
+                dropped.props(node, _PROJ_PROPS, "projector emitter")
+                projector = (tw, float(p.get("fov", 45.0)), p.get("fov_axis"))
                 proj_scale = float(p.get("scale", 1.0))
             else:
-                warnings.warn(f"emitter type {node.get('type')!r} ignored")
+                dropped(("emitter", node.get("type")), f"emitter type {node.get('type')!r} ignored: only `projector` and `spot` emitters illuminate the scene")
+        else:
+            dropped(("top", node.tag), f"top-level <{node.tag}> ignored")
+    if not have_integrator:
+        dropped("integrator.default", "no <integrator>: Mitsuba would run `path` with unbounded depth; only direct illumination at the primary hit is rendered (= max_depth 2)")
     if not sensors:
         raise ValueError(f"{path}: no perspective sensor")
     if not meshes:
@@ -329,6 +458,11 @@ def load_mitsuba_xml(path):
     if projector is not None:
         proxy = sensors[1] if len(sensors) > 1 else None
         w, h = (proxy.width, proxy.height) if proxy is not None else (500, 500)
-        proj = scenes.SensorData(proxy.name if proxy is not None else "PerspectiveCamera_1", projector[0], proxy.fov_x if proxy is not None else projector[1],
+        proj = scenes.SensorData(proxy.name if proxy is not None else "PerspectiveCamera_1", projector[0],
+                                 proxy.fov_x if proxy is not None else _fov_x(projector[1], projector[2], w, h),
                                  proxy.near if proxy is not None else 0.01, proxy.far if proxy is not None else 1e4, w, h)
-    return scenes.SceneData(meshes, sensors[0], proj, spot, proj_scale, notes={"source": path})
+    for m in meshes:
+        if m.bsdf is not None and float(m.bsdf.get("spec_trans", 0.0)) > 0.0:
+            dropped("spec_trans", f"material {m.material!r}: spec_trans > 0 — the principled BSDF's transmission lobe is not evaluated; spec_trans only scales the "
+                                  "diffuse lobe (DESIGN.md 4.3)")
+    return scenes.SceneData(meshes, sensors[0], proj, spot, proj_scale, notes=notes)

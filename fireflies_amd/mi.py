@@ -314,6 +314,8 @@ class Scene:
         rows = scenes.material_rows(data)
         self._mat_stride = 3 if rows is None else scenes.MAT_STRIDE
         alb = alb if rows is None else rows
+        if rows is not None and (rows[:, scenes.MAT_COLUMN["spec_trans"]] > 0).any():
+            self._warn_spec_trans("scene materials")
         self.albedo = torch.from_numpy(alb).to(self.device)
         self._albedo_host = alb.copy()
         self._albedo_ring = None
@@ -433,6 +435,8 @@ class Scene:
                     col = scenes.MAT_COLUMN[name]
                 else:
                     raise KeyError(f"{k}: not a parameter of the principled BSDF")
+                if name == "spec_trans" and v > 0.0:
+                    self._warn_spec_trans(k)
                 for i in self._material_meshes[base]:
                     self._albedo_host[i, col] = v
                 albedo_dirty = True
@@ -450,6 +454,16 @@ class Scene:
                 self._albedo_ring = _PinnedRing(tuple(self._albedo_host.shape))
             self._albedo_ring.upload(self._albedo_host, self.albedo)
         self._sd_cache = None
+
+    def _warn_spec_trans(self, what):
+        """once per scene: the transmission lobe of `spec_trans` is not evaluated (main.py:105 randomises it 0 .. 0.4)"""
+        if not getattr(self, "_warned_spec_trans", False):
+            import warnings
+
+            warnings.warn(f"{what}: spec_trans > 0 — the principled BSDF's TRANSMISSION lobe is not evaluated here (both emitters are on the "
+                          "viewer's side of an opaque surface, refraction through the mesh is not traced); spec_trans only scales the diffuse "
+                          "lobe by (1 - spec_trans), as the plugin's reflection side does (DESIGN.md 4.3).  Not reported again for this scene.", stacklevel=5)
+            self._warned_spec_trans = True
 
     # ------------------------------------------------------------------ render-time blocks
     def _mat(self, key):

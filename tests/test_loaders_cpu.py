@@ -136,3 +136,54 @@ def test_ply_ascii_binary_and_polygons(tmp_path):
     (tmp_path / "scene.xml").write_text(XML.replace('<shape type="obj" id="mesh-Wall">', '<shape type="ply" id="mesh-Wall">').replace("wall.obj", "wall.ply"))
     sc = loaders.load_mitsuba_xml(str(tmp_path / "scene.xml"))
     assert sc.meshes[0].name == "mesh-Wall" and sc.meshes[0].tris.shape[0] == wt.shape[0]
+
+
+def test_nothing_the_file_asks_for_is_dropped_silently(tmp_path):
+    """Every node or property of a scene file that the reader does not honour is reported (round 2 dropped <integrator>,
+    <rfilter>, <sampler> and fov_axis without a word): deep integrators, Mitsuba's default gaussian film filter, other
+    samplers, unknown top-level nodes and properties, area emitters, textures, spec_trans.  A file that asks only for what
+    is implemented (path with max_depth 2, box filter, independent sampler) loads without any warning."""
+    import warnings
+
+    wv, wt = scenes.make_plane(0.0, 1.0, 2, 2)
+    qv, qt = scenes.make_plane(4.0, 0.3, 1, 1)
+    loaders.save_obj(tmp_path / "wall.obj", wv, wt)
+    loaders.save_obj(tmp_path / "quad.obj", qv, qt)
+
+    def load(xml):
+        (tmp_path / "s.xml").write_text(xml)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sc = loaders.load_mitsuba_xml(str(tmp_path / "s.xml"))
+        return sc, [str(x.message) for x in w]
+
+    clean = (XML.replace('<sensor type="perspective" id="PerspectiveCamera">', '<integrator type="path"><integer name="max_depth" value="2"/></integrator>\n'
+                         '<sensor type="perspective" id="PerspectiveCamera"><sampler type="independent"><integer name="sample_count" value="$spp"/></sampler>')
+             .replace('<integer name="height" value="$res"/></film>', '<integer name="height" value="$res"/><rfilter type="box"/></film>'))
+    sc, msgs = load(clean)
+    assert msgs == [], msgs
+    assert sc.notes["integrator"] == {"type": "path", "max_depth": 2} and sc.notes["rfilter"] == "box" and sc.notes["sample_count"] == 64
+    # the plain file: Mitsuba's defaults are a gaussian film filter and an unbounded path integrator
+    _, msgs = load(XML)
+    assert any("no <integrator>" in m for m in msgs) and any("reconstruction filter 'gaussian' (the hdrfilm default)" in m for m in msgs)
+    # what round 2 swallowed
+    noisy = (clean.replace('value="2"/></integrator>', 'value="8"/></integrator>\n<medium type="homogeneous"/>')
+             .replace('<rfilter type="box"/>', '<rfilter type="tent"/>')
+             .replace('<sampler type="independent">', '<sampler type="stratified">')
+             .replace('<float name="fov" value="60"/>', '<float name="fov" value="60"/><string name="fov_axis" value="y"/><float name="aperture_radius" value="0.1"/>')
+             .replace('<float name="clearcoat" value="0.25"/>', '<float name="clearcoat" value="0.25"/><float name="spec_trans" value="0.3"/>'
+                      '<texture type="bitmap" name="base_color"><string name="filename" value="t.png"/></texture>')
+             .replace('<bsdf type="diffuse"><rgb name="reflectance" value="0.2"/></bsdf></shape>',
+                      '<bsdf type="diffuse"><rgb name="reflectance" value="0.2"/></bsdf><emitter type="area"><rgb name="radiance" value="1"/></emitter></shape>\n'
+                      '<emitter type="envmap"><string name="filename" value="e.exr"/></emitter>'))
+    sc, msgs = load(noisy)
+    for needle in ("max_depth 8", "top-level <medium> ignored", "reconstruction filter 'tent'", "sampler type 'stratified'", "sensor property 'aperture_radius' is ignored",
+                   "spec_trans > 0", "texture-valued parameter 'base_color'", "area emitter on a shape ignored", "emitter type 'envmap' ignored"):
+        assert any(needle in m for m in msgs), (needle, msgs)
+    # fov_axis = y on a square film is the same angle; on a 4:3 film it is converted to the horizontal angle
+    assert sc.camera.fov_x == pytest.approx(60.0)
+    assert loaders._fov_x(45.0, "y", 400, 300) == pytest.approx(np.rad2deg(2 * np.arctan(np.tan(np.deg2rad(22.5)) * 4 / 3)))
+    assert loaders._fov_x(45.0, "smaller", 400, 300) == loaders._fov_x(45.0, "y", 400, 300) and loaders._fov_x(45.0, "larger", 400, 300) == 45.0
+    assert loaders._fov_x(50.0, "diagonal", 300, 400) == pytest.approx(np.rad2deg(2 * np.arctan(np.tan(np.deg2rad(25.0)) * 0.6)))
+    other, msgs = load(clean.replace('<integrator type="path">', '<integrator type="ptracer">'))
+    assert any("'ptracer'" in m and "not implemented" in m for m in msgs)

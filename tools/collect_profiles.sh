@@ -1,26 +1,30 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's roofline fields on an MI355X box (run via gpurun
-# from the repo root):  bash tools/collect_profiles.sh <tag>
+# from the repo root):  bash tools/collect_profiles.sh <tag> [bench.py arguments]
+# <tag> = r<N> for bench.py's default workload, r<N>colon with `--workload colon --res 1024 --spp 256 --grid 32 --fp16`
+# (bench.py's profile_key finds the files by that name).
 # Every rocprofv3 pass runs the program directly after `--`; PMC passes are separate from the
 # kernel-trace/stats pass and from each other (FETCH_SIZE, WRITE_SIZE, SQ instruction mix).
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
+shift
+X="$*"   # extra bench.py arguments: the workload
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="--steps 20 --warmup 3 --no-cpu-baseline"
+B="--steps 20 --warmup 3 --no-cpu-baseline $X"
 (cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.log)
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-grad-steps > /dev/null 2>&1)
-  (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/gpmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-render-steps > /dev/null 2>&1)
+  (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-grad-steps $X > /dev/null 2>&1)
+  (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/gpmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-render-steps $X > /dev/null 2>&1)
 done
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_CYCLES SQ_WAVES" \
            "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_INST_CYCLES_VALU" \
            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  (cd $R && rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-grad-steps > /dev/null 2>&1)
+  (cd $R && rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-grad-steps $X > /dev/null 2>&1)
 done
 cd $R
 python tools/summarize_profile.py $TAG $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/summary.txt 2>&1
@@ -29,9 +33,11 @@ rm -f profiles/${TAG}grad_kernel_stats.csv
 mkdir -p $OUT/sq_all; cp -r $OUT/sq_[0-9] $OUT/sq_all/
 python tools/pmc_table.py $OUT/sq_all k_render_fwd_pk > profiles/${TAG}_sq_instruction_mix.json
 tail -1 $OUT/bench_under_rocprof.json > profiles/${TAG}_bench_under_rocprof.json
+if [ -z "$X" ]; then  # workload-independent pieces: with the default workload only
 python tools/microbench.py > profiles/${TAG}_microbench.json 2> $OUT/microbench.log
 # issue-rate microbenchmark (instruction counts are fixed by the inline-asm bodies; `grep -c` on the .s confirms)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rates issue_rates.hip 2> $OUT/issue_rates_build.log && /tmp/issue_rates > $R/profiles/${TAG}_issue_rates.txt 2>&1)
+fi
 # ship the small summaries back (profiles/ is not merged by gpurun, gpurun_out/ is)
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}* gpurun_out/profiles_$TAG/
 rm -rf $OUT/stats $OUT/pmc_* $OUT/gpmc_* $OUT/sq_*
