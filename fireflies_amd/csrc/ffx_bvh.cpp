@@ -303,7 +303,10 @@ size_t ffx_bvh_blob_bytes(int n_tris) {
   // of more than FFX_WIDE triangles or is the parent of clusters; bounded generously), 64 x (16 + 4) B each
   const size_t wmax = f / 16 + 4;
   return 64 + f * sizeof(BvhNode) + f * 4 + f * 4 + 64 + (f + FFX_LEAF_MAX) * sizeof(TriRec) + 64 + FFX_N_APEX * (size_t)ffx_apex_stride(n_tris < 1 ? 1 : n_tris) +
-         wmax * FFX_WIDE * (sizeof(WideChild) + 4) + (f + FFX_WIDE) * sizeof(WideChild) + 256;
+         wmax * FFX_WIDE * (sizeof(WideChild) + 4) + (f + FFX_WIDE) * sizeof(WideChild) + 256 +
+         // refit plan: <= f + 1 headers of 8 ints (every leaf under the top could be a treelet of its own), <= f nodes with <= 2 level
+         // entries each, <= wmax * 64 wide children, the counter
+         ((f + 2) * 8 + 3 * f + 8 + wmax * FFX_WIDE + 64) * 4;
 }
 
 int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int n_tris, void *blob, size_t blob_bytes, ffx_bvh_info *info) {
@@ -402,12 +405,112 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   off = (off + 63) & ~(uint64_t)63;
   info->off_whdr = off;
   off += 64;
+  // ---- refit plan (ffx.h: off_plan).  Treelet roots: the highest inner nodes with at most `tl_max` triangles below them; a
+  // leaf hanging directly off the top forms a treelet without nodes (its records still have to be built).
+  std::vector<int32_t> plan;
+  int n_treelets = 0;
+  {
+    const int tl_max = getenv("FFX_TREELET_TRIS") ? std::max(FFX_LEAF_MAX, atoi(getenv("FFX_TREELET_TRIS"))) : 1024;
+    // out-index heights (as the level refit uses them) per build node
+    std::vector<int> hgt(b.nodes.size(), 0);
+    for (int id = (int)b.nodes.size() - 1; id >= 0; --id) { // children have larger ids than their parent
+      const BuildNode &n = b.nodes[id];
+      if (n.left >= 0) hgt[id] = std::max(b.nodes[n.left].left >= 0 ? hgt[n.left] + 1 : 0, b.nodes[n.right].left >= 0 ? hgt[n.right] + 1 : 0);
+    }
+    std::vector<int> tl_of(b.nodes.size(), -1); // treelet of an inner build node; -2: top
+    struct TL { int root, sfirst, scount; std::vector<int> nodes; std::vector<int> wc; };
+    std::vector<TL> tls;
+    std::vector<int> top_nodes;
+    if (root_is_leaf) {
+      tls.push_back({root, 0, n_tris, {}, {}});
+    } else {
+      std::vector<int> st{root};
+      while (!st.empty()) {
+        const int id = st.back();
+        st.pop_back();
+        const BuildNode &n = b.nodes[id];
+        if (n.left < 0) { tls.push_back({id, n.first, n.count, {}, {}}); continue; } // a leaf directly under the top
+        if (n.scount <= tl_max) {
+          TL t{id, n.sfirst, n.scount, {}, {}};
+          std::vector<int> sub{id};
+          while (!sub.empty()) {
+            const int x = sub.back();
+            sub.pop_back();
+            if (b.nodes[x].left < 0) continue;
+            tl_of[x] = (int)tls.size();
+            t.nodes.push_back(x);
+            sub.push_back(b.nodes[x].left);
+            sub.push_back(b.nodes[x].right);
+          }
+          tls.push_back(std::move(t));
+        } else {
+          tl_of[id] = -2;
+          top_nodes.push_back(id);
+          st.push_back(n.right);
+          st.push_back(n.left);
+        }
+      }
+    }
+    n_treelets = (int)tls.size();
+    TL top{-1, 0, 0, top_nodes, {}};
+    // wide children go with the treelet (or the top) that owns the binary node holding their box: the PARENT of the child's
+    // build node (ffx_scene.hip copies wn[k] from node wsrc[k] >> 1)
+    for (size_t w = 0; w < wide.size(); ++w)
+      for (int j = 0; j < (int)wide[w].kids.size(); ++j) {
+        const int par = b.nodes[wide[w].kids[j]].parent;
+        const int t = tl_of[par];
+        (t >= 0 ? tls[t] : top).wc.push_back((int)(w * FFX_WIDE + j));
+      }
+    tls.push_back(std::move(top));
+    // emit: headers, level starts, node lists (by height), wide children, counter
+    const size_t n_hdr = tls.size();
+    plan.assign(n_hdr * 8, 0);
+    std::vector<int32_t> lvls, nodes_out, wc_out;
+    for (size_t t = 0; t < n_hdr; ++t) {
+      TL &tl = tls[t];
+      const bool single = root_is_leaf && t == 0;
+      std::vector<int> ids = tl.nodes;
+      std::stable_sort(ids.begin(), ids.end(), [&](int a, int c) { return hgt[a] < hgt[c]; });
+      int32_t *h = &plan[t * 8];
+      h[0] = tl.sfirst; h[1] = tl.scount;
+      h[2] = (int32_t)lvls.size();
+      int n_l = 0;
+      if (single) { // the one node of a scene that is a single leaf
+        lvls.push_back((int32_t)nodes_out.size());
+        nodes_out.push_back(0);
+        n_l = 1;
+      }
+      for (size_t i = 0; i < ids.size(); ++i) {
+        if (i == 0 || hgt[ids[i]] != hgt[ids[i - 1]]) { lvls.push_back((int32_t)nodes_out.size()); ++n_l; }
+        nodes_out.push_back(b.nodes[ids[i]].out_index);
+      }
+      lvls.push_back((int32_t)nodes_out.size()); // end of the last level
+      h[3] = n_l;
+      h[4] = (int32_t)wc_out.size(); h[5] = (int32_t)tl.wc.size();
+      for (int k : tl.wc) wc_out.push_back(k);
+    }
+    // absolute int offsets inside the plan: [headers][levels][nodes][wide children][counter]
+    const int32_t o_lvl = (int32_t)plan.size(), o_nodes = o_lvl + (int32_t)lvls.size(), o_wc = o_nodes + (int32_t)nodes_out.size();
+    for (size_t t = 0; t < n_hdr; ++t) { plan[t * 8 + 2] += o_lvl; plan[t * 8 + 4] += o_wc; }
+    for (int32_t &v : lvls) v += o_nodes;
+    plan.insert(plan.end(), lvls.begin(), lvls.end());
+    plan.insert(plan.end(), nodes_out.begin(), nodes_out.end());
+    plan.insert(plan.end(), wc_out.begin(), wc_out.end());
+    plan.push_back(0); // arrival counter
+  }
+  off = (off + 63) & ~(uint64_t)63;
+  info->off_plan = off;
+  info->n_treelets = n_treelets;
+  info->plan_ints = (int32_t)plan.size();
+  off += (uint64_t)plan.size() * 4;
+  off = (off + 63) & ~(uint64_t)63;
   off += FFX_N_APEX * ffx_apex_stride(n_tris); // apex-record areas (ffx_common.h), zero until a render call fills them
   info->total_bytes = off;
   if (off > blob_bytes) FFX_FAIL(FFX_ERR_NOMEM, "bvh_build_host: internal size error");
   if (info->max_depth > FFX_STACK_DEPTH) FFX_FAIL(FFX_ERR_UNSUPPORTED, "bvh_build_host: tree depth %d exceeds the traversal stack", info->max_depth);
 
   memset(blob, 0, (size_t)off);
+  memcpy((char *)blob + info->off_plan, plan.data(), plan.size() * 4);
   BvhNode *out = (BvhNode *)((char *)blob + info->off_nodes);
   int32_t *ord = (int32_t *)((char *)blob + info->off_order);
   int32_t *refit = (int32_t *)((char *)blob + info->off_refit);

@@ -4,6 +4,15 @@
 // (fireflies/scene.py:243-251) and the acceleration-structure rebuild hidden in
 // mitsuba_params.update() (fireflies/scene.py:384).
 //
+// Round 3: ONE launch (k_scene_update_fused).  The host builder cuts the tree into TREELETS (include/ffx.h: off_plan) —
+// maximal subtrees of <= ~1024 triangles with a contiguous run of leaf slots.  A workgroup owns one treelet end to end:
+// it builds its triangle records and per-triangle boxes, re-fits its nodes height by height behind workgroup barriers
+// (one CU, one L1: workgroup-scope visibility is enough), copies the boxes of the wide overlay's children that live in
+// its nodes, then publishes (agent-scope fence + one atomic).  The workgroup that arrives LAST re-fits the few hundred
+// nodes above the treelets the same way.  The eight dependent launches this replaces (records, four levels, tail, wide
+// boxes: 55-65 us of mostly launch gaps, 245 us when sharing the GPU with a render) remain below as the A/B baseline
+// (FFX_REFIT=levels).
+//
 //   k_build_records : one lane per leaf slot.  Gathers the triangle's three source vertices
 //                     (animation frame selected by vert_off[shape]), applies the shape's 4x4 and
 //                     writes the 48-byte record {v0, e1, e2, prim, shape} in LEAF order, so that
@@ -17,6 +26,9 @@
 //                     this replaces ~20 tiny dependent launches by one.
 // HBM traffic per update: 12*V (gather, mostly L2 hits: each vertex is shared by ~6 triangles)
 // + 48*F (records out) + 64*N_nodes (nodes in/out).
+#include <stdlib.h>
+#include <string.h>
+
 #include "ffx_common.h"
 
 #define UPD_BLOCK 256
@@ -197,6 +209,114 @@ __global__ void __launch_bounds__(UPD_BLOCK)
   }
 }
 
+// ---- the fused update.  `recs` and `nodes` are written and read back inside this kernel: no __restrict__, no read-only loads.
+#define FUSED_BLOCK 256
+__device__ __forceinline__ void tri_wide_box(const float (&p0)[3], const float (&e1)[3], const float (&e2)[3], WideChild &c) {
+  // the padded box of ONE triangle exactly as leaf_box forms it from the record (corners re-rounded as v0 + e)
+  float lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q0 = p0[a], q1 = p0[a] + e1[a], q2 = p0[a] + e2[a];
+    const float mn = fminf(q0, fminf(q1, q2)), mx = fmaxf(q0, fmaxf(q1, q2));
+    const float pad = 4e-7f * fmaxf(fabsf(mn), fabsf(mx));
+    lo[a] = mn - pad;
+    hi[a] = mx + pad;
+  }
+  c.lo[0] = lo[0]; c.lo[1] = lo[1]; c.lo[2] = lo[2];
+  c.hi0 = hi[0]; c.hi12[0] = hi[1]; c.hi12[1] = hi[2];
+  c.ref = 0;
+  c.pad = 0;
+}
+
+__device__ __forceinline__ void plan_levels(BvhNode *nodes, const TriRec *recs, const int32_t *__restrict__ plan, const int32_t *__restrict__ h) {
+  const int lvl0 = h[2], n_l = h[3];
+  for (int l = 0; l < n_l; ++l) {
+    const int b = plan[lvl0 + l], e = plan[lvl0 + l + 1];
+    for (int i = b + (int)threadIdx.x; i < e; i += FUSED_BLOCK) refit_node(nodes, recs, plan[i]);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void plan_wide_children(const BvhNode *nodes, WideChild *wn, const int32_t *__restrict__ wsrc, const int32_t *__restrict__ plan,
+                                                   const int32_t *__restrict__ h) {
+  const int w0 = h[4], wc = h[5];
+  for (int j = (int)threadIdx.x; j < wc; j += FUSED_BLOCK) {
+    const int k = plan[w0 + j];
+    const int src = wsrc[k];
+    if (src < 0) continue;
+    const BvhNode &n = nodes[src >> 1];
+    // (only the box is rewritten: ref / pad are topology, written once by the host builder)
+    const float *lo = (src & 1) ? n.lo1 : n.lo0, *hi = (src & 1) ? n.hi1 : n.hi0;
+    WideChild &c = wn[k];
+    c.lo[0] = lo[0]; c.lo[1] = lo[1]; c.lo[2] = lo[2];
+    c.hi0 = hi[0]; c.hi12[0] = hi[1]; c.hi12[1] = hi[2];
+  }
+}
+
+template <bool HOST_TAB>
+__global__ void __launch_bounds__(FUSED_BLOCK)
+    k_scene_update_fused(BvhNode *nodes, TriRec *recs, const int32_t *__restrict__ order, WideChild *tq, WideChild *wn, const int32_t *__restrict__ wsrc,
+                         int32_t *plan, int n_treelets, int counter_at, const float *__restrict__ src_verts, const int32_t *__restrict__ tris,
+                         const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off, const float *__restrict__ xform, int n_shapes, ShapeTabH tab) {
+  __shared__ int s_last;
+  const int32_t *h = plan + 8 * blockIdx.x;
+  // ---- A: records and per-triangle boxes of this treelet's run of leaf slots
+  const int s0 = h[0], sn = h[1];
+  for (int k = s0 + (int)threadIdx.x; k < s0 + sn; k += FUSED_BLOCK) {
+    const int prim = order[k];
+    int sh = tri_shape[prim];
+    sh = min(max(sh, 0), n_shapes - 1);
+    float mm[12];
+    int base;
+    if (HOST_TAB) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) mm[i] = tab.m[sh][i];
+      base = tab.off[sh];
+    } else {
+      const float *m = xform + 16 * sh;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) mm[i] = m[i];
+      base = vert_off[sh];
+    }
+    v3 p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float *sv = src_verts + 3 * ((size_t)base + tris[3 * prim + c]);
+      p[c] = xf_point(mm, V3(sv[0], sv[1], sv[2]));
+    }
+    const v3 e1 = vsub(p[1], p[0]), e2 = vsub(p[2], p[0]);
+    float4 *o = reinterpret_cast<float4 *>(recs + k);
+    o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
+    o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), 0.f);
+    const float a0[3] = {p[0].x, p[0].y, p[0].z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+    WideChild c;
+    tri_wide_box(a0, a1, a2, c);
+    tq[k] = c;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- B, C: this treelet's nodes by height, then the wide children whose boxes live in them
+  plan_levels(nodes, recs, plan, h);
+  plan_wide_children(nodes, wn, wsrc, plan, h);
+  // ---- D: publish; the last workgroup to arrive re-fits the top of the tree
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(plan + counter_at, 1) == n_treelets - 1);
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int32_t *ht = plan + 8 * n_treelets;
+  plan_levels(nodes, recs, plan, ht);
+  plan_wide_children(nodes, wn, wsrc, plan, ht);
+  if (threadIdx.x == 0) plan[counter_at] = 0; // ready for the next update of this blob (stream-ordered)
+}
+
+static int refit_fused_enabled() {
+  const char *e = getenv("FFX_REFIT");
+  return !(e && strcmp(e, "levels") == 0);
+}
+
 static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
                              const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s, bool host_tab) {
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
@@ -217,6 +337,25 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
       tab.off[i] = vert_off[i];
       for (int j = 0; j < 12; ++j) tab.m[i][j] = xform[16 * i + j];
     }
+  }
+#if FFX_WIDE_F32
+  if (info->off_plan != 0 && info->n_treelets > 0 && info->off_tq != 0 && refit_fused_enabled()) {
+    if (info->plan_ints < 8 * (info->n_treelets + 1) + 1 || info->off_plan + 4ull * (uint64_t)info->plan_ints > info->total_bytes)
+      FFX_FAIL(FFX_ERR_ARG, "scene_update: bad refit plan");
+    WideChild *tq = (WideChild *)(base + info->off_tq), *wn = (WideChild *)(base + info->off_wnodes);
+    const int32_t *wsrc = (const int32_t *)(base + info->off_wsrc);
+    int32_t *plan = (int32_t *)(base + info->off_plan);
+    if (host_tab)
+      hipLaunchKernelGGL(k_scene_update_fused<true>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
+                         info->plan_ints - 1, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
+    else
+      hipLaunchKernelGGL(k_scene_update_fused<false>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
+                         info->plan_ints - 1, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab);
+    FFX_CHECK_LAUNCH("scene_update/fused");
+    return FFX_OK;
+  }
+#endif
+  if (host_tab) {
     hipLaunchKernelGGL(k_build_records<true>, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
                        tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
   } else {

@@ -502,11 +502,15 @@ __device__ __forceinline__ void project_xy(const float *__restrict__ rays, int k
 // every texel adds / multiplies in ascending point order); each texel keeps BOTH reductions of the same splat values.
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_fwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, int want_softor, float *__restrict__ pts,
-                  float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws) {
+                  float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws, float *__restrict__ zero, long n_zero) {
   __shared__ float c_p0[CAND_MAX], c_p1[CAND_MAX];
   __shared__ int c_count;
   __shared__ float s_part[SPLAT_BLOCK / 64];
   const int tid = threadIdx.x;
+  if (zero) { // the step's accumulation buffer (texture gradient + loss), cleared by the launch that opens the step instead of a fill of its own
+    const long stride = (long)gridDim.x * gridDim.y * SPLAT_BLOCK;
+    for (long t = ((long)blockIdx.y * gridDim.x + blockIdx.x) * SPLAT_BLOCK + tid; t < n_zero; t += stride) zero[t] = 0.f;
+  }
   const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
   const int j = j0 + (tid % TILE_W), i = i0 + (tid / TILE_W);
   const float inv_sigma = 1.0f / sigma;
@@ -796,9 +800,35 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restric
 // exact transpose: gin[q] = sum over the padded positions t (|t - image| <= r) that reflect onto q
 // of g_pad[t] = sum_k w[k] * gout[t - k + r], separately per axis.
 __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restrict__ gout, int h, int w, BlurW bw, float *__restrict__ gin) {
+  __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
+  const int r = bw.ksize / 2;
+  {
+    // A tile none of whose pixels receives a reflected contribution (rows / columns 1..r and n-1-r..n-2 do) and whose halo
+    // stays inside the image is a plain correlation: staged through LDS like the forward blur (the same terms in the same
+    // order as the general loop below, so the bits do not change) — all but the border tiles of a 500x500 texture; reading
+    // 25 taps per pixel from global memory made this kernel 3x as slow as k_blur_fwd.
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+    const bool interior = x0 - r >= r + 1 && y0 - r >= r + 1 && x0 + TILE_W + r <= w - 1 - r && y0 + TILE_H + r <= h - 1 - r; // (wave-uniform)
+    if (interior) {
+      const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
+      for (int t = threadIdx.x; t < tw * th; t += SPLAT_BLOCK) {
+        const int ly = t / tw, lx = t % tw;
+        tile[t] = gout[(size_t)(y0 + ly - r) * w + (x0 + lx - r)];
+      }
+      __syncthreads();
+      const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
+      float acc = 0.f;
+      for (int ky = 0; ky < bw.ksize; ++ky) { // py = y - ky + r: tile row ly + (2r - ky)
+        float row = 0.f;
+        for (int kx = 0; kx < bw.ksize; ++kx) row = fmaf(bw.w[kx], tile[(ly + 2 * r - ky) * tw + lx + 2 * r - kx], row);
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+      gin[(size_t)(y0 + ly) * w + x0 + lx] = acc;
+      return;
+    }
+  }
   int x = blockIdx.x * TILE_W + threadIdx.x % TILE_W, y = blockIdx.y * TILE_H + threadIdx.x / TILE_W;
   if (x >= w || y >= h) return;
-  const int r = bw.ksize / 2;
   float acc = 0.f;
   // Padded rows -r..-1 reflect onto rows 1..r and rows h..h+r-1 onto h-1-r..h-2: only those rows (columns) have
   // candidates besides themselves — every other pixel is a plain correlation (same terms in the same order, so the
@@ -897,13 +927,14 @@ size_t ffx_pattern_ws_floats(int size0, int size1) {
 }
 
 int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
-                    float *ws, ffx_stream s) {
-  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)))
+                    float *ws, float *zero, long n_zero, ffx_stream s) {
+  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)) || (zero && n_zero < 1))
     FFX_FAIL(FFX_ERR_ARG, "pattern_fwd: bad argument");
   Mat4 m;
   for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
   dim3 grid(ffx_cdiv(size0, TILE_W), ffx_cdiv(size1, TILE_H));
-  hipLaunchKernelGGL(k_pattern_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, want_softor, pts, tsum, tsor, ws);
+  hipLaunchKernelGGL(k_pattern_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, want_softor, pts, tsum, tsor, ws, zero,
+                     zero ? n_zero : 0L);
   FFX_CHECK_LAUNCH("pattern_fwd");
   return FFX_OK;
 }

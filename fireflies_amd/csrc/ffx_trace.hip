@@ -2324,7 +2324,17 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // the pixel's  gimg . albedo[shape] (. colour) / spp  with one global float atomic (a lit pixel touches ~16
 // texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
 // pixel slots): one lane per stray sample record, four taps each.
-struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; }; // ms: floats per material row (3 / FFX_MAT_STRIDE)
+struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; // ms: floats per material row (3 / FFX_MAT_STRIDE)
+              const void *img; int img_fp16; float *dot_out; }; // optional: dot_out[0] += <gimg, img> (the value of a linear loss whose gradient gimg is)
+__device__ __forceinline__ float k9_pixel_dot(const BwdP &p, long pixel, const float *__restrict__ gimg) {
+  const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+  if (p.img_fp16) {
+    const _Float16 *q = (const _Float16 *)p.img + pixel * 3;
+    return g0 * (float)q[0] + g1 * (float)q[1] + g2 * (float)q[2];
+  }
+  const float *q = (const float *)p.img + pixel * 3;
+  return g0 * q[0] + g1 * q[1] + g2 * q[2];
+}
 
 // the stray records of the adjoint cache: thread i replays record i (four bilinear taps each)
 __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_pix, uint32_t i, const BwdP &p, const float *__restrict__ gimg,
@@ -2395,9 +2405,15 @@ __global__ void __launch_bounds__(256)
   // pass 1 (threads 0..63, one per pixel): the tile origin
   if (threadIdx.x < 64) {
     const int x = bx * 8 + (threadIdx.x & 7), y = by * 8 + (threadIdx.x >> 3);
+    float d = 0.f;
     if (x < p.W && y < p.H) {
       const CachePix hp = hdrs[(long)y * p.W + x];
       if (hp.lit) { atomicMin(&s_ox, (int)hp.x0); atomicMin(&s_oy, (int)hp.y0); s_any = 1; }
+      if (p.dot_out) d = k9_pixel_dot(p, (long)y * p.W + x, gimg);
+    }
+    if (p.dot_out) { // <gimg, img> of this 8x8 block: one wave, one atomic (the loss of a pattern optimiser's step: no separate reduction launch)
+      d = wave_sum64(d);
+      if (threadIdx.x == 0 && d != 0.f) atomicAdd(p.dot_out, d);
     }
   }
   __syncthreads();
@@ -2439,6 +2455,15 @@ __global__ void __launch_bounds__(256)
   if ((int)blockIdx.x < slot_blocks) {
     const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const int e = threadIdx.x & 31;
+    if (p.dot_out) { // <gimg, img> of the block's 8 pixels: lanes 0..7 of wave 0, one atomic
+      __shared__ float s_d[8];
+      if (e == 0) s_d[threadIdx.x >> 5] = pixel < n_pix ? k9_pixel_dot(p, pixel, gimg) : 0.f;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float d = ((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) + ((s_d[4] + s_d[5]) + (s_d[6] + s_d[7]));
+        if (d != 0.f) atomicAdd(p.dot_out, d);
+      }
+    }
     if (pixel >= n_pix) return;
     const CachePix hp = reinterpret_cast<const CachePix *>(cache + 64)[pixel];
     if (!hp.lit || e >= 25) return;
@@ -2810,10 +2835,15 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
   return FFX_OK;
 }
 
-int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {
-  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
-  if (!sd->proj.enabled) return FFX_OK;
+int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
+                          int img_fp16, float *dot_out, ffx_stream s) {
+  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!sd->proj.enabled) {
+    if (dot_out) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> is accumulated by the footprint kernel, which a scene without projector does not launch");
+    return FFX_OK;
+  }
   BwdP p;
+  p.img = dot_out ? img : nullptr; p.img_fp16 = img_fp16 & 1; p.dot_out = dot_out;
   p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
   if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || sd->cam.width < 1 || sd->cam.height < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad scene description");
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];

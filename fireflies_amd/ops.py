@@ -112,9 +112,9 @@ def pattern_ws_floats(size0, size1):
     return int(api().lib.ffx_pattern_ws_floats(int(size0), int(size1)))
 
 
-def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True, out=None):
+def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True, out=None, zero=None):
     """K1 + K2(sum) + K2(softor) + partial sums of L1(softor, sum) in one launch -> (pts [n,2], tsum, tsor, ws).
-    `out`: optional tuple of tensors to reuse."""
+    `out`: optional tuple of tensors to reuse.  `zero`: a float32 tensor the same launch clears."""
     n = rays.shape[0]
     if out is None:
         pts = torch.empty((n, 2), dtype=torch.float32, device=rays.device)
@@ -124,7 +124,8 @@ def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True, out=None):
     else:
         pts, tsum, tsor, ws = out
     api().call("ffx_pattern_fwd", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), int(bool(want_softor)), _dev(pts), _dev(tsum),
-               _dev(tsor) if want_softor else None, _dev(ws) if want_softor else None, _stream())
+               _dev(tsor) if want_softor else None, _dev(ws) if want_softor else None, _dev(zero, name="zero") if zero is not None else None,
+               int(zero.numel()) if zero is not None else 0, _stream())
     return pts, tsum, tsor, ws
 
 
@@ -521,14 +522,21 @@ class DeviceGeometry:
         self._release()
         return img
 
-    def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None):
+    def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None, img=None, dot_out=None):
         """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
-        `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one."""
+        `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one.
+        `img` + `dot_out` (a float32 tensor with one element): the same launch adds <gimg, img> to dot_out — the value
+        of a loss that is linear in the image, whose gradient gimg is."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
         _check_materials(sd, albedo)
+        if (img is None) != (dot_out is None):
+            raise ValueError("img and dot_out go together")
+        if img is not None and (tuple(img.shape) != tuple(gimg.shape) or dot_out.dtype != torch.float32 or dot_out.numel() != 1):
+            raise ValueError("img must have gimg's shape and dot_out must be one float32")
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
-                       _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx))
+                       _dev(gimg, name="gimg"), _dev(gtex), _dev(img, img.dtype, "img") if img is not None else None,
+                       int(img is not None and img.dtype == torch.float16), _dev(dot_out) if dot_out is not None else None, _stream(self._didx))
         return gtex
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):

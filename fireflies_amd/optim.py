@@ -59,9 +59,12 @@ def _coverage_accumulate(img, acc):
 
 
 # a task loss may carry `value_and_grad(img) -> (loss, d loss / d img)` and `accumulate_value_and_grad(img, acc) -> d loss / d img`
-# (adds the value to the 0-dim tensor `acc`); otherwise autograd is used for it
+# (adds the value to the 0-dim tensor `acc`); otherwise autograd is used for it.  `linear_gradient(img) -> g` declares the loss
+# LINEAR in the image, loss(img) = <g, img> with a constant g: the adjoint launch then also evaluates the loss
+# (ffx_render_bwd_cached's dot_out) and the step needs no reduction launch at all
 coverage_loss.value_and_grad = _coverage_value_and_grad
 coverage_loss.accumulate_value_and_grad = _coverage_accumulate
+coverage_loss.linear_gradient = _coverage_grad
 
 
 class PatternOptimizer:
@@ -153,12 +156,11 @@ class PatternOptimizer:
         buf = getattr(self, "_pat_buf", None)
         if buf is None or buf[0].shape[0] != rd.shape[0] or tuple(buf[1].shape) != (s1, s0) or (buf[2] is None) == want_reg:
             buf = None
-        pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf)
+        if getattr(self, "_acc", None) is None or self._acc.numel() != s0 * s1 + 1:
+            self._acc = torch.empty(s0 * s1 + 1, dtype=torch.float32, device=rd.device)  # texture gradient + loss, cleared by the pattern launch
+        pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf, zero=self._acc)
         tex = ops.blur_fwd(tsum, self.blur[0], self.blur[1]) if self.blur else tsum
         tex3 = tex.unsqueeze(-1)
-        if getattr(self, "_acc", None) is None or self._acc.numel() != tex3.numel() + 1:
-            self._acc = torch.empty(tex3.numel() + 1, dtype=torch.float32, device=tex.device)  # texture gradient + loss: one fill
-        self._acc.zero_()
         gtex, loss_sum = self._acc[:-1].view(tex3.shape), self._acc[-1]
         # this rank's scene samples: all their random draws up front (each under its own seed, as
         # manual_seed(s); randomize() would make them), ONE device-to-host transfer for the lot
@@ -179,6 +181,7 @@ class PatternOptimizer:
             nxt = self._sample_seeds(self.step_index + 1)
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
+        linear = getattr(self.loss_fn, "linear_gradient", None)
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
@@ -189,6 +192,10 @@ class PatternOptimizer:
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
             img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
+            if linear is not None and use_cache:
+                # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
+                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_sum)
+                continue
             if fast_loss is not None:
                 gimg = fast_loss(img, loss_sum)
             else:

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 3
+#define FFX_ABI_VERSION 4
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -175,7 +175,10 @@ int ffx_l1_value_grad(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, 
 size_t ffx_pattern_ws_floats(int size0, int size1);
 int ffx_pattern_fwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                     int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,
-                    float *tsor /*[dev][size1,size0] or NULL*/, float *ws /*[dev] or NULL*/, ffx_stream stream);
+                    float *tsor /*[dev][size1,size0] or NULL*/, float *ws /*[dev] or NULL*/,
+                    float *zero /*[dev][n_zero] or NULL: cleared by the same launch — the step's accumulation buffer
+                                  (texture gradient + loss), which would otherwise cost a fill launch of its own*/,
+                    long n_zero, ffx_stream stream);
 int ffx_pattern_bwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                     const float *tsum /*[dev]*/, const float *tsor /*[dev] or NULL*/, const float *gts /*[dev] or NULL*/,
                     float reg_weight, const float *ws /*[dev] or NULL*/, float *grays_data /*[dev][n,3] or NULL*/,
@@ -255,6 +258,15 @@ typedef struct ffx_bvh_info {
   uint64_t off_wsrc;   /* n_wide x 64 x int32: where each child's box lives in the binary tree */
   uint64_t off_tq;     /* n_tris (+ 64 of padding) x 32 B triangle boxes, leaf-slot order; = off_wnodes + n_wide * 2048 */
   uint64_t off_whdr;   /* 64 B header of the overlay (the quantisation grid of the current pose in a 16-bit build) */
+  /* refit plan (ABI 4): the tree cut into TREELETS — maximal subtrees of at most ~1024 triangles, each re-fitted by ONE
+   * workgroup from its triangle records up to its root (workgroup barriers only) — plus the TOP of the tree above them,
+   * re-fitted by whichever workgroup finishes last; ffx_scene_update is ONE launch.  int32 tables:
+   * (n_treelets + 1) headers of 8 ints {slot_first, slot_count, level_first, n_levels, wchild_first, wchild_count, 0, 0},
+   * the level starts, the node list (by treelet, then by height), the wide children grouped by the treelet that owns the
+   * binary node their box is copied from, and the arrival counter.  Zero in a blob written by the oracle. */
+  uint64_t off_plan;
+  int32_t n_treelets; /* workgroups of the update launch; the header at index n_treelets describes the top */
+  int32_t plan_ints;  /* int32 words of the plan area (the arrival counter is the last one) */
 } ffx_bvh_info;
 
 /* upper bound of the blob size for n_tris triangles.  The blob ends with scratch areas ("apex records",
@@ -409,9 +421,15 @@ int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[
                          const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                          const float *tex /*[dev]*/, int spp, uint32_t seed, int img_fp16,
                          void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes*/, ffx_stream stream);
+/* Optionally the same launch accumulates  dot_out[0] += <gimg, img>  (img: the forward's image, fp32 or fp16): for a loss that
+ * is linear in the image — the coverage loss of a pattern optimiser, -mean(green) — gimg is constant and that inner product
+ * IS the loss value, so a gradient step needs no separate reduction launch (the reference's loop evaluates the loss with
+ * torch reductions: fireflies/graphics/rasterization.py:589-601).  img = dot_out = NULL: off.  Accumulated with float atomics
+ * (one per 8x8-pixel block): the last bits depend on the order. */
 int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
-                          float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
+                          float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, const void *img /*[dev][H,W,3] or NULL*/, int img_fp16,
+                          float *dot_out /*[dev][1] or NULL*/, ffx_stream stream);
 /* The cache is lossy when its arena of single-sample records fills up (a projector texture much finer than the camera's
  * pixel footprint, grazing views: most samples then miss their pixel's 5x5 window).  Samples beyond the arena are counted
  * in `dropped` and ffx_render_bwd_cached then poisons gtex[0] with NaN instead of returning a gradient with silent holes.

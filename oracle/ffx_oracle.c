@@ -1371,10 +1371,32 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
 }
 
 /* adjoint from the per-sample records: same weights, same clamping as the forward lookup */
-int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, ffx_stream s) {
+static inline float f16_to_f32(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13); }
+  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+  else x = sign | ((e + 112) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
+                          int img_fp16, float *dot_out, ffx_stream s) {
   (void)s;
-  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
-  if (!sd->proj.enabled) return FFX_OK;
+  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!sd->proj.enabled) {
+    if (dot_out) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> needs a projector (as in libffx_hip)");
+    return FFX_OK;
+  }
+  if (dot_out) { /* dot_out[0] += <gimg, img>, double accumulation in pixel order */
+    double acc = 0.0;
+    const long n3 = (long)sd->cam.width * sd->cam.height * 3;
+    for (long i = 0; i < n3; ++i) acc += (double)gimg[i] * (double)((img_fp16 & 1) ? f16_to_f32(((const uint16_t *)img)[i]) : ((const float *)img)[i]);
+    dot_out[0] += (float)acc;
+  }
   int W = sd->cam.width, H = sd->cam.height, tw = sd->proj.tex_w, th = sd->proj.tex_h, tc = sd->proj.tex_channels;
   const crec *cr = (const crec *)cache;
   const int ms = sd->mat_stride ? sd->mat_stride : 3;
@@ -1466,9 +1488,10 @@ size_t ffx_pattern_ws_floats(int size0, int size1) {
 }
 
 int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
-                    float *ws, ffx_stream s) {
-  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)))
+                    float *ws, float *zero, long n_zero, ffx_stream s) {
+  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)) || (zero && n_zero < 1))
     FAIL(FFX_ERR_ARG, "pattern_fwd: bad argument");
+  if (zero) memset(zero, 0, sizeof(float) * (size_t)n_zero);
   float *p3 = (float *)malloc(sizeof(float) * 3 * (size_t)n);
   if (!p3) FAIL(FFX_ERR_NOMEM, "pattern_fwd: out of memory");
   int rc = ffx_project_rays_fwd(rays, n, KF, p3, s);

@@ -89,7 +89,7 @@ def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True):
     tsum = np.empty((size1, size0), np.float32)
     tsor = np.empty((size1, size0), np.float32) if want_softor else None
     ws = np.zeros(int(api().lib.ffx_pattern_ws_floats(size0, size1)), np.float32)
-    api().call("ffx_pattern_fwd", _p(rays), n, _m16(KF), float(sigma), size0, size1, int(want_softor), _p(pts), _p(tsum), _p(tsor) if want_softor else None, _p(ws), None)
+    api().call("ffx_pattern_fwd", _p(rays), n, _m16(KF), float(sigma), size0, size1, int(want_softor), _p(pts), _p(tsum), _p(tsor) if want_softor else None, _p(ws), None, 0, None)
     return pts, tsum, tsor, ws
 
 
@@ -255,11 +255,18 @@ class Geometry:
         return img, cache
 
     @staticmethod
-    def render_bwd_cached(sd, albedo, cache, spp, gimg):
+    def render_bwd_cached(sd, albedo, cache, spp, gimg, img=None):
+        """-> gtex; with `img` (the forward's image, float32 or float16) also <gimg, img>: (gtex, dot)"""
         albedo, gimg = _f32(albedo), _f32(gimg)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
-        api().call("ffx_render_bwd_cached", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(gimg), _p(gtex), None)
-        return gtex
+        if img is None:
+            api().call("ffx_render_bwd_cached", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(gimg), _p(gtex), None, 0, None, None)
+            return gtex
+        img = np.ascontiguousarray(img)
+        dot = np.zeros(1, np.float32)
+        api().call("ffx_render_bwd_cached", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(gimg), _p(gtex), _p(img), int(img.dtype == np.float16),
+                   _p(dot), None)
+        return gtex, float(dot[0])
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         albedo, gimg = _f32(albedo), _f32(gimg)

@@ -92,8 +92,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.Projector) == 4 * (16 + 16 + 1 + 3 + 4)
     assert C.sizeof(_abi.Spot) == 4 * (16 + 3 + 2 + 1)
     assert C.sizeof(_abi.SceneDesc) == C.sizeof(_abi.Camera) + C.sizeof(_abi.Projector) + C.sizeof(_abi.Spot) + 12  # shadows, n_shapes, mat_stride
-    # 4 ints, 5 offsets, level_start, 4 ints of the wide overlay (+ 4 bytes of padding to 8), 4 offsets
-    assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 16 + 4 + 4 * 8
+    # 4 ints, 5 offsets, level_start, 4 ints of the wide overlay (+ 4 bytes of padding to 8), 4 offsets; ABI 4: the refit plan's offset + 2 ints
+    assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 16 + 4 + 4 * 8 + 8 + 8
 
 
 def test_no_cpu_fallback():
@@ -247,3 +247,48 @@ def test_host_bvh_structure(case):
     assert depth_seen == info.wide_depth <= 6
     assert (info.n_wide == 0) == (F <= 64)
     assert info.off_whdr + 64 <= info.total_bytes and info.off_tq + ESZ * F <= info.off_wsrc
+    # ---- the refit plan (ABI 4): treelets tile the leaf slots and the nodes exactly once; inside a treelet (and inside the
+    # top) children are re-fitted before their parents; a treelet's nodes only depend on its own nodes and its own slots;
+    # every used wide child is copied by the treelet (or the top) that owns the binary node holding its box
+    T = info.n_treelets
+    plan = blob[info.off_plan : info.off_plan + 4 * info.plan_ints].view(np.int32)
+    assert T >= 1 and plan[-1] == 0 and info.off_plan + 4 * info.plan_ints <= info.total_bytes
+    hdr = plan[: 8 * (T + 1)].reshape(T + 1, 8)
+    slot_cov = np.zeros(F, np.int32)
+    owner = np.full(info.n_nodes, -1, np.int32)
+    step_of = np.zeros(info.n_nodes, np.int64)
+    for t in range(T + 1):
+        s0, sn, l0, nl, w0, wc = (int(v) for v in hdr[t, :6])
+        slot_cov[s0 : s0 + sn] += 1
+        assert (t < T) or sn == 0  # the top owns no slots
+        for l in range(nl):
+            b, e = int(plan[l0 + l]), int(plan[l0 + l + 1])
+            assert b < e
+            for k in plan[b:e]:
+                assert owner[k] == -1
+                owner[k] = t
+                step_of[k] = l
+    assert (slot_cov == 1).all() and (owner >= 0).all()
+    for k in range(info.n_nodes):
+        t = owner[k]
+        for c in (int(nodes[k, 12]), int(nodes[k, 13])):
+            if c == EMPTY:
+                continue
+            if c < 0:
+                first = ((~c) & 0xFFFFFFFF) >> 3
+                if t < T:  # a treelet only reads records it built itself
+                    assert hdr[t, 0] <= first < hdr[t, 0] + hdr[t, 1]
+            elif t < T:
+                assert owner[c] == t and step_of[c] < step_of[k]
+            else:  # the top reads finished treelets, or top nodes of a lower step
+                assert owner[c] < T or step_of[c] < step_of[k]
+    used = sorted(int(i) * 64 + j for i in range(nw) for j in range(64) if wsrc[i, j] >= 0)
+    copied = []
+    for t in range(T + 1):
+        w0, wc = int(hdr[t, 4]), int(hdr[t, 5])
+        for k in plan[w0 : w0 + wc]:
+            copied.append(int(k))
+            assert owner[int(wsrc.reshape(-1)[k]) >> 1] == t
+    assert sorted(copied) == used
+    if case == "vocalfold":
+        assert 52 <= T <= 400 and int(hdr[:T, 1].max()) <= 1024

@@ -320,6 +320,56 @@ def test_k5k6_update_is_idempotent_and_tracks_frames(oracle):
     assert torch.equal(blob1, gd.blob[:geo])
 
 
+@pytest.mark.parametrize("cfg", ["hello", "one_leaf", "small", "vocalfold", "colon"])
+def test_k5k6_fused_update_writes_the_same_blob_as_the_level_launches(cfg, monkeypatch):
+    """round 3: ffx_scene_update is ONE launch — a workgroup per treelet (records, per-triangle boxes, its nodes height
+    by height behind workgroup barriers, the wide children that live in its nodes), the last workgroup to arrive
+    re-fits the top of the tree.  It must write, bit for bit, what the eight dependent launches it replaces write
+    (FFX_REFIT=levels: records, level by level, tail, wide boxes): nodes, records, wide nodes, triangle boxes — for
+    a scene that is a single leaf, a tree below one treelet, the vocal fold (~100 treelets) and the colon (~1000), over
+    repeated updates of the same blob (the arrival counter must come back to zero)."""
+    if cfg == "hello":
+        sc = scenes.hello_world(32, 32)
+    elif cfg == "one_leaf":
+        sc = scenes.hello_world(32, 32)
+        sc.meshes = [scenes.MeshData("mesh-Tri", sc.meshes[0].frames[:, :3].copy(), np.array([[0, 1, 2]], np.int32), (0.5, 0.5, 0.5), "mat")]
+    elif cfg == "small":
+        sc = scenes.vocalfold(width=32, height=32, tex=32, frames=3, n_fold=20, tube=(20, 24))
+    elif cfg == "vocalfold":
+        sc = scenes.vocalfold(width=32, height=32, tex=32, frames=4)
+    else:
+        sc = scenes.colon(width=32, height=32, tex=32)
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    S = len(sc.meshes)
+    monkeypatch.setenv("FFX_ASYNC_UPDATE", "0")  # one blob each, everything on the current stream
+    monkeypatch.delenv("FFX_REFIT", raising=False)
+    gf = ops.DeviceGeometry(pool, tris, shape, off)
+    gl = ops.DeviceGeometry(pool, tris, shape, off)
+    info = gf.info
+    assert info.n_treelets >= 1 and info.off_plan > 0
+    if cfg == "colon":
+        assert info.n_treelets > 500
+    end = int(info.off_whdr)  # nodes, order, refit list, records, wide nodes, triangle boxes, wsrc
+    for it in range(4):
+        xf = _rand_xforms(S, 40 + it)
+        offs = (off + np.minimum(it, nfr - 1) * stride).astype(np.int32)
+        monkeypatch.delenv("FFX_REFIT", raising=False)
+        gf.update(xf, offs)
+        monkeypatch.setenv("FFX_REFIT", "levels")
+        gl.update(xf, offs)
+        a, b = gf.blob[:end].clone(), gl.blob[:end].clone()
+        if not torch.equal(a, b):
+            d = torch.nonzero(a != b).reshape(-1)
+            raise AssertionError(f"{cfg} update {it}: {d.numel()} bytes differ, first at {int(d[0])} (nodes at {info.off_nodes}, recs at {info.off_recs}, "
+                                 f"wnodes at {info.off_wnodes}, tq at {info.off_tq})")
+        plan_tail = gf.blob[int(info.off_plan) + 4 * (int(info.plan_ints) - 1):][:4].view(torch.int32)
+        assert int(plan_tail[0]) == 0  # arrival counter reset by the last workgroup
+    # the device-table entry point (ffx_scene_update) takes the same path
+    monkeypatch.delenv("FFX_REFIT", raising=False)
+    gf.update(torch.from_numpy(xf).cuda(), offs)
+    assert torch.equal(gf.blob[:end], b)
+
+
 def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
     """update() re-fits the blob that is not being read, on a side stream, while earlier traces may still
     be running; a burst of (update, trace) pairs without any host sync must give exactly what the
@@ -725,6 +775,11 @@ def test_fused_pattern_kernels_match_the_unfused_oracle(oracle, n, size, sigma):
     assert float(host(ws_d).sum()) == pytest.approx(float(ws_o.sum()), rel=1e-5)
     # the fused forward equals the separate HIP kernels bit for bit (same tiles, same point order)
     assert torch.equal(tsum_d, ops.splat_fwd(pts_d, sigma, "sum", -1, s0, s1)) and torch.equal(tsor_d, ops.splat_fwd(pts_d, sigma, "softor", -1, s0, s1))
+    # the same launch clears a caller's buffer (the optimisation step's gradient + loss accumulator): any length, nothing else touched
+    for nz in (1, s0 * s1 + 1, 3 * s0 * s1 + 7):
+        buf = torch.full((nz + 2,), 7.0, device="cuda")
+        _, tsum_z, _, _ = ops.pattern_fwd(dev(rays), KF, sigma, s0, s1, True, zero=buf[1:-1])
+        assert torch.equal(tsum_z, tsum_d) and float(buf[0]) == 7.0 and float(buf[-1]) == 7.0 and float(buf[1:-1].abs().max()) == 0.0
     gts = rng.standard_normal((s1, s0)).astype(np.float32)
     for w in (0.1, 0.0):
         gd_o, gr_o, val_o = oracle.pattern_bwd(rays, KF, sigma, s0, s1, tsum_o, tsor_o, gts, w, ws_o)
