@@ -107,7 +107,7 @@ PROTOTYPES = {
     "ffx_clamp_to_fov": (c_i, [c_p, c_i, PF, PF, C.c_float, C.c_float, c_i, c_p]),
     "ffx_pattern_ws_floats": (C.c_size_t, [c_i, c_i]),
     "ffx_pattern_fwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_p]),
-    "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p]),
     "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
@@ -132,6 +132,7 @@ PROTOTYPES = {
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "ffx_render_dot_slots": (C.c_size_t, [c_i, c_i]),
     "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),
 }
 

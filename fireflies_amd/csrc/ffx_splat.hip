@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
                   const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
-                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, float loss_div) {
+                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n, float loss_div) {
   __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
   __shared__ int nb_count;
   __shared__ double red[4][SPLAT_BLOCK / 64];
@@ -694,15 +694,23 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     float acc = 0.f;
     if (reg && ws) // (no regulariser: the forward wrote no partial sums and ws may be NULL)
       for (int t = tid; t < n_ws; t += SPLAT_BLOCK) acc += ws[t];
-    __shared__ float s_v[SPLAT_BLOCK / 64];
+    // the data term's partial sums (ffx_render_bwd_cached's dot slots, or one value), fixed order too
+    float lacc = 0.f;
+    if (loss_in)
+      for (int t = tid; t < loss_in_n; t += SPLAT_BLOCK) lacc += loss_in[t];
+    __shared__ float s_v[SPLAT_BLOCK / 64], s_l[SPLAT_BLOCK / 64];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((tid & 63) == 0) s_v[tid >> 6] = acc;
+    for (int o = 32; o >= 1; o >>= 1) { acc += __shfl_down(acc, o, 64); lacc += __shfl_down(lacc, o, 64); }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = acc; s_l[tid >> 6] = lacc; }
     __syncthreads();
     if (tid == 0) {
       const float rv = reg ? ((s_v[0] + s_v[1]) + (s_v[2] + s_v[3])) * gscale : 0.f;
       reg_value[0] = rv;
-      if (loss_in) reg_value[1] = loss_in[0] / loss_div + rv; // the step's total loss: data term / S + regulariser
+      if (loss_in) {
+        const float ls = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+        reg_value[1] = ls / loss_div + rv; // the step's total loss: data term / S + regulariser
+        reg_value[2] = ls;                 // the data term as accumulated (what a multi-rank step exchanges)
+      }
     }
   }
 }
@@ -940,15 +948,16 @@ int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int 
 }
 
 int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts,
-                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, float loss_div, ffx_stream s) {
-  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)))
+                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)) ||
+      (loss_in && (loss_in_n < 1 || !reg_value)))
     FFX_FAIL(FFX_ERR_ARG, "pattern_bwd: bad argument");
   if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_bwd: more than 65535 points");
   Mat4 m;
   for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
   hipLaunchKernelGGL(k_pattern_bwd, dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws,
                      ws ? (int)ffx_pattern_ws_floats(size0, size1) : 0, gts ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in,
-                     loss_div > 0.f ? loss_div : 1.0f);
+                     loss_in ? loss_in_n : 0, loss_div > 0.f ? loss_div : 1.0f);
   FFX_CHECK_LAUNCH("pattern_bwd");
   return FFX_OK;
 }

@@ -2325,7 +2325,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
 // pixel slots): one lane per stray sample record, four taps each.
 struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; // ms: floats per material row (3 / FFX_MAT_STRIDE)
-              const void *img; int img_fp16; float *dot_out; }; // optional: dot_out[0] += <gimg, img> (the value of a linear loss whose gradient gimg is)
+              const void *img; int img_fp16; float *dot_out; int dot_slots; }; // optional: sum(dot_out[0 .. dot_slots)) += <gimg, img> (the value of a linear loss whose gradient gimg is)
 __device__ __forceinline__ float k9_pixel_dot(const BwdP &p, long pixel, const float *__restrict__ gimg) {
   const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
   if (p.img_fp16) {
@@ -2411,9 +2411,9 @@ __global__ void __launch_bounds__(256)
       if (hp.lit) { atomicMin(&s_ox, (int)hp.x0); atomicMin(&s_oy, (int)hp.y0); s_any = 1; }
       if (p.dot_out) d = k9_pixel_dot(p, (long)y * p.W + x, gimg);
     }
-    if (p.dot_out) { // <gimg, img> of this 8x8 block: one wave, one atomic (the loss of a pattern optimiser's step: no separate reduction launch)
-      d = wave_sum64(d);
-      if (threadIdx.x == 0 && d != 0.f) atomicAdd(p.dot_out, d);
+    if (p.dot_out) { // <gimg, img> of this 8x8 block: one wave, one add into the block's OWN slot (the loss of a pattern optimiser's step:
+      d = wave_sum64(d); // no separate reduction launch.  4096 atomics on ONE address cost 40 us here — a slot per block costs nothing)
+      if (threadIdx.x == 0 && d != 0.f) atomicAdd(p.dot_out + (int)blockIdx.x % p.dot_slots, d);
     }
   }
   __syncthreads();
@@ -2461,7 +2461,7 @@ __global__ void __launch_bounds__(256)
       __syncthreads();
       if (threadIdx.x == 0) {
         const float d = ((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) + ((s_d[4] + s_d[5]) + (s_d[6] + s_d[7]));
-        if (d != 0.f) atomicAdd(p.dot_out, d);
+        if (d != 0.f) atomicAdd(p.dot_out + (int)blockIdx.x % p.dot_slots, d);
       }
     }
     if (pixel >= n_pix) return;
@@ -2835,6 +2835,8 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
   return FFX_OK;
 }
 
+size_t ffx_render_dot_slots(int width, int height) { return (width < 1 || height < 1) ? 0 : (size_t)ffx_cdiv(width, 8) * (size_t)ffx_cdiv(height, 8); }
+
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
   if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
@@ -2844,6 +2846,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   }
   BwdP p;
   p.img = dot_out ? img : nullptr; p.img_fp16 = img_fp16 & 1; p.dot_out = dot_out;
+  p.dot_slots = (int)ffx_render_dot_slots(sd->cam.width, sd->cam.height);
   p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
   if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || sd->cam.width < 1 || sd->cam.height < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad scene description");
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];

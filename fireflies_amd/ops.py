@@ -131,16 +131,16 @@ def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True, out=None, zero=
 
 def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, loss_in=None, loss_div=1.0):
     """K2-bwd of the data term (gts on the sum texture) and of reg_weight * L1(softor, sum), each through K1-bwd, in
-    one launch -> (grays_data or None, grays_reg or None, [2] tensor: regulariser value, and loss_in / loss_div +
-    regulariser if the 0-dim tensor `loss_in` is given)"""
+    one launch -> (grays_data or None, grays_reg or None, [3] tensor: regulariser value, and — if `loss_in`, a tensor of
+    partial sums of the data term (or one value), is given — sum(loss_in) / loss_div + regulariser, and sum(loss_in))"""
     n = rays.shape[0]
     gd = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if gts is not None else None
     gr = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if reg_weight > 0 else None
-    val = torch.empty(2, dtype=torch.float32, device=rays.device)
+    val = torch.empty(3, dtype=torch.float32, device=rays.device)
     api().call("ffx_pattern_bwd", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), _dev(tsum, name="tsum"),
                _dev(tsor, name="tsor") if tsor is not None else None, _dev(gts, name="gts") if gts is not None else None, float(reg_weight),
                _dev(ws, name="ws") if ws is not None else None, _dev(gd) if gd is not None else None, _dev(gr) if gr is not None else None, _dev(val),
-               _dev(loss_in, name="loss_in") if loss_in is not None else None, float(loss_div), _stream())
+               _dev(loss_in, name="loss_in") if loss_in is not None else None, int(loss_in.numel()) if loss_in is not None else 0, float(loss_div), _stream())
     return gd, gr, val
 
 
@@ -241,6 +241,10 @@ def render_cache_bytes(width, height, spp):
 def render_cache_bytes_sd(sd, spp):
     """the adjoint cache of a render of `sd` (larger with material rows: a second footprint per pixel)"""
     return int(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), int(spp)))
+
+
+def render_dot_slots(width, height):
+    return int(api().lib.ffx_render_dot_slots(int(width), int(height)))
 
 
 def render_cache_status(cache):
@@ -525,14 +529,14 @@ class DeviceGeometry:
     def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None, img=None, dot_out=None):
         """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
         `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one.
-        `img` + `dot_out` (a float32 tensor with one element): the same launch adds <gimg, img> to dot_out — the value
-        of a loss that is linear in the image, whose gradient gimg is."""
+        `img` + `dot_out` (render_dot_slots(W, H) float32 partial sums, one per 8x8-pixel block): the same launch adds
+        <gimg, img> to them — their sum is the value of a loss that is linear in the image, whose gradient gimg is."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
         _check_materials(sd, albedo)
         if (img is None) != (dot_out is None):
             raise ValueError("img and dot_out go together")
-        if img is not None and (tuple(img.shape) != tuple(gimg.shape) or dot_out.dtype != torch.float32 or dot_out.numel() != 1):
-            raise ValueError("img must have gimg's shape and dot_out must be one float32")
+        if img is not None and (tuple(img.shape) != tuple(gimg.shape) or dot_out.dtype != torch.float32 or dot_out.numel() != render_dot_slots(sd.cam.width, sd.cam.height)):
+            raise ValueError("img must have gimg's shape and dot_out must be render_dot_slots(W, H) float32 partial sums (the caller zeroes and sums them)")
         with self._timed("render_bwd_cached"):
             self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
                        _dev(gimg, name="gimg"), _dev(gtex), _dev(img, img.dtype, "img") if img is not None else None,

@@ -156,12 +156,17 @@ class PatternOptimizer:
         buf = getattr(self, "_pat_buf", None)
         if buf is None or buf[0].shape[0] != rd.shape[0] or tuple(buf[1].shape) != (s1, s0) or (buf[2] is None) == want_reg:
             buf = None
-        if getattr(self, "_acc", None) is None or self._acc.numel() != s0 * s1 + 1:
-            self._acc = torch.empty(s0 * s1 + 1, dtype=torch.float32, device=rd.device)  # texture gradient + loss, cleared by the pattern launch
+        # the step's accumulator: the texture gradient, then the data term's partial sums (one slot per 8x8-pixel block of the film:
+        # K9 adds <gimg, img> of its block to its own slot, other losses add to slot 0) — cleared by the pattern launch, summed by pattern_bwd
+        cam = ms.data.camera
+        n_slots = ops.render_dot_slots(cam.width, cam.height)
+        if getattr(self, "_acc", None) is None or self._acc.numel() != s0 * s1 + n_slots:
+            self._acc = torch.empty(s0 * s1 + n_slots, dtype=torch.float32, device=rd.device)
         pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf, zero=self._acc)
         tex = ops.blur_fwd(tsum, self.blur[0], self.blur[1]) if self.blur else tsum
         tex3 = tex.unsqueeze(-1)
-        gtex, loss_sum = self._acc[:-1].view(tex3.shape), self._acc[-1]
+        gtex, loss_slots = self._acc[: s0 * s1].view(tex3.shape), self._acc[s0 * s1:]
+        loss_sum = loss_slots[0]
         # this rank's scene samples: all their random draws up front (each under its own seed, as
         # manual_seed(s); randomize() would make them), ONE device-to-host transfer for the lot
         seeds = self._sample_seeds(self.step_index)
@@ -194,7 +199,7 @@ class PatternOptimizer:
             img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
             if linear is not None and use_cache:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
-                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_sum)
+                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)
                 continue
             if fast_loss is not None:
                 gimg = fast_loss(img, loss_sum)
@@ -216,13 +221,13 @@ class PatternOptimizer:
         st, g = self._adam_state(rays)
         grad = torch.empty_like(rd)
         if w > 1:
-            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws)
-            flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), loss_sum.reshape(1)])
+            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_slots, loss_div=float(S))
+            flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), val[2:3]])  # (val[2]: this rank's data term)
             dist.allreduce_sum_(flat)  # the ONE exchange of a step: [3N + 1] floats
             gsum = flat[:-1].reshape(rays.shape).contiguous()
             loss = flat[-1] / float(S) + val[0]
         else:  # nothing to exchange: the total loss comes out of the backward launch, the gradient parts meet in the update launch
-            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_sum, loss_div=float(S))
+            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_slots, loss_div=float(S))
             gsum = gd if gd is not None else torch.zeros_like(rd)
             loss = val[1]
         # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()

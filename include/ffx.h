@@ -166,7 +166,8 @@ int ffx_l1_value_grad(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, 
  *                     ws[ffx_pattern_ws_floats(size0, size1)] = partial sums of |tsor - tsum| (any partition).
  *   ffx_pattern_bwd : grays_data = d/d rays of <gts, tsum>  (gts = upstream gradient on the SUM texture; NULL: skipped);
  *                     grays_reg  = d/d rays of reg_weight * mean|tsor - tsum|;  reg_value[0] = that value and, if
- *                     loss_in is given, reg_value[1] = loss_in[0] / loss_div + reg_value[0] (the step's total loss).
+ *                     loss_in is given, reg_value[1] = sum(loss_in) / loss_div + reg_value[0] (the step's total loss) and
+ *                     reg_value[2] = sum(loss_in).
  *   ffx_adam_clamp_step : g = grad / grad_div + grad_b (grad_b may be NULL; g is stored in grad_out, which may be NULL
  *                     if there is nothing to combine), then torch.optim.Adam's update of rays with (exp_avg,
  *                     exp_avg_sq, step [dev][1], incremented; lr / betas / eps as the doubles torch holds), then
@@ -182,8 +183,9 @@ int ffx_pattern_fwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[
 int ffx_pattern_bwd(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                     const float *tsum /*[dev]*/, const float *tsor /*[dev] or NULL*/, const float *gts /*[dev] or NULL*/,
                     float reg_weight, const float *ws /*[dev] or NULL*/, float *grays_data /*[dev][n,3] or NULL*/,
-                    float *grays_reg /*[dev][n,3] or NULL*/, float *reg_value /*[dev][2] or NULL*/,
-                    const float *loss_in /*[dev][1] or NULL*/, float loss_div, ffx_stream stream);
+                    float *grays_reg /*[dev][n,3] or NULL*/, float *reg_value /*[dev][3] or NULL*/,
+                    const float *loss_in /*[dev][loss_in_n] or NULL: partial sums of the data term (ffx_render_bwd_cached's dot slots, or one value)*/,
+                    int loss_in_n, float loss_div, ffx_stream stream);
 int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[dev][n,3]*/, const float *grad_b /*[dev][n,3] or NULL*/,
                         float grad_div, float *grad_out /*[dev][n,3] or NULL*/, float *exp_avg /*[dev][n,3]*/,
                         float *exp_avg_sq /*[dev][n,3]*/, float *step /*[dev][1]*/, int n, double lr, double beta1, double beta2,
@@ -421,15 +423,17 @@ int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[
                          const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                          const float *tex /*[dev]*/, int spp, uint32_t seed, int img_fp16,
                          void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes*/, ffx_stream stream);
-/* Optionally the same launch accumulates  dot_out[0] += <gimg, img>  (img: the forward's image, fp32 or fp16): for a loss that
- * is linear in the image — the coverage loss of a pattern optimiser, -mean(green) — gimg is constant and that inner product
- * IS the loss value, so a gradient step needs no separate reduction launch (the reference's loop evaluates the loss with
- * torch reductions: fireflies/graphics/rasterization.py:589-601).  img = dot_out = NULL: off.  Accumulated with float atomics
- * (one per 8x8-pixel block): the last bits depend on the order. */
+/* Optionally the same launch accumulates <gimg, img> (img: the forward's image, fp32 or fp16): for a loss that is linear in
+ * the image — the coverage loss of a pattern optimiser, -mean(green) — gimg is constant and that inner product IS the loss
+ * value, so a gradient step needs no separate reduction launch (the reference's loop evaluates the loss with torch
+ * reductions: fireflies/graphics/rasterization.py:589-601).  dot_out is an array of ffx_render_dot_slots(W, H) partial sums
+ * (one per 8x8-pixel block; each is ADDED to, the caller zeroes them once and sums them — ffx_pattern_bwd's loss_in does):
+ * spread because thousands of float atomics on one address serialise (measured +40 us).  img = dot_out = NULL: off. */
+size_t ffx_render_dot_slots(int width, int height);
 int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, const void *img /*[dev][H,W,3] or NULL*/, int img_fp16,
-                          float *dot_out /*[dev][1] or NULL*/, ffx_stream stream);
+                          float *dot_out /*[dev][ffx_render_dot_slots] or NULL*/, ffx_stream stream);
 /* The cache is lossy when its arena of single-sample records fills up (a projector texture much finer than the camera's
  * pixel footprint, grazing views: most samples then miss their pixel's 5x5 window).  Samples beyond the arena are counted
  * in `dropped` and ffx_render_bwd_cached then poisons gtex[0] with NaN instead of returning a gradient with silent holes.

@@ -1383,6 +1383,8 @@ static inline float f16_to_f32(uint16_t h) {
   return f;
 }
 
+size_t ffx_render_dot_slots(int width, int height) { return (width < 1 || height < 1) ? 0 : (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8); }
+
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
   (void)s;
@@ -1391,7 +1393,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
     if (dot_out) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> needs a projector (as in libffx_hip)");
     return FFX_OK;
   }
-  if (dot_out) { /* dot_out[0] += <gimg, img>, double accumulation in pixel order */
+  if (dot_out) { /* sum of the slots += <gimg, img>: double accumulation in pixel order, added to slot 0 */
     double acc = 0.0;
     const long n3 = (long)sd->cam.width * sd->cam.height * 3;
     for (long i = 0; i < n3; ++i) acc += (double)gimg[i] * (double)((img_fp16 & 1) ? f16_to_f32(((const uint16_t *)img)[i]) : ((const float *)img)[i]);
@@ -1511,8 +1513,9 @@ int ffx_pattern_fwd(const float *rays, int n, const float *KF, float sigma, int 
 }
 
 int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts,
-                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, float loss_div, ffx_stream s) {
-  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)))
+                    float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gts && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)) ||
+      (loss_in && (loss_in_n < 1 || !reg_value)))
     FAIL(FFX_ERR_ARG, "pattern_bwd: bad argument");
   const size_t T = (size_t)size0 * size1;
   float *p3 = (float *)malloc(sizeof(float) * 3 * (size_t)n), *pts = (float *)malloc(sizeof(float) * 2 * (size_t)n);
@@ -1543,7 +1546,12 @@ int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int 
   } else if (reg_value) {
     reg_value[0] = 0.f;
   }
-  if (rc == FFX_OK && reg_value && loss_in) reg_value[1] = loss_in[0] / (loss_div > 0.f ? loss_div : 1.0f) + reg_value[0];
+  if (rc == FFX_OK && reg_value && loss_in) {
+    double ls = 0.0;
+    for (int t = 0; t < loss_in_n; ++t) ls += (double)loss_in[t];
+    reg_value[1] = (float)ls / (loss_div > 0.f ? loss_div : 1.0f) + reg_value[0];
+    reg_value[2] = (float)ls;
+  }
 done:
   free(p3); free(pts); free(gp); free(gp2); free(g3); free(gd);
   return rc;

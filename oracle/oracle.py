@@ -93,16 +93,22 @@ def pattern_fwd(rays, KF, sigma, size0, size1, want_softor=True):
     return pts, tsum, tsor, ws
 
 
-def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws):
+def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, loss_in=None, loss_div=1.0):
+    """-> (grays_data, grays_reg, regulariser value); with `loss_in` (partial sums of the data term) a 4th item:
+    (sum(loss_in) / loss_div + regulariser, sum(loss_in))"""
     rays = _f32(rays)
     n = rays.shape[0]
     gd = np.zeros((n, 3), np.float32)
     gr = np.zeros((n, 3), np.float32)
-    val = np.zeros(2, np.float32)
+    val = np.zeros(3, np.float32)
     gts = None if gts is None else _f32(gts)
+    li = None if loss_in is None else _f32(loss_in).reshape(-1)
     api().call("ffx_pattern_bwd", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(_f32(tsum)), _p(_f32(tsor)) if tsor is not None else None,
-               _p(gts) if gts is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val), None, 1.0, None)
-    return gd, gr, float(val[0])
+               _p(gts) if gts is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val),
+               _p(li) if li is not None else None, 0 if li is None else int(li.size), float(loss_div), None)
+    if li is None:
+        return gd, gr, float(val[0])
+    return gd, gr, float(val[0]), (float(val[1]), float(val[2]))
 
 
 def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1):
