@@ -688,6 +688,26 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
         g_cached = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg)))
         gd.update(xf, pose[0])
         g_oracle = go.render_bwd_cached(sd, alb, cache_o, spp, gimg)
+        # the same launch can add <gimg, img> (the value of a linear loss) to per-block partial sums: both film formats, accumulating
+        want = float((gimg.astype(np.float64) * host(img_c).astype(np.float64)).sum())
+        mag = max(1.0, float(np.abs(gimg * host(img_c)).sum()))
+        n_slots = ops.render_dot_slots(52, 44)
+        assert n_slots == 7 * 6  # one partial sum per 8x8-pixel block
+        dot = torch.full((n_slots,), 0.25, device="cuda")  # the slots are ADDED to
+        g_dot = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img_c, dot_out=dot))
+        assert abs(float(dot.double().sum()) - 0.25 * n_slots - want) <= 2e-5 * mag
+        assert np.abs(g_dot - g_cached).max() <= 1e-3 * max(float(np.abs(g_cached).max()), 1e-20)  # (float atomics: order only)
+        img16 = gd.render_fwd(sd, dev(alb), tex, spp, seed=3, fp16=True)
+        dot16 = torch.zeros(n_slots, device="cuda")
+        gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img16, dot_out=dot16)
+        want16 = float((gimg.astype(np.float64) * host(img16).astype(np.float64)).sum())
+        assert abs(float(dot16.double().sum()) - want16) <= 2e-5 * mag
+        _, dot_o = go.render_bwd_cached(sd, alb, cache_o, spp, gimg, img=img_o)
+        assert abs(dot_o - want) <= 1e-3 * mag  # (the oracle's own image: equal within the image tolerance)
+        with pytest.raises(ValueError):
+            gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img_c)
+        with pytest.raises(ValueError):
+            gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img16, dot_out=torch.zeros(1, device="cuda"))
         scale = float(np.abs(g_oracle).max())
         assert scale > 0
         for a, b in ((g_cached, g_retrace), (g_cached, g_oracle), (g_oracle, go.render_bwd(sd, alb, spp, 3, gimg))):
@@ -790,6 +810,12 @@ def test_fused_pattern_kernels_match_the_unfused_oracle(oracle, n, size, sigma):
             assert float(val_d[0]) == pytest.approx(val_o, rel=1e-5)
         else:
             assert gr_d is None and float(val_d[0]) == 0.0
+    # the data term's partial sums (K9's dot slots) are summed by the same launch: total loss and the raw sum
+    li = rng.standard_normal(300).astype(np.float32)
+    _, _, val_l = ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_d, tsor_d, dev(gts), 0.1, ws_d, loss_in=dev(li), loss_div=4.0)
+    _, _, reg_o, (tot_o, raw_o) = oracle.pattern_bwd(rays, KF, sigma, s0, s1, tsum_o, tsor_o, gts, 0.1, ws_o, loss_in=li, loss_div=4.0)
+    assert float(val_l[2]) == pytest.approx(float(li.astype(np.float64).sum()), abs=1e-4) and raw_o == pytest.approx(float(val_l[2]), abs=1e-4)
+    assert float(val_l[1]) == pytest.approx(tot_o, rel=1e-5, abs=1e-5) and float(val_l[0]) == pytest.approx(reg_o, rel=1e-5)
     # no data term (a rank without samples): only the regulariser
     gd_d, gr_d, _ = ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_d, tsor_d, None, 0.1, ws_d)
     assert gd_d is None
