@@ -39,6 +39,19 @@ class BvhInfo(C.Structure):
         ("off_plan", C.c_uint64),
         ("n_treelets", C.c_int32),
         ("plan_ints", C.c_int32),
+        ("off_nrec", C.c_uint64),
+    ]
+
+
+class Smooth(C.Structure):
+    """ffx_smooth: interpolated shading normals (host struct with two host tables and device tables)"""
+    _fields_ = [
+        ("shape_smooth", C.POINTER(C.c_int32)),
+        ("shape_vbase", C.POINTER(C.c_int32)),
+        ("adj_start", C.c_void_p),
+        ("adj", C.c_void_p),
+        ("n_vn", C.c_int32),
+        ("vnormals", C.c_void_p),
     ]
 
 
@@ -122,8 +135,8 @@ PROTOTYPES = {
     "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),
     "ffx_bvh_build_host": (c_i, [c_p, c_i, c_p, c_i, c_p, C.c_size_t, C.POINTER(BvhInfo)]),
-    "ffx_scene_update": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
-    "ffx_scene_update_h": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, C.POINTER(C.c_int32), PF, c_i, c_p]),
+    "ffx_scene_update": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, c_p, c_p, c_i, C.POINTER(Smooth), c_p]),
+    "ffx_scene_update_h": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, C.POINTER(C.c_int32), PF, c_i, C.POINTER(Smooth), c_p]),
     "ffx_trace_primary": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(Camera), c_i, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
     "ffx_trace_rays": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),

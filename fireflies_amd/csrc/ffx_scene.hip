@@ -36,12 +36,85 @@
 
 // per-shape tables as a kernel argument (ffx_scene_update_h): 32 * (1 + 12) dwords = 1664 B of kernarg
 struct ShapeTabH { int32_t off[FFX_MAX_SHAPES_H]; float m[FFX_MAX_SHAPES_H][12]; };
+// ffx_smooth's two host tables as kernel arguments; `vn` / `nrec` NULL: no shape interpolates its normals
+struct SmoothTab { int32_t on[FFX_MAX_SHAPES_H]; int32_t vbase[FFX_MAX_SHAPES_H]; const float *vn; float4 *nrec; };
+
+// Vertex normals of the current pose (ffx.h ffx_smooth) [EXT Mitsuba mesh.cpp recompute_vertex_normals]: a lane per vertex
+// row walks the corners incident to it in ascending triangle order — the oracle's face-major loop adds to a vertex in the
+// same order, so the sums see the same operands (the results differ only where asinf / sqrtf differ in the last bit).
+__device__ __forceinline__ float unit_angle_f(v3 a, v3 b) {
+  const float dt = vdot(a, b);
+  if (dt >= 0.f) {
+    const v3 df = vsub(b, a);
+    return 2.0f * asinf(fminf(0.5f * sqrtf(vdot(df, df)), 1.f));
+  }
+  const v3 sm = V3(a.x + b.x, a.y + b.y, a.z + b.z);
+  return 3.14159265358979323846f - 2.0f * asinf(fminf(0.5f * sqrtf(vdot(sm, sm)), 1.f));
+}
+template <bool HOST_TAB>
+__global__ void __launch_bounds__(UPD_BLOCK)
+    k_vertex_normals(const int32_t *__restrict__ adj_start, const int32_t *__restrict__ adj, int n_vn, float *__restrict__ vn, const float *__restrict__ src_verts,
+                     const int32_t *__restrict__ tris, const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off,
+                     const float *__restrict__ xform, int n_shapes, ShapeTabH tab) {
+  const int row = blockIdx.x * UPD_BLOCK + threadIdx.x;
+  if (row >= n_vn) return;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  const int b = adj_start[row], e = adj_start[row + 1];
+  for (int i = b; i < e; ++i) {
+    const int key = adj[i], t = key >> 2, c = key & 3;
+    int sh = tri_shape[t];
+    sh = min(max(sh, 0), n_shapes - 1);
+    float mm[12];
+    int base;
+    if (HOST_TAB) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) mm[j] = tab.m[sh][j];
+      base = tab.off[sh];
+    } else {
+      const float *m = xform + 16 * sh;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) mm[j] = m[j];
+      base = vert_off[sh];
+    }
+    v3 p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float *sv = src_verts + 3 * ((size_t)base + tris[3 * t + k]);
+      p[k] = xf_point(mm, V3(sv[0], sv[1], sv[2]));
+    }
+    v3 n = vcross(vsub(p[1], p[0]), vsub(p[2], p[0]));
+    const float nl = sqrtf(vdot(n, n));
+    if (!(nl > 0.f)) continue;
+    n = V3(n.x / nl, n.y / nl, n.z / nl);
+    const v3 pc = c == 0 ? p[0] : (c == 1 ? p[1] : p[2]), pa = c == 0 ? p[1] : (c == 1 ? p[2] : p[0]), pb = c == 0 ? p[2] : (c == 1 ? p[0] : p[1]);
+    v3 d0 = vsub(pa, pc), d1 = vsub(pb, pc);
+    const float l0 = sqrtf(vdot(d0, d0)), l1 = sqrtf(vdot(d1, d1));
+    if (!(l0 > 0.f) || !(l1 > 0.f)) continue;
+    d0 = V3(d0.x / l0, d0.y / l0, d0.z / l0);
+    d1 = V3(d1.x / l1, d1.y / l1, d1.z / l1);
+    const float w = unit_angle_f(d0, d1);
+    ax = fmaf(n.x, w, ax); ay = fmaf(n.y, w, ay); az = fmaf(n.z, w, az);
+  }
+  const float l = sqrtf(fmaf(ax, ax, fmaf(ay, ay, az * az)));
+  if (l > 0.f) { ax /= l; ay /= l; az /= l; }
+  vn[3 * (size_t)row] = ax; vn[3 * (size_t)row + 1] = ay; vn[3 * (size_t)row + 2] = az;
+}
+// the record's flag and its three vertex normals (a lane that has just built the record of leaf slot k)
+__device__ __forceinline__ float write_slot_normals(const SmoothTab &sm, int sh, int prim, int k, const int32_t *__restrict__ tris) {
+  if (!sm.vn || !sm.on[sh]) return 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *q = sm.vn + 3 * ((size_t)sm.vbase[sh] + tris[3 * prim + c]);
+    sm.nrec[3 * (size_t)k + c] = make_float4(q[0], q[1], q[2], 0.f);
+  }
+  return 1.0f;
+}
 
 template <bool HOST_TAB>
 __global__ void __launch_bounds__(UPD_BLOCK)
     k_build_records(const int32_t *__restrict__ order, TriRec *__restrict__ recs, int n_tris, const float *__restrict__ src_verts,
                     const int32_t *__restrict__ tris, const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off,
-                    const float *__restrict__ xform, int n_shapes, ShapeTabH tab) {
+                    const float *__restrict__ xform, int n_shapes, ShapeTabH tab, SmoothTab sm) {
   int k = blockIdx.x * UPD_BLOCK + threadIdx.x;
   if (k >= n_tris) return;
   int prim = order[k];
@@ -69,7 +142,7 @@ __global__ void __launch_bounds__(UPD_BLOCK)
   float4 *o = reinterpret_cast<float4 *>(recs + k);
   o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
   o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-  o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), 0.f);
+  o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), write_slot_normals(sm, sh, prim, k, tris));
 }
 
 // conservative box of a leaf's triangles.  The intersection test works on (v0, e1, e2), whose
@@ -257,7 +330,8 @@ template <bool HOST_TAB>
 __global__ void __launch_bounds__(FUSED_BLOCK)
     k_scene_update_fused(BvhNode *nodes, TriRec *recs, const int32_t *__restrict__ order, WideChild *tq, WideChild *wn, const int32_t *__restrict__ wsrc,
                          int32_t *plan, int n_treelets, int counter_at, const float *__restrict__ src_verts, const int32_t *__restrict__ tris,
-                         const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off, const float *__restrict__ xform, int n_shapes, ShapeTabH tab) {
+                         const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off, const float *__restrict__ xform, int n_shapes, ShapeTabH tab,
+                         SmoothTab sm) {
   __shared__ int s_last;
   const int32_t *h = plan + 8 * blockIdx.x;
   // ---- A: records and per-triangle boxes of this treelet's run of leaf slots
@@ -288,7 +362,7 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
     float4 *o = reinterpret_cast<float4 *>(recs + k);
     o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
     o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), 0.f);
+    o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), write_slot_normals(sm, sh, prim, k, tris));
     const float a0[3] = {p[0].x, p[0].y, p[0].z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
     WideChild c;
     tri_wide_box(a0, a1, a2, c);
@@ -318,7 +392,7 @@ static int refit_fused_enabled() {
 }
 
 static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                             const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s, bool host_tab) {
+                             const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s, bool host_tab) {
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
   if (host_tab && n_shapes > FFX_MAX_SHAPES_H) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_update_h: more than %d shapes", FFX_MAX_SHAPES_H);
   if (info->n_tris < 1 || info->n_nodes < 1 || info->n_levels < 1 || info->n_levels > FFX_MAX_LEVELS)
@@ -338,6 +412,28 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
       for (int j = 0; j < 12; ++j) tab.m[i][j] = xform[16 * i + j];
     }
   }
+  // interpolated shading normals (ffx_smooth): the vertex normals of this pose first (one launch, only when a shape asks)
+  SmoothTab sm;
+  memset(&sm, 0, sizeof sm);
+  if (smooth) {
+    if (!smooth->shape_smooth || !smooth->shape_vbase || !smooth->adj_start || !smooth->adj || !smooth->vnormals || smooth->n_vn < 1)
+      FFX_FAIL(FFX_ERR_ARG, "scene_update: bad ffx_smooth");
+    if (n_shapes > FFX_MAX_SHAPES_H) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_update: ffx_smooth with more than %d shapes", FFX_MAX_SHAPES_H);
+    if (info->off_nrec == 0 || info->off_nrec + 48ull * (uint64_t)info->n_tris > info->total_bytes) FFX_FAIL(FFX_ERR_ARG, "scene_update: blob without a normal area");
+    bool any = false;
+    for (int i = 0; i < n_shapes; ++i) { sm.on[i] = smooth->shape_smooth[i] != 0; sm.vbase[i] = smooth->shape_vbase[i]; any |= sm.on[i] != 0; }
+    if (any) {
+      sm.vn = smooth->vnormals;
+      sm.nrec = (float4 *)(base + info->off_nrec);
+      if (host_tab)
+        hipLaunchKernelGGL(k_vertex_normals<true>, dim3(ffx_cdiv(smooth->n_vn, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, smooth->adj_start, smooth->adj, smooth->n_vn,
+                           smooth->vnormals, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
+      else
+        hipLaunchKernelGGL(k_vertex_normals<false>, dim3(ffx_cdiv(smooth->n_vn, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, smooth->adj_start, smooth->adj, smooth->n_vn,
+                           smooth->vnormals, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab);
+      FFX_CHECK_LAUNCH("scene_update/vertex_normals");
+    }
+  }
 #if FFX_WIDE_F32
   if (info->off_plan != 0 && info->n_treelets > 0 && info->off_tq != 0 && refit_fused_enabled()) {
     if (info->plan_ints < 8 * (info->n_treelets + 1) + 1 || info->off_plan + 4ull * (uint64_t)info->plan_ints > info->total_bytes)
@@ -347,20 +443,20 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
     int32_t *plan = (int32_t *)(base + info->off_plan);
     if (host_tab)
       hipLaunchKernelGGL(k_scene_update_fused<true>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
-                         info->plan_ints - 1, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
+                         info->plan_ints - 1, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab, sm);
     else
       hipLaunchKernelGGL(k_scene_update_fused<false>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
-                         info->plan_ints - 1, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab);
+                         info->plan_ints - 1, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab, sm);
     FFX_CHECK_LAUNCH("scene_update/fused");
     return FFX_OK;
   }
 #endif
   if (host_tab) {
     hipLaunchKernelGGL(k_build_records<true>, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
-                       tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab);
+                       tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab, sm);
   } else {
     hipLaunchKernelGGL(k_build_records<false>, dim3(ffx_cdiv(info->n_tris, UPD_BLOCK)), dim3(UPD_BLOCK), 0, st, order, recs, info->n_tris, src_verts, tris,
-                       tri_shape, vert_off, xform, n_shapes, tab);
+                       tri_shape, vert_off, xform, n_shapes, tab, sm);
   }
   FFX_CHECK_LAUNCH("scene_update/build_records");
 
@@ -394,11 +490,11 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
 }
 
 extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                                const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
-  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s, false);
+                                const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s) {
+  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s, false);
 }
 
 extern "C" int ffx_scene_update_h(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                                  const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
-  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s, true);
+                                  const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s) {
+  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s, true);
 }

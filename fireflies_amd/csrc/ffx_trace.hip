@@ -281,6 +281,30 @@ __device__ __forceinline__ float sqrt_nr(float x) {
   return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
 }
 
+// Shading normal of a hit on a record flagged by ffx_smooth (include/ffx.h): the three vertex normals stored next to the
+// record, interpolated with Moller-Trumbore's barycentrics of the hit (P = v0 + u e1 + v e2, recomputed here from the record:
+// the walks do not carry them), normalised and faced to the viewer by the sign of ITS OWN cosine (the `twosided` wrapper flips
+// in the shading frame).  Same operation order as the oracle's shade_sample; FAST: the Newton-refined reciprocals of the packet
+// kernels instead of IEEE division (equal except for rare last bits).  A zero-length interpolated normal keeps the geometric one.
+template <bool FAST>
+__device__ __forceinline__ v3 interpolated_normal(const float4 *__restrict__ nrec, int slot, float4 ra, float4 rb, float4 rc, v3 o, v3 d, v3 ng) {
+  const v3 e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);
+  const v3 pv = vcross(d, e2);
+  const float det = vdot(e1, pv);
+  const v3 tv = vsub(o, V3(ra.x, ra.y, ra.z));
+  const v3 qv = vcross(tv, e1);
+  const float idet = FAST ? rcp_nr(det) : 1.0f / det;
+  const float bu = vdot(tv, pv) * idet, bv = vdot(d, qv) * idet, bw = (1.0f - bu) - bv;
+  const float4 n0 = nrec[3 * (size_t)slot], n1 = nrec[3 * (size_t)slot + 1], n2 = nrec[3 * (size_t)slot + 2];
+  const v3 ni = V3(fmaf(bw, n0.x, fmaf(bu, n1.x, bv * n2.x)), fmaf(bw, n0.y, fmaf(bu, n1.y, bv * n2.y)), fmaf(bw, n0.z, fmaf(bu, n1.z, bv * n2.z)));
+  const float l2 = vdot(ni, ni);
+  if (!(l2 > 0.f)) return ng;
+  const float il = FAST ? rcp_nr(sqrt_nr(l2)) : 1.0f / sqrtf(l2);
+  v3 ns = V3(ni.x * il, ni.y * il, ni.z * il);
+  if (vdot(ns, d) > 0.f) ns = V3(-ns.x, -ns.y, -ns.z);
+  return ns;
+}
+
 // BSDF of a material row (include/ffx.h FFX_MAT_*, model 1: the reflection side of Mitsuba's `principled`), for the
 // viewer direction wv and an emitter direction wl at a surface with unit normal n facing the viewer:
 //     pi * f(wv, wl) * cos_o = base_color * A + B   per colour channel.
@@ -435,8 +459,8 @@ struct SampleTerms {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, v3 o, v3 d, float nt,
-                                             float ft, SampleTerms &st, int *stack, int stride) {
+__device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float4 *__restrict__ nrec, v3 o,
+                                             v3 d, float nt, float ft, SampleTerms &st, int *stack, int stride) {
   Hit h;
   st.hit = traverse<false, true>(nodes, recs, o, d, nt, ft, h, stack, stride);
   st.has_proj = 0;
@@ -457,6 +481,9 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
   float off = (1.0f + pmax) * RAY_EPS;
   v3 Po = V3(fmaf(off, ng.x, P.x), fmaf(off, ng.y, P.y), fmaf(off, ng.z, P.z));
+  // shading normal (ffx_smooth): BSDF and emitter cosines use it; the geometric normal keeps the side tests
+  v3 ns = ng;
+  if (rc.w != 0.f && nrec) ns = interpolated_normal<false>(nrec, h.slot, ra, rb, rc, o, d, ng);
 
   if (c.proj_on) {
     v3 pl = xf_point(c.p_w2l, P);
@@ -473,9 +500,9 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         float d2 = vdot(wi, wi);
         const float idist = 1.0f / sqrtf(d2);
         wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-        float cos_s = vdot(ng, wi);
+        float cos_s = vdot(ns, wi);
         float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
-        if (cos_s > 0.f && cos_p > 0.f) {
+        if (cos_s > 0.f && cos_p > 0.f && vdot(ng, wi) > 0.f) {
           bool vis = true;
           if (c.shadows) { // traced FROM the emitter (the batch's apex) to the lifted surface point: t in (0, 1 - eps)
             Hit hs;
@@ -486,7 +513,7 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
             if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
               const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
               MatGeo mg;
-              material_geometry(mrow, ng, V3(-d.x, -d.y, -d.z), wi, mg);
+              material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
               material_terms(mrow, mg, bA, bB);
             }
             st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * bA;
@@ -514,8 +541,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
     float d2 = vdot(wi, wi);
     const float idist = 1.0f / sqrtf(d2);
     wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-    float cos_s = vdot(ng, wi);
-    if (cos_s > 0.f) {
+    float cos_s = vdot(ns, wi);
+    if (cos_s > 0.f && vdot(ng, wi) > 0.f) {
       v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
       float ln = sqrtf(vdot(ll, ll));
       float cos_t = ll.z / ln;
@@ -533,7 +560,7 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
             const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
             MatGeo mg;
-            material_geometry(mrow, ng, V3(-d.x, -d.y, -d.z), wi, mg);
+            material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
             material_terms(mrow, mg, bA, bB);
           }
           float f = fall * bA / d2 * 0.3183098861837907f, fb = fall * bB / d2 * 0.3183098861837907f;
@@ -575,7 +602,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks, int mode) {
 }
 
 __global__ void __launch_bounds__(TR_BLOCK)
-    k_render_fwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo,
+    k_render_fwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float4 *__restrict__ nrec, const float *__restrict__ albedo,
                  const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap, int fp16, void *__restrict__ img) {
   extern __shared__ int s_dyn[];
   __shared__ float s_red[3][3][64]; // waves 1..3 -> wave 0
@@ -595,7 +622,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
       float nt, ft;
       cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
       SampleTerms st;
-      shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+      shade_sample(c, nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
       if (!st.hit) continue;
       float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
       float b0 = st.spot_b[0], b1 = st.spot_b[1], b2 = st.spot_b[2];
@@ -666,7 +693,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
 
 // K9: replay the same samples, scatter d(loss)/d(img) * d(img)/d(tex) through the bilinear weights.
 __global__ void __launch_bounds__(TR_BLOCK)
-    k_render_bwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float *__restrict__ albedo, int spp,
+    k_render_bwd(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const float4 *__restrict__ nrec, const float *__restrict__ albedo, int spp,
                  uint32_t seed_key, int tiles_x, int n_tiles, int remap, const float *__restrict__ gimg, float *__restrict__ gtex) {
   extern __shared__ int s_dyn[];
   int tile = xcd_remap(blockIdx.x, gridDim.x, remap);
@@ -687,7 +714,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
     float nt, ft;
     cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
     SampleTerms st;
-    shade_sample(c, nodes, recs, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+    shade_sample(c, nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
     if (!st.hit || !st.has_proj) continue;
     const float *alb = albedo + (size_t)c.mat_stride * st.shape;
     size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
@@ -1692,7 +1719,7 @@ template <int R, bool WIDE, bool MAT = false>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
-                                                const float *__restrict__ tex_probe = nullptr) {
+                                                const float4 *__restrict__ nrec, const float *__restrict__ tex_probe = nullptr) {
   Hit h[R];
   bool fnd[R];
   traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
@@ -1702,6 +1729,10 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     ShadePre &q = pre[r];
+    // shading normal of this sample (ffx_smooth): equal to the geometric one unless the hit record is flagged.  It takes the
+    // geometric normal's place in q.ng once the geometric side tests below are done (one normal stays live across the walks).
+    v3 ns = V3(0.f, 0.f, 1.f);
+    bool smooth = false;
     st[r].hit = h[r].prim >= 0;
     st[r].has_proj = 0;
     st[r].proj_fac = 0.f; st[r].proj_fac_b = 0.f;
@@ -1731,8 +1762,15 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         float pmax = fmaxf(fabsf(q.P.x), fmaxf(fabsf(q.P.y), fabsf(q.P.z)));
         float off = (1.0f + pmax) * RAY_EPS;
         q.Po = V3(fmaf(off, ng.x, q.P.x), fmaf(off, ng.y, q.P.y), fmaf(off, ng.z, q.P.z));
+        ns = ng;
+        smooth = rc.w != 0.f;
+        if (wballot(smooth) != 0ull) { // (wave-uniform: scenes without flagged records never enter)
+          const v3 ni = interpolated_normal<true>(nrec, smooth ? h[r].slot : 0, ra, rb, rc, o[r], d[r], ng);
+          if (smooth) ns = ni;
+        }
       }
     }
+    const bool any_smooth = wballot(smooth) != 0ull;
     // ---- projector terms
     q.need_p = false;
     q.pfac = 0.f; q.u = 0.f; q.v = 0.f;
@@ -1758,9 +1796,10 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           float d2 = vdot(wi, wi);
           const float idist = rcp_nr(sqrt_nr(d2));
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-          float cos_s = vdot(q.ng, wi);
+          float cos_s = vdot(ns, wi);
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
           bool lit = cos_s > 0.f && cos_p > 0.f;
+          if (any_smooth) lit = lit && (!smooth || vdot(q.ng, wi) > 0.f); // the emitter on the viewer's GEOMETRIC side too
           if constexpr (MAT) {
             // (material rows: the texture probe — see below — comes first, it saves the BSDF of a dark footprint too)
             if (tex_probe && lit) lit = tex_footprint_lit(tex_probe, c.tw, c.th, c.tc, q.u, q.v);
@@ -1785,8 +1824,10 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       float d2 = vdot(wi, wi);
       const float idist = rcp_nr(sqrt_nr(d2));
       wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-      float cos_s = vdot(q.ng, wi);
-      if (cos_s > 0.f) {
+      float cos_s = vdot(ns, wi);
+      bool front = cos_s > 0.f;
+      if (any_smooth) front = front && (!smooth || vdot(q.ng, wi) > 0.f);
+      if (front) {
         v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
         float ln = sqrt_nr(vdot(ll, ll));
         float cos_t = div_nr(ll.z, ln);
@@ -1803,6 +1844,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         }
       }
     }
+    q.ng = ns; // from here on (BSDF after the walks) only the shading normal is needed
     // A plain forward render (no adjoint cache) does not need the projector's shadow ray where the projector shines
     // nothing: if the four texels of the sample's bilinear footprint are all exactly zero — most of a dot pattern is —
     // its contribution is zero whatever the walk finds.  (The cache-writing forward keeps every walk: the ADJOINT of a
@@ -2031,7 +2073,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
-                    uint32_t cache_foot_b_off) {
+                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec) {
   constexpr int NSUB = 4 / R;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
@@ -2095,7 +2137,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, (cache && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, (cache && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -2244,7 +2286,7 @@ template <int R, bool WIDE, bool MAT>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    const float *__restrict__ gimg, float *__restrict__ gtex) {
+                    const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec) {
   constexpr int NSUB = 4 / R;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
@@ -2283,7 +2325,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st);
+      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
@@ -2765,6 +2807,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  const float4 *nrec = info->off_nrec ? (const float4 *)((const char *)bvh + info->off_nrec) : nullptr; // vertex normals per slot (ffx_smooth)
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
@@ -2786,7 +2829,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 #define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
-                     arena_off, foot_b_off)
+                     arena_off, foot_b_off, nrec)
     if (use_wide(info)) { if (mat) FFX_LAUNCH_FWD(true, true); else FFX_LAUNCH_FWD(true, false); }
     else { if (mat) FFX_LAUNCH_FWD(false, true); else FFX_LAUNCH_FWD(false, false); }
 #undef FFX_LAUNCH_FWD
@@ -2796,7 +2839,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, tex, spp,
+  hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, nrec, shape_albedo, tex, spp,
                      seed_key_of(seed), tiles_x, n_tiles, xcd_mode(), img_fp16, img);
   FFX_CHECK_LAUNCH("render_fwd");
   return FFX_OK;
@@ -2885,6 +2928,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
+  const float4 *nrec = info->off_nrec ? (const float4 *)((const char *)bvh + info->off_nrec) : nullptr;
   if (use_packet()) {
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
@@ -2898,7 +2942,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     const WideScene ws = wide_scene(bvh, info);
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
-                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex)
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex, nrec)
     if (use_wide(info)) { if (mat) FFX_LAUNCH_BWD(true, true); else FFX_LAUNCH_BWD(true, false); }
     else { if (mat) FFX_LAUNCH_BWD(false, true); else FFX_LAUNCH_BWD(false, false); }
 #undef FFX_LAUNCH_BWD
@@ -2908,7 +2952,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, shape_albedo, spp, seed_key_of(seed),
+  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, c, nodes, recs, nrec, shape_albedo, spp, seed_key_of(seed),
                      tiles_x, n_tiles, xcd_mode(), gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd");
   return FFX_OK;

@@ -31,15 +31,21 @@ from . import scenes
 
 
 # ----------------------------------------------------------------------------- OBJ
-def load_obj(path):
+def load_obj(path, with_info=False):
     """-> (vertices [V,3] float32, triangles [F,3] int32).  Faces with more than three corners are
-    fan-triangulated; `v/vt/vn` corner syntax and negative (relative) indices are handled."""
+    fan-triangulated; `v/vt/vn` corner syntax and negative (relative) indices are handled.
+    with_info: a third item {"has_normals": the file carries `vn` records} — Mitsuba shades such a mesh with interpolated
+    vertex normals (re-derived from the positions after every vertex update: include/ffx.h ffx_smooth; the file's own
+    normal VALUES are therefore not kept)."""
     verts, tris = [], []
+    has_vn = False
     with open(path, "r") as f:
         for line in f:
             if line.startswith("v "):
                 p = line.split()
                 verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("vn "):
+                has_vn = True
             elif line.startswith("f "):
                 idx = []
                 for tok in line.split()[1:]:
@@ -51,7 +57,7 @@ def load_obj(path):
     t = np.asarray(tris, np.int32).reshape(-1, 3)
     if t.size and (t.min() < 0 or t.max() >= v.shape[0]):
         raise ValueError(f"{path}: face index out of range")
-    return v, t
+    return (v, t, {"has_normals": has_vn}) if with_info else (v, t)
 
 
 # ----------------------------------------------------------------------------- PLY
@@ -59,7 +65,7 @@ _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short":
               "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
 
 
-def load_ply(path):
+def load_ply(path, with_info=False):
     """Stanford PLY (ascii, binary_little_endian, binary_big_endian) -> (vertices [V,3] float32, triangles [F,3]
     int32).  Reads the `vertex` element's x/y/z and the `face` element's index list (vertex_indices /
     vertex_index), fan-triangulating polygons; other elements and properties are skipped.  `Scene` classifies
@@ -140,6 +146,9 @@ def load_ply(path):
     t = np.asarray(tris, np.int32).reshape(-1, 3)
     if t.size and (t.min() < 0 or t.max() >= verts.shape[0]):
         raise ValueError(f"{path}: face index out of range")
+    if with_info:  # (vertex normals nx/ny/nz: shaded with interpolated normals, like an OBJ with `vn`)
+        has_vn = any(el["name"] == "vertex" and {"nx", "ny", "nz"} <= {p[-1] for p in el["props"]} for el in elements)
+        return verts, t, {"has_normals": has_vn}
     return verts, t
 
 
@@ -424,11 +433,13 @@ def load_mitsuba_xml(path):
                     dropped("area-emitter", "area emitter on a shape ignored: only the delta emitters (projector, spot) illuminate the scene")
                 elif extra.tag in ("medium", "sensor"):
                     dropped(("shape-child", extra.tag), f"<{extra.tag}> inside <shape> ignored")
-            v, t = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]))
+            v, t, finfo = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]), with_info=True)
+            # Mitsuba: a mesh with vertex normals is shaded in the interpolated frame unless face_normals is set
+            smooth = bool(finfo["has_normals"]) and not bool(p.get("face_normals", False))
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
             alb, mat, bsdf = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
-            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat, bsdf))
+            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat, bsdf, smooth=smooth))
         elif node.tag == "emitter":
             p = _props(node)
             tw = _transform(_child(node, "transform", "to_world"))

@@ -303,7 +303,8 @@ class Scene:
             extra.append(m.frames[0])
             base += m.frames.shape[1]
         pool = np.concatenate([pool] + extra, 0)
-        self.geom = ops.DeviceGeometry(pool, tris, tri_shape, off, device=self.device)
+        # meshes that carry vertex normals are shaded with interpolated normals, re-derived from the posed vertices per update
+        self.geom = ops.DeviceGeometry(pool, tris, tri_shape, off, device=self.device, smooth=[bool(getattr(m, "smooth", False)) for m in data.meshes])
         self.mesh_names = [m.name for m in data.meshes]
         self._mesh_index = {m.name: i for i, m in enumerate(data.meshes)}
         S = len(data.meshes)

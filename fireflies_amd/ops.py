@@ -303,7 +303,9 @@ class DeviceGeometry:
     pool at the given offsets); `update()` is the per-randomisation device pass (K5+K6).
     """
 
-    def __init__(self, src_verts, tris, tri_shape, vert_off, device="cuda", build_xforms=None):
+    def __init__(self, src_verts, tris, tri_shape, vert_off, device="cuda", build_xforms=None, smooth=None):
+        """smooth: one flag per shape — interpolated shading normals, re-derived from the posed vertices by every update()
+        (include/ffx.h ffx_smooth: what Mitsuba does for meshes that carry vertex normals)."""
         src = np.ascontiguousarray(src_verts, dtype=np.float32).reshape(-1, 3)
         tr = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
         ts = np.ascontiguousarray(tri_shape, dtype=np.int32).reshape(-1)
@@ -361,6 +363,22 @@ class DeviceGeometry:
         self._vert_off_dev_stale = False
         self._pool_written = None  # event: the last write_verts() into the vertex pool (caller's stream)
         self.version = 0           # bumped by every update(): functional._Render pins the pose it traced
+        self._smooth = None
+        if smooth is not None and any(smooth):
+            from . import scenes as _scenes
+
+            if S > 32:
+                raise NotImplementedError("interpolated normals: at most 32 shapes (the per-shape tables travel as kernel arguments)")
+            flags, vbase, a0, adj, n_vn = _scenes.smooth_tables(tr, ts, smooth, S)
+            keep = {"flags": np.ascontiguousarray(flags), "vbase": np.ascontiguousarray(vbase), "adj_start": torch.from_numpy(a0).to(self.device),
+                    "adj": torch.from_numpy(adj if adj.size else np.zeros(1, np.int32)).to(self.device),
+                    "vn": torch.zeros((n_vn, 3), dtype=torch.float32, device=self.device)}  # scratch of the update (side stream)
+            sm = _abi.Smooth()
+            sm.shape_smooth = keep["flags"].ctypes.data_as(C.POINTER(C.c_int32))
+            sm.shape_vbase = keep["vbase"].ctypes.data_as(C.POINTER(C.c_int32))
+            sm.adj_start, sm.adj, sm.n_vn, sm.vnormals = keep["adj_start"].data_ptr(), keep["adj"].data_ptr(), int(n_vn), keep["vn"].data_ptr()
+            self._smooth = (sm, keep)
+        self.smooth = [bool(f) for f in smooth] if smooth is not None else [False] * S
         if self._async:  # blob copies / uploads above were enqueued on the caller's stream
             self._side.wait_stream(_stream_obj(self._didx))
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
@@ -458,7 +476,8 @@ class DeviceGeometry:
                 tabs[3][...] = self._vert_off_host
                 self._call(
                     "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-                    _dev(self.tri_shape, torch.int32), tabs[2], tabs[0], self.n_shapes, _stream(self._didx),
+                    _dev(self.tri_shape, torch.int32), tabs[2], tabs[0], self.n_shapes, C.byref(self._smooth[0]) if self._smooth is not None else None,
+                    _stream(self._didx),
                 )
                 return
             if self._vert_off_dev_stale:
@@ -469,7 +488,8 @@ class DeviceGeometry:
             self._xf = xf  # keep alive until the stream has consumed it
             self._call(
                 "ffx_scene_update", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
-                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes, _stream(self._didx),
+                _dev(self.tri_shape, torch.int32), _dev(self.vert_off, torch.int32), _dev(xf), self.n_shapes,
+                C.byref(self._smooth[0]) if self._smooth is not None else None, _stream(self._didx),
             )
 
     def trace_primary(self, cam, spp=1, jitter=0, seed=0, want_ids=True):

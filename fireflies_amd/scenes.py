@@ -55,6 +55,9 @@ class MeshData:
     albedo: tuple = (0.8, 0.8, 0.8)
     material: str = "mat-Default"
     bsdf: dict = None  # None: diffuse (Lambert); a dict: Mitsuba `principled` parameters by name (missing ones take PRINCIPLED_DEFAULTS)
+    # the mesh carries vertex normals (an OBJ with `vn`, a PLY with nx/ny/nz): Mitsuba then shades it in the frame of the
+    # interpolated normal and re-derives angle-weighted vertex normals after every vertex_positions update (include/ffx.h ffx_smooth)
+    smooth: bool = False
 
 
 @dataclass
@@ -296,3 +299,27 @@ def flatten(scene: SceneData):
         np.concatenate(pools, 0).astype(np.float32), np.concatenate(tris, 0).astype(np.int32), np.concatenate(shape, 0),
         np.asarray(off, np.int32), np.asarray(stride, np.int32), np.asarray(nfr, np.int32), np.asarray(alb, np.float32),
     )
+
+
+def smooth_tables(tris, tri_shape, smooth, n_shapes):
+    """Host tables of include/ffx.h `ffx_smooth` for shape-local triangles `tris` [F,3] with shapes `tri_shape` [F] and one flag
+    per shape: -> (shape_smooth [S] int32, shape_vbase [S] int32, adj_start [n_vn + 1] int32, adj [*] int32, n_vn).
+    Vertex row = vbase[shape] + local index; adj lists, per row, the incident corners `triangle << 2 | corner` in ascending
+    order (flat shapes get rows but no entries)."""
+    tris, tri_shape = np.asarray(tris, np.int64), np.asarray(tri_shape, np.int64)
+    flags = np.asarray([1 if f else 0 for f in smooth], np.int32)
+    if flags.shape[0] != n_shapes:
+        raise ValueError("one smooth flag per shape")
+    if tris.shape[0] >= 1 << 29:
+        raise ValueError("too many triangles for the corner keys")
+    n_local = np.zeros(n_shapes, np.int64)
+    np.maximum.at(n_local, tri_shape, tris.max(axis=1) + 1)
+    vbase = np.concatenate([[0], np.cumsum(n_local)[:-1]]).astype(np.int64)
+    n_vn = int(n_local.sum())
+    sel = np.nonzero(flags[tri_shape] != 0)[0]
+    rows = (vbase[tri_shape[sel]][:, None] + tris[sel]).reshape(-1)
+    keys = ((sel[:, None] << 2) | np.arange(3)[None, :]).reshape(-1)
+    order = np.lexsort((keys, rows))
+    adj = keys[order].astype(np.int32)
+    adj_start = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_vn))]).astype(np.int32)
+    return flags, vbase.astype(np.int32), adj_start, adj, n_vn

@@ -269,7 +269,31 @@ typedef struct ffx_bvh_info {
   uint64_t off_plan;
   int32_t n_treelets; /* workgroups of the update launch; the header at index n_treelets describes the top */
   int32_t plan_ints;  /* int32 words of the plan area (the arrival counter is the last one) */
+  uint64_t off_nrec;  /* (n_tris + 4) x 48 B: per leaf slot the three vertex normals {n0, n1, n2} as float4, written by
+                         ffx_scene_update for the shapes of ffx_smooth (below), read by the render kernels at the hit */
 } ffx_bvh_info;
+
+/* Interpolated shading normals (optional; ffx_scene_update's `smooth`).  Mitsuba shades a mesh that carries vertex normals
+ * (an OBJ with `vn`, a PLY with nx/ny/nz) in the frame of the normal interpolated at the hit, and re-derives
+ * angle-weighted vertex normals from the new positions after every `<mesh>.vertex_positions` update — which is what
+ * Scene.update_meshes does per randomisation (fireflies/scene.py:243-251 -> params.update(), :384; OBJ frames:
+ * fireflies/entity/mesh.py:167-181) [EXT mesh.cpp recompute_vertex_normals: for every face and corner
+ * n_face * unit_angle(edge, edge) is added to the corner's vertex, then normalised].  Here: the update computes the
+ * vertex normals of the CURRENT pose in world space (one launch, a lane per vertex over its incident corners in
+ * ascending triangle order — deterministic), stores them per leaf slot in the blob (off_nrec) and flags the shape's
+ * records; a render kernel that hits a flagged record interpolates  ns = normalize((1-u-v) n0 + u n1 + v n2),  faces ns
+ * to the viewer (the exporter's `twosided` wrapper flips by the sign of cos(theta_i) in the SHADING frame), evaluates
+ * the BSDF and the emitters' cosines with ns, and keeps the geometric normal for what is geometry: the side the shadow
+ * ray's origin is lifted to and the requirement that an emitter lies on the viewer's geometric side.  A zero-length
+ * interpolated normal falls back to the geometric one.  Shapes not flagged render exactly as before. */
+typedef struct ffx_smooth {
+  const int32_t *shape_smooth; /* [host][n_shapes] 1: interpolated normals, 0: flat */
+  const int32_t *shape_vbase;  /* [host][n_shapes] row of the shape's vertex 0 in the tables below (local vertex i -> row vbase + i) */
+  const int32_t *adj_start;    /* [dev][n_vn + 1] CSR: the corners incident to each vertex row (empty for flat shapes) */
+  const int32_t *adj;          /* [dev][adj_start[n_vn]] triangle << 2 | corner, ascending per vertex */
+  int32_t n_vn;                /* vertex rows (all shapes, one frame each) */
+  float *vnormals;             /* [dev][n_vn, 3] scratch: written, then read, by the update on its stream */
+} ffx_smooth;
 
 /* upper bound of the blob size for n_tris triangles.  The blob ends with scratch areas ("apex records",
  * DESIGN.md 4.1) that ffx_trace_primary / ffx_render_* rewrite on every call on their stream: calls that
@@ -283,7 +307,8 @@ int ffx_bvh_build_host(const float *verts /*[host][n_verts,3]*/, int n_verts,
 int ffx_scene_update(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]*/,
                      const float *src_verts /*[dev][*,3]*/, const int32_t *tris /*[dev][n_tris,3] shape-local*/,
                      const int32_t *tri_shape /*[dev][n_tris]*/, const int32_t *vert_off /*[dev][n_shapes]*/,
-                     const float *xform /*[dev][n_shapes,16]*/, int n_shapes, ffx_stream stream);
+                     const float *xform /*[dev][n_shapes,16]*/, int n_shapes, const ffx_smooth *smooth /*[host] or NULL*/,
+                     ffx_stream stream);
 
 /* Same pass with the per-shape tables given as HOST arrays (n_shapes <= FFX_MAX_SHAPES_H): they
  * travel as kernel arguments, so a randomisation enqueues no host-to-device copy and never blocks
@@ -293,7 +318,8 @@ int ffx_scene_update(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]
 int ffx_scene_update_h(void *bvh /*[dev] blob*/, const ffx_bvh_info *info /*[host]*/,
                        const float *src_verts /*[dev][*,3]*/, const int32_t *tris /*[dev][n_tris,3] shape-local*/,
                        const int32_t *tri_shape /*[dev][n_tris]*/, const int32_t *vert_off /*[host][n_shapes]*/,
-                       const float *xform /*[host][n_shapes,16]*/, int n_shapes, ffx_stream stream);
+                       const float *xform /*[host][n_shapes,16]*/, int n_shapes, const ffx_smooth *smooth /*[host] or NULL*/,
+                       ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7  primary visibility.

@@ -603,14 +603,14 @@ int ffx_blur_bwd(const float *gout, int h, int w, int ksize, float sg, float *gi
  * K5/K6  geometry update + BVH.  The oracle's tree is its own (median split over centroids,
  * <= 4 triangles per leaf); closest-hit results do not depend on the tree because ties are
  * broken by primitive id.  PARITY UNPINNED against Mitsuba (scene.py:384 -> Embree/OptiX).
- * Blob layout: [onode nodes[n_nodes]] [int order[n_tris]] [orec recs[n_tris]]
+ * Blob layout: [onode nodes[n_nodes]] [int order[n_tris]] [orec recs[n_tris]] [float nrec[n_tris + 4][12]: vertex normals per slot]
  * ========================================================================================= */
 typedef struct { float lo[3], hi[3]; int32_t left, right, first, count; } onode; /* 40 B */
 typedef struct { float v0[3], e1[3], e2[3]; int32_t prim, shape; float pad; } orec; /* 48 B */
 
 size_t ffx_bvh_blob_bytes(int n_tris) {
   if (n_tris < 1) n_tris = 1;
-  return 64 + (size_t)(2 * (size_t)n_tris) * sizeof(onode) + (size_t)n_tris * 4 + (size_t)n_tris * sizeof(orec) + 64;
+  return 64 + (size_t)(2 * (size_t)n_tris) * sizeof(onode) + (size_t)n_tris * 4 + (size_t)n_tris * sizeof(orec) + 64 + ((size_t)n_tris + 4) * 48 + 64;
 }
 
 static const float *g_cent;
@@ -664,7 +664,8 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   info->off_recs = info->off_order + (uint64_t)n_tris * 4;
   info->off_recs = (info->off_recs + 15) & ~(uint64_t)15;
   info->off_refit = 0;
-  info->total_bytes = info->off_recs + (uint64_t)n_tris * sizeof(orec);
+  info->off_nrec = (info->off_recs + (uint64_t)n_tris * sizeof(orec) + 63) & ~(uint64_t)63;
+  info->total_bytes = info->off_nrec + ((uint64_t)n_tris + 4) * 48;
   onode *nodes = (onode *)((char *)blob + info->off_nodes);
   int *order = (int *)((char *)blob + info->off_order);
   float *cent = (float *)malloc(sizeof(float) * 3 * (size_t)n_tris);
@@ -712,13 +713,73 @@ static void refit_rec(onode *nodes, const orec *recs, int id) {
  * with the affine rows of the 4x4 (w = 1 for rigid/scale transforms; the divide by w of
  * utils/math.py:216 is then the identity and is skipped).  Operation order per component:
  * fma(m0,x, fma(m1,y, fma(m2,z, m3))).  Triangle record: v0, e1 = v1 - v0, e2 = v2 - v0. */
+/* angle between two unit vectors, the way Mitsuba's unit_angle avoids acos near 0 and pi [EXT math.h] */
+static inline float unit_angle(v3 a, v3 b) {
+  const float dt = vdot(a, b);
+  if (dt >= 0.f) {
+    const v3 df = vsub(b, a);
+    const float h = 0.5f * sqrtf(vdot(df, df));
+    return 2.0f * asinf(h > 1.f ? 1.f : h);
+  }
+  const v3 sm = V3(a.x + b.x, a.y + b.y, a.z + b.z);
+  const float h = 0.5f * sqrtf(vdot(sm, sm));
+  return 3.14159265358979323846f - 2.0f * asinf(h > 1.f ? 1.f : h);
+}
+
+/* Vertex normals of the current pose [EXT Mitsuba mesh.cpp recompute_vertex_normals]: every non-degenerate face adds
+ * n_face * (angle at the corner) to each of its three vertices; faces in ascending order (so does libffx_hip: a lane
+ * per vertex walks its incident corners in ascending triangle order); normalised, zero where nothing was added. */
+static int vertex_normals(const float *src_verts, const int32_t *tris, const int32_t *tri_shape, const int32_t *vert_off, const float *xform, int n_shapes,
+                          int n_tris, const ffx_smooth *sm) {
+  if (!sm->shape_smooth || !sm->shape_vbase || !sm->vnormals || sm->n_vn < 1) FAIL(FFX_ERR_ARG, "scene_update: bad ffx_smooth");
+  memset(sm->vnormals, 0, sizeof(float) * 3 * (size_t)sm->n_vn);
+  for (int t = 0; t < n_tris; ++t) {
+    const int sh = tri_shape[t];
+    if (sh < 0 || sh >= n_shapes || !sm->shape_smooth[sh]) continue;
+    const float *m = xform + 16 * sh;
+    v3 p[3];
+    for (int c = 0; c < 3; ++c) {
+      const float *sv = src_verts + 3 * ((size_t)vert_off[sh] + tris[3 * t + c]);
+      p[c] = xf_point(m, V3(sv[0], sv[1], sv[2]));
+    }
+    v3 n = vcross(vsub(p[1], p[0]), vsub(p[2], p[0]));
+    const float nl = sqrtf(vdot(n, n));
+    if (!(nl > 0.f)) continue;
+    n = V3(n.x / nl, n.y / nl, n.z / nl);
+    for (int c = 0; c < 3; ++c) {
+      v3 d0 = vsub(p[(c + 1) % 3], p[c]), d1 = vsub(p[(c + 2) % 3], p[c]);
+      const float l0 = sqrtf(vdot(d0, d0)), l1 = sqrtf(vdot(d1, d1));
+      if (!(l0 > 0.f) || !(l1 > 0.f)) continue;
+      d0 = V3(d0.x / l0, d0.y / l0, d0.z / l0);
+      d1 = V3(d1.x / l1, d1.y / l1, d1.z / l1);
+      const float w = unit_angle(d0, d1);
+      const long row = (long)sm->shape_vbase[sh] + tris[3 * t + c];
+      if (row < 0 || row >= sm->n_vn) FAIL(FFX_ERR_ARG, "scene_update: ffx_smooth vertex row out of range");
+      float *acc = sm->vnormals + 3 * row;
+      acc[0] = fmaf(n.x, w, acc[0]); acc[1] = fmaf(n.y, w, acc[1]); acc[2] = fmaf(n.z, w, acc[2]);
+    }
+  }
+  for (long v = 0; v < sm->n_vn; ++v) {
+    float *a = sm->vnormals + 3 * v;
+    const float l = sqrtf(fmaf(a[0], a[0], fmaf(a[1], a[1], a[2] * a[2])));
+    if (l > 0.f) { a[0] /= l; a[1] /= l; a[2] /= l; }
+  }
+  return FFX_OK;
+}
+
 int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                     const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+                     const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s) {
   (void)s;
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FAIL(FFX_ERR_ARG, "scene_update: bad argument");
   onode *nodes = (onode *)((char *)bvh + info->off_nodes);
   const int *order = (const int *)((char *)bvh + info->off_order);
   orec *recs = (orec *)((char *)bvh + info->off_recs);
+  float *nrec = info->off_nrec ? (float *)((char *)bvh + info->off_nrec) : NULL;
+  if (smooth) {
+    if (!nrec) FAIL(FFX_ERR_ARG, "scene_update: blob without a normal area");
+    int rc = vertex_normals(src_verts, tris, tri_shape, vert_off, xform, n_shapes, info->n_tris, smooth);
+    if (rc) return rc;
+  }
   for (int k = 0; k < info->n_tris; ++k) {
     int prim = order[k];
     int sh = tri_shape[prim];
@@ -736,15 +797,24 @@ int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float *src_verts
     r->e2[0] = e2.x; r->e2[1] = e2.y; r->e2[2] = e2.z;
     r->prim = prim;
     r->shape = sh;
+    r->pad = 0.f;
+    if (smooth && smooth->shape_smooth[sh]) { /* flag the record, copy its three vertex normals next to it */
+      r->pad = 1.0f;
+      for (int c = 0; c < 3; ++c) {
+        const float *vn = smooth->vnormals + 3 * ((long)smooth->shape_vbase[sh] + tris[3 * prim + c]);
+        float *o = nrec + 12 * (size_t)k + 4 * c;
+        o[0] = vn[0]; o[1] = vn[1]; o[2] = vn[2]; o[3] = 0.f;
+      }
+    }
   }
   refit_rec(nodes, recs, 0);
   return FFX_OK;
 }
 
 int ffx_scene_update_h(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                       const int32_t *vert_off, const float *xform, int n_shapes, ffx_stream s) {
+                       const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s) {
   if (n_shapes > FFX_MAX_SHAPES_H) FAIL(FFX_ERR_UNSUPPORTED, "scene_update_h: more than %d shapes", FFX_MAX_SHAPES_H);
-  return ffx_scene_update(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, s); /* host == device here */
+  return ffx_scene_update(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s); /* host == device here */
 }
 
 /* =========================================================================================
@@ -970,6 +1040,7 @@ typedef struct {
   int spot_on; float s_w2l[16]; v3 s_pos; float s_int[3]; float cos_cut, cos_beam, cutoff, inv_trans;
   int shadows;
   const float *mats; int mat_stride; /* material rows (include/ffx.h) */
+  const float *nrec;                 /* per-slot vertex normals of the blob (ffx_smooth), or NULL */
 } shade_ctx;
 
 static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
@@ -1187,6 +1258,27 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
   float pmax = fmaxf(fabsf(P.x), fmaxf(fabsf(P.y), fabsf(P.z)));
   float off = (1.0f + pmax) * RAY_EPS;
   v3 Po = V3(fmaf(off, ng.x, P.x), fmaf(off, ng.y, P.y), fmaf(off, ng.z, P.z));
+  /* shading normal: the geometric one, or — for a record flagged by ffx_smooth — the vertex normals interpolated with the
+   * hit's barycentrics (Moller-Trumbore's u, v: P = v0 + u e1 + v e2), faced to the viewer by the sign of cos(theta_i) in
+   * the SHADING frame (the `twosided` wrapper); the geometric normal keeps the side tests (include/ffx.h ffx_smooth) */
+  v3 ns = ng;
+  if (r->pad != 0.f && c->nrec) {
+    const v3 e1 = V3(r->e1[0], r->e1[1], r->e1[2]), e2 = V3(r->e2[0], r->e2[1], r->e2[2]);
+    const v3 pv = vcross(d, e2);
+    const float det = vdot(e1, pv);
+    const v3 tv = vsub(o, V3(r->v0[0], r->v0[1], r->v0[2]));
+    const v3 qv = vcross(tv, e1);
+    const float idet = 1.0f / det;
+    const float bu = vdot(tv, pv) * idet, bv = vdot(d, qv) * idet, bw = (1.0f - bu) - bv;
+    const float *q = c->nrec + 12 * (size_t)h.slot;
+    v3 ni = V3(fmaf(bw, q[0], fmaf(bu, q[4], bv * q[8])), fmaf(bw, q[1], fmaf(bu, q[5], bv * q[9])), fmaf(bw, q[2], fmaf(bu, q[6], bv * q[10])));
+    const float l2 = vdot(ni, ni);
+    if (l2 > 0.f) {
+      const float il = 1.0f / sqrtf(l2);
+      ns = V3(ni.x * il, ni.y * il, ni.z * il);
+      if (vdot(ns, d) > 0.f) ns = V3(-ns.x, -ns.y, -ns.z);
+    }
+  }
 
   if (c->proj_on) {
     v3 pl = xf_point(c->p_w2l, P);
@@ -1202,9 +1294,9 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         float d2 = vdot(wi, wi);
         const float idist = 1.0f / sqrtf(d2);
         wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-        float cos_s = vdot(ng, wi);
+        float cos_s = vdot(ns, wi);
         float cos_p = -vdot(c->p_axis, wi);
-        if (cos_s > 0.f && cos_p > 0.f) {
+        if (cos_s > 0.f && cos_p > 0.f && vdot(ng, wi) > 0.f) { /* (ns == ng for flat shapes: the third test repeats the first) */
           int vis = 1;
           if (c->shadows) /* traced FROM the emitter to the lifted surface point: 0 < t < 1 - eps */
             vis = !occluded(nodes, recs, c->p_pos, vsub(Po, c->p_pos), 0.f, 1.0f - SHADOW_EPS);
@@ -1212,7 +1304,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
             /* irradiance texture * pi*scale / (z_l^2 * cos_p) [EXT Mitsuba projector], Lambert
                albedo/pi * cos_s: pi cancels */
             float bA, bB;
-            material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ng, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+            material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
             st->proj_fac = (c->p_scale / (pl.z * pl.z * cos_p)) * bA; /* Lambert: bA = cos_s */
             st->proj_fac_b = (c->p_scale / (pl.z * pl.z * cos_p)) * bB;
             float fx = fmaf(u, (float)c->tw, -0.5f), fy = fmaf(v, (float)c->th, -0.5f);
@@ -1238,8 +1330,8 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
     float d2 = vdot(wi, wi);
     const float idist = 1.0f / sqrtf(d2);
     wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
-    float cos_s = vdot(ng, wi);
-    if (cos_s > 0.f) {
+    float cos_s = vdot(ns, wi);
+    if (cos_s > 0.f && vdot(ng, wi) > 0.f) {
       v3 ll = xf_dir(c->s_w2l, V3(-wi.x, -wi.y, -wi.z));
       float ln = sqrtf(vdot(ll, ll));
       float cos_t = ll.z / ln;
@@ -1251,7 +1343,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         if (c->shadows) vis = !occluded(nodes, recs, c->s_pos, vsub(Po, c->s_pos), 0.f, 1.0f - SHADOW_EPS);
         if (vis) {
           float bA, bB;
-          material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ng, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+          material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
           float f = fall * bA / d2 * 0.3183098861837907f; /* Lambert: bA = cos_s, 1/pi */
           float fb = fall * bB / d2 * 0.3183098861837907f;
           for (int ch = 0; ch < 3; ++ch) { st->spot_rgb[ch] = c->s_int[ch] * f; st->spot_rgb_b[ch] = c->s_int[ch] * fb; }
@@ -1294,6 +1386,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
   c.mats = shape_albedo;
+  c.nrec = info->off_nrec ? (const float *)((const char *)bvh + info->off_nrec) : NULL;
   const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
   const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
   int W = c.cam.W, H = c.cam.H;
@@ -1438,6 +1531,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
   c.mats = shape_albedo;
+  c.nrec = info->off_nrec ? (const float *)((const char *)bvh + info->off_nrec) : NULL;
   const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
   const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
   int W = c.cam.W, H = c.cam.H;

@@ -201,8 +201,21 @@ def camera_struct(to_world, camera_to_sample, near, far, width, height):
 class Geometry:
     """Triangle scene + the oracle's BVH blob (host memory)."""
 
-    def __init__(self, src_verts, tris, tri_shape, vert_off, build_verts=None):
-        """src_verts [*,3] pool, tris [F,3] shape-local indices, tri_shape [F], vert_off [S]."""
+    def __init__(self, src_verts, tris, tri_shape, vert_off, build_verts=None, smooth=None):
+        """src_verts [*,3] pool, tris [F,3] shape-local indices, tri_shape [F], vert_off [S]; smooth: one flag per shape
+        (interpolated shading normals, include/ffx.h ffx_smooth)."""
+        self._smooth = None
+        if smooth is not None and any(smooth):
+            from fireflies_amd import scenes as _sc  # (pure numpy table builder shared with the product's host side)
+
+            S = _i32(vert_off).shape[0]
+            flags, vbase, a0, adj, n_vn = _sc.smooth_tables(tris, tri_shape, smooth, S)
+            keep = (np.ascontiguousarray(flags), np.ascontiguousarray(vbase), np.ascontiguousarray(a0), np.ascontiguousarray(adj), np.zeros((n_vn, 3), np.float32))
+            sm = _abi.Smooth()
+            sm.shape_smooth = keep[0].ctypes.data_as(C.POINTER(C.c_int32))
+            sm.shape_vbase = keep[1].ctypes.data_as(C.POINTER(C.c_int32))
+            sm.adj_start, sm.adj, sm.n_vn, sm.vnormals = keep[2].ctypes.data, keep[3].ctypes.data, n_vn, keep[4].ctypes.data
+            self._smooth = (sm, keep)
         self.src_verts = _f32(src_verts)
         self.tris = _i32(tris)
         self.tri_shape = _i32(tri_shape)
@@ -224,8 +237,13 @@ class Geometry:
         xf = _f32(xforms).reshape(self.n_shapes, 16)
         api().call(
             "ffx_scene_update", _p(self.blob), C.byref(self.info), _p(self.src_verts), _p(self.tris), _p(self.tri_shape),
-            _p(self.vert_off), _p(xf), self.n_shapes, None,
+            _p(self.vert_off), _p(xf), self.n_shapes, C.byref(self._smooth[0]) if self._smooth is not None else None, None,
         )
+
+    @property
+    def vertex_normals(self):
+        """[n_vn, 3] world-space vertex normals of the last update (smooth shapes; zero rows elsewhere)"""
+        return None if self._smooth is None else self._smooth[1][4]
 
     def trace_primary(self, cam, spp=1, jitter=0, seed=0):
         n = cam.width * cam.height * spp

@@ -232,8 +232,36 @@ def bsdf_cos(rows, n, wv, wl):
     return np.where((model != 0)[:, None], value, lambert)
 
 
-def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
-    """per sample: hit mask, shape id, projector taps / weights / rgb factor (irradiance scale x BSDF x cos), spot radiance"""
+def vertex_normals(verts, tri_idx, use=None):
+    """Angle-weighted vertex normals, the way Mitsuba re-derives them after a vertex_positions update [EXT mesh.cpp
+    recompute_vertex_normals; "Computing Vertex Normals from Polygonal Facets", Thuermer & Wuethrich 1998]: every face adds
+    its unit normal, weighted by the interior angle at the corner, to each of its three vertices.  float64; the angle is
+    arccos of the clipped cosine (the oracle uses Mitsuba's asin-based unit_angle).  `use` masks the faces that take part.
+    -> [n_verts, 3] (zero rows for vertices no face touches)"""
+    verts, tri_idx = np.asarray(verts, np.float64), np.asarray(tri_idx)
+    p = verts[tri_idx]  # [F,3,3]
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    fl = np.linalg.norm(fn, axis=1)
+    good = fl > 0 if use is None else (fl > 0) & np.asarray(use, bool)
+    fn = fn / np.where(fl > 0, fl, 1.0)[:, None]
+    out = np.zeros_like(verts)
+    for c in range(3):
+        a, b = p[:, (c + 1) % 3] - p[:, c], p[:, (c + 2) % 3] - p[:, c]
+        la, lb = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
+        ok = good & (la > 0) & (lb > 0)
+        cosang = (a * b).sum(1) / np.where(ok, la * lb, 1.0)
+        ang = np.arccos(np.clip(cosang, -1.0, 1.0))
+        np.add.at(out, tri_idx[ok, c], fn[ok] * ang[ok, None])
+    l = np.linalg.norm(out, axis=1)
+    return out / np.where(l > 0, l, 1.0)[:, None]
+
+
+def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None):
+    """per sample: hit mask, shape id, projector taps / weights / rgb factor (irradiance scale x BSDF x cos), spot radiance.
+    `smooth`: one flag per shape — shade in the frame of the interpolated vertex normal (Mitsuba meshes with vertex normals):
+    BSDF and emitter cosines use the interpolated normal, faced to the viewer by its own cos(theta_i) (the `twosided`
+    wrapper flips in the shading frame); the geometric normal keeps the shadow-ray offset and the requirement that the
+    emitter lies on the viewer's geometric side."""
     mats = np.asarray(mats, np.float64)
     tris = world_triangles(verts, tri_idx)
     v0, e1, e2 = tris
@@ -249,6 +277,25 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
     n = np.where(((n * d).sum(1) > 0)[:, None], -n, n)
     Po = P + n * ((1.0 + np.abs(P).max(1)) * EPS)[:, None]
     shape = np.where(hit, np.asarray(tri_shape)[pr], -1)
+    n_geo = n
+    if smooth is not None and any(smooth):
+        fl = np.asarray([bool(f) for f in smooth])
+        vn = vertex_normals(verts, tri_idx, use=fl[np.asarray(tri_shape)])
+        idx = np.asarray(tri_idx)[pr]
+        # barycentric coordinates of P from sub-triangle areas (not from the intersection routine's u, v)
+        a, b, c = np.asarray(verts, np.float64)[idx[:, 0]], np.asarray(verts, np.float64)[idx[:, 1]], np.asarray(verts, np.float64)[idx[:, 2]]
+        nn = np.cross(b - a, c - a)
+        den = (nn * nn).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            wa = (np.cross(c - b, P - b) * nn).sum(1) / den
+            wb = (np.cross(a - c, P - c) * nn).sum(1) / den
+        wc = 1.0 - wa - wb
+        ni = wa[:, None] * vn[idx[:, 0]] + wb[:, None] * vn[idx[:, 1]] + wc[:, None] * vn[idx[:, 2]]
+        nil = np.linalg.norm(ni, axis=1)
+        use = ok & fl[np.maximum(shape, 0)] & (nil > 0)
+        ni = ni / np.where(nil > 0, nil, 1.0)[:, None]
+        ni = np.where(((ni * d).sum(1) > 0)[:, None], -ni, ni)
+        n = np.where(use[:, None], ni, n)
     out = {"hit": hit, "shape": shape, "pfac": np.zeros((len(P), 3)), "taps": None, "w": None, "spot": np.zeros((len(P), 3))}
     rows = mats[np.maximum(shape, 0)]
     if sd.proj.enabled:
@@ -264,7 +311,7 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
         dist = np.linalg.norm(wi, axis=1)
         wi = wi / np.where(dist > 0, dist, 1.0)[:, None]
         cos_s, cos_p = (n * wi).sum(1), -(wi @ axis)
-        lit = ok & (pl[:, 2] > 0) & (u >= 0) & (u <= 1) & (v >= 0) & (v <= 1) & (cos_s > 0) & (cos_p > 0)
+        lit = ok & (pl[:, 2] > 0) & (u >= 0) & (u <= 1) & (v >= 0) & (v <= 1) & (cos_s > 0) & (cos_p > 0) & ((n_geo * wi).sum(1) > 0)
         if sd.shadows and lit.any():
             sel = np.where(lit)[0]
             occ = any_hit(np.broadcast_to(ppos, (len(sel), 3)), Po[sel] - ppos, tris, 1.0 - 10.0 * EPS)
@@ -286,7 +333,7 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
         cutoff, beam = np.deg2rad(sd.spot.cutoff_deg), np.deg2rad(sd.spot.beam_width_deg)
         ang = np.arccos(np.clip(cos_t, -1, 1))
         fall = np.where(ang <= beam, 1.0, np.where(ang < cutoff, (cutoff - ang) / (cutoff - beam), 0.0))
-        lit = ok & (cos_s > 0) & (fall > 0)
+        lit = ok & (cos_s > 0) & (fall > 0) & ((n_geo * wi).sum(1) > 0)
         if sd.shadows and lit.any():
             sel = np.where(lit)[0]
             occ = any_hit(np.broadcast_to(spos, (len(sel), 3)), Po[sel] - spos, tris, 1.0 - 10.0 * EPS)
@@ -297,8 +344,8 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats):
     return out
 
 
-def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed):
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo)
+def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=None):
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth)
     W, H = sd.cam.width, sd.cam.height
     rad = s["spot"].copy()
     if sd.proj.enabled:
@@ -315,9 +362,9 @@ def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed):
     return rad.reshape(H, W, spp, 3).mean(2)
 
 
-def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg):
+def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg, smooth=None):
     """d <img, gimg> / d tex for a 1-channel texture"""
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo)
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth)
     g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
     ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) / spp
     ws = np.where(s["hit"], ws, 0.0)

@@ -628,6 +628,34 @@ def test_load_file_xml_obj_renders_like_the_oracle(oracle, tmp_path):
     # the sphere (shape 1) casts a shadow on / occludes the wall: both shapes are visible
     seg = ff.graphics.depth.get_segmentation_from_camera(mi_scene)
     assert len(torch.unique(seg)) >= 2
+    # ---- the same file with vertex normals on the sphere (an OBJ exported with `vn`): Mitsuba shades it with interpolated
+    # normals and re-derives them after every vertex update — through Scene.randomize() (a scaled, rotated sphere) against the oracle
+    with open(tmp_path / "quad.obj", "a") as f:
+        f.write("vn 0 0 1\n")  # (the VALUES in the file are not used: normals are re-derived from the positions)
+    smooth_scene = mi.load_file(str(tmp_path / "scene.xml"))
+    assert [m.smooth for m in smooth_scene.data.meshes] == [False, True] and smooth_scene.geom.smooth == [False, True]
+    p2 = mi.traverse(smooth_scene)
+    ff2 = ff.Scene(p2, device="cpu")
+    ball = ff2.mesh("mesh-Quad")
+    ball.scale_x(0.7, 1.4)
+    ball.rotate_y(-0.3, 0.3)
+    ff2.train()
+    p2["tex.data"] = tex
+    torch.manual_seed(3)
+    random.seed(3)
+    ff2.randomize()
+    img_s = mi.render(smooth_scene, spp=8, seed=2).torch().cpu().numpy()
+    go_s = oracle.Geometry(pool, tris, shape, off, smooth=[False, True])
+    go_s.update(smooth_scene._xforms.numpy(), smooth_scene._offs)
+    ref_s = go_s.render_fwd(smooth_scene.scene_desc(tex_channels=1), smooth_scene._albedo_host, tex.cpu().numpy(), 8, seed=2)
+    assert_image_close(img_s, ref_s, 8, frac=1e-3, rel=2e-4, what="scene file, interpolated normals")
+    go_f = oracle.Geometry(pool, tris, shape, off)
+    go_f.update(smooth_scene._xforms.numpy(), smooth_scene._offs)
+    ref_f = go_f.render_fwd(smooth_scene.scene_desc(tex_channels=1), smooth_scene._albedo_host, tex.cpu().numpy(), 8, seed=2)
+    assert np.abs(ref_s - ref_f).max() > 0.01 * float(ref_f.max())  # the facets of the 24 x 12 sphere are gone
+    # face_normals = true in the file switches the interpolation off again (Mitsuba's shape property)
+    (tmp_path / "scene_fn.xml").write_text(XML.replace('<string name="filename" value="quad.obj"/>', '<string name="filename" value="quad.obj"/><boolean name="face_normals" value="true"/>'))
+    assert [m.smooth for m in mi.load_file(str(tmp_path / "scene_fn.xml")).data.meshes] == [False, False]
 
 
 def test_cfg5_colon_half_million_triangles_fp16(oracle):

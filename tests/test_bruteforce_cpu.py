@@ -224,3 +224,81 @@ def test_oracle_render_with_principled_materials_agrees_with_bruteforce(oracle):
     np.testing.assert_array_equal(img_c, go.render_fwd(sd, mats, tex, spp, seed=9))
     gt_c = go.render_bwd_cached(sd, mats, cache, spp, gimg)[..., 0]
     np.testing.assert_allclose(gt_c, gt_o, rtol=1e-5, atol=1e-6 * gs)
+
+
+def test_vertex_normals_of_a_sphere_are_radial_and_match_the_float64_restatement(oracle):
+    """ffx_smooth: the update re-derives angle-weighted vertex normals from the posed vertices [EXT Mitsuba
+    recompute_vertex_normals].  Closed form: on a tessellated sphere they point along the radius (to the tessellation's
+    accuracy), also after a rigid motion and a uniform scale; under a NON-uniform scale they follow the deformed surface
+    (normal ~ M^-T r), which is why they are recomputed from positions and not transformed.  And the oracle's float32 values
+    (asin-based unit_angle) equal the float64 restatement (arccos) of tests/ref_bruteforce.py."""
+    v, t = scenes.make_uv_sphere((0.0, 0.0, 0.0), 1.0, 24, 12)
+    pool, tris = v.astype(np.float32), t.astype(np.int32)
+    shape, off = np.zeros(len(tris), np.int32), np.zeros(1, np.int32)
+    go = oracle.Geometry(pool, tris, shape, off, smooth=[True])
+    a = 0.7
+    R = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]])
+    T = np.eye(4)
+    T[:3, 3] = (0.3, -0.2, 2.0)
+    for M in (np.eye(4), T @ R @ np.diag([1.7, 1.7, 1.7, 1.0]), T @ R @ np.diag([2.0, 1.0, 0.5, 1.0])):
+        go.update(M.astype(np.float32)[None])
+        body = np.abs(pool[:, 2]) < 0.99  # (the uv-sphere's pole rings are coincident vertices with zero-area faces: ill-defined)
+        vn = go.vertex_normals.astype(np.float64)[body]
+        world = pool.astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+        want = bf.vertex_normals(world, tris)[body]
+        np.testing.assert_allclose(vn, want, rtol=0, atol=3e-6)
+        expect = pool.astype(np.float64)[body] @ np.linalg.inv(M[:3, :3])  # rows: (M^-T r)^T
+        expect /= np.linalg.norm(expect, axis=1, keepdims=True)
+        ca = (vn * expect).sum(1)  # (the winding of make_uv_sphere decides inward or outward: one sign for the whole mesh)
+        assert np.abs(ca).min() > 0.985 and (np.sign(ca) == np.sign(ca[0])).all()  # within the tessellation's accuracy (24 x 12 facets)
+        np.testing.assert_allclose(np.linalg.norm(vn, axis=1), 1.0, atol=1e-6)
+    # a flat shape next to a smooth one: rows exist, nothing is accumulated
+    pool2 = np.concatenate([pool, pool + 3.0]).astype(np.float32)
+    tris2, shape2 = np.concatenate([tris, tris]), np.concatenate([shape, shape + 1])
+    g2 = oracle.Geometry(pool2, tris2, shape2, np.array([0, len(pool)], np.int32), smooth=[False, True])
+    assert np.all(g2.vertex_normals[: len(pool)] == 0) and np.allclose(np.linalg.norm(g2.vertex_normals[len(pool):], axis=1), 1.0, atol=1e-6)
+
+
+def test_oracle_render_with_interpolated_normals_agrees_with_bruteforce(oracle):
+    """shading normals (SURVEY 8a a14 / VERDICT r2 missing 2): oracle vs the float64 brute force with per-shape flags — a
+    smooth and a flat shape in one scene, Lambert and principled rows, shadows on and off, forward and adjoint; the image
+    differs from the flat-shaded one and is smoother across facet edges."""
+    sc, spp, frame = scenes.vocalfold(width=28, height=24, tex=32, frames=3, n_fold=12, tube=(12, 16)), 4, 1
+    xf = _xf(len(sc.meshes), 5)
+    pool, tris, shape, off, offs, xf, alb, verts, gidx = _world(sc, frame, xf)
+    rng = np.random.default_rng(2)
+    tex = rng.random((sc.projector.height, sc.projector.width)).astype(np.float32)
+    mats = material_rows(len(sc.meshes), 9, anisotropic=0.0)
+    for smooth in ([True, True], [False, True]):
+        go = oracle.Geometry(pool, tris, shape, off, smooth=smooth)
+        go.update(xf, offs)
+        for rows, stride in ((alb, 0), (mats, _abi.MAT_STRIDE)):
+            for shadows in (True, False):
+                sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=shadows)
+                sd.mat_stride = stride
+                img_o = go.render_fwd(sd, rows, tex, spp, seed=4)
+                img_b = bf.render_fwd(verts, gidx, shape, sd, rows, tex, spp, 4, smooth=smooth)
+                scale = float(img_b.max())
+                err = np.abs(img_o - img_b)
+                assert scale > 0.01
+                assert (err > 5e-4 * scale).mean() <= 1e-2 and err.max() <= 1.5 * scale / spp, (smooth, stride, shadows, err.max() / scale)
+                assert abs(float(img_o.mean()) - float(img_b.mean())) <= 2e-3 * float(img_b.mean())
+        sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+        gimg = rng.standard_normal((sc.camera.height, sc.camera.width, 3)).astype(np.float32)
+        gt_o = go.render_bwd(sd, alb, spp, 4, gimg)[..., 0]
+        gt_b = bf.render_bwd(verts, gidx, shape, sd, alb, spp, 4, gimg, smooth=smooth)
+        gs = float(np.abs(gt_b).max())
+        gerr = np.abs(gt_o - gt_b)
+        assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-2 and gerr.max() <= 0.5 * gs
+        img_c, cache = go.render_fwd_cache(sd, alb, tex, spp, seed=4)
+        gt_c = go.render_bwd_cached(sd, alb, cache, spp, gimg)[..., 0]
+        np.testing.assert_allclose(gt_c, gt_o, rtol=1e-5, atol=1e-6 * gs)
+    # flat shading is something else
+    gf = oracle.Geometry(pool, tris, shape, off)
+    gf.update(xf, offs)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    flat = gf.render_fwd(sd, alb, tex, spp, seed=4)
+    go = oracle.Geometry(pool, tris, shape, off, smooth=[True, True])
+    go.update(xf, offs)
+    smooth_img = go.render_fwd(sd, alb, tex, spp, seed=4)
+    assert np.abs(flat - smooth_img).max() > 0.02 * float(flat.max())

@@ -969,6 +969,75 @@ def test_principled_materials_match_the_oracle(oracle, env, ch, monkeypatch):
         gd.render_fwd(scene_desc.scene_desc(sc, tex_channels=ch, mat_stride=16), dev(alb), tex, 4)
 
 
+@pytest.mark.parametrize("env", [{}, {"FFX_WIDE": "0"}, {"FFX_TRAVERSAL": "lane"}, {"FFX_REFIT": "levels"}])
+def test_interpolated_shading_normals_match_the_oracle(oracle, env, monkeypatch):
+    """ffx_smooth (VERDICT r2 missing 2; fireflies/scene.py:243-251 -> Mitsuba re-derives vertex normals per update and
+    shades in the interpolated frame): the update's vertex normals, the per-slot copies, and the render / both adjoints with
+    a smooth and a flat shape in one scene, Lambert and principled rows, every walk and both refit paths, over several poses
+    and animation frames — against the oracle, whose float64 cross-check is tests/test_bruteforce_cpu.py."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    for k in ("FFX_TRAVERSAL", "FFX_WIDE", "FFX_REFIT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = scenes.vocalfold(width=56, height=48, tex=80, frames=4, n_fold=20, tube=(20, 24))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    rng = np.random.default_rng(3)
+    gimg = rng.standard_normal((48, 56, 3)).astype(np.float32)
+    tex = _tex(sc, 1)
+    mats = material_rows(2, 17, anisotropic=0.0)
+    for smooth in ([True, True], [False, True]):
+        gd = ops.DeviceGeometry(pool, tris, shape, off, smooth=smooth)
+        go = oracle.Geometry(pool, tris, shape, off, smooth=smooth)
+        for it in range(3):
+            xf = _rand_xforms(2, 60 + it)
+            xf[1] = xf[1] @ np.diag([1.0, 1.0 + 0.3 * it, 1.0, 1.0]).astype(np.float32)  # a non-uniform scale: normals follow the deformed surface
+            offs = (off + np.minimum(it, nfr - 1) * stride).astype(np.int32)
+            gd.update(xf, offs)
+            go.update(xf, offs)
+            _ = gd.blob  # (orders the current stream behind the refit on the side stream)
+            vn_d, vn_o = host(gd._smooth[1]["vn"]), go.vertex_normals
+            np.testing.assert_allclose(vn_d, vn_o, rtol=0, atol=2e-6)
+            # the per-slot copies next to the flagged records
+            info = gd.info
+            nrec = host(gd.blob[int(info.off_nrec): int(info.off_nrec) + 48 * int(info.n_tris)]).view(np.float32).reshape(-1, 3, 4)
+            recs = host(gd.blob[int(info.off_recs): int(info.off_recs) + 48 * int(info.n_tris)]).view(np.float32).reshape(-1, 12)
+            flagged = recs[:, 11] != 0
+            prim, shp = recs[:, 9].view(np.int32), recs[:, 10].view(np.int32)
+            assert (flagged == np.asarray(smooth)[shp]).all()
+            vbase = gd._smooth[1]["vbase"]
+            want = vn_d[(vbase[shp][:, None] + tris[prim])]
+            np.testing.assert_array_equal(nrec[flagged][:, :, :3], want[flagged])
+            for rows, stride_m in ((alb, 0), (mats, 16)):
+                sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=stride_m)
+                img_d = host(gd.render_fwd(sd, dev(rows), tex, 9, seed=5))
+                img_o = go.render_fwd(sd, rows, host(tex), 9, seed=5)
+                scale, _ = _assert_image_close(img_d, img_o, 9, frac=5e-4, rel=2e-4, what=f"{env} smooth={smooth} pose {it} stride {stride_m}")
+                assert scale > 0.02
+            g_o = go.render_bwd(sd, mats, 9, 5, gimg)
+            g_d = host(gd.render_bwd(sd, dev(mats), 9, 5, dev(gimg)))
+            gs = float(np.abs(g_o).max())
+            gerr = np.abs(g_d - g_o)
+            assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs
+            cache = torch.zeros(ops.render_cache_bytes_sd(sd, 9), dtype=torch.uint8, device="cuda")
+            gd.render_fwd(sd, dev(mats), tex, 9, seed=5, cache=cache)
+            g_c = host(gd.render_bwd_cached(sd, dev(mats), cache, 9, dev(gimg)))
+            cerr = np.abs(g_c - g_o)
+            assert (cerr > 1e-3 * gs).mean() <= 1e-3 and cerr.max() <= 0.1 * gs
+    # ... and it is not the flat-shaded image
+    gf = ops.DeviceGeometry(pool, tris, shape, off)
+    gf.update(xf, offs)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    flat = host(gf.render_fwd(sd, dev(alb), tex, 9, seed=5))
+    gs2 = ops.DeviceGeometry(pool, tris, shape, off, smooth=[True, True])
+    gs2.update(xf, offs)
+    assert np.abs(host(gs2.render_fwd(sd, dev(alb), tex, 9, seed=5)) - flat).max() > 0.02 * float(flat.max())
+    # a flat geometry writes no flags: bit-identical to what it rendered before the feature existed (same kernels, same records)
+    recs_f = host(gf.blob[int(gf.info.off_recs): int(gf.info.off_recs) + 48 * int(gf.info.n_tris)]).view(np.float32).reshape(-1, 12)
+    assert (recs_f[:, 11] == 0).all()
+
+
 def test_principled_materials_mid_size_and_abi_errors(oracle):
     """material rows at 256x256x64 spp on the full-detail vocal fold (one pixel per wave, the production launch shape) against
     the oracle, with the reference's vocal-fold randomisation (specular 0 .. 0.75, roughness 0.5); and the C ABI's refusals:
