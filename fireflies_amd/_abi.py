@@ -97,6 +97,11 @@ class SceneDesc(C.Structure):
         ("shadows", C.c_int32),
         ("n_shapes", C.c_int32),
         ("mat_stride", C.c_int32),
+        ("n_base_tex", C.c_int32),
+        ("base_tex_w", C.c_int32 * 4),
+        ("base_tex_h", C.c_int32 * 4),
+        ("base_tex", C.c_void_p * 4),
+        ("slot_uv", C.c_void_p),
     ]
 
 
@@ -104,6 +109,8 @@ class SceneDesc(C.Structure):
 MAT_STRIDE = 16
 MAT_MODEL, MAT_ROUGHNESS, MAT_ANISOTROPIC, MAT_METALLIC, MAT_SPEC_TRANS, MAT_ETA = 3, 4, 5, 6, 7, 8
 MAT_SPEC_TINT, MAT_SHEEN, MAT_SHEEN_TINT, MAT_FLATNESS, MAT_CLEARCOAT, MAT_CLEARCOAT_GLOSS = 9, 10, 11, 12, 13, 14
+MAT_BASE_TEX = 15
+MAX_BASE_TEX = 4
 
 
 PF = C.POINTER(c_f)

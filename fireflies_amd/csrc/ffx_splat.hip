@@ -810,39 +810,29 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restric
 __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restrict__ gout, int h, int w, BlurW bw, float *__restrict__ gin) {
   __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
   const int r = bw.ksize / 2;
-  {
-    // A tile none of whose pixels receives a reflected contribution (rows / columns 1..r and n-1-r..n-2 do) and whose halo
-    // stays inside the image is a plain correlation: staged through LDS like the forward blur (the same terms in the same
-    // order as the general loop below, so the bits do not change) — all but the border tiles of a 500x500 texture; reading
-    // 25 taps per pixel from global memory made this kernel 3x as slow as k_blur_fwd.
-    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
-    const bool interior = x0 - r >= r + 1 && y0 - r >= r + 1 && x0 + TILE_W + r <= w - 1 - r && y0 + TILE_H + r <= h - 1 - r; // (wave-uniform)
-    if (interior) {
-      const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
-      for (int t = threadIdx.x; t < tw * th; t += SPLAT_BLOCK) {
-        const int ly = t / tw, lx = t % tw;
-        tile[t] = gout[(size_t)(y0 + ly - r) * w + (x0 + lx - r)];
-      }
-      __syncthreads();
-      const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
-      float acc = 0.f;
-      for (int ky = 0; ky < bw.ksize; ++ky) { // py = y - ky + r: tile row ly + (2r - ky)
-        float row = 0.f;
-        for (int kx = 0; kx < bw.ksize; ++kx) row = fmaf(bw.w[kx], tile[(ly + 2 * r - ky) * tw + lx + 2 * r - kx], row);
-        acc = fmaf(bw.w[ky], row, acc);
-      }
-      gin[(size_t)(y0 + ly) * w + x0 + lx] = acc;
-      return;
+  const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+  const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
+  const int x = x0 + lx, y = y0 + ly;
+  // Padded rows -r..-1 reflect onto rows 1..r and rows h..h+r-1 onto h-1-r..h-2: only those rows (columns) have
+  // candidates besides themselves — every other pixel is a plain correlation.  Whatever a pixel of this tile reads lies
+  // in the tile's halo [y0 - r, y0 + TILE_H + r) x [x0 - r, x0 + TILE_W + r) clipped to the image (the reflected
+  // candidates of a border pixel read the first / last r rows, which are in the halo of the border tiles): staged through
+  // LDS like the forward blur, zero outside the image.  Reading the 25 taps per pixel from global memory — and the
+  // candidate search of the border tiles — had made this kernel 3x as slow as k_blur_fwd (15 us against 5).  Images
+  // smaller than 2r + 3 (reflections of reflections) keep the direct loop.  Same terms in the same order either way.
+  const bool small = h <= 2 * r + 2 || w <= 2 * r + 2; // (uniform)
+  const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
+  if (!small) {
+    for (int t = threadIdx.x; t < tw * th; t += SPLAT_BLOCK) {
+      const int gy = y0 + t / tw - r, gx = x0 + t % tw - r;
+      tile[t] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? gout[(size_t)gy * w + gx] : 0.f;
     }
+    __syncthreads();
   }
-  int x = blockIdx.x * TILE_W + threadIdx.x % TILE_W, y = blockIdx.y * TILE_H + threadIdx.x / TILE_W;
   if (x >= w || y >= h) return;
   float acc = 0.f;
-  // Padded rows -r..-1 reflect onto rows 1..r and rows h..h+r-1 onto h-1-r..h-2: only those rows (columns) have
-  // candidates besides themselves — every other pixel is a plain correlation (same terms in the same order, so the
-  // result does not change; the candidate search had made this kernel three times as slow as the forward blur).
-  const bool edge_y = h <= 2 * r + 2 || (y >= 1 && y <= r) || (y >= h - 1 - r && y <= h - 2);
-  const bool edge_x = w <= 2 * r + 2 || (x >= 1 && x <= r) || (x >= w - 1 - r && x <= w - 2);
+  const bool edge_y = small || (y >= 1 && y <= r) || (y >= h - 1 - r && y <= h - 2);
+  const bool edge_x = small || (x >= 1 && x <= r) || (x >= w - 1 - r && x <= w - 2);
   const int na = edge_y ? 2 * r : 0, nb = edge_x ? 2 * r : 0;
   // candidate padded rows: y itself, then the r rows above the image and the r rows below it
   for (int a = -1; a < na; ++a) {
@@ -858,7 +848,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
         for (int kx = 0; kx < bw.ksize; ++kx) {
           int px = tx - kx + r;
           if (px < 0 || px >= w) continue;
-          row = fmaf(bw.w[kx], gout[(size_t)py * w + px], row);
+          const float g = small ? gout[(size_t)py * w + px] : tile[(py - y0 + r) * tw + (px - x0 + r)];
+          row = fmaf(bw.w[kx], g, row);
         }
         acc = fmaf(bw.w[ky], row, acc);
       }

@@ -47,6 +47,11 @@ struct ShadeK {
   float cos_cut, cos_beam, cutoff, inv_trans;
   int mat_stride;    // floats per row of the material table: 3 (Lambert albedo) or FFX_MAT_STRIDE
   const float *mats; // the material table (the render calls' shape_albedo)
+  // texture-valued base colours (ffx_scene_desc.base_tex): rows select one with FFX_MAT_BASE_TEX
+  int n_base_tex;
+  int btw[FFX_MAX_BASE_TEX], bth[FFX_MAX_BASE_TEX];
+  const float *btex[FFX_MAX_BASE_TEX];
+  const float *slot_uv;
 };
 
 struct Hit { float t; int prim, shape, slot; };
@@ -287,14 +292,44 @@ __device__ __forceinline__ float sqrt_nr(float x) {
 // in the shading frame).  Same operation order as the oracle's shade_sample; FAST: the Newton-refined reciprocals of the packet
 // kernels instead of IEEE division (equal except for rare last bits).  A zero-length interpolated normal keeps the geometric one.
 template <bool FAST>
-__device__ __forceinline__ v3 interpolated_normal(const float4 *__restrict__ nrec, int slot, float4 ra, float4 rb, float4 rc, v3 o, v3 d, v3 ng) {
+__device__ __forceinline__ void hit_barycentrics(float4 ra, float4 rb, float4 rc, v3 o, v3 d, float &bu, float &bv) {
   const v3 e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);
   const v3 pv = vcross(d, e2);
   const float det = vdot(e1, pv);
   const v3 tv = vsub(o, V3(ra.x, ra.y, ra.z));
   const v3 qv = vcross(tv, e1);
   const float idet = FAST ? rcp_nr(det) : 1.0f / det;
-  const float bu = vdot(tv, pv) * idet, bv = vdot(d, qv) * idet, bw = (1.0f - bu) - bv;
+  bu = vdot(tv, pv) * idet;
+  bv = vdot(d, qv) * idet;
+}
+// base colour of a hit on a row with FFX_MAT_BASE_TEX = k + 1 (ffx.h ffx_scene_desc.base_tex): the slot's texture coordinates
+// interpolated with the hit's barycentrics, repeat wrap, bilinear between texel centres — the oracle's base_tex_lookup
+__device__ __forceinline__ void base_tex_sample(const ShadeK &c, int k, int slot, float bu, float bv, float (&rgb)[3]) {
+  const float *uv = c.slot_uv + 6 * (size_t)slot;
+  const float bw = (1.0f - bu) - bv;
+  float u = fmaf(bw, uv[0], fmaf(bu, uv[2], bv * uv[4])), v = fmaf(bw, uv[1], fmaf(bu, uv[3], bv * uv[5]));
+  u = u - floorf(u);
+  v = v - floorf(v);
+  const int w = c.btw[k], h = c.bth[k];
+  const float fx = fmaf(u, (float)w, -0.5f), fy = fmaf(v, (float)h, -0.5f);
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1; // in [-1, w]: one conditional step wraps them
+  x0 = x0 < 0 ? x0 + w : x0; x1 = x1 >= w ? x1 - w : x1; y0 = y0 < 0 ? y0 + h : y0; y1 = y1 >= h ? y1 - h : y1;
+  x0 = x0 >= w ? x0 - w : x0; y0 = y0 >= h ? y0 - h : y0; x1 = x1 < 0 ? x1 + w : x1; y1 = y1 < 0 ? y1 + h : y1;
+  const float *t = c.btex[k];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float t00 = t[((size_t)y0 * w + x0) * 3 + ch], t01 = t[((size_t)y0 * w + x1) * 3 + ch];
+    const float t10 = t[((size_t)y1 * w + x0) * 3 + ch], t11 = t[((size_t)y1 * w + x1) * 3 + ch];
+    rgb[ch] = (1.0f - ay) * ((1.0f - ax) * t00 + ax * t01) + ay * ((1.0f - ax) * t10 + ax * t11);
+  }
+}
+template <bool FAST>
+__device__ __forceinline__ v3 interpolated_normal(const float4 *__restrict__ nrec, int slot, float4 ra, float4 rb, float4 rc, v3 o, v3 d, v3 ng) {
+  float bu, bv;
+  hit_barycentrics<FAST>(ra, rb, rc, o, d, bu, bv);
+  const float bw = (1.0f - bu) - bv;
   const float4 n0 = nrec[3 * (size_t)slot], n1 = nrec[3 * (size_t)slot + 1], n2 = nrec[3 * (size_t)slot + 2];
   const v3 ni = V3(fmaf(bw, n0.x, fmaf(bu, n1.x, bv * n2.x)), fmaf(bw, n0.y, fmaf(bu, n1.y, bv * n2.y)), fmaf(bw, n0.z, fmaf(bu, n1.z, bv * n2.z)));
   const float l2 = vdot(ni, ni);
@@ -374,7 +409,9 @@ __device__ __forceinline__ float ggx1_cc(float c, float c_dot_h) { // smith_ggx1
 }
 // the lobes, one after the other, each reading the material values it needs from the row when it needs them (the row is
 // 64 bytes in the vector L1; holding all of it plus the directions in registers cost the kernel two waves of occupancy)
-__device__ __forceinline__ void material_terms(const float *__restrict__ m, const MatGeo &g, float &A, float &B) {
+// TEX: the base colour is (b0, b1, b2) — the row's texture sampled at the hit — instead of the row's own m[0..2]
+template <bool TEX = false>
+__device__ __forceinline__ void material_terms(const float *__restrict__ m, const MatGeo &g, float &A, float &B, float b0 = 0.f, float b1 = 0.f, float b2 = 0.f) {
   const float cos_i = g.cos_i, cos_o = g.cos_o, ch = g.ch, ci_h = g.ci_h, co_h = g.co_h;
   A = 0.f; B = 0.f;
   if (!(cos_i > 0.f && cos_o > 0.f)) return;
@@ -403,7 +440,7 @@ __device__ __forceinline__ void material_terms(const float *__restrict__ m, cons
     const float spec_tint = m[FFX_MAT_SPEC_TINT], m1 = 1.0f - metallic;
     float Fa = metallic * (1.0f - sw), Fb = metallic * sw + m1 * spec_tint * sw + m1 * (1.0f - spec_tint) * F_d;
     if (spec_tint != 0.f) {
-      const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
+      const float lum = TEX ? 0.212671f * b0 + 0.715160f * b1 + 0.072169f * b2 : 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
       const float t = m1 * spec_tint * sqrf((eta - 1.0f) * brcp(eta + 1.0f)) * (1.0f - sw);
       if (lum > 0.f) Fa += bdiv(t, lum);
       else Fb += t;
@@ -439,7 +476,7 @@ __device__ __forceinline__ void material_terms(const float *__restrict__ m, cons
   const float sheen = m[FFX_MAT_SHEEN];
   if (sheen > 0.f && 1.0f - metallic > 0.f) {
     const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
-    const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2], sheen_tint = m[FFX_MAT_SHEEN_TINT];
+    const float lum = TEX ? 0.212671f * b0 + 0.715160f * b1 + 0.072169f * b2 : 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2], sheen_tint = m[FFX_MAT_SHEEN_TINT];
     if (lum > 0.f) { a += bdiv(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
     else b += sv;
   }
@@ -455,6 +492,7 @@ struct SampleTerms {
   float proj_fac;
   float spot[3];
   float proj_fac_b, spot_b[3]; // material rows: the part of the BSDF that does not scale with base_color
+  float base[3];               // textured base colours only (MATM == 2 / the lane kernels): the sample's base colour
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -484,6 +522,19 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   // shading normal (ffx_smooth): BSDF and emitter cosines use it; the geometric normal keeps the side tests
   v3 ns = ng;
   if (rc.w != 0.f && nrec) ns = interpolated_normal<false>(nrec, h.slot, ra, rb, rc, o, d, ng);
+  // base colour: the shape's row, or (FFX_MAT_BASE_TEX) its texture at the hit
+  const float *row0 = c.mats + (size_t)c.mat_stride * h.shape;
+  st.base[0] = row0[0]; st.base[1] = row0[1]; st.base[2] = row0[2];
+  bool textured = false;
+  if (c.mat_stride == FFX_MAT_STRIDE && c.n_base_tex > 0) {
+    const int tix = (int)row0[FFX_MAT_BASE_TEX];
+    if (tix > 0 && tix <= c.n_base_tex) {
+      float bu, bv;
+      hit_barycentrics<false>(ra, rb, rc, o, d, bu, bv);
+      base_tex_sample(c, tix - 1, h.slot, bu, bv, st.base);
+      textured = true;
+    }
+  }
 
   if (c.proj_on) {
     v3 pl = xf_point(c.p_w2l, P);
@@ -514,7 +565,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
               const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
               MatGeo mg;
               material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
-              material_terms(mrow, mg, bA, bB);
+              if (textured) material_terms<true>(mrow, mg, bA, bB, st.base[0], st.base[1], st.base[2]);
+              else material_terms(mrow, mg, bA, bB);
             }
             st.proj_fac = (c.p_scale / (pl.z * pl.z * cos_p)) * bA;
             st.proj_fac_b = (c.p_scale / (pl.z * pl.z * cos_p)) * bB;
@@ -561,7 +613,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
             const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
             MatGeo mg;
             material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
-            material_terms(mrow, mg, bA, bB);
+            if (textured) material_terms<true>(mrow, mg, bA, bB, st.base[0], st.base[1], st.base[2]);
+            else material_terms(mrow, mg, bA, bB);
           }
           float f = fall * bA / d2 * 0.3183098861837907f, fb = fall * bB / d2 * 0.3183098861837907f;
           st.spot[0] = c.s_int[0] * f;
@@ -650,7 +703,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
           b2 += tv2 * 1.0f * st.proj_fac_b;
         }
       }
-      const float *alb = albedo + (size_t)c.mat_stride * st.shape;
+      const float *alb = st.base; // (the shape's row, or its base-colour texture at the hit)
       if (c.mat_stride == 3) {
         acc0 += alb[0] * r0;
         acc1 += alb[1] * r1;
@@ -716,7 +769,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
     SampleTerms st;
     shade_sample(c, nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
     if (!st.hit || !st.has_proj) continue;
-    const float *alb = albedo + (size_t)c.mat_stride * st.shape;
+    const float *alb = st.base;
     size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
     size_t o10 = ((size_t)st.iy1 * c.tw + st.ix0) * tc, o11 = ((size_t)st.iy1 * c.tw + st.ix1) * tc;
     if (tc == 1) {
@@ -1715,11 +1768,13 @@ __device__ __forceinline__ bool tex_footprint_lit(const float *__restrict__ tex,
   return m > 0.f; // (NaN texels: fmaxf drops them — as before, a NaN next to zeros reads as dark)
 }
 
-template <int R, bool WIDE, bool MAT = false>
+// MATM: 0 = [S,3] Lambert albedos, 1 = material rows, 2 = material rows some of which take their base colour from a texture
+template <int R, bool WIDE, int MATM = 0>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
                                                 const float4 *__restrict__ nrec, const float *__restrict__ tex_probe = nullptr) {
+  constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   Hit h[R];
   bool fnd[R];
   traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
@@ -1889,10 +1944,21 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     if constexpr (MAT) {
       // BSDF of the samples an emitter reaches: pi f cos = base_color * bA + bB (material_eval); Lambert rows: bA = cos_s
       const bool lit_p = q.need_p && !occ_p[r], lit_s = q.need_s && !occ_s[r];
+      if constexpr (TEX) { st[r].base[0] = st[r].base[1] = st[r].base[2] = 0.f; }
       if (lit_p || lit_s) {
         const float *mrow = c2.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
         const bool mat_on = mrow[FFX_MAT_MODEL] != 0.f;
         const v3 wv = V3(-d[r].x, -d[r].y, -d[r].z);
+        if constexpr (TEX) { // base colour of this sample: the row's, or its texture at the hit (only lit samples need one)
+          st[r].base[0] = mrow[0]; st[r].base[1] = mrow[1]; st[r].base[2] = mrow[2];
+          const int tix = (int)mrow[FFX_MAT_BASE_TEX];
+          if (tix > 0 && tix <= c2.n_base_tex) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
+            float bu, bv;
+            hit_barycentrics<true>(r4[0], r4[1], r4[2], o[r], d[r], bu, bv);
+            base_tex_sample(c2, tix - 1, h[r].slot, bu, bv, st[r].base);
+          }
+        }
         // one emitter after the other: directions -> cosines (MatGeo) -> lobes
         if (lit_p) {
           v3 wi = vsub(V3(c2.p_pos[0], c2.p_pos[1], c2.p_pos[2]), q.P);
@@ -1902,7 +1968,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           if (mat_on) {
             MatGeo g;
             material_geometry(mrow, q.ng, wv, wi, g);
-            material_terms(mrow, g, bA, bB);
+            material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]);
           }
           q.pfac_b = q.pfac * bB;
           q.pfac = q.pfac * bA;
@@ -1915,7 +1981,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           if (mat_on) {
             MatGeo g;
             material_geometry(mrow, q.ng, wv, wi, g);
-            material_terms(mrow, g, bA, bB);
+            material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]);
           }
           q.sfac_b = q.sfac * bB;
           q.sfac = q.sfac * bA;
@@ -2068,13 +2134,14 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 #ifndef FFX_PK_MAT_WAVES
 #define FFX_PK_MAT_WAVES 7 // material rows: 75 VGPRs (72 at this setting without spills; 8 waves spill 4)
 #endif
-template <int R, bool WIDE, bool MAT>
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
+template <int R, bool WIDE, int MATM>
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
                     uint32_t cache_foot_b_off, const float4 *__restrict__ nrec) {
   constexpr int NSUB = 4 / R;
+  constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
@@ -2137,7 +2204,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, (cache && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, (cache && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -2227,10 +2294,16 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             }
           }
         }
+        if constexpr (TEX) { // (a textured row: the sample's own base colour; zero where nothing lit it, and then r0..2 are zero too)
+          c0 = st[r].base[0] * r0;
+          c1 = st[r].base[1] * r1;
+          c2 = st[r].base[2] * r2;
+        } else {
         const float *alb = albedo + MS * st[r].shape;
         c0 = alb[0] * r0;
         c1 = alb[1] * r1;
         c2 = alb[2] * r2;
+        }
         if constexpr (MAT) { c0 += b0; c1 += b1; c2 += b2; }
         }
         // running sums of a pixel that needs several 64-sample passes are parked in LDS between the passes; the
@@ -2282,12 +2355,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   FFX_TFLUSH();
 }
 
-template <int R, bool WIDE, bool MAT>
-__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MAT ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
+template <int R, bool WIDE, int MATM>
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec) {
   constexpr int NSUB = 4 / R;
+  constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
   const int lane = threadIdx.x & 63;
@@ -2325,13 +2399,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE, MAT>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit || !st[r].has_proj) continue;
-        const float *alb = albedo + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
+        const float *alb = TEX ? st[r].base : albedo + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
         size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
         size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
         const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1;
@@ -2553,6 +2627,13 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   c.shadows = sd->shadows;
   c.mat_stride = sd->mat_stride ? sd->mat_stride : 3;
   if (c.mat_stride != 3 && c.mat_stride != FFX_MAT_STRIDE) return 0;
+  c.n_base_tex = sd->n_base_tex;
+  if (c.n_base_tex < 0 || c.n_base_tex > FFX_MAX_BASE_TEX || (c.n_base_tex > 0 && (c.mat_stride != FFX_MAT_STRIDE || !sd->slot_uv))) return 0;
+  c.slot_uv = sd->slot_uv;
+  for (int k = 0; k < c.n_base_tex; ++k) {
+    c.btex[k] = sd->base_tex[k]; c.btw[k] = sd->base_tex_w[k]; c.bth[k] = sd->base_tex_h[k];
+    if (!c.btex[k] || c.btw[k] < 1 || c.bth[k] < 1) return 0;
+  }
   float inv[16];
   if (c.proj_on) {
     if (!ffx_inv4(sd->proj.to_world, inv)) return 0;
@@ -2808,6 +2889,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   const float4 *nrec = info->off_nrec ? (const float4 *)((const char *)bvh + info->off_nrec) : nullptr; // vertex normals per slot (ffx_smooth)
+  if (cache && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
@@ -2830,8 +2912,9 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
                      arena_off, foot_b_off, nrec)
-    if (use_wide(info)) { if (mat) FFX_LAUNCH_FWD(true, true); else FFX_LAUNCH_FWD(true, false); }
-    else { if (mat) FFX_LAUNCH_FWD(false, true); else FFX_LAUNCH_FWD(false, false); }
+    const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
+    if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD(true, 2); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
+    else { if (matm == 2) FFX_LAUNCH_FWD(false, 2); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
 #undef FFX_LAUNCH_FWD
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
@@ -2878,7 +2961,13 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
   return FFX_OK;
 }
 
-size_t ffx_render_dot_slots(int width, int height) { return (width < 1 || height < 1) ? 0 : (size_t)ffx_cdiv(width, 8) * (size_t)ffx_cdiv(height, 8); }
+// at most 256 slots (one per 8x8-pixel block, folded modulo 256): enough to take the contention out of the atomics (a 512x512 film
+// adds 16 values to each) and few enough for ONE load per thread of the launch that sums them (ffx_pattern_bwd's block 0)
+size_t ffx_render_dot_slots(int width, int height) {
+  if (width < 1 || height < 1) return 0;
+  const size_t b = (size_t)ffx_cdiv(width, 8) * (size_t)ffx_cdiv(height, 8);
+  return b < 256 ? b : 256;
+}
 
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
@@ -2943,8 +3032,9 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
                      spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex, nrec)
-    if (use_wide(info)) { if (mat) FFX_LAUNCH_BWD(true, true); else FFX_LAUNCH_BWD(true, false); }
-    else { if (mat) FFX_LAUNCH_BWD(false, true); else FFX_LAUNCH_BWD(false, false); }
+    const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1);
+    if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BWD(true, 2); else if (matm == 1) FFX_LAUNCH_BWD(true, 1); else FFX_LAUNCH_BWD(true, 0); }
+    else { if (matm == 2) FFX_LAUNCH_BWD(false, 2); else if (matm == 1) FFX_LAUNCH_BWD(false, 1); else FFX_LAUNCH_BWD(false, 0); }
 #undef FFX_LAUNCH_BWD
     FFX_CHECK_LAUNCH("render_bwd");
     return FFX_OK;

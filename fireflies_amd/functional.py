@@ -145,7 +145,7 @@ def cache_supported(sd, spp):
     stay inside one 5x5-texel footprint"""
     if not sd.proj.enabled:
         return False
-    if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255:
+    if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255 or sd.n_base_tex > 0:  # (textured base colours: one colour per shape in the footprint)
         return False
     if texels_per_pixel(sd) > max_texels_per_pixel():
         return False

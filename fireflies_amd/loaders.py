@@ -34,10 +34,14 @@ from . import scenes
 def load_obj(path, with_info=False):
     """-> (vertices [V,3] float32, triangles [F,3] int32).  Faces with more than three corners are
     fan-triangulated; `v/vt/vn` corner syntax and negative (relative) indices are handled.
-    with_info: a third item {"has_normals": the file carries `vn` records} — Mitsuba shades such a mesh with interpolated
-    vertex normals (re-derived from the positions after every vertex update: include/ffx.h ffx_smooth; the file's own
-    normal VALUES are therefore not kept)."""
-    verts, tris = [], []
+    with_info: a third item {"has_normals": the file carries `vn` records, "uv": [V,2] texture coordinates or None} —
+    Mitsuba shades a mesh with `vn` with interpolated vertex normals (re-derived from the positions after every vertex
+    update: include/ffx.h ffx_smooth; the file's own normal VALUES are therefore not kept).  Texture coordinates are per
+    VERTEX here as in Mitsuba's mesh: a vertex that faces use with different `vt` (a seam) is duplicated once per extra
+    `vt` (appended after the file's vertices, so that vertex i < V keeps its index); v is flipped (v -> 1 - v: Mitsuba's
+    `flip_tex_coords` default for OBJ)."""
+    verts, tris, vts = [], [], []
+    corner_vt = []  # per triangle corner: vt index or -1
     has_vn = False
     with open(path, "r") as f:
         for line in f:
@@ -46,18 +50,57 @@ def load_obj(path, with_info=False):
                 verts.append((float(p[1]), float(p[2]), float(p[3])))
             elif line.startswith("vn "):
                 has_vn = True
+            elif line.startswith("vt "):
+                p = line.split()
+                vts.append((float(p[1]), float(p[2]) if len(p) > 2 else 0.0))
             elif line.startswith("f "):
-                idx = []
+                idx, tix = [], []
                 for tok in line.split()[1:]:
-                    i = int(tok.split("/")[0])
+                    parts = tok.split("/")
+                    i = int(parts[0])
                     idx.append(i - 1 if i > 0 else len(verts) + i)
+                    if len(parts) > 1 and parts[1] != "":
+                        k = int(parts[1])
+                        tix.append(k - 1 if k > 0 else len(vts) + k)
+                    else:
+                        tix.append(-1)
                 for k in range(1, len(idx) - 1):
                     tris.append((idx[0], idx[k], idx[k + 1]))
+                    corner_vt.append((tix[0], tix[k], tix[k + 1]))
     v = np.asarray(verts, np.float32).reshape(-1, 3)
     t = np.asarray(tris, np.int32).reshape(-1, 3)
     if t.size and (t.min() < 0 or t.max() >= v.shape[0]):
         raise ValueError(f"{path}: face index out of range")
-    return (v, t, {"has_normals": has_vn}) if with_info else (v, t)
+    if not with_info:
+        return v, t
+    uv = None
+    cv = np.asarray(corner_vt, np.int64).reshape(-1, 3)
+    if len(vts) and cv.size and (cv >= 0).all():
+        if cv.max() >= len(vts):
+            raise ValueError(f"{path}: texture-coordinate index out of range")
+        vt = np.asarray(vts, np.float32).reshape(-1, 2)
+        first = {}  # vertex -> its first vt; (vertex, other vt) -> duplicated vertex
+        extra_v, extra_uv = [], []
+        uv_of = np.full(v.shape[0], -1, np.int64)
+        t = t.copy()
+        for f_ in range(t.shape[0]):
+            for c in range(3):
+                vi, ti = int(t[f_, c]), int(cv[f_, c])
+                if uv_of[vi] < 0:
+                    uv_of[vi] = ti
+                elif uv_of[vi] != ti:  # a seam: this corner needs its own copy of the vertex
+                    key = (vi, ti)
+                    if key not in first:
+                        first[key] = v.shape[0] + len(extra_v)
+                        extra_v.append(v[vi])
+                        extra_uv.append(ti)
+                    t[f_, c] = first[key]
+        uv_idx = np.concatenate([np.where(uv_of >= 0, uv_of, 0), np.asarray(extra_uv, np.int64)]) if extra_uv else np.where(uv_of >= 0, uv_of, 0)
+        if extra_v:
+            v = np.concatenate([v, np.asarray(extra_v, np.float32)], 0)
+        uv = vt[uv_idx].copy()
+        uv[:, 1] = 1.0 - uv[:, 1]
+    return v, t, {"has_normals": has_vn, "uv": uv}
 
 
 # ----------------------------------------------------------------------------- PLY
@@ -148,7 +191,7 @@ def load_ply(path, with_info=False):
         raise ValueError(f"{path}: face index out of range")
     if with_info:  # (vertex normals nx/ny/nz: shaded with interpolated normals, like an OBJ with `vn`)
         has_vn = any(el["name"] == "vertex" and {"nx", "ny", "nz"} <= {p[-1] for p in el["props"]} for el in elements)
-        return verts, t, {"has_normals": has_vn}
+        return verts, t, {"has_normals": has_vn, "uv": None}
     return verts, t
 
 
@@ -265,6 +308,39 @@ def _child(node, tag, name=None):
     return None
 
 
+def _base_texture_of(bsdf, bsdfs, base_dir):
+    """the [h,w,3] float32 texture of a bsdf's texture-valued base colour (`<texture type="bitmap" name="base_color">`), or None.
+    The bitmap is read with PIL when it is there (sRGB -> linear like Mitsuba's default `raw` = false); a missing file or
+    decoder gives a mid-grey 1x1 texture with a warning — the parameter `<mat>.brdf_0.base_color.data` exists either way, which
+    is what the reference's loop assigns to (main.py:147-153)."""
+    if bsdf is None:
+        return None
+    if bsdf.tag == "ref":
+        return _base_texture_of(bsdfs.get(bsdf.get("id")), bsdfs, base_dir)
+    inner = bsdf
+    while inner.get("type") in ("twosided", "bumpmap", "normalmap", "mask") and _child(inner, "bsdf") is not None:
+        inner = _child(inner, "bsdf")
+    for c in inner:
+        if c.tag == "texture" and c.get("name") in ("base_color", "reflectance"):
+            if c.get("type") != "bitmap":
+                warnings.warn(f"texture type {c.get('type')!r} for the base colour: a mid-grey 1x1 texture stands in for it")
+                return np.full((1, 1, 3), 0.5, np.float32)
+            fn = _props(c).get("filename")
+            path = os.path.join(base_dir, fn) if fn else None
+            try:
+                from PIL import Image  # (not a dependency: used when present)
+
+                img = np.asarray(Image.open(path).convert("RGB"), np.float32) / 255.0
+                if not bool(_props(c).get("raw", False)):  # sRGB -> linear
+                    img = np.where(img <= 0.04045, img / 12.92, ((img + 0.055) / 1.055) ** 2.4)
+                return np.ascontiguousarray(img, np.float32)
+            except Exception as e:  # noqa: BLE001 — any reason the bitmap cannot be had
+                warnings.warn(f"base-colour bitmap {fn!r} could not be read ({type(e).__name__}): a mid-grey 1x1 texture stands in for it; "
+                              "assign params['<mat>.brdf_0.base_color.data']")
+                return np.full((1, 1, 3), 0.5, np.float32)
+    return None
+
+
 def _albedo_of(bsdf, bsdfs):
     """-> (base colour, material id, principled parameters or None for a diffuse material)"""
     if bsdf is None:
@@ -280,9 +356,9 @@ def _albedo_of(bsdf, bsdfs):
         inner = _child(inner, "bsdf")
     p = _props(inner)
     for c in inner:
-        if c.tag == "texture" and c.get("name"):
-            warnings.warn(f"bsdf {bsdf.get('id') or inner.get('type')!r}: texture-valued parameter {c.get('name')!r} is not read from the file (bitmap files are not "
-                          "loaded): its default is used — assign params['<mat>.brdf_0.base_color.data'] for a textured base colour")
+        if c.tag == "texture" and c.get("name") and c.get("name") not in ("base_color", "reflectance"):
+            warnings.warn(f"bsdf {bsdf.get('id') or inner.get('type')!r}: texture-valued parameter {c.get('name')!r} is not evaluated: its default is used "
+                          "(only the base colour can be a texture)")
     col = p.get("reflectance", p.get("base_color", p.get("diffuse_reflectance", (0.5, 0.5, 0.5))))
     if isinstance(col, float):
         col = (col,) * 3
@@ -439,7 +515,13 @@ def load_mitsuba_xml(path):
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
             alb, mat, bsdf = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
-            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat, bsdf, smooth=smooth))
+            bnode = _child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref")
+            btex = _base_texture_of(bnode, bsdfs, base)
+            uv = finfo.get("uv")
+            if btex is not None and uv is None:
+                dropped(("tex-without-uv", node.get("id")), f"shape {node.get('id')!r}: a textured base colour but no texture coordinates in the mesh file: the constant base colour is used")
+                btex = None
+            meshes.append(scenes.MeshData(node.get("id") or f"mesh-{len(meshes)}", v[None], t, alb, mat, bsdf, smooth=smooth, uv=uv, base_tex=btex))
         elif node.tag == "emitter":
             p = _props(node)
             tw = _transform(_child(node, "transform", "to_world"))

@@ -320,6 +320,14 @@ class Scene:
         self.albedo = torch.from_numpy(alb).to(self.device)
         self._albedo_host = alb.copy()
         self._albedo_ring = None
+        # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
+        # leaf slot's three corners (static: the slot order is the tree's)
+        self._base_tex = [(name, torch.from_numpy(t).to(self.device).contiguous()) for name, t in scenes.base_textures(data)]
+        self._slot_uv = None
+        if self._base_tex:
+            info = self.geom.info
+            order = self.geom._blobs[0][int(info.off_order): int(info.off_order) + 4 * int(info.n_tris)].cpu().numpy().view(np.int32)
+            self._slot_uv = torch.from_numpy(scenes.slot_uv_table(order, tris, tri_shape, data.meshes)).to(self.device).contiguous()
         self.shadows = shadows
         self.tex_color = (0.0, 1.0, 0.0)
         self._film_size = {}
@@ -346,6 +354,8 @@ class Scene:
         # `twosided` wrapper (main.py:97-107: "brdf_0.roughness.value", ..., and "brdf_0.specular" without ".value");
         # diffuse materials keep base_color / specular / roughness so that the reference's scripts run on them
         self._material_principled = {k: v[0].bsdf is not None for k, v in mats.items()}
+        for name, t in self._base_tex:  # (Mitsuba exposes a bitmap-valued base colour as `.data`, a constant one as `.value`)
+            p._init(name + ".brdf_0.base_color.data", TensorXf(t))
         for mat, ms in mats.items():
             p._init(mat + ".brdf_0.base_color.value", Color3f(torch.tensor(ms[0].albedo, dtype=torch.float32)))
             b = dict(scenes.PRINCIPLED_DEFAULTS)
@@ -441,6 +451,15 @@ class Scene:
                 for i in self._material_meshes[base]:
                     self._albedo_host[i, col] = v
                 albedo_dirty = True
+            elif rest == "brdf_0.base_color.data" and any(n == base for n, _ in self._base_tex):
+                # a new base-colour texture (main.py:147-153 assigns one per iteration, through numpy): any resolution, [h,w,3]
+                v = self._params._d[k]
+                v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(np.asarray(v, np.float32))
+                if v.dim() != 3 or v.shape[-1] != 3:
+                    raise ValueError(f"{k}: expected a [height, width, 3] texture, got {tuple(v.shape)}")
+                v = v.detach().to(self.device, torch.float32).contiguous()
+                self._base_tex = [(n, v if n == base else t) for n, t in self._base_tex]
+                self._params._d[k] = TensorXf(v)
             elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
                 c = self._params._d[k]
                 c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]
@@ -491,7 +510,9 @@ class Scene:
             spot = scenes.SpotData(s.name, self._mat(s.name + ".to_world"), tuple(float(v) for v in inten), float(p[s.name + ".cutoff_angle"]),
                                    float(p[s.name + ".beam_width"]))
         tmp = scenes.SceneData(d.meshes, sensor, proj, spot, float(p["Projector.scale"]) if proj is not None else 1.0)
-        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride)
+        btex = [(t.data_ptr(), t.shape[1], t.shape[0]) for _, t in self._base_tex] or None
+        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride, base_tex=btex,
+                                   slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None)
         self._sd_cache = (tex_channels, sd)
         return sd
 

@@ -26,7 +26,7 @@ def camera_from_sensor(s, to_world=None):
 
 
 def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shadows=True, cam_to_world=None, proj_to_world=None,
-               spot_to_world=None, spot_intensity=None, mat_stride=0):
+               spot_to_world=None, spot_intensity=None, mat_stride=0, base_tex=None, slot_uv=None):
     """ffx_scene_desc for a scenes.SceneData.  `color` is the RGB weight of a 1-channel projector
     texture (the reference packs the laser texture into the green channel,
     examples/vocalfold_scene.py:64-67)."""
@@ -35,6 +35,13 @@ def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shad
     sd.shadows = int(bool(shadows))
     sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
     sd.mat_stride = int(mat_stride)  # 0 / 3: the material table is [S,3] Lambert albedos; 16: material rows (scenes.material_rows)
+    if base_tex:  # texture-valued base colours: [(address, width, height)] + the address of the per-slot texture coordinates
+        if len(base_tex) > _abi.MAX_BASE_TEX or slot_uv is None:
+            raise ValueError("at most 4 base-colour textures, and they need slot_uv")
+        sd.n_base_tex = len(base_tex)
+        for k, (addr, w, h) in enumerate(base_tex):
+            sd.base_tex[k], sd.base_tex_w[k], sd.base_tex_h[k] = int(addr), int(w), int(h)
+        sd.slot_uv = int(slot_uv)
     if scene.projector is not None:
         p = scene.projector
         sd.proj.to_world = _m16(p.to_world if proj_to_world is None else proj_to_world)

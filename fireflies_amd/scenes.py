@@ -58,6 +58,11 @@ class MeshData:
     # the mesh carries vertex normals (an OBJ with `vn`, a PLY with nx/ny/nz): Mitsuba then shades it in the frame of the
     # interpolated normal and re-derives angle-weighted vertex normals after every vertex_positions update (include/ffx.h ffx_smooth)
     smooth: bool = False
+    # per-vertex texture coordinates [V,2] (an OBJ's `vt`, v already flipped as Mitsuba's flip_tex_coords default does) and the
+    # material's texture-valued base colour [h,w,3] (Mitsuba: <bsdf> with a bitmap `base_color`; parameter key
+    # `<mat>.brdf_0.base_color.data`, re-assigned per iteration by the reference's dataset loop, main.py:120-153)
+    uv: np.ndarray = None
+    base_tex: np.ndarray = None
 
 
 @dataclass
@@ -274,10 +279,45 @@ def material_row(albedo, bsdf):
 
 
 def material_rows(scene):
-    """[S,16] material rows, or None if every mesh is diffuse (the renderer then takes the [S,3] albedo table)"""
-    if all(m.bsdf is None for m in scene.meshes):
+    """[S,16] material rows, or None if every mesh is diffuse and untextured (the renderer then takes the [S,3] albedo table).
+    Column FFX_MAT_BASE_TEX = 1 + index of the mesh's material among base_textures(scene)."""
+    if all(m.bsdf is None and m.base_tex is None for m in scene.meshes):
         return None
-    return np.stack([material_row(m.albedo, m.bsdf) for m in scene.meshes]).astype(np.float32)
+    rows = np.stack([material_row(m.albedo, m.bsdf) for m in scene.meshes]).astype(np.float32)
+    tex_mats = [k for k, _ in base_textures(scene)]
+    for i, m in enumerate(scene.meshes):
+        if m.base_tex is not None and m.uv is not None and m.material in tex_mats:
+            rows[i, 15] = 1.0 + tex_mats.index(m.material)
+    return rows
+
+
+def base_textures(scene):
+    """[(material name, [h,w,3] float32)] — one texture-valued base colour per material (first mesh that declares one; at
+    most 4: include/ffx.h FFX_MAX_BASE_TEX)"""
+    out, seen = [], set()
+    for m in scene.meshes:
+        if m.base_tex is not None and m.uv is not None and m.material not in seen:
+            seen.add(m.material)
+            out.append((m.material, np.ascontiguousarray(m.base_tex, np.float32).reshape(m.base_tex.shape[0], m.base_tex.shape[1], 3)))
+    if len(out) > 4:
+        raise NotImplementedError("more than 4 textured base colours in one scene")
+    return out
+
+
+def slot_uv_table(order, tris, tri_shape, meshes):
+    """[F + 4, 6] float32: the texture coordinates (u0 v0 u1 v1 u2 v2) of every LEAF SLOT's triangle (`order`: slot -> triangle,
+    ffx_bvh_info.off_order); zeros for meshes without uv"""
+    order, tris, tri_shape = np.asarray(order, np.int64), np.asarray(tris, np.int64), np.asarray(tri_shape, np.int64)
+    out = np.zeros((order.shape[0] + 4, 6), np.float32)
+    for s_, m in enumerate(meshes):
+        if m.uv is None:
+            continue
+        uv = np.asarray(m.uv, np.float32).reshape(-1, 2)
+        if uv.shape[0] != m.frames.shape[1]:
+            raise ValueError(f"{m.name}: {uv.shape[0]} texture coordinates for {m.frames.shape[1]} vertices")
+        slots = np.nonzero(tri_shape[order] == s_)[0]
+        out[slots] = uv[tris[order[slots]]].reshape(-1, 6)
+    return out
 
 
 # ----------------------------------------------------------------------------- flattening

@@ -374,6 +374,7 @@ typedef struct ffx_spot {
   int32_t enabled;
 } ffx_spot;
 
+#define FFX_MAX_BASE_TEX 4
 typedef struct ffx_scene_desc {
   ffx_camera cam;
   ffx_projector proj;
@@ -381,6 +382,18 @@ typedef struct ffx_scene_desc {
   int32_t shadows;    /* trace shadow rays toward both emitters */
   int32_t n_shapes;   /* rows of shape_albedo */
   int32_t mat_stride; /* floats per row of shape_albedo: 0 or 3 = Lambert albedo only, FFX_MAT_STRIDE = material rows (below) */
+  /* Texture-valued base colours (Mitsuba: `<mat>.brdf_0.base_color.data`, which the reference's dataset loop re-assigns every
+   * iteration: main.py:120-153).  A material row selects one with FFX_MAT_BASE_TEX = 1 + index (0: the row's own base_color).
+   * Lookup [EXT Mitsuba `bitmap` texture, defaults]: the hit's texture coordinates — slot_uv's three corners interpolated with
+   * the hit's barycentrics — wrapped to [0,1) (repeat), bilinear between texel centres (u w - 0.5, v h - 0.5), rows top-down
+   * (the OBJ loader's flip_tex_coords default, v -> 1 - v, is applied to slot_uv by the caller).  The sampled RGB takes the
+   * place of base_color everywhere in the row's BSDF (diffuse, metallic Fresnel, tints).  The adjoint with respect to the
+   * PROJECTOR texture stays available through ffx_render_bwd (re-tracing); ffx_render_fwd_cache refuses such a scene
+   * (its per-pixel footprint folds ONE base colour per shape). */
+  int32_t n_base_tex;
+  int32_t base_tex_w[FFX_MAX_BASE_TEX], base_tex_h[FFX_MAX_BASE_TEX];
+  const float *base_tex[FFX_MAX_BASE_TEX]; /* [dev][h, w, 3] */
+  const float *slot_uv;                    /* [dev][n_tris + 4, 6] (u0 v0 u1 v1 u2 v2 per leaf slot: ffx_bvh_info.off_order gives slot -> triangle) */
 } ffx_scene_desc;
 
 /* Material rows (mat_stride == FFX_MAT_STRIDE): shape_albedo is then [n_shapes, 16] floats.  Model 1 is the reflection
@@ -410,7 +423,8 @@ typedef struct ffx_scene_desc {
 #define FFX_MAT_SHEEN_TINT 11
 #define FFX_MAT_FLATNESS 12
 #define FFX_MAT_CLEARCOAT 13
-#define FFX_MAT_CLEARCOAT_GLOSS 14 /* 15: reserved, 0 */
+#define FFX_MAT_CLEARCOAT_GLOSS 14
+#define FFX_MAT_BASE_TEX 15        /* 0.0: base_color is the row's; k + 1: ffx_scene_desc.base_tex[k] sampled at the hit's texture coordinates */
 
 int ffx_render_fwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
                    const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
@@ -453,8 +467,9 @@ int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[
  * the image — the coverage loss of a pattern optimiser, -mean(green) — gimg is constant and that inner product IS the loss
  * value, so a gradient step needs no separate reduction launch (the reference's loop evaluates the loss with torch
  * reductions: fireflies/graphics/rasterization.py:589-601).  dot_out is an array of ffx_render_dot_slots(W, H) partial sums
- * (one per 8x8-pixel block; each is ADDED to, the caller zeroes them once and sums them — ffx_pattern_bwd's loss_in does):
- * spread because thousands of float atomics on one address serialise (measured +40 us).  img = dot_out = NULL: off. */
+ * (8x8-pixel blocks folded onto at most 256 slots; each is ADDED to, the caller zeroes them once and sums them —
+ * ffx_pattern_bwd's loss_in does): spread because thousands of float atomics on one address serialise (measured +40 us).
+ * img = dot_out = NULL: off. */
 size_t ffx_render_dot_slots(int width, int height);
 int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,

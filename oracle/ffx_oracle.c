@@ -1041,6 +1041,7 @@ typedef struct {
   int shadows;
   const float *mats; int mat_stride; /* material rows (include/ffx.h) */
   const float *nrec;                 /* per-slot vertex normals of the blob (ffx_smooth), or NULL */
+  int n_base_tex; const float *base_tex[FFX_MAX_BASE_TEX]; int btw[FFX_MAX_BASE_TEX], bth[FFX_MAX_BASE_TEX]; const float *slot_uv; /* textured base colours */
 } shade_ctx;
 
 static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
@@ -1071,6 +1072,13 @@ static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
     c->cos_cut = cosf(c->cutoff);
     c->cos_beam = cosf(beam);
     c->inv_trans = 1.0f / (c->cutoff - beam);
+  }
+  c->n_base_tex = sd->n_base_tex;
+  if (c->n_base_tex < 0 || c->n_base_tex > FFX_MAX_BASE_TEX) return 0;
+  c->slot_uv = sd->slot_uv;
+  for (int k = 0; k < c->n_base_tex; ++k) {
+    c->base_tex[k] = sd->base_tex[k]; c->btw[k] = sd->base_tex_w[k]; c->bth[k] = sd->base_tex_h[k];
+    if (!c->base_tex[k] || c->btw[k] < 1 || c->bth[k] < 1 || !c->slot_uv) return 0;
   }
   return 1;
 }
@@ -1148,7 +1156,8 @@ static void material_geometry(const float *m, v3 n, v3 wv, v3 wl, mat_geo *g) {
     g->axay = a2;
   }
 }
-static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, float *A, float *B) {
+static void material_eval(const float *m, int mat_stride, const float *base /* the base colour: m, or the texture's sample */, v3 n, v3 wv, v3 wl, float *A,
+                          float *B) {
   *A = 0.f; *B = 0.f;
   if (mat_stride != FFX_MAT_STRIDE || m[FFX_MAT_MODEL] == 0.f) { *A = vdot(n, wl); return; } /* Lambert: pi * (1/pi) * cos_o */
   mat_geo g;
@@ -1158,7 +1167,7 @@ static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, fl
   const float rough = m[FFX_MAT_ROUGHNESS], metallic = m[FFX_MAT_METALLIC], spec_trans = m[FFX_MAT_SPEC_TRANS];
   const float eta = m[FFX_MAT_ETA], spec_tint = m[FFX_MAT_SPEC_TINT], sheen = m[FFX_MAT_SHEEN], sheen_tint = m[FFX_MAT_SHEEN_TINT];
   const float flat = m[FFX_MAT_FLATNESS], cc = m[FFX_MAT_CLEARCOAT], ccg = m[FFX_MAT_CLEARCOAT_GLOSS];
-  const float lum = 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
+  const float lum = 0.212671f * base[0] + 0.715160f * base[1] + 0.072169f * base[2];
   const float brdf = (1.0f - metallic) * (1.0f - spec_trans);
   const int facing = ci_h * cos_i > 0.f && co_h * cos_o > 0.f;
   /* Schlick weight as calc_schlick takes it (cos >= 0: outside) */
@@ -1228,14 +1237,31 @@ static void material_eval(const float *m, int mat_stride, v3 n, v3 wv, v3 wl, fl
 /* test hook (not part of include/ffx.h): material_eval for `count` direction triples */
 int ffx_oracle_material_eval(const float *row, int mat_stride, const float *n, const float *wv, const float *wl, int count, float *ab) {
   for (int i = 0; i < count; ++i)
-    material_eval(row, mat_stride, V3(n[3 * i], n[3 * i + 1], n[3 * i + 2]), V3(wv[3 * i], wv[3 * i + 1], wv[3 * i + 2]),
+    material_eval(row, mat_stride, row, V3(n[3 * i], n[3 * i + 1], n[3 * i + 2]), V3(wv[3 * i], wv[3 * i + 1], wv[3 * i + 2]),
                   V3(wl[3 * i], wl[3 * i + 1], wl[3 * i + 2]), &ab[2 * i], &ab[2 * i + 1]);
   return FFX_OK;
 }
 
 /* per-sample shading terms: projector texel footprint (4 bilinear taps with weights) and the
  * scalar factor multiplying the texture value, plus the spot contribution. */
-typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, uby; float wx[2], wy[2]; float proj_fac, proj_fac_b; float spot_rgb[3], spot_rgb_b[3]; } sample_terms; /* _b: the part that does not scale with base_color */
+typedef struct { int hit; int shape; int has_proj; int ix[2], iy[2]; int ubx, uby; float wx[2], wy[2]; float proj_fac, proj_fac_b; float spot_rgb[3], spot_rgb_b[3];
+                 float base[3]; /* the sample's base colour: the shape's row, or its texture at the hit (FFX_MAT_BASE_TEX) */ } sample_terms; /* _b: the part that does not scale with base_color */
+
+/* bilinear lookup of a [h, w, 3] texture at (u, v) [EXT Mitsuba bitmap texture defaults: repeat, bilinear between texel centres] */
+static void base_tex_lookup(const float *tex, int w, int h, float u, float v, float *rgb) {
+  u = u - floorf(u);
+  v = v - floorf(v);
+  const float fx = fmaf(u, (float)w, -0.5f), fy = fmaf(v, (float)h, -0.5f);
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  x0 = ((x0 % w) + w) % w; x1 = ((x1 % w) + w) % w; y0 = ((y0 % h) + h) % h; y1 = ((y1 % h) + h) % h;
+  for (int ch = 0; ch < 3; ++ch) {
+    const float t00 = tex[((size_t)y0 * w + x0) * 3 + ch], t01 = tex[((size_t)y0 * w + x1) * 3 + ch];
+    const float t10 = tex[((size_t)y1 * w + x0) * 3 + ch], t11 = tex[((size_t)y1 * w + x1) * 3 + ch];
+    rgb[ch] = (1.0f - ay) * ((1.0f - ax) * t00 + ax * t01) + ay * ((1.0f - ax) * t10 + ax * t11);
+  }
+}
 
 static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *recs, v3 o, v3 d, float nt, float ft, sample_terms *st) {
   hit_t h;
@@ -1262,14 +1288,25 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
    * hit's barycentrics (Moller-Trumbore's u, v: P = v0 + u e1 + v e2), faced to the viewer by the sign of cos(theta_i) in
    * the SHADING frame (the `twosided` wrapper); the geometric normal keeps the side tests (include/ffx.h ffx_smooth) */
   v3 ns = ng;
-  if (r->pad != 0.f && c->nrec) {
+  const float *mrow0 = c->mats + (size_t)c->mat_stride * h.shape;
+  st->base[0] = mrow0[0]; st->base[1] = mrow0[1]; st->base[2] = mrow0[2];
+  const int tex_ix = (c->mat_stride == FFX_MAT_STRIDE) ? (int)mrow0[FFX_MAT_BASE_TEX] : 0;
+  float bu = 0.f, bv = 0.f, bw = 1.f;
+  if ((r->pad != 0.f && c->nrec) || tex_ix > 0) { /* the hit's barycentrics (Moller-Trumbore's u, v, recomputed from the record) */
     const v3 e1 = V3(r->e1[0], r->e1[1], r->e1[2]), e2 = V3(r->e2[0], r->e2[1], r->e2[2]);
     const v3 pv = vcross(d, e2);
     const float det = vdot(e1, pv);
     const v3 tv = vsub(o, V3(r->v0[0], r->v0[1], r->v0[2]));
     const v3 qv = vcross(tv, e1);
     const float idet = 1.0f / det;
-    const float bu = vdot(tv, pv) * idet, bv = vdot(d, qv) * idet, bw = (1.0f - bu) - bv;
+    bu = vdot(tv, pv) * idet; bv = vdot(d, qv) * idet; bw = (1.0f - bu) - bv;
+  }
+  if (tex_ix > 0 && tex_ix <= c->n_base_tex) { /* textured base colour: interpolate the slot's texture coordinates, look the texture up */
+    const float *uv = c->slot_uv + 6 * (size_t)h.slot;
+    const float tu = fmaf(bw, uv[0], fmaf(bu, uv[2], bv * uv[4])), tv_ = fmaf(bw, uv[1], fmaf(bu, uv[3], bv * uv[5]));
+    base_tex_lookup(c->base_tex[tex_ix - 1], c->btw[tex_ix - 1], c->bth[tex_ix - 1], tu, tv_, st->base);
+  }
+  if (r->pad != 0.f && c->nrec) {
     const float *q = c->nrec + 12 * (size_t)h.slot;
     v3 ni = V3(fmaf(bw, q[0], fmaf(bu, q[4], bv * q[8])), fmaf(bw, q[1], fmaf(bu, q[5], bv * q[9])), fmaf(bw, q[2], fmaf(bu, q[6], bv * q[10])));
     const float l2 = vdot(ni, ni);
@@ -1304,7 +1341,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
             /* irradiance texture * pi*scale / (z_l^2 * cos_p) [EXT Mitsuba projector], Lambert
                albedo/pi * cos_s: pi cancels */
             float bA, bB;
-            material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+            material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, st->base, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
             st->proj_fac = (c->p_scale / (pl.z * pl.z * cos_p)) * bA; /* Lambert: bA = cos_s */
             st->proj_fac_b = (c->p_scale / (pl.z * pl.z * cos_p)) * bB;
             float fx = fmaf(u, (float)c->tw, -0.5f), fy = fmaf(v, (float)c->th, -0.5f);
@@ -1343,7 +1380,7 @@ static void shade_sample(const shade_ctx *c, const onode *nodes, const orec *rec
         if (c->shadows) vis = !occluded(nodes, recs, c->s_pos, vsub(Po, c->s_pos), 0.f, 1.0f - SHADOW_EPS);
         if (vis) {
           float bA, bB;
-          material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
+          material_eval(c->mats + (size_t)c->mat_stride * h.shape, c->mat_stride, st->base, ns, V3(-d.x, -d.y, -d.z), wi, &bA, &bB);
           float f = fall * bA / d2 * 0.3183098861837907f; /* Lambert: bA = cos_s, 1/pi */
           float fb = fall * bB / d2 * 0.3183098861837907f;
           for (int ch = 0; ch < 3; ++ch) { st->spot_rgb[ch] = c->s_int[ch] * f; st->spot_rgb_b[ch] = c->s_int[ch] * fb; }
@@ -1413,7 +1450,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
         }
       }
       if (!st.hit) continue;
-      const float *alb = shape_albedo + (size_t)c.mat_stride * st.shape;
+      const float *alb = st.base; /* the shape's base colour, or its texture at the hit */
       float rgb[3] = {st.spot_rgb[0], st.spot_rgb[1], st.spot_rgb[2]};
       float rgb_b[3] = {st.spot_rgb_b[0], st.spot_rgb_b[1], st.spot_rgb_b[2]};
       if (st.has_proj) {
@@ -1452,6 +1489,7 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   (void)s;
   if (!cache) FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
+  if (sd && sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: textured base colours (use ffx_render_bwd)");
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, (crec *)cache); /* bit 1 (sparse adjoint) ignored: full gradient */
 }
 
@@ -1476,7 +1514,11 @@ static inline float f16_to_f32(uint16_t h) {
   return f;
 }
 
-size_t ffx_render_dot_slots(int width, int height) { return (width < 1 || height < 1) ? 0 : (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8); }
+size_t ffx_render_dot_slots(int width, int height) {
+  if (width < 1 || height < 1) return 0;
+  const size_t b = (size_t)((width + 7) / 8) * (size_t)((height + 7) / 8);
+  return b < 256 ? b : 256;
+}
 
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
@@ -1553,7 +1595,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
       sample_terms st;
       shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
       if (!st.hit || !st.has_proj) continue;
-      const float *alb = shape_albedo + (size_t)c.mat_stride * st.shape;
+      const float *alb = st.base;
       for (int tch = 0; tch < c.tc; ++tch) {
         float wsum;
         if (c.tc == 3) wsum = g[tch] * alb[tch] * st.proj_fac * inv_spp;

@@ -256,7 +256,31 @@ def vertex_normals(verts, tri_idx, use=None):
     return out / np.where(l > 0, l, 1.0)[:, None]
 
 
-def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None):
+def sample_texture(tex, u, v):
+    """[h,w,3] texture at texture coordinates (u, v): repeat wrap, bilinear between texel centres, row 0 at v = 0
+    [EXT Mitsuba `bitmap` defaults]"""
+    tex = np.asarray(tex, np.float64)
+    h, w = tex.shape[:2]
+    fx, fy = (u % 1.0) * w - 0.5, (v % 1.0) * h - 0.5
+    x0, y0 = np.floor(fx), np.floor(fy)
+    ax, ay = (fx - x0)[:, None], (fy - y0)[:, None]
+    x0, y0 = x0.astype(int), y0.astype(int)
+    xa, xb, ya, yb = x0 % w, (x0 + 1) % w, y0 % h, (y0 + 1) % h
+    return (1 - ay) * ((1 - ax) * tex[ya, xa] + ax * tex[ya, xb]) + ay * ((1 - ax) * tex[yb, xa] + ax * tex[yb, xb])
+
+
+def _barycentric(verts, idx, P):
+    """weights of P in the triangles idx [N,3] from sub-triangle areas (not from the intersection routine's u, v)"""
+    a, b, c = verts[idx[:, 0]], verts[idx[:, 1]], verts[idx[:, 2]]
+    nn = np.cross(b - a, c - a)
+    den = (nn * nn).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wa = (np.cross(c - b, P - b) * nn).sum(1) / den
+        wb = (np.cross(a - c, P - c) * nn).sum(1) / den
+    return wa, wb, 1.0 - wa - wb
+
+
+def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None, vert_uv=None, base_tex=None):
     """per sample: hit mask, shape id, projector taps / weights / rgb factor (irradiance scale x BSDF x cos), spot radiance.
     `smooth`: one flag per shape — shade in the frame of the interpolated vertex normal (Mitsuba meshes with vertex normals):
     BSDF and emitter cosines use the interpolated normal, faced to the viewer by its own cos(theta_i) (the `twosided`
@@ -282,14 +306,7 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None):
         fl = np.asarray([bool(f) for f in smooth])
         vn = vertex_normals(verts, tri_idx, use=fl[np.asarray(tri_shape)])
         idx = np.asarray(tri_idx)[pr]
-        # barycentric coordinates of P from sub-triangle areas (not from the intersection routine's u, v)
-        a, b, c = np.asarray(verts, np.float64)[idx[:, 0]], np.asarray(verts, np.float64)[idx[:, 1]], np.asarray(verts, np.float64)[idx[:, 2]]
-        nn = np.cross(b - a, c - a)
-        den = (nn * nn).sum(1)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            wa = (np.cross(c - b, P - b) * nn).sum(1) / den
-            wb = (np.cross(a - c, P - c) * nn).sum(1) / den
-        wc = 1.0 - wa - wb
+        wa, wb, wc = _barycentric(np.asarray(verts, np.float64), idx, P)
         ni = wa[:, None] * vn[idx[:, 0]] + wb[:, None] * vn[idx[:, 1]] + wc[:, None] * vn[idx[:, 2]]
         nil = np.linalg.norm(ni, axis=1)
         use = ok & fl[np.maximum(shape, 0)] & (nil > 0)
@@ -297,7 +314,18 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None):
         ni = np.where(((ni * d).sum(1) > 0)[:, None], -ni, ni)
         n = np.where(use[:, None], ni, n)
     out = {"hit": hit, "shape": shape, "pfac": np.zeros((len(P), 3)), "taps": None, "w": None, "spot": np.zeros((len(P), 3))}
-    rows = mats[np.maximum(shape, 0)]
+    rows = mats[np.maximum(shape, 0)].copy()
+    if base_tex is not None and rows.shape[1] == 16:
+        # texture-valued base colour (Mitsuba: <mat>.brdf_0.base_color.data): rows[:, 15] = 1 + texture index; the hit's texture
+        # coordinates are the vertices' interpolated with the barycentric weights
+        idx = np.asarray(tri_idx)[pr]
+        wa, wb, wc = _barycentric(np.asarray(verts, np.float64), idx, P)
+        uvs = np.asarray(vert_uv, np.float64)
+        uv = wa[:, None] * uvs[idx[:, 0]] + wb[:, None] * uvs[idx[:, 1]] + wc[:, None] * uvs[idx[:, 2]]
+        for k, tex in enumerate(base_tex):
+            sel = ok & (rows[:, 15] == k + 1)
+            if sel.any():
+                rows[sel, :3] = sample_texture(tex, uv[sel, 0], uv[sel, 1])
     if sd.proj.enabled:
         tw = _m(sd.proj.to_world, 4)
         w2l = np.linalg.inv(tw)
@@ -344,8 +372,8 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None):
     return out
 
 
-def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=None):
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth)
+def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=None, vert_uv=None, base_tex=None):
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth, vert_uv, base_tex)
     W, H = sd.cam.width, sd.cam.height
     rad = s["spot"].copy()
     if sd.proj.enabled:
@@ -362,9 +390,9 @@ def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=Non
     return rad.reshape(H, W, spp, 3).mean(2)
 
 
-def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg, smooth=None):
+def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg, smooth=None, vert_uv=None, base_tex=None):
     """d <img, gimg> / d tex for a 1-channel texture"""
-    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth)
+    s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth, vert_uv, base_tex)
     g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
     ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) / spp
     ws = np.where(s["hit"], ws, 0.0)

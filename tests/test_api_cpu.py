@@ -418,3 +418,31 @@ def test_intersection_helpers_match_reference():
     hit = intersections.sphereSphere(torch.from_numpy(g["ss_a"]), torch.from_numpy(g["ss_ar"]), torch.from_numpy(g["ss_b"]), torch.from_numpy(g["ss_br"]))
     np.testing.assert_array_equal(hit.numpy(), g["ss_hit"])
     assert 0 < int(g["ss_hit"].sum()) < g["ss_hit"].size
+
+
+def test_noise_texture_sampler_matches_the_reference():
+    """sampling.NoiseTextureLerpSampler (fireflies/sampling/noise_texture_lerp.py): the base-colour textures of the reference's
+    dataset loop (main.py:138-153), under the same torch / random seeds — golden g13 (every 8th texel + mean + sum of squares
+    of two consecutive draws; a 512-wide texture is the smallest the 64 * 2^3 lattice admits)."""
+    import random
+
+    from fireflies_amd.sampling import NoiseTextureLerpSampler
+
+    g = load_golden("g13_noise_texture.npz")
+    for tag in "abc":
+        seed, shape = int(g[f"{tag}_seed"]), tuple(int(v) for v in g[f"{tag}_shape"])
+        torch.manual_seed(seed)
+        random.seed(seed)
+        ca, cb = torch.rand(3), torch.rand(3)
+        np.testing.assert_array_equal(ca.numpy(), g[f"{tag}_color_a"])
+        smp = NoiseTextureLerpSampler(color_a=ca, color_b=cb, texture_shape=shape, device=torch.device("cpu"))
+        for k in range(2):
+            t = smp.sample().numpy()
+            assert t.shape == (3,) + shape
+            np.testing.assert_allclose(t[:, ::8, ::8], g[f"{tag}_tex{k}_sub"], rtol=0, atol=1e-6)
+            assert float(t.astype(np.float64).mean()) == pytest.approx(float(g[f"{tag}_tex{k}_mean"]), abs=1e-7)
+            assert float((t.astype(np.float64) ** 2).sum()) == pytest.approx(float(g[f"{tag}_tex{k}_sq"]), rel=1e-6)
+    from fireflies_amd.sampling.noise_texture_lerp import perlin_2d
+
+    with pytest.raises(ValueError):  # fewer texels than lattice cells (the reference fails with a shape error deep inside)
+        perlin_2d((16, 16), (32, 32))

@@ -53,6 +53,26 @@ def test_laser_projection_and_clamp_match_reference():
     laser.randomize_laser_out_of_bounds()
     laser.randomize_camera_out_of_bounds(torch.rand(laser._rays.shape[0], 3, device=DEV) * 4 - 2)
     assert torch.isfinite(laser._rays).all()
+    # randomize_camera_out_of_bounds against the reference on a CPU seed (golden g14, fireflies/projection/laser.py:233-249): which
+    # rays are respawned, where they land (the respawn draws are the reference's CPU stream, handed to the device), and that the
+    # others are only re-normalised; nothing out of bounds -> untouched
+    g14 = load_golden("g14_camera_out_of_bounds.npz")
+    laser = _laser(g14["rays_before"], g14["K"])
+    ndc = dev(g14["ndc"])
+    n_out = int((((ndc[:, :2] >= 1.0) | (ndc[:, :2] <= -1.0)).any(dim=1)).sum())
+    assert 8 < n_out < 60
+    torch.manual_seed(23)
+    cpu_draw = torch.rand(n_out, 3)  # the reference's `torch.rand(out_of_bounds_points.shape, device=cpu)`
+    real_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: cpu_draw.to(DEV) if tuple(a[0]) == (n_out, 3) else real_rand(*a, **k)
+        laser.randomize_camera_out_of_bounds(ndc)
+    finally:
+        torch.rand = real_rand
+    np.testing.assert_allclose(laser._rays.cpu().numpy(), g14["rays_after"], rtol=2e-5, atol=2e-6)
+    laser2 = _laser(g14["rays_before"], g14["K"])
+    laser2.randomize_camera_out_of_bounds(dev(g14["inside"]))
+    np.testing.assert_array_equal(laser2._rays.cpu().numpy(), g14["rays_inside_after"])
 
 
 def test_rasterization_api_matches_reference():
@@ -656,6 +676,86 @@ def test_load_file_xml_obj_renders_like_the_oracle(oracle, tmp_path):
     # face_normals = true in the file switches the interpolation off again (Mitsuba's shape property)
     (tmp_path / "scene_fn.xml").write_text(XML.replace('<string name="filename" value="quad.obj"/>', '<string name="filename" value="quad.obj"/><boolean name="face_normals" value="true"/>'))
     assert [m.smooth for m in mi.load_file(str(tmp_path / "scene_fn.xml")).data.meshes] == [False, False]
+
+
+def test_the_dataset_loop_of_main_py_with_a_textured_mucosa(oracle, tmp_path):
+    """The reference's only shipped end-to-end workload (main.py:120-156), with this repo's imports: a scene file whose mucosa
+    has a bitmap base colour, `params["mat-Mucosa.brdf_0.base_color.data"]` read for its shape, a NoiseTextureLerpSampler
+    texture assigned through numpy every iteration, randomize(), mi.render at a sampled spp — each render against the oracle
+    on the same pose, material row and texture.  (Round 2 raised KeyError at the first line of the loop.)"""
+    import warnings
+
+    from fireflies_amd import loaders
+    from fireflies_amd.sampling import AnimationSampler, NoiseTextureLerpSampler
+    from tests.test_loaders_cpu import XML
+
+    wv, wt = scenes.make_plane(0.0, 1.0, 8, 8)
+    n = wv.shape[0]
+    lines = [f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}" for p in wv] + [f"vt {(p[0] + 1) / 2:.6f} {(p[1] + 1) / 2:.6f}" for p in wv]
+    lines += [f"f {a + 1}/{a + 1} {b + 1}/{b + 1} {c + 1}/{c + 1}" for a, b, c in wt]
+    (tmp_path / "wall.obj").write_text("\n".join(lines) + "\n")
+    loaders.save_obj(tmp_path / "quad.obj", *scenes.make_uv_sphere((0.1, 0.05, 4.0), 0.35, 16, 8))
+    xml = XML.replace('<float name="clearcoat" value="0.25"/>', '<float name="clearcoat" value="0.25"/><texture type="bitmap" name="base_color"><string name="filename" value="mucosa.png"/></texture>')
+    (tmp_path / "scene.xml").write_text(xml)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (the bitmap file does not exist: a 1x1 stand-in; the loop assigns the real texture)
+        mitsuba_scene = mi.load_file(str(tmp_path / "scene.xml"))
+    mitsuba_params = mi.traverse(mitsuba_scene)
+    ff_scene = ff.Scene(mitsuba_params, device=DEV)
+    wall = ff_scene.mesh("mesh-Wall")
+    wall.rotate_y(-0.2, 0.2)
+    material = ff_scene.material("mat-Mucosa")
+    material.add_float_key("brdf_0.clearcoat.value", 0.0, 1.0)
+    material.add_float_key("brdf_0.specular", 0.0, 1.0)
+    material.add_float_key("brdf_0.roughness.value", 0.2, 1.0)
+    texture = mitsuba_params["mat-Mucosa.brdf_0.base_color.data"].torch().moveaxis(-1, 0).shape
+    assert len(texture) == 3 and texture[0] == 3
+    lerp_sampler = NoiseTextureLerpSampler(color_a=torch.zeros(3, device=DEV), color_b=torch.ones(3, device=DEV), texture_shape=(512, 512), device=DEV)
+    spp_sampler = AnimationSampler(1, 100, 1, 100)
+    ff_scene.train()
+    mitsuba_params["tex.data"] = torch.rand(128, 128, device=DEV)
+    torch.manual_seed(5)
+    random.seed(5)
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(mitsuba_scene.data)
+    go = oracle.Geometry(pool, tris, shape, off)
+    order_o = go.blob[go.info.off_order: go.info.off_order + 4 * go.info.n_tris].view(np.int32)
+    suv_o = scenes.slot_uv_table(order_o, tris, shape, mitsuba_scene.data.meshes)
+    seen = []
+    for count in range(3):
+        lerp_sampler._color_a = torch.rand((3), device=DEV)
+        lerp_sampler._color_b = torch.rand((3), device=DEV)
+        mucosa_texture = lerp_sampler.sample()
+        mitsuba_params["mat-Mucosa.brdf_0.base_color.data"] = mi.TensorXf(mucosa_texture.moveaxis(0, -1).cpu().numpy())
+        ff_scene.randomize()
+        spp = max(4, int(spp_sampler.sample()) // 8)
+        render = mi.render(mitsuba_scene, spp=spp, seed=count).torch().cpu().numpy()
+        sd = mitsuba_scene.scene_desc(tex_channels=1)
+        assert sd.n_base_tex == 1 and sd.base_tex_w[0] == 512 and sd.mat_stride == 16
+        tex_host = np.ascontiguousarray(mucosa_texture.moveaxis(0, -1).cpu().numpy())
+        sd_o = scene_desc_of(mitsuba_scene, tex_host, suv_o)
+        go.update(mitsuba_scene._xforms.numpy(), mitsuba_scene._offs)
+        ref = go.render_fwd(sd_o, mitsuba_scene._albedo_host, mitsuba_params["tex.data"].torch().cpu().numpy(), spp, seed=count)
+        assert_image_close(render, ref, spp, frac=1e-3, rel=2e-4, what=f"iteration {count}")
+        seen.append(render)
+    assert np.abs(seen[0] - seen[1]).max() > 0.01  # new texture, new pose, new material every iteration
+    # a texture of another resolution is accepted; a wrong layout is refused
+    mitsuba_params["mat-Mucosa.brdf_0.base_color.data"] = mi.TensorXf(np.full((4, 6, 3), 0.25, np.float32))
+    mitsuba_params.update()
+    assert mitsuba_scene.scene_desc(tex_channels=1).base_tex_w[0] == 6
+    mitsuba_params["mat-Mucosa.brdf_0.base_color.data"] = mi.TensorXf(np.zeros((3, 4, 6), np.float32))
+    with pytest.raises(ValueError):
+        mitsuba_params.update()
+
+
+def scene_desc_of(mi_scene, tex_host, slot_uv_host):
+    """the oracle's view of mi_scene's current scene description: same blocks, host pointers for the texture tables"""
+    import copy
+
+    sd = copy.copy(mi_scene.scene_desc(tex_channels=1))
+    sd.base_tex[0] = tex_host.ctypes.data
+    sd.base_tex_w[0], sd.base_tex_h[0] = tex_host.shape[1], tex_host.shape[0]
+    sd.slot_uv = slot_uv_host.ctypes.data
+    return sd
 
 
 def test_cfg5_colon_half_million_triangles_fp16(oracle):

@@ -692,7 +692,7 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
         want = float((gimg.astype(np.float64) * host(img_c).astype(np.float64)).sum())
         mag = max(1.0, float(np.abs(gimg * host(img_c)).sum()))
         n_slots = ops.render_dot_slots(52, 44)
-        assert n_slots == 7 * 6  # one partial sum per 8x8-pixel block
+        assert n_slots == 7 * 6 and ops.render_dot_slots(512, 512) == 256  # one partial sum per 8x8-pixel block, folded onto at most 256
         dot = torch.full((n_slots,), 0.25, device="cuda")  # the slots are ADDED to
         g_dot = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img_c, dot_out=dot))
         assert abs(float(dot.double().sum()) - 0.25 * n_slots - want) <= 2e-5 * mag
@@ -1036,6 +1036,69 @@ def test_interpolated_shading_normals_match_the_oracle(oracle, env, monkeypatch)
     # a flat geometry writes no flags: bit-identical to what it rendered before the feature existed (same kernels, same records)
     recs_f = host(gf.blob[int(gf.info.off_recs): int(gf.info.off_recs) + 48 * int(gf.info.n_tris)]).view(np.float32).reshape(-1, 12)
     assert (recs_f[:, 11] == 0).all()
+
+
+@pytest.mark.parametrize("env", [{}, {"FFX_WIDE": "0"}, {"FFX_TRAVERSAL": "lane"}])
+def test_textured_base_colour_matches_the_oracle(oracle, env, monkeypatch):
+    """texture-valued base colours (`<mat>.brdf_0.base_color.data`, main.py:120-153; VERDICT r2 missing 3): material rows that
+    select a texture (FFX_MAT_BASE_TEX), texture coordinates per leaf slot interpolated at the hit, repeat wrap, bilinear —
+    a principled and a Lambert row on two textures of odd sizes, coordinates outside [0,1], together with interpolated
+    normals, forward and re-tracing adjoint, packet and lane kernels; the footprint cache refuses such a scene."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    for k in ("FFX_TRAVERSAL", "FFX_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = scenes.vocalfold(width=56, height=48, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    rng = np.random.default_rng(4)
+    for m in sc.meshes:
+        m.uv = (rng.random((m.frames.shape[1], 2)) * 3.0 - 1.0).astype(np.float32)
+    btex = [rng.random((17, 23, 3)).astype(np.float32), rng.random((8, 5, 3)).astype(np.float32)]
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    xf = _rand_xforms(2, 7)
+    offs = (off + stride).astype(np.int32)
+    for smooth in (None, [True, False]):
+        gd = ops.DeviceGeometry(pool, tris, shape, off, smooth=smooth)
+        go = oracle.Geometry(pool, tris, shape, off, smooth=smooth)
+        gd.update(xf, offs)
+        go.update(xf, offs)
+        order_d = host(gd.blob[int(gd.info.off_order): int(gd.info.off_order) + 4 * int(gd.info.n_tris)]).view(np.int32)
+        order_o = go.blob[go.info.off_order: go.info.off_order + 4 * go.info.n_tris].view(np.int32)
+        suv_d, suv_o = dev(scenes.slot_uv_table(order_d, tris, shape, sc.meshes)), scenes.slot_uv_table(order_o, tris, shape, sc.meshes)
+        btex_d = [dev(b) for b in btex]
+        mats = material_rows(2, 23, anisotropic=0.0)
+        mats[0, 15], mats[1, 15], mats[1, 3] = 1.0, 2.0, 0.0  # a principled row on texture 0, a Lambert row on texture 1
+        tex = _tex(sc, 1)
+        gimg = rng.standard_normal((48, 56, 3)).astype(np.float32)
+        kw = dict(tex_channels=1, shadows=True, mat_stride=16)
+        sd_d = scene_desc.scene_desc(sc, base_tex=[(b.data_ptr(), b.shape[1], b.shape[0]) for b in btex_d], slot_uv=suv_d.data_ptr(), **kw)
+        sd_o = scene_desc.scene_desc(sc, base_tex=[(b.ctypes.data, b.shape[1], b.shape[0]) for b in btex], slot_uv=suv_o.ctypes.data, **kw)
+        for spp in (9, 70):
+            img_d = host(gd.render_fwd(sd_d, dev(mats), tex, spp, seed=6))
+            img_o = go.render_fwd(sd_o, mats, host(tex), spp, seed=6)
+            scale, _ = _assert_image_close(img_d, img_o, spp, frac=5e-4, rel=2e-4, what=f"{env} smooth={smooth} spp {spp}")
+            assert scale > 0.02
+        g_d = host(gd.render_bwd(sd_d, dev(mats), 9, 6, dev(gimg)))
+        g_o = go.render_bwd(sd_o, mats, 9, 6, gimg)
+        gs = float(np.abs(g_o).max())
+        gerr = np.abs(g_d - g_o)
+        assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs
+        # the textures matter, and a row without one is untouched by their presence
+        plain = mats.copy()
+        plain[:, 15] = 0.0
+        sd_p = scene_desc.scene_desc(sc, **kw)
+        img_p = host(gd.render_fwd(sd_p, dev(plain), tex, 9, seed=6))
+        img_t = host(gd.render_fwd(sd_d, dev(mats), tex, 9, seed=6))
+        assert np.abs(img_p - img_t).max() > 0.05 * float(img_p.max())
+        np.testing.assert_allclose(host(gd.render_fwd(sd_d, dev(plain), tex, 9, seed=6)), img_p, rtol=1e-5, atol=1e-6 * float(img_p.max()))
+        # the footprint cache folds one base colour per shape: refused for textured scenes, through the C ABI and by the wrapper
+        from fireflies_amd import functional as Fn
+
+        assert not Fn.cache_supported(sd_d, 9)
+        cache = torch.zeros(ops.render_cache_bytes_sd(sd_d, 9), dtype=torch.uint8, device="cuda")
+        with pytest.raises(Exception, match="textured base colours"):
+            gd.render_fwd(sd_d, dev(mats), tex, 9, seed=6, cache=cache)
 
 
 def test_principled_materials_mid_size_and_abi_errors(oracle):

@@ -172,13 +172,15 @@ def test_nothing_the_file_asks_for_is_dropped_silently(tmp_path):
              .replace('<sampler type="independent">', '<sampler type="stratified">')
              .replace('<float name="fov" value="60"/>', '<float name="fov" value="60"/><string name="fov_axis" value="y"/><float name="aperture_radius" value="0.1"/>')
              .replace('<float name="clearcoat" value="0.25"/>', '<float name="clearcoat" value="0.25"/><float name="spec_trans" value="0.3"/>'
-                      '<texture type="bitmap" name="base_color"><string name="filename" value="t.png"/></texture>')
+                      '<texture type="bitmap" name="base_color"><string name="filename" value="t.png"/></texture>'
+                      '<texture type="bitmap" name="roughness"><string name="filename" value="r.png"/></texture>')
              .replace('<bsdf type="diffuse"><rgb name="reflectance" value="0.2"/></bsdf></shape>',
                       '<bsdf type="diffuse"><rgb name="reflectance" value="0.2"/></bsdf><emitter type="area"><rgb name="radiance" value="1"/></emitter></shape>\n'
                       '<emitter type="envmap"><string name="filename" value="e.exr"/></emitter>'))
     sc, msgs = load(noisy)
     for needle in ("max_depth 8", "top-level <medium> ignored", "reconstruction filter 'tent'", "sampler type 'stratified'", "sensor property 'aperture_radius' is ignored",
-                   "spec_trans > 0", "texture-valued parameter 'base_color'", "area emitter on a shape ignored", "emitter type 'envmap' ignored"):
+                   "spec_trans > 0", "texture-valued parameter 'roughness' is not evaluated", "base-colour bitmap 't.png' could not be read",
+                   "a textured base colour but no texture coordinates", "area emitter on a shape ignored", "emitter type 'envmap' ignored"):
         assert any(needle in m for m in msgs), (needle, msgs)
     # fov_axis = y on a square film is the same angle; on a 4:3 film it is converted to the horizontal angle
     assert sc.camera.fov_x == pytest.approx(60.0)
@@ -187,3 +189,46 @@ def test_nothing_the_file_asks_for_is_dropped_silently(tmp_path):
     assert loaders._fov_x(50.0, "diagonal", 300, 400) == pytest.approx(np.rad2deg(2 * np.arctan(np.tan(np.deg2rad(25.0)) * 0.6)))
     other, msgs = load(clean.replace('<integrator type="path">', '<integrator type="ptracer">'))
     assert any("'ptracer'" in m and "not implemented" in m for m in msgs)
+
+
+def test_obj_texture_coordinates_and_a_bitmap_base_colour(tmp_path):
+    """`vt` records become per-vertex texture coordinates (v flipped like Mitsuba's flip_tex_coords default); a vertex used with
+    two different `vt` (a seam) is duplicated; a <texture type="bitmap" name="base_color"> inside the bsdf gives the mesh a
+    texture-valued base colour (read with PIL when present) — the scene then exposes `<mat>.brdf_0.base_color.data`."""
+    (tmp_path / "q.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+                                    "f 1/1 2/2 3/3\nf 1/5 3/3 4/4\n")  # vertex 1 carries vt 1 in one face and vt 5 in the other
+    v, t, info = loaders.load_obj(tmp_path / "q.obj", with_info=True)
+    assert v.shape == (5, 3) and t.tolist() == [[0, 1, 2], [4, 2, 3]] and not info["has_normals"]
+    np.testing.assert_allclose(v[4], v[0])
+    np.testing.assert_allclose(info["uv"], [[0, 1], [1, 1], [1, 0], [0, 0], [0.5, 0.5]])
+    v2, t2 = loaders.load_obj(tmp_path / "q.obj")  # the plain call keeps the file's vertices
+    assert v2.shape == (4, 3)
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    if Image is not None:
+        px = np.zeros((2, 3, 3), np.uint8)
+        px[0, 1] = (255, 128, 0)
+        Image.fromarray(px).save(tmp_path / "t.png")
+    wv, wt = scenes.make_plane(0.0, 1.0, 2, 2)
+    loaders.save_obj(tmp_path / "wall.obj", wv, wt)
+    xml = XML.replace("wall.obj", "q.obj").replace('<float name="clearcoat" value="0.25"/>',
+                                                   '<float name="clearcoat" value="0.25"/><texture type="bitmap" name="base_color"><string name="filename" value="t.png"/></texture>')
+    loaders.save_obj(tmp_path / "quad.obj", *scenes.make_plane(4.0, 0.3, 1, 1))
+    (tmp_path / "s.xml").write_text(xml)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = loaders.load_mitsuba_xml(str(tmp_path / "s.xml"))
+    m = sc.meshes[0]
+    assert m.uv.shape == (5, 2) and m.base_tex is not None and m.base_tex.shape[-1] == 3 and sc.meshes[1].base_tex is None
+    if Image is not None:
+        assert m.base_tex.shape == (2, 3, 3)
+        np.testing.assert_allclose(m.base_tex[0, 1], [1.0, ((128 / 255 + 0.055) / 1.055) ** 2.4, 0.0], rtol=1e-5)  # sRGB -> linear
+    rows = scenes.material_rows(sc)
+    assert rows[0, 15] == 1.0 and rows[1, 15] == 0.0 and [n for n, _ in scenes.base_textures(sc)] == ["mat-Mucosa"]
+    suv = scenes.slot_uv_table(np.array([1, 0, 2, 3]), np.concatenate([m.tris, sc.meshes[1].tris]), np.array([0, 0, 1, 1]), sc.meshes)
+    np.testing.assert_allclose(suv[0], m.uv[m.tris[1]].reshape(-1))
+    assert suv.shape == (8, 6) and (suv[2:] == 0).all()
