@@ -807,9 +807,13 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restric
 }
 // exact transpose: gin[q] = sum over the padded positions t (|t - image| <= r) that reflect onto q
 // of g_pad[t] = sum_k w[k] * gout[t - k + r], separately per axis.
+// KS: the kernel size as a compile-time constant (5: the size every call site of the reference uses, vocalfold_scene.py:61-63) or
+// 0 = taken from bw at run time
+template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restrict__ gout, int h, int w, BlurW bw, float *__restrict__ gin) {
   __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
-  const int r = bw.ksize / 2;
+  const int ksize = KS ? KS : bw.ksize;
+  const int r = ksize / 2;
   const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
   const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
   const int x = x0 + lx, y = y0 + ly;
@@ -833,6 +837,30 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
   float acc = 0.f;
   const bool edge_y = small || (y >= 1 && y <= r) || (y >= h - 1 - r && y <= h - 2);
   const bool edge_x = small || (x >= 1 && x <= r) || (x >= w - 1 - r && x <= w - 2);
+  if (!edge_y && !edge_x) {
+    // no reflected candidate: a plain correlation over the zero-padded tile (a tap outside the image adds w * 0, which leaves
+    // the running sum as the skipped term of the general loop does).  With KS known the 25 taps are LDS reads at constant
+    // offsets: the general loop below spent ~36 instructions per tap on bounds tests and integer multiplies.
+    const float *t0 = tile + ly * tw + lx; // tile element of (y - r, x - r)
+    if constexpr (KS != 0) {
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) row = fmaf(bw.w[kx], t0[(2 * r - ky) * tw + (2 * r - kx)], row);
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    } else {
+      for (int ky = 0; ky < ksize; ++ky) {
+        const float *tr = t0 + (2 * r - ky) * tw + 2 * r;
+        float row = 0.f;
+        for (int kx = 0; kx < ksize; ++kx) row = fmaf(bw.w[kx], tr[-kx], row);
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    }
+    gin[(size_t)y * w + x] = acc;
+    return;
+  }
   const int na = edge_y ? 2 * r : 0, nb = edge_x ? 2 * r : 0;
   // candidate padded rows: y itself, then the r rows above the image and the r rows below it
   for (int a = -1; a < na; ++a) {
@@ -841,11 +869,11 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
     for (int b = -1; b < nb; ++b) {
       int tx = (b < 0) ? x : (b < r ? -(b + 1) : w + (b - r));
       if (b >= 0 && reflect_idx(tx, w) != x) continue;
-      for (int ky = 0; ky < bw.ksize; ++ky) {
+      for (int ky = 0; ky < ksize; ++ky) {
         int py = ty - ky + r;
         if (py < 0 || py >= h) continue;
         float row = 0.f;
-        for (int kx = 0; kx < bw.ksize; ++kx) {
+        for (int kx = 0; kx < ksize; ++kx) {
           int px = tx - kx + r;
           if (px < 0 || px >= w) continue;
           const float g = small ? gout[(size_t)py * w + px] : tile[(py - y0 + r) * tw + (px - x0 + r)];
@@ -1076,7 +1104,8 @@ int ffx_blur_bwd(const float *gout, int h, int w, int ksize, float sg, float *gi
   BlurW bw;
   if (!gout || !gin || h <= 0 || w <= 0 || !blur_weights(ksize, sg, bw)) FFX_FAIL(FFX_ERR_ARG, "blur_bwd: bad argument");
   dim3 grid(ffx_cdiv(w, TILE_W), ffx_cdiv(h, TILE_H));
-  hipLaunchKernelGGL(k_blur_bwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, gout, h, w, bw, gin);
+  if (ksize == 5) hipLaunchKernelGGL(k_blur_bwd<5>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, gout, h, w, bw, gin);
+  else hipLaunchKernelGGL(k_blur_bwd<0>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, gout, h, w, bw, gin);
   FFX_CHECK_LAUNCH("blur_bwd");
   return FFX_OK;
 }

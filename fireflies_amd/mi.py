@@ -422,7 +422,7 @@ class Scene:
                 v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v)
                 self._set_pose(base, torch.eye(4), None, v)
                 geom_dirty = True
-            elif rest.startswith("brdf_0.") and rest != "brdf_0.base_color.value" and base in self._material_meshes:
+            elif rest.startswith("brdf_0.") and rest not in ("brdf_0.base_color.value", "brdf_0.base_color.data") and base in self._material_meshes:
                 # principled-BSDF parameters (specular, roughness, clearcoat, ...; the reference randomises them:
                 # main.py:97-107, examples/vocalfold_scene.py:93)
                 name = rest[len("brdf_0."):]
