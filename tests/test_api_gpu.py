@@ -749,9 +749,11 @@ def test_the_dataset_loop_of_main_py_with_a_textured_mucosa(oracle, tmp_path):
 
 def scene_desc_of(mi_scene, tex_host, slot_uv_host):
     """the oracle's view of mi_scene's current scene description: same blocks, host pointers for the texture tables"""
-    import copy
+    import ctypes as C
 
-    sd = copy.copy(mi_scene.scene_desc(tex_channels=1))
+    src = mi_scene.scene_desc(tex_channels=1)
+    sd = type(src)()
+    C.memmove(C.byref(sd), C.byref(src), C.sizeof(src))
     sd.base_tex[0] = tex_host.ctypes.data
     sd.base_tex_w[0], sd.base_tex_h[0] = tex_host.shape[1], tex_host.shape[0]
     sd.slot_uv = slot_uv_host.ctypes.data
