@@ -713,7 +713,8 @@ def test_the_dataset_loop_of_main_py_with_a_textured_mucosa(oracle, tmp_path):
     lerp_sampler = NoiseTextureLerpSampler(color_a=torch.zeros(3, device=DEV), color_b=torch.ones(3, device=DEV), texture_shape=(512, 512), device=DEV)
     spp_sampler = AnimationSampler(1, 100, 1, 100)
     ff_scene.train()
-    mitsuba_params["tex.data"] = torch.rand(128, 128, device=DEV)
+    proj_tex = torch.rand(128, 128, device=DEV)
+    mitsuba_params["tex.data"] = proj_tex
     torch.manual_seed(5)
     random.seed(5)
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(mitsuba_scene.data)
@@ -734,7 +735,7 @@ def test_the_dataset_loop_of_main_py_with_a_textured_mucosa(oracle, tmp_path):
         tex_host = np.ascontiguousarray(mucosa_texture.moveaxis(0, -1).cpu().numpy())
         sd_o = scene_desc_of(mitsuba_scene, tex_host, suv_o)
         go.update(mitsuba_scene._xforms.numpy(), mitsuba_scene._offs)
-        ref = go.render_fwd(sd_o, mitsuba_scene._albedo_host, mitsuba_params["tex.data"].torch().cpu().numpy(), spp, seed=count)
+        ref = go.render_fwd(sd_o, mitsuba_scene._albedo_host, proj_tex.cpu().numpy(), spp, seed=count)
         assert_image_close(render, ref, spp, frac=1e-3, rel=2e-4, what=f"iteration {count}")
         seen.append(render)
     assert np.abs(seen[0] - seen[1]).max() > 0.01  # new texture, new pose, new material every iteration
