@@ -32,6 +32,11 @@ struct CamK {
   float tw[12]; // rows 0..2 of to_world
   float near_clip, far_clip, inv_w, inv_h;
   int W, H;
+  // a perspective sensor's sample_to_camera has m12 = m13 = 0: the homogeneous w of a near-plane point is the constant m15 and
+  // 1 / w is formed once on the host (the same IEEE quotient the per-sample division gave: identical rays).  Measured with
+  // tools/k8ab.py: within the noise (the ten VALU it saves are 0.7 % of a pixel's) — kept because it is free.
+  int w_uniform;
+  float iw_u;
 };
 
 struct ShadeK {
@@ -214,9 +219,10 @@ __device__ __forceinline__ void cam_ray(const CamK &k, float sx, float sy, v3 &o
   float qx = fmaf(m[0], sx, fmaf(m[1], sy, m[3]));
   float qy = fmaf(m[4], sx, fmaf(m[5], sy, m[7]));
   float qz = fmaf(m[8], sx, fmaf(m[9], sy, m[11]));
-  float qw = fmaf(m[12], sx, fmaf(m[13], sy, m[15]));
   // one IEEE reciprocal + multiplies instead of a division per component (same order as the oracle)
-  const float iw = 1.0f / qw;
+  float iw;
+  if (k.w_uniform) iw = k.iw_u; // (wave-uniform branch)
+  else iw = 1.0f / fmaf(m[12], sx, fmaf(m[13], sy, m[15]));
   v3 np = V3(qx * iw, qy * iw, qz * iw);
   const float il = 1.0f / sqrtf(vdot(np, np));
   v3 dl = V3(np.x * il, np.y * il, np.z * il);
@@ -2616,6 +2622,8 @@ static int cam_prepare(const ffx_camera *c, CamK &k) {
   k.H = c->height;
   k.inv_w = 1.0f / (float)c->width;
   k.inv_h = 1.0f / (float)c->height;
+  k.w_uniform = (k.s2c[12] == 0.f && k.s2c[13] == 0.f && k.s2c[15] != 0.f) ? 1 : 0;
+  k.iw_u = k.w_uniform ? 1.0f / k.s2c[15] : 0.f;
   return 1;
 }
 

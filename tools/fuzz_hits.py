@@ -24,6 +24,10 @@ def main():
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
     gd = ops.DeviceGeometry(pool, tris, shape, off)
     go = oracle.Geometry(pool, tris, shape, off)
+    # the same scene with interpolated shading normals on every shape (ffx_smooth): its own pair of geometries
+    gds = ops.DeviceGeometry(pool, tris, shape, off, smooth=[True] * len(off))
+    gos = oracle.Geometry(pool, tris, shape, off, smooth=[True] * len(off))
+    worst_s, bad_s = 0.0, 0
     cam = scene_desc.camera_from_sensor(sc.camera)
     sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
     tex = torch.rand((64, 64, 1), device="cuda")
@@ -72,9 +76,18 @@ def main():
         em = np.abs(im_d - im_o) / max(float(im_o.max()), 1e-6)
         worst_m = max(worst_m, float(em.max()))
         bad_m += int((em > 2e-4).sum())
+        if i % 2 == 0:  # every other pose also with interpolated normals (same material table)
+            gds.update(xf, offs)
+            gos.update(xf, offs)
+            is_d = gds.render_fwd(sdm, torch.from_numpy(mats).cuda(), tex, 16, seed=i).cpu().numpy()
+            is_o = gos.render_fwd(sdm, mats, tex.cpu().numpy(), 16, seed=i)
+            es = np.abs(is_d - is_o) / max(float(is_o.max()), 1e-6)
+            worst_s = max(worst_s, float(es.max()))
+            bad_s += int((es > 2e-4).sum())
     print(f"poses {n_pose}: rays {tot}, different primitive {flips} ({flips / tot:.2e}), oracle-hit-but-GPU-miss {lost}")
     print(f"render: pixels*channels {npx}, |diff| > 1e-4 of scale: {bad_px} ({bad_px / npx:.2e}), worst {worst:.3e} of scale")
     print(f"render with random principled material rows: |diff| > 2e-4 of scale: {bad_m} ({bad_m / npx:.2e}), worst {worst_m:.3e} of scale")
+    print(f"the same with interpolated shading normals (every other pose): |diff| > 2e-4 of scale: {bad_s} ({bad_s / max(npx // 2, 1):.2e}), worst {worst_s:.3e} of scale")
 
 
 if __name__ == "__main__":
