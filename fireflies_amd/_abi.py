@@ -40,6 +40,7 @@ class BvhInfo(C.Structure):
         ("n_treelets", C.c_int32),
         ("plan_ints", C.c_int32),
         ("off_nrec", C.c_uint64),
+        ("off_gn", C.c_uint64),
     ]
 
 

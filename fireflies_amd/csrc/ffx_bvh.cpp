@@ -306,7 +306,7 @@ size_t ffx_bvh_blob_bytes(int n_tris) {
          wmax * FFX_WIDE * (sizeof(WideChild) + 4) + (f + FFX_WIDE) * sizeof(WideChild) + 256 +
          // refit plan: <= f + 1 headers of 8 ints (every leaf under the top could be a treelet of its own), <= f nodes with <= 2 level
          // entries each, <= wmax * 64 wide children, the counter
-         ((f + 2) * 8 + 3 * f + 8 + wmax * FFX_WIDE + 64) * 4 + (f + FFX_LEAF_MAX) * 48 + 128;
+         ((f + 2) * 8 + 3 * f + 8 + wmax * FFX_WIDE + 64) * 4 + (f + FFX_LEAF_MAX) * (48 + 16) + 192;
 }
 
 int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int n_tris, void *blob, size_t blob_bytes, ffx_bvh_info *info) {
@@ -506,6 +506,9 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   off = (off + 63) & ~(uint64_t)63;
   info->off_nrec = off; // per-slot vertex normals of the shapes of ffx_smooth (ffx.h); untouched for flat scenes
   off += ((uint64_t)n_tris + FFX_LEAF_MAX) * 48;
+  off = (off + 63) & ~(uint64_t)63;
+  info->off_gn = off; // per-slot unit geometric normals
+  off += ((uint64_t)n_tris + FFX_LEAF_MAX) * 16;
   off = (off + 63) & ~(uint64_t)63;
   off += FFX_N_APEX * ffx_apex_stride(n_tris); // apex-record areas (ffx_common.h), zero until a render call fills them
   info->total_bytes = off;

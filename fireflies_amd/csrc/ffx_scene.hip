@@ -37,7 +37,15 @@
 // per-shape tables as a kernel argument (ffx_scene_update_h): 32 * (1 + 12) dwords = 1664 B of kernarg
 struct ShapeTabH { int32_t off[FFX_MAX_SHAPES_H]; float m[FFX_MAX_SHAPES_H][12]; };
 // ffx_smooth's two host tables as kernel arguments; `vn` / `nrec` NULL: no shape interpolates its normals
-struct SmoothTab { int32_t on[FFX_MAX_SHAPES_H]; int32_t vbase[FFX_MAX_SHAPES_H]; const float *vn; float4 *nrec; };
+struct SmoothTab { int32_t on[FFX_MAX_SHAPES_H]; int32_t vbase[FFX_MAX_SHAPES_H]; const float *vn; float4 *nrec; float4 *gn; };
+// unit geometric normal of a record, IEEE cross / sqrt / divide in the order of the oracle's shade_sample (ffx_bvh_info.off_gn)
+__device__ __forceinline__ float4 unit_normal_of(v3 e1, v3 e2) {
+  v3 n = vcross(e1, e2);
+  const float nl = sqrtf(vdot(n, n));
+  if (!(nl > 0.f)) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float inl = 1.0f / nl;
+  return make_float4(n.x * inl, n.y * inl, n.z * inl, 1.0f);
+}
 
 // Vertex normals of the current pose (ffx.h ffx_smooth) [EXT Mitsuba mesh.cpp recompute_vertex_normals]: a lane per vertex
 // row walks the corners incident to it in ascending triangle order — the oracle's face-major loop adds to a vertex in the
@@ -143,6 +151,7 @@ __global__ void __launch_bounds__(UPD_BLOCK)
   o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
   o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
   o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), write_slot_normals(sm, sh, prim, k, tris));
+  if (sm.gn) sm.gn[k] = unit_normal_of(e1, e2);
 }
 
 // conservative box of a leaf's triangles.  The intersection test works on (v0, e1, e2), whose
@@ -363,6 +372,7 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
     o[0] = make_float4(p[0].x, p[0].y, p[0].z, e1.x);
     o[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
     o[2] = make_float4(e2.z, __int_as_float(prim), __int_as_float(sh), write_slot_normals(sm, sh, prim, k, tris));
+    if (sm.gn) sm.gn[k] = unit_normal_of(e1, e2);
     const float a0[3] = {p[0].x, p[0].y, p[0].z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
     WideChild c;
     tri_wide_box(a0, a1, a2, c);
@@ -415,6 +425,7 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
   // interpolated shading normals (ffx_smooth): the vertex normals of this pose first (one launch, only when a shape asks)
   SmoothTab sm;
   memset(&sm, 0, sizeof sm);
+  if (info->off_gn != 0 && info->off_gn + 16ull * (uint64_t)info->n_tris <= info->total_bytes) sm.gn = (float4 *)(base + info->off_gn);
   if (smooth) {
     if (!smooth->shape_smooth || !smooth->shape_vbase || !smooth->adj_start || !smooth->adj || !smooth->vnormals || smooth->n_vn < 1)
       FFX_FAIL(FFX_ERR_ARG, "scene_update: bad ffx_smooth");

@@ -1779,7 +1779,7 @@ template <int R, bool WIDE, int MATM = 0>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
-                                                const float4 *__restrict__ nrec, const float *__restrict__ tex_probe = nullptr) {
+                                                const float4 *__restrict__ nrec, const float4 *__restrict__ gn, const float *__restrict__ tex_probe = nullptr) {
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   Hit h[R];
   bool fnd[R];
@@ -1809,15 +1809,14 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 #endif
     if (q.ok) {
       const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
-      float4 ra = r4[0], rb = r4[1], rc = r4[2];
+      // the unit geometric normal comes from the update (ffx_bvh_info.off_gn: IEEE, the oracle's bits) — re-deriving it from the
+      // record cost 22 VALU per sample (cross, dot, sqrt, reciprocal, scale); only shape id / flag are read from the record here
+      const float4 rc = r4[2], gq = gn[h[r].slot];
       st[r].shape = __float_as_int(rc.z);
       q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
-      v3 ng = vcross(V3(ra.w, rb.x, rb.y), V3(rb.z, rb.w, rc.x));
-      float nl = sqrt_nr(vdot(ng, ng));
-      q.ok = nl > 0.f;
+      v3 ng = V3(gq.x, gq.y, gq.z);
+      q.ok = gq.w != 0.f;
       if (q.ok) {
-        const float inl = rcp_nr(nl);
-        ng = V3(ng.x * inl, ng.y * inl, ng.z * inl);
         if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
         q.ng = ng;
         float pmax = fmaxf(fabsf(q.P.x), fmaxf(fabsf(q.P.y), fabsf(q.P.z)));
@@ -1826,6 +1825,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         ns = ng;
         smooth = rc.w != 0.f;
         if (wballot(smooth) != 0ull) { // (wave-uniform: scenes without flagged records never enter)
+          const float4 ra = r4[0], rb = r4[1];
           const v3 ni = interpolated_normal<true>(nrec, smooth ? h[r].slot : 0, ra, rb, rc, o[r], d[r], ng);
           if (smooth) ns = ni;
         }
@@ -2145,7 +2145,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
-                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec) {
+                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
   constexpr int NSUB = 4 / R;
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
@@ -2210,7 +2210,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, (cache && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, (cache && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (cache) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -2365,7 +2365,7 @@ template <int R, bool WIDE, int MATM>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec) {
+                    const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
   constexpr int NSUB = 4 / R;
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
@@ -2405,7 +2405,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
@@ -2897,9 +2897,11 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   const float4 *nrec = info->off_nrec ? (const float4 *)((const char *)bvh + info->off_nrec) : nullptr; // vertex normals per slot (ffx_smooth)
+  const float4 *gn = info->off_gn ? (const float4 *)((const char *)bvh + info->off_gn) : nullptr;         // unit geometric normals per slot
   if (cache && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
+  if ((use_packet() || cache) && !gn) FFX_FAIL(FFX_ERR_ARG, "render_fwd: blob without per-slot normals (built by another library version?)");
   if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
@@ -2919,7 +2921,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 #define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
-                     arena_off, foot_b_off, nrec)
+                     arena_off, foot_b_off, nrec, gn)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD(true, 2); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_FWD(false, 2); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
@@ -3026,6 +3028,8 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   const float4 *nrec = info->off_nrec ? (const float4 *)((const char *)bvh + info->off_nrec) : nullptr;
+  const float4 *gn = info->off_gn ? (const float4 *)((const char *)bvh + info->off_gn) : nullptr;
+  if (use_packet() && !gn) FFX_FAIL(FFX_ERR_ARG, "render_bwd: blob without per-slot normals (built by another library version?)");
   if (use_packet()) {
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
@@ -3039,7 +3043,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     const WideScene ws = wide_scene(bvh, info);
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
-                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex, nrec)
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex, nrec, gn)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1);
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BWD(true, 2); else if (matm == 1) FFX_LAUNCH_BWD(true, 1); else FFX_LAUNCH_BWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_BWD(false, 2); else if (matm == 1) FFX_LAUNCH_BWD(false, 1); else FFX_LAUNCH_BWD(false, 0); }

@@ -271,6 +271,9 @@ typedef struct ffx_bvh_info {
   int32_t plan_ints;  /* int32 words of the plan area (the arrival counter is the last one) */
   uint64_t off_nrec;  /* (n_tris + 4) x 48 B: per leaf slot the three vertex normals {n0, n1, n2} as float4, written by
                          ffx_scene_update for the shapes of ffx_smooth (below), read by the render kernels at the hit */
+  uint64_t off_gn;    /* (n_tris + 4) x 16 B: per leaf slot the unit geometric normal {nx, ny, nz, 1} ({0,0,0,0} for a degenerate
+                         triangle), written by ffx_scene_update with IEEE cross / sqrt / divide in the oracle's order; the packet
+                         render kernels read it instead of re-deriving it per sample.  0 in the oracle's blob. */
 } ffx_bvh_info;
 
 /* Interpolated shading normals (optional; ffx_scene_update's `smooth`).  Mitsuba shades a mesh that carries vertex normals
