@@ -103,6 +103,8 @@ class SceneDesc(C.Structure):
         ("base_tex_h", C.c_int32 * 4),
         ("base_tex", C.c_void_p * 4),
         ("slot_uv", C.c_void_p),
+        ("n_mat_h", C.c_int32),
+        ("mat_h", c_f * 128),
     ]
 
 
@@ -112,6 +114,7 @@ MAT_MODEL, MAT_ROUGHNESS, MAT_ANISOTROPIC, MAT_METALLIC, MAT_SPEC_TRANS, MAT_ETA
 MAT_SPEC_TINT, MAT_SHEEN, MAT_SHEEN_TINT, MAT_FLATNESS, MAT_CLEARCOAT, MAT_CLEARCOAT_GLOSS = 9, 10, 11, 12, 13, 14
 MAT_BASE_TEX = 15
 MAX_BASE_TEX = 4
+MAX_MAT_H = 128
 
 
 PF = C.POINTER(c_f)

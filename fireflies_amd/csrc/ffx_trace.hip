@@ -57,7 +57,24 @@ struct ShadeK {
   int btw[FFX_MAX_BASE_TEX], bth[FFX_MAX_BASE_TEX];
   const float *btex[FFX_MAX_BASE_TEX];
   const float *slot_uv;
+  // the material table as a kernel argument (ffx_scene_desc.mat_h): the kernels then read the rows from their own kernarg segment
+  int mat_inline;
+  float mat_h[FFX_MAX_MAT_H];
 };
+// The first kernel argument, read in place.  The scene constants (ShadeK, ~100 dwords + the inline material rows) are the first
+// argument of the render kernels.  Read through the by-value copy the compiler loads them all up front and, out of SGPRs, parks
+// them in VGPR lanes (v_writelane / v_readlane: ~480 spill instructions on the VALU, the unit that bounds these kernels); through
+// this pointer — which the compiler cannot see through — each phase re-reads what it needs with scalar loads from the kernarg
+// segment (no VALU work at all), and per-lane indexed tables (the material rows) are ordinary global loads from it.
+template <typename T>
+__device__ __forceinline__ const T &kernarg_first() {
+  const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const T *)p;
+}
+__device__ __forceinline__ const ShadeK &kernarg_shade() { return kernarg_first<ShadeK>(); }
+// the material table of a launch: its own kernel arguments, or the caller's device array
+__device__ __forceinline__ const float *mat_table(const ShadeK &k) { return k.mat_inline ? k.mat_h : k.mats; }
 
 struct Hit { float t; int prim, shape, slot; };
 
@@ -529,7 +546,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
   v3 ns = ng;
   if (rc.w != 0.f && nrec) ns = interpolated_normal<false>(nrec, h.slot, ra, rb, rc, o, d, ng);
   // base colour: the shape's row, or (FFX_MAT_BASE_TEX) its texture at the hit
-  const float *row0 = c.mats + (size_t)c.mat_stride * h.shape;
+  const float *mt = mat_table(c);
+  const float *row0 = mt + (size_t)c.mat_stride * h.shape;
   st.base[0] = row0[0]; st.base[1] = row0[1]; st.base[2] = row0[2];
   bool textured = false;
   if (c.mat_stride == FFX_MAT_STRIDE && c.n_base_tex > 0) {
@@ -567,8 +585,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
           }
           if (vis) {
             float bA = cos_s, bB = 0.f; // Lambert; material rows: pi f cos = base_color * bA + bB
-            if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
-              const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
+            if (c.mat_stride == FFX_MAT_STRIDE && mt[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
+              const float *mrow = mt + (size_t)FFX_MAT_STRIDE * h.shape;
               MatGeo mg;
               material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
               if (textured) material_terms<true>(mrow, mg, bA, bB, st.base[0], st.base[1], st.base[2]);
@@ -615,8 +633,8 @@ __device__ __forceinline__ void shade_sample(const ShadeK &c, const BvhNode *__r
         }
         if (vis) {
           float bA = cos_s, bB = 0.f;
-          if (c.mat_stride == FFX_MAT_STRIDE && c.mats[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
-            const float *mrow = c.mats + (size_t)FFX_MAT_STRIDE * h.shape;
+          if (c.mat_stride == FFX_MAT_STRIDE && mt[(size_t)FFX_MAT_STRIDE * h.shape + FFX_MAT_MODEL] != 0.f) {
+            const float *mrow = mt + (size_t)FFX_MAT_STRIDE * h.shape;
             MatGeo mg;
             material_geometry(mrow, ns, V3(-d.x, -d.y, -d.z), wi, mg);
             if (textured) material_terms<true>(mrow, mg, bA, bB, st.base[0], st.base[1], st.base[2]);
@@ -681,7 +699,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
       float nt, ft;
       cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
       SampleTerms st;
-      shade_sample(c, nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+      shade_sample(kernarg_shade(), nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
       if (!st.hit) continue;
       float r0 = st.spot[0], r1 = st.spot[1], r2 = st.spot[2];
       float b0 = st.spot_b[0], b1 = st.spot_b[1], b2 = st.spot_b[2];
@@ -773,7 +791,7 @@ __global__ void __launch_bounds__(TR_BLOCK)
     float nt, ft;
     cam_ray(c.cam, ((float)px + jx) * c.cam.inv_w, ((float)py + jy) * c.cam.inv_h, o, d, nt, ft);
     SampleTerms st;
-    shade_sample(c, nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
+    shade_sample(kernarg_shade(), nodes, recs, nrec, o, d, nt, ft, st, s_dyn + threadIdx.x, TR_BLOCK);
     if (!st.hit || !st.has_proj) continue;
     const float *alb = st.base;
     size_t o00 = ((size_t)st.iy0 * c.tw + st.ix0) * tc, o01 = ((size_t)st.iy0 * c.tw + st.ix1) * tc;
@@ -1756,11 +1774,6 @@ struct ShadePre {
 // (v_writelane / v_readlane: ~480 spill instructions on the VALU, the unit that bounds these kernels).
 // kernarg_shade() hands out the same constants through a pointer the compiler cannot see through, so
 // each phase re-reads what it needs with scalar loads from the kernarg segment (no VALU work at all).
-__device__ __forceinline__ const ShadeK &kernarg_shade() {
-  const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  return *(const ShadeK *)p;
-}
 
 // whether any of the four texels of the bilinear footprint at (u, v) is non-zero (same texel arithmetic as the footprint phase)
 __device__ __forceinline__ bool tex_footprint_lit(const float *__restrict__ tex, int tw, int th, int tc, float u, float v) {
@@ -1952,7 +1965,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       const bool lit_p = q.need_p && !occ_p[r], lit_s = q.need_s && !occ_s[r];
       if constexpr (TEX) { st[r].base[0] = st[r].base[1] = st[r].base[2] = 0.f; }
       if (lit_p || lit_s) {
-        const float *mrow = c2.mats + (size_t)FFX_MAT_STRIDE * st[r].shape;
+        const float *mrow = mat_table(c2) + (size_t)FFX_MAT_STRIDE * st[r].shape;
         const bool mat_on = mrow[FFX_MAT_MODEL] != 0.f;
         const v3 wv = V3(-d[r].x, -d[r].y, -d[r].z);
         if constexpr (TEX) { // base colour of this sample: the row's, or its texture at the hit (only lit samples need one)
@@ -2305,7 +2318,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           c1 = st[r].base[1] * r1;
           c2 = st[r].base[2] * r2;
         } else {
-        const float *alb = albedo + MS * st[r].shape;
+        const float *alb = mat_table(ct) + MS * st[r].shape;
         c0 = alb[0] * r0;
         c1 = alb[1] * r1;
         c2 = alb[2] * r2;
@@ -2411,7 +2424,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!st[r].hit || !st[r].has_proj) continue;
-        const float *alb = TEX ? st[r].base : albedo + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
+        const float *alb = TEX ? st[r].base : mat_table(ct) + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
         size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
         size_t o10 = ((size_t)st[r].iy1 * ct.tw + st[r].ix0) * tc, o11 = ((size_t)st[r].iy1 * ct.tw + st[r].ix1) * tc;
         const float wx0 = st[r].wx0, wx1 = st[r].wx1, wy0 = st[r].wy0, wy1 = st[r].wy1;
@@ -2447,7 +2460,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // texels: ~0.8 M atomics per 512x512 render instead of 4 x 16.8 M sample taps).  Part 2 (the blocks past the
 // pixel slots): one lane per stray sample record, four taps each.
 struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; // ms: floats per material row (3 / FFX_MAT_STRIDE)
-              const void *img; int img_fp16; float *dot_out; int dot_slots; }; // optional: sum(dot_out[0 .. dot_slots)) += <gimg, img> (the value of a linear loss whose gradient gimg is)
+              const void *img; int img_fp16; float *dot_out; int dot_slots; // optional: sum(dot_out[0 .. dot_slots)) += <gimg, img> (the value of a linear loss whose gradient gimg is)
+              const float *mats; int mat_inline; float mat_h[FFX_MAX_MAT_H]; }; // the material table: the caller's device array or (ffx_scene_desc.mat_h) this kernel argument
+__device__ __forceinline__ const float *mat_table(const BwdP &k) { return k.mat_inline ? k.mat_h : k.mats; }
 __device__ __forceinline__ float k9_pixel_dot(const BwdP &p, long pixel, const float *__restrict__ gimg) {
   const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
   if (p.img_fp16) {
@@ -2509,10 +2524,12 @@ __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_
 // directly.  Summation order inside a block is not fixed (LDS float atomics) — like the global atomics it replaces.
 #define K9_TILE 32
 __global__ void __launch_bounds__(256)
-    k_render_bwd_cached_tiled(const char *__restrict__ cache, BwdP p, int blocks_x, int tile_blocks, const float *__restrict__ gimg,
-                              const float *__restrict__ albedo, float *__restrict__ gtex) {
+    k_render_bwd_cached_tiled(BwdP p_by_value, const char *__restrict__ cache, int blocks_x, int tile_blocks, const float *__restrict__ gimg,
+                              float *__restrict__ gtex) {
   __shared__ float s_tile[K9_TILE * K9_TILE];
   __shared__ int s_ox, s_oy, s_any;
+  const BwdP &p = kernarg_first<BwdP>(); // (read in place: the inline material rows are indexed per lane)
+  const float *albedo = mat_table(p);
   const long n_pix = (long)p.W * p.H;
   if ((int)blockIdx.x >= tile_blocks) { // the tail of the grid replays the stray records
     k9_stray(cache, n_pix, (uint32_t)((int)blockIdx.x - tile_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
@@ -2572,8 +2589,9 @@ __global__ void __launch_bounds__(256)
 }
 
 __global__ void __launch_bounds__(256)
-    k_render_bwd_cached(const char *__restrict__ cache, long n_pix, int slot_blocks, BwdP p, const float *__restrict__ gimg, const float *__restrict__ albedo,
-                        float *__restrict__ gtex) {
+    k_render_bwd_cached(BwdP p_by_value, const char *__restrict__ cache, long n_pix, int slot_blocks, const float *__restrict__ gimg, float *__restrict__ gtex) {
+  const BwdP &p = kernarg_first<BwdP>();
+  const float *albedo = mat_table(p);
   if ((int)blockIdx.x < slot_blocks) {
     const long pixel = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const int e = threadIdx.x & 31;
@@ -2635,6 +2653,11 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   c.shadows = sd->shadows;
   c.mat_stride = sd->mat_stride ? sd->mat_stride : 3;
   if (c.mat_stride != 3 && c.mat_stride != FFX_MAT_STRIDE) return 0;
+  if (sd->n_mat_h > 0) { // the material table travels with the call (ffx_scene_desc.mat_h)
+    if (sd->n_mat_h > FFX_MAX_MAT_H || sd->n_mat_h != sd->n_shapes * c.mat_stride) return 0;
+    c.mat_inline = 1;
+    for (int i = 0; i < sd->n_mat_h; ++i) c.mat_h[i] = sd->mat_h[i];
+  }
   c.n_base_tex = sd->n_base_tex;
   if (c.n_base_tex < 0 || c.n_base_tex > FFX_MAX_BASE_TEX || (c.n_base_tex > 0 && (c.mat_stride != FFX_MAT_STRIDE || !sd->slot_uv))) return 0;
   c.slot_uv = sd->slot_uv;
@@ -2885,14 +2908,14 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                            uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
-  if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
+  if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
   ShadeK c;
   if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
   c.mats = shape_albedo;
   const bool mat = c.mat_stride == FFX_MAT_STRIDE;
-  if (mat && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd: material rows must be 16-byte aligned");
+  if (mat && !c.mat_inline && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd: material rows must be 16-byte aligned");
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
@@ -2981,12 +3004,20 @@ size_t ffx_render_dot_slots(int width, int height) {
 
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
-  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!sd || (!shape_albedo && sd->n_mat_h <= 0) || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
   if (!sd->proj.enabled) {
     if (dot_out) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> is accumulated by the footprint kernel, which a scene without projector does not launch");
     return FFX_OK;
   }
   BwdP p;
+  memset(&p, 0, sizeof p);
+  p.mats = shape_albedo;
+  if (sd->n_mat_h > 0) {
+    const int ms_ = sd->mat_stride ? sd->mat_stride : 3;
+    if (sd->n_mat_h > FFX_MAX_MAT_H || sd->n_mat_h != sd->n_shapes * ms_) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: n_mat_h must be n_shapes x stride (<= %d)", FFX_MAX_MAT_H);
+    p.mat_inline = 1;
+    for (int i = 0; i < sd->n_mat_h; ++i) p.mat_h[i] = sd->mat_h[i];
+  }
   p.img = dot_out ? img : nullptr; p.img_fp16 = img_fp16 & 1; p.dot_out = dot_out;
   p.dot_slots = (int)ffx_render_dot_slots(sd->cam.width, sd->cam.height);
   p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
@@ -3002,28 +3033,27 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   if (p.tc == 1) {
     // footprints by 8x8-pixel blocks through an LDS tile; the tail of the grid replays the stray records
     const int blocks_x = ffx_cdiv(p.W, 8), blocks_y = ffx_cdiv(p.H, 8);
-    hipLaunchKernelGGL(k_render_bwd_cached_tiled, dim3(blocks_x * blocks_y + stray_blocks), dim3(256), 0, (hipStream_t)s, (const char *)cache, p, blocks_x,
-                       blocks_x * blocks_y, gimg, shape_albedo, gtex);
+    hipLaunchKernelGGL(k_render_bwd_cached_tiled, dim3(blocks_x * blocks_y + stray_blocks), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, blocks_x,
+                       blocks_x * blocks_y, gimg, gtex);
     FFX_CHECK_LAUNCH("render_bwd_cached/tiled");
     return FFX_OK;
   }
   const int slot_blocks = ffx_cdiv(n_pix, 8);
-  hipLaunchKernelGGL(k_render_bwd_cached, dim3(slot_blocks + stray_blocks), dim3(256), 0, (hipStream_t)s, (const char *)cache, n_pix, slot_blocks, p, gimg,
-                     shape_albedo, gtex);
+  hipLaunchKernelGGL(k_render_bwd_cached, dim3(slot_blocks + stray_blocks), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, n_pix, slot_blocks, gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd_cached");
   return FFX_OK;
 }
 
 int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
                    const float *gimg, float *gtex, ffx_stream s) {
-  if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+  if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if (!sd->proj.enabled) return FFX_OK;
   if (!check_info(info, "render_bwd")) return FFX_ERR_ARG;
   ShadeK c;
   if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
   c.mats = shape_albedo;
   const bool mat = c.mat_stride == FFX_MAT_STRIDE;
-  if (mat && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd: material rows must be 16-byte aligned");
+  if (mat && !c.mat_inline && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd: material rows must be 16-byte aligned");
   if ((long)c.cam.W * c.cam.H * spp >= (1L << 32)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: more than 2^32 samples");
   const BvhNode *nodes = (const BvhNode *)((const char *)bvh + info->off_nodes);
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);

@@ -168,8 +168,9 @@ class _Render(torch.autograd.Function):
         ctx.albedo = albedo
         if tex.requires_grad and sd.proj.enabled:
             # the adjoint needs the albedo as it was at the forward pass (Scene._apply overwrites the
-            # tensor in place on the next randomisation): keep a private copy (3 or 16 floats per shape)
-            ctx.albedo = albedo.clone()
+            # tensor in place on the next randomisation): keep a private copy (3 or 16 floats per shape) — unless the scene
+            # description carries the rows itself (sd.n_mat_h: a value, already a snapshot)
+            ctx.albedo = albedo.clone() if albedo is not None and sd.n_mat_h == 0 else None
             if cache_supported(sd, spp):
                 # store a texture footprint per pixel now instead of re-tracing the scene in backward
                 ctx.cache = torch.empty(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device=t.device)

@@ -317,9 +317,13 @@ class Scene:
         alb = alb if rows is None else rows
         if rows is not None and (rows[:, scenes.MAT_COLUMN["spec_trans"]] > 0).any():
             self._warn_spec_trans("scene materials")
-        self.albedo = torch.from_numpy(alb).to(self.device)
+        self._albedo_dev = torch.from_numpy(alb).to(self.device)
         self._albedo_host = alb.copy()
         self._albedo_ring = None
+        self._albedo_stale = False  # the device copy lags behind _albedo_host (refreshed when somebody asks for it)
+        # up to 8 material rows (42 albedos) travel inside the scene description as kernel arguments: a randomisation of the
+        # material then costs no host-to-device copy at all (it was the one copyBuffer launch of every step)
+        self._mats_in_sd = alb.size <= 128 and os.environ.get("FFX_HOST_MATERIALS", "1") != "0"
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
         # leaf slot's three corners (static: the slot order is the tree's)
         self._base_tex = [(name, torch.from_numpy(t).to(self.device).contiguous()) for name, t in scenes.base_textures(data)]
@@ -470,10 +474,29 @@ class Scene:
         if geom_dirty:
             self.geom.update(self._xforms, self._offs)
         if albedo_dirty:
-            if self._albedo_ring is None:
-                self._albedo_ring = _PinnedRing(tuple(self._albedo_host.shape))
-            self._albedo_ring.upload(self._albedo_host, self.albedo)
+            if self._mats_in_sd:
+                self._albedo_stale = True  # the next scene_desc() carries the new rows; the device tensor is refreshed on demand
+            else:
+                self._upload_albedo()
         self._sd_cache = None
+
+    def _upload_albedo(self):
+        if self._albedo_ring is None:
+            self._albedo_ring = _PinnedRing(tuple(self._albedo_host.shape))
+        self._albedo_ring.upload(self._albedo_host, self._albedo_dev)
+        self._albedo_stale = False
+
+    @property
+    def albedo(self):
+        """the material table on the device ([S,3] albedos or [S,16] material rows).  With the rows inside the scene description
+        (the default for small tables) the render calls do not read it; it is brought up to date whenever it is asked for."""
+        if self._albedo_stale:
+            self._upload_albedo()
+        return self._albedo_dev
+
+    def materials_arg(self, sd):
+        """what to pass as the render calls' material table for `sd`: None when sd carries the rows itself"""
+        return None if sd.n_mat_h > 0 else self.albedo
 
     def _warn_spec_trans(self, what):
         """once per scene: the transmission lobe of `spec_trans` is not evaluated (main.py:105 randomises it 0 .. 0.4)"""
@@ -512,7 +535,8 @@ class Scene:
         tmp = scenes.SceneData(d.meshes, sensor, proj, spot, float(p["Projector.scale"]) if proj is not None else 1.0)
         btex = [(t.data_ptr(), t.shape[1], t.shape[0]) for _, t in self._base_tex] or None
         sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride, base_tex=btex,
-                                   slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None)
+                                   slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None,
+                                   host_mats=self._albedo_host if self._mats_in_sd else None)
         self._sd_cache = (tex_channels, sd)
         return sd
 
@@ -561,8 +585,8 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
     elif tex.dtype != torch.float32:
         tex = tex.float()
     if tex.requires_grad and torch.is_grad_enabled():
-        img = Fn.render(tex, scene.geom, sd, scene.albedo, spp, seed, fp16)
+        img = Fn.render(tex, scene.geom, sd, scene.materials_arg(sd), spp, seed, fp16)
     else:  # nothing to differentiate: straight to the kernel (autograd.Function.apply costs ~80 us of host time per call)
         t = tex if tex.is_contiguous() else tex.contiguous()
-        img = scene.geom.render_fwd(sd, scene.albedo, t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
+        img = scene.geom.render_fwd(sd, scene.materials_arg(sd), t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
     return TensorXf(img)

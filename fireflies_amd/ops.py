@@ -257,9 +257,15 @@ def render_cache_status(cache):
 
 
 def _check_materials(sd, albedo):
+    """-> the pointer argument for shape_albedo: None when the scene description carries the rows itself (sd.n_mat_h)"""
+    if sd.n_mat_h > 0:
+        return None
+    if albedo is None:
+        raise ValueError("no material table: pass the device tensor or put the rows into the scene description (scene_desc.set_host_materials)")
     ms = int(sd.mat_stride) or 3
     if albedo.dim() != 2 or albedo.shape[1] != ms or albedo.shape[0] < sd.n_shapes:
         raise ValueError(f"material table {tuple(albedo.shape)} does not match the scene description (n_shapes {sd.n_shapes}, mat_stride {ms})")
+    return _dev(albedo, name="albedo")
 
 
 # ------------------------------------------------------------------ K5..K9
@@ -525,14 +531,14 @@ class DeviceGeometry:
         sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
         not zero (a pattern optimiser's case), dark footprints are skipped."""
         H, W = sd.cam.height, sd.cam.width
-        _check_materials(sd, albedo)
+        mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         if cache is not None:
             if cache.numel() < render_cache_bytes_sd(sd, spp):
                 raise ValueError("cache tensor too small")
             with self._timed("render_fwd"):
                 self._call(
-                    "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
+                    "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
                     _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(bool(fp16)) | (2 if sparse_adjoint else 0),
                     _dev(img, img.dtype), _dev(cache, torch.uint8, "cache"), _stream(self._didx),
                 )
@@ -540,7 +546,7 @@ class DeviceGeometry:
             return img
         with self._timed("render_fwd"):
           self._call(
-            "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"),
+            "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
             _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(self._didx),
           )
         self._release()
@@ -552,23 +558,23 @@ class DeviceGeometry:
         `img` + `dot_out` (render_dot_slots(W, H) float32 partial sums, one per 8x8-pixel block): the same launch adds
         <gimg, img> to them — their sum is the value of a loss that is linear in the image, whose gradient gimg is."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
-        _check_materials(sd, albedo)
+        mats_arg = _check_materials(sd, albedo)
         if (img is None) != (dot_out is None):
             raise ValueError("img and dot_out go together")
         if img is not None and (tuple(img.shape) != tuple(gimg.shape) or dot_out.dtype != torch.float32 or dot_out.numel() != render_dot_slots(sd.cam.width, sd.cam.height)):
             raise ValueError("img must have gimg's shape and dot_out must be render_dot_slots(W, H) float32 partial sums (the caller zeroes and sums them)")
         with self._timed("render_bwd_cached"):
-            self._call("ffx_render_bwd_cached", C.byref(sd), _dev(albedo, name="albedo"), _dev(cache, torch.uint8, "cache"), int(spp),
+            self._call("ffx_render_bwd_cached", C.byref(sd), mats_arg, _dev(cache, torch.uint8, "cache"), int(spp),
                        _dev(gimg, name="gimg"), _dev(gtex), _dev(img, img.dtype, "img") if img is not None else None,
                        int(img is not None and img.dtype == torch.float16), _dev(dot_out) if dot_out is not None else None, _stream(self._didx))
         return gtex
 
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
-        _check_materials(sd, albedo)
+        mats_arg = _check_materials(sd, albedo)
         with self._timed("render_bwd"):
             self._call(
-                "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), _dev(albedo, name="albedo"), int(spp),
+                "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp),
                 int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx),
             )
         self._release()

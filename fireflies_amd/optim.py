@@ -102,7 +102,7 @@ class PatternOptimizer:
         self.ff_scene.randomize()
         leaf = tex_value.detach().clone().requires_grad_(True)
         sd = self.mi_scene.scene_desc(tex_channels=1)
-        img = Fn.render(leaf, self.mi_scene.geom, sd, self.mi_scene.albedo, self.spp, seed)
+        img = Fn.render(leaf, self.mi_scene.geom, sd, self.mi_scene.materials_arg(sd), self.spp, seed)
         loss = self.loss_fn(img)
         (g,) = torch.autograd.grad(loss, leaf)
         return g, loss.detach()
@@ -196,10 +196,11 @@ class PatternOptimizer:
                 self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
-            img = geom.render_fwd(sd, ms.albedo, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
+            mats = ms.materials_arg(sd)  # (None: the rows are part of sd — no upload, no device tensor)
+            img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
             if linear is not None and use_cache:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
-                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)
+                geom.render_bwd_cached(sd, mats, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)
                 continue
             if fast_loss is not None:
                 gimg = fast_loss(img, loss_sum)
@@ -209,9 +210,9 @@ class PatternOptimizer:
                 loss_sum += l
                 gimg = gimg.float().contiguous()
             if use_cache:
-                geom.render_bwd_cached(sd, ms.albedo, self._cache, self.spp, gimg, out=gtex)
+                geom.render_bwd_cached(sd, mats, self._cache, self.spp, gimg, out=gtex)
             else:
-                gtex += geom.render_bwd(sd, ms.albedo, self.spp, seed, gimg).reshape(gtex.shape)
+                gtex += geom.render_bwd(sd, mats, self.spp, seed, gimg).reshape(gtex.shape)
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
         gts = None
         if seeds:

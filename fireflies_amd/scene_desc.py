@@ -26,7 +26,7 @@ def camera_from_sensor(s, to_world=None):
 
 
 def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shadows=True, cam_to_world=None, proj_to_world=None,
-               spot_to_world=None, spot_intensity=None, mat_stride=0, base_tex=None, slot_uv=None):
+               spot_to_world=None, spot_intensity=None, mat_stride=0, base_tex=None, slot_uv=None, host_mats=None):
     """ffx_scene_desc for a scenes.SceneData.  `color` is the RGB weight of a 1-channel projector
     texture (the reference packs the laser texture into the green channel,
     examples/vocalfold_scene.py:64-67)."""
@@ -35,6 +35,8 @@ def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shad
     sd.shadows = int(bool(shadows))
     sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
     sd.mat_stride = int(mat_stride)  # 0 / 3: the material table is [S,3] Lambert albedos; 16: material rows (scenes.material_rows)
+    if host_mats is not None:  # the material table travels with the call (kernel arguments): [n_shapes, 3 | 16] host array
+        set_host_materials(sd, host_mats)
     if base_tex:  # texture-valued base colours: [(address, width, height)] + the address of the per-slot texture coordinates
         if len(base_tex) > _abi.MAX_BASE_TEX or slot_uv is None:
             raise ValueError("at most 4 base-colour textures, and they need slot_uv")
@@ -58,3 +60,18 @@ def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shad
         sd.spot.cutoff_deg, sd.spot.beam_width_deg = float(s.cutoff_angle), float(s.beam_width)
         sd.spot.enabled = 1
     return sd
+
+
+def set_host_materials(sd, rows):
+    """ffx_scene_desc.mat_h: the rows [n_shapes, stride] (host array) become part of the scene description — the render calls then
+    take no material pointer and a randomisation enqueues no upload.  False (nothing set) if the table is too large."""
+    a = np.ascontiguousarray(rows, np.float32)
+    stride = int(sd.mat_stride) or 3
+    if a.ndim != 2 or a.shape[1] != stride or a.shape[0] < sd.n_shapes:
+        raise ValueError(f"host material table {a.shape} does not match the scene description (n_shapes {sd.n_shapes}, stride {stride})")
+    n = int(sd.n_shapes) * stride
+    if n > _abi.MAX_MAT_H:
+        return False
+    C.memmove(sd.mat_h, a.ctypes.data, 4 * n)
+    sd.n_mat_h = n
+    return True

@@ -397,7 +397,15 @@ typedef struct ffx_scene_desc {
   int32_t base_tex_w[FFX_MAX_BASE_TEX], base_tex_h[FFX_MAX_BASE_TEX];
   const float *base_tex[FFX_MAX_BASE_TEX]; /* [dev][h, w, 3] */
   const float *slot_uv;                    /* [dev][n_tris + 4, 6] (u0 v0 u1 v1 u2 v2 per leaf slot: ffx_bvh_info.off_order gives slot -> triangle) */
+  /* The material table as part of the call (round 3): with n_mat_h > 0, mat_h holds the n_shapes rows (n_mat_h = n_shapes x
+   * stride floats <= FFX_MAX_MAT_H: 8 material rows or 42 albedos) and travels to the kernels as a KERNEL ARGUMENT; the
+   * shape_albedo pointer of the render calls is then ignored (may be NULL).  The reference writes the randomised material
+   * parameters one by one into Mitsuba's parameter map (fireflies/scene.py:324-342) and Mitsuba uploads them in update(); here
+   * a randomisation then enqueues no host-to-device copy at all — like the per-shape transforms of ffx_scene_update_h. */
+  int32_t n_mat_h;
+  float mat_h[128];
 } ffx_scene_desc;
+#define FFX_MAX_MAT_H 128
 
 /* Material rows (mat_stride == FFX_MAT_STRIDE): shape_albedo is then [n_shapes, 16] floats.  Model 1 is the reflection
  * side of Mitsuba 3.5's `principled` BSDF [EXT: src/bsdfs/principled.cpp eval(), principledhelpers.h,

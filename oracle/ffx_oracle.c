@@ -1073,6 +1073,7 @@ static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
     c->cos_beam = cosf(beam);
     c->inv_trans = 1.0f / (c->cutoff - beam);
   }
+  if (sd->n_mat_h > 0 && (sd->n_mat_h > FFX_MAX_MAT_H || sd->n_mat_h != sd->n_shapes * (sd->mat_stride ? sd->mat_stride : 3))) return 0;
   c->n_base_tex = sd->n_base_tex;
   if (c->n_base_tex < 0 || c->n_base_tex > FFX_MAX_BASE_TEX) return 0;
   c->slot_uv = sd->slot_uv;
@@ -1418,6 +1419,7 @@ typedef struct { uint32_t w0; float ax, ay, fac, fac_b; uint32_t pad; } crec; /*
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                            uint32_t seed, int img_fp16, void *img, crec *cache) {
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h; /* the material table travels with the call */
   if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   shade_ctx c;
@@ -1523,6 +1525,7 @@ size_t ffx_render_dot_slots(int width, int height) {
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
   (void)s;
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
   if (!sd->proj.enabled) {
     if (dot_out) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> needs a projector (as in libffx_hip)");
@@ -1568,6 +1571,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
 int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
                    const float *gimg, float *gtex, ffx_stream s) {
   (void)s;
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if (!sd->proj.enabled) return FFX_OK;
   shade_ctx c;

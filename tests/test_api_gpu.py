@@ -374,6 +374,39 @@ def test_principled_parameters_reach_the_render(oracle):
         wd.ff_scene.randomize()  # reported once per scene
 
 
+def test_randomised_materials_travel_without_an_upload(oracle):
+    """mi.Scene keeps small material tables inside the scene description (kernel arguments): after a randomisation the render sees
+    the new values although nothing was copied to the device; `scene.albedo` (the device tensor other callers may hold) is
+    refreshed when asked for; FFX_HOST_MATERIALS=0 restores the upload and gives the same image."""
+    import os
+
+    imgs = {}
+    for flag in ("1", "0"):
+        os.environ["FFX_HOST_MATERIALS"] = flag
+        try:
+            wl = _small()
+        finally:
+            os.environ.pop("FFX_HOST_MATERIALS")
+        assert wl.mi_scene._mats_in_sd == (flag == "1")
+        tex = workloads.build_texture(wl).detach()
+        wl.params["tex.data"] = tex
+        torch.manual_seed(8)
+        random.seed(8)
+        wl.ff_scene.randomize()
+        sd = wl.mi_scene.scene_desc(tex_channels=1)
+        assert (sd.n_mat_h > 0) == (flag == "1")
+        if flag == "1":
+            assert wl.mi_scene._albedo_stale and wl.mi_scene.materials_arg(sd) is None
+            np.testing.assert_array_equal(np.ctypeslib.as_array(sd.mat_h)[: sd.n_mat_h].reshape(wl.mi_scene._albedo_host.shape), wl.mi_scene._albedo_host)
+        imgs[flag] = mi.render(wl.mi_scene, spp=8, seed=8).torch()
+        go = _oracle_pose(oracle, wl)
+        ref = go.render_fwd(sd, wl.mi_scene._albedo_host, tex.cpu().numpy(), 8, seed=8)
+        assert_image_close(imgs[flag].cpu().numpy(), ref, 8, frac=1e-3, rel=2e-4, what=f"FFX_HOST_MATERIALS={flag}")
+        np.testing.assert_array_equal(wl.mi_scene.albedo.cpu().numpy(), wl.mi_scene._albedo_host)  # brought up to date on access
+        assert not wl.mi_scene._albedo_stale
+    assert torch.equal(imgs["0"], imgs["1"])
+
+
 def test_generic_vertex_assignment_path(oracle):
     """Mitsuba-style use: assign transformed vertices to `<mesh>.vertex_positions` and update()."""
     wl = _small(randomize=False)

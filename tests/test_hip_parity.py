@@ -1101,6 +1101,52 @@ def test_textured_base_colour_matches_the_oracle(oracle, env, monkeypatch):
             gd.render_fwd(sd_d, dev(mats), tex, 9, seed=6, cache=cache)
 
 
+@pytest.mark.parametrize("env", [{}, {"FFX_TRAVERSAL": "lane"}])
+def test_material_table_inside_the_scene_description(oracle, env, monkeypatch):
+    """ffx_scene_desc.mat_h (round 3): up to 128 floats of material table travel as a KERNEL ARGUMENT — the render calls take no
+    material pointer, a randomisation enqueues no upload.  Same bits as the device table for [S,3] albedos and [S,16] rows,
+    forward, cache-writing forward, cached and re-tracing adjoint; the oracle honours the field too; a table that does not fit
+    or does not match n_shapes x stride is refused."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    for k in ("FFX_TRAVERSAL",):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 9))
+    tex = _tex(sc, 1)
+    gimg = dev(np.random.default_rng(5).standard_normal((44, 52, 3)).astype(np.float32))
+    for rows, stride in ((alb, 0), (material_rows(2, 31), 16)):
+        sd_dev = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=stride)
+        sd_host = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=stride, host_mats=rows)
+        assert sd_dev.n_mat_h == 0 and sd_host.n_mat_h == rows.size
+        a = gd.render_fwd(sd_dev, dev(rows), tex, 9, seed=4)
+        b = gd.render_fwd(sd_host, None, tex, 9, seed=4)
+        assert torch.equal(a, b)
+        assert torch.equal(b, gd.render_fwd(sd_host, dev(np.zeros_like(rows)), tex, 9, seed=4))  # a pointer that is passed anyway is ignored
+        np.testing.assert_array_equal(go.render_fwd(sd_host, np.zeros_like(rows), host(tex), 9, seed=4), go.render_fwd(sd_dev, rows, host(tex), 9, seed=4))
+        ga = gd.render_bwd(sd_dev, dev(rows), 9, 4, gimg)
+        gb = gd.render_bwd(sd_host, None, 9, 4, gimg)
+        gs = float(ga.abs().max())
+        assert float((ga - gb).abs().max()) <= 1e-3 * gs  # (float atomics: order only)
+        cache = torch.zeros(ops.render_cache_bytes_sd(sd_host, 9), dtype=torch.uint8, device="cuda")
+        assert torch.equal(gd.render_fwd(sd_host, None, tex, 9, seed=4, cache=cache), gd.render_fwd(sd_dev, dev(rows), tex, 9, seed=4, cache=torch.zeros_like(cache)))
+        gc = gd.render_bwd_cached(sd_host, None, cache, 9, gimg)
+        assert float((gc - ga).abs().max()) <= 2e-3 * gs
+    with pytest.raises(ValueError):  # no table at all
+        gd.render_fwd(scene_desc.scene_desc(sc, tex_channels=1), None, tex, 4)
+    with pytest.raises(ValueError):  # rows of the wrong stride
+        scene_desc.scene_desc(sc, tex_channels=1, mat_stride=16, host_mats=alb)
+    bad = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, host_mats=alb)
+    bad.n_mat_h = 5  # not n_shapes x stride: refused by the library
+    with pytest.raises(Exception, match="scene description"):
+        gd.render_fwd(bad, None, tex, 4)
+    many = scene_desc.scene_desc(sc, tex_channels=1)
+    many.n_shapes = 50
+    assert scene_desc.set_host_materials(many, np.zeros((50, 3), np.float32)) is False and many.n_mat_h == 0  # 150 floats: stays a device table
+
+
 def test_principled_materials_mid_size_and_abi_errors(oracle):
     """material rows at 256x256x64 spp on the full-detail vocal fold (one pixel per wave, the production launch shape) against
     the oracle, with the reference's vocal-fold randomisation (specular 0 .. 0.75, roughness 0.5); and the C ABI's refusals:

@@ -32,7 +32,8 @@ wl = workloads.vocalfold()
 print("principled         %.4f ms" % k8(wl))
 wl = workloads.vocalfold(randomize=False)
 wl.mi_scene._albedo_host[:, 3] = 0.0
-wl.mi_scene.albedo.copy_(torch.from_numpy(wl.mi_scene._albedo_host))
+wl.mi_scene._albedo_stale = True  # (the device table / the scene description pick the edited host rows up)
+wl.mi_scene._sd_cache = None
 print("rows, all Lambert  %.4f ms" % k8(wl))
 wl = workloads.vocalfold(randomize=False)
 print("principled, fixed  %.4f ms" % k8(wl))
