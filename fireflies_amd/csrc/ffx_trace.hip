@@ -1796,7 +1796,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   Hit h[R];
   bool fnd[R];
+  FFX_TSTART(tp);
   traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
+  FFX_TSTOP(tp, 22);
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
   bool any_p = false, any_s = false;
@@ -1936,6 +1938,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
   bool occ_p[R], occ_s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) occ_p[r] = occ_s[r] = false;
+  FFX_TSTOP(tp, 18);
   if (c.shadows && wballot(any_p) != 0ull) {
     const v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
     v3 so[R], sdir[R];
@@ -1946,6 +1949,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     for (int r = 0; r < R; ++r) { so[r] = ppos; sdir[r] = vsub(pre[r].Po, ppos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_p; }
     traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride), ws, stack, so, sdir, s0, s1, act, hs, occ_p);
   }
+  FFX_TSTOP(tp, 19);
   if (c.shadows && wballot(any_s) != 0ull) {
     const v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
     v3 so[R], sdir[R];
@@ -1956,6 +1960,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     for (int r = 0; r < R; ++r) { so[r] = spos; sdir[r] = vsub(pre[r].Po, spos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_s; }
     traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride), ws, stack, so, sdir, s0, s1, act, hs, occ_s);
   }
+  FFX_TSTOP(tp, 20);
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -2034,6 +2039,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       }
     }
   }
+  FFX_TSTOP(tp, 21);
 }
 
 // Packet kernels.  A wavefront owns one 2x2-pixel tile (65,536 work items at 512x512): tile costs vary
@@ -2167,6 +2173,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
   static_assert(R == 1, "the adjoint cache is written one pixel at a time");
   FFX_TINIT();
+  FFX_TSTART(twave);
+  FFX_TSTART(tpro);
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
   // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
@@ -2181,6 +2189,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int passes = (spp + 63) >> 6;
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
+  FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
     packet_pixels<R>(tile, tiles_x, sub, px, py);
@@ -2353,6 +2362,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           }
         }
       }
+      FFX_TSTOP(tk, 23);
     }
     if (cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
       __builtin_amdgcn_wave_barrier();
@@ -2371,6 +2381,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       }
     }
   }
+  FFX_TSTOP(twave, 24);
   FFX_TFLUSH();
 }
 

@@ -13,6 +13,7 @@ Everything numeric lives on the HIP device: `params.update()` runs K5+K6 (ffx_sc
 `mi.render` runs K8 (and K9 under autograd when `tex.data` requires grad).
 """
 import math
+import os
 
 import numpy as np
 import torch
