@@ -2164,7 +2164,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
-                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
+                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec, const float4 *__restrict__ gn, uint32_t cap_stray) {
   constexpr int NSUB = 4 / R;
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
@@ -2189,6 +2189,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int passes = (spp + 63) >> 6;
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
+  if (cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
   FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
@@ -2269,7 +2270,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&hdr->n_stray, n);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t cap = hdr->cap_stray;
+            const uint32_t cap = cap_stray; // (a kernel argument: the header may have been cleared as a whole by the caller, FFX_RENDER_CACHE_ZEROED)
             if (base + n <= cap) {
               if (lit && !in_win) {
                 CacheStray *rec = reinterpret_cast<CacheStray *>(cache + ((size_t)cache_arena_off << 7)) + base + mbcnt64(straym);
@@ -2785,8 +2786,13 @@ static size_t dummy_lds() {
 }
 
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
+__global__ void k_cache_reset(uint32_t *__restrict__ cache_hdr, uint32_t cap_stray) {
+  cache_hdr[0] = 0u; cache_hdr[1] = cap_stray; cache_hdr[2] = 0u;
+}
+// flags: FFX_RENDER_APEX_READY — the areas already hold this call's apexes (ffx_apex_prepare, or an earlier call with the same
+// origins on records that have not changed since): no launch; FFX_RENDER_CACHE_ZEROED — the caller has cleared the cache header.
 static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *cam_to_world, const ffx_scene_desc *sd, const TriApex **arecs,
-                       uint32_t *astride, hipStream_t s, void *cache = nullptr, uint32_t cap_stray = 0) {
+                       uint32_t *astride, hipStream_t s, void *cache = nullptr, uint32_t cap_stray = 0, int flags = 0) {
   ApexK ak;
   memset(&ak, 0, sizeof ak);
   ak.on[0] = 1;
@@ -2806,7 +2812,11 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   }
   TriApex *out = (TriApex *)((char *)bvh + ffx_apex_offset(info, 0));
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
-  hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
+  if (flags & FFX_RENDER_CACHE_ZEROED) cache = nullptr;
+  if (!(flags & FFX_RENDER_APEX_READY))
+    hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
+  else if (cache)
+    hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);
   *arecs = out;
   *astride = (uint32_t)stride;
   return 1;
@@ -2918,7 +2928,8 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
 }
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
-                           uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
+                           uint32_t seed, int call_flags, void *img, void *cache, ffx_stream s) {
+  const int img_fp16 = call_flags & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT); // what the kernels see; the other bits steer the pre-pass
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
@@ -2946,8 +2957,8 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
-    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u))
-      return FFX_ERR_ARG;
+    const uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u;
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cap_stray, call_flags)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
     // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
     const uint32_t foot_off = (uint32_t)(cache_off_foot((size_t)c.cam.W * c.cam.H) >> 7), arena_off = (uint32_t)(cache_off_arena((size_t)c.cam.W * c.cam.H) >> 7);
@@ -2955,7 +2966,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 #define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
-                     arena_off, foot_b_off, nrec, gn)
+                     arena_off, foot_b_off, nrec, gn, cap_stray)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD(true, 2); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_FWD(false, 2); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
@@ -2974,7 +2985,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 
 int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                    uint32_t seed, int img_fp16, void *img, ffx_stream s) {
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, nullptr, s);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_APEX_READY), img, nullptr, s);
 }
 
 size_t ffx_render_cache_bytes(int width, int height, int spp) {
@@ -2993,7 +3004,7 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
   if (((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache must be 16-byte aligned");
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 3, img, cache, s);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 15, img, cache, s);
 }
 
 int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
@@ -3002,6 +3013,16 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
   if (hipMemcpyAsync(&h, cache, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess || hipStreamSynchronize((hipStream_t)s) != hipSuccess)
     FFX_FAIL(FFX_ERR_LAUNCH, "render_cache_status: reading the cache header failed");
   out3[0] = h.n_stray; out3[1] = h.cap_stray; out3[2] = h.dropped;
+  return FFX_OK;
+}
+
+int ffx_apex_prepare(void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, ffx_stream s) {
+  if (!bvh || !info || !sd) FFX_FAIL(FFX_ERR_ARG, "apex_prepare: bad argument");
+  if (!check_info(info, "apex_prepare")) return FFX_ERR_ARG;
+  const TriApex *arecs;
+  uint32_t astride;
+  if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+  FFX_CHECK_LAUNCH("apex_prepare");
   return FFX_OK;
 }
 

@@ -325,6 +325,7 @@ class Scene:
         # up to 8 material rows (42 albedos) travel inside the scene description as kernel arguments: a randomisation of the
         # material then costs no host-to-device copy at all (it was the one copyBuffer launch of every step)
         self._mats_in_sd = alb.size <= 128 and os.environ.get("FFX_HOST_MATERIALS", "1") != "0"
+        self._apex_ahead = os.environ.get("FFX_APEX_AHEAD", "1") != "0"  # apex records written with the re-fit instead of in front of the render
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
         # leaf slot's three corners (static: the slot order is the tree's)
         self._base_tex = [(name, torch.from_numpy(t).to(self.device).contiguous()) for name, t in scenes.base_textures(data)]
@@ -472,14 +473,18 @@ class Scene:
                 for i in self._material_meshes[base]:
                     self._albedo_host[i, :3] = c
                 albedo_dirty = True
-        if geom_dirty:
-            self.geom.update(self._xforms, self._offs)
         if albedo_dirty:
             if self._mats_in_sd:
                 self._albedo_stale = True  # the next scene_desc() carries the new rows; the device tensor is refreshed on demand
             else:
                 self._upload_albedo()
+        ch = self._sd_cache[0] if self._sd_cache is not None else 3
         self._sd_cache = None
+        if geom_dirty:
+            # the renders of this pose will come from the camera / emitter positions the parameters hold NOW (every assignment of
+            # the update has been applied above): their apex records are written behind the re-fit, on its side stream, and the
+            # render launches without a pre-pass (ops.DeviceGeometry.update; the description is built here instead of in render())
+            self.geom.update(self._xforms, self._offs, apex_sd=self.scene_desc(tex_channels=ch) if self._apex_ahead else None)
 
     def _upload_albedo(self):
         if self._albedo_ring is None:

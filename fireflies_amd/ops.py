@@ -298,6 +298,23 @@ class _EventPair:
         return False
 
 
+def apex_key(sd=None, cam=None):
+    """what the blob's apex areas must hold for a packet render / trace call (include/ffx.h ffx_apex_prepare): the positions of the
+    camera and of the enabled emitters, as the exact floats the library reads"""
+    c = sd.cam if sd is not None else cam
+    key = [c.to_world[3], c.to_world[7], c.to_world[11]]
+    if sd is not None:
+        key += [sd.proj.to_world[3], sd.proj.to_world[7], sd.proj.to_world[11]] if sd.proj.enabled else [None]
+        key += [sd.spot.to_world[3], sd.spot.to_world[7], sd.spot.to_world[11]] if sd.spot.enabled else [None]
+    else:
+        key += [None, None]
+    return tuple(key)
+
+
+def _lane_kernels():
+    return os.environ.get("FFX_TRAVERSAL") == "lane"  # (the per-lane A/B kernels neither read nor write apex records)
+
+
 class DeviceGeometry:
     """Triangle soup + BVH blob resident in HBM.
 
@@ -360,6 +377,7 @@ class DeviceGeometry:
         self._cur = 0
         self._side = torch.cuda.Stream(self.device) if self._async else None
         self._upd_done = [None, None]   # event: the refit of blob i has been enqueued up to here (side stream)
+        self._apex = [None, None]       # apex_key of what blob i's apex areas hold (None: nothing usable)
         self._last_use = [None, None]   # event: the last reader of blob i (caller's stream)
         self.src_verts = torch.from_numpy(src).to(self.device)
         self.tris = torch.from_numpy(tr).to(self.device)
@@ -434,8 +452,10 @@ class DeviceGeometry:
         if (vo < 0).any() or ((vo.astype(np.int64) + self._max_local) >= self._pool_size).any():
             raise ValueError("vert_off + triangle index exceeds the vertex pool")
 
-    def update(self, xforms, vert_off=None):
+    def update(self, xforms, vert_off=None, apex_sd=None):
         """K5+K6.  xforms [S,4,4]; optional new frame offsets [S] (host ints).
+        apex_sd: the scene description the next renders will use — its apex records are written right behind the re-fit (on the
+        side stream, off the renders' critical path) and those renders are told FFX_RENDER_APEX_READY.
         Host xforms (CPU tensor / ndarray) with S <= 32 go through ffx_scene_update_h: the tables
         are kernel arguments, nothing is copied to the device and the call never blocks.  A device
         tensor of xforms uses ffx_scene_update (device-resident randomisers)."""
@@ -450,6 +470,7 @@ class DeviceGeometry:
         self.version += 1
         if not self._async:
             self._update_into(self._blobs[0], xforms, on_device)
+            self._prepare_apex(0, apex_sd)
             return
         nxt = 1 - self._cur
         main = _stream_obj(self._didx)
@@ -462,11 +483,28 @@ class DeviceGeometry:
             xforms.record_stream(self._side)
         with torch.cuda.stream(self._side):
             self._update_into(self._blobs[nxt], xforms, on_device)
+            self._prepare_apex(nxt, apex_sd)
             ev = self._upd_done[nxt]
             if ev is None:
                 ev = self._upd_done[nxt] = torch.cuda.Event()
             ev.record(self._side)
         self._cur = nxt
+
+    def _prepare_apex(self, i, sd):
+        """(on the stream the re-fit of blob i was enqueued on) the records changed: what the apex areas held is void"""
+        self._apex[i] = None
+        if sd is not None and not _lane_kernels():
+            self._call("ffx_apex_prepare", _dev(self._blobs[i], torch.uint8, "blob"), C.byref(self.info), C.byref(sd), _stream(self._didx))
+            self._apex[i] = apex_key(sd)
+
+    def _apex_flag(self, key):
+        """FFX_RENDER_APEX_READY if the current blob's apex areas hold `key`; they will after the call either way"""
+        i = self._cur if self._async else 0
+        if _lane_kernels():
+            return 0
+        ready = self._apex[i] == key
+        self._apex[i] = key
+        return _abi.RENDER_APEX_READY if ready else 0
 
     def _update_into(self, blob, xforms, on_device):
         with self._timed("scene_update"):
@@ -503,6 +541,8 @@ class DeviceGeometry:
         t = torch.empty(n, dtype=torch.float32, device=self.device)
         shape = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
+        if not _lane_kernels():
+            self._apex[self._cur if self._async else 0] = None  # (it rewrites the camera's area; the emitters' areas keep what they had: claim nothing)
         self._call(
             "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
             _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self._didx),
@@ -525,29 +565,33 @@ class DeviceGeometry:
     def _timed(self, name):
         return _EventPair(self.timing, name)
 
-    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False):
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False, cache_zeroed=False):
         """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
         footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h).
         sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
-        not zero (a pattern optimiser's case), dark footprints are skipped."""
+        not zero (a pattern optimiser's case), dark footprints are skipped.  cache_zeroed: FFX_RENDER_CACHE_ZEROED — the caller has
+        cleared the first 64 bytes of `cache` on this stream."""
         H, W = sd.cam.height, sd.cam.width
         mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        blob = self.blob  # (acquire first: the flag below speaks about the blob this call reads)
+        flags = int(bool(fp16)) | self._apex_flag(apex_key(sd))
         if cache is not None:
             if cache.numel() < render_cache_bytes_sd(sd, spp):
                 raise ValueError("cache tensor too small")
+            flags |= (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | (_abi.RENDER_CACHE_ZEROED if cache_zeroed else 0)
             with self._timed("render_fwd"):
                 self._call(
-                    "ffx_render_fwd_cache", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
-                    _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(bool(fp16)) | (2 if sparse_adjoint else 0),
+                    "ffx_render_fwd_cache", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
+                    _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags,
                     _dev(img, img.dtype), _dev(cache, torch.uint8, "cache"), _stream(self._didx),
                 )
             self._release()
             return img
         with self._timed("render_fwd"):
           self._call(
-            "ffx_render_fwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
-            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, int(fp16), _dev(img, img.dtype), _stream(self._didx),
+            "ffx_render_fwd", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
+            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _stream(self._didx),
           )
         self._release()
         return img
@@ -572,9 +616,11 @@ class DeviceGeometry:
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         mats_arg = _check_materials(sd, albedo)
+        blob = self.blob
+        self._apex_flag(apex_key(sd))  # (the call has no flags argument: it always writes its own apex records — which the areas then hold)
         with self._timed("render_bwd"):
             self._call(
-                "ffx_render_bwd", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp),
+                "ffx_render_bwd", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp),
                 int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx),
             )
         self._release()

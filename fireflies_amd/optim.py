@@ -158,15 +158,25 @@ class PatternOptimizer:
             buf = None
         # the step's accumulator: the texture gradient, then the data term's partial sums (one slot per 8x8-pixel block of the film:
         # K9 adds <gimg, img> of its block to its own slot, other losses add to slot 0) — cleared by the pattern launch, summed by pattern_bwd
+        # The adjoint cache sits right behind them in ONE allocation, so that the same launch also clears the cache's 64-byte header
+        # (FFX_RENDER_CACHE_ZEROED: the step's first render then has nothing to reset — with the apex records written behind the
+        # re-fit, ops.DeviceGeometry.update, it launches no pre-pass at all).
         cam = ms.data.camera
         n_slots = ops.render_dot_slots(cam.width, cam.height)
-        if getattr(self, "_acc", None) is None or self._acc.numel() != s0 * s1 + n_slots:
-            self._acc = torch.empty(s0 * s1 + n_slots, dtype=torch.float32, device=rd.device)
+        sd0 = ms.scene_desc(tex_channels=1)  # (sizes only: the pose of the samples comes later)
+        use_cache = Fn.cache_supported(sd0, self.spp)
+        nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0
+        acc_bytes = -(-4 * (s0 * s1 + n_slots) // 128) * 128
+        if getattr(self, "_arena", None) is None or self._arena.numel() != acc_bytes + max(nbytes, 64):
+            self._arena = torch.empty(acc_bytes + max(nbytes, 64), dtype=torch.uint8, device=rd.device)
+            self._acc = self._arena[: acc_bytes + 64].view(torch.float32)  # what the pattern launch clears: accumulator + cache header
+            self._cache = self._arena[acc_bytes:] if use_cache else None
         pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf, zero=self._acc)
         tex = ops.blur_fwd(tsum, self.blur[0], self.blur[1]) if self.blur else tsum
         tex3 = tex.unsqueeze(-1)
-        gtex, loss_slots = self._acc[: s0 * s1].view(tex3.shape), self._acc[s0 * s1:]
+        gtex, loss_slots = self._acc[: s0 * s1].view(tex3.shape), self._acc[s0 * s1: s0 * s1 + n_slots]
         loss_sum = loss_slots[0]
+        header_clear = True  # (until the first cache-writing render of the step has used it)
         # this rank's scene samples: all their random draws up front (each under its own seed, as
         # manual_seed(s); randomize() would make them), ONE device-to-host transfer for the lot
         seeds = self._sample_seeds(self.step_index)
@@ -190,14 +200,12 @@ class PatternOptimizer:
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
-            use_cache = Fn.cache_supported(sd, self.spp)
-            nbytes = ops.render_cache_bytes_sd(sd, self.spp) if use_cache else 0
-            if use_cache and (self._cache is None or self._cache.numel() != nbytes):
-                self._cache = torch.empty(nbytes, dtype=torch.uint8, device=tex.device)
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
             mats = ms.materials_arg(sd)  # (None: the rows are part of sd — no upload, no device tensor)
-            img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache)
+            img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache,
+                                  cache_zeroed=header_clear)
+            header_clear = False
             if linear is not None and use_cache:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)

@@ -466,6 +466,20 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                                        produced the texture (rasterization.py:583-607): samples whose four bilinear taps are all exactly
                                        zero are then neither shadow-traced nor cached.  The image is the same; gtex at zero-valued texels
                                        is unspecified.  The oracle ignores the bit (it always computes the full gradient). */
+#define FFX_RENDER_APEX_READY 4      /* img_fp16 bit 2 (ffx_render_fwd, ffx_render_fwd_cache): the blob's apex areas already hold the records
+                                       of THIS call's camera / projector / spot positions — written by ffx_apex_prepare, or by an earlier
+                                       render / trace call with the same positions, and neither ffx_scene_update nor a call with other
+                                       positions has touched the blob since.  The call then launches no pre-pass (6 us in front of every
+                                       render; a caller that re-fits on a side stream prepares there, off the critical path).  A promise
+                                       the library cannot check: stale records give a wrong image.  The oracle ignores the bit. */
+#define FFX_RENDER_CACHE_ZEROED 8    /* img_fp16 bit 3 (ffx_render_fwd_cache): the first 64 bytes of `cache` are zero (cleared by the caller,
+                                       stream-ordered before this call — e.g. by the launch that clears its gradient buffer): the call
+                                       does not reset the header itself.  The oracle ignores the bit. */
+/* Writes the apex records (the triangles as seen from a fixed ray origin) of sd's camera and enabled emitters into
+ * the blob's apex areas — what every packet render does in front of its kernel unless told FFX_RENDER_APEX_READY.  Only
+ * sd->cam.to_world, sd->proj.{enabled,to_world} and sd->spot.{enabled,to_world} are read.  No reference counterpart (Mitsuba
+ * builds its acceleration structure inside params.update(), /root/reference/fireflies/scene.py:384). */
+int ffx_apex_prepare(void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/, ffx_stream stream);
 size_t ffx_render_cache_bytes(int width, int height, int spp); /* Lambert scenes (mat_stride 0 / 3) */
 /* the same for any scene: with material rows the cache holds a second footprint per pixel (the part of the BSDF
  * that does not scale with base_color): 67.1 MB at 512x512x64 */

@@ -1481,7 +1481,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                    uint32_t seed, int img_fp16, void *img, ffx_stream s) {
   (void)s;
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, NULL);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, NULL); /* FFX_RENDER_APEX_READY ignored: the apex vectors are formed per test */
 }
 
 size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * sizeof(crec); }
@@ -1493,6 +1493,13 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
   if (!cache) FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
   if (sd && sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: textured base colours (use ffx_render_bwd)");
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, (crec *)cache); /* bit 1 (sparse adjoint) ignored: full gradient */
+}
+
+/* nothing to prepare: the oracle forms the apex vectors inside every triangle test (same four quantities, same order) */
+int ffx_apex_prepare(void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, ffx_stream s) {
+  (void)s;
+  if (!bvh || !info || !sd) FAIL(FFX_ERR_ARG, "apex_prepare: bad argument");
+  return FFX_OK;
 }
 
 /* this cache is one record per sample: nothing is ever dropped */

@@ -717,6 +717,62 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
     assert ops.render_cache_bytes(512, 512, 64) <= 40 * 10**6
 
 
+def test_apex_records_written_ahead_and_cache_header_cleared_by_the_caller(oracle):
+    """FFX_RENDER_APEX_READY / FFX_RENDER_CACHE_ZEROED (include/ffx.h): the apex records may be written by ffx_apex_prepare behind the
+    re-fit (ops.DeviceGeometry.update(apex_sd=...)) and the cache header cleared by the caller, so that a render launches nothing in
+    front of its kernel.  Same bits as the call that prepares for itself; the host-side bookkeeping (ops.apex_key) never claims
+    records that a re-fit, a trace or a render from other positions has replaced."""
+    sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    xf = _rand_xforms(2, 5)
+    go, gd, alb = _pair(oracle, sc, frame=2, xforms=xf)
+    offs = gd._vert_off_host.copy()
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    tex = _tex(sc, 1)
+    i_cur = lambda: gd._cur if gd._async else 0  # noqa: E731
+    assert gd._apex[i_cur()] is None  # a re-fit without apex_sd leaves nothing to claim
+    ref = gd.render_fwd(sd, dev(alb), tex, 9, seed=3)  # (prepares for itself)
+    assert gd._apex[i_cur()] == ops.apex_key(sd)
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)  # second call on the same records: flag set, no pre-pass
+    gd.update(xf, offs, apex_sd=sd)  # records re-written, apex records behind them on the side stream
+    assert gd._apex[i_cur()] == ops.apex_key(sd)
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)
+    np.testing.assert_allclose(host(ref), go.render_fwd(sd, alb, host(tex), 9, seed=3), rtol=2e-4, atol=2e-6 * float(ref.max()))
+    # another camera position between two renders of the first: each call sees its own records
+    cam2 = np.array(sc.camera.to_world, np.float32).copy()
+    cam2[:3, 3] += np.float32([0.01, -0.02, 0.015])
+    sd2 = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, cam_to_world=cam2)
+    other = gd.render_fwd(sd2, dev(alb), tex, 9, seed=3)
+    assert gd._apex[i_cur()] == ops.apex_key(sd2) and not torch.equal(other, ref)
+    np.testing.assert_allclose(host(other), go.render_fwd(sd2, alb, host(tex), 9, seed=3), rtol=2e-4, atol=2e-6 * float(ref.max()))
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)
+    # a primary trace rewrites the camera's area only: nothing is claimed afterwards
+    gd.trace_primary(scene_desc.camera_from_sensor(sc.camera, cam2), 1, 0, 0)
+    assert gd._apex[i_cur()] is None
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)
+    # the re-tracing adjoint prepares for itself and leaves its records behind
+    gimg = dev(np.random.default_rng(0).standard_normal((44, 52, 3)).astype(np.float32))
+    g_ref = gd.render_bwd(sd2, dev(alb), 9, 3, gimg)
+    assert gd._apex[i_cur()] == ops.apex_key(sd2)
+    assert torch.equal(gd.render_fwd(sd2, dev(alb), tex, 9, seed=3), other)
+    # the cache header: cleared by the caller (FFX_RENDER_CACHE_ZEROED) or by the call — the same cache, the same adjoint
+    nbytes = ops.render_cache_bytes(52, 44, 9)
+    c_a = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")  # (a header full of garbage: the call resets it)
+    c_b = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+    c_b[:64] = 0
+    gd.update(xf, offs, apex_sd=sd2)
+    img_a = gd.render_fwd(sd2, dev(alb), tex, 9, seed=3, cache=c_a)  # apex ready, header reset by the call (its own one-thread launch)
+    img_b = gd.render_fwd(sd2, dev(alb), tex, 9, seed=3, cache=c_b, cache_zeroed=True)  # nothing in front of the kernel
+    assert torch.equal(img_a, other) and torch.equal(img_b, other)
+    ha, hb = host(c_a[:12]).view(np.uint32), host(c_b[:12]).view(np.uint32)
+    assert (ha == hb).all() and ha[1] == max(4096, 52 * 44 * 9 // 64) and ha[2] == 0
+    for c in (c_a, c_b):
+        g = gd.render_bwd_cached(sd2, dev(alb), c, 9, gimg)
+        assert float((g - g_ref).abs().max()) <= 2e-3 * float(g_ref.abs().max())
+    # the raw entry point refuses what it cannot use
+    with pytest.raises(Exception, match="apex_prepare"):
+        gd._call("ffx_apex_prepare", None, None, None, None)
+
+
 def test_adjoint_cache_overflow_is_refused_up_front_or_loud(oracle, monkeypatch):
     """The adjoint cache is lossy once its arena of single-sample records is full.  A projector texture much finer
     than the camera's pixels (55 texels per pixel here) makes most samples strays: (a) functional.cache_supported
