@@ -56,6 +56,27 @@ class Smooth(C.Structure):
     ]
 
 
+class AdamArgs(C.Structure):
+    """ffx_adam_args: the update ffx_pattern_bwd_blur applies behind the gradient"""
+    _fields_ = [
+        ("rays", C.c_void_p),
+        ("exp_avg", C.c_void_p),
+        ("exp_avg_sq", C.c_void_p),
+        ("step", C.c_void_p),
+        ("grad_out", C.c_void_p),
+        ("counter", C.c_void_p),
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("KF_inv", C.c_float * 16),
+        ("lo", C.c_float),
+        ("hi", C.c_float),
+        ("grad_div", C.c_float),
+        ("n_normalize", C.c_int32),
+    ]
+
+
 class Camera(C.Structure):
     _fields_ = [
         ("to_world", c_f * 16),
@@ -133,6 +154,8 @@ PROTOTYPES = {
     "ffx_pattern_ws_floats": (C.c_size_t, [c_i, c_i]),
     "ffx_pattern_fwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_p]),
     "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p]),
+    "ffx_pattern_fwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_i, c_f, c_p, c_p]),
+    "ffx_pattern_bwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_f, c_p, C.POINTER(AdamArgs), c_p]),
     "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),

@@ -6,6 +6,7 @@
 // and adds; the file is compiled with -ffp-contract=off), so results agree with the reference to
 // the last few ulps of expf.
 #include "ffx_common.h"
+#include <cstring>
 
 #define SPLAT_BLOCK 256
 #define TILE_W 32
@@ -482,6 +483,125 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 }
 
 
+// ---- K3 pieces shared by the blur kernels and by the pattern launches that carry the blur along (ffx_pattern_*_blur)
+struct BlurW { float w[15]; int ksize; };
+__device__ __forceinline__ int reflect_idx(int t, int n) {
+  if (n == 1) return 0;
+  while (t < 0 || t >= n) {
+    if (t < 0) t = -t;
+    if (t >= n) t = 2 * (n - 1) - t;
+  }
+  return t;
+}
+// K3^T at one pixel (y, x) of an h x w image (both > 2r + 2) from an LDS window of the upstream gradient: win[(gy - oy) * ww + (gx - ox)]
+// holds gout(gy, gx), zero outside the image, and covers (at least) rows y - r .. y + r, columns x - r .. x + r and — for the pixels
+// next to a border — the first / last r + 1 rows (columns), which the reflected candidates read.  The exact transpose of the
+// reflect-padded correlation: gin[q] = sum over the padded positions t (|t - image| <= r) that reflect onto q of
+// g_pad[t] = sum_k w[k] * gout[t - k + r], separately per axis; same terms in the same order wherever it is called from.
+// KS: the kernel size as a compile-time constant (5: the size every call site of the reference uses, vocalfold_scene.py:61-63) or
+// 0 = taken from bw at run time
+template <int KS>
+__device__ __forceinline__ float blur_bwd_texel(const float *__restrict__ win, int ww, int oy, int ox, int y, int x, int h, int w, const BlurW &bw) {
+  const int ksize = KS ? KS : bw.ksize;
+  const int r = ksize / 2;
+  // Padded rows -r..-1 reflect onto rows 1..r and rows h..h+r-1 onto h-1-r..h-2: only those rows (columns) have
+  // candidates besides themselves — every other pixel is a plain correlation.
+  const bool edge_y = (y >= 1 && y <= r) || (y >= h - 1 - r && y <= h - 2);
+  const bool edge_x = (x >= 1 && x <= r) || (x >= w - 1 - r && x <= w - 2);
+  float acc = 0.f;
+  if (!edge_y && !edge_x) {
+    // no reflected candidate: a plain correlation over the zero-padded window (a tap outside the image adds w * 0, which leaves
+    // the running sum as the skipped term of the general loop does).  With KS known the 25 taps are LDS reads at constant
+    // offsets: the general loop below spends ~36 instructions per tap on bounds tests and integer multiplies.
+    const float *t0 = win + (y - r - oy) * ww + (x - r - ox); // window element of (y - r, x - r)
+    if constexpr (KS != 0) {
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) row = fmaf(bw.w[kx], t0[(2 * r - ky) * ww + (2 * r - kx)], row);
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    } else {
+      for (int ky = 0; ky < ksize; ++ky) {
+        const float *tr = t0 + (2 * r - ky) * ww + 2 * r;
+        float row = 0.f;
+        for (int kx = 0; kx < ksize; ++kx) row = fmaf(bw.w[kx], tr[-kx], row);
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    }
+    return acc;
+  }
+  const int na = edge_y ? 2 * r : 0, nb = edge_x ? 2 * r : 0;
+  // candidate padded rows: y itself, then the r rows above the image and the r rows below it
+  for (int a = -1; a < na; ++a) {
+    int ty = (a < 0) ? y : (a < r ? -(a + 1) : h + (a - r));
+    if (a >= 0 && reflect_idx(ty, h) != y) continue;
+    for (int b = -1; b < nb; ++b) {
+      int tx = (b < 0) ? x : (b < r ? -(b + 1) : w + (b - r));
+      if (b >= 0 && reflect_idx(tx, w) != x) continue;
+      for (int ky = 0; ky < ksize; ++ky) {
+        int py = ty - ky + r;
+        if (py < 0 || py >= h) continue;
+        float row = 0.f;
+        for (int kx = 0; kx < ksize; ++kx) {
+          int px = tx - kx + r;
+          if (px < 0 || px >= w) continue;
+          row = fmaf(bw.w[kx], win[(py - oy) * ww + (px - ox)], row);
+        }
+        acc = fmaf(bw.w[ky], row, acc);
+      }
+    }
+  }
+  return acc;
+}
+
+// Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the step count t kept
+// on the device) followed by Laser.clamp_to_fov + normalize_rays on the updated ray i
+__device__ __forceinline__ void adam_clamp_one(int i, float t, float *__restrict__ rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
+                                               float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
+                                               const float *K, const float *I, float lo, float hi, int n_norm) {
+  // the scalars as torch forms them: in double from the Python floats, rounded to float where they meet the tensors
+  const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float g = grad ? grad[3 * i + c] : 0.f;
+    if (grad_out) { // g = grad / S + grad_b, rounded like the two torch ops it replaces; kept as the parameter's .grad
+      if (scale_a != 1.0f) g = g / scale_a;
+      if (grad_b) g = g + grad_b[3 * i + c];
+      grad_out[3 * i + c] = g;
+    }
+    float mm = m[3 * i + c], vv = v[3 * i + c];
+    mm = mm + omb1 * (g - mm);
+    vv = b2 * vv + omb2 * g * g;
+    m[3 * i + c] = mm;
+    v[3 * i + c] = vv;
+    const float denom = sqrtf(vv) / bc2s + eps;
+    r[c] = rays[3 * i + c] - step_size * mm / denom;
+  }
+  float x = r[0], y = r[1], z = r[2];
+  const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+  const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+  const float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
+  const float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+  float px = q0 / q3, py = q1 / q3, pz = q2 / q3;
+  px = fminf(fmaxf(px, lo), hi);
+  py = fminf(fmaxf(py, lo), hi);
+  const float w0 = I[0] * px + I[1] * py + I[2] * pz + I[3];
+  const float w1 = I[4] * px + I[5] * py + I[6] * pz + I[7];
+  const float w2 = I[8] * px + I[9] * py + I[10] * pz + I[11];
+  const float w3 = I[12] * px + I[13] * py + I[14] * pz + I[15];
+  x = w0 / w3; y = w1 / w3; z = w2 / w3;
+  for (int k = 0; k < n_norm; ++k) {
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    x /= nrm; y /= nrm; z /= nrm;
+  }
+  rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
+}
+
 // =================================================================================== fused pattern side of an optimisation step
 // The pattern has 64..1024 points and the texture 500^2 texels: every kernel of the pattern side is launch-bound,
 // and as separate entry points one gradient step issued ~30 of them (~0.11 ms next to a 0.75 ms render).  Three
@@ -571,14 +691,138 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   }
 }
 
+// k_pattern_fwd that also writes tex = K3(tsum), the (2R+1)^2 Gaussian blur with reflected borders (ffx_pattern_fwd_blur): the
+// workgroup evaluates the splat sums of its 32x8 tile PLUS the halo of R texels around it (at the reflected positions where the
+// halo leaves the image: exactly what k_blur_fwd stages) into LDS — 36x12 instead of 32x8 evaluations at R = 2 — and blurs from
+// there.  Every value is formed as the separate launches form it (same candidate order per texel: points that cannot reach a
+// texel add an exact 0; same thread-to-texel mapping for the regulariser's partial sums and for the blur), so tsum, tsor, ws
+// and tex are bitwise those of ffx_pattern_fwd + ffx_blur_fwd; one launch (~5 us on the critical path of a step) less.
+template <int R>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_fwd_blur(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, int want_softor, float *__restrict__ pts,
+                       float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws, float *__restrict__ zero, long n_zero, BlurW bw,
+                       float *__restrict__ tex) {
+  constexpr int HW = TILE_W + 2 * R, HH = TILE_H + 2 * R, NT = (HW * HH + SPLAT_BLOCK - 1) / SPLAT_BLOCK;
+  __shared__ float c_p0[CAND_MAX], c_p1[CAND_MAX];
+  __shared__ int c_count;
+  __shared__ float s_part[SPLAT_BLOCK / 64];
+  __shared__ float s_t[HW * HH];                 // tsum over the haloed tile (the blur's input tile)
+  __shared__ float s_o[TILE_W * TILE_H];         // tsor of the tile itself
+  const int tid = threadIdx.x;
+  if (zero) {
+    const long stride = (long)gridDim.x * gridDim.y * SPLAT_BLOCK;
+    for (long t = ((long)blockIdx.y * gridDim.x + blockIdx.x) * SPLAT_BLOCK + tid; t < n_zero; t += stride) zero[t] = 0.f;
+  }
+  const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+  const float inv_sigma = 1.0f / sigma;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  // the texels of this thread: haloed-tile elements tid, tid + 256, ... at their reflected image positions
+  float fj[NT], fi[NT], acc_s[NT], acc_p[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int t = tid + u * SPLAT_BLOCK;
+    const int lx = t % HW, ly = t / HW;
+    fj[u] = (float)reflect_idx(j0 + lx - R, size0);
+    fi[u] = (float)reflect_idx(i0 + ly - R, size1);
+    acc_s[u] = 0.f;
+    acc_p[u] = 1.f;
+  }
+  for (int chunk = 0; chunk < n; chunk += CAND_MAX) {
+    if (tid < 64) {
+      int count = 0;
+      const int lim = min(CAND_MAX, n - chunk);
+      for (int base = 0; base < lim; base += 64) {
+        const int k = chunk + base + tid;
+        bool keep = false;
+        float p0s = 0.f, p1s = 0.f;
+        if (base + tid < lim) {
+          float p0, p1;
+          project_xy(rays, k, KF.m, p0, p1);
+          if (first) { pts[2 * k] = p0; pts[2 * k + 1] = p1; }
+          p0s = p0 * (float)size0;
+          p1s = p1 * (float)size1;
+          const float dx = fmaxf(fmaxf((float)(j0 - R) - p0s, p0s - (float)(j0 + TILE_W - 1 + R)), 0.f); // distance to the HALOED tile
+          const float dy = fmaxf(fmaxf((float)(i0 - R) - p1s, p1s - (float)(i0 + TILE_H - 1 + R)), 0.f);
+          keep = (dx * dx + dy * dy) * inv_sigma <= FFX_QCUT;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = count + __popcll(m & ((1ull << tid) - 1ull));
+        if (keep) { c_p0[pos] = p0s; c_p1[pos] = p1s; }
+        count += __popcll(m);
+      }
+      if (tid == 0) c_count = count;
+    }
+    __syncthreads();
+    const int cnt = c_count;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (tid + u * SPLAT_BLOCK >= HW * HH) continue;
+      for (int c = 0; c < cnt; ++c) {
+        float d, yd, xd;
+        const float v = splat_val(fj[u], fi[u], c_p0[c], c_p1[c], sigma, inv_sigma, d, yd, xd);
+        acc_s[u] += v;
+        acc_p[u] *= (1.0f - v);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int t = tid + u * SPLAT_BLOCK;
+    if (t >= HW * HH) continue;
+    s_t[t] = acc_s[u];
+    const int lx = t % HW - R, ly = t / HW - R; // position inside the tile itself
+    if (lx >= 0 && lx < TILE_W && ly >= 0 && ly < TILE_H) s_o[ly * TILE_W + lx] = 1.0f - acc_p[u];
+  }
+  __syncthreads();
+  // the tile's own texels, one per thread as in k_pattern_fwd / k_blur_fwd
+  const int lx = tid % TILE_W, ly = tid / TILE_W;
+  const int j = j0 + lx, i = i0 + ly;
+  const bool inside = j < size0 && i < size1;
+  float l1 = 0.f;
+  if (inside) {
+    const float a = s_t[(ly + R) * HW + lx + R];
+    tsum[(size_t)i * size0 + j] = a;
+    if (want_softor) {
+      const float so = s_o[tid];
+      tsor[(size_t)i * size0 + j] = so;
+      l1 = fabsf(so - a);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 2 * R + 1; ++ky) {
+      float row = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 2 * R + 1; ++kx) row = fmaf(bw.w[kx], s_t[(ly + ky) * HW + lx + kx], row);
+      acc = fmaf(bw.w[ky], row, acc);
+    }
+    tex[(size_t)i * size0 + j] = acc;
+  }
+  if (want_softor) { // partial sum of |softor - sum| of this tile, fixed order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l1 += __shfl_down(l1, o, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = l1;
+    __syncthreads();
+    if (tid == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  }
+}
+
 // one workgroup per point over its non-zero footprint, like k_splat_bwd.  Data term: upstream gts on the SUM
 // texture.  Regulariser w * mean|softor - sum|: upstream gd = w * sign(softor - sum) / T on softor and -gd on
 // sum, i.e. per texel gd * (prod_{m != k}(1 - v_m) - 1) on this point's splat value.  fp64 partial sums; then
 // K1-bwd of both results (the chain through the perspective divide) by one lane.
+// KS >= 0 (ffx_pattern_bwd_blur): gts is the gradient on the BLURRED texture and K3^T is applied here, over the point's footprint
+// only — the footprint plus a halo of r texels is staged in (dynamic) LDS and every texel's value is formed by blur_bwd_texel, the
+// code k_blur_bwd runs: bitwise the separate launches' gradient without the 250 000-texel transpose blur in front (11 us) —
+// and `adam` (if it names rays): the workgroup that finishes last applies ffx_adam_clamp_step's update to every point.
+struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm; };
+template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
                   const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
-                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n, float loss_div) {
+                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n, float loss_div,
+                  BlurW bw, AdamK adam) {
+  extern __shared__ float s_win[]; // KS >= 0: gts over the footprint + halo
   __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
   __shared__ int nb_count;
   __shared__ double red[4][SPLAT_BLOCK / 64];
@@ -618,6 +862,18 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   }
   const float gscale = reg_weight / ((float)size0 * (float)size1);
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  const int br = KS >= 0 ? (KS ? KS : bw.ksize) / 2 : 0;
+  const int ww = hi0 - lo0 + 2 * br; // row length of the staged window
+  if constexpr (KS >= 0) {
+    if (alive && gts) {
+      const int wh = hi1 - lo1 + 2 * br;
+      for (int t = tid; t < ww * wh; t += SPLAT_BLOCK) {
+        const int gy = lo1 - br + t / ww, gx = lo0 - br + t % ww;
+        s_win[t] = (gy >= 0 && gy < size1 && gx >= 0 && gx < size0) ? gts[(size_t)gy * size0 + gx] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
   if (alive) {
     const int rw = hi0 - lo0, rh = hi1 - lo1;
     for (int t = tid; t < rw * rh; t += SPLAT_BLOCK) {
@@ -628,7 +884,9 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
       const size_t T = (size_t)i * size0 + j;
       const float cf = splat_gcoef(v, d, sigma);
       if (gts) {
-        const float w = gts[T];
+        float w;
+        if constexpr (KS >= 0) w = blur_bwd_texel<(KS > 0 ? KS : 0)>(s_win, ww, lo1 - br, lo0 - br, i, j, size1, size0, bw);
+        else w = gts[T];
         a0 += (double)(w * (cf * yd));
         a1 += (double)(w * (cf * xd));
       }
@@ -713,6 +971,24 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
       }
     }
   }
+  if (adam.rays) { // the update rides along: whoever finishes last sees every point's gradient (agent-scope fence + counter)
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      s_last = atomicAdd(adam.counter, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const float t = adam.step[0] + 1.0f;
+      for (int i = tid; i < n; i += SPLAT_BLOCK)
+        adam_clamp_one(i, t, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
+                       adam.lo, adam.hi, adam.n_norm);
+      __syncthreads();
+      if (tid == 0) { adam.step[0] = t; *adam.counter = 0u; } // (the counter is ready for the next launch)
+    }
+  }
 }
 
 // Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the
@@ -722,49 +998,7 @@ __global__ void __launch_bounds__(256)
                  float *__restrict__ m, float *__restrict__ v, float *__restrict__ step, int n, double lr, double beta1, double beta2, double eps_d, Mat4 KF, Mat4 KI, float lo, float hi, int n_norm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float t = step[0] + 1.0f;
-  if (i < n) {
-    // the scalars as torch forms them: in double from the Python floats, rounded to float where they meet the tensors
-    const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
-    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-    const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
-    float r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float g = grad[3 * i + c];
-      if (grad_out) { // g = grad / S + grad_b, rounded like the two torch ops it replaces; kept as the parameter's .grad
-        if (scale_a != 1.0f) g = g / scale_a;
-        if (grad_b) g = g + grad_b[3 * i + c];
-        grad_out[3 * i + c] = g;
-      }
-      float mm = m[3 * i + c], vv = v[3 * i + c];
-      mm = mm + omb1 * (g - mm);
-      vv = b2 * vv + omb2 * g * g;
-      m[3 * i + c] = mm;
-      v[3 * i + c] = vv;
-      const float denom = sqrtf(vv) / bc2s + eps;
-      r[c] = rays[3 * i + c] - step_size * mm / denom;
-    }
-    float x = r[0], y = r[1], z = r[2];
-    const float *K = KF.m;
-    const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
-    const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
-    const float q2 = K[8] * x + K[9] * y + K[10] * z + K[11];
-    const float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
-    float px = q0 / q3, py = q1 / q3, pz = q2 / q3;
-    px = fminf(fmaxf(px, lo), hi);
-    py = fminf(fmaxf(py, lo), hi);
-    const float *I = KI.m;
-    const float w0 = I[0] * px + I[1] * py + I[2] * pz + I[3];
-    const float w1 = I[4] * px + I[5] * py + I[6] * pz + I[7];
-    const float w2 = I[8] * px + I[9] * py + I[10] * pz + I[11];
-    const float w3 = I[12] * px + I[13] * py + I[14] * pz + I[15];
-    x = w0 / w3; y = w1 / w3; z = w2 / w3;
-    for (int k = 0; k < n_norm; ++k) {
-      const float nrm = sqrtf(x * x + y * y + z * z);
-      x /= nrm; y /= nrm; z /= nrm;
-    }
-    rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
-  }
+  if (i < n) adam_clamp_one(i, t, rays, grad, grad_b, scale_a, grad_out, m, v, lr, beta1, beta2, eps_d, KF.m, KI.m, lo, hi, n_norm);
   // every lane has read the step count: the last workgroup to get here... (one workgroup covers up to 256 rays;
   // with more rays the count must not be bumped before every workgroup has read it: the host passes it instead)
   if (gridDim.x == 1) {
@@ -776,15 +1010,6 @@ __global__ void k_bump_step(float *step) { step[0] += 1.0f; }
 
 // =================================================================================== K3 blur
 // (ksize x ksize) Gaussian, reflect border.  One workgroup per 32x8 output tile, halo staged in LDS.
-struct BlurW { float w[15]; int ksize; };
-__device__ __forceinline__ int reflect_idx(int t, int n) {
-  if (n == 1) return 0;
-  while (t < 0 || t >= n) {
-    if (t < 0) t = -t;
-    if (t >= n) t = 2 * (n - 1) - t;
-  }
-  return t;
-}
 __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restrict__ in, int h, int w, BlurW bw, float *__restrict__ out) {
   __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
   const int r = bw.ksize / 2, tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
@@ -805,10 +1030,11 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restric
   }
   out[(size_t)y * w + x] = acc;
 }
-// exact transpose: gin[q] = sum over the padded positions t (|t - image| <= r) that reflect onto q
-// of g_pad[t] = sum_k w[k] * gout[t - k + r], separately per axis.
-// KS: the kernel size as a compile-time constant (5: the size every call site of the reference uses, vocalfold_scene.py:61-63) or
-// 0 = taken from bw at run time
+// K3^T (blur_bwd_texel above).  One workgroup per 32x8 tile.  Whatever a pixel of the tile reads lies in the tile's halo
+// [y0 - r, y0 + TILE_H + r) x [x0 - r, x0 + TILE_W + r) clipped to the image (the reflected candidates of a border pixel read the
+// first / last r rows, which are in the halo of the border tiles): staged through LDS like the forward blur, zero outside the
+// image.  Reading the 25 taps per pixel from global memory — and the candidate search of the border tiles — had made this kernel
+// 3x as slow as k_blur_fwd (15 us against 5).  Images smaller than 2r + 3 (reflections of reflections) keep a direct loop.
 template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restrict__ gout, int h, int w, BlurW bw, float *__restrict__ gin) {
   __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
@@ -817,13 +1043,6 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
   const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
   const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
   const int x = x0 + lx, y = y0 + ly;
-  // Padded rows -r..-1 reflect onto rows 1..r and rows h..h+r-1 onto h-1-r..h-2: only those rows (columns) have
-  // candidates besides themselves — every other pixel is a plain correlation.  Whatever a pixel of this tile reads lies
-  // in the tile's halo [y0 - r, y0 + TILE_H + r) x [x0 - r, x0 + TILE_W + r) clipped to the image (the reflected
-  // candidates of a border pixel read the first / last r rows, which are in the halo of the border tiles): staged through
-  // LDS like the forward blur, zero outside the image.  Reading the 25 taps per pixel from global memory — and the
-  // candidate search of the border tiles — had made this kernel 3x as slow as k_blur_fwd (15 us against 5).  Images
-  // smaller than 2r + 3 (reflections of reflections) keep the direct loop.  Same terms in the same order either way.
   const bool small = h <= 2 * r + 2 || w <= 2 * r + 2; // (uniform)
   const int tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
   if (!small) {
@@ -834,39 +1053,16 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
     __syncthreads();
   }
   if (x >= w || y >= h) return;
-  float acc = 0.f;
-  const bool edge_y = small || (y >= 1 && y <= r) || (y >= h - 1 - r && y <= h - 2);
-  const bool edge_x = small || (x >= 1 && x <= r) || (x >= w - 1 - r && x <= w - 2);
-  if (!edge_y && !edge_x) {
-    // no reflected candidate: a plain correlation over the zero-padded tile (a tap outside the image adds w * 0, which leaves
-    // the running sum as the skipped term of the general loop does).  With KS known the 25 taps are LDS reads at constant
-    // offsets: the general loop below spent ~36 instructions per tap on bounds tests and integer multiplies.
-    const float *t0 = tile + ly * tw + lx; // tile element of (y - r, x - r)
-    if constexpr (KS != 0) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        float row = 0.f;
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) row = fmaf(bw.w[kx], t0[(2 * r - ky) * tw + (2 * r - kx)], row);
-        acc = fmaf(bw.w[ky], row, acc);
-      }
-    } else {
-      for (int ky = 0; ky < ksize; ++ky) {
-        const float *tr = t0 + (2 * r - ky) * tw + 2 * r;
-        float row = 0.f;
-        for (int kx = 0; kx < ksize; ++kx) row = fmaf(bw.w[kx], tr[-kx], row);
-        acc = fmaf(bw.w[ky], row, acc);
-      }
-    }
-    gin[(size_t)y * w + x] = acc;
+  if (!small) {
+    gin[(size_t)y * w + x] = blur_bwd_texel<KS>(tile, tw, y0 - r, x0 - r, y, x, h, w, bw);
     return;
   }
-  const int na = edge_y ? 2 * r : 0, nb = edge_x ? 2 * r : 0;
+  float acc = 0.f;
   // candidate padded rows: y itself, then the r rows above the image and the r rows below it
-  for (int a = -1; a < na; ++a) {
+  for (int a = -1; a < 2 * r; ++a) {
     int ty = (a < 0) ? y : (a < r ? -(a + 1) : h + (a - r));
     if (a >= 0 && reflect_idx(ty, h) != y) continue;
-    for (int b = -1; b < nb; ++b) {
+    for (int b = -1; b < 2 * r; ++b) {
       int tx = (b < 0) ? x : (b < r ? -(b + 1) : w + (b - r));
       if (b >= 0 && reflect_idx(tx, w) != x) continue;
       for (int ky = 0; ky < ksize; ++ky) {
@@ -876,8 +1072,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_bwd(const float *__restric
         for (int kx = 0; kx < ksize; ++kx) {
           int px = tx - kx + r;
           if (px < 0 || px >= w) continue;
-          const float g = small ? gout[(size_t)py * w + px] : tile[(py - y0 + r) * tw + (px - x0 + r)];
-          row = fmaf(bw.w[kx], g, row);
+          row = fmaf(bw.w[kx], gout[(size_t)py * w + px], row);
         }
         acc = fmaf(bw.w[ky], row, acc);
       }
@@ -974,10 +1169,85 @@ int ffx_pattern_bwd(const float *rays, int n, const float *KF, float sigma, int 
   if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_bwd: more than 65535 points");
   Mat4 m;
   for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
-  hipLaunchKernelGGL(k_pattern_bwd, dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws,
+  BlurW nobw;
+  AdamK noadam;
+  memset(&nobw, 0, sizeof nobw);
+  memset(&noadam, 0, sizeof noadam);
+  hipLaunchKernelGGL(k_pattern_bwd<-1>, dim3(n), dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws,
                      ws ? (int)ffx_pattern_ws_floats(size0, size1) : 0, gts ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in,
-                     loss_in ? loss_in_n : 0, loss_div > 0.f ? loss_div : 1.0f);
+                     loss_in ? loss_in_n : 0, loss_div > 0.f ? loss_div : 1.0f, nobw, noadam);
   FFX_CHECK_LAUNCH("pattern_bwd");
+  return FFX_OK;
+}
+
+int ffx_pattern_fwd_blur(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
+                         float *ws, float *zero, long n_zero, int blur_ksize, float blur_sigma, float *tex, ffx_stream s) {
+  if (!tex) FFX_FAIL(FFX_ERR_ARG, "pattern_fwd_blur: tex is NULL");
+  BlurW bw;
+  if (!blur_weights(blur_ksize, blur_sigma, bw)) FFX_FAIL(FFX_ERR_ARG, "pattern_fwd_blur: ksize must be odd, 1..15, sigma positive");
+  if (blur_ksize != 5) { // other sizes: the separate launches (same values)
+    const int rc = ffx_pattern_fwd(rays, n, KF, sigma, size0, size1, want_softor, pts, tsum, tsor, ws, zero, n_zero, s);
+    return rc != FFX_OK ? rc : ffx_blur_fwd(tsum, size1, size0, blur_ksize, blur_sigma, tex, s);
+  }
+  if (!rays || !KF || !pts || !tsum || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (want_softor && (!tsor || !ws)) || (zero && n_zero < 1))
+    FFX_FAIL(FFX_ERR_ARG, "pattern_fwd_blur: bad argument");
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  dim3 grid(ffx_cdiv(size0, TILE_W), ffx_cdiv(size1, TILE_H));
+  hipLaunchKernelGGL(k_pattern_fwd_blur<2>, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, want_softor, pts, tsum, tsor, ws, zero,
+                     zero ? n_zero : 0L, bw, tex);
+  FFX_CHECK_LAUNCH("pattern_fwd_blur");
+  return FFX_OK;
+}
+
+int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gtex,
+                         float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div,
+                         int blur_ksize, float blur_sigma, float *gts_scratch, const ffx_adam_args *adam, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || (gtex && !grays_data) || (reg_weight > 0.f && (!tsum || !tsor || !ws || !grays_reg)) ||
+      (loss_in && (loss_in_n < 1 || !reg_value)))
+    FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: bad argument");
+  if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_bwd_blur: more than 65535 points");
+  BlurW bw;
+  memset(&bw, 0, sizeof bw);
+  if (blur_ksize != 0 && !blur_weights(blur_ksize, blur_sigma, bw)) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: ksize must be 0 (no blur) or odd, 1..15, with a positive sigma");
+  AdamK ak;
+  memset(&ak, 0, sizeof ak);
+  if (adam) {
+    if (!adam->rays || !adam->exp_avg || !adam->exp_avg_sq || !adam->step || !adam->counter || !(adam->grad_div > 0.f) || adam->n_normalize < 0 || !(adam->lo <= adam->hi))
+      FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: bad Adam arguments");
+    if ((grays_reg || adam->grad_div != 1.0f) && !adam->grad_out) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: combining gradients needs grad_out");
+    if (adam->rays != rays) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the update is applied to the rays the gradient was taken at");
+    ak.rays = adam->rays; ak.m = adam->exp_avg; ak.v = adam->exp_avg_sq; ak.step = adam->step; ak.grad_out = adam->grad_out; ak.counter = adam->counter;
+    ak.lr = adam->lr; ak.beta1 = adam->beta1; ak.beta2 = adam->beta2; ak.eps = adam->eps;
+    for (int i = 0; i < 16; ++i) ak.KI.m[i] = adam->KF_inv[i];
+    ak.lo = adam->lo; ak.hi = adam->hi; ak.grad_div = adam->grad_div; ak.n_norm = adam->n_normalize;
+  }
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  const int n_ws = ws ? (int)ffx_pattern_ws_floats(size0, size1) : 0;
+  float *gd = gtex ? grays_data : nullptr, *gr = reg_weight > 0.f ? grays_reg : nullptr;
+  const float ld = loss_div > 0.f ? loss_div : 1.0f;
+  const int lin = loss_in ? loss_in_n : 0;
+  // the footprint + halo must fit the workgroup's LDS next to the neighbour list; images too small for the windowed transpose
+  // (reflections of reflections) and windows too large take the separate transpose blur into gts_scratch
+  const int r = blur_ksize / 2;
+  const int wmax = 2 * (int)ceilf(sqrtf(FFX_QCUT * sigma) + 1.0f) + 4 + 2 * r;
+  const size_t lds = (size_t)wmax * wmax * sizeof(float);
+  const bool windowed = blur_ksize > 0 && gtex && lds <= 40 * 1024 && size0 > 2 * r + 2 && size1 > 2 * r + 2;
+  if (blur_ksize > 0 && gtex && !windowed) {
+    if (!gts_scratch) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: this size needs gts_scratch [size1,size0]");
+    const int rc = ffx_blur_bwd(gtex, size1, size0, blur_ksize, blur_sigma, gts_scratch, s);
+    if (rc != FFX_OK) return rc;
+    gtex = gts_scratch;
+  }
+#define FFX_LAUNCH_PB(KS_, LDS_)                                                                                                                              \
+  hipLaunchKernelGGL(k_pattern_bwd<KS_>, dim3(n), dim3(SPLAT_BLOCK), LDS_, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gtex, reg_weight, ws, \
+                     n_ws, gd, gr, reg_value, loss_in, lin, ld, bw, ak)
+  if (!windowed) FFX_LAUNCH_PB(-1, 0);
+  else if (blur_ksize == 5) FFX_LAUNCH_PB(5, lds);
+  else FFX_LAUNCH_PB(0, lds);
+#undef FFX_LAUNCH_PB
+  FFX_CHECK_LAUNCH("pattern_bwd_blur");
   return FFX_OK;
 }
 

@@ -144,6 +144,52 @@ def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, 
     return gd, gr, val
 
 
+def pattern_fwd_blur(rays, KF, sigma, size0, size1, ksize, blur_sigma, want_softor=True, out=None, zero=None):
+    """pattern_fwd + tex = blur_fwd(tsum, ksize, blur_sigma) in one launch (ffx_pattern_fwd_blur) -> (pts, tsum, tsor, ws, tex); `out`: the five
+    tensors to reuse."""
+    n = rays.shape[0]
+    if out is None:
+        pts = torch.empty((n, 2), dtype=torch.float32, device=rays.device)
+        tsum = torch.empty((size1, size0), dtype=torch.float32, device=rays.device)
+        tsor = torch.empty((size1, size0), dtype=torch.float32, device=rays.device) if want_softor else None
+        ws = torch.empty(pattern_ws_floats(size0, size1), dtype=torch.float32, device=rays.device) if want_softor else None
+        tex = torch.empty((size1, size0), dtype=torch.float32, device=rays.device)
+    else:
+        pts, tsum, tsor, ws, tex = out
+    api().call("ffx_pattern_fwd_blur", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), int(bool(want_softor)), _dev(pts), _dev(tsum),
+               _dev(tsor) if want_softor else None, _dev(ws) if want_softor else None, _dev(zero, name="zero") if zero is not None else None,
+               int(zero.numel()) if zero is not None else 0, int(ksize), float(blur_sigma), _dev(tex), _stream())
+    return pts, tsum, tsor, ws, tex
+
+
+def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight, ws, ksize, blur_sigma, loss_in=None, loss_div=1.0, adam=None, scratch=None):
+    """pattern_bwd with K3^T in front (gtex: the gradient on the BLURRED texture; ksize 0: on tsum) and, with `adam` (an _abi.AdamArgs whose
+    rays field names `rays`), the Adam + clamp_to_fov update behind it — one launch (ffx_pattern_bwd_blur).  -> (grays_data, grays_reg, [3])"""
+    n = rays.shape[0]
+    gd = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if gtex is not None else None
+    gr = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if reg_weight > 0 else None
+    val = torch.empty(3, dtype=torch.float32, device=rays.device)
+    api().call("ffx_pattern_bwd_blur", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), _dev(tsum, name="tsum"),
+               _dev(tsor, name="tsor") if tsor is not None else None, _dev(gtex, name="gtex") if gtex is not None else None, float(reg_weight),
+               _dev(ws, name="ws") if ws is not None else None, _dev(gd) if gd is not None else None, _dev(gr) if gr is not None else None, _dev(val),
+               _dev(loss_in, name="loss_in") if loss_in is not None else None, int(loss_in.numel()) if loss_in is not None else 0, float(loss_div),
+               int(ksize), float(blur_sigma), _dev(scratch, name="scratch") if scratch is not None else None, C.byref(adam) if adam is not None else None, _stream())
+    return gd, gr, val
+
+
+def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None):
+    """ffx_adam_args for pattern_bwd_blur (the tensors must outlive the launch; `counter`: one zeroed int32 / uint32 device word)"""
+    a = _abi.AdamArgs()
+    a.rays, a.exp_avg, a.exp_avg_sq = _dev(rays, name="rays").value, _dev(exp_avg, name="exp_avg").value, _dev(exp_avg_sq, name="exp_avg_sq").value
+    a.step = _dev(step, name="step").value
+    a.grad_out = _dev(grad_out, name="grad_out").value if grad_out is not None else None
+    a.counter = _dev(counter, torch.int32, "counter").value
+    a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
+    a.KF_inv = _m16(KF_inv)
+    a.lo, a.hi, a.grad_div, a.n_normalize = float(lo), float(hi), float(grad_div), int(n_normalize)
+    return a
+
+
 def adam_clamp_step_(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, grad_b=None, grad_div=1.0, grad_out=None):
     """in place: torch.optim.Adam's update of `rays` followed by Laser.clamp_to_fov + normalisation, one launch.
     With grad_out the gradient used is grad / grad_div + grad_b (stored in grad_out)."""

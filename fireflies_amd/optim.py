@@ -171,8 +171,15 @@ class PatternOptimizer:
             self._arena = torch.empty(acc_bytes + max(nbytes, 64), dtype=torch.uint8, device=rd.device)
             self._acc = self._arena[: acc_bytes + 64].view(torch.float32)  # what the pattern launch clears: accumulator + cache header
             self._cache = self._arena[acc_bytes:] if use_cache else None
-        pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf, zero=self._acc)
-        tex = ops.blur_fwd(tsum, self.blur[0], self.blur[1]) if self.blur else tsum
+        if self.blur:  # K1 + K2 + K3 in one launch (the blur rides on the splat's tiles)
+            if buf is not None and len(buf) != 5:
+                buf = None
+            pts, tsum, tsor, ws, tex = self._pat_buf = ops.pattern_fwd_blur(rd, KF, self.sigma, s0, s1, self.blur[0], self.blur[1], want_softor=want_reg, out=buf, zero=self._acc)
+        else:
+            if buf is not None and len(buf) != 4:
+                buf = None
+            pts, tsum, tsor, ws = self._pat_buf = ops.pattern_fwd(rd, KF, self.sigma, s0, s1, want_softor=want_reg, out=buf, zero=self._acc)
+            tex = tsum
         tex3 = tex.unsqueeze(-1)
         gtex, loss_slots = self._acc[: s0 * s1].view(tex3.shape), self._acc[s0 * s1: s0 * s1 + n_slots]
         loss_sum = loss_slots[0]
@@ -222,26 +229,34 @@ class PatternOptimizer:
             else:
                 gtex += geom.render_bwd(sd, mats, self.spp, seed, gimg).reshape(gtex.shape)
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
-        gts = None
-        if seeds:
-            g2 = gtex.reshape(tex.shape)
-            gts = ops.blur_bwd(g2, self.blur[0], self.blur[1]) if self.blur else g2
+        # K3^T is applied inside the gradient launch, over the points' footprints only (ffx_pattern_bwd_blur: the gradient of the separate
+        # transpose blur + ffx_pattern_bwd, bit for bit)
+        g2 = gtex.reshape(tex.shape) if seeds else None
+        bk, bs = (self.blur[0], self.blur[1]) if self.blur else (0, 1.0)
         reg_w = self.reg_weight if want_reg else 0.0
         st, g = self._adam_state(rays)
         grad = torch.empty_like(rd)
+        if getattr(self, "_scratch", None) is None or self._scratch.shape != tsum.shape:
+            self._scratch = torch.empty_like(tsum)  # (only touched when a footprint does not fit the workgroup's LDS)
         if w > 1:
-            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_slots, loss_div=float(S))
+            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=loss_slots, loss_div=float(S), scratch=self._scratch)
             flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), val[2:3]])  # (val[2]: this rank's data term)
             dist.allreduce_sum_(flat)  # the ONE exchange of a step: [3N + 1] floats
             gsum = flat[:-1].reshape(rays.shape).contiguous()
             loss = flat[-1] / float(S) + val[0]
-        else:  # nothing to exchange: the total loss comes out of the backward launch, the gradient parts meet in the update launch
-            gd, gr, val = ops.pattern_bwd(rd, KF, self.sigma, s0, s1, tsum, tsor, gts, reg_w, ws, loss_in=loss_slots, loss_div=float(S))
-            gsum = gd if gd is not None else torch.zeros_like(rd)
+            # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()
+            ops.adam_clamp_step_(rd, gsum, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], KF, self.laser._KF_inv,
+                                 1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad)
+        else:
+            # nothing to exchange: the whole backward half is ONE launch — gradient of the data term and of the regulariser, the step's total
+            # loss, and (by the workgroup that finishes last) Adam + Laser.clamp_to_fov() + normalize_rays() on grad = gsum / S + regulariser
+            if getattr(self, "_adam_counter", None) is None:
+                self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
+            aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
+                               1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad)
+            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=loss_slots, loss_div=float(S), adam=aa,
+                                               scratch=self._scratch)
             loss = val[1]
-        # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()
-        ops.adam_clamp_step_(rd, gsum, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], KF, self.laser._KF_inv,
-                             1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad)
         rays.grad = grad
         self.step_index += 1
         self._watch_cache()

@@ -191,6 +191,45 @@ int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[
                         float *exp_avg_sq /*[dev][n,3]*/, float *step /*[dev][1]*/, int n, double lr, double beta1, double beta2,
                         double eps, const float *KF /*[host][16]*/, const float *KF_inv /*[host][16]*/, float lo, float hi,
                         int n_normalize, ffx_stream stream);
+/* The same two launches carrying their neighbours along (round 3: every launch of the pattern side sits on the critical path of
+ * a step, ~5 us each behind a 0.54 ms render):
+ *   ffx_pattern_fwd_blur : ffx_pattern_fwd + tex = ffx_blur_fwd(tsum, blur_ksize, blur_sigma) in ONE launch (a11: the texture
+ *                     finalise of examples/vocalfold_scene.py:59-63) — the workgroup of a 32x8 tile evaluates its halo too and blurs
+ *                     from LDS.  tsum, tsor, ws, tex: bitwise the separate calls' (ksize 5; other sizes run the two launches).
+ *   ffx_pattern_bwd_blur : ffx_pattern_bwd where gtex is d loss / d tex of the BLURRED texture: K3^T (ffx_blur_bwd) is applied inside
+ *                     the gradient launch over the points' footprints only (bitwise the separate calls' gradient; blur_ksize 0: gtex
+ *                     is the gradient on tsum, as ffx_pattern_bwd's gts).  gts_scratch [size1,size0] is only used when a footprint
+ *                     does not fit the workgroup's LDS or the image is smaller than the kernel (then the transpose blur runs as its own
+ *                     launch into it); may be NULL otherwise.
+ *                     adam != NULL: the workgroup that finishes last applies ffx_adam_clamp_step(rays, grays_data, grays_reg,
+ *                     grad_div, grad_out, ...) — the whole backward half of a single-process step is then ONE launch.  `counter`:
+ *                     one device word, zero before the first call (the launch leaves it zero).  A multi-rank step exchanges the
+ *                     gradient between the two and keeps them apart (adam = NULL).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ffx_adam_args {
+  float *rays;        /* [dev][n,3] in/out: must be the `rays` argument of the call */
+  float *exp_avg;     /* [dev][n,3] */
+  float *exp_avg_sq;  /* [dev][n,3] */
+  float *step;        /* [dev][1], incremented */
+  float *grad_out;    /* [dev][n,3] or NULL (needed when there is anything to combine: grays_reg or grad_div != 1) */
+  uint32_t *counter;  /* [dev][1], zero */
+  double lr, beta1, beta2, eps;
+  float KF_inv[16];
+  float lo, hi;       /* Laser.clamp_to_fov's bounds */
+  float grad_div;
+  int32_t n_normalize;
+} ffx_adam_args;
+int ffx_pattern_fwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
+                         int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,
+                         float *tsor /*[dev] or NULL*/, float *ws /*[dev] or NULL*/, float *zero /*[dev][n_zero] or NULL*/, long n_zero,
+                         int blur_ksize, float blur_sigma, float *tex /*[dev][size1,size0]*/, ffx_stream stream);
+int ffx_pattern_bwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
+                         const float *tsum /*[dev]*/, const float *tsor /*[dev] or NULL*/, const float *gtex /*[dev][size1,size0] or NULL*/,
+                         float reg_weight, const float *ws /*[dev] or NULL*/, float *grays_data /*[dev][n,3] or NULL*/,
+                         float *grays_reg /*[dev][n,3] or NULL*/, float *reg_value /*[dev][3] or NULL*/,
+                         const float *loss_in /*[dev][loss_in_n] or NULL*/, int loss_in_n, float loss_div, int blur_ksize,
+                         float blur_sigma, float *gts_scratch /*[dev][size1,size0] or NULL*/, const ffx_adam_args *adam /*[host] or NULL*/,
+                         ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * f1  sampler draws of a scene randomisation, on the host.

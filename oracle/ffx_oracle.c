@@ -1734,3 +1734,35 @@ int ffx_adam_clamp_step(float *rays, const float *grad, const float *grad_b, flo
   step[0] = t;
   return ffx_clamp_to_fov(rays, n, KF, KF_inv, lo, hi, n_normalize, s);
 }
+/* the same steps carried by one call each (include/ffx.h): here simply the compositions they stand for */
+int ffx_pattern_fwd_blur(const float *rays, int n, const float *KF, float sigma, int size0, int size1, int want_softor, float *pts, float *tsum, float *tsor,
+                         float *ws, float *zero, long n_zero, int blur_ksize, float blur_sigma, float *tex, ffx_stream s) {
+  if (!tex) FAIL(FFX_ERR_ARG, "pattern_fwd_blur: tex is NULL");
+  int rc = ffx_pattern_fwd(rays, n, KF, sigma, size0, size1, want_softor, pts, tsum, tsor, ws, zero, n_zero, s);
+  if (rc != FFX_OK) return rc;
+  return ffx_blur_fwd(tsum, size1, size0, blur_ksize, blur_sigma, tex, s);
+}
+
+int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gtex,
+                         float reg_weight, const float *ws, float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div,
+                         int blur_ksize, float blur_sigma, float *gts_scratch, const ffx_adam_args *adam, ffx_stream s) {
+  (void)gts_scratch;
+  if (size0 <= 0 || size1 <= 0) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: bad argument");
+  float *gts = NULL;
+  if (gtex && blur_ksize > 0) {
+    gts = (float *)malloc((size_t)size0 * size1 * sizeof(float));
+    int rc = ffx_blur_bwd(gtex, size1, size0, blur_ksize, blur_sigma, gts, s);
+    if (rc != FFX_OK) { free(gts); return rc; }
+  }
+  int rc = ffx_pattern_bwd(rays, n, KF, sigma, size0, size1, tsum, tsor, gts ? gts : gtex, reg_weight, ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, s);
+  free(gts);
+  if (rc != FFX_OK || !adam) return rc;
+  if (adam->rays != rays) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the update is applied to the rays the gradient was taken at");
+  float *zeros = NULL;
+  const float *gd = gtex ? grays_data : NULL;
+  if (!gd) { zeros = (float *)calloc((size_t)3 * n, sizeof(float)); gd = zeros; }
+  rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
+                           adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, s);
+  free(zeros);
+  return rc;
+}

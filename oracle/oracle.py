@@ -111,6 +111,51 @@ def pattern_bwd(rays, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, 
     return gd, gr, float(val[0]), (float(val[1]), float(val[2]))
 
 
+def pattern_fwd_blur(rays, KF, sigma, size0, size1, ksize, blur_sigma, want_softor=True):
+    """ffx_pattern_fwd_blur -> (pts, tsum, tsor, ws, tex)"""
+    rays = _f32(rays)
+    n = rays.shape[0]
+    pts = np.empty((n, 2), np.float32)
+    tsum = np.empty((size1, size0), np.float32)
+    tsor = np.empty((size1, size0), np.float32) if want_softor else None
+    ws = np.zeros(int(api().lib.ffx_pattern_ws_floats(size0, size1)), np.float32)
+    tex = np.empty((size1, size0), np.float32)
+    api().call("ffx_pattern_fwd_blur", _p(rays), n, _m16(KF), float(sigma), size0, size1, int(want_softor), _p(pts), _p(tsum), _p(tsor) if want_softor else None, _p(ws),
+               None, 0, int(ksize), float(blur_sigma), _p(tex), None)
+    return pts, tsum, tsor, ws, tex
+
+
+def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight, ws, ksize, blur_sigma, loss_in=None, loss_div=1.0, adam=None):
+    """ffx_pattern_bwd_blur -> (grays_data, grays_reg, [3] values).  adam: dict(exp_avg, exp_avg_sq, step (float32 arrays, updated in place —
+    as `rays` is), lr, beta1, beta2, eps, KF_inv, lo, hi, grad_div, n_normalize) -> additionally the gradient used (grad_out)"""
+    import ctypes as C
+
+    from fireflies_amd import _abi
+
+    assert rays.dtype == np.float32 and rays.flags.c_contiguous
+    n = rays.shape[0]
+    gd = np.zeros((n, 3), np.float32)
+    gr = np.zeros((n, 3), np.float32)
+    val = np.zeros(3, np.float32)
+    gtex = None if gtex is None else _f32(gtex)
+    li = None if loss_in is None else _f32(loss_in).reshape(-1)
+    aa, gout = None, None
+    if adam is not None:
+        gout = np.zeros((n, 3), np.float32)
+        cnt = np.zeros(1, np.uint32)
+        aa = _abi.AdamArgs()
+        aa.rays, aa.exp_avg, aa.exp_avg_sq, aa.step = rays.ctypes.data, adam["exp_avg"].ctypes.data, adam["exp_avg_sq"].ctypes.data, adam["step"].ctypes.data
+        aa.grad_out, aa.counter = gout.ctypes.data, cnt.ctypes.data
+        aa.lr, aa.beta1, aa.beta2, aa.eps = float(adam["lr"]), float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"])
+        aa.KF_inv = _m16(adam["KF_inv"])
+        aa.lo, aa.hi, aa.grad_div, aa.n_normalize = float(adam["lo"]), float(adam["hi"]), float(adam.get("grad_div", 1.0)), int(adam.get("n_normalize", 1))
+    api().call("ffx_pattern_bwd_blur", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(_f32(tsum)), _p(_f32(tsor)) if tsor is not None else None,
+               _p(gtex) if gtex is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val),
+               _p(li) if li is not None else None, 0 if li is None else int(li.size), float(loss_div), int(ksize), float(blur_sigma), None,
+               C.byref(aa) if aa is not None else None, None)
+    return (gd, gr, val) if adam is None else (gd, gr, val, gout)
+
+
 def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1):
     """in place on rays / exp_avg / exp_avg_sq / step (float32 arrays)"""
     api().call("ffx_adam_clamp_step", _p(rays), _p(_f32(grad)), None, 1.0, None, _p(exp_avg), _p(exp_avg_sq), _p(step), rays.shape[0], float(lr), float(beta1), float(beta2), float(eps),

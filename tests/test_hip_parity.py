@@ -900,6 +900,88 @@ def test_fused_pattern_kernels_match_the_unfused_oracle(oracle, n, size, sigma):
     np.testing.assert_allclose(host(v_d), host(opt.state[r_t]["exp_avg_sq"]), rtol=1e-6, atol=1e-10)
 
 
+@pytest.mark.parametrize("n,size,sigma,ks", [(64, (96, 80), 10.0, 5), (256, (500, 500), 10.0, 5), (700, (128, 128), 30.0, 5), (40, (70, 33), 10.0, 3),
+                                             (20, (64, 64), 400.0, 5), (9, (6, 40), 4.0, 5)])
+def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, size, sigma, ks):
+    """ffx_pattern_fwd_blur / ffx_pattern_bwd_blur (round 3): the texture finalise K3 rides on the splat's tiles, its transpose is applied
+    inside the gradient launch over the points' footprints only, and the Adam + clamp_to_fov update is done by the workgroup that
+    finishes last.  Bit for bit the separate launches' results (same arithmetic in the same order: that is the design), and the oracle's
+    composition within the tolerances of the separate kernels.  Cases: border points, a 3x3 kernel (run-time size), a footprint too
+    large for the workgroup's LDS and an image narrower than the kernel's reflections (both fall back to the transpose blur as its own
+    launch), points whose footprints hang over the image border."""
+    rng = np.random.default_rng(n)
+    s0, s1 = size
+    g2 = load_golden("g2_projection.npz")
+    KF = (g2["K"] @ FLIP_Y).astype(np.float32)
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    ndc = (rng.random((n, 3)) * np.array([1.0, 1.0, 0.0]) + np.array([0.0, 0.0, -1.0])).astype(np.float32)  # up to the very border
+    rays = oracle.transform_points(ndc, KFi)
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    bs = 3.0
+    # ---- forward
+    pts_a, tsum_a, tsor_a, ws_a = ops.pattern_fwd(dev(rays), KF, sigma, s0, s1, True)
+    tex_a = ops.blur_fwd(tsum_a, ks, bs)
+    buf = torch.full((s0 * s1 + 9,), 7.0, device="cuda")
+    pts_b, tsum_b, tsor_b, ws_b, tex_b = ops.pattern_fwd_blur(dev(rays), KF, sigma, s0, s1, ks, bs, True, zero=buf[1:-1])
+    for a, b, what in ((pts_a, pts_b, "pts"), (tsum_a, tsum_b, "tsum"), (tsor_a, tsor_b, "tsor"), (ws_a, ws_b, "ws"), (tex_a, tex_b, "tex")):
+        assert torch.equal(a, b), what
+    assert float(buf[0]) == 7.0 and float(buf[-1]) == 7.0 and float(buf[1:-1].abs().max()) == 0.0
+    _, tsum_n, tsor_n, ws_n, tex_n = ops.pattern_fwd_blur(dev(rays), KF, sigma, s0, s1, ks, bs, False)  # without the regulariser's outputs
+    assert tsor_n is None and ws_n is None and torch.equal(tsum_n, tsum_a) and torch.equal(tex_n, tex_a)
+    pts_o, tsum_o, tsor_o, ws_o, tex_o = oracle.pattern_fwd_blur(rays, KF, sigma, s0, s1, ks, bs, True)
+    np.testing.assert_allclose(host(tex_b), tex_o, rtol=3e-6, atol=2e-6)
+    # ---- backward: K3^T inside the gradient launch
+    gtex = rng.standard_normal((s1, s0)).astype(np.float32)
+    gtex[rng.random((s1, s0)) < 0.3] = 0.0
+    li = rng.standard_normal(37).astype(np.float32)
+    for w in (0.1, 0.0):
+        gts = ops.blur_bwd(dev(gtex), ks, bs)
+        gd_a, gr_a, val_a = ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_a, tsor_a, gts, w, ws_a, loss_in=dev(li), loss_div=2.0)
+        scratch = torch.empty_like(tsum_a)
+        gd_b, gr_b, val_b = ops.pattern_bwd_blur(dev(rays), KF, sigma, s0, s1, tsum_a, tsor_a, dev(gtex), w, ws_a, ks, bs, loss_in=dev(li), loss_div=2.0, scratch=scratch)
+        assert torch.equal(gd_a, gd_b) and torch.equal(val_a, val_b) and (gr_a is None) == (gr_b is None) and (gr_a is None or torch.equal(gr_a, gr_b))
+        gd_o, gr_o, val_o = oracle.pattern_bwd_blur(rays.copy(), KF, sigma, s0, s1, tsum_o, tsor_o, gtex, w, ws_o, ks, bs, loss_in=li, loss_div=2.0)
+        np.testing.assert_allclose(host(gd_b), gd_o, rtol=3e-4, atol=3e-5 * max(np.abs(gd_o).max(), 1e-20))
+        if w > 0:
+            np.testing.assert_allclose(host(gr_b), gr_o, rtol=5e-4, atol=5e-5 * max(np.abs(gr_o).max(), 1e-20))
+        np.testing.assert_allclose(host(val_b), val_o, rtol=2e-5, atol=2e-5)
+    # ksize 0: gtex is the gradient on the sum texture itself (ffx_pattern_bwd's meaning)
+    gd_c, _, _ = ops.pattern_bwd_blur(dev(rays), KF, sigma, s0, s1, tsum_a, tsor_a, dev(gtex), 0.0, ws_a, 0, 1.0)
+    assert torch.equal(gd_c, ops.pattern_bwd(dev(rays), KF, sigma, s0, s1, tsum_a, tsor_a, dev(gtex), 0.0, ws_a)[0])
+    # ---- the update carried along: three steps, against the separate launches (bitwise) and the oracle
+    def fresh():
+        r = dev(rays).clone()
+        return r, torch.zeros_like(r), torch.zeros_like(r), torch.zeros((), device="cuda")
+
+    (r_a, m_a, v_a, st_a), (r_b, m_b, v_b, st_b) = fresh(), fresh()
+    r_o, m_o, v_o, st_o = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k in range(3):
+        gtex_k = (rng.standard_normal((s1, s0)) * (k + 1)).astype(np.float32)
+        w = 0.1 if k != 1 else 0.0  # (a step without the regulariser in between: grays_reg is then not combined)
+        _, ts_k, to_k, ws_k, _ = ops.pattern_fwd_blur(r_a, KF, sigma, s0, s1, ks, bs, True)
+        gd, gr, _ = ops.pattern_bwd(r_a, KF, sigma, s0, s1, ts_k, to_k, ops.blur_bwd(dev(gtex_k), ks, bs), w, ws_k)
+        g_a = torch.empty_like(r_a)
+        ops.adam_clamp_step_(r_a, gd, m_a, v_a, st_a, 5e-3, 0.9, 0.999, 1e-8, KF, KFi, 0.05, 0.95, 2, grad_b=gr, grad_div=4.0, grad_out=g_a)
+        _, ts_b, to_b, ws_kb, _ = ops.pattern_fwd_blur(r_b, KF, sigma, s0, s1, ks, bs, True)
+        g_b = torch.empty_like(r_b)
+        aa = ops.adam_args(r_b, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_b)
+        ops.pattern_bwd_blur(r_b, KF, sigma, s0, s1, ts_b, to_b, dev(gtex_k), w, ws_kb, ks, bs, adam=aa, scratch=torch.empty_like(ts_b))
+        assert torch.equal(r_a, r_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b) and torch.equal(g_a, g_b) and float(st_b) == k + 1 and int(counter) == 0
+        _, ts_ok, to_ok, ws_ok, _ = oracle.pattern_fwd_blur(r_o, KF, sigma, s0, s1, ks, bs, True)
+        _, _, _, g_o = oracle.pattern_bwd_blur(r_o, KF, sigma, s0, s1, ts_ok, to_ok, gtex_k, w, ws_ok, ks, bs,
+                                               adam=dict(exp_avg=m_o, exp_avg_sq=v_o, step=st_o, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, KF_inv=KFi, lo=0.05, hi=0.95,
+                                                         grad_div=4.0, n_normalize=2))
+        np.testing.assert_allclose(host(g_b), g_o, rtol=1e-3, atol=1e-4 * max(np.abs(g_o).max(), 1e-20))
+    np.testing.assert_allclose(host(r_b), r_o, rtol=1e-4, atol=2e-5)  # (Adam's first steps are sign-like: tiny gradient differences move a ray by lr at most)
+    # misuse is refused: an update of other rays than the gradient's, Adam arguments without a counter
+    bad = ops.adam_args(r_a, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_b)
+    with pytest.raises(Exception, match="rays the gradient was taken at"):
+        ops.pattern_bwd_blur(r_b, KF, sigma, s0, s1, ts_b, to_b, dev(gtex), 0.1, ws_kb, ks, bs, adam=bad)
+    with pytest.raises(Exception, match="ksize"):
+        ops.pattern_fwd_blur(dev(rays), KF, sigma, s0, s1, 4, bs, True)
+
+
 def test_dpp_three_chain_reduction_against_shuffle_reference(tmp_path):
     """the interleaved DPP / row_bcast wave reduction that make_widepk uses for the packet bounds
     (ffx_trace.hip: wave_reduce3_nn), compiled as the stand-alone checker tools/ubench/reduce3_check.hip and compared
