@@ -2600,6 +2600,89 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same with 16x16-pixel blocks (round 3, the default).  Most of K9's time was not the scatter but finding out that there is nothing to
+// scatter: 96 % of the pixels of a dot pattern's render are unlit, and a workgroup of the 8x8 kernel spent an LDS clear, two barriers
+// and a dependent header -> atomicMin chain on 64 of its 256 lanes to learn that (4096 workgroups in two rounds: 20 us for 8 MB).
+// Here every lane owns a pixel in pass 1 — header, <gimg, img>, a ballot — and a workgroup without a lit pixel ends after ONE round of
+// independent loads; the lit pixels are compacted into a list that pass 2 walks 8 at a time (32 lanes per pixel, 25 footprint weights),
+// through a 48x48-texel LDS tile anchored at the smallest window origin.
+#define K9_TILE16 48
+__global__ void __launch_bounds__(256)
+    k_render_bwd_cached_tiled16(BwdP p_by_value, const char *__restrict__ cache, int blocks_x, int tile_blocks, const float *__restrict__ gimg,
+                                float *__restrict__ gtex) {
+  __shared__ float s_tile[K9_TILE16 * K9_TILE16];
+  __shared__ int s_ox, s_oy, s_n;
+  __shared__ unsigned short s_list[256];
+  const BwdP &p = kernarg_first<BwdP>();
+  const float *albedo = mat_table(p);
+  const long n_pix = (long)p.W * p.H;
+  if ((int)blockIdx.x >= tile_blocks) { // the tail of the grid replays the stray records
+    k9_stray(cache, n_pix, (uint32_t)((int)blockIdx.x - tile_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
+    return;
+  }
+  const int bx = (int)blockIdx.x % blocks_x, by = (int)blockIdx.x / blocks_x;
+  const CachePix *hdrs = reinterpret_cast<const CachePix *>(cache + 64);
+  const CacheFoot *foots = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix));
+  if (threadIdx.x == 0) { s_ox = 0x7fffffff; s_oy = 0x7fffffff; s_n = 0; }
+  __syncthreads();
+  // pass 1: one lane per pixel of the 16x16 block
+  {
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = bx * 16 + lx, y = by * 16 + ly;
+    const bool in = x < p.W && y < p.H;
+    const long pixel = (long)y * p.W + x;
+    CachePix hp;
+    hp.lit = 0;
+    if (in) hp = hdrs[pixel];
+    const bool lit = in && hp.lit;
+    float d = (in && p.dot_out) ? k9_pixel_dot(p, pixel, gimg) : 0.f;
+    const wmask lm = wballot(lit);
+    if (lm != 0ull) { // (per wave) origin of the tile and the wave's share of the list
+      if (lit) { atomicMin(&s_ox, (int)hp.x0); atomicMin(&s_oy, (int)hp.y0); }
+      int base = 0;
+      if ((threadIdx.x & 63) == 0) base = atomicAdd(&s_n, wpop(lm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (lit) s_list[base + (int)mbcnt64(lm)] = (unsigned short)threadIdx.x;
+    }
+    if (p.dot_out) { // <gimg, img> of this wave's 4 rows: one add into the block's own slot (ffx_render_dot_slots)
+      d = wave_sum64(d);
+      if ((threadIdx.x & 63) == 0 && d != 0.f) atomicAdd(p.dot_out + (int)blockIdx.x % p.dot_slots, d);
+    }
+  }
+  __syncthreads();
+  const int n_lit = s_n;
+  if (n_lit == 0) return; // (uniform: nothing lit in this block)
+  for (int i = threadIdx.x; i < K9_TILE16 * K9_TILE16; i += 256) s_tile[i] = 0.f;
+  __syncthreads();
+  const int ox = s_ox, oy = s_oy;
+  // pass 2: 32 lanes per lit pixel (25 footprint elements), 8 pixels per iteration
+  const int e = threadIdx.x & 31;
+  for (int it = threadIdx.x >> 5; it < n_lit; it += 8) {
+    if (e >= 25) continue;
+    const int pl = (int)s_list[it];
+    const long pixel = (long)(by * 16 + (pl >> 4)) * p.W + (bx * 16 + (pl & 15));
+    const CachePix hp = hdrs[pixel];
+    const float w = foots[pixel].w[e];
+    const float wb = p.ms == 3 ? 0.f : reinterpret_cast<const CacheFoot *>(cache + p.off_foot_b)[pixel].w[e];
+    if (w == 0.f && wb == 0.f) continue;
+    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+    const float *alb = albedo + p.ms * (int)hp.shape;
+    const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
+    float val = ws * w;
+    if (wb != 0.f) val += (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp * wb;
+    if (val == 0.f) continue;
+    const int tx = (int)hp.x0 + e % 5, ty = (int)hp.y0 + e / 5;
+    const int lx = tx - ox, ly = ty - oy;
+    if (lx < K9_TILE16 && ly < K9_TILE16) atomicAdd(&s_tile[ly * K9_TILE16 + lx], val); // (lx, ly >= 0 by construction)
+    else atomicAdd(gtex + (size_t)ty * p.tw + tx, val);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K9_TILE16 * K9_TILE16; i += 256) {
+    const float v = s_tile[i];
+    if (v != 0.f) atomicAdd(gtex + (size_t)(oy + i / K9_TILE16) * p.tw + (ox + i % K9_TILE16), v);
+  }
+}
+
 __global__ void __launch_bounds__(256)
     k_render_bwd_cached(BwdP p_by_value, const char *__restrict__ cache, long n_pix, int slot_blocks, const float *__restrict__ gimg, float *__restrict__ gtex) {
   const BwdP &p = kernarg_first<BwdP>();
@@ -3062,8 +3145,17 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   if (p.ms != 3 && p.ms != FFX_MAT_STRIDE) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad material stride");
   p.off_foot_b = cache_off_foot_b((size_t)n_pix, cache_stray_capacity(sd->cam.width, sd->cam.height, spp));
   const int stray_blocks = ffx_cdiv((long)cache_stray_capacity(sd->cam.width, sd->cam.height, spp), 256);
+  const char *k9e = getenv("FFX_K9_BLOCK"); // (8: the round-2 kernel, for A/B; read per call like the other knobs)
+  const int k9_block = (k9e && atoi(k9e) == 8) ? 8 : 16;
+  if (p.tc == 1 && k9_block == 16) {
+    // footprints by 16x16-pixel blocks through an LDS tile; the tail of the grid replays the stray records
+    const int blocks_x = ffx_cdiv(p.W, 16), blocks_y = ffx_cdiv(p.H, 16);
+    hipLaunchKernelGGL(k_render_bwd_cached_tiled16, dim3(blocks_x * blocks_y + stray_blocks), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, blocks_x,
+                       blocks_x * blocks_y, gimg, gtex);
+    FFX_CHECK_LAUNCH("render_bwd_cached/tiled16");
+    return FFX_OK;
+  }
   if (p.tc == 1) {
-    // footprints by 8x8-pixel blocks through an LDS tile; the tail of the grid replays the stray records
     const int blocks_x = ffx_cdiv(p.W, 8), blocks_y = ffx_cdiv(p.H, 8);
     hipLaunchKernelGGL(k_render_bwd_cached_tiled, dim3(blocks_x * blocks_y + stray_blocks), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, blocks_x,
                        blocks_x * blocks_y, gimg, gtex);

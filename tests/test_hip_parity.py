@@ -652,14 +652,15 @@ def test_k8k9_every_kernel_variant_matches_the_oracle(oracle, env, monkeypatch):
         assert gs > 0 and (gerr > 1e-3 * gs).mean() <= 1e-3 and gerr.max() <= 0.1 * gs, env
 
 
-@pytest.mark.parametrize("ch", [1, 3])
-def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch):
+@pytest.mark.parametrize("ch,k9_block", [(1, "16"), (1, "8"), (3, "16")])
+def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch, k9_block, monkeypatch):
     """store-instead-of-retrace: the forward also writes, per pixel, the footprint of its samples in the
     projector texture (5x5 weights + window origin + shape; single samples that do not fit go to a small
     arena); the adjoint scatters the footprints.  Same image as the plain forward (bitwise), same gradient as
     the re-tracing adjoint and as the oracle (whose own cache keeps one record per sample — the cache is opaque,
     each library reads only what it wrote); it survives a re-fit between forward and backward; and it is an
     order of magnitude smaller than one record per sample."""
+    monkeypatch.setenv("FFX_K9_BLOCK", k9_block)  # (1-channel textures: 16x16-pixel blocks by default, the round-2 8x8 kernel for A/B)
     sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
     xf = _rand_xforms(2, 5)
     go, gd, alb = _pair(oracle, sc, frame=2, xforms=xf)
