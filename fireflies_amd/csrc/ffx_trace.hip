@@ -2612,7 +2612,10 @@ __global__ void __launch_bounds__(256)
                                 float *__restrict__ gtex) {
   __shared__ float s_tile[K9_TILE16 * K9_TILE16];
   __shared__ int s_ox, s_oy, s_n;
-  __shared__ unsigned short s_list[256];
+  // the lit pixels of the block, compacted: pixel (lane of pass 1), window origin, and the two per-pixel factors of its footprints
+  __shared__ unsigned short s_px[256];
+  __shared__ int s_xy[256];
+  __shared__ float s_ws[256], s_wsb[256];
   const BwdP &p = kernarg_first<BwdP>();
   const float *albedo = mat_table(p);
   const long n_pix = (long)p.W * p.H;
@@ -2623,6 +2626,7 @@ __global__ void __launch_bounds__(256)
   const int bx = (int)blockIdx.x % blocks_x, by = (int)blockIdx.x / blocks_x;
   const CachePix *hdrs = reinterpret_cast<const CachePix *>(cache + 64);
   const CacheFoot *foots = reinterpret_cast<const CacheFoot *>(cache + cache_off_foot((size_t)n_pix));
+  const CacheFoot *foots_b = reinterpret_cast<const CacheFoot *>(cache + p.off_foot_b);
   if (threadIdx.x == 0) { s_ox = 0x7fffffff; s_oy = 0x7fffffff; s_n = 0; }
   __syncthreads();
   // pass 1: one lane per pixel of the 16x16 block
@@ -2635,16 +2639,30 @@ __global__ void __launch_bounds__(256)
     hp.lit = 0;
     if (in) hp = hdrs[pixel];
     const bool lit = in && hp.lit;
-    float d = (in && p.dot_out) ? k9_pixel_dot(p, pixel, gimg) : 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (in && (p.dot_out || lit)) { g0 = gimg[pixel * 3]; g1 = gimg[pixel * 3 + 1]; g2 = gimg[pixel * 3 + 2]; }
     const wmask lm = wballot(lit);
     if (lm != 0ull) { // (per wave) origin of the tile and the wave's share of the list
-      if (lit) { atomicMin(&s_ox, (int)hp.x0); atomicMin(&s_oy, (int)hp.y0); }
       int base = 0;
       if ((threadIdx.x & 63) == 0) base = atomicAdd(&s_n, wpop(lm));
       base = __builtin_amdgcn_readfirstlane(base);
-      if (lit) s_list[base + (int)mbcnt64(lm)] = (unsigned short)threadIdx.x;
+      if (lit) {
+        atomicMin(&s_ox, (int)hp.x0);
+        atomicMin(&s_oy, (int)hp.y0);
+        const float *alb = albedo + p.ms * (int)hp.shape;
+        const int k = base + (int)mbcnt64(lm);
+        s_px[k] = (unsigned short)threadIdx.x;
+        s_xy[k] = (int)hp.x0 | ((int)hp.y0 << 16);
+        s_ws[k] = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
+        s_wsb[k] = (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp;
+      }
     }
     if (p.dot_out) { // <gimg, img> of this wave's 4 rows: one add into the block's own slot (ffx_render_dot_slots)
+      float d = 0.f;
+      if (in) {
+        if (p.img_fp16) { const _Float16 *q = (const _Float16 *)p.img + pixel * 3; d = g0 * (float)q[0] + g1 * (float)q[1] + g2 * (float)q[2]; }
+        else { const float *q = (const float *)p.img + pixel * 3; d = g0 * q[0] + g1 * q[1] + g2 * q[2]; }
+      }
       d = wave_sum64(d);
       if ((threadIdx.x & 63) == 0 && d != 0.f) atomicAdd(p.dot_out + (int)blockIdx.x % p.dot_slots, d);
     }
@@ -2655,26 +2673,36 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < K9_TILE16 * K9_TILE16; i += 256) s_tile[i] = 0.f;
   __syncthreads();
   const int ox = s_ox, oy = s_oy;
-  // pass 2: 32 lanes per lit pixel (25 footprint elements), 8 pixels per iteration
+  // pass 2: 32 lanes per lit pixel (25 footprint weights), 8 pixels side by side and four of those rounds in flight (the block of a
+  // laser dot holds ~140 lit pixels: walked one round at a time its dependent loads were the tail of the whole launch)
   const int e = threadIdx.x & 31;
-  for (int it = threadIdx.x >> 5; it < n_lit; it += 8) {
-    if (e >= 25) continue;
-    const int pl = (int)s_list[it];
-    const long pixel = (long)(by * 16 + (pl >> 4)) * p.W + (bx * 16 + (pl & 15));
-    const CachePix hp = hdrs[pixel];
-    const float w = foots[pixel].w[e];
-    const float wb = p.ms == 3 ? 0.f : reinterpret_cast<const CacheFoot *>(cache + p.off_foot_b)[pixel].w[e];
-    if (w == 0.f && wb == 0.f) continue;
-    const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
-    const float *alb = albedo + p.ms * (int)hp.shape;
-    const float ws = (g0 * alb[0] * p.color[0] + g1 * alb[1] * p.color[1] + g2 * alb[2] * p.color[2]) * p.inv_spp;
-    float val = ws * w;
-    if (wb != 0.f) val += (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp * wb;
-    if (val == 0.f) continue;
-    const int tx = (int)hp.x0 + e % 5, ty = (int)hp.y0 + e / 5;
-    const int lx = tx - ox, ly = ty - oy;
-    if (lx < K9_TILE16 && ly < K9_TILE16) atomicAdd(&s_tile[ly * K9_TILE16 + lx], val); // (lx, ly >= 0 by construction)
-    else atomicAdd(gtex + (size_t)ty * p.tw + tx, val);
+  const bool has_b = p.ms != 3;
+  for (int it0 = threadIdx.x >> 5; it0 < n_lit; it0 += 32) {
+    float w[4], wb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = it0 + 8 * u;
+      w[u] = 0.f; wb[u] = 0.f;
+      if (it < n_lit && e < 25) {
+        const int pl = (int)s_px[it];
+        const long pixel = (long)(by * 16 + (pl >> 4)) * p.W + (bx * 16 + (pl & 15));
+        w[u] = foots[pixel].w[e];
+        if (has_b) wb[u] = foots_b[pixel].w[e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = it0 + 8 * u;
+      if (it >= n_lit || (w[u] == 0.f && wb[u] == 0.f)) continue;
+      float val = s_ws[it] * w[u];
+      if (wb[u] != 0.f) val += s_wsb[it] * wb[u];
+      if (val == 0.f) continue;
+      const int xy = s_xy[it];
+      const int tx = (xy & 0xffff) + e % 5, ty = (xy >> 16) + e / 5;
+      const int lx = tx - ox, ly = ty - oy;
+      if (lx < K9_TILE16 && ly < K9_TILE16) atomicAdd(&s_tile[ly * K9_TILE16 + lx], val); // (lx, ly >= 0 by construction)
+      else atomicAdd(gtex + (size_t)ty * p.tw + tx, val);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < K9_TILE16 * K9_TILE16; i += 256) {
