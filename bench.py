@@ -150,7 +150,7 @@ def pmc_traffic(kernel_prefix, tag="r", key=""):
 
 
 # cycles per wave64 instruction per SIMD: the NOMINAL issue rates, which the microbenchmark (tools/ubench/issue_rates.hip,
-# profiles/r2_issue_rates.txt; instruction counts fixed by the asm bodies; >= 4 resident waves) approaches from above:
+# profiles/r3_issue_rates.txt; instruction counts fixed by the asm bodies; >= 4 resident waves) approaches from above:
 #   fast: v_fma/v_mul/v_add/v_fmac_f32 and v_mov on VGPR operands only ......... 2   (measured 2.17 - 2.47)
 #   slow: any VALU op with an SGPR/constant source, min/max/med3, compares, v_cndmask, conversions, integer ops,
 #         DPP, v_readlane/v_writelane, packed fp32 ................................. 4   (measured 4.07 - 4.8)
@@ -182,12 +182,25 @@ def valu_issue(kernel_substr, kernel_ms, key=""):
                 slow = n - fast - trans
                 cyc = fast * VALU_CYCLES["fast"] + slow * VALU_CYCLES["slow"] + trans * VALU_CYCLES["trans"]
                 ceil_ms = 1e3 * cyc / SIMDS / CLOCK_HZ
+                # ... and with the share of the add/mul/fma class that carries a scalar or constant source (tools/isa_mix.py, from the
+                # kernel's disassembly: static) priced at the 4-cycle rate such forms issue at — the figure that says how much a
+                # pure scheduling improvement could still buy
+                forms = {}
+                ff = _profile_files("isa_operand_forms.json", "")
+                if ff:
+                    try:
+                        fr = float(json.load(open(ff[-1]))["scalar_source_fraction"])
+                        cyc2 = cyc + fast * fr * (VALU_CYCLES["slow"] - VALU_CYCLES["fast"])
+                        forms = {"scalar_source_fraction_static": fr, "ceiling_ms_operand_forms": 1e3 * cyc2 / SIMDS / CLOCK_HZ,
+                                 "frac_operand_forms": min(1.0, 1e3 * cyc2 / SIMDS / CLOCK_HZ / kernel_ms), "operand_forms_source": "profiles/" + os.path.basename(ff[-1])}
+                    except Exception:
+                        forms = {}
                 return {"valu_wave_instr_per_launch": n, "fp32_fma_mul_add": fast, "transcendental": trans, "other_valu": slow,
                         "cycles_per_instr": VALU_CYCLES, "simds": SIMDS, "clock_ghz": CLOCK_HZ / 1e9,
-                        "ceiling_ms": ceil_ms, "kernel_ms": kernel_ms, "frac": ceil_ms / kernel_ms,
+                        "ceiling_ms": ceil_ms, "kernel_ms": kernel_ms, "frac": ceil_ms / kernel_ms, **forms,
                         "salu_per_launch": g("SQ_INSTS_SALU"), "smem_per_launch": g("SQ_INSTS_SMEM"), "vmem_per_launch": g("SQ_INSTS_VMEM"),
                         "lds_per_launch": g("SQ_INSTS_LDS"),
-                        "source": f"counts: profiles/{os.path.basename(f)} (committed rocprofv3 --pmc passes of this workload, not this run); rates: profiles/r2_issue_rates.txt; time: this run"}
+                        "source": f"counts: profiles/{os.path.basename(f)} (committed rocprofv3 --pmc passes of this workload, not this run); rates: profiles/r3_issue_rates.txt; time: this run"}
     return None
 
 
@@ -426,6 +439,17 @@ def main():
     k8_ms, k8_n = _kernel_ms(events, "render_fwd")
     upd_ms, _ = _kernel_ms(events, "scene_update")
     events.clear()
+    # a steadier kernel figure than the bracket's two instrumented launches: 16 more steps of the same loop AFTER the bracket (not part of
+    # `value`), every launch between HIP events — the markers keep the next re-fit from overlapping the kernel, so this is K8 alone
+    k8_post_ms = k8_post_n = None
+    if not args.no_render_steps:
+        geom.timing = events
+        for i in range(16):
+            render_step(args.warmup + args.steps + i)
+        geom.timing = None
+        torch.cuda.synchronize()
+        k8_post_ms, k8_post_n = _kernel_ms(events, "render_fwd")
+        events.clear()
     bytes_ = algorithmic_bytes(wl, W, H, fp16=args.fp16)
 
     # ------------------------------------------------------------------ pattern-gradient steps/sec
@@ -513,9 +537,12 @@ def main():
             "algorithmic_bytes_per_launch": bytes_["render_fwd"],
             "avg_kernel_ms": k8_ms,
             "launches_timed": k8_n,
+            "avg_kernel_ms_after_bracket": k8_post_ms,
+            "launches_timed_after_bracket": k8_post_n,
             "valu_issue": valu_issue("k_render_fwd_pk", k8_ms, pkey) if pkey is not None else None,
-            "note": "by design NOT HBM-bound: samples are reduced in registers, so compulsory traffic is ~6 MB per render; the kernel is "
-                    "VALU-issue bound (valu_issue below; SQ counters in profiles/r2_sq_instruction_mix.json, DESIGN 8; SURVEY 8d). rays/s is the meaningful secondary figure.",
+            "note": "by design NOT HBM-bound: samples are reduced in registers, so the compulsory traffic per render is algorithmic_bytes_per_launch (geometry + "
+                    "texture + film, SURVEY 8d); the kernel is bound by VALU / scalar issue (valu_issue below; SQ counters in profiles/r*_sq_instruction_mix.json, "
+                    "phase shares in profiles/r3_phaseclk.txt, DESIGN 8). rays/s is the meaningful secondary figure.",
             "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
         },
         "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_ms},

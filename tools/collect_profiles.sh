@@ -38,6 +38,18 @@ python tools/microbench.py > profiles/${TAG}_microbench.json 2> $OUT/microbench.
 # issue-rate microbenchmark (instruction counts are fixed by the inline-asm bodies; `grep -c` on the .s confirms)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rates issue_rates.hip 2> $OUT/issue_rates_build.log && /tmp/issue_rates > $R/profiles/${TAG}_issue_rates.txt 2>&1)
 fi
+# where K8's wave time goes (shader-clock stamps; needs the -DFFX_TIMERS build: tools/build_variant_lib.sh timers -DFFX_TIMERS, before gpurun)
+if [ -f fireflies_amd/csrc/_stats/libffx_hip_timers.so ]; then
+  if [ -z "$X" ]; then FFX_LIB=fireflies_amd/csrc/_stats/libffx_hip_timers.so python tools/phaseclk.py vocalfold 64 8 > profiles/${TAG}_phaseclk.txt 2> $OUT/phaseclk.log
+  else FFX_LIB=fireflies_amd/csrc/_stats/libffx_hip_timers.so python tools/phaseclk.py colon 256 2 > profiles/${TAG}_phaseclk.txt 2> $OUT/phaseclk.log; fi
+fi
+if [ -z "$X" ]; then
+python tools/isa_mix.py > profiles/${TAG}_isa_operand_forms.json 2> $OUT/isa_mix.log   # (static: needs no GPU, kept with the rest)
+python tools/k8ab.py > profiles/${TAG}_k8ab.txt 2> $OUT/k8ab.log
+(cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1)
+python tools/steptrace.py $OUT/trace > profiles/${TAG}_steptrace.txt 2>> $OUT/trace.log
+rm -rf $OUT/trace
+fi
 # ship the small summaries back (profiles/ is not merged by gpurun, gpurun_out/ is)
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}* gpurun_out/profiles_$TAG/
 rm -rf $OUT/stats $OUT/pmc_* $OUT/gpmc_* $OUT/sq_*
