@@ -60,7 +60,30 @@ def _max_over_ranks(x, device):
     return float(t.item())
 
 
-def _bracket(fn, steps, warmup, device):
+def _images_agree(a, b, spp, what):
+    """the bound of tests/conftest.assert_image_close: all but 2e-4 of the pixel channels within 1e-4 of the image scale, none off by more
+    than one or two samples' worth"""
+    a, b = a.float(), b.float()
+    scale = float(b.max())
+    err = (a - b).abs()
+    bad = float((err > 1e-4 * scale).float().mean())
+    if not (scale > 0 and bad <= 2e-4 and float(err.max()) <= 1.5 * scale / spp):
+        raise SystemExit(f"bench.py preflight: {what}: {bad:.2e} of the pixel channels differ, worst {float(err.max()) / max(scale, 1e-30):.3g} of the scale — not timing a kernel whose output is in doubt")
+    return bad
+
+
+# The GPU's clocks follow its load: after an idle phase (the host-side scene set-up, the garbage collection in front of a bracket) the first
+# ~40 launches of the render kernel run up to 6 % slower than the ones after them, whatever ran before the idle phase, and a latency-bound
+# kernel does not bring them up (tools/posecost.py, profiles/r3_posecost.txt: ten-step windows 0.580 0.563 0.547 0.541 ... after 0.3 s of
+# idle; 0.533 0.547 0.545 ... when 48 back-to-back launches of the same kernel precede the loop).  A 20-step bracket with 5 warm-up steps
+# sits entirely inside that ramp and reads the ramp, not the kernel.  SETTLE_RENDERS launches of the render kernel on the scene's current
+# pose (no randomisation, no re-fit, nothing of a step but the kernel: ~26 ms) are therefore issued right in front of the W warm-up steps
+# of each bracket; the line says so ("clock_settle").  FFX_BENCH_SETTLE=0 turns it off (the cold-start figure: ~4 % lower over 20 steps,
+# the same over 100).  The timed region is untouched: exactly K steps between barrier + synchronize on both sides.
+SETTLE_RENDERS = int(os.environ.get("FFX_BENCH_SETTLE", "48"))
+
+
+def _bracket(fn, steps, warmup, device, preflight=None, settle=None):
     """W untimed steps, then exactly K timed steps between barrier + synchronize on both sides.
     The cyclic garbage collector is paused over the timed steps, as timeit does: a generation-2 pass
     over the scene graphs built during set-up stalls the host for ~70 ms (seen once per ~200 steps),
@@ -73,6 +96,11 @@ def _bracket(fn, steps, warmup, device):
     gc.collect()
     gc.disable()
     try:
+        if preflight is not None:
+            preflight()
+        if settle is not None:
+            for k in range(SETTLE_RENDERS):
+                settle(k)
         for i in range(warmup):
             fn(i)
         torch.cuda.synchronize()
@@ -430,7 +458,31 @@ def main():
         geom.timing = events if _timed(i, w_render, args.steps if not args.no_render_steps else 1) else None
         return render_step(i)
 
-    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev)
+    # Preflight (FFX_BENCH_PREFLIGHT=0: off): before anything is timed on this box, the kernel about to be timed must agree with the library's
+    # OTHER implementation of the same render — the per-lane kernels (one ray per lane, LDS stack, binary BVH: FFX_TRAVERSAL=lane; ~20x
+    # slower, the A/B baseline of DESIGN 5.1) — on the scene's current pose, three sample seeds.  The oracle is the checker of the test
+    # suite and of smoke(); this is the cheap on-device cross-check that a broken build or a faulty box does not produce a benchmark line.
+    # Side effect, stated because it matters for a 20-step bracket: the ~35 ms of GPU work it does end right where the warm-up steps
+    # begin, so the bracket starts at sustained clocks instead of the idle clocks the host-side set-up left (tools/posecost.py: the first
+    # ~50 renders after an idle phase run up to 6 % slower; README "Numbers").
+    preflight = {}
+
+    def preflight_render():
+        imgs = {}
+        for mode in ("lane", None):
+            if mode:
+                os.environ["FFX_TRAVERSAL"] = mode
+            try:
+                imgs[mode] = [mi.render(wl.mi_scene, spp=args.spp, seed=77 + k, fp16=args.fp16).torch() for k in range(3 if args.workload == "vocalfold" else 1)]
+            finally:
+                os.environ.pop("FFX_TRAVERSAL", None)
+        worst = max(_images_agree(a, b, args.spp, "packet kernel vs per-lane kernel") for a, b in zip(imgs[None], imgs["lane"]))
+        preflight["render"] = {"checked": "k_render_fwd_pk against k_render_fwd (FFX_TRAVERSAL=lane) on the current pose", "images": len(imgs[None]),
+                               "pixel_channels_beyond_1e-4_of_scale": worst}
+
+    do_preflight = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ and not args.no_render_steps
+    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev, preflight_render if do_preflight else None,
+                        (lambda k: mi.render(wl.mi_scene, spp=args.spp, seed=k, fp16=args.fp16)) if (SETTLE_RENDERS > 0 and not args.no_render_steps) else None)
     geom.timing = None
     torch.cuda.synchronize()
     renders_per_sec = world * args.steps / t_render
@@ -464,7 +516,39 @@ def main():
             wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup, args.steps) else None
             return opt.step()
 
-        t_grad = _bracket(grad_step, args.steps, args.warmup, dev)
+        def preflight_grad():
+            # the adjoint about to be timed (K9 from the footprint cache K8 writes) against the library's other adjoint (re-tracing every
+            # sample, ffx_render_bwd) on the scene's current pose, four sample seeds; the bound is the parity tests' (float atomics: order)
+            from fireflies_amd import functional as Fn
+            from fireflies_amd import ops
+
+            ms, geom_g = wg.mi_scene, wg.mi_scene.geom
+            sd = ms.scene_desc(tex_channels=1)
+            if not Fn.cache_supported(sd, args.spp):
+                return
+            with torch.no_grad():
+                tex3 = workloads.build_texture(wg).contiguous()
+            tex3 = tex3[..., 1:2].contiguous() if tex3.dim() == 3 else tex3.unsqueeze(-1).contiguous()
+            cache = torch.empty(ops.render_cache_bytes_sd(sd, args.spp), dtype=torch.uint8, device=dev)
+            gimg = torch.zeros((H, W, 3), device=dev)
+            gimg[..., 1] = -1.0 / (H * W)
+            worst = 0.0
+            for k in range(4):
+                mats = ms.materials_arg(sd)
+                geom_g.render_fwd(sd, mats, tex3, args.spp, 55 + k, False, cache=cache)
+                a = geom_g.render_bwd_cached(sd, mats, cache, args.spp, gimg)
+                b = geom_g.render_bwd(sd, mats, args.spp, 55 + k, gimg)
+                scale = float(b.abs().max())
+                err = (a - b).abs()
+                bad = float((err > 1e-3 * scale).float().mean())
+                if not (scale > 0 and bad <= 1e-3 and float(err.max()) <= 0.1 * scale):
+                    raise SystemExit(f"bench.py preflight: cached adjoint vs re-traced adjoint: {bad:.2e} of the texels differ — not timing an adjoint whose output is in doubt")
+                worst = max(worst, bad)
+            preflight["gradient"] = {"checked": "k_render_bwd_cached (from K8's footprint cache) against k_render_bwd_pk (re-tracing) on the current pose", "adjoints": 4,
+                                     "texels_beyond_1e-3_of_scale": worst}
+
+        t_grad = _bracket(grad_step, args.steps, args.warmup, dev, preflight_grad if (do_preflight or (args.no_render_steps and os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ)) else None,
+                          (lambda k: mi.render(wg.mi_scene, spp=args.spp, seed=k)) if SETTLE_RENDERS > 0 else None)
         wg.mi_scene.geom.timing = None
         torch.cuda.synchronize()
         k9_ms, _ = _kernel_ms(gevents, "render_bwd")  # re-tracing adjoint (only above FFX_CACHE_LIMIT_GB)
@@ -518,6 +602,11 @@ def main():
             (f"BASELINE configs[4]: procedural colon scene, {bytes_['F']} triangles, {args.grid**2}-point projector, {W}x{H}, {args.spp} spp, "
              f"{'fp16' if args.fp16 else 'fp32'} radiance buffer"),
             "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render [K8]; texture built once before the loop",
+            "preflight": preflight or None,
+            "clock_settle": {"renders_before_each_bracket": SETTLE_RENDERS,
+                             "what": "launches of the render kernel on the current pose issued in front of the W warm-up steps (not steps: no randomisation, no re-fit, no adjoint)",
+                             "why": "the first ~40 launches after an idle GPU run up to 6 % slower (clock ramp; tools/posecost.py, profiles/r3_posecost.txt): a 20-step bracket "
+                                    "would time the ramp. FFX_BENCH_SETTLE=0 gives the cold-start figure (~4 % lower over 20 steps, equal over 100)"},
             "entity_device": args.entity_device,
             "material": ("principled BSDF (Mitsuba's model, reflection side), parameters randomised as the reference's scripts do" if args.material == "principled"
                          else "diffuse (Lambert)"),
