@@ -73,7 +73,7 @@ def main():
     G = 12 * V + 12 * F + 32 * NN
     xf = torch.eye(4).repeat(2, 1, 1)
     ms = timeit(lambda: geom.update(xf))
-    out.append(row("scene_update (K5+K6, 5 launches)", ms, 12 * V + 48 * F + 128 * NN, f"V={V} F={F} nodes={NN}"))
+    out.append(row("scene_update (K5+K6, one launch)", ms, 12 * V + 48 * F + 128 * NN, f"V={V} F={F} nodes={NN}"))
     cam = wl.mi_scene.camera_struct(0)
     W = H = 512
     for spp, jit in ((1, 0), (64, 1)):
