@@ -97,7 +97,9 @@ def test_self_launcher_refuses_more_ranks_than_devices_and_propagates_failures()
     assert r.returncode != 0 and "only 0 device(s)" in r.stderr and r.stdout.strip() == ""
     r = _run_bench(["--gpus", "2", "--steps", "2"], {"FFX_DIST_BACKEND": "gloo"})
     assert r.returncode != 0 and r.stdout.strip() == ""
-    assert r.stderr.count("bench.py needs a HIP device") == 2  # both ranks were started, each failed loudly
+    # the ranks were started and fail loudly; the launcher terminates the others as soon as the first one has died, so the second
+    # message may or may not have been printed by then (it was a flaky == 2 once)
+    assert 1 <= r.stderr.count("bench.py needs a HIP device") <= 2
     # inside a torchrun environment the world size must match --gpus
     r = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
