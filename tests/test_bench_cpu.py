@@ -42,6 +42,23 @@ def test_valu_ceiling_is_rederivable_and_below_one(bench):
     assert scalar_ms <= avg_ns * 1e-6 * 1.02
 
 
+def test_operand_form_ceiling_is_consistent(bench):
+    """round 3: the share of the add / mul / fma class that carries a scalar source (tools/isa_mix.py, committed) is priced at the
+    4-cycle rate — a ceiling between the nominal one and the kernel time recorded in the same profile set"""
+    forms = json.load(open(bench._profile_files("isa_operand_forms.json")[-1]))
+    assert "k_render_fwd_pk<1, true, 1>" in forms["kernel"]
+    assert forms["with_scalar_or_constant_source"] == sum(v["with_scalar_source"] for v in forms["per_opcode"].values())
+    fr = forms["scalar_source_fraction"]
+    assert 0.2 < fr < 0.7
+    tag = os.path.basename(bench._profile_files("sq_instruction_mix.json")[-1]).split("_")[0]
+    stats = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()
+    avg_ms = float(re.search(r'k_render_fwd_pk[^\n]*?",\d+,\d+,([0-9.]+),', stats).group(1)) * 1e-6
+    vi = bench.valu_issue("k_render_fwd_pk", avg_ms)
+    assert vi["scalar_source_fraction_static"] == fr
+    assert vi["ceiling_ms_operand_forms"] == pytest.approx(vi["ceiling_ms"] + 1e3 * vi["fp32_fma_mul_add"] * fr * 2.0 / 1024 / 2.4e9, rel=1e-9)
+    assert vi["frac"] < vi["frac_operand_forms"] <= 1.0, vi
+
+
 def test_issue_rates_file_backs_the_class_rates(bench):
     txt = open(os.path.join(ROOT, "profiles", "r2_issue_rates.txt")).read()
 
