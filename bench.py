@@ -257,6 +257,28 @@ def _omp_set_threads(n):
         return False
 
 
+def _effective_cores():
+    """threads this process can actually run at once: the affinity mask, cut down to the cgroup's CPU quota where one is set (the GPU box
+    shows 256 logical CPUs to a container that may use 16 of them: 256 OpenMP threads were then 12x one thread, and `cores: 256` wrong)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
     """CPU oracle on the same pose / texture: all host threads (OpenMP over pixels) at `cpu_spp` samples per pixel,
     and ONE thread on a smaller bounded sample; both scaled to the full spp.  Rank 0, N = 1 only."""
@@ -270,6 +292,8 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
     t_upd = time.perf_counter() - t0
     sd = wl.mi_scene.scene_desc(tex_channels=1)
     alb, texh = wl.mi_scene.albedo.cpu().numpy(), tex.detach().cpu().numpy()
+    cores, quota = _effective_cores()
+    _omp_set_threads(cores)
     # whole renders of the same pose (different sample seeds) until >= 10 s of CPU work have been timed
     n, t_r = 0, 0.0
     while n < 8 and t_r < 10.0:
@@ -278,9 +302,10 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
         t_r += time.perf_counter() - t0
         n += 1
     per_render = t_upd + (t_r / n) * (spp_full / cpu_spp)
-    out = {"value": 1.0 / per_render, "unit": "renders/sec", "cores": os.cpu_count(), "kind": "port",
+    out = {"value": 1.0 / per_render, "unit": "renders/sec", "cores": cores, "kind": "port",
            "sample": f"{n} renders of the same pose at {cpu_spp} of {spp_full} spp ({t_r:.1f} s measured in total, scaled x{spp_full / cpu_spp:g}) + refit "
-                     f"{t_upd * 1e3:.1f} ms; gcc -O2 scalar oracle (a restatement for checking, not a tuned CPU renderer), OpenMP over pixels on {os.cpu_count()} threads",
+                     f"{t_upd * 1e3:.1f} ms; gcc -O2 scalar oracle (a restatement for checking, not a tuned CPU renderer), OpenMP over pixels on {cores} threads "
+                     f"(logical CPUs {os.cpu_count()}, affinity {len(os.sched_getaffinity(0))}, cgroup CPU quota {'none' if quota is None else f'{quota:g}'})",
            "mitsuba_scalar_rgb": "unavailable (mitsuba 3.5.0 / drjit 0.4.4 are not installed here or on the GPU box and are not part of /root/reference)"}
     # one thread: a bounded sample (1/16 of the samples per pixel, >= 1), scaled
     spp1 = max(1, spp_full // 16)
@@ -293,7 +318,7 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
             geo.render_fwd(sd, alb, texh, spp1, seed=seed)
             t1 = time.perf_counter() - t0
         finally:
-            _omp_set_threads(os.cpu_count())
+            _omp_set_threads(cores)
         out["one_thread"] = {"value": 1.0 / (t_upd1 + t1 * spp_full / spp1), "unit": "renders/sec", "cores": 1,
                              "sample": f"1 render at {spp1} of {spp_full} spp ({t1:.1f} s measured, scaled x{spp_full / spp1:g}) + refit {t_upd1 * 1e3:.1f} ms"}
     return out

@@ -410,7 +410,13 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   std::vector<int32_t> plan;
   int n_treelets = 0;
   {
-    const int tl_max = getenv("FFX_TREELET_TRIS") ? std::max(FFX_LEAF_MAX, atoi(getenv("FFX_TREELET_TRIS"))) : 1024;
+    // treelet size: <= 1024 triangles, grown (powers of two, up to 8192) until ~128-256 treelets are left — the top of the tree above
+    // them is re-fitted by ONE workgroup after the last treelet has arrived, a serial tail that grows with their number
+    // (tools/refittime.py, MI355X: colon, 524 k triangles: 3004 / 1519 / 751 / 379 / 191 / 95 treelets = 396 / 205 / 134 / 106 /
+    // 100 / 128 us per update; vocal fold, 53 k: 302 / 152 / 76 / 38 / 21 treelets = 55 / 44 / 40 / 45 / 50 us)
+    int tl_auto = 1024;
+    while (tl_auto < 8192 && n_tris / tl_auto > 192) tl_auto *= 2;
+    const int tl_max = getenv("FFX_TREELET_TRIS") ? std::max(FFX_LEAF_MAX, atoi(getenv("FFX_TREELET_TRIS"))) : tl_auto;
     // out-index heights (as the level refit uses them) per build node
     std::vector<int> hgt(b.nodes.size(), 0);
     for (int id = (int)b.nodes.size() - 1; id >= 0; --id) { // children have larger ids than their parent
