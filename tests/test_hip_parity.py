@@ -320,14 +320,15 @@ def test_k5k6_update_is_idempotent_and_tracks_frames(oracle):
     assert torch.equal(blob1, gd.blob[:geo])
 
 
-@pytest.mark.parametrize("cfg", ["hello", "one_leaf", "small", "vocalfold", "colon"])
+@pytest.mark.parametrize("cfg", ["hello", "one_leaf", "small", "vocalfold", "colon", "colon_small_treelets"])
 def test_k5k6_fused_update_writes_the_same_blob_as_the_level_launches(cfg, monkeypatch):
     """round 3: ffx_scene_update is ONE launch — a workgroup per treelet (records, per-triangle boxes, its nodes height
     by height behind workgroup barriers, the wide children that live in its nodes), the last workgroup to arrive
     re-fits the top of the tree.  It must write, bit for bit, what the eight dependent launches it replaces write
     (FFX_REFIT=levels: records, level by level, tail, wide boxes): nodes, records, wide nodes, triangle boxes — for
     a scene that is a single leaf, a tree below one treelet, the vocal fold (~100 treelets) and the colon (~1000), over
-    repeated updates of the same blob (the arrival counter must come back to zero)."""
+    repeated updates of the same blob (the arrival counter must come back to zero).  The builder grows the treelets with the
+    scene (colon: <= 4096 triangles each, ~190 of them); `colon_small_treelets` keeps the 1024-triangle cut (~750, a long top)."""
     if cfg == "hello":
         sc = scenes.hello_world(32, 32)
     elif cfg == "one_leaf":
@@ -339,6 +340,9 @@ def test_k5k6_fused_update_writes_the_same_blob_as_the_level_launches(cfg, monke
         sc = scenes.vocalfold(width=32, height=32, tex=32, frames=4)
     else:
         sc = scenes.colon(width=32, height=32, tex=32)
+    monkeypatch.delenv("FFX_TREELET_TRIS", raising=False)
+    if cfg == "colon_small_treelets":
+        monkeypatch.setenv("FFX_TREELET_TRIS", "1024")  # (read by the host builder)
     pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
     S = len(sc.meshes)
     monkeypatch.setenv("FFX_ASYNC_UPDATE", "0")  # one blob each, everything on the current stream
@@ -348,6 +352,8 @@ def test_k5k6_fused_update_writes_the_same_blob_as_the_level_launches(cfg, monke
     info = gf.info
     assert info.n_treelets >= 1 and info.off_plan > 0
     if cfg == "colon":
+        assert 100 <= info.n_treelets <= 256
+    if cfg == "colon_small_treelets":
         assert info.n_treelets > 500
     end = int(info.off_whdr)  # nodes, order, refit list, records, wide nodes, triangle boxes, wsrc
     for it in range(4):
