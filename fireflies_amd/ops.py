@@ -547,6 +547,7 @@ class DeviceGeometry:
         """FFX_RENDER_APEX_READY if the current blob's apex areas hold `key`; they will after the call either way"""
         i = self._cur if self._async else 0
         if _lane_kernels():
+            self._apex[i] = None  # (a cache-writing render runs the packet kernel — and its pre-pass — even then: claim nothing afterwards)
             return 0
         ready = self._apex[i] == key
         self._apex[i] = key
