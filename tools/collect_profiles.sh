@@ -13,6 +13,9 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# the profiled runs time and count the bracket's own launches only: no clock-settle launches (the same kernel on ONE pose, cheaper than
+# the average random pose: they would pull the per-kernel averages down) and no preflight renders (bench.py: FFX_BENCH_SETTLE / _PREFLIGHT)
+export FFX_BENCH_SETTLE=0 FFX_BENCH_PREFLIGHT=0
 B="--steps 20 --warmup 3 --no-cpu-baseline $X"
 (cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.log)
 for c in FETCH_SIZE WRITE_SIZE; do
