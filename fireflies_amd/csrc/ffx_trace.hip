@@ -293,6 +293,11 @@ __global__ void __launch_bounds__(TR_BLOCK)
 // compiler's IEEE expansions (which also cover denormal and overflow ranges that cannot occur here:
 // arguments are lengths and depths of visible surface points).  Ray generation and the triangle test
 // keep the IEEE forms: they decide WHICH primitive is hit.
+#ifdef FFX_EXP_SEED_LIGHT // timing experiment: the light terms on the bare hardware seeds (1 ulp), like the BSDF
+__device__ __forceinline__ float rcp_nr(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float div_nr(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float sqrt_nr(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
 __device__ __forceinline__ float rcp_nr(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.0f), r);
@@ -308,6 +313,7 @@ __device__ __forceinline__ float sqrt_nr(float x) {
   const float s1 = fmaf(fmaf(-s, s, x), h, s);
   return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
 }
+#endif
 
 // Shading normal of a hit on a record flagged by ffx_smooth (include/ffx.h): the three vertex normals stored next to the
 // record, interpolated with Moller-Trumbore's barycentrics of the hit (P = v0 + u e1 + v e2, recomputed here from the record:
