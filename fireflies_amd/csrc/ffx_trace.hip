@@ -2939,9 +2939,13 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   return 1;
 }
 
-static int xcd_mode() {
+// default 128 workgroups per XCD per round of the blocked interleave; 256 for films above 512 k pixels: with four times the tiles the
+// load still balances at the coarser grain and each L2 walks a smaller part of a larger scene (tools/xcdsweep_colon.sh, config 5:
+// 64 / 128 / 256 / 512 / 1024 / 2048 = 90.1 / 90.2 / 89.7 / 88.2 / 84.2 / 67.7 renders/s at 181 / 128 / 80 / 64 / 56 / 54 MB of raw
+// FETCH_SIZE per launch; the vocal fold at 512x512 loses 1 % at 256)
+static int xcd_mode(long pixels = 0) {
   const char *e = getenv("FFX_XCD_REMAP");
-  int m = e ? atoi(e) : 128;
+  int m = e ? atoi(e) : (pixels > 2L * 512 * 512 ? 256 : 128);
   return m < 0 ? 0 : m;
 }
 
@@ -3082,7 +3086,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const uint32_t foot_b_off = (uint32_t)(cache_off_foot_b((size_t)c.cam.W * c.cam.H, cache_stray_capacity(c.cam.W, c.cam.H, spp)) >> 7);
 #define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
-                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode(), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
+                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
                      arena_off, foot_b_off, nrec, gn, cap_stray)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD(true, 2); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
@@ -3231,7 +3235,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     const WideScene ws = wide_scene(bvh, info);
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
-                     spp, seed_key_of(seed), ptx, pn, xcd_mode(), gimg, gtex, nrec, gn)
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), gimg, gtex, nrec, gn)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1);
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BWD(true, 2); else if (matm == 1) FFX_LAUNCH_BWD(true, 1); else FFX_LAUNCH_BWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_BWD(false, 2); else if (matm == 1) FFX_LAUNCH_BWD(false, 1); else FFX_LAUNCH_BWD(false, 0); }
