@@ -1831,12 +1831,15 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     if (q.ok) {
       const float4 *r4 = reinterpret_cast<const float4 *>(recs + h[r].slot);
       // the unit geometric normal comes from the update (ffx_bvh_info.off_gn: IEEE, the oracle's bits) — re-deriving it from the
-      // record cost 22 VALU per sample (cross, dot, sqrt, reciprocal, scale); only shape id / flag are read from the record here
-      const float4 rc = r4[2], gq = gn[h[r].slot];
-      st[r].shape = __float_as_int(rc.z);
+      // record cost 22 VALU per sample (cross, dot, sqrt, reciprocal, scale) — with the shape id and the smooth flag in its fourth
+      // word: the record itself is only touched by samples that interpolate normals or look up a base-colour texture
+      const float4 gq = gn[h[r].slot];
+      const int gbits = __float_as_int(gq.w); // 0: degenerate triangle; else (shape + 1) | smooth << 30
+      st[r].shape = (gbits & 0x3fffffff) - 1;
       q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
       v3 ng = V3(gq.x, gq.y, gq.z);
-      q.ok = gq.w != 0.f;
+      q.ok = gbits != 0;
+      if (!q.ok) st[r].shape = 0;
       if (q.ok) {
         if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
         q.ng = ng;
@@ -1844,9 +1847,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         float off = (1.0f + pmax) * RAY_EPS;
         q.Po = V3(fmaf(off, ng.x, q.P.x), fmaf(off, ng.y, q.P.y), fmaf(off, ng.z, q.P.z));
         ns = ng;
-        smooth = rc.w != 0.f;
+        smooth = (gbits & 0x40000000) != 0;
         if (wballot(smooth) != 0ull) { // (wave-uniform: scenes without flagged records never enter)
-          const float4 ra = r4[0], rb = r4[1];
+          const float4 ra = r4[0], rb = r4[1], rc = r4[2];
           const v3 ni = interpolated_normal<true>(nrec, smooth ? h[r].slot : 0, ra, rb, rc, o[r], d[r], ng);
           if (smooth) ns = ni;
         }
