@@ -137,6 +137,7 @@ MAT_BASE_TEX = 15
 RENDER_FP16, RENDER_SPARSE_ADJOINT, RENDER_APEX_READY, RENDER_CACHE_ZEROED = 1, 2, 4, 8  # flags in the img_fp16 argument of the render calls
 MAX_BASE_TEX = 4
 MAX_MAT_H = 128
+ADJOINT_DOT_SLOTS = 4096  # FFX_ADJOINT_DOT_SLOTS: partial sums of <gimg, img> in ffx_render_fwd_adjoint
 
 
 PF = C.POINTER(c_f)
@@ -181,6 +182,7 @@ PROTOTYPES = {
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
     "ffx_render_dot_slots": (C.c_size_t, [c_i, c_i]),
+    "ffx_render_fwd_adjoint": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_apex_prepare": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p]),
     "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),
 }

@@ -2168,15 +2168,21 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 #ifndef FFX_PK_MAT_WAVES
 #define FFX_PK_MAT_WAVES 7 // material rows: 75 VGPRs (72 at this setting without spills; 8 waves spill 4)
 #endif
-template <int R, bool WIDE, int MATM>
+template <int R, bool WIDE, int MATM, bool ADJ = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
                     int fp16, void *__restrict__ img, char *__restrict__ cache, int ppw, float inv_spp_arg, uint32_t cache_foot_off, uint32_t cache_arena_off,
-                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec, const float4 *__restrict__ gn, uint32_t cap_stray) {
+                    uint32_t cache_foot_b_off, const float4 *__restrict__ nrec, const float4 *__restrict__ gn, uint32_t cap_stray,
+                    const float *__restrict__ adj_gimg, float *__restrict__ adj_gtex, float *__restrict__ adj_dot) {
   constexpr int NSUB = 4 / R;
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3; // floats per material row
+  // adj_gtex (ffx_render_fwd_adjoint): the adjoint of a loss whose gradient gimg does not depend on the image (a loss linear in it) needs
+  // no second pass — the pixel's footprint is scattered into gtex where it is formed instead of being stored for K9, stray samples at
+  // once: no cache, no arena that could overflow, no launch behind the render.  `fold`: the footprint bookkeeping runs for either mode.
+  // (ADJ is a template parameter: as a run-time mode its three pointers and the epilogue cost the plain forward a dozen scalar spills)
+  const bool fold = ADJ || cache != nullptr;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
   __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
@@ -2198,7 +2204,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int passes = (spp + 63) >> 6;
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
-  if (cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
+  if (!ADJ && cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
   FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
@@ -2214,7 +2220,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     if (wballot(any_live) == 0ull) continue;
     // adjoint cache: window origin (wave-uniform) and shape of this pixel's footprint, -1 until a sample is lit
     int fox = -1, foy = -1, fshape = -1;
-    if (cache) {
+    float fin0 = 0.f, fin1 = 0.f, fin2 = 0.f; // the pixel's value as stored (ffx_render_fwd_adjoint: <gimg, img>)
+    if (fold) {
       // (index laundered: the compiler otherwise keeps &s_foot[lane] in a VGPR across the whole kernel — and, at the
       // 64-VGPR budget, spills it: 256 B of scratch traffic per wave for an address that costs two instructions)
       int lz = lane;
@@ -2242,9 +2249,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, (cache && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, (fold && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
-      if (cache) {
+      if (fold) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
         const bool lit = active[0] && st[0].hit && st[0].has_proj;
         const wmask litm = wballot(lit);
@@ -2273,7 +2280,39 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             }
           }
           const wmask straym = wballot(lit && !in_win);
-          if (straym != 0ull) { // single samples that do not fit the footprint: one allocation per wave
+          if (ADJ && straym != 0ull) { // fused adjoint: the four taps of a sample that does not fit the footprint, at once (k9_stray's arithmetic)
+            if (lit && !in_win) {
+              const ShadeK &ca = kernarg_shade();
+              const float g0 = adj_gimg[(size_t)pix[0] * 3], g1 = adj_gimg[(size_t)pix[0] * 3 + 1], g2 = adj_gimg[(size_t)pix[0] * 3 + 2];
+              const float *alb = mat_table(ca) + MS * st[0].shape;
+              const float pf = st[0].proj_fac, pb = MAT ? st[0].proj_fac_b : 0.f;
+              const float wx0 = st[0].wx0, wx1 = st[0].wx1, wy0 = st[0].wy0, wy1 = st[0].wy1;
+              if (ca.tc == 1) {
+                float wsv = (g0 * alb[0] * ca.p_color[0] + g1 * alb[1] * ca.p_color[1] + g2 * alb[2] * ca.p_color[2]) * pf * inv_spp_u;
+                if (pb != 0.f) wsv += (g0 * ca.p_color[0] + g1 * ca.p_color[1] + g2 * ca.p_color[2]) * pb * inv_spp_u;
+                if (wsv != 0.f) {
+                  atomicAdd(adj_gtex + (size_t)st[0].iy0 * ca.tw + st[0].ix0, wsv * wy0 * wx0);
+                  atomicAdd(adj_gtex + (size_t)st[0].iy0 * ca.tw + st[0].ix1, wsv * wy0 * wx1);
+                  atomicAdd(adj_gtex + (size_t)st[0].iy1 * ca.tw + st[0].ix0, wsv * wy1 * wx0);
+                  atomicAdd(adj_gtex + (size_t)st[0].iy1 * ca.tw + st[0].ix1, wsv * wy1 * wx1);
+                }
+              } else {
+                const size_t o00 = ((size_t)st[0].iy0 * ca.tw + st[0].ix0) * 3, o01 = ((size_t)st[0].iy0 * ca.tw + st[0].ix1) * 3;
+                const size_t o10 = ((size_t)st[0].iy1 * ca.tw + st[0].ix0) * 3, o11 = ((size_t)st[0].iy1 * ca.tw + st[0].ix1) * 3;
+                const float gg[3] = {g0, g1, g2};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                  float wsv = gg[ch] * alb[ch] * pf * inv_spp_u;
+                  if (pb != 0.f) wsv += gg[ch] * pb * inv_spp_u;
+                  if (wsv == 0.f) continue;
+                  atomicAdd(adj_gtex + o00 + ch, wsv * wy0 * wx0);
+                  atomicAdd(adj_gtex + o01 + ch, wsv * wy0 * wx1);
+                  atomicAdd(adj_gtex + o10 + ch, wsv * wy1 * wx0);
+                  atomicAdd(adj_gtex + o11 + ch, wsv * wy1 * wx1);
+                }
+              }
+            }
+          } else if (!ADJ && straym != 0ull) { // single samples that do not fit the footprint: one allocation per wave
             CacheHdr *hdr = reinterpret_cast<CacheHdr *>(cache);
             const uint32_t n = (uint32_t)wpop(straym);
             uint32_t base = 0;
@@ -2370,11 +2409,50 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
               p[o + 2] = vmul_s(a2, inv_spp_u);
             }
           }
+          if (ADJ && adj_dot) { // (wave-uniform values: the same in every lane)
+            fin0 = (fp16 & 1) ? (float)(_Float16)vmul_s(a0, inv_spp_u) : vmul_s(a0, inv_spp_u);
+            fin1 = (fp16 & 1) ? (float)(_Float16)vmul_s(a1, inv_spp_u) : vmul_s(a1, inv_spp_u);
+            fin2 = (fp16 & 1) ? (float)(_Float16)vmul_s(a2, inv_spp_u) : vmul_s(a2, inv_spp_u);
+          }
         }
       }
       FFX_TSTOP(tk, 23);
     }
-    if (cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
+    if (ADJ && live[0]) { // fused adjoint: the pixel's footprint x (gimg . albedo . colour) / spp goes straight into gtex (K9's arithmetic)
+      __builtin_amdgcn_wave_barrier();
+      const ShadeK &ca = kernarg_shade();
+      const float g0 = adj_gimg[(size_t)pix[0] * 3], g1 = adj_gimg[(size_t)pix[0] * 3 + 1], g2 = adj_gimg[(size_t)pix[0] * 3 + 2];
+      if (fox >= 0) {
+        int lw = lane;
+        asm volatile("" : "+v"(lw));
+        if (lw < 25) {
+          const float *alb = mat_table(ca) + MS * fshape;
+          const float w = s_foot[lw];
+          float wb = 0.f;
+          if constexpr (MAT) wb = s_foot_b[lw];
+          const int ey = (lw * 13) >> 6, ex = lw - 5 * ey; // lw / 5, lw % 5 for lw < 25
+          const int tx = fox + ex, ty = foy + ey;
+          if (w != 0.f || wb != 0.f) {
+            if (ca.tc == 1) {
+              const float wsv = (g0 * alb[0] * ca.p_color[0] + g1 * alb[1] * ca.p_color[1] + g2 * alb[2] * ca.p_color[2]) * inv_spp_u;
+              float val = wsv * w;
+              if (wb != 0.f) val += (g0 * ca.p_color[0] + g1 * ca.p_color[1] + g2 * ca.p_color[2]) * inv_spp_u * wb;
+              if (val != 0.f) atomicAdd(adj_gtex + (size_t)ty * ca.tw + tx, val);
+            } else {
+              float *t = adj_gtex + ((size_t)ty * ca.tw + tx) * 3;
+              if (g0 != 0.f) atomicAdd(t, g0 * alb[0] * inv_spp_u * w + g0 * inv_spp_u * wb);
+              if (g1 != 0.f) atomicAdd(t + 1, g1 * alb[1] * inv_spp_u * w + g1 * inv_spp_u * wb);
+              if (g2 != 0.f) atomicAdd(t + 2, g2 * alb[2] * inv_spp_u * w + g2 * inv_spp_u * wb);
+            }
+          }
+        }
+      }
+      if (adj_dot && lane == 0) { // <gimg, img> of this pixel into one of FFX_ADJOINT_DOT_SLOTS partial sums (256 cache lines: a quarter of a
+        const float dd = g0 * fin0 + g1 * fin1 + g2 * fin2; // million atomics over the launch meet ~1000 times per line, not on one address)
+        if (dd != 0.f) atomicAdd(adj_dot + (pix[0] & (FFX_ADJOINT_DOT_SLOTS - 1)), dd);
+      }
+    }
+    if (!ADJ && cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) {
         CachePix hp;
@@ -3052,7 +3130,8 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
 }
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
-                           uint32_t seed, int call_flags, void *img, void *cache, ffx_stream s) {
+                           uint32_t seed, int call_flags, void *img, void *cache, ffx_stream s, const float *adj_gimg = nullptr, float *adj_gtex = nullptr,
+                           float *adj_dot = nullptr) {
   const int img_fp16 = call_flags & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT); // what the kernels see; the other bits steer the pre-pass
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
@@ -3070,14 +3149,15 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (cache && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
   if (cache && sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache: texture larger than 4094^2 or more than 255 shapes");
-  if ((use_packet() || cache) && !gn) FFX_FAIL(FFX_ERR_ARG, "render_fwd: blob without per-slot normals (built by another library version?)");
-  if (use_packet() || cache) { // the per-sample cache is written by the packet kernels
+  if (adj_gtex && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
+  if ((use_packet() || cache || adj_gtex) && !gn) FFX_FAIL(FFX_ERR_ARG, "render_fwd: blob without per-slot normals (built by another library version?)");
+  if (use_packet() || cache || adj_gtex) { // the per-sample cache / the fused adjoint are the packet kernels' 
     const int tb = tile_block_log2();
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
     int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb); // whole blocks; tiles outside the image are skipped
     ptx |= tb << 24;
     const int wpb = packet_waves();
-    const int ppw = pixels_per_wave(cache != nullptr);
+    const int ppw = pixels_per_wave(cache != nullptr || adj_gtex != nullptr);
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
@@ -3087,14 +3167,16 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
     const uint32_t foot_off = (uint32_t)(cache_off_foot((size_t)c.cam.W * c.cam.H) >> 7), arena_off = (uint32_t)(cache_off_arena((size_t)c.cam.W * c.cam.H) >> 7);
     const uint32_t foot_b_off = (uint32_t)(cache_off_foot_b((size_t)c.cam.W * c.cam.H, cache_stray_capacity(c.cam.W, c.cam.H, spp)) >> 7);
-#define FFX_LAUNCH_FWD(WIDE_, MAT_)                                                                                                                      \
-  hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws,    \
+#define FFX_LAUNCH_FWD_(WIDE_, MAT_, ADJ_)                                                                                                               \
+  hipLaunchKernelGGL((k_render_fwd_pk<1, WIDE_, MAT_, ADJ_>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16, img, (char *)cache, ppw, 1.0f / (float)spp, foot_off,     \
-                     arena_off, foot_b_off, nrec, gn, cap_stray)
+                     arena_off, foot_b_off, nrec, gn, cap_stray, adj_gimg, adj_gtex, adj_dot)
+#define FFX_LAUNCH_FWD(WIDE_, MAT_) do { if (adj_gtex) FFX_LAUNCH_FWD_(WIDE_, MAT_, true); else FFX_LAUNCH_FWD_(WIDE_, MAT_, false); } while (0)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
-    if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD(true, 2); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
-    else { if (matm == 2) FFX_LAUNCH_FWD(false, 2); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
+    if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD_(true, 2, false); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
+    else { if (matm == 2) FFX_LAUNCH_FWD_(false, 2, false); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
 #undef FFX_LAUNCH_FWD
+#undef FFX_LAUNCH_FWD_
     FFX_CHECK_LAUNCH("render_fwd");
     return FFX_OK;
   }
@@ -3138,6 +3220,14 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
     FFX_FAIL(FFX_ERR_LAUNCH, "render_cache_status: reading the cache header failed");
   out3[0] = h.n_stray; out3[1] = h.cap_stray; out3[2] = h.dropped;
   return FFX_OK;
+}
+
+int ffx_render_fwd_adjoint(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                           uint32_t seed, int img_fp16, void *img, const float *gimg, float *gtex, float *dot_out, ffx_stream s) {
+  if (!gimg || !gtex) FFX_FAIL(FFX_ERR_ARG, "render_fwd_adjoint: gimg / gtex is NULL");
+  if (sd && !sd->proj.enabled) FFX_FAIL(FFX_ERR_ARG, "render_fwd_adjoint: the scene has no projector (nothing to differentiate)");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT | FFX_RENDER_APEX_READY), img, nullptr, s, gimg,
+                         gtex, dot_out);
 }
 
 int ffx_apex_prepare(void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, ffx_stream s) {

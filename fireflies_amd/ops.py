@@ -643,6 +643,27 @@ class DeviceGeometry:
         self._release()
         return img
 
+    def render_fwd_adjoint(self, sd, albedo, tex, spp, seed, gimg, out=None, dot_out=None, fp16=False, sparse_adjoint=False):
+        """K8 with the adjoint folded in (ffx_render_fwd_adjoint): for a loss whose gradient `gimg` [H,W,3] does not depend on the image.
+        -> (img, gtex): the render, and gtex (+)= its adjoint applied to gimg — `out`: accumulate into this [tex_h, tex_w, channels]
+        tensor instead of a fresh zeroed one.  dot_out: _abi.ADJOINT_DOT_SLOTS float32 partial sums that <gimg, img> is added to."""
+        H, W = sd.cam.height, sd.cam.width
+        mats_arg = _check_materials(sd, albedo)
+        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
+        if tuple(gimg.shape) != (H, W, 3):
+            raise ValueError("gimg must be [H, W, 3]")
+        if dot_out is not None and (dot_out.dtype != torch.float32 or dot_out.numel() != _abi.ADJOINT_DOT_SLOTS):
+            raise ValueError(f"dot_out must hold {_abi.ADJOINT_DOT_SLOTS} float32 partial sums (the caller zeroes and sums them)")
+        blob = self.blob
+        flags = int(bool(fp16)) | (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | self._apex_flag(apex_key(sd))
+        with self._timed("render_fwd"):
+            self._call("ffx_render_fwd_adjoint", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, _dev(tex, name="tex"), int(spp),
+                       int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _dev(gimg, name="gimg"), _dev(gtex), _dev(dot_out) if dot_out is not None else None,
+                       _stream(self._didx))
+        self._release()
+        return img, gtex
+
     def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None, img=None, dot_out=None):
         """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
         `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one.

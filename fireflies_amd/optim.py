@@ -14,11 +14,12 @@ examples/09_point_pattern_optimization.py and examples/11_domain_specific_patter
         all-reduce [3N+1]; Adam step; laser.clamp_to_fov(); laser.normalize_rays()
                                                                   (laser.py:199-206,254-255)
 """
+import os
 import random
 
 import torch
 
-from . import dist
+from . import _abi, dist
 from . import functional as Fn
 from .scene import StaleDrawError
 
@@ -162,9 +163,13 @@ class PatternOptimizer:
         # (FFX_RENDER_CACHE_ZEROED: the step's first render then has nothing to reset — with the apex records written behind the
         # re-fit, ops.DeviceGeometry.update, it launches no pre-pass at all).
         cam = ms.data.camera
-        n_slots = ops.render_dot_slots(cam.width, cam.height)
+        linear = getattr(self.loss_fn, "linear_gradient", None)
         sd0 = ms.scene_desc(tex_channels=1)  # (sizes only: the pose of the samples comes later)
-        use_cache = Fn.cache_supported(sd0, self.spp)
+        # a loss that is linear in the image (its gradient does not depend on the render): forward and adjoint are ONE launch
+        # (ffx_render_fwd_adjoint) — no cache, no K9; <gimg, img> goes to _abi.ADJOINT_DOT_SLOTS partial sums
+        fused = linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0"
+        n_slots = _abi.ADJOINT_DOT_SLOTS if fused else ops.render_dot_slots(cam.width, cam.height)
+        use_cache = (not fused) and Fn.cache_supported(sd0, self.spp)
         nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0
         acc_bytes = -(-4 * (s0 * s1 + n_slots) // 128) * 128
         if getattr(self, "_arena", None) is None or self._arena.numel() != acc_bytes + max(nbytes, 64):
@@ -203,10 +208,14 @@ class PatternOptimizer:
             nxt = self._sample_seeds(self.step_index + 1)
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
-        linear = getattr(self.loss_fn, "linear_gradient", None)
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
+            if fused:  # K8 scatters the pixel's footprint x gimg straight into gtex and adds <gimg, img> to the loss slots
+                if getattr(self, "_lin_g", None) is None or tuple(self._lin_g.shape) != (cam.height, cam.width, 3):
+                    self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()  # (constant by definition)
+                geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, dot_out=loss_slots, sparse_adjoint=True)
+                continue
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
             mats = ms.materials_arg(sd)  # (None: the rows are part of sd — no upload, no device tensor)

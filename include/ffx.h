@@ -535,6 +535,19 @@ int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[
  * ffx_pattern_bwd's loss_in does): spread because thousands of float atomics on one address serialise (measured +40 us).
  * img = dot_out = NULL: off. */
 size_t ffx_render_dot_slots(int width, int height);
+/* Forward render and adjoint in ONE launch, for a loss whose gradient does not depend on the image (linear in it: the coverage loss
+ * -mean(green) of the reference's pattern optimisation, fireflies/graphics/rasterization.py:583-607 with `loss = -img[..., 1].mean()` style
+ * objectives; gimg is then a constant the caller knows before the render).  img = the render; gtex += its adjoint applied to gimg
+ * (accumulated: the caller zeroes it), formed where the pixel's footprint is: no cache, nothing that can overflow, no launch behind the
+ * render.  dot_out (optional): FFX_ADJOINT_DOT_SLOTS partial sums that <gimg, img> is ADDED to (their sum is the value of the loss).
+ * Flags in img_fp16: FFX_RENDER_FP16, FFX_RENDER_SPARSE_ADJOINT, FFX_RENDER_APEX_READY.  Same result as ffx_render_fwd_cache +
+ * ffx_render_bwd_cached up to the order of the float atomics.  FFX_ERR_UNSUPPORTED with textured base colours (use ffx_render_bwd). */
+#define FFX_ADJOINT_DOT_SLOTS 4096
+int ffx_render_fwd_adjoint(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                           const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
+                           int img_fp16, void *img /*[dev][H,W,3]*/, const float *gimg /*[dev][H,W,3] fp32*/,
+                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, float *dot_out /*[dev][FFX_ADJOINT_DOT_SLOTS] or NULL*/,
+                           ffx_stream stream);
 int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, const void *img /*[dev][H,W,3] or NULL*/, int img_fp16,

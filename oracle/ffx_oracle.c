@@ -1495,6 +1495,21 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, (crec *)cache); /* bit 1 (sparse adjoint) ignored: full gradient */
 }
 
+/* forward + adjoint in one call (include/ffx.h): here the composition it stands for — the per-sample cache, then its adjoint */
+int ffx_render_fwd_adjoint(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                           uint32_t seed, int img_fp16, void *img, const float *gimg, float *gtex, float *dot_out, ffx_stream s) {
+  if (!gimg || !gtex) FAIL(FFX_ERR_ARG, "render_fwd_adjoint: gimg / gtex is NULL");
+  if (!sd || !sd->proj.enabled) FAIL(FFX_ERR_ARG, "render_fwd_adjoint: the scene has no projector (nothing to differentiate)");
+  if (sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint: textured base colours (use ffx_render_bwd)");
+  if (spp < 1) FAIL(FFX_ERR_ARG, "render_fwd_adjoint: bad argument");
+  void *cache = malloc(ffx_render_cache_bytes_sd(sd, spp));
+  if (!cache) FAIL(FFX_ERR_NOMEM, "render_fwd_adjoint: out of memory");
+  int rc = ffx_render_fwd_cache(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, cache, s);
+  if (rc == FFX_OK) rc = ffx_render_bwd_cached(sd, shape_albedo, cache, spp, gimg, gtex, dot_out ? img : NULL, img_fp16 & 1, dot_out, s);
+  free(cache);
+  return rc;
+}
+
 /* nothing to prepare: the oracle forms the apex vectors inside every triangle test (same four quantities, same order) */
 int ffx_apex_prepare(void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, ffx_stream s) {
   (void)s;

@@ -323,6 +323,16 @@ class Geometry:
         api().call("ffx_render_fwd_cache", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(cache), None)
         return img, cache
 
+    def render_fwd_adjoint(self, sd, albedo, tex, spp, seed, gimg, fp16=False):
+        """ffx_render_fwd_adjoint -> (img, gtex, <gimg, img>)"""
+        albedo, tex, gimg = _f32(albedo), _f32(tex), _f32(gimg)
+        H, W = sd.cam.height, sd.cam.width
+        img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
+        gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        dot = np.zeros(4096, np.float32)
+        api().call("ffx_render_fwd_adjoint", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(gimg), _p(gtex), _p(dot), None)
+        return img, gtex, float(dot.astype(np.float64).sum())
+
     @staticmethod
     def render_bwd_cached(sd, albedo, cache, spp, gimg, img=None):
         """-> gtex; with `img` (the forward's image, float32 or float16) also <gimg, img>: (gtex, dot)"""

@@ -1,6 +1,7 @@
 """GPU tests of the reference-API mirror (Laser, rasterization, depth, Scene, mi.render, the
 optimiser): results against golden vectors from the reference and against the CPU oracle chained
 through the same steps.  Run with `-m gpu`."""
+import os
 import random
 
 import numpy as np
@@ -494,13 +495,20 @@ def test_pattern_optimizer_explicit_adjoints_match_autograd():
 
     # (reg_weight 0: the forward launch writes no softor texture and no partial sums — ffx_pattern_bwd is then called with
     # ws = NULL and still emits the loss value; the kernel once summed ws regardless)
-    for loss_fn, reg_w in ((None, 0.1), (custom, 0.1), (None, 0.0)):
+    # (the default loss is linear in the image: forward and adjoint are then one launch, ffx_render_fwd_adjoint; "cached" runs the
+    # same steps through the footprint cache and K9 — the path every other loss takes — by switching the fused launch off)
+    for loss_fn, reg_w, fused in ((None, 0.1, "1"), (None, 0.1, "0"), (custom, 0.1, "1"), (None, 0.0, "1")):
         runs = []
         for which in ("step", "step_autograd"):
+            os.environ["FFX_FUSED_ADJOINT"] = fused
             wl = _small()
             kw = {"reg_weight": reg_w} if loss_fn is None else {"loss_fn": loss_fn, "reg_weight": reg_w}
             opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, samples_per_step=2, base_seed=5, **kw)
-            losses = [float(getattr(opt, which)()["loss"]) for _ in range(3)]
+            try:
+                losses = [float(getattr(opt, which)()["loss"]) for _ in range(3)]
+            finally:
+                os.environ.pop("FFX_FUSED_ADJOINT", None)
+            assert which != "step" or (opt._cache is None) == (loss_fn is None and fused == "1")  # (the fused launch needs no cache)
             runs.append((losses, wl.laser._rays.detach().clone()))
         np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(runs[0][1], runs[1][1], rtol=1e-5, atol=2e-6)

@@ -724,6 +724,63 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch, k9_block, monk
     assert ops.render_cache_bytes(512, 512, 64) <= 40 * 10**6
 
 
+@pytest.mark.parametrize("ch", [1, 3])
+@pytest.mark.parametrize("rows", ["albedo", "material_rows"])
+def test_forward_and_adjoint_in_one_launch(oracle, ch, rows):
+    """ffx_render_fwd_adjoint (round 3): for a loss whose gradient does not depend on the image the adjoint is formed inside the render —
+    the pixel's footprint times gimg goes straight into gtex, stray samples at once, <gimg, img> into 4096 partial sums.  Same image as
+    the plain forward (bitwise), same gradient as the cached and the re-tracing adjoints and as the oracle's composition; accumulates
+    into the caller's gtex; one and two passes per pixel; the sparse flag agrees where the texture is not zero."""
+    from tests.test_bruteforce_cpu import material_rows
+
+    sc = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    go, gd, alb = _pair(oracle, sc, frame=2, xforms=_rand_xforms(2, 5))
+    mats = alb if rows == "albedo" else material_rows(2, 31)
+    sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=0 if rows == "albedo" else 16)
+    tex = _tex(sc, ch)
+    rng = np.random.default_rng(1)
+    gimg = rng.standard_normal((44, 52, 3)).astype(np.float32)
+    for spp in (9, 70):
+        img_p = gd.render_fwd(sd, dev(mats), tex, spp, seed=3)
+        dot = torch.full((4096,), 0.5, device="cuda")
+        acc = torch.full((sd.proj.tex_h, sd.proj.tex_w, ch), 2.0, device="cuda")  # gtex is ACCUMULATED into
+        img_f, g_f = gd.render_fwd_adjoint(sd, dev(mats), tex, spp, 3, dev(gimg), out=acc, dot_out=dot)
+        assert torch.equal(img_f, img_p) and g_f is acc
+        g_f = host(acc) - 2.0
+        cache = torch.zeros(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device="cuda")
+        gd.render_fwd(sd, dev(mats), tex, spp, seed=3, cache=cache)
+        g_c = host(gd.render_bwd_cached(sd, dev(mats), cache, spp, dev(gimg)))
+        g_r = host(gd.render_bwd(sd, dev(mats), spp, 3, dev(gimg)))
+        img_o, g_o, dot_o = go.render_fwd_adjoint(sd, mats, host(tex), spp, 3, gimg)
+        scale = float(np.abs(g_o).max())
+        assert scale > 0
+        for a, b, what in ((g_f, g_c, "cached"), (g_f, g_r, "re-traced"), (g_f, g_o, "oracle")):
+            err = np.abs(a - b)
+            assert (err > 1e-3 * scale).mean() <= 1e-3 and err.max() <= 0.1 * scale, (what, spp, float(err.max() / scale))
+        want = float((gimg.astype(np.float64) * host(img_f).astype(np.float64)).sum())
+        mag = max(1.0, float(np.abs(gimg * host(img_f)).sum()))
+        assert abs(float(dot.double().sum()) - 0.5 * 4096 - want) <= 2e-5 * mag and abs(dot_o - want) <= 1e-3 * mag
+        # fp16 film: <gimg, img> is taken with the image as stored
+        dot16 = torch.zeros(4096, device="cuda")
+        img16, _ = gd.render_fwd_adjoint(sd, dev(mats), tex, spp, 3, dev(gimg), dot_out=dot16, fp16=True)
+        assert img16.dtype == torch.float16
+        assert abs(float(dot16.double().sum()) - float((gimg.astype(np.float64) * host(img16).astype(np.float64)).sum())) <= 2e-5 * mag
+    # sparse adjoint: texels whose value is zero may be left out, the others agree
+    tex_s = tex.clone()
+    tex_s[: tex_s.shape[0] // 2] = 0.0
+    _, g_full = gd.render_fwd_adjoint(sd, dev(mats), tex_s, 9, 3, dev(gimg))
+    _, g_sp = gd.render_fwd_adjoint(sd, dev(mats), tex_s, 9, 3, dev(gimg), sparse_adjoint=True)
+    nz = (tex_s.reshape(g_full.shape) != 0)
+    gs = float(g_full.abs().max())
+    assert float(((g_full - g_sp).abs() * nz).max()) <= 2e-3 * gs
+    with pytest.raises(ValueError):
+        gd.render_fwd_adjoint(sd, dev(mats), tex, 9, 3, dev(gimg), dot_out=torch.zeros(7, device="cuda"))
+    nop = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=0 if rows == "albedo" else 16)
+    nop.proj.enabled = 0
+    with pytest.raises(Exception, match="no projector"):
+        gd.render_fwd_adjoint(nop, dev(mats), tex, 9, 3, dev(gimg))
+
+
 def test_apex_records_written_ahead_and_cache_header_cleared_by_the_caller(oracle):
     """FFX_RENDER_APEX_READY / FFX_RENDER_CACHE_ZEROED (include/ffx.h): the apex records may be written by ffx_apex_prepare behind the
     re-fit (ops.DeviceGeometry.update(apex_sd=...)) and the cache header cleared by the caller, so that a render launches nothing in
