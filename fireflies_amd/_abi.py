@@ -74,6 +74,10 @@ class AdamArgs(C.Structure):
         ("hi", C.c_float),
         ("grad_div", C.c_float),
         ("n_normalize", C.c_int32),
+        ("dot_a", C.c_void_p),
+        ("dot_b", C.c_void_p),
+        ("dot_n", C.c_int64),
+        ("dot_partial", C.c_void_p),
     ]
 
 

@@ -815,7 +815,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // only — the footprint plus a halo of r texels is staged in (dynamic) LDS and every texel's value is formed by blur_bwd_texel, the
 // code k_blur_bwd runs: bitwise the separate launches' gradient without the 250 000-texel transpose blur in front (11 us) —
 // and `adam` (if it names rays): the workgroup that finishes last applies ffx_adam_clamp_step's update to every point.
-struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm; };
+struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm;
+               const float *dot_a, *dot_b; long dot_n; float *dot_partial; };
 template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
@@ -971,6 +972,26 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
       }
     }
   }
+  if (adam.rays && adam.dot_a) { // this workgroup's slice of <dot_a, dot_b> (the data term of a loss that is linear in the image)
+    __shared__ double s_dot[SPLAT_BLOCK / 64];
+    const long per = ((adam.dot_n + gridDim.x - 1) / gridDim.x + 3) & ~3L; // (slices of whole float4s)
+    const long lo_i = per * k, hi_i = min(adam.dot_n, lo_i + per);
+    double acc = 0.0;
+    const bool vec = ((((uintptr_t)adam.dot_a | (uintptr_t)adam.dot_b) & 15) == 0);
+    if (vec) {
+      for (long i = lo_i + 4 * tid; i + 3 < hi_i; i += 4 * SPLAT_BLOCK) {
+        const float4 a = *reinterpret_cast<const float4 *>(adam.dot_a + i), b = *reinterpret_cast<const float4 *>(adam.dot_b + i);
+        acc += (double)(a.x * b.x) + (double)(a.y * b.y) + (double)(a.z * b.z) + (double)(a.w * b.w);
+      }
+      for (long i = lo_i + ((hi_i - lo_i) & ~3L) + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i]);
+    } else {
+      for (long i = lo_i + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i]);
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) s_dot[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) adam.dot_partial[k] = (float)((s_dot[0] + s_dot[1]) + (s_dot[2] + s_dot[3]));
+  }
   if (adam.rays) { // the update rides along: whoever finishes last sees every point's gradient (agent-scope fence + counter)
     __shared__ int s_last;
     __syncthreads();
@@ -985,6 +1006,19 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
       for (int i = tid; i < n; i += SPLAT_BLOCK)
         adam_clamp_one(i, t, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
                        adam.lo, adam.hi, adam.n_norm);
+      if (adam.dot_a && reg_value) { // the data term: the slices in workgroup order
+        __shared__ double s_tot[SPLAT_BLOCK / 64];
+        double tot = 0.0;
+        for (int i = tid; i < (int)gridDim.x; i += SPLAT_BLOCK) tot += (double)adam.dot_partial[i];
+        tot = wave_sum(tot);
+        if ((tid & 63) == 0) s_tot[tid >> 6] = tot;
+        __syncthreads();
+        if (tid == 0) {
+          const float ls = (float)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]));
+          reg_value[1] = ls / loss_div + reg_value[0]; // (reg_value[0]: written by workgroup 0 before it arrived at the counter)
+          reg_value[2] = ls;
+        }
+      }
       __syncthreads();
       if (tid == 0) { adam.step[0] = t; *adam.counter = 0u; } // (the counter is ready for the next launch)
     }
@@ -1221,6 +1255,11 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
     ak.lr = adam->lr; ak.beta1 = adam->beta1; ak.beta2 = adam->beta2; ak.eps = adam->eps;
     for (int i = 0; i < 16; ++i) ak.KI.m[i] = adam->KF_inv[i];
     ak.lo = adam->lo; ak.hi = adam->hi; ak.grad_div = adam->grad_div; ak.n_norm = adam->n_normalize;
+    if (adam->dot_a) {
+      if (!adam->dot_b || adam->dot_n < 1 || !adam->dot_partial || !reg_value) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the inner product needs dot_b, dot_n, dot_partial and reg_value");
+      if (loss_in) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the data term comes either as partial sums (loss_in) or as an inner product (dot_a), not both");
+      ak.dot_a = adam->dot_a; ak.dot_b = adam->dot_b; ak.dot_n = (long)adam->dot_n; ak.dot_partial = adam->dot_partial;
+    }
   }
   Mat4 m;
   for (int i = 0; i < 16; ++i) m.m[i] = KF[i];

@@ -177,8 +177,10 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
     return gd, gr, val
 
 
-def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None):
-    """ffx_adam_args for pattern_bwd_blur (the tensors must outlive the launch; `counter`: one zeroed int32 / uint32 device word)"""
+def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None, dot=None):
+    """ffx_adam_args for pattern_bwd_blur (the tensors must outlive the launch; `counter`: one zeroed int32 / uint32 device word).
+    dot = (a, b, partial): the launch also evaluates <a, b> (two float32 tensors of equal size: the render and the constant gradient of a loss
+    linear in it) as the step's data term; partial: float32 scratch of one element per point."""
     a = _abi.AdamArgs()
     a.rays, a.exp_avg, a.exp_avg_sq = _dev(rays, name="rays").value, _dev(exp_avg, name="exp_avg").value, _dev(exp_avg_sq, name="exp_avg_sq").value
     a.step = _dev(step, name="step").value
@@ -187,6 +189,11 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
     a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
     a.KF_inv = _m16(KF_inv)
     a.lo, a.hi, a.grad_div, a.n_normalize = float(lo), float(hi), float(grad_div), int(n_normalize)
+    if dot is not None:
+        da, db, part = dot
+        if da.numel() != db.numel() or part.numel() < rays.shape[0]:
+            raise ValueError("dot = (a, b, partial): a and b of equal size, partial with one float per point")
+        a.dot_a, a.dot_b, a.dot_n, a.dot_partial = _dev(da, name="dot a").value, _dev(db, name="dot b").value, int(da.numel()), _dev(part, name="dot partial").value
     return a
 
 

@@ -214,7 +214,11 @@ class PatternOptimizer:
             if fused:  # K8 scatters the pixel's footprint x gimg straight into gtex and adds <gimg, img> to the loss slots
                 if getattr(self, "_lin_g", None) is None or tuple(self._lin_g.shape) != (cam.height, cam.width, 3):
                     self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()  # (constant by definition)
-                geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, dot_out=loss_slots, sparse_adjoint=True)
+                # (<gimg, img>: with ONE sample per step the gradient launch evaluates it from the image — 3 us; K8's own partial sums are
+                # a quarter of a million atomics per render, 27 us, and only used when a step has several samples)
+                one = len(seeds) == 1 and w == 1
+                last_img, _ = geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, dot_out=None if one else loss_slots,
+                                                      sparse_adjoint=True)
                 continue
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
@@ -261,10 +265,15 @@ class PatternOptimizer:
             # loss, and (by the workgroup that finishes last) Adam + Laser.clamp_to_fov() + normalize_rays() on grad = gsum / S + regulariser
             if getattr(self, "_adam_counter", None) is None:
                 self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
+            dot = None
+            if fused and len(seeds) == 1:
+                if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
+                    self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
+                dot = (last_img, self._lin_g, self._dot_part)
             aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
-                               1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad)
-            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=loss_slots, loss_div=float(S), adam=aa,
-                                               scratch=self._scratch)
+                               1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot)
+            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
+                                               loss_div=float(S), adam=aa, scratch=self._scratch)
             loss = val[1]
         rays.grad = grad
         self.step_index += 1

@@ -218,6 +218,14 @@ typedef struct ffx_adam_args {
   float lo, hi;       /* Laser.clamp_to_fov's bounds */
   float grad_div;
   int32_t n_normalize;
+  /* optional: the step's data term as an inner product <dot_a, dot_b> over dot_n floats (a loss linear in the image: the render and its
+   * constant gradient), evaluated by the same launch — every workgroup sums a slice into dot_partial[n], the workgroup that applies the
+   * update adds them up: reg_value[2] = the sum, reg_value[1] = sum / loss_div + reg_value[0].  Takes the place of loss_in (not both).
+   * K8's own partial sums (ffx_render_fwd_adjoint's dot_out) cost a quarter of a million atomics per render: 27 us; this costs 3. */
+  const float *dot_a; /* [dev][dot_n] or NULL */
+  const float *dot_b; /* [dev][dot_n] */
+  int64_t dot_n;
+  float *dot_partial; /* [dev][n] scratch */
 } ffx_adam_args;
 int ffx_pattern_fwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                          int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,

@@ -1779,5 +1779,12 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
                            adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, s);
   free(zeros);
+  if (rc == FFX_OK && adam->dot_a) { /* the data term as an inner product (takes the place of loss_in) */
+    if (!adam->dot_b || adam->dot_n < 1 || !reg_value || loss_in) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the inner product needs dot_b, dot_n, reg_value and no loss_in");
+    double acc = 0.0;
+    for (int64_t i = 0; i < adam->dot_n; ++i) acc += (double)adam->dot_a[i] * (double)adam->dot_b[i];
+    reg_value[2] = (float)acc;
+    reg_value[1] = (float)acc / (loss_div > 0.f ? loss_div : 1.0f) + reg_value[0];
+  }
   return rc;
 }

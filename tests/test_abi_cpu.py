@@ -294,3 +294,27 @@ def test_host_bvh_structure(case):
     assert sorted(copied) == used
     if case == "vocalfold":
         assert 52 <= T <= 400 and int(hdr[:T, 1].max()) <= 1024
+
+
+def test_ctypes_mirrors_have_the_compilers_layout(tmp_path):
+    """sizeof and the offset of every field of every struct of include/ffx.h as gcc lays them out, against the ctypes mirrors of
+    fireflies_amd/_abi.py (a field inserted on one side only would shift everything behind it silently)"""
+    import subprocess
+
+    pairs = {"ffx_bvh_info": _abi.BvhInfo, "ffx_smooth": _abi.Smooth, "ffx_camera": _abi.Camera, "ffx_projector": _abi.Projector, "ffx_spot": _abi.Spot,
+             "ffx_scene_desc": _abi.SceneDesc, "ffx_adam_args": _abi.AdamArgs}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "ffx.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"

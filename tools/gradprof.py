@@ -14,7 +14,7 @@ from fireflies_amd.optim import PatternOptimizer  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    wg = workloads.vocalfold(device=dev, grid=8, entity_device="cpu")
+    wg = workloads.vocalfold(device=dev, grid=8, entity_device=sys.argv[1] if len(sys.argv) > 1 else "cuda")  # (bench.py's default: cuda)
     opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=64, samples_per_step=1, base_seed=7)
     for _ in range(5):
         opt.step()
@@ -38,6 +38,7 @@ def main():
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats("cumulative").print_stats(28)
+    st.sort_stats("tottime").print_stats(22)
 
 
 if __name__ == "__main__":
