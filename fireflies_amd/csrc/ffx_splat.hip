@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   if (adam.rays && adam.dot_a) { // this workgroup's slice of <dot_a, dot_b> (the data term of a loss that is linear in the image)
     __shared__ double s_dot[SPLAT_BLOCK / 64];
     const long per = ((adam.dot_n + gridDim.x - 1) / gridDim.x + 3) & ~3L; // (slices of whole float4s)
-    const long lo_i = per * k, hi_i = min(adam.dot_n, lo_i + per);
+    const long lo_i = min(adam.dot_n, per * k), hi_i = min(adam.dot_n, lo_i + per); // (workgroups past the end: an empty slice)
     double acc = 0.0;
     const bool vec = ((((uintptr_t)adam.dot_a | (uintptr_t)adam.dot_b) & 15) == 0);
     if (vec) {
