@@ -594,7 +594,10 @@ def main():
             "grad_samples_per_sec": S * args.steps / t_grad,
             "grad_ms_per_step": 1e3 * t_grad / args.steps,
             "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world))},
-            "grad_kernels_ms": {"render_fwd(+cache write)": k8g_ms, "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
+            "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if opt._cache is None and k9_ms is None else "render_fwd(+cache write)"): k8g_ms,
+                                "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
+            "grad_launches_per_step": "pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if opt._cache is None and k9_ms is None
+            else "pattern_fwd_blur, render_fwd_cache, render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)",
             "render_bwd_cached_roofline": None if k9c_ms is None else {
                 "kernel": "k_render_bwd_cached (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",
                 "lit_pixels": n_lit, "stray_samples": n_stray,
