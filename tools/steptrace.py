@@ -46,8 +46,10 @@ def main():
     med = periods[len(periods) // 2]
     steady = [(p, seg) for p, seg in steps if p < 1.5 * med]
     print(f"median period {med / 1e3:.1f} us; {len(steady)} steady steps")
-    for label, pick in (("steps without an adjoint launch (render bracket)", lambda seg: not any("render_bwd" in r[2] for r in seg)),
-                        ("steps with an adjoint launch (gradient bracket)", lambda seg: any("render_bwd" in r[2] for r in seg))):
+    # (a gradient step: one with an adjoint launch or — the fused forward + adjoint, ffx_render_fwd_adjoint — a pattern launch)
+    is_grad = lambda seg: any("render_bwd" in r[2] or "k_pattern_bwd" in r[2] for r in seg)  # noqa: E731
+    for label, pick in (("steps without an adjoint / pattern launch (render bracket)", lambda seg: not is_grad(seg)),
+                        ("steps with an adjoint / pattern launch (gradient bracket)", is_grad)):
         sel = [(p, seg) for p, seg in steady if pick(seg)]
         if not sel:
             continue
