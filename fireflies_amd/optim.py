@@ -167,7 +167,10 @@ class PatternOptimizer:
         sd0 = ms.scene_desc(tex_channels=1)  # (sizes only: the pose of the samples comes later)
         # a loss that is linear in the image (its gradient does not depend on the render): forward and adjoint are ONE launch
         # (ffx_render_fwd_adjoint) — no cache, no K9; <gimg, img> goes to _abi.ADJOINT_DOT_SLOTS partial sums
-        fused = linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0"
+        # (one scene sample per step and rank: the loss value then comes out of the gradient launch; with several, K9's per-block partial
+        # sums — 4096 atomics — are cheaper than the fused launch's per-pixel ones: tools/adjprobe.py, 510 against 519 us per sample)
+        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and w == 1 and len(self._sample_seeds(self.step_index)) == 1
+                 and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
         n_slots = _abi.ADJOINT_DOT_SLOTS if fused else ops.render_dot_slots(cam.width, cam.height)
         use_cache = (not fused) and Fn.cache_supported(sd0, self.spp)
         nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0

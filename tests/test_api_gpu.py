@@ -497,18 +497,19 @@ def test_pattern_optimizer_explicit_adjoints_match_autograd():
     # ws = NULL and still emits the loss value; the kernel once summed ws regardless)
     # (the default loss is linear in the image: forward and adjoint are then one launch, ffx_render_fwd_adjoint; "cached" runs the
     # same steps through the footprint cache and K9 — the path every other loss takes — by switching the fused launch off)
-    for loss_fn, reg_w, fused in ((None, 0.1, "1"), (None, 0.1, "0"), (custom, 0.1, "1"), (None, 0.0, "1")):
+    # (the fused launch is used with one scene sample per step and rank; with several, K9's partial sums of the loss are cheaper)
+    for loss_fn, reg_w, fused, S in ((None, 0.1, "1", 1), (None, 0.1, "0", 1), (None, 0.1, "1", 2), (custom, 0.1, "1", 1), (custom, 0.1, "1", 2), (None, 0.0, "1", 1)):
         runs = []
         for which in ("step", "step_autograd"):
             os.environ["FFX_FUSED_ADJOINT"] = fused
             wl = _small()
             kw = {"reg_weight": reg_w} if loss_fn is None else {"loss_fn": loss_fn, "reg_weight": reg_w}
-            opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, samples_per_step=2, base_seed=5, **kw)
+            opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, samples_per_step=S, base_seed=5, **kw)
             try:
                 losses = [float(getattr(opt, which)()["loss"]) for _ in range(3)]
             finally:
                 os.environ.pop("FFX_FUSED_ADJOINT", None)
-            assert which != "step" or (opt._cache is None) == (loss_fn is None and fused == "1")  # (the fused launch needs no cache)
+            assert which != "step" or (opt._cache is None) == (loss_fn is None and fused == "1" and S == 1)  # (the fused launch needs no cache)
             runs.append((losses, wl.laser._rays.detach().clone()))
         np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(runs[0][1], runs[1][1], rtol=1e-5, atol=2e-6)
