@@ -46,7 +46,7 @@ def test_operand_form_ceiling_is_consistent(bench):
     """round 3: the share of the add / mul / fma class that carries a scalar source (tools/isa_mix.py, committed) is priced at the
     4-cycle rate — a ceiling between the nominal one and the kernel time recorded in the same profile set"""
     forms = json.load(open(bench._profile_files("isa_operand_forms.json")[-1]))
-    assert "k_render_fwd_pk<1, true, 1>" in forms["kernel"]
+    assert "k_render_fwd_pk<1, true, 1" in forms["kernel"]
     assert forms["with_scalar_or_constant_source"] == sum(v["with_scalar_source"] for v in forms["per_opcode"].values())
     fr = forms["scalar_source_fraction"]
     assert 0.2 < fr < 0.7

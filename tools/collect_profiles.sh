@@ -47,7 +47,7 @@ if [ -f fireflies_amd/csrc/_stats/libffx_hip_timers.so ]; then
   else FFX_LIB=fireflies_amd/csrc/_stats/libffx_hip_timers.so python tools/phaseclk.py colon 256 2 > profiles/${TAG}_phaseclk.txt 2> $OUT/phaseclk.log; fi
 fi
 if [ -z "$X" ]; then
-python tools/isa_mix.py > profiles/${TAG}_isa_operand_forms.json 2> $OUT/isa_mix.log   # (static: needs no GPU, kept with the rest)
+python tools/isa_mix.py > $OUT/isa_operand_forms.json 2> $OUT/isa_mix.log && mv $OUT/isa_operand_forms.json profiles/${TAG}_isa_operand_forms.json   # (static: needs no GPU, kept with the rest)
 python tools/k8ab.py > profiles/${TAG}_k8ab.txt 2> $OUT/k8ab.log
 (cd /tmp && rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1)
 python tools/steptrace.py $OUT/trace > profiles/${TAG}_steptrace.txt 2>> $OUT/trace.log
