@@ -73,10 +73,13 @@ class Sampler:
         """float32 numpy mirrors of (min, max), refreshed when the configuration counter moved (one sync then,
         for device bounds)"""
         hb = getattr(self, "_hb", None)
-        if hb is None or hb[0] != _MUTATIONS[0]:
+        # (the tensors' version counters catch in-place writes through a tensor that get_min() / get_max() handed out EARLIER — the
+        # accessor itself bumps the configuration counter, a later `t += 1` on its result does not)
+        key = (_MUTATIONS[0], self._min_range._version, self._max_range._version, id(self._min_range), id(self._max_range))
+        if hb is None or hb[0] != key:
             lo = self._min_range.detach().reshape(-1).to("cpu", torch.float32).numpy().copy()
             hi = self._max_range.detach().reshape(-1).to("cpu", torch.float32).numpy().copy()
-            hb = self._hb = (_MUTATIONS[0], lo, hi)
+            hb = self._hb = (key, lo, hi)
         return hb[1], hb[2]
 
     def draw(self, batch) -> int:

@@ -308,6 +308,34 @@ def test_randomize_is_one_transfer_and_batches_replay_the_sequential_draws(monke
     assert not torch.equal(seq[0]["mesh-Cube.vertex_positions"], seq[1]["mesh-Cube.vertex_positions"])
 
 
+def test_sampler_host_mirrors_follow_in_place_writes_through_an_old_handle():
+    """a draw through entity.DrawBatch uses float32 host mirrors of the sampler's bounds; a caller that keeps the tensor get_min() handed
+    out and writes to it LATER (`lo += 1`) changes the bounds the reference's sampler reads live — the mirrors follow (tensor version
+    counters), so batched draws and plain sample() keep agreeing"""
+    from fireflies_amd import entity
+    from fireflies_amd import sampling as S
+
+    smp = S.UniformSampler(torch.tensor([0.0, 10.0]), torch.tensor([1.0, 11.0]), device="cpu")
+    lo_handle, hi_handle = smp.get_min(), smp.get_max()
+
+    def batched():
+        torch.manual_seed(3)
+        b = entity.DrawBatch()
+        i = smp.draw(b)
+        return np.asarray(b.fetch()[i], np.float32).reshape(-1)
+
+    def plain():
+        torch.manual_seed(3)
+        return smp.sample().numpy().reshape(-1)
+
+    np.testing.assert_array_equal(batched(), plain())
+    lo_handle += 5.0  # (no accessor is called: only the tensor's version moves)
+    hi_handle.mul_(2.0).add_(10.0)
+    after = batched()
+    np.testing.assert_array_equal(after, plain())
+    assert (after >= np.float32([5.0, 15.0])).all() and (after <= np.float32([12.0, 32.0])).all()
+
+
 def test_material_has_no_pose_but_warns():
     m = ff.material.Material("mat-X", device=CPU)
     with pytest.warns(UserWarning):
