@@ -104,6 +104,25 @@ class TensorXf(_ArrayBase):
     pass
 
 
+class _RenderedXf(TensorXf):
+    """The image of a render that was issued on one of the scene's render streams (Scene._render_stream): whoever reads it first makes the
+    stream that is current THEN wait for the render — `mi.render(...).torch()`, the reference's idiom, costs one event wait; a loop that
+    never looks at the image (or looks later) lets consecutive renders overlap."""
+
+    def __init__(self, img, done):
+        self._img, self._done = img, done
+
+    @property
+    def t(self):
+        d = self._done
+        if d is not None:
+            cur = torch.cuda.current_stream(self._img.device)
+            cur.wait_event(d)
+            self._img.record_stream(cur)  # (allocated on the render stream, consumed here)
+            self._done = None
+        return self._img
+
+
 class _Matrix:
     def __init__(self, m):
         self.m = m
@@ -271,6 +290,8 @@ class SceneParameters:
             raise KeyError(f"unknown scene parameter {k!r}")
         self._d[k] = v
         self._dirty.add(k)
+        if k == "tex.data":
+            self._scene._note_texture(v)
 
     def _init(self, k, v):
         self._d[k] = v
@@ -326,6 +347,18 @@ class Scene:
         # material then costs no host-to-device copy at all (it was the one copyBuffer launch of every step)
         self._mats_in_sd = alb.size <= 128 and os.environ.get("FFX_HOST_MATERIALS", "1") != "0"
         self._apex_ahead = os.environ.get("FFX_APEX_AHEAD", "1") != "0"  # apex records written with the re-fit instead of in front of the render
+        # Two render streams, used in turn (FFX_RENDER_STREAMS=1: the caller's stream, as before): consecutive renders are independent of
+        # each other — each reads its own blob copy, the texture and kernel arguments — and back to back on ONE stream they leave the tail
+        # of every launch (the last of 262 144 one-wave workgroups draining) and the dependency gap behind it unused: tools/overlapprobe.py,
+        # 519.2 us per render on one stream, 505.5 on two.  What a render depends on is waited for explicitly (the texture's assignment,
+        # the re-fit of its blob); the image is handed out as _RenderedXf.
+        self._render_streams = None
+        if self.device.type == "cuda" and os.environ.get("FFX_RENDER_STREAMS", "2") != "1":
+            self._render_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            self._render_done = [[torch.cuda.Event() for _ in range(4)] for _ in range(2)]
+        self._render_turn = 0
+        self._tex_src = self._tex_ready = self._tex_private = None
+        self._tex_ver = -1
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
         # leaf slot's three corners (static: the slot order is the tree's)
         self._base_tex = [(name, torch.from_numpy(t).to(self.device).contiguous()) for name, t in scenes.base_textures(data)]
@@ -486,6 +519,34 @@ class Scene:
             # render launches without a pre-pass (ops.DeviceGeometry.update; the description is built here instead of in render())
             self.geom.update(self._xforms, self._offs, apex_sd=self.scene_desc(tex_channels=ch) if self._apex_ahead else None)
 
+    def _note_texture(self, v):
+        """`params["tex.data"] = v`: from here on the texture is this tensor as the current stream leaves it — what a render stream waits for"""
+        t = v.t if isinstance(v, _ArrayBase) else v
+        self._tex_src = self._tex_private = None
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.device == self.device and not t.requires_grad and self._render_streams is not None:
+            # the render streams read a PRIVATE copy (as Mitsuba's scene owns its copy of an assigned tensor): the caller may write into
+            # its tensor right after a render whose image it has not looked at yet — that render must not see the write
+            cur = torch.cuda.current_stream(t.device)
+            priv = t.detach().to(torch.float32).contiguous().clone()
+            for rs in self._render_streams:
+                priv.record_stream(rs)
+            if self._tex_ready is None:
+                self._tex_ready = torch.cuda.Event()
+            self._tex_ready.record(cur)
+            self._tex_src, self._tex_ver, self._tex_private = t, t._version, priv
+
+    def _render_stream(self, tex, mats):
+        """(stream, completion event) for a render of `tex` that can run beside the previous one — or None: the caller's stream.  Only when
+        everything the render reads is accounted for: the texture is the tensor that was assigned, untouched since (its version counter), the
+        materials travel as kernel arguments, no base-colour textures."""
+        if self._render_streams is None or tex is not self._tex_src or tex._version != self._tex_ver or mats is not None or self._base_tex or not self.geom._async:
+            return None  # (a texture written in place since its assignment: the live tensor, on the caller's stream, as before)
+        i = self._render_turn & 1
+        self._render_turn += 1
+        rs = self._render_streams[i]
+        rs.wait_event(self._tex_ready)
+        return rs, self._render_done[i][(self._render_turn >> 1) & 3], self._tex_private
+
     def _upload_albedo(self):
         if self._albedo_ring is None:
             self._albedo_ring = _PinnedRing(tuple(self._albedo_host.shape))
@@ -575,11 +636,11 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
     if sensor != 0:
         raise NotImplementedError("only sensor 0 renders; further sensors are projector proxies")
     p = scene._params
-    tex = None
+    tex = tex_in = None
     ch = 3
     if scene.data.projector is not None:
         tex = p["tex.data"]
-        tex = tex.t if isinstance(tex, _ArrayBase) else tex
+        tex = tex_in = tex.t if isinstance(tex, _ArrayBase) else tex  # (tex_in: the tensor as assigned, before any conversion below)
         if not isinstance(tex, torch.Tensor):
             tex = torch.as_tensor(np.asarray(tex, np.float32))
         if tex.device != scene.device:
@@ -593,6 +654,14 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
     if tex.requires_grad and torch.is_grad_enabled():
         img = Fn.render(tex, scene.geom, sd, scene.materials_arg(sd), spp, seed, fp16)
     else:  # nothing to differentiate: straight to the kernel (autograd.Function.apply costs ~80 us of host time per call)
+        mats = scene.materials_arg(sd)
+        slot = scene._render_stream(tex_in, mats) if tex_in is not None else None
+        if slot is not None:  # beside the previous render, on the scene's other render stream
+            rs, done, priv = slot
+            with torch.cuda.stream(rs):
+                img = scene.geom.render_fwd(sd, mats, priv.unsqueeze(-1) if priv.dim() == 2 else priv, int(spp), int(seed), bool(fp16))
+                done.record(rs)
+            return _RenderedXf(img, done)
         t = tex if tex.is_contiguous() else tex.contiguous()
-        img = scene.geom.render_fwd(sd, scene.materials_arg(sd), t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
+        img = scene.geom.render_fwd(sd, mats, t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
     return TensorXf(img)

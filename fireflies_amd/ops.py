@@ -431,7 +431,7 @@ class DeviceGeometry:
         self._side = torch.cuda.Stream(self.device) if self._async else None
         self._upd_done = [None, None]   # event: the refit of blob i has been enqueued up to here (side stream)
         self._apex = [None, None]       # apex_key of what blob i's apex areas hold (None: nothing usable)
-        self._last_use = [None, None]   # event: the last reader of blob i (caller's stream)
+        self._last_use = [{}, {}]       # per blob: stream handle -> event behind that stream's last reader (renders may come from several streams)
         self.src_verts = torch.from_numpy(src).to(self.device)
         self.tris = torch.from_numpy(tr).to(self.device)
         self.tri_shape = torch.from_numpy(ts).to(self.device)
@@ -472,11 +472,19 @@ class DeviceGeometry:
             _stream_obj(self._didx).wait_event(ev)
 
     def _release(self):
-        if self._async:
-            ev = self._last_use[self._cur]
+        if self.device.type == "cuda":
+            so = _stream_obj(self._didx)
+            d = self._last_use[self._cur if self._async else 0]
+            ev = d.get(so.cuda_stream)
             if ev is None:
-                ev = self._last_use[self._cur] = torch.cuda.Event()
-            ev.record(_stream_obj(self._didx))
+                ev = d[so.cuda_stream] = torch.cuda.Event()
+            ev.record(so)
+
+    def _wait_readers(self, i, stream_obj):
+        """`stream_obj` is about to WRITE into blob i (a re-fit, an apex pre-pass): every reader on another stream must be done"""
+        for handle, ev in self._last_use[i].items():
+            if handle != stream_obj.cuda_stream:
+                stream_obj.wait_event(ev)
 
     def write_verts(self, offset, verts):
         """copy caller-supplied vertices [V,3] into the pool at `offset` (animation functions, direct
@@ -522,13 +530,14 @@ class DeviceGeometry:
         on_device = isinstance(xforms, torch.Tensor) and xforms.is_cuda
         self.version += 1
         if not self._async:
+            if self.device.type == "cuda":
+                self._wait_readers(0, _stream_obj(self._didx))
             self._update_into(self._blobs[0], xforms, on_device)
             self._prepare_apex(0, apex_sd)
             return
         nxt = 1 - self._cur
         main = _stream_obj(self._didx)
-        if self._last_use[nxt] is not None:
-            self._side.wait_event(self._last_use[nxt])  # its last reader must be done before it is overwritten
+        self._wait_readers(nxt, self._side)  # its readers must be done before it is overwritten
         if self._pool_written is not None:
             self._side.wait_event(self._pool_written)  # caller-supplied vertices must have landed in the pool
         if on_device:
@@ -553,10 +562,12 @@ class DeviceGeometry:
     def _apex_flag(self, key):
         """FFX_RENDER_APEX_READY if the current blob's apex areas hold `key`; they will after the call either way"""
         i = self._cur if self._async else 0
+        ready = self._apex[i] == key and not _lane_kernels()
+        if not ready and self.device.type == "cuda":
+            self._wait_readers(i, _stream_obj(self._didx))  # the call's pre-pass rewrites the apex areas: renders on other streams may still read them
         if _lane_kernels():
             self._apex[i] = None  # (a cache-writing render runs the packet kernel — and its pre-pass — even then: claim nothing afterwards)
             return 0
-        ready = self._apex[i] == key
         self._apex[i] = key
         return _abi.RENDER_APEX_READY if ready else 0
 
@@ -596,7 +607,10 @@ class DeviceGeometry:
         shape = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         if not _lane_kernels():
-            self._apex[self._cur if self._async else 0] = None  # (it rewrites the camera's area; the emitters' areas keep what they had: claim nothing)
+            i = self._cur if self._async else 0
+            self._apex[i] = None  # (it rewrites the camera's area; the emitters' areas keep what they had: claim nothing)
+            self._acquire()
+            self._wait_readers(i, _stream_obj(self._didx))
         self._call(
             "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
             _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self._didx),

@@ -375,6 +375,50 @@ def test_principled_parameters_reach_the_render(oracle):
         wd.ff_scene.randomize()  # reported once per scene
 
 
+def test_consecutive_renders_on_two_streams_are_the_renders_of_one(oracle, monkeypatch):
+    """mi.render issues consecutive renders on two render streams in turn (they overlap at their tails: tools/overlapprobe.py) and hands the image
+    out as a handle whose first reader waits for it.  Same images as on the caller's stream, in every order of use: read at once, read later,
+    never read; the camera moved between two renders (the second one's apex pre-pass must wait for the first render, which still reads the
+    areas it rewrites); a depth trace in between; the texture written in place (version counter -> the caller's stream again)."""
+    def run(streams):
+        monkeypatch.setenv("FFX_RENDER_STREAMS", streams)
+        wl = _small()
+        tex = workloads.build_texture(wl).detach().contiguous()
+        wl.params["tex.data"] = tex
+        torch.manual_seed(11)
+        random.seed(11)
+        out = []
+        held = []
+        cam_key = wl.mi_scene.data.camera.name + ".to_world"
+        for i in range(10):
+            if i % 3 != 2:
+                wl.ff_scene.randomize()
+            if i in (4, 5):  # a camera that moves WITHOUT a re-fit: the render prepares its own apex records
+                m = wl.mi_scene._mat(cam_key).copy()
+                m[:3, 3] += np.float32([0.002 * i, -0.001, 0.0015])
+                wl.params[cam_key] = mi.Transform4f(m.tolist())
+                wl.params.update()
+            if i == 6:
+                t, _, _ = wl.mi_scene.geom.trace_primary(wl.mi_scene.camera_struct(0), 1, 0, 0)
+                out.append(t.clone())
+            if i == 8:
+                tex.mul_(0.5)  # in place: no assignment, the version counter is all that moves
+            r = mi.render(wl.mi_scene, spp=8, seed=20 + i)
+            assert isinstance(r, mi._RenderedXf) == (streams == "2" and i < 8)
+            if i % 2 == 0:
+                out.append(r.torch().clone())  # read at once
+            else:
+                held.append(r)  # read after the loop
+        out += [h.torch().clone() for h in held]
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run("2"), run("1")
+    assert len(a) == len(b) == 11
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), k
+
+
 def test_randomised_materials_travel_without_an_upload(oracle):
     """mi.Scene keeps small material tables inside the scene description (kernel arguments): after a randomisation the render sees
     the new values although nothing was copied to the device; `scene.albedo` (the device tensor other callers may hold) is
