@@ -523,7 +523,8 @@ class Scene:
         """`params["tex.data"] = v`: from here on the texture is this tensor as the current stream leaves it — what a render stream waits for"""
         t = v.t if isinstance(v, _ArrayBase) else v
         self._tex_src = self._tex_private = None
-        if isinstance(t, torch.Tensor) and t.is_cuda and t.device == self.device and not t.requires_grad and self._render_streams is not None:
+        mine = self.device.index if self.device.index is not None else torch.cuda.current_device() if self.device.type == "cuda" else None
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == mine and not t.requires_grad and self._render_streams is not None:
             # the render streams read a PRIVATE copy (as Mitsuba's scene owns its copy of an assigned tensor): the caller may write into
             # its tensor right after a render whose image it has not looked at yet — that render must not see the write
             cur = torch.cuda.current_stream(t.device)
