@@ -431,6 +431,8 @@ class DeviceGeometry:
         self._side = torch.cuda.Stream(self.device) if self._async else None
         self._upd_done = [None, None]   # event: the refit of blob i has been enqueued up to here (side stream)
         self._apex = [None, None]       # apex_key of what blob i's apex areas hold (None: nothing usable)
+        self._apex_written = [None, None]  # (stream handle, event) behind the call whose own pre-pass last wrote blob i's apex areas
+        self._apex_writer_pending = False
         self._last_use = [{}, {}]       # per blob: stream handle -> event behind that stream's last reader (renders may come from several streams)
         self.src_verts = torch.from_numpy(src).to(self.device)
         self.tris = torch.from_numpy(tr).to(self.device)
@@ -479,6 +481,9 @@ class DeviceGeometry:
             if ev is None:
                 ev = d[so.cuda_stream] = torch.cuda.Event()
             ev.record(so)
+            if self._apex_writer_pending:  # this call wrote the apex areas itself: a render on ANOTHER stream that finds them "ready" waits for it
+                self._apex_written[self._cur if self._async else 0] = (so.cuda_stream, ev)
+                self._apex_writer_pending = False
 
     def _wait_readers(self, i, stream_obj):
         """`stream_obj` is about to WRITE into blob i (a re-fit, an apex pre-pass): every reader on another stream must be done"""
@@ -555,6 +560,7 @@ class DeviceGeometry:
     def _prepare_apex(self, i, sd):
         """(on the stream the re-fit of blob i was enqueued on) the records changed: what the apex areas held is void"""
         self._apex[i] = None
+        self._apex_written[i] = None
         if sd is not None and not _lane_kernels():
             self._call("ffx_apex_prepare", _dev(self._blobs[i], torch.uint8, "blob"), C.byref(self.info), C.byref(sd), _stream(self._didx))
             self._apex[i] = apex_key(sd)
@@ -563,8 +569,15 @@ class DeviceGeometry:
         """FFX_RENDER_APEX_READY if the current blob's apex areas hold `key`; they will after the call either way"""
         i = self._cur if self._async else 0
         ready = self._apex[i] == key and not _lane_kernels()
-        if not ready and self.device.type == "cuda":
-            self._wait_readers(i, _stream_obj(self._didx))  # the call's pre-pass rewrites the apex areas: renders on other streams may still read them
+        if self.device.type == "cuda":
+            so = _stream_obj(self._didx)
+            if not ready:
+                self._wait_readers(i, so)  # the call's pre-pass rewrites the apex areas: renders on other streams may still read them
+                self._apex_writer_pending = True
+            else:
+                w = self._apex_written[i]
+                if w is not None and w[0] != so.cuda_stream:
+                    so.wait_event(w[1])  # written by a pre-pass on another stream (not by the re-fit, which _acquire has waited for)
         if _lane_kernels():
             self._apex[i] = None  # (a cache-writing render runs the packet kernel — and its pre-pass — even then: claim nothing afterwards)
             return 0
