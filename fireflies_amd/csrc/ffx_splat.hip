@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // code k_blur_bwd runs: bitwise the separate launches' gradient without the 250 000-texel transpose blur in front (11 us) —
 // and `adam` (if it names rays): the workgroup that finishes last applies ffx_adam_clamp_step's update to every point.
 struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm;
-               const float *dot_a, *dot_b; long dot_n; float *dot_partial; };
+               const float *dot_a, *dot_b; long dot_n; float *dot_partial; long dot_b_n; };
 template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
@@ -977,15 +977,16 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     const long per = ((adam.dot_n + gridDim.x - 1) / gridDim.x + 3) & ~3L; // (slices of whole float4s)
     const long lo_i = min(adam.dot_n, per * k), hi_i = min(adam.dot_n, lo_i + per); // (workgroups past the end: an empty slice)
     double acc = 0.0;
-    const bool vec = ((((uintptr_t)adam.dot_a | (uintptr_t)adam.dot_b) & 15) == 0);
+    const long bn = adam.dot_b_n; // period of b (a whole number of float4s for the vector path: a quad of a never straddles two periods)
+    const bool vec = ((((uintptr_t)adam.dot_a | (uintptr_t)adam.dot_b) & 15) == 0) && (bn & 3) == 0;
     if (vec) {
       for (long i = lo_i + 4 * tid; i + 3 < hi_i; i += 4 * SPLAT_BLOCK) {
-        const float4 a = *reinterpret_cast<const float4 *>(adam.dot_a + i), b = *reinterpret_cast<const float4 *>(adam.dot_b + i);
+        const float4 a = *reinterpret_cast<const float4 *>(adam.dot_a + i), b = *reinterpret_cast<const float4 *>(adam.dot_b + i % bn);
         acc += (double)(a.x * b.x) + (double)(a.y * b.y) + (double)(a.z * b.z) + (double)(a.w * b.w);
       }
-      for (long i = lo_i + ((hi_i - lo_i) & ~3L) + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i]);
+      for (long i = lo_i + ((hi_i - lo_i) & ~3L) + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i % bn]);
     } else {
-      for (long i = lo_i + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i]);
+      for (long i = lo_i + tid; i < hi_i; i += SPLAT_BLOCK) acc += (double)(adam.dot_a[i] * adam.dot_b[i % bn]);
     }
     acc = wave_sum(acc);
     if ((tid & 63) == 0) s_dot[tid >> 6] = acc;
@@ -1258,7 +1259,9 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
     if (adam->dot_a) {
       if (!adam->dot_b || adam->dot_n < 1 || !adam->dot_partial || !reg_value) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the inner product needs dot_b, dot_n, dot_partial and reg_value");
       if (loss_in) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the data term comes either as partial sums (loss_in) or as an inner product (dot_a), not both");
+      if (adam->dot_b_n < 0 || adam->dot_b_n > adam->dot_n) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: dot_b_n must be 0 or a period <= dot_n");
       ak.dot_a = adam->dot_a; ak.dot_b = adam->dot_b; ak.dot_n = (long)adam->dot_n; ak.dot_partial = adam->dot_partial;
+      ak.dot_b_n = adam->dot_b_n > 0 ? (long)adam->dot_b_n : (long)adam->dot_n;
     }
   }
   Mat4 m;

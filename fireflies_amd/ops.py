@@ -191,9 +191,10 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
     a.lo, a.hi, a.grad_div, a.n_normalize = float(lo), float(hi), float(grad_div), int(n_normalize)
     if dot is not None:
         da, db, part = dot
-        if da.numel() != db.numel() or part.numel() < rays.shape[0]:
-            raise ValueError("dot = (a, b, partial): a and b of equal size, partial with one float per point")
+        if da.numel() % db.numel() != 0 or part.numel() < rays.shape[0]:
+            raise ValueError("dot = (a, b, partial): a a whole number of b's long (b is repeated), partial with one float per point")
         a.dot_a, a.dot_b, a.dot_n, a.dot_partial = _dev(da, name="dot a").value, _dev(db, name="dot b").value, int(da.numel()), _dev(part, name="dot partial").value
+        a.dot_b_n = int(db.numel())
     return a
 
 
@@ -677,13 +678,15 @@ class DeviceGeometry:
         self._release()
         return img
 
-    def render_fwd_adjoint(self, sd, albedo, tex, spp, seed, gimg, out=None, dot_out=None, fp16=False, sparse_adjoint=False):
+    def render_fwd_adjoint(self, sd, albedo, tex, spp, seed, gimg, out=None, dot_out=None, fp16=False, sparse_adjoint=False, img_out=None):
         """K8 with the adjoint folded in (ffx_render_fwd_adjoint): for a loss whose gradient `gimg` [H,W,3] does not depend on the image.
         -> (img, gtex): the render, and gtex (+)= its adjoint applied to gimg — `out`: accumulate into this [tex_h, tex_w, channels]
         tensor instead of a fresh zeroed one.  dot_out: _abi.ADJOINT_DOT_SLOTS float32 partial sums that <gimg, img> is added to."""
         H, W = sd.cam.height, sd.cam.width
         mats_arg = _check_materials(sd, albedo)
-        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device) if img_out is None else img_out
+        if tuple(img.shape) != (H, W, 3) or img.dtype != (torch.float16 if fp16 else torch.float32):
+            raise ValueError("img_out must be [H, W, 3] of the film's type")
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device) if out is None else out
         if tuple(gimg.shape) != (H, W, 3):
             raise ValueError("gimg must be [H, W, 3]")

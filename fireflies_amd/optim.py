@@ -167,11 +167,12 @@ class PatternOptimizer:
         sd0 = ms.scene_desc(tex_channels=1)  # (sizes only: the pose of the samples comes later)
         # a loss that is linear in the image (its gradient does not depend on the render): forward and adjoint are ONE launch
         # (ffx_render_fwd_adjoint) — no cache, no K9; <gimg, img> goes to _abi.ADJOINT_DOT_SLOTS partial sums
-        # (one scene sample per step and rank: the loss value then comes out of the gradient launch; with several, K9's per-block partial
-        # sums — 4096 atomics — are cheaper than the fused launch's per-pixel ones: tools/adjprobe.py, 510 against 519 us per sample)
-        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and w == 1 and len(self._sample_seeds(self.step_index)) == 1
+        # (one process: the loss value then comes out of the gradient launch, from the step's renders stacked in one buffer; the fused
+        # launch's own per-pixel partial sums would cost more than K9 — tools/adjprobe.py, 519 against 510 us per sample.  Several ranks
+        # exchange the gradient between gradient and update launch and take the cache + K9)
+        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and w == 1 and 1 <= len(self._sample_seeds(self.step_index)) <= 64
                  and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
-        n_slots = _abi.ADJOINT_DOT_SLOTS if fused else ops.render_dot_slots(cam.width, cam.height)
+        n_slots = ops.render_dot_slots(cam.width, cam.height)  # (K9's partial sums of the loss; the fused path evaluates it in the gradient launch)
         use_cache = (not fused) and Fn.cache_supported(sd0, self.spp)
         nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0
         acc_bytes = -(-4 * (s0 * s1 + n_slots) // 128) * 128
@@ -211,6 +212,7 @@ class PatternOptimizer:
             nxt = self._sample_seeds(self.step_index + 1)
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
+        k_sample = 0
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
@@ -219,9 +221,10 @@ class PatternOptimizer:
                     self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()  # (constant by definition)
                 # (<gimg, img>: with ONE sample per step the gradient launch evaluates it from the image — 3 us; K8's own partial sums are
                 # a quarter of a million atomics per render, 27 us, and only used when a step has several samples)
-                one = len(seeds) == 1 and w == 1
-                last_img, _ = geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, dot_out=None if one else loss_slots,
-                                                      sparse_adjoint=True)
+                if getattr(self, "_img_stack", None) is None or tuple(self._img_stack.shape) != (len(seeds), cam.height, cam.width, 3):
+                    self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
+                geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
+                k_sample += 1
                 continue
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
@@ -269,10 +272,10 @@ class PatternOptimizer:
             if getattr(self, "_adam_counter", None) is None:
                 self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
             dot = None
-            if fused and len(seeds) == 1:
+            if fused and seeds:
                 if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
                     self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
-                dot = (last_img, self._lin_g, self._dot_part)
+                dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)
             aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
                                1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot)
             gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,

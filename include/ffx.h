@@ -223,9 +223,11 @@ typedef struct ffx_adam_args {
    * update adds them up: reg_value[2] = the sum, reg_value[1] = sum / loss_div + reg_value[0].  Takes the place of loss_in (not both).
    * K8's own partial sums (ffx_render_fwd_adjoint's dot_out) cost a quarter of a million atomics per render: 27 us; this costs 3. */
   const float *dot_a; /* [dev][dot_n] or NULL */
-  const float *dot_b; /* [dev][dot_n] */
+  const float *dot_b; /* [dev][dot_b_n] */
   int64_t dot_n;
   float *dot_partial; /* [dev][n] scratch */
+  int64_t dot_b_n;    /* period of dot_b: <a, b> = sum_i a[i] * b[i mod dot_b_n] (the S renders of a step stacked in dot_a against ONE
+                         constant gradient); 0 = dot_n */
 } ffx_adam_args;
 int ffx_pattern_fwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                          int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,

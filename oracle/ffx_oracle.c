@@ -1782,7 +1782,8 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   if (rc == FFX_OK && adam->dot_a) { /* the data term as an inner product (takes the place of loss_in) */
     if (!adam->dot_b || adam->dot_n < 1 || !reg_value || loss_in) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the inner product needs dot_b, dot_n, reg_value and no loss_in");
     double acc = 0.0;
-    for (int64_t i = 0; i < adam->dot_n; ++i) acc += (double)adam->dot_a[i] * (double)adam->dot_b[i];
+    const int64_t bn = adam->dot_b_n > 0 ? adam->dot_b_n : adam->dot_n;
+    for (int64_t i = 0; i < adam->dot_n; ++i) acc += (double)adam->dot_a[i] * (double)adam->dot_b[i % bn];
     reg_value[2] = (float)acc;
     reg_value[1] = (float)acc / (loss_div > 0.f ? loss_div : 1.0f) + reg_value[0];
   }

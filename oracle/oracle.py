@@ -153,6 +153,7 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
             da, db = (np.ascontiguousarray(v, np.float32).reshape(-1) for v in adam["dot"])
             part = np.zeros(n, np.float32)
             aa.dot_a, aa.dot_b, aa.dot_n, aa.dot_partial = da.ctypes.data, db.ctypes.data, int(da.size), part.ctypes.data
+            aa.dot_b_n = int(db.size)
     api().call("ffx_pattern_bwd_blur", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(_f32(tsum)), _p(_f32(tsor)) if tsor is not None else None,
                _p(gtex) if gtex is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val),
                _p(li) if li is not None else None, 0 if li is None else int(li.size), float(loss_div), int(ksize), float(blur_sigma), None,

@@ -1040,9 +1040,12 @@ def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, si
     np.testing.assert_allclose(host(r_b), r_o, rtol=1e-4, atol=2e-5)  # (Adam's first steps are sign-like: tiny gradient differences move a ray by lr at most)
     # ---- the data term as an inner product evaluated by the same launch (ffx_adam_args.dot_*): <a, b> over an odd number of floats,
     #      16-byte aligned and not; reg_value[2] = the sum, reg_value[1] = sum / loss_div + regulariser — and the update is the same
-    for n_dot, shift in ((3 * 37 * 29, 0), (4099, 1), (5, 0)):
-        a_np, b_np = rng.standard_normal(n_dot + shift).astype(np.float32), rng.standard_normal(n_dot + shift).astype(np.float32)
+    #      b may be shorter than a and is then repeated (the renders of a step stacked against one constant gradient)
+    for n_dot, shift, reps in ((3 * 37 * 29, 0, 1), (4099, 1, 1), (5, 0, 1), (4 * 500, 0, 3), (7 * 11, 0, 5)):
+        b_np = rng.standard_normal(n_dot + shift).astype(np.float32)
+        a_np = np.concatenate([np.zeros(shift, np.float32), rng.standard_normal(n_dot * reps).astype(np.float32)])
         a_d, b_d = dev(a_np)[shift:], dev(b_np)[shift:]
+        b_np = np.concatenate([b_np[:shift], np.tile(b_np[shift:], reps)])  # (what the products are taken with)
         (r_c, m_c, v_c, st_c), (r_e, m_e, v_e, st_e) = fresh(), fresh()
         _, ts_c, to_c, ws_c, _ = ops.pattern_fwd_blur(r_c, KF, sigma, s0, s1, ks, bs, True)
         part = torch.empty(n, device="cuda")
@@ -1060,7 +1063,7 @@ def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, si
             ops.pattern_bwd_blur(r_c, KF, sigma, s0, s1, ts_c, to_c, dev(gtex), 0.1, ws_c, ks, bs, loss_in=dev(li), adam=bad_aa)
     _, _, val_o, _ = oracle.pattern_bwd_blur(rays.copy(), KF, sigma, s0, s1, tsum_o, tsor_o, gtex, 0.1, ws_o, ks, bs, loss_div=4.0,
                                               adam=dict(exp_avg=np.zeros_like(rays), exp_avg_sq=np.zeros_like(rays), step=np.zeros(1, np.float32), lr=5e-3, beta1=0.9, beta2=0.999,
-                                                        eps=1e-8, KF_inv=KFi, lo=0.05, hi=0.95, grad_div=4.0, n_normalize=2, dot=(a_np[shift:], b_np[shift:])))
+                                                        eps=1e-8, KF_inv=KFi, lo=0.05, hi=0.95, grad_div=4.0, n_normalize=2, dot=(a_np[shift:], b_np[shift:shift + n_dot])))
     assert abs(float(val_o[2]) - want) <= 2e-6 * max(mag, 1.0)
     # misuse is refused: an update of other rays than the gradient's, Adam arguments without a counter
     bad = ops.adam_args(r_a, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_b)
