@@ -182,8 +182,10 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
     dot = (a, b, partial): the launch also evaluates <a, b> (two float32 tensors of equal size: the render and the constant gradient of a loss
     linear in it) as the step's data term; partial: float32 scratch of one element per point."""
     a = _abi.AdamArgs()
-    a.rays, a.exp_avg, a.exp_avg_sq = _dev(rays, name="rays").value, _dev(exp_avg, name="exp_avg").value, _dev(exp_avg_sq, name="exp_avg_sq").value
-    a.step = _dev(step, name="step").value
+    a.rays = _dev(rays, name="rays").value
+    if exp_avg is not None:  # (exp_avg = exp_avg_sq = step = None: no update, only the inner product — a multi-rank step)
+        a.exp_avg, a.exp_avg_sq = _dev(exp_avg, name="exp_avg").value, _dev(exp_avg_sq, name="exp_avg_sq").value
+        a.step = _dev(step, name="step").value
     a.grad_out = _dev(grad_out, name="grad_out").value if grad_out is not None else None
     a.counter = _dev(counter, torch.int32, "counter").value
     a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)

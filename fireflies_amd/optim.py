@@ -170,7 +170,7 @@ class PatternOptimizer:
         # (one process: the loss value then comes out of the gradient launch, from the step's renders stacked in one buffer; the fused
         # launch's own per-pixel partial sums would cost more than K9 — tools/adjprobe.py, 519 against 510 us per sample.  Several ranks
         # exchange the gradient between gradient and update launch and take the cache + K9)
-        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and w == 1 and 1 <= len(self._sample_seeds(self.step_index)) <= 64
+        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
                  and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
         n_slots = ops.render_dot_slots(cam.width, cam.height)  # (K9's partial sums of the loss; the fused path evaluates it in the gradient launch)
         use_cache = (not fused) and Fn.cache_supported(sd0, self.spp)
@@ -257,8 +257,18 @@ class PatternOptimizer:
         grad = torch.empty_like(rd)
         if getattr(self, "_scratch", None) is None or self._scratch.shape != tsum.shape:
             self._scratch = torch.empty_like(tsum)  # (only touched when a footprint does not fit the workgroup's LDS)
+        if getattr(self, "_adam_counter", None) is None:
+            self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
+        dot = None
+        if fused and seeds:
+            if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
+                self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
+            dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)
         if w > 1:
-            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=loss_slots, loss_div=float(S), scratch=self._scratch)
+            # (several ranks: this rank's data term from the gradient launch — Adam arguments without state: no update —, then the exchange)
+            aa = ops.adam_args(rd, None, None, None, self._adam_counter, 0.0, 0.0, 0.0, 0.0, self.laser._KF_inv, 0.0, 1.0, dot=dot) if dot is not None else None
+            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
+                                               loss_div=float(S), adam=aa, scratch=self._scratch)
             flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), val[2:3]])  # (val[2]: this rank's data term)
             dist.allreduce_sum_(flat)  # the ONE exchange of a step: [3N + 1] floats
             gsum = flat[:-1].reshape(rays.shape).contiguous()
@@ -269,13 +279,6 @@ class PatternOptimizer:
         else:
             # nothing to exchange: the whole backward half is ONE launch — gradient of the data term and of the regulariser, the step's total
             # loss, and (by the workgroup that finishes last) Adam + Laser.clamp_to_fov() + normalize_rays() on grad = gsum / S + regulariser
-            if getattr(self, "_adam_counter", None) is None:
-                self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
-            dot = None
-            if fused and seeds:
-                if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
-                    self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
-                dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)
             aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
                                1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot)
             gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,

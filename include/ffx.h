@@ -208,7 +208,8 @@ int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[
  * ---------------------------------------------------------------------------------------- */
 typedef struct ffx_adam_args {
   float *rays;        /* [dev][n,3] in/out: must be the `rays` argument of the call */
-  float *exp_avg;     /* [dev][n,3] */
+  float *exp_avg;     /* [dev][n,3]; NULL (with exp_avg_sq, step NULL): NO update — only the inner product below is evaluated (a multi-rank
+                         step, which exchanges the gradient before it updates: ffx_adam_clamp_step afterwards) */
   float *exp_avg_sq;  /* [dev][n,3] */
   float *step;        /* [dev][1], incremented */
   float *grad_out;    /* [dev][n,3] or NULL (needed when there is anything to combine: grays_reg or grad_div != 1) */

@@ -1773,10 +1773,11 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   free(gts);
   if (rc != FFX_OK || !adam) return rc;
   if (adam->rays != rays) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the update is applied to the rays the gradient was taken at");
+  const int no_update = !adam->exp_avg && !adam->exp_avg_sq && !adam->step; /* only the inner product (a multi-rank step) */
   float *zeros = NULL;
   const float *gd = gtex ? grays_data : NULL;
   if (!gd) { zeros = (float *)calloc((size_t)3 * n, sizeof(float)); gd = zeros; }
-  rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
+  if (!no_update) rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
                            adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, s);
   free(zeros);
   if (rc == FFX_OK && adam->dot_a) { /* the data term as an inner product (takes the place of loss_in) */

@@ -1058,6 +1058,11 @@ def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, si
         assert abs(float(val_c[2]) - want) <= 2e-6 * mag and float(val_c[0]) == float(val_e[0])
         assert float(val_c[1]) == pytest.approx(want / 4.0 + float(val_c[0]), rel=1e-5, abs=1e-6 * mag)
         assert torch.equal(r_c, r_e) and int(counter) == 0
+        # Adam arguments WITHOUT state: no update, only the inner product (a multi-rank step exchanges the gradient before it updates)
+        r_n = dev(rays).clone()
+        aa = ops.adam_args(r_n, None, None, None, counter, 0.0, 0.0, 0.0, 0.0, KFi, 0.0, 1.0, dot=(a_d, b_d, part))
+        gd_n, _, val_n = ops.pattern_bwd_blur(r_n, KF, sigma, s0, s1, ts_c, to_c, dev(gtex), 0.1, ws_c, ks, bs, loss_div=4.0, adam=aa, scratch=torch.empty_like(ts_c))
+        assert torch.equal(r_n, dev(rays)) and float(val_n[2]) == float(val_c[2]) and int(counter) == 0
         with pytest.raises(Exception, match="not both"):
             bad_aa = ops.adam_args(r_c, m_c, v_c, st_c, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=torch.empty_like(r_c), dot=(a_d, b_d, part))
             ops.pattern_bwd_blur(r_c, KF, sigma, s0, s1, ts_c, to_c, dev(gtex), 0.1, ws_c, ks, bs, loss_in=dev(li), adam=bad_aa)
