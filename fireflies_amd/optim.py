@@ -213,35 +213,17 @@ class PatternOptimizer:
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
         k_sample = 0
-        # the samples of a step are independent renders into one accumulator (float atomics): with several of them the fused launches go to
-        # two streams in turn, so that the tail of one overlaps the start of the next (mi.render does the same for plain renders)
-        two = None
-        if fused and len(seeds) > 1 and os.environ.get("FFX_RENDER_STREAMS", "2") != "1" and geom._async and ms._mats_in_sd:  # (materials as kernel arguments: nothing uploaded on the caller's stream)
-            if getattr(self, "_sample_streams", None) is None:
-                self._sample_streams = [torch.cuda.Stream(tex.device), torch.cuda.Stream(tex.device)]
-            two = self._sample_streams
-            main = torch.cuda.current_stream(tex.device)
-            for rs in two:
-                rs.wait_stream(main)  # texture, cleared accumulator
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
             if fused:  # K8 scatters the pixel's footprint x gimg straight into gtex and adds <gimg, img> to the loss slots
                 if getattr(self, "_lin_g", None) is None or tuple(self._lin_g.shape) != (cam.height, cam.width, 3):
                     self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()  # (constant by definition)
-                    if two is not None:
-                        for rs in two:
-                            rs.wait_stream(torch.cuda.current_stream(tex.device))
                 # (<gimg, img>: with ONE sample per step the gradient launch evaluates it from the image — 3 us; K8's own partial sums are
                 # a quarter of a million atomics per render, 27 us, and only used when a step has several samples)
                 if getattr(self, "_img_stack", None) is None or tuple(self._img_stack.shape) != (len(seeds), cam.height, cam.width, 3):
                     self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
-                if two is None:
-                    geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
-                else:
-                    with torch.cuda.stream(two[k_sample & 1]):
-                        geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True,
-                                                img_out=self._img_stack[k_sample])
+                geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
                 k_sample += 1
                 continue
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
@@ -266,9 +248,6 @@ class PatternOptimizer:
             else:
                 gtex += geom.render_bwd(sd, mats, self.spp, seed, gimg).reshape(gtex.shape)
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
-        if two is not None:
-            for rs in two:
-                torch.cuda.current_stream(tex.device).wait_stream(rs)  # every sample's adjoint has landed in gtex
         # K3^T is applied inside the gradient launch, over the points' footprints only (ffx_pattern_bwd_blur: the gradient of the separate
         # transpose blur + ffx_pattern_bwd, bit for bit)
         g2 = gtex.reshape(tex.shape) if seeds else None
