@@ -144,7 +144,9 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
         gout = np.zeros((n, 3), np.float32)
         cnt = np.zeros(1, np.uint32)
         aa = _abi.AdamArgs()
-        aa.rays, aa.exp_avg, aa.exp_avg_sq, aa.step = rays.ctypes.data, adam["exp_avg"].ctypes.data, adam["exp_avg_sq"].ctypes.data, adam["step"].ctypes.data
+        aa.rays = rays.ctypes.data
+        if adam["exp_avg"] is not None:  # (None: no update, only the inner product)
+            aa.exp_avg, aa.exp_avg_sq, aa.step = adam["exp_avg"].ctypes.data, adam["exp_avg_sq"].ctypes.data, adam["step"].ctypes.data
         aa.grad_out, aa.counter = gout.ctypes.data, cnt.ctypes.data
         aa.lr, aa.beta1, aa.beta2, aa.eps = float(adam["lr"]), float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"])
         aa.KF_inv = _m16(adam["KF_inv"])

@@ -399,6 +399,62 @@ def test_pattern_gradient_matches_central_differences(oracle):
     assert checked == 12
 
 
+def test_round3_entry_points_are_the_compositions_they_replace(oracle):
+    """The entry points that carry their neighbours along (include/ffx.h, round 3), as the oracle implements them: each equals, bit for
+    bit, the chain of separate calls it stands for — the chain that the central-difference test above validates.
+    ffx_pattern_fwd_blur = pattern_fwd + blur_fwd;  ffx_pattern_bwd_blur = blur_bwd + pattern_bwd (+ adam_clamp_step, + <a, b>);
+    ffx_render_fwd_adjoint = render_fwd_cache + render_bwd_cached."""
+    sc = scenes.vocalfold(width=40, height=32, tex=48, frames=2, n_fold=12, tube=(16, 16))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    g = oracle.Geometry(pool, tris, shape, off)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    K = sc.projector.K.astype(np.float64)
+    KF = (K @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    ndc = (rng.random((12, 3)) * [0.9, 0.9, 0.0] + [0.05, 0.05, 0.5]).astype(np.float32)
+    rays = oracle.transform_points(ndc, KFi)
+    rays = (rays / np.linalg.norm(rays, axis=1, keepdims=True)).astype(np.float32)
+    s0 = s1 = 48
+    # forward
+    pts, tsum, tsor, ws = oracle.pattern_fwd(rays, KF, 10.0, s0, s1, True)
+    tex = oracle.blur_fwd(tsum)
+    pts2, tsum2, tsor2, ws2, tex2 = oracle.pattern_fwd_blur(rays, KF, 10.0, s0, s1, 5, 3.0, True)
+    for a, b in ((pts, pts2), (tsum, tsum2), (tsor, tsor2), (ws, ws2), (tex, tex2)):
+        np.testing.assert_array_equal(a, b)
+    # render + adjoint in one call
+    gimg = rng.standard_normal((32, 40, 3)).astype(np.float32)
+    img_c, cache = g.render_fwd_cache(sd, alb, tex[..., None], 4, seed=2)
+    gtex_c, dot_c = g.render_bwd_cached(sd, alb, cache, 4, gimg, img=img_c)
+    img_f, gtex_f, dot_f = g.render_fwd_adjoint(sd, alb, tex[..., None], 4, 2, gimg)
+    np.testing.assert_array_equal(img_c, img_f)
+    np.testing.assert_array_equal(gtex_c, gtex_f)
+    assert dot_f == pytest.approx(dot_c, rel=1e-6) and dot_f == pytest.approx(float((gimg.astype(np.float64) * img_f).sum()), rel=1e-5)
+    np.testing.assert_allclose(gtex_f, g.render_bwd(sd, alb, 4, 2, gimg), rtol=1e-4, atol=1e-6 * np.abs(gtex_f).max())  # (the re-tracing adjoint)
+    # backward: K3^T + pattern gradient + update + the step's data term as an inner product
+    gts = oracle.blur_bwd(gtex_f[..., 0])
+    gd, gr, reg = oracle.pattern_bwd(rays, KF, 10.0, s0, s1, tsum, tsor, gts, 0.1, ws)
+    r_a, m_a, v_a, st_a = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    g_a = (gd / np.float32(2.0) + gr).astype(np.float32)
+    oracle.adam_clamp_step(r_a, g_a, m_a, v_a, st_a, 5e-3, 0.9, 0.999, 1e-8, KF, KFi, 0.05, 0.95, 2)
+    r_b, m_b, v_b, st_b = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    gd2, gr2, val2, g_b = oracle.pattern_bwd_blur(r_b, KF, 10.0, s0, s1, tsum, tsor, gtex_f[..., 0], 0.1, ws, 5, 3.0, loss_div=2.0,
+                                                  adam=dict(exp_avg=m_b, exp_avg_sq=v_b, step=st_b, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, KF_inv=KFi, lo=0.05, hi=0.95,
+                                                            grad_div=2.0, n_normalize=2, dot=(img_f, gimg)))
+    np.testing.assert_array_equal(gd, gd2)
+    np.testing.assert_array_equal(gr, gr2)
+    np.testing.assert_array_equal(g_a, g_b)
+    np.testing.assert_array_equal(r_a, r_b)
+    assert st_b[0] == 1.0 and float(val2[0]) == pytest.approx(reg, rel=1e-6)
+    assert float(val2[2]) == pytest.approx(dot_f, rel=1e-5) and float(val2[1]) == pytest.approx(dot_f / 2.0 + reg, rel=1e-5)
+    # ... and without optimiser state: the gradient and the data term, no update
+    r_c = rays.copy()
+    _, _, val3, _ = oracle.pattern_bwd_blur(r_c, KF, 10.0, s0, s1, tsum, tsor, gtex_f[..., 0], 0.1, ws, 5, 3.0, loss_div=2.0,
+                                            adam=dict(exp_avg=None, exp_avg_sq=None, step=None, lr=0, beta1=0, beta2=0, eps=0, KF_inv=KFi, lo=0, hi=1, dot=(img_f, gimg)))
+    np.testing.assert_array_equal(r_c, rays)
+    assert float(val3[2]) == float(val2[2])
+
+
 def test_l1_value_grad(oracle):
     """weight * L1Loss(a, b) (rasterization.py:579,589-600) and its gradient with respect to a"""
     rng = np.random.default_rng(2)
