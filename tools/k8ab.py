@@ -71,7 +71,7 @@ def main():
     base = None
     for rnd in range(2):  # two interleaved rounds: drift of the clocks shows up as a difference between them
         for name, path in builds:
-            env = dict(os.environ, FFX_LIB=path)
+            env = dict(os.environ, FFX_LIB=path, FFX_RENDER_STREAMS="1")  # (one stream: back-to-back launches of ONE kernel at a time — on two they overlap and each reads twice as long)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + extra, env=env, capture_output=True, text=True)
             try:
                 d = json.loads(r.stdout.strip().splitlines()[-1])
