@@ -15,6 +15,8 @@ import time
 
 import torch
 
+os.environ.setdefault("FFX_RENDER_STREAMS", "1")  # (per-step GPU intervals are read from events on the CURRENT stream: renders must run there)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fireflies_amd import mi, workloads  # noqa: E402
 
