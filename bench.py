@@ -159,7 +159,7 @@ def _profile_files(suffix, key="", grad=False):
     return [f for _, f in sorted(hits)]
 
 
-def pmc_traffic(kernel_prefix, tag="r", key=""):
+def pmc_traffic(kernel_prefix, tag="r", key="", adjoint_instance=False):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC passes (profiles/*_pmc_summary.json,
     written by tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench at the workload
     `key` names; FETCH_SIZE doubled as MI355X_MICROARCH.md HBM section prescribes for gfx950).  The caller
@@ -171,7 +171,10 @@ def pmc_traffic(kernel_prefix, tag="r", key=""):
             d = json.load(open(f))
         except Exception:
             continue
-        for k, v in sorted(d.items(), key=lambda kv: ", true>" in kv[0]):  # (of the render kernel's instances: the plain forward before the forward + adjoint one)
+        # (of the render kernel's instances: the plain forward `<..., false>` unless the forward + adjoint one `<..., true>` is asked for)
+        for k, v in sorted(d.items(), key=lambda kv: (", true>" in kv[0]) != adjoint_instance):
+            if adjoint_instance and ", true>" not in k:
+                continue
             if k.startswith(kernel_prefix) and "hbm_bytes_corrected" in v:
                 best = {"bytes": v["hbm_bytes_corrected"], "raw_bytes": v["hbm_bytes_raw"], "source": os.path.basename(f)}
                 break
@@ -236,6 +239,24 @@ def valu_issue(kernel_substr, kernel_ms, key=""):
     return None
 
 
+def cited_profiles(pkey=""):
+    """the committed files (profiles/...) a line of this bench cites for workload `pkey` — newest of each kind; tests/test_bench_cpu.py
+    checks that each exists, is not empty and names kernels of the current tree"""
+    if pkey is None:
+        return []
+    out = []
+    for suffix, grad in (("pmc_summary.json", False), ("pmc_summary.json", True), ("sq_instruction_mix.json", False), ("kernel_stats.csv", False),
+                         ("phaseclk.txt", False), ("cpu_oracle_table.json", False)):
+        ff = _profile_files(suffix, pkey, grad=grad)
+        if ff:
+            out.append("profiles/" + os.path.basename(ff[-1]))
+    for suffix in ("isa_operand_forms.json", "issue_rates.txt"):
+        ff = _profile_files(suffix, "")
+        if ff:
+            out.append("profiles/" + os.path.basename(ff[-1]))
+    return out
+
+
 def algorithmic_bytes(wl, width, height, fp16=False):
     """K8 render_fwd  B = G + 4*T + 3*s_r*W*H,  G = 12*V + 12*F + 32*N_nodes
     (V = vertices of one pose, F = triangles, N_nodes = BVH nodes, T = texels of the 1-channel
@@ -283,7 +304,7 @@ def _effective_cores():
     return n, quota
 
 
-def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
+def cpu_baseline(wl, tex, spp_full, cpu_spp, seed, grad_wl=None):
     """CPU oracle on the same pose / texture: all host threads (OpenMP over pixels) at `cpu_spp` samples per pixel,
     and ONE thread on a smaller bounded sample; both scaled to the full spp.  Rank 0, N = 1 only."""
     from fireflies_amd import scenes
@@ -325,7 +346,55 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed):
             _omp_set_threads(cores)
         out["one_thread"] = {"value": 1.0 / (t_upd1 + t1 * spp_full / spp1), "unit": "renders/sec", "cores": 1,
                              "sample": f"1 render at {spp1} of {spp_full} spp ({t1:.1f} s measured, scaled x{spp_full / spp1:g}) + refit {t_upd1 * 1e3:.1f} ms"}
+    if grad_wl is not None:
+        out["grad_steps_per_sec"] = cpu_grad_step(grad_wl, spp_full, cpu_spp, seed, cores)
     return out
+
+
+def cpu_grad_step(wg, spp_full, cpu_spp, seed, cores):
+    """the second half of the metric on the host: ONE pattern-gradient step chained through the oracle's entry points — K1 + K2 (sum,
+    softor) + K3, re-fit, forward + adjoint of the coverage loss (the oracle's ffx_render_fwd_adjoint), K3^T, K2-bwd, K1-bwd, the
+    overlap regulariser, Adam + clamp_to_fov — on the gradient bracket's scene (64-point pattern), all threads, one scene sample."""
+    import numpy as np
+
+    from fireflies_amd import scenes
+    from oracle import oracle as orc
+
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(wg.data)
+    geo = orc.Geometry(wg.mi_scene.geom.src_verts.cpu().numpy(), tris, shape, off)
+    sd = wg.mi_scene.scene_desc(tex_channels=1)
+    albh = wg.mi_scene.albedo.cpu().numpy()
+    rays = wg.laser._rays.detach().cpu().numpy().copy()
+    KF, KFi = wg.laser._KF, wg.laser._KF_inv
+    s0, s1 = wg.tex_size
+    H, W = sd.cam.height, sd.cam.width
+    gimg = np.zeros((H, W, 3), np.float32)
+    gimg[..., 1] = -1.0 / float(H * W)
+    _omp_set_threads(cores)
+    t0 = time.perf_counter()
+    pts = np.ascontiguousarray(orc.project_rays_fwd(rays, KF)[:, :2])
+    tsum = orc.splat_fwd(pts, wg.sigma, 0, -1, s0, s1)
+    tsor = orc.splat_fwd(pts, wg.sigma, 1, -1, s0, s1)
+    texh = orc.blur_fwd(tsum)
+    t_pat_f = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    geo.update(wg.mi_scene._xforms.numpy(), wg.mi_scene._offs)
+    t_upd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    img, gtex, _dot = geo.render_fwd_adjoint(sd, albh, texh, cpu_spp, seed, gimg)
+    t_r = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gts = orc.blur_bwd(np.ascontiguousarray(gtex.reshape(texh.shape)))
+    gp = orc.splat_bwd(pts, wg.sigma, 0, -1, s0, s1, tsum, gts)
+    reg, gd = orc.l1_value_grad(tsor, tsum, 0.1)
+    gp = gp + orc.splat_bwd(pts, wg.sigma, 1, -1, s0, s1, tsor, gd) - orc.splat_bwd(pts, wg.sigma, 0, -1, s0, s1, tsum, gd)
+    grad = orc.project_rays_bwd(rays, KF, np.concatenate([gp, np.zeros((pts.shape[0], 1), np.float32)], 1))
+    orc.adam_clamp_step(rays, grad, np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32), 1e-3, 0.9, 0.999, 1e-8, KF, KFi, 0.05, 0.95, 2)
+    t_pat_b = time.perf_counter() - t0
+    per_step = t_pat_f + t_upd + t_r * (spp_full / cpu_spp) + t_pat_b
+    return {"value": 1.0 / per_step, "unit": "pattern-gradient steps/sec", "cores": cores, "kind": "port",
+            "sample": f"1 step, 1 scene sample: pattern forward {t_pat_f * 1e3:.0f} ms + refit {t_upd * 1e3:.1f} ms + forward-and-adjoint render at {cpu_spp} of {spp_full} spp "
+                      f"{t_r:.1f} s (scaled x{spp_full / cpu_spp:g}) + pattern backward and update {t_pat_b * 1e3:.0f} ms; gcc -O2 scalar oracle, OpenMP on {cores} threads"}
 
 
 def launch_ranks(n, argv):
@@ -465,6 +534,14 @@ def main():
     random.seed(base_seed + rank)
 
     def render_step(i):
+        # the reference's loop consumes every image (examples/vocalfold_scene.py:14-16,115: `mi.render(...).torch()`): the caller's stream
+        # waits for the render before the next step's work is issued on it
+        wl.ff_scene.randomize()
+        return mi.render(wl.mi_scene, spp=args.spp, seed=base_seed + i * world + rank, fp16=args.fp16).torch()
+
+    def render_step_unread(i):
+        # the same step with the image handle dropped unread: consecutive renders then overlap on the scene's two render streams
+        # (fireflies_amd/mi.py _RenderedXf) — reported as `value_overlapped`, never as `value`
         wl.ff_scene.randomize()
         return mi.render(wl.mi_scene, spp=args.spp, seed=base_seed + i * world + rank, fp16=args.fp16)
 
@@ -482,18 +559,16 @@ def main():
         return i >= first + off and (i - first - off) % 8 == 0 and (i - first - off) // 8 < TIMED_STEPS
 
     w_render = 0 if args.no_render_steps else args.warmup
+    n_render = args.steps if not args.no_render_steps else 1
 
     def timed_render_step(i):
-        geom.timing = events if _timed(i, w_render, args.steps if not args.no_render_steps else 1) else None
+        geom.timing = events if _timed(i, w_render, n_render) else None
         return render_step(i)
 
     # Preflight (FFX_BENCH_PREFLIGHT=0: off): before anything is timed on this box, the kernel about to be timed must agree with the library's
     # OTHER implementation of the same render — the per-lane kernels (one ray per lane, LDS stack, binary BVH: FFX_TRAVERSAL=lane; ~20x
     # slower, the A/B baseline of DESIGN 5.1) — on the scene's current pose, three sample seeds.  The oracle is the checker of the test
     # suite and of smoke(); this is the cheap on-device cross-check that a broken build or a faulty box does not produce a benchmark line.
-    # Side effect, stated because it matters for a 20-step bracket: the ~35 ms of GPU work it does end right where the warm-up steps
-    # begin, so the bracket starts at sustained clocks instead of the idle clocks the host-side set-up left (tools/posecost.py: the first
-    # ~50 renders after an idle phase run up to 6 % slower; README "Numbers").
     preflight = {}
 
     def preflight_render():
@@ -510,8 +585,9 @@ def main():
                                "pixel_channels_beyond_1e-4_of_scale": worst}
 
     do_preflight = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ and not args.no_render_steps
-    t_render = _bracket(timed_render_step, args.steps if not args.no_render_steps else 1, w_render, dev, preflight_render if do_preflight else None,
-                        (lambda k: mi.render(wl.mi_scene, spp=args.spp, seed=k, fp16=args.fp16)) if (SETTLE_RENDERS > 0 and not args.no_render_steps) else None)
+    settle_render = (lambda k: mi.render(wl.mi_scene, spp=args.spp, seed=k, fp16=args.fp16)) if (SETTLE_RENDERS > 0 and not args.no_render_steps) else None
+    # `value`: the consuming step, settled clocks (config.clock_settle)
+    t_render = _bracket(timed_render_step, n_render, w_render, dev, preflight_render if do_preflight else None, settle_render)
     geom.timing = None
     torch.cuda.synchronize()
     renders_per_sec = world * args.steps / t_render
@@ -523,6 +599,7 @@ def main():
     # a steadier kernel figure than the bracket's two instrumented launches: 16 more steps of the same loop AFTER the bracket (not part of
     # `value`), every launch between HIP events — the markers keep the next re-fit from overlapping the kernel, so this is K8 alone
     k8_post_ms = k8_post_n = None
+    value_overlapped = value_cold = None
     if not args.no_render_steps:
         geom.timing = events
         for i in range(16):
@@ -531,89 +608,177 @@ def main():
         torch.cuda.synchronize()
         k8_post_ms, k8_post_n = _kernel_ms(events, "render_fwd")
         events.clear()
+        if os.environ.get("FFX_BENCH_EXTRA_BRACKETS", "1") != "0":
+            # (i) the same bracket with the image handles dropped unread (two render streams overlap consecutive renders)
+            paths0 = dict(wl.mi_scene.render_paths)
+            t_unread = _bracket(render_step_unread, args.steps, args.warmup, dev, None, settle_render)
+            value_overlapped = world * args.steps / t_unread
+            paths_unread = {k: v - paths0[k] for k, v in wl.mi_scene.render_paths.items()}
+            # (ii) the consuming bracket again from a COLD start: the GPU idles first (the clocks fall back within ~0.3 s, tools/posecost.py),
+            # no settle launches — what `python bench.py --steps K --warmup W` measured before round 3
+            torch.cuda.synchronize()
+            time.sleep(0.4)
+            t_cold = _bracket(render_step, args.steps, args.warmup, dev, None, None)
+            value_cold = world * args.steps / t_cold
     bytes_ = algorithmic_bytes(wl, W, H, fp16=args.fp16)
 
     # ------------------------------------------------------------------ pattern-gradient steps/sec
     grad = {}
     if not args.no_grad_steps:
+        from fireflies_amd import functional as Fn
+        from fireflies_amd import ops
+        from fireflies_amd.optim import image_l1_loss
+
         wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device, principled=args.material == "principled")
         S = args.grad_samples if args.grad_samples > 0 else world
         opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=S, base_seed=7)
         gevents = []
+        T = wg.tex_size[0] * wg.tex_size[1]
 
         def grad_step(i):
             wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup, args.steps) else None
             return opt.step()
 
-        def preflight_grad():
-            # the adjoint about to be timed (K9 from the footprint cache K8 writes) against the library's other adjoint (re-tracing every
-            # sample, ffx_render_bwd) on the scene's current pose, four sample seeds; the bound is the parity tests' (float atomics: order)
-            from fireflies_amd import functional as Fn
-            from fireflies_amd import ops
+        def _adjoint_close(a, b, what):
+            scale = float(b.abs().max())
+            err = (a - b).abs()
+            bad = float((err > 1e-3 * scale).float().mean())
+            if not (scale > 0 and bad <= 1e-3 and float(err.max()) <= 0.1 * scale):
+                raise SystemExit(f"bench.py preflight: {what}: {bad:.2e} of the texels differ — not timing an adjoint whose output is in doubt")
+            return bad
 
+        def _pose_inputs():
             ms, geom_g = wg.mi_scene, wg.mi_scene.geom
             sd = ms.scene_desc(tex_channels=1)
-            if not Fn.cache_supported(sd, args.spp):
-                return
             with torch.no_grad():
                 tex3 = workloads.build_texture(wg).contiguous()
             tex3 = tex3[..., 1:2].contiguous() if tex3.dim() == 3 else tex3.unsqueeze(-1).contiguous()
-            cache = torch.empty(ops.render_cache_bytes_sd(sd, args.spp), dtype=torch.uint8, device=dev)
+            return ms, geom_g, sd, tex3
+
+        def preflight_grad_fused():
+            # the kernel the default gradient bracket times — forward + adjoint in ONE launch (ffx_render_fwd_adjoint, the instance
+            # k_render_fwd_pk<..., true>) — against the library's two other routes to the same pair: the plain forward for the image and
+            # the re-tracing adjoint (ffx_render_bwd) for the texture gradient, on the scene's current pose, four sample seeds
+            ms, geom_g, sd, tex3 = _pose_inputs()
             gimg = torch.zeros((H, W, 3), device=dev)
             gimg[..., 1] = -1.0 / (H * W)
+            worst = worst_img = 0.0
+            for k in range(4):
+                mats = ms.materials_arg(sd)
+                img_f, gt_f = geom_g.render_fwd_adjoint(sd, mats, tex3, args.spp, 55 + k, gimg)
+                img_p = geom_g.render_fwd(sd, mats, tex3, args.spp, 55 + k, False)
+                gt_r = geom_g.render_bwd(sd, mats, args.spp, 55 + k, gimg)
+                worst_img = max(worst_img, _images_agree(img_f, img_p, args.spp, "forward + adjoint launch vs plain forward (image)"))
+                worst = max(worst, _adjoint_close(gt_f, gt_r, "forward + adjoint launch vs re-traced adjoint"))
+            preflight["gradient"] = {"checked": "k_render_fwd_pk<..., true> (ffx_render_fwd_adjoint: the launch the gradient bracket times) against k_render_fwd_pk<..., false> "
+                                                "(image) and k_render_bwd_pk (re-tracing adjoint) on the current pose", "adjoints": 4,
+                                     "texels_beyond_1e-3_of_scale": worst, "pixel_channels_beyond_1e-4_of_scale": worst_img}
+
+        def preflight_grad_cached():
+            # the adjoint the NON-LINEAR bracket times (K9 from the footprint cache K8 writes) against the re-tracing adjoint, four seeds
+            ms, geom_g, sd, tex3 = _pose_inputs()
+            if not Fn.cache_supported(sd, args.spp):
+                return
+            cache = torch.empty(ops.render_cache_bytes_sd(sd, args.spp), dtype=torch.uint8, device=dev)
+            gimg = torch.randn((H, W, 3), device=dev).sign_() / (3.0 * H * W)  # (the shape of an L1 loss's gradient)
             worst = 0.0
             for k in range(4):
                 mats = ms.materials_arg(sd)
                 geom_g.render_fwd(sd, mats, tex3, args.spp, 55 + k, False, cache=cache)
                 a = geom_g.render_bwd_cached(sd, mats, cache, args.spp, gimg)
                 b = geom_g.render_bwd(sd, mats, args.spp, 55 + k, gimg)
-                scale = float(b.abs().max())
-                err = (a - b).abs()
-                bad = float((err > 1e-3 * scale).float().mean())
-                if not (scale > 0 and bad <= 1e-3 and float(err.max()) <= 0.1 * scale):
-                    raise SystemExit(f"bench.py preflight: cached adjoint vs re-traced adjoint: {bad:.2e} of the texels differ — not timing an adjoint whose output is in doubt")
-                worst = max(worst, bad)
-            preflight["gradient"] = {"checked": "k_render_bwd_cached (from K8's footprint cache) against k_render_bwd_pk (re-tracing) on the current pose", "adjoints": 4,
-                                     "texels_beyond_1e-3_of_scale": worst}
+                worst = max(worst, _adjoint_close(a, b, "cached adjoint vs re-traced adjoint"))
+            preflight["gradient_nonlinear"] = {"checked": "k_render_bwd_cached_tiled16 (from the footprint cache k_render_fwd_pk writes) against k_render_bwd_pk (re-tracing) "
+                                                          "on the current pose", "adjoints": 4, "texels_beyond_1e-3_of_scale": worst}
 
-        t_grad = _bracket(grad_step, args.steps, args.warmup, dev, preflight_grad if (do_preflight or (args.no_render_steps and os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ)) else None,
-                          (lambda k: mi.render(wg.mi_scene, spp=args.spp, seed=k)) if SETTLE_RENDERS > 0 else None)
+        pre_ok = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ
+        settle_grad = (lambda k: mi.render(wg.mi_scene, spp=args.spp, seed=k)) if SETTLE_RENDERS > 0 else None
+        fused_expected = os.environ.get("FFX_FUSED_ADJOINT", "1") != "0" and len(opt._sample_seeds(0)) <= 64
+        t_grad = _bracket(grad_step, args.steps, args.warmup, dev, (preflight_grad_fused if fused_expected else preflight_grad_cached) if pre_ok else None, settle_grad)
         wg.mi_scene.geom.timing = None
         torch.cuda.synchronize()
         k9_ms, _ = _kernel_ms(gevents, "render_bwd")  # re-tracing adjoint (only above FFX_CACHE_LIMIT_GB)
         k9c_ms, _ = _kernel_ms(gevents, "render_bwd_cached")
-        k8g_ms, _ = _kernel_ms(gevents, "render_fwd")
+        k8g_ms, k8g_n = _kernel_ms(gevents, "render_fwd")
         gevents.clear()
+        lin_paths = dict(opt.step_paths)
+        fused_ran = lin_paths["fused"] > 0
         bg = algorithmic_bytes(wg, W, H)
-        # streaming adjoint over the per-pixel footprint cache written by K8: the 8-byte header of every
-        # pixel, the 25-float footprint of the LIT pixels, the stray records, d(loss)/d(img); gtex written once.
-        # Lit pixels / strays are counted in the cache the last step left behind.
-        n_lit = n_stray = 0
-        if opt._cache is not None:
-            n_stray = int(opt._cache[:4].view(torch.int32).item())
-            n_lit = int((opt._cache[64:64 + 8 * W * H].view(W * H, 8)[:, 6] != 0).sum().item())  # CachePix.lit (8-byte headers, dense)
-        bytes_k9c = 8 * W * H + 100 * n_lit + 24 * n_stray + 12 * W * H + 4 * wg.tex_size[0] * wg.tex_size[1]
+        bytes_fused = bg["G"] + 4 * T + 12 * W * H + 12 * W * H + 4 * T  # G + tex + img out + gimg in + gtex
         grad = {
             "grad_steps_per_sec": args.steps / t_grad,
             "grad_samples_per_sec": S * args.steps / t_grad,
             "grad_ms_per_step": 1e3 * t_grad / args.steps,
-            "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world))},
-            "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if opt._cache is None and k9_ms is None else "render_fwd(+cache write)"): k8g_ms,
+            "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world)),
+                            "loss": "coverage_loss = -mean(green): linear in the image (forward + adjoint in one launch)" if fused_ran else "coverage_loss through the cache + K9"},
+            "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if fused_ran else "render_fwd(+cache write)"): k8g_ms,
                                 "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
-            "grad_launches_per_step": "pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if opt._cache is None and k9_ms is None
+            "grad_launches_per_step": "pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if fused_ran
             else "pattern_fwd_blur, render_fwd_cache, render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)",
-            "render_bwd_cached_roofline": None if k9c_ms is None else {
-                "kernel": "k_render_bwd_cached (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",
-                "lit_pixels": n_lit, "stray_samples": n_stray,
-                "achieved": bytes_k9c / (k9c_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_k9c / (k9c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
-                "traffic": (pmc_traffic("k_render_bwd_cached", "grad", pkey) or {}).get("bytes") if pkey is not None else None},
+            "grad_step_paths": lin_paths,
+            "render_fwd_adjoint_roofline": None if not (fused_ran and k8g_ms) else {
+                "kernel": "k_render_fwd_pk<1, wide, material rows, true> (ffx_render_fwd_adjoint: K8 with the adjoint folded in)", "bound": "hbm",
+                "achieved": bytes_fused / (k8g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_fused / (k8g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": bytes_fused, "bytes_formula": "G + 4T (tex) + 12WH (img) + 12WH (gimg) + 4T (gtex)",
+                "avg_kernel_ms": k8g_ms, "launches_timed": k8g_n,
+                "traffic": (pmc_traffic("k_render_fwd_pk", "grad", pkey, adjoint_instance=True) or {}).get("bytes") if pkey is not None else None,
+                "traffic_source": (pmc_traffic("k_render_fwd_pk", "grad", pkey, adjoint_instance=True) or {}).get("source") if pkey is not None else None},
         }
+        # ---- the same step with a loss that is NOT linear in the image (torch.nn.L1Loss against a fixed target render, the loss class of
+        # the reference's loop: fireflies/graphics/rasterization.py:579,596-602): cache-writing forward + K9 (ffx_render_bwd_cached)
+        if os.environ.get("FFX_BENCH_NONLINEAR", "1") != "0":
+            with torch.no_grad():
+                target = mi.render(wg.mi_scene, spp=args.spp, seed=4242).torch().clone()
+            opt2 = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=S, base_seed=11,
+                                    loss_fn=image_l1_loss(target))
+
+            def grad_step2(i):
+                wg.mi_scene.geom.timing = gevents if _timed(i, args.warmup, args.steps) else None
+                return opt2.step()
+
+            t_grad2 = _bracket(grad_step2, args.steps, args.warmup, dev, preflight_grad_cached if pre_ok else None, settle_grad)
+            wg.mi_scene.geom.timing = None
+            torch.cuda.synchronize()
+            k9r2_ms, _ = _kernel_ms(gevents, "render_bwd")
+            k9c2_ms, k9c2_n = _kernel_ms(gevents, "render_bwd_cached")
+            k8g2_ms, _ = _kernel_ms(gevents, "render_fwd")
+            gevents.clear()
+            # streaming adjoint over the per-pixel footprint cache written by K8: the 8-byte header of every pixel, the 25-float
+            # footprint(s) of the LIT pixels, the stray records, d(loss)/d(img); gtex written once.  Counted in the cache the last step left.
+            n_lit = n_stray = 0
+            if opt2._cache is not None:
+                n_stray = int(opt2._cache[:4].view(torch.int32).item())
+                n_lit = int((opt2._cache[64:64 + 8 * W * H].view(W * H, 8)[:, 6] != 0).sum().item())  # CachePix.lit (8-byte headers, dense)
+            foot = 200 if args.material == "principled" else 100  # (material rows: a second footprint per lit pixel)
+            bytes_k9c = 8 * W * H + foot * n_lit + 24 * n_stray + 12 * W * H + 4 * T
+            grad.update({
+                "grad_steps_per_sec_nonlinear": args.steps / t_grad2,
+                "grad_ms_per_step_nonlinear": 1e3 * t_grad2 / args.steps,
+                "grad_nonlinear_config": {"loss": "torch.nn.L1Loss()(img, target) against a fixed target render (optim.image_l1_loss): its gradient depends on the image",
+                                          "step_paths": dict(opt2.step_paths),
+                                          "launches_per_step": "pattern_fwd_blur, render_fwd_cache, l1_value_grad (+ add), render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)"},
+                "grad_nonlinear_kernels_ms": {"render_fwd(+cache write)": k8g2_ms, "render_bwd_cached": k9c2_ms, "render_bwd(retrace)": k9r2_ms},
+                "render_bwd_cached_roofline": None if k9c2_ms is None else {
+                    "kernel": "k_render_bwd_cached_tiled16 (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",
+                    "lit_pixels": n_lit, "stray_samples": n_stray,
+                    "achieved": bytes_k9c / (k9c2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_k9c / (k9c2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_k9c,
+                    "bytes_formula": f"8WH (pixel headers) + {foot} n_lit + 24 n_stray + 12WH (gimg) + 4T (gtex)",
+                    "avg_kernel_ms": k9c2_ms, "launches_timed": k9c2_n,
+                    "traffic": (pmc_traffic("k_render_bwd_cached", "grad", pkey) or {}).get("bytes") if pkey is not None else None,
+                    "traffic_source": (pmc_traffic("k_render_bwd_cached", "grad", pkey) or {}).get("source") if pkey is not None else None},
+            })
+        grad["grad_config"]["algorithmic_bytes"] = {"render_fwd_adjoint": bytes_fused, "G": bg["G"]}
 
     if rank != 0:
         return
-    achieved = bytes_["render_fwd"] / (k8_ms * 1e-3) / 1e9
+    # the dominant kernel's time: the SIXTEEN launches timed behind the bracket (each between HIP events on its launch stream); the
+    # bracket's own two instrumented launches are kept beside it
+    k8_roof_ms = k8_post_ms if k8_post_ms else k8_ms
+    achieved = bytes_["render_fwd"] / (k8_roof_ms * 1e-3) / 1e9
     traffic = pmc_traffic("k_render_fwd_pk", "r", pkey) if pkey is not None else None  # only workloads the committed PMC passes ran
+    phase_files = _profile_files("phaseclk.txt", pkey or "") if pkey is not None else []
+    phase_files = [f for f in phase_files if os.path.getsize(f) > 0]
     out = {
         "metric": "renders/sec @512x512,64spp vocal-fold (+ pattern-grad-steps/sec in grad_steps_per_sec); HBM GB/s vs peak in roofline",
         "value": renders_per_sec,
@@ -627,26 +792,32 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if not args.fp16 else "f32 (f16 film)",
         "data": "synthetic",
+        # the same K steps without the clock-settle launches, after 0.4 s of idle GPU (what a bare `--steps K --warmup W` loop reads), and with
+        # the image handles dropped unread (consecutive renders then overlap on two streams; the reference's loop reads every image)
+        "value_cold": value_cold,
+        "value_overlapped": value_overlapped,
         "config": {
             "workload": (f"BASELINE configs[2] (renders): procedural animated vocal-fold scene, {bytes_['F']} triangles, {args.grid**2}-point projector, "
                          f"{W}x{H}, {args.spp} spp, shadows {'on' if not args.no_shadows else 'off'}; configs[1] (grad steps): same scene, {args.grad_grid**2}-point pattern")
             if args.workload == "vocalfold" else
             (f"BASELINE configs[4]: procedural colon scene, {bytes_['F']} triangles, {args.grid**2}-point projector, {W}x{H}, {args.spp} spp, "
              f"{'fp16' if args.fp16 else 'fp32'} radiance buffer"),
-            "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render [K8]; texture built once before the loop",
+            "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render(...).torch() [K8; the image is consumed on the caller's stream, as the reference's loop "
+                    "does]; texture built once before the loop",
             "preflight": preflight or None,
             "clock_settle": {"renders_before_each_bracket": SETTLE_RENDERS,
                              "what": "launches of the render kernel on the current pose issued in front of the W warm-up steps (not steps: no randomisation, no re-fit, no adjoint)",
                              "why": "the first ~40 launches after an idle GPU run up to 6 % slower (clock ramp; tools/posecost.py, profiles/r3_posecost.txt): a 20-step bracket "
-                                    "would time the ramp. FFX_BENCH_SETTLE=0 gives the cold-start figure (~4 % lower over 20 steps, equal over 100)"},
+                                    "would time the ramp.  `value_cold` is the same bracket without them, after an idle phase"},
             "entity_device": args.entity_device,
             "material": ("principled BSDF (Mitsuba's model, reflection side), parameters randomised as the reference's scripts do" if args.material == "principled"
                          else "diffuse (Lambert)"),
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
+            "render_paths": dict(wl.mi_scene.render_paths),
         },
         "roofline": {
-            "kernel": "k_render_fwd_pk<1, wide, %s> (ffx_render_fwd, K8)" % ("material rows" if args.material == "principled" else "albedo"),
+            "kernel": "k_render_fwd_pk<1, wide, %s, false> (ffx_render_fwd, K8)" % ("material rows" if args.material == "principled" else "albedo"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -656,27 +827,27 @@ def main():
             "traffic_source": ("no committed PMC pass for this workload" if pkey is None else f"no profiles/r*{pkey}_pmc_summary.json yet") if traffic is None else
             f"profiles/{traffic['source']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at this workload, not this run; raw {traffic['raw_bytes']:.0f} B, FETCH_SIZE x2 gfx950 correction)",
             "algorithmic_bytes_per_launch": bytes_["render_fwd"],
-            "avg_kernel_ms": k8_ms,
-            "launches_timed": k8_n,
-            "avg_kernel_ms_after_bracket": k8_post_ms,
-            "launches_timed_after_bracket": k8_post_n,
-            # (against the mean over ALL launches this run timed — the bracket's two and the sixteen behind it: fewer poses, more noise)
-            "valu_issue": valu_issue("k_render_fwd_pk", (k8_ms * k8_n + (k8_post_ms or 0.0) * (k8_post_n or 0)) / max(k8_n + (k8_post_n or 0), 1), pkey) if pkey is not None else None,
+            "avg_kernel_ms": k8_roof_ms,
+            "launches_timed": k8_post_n if k8_post_ms else k8_n,
+            "avg_kernel_ms_in_bracket": k8_ms,
+            "launches_timed_in_bracket": k8_n,
+            "valu_issue": valu_issue("k_render_fwd_pk", k8_roof_ms, pkey) if pkey is not None else None,
             "note": "by design NOT HBM-bound: samples are reduced in registers, so the compulsory traffic per render is algorithmic_bytes_per_launch (geometry + "
-                    "texture + film, SURVEY 8d); the kernel is bound by VALU / scalar issue (valu_issue below; SQ counters in profiles/r*_sq_instruction_mix.json, "
-                    "phase shares in profiles/r3_phaseclk.txt, DESIGN 8). rays/s is the meaningful secondary figure.",
-            "kernel_ray_samples_per_sec": W * H * args.spp / (k8_ms * 1e-3),
+                    "texture + film, SURVEY 8d); the kernel is bound by VALU / scalar issue (valu_issue below; SQ counters in profiles/r*_sq_instruction_mix.json"
+                    + (f", phase shares in profiles/{os.path.basename(phase_files[-1])}" if phase_files else "") + ", DESIGN 8). rays/s is the meaningful secondary figure.",
+            "kernel_ray_samples_per_sec": W * H * args.spp / (k8_roof_ms * 1e-3),
         },
-        "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_ms},
+        "kernels_ms": {"scene_update(K5+K6: side stream, overlapped with K8; elapsed incl. waiting for CUs)": upd_ms, "render_fwd(K8)": k8_roof_ms},
         "rccl": rccl,
     }
     if rccl is not None:
         rccl["renders_per_sec_per_rank"] = [args.steps / t for t in per_rank_t]
     out.update(grad)
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(wl, tex, args.spp, args.cpu_spp, seed=base_seed)
+        out["cpu_baseline"] = cpu_baseline(wl, tex, args.spp, args.cpu_spp, seed=base_seed, grad_wl=wg if not args.no_grad_steps else None)
     else:
         out["cpu_baseline"] = None
+    out["evidence"] = cited_profiles(pkey)
     print(json.dumps(out))
 
 

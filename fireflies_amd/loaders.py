@@ -31,7 +31,7 @@ from . import scenes
 
 
 # ----------------------------------------------------------------------------- OBJ
-def load_obj(path, with_info=False):
+def load_obj(path, with_info=False, split_seams=True):
     """-> (vertices [V,3] float32, triangles [F,3] int32).  Faces with more than three corners are
     fan-triangulated; `v/vt/vn` corner syntax and negative (relative) indices are handled.
     with_info: a third item {"has_normals": the file carries `vn` records, "uv": [V,2] texture coordinates or None} —
@@ -75,7 +75,10 @@ def load_obj(path, with_info=False):
         return v, t
     uv = None
     cv = np.asarray(corner_vt, np.int64).reshape(-1, 3)
-    if len(vts) and cv.size and (cv >= 0).all():
+    # split_seams=False: the caller has no use for texture coordinates (no textured base colour bound to the shape) — the file's vertex
+    # list is kept as it is, so that OBJ animation frames and user `vertex_positions` (which carry the file's V vertices, as the reference
+    # feeds them: fireflies/entity/mesh.py:167-181) still fit the mesh
+    if split_seams and len(vts) and cv.size and (cv >= 0).all():
         if cv.max() >= len(vts):
             raise ValueError(f"{path}: texture-coordinate index out of range")
         vt = np.asarray(vts, np.float32).reshape(-1, 2)
@@ -509,14 +512,17 @@ def load_mitsuba_xml(path):
                     dropped("area-emitter", "area emitter on a shape ignored: only the delta emitters (projector, spot) illuminate the scene")
                 elif extra.tag in ("medium", "sensor"):
                     dropped(("shape-child", extra.tag), f"<{extra.tag}> inside <shape> ignored")
-            v, t, finfo = (load_ply if node.get("type") == "ply" else load_obj)(os.path.join(base, p["filename"]), with_info=True)
+            bnode = _child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref")
+            btex = _base_texture_of(bnode, bsdfs, base)
+            if node.get("type") == "ply":
+                v, t, finfo = load_ply(os.path.join(base, p["filename"]), with_info=True)
+            else:  # seam vertices are only duplicated for a shape that actually gets a textured base colour
+                v, t, finfo = load_obj(os.path.join(base, p["filename"]), with_info=True, split_seams=btex is not None)
             # Mitsuba: a mesh with vertex normals is shaded in the interpolated frame unless face_normals is set
             smooth = bool(finfo["has_normals"]) and not bool(p.get("face_normals", False))
             M = _transform(_child(node, "transform", "to_world"))
             v = (v @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
             alb, mat, bsdf = _albedo_of(_child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref"), bsdfs)
-            bnode = _child(node, "bsdf") if _child(node, "bsdf") is not None else _child(node, "ref")
-            btex = _base_texture_of(bnode, bsdfs, base)
             uv = finfo.get("uv")
             if btex is not None and uv is None:
                 dropped(("tex-without-uv", node.get("id")), f"shape {node.get('id')!r}: a textured base colour but no texture coordinates in the mesh file: the constant base colour is used")

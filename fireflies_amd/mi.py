@@ -357,6 +357,10 @@ class Scene:
             self._render_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
             self._render_done = [[torch.cuda.Event() for _ in range(4)] for _ in range(2)]
         self._render_turn = 0
+        # which path each mi.render of this scene took (bench.py prints it): "two_stream" = beside the previous render on the scene's
+        # render streams, "caller_stream" = the plain forward on the caller's stream (a texture written in place since its assignment,
+        # device material tables, base-colour textures, FFX_RENDER_STREAMS=1), "autograd" = through functional.render (tex.data requires grad)
+        self.render_paths = {"two_stream": 0, "caller_stream": 0, "autograd": 0}
         self._tex_src = self._tex_ready = self._tex_private = None
         self._tex_ver = -1
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
@@ -653,16 +657,19 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
     elif tex.dtype != torch.float32:
         tex = tex.float()
     if tex.requires_grad and torch.is_grad_enabled():
+        scene.render_paths["autograd"] += 1
         img = Fn.render(tex, scene.geom, sd, scene.materials_arg(sd), spp, seed, fp16)
     else:  # nothing to differentiate: straight to the kernel (autograd.Function.apply costs ~80 us of host time per call)
         mats = scene.materials_arg(sd)
         slot = scene._render_stream(tex_in, mats) if tex_in is not None else None
         if slot is not None:  # beside the previous render, on the scene's other render stream
             rs, done, priv = slot
+            scene.render_paths["two_stream"] += 1
             with torch.cuda.stream(rs):
                 img = scene.geom.render_fwd(sd, mats, priv.unsqueeze(-1) if priv.dim() == 2 else priv, int(spp), int(seed), bool(fp16))
                 done.record(rs)
             return _RenderedXf(img, done)
+        scene.render_paths["caller_stream"] += 1
         t = tex if tex.is_contiguous() else tex.contiguous()
         img = scene.geom.render_fwd(sd, mats, t.unsqueeze(-1) if t.dim() == 2 else t, int(spp), int(seed), bool(fp16))
     return TensorXf(img)

@@ -68,6 +68,34 @@ coverage_loss.accumulate_value_and_grad = _coverage_accumulate
 coverage_loss.linear_gradient = _coverage_grad
 
 
+def image_l1_loss(target):
+    """A task loss that is NOT linear in the image: torch.nn.L1Loss()(img, target) against a fixed target render — the loss class
+    the reference's own optimisation loop uses (fireflies/graphics/rasterization.py:579, 596-602), applied to the image as SURVEY 3.5's
+    `task_loss(img | ...)`.  Its gradient sign(img - target) / n depends on the render, so a step takes the general adjoint path:
+    cache-writing forward + ffx_render_bwd_cached (K9).  Value and gradient come from ONE launch (ffx_l1_value_grad)."""
+    tgt = target.detach().float().contiguous()
+
+    def loss(img):
+        return (img.float() - tgt).abs().mean()
+
+    def value_and_grad(img):
+        from . import ops
+
+        a = img if img.dtype == torch.float32 else img.float()
+        v, g = ops.l1_value_grad(a.reshape(-1), tgt.reshape(-1))
+        return v, g.view(a.shape)
+
+    def accumulate(img, acc):
+        v, g = value_and_grad(img)
+        acc.add_(v)
+        return g
+
+    loss.value_and_grad = value_and_grad
+    loss.accumulate_value_and_grad = accumulate
+    loss.target = tgt
+    return loss
+
+
 class PatternOptimizer:
     def __init__(self, mi_scene, ff_scene, laser, sigma=10.0, tex_size=(500, 500), spp=64, lr=1e-3, reg_weight=0.1, samples_per_step=1,
                  base_seed=0, loss_fn=coverage_loss, blur=(5, 3.0)):
@@ -82,6 +110,9 @@ class PatternOptimizer:
             self.opt = torch.optim.Adam([laser._rays], lr=lr)
         self.step_index = 0
         self._cache = None
+        # scene samples per adjoint path (bench.py prints it): "fused" = forward + adjoint in one launch (a loss linear in the image),
+        # "cache_k9" = cache-writing forward + ffx_render_bwd_cached (every other loss), "retrace" = ffx_render_bwd (no cache possible)
+        self.step_paths = {"fused": 0, "cache_k9": 0, "retrace": 0}
 
     def _sample_seeds(self, step):
         """seeds of this rank's scene samples of optimisation step `step` (dist.sample_seed: independent of the world size)"""
@@ -225,6 +256,7 @@ class PatternOptimizer:
                     self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
                 geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
                 k_sample += 1
+                self.step_paths["fused"] += 1
                 continue
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
@@ -232,6 +264,7 @@ class PatternOptimizer:
             img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache,
                                   cache_zeroed=header_clear)
             header_clear = False
+            self.step_paths["cache_k9" if use_cache else "retrace"] += 1
             if linear is not None and use_cache:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)

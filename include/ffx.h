@@ -321,9 +321,12 @@ typedef struct ffx_bvh_info {
   int32_t plan_ints;  /* int32 words of the plan area (the arrival counter is the last one) */
   uint64_t off_nrec;  /* (n_tris + 4) x 48 B: per leaf slot the three vertex normals {n0, n1, n2} as float4, written by
                          ffx_scene_update for the shapes of ffx_smooth (below), read by the render kernels at the hit */
-  uint64_t off_gn;    /* (n_tris + 4) x 16 B: per leaf slot the unit geometric normal {nx, ny, nz, 1} ({0,0,0,0} for a degenerate
-                         triangle), written by ffx_scene_update with IEEE cross / sqrt / divide in the oracle's order; the packet
-                         render kernels read it instead of re-deriving it per sample.  0 in the oracle's blob. */
+  uint64_t off_gn;    /* (n_tris + 4) x 16 B: per leaf slot the unit geometric normal {nx, ny, nz, bits}, written by ffx_scene_update with
+                         IEEE cross / sqrt / divide in the oracle's order; the packet render kernels read it instead of re-deriving it
+                         per sample.  The fourth word is NOT a float: raw bits 0 for a degenerate triangle (the normal is then
+                         {0,0,0}), else (shape + 1) | smooth << 30 (smooth: the record is flagged by ffx_smooth) — the kernels take
+                         the hit's shape id and smooth flag from it, so a blob written to any other encoding renders with a wrong
+                         material row.  0 in the oracle's blob (it has no such area). */
 } ffx_bvh_info;
 
 /* Interpolated shading normals (optional; ffx_scene_update's `smooth`).  Mitsuba shades a mesh that carries vertex normals

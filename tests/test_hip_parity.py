@@ -595,6 +595,25 @@ def test_full_size_parity_with_the_oracle_at_512x512x64(oracle):
         img_d = host(gd.render_fwd(sdm, dev(mats), tex, 64, seed=i))
         img_o = go.render_fwd(sdm, mats, host(tex), 64, seed=i)
         _assert_image_close(img_d, img_o, 64, what=f"pose {i}, material rows")
+        if i == 2:
+            # ... and the launch the gradient bracket times: k_render_fwd_pk<1, wide, material rows, true> (ffx_render_fwd_adjoint, forward and
+            # adjoint of a loss linear in the image in ONE launch) against the oracle's ffx_render_fwd_adjoint at the full size — image,
+            # texture gradient and <gimg, img>.  gimg: the coverage loss's constant gradient plus a fixed pattern in red / blue, so that
+            # every channel's albedo and colour factor is exercised.
+            gimg = np.zeros((512, 512, 3), np.float32)
+            gimg[..., 1] = -1.0 / (512 * 512)
+            gimg[..., 0] = 0.5 / (512 * 512) * np.cos(np.arange(512, dtype=np.float32) * 0.05)[None, :]
+            gimg[..., 2] = 0.25 / (512 * 512) * np.sin(np.arange(512, dtype=np.float32) * 0.03)[:, None]
+            dot = torch.zeros(4096, device="cuda")
+            img_f, gtex_f = gd.render_fwd_adjoint(sdm, dev(mats), tex, 64, i, dev(gimg), dot_out=dot)
+            img_fo, gtex_o, dot_o = go.render_fwd_adjoint(sdm, mats, host(tex), 64, i, gimg)
+            _assert_image_close(host(img_f), img_fo, 64, what="forward + adjoint launch at 512x512x64 (image)")
+            np.testing.assert_allclose(host(img_f), img_d, rtol=0, atol=1e-6 * float(img_d.max()), err_msg="the forward + adjoint launch renders the plain forward's image")
+            gs = float(np.abs(gtex_o).max())
+            assert gs > 0
+            ge = np.abs(host(gtex_f) - gtex_o)
+            assert (ge > 1e-3 * gs).mean() <= 1e-3 and ge.max() <= 0.05 * gs, ((ge > 1e-3 * gs).mean(), ge.max() / gs)
+            assert float(dot.double().sum()) == pytest.approx(dot_o, rel=1e-4)
     assert total == 3 * 512 * 512 * 64
     assert lost == 0, f"{lost} rays hit in the oracle and missed on the GPU"
     assert flips <= 2, f"{flips} of {total} rays hit a different primitive"

@@ -15,7 +15,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the profiled runs time and count the bracket's own launches only: no clock-settle launches (the same kernel on ONE pose, cheaper than
 # the average random pose: they would pull the per-kernel averages down) and no preflight renders (bench.py: FFX_BENCH_SETTLE / _PREFLIGHT)
-export FFX_BENCH_SETTLE=0 FFX_BENCH_PREFLIGHT=0
+export FFX_BENCH_SETTLE=0 FFX_BENCH_PREFLIGHT=0 FFX_BENCH_EXTRA_BRACKETS=0
 B="--steps 20 --warmup 3 --no-cpu-baseline $X"
 (cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.log)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -41,10 +41,21 @@ python tools/microbench.py > profiles/${TAG}_microbench.json 2> $OUT/microbench.
 # issue-rate microbenchmark (instruction counts are fixed by the inline-asm bodies; `grep -c` on the .s confirms)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rates issue_rates.hip 2> $OUT/issue_rates_build.log && /tmp/issue_rates > $R/profiles/${TAG}_issue_rates.txt 2>&1)
 fi
-# where K8's wave time goes (shader-clock stamps; needs the -DFFX_TIMERS build: tools/build_variant_lib.sh timers -DFFX_TIMERS, before gpurun)
-if [ -f fireflies_amd/csrc/_stats/libffx_hip_timers.so ]; then
-  if [ -z "$X" ]; then FFX_LIB=fireflies_amd/csrc/_stats/libffx_hip_timers.so python tools/phaseclk.py vocalfold 64 8 > profiles/${TAG}_phaseclk.txt 2> $OUT/phaseclk.log
-  else FFX_LIB=fireflies_amd/csrc/_stats/libffx_hip_timers.so python tools/phaseclk.py colon 256 2 > profiles/${TAG}_phaseclk.txt 2> $OUT/phaseclk.log; fi
+# where K8's wave time goes (shader-clock stamps; needs the -DFFX_TIMERS build of the CURRENT sources: tools/build_variant_lib.sh timers -DFFX_TIMERS,
+# before gpurun — a stale variant library fails to load (missing symbols) and used to leave an empty file behind)
+FAILED=""
+TL=fireflies_amd/csrc/_stats/libffx_hip_timers.so
+if [ -f $TL ] && [ ! $TL -ot fireflies_amd/csrc/libffx_hip.so ]; then
+  if [ -z "$X" ]; then FFX_LIB=$TL python tools/phaseclk.py vocalfold 64 8 > $OUT/phaseclk.txt 2> $OUT/phaseclk.log
+  else FFX_LIB=$TL python tools/phaseclk.py colon 256 2 > $OUT/phaseclk.txt 2> $OUT/phaseclk.log; fi
+  if [ $? -eq 0 ] && [ -s $OUT/phaseclk.txt ]; then mv $OUT/phaseclk.txt profiles/${TAG}_phaseclk.txt
+  else FAILED="$FAILED phaseclk(see $OUT/phaseclk.log)"; rm -f profiles/${TAG}_phaseclk.txt; tail -3 $OUT/phaseclk.log; fi
+else
+  FAILED="$FAILED phaseclk(no current timers build: tools/build_variant_lib.sh timers -DFFX_TIMERS)"; rm -f profiles/${TAG}_phaseclk.txt
+fi
+if [ -n "${COLLECT_CPU_TABLE:-}" ]; then
+  python tools/cpu_oracle_table.py > $OUT/cpu_oracle_table.json 2> $OUT/cpu_table.log && [ -s $OUT/cpu_oracle_table.json ] && mv $OUT/cpu_oracle_table.json profiles/${TAG}_cpu_oracle_table.json \
+    || FAILED="$FAILED cpu_oracle_table"
 fi
 if [ -z "$X" ]; then
 python tools/isa_mix.py > $OUT/isa_operand_forms.json 2> $OUT/isa_mix.log && mv $OUT/isa_operand_forms.json profiles/${TAG}_isa_operand_forms.json   # (static: needs no GPU, kept with the rest)
@@ -53,7 +64,30 @@ python tools/k8ab.py > profiles/${TAG}_k8ab.txt 2> $OUT/k8ab.log
 python tools/steptrace.py $OUT/trace > profiles/${TAG}_steptrace.txt 2>> $OUT/trace.log
 rm -rf $OUT/trace
 fi
+# nothing empty leaves this script: a summary that came out empty (a pass that failed behind a redirect) is removed and reported, and the
+# script exits non-zero — profiles/r3_phaseclk.txt was committed as a 0-byte file once
+for f in profiles/${TAG}_* profiles/${TAG}grad_*; do
+  [ -e "$f" ] || continue
+  if [ ! -s "$f" ]; then FAILED="$FAILED $(basename $f)(empty)"; rm -f "$f"; fi
+done
+for need in kernel_stats.csv pmc_summary.json sq_instruction_mix.json bench_under_rocprof.json; do
+  [ -s profiles/${TAG}_$need ] || FAILED="$FAILED ${TAG}_$need(missing)"
+done
+[ -s profiles/${TAG}grad_pmc_summary.json ] || FAILED="$FAILED ${TAG}grad_pmc_summary.json(missing)"
+python - "$TAG" <<'PYEOF' || FAILED="$FAILED kernel-names"
+import json, sys
+tag = sys.argv[1]
+g = json.load(open(f"profiles/{tag}grad_pmc_summary.json"))
+want = ["k_render_fwd_pk<", "k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached"]
+missing = [w for w in want if not any(k.startswith(w) for k in g)]
+if not any(k.startswith("k_render_fwd_pk<") and ", true>" in k for k in g):
+    missing.append("k_render_fwd_pk<..., true> (forward + adjoint)")
+if missing:
+    print("collect_profiles: the gradient bracket's PMC summary lacks", missing, file=sys.stderr)
+    sys.exit(1)
+PYEOF
 # ship the small summaries back (profiles/ is not merged by gpurun, gpurun_out/ is)
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}* gpurun_out/profiles_$TAG/
 rm -rf $OUT/stats $OUT/pmc_* $OUT/gpmc_* $OUT/sq_*
 tail -5 $OUT/summary.txt
+if [ -n "$FAILED" ]; then echo "collect_profiles.sh: FAILED:$FAILED" >&2; exit 1; fi
