@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 4
+FFX_ABI_VERSION = 5
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -41,6 +41,8 @@ class BvhInfo(C.Structure):
         ("plan_ints", C.c_int32),
         ("off_nrec", C.c_uint64),
         ("off_gn", C.c_uint64),
+        ("off_bins", C.c_uint64),
+        ("bins_stride", C.c_uint64),
     ]
 
 

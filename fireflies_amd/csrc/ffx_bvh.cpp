@@ -306,7 +306,9 @@ size_t ffx_bvh_blob_bytes(int n_tris) {
          wmax * FFX_WIDE * (sizeof(WideChild) + 4) + (f + FFX_WIDE) * sizeof(WideChild) + 256 +
          // refit plan: <= f + 1 headers of 8 ints (every leaf under the top could be a treelet of its own), <= f nodes with <= 2 level
          // entries each, <= wmax * 64 wide children, the counter
-         ((f + 2) * 8 + 3 * f + 8 + wmax * FFX_WIDE + 64) * 4 + (f + FFX_LEAF_MAX) * (48 + 16) + 192;
+         ((f + 2) * 8 + 3 * f + 8 + wmax * FFX_WIDE + 64) * 4 + (f + FFX_LEAF_MAX) * (48 + 16) + 192 +
+         // tile bins of the three apexes (ffx_common.h)
+         FFX_N_APEX * (size_t)ffx_bin_stride(n_tris < 1 ? 1 : n_tris) + 64;
 }
 
 int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int n_tris, void *blob, size_t blob_bytes, ffx_bvh_info *info) {
@@ -516,12 +518,19 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
   info->off_gn = off; // per-slot unit geometric normals
   off += ((uint64_t)n_tris + FFX_LEAF_MAX) * 16;
   off = (off + 63) & ~(uint64_t)63;
-  off += FFX_N_APEX * ffx_apex_stride(n_tris); // apex-record areas (ffx_common.h), zero until a render call fills them
+  // ---- everything from here on is SCRATCH of the render calls' pre-pass (written before it is read, never read by the host): the
+  // tile bins and, last, the apex-record areas.  The host copy of the blob only needs its first off_bins bytes.
+  info->off_bins = off;
+  info->bins_stride = ffx_bin_stride(n_tris);
+  const uint64_t static_bytes = off;
+  off += FFX_N_APEX * info->bins_stride;
+  off = (off + 63) & ~(uint64_t)63;
+  off += FFX_N_APEX * ffx_apex_stride(n_tris); // apex-record areas (ffx_common.h)
   info->total_bytes = off;
   if (off > blob_bytes) FFX_FAIL(FFX_ERR_NOMEM, "bvh_build_host: internal size error");
   if (info->max_depth > FFX_STACK_DEPTH) FFX_FAIL(FFX_ERR_UNSUPPORTED, "bvh_build_host: tree depth %d exceeds the traversal stack", info->max_depth);
 
-  memset(blob, 0, (size_t)off);
+  memset(blob, 0, (size_t)static_bytes); // (the scratch tail is the device's business)
   memcpy((char *)blob + info->off_plan, plan.data(), plan.size() * 4);
   BvhNode *out = (BvhNode *)((char *)blob + info->off_nodes);
   int32_t *ord = (int32_t *)((char *)blob + info->off_order);

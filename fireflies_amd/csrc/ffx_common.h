@@ -132,6 +132,45 @@ static_assert(sizeof(WideChild) == 16, "wide child must be 16 bytes");
 struct WideHdr { float org[3]; float step[3]; float pad[10]; };
 static_assert(sizeof(WideHdr) == 64, "wide header must be 64 bytes");
 
+// ------------------------------------------------------------------ tile bins (include/ffx.h ffx_bvh_info.off_bins)
+// A render's rays leave three fixed points (camera, projector, spot).  Seen from such a point a triangle is a 2-D triangle on a
+// perspective image plane, and a ray hits it iff the ray's image point lies inside: per apex the pre-pass bins every triangle of the
+// current pose into the tiles of a grid over that plane (a software rasteriser's binning stage), and a pixel's packet — whose rays
+// cover a known rectangle of the plane — tests the entries of its tile(s) with the LANES ON THE ENTRIES (box + three edge equations
+// against the rectangle) and hands the survivors to the exact apex test.  Conservative by construction: an entry's box and edge
+// offsets are padded by FFX_BIN_PAD tile units (~0.03 pixels, four orders of magnitude above the rounding of the projection), a
+// triangle is listed in every tile its padded projection touches, and triangles the projection is ill-conditioned for (a vertex
+// behind or beside the apex) are listed by 3-D plane tests with an entry that always passes.  The exact test alone decides hits.
+#define FFX_BIN_MAX_TILES 16384 // per apex (128 x 128)
+#define FFX_BIN_PAD 0.00390625f // 1/256 tile
+#define FFX_BIN_FAR 512.0f      // projected coordinates beyond this many tiles are not trusted (float rounding would approach the pad)
+struct __attribute__((aligned(16))) BinEntry {
+  float bb[4];  // padded box of the projection: min x, min y, max x, max y (tile units); (-inf, -inf, inf, inf): always passes
+  float e[9];   // three edge functions n.x * x + n.y * y + c >= 0 inside (offsets padded); a degenerate projection: (0, 0, 1)
+  int32_t slot; // leaf slot of the triangle
+  uint32_t pad[2];
+};
+static_assert(sizeof(BinEntry) == 64, "bin entry must be 64 bytes");
+// tile coordinates of a world point p seen from the apex o: (M[0..2] . (p - o)) / Z, (M[3..5] . (p - o)) / Z with Z = M[6..8] . (p - o) > 0
+struct BinGrid { float M[9]; float o[3]; int32_t nx, ny, on; };
+struct BinHdr { uint32_t ok, total, cap, pad[13]; };
+static_assert(sizeof(BinHdr) == 64, "bin header must be 64 bytes");
+__host__ __device__ static inline uint64_t ffx_bin_cap(int n_tris) { return (uint64_t)2 * (uint64_t)n_tris + FFX_BIN_MAX_TILES; } // (a few screen-filling triangles fit)
+__host__ __device__ static inline uint64_t ffx_bin_off_starts() { return 64; }
+__host__ __device__ static inline uint64_t ffx_bin_off_cursors() { return 64 + 4 * (uint64_t)(FFX_BIN_MAX_TILES + 16); }
+__host__ __device__ static inline uint64_t ffx_bin_off_entries() { return (ffx_bin_off_cursors() + 4 * (uint64_t)FFX_BIN_MAX_TILES + 63) & ~(uint64_t)63; }
+__host__ __device__ static inline uint64_t ffx_bin_stride(int n_tris) { return (ffx_bin_off_entries() + 64 * (ffx_bin_cap(n_tris) + 64) + 63) & ~(uint64_t)63; }
+// what the render kernels need of the bins (part of their first kernel argument)
+struct BinsK {
+  const char *base[3]; // per apex: BinHdr, list starts, cursors, entries
+  BinGrid g[3];
+  float cam_inv_ts_x, cam_inv_ts_y; // camera pixels -> tile units
+};
+// builds the bins of the enabled grids on `s` (ffx_bins.hip): count, scan, fill — three launches; `clear` has been done by the caller
+struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; };
+void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, hipStream_t s);
+void ffx_bins_clear_launch(const BinBuild &bb, hipStream_t s);
+
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };
 

@@ -60,6 +60,8 @@ struct ShadeK {
   // the material table as a kernel argument (ffx_scene_desc.mat_h): the kernels then read the rows from their own kernarg segment
   int mat_inline;
   float mat_h[FFX_MAX_MAT_H];
+  // tile bins of the three apexes (ffx_common.h BinsK): the packet kernels try them before the tree walks
+  BinsK bins;
 };
 // The first kernel argument, read in place.  The scene constants (ShadeK, ~100 dwords + the inline material rows) are the first
 // argument of the render kernels.  Read through the by-value copy the compiler loads them all up front and, out of SGPRs, parks
@@ -1099,7 +1101,7 @@ __device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], 
 // nested uniform branches instead of combined predicates.
 #ifdef FFX_STATS
 // debug build only (-DFFX_STATS): per-launch totals of packet walks / node steps / triangle tests
-__device__ unsigned long long g_ffx_stats[32];
+__device__ unsigned long long g_ffx_stats[48]; // [32..47]: tile bins (closest-hit 32.., any-hit 40..: walks served, chunk steps, exact tests, second barycentric, fallbacks to the tree)
 #define FFX_STAT(i) do { if (threadIdx.x % 64 == 0) atomicAdd(&g_ffx_stats[i], 1ull); } while (0)
 #define FFX_STAT_MAX(i, v) do { if (threadIdx.x % 64 == 0) atomicMax(&g_ffx_stats[i], (unsigned long long)(v)); } while (0)
 #else
@@ -1766,6 +1768,174 @@ __device__ __forceinline__ void traverse_packet_any(const BvhNode *__restrict__ 
   else traverse_packet<ANY, R>(nodes, arecs, o, d, tmin, tmax, active, h, found);
 }
 
+// ------------------------------------------------------------------------------------------ tile bins instead of a tree walk
+// (ffx_common.h BinEntry / BinGrid, ffx_bins.hip.)  The rays of a packet leave one apex and cover a rectangle of that apex's image
+// plane: one pixel for the primary rays, the (tiny) bounding box of the samples' image points for a packet of shadow rays.  Every
+// triangle such a ray can hit is listed in the tile(s) the rectangle touches.  A step loads 64 entries — one per lane, coalesced —
+// and tests each against the rectangle: its padded box, then the rectangle's most-inside corner against the three edge functions,
+//     max over the rectangle of (n.x x + n.y y + c) = n.x cx + |n.x| hx + n.y cy + |n.y| hy + c      (centre c*, half extents h*)
+// four fma per edge with the rectangle as scalar operands, no selects.  The survivors — the triangles whose projection really
+// overlaps the pixel, 1 - 3 of them — get the exact apex test of the tree walks (same arithmetic, same acceptance rule, closest hit
+// with the primitive-id tie-break: the result does not depend on the order, and is the tree walk's bit for bit).
+// No stack, no descent, no packet constants: where the 64-wide walk took 4.2 dependent steps and 100 VALU of set-up per pixel
+// this is ~1.3 steps.  tx0..ty1: the tiles the rectangle touches (at most four: the caller falls back to the tree otherwise).
+template <bool ANY>
+__device__ __forceinline__ void traverse_bins(const char *__restrict__ bbase, const int nx, const int tx0, const int ty0, const int tx1, const int ty1, const float rcx,
+                                              const float rcy, const float rhx, const float rhy, const TriApex *__restrict__ recs, const v3 d, const float tmin,
+                                              const float tmax, const wmask active, Hit &h, wmask &occluded) {
+  h.t = msel(active, tmax, -INFINITY);
+  h.prim = -1;
+  h.shape = -1;
+  h.slot = -1;
+  occluded = 0ull;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t *starts = reinterpret_cast<const uint32_t *>(bbase + 64); // ffx_bin_off_starts()
+  const char *ents = bbase + ffx_bin_off_entries();
+  const char *rbase = reinterpret_cast<const char *>(recs);
+  // the rectangle's bounds for the box test — wave-uniform like centre and half extents: kept in SGPRs (they feed the step as scalar
+  // operands; as VGPRs they would be eight more registers live across the exact tests)
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const float rx0 = uni(rcx - rhx), rx1 = uni(rcx + rhx), ry0 = uni(rcy - rhy), ry1 = uni(rcy + rhy);
+  FFX_STAT(ANY ? 40 : 32);
+  bool go = true;
+  for (int ty = ty0; ty <= ty1 && go; ++ty) {
+    for (int tx = tx0; tx <= tx1 && go; ++tx) {
+      const uint32_t tile = (uint32_t)(ty * nx + tx);
+      const uint32_t beg = starts[tile], end = starts[tile + 1]; // (uniform address: scalar loads)
+      for (uint32_t b0 = beg; b0 < end && go; b0 += 64u) {
+        FFX_STAT(ANY ? 41 : 33);
+        const uint32_t idx = b0 + lane;
+        const uint32_t idc = idx < end ? idx : end - 1u; // lanes beyond the list re-read its last entry and are masked out
+        const float4 *e4 = reinterpret_cast<const float4 *>(ents + ((size_t)idc << 6));
+        const float4 A = e4[0], B = e4[1], C = e4[2], D = e4[3];
+        wmask m = m_ult(idx, end) & m_le(A.x, rx1) & m_ge(A.z, rx0) & m_le(A.y, ry1) & m_ge(A.w, ry0);
+        m &= m_ge(fmaf(B.x, rcx, fmaf(fabsf(B.x), rhx, fmaf(B.y, rcy, fmaf(fabsf(B.y), rhy, B.z)))), 0.f);
+        m &= m_ge(fmaf(B.w, rcx, fmaf(fabsf(B.w), rhx, fmaf(C.x, rcy, fmaf(fabsf(C.x), rhy, C.y)))), 0.f);
+        m &= m_ge(fmaf(C.z, rcx, fmaf(fabsf(C.z), rhx, fmaf(C.w, rcy, fmaf(fabsf(C.w), rhy, D.x)))), 0.f);
+        const int slot_v = __float_as_int(D.y);
+        while (m != 0ull) {
+          const uint32_t j = (uint32_t)wff1(m);
+          asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
+          FFX_STAT(ANY ? 42 : 34);
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(slot_v, (int)j);
+          const uint32_t roff = slot * 48u;
+          const v8i r8 = *reinterpret_cast<const v8i *>(rbase + roff);
+          const v4i r4 = *reinterpret_cast<const v4i *>(rbase + roff + 32);
+          asm volatile("" ::"s"(r8), "s"(r4));
+          const int prim = r4.z;
+          // apex test, staged with wave-uniform early-outs (identical arithmetic to traverse_wide_oct / traverse_packet_oct)
+          const v3 Av = V3(__int_as_float(r8.s0), __int_as_float(r8.s1), __int_as_float(r8.s2));
+          const v3 Bv = V3(__int_as_float(r8.s3), __int_as_float(r8.s4), __int_as_float(r8.s5));
+          const v3 Cv = V3(__int_as_float(r8.s6), __int_as_float(r8.s7), __int_as_float(r4.x));
+          const float T = __int_as_float(r4.y);
+          const float det = vdot(d, Av);
+          const float U = vdot(d, Bv);
+          const wmask neg = m_lt(det, 0.f);
+          const float detA = fabsf(det);
+          const float Us = msel(neg, -U, U);
+          const wmask alive = ANY ? (active & ~occluded) : active;
+          const wmask p1 = alive & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
+          if (p1 == 0ull) continue;
+          FFX_STAT(ANY ? 43 : 35);
+          const float Vv = vdot(d, Cv);
+          const float Vs = msel(neg, -Vv, Vv);
+          const wmask p2 = p1 & m_ge(Vs, 0.f) & m_le(Us + Vs, detA);
+          if (p2 == 0ull) continue;
+          const float t = msel(neg, -T, T) / detA;
+          const wmask hitm = p2 & m_gt(t, tmin);
+          if (ANY) {
+            const wmask occ = hitm & m_lt(t, tmax);
+            occluded |= occ;
+            msel_into(h.t, occ, -INFINITY);
+            if (occ != 0ull && (active & ~occluded) == 0ull) { go = false; m = 0ull; } // every ray of the packet is decided
+          } else {
+            const wmask better = hitm & (m_lt(t, h.t) | (m_eq(t, h.t) & m_ult((uint32_t)prim, (uint32_t)h.prim)));
+            msel_into(h.t, better, t);
+            msel_into(h.prim, better, prim);
+            msel_into(h.slot, better, (int)slot);
+          }
+        }
+      }
+    }
+  }
+}
+
+// the bins of apex `a` are usable for this launch and this pose?  (grid enabled by the host; lists complete: written by k_bin_scan)
+__device__ __forceinline__ bool bins_ready(const BinsK &bk, const int a) {
+  if (!bk.g[a].on) return false;
+  return reinterpret_cast<const BinHdr *>(bk.base[a])->ok != 0u; // (uniform address: a scalar load)
+}
+
+// primary rays of pixel (px, py): its own tile, its own square of the image plane.  The square is taken a half pad short at the far
+// side: a sample position of exactly px + 1 (rounding of px + jitter) still lies within the entries' padding, and the pixels of a
+// tile's last column do not drag the next tile's list in.
+__device__ __forceinline__ bool bins_primary(const BinsK &bk, const int px, const int py, const TriApex *__restrict__ recs, const v3 d, const float tmin, const float tmax,
+                                             const wmask active, Hit &h) {
+  if (!bins_ready(bk, 0)) return false;
+  if (active == 0ull) { h.t = -INFINITY; h.prim = -1; h.shape = -1; h.slot = -1; return true; } // nothing to trace
+  const float its_x = bk.cam_inv_ts_x, its_y = bk.cam_inv_ts_y; // 1 / tile side: a power of two
+  const float x0 = (float)px * its_x, y0 = (float)py * its_y;
+  const int tx = (int)x0, ty = (int)y0;
+  const float hx = 0.5f * its_x - 0.25f * FFX_BIN_PAD, hy = 0.5f * its_y - 0.25f * FFX_BIN_PAD;
+  const float cx = x0 + hx, cy = y0 + hy;
+  // (uniform values computed on the vector ALU: say so, so that they feed the step as scalar operands)
+  const int stx = __builtin_amdgcn_readfirstlane(tx), sty = __builtin_amdgcn_readfirstlane(ty);
+  const float scx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx))), scy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+  const float shx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hx))), shy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hy)));
+  if (stx >= bk.g[0].nx || sty >= bk.g[0].ny) return false;
+  wmask occ;
+  traverse_bins<false>(bk.base[0], bk.g[0].nx, stx, sty, stx, sty, scx, scy, shx, shy, recs, d, tmin, tmax, active, h, occ);
+  return true;
+}
+
+// four wave-wide reductions of non-negative floats at once — two minima, two maxima — in interleaved DPP chains (wave_reduce3_nn's
+// scheme: the three instructions between a DPP write and the next read of the same register are the wait states the hazard needs)
+__device__ __forceinline__ void wave_reduce_minmax4(uint32_t &mn0, uint32_t &mn1, uint32_t &mx0, uint32_t &mx1) {
+#define FFX_R4_STEP(CTRL, MASK)                                                   \
+  "v_min_u32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"       \
+  "v_min_u32_dpp %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"       \
+  "v_max_u32_dpp %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"       \
+  "v_max_u32_dpp %3, %3, %3 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t" FFX_R4_STEP("quad_perm:[1,0,3,2]", "0xf") FFX_R4_STEP("quad_perm:[2,3,0,1]", "0xf") FFX_R4_STEP("row_half_mirror", "0xf")
+          FFX_R4_STEP("row_mirror", "0xf") FFX_R4_STEP("row_bcast:15", "0xa") FFX_R4_STEP("row_bcast:31", "0xc")
+      : "+v"(mn0), "+v"(mn1), "+v"(mx0), "+v"(mx1));
+#undef FFX_R4_STEP
+  mn0 = (uint32_t)__builtin_amdgcn_readlane((int)mn0, 63);
+  mn1 = (uint32_t)__builtin_amdgcn_readlane((int)mn1, 63);
+  mx0 = (uint32_t)__builtin_amdgcn_readlane((int)mx0, 63);
+  mx1 = (uint32_t)__builtin_amdgcn_readlane((int)mx1, 63);
+}
+
+// shadow rays from emitter apex `a` (1 projector, 2 spot) to the lifted surface points: direction sdir = Po - E per lane.  Their image
+// points on the emitter's grid are (M sdir).xy / (M sdir).z; the packet's rectangle is their bounding box (the samples of one pixel:
+// a pixel's footprint as the emitter sees it).  A packet that leaves the grid or spreads over more than four tiles (the two sides of
+// a depth discontinuity, far apart as seen from the emitter) takes the tree walk.
+__device__ __forceinline__ bool bins_shadow(const BinsK &bk, const int a, const TriApex *__restrict__ recs, const v3 sdir, const wmask active, wmask &occluded) {
+  if (!bins_ready(bk, a)) return false;
+  const float *M = bk.g[a].M;
+  const float Z = fmaf(M[6], sdir.x, fmaf(M[7], sdir.y, M[8] * sdir.z));
+  const float iz = __builtin_amdgcn_rcpf(Z);
+  const float fx = fmaf(M[0], sdir.x, fmaf(M[1], sdir.y, M[2] * sdir.z)) * iz, fy = fmaf(M[3], sdir.x, fmaf(M[4], sdir.y, M[5] * sdir.z)) * iz;
+  const float gx = (float)bk.g[a].nx, gy = (float)bk.g[a].ny;
+  // inside the grid (NaN fails): everything else is the tree's business
+  const wmask inside = m_gt(Z, 0.f) & m_ge(fx, 0.f) & m_ge(fy, 0.f) & m_lt(fx, gx) & m_lt(fy, gy);
+  if ((active & ~inside) != 0ull) return false;
+  uint32_t mnx = msel(active, __float_as_uint(fx), 0x7f800000u), mny = msel(active, __float_as_uint(fy), 0x7f800000u);
+  uint32_t mxx = msel(active, __float_as_uint(fx), 0u), mxy = msel(active, __float_as_uint(fy), 0u);
+  wave_reduce_minmax4(mnx, mny, mxx, mxy);
+  const float x0 = __uint_as_float(mnx), y0 = __uint_as_float(mny), x1 = __uint_as_float(mxx), y1 = __uint_as_float(mxy);
+  const int tx0 = (int)x0, ty0 = (int)y0, tx1 = (int)x1, ty1 = (int)y1; // (non-negative: truncation is floor)
+  const int stx0 = __builtin_amdgcn_readfirstlane(tx0), sty0 = __builtin_amdgcn_readfirstlane(ty0);
+  const int stx1 = __builtin_amdgcn_readfirstlane(tx1), sty1 = __builtin_amdgcn_readfirstlane(ty1);
+  if ((stx1 - stx0 + 1) * (sty1 - sty0 + 1) > 4) return false;
+  const float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1), hx = 0.5f * (x1 - x0) + 1e-5f * gx, hy = 0.5f * (y1 - y0) + 1e-5f * gy; // (+ the rounding of the centre form)
+  const float scx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx))), scy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+  const float shx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hx))), shy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hy)));
+  Hit hs;
+  traverse_bins<true>(bk.base[a], bk.g[a].nx, stx0, sty0, stx1, sty1, scx, scy, shx, shy, recs, sdir, 0.f, 1.0f - SHADOW_EPS, active, hs, occluded);
+  return true;
+}
+
 // per-sample shading state between the three packet walks
 struct ShadePre {
   bool ok, need_p, need_s;
@@ -1794,16 +1964,24 @@ __device__ __forceinline__ bool tex_footprint_lit(const float *__restrict__ tex,
 }
 
 // MATM: 0 = [S,3] Lambert albedos, 1 = material rows, 2 = material rows some of which take their base colour from a texture
+// px, py (wave-uniform): the pixel the packet's primary rays belong to — the tile bins are tried first (R == 1), the tree walks serve
+// what they cannot
 template <int R, bool WIDE, int MATM = 0>
 __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs,
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
-                                                const float4 *__restrict__ nrec, const float4 *__restrict__ gn, const float *__restrict__ tex_probe = nullptr) {
+                                                const float4 *__restrict__ nrec, const float4 *__restrict__ gn, const int px, const int py,
+                                                const float *__restrict__ tex_probe = nullptr) {
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   Hit h[R];
   bool fnd[R];
   FFX_TSTART(tp);
-  traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
+  bool binned = false;
+  if constexpr (R == 1) binned = bins_primary(kernarg_shade().bins, px, py, arecs, d[0], nt[0], ft[0], wballot(active[0]), h[0]);
+  if (!binned) {
+    if constexpr (R == 1) FFX_STAT(36);
+    traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
+  }
   FFX_TSTOP(tp, 22);
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
@@ -1956,7 +2134,17 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = ppos; sdir[r] = vsub(pre[r].Po, ppos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_p; }
-    traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride), ws, stack, so, sdir, s0, s1, act, hs, occ_p);
+    const TriApex *arecs_p = reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + astride);
+    bool binned_p = false;
+    if constexpr (R == 1) {
+      wmask occm;
+      binned_p = bins_shadow(kernarg_shade().bins, 1, arecs_p, sdir[0], wballot(act[0]), occm);
+      if (binned_p) occ_p[0] = __builtin_amdgcn_inverse_ballot_w64(occm);
+    }
+    if (!binned_p) {
+      if constexpr (R == 1) FFX_STAT(44);
+      traverse_packet_any<true, R, WIDE>(nodes, arecs_p, ws, stack, so, sdir, s0, s1, act, hs, occ_p);
+    }
   }
   FFX_TSTOP(tp, 19);
   if (c.shadows && wballot(any_s) != 0ull) {
@@ -1967,7 +2155,17 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     Hit hs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { so[r] = spos; sdir[r] = vsub(pre[r].Po, spos); s0[r] = 0.f; s1[r] = 1.0f - SHADOW_EPS; act[r] = pre[r].need_s; }
-    traverse_packet_any<true, R, WIDE>(nodes, reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride), ws, stack, so, sdir, s0, s1, act, hs, occ_s);
+    const TriApex *arecs_s = reinterpret_cast<const TriApex *>(reinterpret_cast<const char *>(arecs) + 2u * astride);
+    bool binned_s = false;
+    if constexpr (R == 1) {
+      wmask occm;
+      binned_s = bins_shadow(kernarg_shade().bins, 2, arecs_s, sdir[0], wballot(act[0]), occm);
+      if (binned_s) occ_s[0] = __builtin_amdgcn_inverse_ballot_w64(occm);
+    }
+    if (!binned_s) {
+      if constexpr (R == 1) FFX_STAT(45);
+      traverse_packet_any<true, R, WIDE>(nodes, arecs_s, ws, stack, so, sdir, s0, s1, act, hs, occ_s);
+    }
   }
   FFX_TSTOP(tp, 20);
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
@@ -2249,7 +2447,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, (fold && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, px[0], py[0], (fold && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
       if (fold) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
@@ -2517,7 +2715,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         cam_ray(cam, ((float)px[r] + jx) * cam.inv_w, ((float)py[r] + jy) * cam.inv_h, o[r], d[r], nt[r], ft[r]);
       }
       SampleTerms st[R];
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, px[0], py[0]);
       const ShadeK &ct = kernarg_shade(); // phase: scatter into the texture gradient
       const int tc = ct.tc;
 #pragma unroll
@@ -2983,6 +3181,81 @@ static size_t dummy_lds() {
   return e ? (size_t)atol(e) : 0;
 }
 
+// ---- tile bins: the three grids of a scene description (ffx_common.h BinGrid).  A pure function of sd (and the environment), so that
+// ffx_apex_prepare and the render calls that follow it derive the same grids.  A grid is switched off (its packets walk the tree)
+// when its projection is not a central perspective, when a spot's cone is too wide for a perspective grid, or by FFX_BINS=0.
+static int bins_enabled() {
+  const char *e = getenv("FFX_BINS");
+  return !(e && strcmp(e, "0") == 0);
+}
+static int env_pow2(const char *name, int dflt, int lo, int hi) {
+  const char *e = getenv(name);
+  int v = e ? atoi(e) : dflt;
+  if (v < lo || v > hi || (v & (v - 1)) != 0) v = dflt;
+  return v;
+}
+// rows of M for a sensor-like apex: tile coordinates = (film / tile) * sample coordinates of camera_to_sample * world_to_camera
+static int grid_from_sensor(const float *to_world, const float *c2s, int width, int height, int tile, BinGrid &g) {
+  memset(&g, 0, sizeof g);
+  if (width < 1 || height < 1) return 0;
+  float w2c[16];
+  if (!ffx_inv4(to_world, w2c)) return 0;
+  // a central projection: sample = (r0 . p, r1 . p) / (r3 . p) with no dependence on the homogeneous 1 of a camera-space point
+  if (c2s[3] != 0.f || c2s[7] != 0.f || c2s[15] != 0.f || !(c2s[14] > 0.f)) return 0;
+  while ((width + tile - 1) / tile > 128 || (height + tile - 1) / tile > 128) tile *= 2;
+  g.nx = (width + tile - 1) / tile;
+  g.ny = (height + tile - 1) / tile;
+  if ((long)g.nx * g.ny > FFX_BIN_MAX_TILES) return 0;
+  const double sx = (double)width / tile, sy = (double)height / tile;
+  for (int j = 0; j < 3; ++j) {
+    double x = 0, y = 0, z = 0;
+    for (int k = 0; k < 3; ++k) {
+      x += (double)c2s[k] * w2c[4 * k + j];
+      y += (double)c2s[4 + k] * w2c[4 * k + j];
+      z += (double)c2s[12 + k] * w2c[4 * k + j];
+    }
+    g.M[j] = (float)(sx * x); g.M[3 + j] = (float)(sy * y); g.M[6 + j] = (float)z;
+  }
+  g.o[0] = to_world[3]; g.o[1] = to_world[7]; g.o[2] = to_world[11];
+  g.on = 1;
+  return tile;
+}
+static void bins_grids(const ffx_scene_desc *sd, BinGrid (&g)[FFX_N_APEX], float &cam_its_x, float &cam_its_y) {
+  memset(g, 0, sizeof g);
+  cam_its_x = cam_its_y = 0.f;
+  if (!sd || !bins_enabled()) return;
+  const int ts = env_pow2("FFX_BIN_TILE", 8, 4, 32);
+  const int tile = grid_from_sensor(sd->cam.to_world, sd->cam.camera_to_sample, sd->cam.width, sd->cam.height, ts, g[0]);
+  if (tile > 0) cam_its_x = cam_its_y = 1.0f / (float)tile;
+  if (sd->proj.enabled) grid_from_sensor(sd->proj.to_world, sd->proj.camera_to_sample, sd->proj.tex_w, sd->proj.tex_h, env_pow2("FFX_BIN_TILE_PROJ", 2 * ts, 4, 64), g[1]);
+  if (sd->spot.enabled && sd->spot.cutoff_deg > 0.f && sd->spot.cutoff_deg <= 75.f) {
+    // a square perspective grid around the cone's axis: half angle = cutoff + 1 degree, ~1 degree per tile at the centre
+    float w2l[16];
+    if (ffx_inv4(sd->spot.to_world, w2l)) {
+      const char *e = getenv("FFX_BIN_SPOT_N");
+      int n = e ? atoi(e) : (int)(2.0f * sd->spot.cutoff_deg + 0.999f);
+      n = n < 8 ? 8 : (n > 128 ? 128 : n);
+      const double tanc = tan(((double)sd->spot.cutoff_deg + 1.0) * 0.017453292519943295);
+      BinGrid &q = g[2];
+      for (int j = 0; j < 3; ++j) {
+        q.M[j] = (float)(0.5 * n * (w2l[j] / tanc + w2l[8 + j]));
+        q.M[3 + j] = (float)(0.5 * n * (w2l[4 + j] / tanc + w2l[8 + j]));
+        q.M[6 + j] = w2l[8 + j];
+      }
+      q.o[0] = sd->spot.to_world[3]; q.o[1] = sd->spot.to_world[7]; q.o[2] = sd->spot.to_world[11];
+      q.nx = q.ny = n;
+      q.on = 1;
+    }
+  }
+}
+// the kernels' view of the bins of `sd` in the blob (grids as bins_grids gives them; built by launch_apex / ffx_apex_prepare)
+static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, BinsK &bk) {
+  memset(&bk, 0, sizeof bk);
+  if (!info->off_bins || !info->bins_stride) return;
+  bins_grids(sd, bk.g, bk.cam_inv_ts_x, bk.cam_inv_ts_y);
+  for (int a = 0; a < FFX_N_APEX; ++a) bk.base[a] = (const char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
+}
+
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
 __global__ void k_cache_reset(uint32_t *__restrict__ cache_hdr, uint32_t cap_stray) {
   cache_hdr[0] = 0u; cache_hdr[1] = cap_stray; cache_hdr[2] = 0u;
@@ -3011,9 +3284,21 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   TriApex *out = (TriApex *)((char *)bvh + ffx_apex_offset(info, 0));
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (flags & FFX_RENDER_CACHE_ZEROED) cache = nullptr;
-  if (!(flags & FFX_RENDER_APEX_READY))
+  if (!(flags & FFX_RENDER_APEX_READY)) {
     hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
-  else if (cache)
+    if (sd && info->off_bins && info->bins_stride && info->bins_stride >= ffx_bin_stride(info->n_tris)) { // the tile bins of this pose and these apexes
+      BinBuild bb;
+      memset(&bb, 0, sizeof bb);
+      float ix, iy;
+      bins_grids(sd, bb.g, ix, iy);
+      if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
+        for (int a = 0; a < FFX_N_APEX; ++a) bb.base[a] = (char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
+        bb.cap = (uint32_t)ffx_bin_cap(info->n_tris);
+        ffx_bins_clear_launch(bb, s);
+        ffx_bins_launch(recs, info->n_tris, bb, s);
+      }
+    }
+  } else if (cache)
     hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);
   *arecs = out;
   *astride = (uint32_t)stride;
@@ -3057,10 +3342,18 @@ extern "C" int ffx_debug_timers(unsigned long long *out32, int reset) {
 }
 #endif
 #ifdef FFX_STATS
-extern "C" int ffx_debug_stats(unsigned long long *out16, int reset) {
+extern "C" int ffx_debug_stats(unsigned long long *out16, int reset) { // the tree walks' counters [0, 32); resets all 48
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ffx_stats), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+extern "C" int ffx_debug_stats48(unsigned long long *out48, int reset) { // ... with the tile bins' counters [32, 48)
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_ffx_stats), sizeof(unsigned long long) * 48) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[48] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_stats), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
@@ -3164,6 +3457,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cap_stray, call_flags)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
+    bins_k(bvh, info, sd, c.bins);
     // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
     const uint32_t foot_off = (uint32_t)(cache_off_foot((size_t)c.cam.W * c.cam.H) >> 7), arena_off = (uint32_t)(cache_off_arena((size_t)c.cam.W * c.cam.H) >> 7);
     const uint32_t foot_b_off = (uint32_t)(cache_off_foot_b((size_t)c.cam.W * c.cam.H, cache_stray_capacity(c.cam.W, c.cam.H, spp)) >> 7);
@@ -3326,6 +3620,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
     uint32_t astride;
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
+    bins_k(bvh, info, sd, c.bins);
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
                      spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), gimg, gtex, nrec, gn)

@@ -355,15 +355,17 @@ class _EventPair:
 
 
 def apex_key(sd=None, cam=None):
-    """what the blob's apex areas must hold for a packet render / trace call (include/ffx.h ffx_apex_prepare): the positions of the
-    camera and of the enabled emitters, as the exact floats the library reads"""
+    """what the blob's pre-pass areas must hold for a packet render / trace call (include/ffx.h ffx_apex_prepare): the apex records depend
+    on the POSITIONS of the camera and of the enabled emitters, the tile bins (ffx_bvh_info.off_bins) on their whole projections — pose,
+    field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
     c = sd.cam if sd is not None else cam
-    key = [c.to_world[3], c.to_world[7], c.to_world[11]]
+    key = [tuple(c.to_world), tuple(c.camera_to_sample), c.width, c.height]
     if sd is not None:
-        key += [sd.proj.to_world[3], sd.proj.to_world[7], sd.proj.to_world[11]] if sd.proj.enabled else [None]
-        key += [sd.spot.to_world[3], sd.spot.to_world[7], sd.spot.to_world[11]] if sd.spot.enabled else [None]
+        key += [(tuple(sd.proj.to_world), tuple(sd.proj.camera_to_sample), sd.proj.tex_w, sd.proj.tex_h) if sd.proj.enabled else None]
+        key += [(tuple(sd.spot.to_world), sd.spot.cutoff_deg) if sd.spot.enabled else None]
+        key += [os.environ.get("FFX_BINS"), os.environ.get("FFX_BIN_TILE"), os.environ.get("FFX_BIN_TILE_PROJ"), os.environ.get("FFX_BIN_SPOT_N")]
     else:
-        key += [None, None]
+        key += [None, None, None]
     return tuple(key)
 
 
@@ -427,7 +429,10 @@ class DeviceGeometry:
         # the render kernels of the previous step are still running on the caller's stream (the refit is
         # five small dependent launches, ~55 us with the GPU otherwise idle; overlapped it costs nothing).
         # FFX_ASYNC_UPDATE=0 falls back to one blob, everything on the caller's stream.
-        b0 = torch.from_numpy(blob[: self.info.total_bytes].copy()).to(self.device)
+        # the host builder fills the first off_bins bytes; the tail (tile bins, apex records) is scratch of the render calls' pre-pass
+        static = int(self.info.off_bins) if int(self.info.off_bins) > 0 else int(self.info.total_bytes)
+        b0 = torch.zeros(int(self.info.total_bytes), dtype=torch.uint8, device=self.device)
+        b0[:static].copy_(torch.from_numpy(blob[:static]))
         self._async = self.device.type == "cuda" and os.environ.get("FFX_ASYNC_UPDATE", "1") != "0"
         self._blobs = [b0, b0.clone()] if self._async else [b0]
         self._cur = 0

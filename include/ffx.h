@@ -31,6 +31,8 @@
  *                                B >= 2: each XCD takes B consecutive work items of every 8 B (default 128)
  *       FFX_DUMMY_LDS=bytes      extra dynamic LDS per workgroup (occupancy experiments)
  *       FFX_K7_PPW_LOG2=0..6     cap on log2(pixels per wavefront) of ffx_trace_primary (default 4 at 1 spp, else 3)
+ *       FFX_BINS=0               the packet render kernels walk the tree for every packet (default: tile bins first, ffx_bvh_info.off_bins)
+ *       FFX_BIN_TILE=4..32       side of a camera tile of the bins in pixels (default 8)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
  *     tests/test_hip_parity.py::test_wide_overlay_builders_give_identical_images):
  *       FFX_WIDE_BUILD=area|count|layers   builder of the 64-wide overlay (default area: greedy SAH cut)
@@ -49,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 4
+#define FFX_ABI_VERSION 5
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -327,6 +329,17 @@ typedef struct ffx_bvh_info {
                          {0,0,0}), else (shape + 1) | smooth << 30 (smooth: the record is flagged by ffx_smooth) — the kernels take
                          the hit's shape id and smooth flag from it, so a blob written to any other encoding renders with a wrong
                          material row.  0 in the oracle's blob (it has no such area). */
+  /* tile bins (ABI 5, DESIGN.md 5.1 "round 4"): for each of the three ray origins of a render (camera, projector, spot) a
+   * perspective grid of tiles over that origin's field of view and, per tile, the list of triangles whose projection overlaps it —
+   * 64-byte entries {padded 2-D box, three edge equations, leaf slot} in the grid's tile units.  Written by the render calls' pre-pass
+   * (ffx_apex_prepare / a render without FFX_RENDER_APEX_READY) next to the apex records, read by the packet render kernels: a
+   * pixel's packet tests the entries of its tile against its own screen rectangle with the lanes on the entries and runs the exact
+   * ray / triangle test on the survivors only — no tree walk.  Packets the bins cannot serve (outside a grid, more than four tiles,
+   * an overflowed or disabled grid) take the tree walks as before; results are identical either way.
+   * Layout: FFX_N_APEX areas of bins_stride bytes from off_bins: a 64-byte header {ok, entries, capacity}, (tiles + 1) uint32 list
+   * starts, `tiles` uint32 fill cursors, then the entries.  0 in the oracle's blob. */
+  uint64_t off_bins;
+  uint64_t bins_stride;
 } ffx_bvh_info;
 
 /* Interpolated shading normals (optional; ffx_scene_update's `smooth`).  Mitsuba shades a mesh that carries vertex normals
