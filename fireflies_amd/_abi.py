@@ -84,6 +84,17 @@ class AdamArgs(C.Structure):
     ]
 
 
+class RandDraw(C.Structure):
+    """ffx_rand_draw: one uniform sampler call of a randomisation"""
+    _fields_ = [("n", C.c_int32), ("lo", C.c_float * 4), ("hi", C.c_float * 4), ("pad", C.c_int32 * 3)]
+
+
+class RandEntity(C.Structure):
+    """ffx_rand_entity: how one entity's matrices follow from its draws"""
+    _fields_ = [("kind", C.c_int32), ("parent", C.c_int32), ("draw_t", C.c_int32), ("draw_r", C.c_int32), ("draw_s", C.c_int32), ("pad", C.c_int32 * 3),
+                ("world", C.c_float * 16), ("centroid", C.c_float * 3), ("pad2", C.c_float)]
+
+
 class Camera(C.Structure):
     _fields_ = [
         ("to_world", c_f * 16),
@@ -174,6 +185,7 @@ PROTOTYPES = {
     "ffx_splat_lines_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
     "ffx_torch_rand_h": (c_i, [C.c_uint64, C.c_uint64, c_i, PF, C.POINTER(C.c_uint64)]),
     "ffx_torch_rand_batch_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), PF]),
+    "ffx_scene_randomize_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(RandDraw), c_i, C.POINTER(RandEntity), c_i, c_p, c_p, c_p, c_p]),
     "ffx_blur_fwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),

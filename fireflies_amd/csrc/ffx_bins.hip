@@ -8,13 +8,17 @@
 // packet's screen rectangle — lanes on the entries — and runs the exact ray / triangle test on the survivors: what were 4.2 + 3.9
 // dependent steps through the 64-wide tree per pixel (closest-hit + any-hit walk) is one coalesced load and ~1.3 steps.
 //
-// Three launches on the stream of the apex records (normally the side stream behind the re-fit, off the renders' critical path):
-//   k_bin<false>  a lane per triangle and apex: project, classify, count the tiles it touches (one atomic per tile)
-//   k_bin_scan    a workgroup per apex: exclusive scan of the counts -> list starts; overflow check against the capacity
-//   k_bin<true>   the same walk again, writing the 64-byte entries at start[tile] + cursor[tile]++
-// Triangles that touch more than four tiles (slivers at grazing angles, large faces) and triangles the projection is not trusted
-// for (a vertex behind / beside the apex) are handled by the whole wave, lanes on tiles.  Entry order inside a tile is the order
+// Two launches on the stream of the re-fit (normally the side stream, off the renders' critical path):
+//   k_bin<false>  a lane per triangle and apex: writes the triangle's APEX RECORD (ffx_common.h TriApex — what k_apex_records did as a
+//                 launch of its own), projects, classifies and counts the tiles it touches (one atomic per tile into `cursors`);
+//                 the workgroup that finishes last scans the counts of all three grids into list starts (overflow check included)
+//   k_bin<true>   the same walk again, writing the 64-byte entries at start[tile] + --cursor[tile]: the cursors count back down to
+//                 zero, which is what the next pose's counting pass needs to find (no clearing launch)
+// Triangles that touch up to sixteen tiles loop over them per lane; larger ones (faces next to the apex) and triangles the projection
+// is not trusted for (a vertex behind / beside the apex) are handled by the whole wave, lanes on tiles.  Entry order inside a tile is the order
 // of the atomics — it does not affect a result: closest hits carry the primitive-id tie-break, any-hit answers are booleans.
+#include <string.h>
+
 #include "ffx_common.h"
 
 typedef unsigned long long wmask_t;
@@ -62,43 +66,93 @@ __device__ __forceinline__ bool bin_entry_touches(const BinEntry &en, float rx0,
   return ok;
 }
 
-__global__ void __launch_bounds__(256) k_bin_clear(BinBuild bb) {
-  const int a = blockIdx.y;
-  if (!bb.g[a].on) return;
-  char *base = bb.base[a];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// the scan of one grid's counts (in `cursors`) into list starts, by one workgroup of 256 threads through LDS (coalesced loads and
+// stores; a thread scans a contiguous run of the LDS copy).  The cursors keep the counts (the fill pass counts them down) unless the
+// lists do not fit — then they are cleared here, because no fill pass will run.  s_cnt: nt + 1 words of dynamic LDS.
+__device__ void bin_scan_one(char *base, int nt, uint32_t cap, uint32_t *s_cnt) {
   uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
   uint32_t *cursors = (uint32_t *)(base + ffx_bin_off_cursors());
-  const int nt = bb.g[a].nx * bb.g[a].ny;
-  if (i <= nt) starts[i] = 0u;
-  if (i < nt) cursors[i] = 0u;
-  if (i == 0) { BinHdr *h = (BinHdr *)base; h->ok = 0u; h->total = 0u; h->cap = bb.cap; }
+  __shared__ uint32_t s_part[256];
+  for (int i = threadIdx.x; i < nt; i += 256) s_cnt[i] = cursors[i];
+  __syncthreads();
+  const int per = (nt + 255) / 256; // <= 64
+  const int t0 = threadIdx.x * per, t1 = min(t0 + per, nt);
+  uint32_t sum = 0;
+  for (int t = t0; t < t1; ++t) sum += s_cnt[t];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan of the 256 partial sums
+    const uint32_t v = threadIdx.x >= (unsigned)off ? s_part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t total = s_part[255];
+  const bool ok = total <= cap;
+  uint32_t run = s_part[threadIdx.x] - sum; // exclusive
+  for (int t = t0; t < t1; ++t) {
+    const uint32_t c = s_cnt[t];
+    s_cnt[t] = run;
+    run += c;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nt; i += 256) {
+    starts[i] = s_cnt[i];
+    if (!ok) cursors[i] = 0u;
+  }
+  if (threadIdx.x == 0) {
+    starts[nt] = total;
+    BinHdr *h = (BinHdr *)base;
+    h->total = total;
+    h->cap = cap;
+    h->ok = ok ? 1u : 0u;
+  }
+  __syncthreads();
 }
 
+// apex records of the pre-pass (k_apex_records of ffx_trace.hip, same arithmetic): what to write for apex a
+struct BinApex { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; TriApex *out; uint32_t astride; uint32_t *cache_hdr; uint32_t cap_stray; };
+
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb) {
+__global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb, BinApex ba) {
   const int a = blockIdx.y;
-  if (!bb.g[a].on) return;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+  if (k < n_tris) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
+    ra = r4[0]; rb = r4[1]; rc = r4[2];
+  }
+  if (!FILL) {
+    if (k == 0 && a == 0 && ba.cache_hdr) { ba.cache_hdr[0] = 0u; ba.cache_hdr[1] = ba.cap_stray; ba.cache_hdr[2] = 0u; } // adjoint cache: stray arena empty
+    if (k < n_tris && ba.out && ba.on[a]) { // the triangle as seen from apex a (ffx_common.h TriApex; the oracle's operation order)
+      const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);
+      const v3 A = vcross(e2, e1);
+      const v3 tv = vsub(V3(ba.o[a][0], ba.o[a][1], ba.o[a][2]), v0);
+      const v3 B = vcross(e2, tv), Cc = vcross(tv, e1);
+      const float T = vdot(e2, Cc);
+      float4 *o4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ba.out) + (size_t)a * ba.astride) + 3 * (size_t)k;
+      o4[0] = make_float4(A.x, A.y, A.z, B.x);
+      o4[1] = make_float4(B.y, B.z, Cc.x, Cc.y);
+      o4[2] = make_float4(Cc.z, T, rc.y, rc.z); // prim, shape as in TriRec
+    }
+  }
+  const bool grid_on = bb.g[a].on != 0 && bb.base[a] != nullptr;
   char *base = bb.base[a];
-  const BinHdr *hdr = (const BinHdr *)base;
-  if (FILL && hdr->ok == 0u) return; // the lists do not fit: this pose renders through the tree walks
   uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
   uint32_t *cursors = (uint32_t *)(base + ffx_bin_off_cursors());
   BinEntry *ents = (BinEntry *)(base + ffx_bin_off_entries());
   const int nx = bb.g[a].nx, ny = bb.g[a].ny;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const bool work = grid_on && !(FILL && ((const BinHdr *)base)->ok == 0u); // (fill: the lists do not fit — this pose renders through the tree walks)
   auto emit = [&](int tile, const BinEntry &en) {
-    if (!FILL) atomicAdd(&starts[tile], 1u);
+    if (!FILL) atomicAdd(&cursors[tile], 1u);
     else {
-      const uint32_t i = atomicAdd(&cursors[tile], 1u);
+      const uint32_t i = atomicSub(&cursors[tile], 1u) - 1u;
       ents[starts[tile] + i] = en;
     }
   };
   float X[3] = {0.f, 0.f, 0.f}, Y[3] = {0.f, 0.f, 0.f}, Z[3] = {-1.f, -1.f, -1.f};
-  if (k < n_tris) {
-    const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
-    const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+  if (work && k < n_tris) {
     const float vx[3] = {ra.x, ra.x + ra.w, ra.x + rb.z}, vy[3] = {ra.y, ra.y + rb.x, ra.y + rb.w}, vz[3] = {ra.z, ra.z + rb.y, ra.z + rc.x};
     const float *M = bb.g[a].M;
 #pragma unroll
@@ -109,7 +163,7 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
       Z[i] = fmaf(M[6], dx, fmaf(M[7], dy, M[8] * dz));
     }
   }
-  // class 0: wholly behind the apex plane (no ray of the grid reaches it), 1: touches at most four tiles, 2: more, 3: the projection
+  // class 0: wholly behind the apex plane (no ray of the grid reaches it), 1: touches at most sixteen tiles, 2: more, 3: the projection
   // is not trusted (a vertex behind / beside the apex, or far outside the grid): listed by plane tests
   int cls = 0;
   float x[3] = {0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
@@ -126,10 +180,21 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
       if (mxx >= 0.f && mxy >= 0.f && mnx < (float)nx && mny < (float)ny) {
         tx0 = max(0, (int)floorf(mnx)); tx1 = min(nx - 1, (int)floorf(mxx));
         ty0 = max(0, (int)floorf(mny)); ty1 = min(ny - 1, (int)floorf(mxy));
-        if (tx0 <= tx1 && ty0 <= ty1) cls = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 4 ? 1 : 2;
+        if (tx0 <= tx1 && ty0 <= ty1) cls = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 16 ? 1 : 2;
       }
     } else {
-      cls = 3;
+      // not trusted — but most such triangles (the ring of the tube beside the apex, 85 - 90 degrees off its axis) miss the grid's whole
+      // frustum: all three vertices beyond one of its four planes (any vertex position, also behind the apex).  The others take the wave.
+      const float gx = (float)nx + FFX_BIN_PAD, gy = (float)ny + FFX_BIN_PAD;
+      bool oL = true, oR = true, oT = true, oB = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        oL = oL && (X[i] + FFX_BIN_PAD * Z[i] < 0.f);
+        oR = oR && (gx * Z[i] - X[i] < 0.f);
+        oT = oT && (Y[i] + FFX_BIN_PAD * Z[i] < 0.f);
+        oB = oB && (gy * Z[i] - Y[i] < 0.f);
+      }
+      cls = (oL || oR || oT || oB) ? 0 : 3;
     }
   }
   if (cls == 1) {
@@ -144,11 +209,13 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
   while (big != 0ull) {
     const int j = __builtin_ctzll(big);
     big &= big - 1ull;
-    const int jc = __shfl(cls, j, 64), js = __shfl(k, j, 64);
+    // (j is wave-uniform: v_readlane — a shuffle would be an LDS round trip per value)
+    auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+    const int jc = __builtin_amdgcn_readlane(cls, j), js = __builtin_amdgcn_readlane(k, j);
     BinEntry en;
     if (jc == 2) {
-      const float q0 = __shfl(x[0], j, 64), q1 = __shfl(y[0], j, 64), q2 = __shfl(x[1], j, 64), q3 = __shfl(y[1], j, 64), q4 = __shfl(x[2], j, 64), q5 = __shfl(y[2], j, 64);
-      const int bx0 = __shfl(tx0, j, 64), bx1 = __shfl(tx1, j, 64), by0 = __shfl(ty0, j, 64), by1 = __shfl(ty1, j, 64);
+      const float q0 = rl(x[0]), q1 = rl(y[0]), q2 = rl(x[1]), q3 = rl(y[1]), q4 = rl(x[2]), q5 = rl(y[2]);
+      const int bx0 = __builtin_amdgcn_readlane(tx0, j), bx1 = __builtin_amdgcn_readlane(tx1, j), by0 = __builtin_amdgcn_readlane(ty0, j), by1 = __builtin_amdgcn_readlane(ty1, j);
       bin_make_entry(q0, q1, q2, q3, q4, q5, js, false, en);
       const int w = bx1 - bx0 + 1, n = w * (by1 - by0 + 1);
       for (int t = lane; t < n; t += 64) {
@@ -158,7 +225,7 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
     } else {
       float PX[3], PY[3], PZ[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { PX[i] = __shfl(X[i], j, 64); PY[i] = __shfl(Y[i], j, 64); PZ[i] = __shfl(Z[i], j, 64); }
+      for (int i = 0; i < 3; ++i) { PX[i] = rl(X[i]); PY[i] = rl(Y[i]); PZ[i] = rl(Z[i]); }
       bin_make_entry(0.f, 0.f, 0.f, 0.f, 0.f, 0.f, js, true, en);
       // a column (row) of tiles is a wedge between two planes through the apex: the triangle misses it iff all three vertices lie
       // beyond the same plane (any vertex position, also behind the apex).  Columns and rows separate: the tiles are their product.
@@ -188,56 +255,37 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
       }
     }
   }
-}
-
-// exclusive scan of the per-tile counts of one apex -> list starts (in place), the total behind the last tile; the lists fit?
-__global__ void __launch_bounds__(1024) k_bin_scan(BinBuild bb) {
-  const int a = blockIdx.x;
-  if (!bb.g[a].on) return;
-  char *base = bb.base[a];
-  uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
-  const int nt = bb.g[a].nx * bb.g[a].ny;
-  __shared__ uint32_t s_part[1024];
-  const int per = (nt + 1023) / 1024; // <= 16
-  const int t0 = threadIdx.x * per;
-  uint32_t loc[16];
-  uint32_t sum = 0;
-  for (int i = 0; i < per; ++i) {
-    const int t = t0 + i;
-    loc[i] = t < nt ? starts[t] : 0u;
-    sum += loc[i];
-  }
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
-    const uint32_t v = threadIdx.x >= (unsigned)off ? s_part[threadIdx.x - off] : 0u;
+  if (!FILL) {
+    // ---- publish; the workgroup that arrives last turns the counts of all three grids into list starts (the refit kernel's pattern:
+    // agent-scope fence + one atomic; the counter is left at zero for the next pose)
+    __shared__ int s_last;
+    __threadfence();
     __syncthreads();
-    s_part[threadIdx.x] += v;
+    if (threadIdx.x == 0) {
+      const uint32_t t = atomicAdd(bb.arrive, 1u);
+      s_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
+      if (s_last) atomicExch(bb.arrive, 0u);
+    }
     __syncthreads();
-  }
-  uint32_t run = s_part[threadIdx.x] - sum; // exclusive
-  for (int i = 0; i < per; ++i) {
-    const int t = t0 + i;
-    if (t < nt) starts[t] = run;
-    run += loc[i];
-  }
-  if (threadIdx.x == 1023) {
-    const uint32_t total = s_part[1023];
-    starts[nt] = total;
-    BinHdr *h = (BinHdr *)base;
-    h->total = total;
-    h->cap = bb.cap;
-    h->ok = total <= bb.cap ? 1u : 0u;
+    if (s_last) {
+      __threadfence();
+      extern __shared__ uint32_t s_dyn_cnt[];
+      for (int g = 0; g < FFX_N_APEX; ++g)
+        if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, s_dyn_cnt);
+    }
   }
 }
 
-void ffx_bins_clear_launch(const BinBuild &bb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bin_clear, dim3(ffx_cdiv(FFX_BIN_MAX_TILES + 1, 256), FFX_N_APEX), dim3(256), 0, s, bb);
-}
-
-void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, hipStream_t s) {
+void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s) {
+  BinApex ba;
+  memset(&ba, 0, sizeof ba);
+  for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
+  ba.out = (TriApex *)apex_out; ba.astride = astride; ba.cache_hdr = cache_hdr; ba.cap_stray = cap_stray;
   const dim3 grid(ffx_cdiv(n_tris, 256), FFX_N_APEX);
-  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), 0, s, recs, n_tris, bb);
-  hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(1024), 0, s, bb);
-  hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, s, recs, n_tris, bb);
+  int max_nt = 0; // dynamic LDS of the counting launch: the largest grid's counts (the scan of the workgroup that finishes last)
+  for (int a = 0; a < FFX_N_APEX; ++a)
+    if (bb.g[a].on && bb.g[a].nx * bb.g[a].ny > max_nt) max_nt = bb.g[a].nx * bb.g[a].ny;
+  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), (size_t)4 * (max_nt + 1), s, recs, n_tris, bb, ba);
+  if (bb.g[0].on || bb.g[1].on || bb.g[2].on) hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
 }

@@ -166,10 +166,11 @@ struct BinsK {
   BinGrid g[3];
   float cam_inv_ts_x, cam_inv_ts_y; // camera pixels -> tile units
 };
-// builds the bins of the enabled grids on `s` (ffx_bins.hip): count, scan, fill — three launches; `clear` has been done by the caller
-struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; };
-void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, hipStream_t s);
-void ffx_bins_clear_launch(const BinBuild &bb, hipStream_t s);
+// the pre-pass of a packet render on `s` (ffx_bins.hip): apex records + the bins of the enabled grids — two launches (count + scan,
+// fill); with every grid off it is the apex records alone (one launch)
+struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad[0] of apex 0 */ };
+void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s);
 
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };

@@ -10,6 +10,7 @@
 // philox4x32_10_engine + uniform_distribution).  Evaluating it here costs ~40 integer multiplies per value
 // and no device work at all; the caller advances the generator's offset by what the kernel launch would
 // have consumed, so every later consumer of the generator sees the same stream as in the reference program.
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/ffx.h"
@@ -61,6 +62,108 @@ extern "C" int ffx_torch_rand_batch_h(int k, const uint64_t *seeds, const uint64
     const int rc = ffx_torch_rand_h(seeds[i], offsets[i], counts[i], out, &inc);
     if (rc != FFX_OK) return rc;
     out += counts[i];
+  }
+  return FFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ f1: a whole Scene.randomize(), natively
+// The reference's randomisation is Python around torch.rand: per entity a translation and a rotation draw (a Mesh: a scale draw too),
+// per attribute a draw, each mapped to its interval; then 4x4 algebra — (T + centroid) @ R @ [S @] world — and the parent chains
+// (/root/reference/fireflies/scene.py:344-384, entity/base.py:194-244, entity/mesh.py:141-165).  Here the whole of it — the draws of
+// every entity in the reference's order from the generator's Philox stream, the interval maps, the matrices, the chains — is ONE host
+// call for all the scene samples of a step.  The float32 arithmetic is that of the Python mirror (fireflies_amd/entity), which is
+// torch's / numpy's: interval map as multiply then add; 3x3 and 4x4 products as an fma chain over k (what both libraries' sgemm
+// kernels compute for these sizes — checked by tests/test_api_cpu.py against numpy on random matrices); Euler angles through the
+// C library's double cos / sin like Python's math module.  So the two paths agree bit for bit and the goldens pin both.
+namespace {
+inline void mm4(const float *A, const float *B, float *C) {
+  float t[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = A[4 * i] * B[j];
+      for (int k = 1; k < 4; ++k) acc = fmaf(A[4 * i + k], B[4 * k + j], acc);
+      t[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 16; ++i) C[i] = t[i];
+}
+inline void mm3(const float *A, const float *B, float *C) {
+  float t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float acc = A[3 * i] * B[j];
+      for (int k = 1; k < 3; ++k) acc = fmaf(A[3 * i + k], B[3 * k + j], acc);
+      t[3 * i + j] = acc;
+    }
+  for (int i = 0; i < 9; ++i) C[i] = t[i];
+}
+} // namespace
+
+extern "C" int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const uint64_t *offsets, const ffx_rand_draw *draws, int n_draws,
+                                     const ffx_rand_entity *ents, int n_ents, float *values, float *local, float *chain, float *chain_unc) {
+  if (n_samples < 0 || n_draws < 0 || n_ents < 0 || (n_samples > 0 && (!seeds || !offsets)) || (n_draws > 0 && (!draws || !values)) ||
+      (n_ents > 0 && (!ents || !local || !chain || !chain_unc)))
+    FFX_FAIL(FFX_ERR_ARG, "scene_randomize_h: bad argument");
+  for (int d = 0; d < n_draws; ++d)
+    if (draws[d].n < 1 || draws[d].n > 4) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_randomize_h: draw %d has %d values (1..4)", d, draws[d].n);
+  for (int e = 0; e < n_ents; ++e) {
+    const ffx_rand_entity &q = ents[e];
+    if (q.parent >= e || q.kind < 0 || q.kind > 2 || q.draw_t >= n_draws || q.draw_r >= n_draws || q.draw_s >= n_draws)
+      FFX_FAIL(FFX_ERR_ARG, "scene_randomize_h: entity %d: parents come first, draw rows must exist", e);
+  }
+  for (int s = 0; s < n_samples; ++s) {
+    if (offsets[s] & 3u) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_randomize_h: generator offset not a multiple of 4");
+    float *val = values + (size_t)s * n_draws * 4;
+    for (int d = 0; d < n_draws; ++d) {
+      float u[4];
+      uint64_t inc;
+      const int rc = ffx_torch_rand_h(seeds[s], offsets[s] + 4u * (uint64_t)d, draws[d].n, u, &inc); // (every draw of <= 256 values advances the generator by 4)
+      if (rc != FFX_OK) return rc;
+      for (int i = 0; i < 4; ++i) {
+        if (i < draws[d].n) {
+          const float w = draws[d].hi[i] - draws[d].lo[i];
+          const float p = u[i] * w;
+          val[4 * d + i] = p + draws[d].lo[i];
+        } else {
+          val[4 * d + i] = 0.f;
+        }
+      }
+    }
+    float *loc = local + (size_t)s * n_ents * 16, *ch = chain + (size_t)s * n_ents * 16, *cu = chain_unc + (size_t)s * n_ents * 16;
+    for (int e = 0; e < n_ents; ++e) {
+      const ffx_rand_entity &q = ents[e];
+      float *L = loc + 16 * e;
+      if (q.kind == 0 || q.draw_t < 0 || q.draw_r < 0) { // not randomised: its world as it stands
+        for (int i = 0; i < 16; ++i) L[i] = q.world[i];
+      } else {
+        const float *t = val + 4 * q.draw_t, *r = val + 4 * q.draw_r;
+        // names as in the reference: the "z" slot feeds getPitchTransform (about Y), the "y" slot getYawTransform (about Z); Z @ Y @ X
+        const float cz = (float)cos((double)r[2]), sz = (float)sin((double)r[2]);
+        const float cy = (float)cos((double)r[1]), sy = (float)sin((double)r[1]);
+        const float cx = (float)cos((double)r[0]), sx = (float)sin((double)r[0]);
+        const float zM[9] = {cz, 0.f, sz, 0.f, 1.f, 0.f, -sz, 0.f, cz};
+        const float yM[9] = {cy, -sy, 0.f, sy, cy, 0.f, 0.f, 0.f, 1.f};
+        const float xM[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
+        float zy[9], R3[9];
+        mm3(zM, yM, zy);
+        mm3(zy, xM, R3);
+        const float R[16] = {R3[0], R3[1], R3[2], 0.f, R3[3], R3[4], R3[5], 0.f, R3[6], R3[7], R3[8], 0.f, 0.f, 0.f, 0.f, 1.f};
+        // T + centroid matrix (identity + translation, plus a matrix that is zero but for the centroid in its last column)
+        const float TC[16] = {1.f, 0.f, 0.f, t[0] + q.centroid[0], 0.f, 1.f, 0.f, t[1] + q.centroid[1], 0.f, 0.f, 1.f, t[2] + q.centroid[2], 0.f, 0.f, 0.f, 1.f};
+        float M[16];
+        mm4(TC, R, M);
+        if (q.kind == 2 && q.draw_s >= 0) {
+          const float *sc = val + 4 * q.draw_s;
+          const float S[16] = {sc[0], 0.f, 0.f, 0.f, 0.f, sc[1], 0.f, 0.f, 0.f, 0.f, sc[2], 0.f, 0.f, 0.f, 0.f, 1.f};
+          mm4(M, S, M);
+        }
+        mm4(M, q.world, L);
+      }
+      float *Cn = ch + 16 * e;
+      if (q.parent >= 0) mm4(ch + 16 * q.parent, L, Cn);
+      else for (int i = 0; i < 16; ++i) Cn[i] = L[i];
+      const float U[16] = {1.f, 0.f, 0.f, -q.centroid[0], 0.f, 1.f, 0.f, -q.centroid[1], 0.f, 0.f, 1.f, -q.centroid[2], 0.f, 0.f, 0.f, 1.f};
+      mm4(Cn, U, cu + 16 * e);
+    }
   }
   return FFX_OK;
 }

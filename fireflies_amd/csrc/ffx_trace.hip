@@ -1797,6 +1797,7 @@ __device__ __forceinline__ void traverse_bins(const char *__restrict__ bbase, co
   auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
   const float rx0 = uni(rcx - rhx), rx1 = uni(rcx + rhx), ry0 = uni(rcy - rhy), ry1 = uni(rcy + rhy);
   FFX_STAT(ANY ? 40 : 32);
+  const float tmax_up = tmax * 1.0000038f; // tmax (1 + 2^-18)
   bool go = true;
   for (int ty = ty0; ty <= ty1 && go; ++ty) {
     for (int tx = tx0; tx <= tx1 && go; ++tx) {
@@ -1829,11 +1830,19 @@ __device__ __forceinline__ void traverse_bins(const char *__restrict__ bbase, co
           const v3 Cv = V3(__int_as_float(r8.s6), __int_as_float(r8.s7), __int_as_float(r4.x));
           const float T = __int_as_float(r4.y);
           const float det = vdot(d, Av);
-          const float U = vdot(d, Bv);
           const wmask neg = m_lt(det, 0.f);
           const float detA = fabsf(det);
-          const float Us = msel(neg, -U, U);
           const wmask alive = ANY ? (active & ~occluded) : active;
+          if (ANY) {
+            // t = +-T / |det| must lie below tmax.  Most candidates of a shadow packet are the triangles of the surface the rays END on
+            // (t = 1 up to rounding, beyond tmax = 1 - 10 eps): T and det alone settle them — |T| >= tmax (1 + 2^-18) |det| implies
+            // fl(|T| / |det|) >= tmax — before either barycentric is formed (8 VALU instead of the 36 of a test that passes both)
+            const float Ts = msel(neg, -T, T);
+            if ((alive & m_lt(Ts, detA * tmax_up)) == 0ull) continue;
+            FFX_STAT(46);
+          }
+          const float U = vdot(d, Bv);
+          const float Us = msel(neg, -U, U);
           const wmask p1 = alive & m_gt(detA, 0.f) & m_ge(Us, 0.f) & m_le(Us, detA);
           if (p1 == 0ull) continue;
           FFX_STAT(ANY ? 43 : 35);
@@ -3285,18 +3294,21 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (flags & FFX_RENDER_CACHE_ZEROED) cache = nullptr;
   if (!(flags & FFX_RENDER_APEX_READY)) {
-    hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
-    if (sd && info->off_bins && info->bins_stride && info->bins_stride >= ffx_bin_stride(info->n_tris)) { // the tile bins of this pose and these apexes
-      BinBuild bb;
-      memset(&bb, 0, sizeof bb);
+    // ONE pre-pass for both: the counting launch of the tile bins writes the apex records too (ffx_bins.hip k_bin<false>), the fill
+    // launch follows when a grid is on.  A blob without a bins area (or a primary-visibility call: sd == NULL) gets the apex records alone.
+    BinBuild bb;
+    memset(&bb, 0, sizeof bb);
+    if (sd && info->off_bins && info->bins_stride >= ffx_bin_stride(info->n_tris)) {
       float ix, iy;
       bins_grids(sd, bb.g, ix, iy);
-      if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
-        for (int a = 0; a < FFX_N_APEX; ++a) bb.base[a] = (char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
-        bb.cap = (uint32_t)ffx_bin_cap(info->n_tris);
-        ffx_bins_clear_launch(bb, s);
-        ffx_bins_launch(recs, info->n_tris, bb, s);
-      }
+      for (int a = 0; a < FFX_N_APEX; ++a) bb.base[a] = (char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
+      bb.cap = (uint32_t)ffx_bin_cap(info->n_tris);
+      bb.arrive = (uint32_t *)(bb.base[0] + offsetof(BinHdr, pad));
+    }
+    if (!bb.arrive) { // no bins area to hold the arrival counter: the plain apex launch
+      hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
+    } else {
+      ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s);
     }
   } else if (cache)
     hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);

@@ -302,6 +302,11 @@ class SceneParameters:
         self._scene._set_pose(name, world, frame, vertices)
         self._dirty.add(name + ".__pose__")
 
+    def set_mesh_pose_np(self, name, pose16, frame=None, vertices=None):
+        """set_mesh_pose for a pose that already is a row of 16 host floats (Scene._apply_native: the native randomiser's tables)"""
+        self._scene._set_pose_np(name, pose16, frame, vertices)
+        self._dirty.add(name + ".__pose__")
+
     def update(self):
         self._scene._apply(self._dirty)
         self._dirty = set()
@@ -446,6 +451,20 @@ class Scene:
             o = self._scratch_off[i]
             self.geom.write_verts(o, v)  # ordered against the refits on the side stream
             self._offs[i] = o
+        elif frame is not None:
+            f = int(frame)
+            if not (0 <= f < int(self._n_frames[i])):
+                raise IndexError(f"{name}: frame {f} out of range [0, {int(self._n_frames[i])})")
+            self._offs[i] = self._base_off[i] + f * int(self._stride[i])
+
+    def _set_pose_np(self, name, pose16, frame, vertices):
+        i = self._mesh_index[name]
+        xn = getattr(self, "_xforms_np", None)
+        if xn is None:
+            xn = self._xforms_np = self._xforms.numpy()  # (shares the host tensor's memory; _xforms is only ever written in place)
+        xn[i] = pose16.reshape(4, 4)
+        if vertices is not None:
+            self._set_pose(name, self._xforms[i], None, vertices)
         elif frame is not None:
             f = int(frame)
             if not (0 <= f < int(self._n_frames[i])):

@@ -11,6 +11,7 @@ structure (scene.py:243-251,384).  Here `update_meshes` hands (world matrix, ani
 the parameter object and `params.update()` issues ONE fused device pass (vertex transform +
 triangle records + BVH refit; ffx_scene_update).
 """
+import ctypes as C
 from typing import List
 
 import torch
@@ -28,6 +29,114 @@ def _seed_generators(seed: int) -> None:
             g.manual_seed(seed)
     elif torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)  # queued until the device is initialised, as torch.manual_seed would
+
+
+class _NativePlan:
+    """the compiled form of one sampler configuration for ffx_scene_randomize_h (Scene._native_plan)"""
+
+    @staticmethod
+    def build(scene):
+        from . import _abi
+        from ._lib import api
+
+        ents = list(scene._draw_order())
+        row_of = {id(e): i for i, e in enumerate(ents)}
+        draws, samplers, rows, posed, attrs = [], [], [], [], []
+        dev = None
+
+        def add(smp):
+            nonlocal dev
+            if type(smp) not in (sampling.UniformSampler, sampling.UniformScalarToVec3Sampler) or not smp._train:
+                return None
+            a = smp._min_range
+            if not a.is_cuda or a.numel() < 1 or a.numel() > 4 or a.size() != smp._max_range.size() or smp._max_range.device != a.device:
+                return None
+            if dev is None:
+                dev = a.device
+            elif a.device != dev:
+                return None
+            lo, hi = smp._host_bounds()
+            d = _abi.RandDraw()
+            d.n = int(a.numel())
+            for j in range(d.n):
+                d.lo[j], d.hi[j] = float(lo[j]), float(hi[j])
+            draws.append(d)
+            samplers.append(smp)
+            return len(draws) - 1
+
+        for i, e in enumerate(ents):
+            cls = type(e)
+            if cls not in (entity.Transformable, entity.Mesh, emitter.Light, material.Material):
+                return None  # a user subclass may override _draw / _compose
+            kind = 0 if cls is material.Material else (2 if cls is entity.Mesh else 1)
+            r = _abi.RandEntity()
+            r.kind, r.parent, r.draw_t, r.draw_r, r.draw_s = kind, -1, -1, -1, -1
+            par = e.parent()
+            if par is not None:
+                if id(par) not in row_of or row_of[id(par)] >= i:
+                    return None
+                r.parent = row_of[id(par)]
+            c = e._centroid_mat
+            r.centroid[0], r.centroid[1], r.centroid[2] = float(c[0, 3]), float(c[1, 3]), float(c[2, 3])
+            src = e._world
+            # (a Material draws its attributes whether it is marked randomisable or not — material.Material._draw has no such test,
+            # the draws are part of the stream — and Scene.update_materials then writes them back only if it is)
+            if e.randomizable() or kind == 0:
+                if kind != 0:
+                    dt, dr = add(e._translation_sampler), add(e._rotation_sampler)
+                    if dt is None or dr is None:
+                        return None
+                    r.draw_t, r.draw_r = dt, dr
+                    if kind == 2:
+                        ds = add(e._scale_sampler)
+                        if ds is None:
+                            return None
+                        r.draw_s = ds
+                    posed.append((i, e, dt, dr))
+                if kind != 2:  # (a Mesh does not sample its attributes: mesh.py:141-150)
+                    fl, v3 = [], []
+                    for key, smp in e._float_attributes.items():
+                        d = add(smp)
+                        if d is None or draws[d].n != 1:
+                            return None
+                        fl.append((key, d))
+                    for key, smp in e._vec3_attributes.items():
+                        d = add(smp)
+                        if d is None:
+                            return None
+                        rep = 3 if type(smp) is sampling.UniformScalarToVec3Sampler else 1
+                        if (rep == 1 and draws[d].n != 3) or (rep == 3 and draws[d].n != 1):
+                            return None
+                        v3.append((key, d, rep))
+                    attrs.append((e, fl, v3))
+            else:
+                src = e._randomized_world  # (its local matrix as it stands: what _world_host() multiplies)
+            w = src.detach().to("cpu", torch.float32).reshape(-1).tolist()
+            for j in range(16):
+                r.world[j] = w[j]
+            rows.append(r)
+        if dev is None:
+            return None  # nothing is drawn from the device generator: the Python path has nothing to win or lose
+        plan = _NativePlan()
+        plan.n_draws, plan.n_ents = len(draws), len(rows)
+        plan.draws = (_abi.RandDraw * max(len(draws), 1))(*draws)
+        plan.ents = (_abi.RandEntity * max(len(rows), 1))(*rows)
+        plan.posed, plan.attrs, plan.samplers = posed, attrs, samplers
+        plan.mesh_rows = [row_of[id(m)] for m in scene._meshes]
+        plan.gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        plan.seed1, plan.off1 = (C.c_uint64 * 1)(), (C.c_uint64 * 1)()
+        fn = api().lib.ffx_scene_randomize_h
+        plan.fn = fn
+        plan.version_key = plan.versions()
+        return plan
+
+    def versions(self):
+        """in-place writes into a sampler's bound tensors (through a tensor get_min() / get_max() handed out earlier) do not move the
+        configuration counter: the tensors' own version counters do"""
+        t = 0
+        for s_ in self.samplers:
+            t += s_._min_range._version + s_._max_range._version
+        return t
 
 
 class StaleDrawError(RuntimeError):
@@ -409,7 +518,109 @@ class Scene:
             c = self._hd = (sbase.mutation_count(), ok)
         return c[1]
 
+    # ---- f1: the whole randomisation as ONE native call (include/ffx.h ffx_scene_randomize_h).
+    # When every draw of a randomisation is a plain uniform draw from the device generator's stream (_host_drawable) and every entity
+    # is one of the library's own classes, the order of the draws, their bounds and the way each entity's matrices follow from them
+    # are fixed by the configuration: they are compiled once into two small tables (ffx_rand_draw / ffx_rand_entity), and a
+    # randomisation is then a single host call that evaluates the Philox stream, the interval maps, the 4x4 algebra and the parent
+    # chains for all the scene samples of a step — the Python per draw and per entity (0.17 ms per randomisation) is gone.  Anything
+    # else — user samplers, Gaussian draws, eval mode, samplers on the CPU generator, subclasses that override _draw / _compose —
+    # keeps the Python path below (per scene; FFX_NATIVE_RANDOMIZE=0 forces it).  Same values bit for bit: the native arithmetic is
+    # the mirror's (tests/test_api_cpu.py), animation picks stay Python `random` draws made after the entity draws, as before.
+    def _native_plan(self):
+        import os
+
+        from .sampling import base as sbase
+
+        c = getattr(self, "_nplan", None)
+        if c is not None and c[0] == sbase.mutation_count():
+            plan = c[1]
+            if plan is None or plan.versions() == plan.version_key:
+                return plan
+        plan = None
+        if os.environ.get("FFX_NATIVE_RANDOMIZE", "1") != "0" and self._host_drawable():
+            plan = _NativePlan.build(self)
+        self._nplan = (sbase.mutation_count(), plan)
+        return plan
+
+    def _randomize_native(self, plan, seeds=None):
+        """seeds None: one sample from the generator as it stands (advanced by the draws); a list: one sample per seed, each from offset 0
+        of its seed (what `torch.manual_seed(s); randomize()` draws) — the generator is left seeded with the last one, advanced past its draws"""
+        import numpy as np
+
+        gen = plan.gen
+        S = 1 if seeds is None else len(seeds)
+        nd, ne = plan.n_draws, plan.n_ents
+        if seeds is None:
+            off = gen.get_offset()
+            if off & 3:
+                return None
+            sa, oa = plan.seed1, plan.off1
+            sa[0], oa[0] = gen.initial_seed(), off
+        else:
+            sa, oa = (C.c_uint64 * S)(*[int(s_) for s_ in seeds]), (C.c_uint64 * S)()
+        vals = np.empty((S, nd, 4), np.float32)
+        mats = np.empty((3, S, ne, 16), np.float32)  # local, chain, chain x un-centring
+        rc = plan.fn(S, sa, oa, plan.draws, nd, plan.ents, ne, vals.ctypes.data, mats[0].ctypes.data, mats[1].ctypes.data, mats[2].ctypes.data)
+        if rc != 0:
+            return None
+        if seeds is None:
+            gen.set_offset(off + 4 * nd)
+        return vals, mats
+
+    def _apply_native(self, plan, vals, mats, k, picks) -> None:
+        """phase 2 + push for sample k of a native call: entity state from the tables, parameter writes, ONE device pass"""
+        v = vals[k].tolist()
+        loc = mats[0][k]
+        for i, e, dt, dr in plan.posed:
+            e._randomized_world = torch.from_numpy(loc[i].reshape(4, 4))
+            e._last_draw = (v[dt][:3], v[dr][:3])
+        for e, fl, v3 in plan.attrs:
+            e._host_float_attributes = {key: v[d][0] for key, d in fl}
+            e._host_vec3_attributes = {key: (v[d][:3] if rep == 1 else [v[d][0]] * 3) for key, d, rep in v3}
+            e._randomized_float_attributes = e._randomized_vec3_attributes = None
+        p = self._mitsuba_params
+        if hasattr(p, "set_mesh_pose_np"):  # our parameter object: poses straight from the tables
+            chain, unc = mats[1][k], mats[2][k]
+            for m, pick, i in zip(self._meshes, picks, plan.mesh_rows):
+                if not m.randomizable():
+                    continue
+                if pick is None:
+                    p.set_mesh_pose_np(m.name(), unc[i], 0, None)
+                elif pick[0] == "func":
+                    p.set_mesh_pose_np(m.name(), chain[i], None, m._animation_func(m._vertices, pick[2]))
+                else:
+                    pool = getattr(m, "_pool_frames", None)
+                    if pool is not None:
+                        p.set_mesh_pose_np(m.name(), unc[i], pool[pick[1]][0] + pick[2], None)
+                    else:
+                        stack = m._anim_data_train if pick[1] == "train" else m._anim_data_eval
+                        p.set_mesh_pose_np(m.name(), chain[i], None, stack[pick[2]])
+        else:
+            for m, pick in zip(self._meshes, picks):
+                m._pending_pick = pick
+            try:
+                self.update_meshes()
+            finally:
+                for m in self._meshes:
+                    del m._pending_pick
+        if self._camera is not None:
+            self.update_camera()
+        if self._projector is not None:
+            self.update_projector()
+        self.update_lights()
+        self.update_materials()
+        p.update()
+
     def randomize(self) -> None:
+        plan = self._native_plan()
+        if plan is not None:
+            out = self._randomize_native(plan)
+            if out is not None:
+                self._pre = None
+                picks = [m.sample_animation_index() if m.randomizable() else None for m in self._meshes]
+                self._apply_native(plan, out[0], out[1], 0, picks)
+                return
         if self._host_drawable():
             # f1: no device work at all for the draws — values from the generator's Philox stream on the host,
             # 4x4 algebra on the host, matrices as kernel arguments of the one refit pass
@@ -448,6 +659,33 @@ class Scene:
 
         from .sampling import base as sbase
 
+        plan = self._native_plan()
+        if plan is not None and len(seeds) > 0:
+            # one native call for the draws and matrices of all the samples; per sample the animation picks under its own `random` seed
+            keep = None
+            if lazy:
+                keep = (torch.cuda.get_rng_state(torch.device(self._device)), torch.get_rng_state(), _random.getstate())
+            out = self._randomize_native(plan, [int(s_) for s_ in seeds])
+            if out is not None:
+                all_picks = []
+                for seed in seeds:
+                    _random.seed(int(seed))
+                    all_picks.append([m.sample_animation_index() if m.randomizable() else None for m in self._meshes])
+                # the generators as `manual_seed(last); randomize()` leaves them
+                _seed_generators(int(seeds[-1]))
+                plan.gen.set_offset(4 * plan.n_draws)
+                config = sbase.mutation_count()
+                if keep is not None:
+                    torch.cuda.set_rng_state(keep[0], torch.device(self._device))
+                    torch.set_rng_state(keep[1])
+                    _random.setstate(keep[2])
+
+                def native_appliers():
+                    if sbase.mutation_count() != config:
+                        raise StaleDrawError("the sampler configuration changed after these scene samples were drawn")
+                    return [(lambda k=k: self._apply_native(plan, out[0], out[1], k, all_picks[k])) for k in range(len(seeds))]
+
+                return native_appliers if lazy else native_appliers()
         side = None if self._host_drawable() else self._draw_stream()  # host-evaluated draws: no device work to order
         keep = None
         if lazy:

@@ -266,6 +266,38 @@ int ffx_torch_rand_h(uint64_t seed, uint64_t offset, int n, float *out /*[host][
 int ffx_torch_rand_batch_h(int k, const uint64_t *seeds /*[host][k]*/, const uint64_t *offsets /*[host][k]*/,
                            const int32_t *counts /*[host][k]*/, float *out /*[host][sum counts]*/);
 
+/* The whole of Scene.randomize() on the host, for the S scene samples of a step, in ONE call (ABI 5).
+ * Replaces the Python of fireflies/scene.py:344-384 (randomize_list over meshes, lights, materials, camera, projector),
+ * Transformable.randomize (fireflies/entity/base.py:194-244: translation draw, rotation draw, attribute draws; world =
+ * (T + centroid) @ R @ world with R = Z @ Y @ X and the reference's swapped axis names) and Mesh.randomize (fireflies/entity/mesh.py:
+ * 141-165: translation, rotation, scale; (T + centroid) @ R @ S @ world), including the parent chains of Transformable.world()
+ * (entity/base.py:239-244) and the un-centring translation Scene.update_meshes applies to a posed mesh (fireflies/scene.py:243-251).
+ * `draws`: every sampler call of one randomisation in the reference's order — draw d is the torch.rand of draws[d].n <= 4 values at
+ * generator offset offsets[s] + 4 d under seeds[s] (ffx_torch_rand_h), mapped to lo + u * (hi - lo) in float32 (multiply, then add).
+ * `ents`: the entities in the same order (parents before children), each naming its draws.  Outputs per sample: the drawn values
+ * (4 per draw, unused ones 0), each entity's randomised local matrix, its world matrix through the parent chain, and that matrix
+ * times the translation by -centroid.  The float32 arithmetic is the reference's torch expressions' (an fma chain over k for the 3x3 /
+ * 4x4 products, as torch's and numpy's sgemm kernels compute them; angles through double cos / sin): bit-identical to the Python
+ * mirror, which the goldens g7 pin.  Samplers that are not plain uniform draws stay in Python (fireflies_amd/scene.py falls back). */
+typedef struct ffx_rand_draw {
+  int32_t n;          /* values of this torch.rand call: 1..4 */
+  float lo[4], hi[4]; /* the sampler's bounds */
+  int32_t pad[3];
+} ffx_rand_draw;
+typedef struct ffx_rand_entity {
+  int32_t kind;    /* 0: no transform of its own (a Material: attributes only), 1: Transformable, 2: Mesh (with a scale draw) */
+  int32_t parent;  /* row of the parent entity (< this row), -1: none */
+  int32_t draw_t, draw_r, draw_s; /* rows of its translation / rotation / scale draws; draw_t < 0: not randomised — `world` is taken as it stands */
+  int32_t pad[3];
+  float world[16]; /* the entity's base world matrix (row-major); for an entity that is not randomised: its current local matrix */
+  float centroid[3];
+  float pad2;
+} ffx_rand_entity;
+int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds /*[host][n_samples]*/, const uint64_t *offsets /*[host][n_samples]*/,
+                          const ffx_rand_draw *draws /*[host][n_draws]*/, int n_draws, const ffx_rand_entity *ents /*[host][n_ents]*/, int n_ents,
+                          float *values /*[host][n_samples, n_draws, 4]*/, float *local /*[host][n_samples, n_ents, 16]*/,
+                          float *chain /*[host][n_samples, n_ents, 16]*/, float *chain_uncentred /*[host][n_samples, n_ents, 16]*/);
+
 /* ------------------------------------------------------------------------------------------
  * K3  texture finalise: separable Gaussian blur, reflect border.
  * Replaces kornia.filters.gaussian_blur2d(tex, (k,k), (s,s)) at

@@ -534,6 +534,88 @@ int ffx_torch_rand_batch_h(int k, const uint64_t *seeds, const uint64_t *offsets
   return FFX_OK;
 }
 
+/* Scene.randomize() restated (include/ffx.h ffx_scene_randomize_h): the reference's statements, one after the other, on plain arrays.
+ *   fireflies/entity/base.py:220-234  Transformable.randomize: translation draw, rotation draw, (T + centroid) @ R @ world
+ *   fireflies/entity/base.py:194-207  sample_rotation: Z @ Y @ X with "z" -> getPitchTransform (about Y), "y" -> getYawTransform (about Z)
+ *   fireflies/utils/math.py:24-60     the three Euler matrices
+ *   fireflies/entity/mesh.py:141-150  Mesh.randomize: the scale draw and (T + centroid) @ R @ S @ world
+ *   fireflies/entity/base.py:239-244  world(): parent.world() @ randomized world
+ *   fireflies/utils/math.py:170-175   randomBetweenTensors: a + rand * (b - a)  [evaluated as rand * (b - a) + a by the mirror: the same
+ *                                     two roundings]
+ * torch.matmul on float32 4x4 / 3x3 operands rounds like an fma chain over the inner index (sgemm micro-kernels): matmul_f32 below. */
+static void matmul_f32(const float *A, const float *B, float *out, int n) {
+  float tmp[16];
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) {
+      float acc = A[n * r] * B[c];
+      for (int k = 1; k < n; ++k) acc = fmaf(A[n * r + k], B[n * k + c], acc);
+      tmp[n * r + c] = acc;
+    }
+  memcpy(out, tmp, sizeof(float) * (size_t)(n * n));
+}
+static void embed3(const float *m3, float *m4) {
+  memset(m4, 0, 16 * sizeof(float));
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) m4[4 * r + c] = m3[3 * r + c];
+  m4[15] = 1.0f;
+}
+int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const uint64_t *offsets, const ffx_rand_draw *draws, int n_draws,
+                          const ffx_rand_entity *ents, int n_ents, float *values, float *local, float *chain, float *chain_uncentred) {
+  if (n_samples < 0 || n_draws < 0 || n_ents < 0 || (n_samples > 0 && (!seeds || !offsets)) || (n_draws > 0 && (!draws || !values)) ||
+      (n_ents > 0 && (!ents || !local || !chain || !chain_uncentred)))
+    FAIL(FFX_ERR_ARG, "scene_randomize_h: bad argument");
+  for (int d = 0; d < n_draws; ++d)
+    if (draws[d].n < 1 || draws[d].n > 4) FAIL(FFX_ERR_UNSUPPORTED, "scene_randomize_h: draw %d has %d values", d, draws[d].n);
+  for (int e = 0; e < n_ents; ++e)
+    if (ents[e].parent >= e || ents[e].kind < 0 || ents[e].kind > 2 || ents[e].draw_t >= n_draws || ents[e].draw_r >= n_draws || ents[e].draw_s >= n_draws)
+      FAIL(FFX_ERR_ARG, "scene_randomize_h: entity %d: bad parent / draw row", e);
+  for (int s = 0; s < n_samples; ++s) {
+    float *val = values + (size_t)s * (size_t)n_draws * 4;
+    for (int d = 0; d < n_draws; ++d) { /* the draws, in program order: each torch.rand launch advances the generator by 4 */
+      float u[4] = {0.f, 0.f, 0.f, 0.f};
+      uint64_t inc;
+      int rc = ffx_torch_rand_h(seeds[s], offsets[s] + (uint64_t)4 * (uint64_t)d, draws[d].n, u, &inc);
+      if (rc != FFX_OK) return rc;
+      for (int i = 0; i < 4; ++i) val[4 * d + i] = i < draws[d].n ? u[i] * (draws[d].hi[i] - draws[d].lo[i]) + draws[d].lo[i] : 0.f;
+    }
+    for (int e = 0; e < n_ents; ++e) {
+      const ffx_rand_entity *q = &ents[e];
+      float *L = local + ((size_t)s * (size_t)n_ents + (size_t)e) * 16;
+      float *W = chain + ((size_t)s * (size_t)n_ents + (size_t)e) * 16;
+      float *U = chain_uncentred + ((size_t)s * (size_t)n_ents + (size_t)e) * 16;
+      if (q->kind == 0 || q->draw_t < 0 || q->draw_r < 0) {
+        memcpy(L, q->world, 16 * sizeof(float));
+      } else {
+        const float *t = val + 4 * q->draw_t, *r = val + 4 * q->draw_r;
+        const double az = (double)r[2], ay = (double)r[1], ax = (double)r[0];
+        const float pitch[9] = {(float)cos(az), 0.f, (float)sin(az), 0.f, 1.f, 0.f, -(float)sin(az), 0.f, (float)cos(az)}; /* getPitchTransform: about Y */
+        const float yaw[9] = {(float)cos(ay), -(float)sin(ay), 0.f, (float)sin(ay), (float)cos(ay), 0.f, 0.f, 0.f, 1.f};   /* getYawTransform: about Z */
+        const float roll[9] = {1.f, 0.f, 0.f, 0.f, (float)cos(ax), -(float)sin(ax), 0.f, (float)sin(ax), (float)cos(ax)};  /* getRollTransform: about X */
+        float r3[9], R[16], M[16];
+        matmul_f32(pitch, yaw, r3, 3);
+        matmul_f32(r3, roll, r3, 3);
+        embed3(r3, R);
+        float TC[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+        for (int i = 0; i < 3; ++i) TC[4 * i + 3] = t[i] + q->centroid[i]; /* translation matrix + centroid matrix, element by element */
+        matmul_f32(TC, R, M, 4);
+        if (q->kind == 2 && q->draw_s >= 0) {
+          const float *sc = val + 4 * q->draw_s;
+          float S[16] = {0};
+          S[0] = sc[0]; S[5] = sc[1]; S[10] = sc[2]; S[15] = 1.f;
+          matmul_f32(M, S, M, 4);
+        }
+        matmul_f32(M, q->world, L, 4);
+      }
+      if (q->parent >= 0) matmul_f32(chain + ((size_t)s * (size_t)n_ents + (size_t)q->parent) * 16, L, W, 4);
+      else memcpy(W, L, 16 * sizeof(float));
+      float Un[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+      for (int i = 0; i < 3; ++i) Un[4 * i + 3] = -q->centroid[i];
+      matmul_f32(W, Un, U, 4);
+    }
+  }
+  return FFX_OK;
+}
+
 /* =========================================================================================
  * K3  gaussian_blur2d with reflect border [EXT kornia 0.7.1, call site
  * examples/vocalfold_scene.py:61-63].  Kernel: g[k] = exp(-(k - r)^2 / (2 s^2)), normalised

@@ -474,3 +474,115 @@ def test_noise_texture_sampler_matches_the_reference():
 
     with pytest.raises(ValueError):  # fewer texels than lattice cells (the reference fails with a shape error deep inside)
         perlin_2d((16, 16), (32, 32))
+
+
+def test_native_scene_randomiser_is_the_python_mirror_bit_for_bit(oracle):
+    """f1 (include/ffx.h ffx_scene_randomize_h): the draws, interval maps, 4x4 algebra and parent chains of a whole randomisation in one
+    host call.  Product library and oracle restatement against the Python mirror's own arithmetic (entity.Transformable / Mesh: numpy
+    float32 products, math.cos / sin) on random configurations — bit for bit, which is what lets Scene.randomize() switch between the
+    native call and the Python path without changing a seeded run; and numpy's 4x4 float32 product is the fma chain both restate."""
+    import ctypes as C
+
+    from fireflies_amd import _abi, _lib
+    from fireflies_amd.entity import Mesh, Transformable
+
+    rng = np.random.default_rng(5)
+    for _ in range(50):  # the premise: numpy (and torch) float32 matmul of these sizes = an fma chain over k
+        A, B = rng.standard_normal((4, 4)).astype(np.float32), rng.standard_normal((4, 4)).astype(np.float32)
+        ref = np.zeros((4, 4), np.float32)
+        for i in range(4):
+            for j in range(4):
+                acc = np.float32(A[i, 0] * B[0, j])
+                for k in range(1, 4):
+                    acc = np.float32(np.float64(A[i, k]) * np.float64(B[k, j]) + np.float64(acc))
+                ref[i, j] = acc
+        np.testing.assert_array_equal(A @ B, ref)
+        np.testing.assert_array_equal((torch.from_numpy(A) @ torch.from_numpy(B)).numpy(), ref)
+    libs = {"hip": _lib.api().lib, "oracle": oracle.api().lib}
+    for trial in range(20):
+        n_ents = int(rng.integers(1, 6))
+        draws, ents, spec = [], [], []
+        for e in range(n_ents):
+            kind = int(rng.integers(0, 3))
+            r = _abi.RandEntity()
+            r.kind, r.parent, r.draw_t, r.draw_r, r.draw_s = kind, (int(rng.integers(-1, e)) if e > 0 else -1), -1, -1, -1
+            world = rng.standard_normal((4, 4)).astype(np.float32)
+            world[3] = (0, 0, 0, 1)
+            cen = rng.standard_normal(3).astype(np.float32)
+            for j in range(16):
+                r.world[j] = float(world.reshape(-1)[j])
+            for j in range(3):
+                r.centroid[j] = float(cen[j])
+            randomised = kind != 0 and rng.random() < 0.8
+
+            def add(n):
+                d = _abi.RandDraw()
+                d.n = n
+                lo = rng.uniform(-2, 1, n).astype(np.float32)
+                hi = (lo + rng.uniform(0, 2, n)).astype(np.float32)
+                for j in range(n):
+                    d.lo[j], d.hi[j] = float(lo[j]), float(hi[j])
+                draws.append((d, lo, hi))
+                return len(draws) - 1
+
+            if randomised:
+                r.draw_t, r.draw_r = add(3), add(3)
+                if kind == 2:
+                    r.draw_s = add(3)
+            for _k in range(int(rng.integers(0, 3))):
+                add(int(rng.integers(1, 5)))  # attribute draws in between
+            ents.append(r)
+            spec.append((kind, r.parent, r.draw_t, r.draw_r, r.draw_s, world, cen))
+        nd, S = len(draws), 3
+        seeds = (C.c_uint64 * S)(*[int(v) for v in rng.integers(0, 2**40, S)])
+        offs = (C.c_uint64 * S)(*[4 * int(v) for v in rng.integers(0, 1000, S)])
+        darr = (_abi.RandDraw * max(nd, 1))(*[d for d, _, _ in draws])
+        earr = (_abi.RandEntity * n_ents)(*ents)
+        outs = {}
+        for name, lib in libs.items():
+            vals = np.full((S, max(nd, 1), 4), np.nan, np.float32)
+            mats = np.full((3, S, n_ents, 16), np.nan, np.float32)
+            fn = lib.ffx_scene_randomize_h
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(_abi.RandDraw), C.c_int, C.POINTER(_abi.RandEntity), C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            assert fn(S, seeds, offs, darr, nd, earr, n_ents, vals.ctypes.data, mats[0].ctypes.data, mats[1].ctypes.data, mats[2].ctypes.data) == 0
+            outs[name] = (vals, mats)
+        np.testing.assert_array_equal(outs["hip"][0], outs["oracle"][0])
+        np.testing.assert_array_equal(outs["hip"][1], outs["oracle"][1])
+        vals, mats = outs["hip"]
+        rand = libs["hip"].ffx_torch_rand_h
+        rand.restype = C.c_int
+        rand.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        for s in range(S):
+            want_vals = []
+            for d, (dr, lo, hi) in enumerate(draws):
+                buf, inc = (C.c_float * 4)(), C.c_uint64()
+                assert rand(seeds[s], offs[s] + 4 * d, dr.n, buf, C.byref(inc)) == 0
+                u = np.asarray(buf[: dr.n], np.float32)
+                v = u * (hi - lo) + lo  # (DrawBatch._values: float32, one rounding per operation)
+                want_vals.append(v)
+                np.testing.assert_array_equal(vals[s, d, : dr.n], v)
+            chain = []
+            for e, (kind, parent, dt, dr_, ds, world, cen) in enumerate(spec):
+                if kind == 0 or dt < 0:
+                    local = world
+                else:
+                    t = Transformable._translation_matrix(*[float(x) for x in want_vals[dt]]).numpy()
+                    cm = np.zeros((4, 4), np.float32)
+                    cm[:3, 3] = cen
+                    rot = Transformable._rotation_matrix(*[float(x) for x in want_vals[dr_]]).numpy()
+                    if kind == 2:
+                        sc = np.zeros((4, 4), np.float32)
+                        sc[0, 0], sc[1, 1], sc[2, 2], sc[3, 3] = *[float(x) for x in want_vals[ds]], 1.0
+                        local = (((t + cm) @ rot) @ sc) @ world  # entity/mesh.py Mesh._compose
+                    else:
+                        local = ((t + cm) @ rot) @ world  # entity/base.py Transformable._compose
+                w = local if parent < 0 else chain[parent] @ local
+                chain.append(w)
+                unc = np.eye(4, dtype=np.float32)
+                unc[:3, 3] = -cen
+                np.testing.assert_array_equal(mats[0, s, e].reshape(4, 4), local)
+                np.testing.assert_array_equal(mats[1, s, e].reshape(4, 4), w)
+                np.testing.assert_array_equal(mats[2, s, e].reshape(4, 4), (torch.from_numpy(w) @ torch.from_numpy(unc)).numpy())  # Scene.update_meshes
+    assert Mesh is not None

@@ -96,6 +96,7 @@ def main():
         for base, kind in ((32, "closest (camera)"), (40, "any (emitters)")):
             w = max(st[base], 1)
             print(f"bins, {kind}: walks {st[base]}, chunk steps per walk {st[base + 1] / w:.2f}, exact tests {st[base + 2] / w:.2f}, second barycentric {st[base + 3] / w:.2f}")
+        print(f"any-hit candidates within reach (t-range pre-check passed): {st[46] / max(st[40], 1):.2f} per walk")
         print(f"fall-backs to the tree: primary {st[36]}, projector shadow {st[44]}, spot shadow {st[45]}")
         print(f"tree walks that ran: closest {st[0]} ({st[1] / max(st[0], 1):.2f} steps), any {st[4]} ({st[5] / max(st[4], 1):.2f} steps)")
 

@@ -14,6 +14,7 @@ with torch.no_grad():
     wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
 sc = wl.ff_scene
 acc = {}
+SPP = int(os.environ.get("FFX_HP_SPP", "64"))  # (a small value keeps the GPU ahead of the host: pure host time per step)
 
 
 def tick(name, t0):
@@ -46,7 +47,7 @@ def step(i):
     t = tick("update_cam/proj/lights/mats", t)
     sc._mitsuba_params.update()
     t = tick("params.update (refit launch)", t)
-    mi.render(wl.mi_scene, spp=64, seed=i)
+    mi.render(wl.mi_scene, spp=SPP, seed=i).torch()
     t = tick("mi.render (launch)", t)
 
 
@@ -66,3 +67,26 @@ torch.cuda.synchronize()
 for k, v in acc.items():
     print(f"{k:36s} {1e6 * v / N:7.1f} us")
 print(f"{'total host per step':36s} {1e6 * tot / N:7.1f} us")
+# the plain loop (no phase timers), and — FFX_HP_PROFILE=1 — where its time goes by function
+import random
+
+t00 = time.perf_counter()
+for i in range(N):
+    sc.randomize()
+    mi.render(wl.mi_scene, spp=SPP, seed=i).torch()
+tot = time.perf_counter() - t00
+torch.cuda.synchronize()
+print(f"{'ff_scene.randomize() + mi.render':36s} {1e6 * tot / N:7.1f} us per step (plain loop)")
+if os.environ.get("FFX_HP_PROFILE") == "1":
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(N):
+        sc.randomize()
+        mi.render(wl.mi_scene, spp=SPP, seed=i).torch()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
