@@ -185,6 +185,7 @@ PROTOTYPES = {
     "ffx_splat_lines_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
     "ffx_torch_rand_h": (c_i, [C.c_uint64, C.c_uint64, c_i, PF, C.POINTER(C.c_uint64)]),
     "ffx_torch_rand_batch_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), PF]),
+    "ffx_mat4_mul_h": (c_i, [c_p, c_p, c_p]),
     "ffx_scene_randomize_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(RandDraw), c_i, C.POINTER(RandEntity), c_i, c_p, c_p, c_p, c_p]),
     "ffx_blur_fwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),

@@ -8,10 +8,10 @@
 // packet's screen rectangle — lanes on the entries — and runs the exact ray / triangle test on the survivors: what were 4.2 + 3.9
 // dependent steps through the 64-wide tree per pixel (closest-hit + any-hit walk) is one coalesced load and ~1.3 steps.
 //
-// Two launches on the stream of the re-fit (normally the side stream, off the renders' critical path):
+// Three launches on the stream of the re-fit (normally the side stream, off the renders' critical path):
 //   k_bin<false>  a lane per triangle and apex: writes the triangle's APEX RECORD (ffx_common.h TriApex — what k_apex_records did as a
-//                 launch of its own), projects, classifies and counts the tiles it touches (one atomic per tile into `cursors`);
-//                 the workgroup that finishes last scans the counts of all three grids into list starts (overflow check included)
+//                 launch of its own), projects, classifies and counts the tiles it touches (one atomic per tile into `cursors`)
+//   k_bin_scan    a workgroup per grid: the counts into list starts (through LDS), overflow check against the capacity
 //   k_bin<true>   the same walk again, writing the 64-byte entries at start[tile] + --cursor[tile]: the cursors count back down to
 //                 zero, which is what the next pose's counting pass needs to find (no clearing launch)
 // Triangles that touch up to sixteen tiles loop over them per lane; larger ones (faces next to the apex) and triangles the projection
@@ -197,12 +197,66 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
       cls = (oL || oR || oT || oB) ? 0 : 3;
     }
   }
-  if (cls == 1) {
+#ifdef FFX_BINPROBE // timing experiments (tools/binprobe.py): 1 = no wave-cooperative path, 2 = no per-lane path, 3 = neither
+  if (FFX_BINPROBE & 2) { if (cls == 1) cls = 0; }
+  if (FFX_BINPROBE & 1) { if (cls >= 2) cls = 0; }
+#endif
+  {
+    // ---- triangles that touch at most sixteen tiles, a lane each.  Which tiles: a bit mask over the lane's own window (no atomics
+    // yet).  Then the wave walks its lanes' masks in rounds, every lane offering its next tile, and lanes that offer the SAME tile —
+    // neighbouring leaf slots are neighbouring triangles: usually a dozen of them — are served by ONE atomic of their first lane:
+    // a tile of the far wall receives 400 entries, and 400 same-address atomics from eight XCDs were the tail of both launches
+    // (they serialise at the memory side, ~90 ns each).  Four rounds are in flight at a time: a fill-pass atomic returns the group's
+    // place in the list, and one dependent round trip per round was the rest of that tail.
     BinEntry en;
-    bin_make_entry(x[0], y[0], x[1], y[1], x[2], y[2], k, false, en);
-    for (int ty = ty0; ty <= ty1; ++ty)
-      for (int tx = tx0; tx <= tx1; ++tx)
-        if (bin_entry_touches(en, (float)tx, (float)ty, (float)(tx + 1), (float)(ty + 1))) emit(ty * nx + tx, en);
+    uint32_t touched = 0u;
+    const int w = tx1 - tx0 + 1;
+    if (cls == 1) {
+      bin_make_entry(x[0], y[0], x[1], y[1], x[2], y[2], k, false, en);
+      const int nt_ = w * (ty1 - ty0 + 1);
+#pragma nounroll
+      for (int t = 0; t < nt_; ++t) {
+        const int ty = ty0 + t / w, tx = tx0 + t % w;
+        if (bin_entry_touches(en, (float)tx, (float)ty, (float)(tx + 1), (float)(ty + 1))) touched |= 1u << t;
+      }
+    }
+    const wmask_t below = (1ull << lane) - 1ull;
+#pragma nounroll
+    while (__ballot(touched != 0u) != 0ull) {
+      int tl[4], leader[4], rank[4], cnt[4];
+      uint32_t at[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        tl[q] = -1; leader[q] = lane; rank[q] = 0; cnt[q] = 0; at[q] = 0u;
+        if (touched != 0u) {
+          const int t = __builtin_ctz(touched);
+          touched &= touched - 1u;
+          tl[q] = (ty0 + t / w) * nx + tx0 + t % w;
+        }
+        wmask_t pend = __ballot(tl[q] >= 0);
+#pragma nounroll
+        while (pend != 0ull) { // group the lanes of this round by tile
+          const int ld = __builtin_ctzll(pend);
+          const int lt = __builtin_amdgcn_readlane(tl[q], ld);
+          const wmask_t same = __ballot(tl[q] == lt);
+          if (tl[q] == lt) { leader[q] = ld; rank[q] = __builtin_popcountll(same & below); cnt[q] = __builtin_popcountll(same); }
+          pend &= ~same;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tl[q] >= 0 && leader[q] == lane) {
+          if (!FILL) atomicAdd(&cursors[tl[q]], (uint32_t)cnt[q]);
+          else at[q] = atomicSub(&cursors[tl[q]], (uint32_t)cnt[q]) - (uint32_t)cnt[q];
+        }
+      if (FILL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t base_ = (uint32_t)__shfl((int)at[q], leader[q], 64);
+          if (tl[q] >= 0) ents[starts[tl[q]] + base_ + (uint32_t)rank[q]] = en;
+        }
+      }
+    }
   }
   // ---- the whole wave on one triangle at a time: lanes on tiles
   wmask_t big = __ballot(cls >= 2);
@@ -255,25 +309,15 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
       }
     }
   }
-  if (!FILL) {
-    // ---- publish; the workgroup that arrives last turns the counts of all three grids into list starts (the refit kernel's pattern:
-    // agent-scope fence + one atomic; the counter is left at zero for the next pose)
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t t = atomicAdd(bb.arrive, 1u);
-      s_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
-      if (s_last) atomicExch(bb.arrive, 0u);
-    }
-    __syncthreads();
-    if (s_last) {
-      __threadfence();
-      extern __shared__ uint32_t s_dyn_cnt[];
-      for (int g = 0; g < FFX_N_APEX; ++g)
-        if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, s_dyn_cnt);
-    }
-  }
+}
+
+// a workgroup per grid: its counts into list starts.  (A launch of its own: folded into the counting launch as the job of the workgroup
+// that finishes last, it needed an agent-scope release fence in EVERY workgroup — which on this part writes back the whole L2, 7.7 MB of
+// fresh apex records included: the counting launch took 65 us instead of 10.)
+__global__ void __launch_bounds__(256) k_bin_scan(BinBuild bb) {
+  extern __shared__ uint32_t s_dyn_cnt[];
+  const int g = blockIdx.x;
+  if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, s_dyn_cnt);
 }
 
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
@@ -286,6 +330,9 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
   int max_nt = 0; // dynamic LDS of the counting launch: the largest grid's counts (the scan of the workgroup that finishes last)
   for (int a = 0; a < FFX_N_APEX; ++a)
     if (bb.g[a].on && bb.g[a].nx * bb.g[a].ny > max_nt) max_nt = bb.g[a].nx * bb.g[a].ny;
-  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), (size_t)4 * (max_nt + 1), s, recs, n_tris, bb, ba);
-  if (bb.g[0].on || bb.g[1].on || bb.g[2].on) hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
+  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
+  if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
+    hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(256), (size_t)4 * (max_nt + 1), s, bb);
+    hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
+  }
 }

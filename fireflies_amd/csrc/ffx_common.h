@@ -166,7 +166,7 @@ struct BinsK {
   BinGrid g[3];
   float cam_inv_ts_x, cam_inv_ts_y; // camera pixels -> tile units
 };
-// the pre-pass of a packet render on `s` (ffx_bins.hip): apex records + the bins of the enabled grids — two launches (count + scan,
+// the pre-pass of a packet render on `s` (ffx_bins.hip): apex records + the bins of the enabled grids — three launches (count, scan,
 // fill); with every grid off it is the apex records alone (one launch)
 struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad[0] of apex 0 */ };
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,

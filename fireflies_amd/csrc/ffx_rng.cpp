@@ -76,7 +76,7 @@ extern "C" int ffx_torch_rand_batch_h(int k, const uint64_t *seeds, const uint64
 // kernels compute for these sizes — checked by tests/test_api_cpu.py against numpy on random matrices); Euler angles through the
 // C library's double cos / sin like Python's math module.  So the two paths agree bit for bit and the goldens pin both.
 namespace {
-inline void mm4(const float *A, const float *B, float *C) {
+inline void mm4(const float *A, const float *B, float *C) { // (through a temporary: C may alias A or B)
   float t[16];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
@@ -86,17 +86,16 @@ inline void mm4(const float *A, const float *B, float *C) {
     }
   for (int i = 0; i < 16; ++i) C[i] = t[i];
 }
-inline void mm3(const float *A, const float *B, float *C) {
-  float t[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      float acc = A[3 * i] * B[j];
-      for (int k = 1; k < 3; ++k) acc = fmaf(A[3 * i + k], B[3 * k + j], acc);
-      t[3 * i + j] = acc;
-    }
-  for (int i = 0; i < 9; ++i) C[i] = t[i];
-}
 } // namespace
+
+// out = a @ b for row-major 4x4 float32 matrices as an fma chain over k.  The Python mirror of the entity classes forms every matrix
+// product through this call, so that it and ffx_scene_randomize_h agree bit for bit on any host (numpy's / torch's own sgemm kernels
+// round a 4x4 product differently from CPU to CPU: OpenBLAS picks its kernel per micro-architecture).  out may alias a or b.
+extern "C" int ffx_mat4_mul_h(const float *a, const float *b, float *out) {
+  if (!a || !b || !out) FFX_FAIL(FFX_ERR_ARG, "mat4_mul_h: bad argument");
+  mm4(a, b, out);
+  return FFX_OK;
+}
 
 extern "C" int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const uint64_t *offsets, const ffx_rand_draw *draws, int n_draws,
                                      const ffx_rand_entity *ents, int n_ents, float *values, float *local, float *chain, float *chain_unc) {
@@ -140,13 +139,13 @@ extern "C" int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const
         const float cz = (float)cos((double)r[2]), sz = (float)sin((double)r[2]);
         const float cy = (float)cos((double)r[1]), sy = (float)sin((double)r[1]);
         const float cx = (float)cos((double)r[0]), sx = (float)sin((double)r[0]);
-        const float zM[9] = {cz, 0.f, sz, 0.f, 1.f, 0.f, -sz, 0.f, cz};
-        const float yM[9] = {cy, -sy, 0.f, sy, cy, 0.f, 0.f, 0.f, 1.f};
-        const float xM[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
-        float zy[9], R3[9];
-        mm3(zM, yM, zy);
-        mm3(zy, xM, R3);
-        const float R[16] = {R3[0], R3[1], R3[2], 0.f, R3[3], R3[4], R3[5], 0.f, R3[6], R3[7], R3[8], 0.f, 0.f, 0.f, 0.f, 1.f};
+        // (as 4x4 matrices with a zero border, like the mirror's: one product routine for everything, identical zero signs)
+        const float zM[16] = {cz, 0.f, sz, 0.f, 0.f, 1.f, 0.f, 0.f, -sz, 0.f, cz, 0.f, 0.f, 0.f, 0.f, 1.f};
+        const float yM[16] = {cy, -sy, 0.f, 0.f, sy, cy, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+        const float xM[16] = {1.f, 0.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, 0.f, sx, cx, 0.f, 0.f, 0.f, 0.f, 1.f};
+        float R[16];
+        mm4(zM, yM, R);
+        mm4(R, xM, R);
         // T + centroid matrix (identity + translation, plus a matrix that is zero but for the centroid in its last column)
         const float TC[16] = {1.f, 0.f, 0.f, t[0] + q.centroid[0], 0.f, 1.f, 0.f, t[1] + q.centroid[1], 0.f, 0.f, 1.f, t[2] + q.centroid[2], 0.f, 0.f, 0.f, 1.f};
         float M[16];

@@ -1099,6 +1099,11 @@ __device__ __forceinline__ wmask slab_oct(const float lo[3], const float hi[3], 
 // uniform bookkeeping is written to stay short: 32-bit byte offsets for node / record addressing, a
 // fast path for nodes whose children are both inner nodes (no leaf or empty-child logic at all), and
 // nested uniform branches instead of combined predicates.
+#ifdef FFX_BINCHECK
+// self-check build (-DFFX_BINCHECK): [0] binned primary walks whose result differs from the tree walk's (per wave), [1] first-record latch,
+// [2..4] the first one (pixel, lane; primitives; slots); [8..11] projector shadow walks; [16..19] spot shadow walks
+__device__ unsigned long long g_ffx_chk[24];
+#endif
 #ifdef FFX_STATS
 // debug build only (-DFFX_STATS): per-launch totals of packet walks / node steps / triangle tests
 __device__ unsigned long long g_ffx_stats[48]; // [32..47]: tile bins (closest-hit 32.., any-hit 40..: walks served, chunk steps, exact tests, second barycentric, fallbacks to the tree)
@@ -1991,6 +1996,21 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
     if constexpr (R == 1) FFX_STAT(36);
     traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
   }
+#ifdef FFX_BINCHECK // self-check build: every binned walk is repeated on the tree and compared lane by lane (tools/bincheck.py)
+  if constexpr (R == 1) {
+    if (binned) {
+      Hit h2[R];
+      traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h2, fnd);
+      const bool bad = active[0] && (h2[0].prim != h[0].prim || (h2[0].prim >= 0 && h2[0].t != h[0].t));
+      const wmask bm = wballot(bad);
+      if (bm != 0ull && (threadIdx.x & 63) == (unsigned)wff1(bm)) {
+        atomicAdd(&g_ffx_chk[0], 1ull);
+        if (atomicAdd(&g_ffx_chk[1], 1ull) == 0ull) { g_ffx_chk[2] = (unsigned long long)px | ((unsigned long long)py << 16) | ((unsigned long long)(threadIdx.x & 63) << 32); g_ffx_chk[3] = (unsigned long long)(uint32_t)h[0].prim | ((unsigned long long)(uint32_t)h2[0].prim << 32); g_ffx_chk[4] = (unsigned long long)(uint32_t)h[0].slot | ((unsigned long long)(uint32_t)h2[0].slot << 32); g_ffx_chk[5] = (unsigned long long)__float_as_uint(h[0].t) | ((unsigned long long)__float_as_uint(h2[0].t) << 32); }
+      }
+      h[0] = h2[0];
+    }
+  }
+#endif
   FFX_TSTOP(tp, 22);
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
@@ -2154,6 +2174,20 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       if constexpr (R == 1) FFX_STAT(44);
       traverse_packet_any<true, R, WIDE>(nodes, arecs_p, ws, stack, so, sdir, s0, s1, act, hs, occ_p);
     }
+#ifdef FFX_BINCHECK
+    if constexpr (R == 1) {
+      if (binned_p) {
+        bool occ2[R];
+        traverse_packet_any<true, R, WIDE>(nodes, arecs_p, ws, stack, so, sdir, s0, s1, act, hs, occ2);
+        const wmask bm = wballot(act[0] && occ2[0] != occ_p[0]);
+        if (bm != 0ull && (threadIdx.x & 63) == (unsigned)wff1(bm)) {
+          atomicAdd(&g_ffx_chk[8], 1ull);
+          if (atomicAdd(&g_ffx_chk[9], 1ull) == 0ull) { g_ffx_chk[10] = (unsigned long long)px | ((unsigned long long)py << 16) | ((unsigned long long)(threadIdx.x & 63) << 32) | ((unsigned long long)occ2[0] << 40); g_ffx_chk[11] = (unsigned long long)(uint32_t)hs[0].slot; }
+        }
+        occ_p[0] = occ2[0];
+      }
+    }
+#endif
   }
   FFX_TSTOP(tp, 19);
   if (c.shadows && wballot(any_s) != 0ull) {
@@ -2175,6 +2209,20 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       if constexpr (R == 1) FFX_STAT(45);
       traverse_packet_any<true, R, WIDE>(nodes, arecs_s, ws, stack, so, sdir, s0, s1, act, hs, occ_s);
     }
+#ifdef FFX_BINCHECK
+    if constexpr (R == 1) {
+      if (binned_s) {
+        bool occ2[R];
+        traverse_packet_any<true, R, WIDE>(nodes, arecs_s, ws, stack, so, sdir, s0, s1, act, hs, occ2);
+        const wmask bm = wballot(act[0] && occ2[0] != occ_s[0]);
+        if (bm != 0ull && (threadIdx.x & 63) == (unsigned)wff1(bm)) {
+          atomicAdd(&g_ffx_chk[16], 1ull);
+          if (atomicAdd(&g_ffx_chk[17], 1ull) == 0ull) { g_ffx_chk[18] = (unsigned long long)px | ((unsigned long long)py << 16) | ((unsigned long long)(threadIdx.x & 63) << 32) | ((unsigned long long)occ2[0] << 40); g_ffx_chk[19] = (unsigned long long)(uint32_t)hs[0].slot; }
+        }
+        occ_s[0] = occ2[0];
+      }
+    }
+#endif
   }
   FFX_TSTOP(tp, 20);
   const ShadeK &c2 = kernarg_shade(); // phase: texture footprint and light intensities
@@ -3342,6 +3390,16 @@ static inline size_t stack_bytes(const ffx_bvh_info *info) {
 }
 
 #ifdef FFX_STATS
+#endif
+#ifdef FFX_BINCHECK
+extern "C" int ffx_debug_bincheck(unsigned long long *out24, int reset) {
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_ffx_chk), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[24] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffx_chk), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 #endif
 #ifdef FFX_TIMERS
 extern "C" int ffx_debug_timers(unsigned long long *out32, int reset) {

@@ -23,6 +23,25 @@ from .. import sampling
 from ..utils import math as ffmath
 
 _CPU = torch.device("cpu")
+_MM4 = None
+
+
+def mm4(a, b):
+    """a @ b for 4x4 float32 matrices (numpy arrays or host tensors) -> numpy, through the library's ONE host definition of that product
+    (include/ffx.h ffx_mat4_mul_h: an fma chain over k).  numpy's and torch's own 4x4 products differ in the last bit from CPU to CPU
+    (their sgemm kernels are chosen per micro-architecture); with this the Python path of a randomisation and the native one
+    (ffx_scene_randomize_h) give the same matrices everywhere."""
+    global _MM4
+    if _MM4 is None:
+        from .._lib import api
+
+        _MM4 = api().lib.ffx_mat4_mul_h
+    a = np.ascontiguousarray(a.numpy() if isinstance(a, torch.Tensor) else a, np.float32)
+    b = np.ascontiguousarray(b.numpy() if isinstance(b, torch.Tensor) else b, np.float32)
+    out = np.empty((4, 4), np.float32)
+    if a.shape != (4, 4) or b.shape != (4, 4) or _MM4(a.ctypes.data, b.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("mm4: two 4x4 float32 matrices expected")
+    return out
 
 
 class DrawBatch:
@@ -292,12 +311,10 @@ class Transformable:
         cz, sz = math.cos(rz), math.sin(rz)
         cy, sy = math.cos(ry), math.sin(ry)
         cx, sx = math.cos(rx), math.sin(rx)
-        zMat = np.array([[cz, 0, sz], [0, 1, 0], [-sz, 0, cz]], dtype=np.float32)  # getPitchTransform
-        yMat = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]], dtype=np.float32)  # getYawTransform
-        xMat = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=np.float32)  # getRollTransform
-        m = np.zeros((4, 4), dtype=np.float32)
-        m[:3, :3] = (zMat @ yMat) @ xMat
-        m[3, 3] = 1.0
+        zMat = np.array([[cz, 0, sz, 0], [0, 1, 0, 0], [-sz, 0, cz, 0], [0, 0, 0, 1]], dtype=np.float32)  # getPitchTransform
+        yMat = np.array([[cy, -sy, 0, 0], [sy, cy, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)  # getYawTransform
+        xMat = np.array([[1, 0, 0, 0], [0, cx, -sx, 0], [0, sx, cx, 0], [0, 0, 0, 1]], dtype=np.float32)  # getRollTransform
+        m = mm4(mm4(zMat, yMat), xMat)  # (4x4 with a zero border: the same products as the 3x3 ones, through the one product routine)
         return torch.from_numpy(m)
 
     @staticmethod
@@ -334,7 +351,7 @@ class Transformable:
         self._last_translation = t
         self._last_draw = (values[ticket["t"]], values[ticket["r"]])
         rot = self._rotation_matrix(*values[ticket["r"]])
-        self._randomized_world = torch.from_numpy(((t.numpy() + self._centroid_mat.numpy()) @ rot.numpy()) @ self._world.numpy())
+        self._randomized_world = torch.from_numpy(mm4(mm4(t.numpy() + self._centroid_mat.numpy(), rot), self._world))
         self._compose_attributes(ticket["a"], values)
 
     # the last drawn translation / rotation (attributes of the reference), as tensors on demand
@@ -374,7 +391,7 @@ class Transformable:
     def _world_host(self):
         if self._parent is None:
             return self._randomized_world.clone()
-        return self._parent._world_host() @ self._randomized_world
+        return torch.from_numpy(mm4(self._parent._world_host(), self._randomized_world))
 
     def world(self):
         return self._world_host().to(self._device)

@@ -173,7 +173,7 @@ class Mesh(base.Transformable):
         sc[0, 0], sc[1, 1], sc[2, 2], sc[3, 3] = sx, sy, sz, 1.0
         rot = self._rotation_matrix(*values[ticket["r"]])
         # (numpy: the same float32 products as the torch expression, see Transformable._rotation_matrix)
-        self._randomized_world = torch.from_numpy((((t.numpy() + self._centroid_mat.numpy()) @ rot.numpy()) @ sc) @ self._world.numpy())
+        self._randomized_world = torch.from_numpy(base.mm4(base.mm4(base.mm4(t.numpy() + self._centroid_mat.numpy(), rot), sc), self._world))
 
     def load_animation(self, path: str):
         frames = [load_obj_vertices(os.path.join(path, f)) for f in sorted(os.listdir(path)) if f.endswith(".obj")]

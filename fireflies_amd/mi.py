@@ -500,7 +500,7 @@ class Scene:
                         self._warned_bsdf = True
                     continue
                 v = self._params._d[k]
-                v = float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
+                v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
                 if name == "specular":  # the plugin re-derives eta from it (principled.cpp parameters_changed)
                     col, v = scenes.MAT_COLUMN["eta"], scenes.specular_to_eta(v)
                     self._params._d[base + ".brdf_0.eta"] = Float(v)

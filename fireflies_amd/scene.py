@@ -312,13 +312,13 @@ class Scene:
             uncentre = torch.eye(4)
             uncentre[0:3, 3] = -mesh._centroid_mat[0:3, 3]
             if pick is None:
-                p.set_mesh_pose(mesh.name(), world @ uncentre, frame=0)
+                p.set_mesh_pose(mesh.name(), torch.from_numpy(entity.base.mm4(world, uncentre)), frame=0)
             elif pick[0] == "func":
                 p.set_mesh_pose(mesh.name(), world, vertices=mesh._animation_func(mesh._vertices, pick[2]))
             else:
                 pool = getattr(mesh, "_pool_frames", None)
                 if pool is not None:  # frames already resident in the device pool, stored like the rest pose
-                    p.set_mesh_pose(mesh.name(), world @ uncentre, frame=pool[pick[1]][0] + pick[2])
+                    p.set_mesh_pose(mesh.name(), torch.from_numpy(entity.base.mm4(world, uncentre)), frame=pool[pick[1]][0] + pick[2])
                 else:
                     stack = mesh._anim_data_train if pick[1] == "train" else mesh._anim_data_eval
                     p.set_mesh_pose(mesh.name(), world, vertices=stack[pick[2]])

@@ -279,6 +279,11 @@ int ffx_torch_rand_batch_h(int k, const uint64_t *seeds /*[host][k]*/, const uin
  * times the translation by -centroid.  The float32 arithmetic is the reference's torch expressions' (an fma chain over k for the 3x3 /
  * 4x4 products, as torch's and numpy's sgemm kernels compute them; angles through double cos / sin): bit-identical to the Python
  * mirror, which the goldens g7 pin.  Samplers that are not plain uniform draws stay in Python (fireflies_amd/scene.py falls back). */
+/* out = a @ b, row-major 4x4 float32, each element an fma chain over the inner index (the first product plain): the ONE definition of
+ * a matrix product on the host side of the randomiser — the Python mirror (fireflies_amd/entity) calls it where the reference writes
+ * torch.matmul (fireflies/entity/base.py:220-244), because sgemm libraries round a 4x4 product differently from CPU to CPU.
+ * out may alias a or b. */
+int ffx_mat4_mul_h(const float *a /*[host][16]*/, const float *b /*[host][16]*/, float *out /*[host][16]*/);
 typedef struct ffx_rand_draw {
   int32_t n;          /* values of this torch.rand call: 1..4 */
   float lo[4], hi[4]; /* the sampler's bounds */

@@ -553,11 +553,10 @@ static void matmul_f32(const float *A, const float *B, float *out, int n) {
     }
   memcpy(out, tmp, sizeof(float) * (size_t)(n * n));
 }
-static void embed3(const float *m3, float *m4) {
-  memset(m4, 0, 16 * sizeof(float));
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) m4[4 * r + c] = m3[3 * r + c];
-  m4[15] = 1.0f;
+int ffx_mat4_mul_h(const float *a, const float *b, float *out) {
+  if (!a || !b || !out) FAIL(FFX_ERR_ARG, "mat4_mul_h: bad argument");
+  matmul_f32(a, b, out, 4);
+  return FFX_OK;
 }
 int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const uint64_t *offsets, const ffx_rand_draw *draws, int n_draws,
                           const ffx_rand_entity *ents, int n_ents, float *values, float *local, float *chain, float *chain_uncentred) {
@@ -588,13 +587,13 @@ int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const uint64_t *
       } else {
         const float *t = val + 4 * q->draw_t, *r = val + 4 * q->draw_r;
         const double az = (double)r[2], ay = (double)r[1], ax = (double)r[0];
-        const float pitch[9] = {(float)cos(az), 0.f, (float)sin(az), 0.f, 1.f, 0.f, -(float)sin(az), 0.f, (float)cos(az)}; /* getPitchTransform: about Y */
-        const float yaw[9] = {(float)cos(ay), -(float)sin(ay), 0.f, (float)sin(ay), (float)cos(ay), 0.f, 0.f, 0.f, 1.f};   /* getYawTransform: about Z */
-        const float roll[9] = {1.f, 0.f, 0.f, 0.f, (float)cos(ax), -(float)sin(ax), 0.f, (float)sin(ax), (float)cos(ax)};  /* getRollTransform: about X */
-        float r3[9], R[16], M[16];
-        matmul_f32(pitch, yaw, r3, 3);
-        matmul_f32(r3, roll, r3, 3);
-        embed3(r3, R);
+        /* the three Euler matrices as 4x4 (fireflies/utils/math.py:24-60 returns 3x3; the border of zeros and the 1 change no product) */
+        const float pitch[16] = {(float)cos(az), 0.f, (float)sin(az), 0.f, 0.f, 1.f, 0.f, 0.f, -(float)sin(az), 0.f, (float)cos(az), 0.f, 0.f, 0.f, 0.f, 1.f}; /* getPitchTransform: about Y */
+        const float yaw[16] = {(float)cos(ay), -(float)sin(ay), 0.f, 0.f, (float)sin(ay), (float)cos(ay), 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};     /* getYawTransform: about Z */
+        const float roll[16] = {1.f, 0.f, 0.f, 0.f, 0.f, (float)cos(ax), -(float)sin(ax), 0.f, 0.f, (float)sin(ax), (float)cos(ax), 0.f, 0.f, 0.f, 0.f, 1.f};    /* getRollTransform: about X */
+        float R[16], M[16];
+        matmul_f32(pitch, yaw, R, 4);
+        matmul_f32(R, roll, R, 4);
         float TC[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
         for (int i = 0; i < 3; ++i) TC[4 * i + 3] = t[i] + q->centroid[i]; /* translation matrix + centroid matrix, element by element */
         matmul_f32(TC, R, M, 4);

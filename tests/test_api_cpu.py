@@ -479,25 +479,34 @@ def test_noise_texture_sampler_matches_the_reference():
 def test_native_scene_randomiser_is_the_python_mirror_bit_for_bit(oracle):
     """f1 (include/ffx.h ffx_scene_randomize_h): the draws, interval maps, 4x4 algebra and parent chains of a whole randomisation in one
     host call.  Product library and oracle restatement against the Python mirror's own arithmetic (entity.Transformable / Mesh: numpy
-    float32 products, math.cos / sin) on random configurations — bit for bit, which is what lets Scene.randomize() switch between the
-    native call and the Python path without changing a seeded run; and numpy's 4x4 float32 product is the fma chain both restate."""
+    products through ffx_mat4_mul_h, math.cos / sin) on random configurations — bit for bit, which is what lets Scene.randomize() switch
+    between the native call and the Python path without changing a seeded run, on any host CPU."""
     import ctypes as C
 
     from fireflies_amd import _abi, _lib
     from fireflies_amd.entity import Mesh, Transformable
 
     rng = np.random.default_rng(5)
-    for _ in range(50):  # the premise: numpy (and torch) float32 matmul of these sizes = an fma chain over k
-        A, B = rng.standard_normal((4, 4)).astype(np.float32), rng.standard_normal((4, 4)).astype(np.float32)
-        ref = np.zeros((4, 4), np.float32)
+
+    def fma_mm(A, B):
+        """the definition (include/ffx.h ffx_mat4_mul_h): every element an fma chain over k, the first product plain — evaluated here in
+        float64 with one rounding per step (a float32 product is exact in float64), independent of any BLAS"""
+        A, B = np.asarray(A, np.float32), np.asarray(B, np.float32)
+        out = np.zeros((4, 4), np.float32)
         for i in range(4):
             for j in range(4):
                 acc = np.float32(A[i, 0] * B[0, j])
                 for k in range(1, 4):
                     acc = np.float32(np.float64(A[i, k]) * np.float64(B[k, j]) + np.float64(acc))
-                ref[i, j] = acc
-        np.testing.assert_array_equal(A @ B, ref)
-        np.testing.assert_array_equal((torch.from_numpy(A) @ torch.from_numpy(B)).numpy(), ref)
+                out[i, j] = acc
+        return out
+
+    from fireflies_amd.entity.base import mm4
+
+    for _ in range(50):  # the mirror's product routine IS that definition (numpy's own 4x4 product rounds differently from CPU to CPU)
+        A, B = rng.standard_normal((4, 4)).astype(np.float32), rng.standard_normal((4, 4)).astype(np.float32)
+        np.testing.assert_array_equal(mm4(A, B), fma_mm(A, B))
+        np.testing.assert_array_equal(mm4(torch.from_numpy(A), B), fma_mm(A, B))
     libs = {"hip": _lib.api().lib, "oracle": oracle.api().lib}
     for trial in range(20):
         n_ents = int(rng.integers(1, 6))
@@ -575,14 +584,14 @@ def test_native_scene_randomiser_is_the_python_mirror_bit_for_bit(oracle):
                     if kind == 2:
                         sc = np.zeros((4, 4), np.float32)
                         sc[0, 0], sc[1, 1], sc[2, 2], sc[3, 3] = *[float(x) for x in want_vals[ds]], 1.0
-                        local = (((t + cm) @ rot) @ sc) @ world  # entity/mesh.py Mesh._compose
+                        local = fma_mm(fma_mm(fma_mm(t + cm, rot), sc), world)  # entity/mesh.py Mesh._compose
                     else:
-                        local = ((t + cm) @ rot) @ world  # entity/base.py Transformable._compose
-                w = local if parent < 0 else chain[parent] @ local
+                        local = fma_mm(fma_mm(t + cm, rot), world)  # entity/base.py Transformable._compose
+                w = local if parent < 0 else fma_mm(chain[parent], local)
                 chain.append(w)
                 unc = np.eye(4, dtype=np.float32)
                 unc[:3, 3] = -cen
                 np.testing.assert_array_equal(mats[0, s, e].reshape(4, 4), local)
                 np.testing.assert_array_equal(mats[1, s, e].reshape(4, 4), w)
-                np.testing.assert_array_equal(mats[2, s, e].reshape(4, 4), (torch.from_numpy(w) @ torch.from_numpy(unc)).numpy())  # Scene.update_meshes
+                np.testing.assert_array_equal(mats[2, s, e].reshape(4, 4), fma_mm(w, unc))  # Scene.update_meshes
     assert Mesh is not None
