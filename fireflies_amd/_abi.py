@@ -81,6 +81,7 @@ class AdamArgs(C.Structure):
         ("dot_n", C.c_int64),
         ("dot_partial", C.c_void_p),
         ("dot_b_n", C.c_int64),
+        ("guard", C.c_void_p),
     ]
 
 

@@ -416,8 +416,10 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
     // them is re-fitted by ONE workgroup after the last treelet has arrived, a serial tail that grows with their number
     // (tools/refittime.py, MI355X: colon, 524 k triangles: 3004 / 1519 / 751 / 379 / 191 / 95 treelets = 396 / 205 / 134 / 106 /
     // 100 / 128 us per update; vocal fold, 53 k: 302 / 152 / 76 / 38 / 21 treelets = 55 / 44 / 40 / 45 / 50 us)
+    // (round 4: the update is two launches — treelets, then the top — without the per-workgroup release fence that made many treelets
+    // expensive; 1024 triangles per treelet is then best for both scenes: colon 751 treelets 65 us (fused, 4096: 83), vocal fold 76: 36 us;
+    // FFX_REFIT=fused with the sizes above remains the A/B baseline)
     int tl_auto = 1024;
-    while (tl_auto < 8192 && n_tris / tl_auto > 192) tl_auto *= 2;
     const int tl_max = getenv("FFX_TREELET_TRIS") ? std::max(FFX_LEAF_MAX, atoi(getenv("FFX_TREELET_TRIS"))) : tl_auto;
     // out-index heights (as the level refit uses them) per build node
     std::vector<int> hgt(b.nodes.size(), 0);

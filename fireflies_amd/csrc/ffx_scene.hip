@@ -343,8 +343,17 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
     k_scene_update_fused(BvhNode *nodes, TriRec *recs, const int32_t *__restrict__ order, WideChild *tq, WideChild *wn, const int32_t *__restrict__ wsrc,
                          int32_t *plan, int n_treelets, int counter_at, const float *__restrict__ src_verts, const int32_t *__restrict__ tris,
                          const int32_t *__restrict__ tri_shape, const int32_t *__restrict__ vert_off, const float *__restrict__ xform, int n_shapes, ShapeTabH tab,
-                         SmoothTab sm) {
+                         SmoothTab sm, int mode) {
+  // mode 0: the whole update (the workgroup that arrives last re-fits the top); 1: the treelets only, 2: the top only — the same update as
+  // two launches (FFX_REFIT=split).  Publishing needs an agent-scope release fence in every treelet's workgroup, and on this part that fence
+  // writes back the workgroup's whole L2 — megabytes of fresh records; a kernel boundary does the same once.
   __shared__ int s_last;
+  if (mode == 2) {
+    const int32_t *ht = plan + 8 * n_treelets;
+    plan_levels(nodes, recs, plan, ht);
+    plan_wide_children(nodes, wn, wsrc, plan, ht);
+    return;
+  }
   const int32_t *h = plan + 8 * blockIdx.x;
   // ---- A: records and per-triangle boxes of this treelet's run of leaf slots
   const int s0 = h[0], sn = h[1];
@@ -387,6 +396,7 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
   // ---- B, C: this treelet's nodes by height, then the wide children whose boxes live in them
   plan_levels(nodes, recs, plan, h);
   plan_wide_children(nodes, wn, wsrc, plan, h);
+  if (mode == 1) return;
   // ---- D: publish; the last workgroup to arrive re-fits the top of the tree
   __threadfence();
   __syncthreads();
@@ -400,6 +410,10 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
   if (threadIdx.x == 0) plan[counter_at] = 0; // ready for the next update of this blob (stream-ordered)
 }
 
+static int refit_split_enabled() { // FFX_REFIT=fused: the one-launch form (A/B); default: treelets + top as two launches
+  const char *e = getenv("FFX_REFIT");
+  return !(e && strcmp(e, "fused") == 0);
+}
 static int refit_fused_enabled() {
   const char *e = getenv("FFX_REFIT");
   return !(e && strcmp(e, "levels") == 0);
@@ -456,12 +470,17 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
     WideChild *tq = (WideChild *)(base + info->off_tq), *wn = (WideChild *)(base + info->off_wnodes);
     const int32_t *wsrc = (const int32_t *)(base + info->off_wsrc);
     int32_t *plan = (int32_t *)(base + info->off_plan);
-    if (host_tab)
-      hipLaunchKernelGGL(k_scene_update_fused<true>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
-                         info->plan_ints - 1, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab, sm);
-    else
-      hipLaunchKernelGGL(k_scene_update_fused<false>, dim3(info->n_treelets), dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
-                         info->plan_ints - 1, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab, sm);
+    const int split = refit_split_enabled();
+    for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+      const int mode = split ? pass + 1 : 0;
+      const dim3 grid(mode == 2 ? 1 : info->n_treelets);
+      if (host_tab)
+        hipLaunchKernelGGL(k_scene_update_fused<true>, grid, dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
+                           info->plan_ints - 1, src_verts, tris, tri_shape, (const int32_t *)nullptr, (const float *)nullptr, n_shapes, tab, sm, mode);
+      else
+        hipLaunchKernelGGL(k_scene_update_fused<false>, grid, dim3(FUSED_BLOCK), 0, st, nodes, recs, order, tq, wn, wsrc, plan, info->n_treelets,
+                           info->plan_ints - 1, src_verts, tris, tri_shape, vert_off, xform, n_shapes, tab, sm, mode);
+    }
     FFX_CHECK_LAUNCH("scene_update/fused");
     return FFX_OK;
   }

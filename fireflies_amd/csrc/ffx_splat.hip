@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // code k_blur_bwd runs: bitwise the separate launches' gradient without the 250 000-texel transpose blur in front (11 us) —
 // and `adam` (if it names rays): the workgroup that finishes last applies ffx_adam_clamp_step's update to every point.
 struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm;
-               const float *dot_a, *dot_b; long dot_n; float *dot_partial; long dot_b_n; int no_update; };
+               const float *dot_a, *dot_b; long dot_n; float *dot_partial; long dot_b_n; int no_update; const unsigned int *guard; };
 template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
@@ -1003,8 +1003,11 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     __syncthreads();
     if (s_last) {
       __threadfence();
-      const float t = adam.no_update ? 0.f : adam.step[0] + 1.0f;
-      if (!adam.no_update)
+      // (ffx_adam_args.guard: an adjoint-cache header whose `dropped` word says the gradient of this step is incomplete — K9 has poisoned
+      // it with NaN: the update is then NOT applied, so that rays and the optimiser state stay what they were)
+      const bool skip = adam.no_update || (adam.guard && adam.guard[2] != 0u);
+      const float t = skip ? 0.f : adam.step[0] + 1.0f;
+      if (!skip)
         for (int i = tid; i < n; i += SPLAT_BLOCK)
           adam_clamp_one(i, t, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
                          adam.lo, adam.hi, adam.n_norm);
@@ -1022,7 +1025,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
         }
       }
       __syncthreads();
-      if (tid == 0) { if (!adam.no_update) adam.step[0] = t; *adam.counter = 0u; } // (the counter is ready for the next launch)
+      if (tid == 0) { if (!skip) adam.step[0] = t; *adam.counter = 0u; } // (the counter is ready for the next launch)
     }
   }
 }
@@ -1256,6 +1259,7 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
     if (!no_update && (grays_reg || adam->grad_div != 1.0f) && !adam->grad_out) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: combining gradients needs grad_out");
     ak.no_update = no_update ? 1 : 0;
     if (adam->rays != rays) FFX_FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the update is applied to the rays the gradient was taken at");
+    ak.guard = (const unsigned int *)adam->guard;
     ak.rays = adam->rays; ak.m = adam->exp_avg; ak.v = adam->exp_avg_sq; ak.step = adam->step; ak.grad_out = adam->grad_out; ak.counter = adam->counter;
     ak.lr = adam->lr; ak.beta1 = adam->beta1; ak.beta2 = adam->beta2; ak.eps = adam->eps;
     for (int i = 0; i < 16; ++i) ak.KI.m[i] = adam->KF_inv[i];

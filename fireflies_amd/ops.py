@@ -177,7 +177,7 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
     return gd, gr, val
 
 
-def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None, dot=None):
+def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None, dot=None, guard=None):
     """ffx_adam_args for pattern_bwd_blur (the tensors must outlive the launch; `counter`: one zeroed int32 / uint32 device word).
     dot = (a, b, partial): the launch also evaluates <a, b> (two float32 tensors of equal size: the render and the constant gradient of a loss
     linear in it) as the step's data term; partial: float32 scratch of one element per point."""
@@ -197,6 +197,8 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
             raise ValueError("dot = (a, b, partial): a a whole number of b's long (b is repeated), partial with one float per point")
         a.dot_a, a.dot_b, a.dot_n, a.dot_partial = _dev(da, name="dot a").value, _dev(db, name="dot b").value, int(da.numel()), _dev(part, name="dot partial").value
         a.dot_b_n = int(db.numel())
+    if guard is not None:  # an adjoint cache (uint8 tensor): the update is skipped when its header reports dropped samples
+        a.guard = _dev(guard, torch.uint8, "guard").value
     return a
 
 

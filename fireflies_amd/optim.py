@@ -204,7 +204,7 @@ class PatternOptimizer:
         fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
                  and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
         n_slots = ops.render_dot_slots(cam.width, cam.height)  # (K9's partial sums of the loss; the fused path evaluates it in the gradient launch)
-        use_cache = (not fused) and Fn.cache_supported(sd0, self.spp)
+        use_cache = (not fused) and Fn.cache_supported(sd0, self.spp) and not getattr(self, "_cache_overflowed", False)
         nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0
         acc_bytes = -(-4 * (s0 * s1 + n_slots) // 128) * 128
         if getattr(self, "_arena", None) is None or self._arena.numel() != acc_bytes + max(nbytes, 64):
@@ -312,8 +312,10 @@ class PatternOptimizer:
         else:
             # nothing to exchange: the whole backward half is ONE launch — gradient of the data term and of the regulariser, the step's total
             # loss, and (by the workgroup that finishes last) Adam + Laser.clamp_to_fov() + normalize_rays() on grad = gsum / S + regulariser
+            # (guard: with the adjoint cache in play the in-kernel update is skipped when its header reports dropped samples — K9 has then
+            # poisoned the gradient with NaN; rays and the Adam state stay intact and _watch_cache switches this optimiser to the re-tracing adjoint)
             aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
-                               1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot)
+                               1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot, guard=self._cache if use_cache else None)
             gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
                                                loss_div=float(S), adam=aa, scratch=self._scratch)
             loss = val[1]
@@ -331,10 +333,20 @@ class PatternOptimizer:
             used, cap, dropped = (int(v) for v in w[0][:3].tolist())
             self._watch = None
             if dropped:
-                raise Fn.CacheOverflowError(
-                    f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample "
-                    "records: a projector texture much finer than the camera's pixels, or grazing views) — gradients since then carry NaN. "
-                    "Set FFX_CACHE_LIMIT_GB=0 (re-tracing adjoint) or lower FFX_CACHE_MAX_TEXELS_PER_PIXEL.")
+                import warnings
+
+                # the steps since then were NOT applied (ffx_adam_args.guard: the update launch skips when the header reports drops), so the
+                # optimiser state is intact: from here on this optimiser takes the re-tracing adjoint (single process; several ranks update
+                # through ffx_adam_clamp_step after the exchange and still raise)
+                if dist.world_size() > 1:
+                    raise Fn.CacheOverflowError(
+                        f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample "
+                        "records) — gradients since then carry NaN. Set FFX_CACHE_LIMIT_GB=0 (re-tracing adjoint).")
+                self._cache_overflowed = True
+                self._arena = None
+                warnings.warn(f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample records: a projector "
+                              "texture much finer than the camera's pixels, or grazing views).  The updates of the affected steps were skipped; this optimiser "
+                              "now uses the re-tracing adjoint (ffx_render_bwd).", stacklevel=3)
         if getattr(self, "_watch", None) is None and self._cache is not None and (self.step_index - 1) % every == 0:
             pin = getattr(self, "_watch_pin", None)
             if pin is None:

@@ -231,6 +231,11 @@ typedef struct ffx_adam_args {
   float *dot_partial; /* [dev][n] scratch */
   int64_t dot_b_n;    /* period of dot_b: <a, b> = sum_i a[i] * b[i mod dot_b_n] (the S renders of a step stacked in dot_a against ONE
                          constant gradient); 0 = dot_n */
+  /* optional (ABI 5): the adjoint cache the step's gradient came from (ffx_render_fwd_cache's `cache`: its header).  When that header's
+   * `dropped` word is not zero — the arena of single-sample records overflowed, ffx_render_bwd_cached has poisoned gtex with NaN — the
+   * update is NOT applied: rays, exp_avg, exp_avg_sq and step keep their values, and the caller, who finds out with
+   * ffx_render_cache_status, can repeat the step with the re-tracing adjoint instead of finding its optimiser state full of NaN. */
+  const void *guard;  /* [dev] or NULL */
 } ffx_adam_args;
 int ffx_pattern_fwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
                          int want_softor, float *pts /*[dev][n,2]*/, float *tsum /*[dev][size1,size0]*/,

@@ -1858,7 +1858,9 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   float *zeros = NULL;
   const float *gd = gtex ? grays_data : NULL;
   if (!gd) { zeros = (float *)calloc((size_t)3 * n, sizeof(float)); gd = zeros; }
-  if (!no_update) rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
+  /* guard (ffx.h): an adjoint cache header {n_stray, cap_stray, dropped}: dropped != 0 -> no update (the oracle's own cache never drops) */
+  const int skip = adam->guard && ((const uint32_t *)adam->guard)[2] != 0u;
+  if (!no_update && !skip) rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
                            adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, s);
   free(zeros);
   if (rc == FFX_OK && adam->dot_a) { /* the data term as an inner product (takes the place of loss_in) */

@@ -1463,3 +1463,34 @@ def test_material_rows_forward_and_adjoint_are_transposes(ch):
     zero = gd.render_fwd(sd, mats, torch.zeros_like(tex), spp, seed=8).double()
     two = gd.render_fwd(sd, mats, 2 * tex, spp, seed=8).double()
     torch.testing.assert_close(two - base, base - zero, rtol=1e-4, atol=1e-5 * float(base.max()))
+
+
+def test_the_in_kernel_update_is_skipped_when_the_adjoint_cache_dropped_samples(oracle):
+    """ffx_adam_args.guard (round 4, advisor): the Adam + clamp_to_fov update that rides on ffx_pattern_bwd_blur looks at the adjoint
+    cache's header — `dropped` != 0 means K9 has poisoned the gradient with NaN — and then leaves rays, both moments and the step count
+    untouched, so that the caller can repeat the step with the re-tracing adjoint instead of finding NaN in its optimiser state.
+    HIP and oracle; the same launch with a clean header applies the update."""
+    rng = np.random.default_rng(3)
+    n, (s0, s1), sigma, ks, bs = 32, (64, 48), 10.0, 5, 3.0
+    g2 = load_golden("g2_projection.npz")
+    KF = (g2["K"] @ FLIP_Y).astype(np.float32)
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    ndc = (rng.random((n, 3)) * np.array([0.8, 0.8, 0.0]) + np.array([0.1, 0.1, -1.0])).astype(np.float32)
+    rays = oracle.transform_points(ndc, KFi)
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    gtex = rng.standard_normal((s1, s0)).astype(np.float32)
+    gtex[0, 0] = np.nan  # what K9 leaves behind when the cache dropped samples
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for dropped in (7, 0):
+        hdr = np.zeros(16, np.uint32)
+        hdr[0], hdr[1], hdr[2] = 4096 + dropped, 4096, dropped
+        guard = torch.from_numpy(hdr.view(np.uint8).copy()).cuda()
+        r, m, v, st = dev(rays).clone(), torch.zeros(n, 3, device="cuda"), torch.zeros(n, 3, device="cuda"), torch.zeros((), device="cuda")
+        _, ts, to, ws, _ = ops.pattern_fwd_blur(r, KF, sigma, s0, s1, ks, bs, True)
+        aa = ops.adam_args(r, m, v, st, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=1.0, grad_out=torch.empty_like(r), guard=guard)
+        g_in = dev(gtex if dropped else np.nan_to_num(gtex))
+        ops.pattern_bwd_blur(r, KF, sigma, s0, s1, ts, to, g_in, 0.1, ws, ks, bs, adam=aa, scratch=torch.empty_like(ts))
+        if dropped:
+            assert torch.equal(r, dev(rays)) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0 and float(st) == 0.0 and int(counter) == 0
+        else:
+            assert not torch.equal(r, dev(rays)) and float(st) == 1.0 and bool(torch.isfinite(r).all()) and int(counter) == 0
