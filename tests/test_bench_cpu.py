@@ -121,3 +121,44 @@ def test_self_launcher_refuses_more_ranks_than_devices_and_propagates_failures()
     # inside a torchrun environment the world size must match --gpus
     r = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_every_profile_the_bench_line_cites_exists_is_not_empty_and_names_kernels_of_this_tree(bench):
+    """round 3 committed a 0-byte profiles/r3_phaseclk.txt and a gradient PMC summary that listed kernels the step no longer launched,
+    and the bench line cited both.  bench.cited_profiles() is what a default line's `evidence` field lists: every file must exist, be
+    non-empty, come from ONE round's collection (tools/collect_profiles.sh) and name only kernels that exist in csrc/ today — and the
+    gradient bracket's summary must contain the launches a gradient step makes now."""
+    files = bench.cited_profiles("")
+    assert files, "no committed profile set"
+    kernels = set()
+    for src in ("ffx_trace.hip", "ffx_splat.hip", "ffx_scene.hip", "ffx_bins.hip"):
+        txt = open(os.path.join(ROOT, "fireflies_amd", "csrc", src)).read()
+        kernels |= set(re.findall(r"__global__[^;{]*?\b(k_[A-Za-z0-9_]+)\s*\(", txt, flags=re.S))
+    assert {"k_render_fwd_pk", "k_bin", "k_pattern_bwd", "k_render_bwd_cached_tiled16"} <= kernels
+    tags = set()
+    for rel in files:
+        path = os.path.join(ROOT, rel)
+        assert os.path.isfile(path) and os.path.getsize(path) > 0, f"{rel}: cited by the bench line but missing or empty"
+        name = os.path.basename(rel)
+        if any(name.endswith(sfx) for sfx in ("pmc_summary.json", "sq_instruction_mix.json", "kernel_stats.csv", "phaseclk.txt")):
+            tags.add(re.match(r"(r\d+)", name).group(1))
+    assert len(tags) == 1, f"the cited kernel profiles come from different rounds: {sorted(tags)}"
+    (tag,) = tags
+
+    def base(k):
+        return k.replace("void ", "").split("<")[0].split("(")[0].strip()
+
+    for name in (f"{tag}_pmc_summary.json", f"{tag}grad_pmc_summary.json", f"{tag}_sq_instruction_mix.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        stale = sorted({base(k) for k in d if base(k).startswith("k_")} - kernels)
+        assert not stale, f"profiles/{name} names kernels that are not in csrc/ any more: {stale}"
+    g = json.load(open(os.path.join(ROOT, "profiles", f"{tag}grad_pmc_summary.json")))
+    assert any(k.startswith("k_render_fwd_pk<") and ", true>" in k for k in g), "no counters for the forward + adjoint launch the gradient bracket times"
+    for want in ("k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached", "k_bin<"):
+        assert any(k.startswith(want) for k in g), f"the gradient bracket's PMC summary lacks {want}"
+    stats = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()
+    assert "k_render_fwd_pk<1, true, 1, false>" in stats and "k_bin<true>" in stats
+    # ... and what the line derives from them resolves to that same set
+    t = bench.pmc_traffic("k_render_fwd_pk", "grad", "", adjoint_instance=True)
+    assert t is not None and t["source"] == f"{tag}grad_pmc_summary.json"
+    assert bench.pmc_traffic("k_render_bwd_cached", "grad", "")["source"] == f"{tag}grad_pmc_summary.json"
