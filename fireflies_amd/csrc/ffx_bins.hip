@@ -113,10 +113,15 @@ __device__ void bin_scan_one(char *base, int nt, uint32_t cap, uint32_t *s_cnt) 
 // apex records of the pre-pass (k_apex_records of ffx_trace.hip, same arithmetic): what to write for apex a
 struct BinApex { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; TriApex *out; uint32_t astride; uint32_t *cache_hdr; uint32_t cap_stray; };
 
+// One wave per workgroup, at most 80 VGPRs: these launches run beside a render whose one-wave workgroups (72 VGPRs, seven per SIMD) refill
+// every slot the moment it frees — a four-wave workgroup of 96-VGPR waves waited for four slots and enough registers on ONE compute unit at
+// the same time and hardly ever found them; a wave that fits the hole one retired render wave leaves is dispatched at once.
+#define BIN_BLOCK 64
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb, BinApex ba) {
+__global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb, BinApex ba) {
+  FFX_SIDE_PRIO();
   const int a = blockIdx.y;
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.x * BIN_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63;
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
   if (k < n_tris) {
@@ -315,6 +320,7 @@ __global__ void __launch_bounds__(256) k_bin(const TriRec *__restrict__ recs, in
 // that finishes last, it needed an agent-scope release fence in EVERY workgroup — which on this part writes back the whole L2, 7.7 MB of
 // fresh apex records included: the counting launch took 65 us instead of 10.)
 __global__ void __launch_bounds__(256) k_bin_scan(BinBuild bb) {
+  FFX_SIDE_PRIO();
   extern __shared__ uint32_t s_dyn_cnt[];
   const int g = blockIdx.x;
   if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, s_dyn_cnt);
@@ -326,13 +332,13 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
   memset(&ba, 0, sizeof ba);
   for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
   ba.out = (TriApex *)apex_out; ba.astride = astride; ba.cache_hdr = cache_hdr; ba.cap_stray = cap_stray;
-  const dim3 grid(ffx_cdiv(n_tris, 256), FFX_N_APEX);
+  const dim3 grid(ffx_cdiv(n_tris, BIN_BLOCK), FFX_N_APEX);
   int max_nt = 0; // dynamic LDS of the counting launch: the largest grid's counts (the scan of the workgroup that finishes last)
   for (int a = 0; a < FFX_N_APEX; ++a)
     if (bb.g[a].on && bb.g[a].nx * bb.g[a].ny > max_nt) max_nt = bb.g[a].nx * bb.g[a].ny;
-  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
+  hipLaunchKernelGGL(k_bin<false>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
     hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(256), (size_t)4 * (max_nt + 1), s, bb);
-    hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, s, recs, n_tris, bb, ba);
+    hipLaunchKernelGGL(k_bin<true>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   }
 }

@@ -419,7 +419,7 @@ int ffx_bvh_build_host(const float *verts, int n_verts, const int32_t *tris, int
     // (round 4: the update is two launches — treelets, then the top — without the per-workgroup release fence that made many treelets
     // expensive; 1024 triangles per treelet is then best for both scenes: colon 751 treelets 65 us (fused, 4096: 83), vocal fold 76: 36 us;
     // FFX_REFIT=fused with the sizes above remains the A/B baseline)
-    int tl_auto = 1024;
+    int tl_auto = 512; // (one WAVE per treelet since the end of round 4: 512 / 1024 measure the same, 256 slightly worse)
     const int tl_max = getenv("FFX_TREELET_TRIS") ? std::max(FFX_LEAF_MAX, atoi(getenv("FFX_TREELET_TRIS"))) : tl_auto;
     // out-index heights (as the level refit uses them) per build node
     std::vector<int> hgt(b.nodes.size(), 0);

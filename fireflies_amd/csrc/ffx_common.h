@@ -22,6 +22,17 @@ void ffx_set_error(const char *fmt, ...);
 
 static inline int ffx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The kernels of a pose's preparation (re-fit, apex records, tile bins) run on a side stream BESIDE the previous pose's render, whose
+// quarter of a million one-wave workgroups keep every SIMD's issue port busy: a wave of these latency-bound kernels then gets one issue
+// slot in eight, and their dependent chain — which the next render waits for — took 0.46 ms instead of 0.12 (tools/steptrace.py: the
+// step's period WAS that chain).  s_setprio raises the wave's priority at the SIMD's arbiter: their few instructions go first, the
+// render loses nothing measurable.  -DFFX_NO_SIDE_PRIO switches it off (A/B).
+#ifdef FFX_NO_SIDE_PRIO
+#define FFX_SIDE_PRIO() do { } while (0)
+#else
+#define FFX_SIDE_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // ------------------------------------------------------------------ small POD blocks passed by value
 struct Mat4 { float m[16]; };
 

@@ -295,7 +295,12 @@ __global__ void __launch_bounds__(UPD_BLOCK)
 }
 
 // ---- the fused update.  `recs` and `nodes` are written and read back inside this kernel: no __restrict__, no read-only loads.
-#define FUSED_BLOCK 256
+// One wave per treelet (round 4): beside a render whose one-wave workgroups refill every slot at once, a four-wave workgroup waits for four
+// free slots on one compute unit — the update's elapsed time was 128 us at 256 threads, 59 us at 64 (alone: 36 / ~60), renders/s +2.5 %
+// (tools: bench.py under -DFUSED_BLOCK=64 / 128 / 256 builds and FFX_TREELET_TRIS).
+#ifndef FUSED_BLOCK
+#define FUSED_BLOCK 64
+#endif
 __device__ __forceinline__ void tri_wide_box(const float (&p0)[3], const float (&e1)[3], const float (&e2)[3], WideChild &c) {
   // the padded box of ONE triangle exactly as leaf_box forms it from the record (corners re-rounded as v0 + e)
   float lo[3], hi[3];
@@ -347,6 +352,7 @@ __global__ void __launch_bounds__(FUSED_BLOCK)
   // mode 0: the whole update (the workgroup that arrives last re-fits the top); 1: the treelets only, 2: the top only — the same update as
   // two launches (FFX_REFIT=split).  Publishing needs an agent-scope release fence in every treelet's workgroup, and on this part that fence
   // writes back the workgroup's whole L2 — megabytes of fresh records; a kernel boundary does the same once.
+  FFX_SIDE_PRIO();
   __shared__ int s_last;
   if (mode == 2) {
     const int32_t *ht = plan + 8 * n_treelets;

@@ -22,7 +22,8 @@ def main():
     rank, world, local = dist.init(backend)
     dev = torch.cuda.current_device()
     wl = workloads.vocalfold(device="cuda", width=64, height=56, tex=96, grid=6, frames=5, n_fold=20, tube=(20, 24))
-    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=4)
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # scene samples per step over all ranks
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=S)
     res = opt.step()
     import torch.distributed as td
 

@@ -696,6 +696,53 @@ def test_bench_self_launches_its_ranks():
         assert bad.returncode != 0 and bad.stdout.strip() == "" and "only 1 device(s)" in bad.stderr
 
 
+def test_four_rank_rehearsal_of_the_drivers_multi_gpu_command(tmp_path):
+    """Rehearsal of the driver's scaling run on the one device this box has (`FFX_DIST_BACKEND=gloo`; four ranks — the box allows six
+    processes on its GPU, so the eight-rank command itself cannot run here: the code path is the same for any N): (i) `bench.py --gpus 4
+    --grad-samples 32` self-launches four fresh ranks, rank 0's line says n_gpus 4, four devices / rates, samples_per_rank 8, one [3N+1]
+    all-reduce timed, both gradient brackets ran on every rank; (ii) BASELINE configs[3]'s step — 32 scene samples over four ranks, k mod 4 —
+    reduces to the gradient, loss and updated rays of ONE process that ran all 32 (seeds independent of the world size)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FFX_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--res", "128", "--no-cpu-baseline",
+                          "--grad-samples", "32"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    (line,) = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    out = json.loads(line)
+    assert out["n_gpus"] == 4 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak" and out["cpu_baseline"] is None
+    r = out["rccl"]
+    assert r["world_size"] == 4 and r["backend"] == "gloo" and r["allreduce_us"] > 0 and r["allreduce_floats"] == 3 * 64 + 1
+    assert [d["rank"] for d in r["devices"]] == [0, 1, 2, 3] and len(r["renders_per_sec_per_rank"]) == 4 and all(v > 0 for v in r["renders_per_sec_per_rank"])
+    assert out["grad_config"]["samples_per_step"] == 32 and out["grad_config"]["samples_per_rank"] == 8
+    assert out["grad_steps_per_sec"] > 0 and out["grad_steps_per_sec_nonlinear"] > 0 and out["value_cold"] > 0
+    # (ii) the 32-sample step on four ranks against one process
+    env2 = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path), "gloo", "32"]
+    res = subprocess.run(cmd, env=env2, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    outs = [json.load(open(tmp_path / f"rank{r_}.json")) for r_ in range(4)]
+    assert all(o["world"] == 4 and o["backend"] == "gloo" for o in outs)
+    kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21)
+    wl = _small()
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, samples_per_step=32, **kw)
+    one = opt.step()
+    ref = wl.laser._rays.grad.detach().cpu().numpy()
+    for o in outs:
+        np.testing.assert_allclose(np.asarray(o["grad"], np.float32), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+        assert o["loss"] == pytest.approx(float(one["loss"]), rel=1e-4)
+        np.testing.assert_allclose(np.asarray(o["rays"], np.float32), wl.laser._rays.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(np.asarray(outs[0]["grad"]), np.asarray(o["grad"]))  # replicated optimiser state
+
+
 def test_laser_yaml_roundtrip(tmp_path):
     wl = _small(randomize=False)
     f = tmp_path / "laser.yaml"
