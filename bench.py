@@ -137,7 +137,7 @@ PROFILED_WORKLOAD = PROFILED_WORKLOADS[""]
 
 def profile_key(args):
     """"" / "colon": which committed profile set describes this run's workload; None: none does"""
-    if args.no_shadows:
+    if args.no_shadows or getattr(args, "rfilter", "box") != "box":
         return None
     for key, w in PROFILED_WORKLOADS.items():
         if all(getattr(args, k) == v for k, v in w.items()) and (key != "colon" or args.grid == 32):
@@ -381,7 +381,11 @@ def cpu_grad_step(wg, spp_full, cpu_spp, seed, cores):
     geo.update(wg.mi_scene._xforms.numpy(), wg.mi_scene._offs)
     t_upd = time.perf_counter() - t0
     t0 = time.perf_counter()
-    img, gtex, _dot = geo.render_fwd_adjoint(sd, albh, texh, cpu_spp, seed, gimg)
+    if sd.rfilter:  # (a filtered film: forward, then the re-traced filtered adjoint — the step the device takes, too)
+        img = geo.render_fwd(sd, albh, texh, cpu_spp, seed)
+        gtex = geo.render_bwd(sd, albh, cpu_spp, seed, gimg)
+    else:
+        img, gtex, _dot = geo.render_fwd_adjoint(sd, albh, texh, cpu_spp, seed, gimg)
     t_r = time.perf_counter() - t0
     t0 = time.perf_counter()
     gts = orc.blur_bwd(np.ascontiguousarray(gtex.reshape(texh.shape)))
@@ -497,6 +501,9 @@ def main():
     ap.add_argument("--material", default="principled", choices=["principled", "diffuse"],
                     help="principled (default): the scene's material is Mitsuba's principled BSDF whose parameters the reference randomises "
                          "(examples/vocalfold_scene.py:86-93, main.py:97-107); diffuse: Lambert only")
+    ap.add_argument("--rfilter", default="box", choices=["box", "gaussian"],
+                    help="the film's reconstruction filter: box (the headline workload of every round) or Mitsuba's gaussian, hdrfilm's default, which a scene "
+                         "FILE without <rfilter> gets (ffx_render_fwd_filtered; the gradient step then re-traces: ffx_render_bwd_filtered)")
     ap.add_argument("--entity-device", default="cuda", help="device argument of ff.Scene (where the sampler bounds live and whose generator is used): cuda (the reference default) or cpu")
     args = ap.parse_args()
 
@@ -525,6 +532,7 @@ def main():
     with torch.no_grad():
         tex = workloads.build_texture(wl).contiguous()
     wl.params["tex.data"] = tex
+    wl.mi_scene.rfilter = args.rfilter
     geom = wl.mi_scene.geom
     base_seed = 1000
 
@@ -584,7 +592,8 @@ def main():
         preflight["render"] = {"checked": "k_render_fwd_pk against k_render_fwd (FFX_TRAVERSAL=lane) on the current pose", "images": len(imgs[None]),
                                "pixel_channels_beyond_1e-4_of_scale": worst}
 
-    do_preflight = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ and not args.no_render_steps
+    # (the per-lane kernels carry the box filter only: a filtered run is checked by the test suite and smoke(), not here)
+    do_preflight = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ and not args.no_render_steps and args.rfilter == "box"
     settle_render = (lambda k: mi.render(wl.mi_scene, spp=args.spp, seed=k, fp16=args.fp16)) if (SETTLE_RENDERS > 0 and not args.no_render_steps) else None
     # `value`: the consuming step, settled clocks (config.clock_settle)
     t_render = _bracket(timed_render_step, n_render, w_render, dev, preflight_render if do_preflight else None, settle_render)
@@ -630,6 +639,7 @@ def main():
         from fireflies_amd.optim import image_l1_loss
 
         wg = make(device=dev, width=W, height=H, grid=args.grad_grid, shadows=not args.no_shadows, entity_device=args.entity_device, principled=args.material == "principled")
+        wg.mi_scene.rfilter = args.rfilter
         S = args.grad_samples if args.grad_samples > 0 else world
         opt = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=S, base_seed=7)
         gevents = []
@@ -691,7 +701,7 @@ def main():
             preflight["gradient_nonlinear"] = {"checked": "k_render_bwd_cached_tiled16 (from the footprint cache k_render_fwd_pk writes) against k_render_bwd_pk (re-tracing) "
                                                           "on the current pose", "adjoints": 4, "texels_beyond_1e-3_of_scale": worst}
 
-        pre_ok = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ
+        pre_ok = os.environ.get("FFX_BENCH_PREFLIGHT", "1") != "0" and "FFX_TRAVERSAL" not in os.environ and args.rfilter == "box"
         settle_grad = (lambda k: mi.render(wg.mi_scene, spp=args.spp, seed=k)) if SETTLE_RENDERS > 0 else None
         fused_expected = os.environ.get("FFX_FUSED_ADJOINT", "1") != "0" and len(opt._sample_seeds(0)) <= 64
         t_grad = _bracket(grad_step, args.steps, args.warmup, dev, (preflight_grad_fused if fused_expected else preflight_grad_cached) if pre_ok else None, settle_grad)
@@ -710,7 +720,9 @@ def main():
             "grad_samples_per_sec": S * args.steps / t_grad,
             "grad_ms_per_step": 1e3 * t_grad / args.steps,
             "grad_config": {"points": args.grad_grid**2, "samples_per_step": S, "samples_per_rank": len(range(rank, S, world)),
-                            "loss": "coverage_loss = -mean(green): linear in the image (forward + adjoint in one launch)" if fused_ran else "coverage_loss through the cache + K9"},
+                            "loss": "coverage_loss = -mean(green): linear in the image (forward + adjoint in one launch)" if fused_ran
+                            else ("coverage_loss, filtered film: forward (ffx_render_fwd_filtered) + re-traced adjoint (ffx_render_bwd_filtered)" if lin_paths["retrace"] > 0
+                                  else "coverage_loss through the cache + K9")},
             "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if fused_ran else "render_fwd(+cache write)"): k8g_ms,
                                 "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
             "grad_launches_per_step": "pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if fused_ran
@@ -810,6 +822,7 @@ def main():
                              "why": "the first ~40 launches after an idle GPU run up to 6 % slower (clock ramp; tools/posecost.py, profiles/r3_posecost.txt): a 20-step bracket "
                                     "would time the ramp.  `value_cold` is the same bracket without them, after an idle phase"},
             "entity_device": args.entity_device,
+            "rfilter": args.rfilter,
             "material": ("principled BSDF (Mitsuba's model, reflection side), parameters randomised as the reference's scripts do" if args.material == "principled"
                          else "diffuse (Lambert)"),
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,

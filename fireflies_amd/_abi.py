@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 5
+FFX_ABI_VERSION = 6
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -145,6 +145,8 @@ class SceneDesc(C.Structure):
         ("slot_uv", C.c_void_p),
         ("n_mat_h", C.c_int32),
         ("mat_h", c_f * 128),
+        ("rfilter", C.c_int32),  # RFILTER_BOX / RFILTER_GAUSSIAN: served by ffx_render_{fwd,bwd}_filtered only
+        ("rfilter_stddev", c_f),
     ]
 
 
@@ -155,6 +157,7 @@ MAT_SPEC_TINT, MAT_SHEEN, MAT_SHEEN_TINT, MAT_FLATNESS, MAT_CLEARCOAT, MAT_CLEAR
 MAT_BASE_TEX = 15
 RENDER_FP16, RENDER_SPARSE_ADJOINT, RENDER_APEX_READY, RENDER_CACHE_ZEROED = 1, 2, 4, 8  # flags in the img_fp16 argument of the render calls
 MAX_BASE_TEX = 4
+RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 MAX_MAT_H = 128
 ADJOINT_DOT_SLOTS = 4096  # FFX_ADJOINT_DOT_SLOTS: partial sums of <gimg, img> in ffx_render_fwd_adjoint
 
@@ -203,6 +206,9 @@ PROTOTYPES = {
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
     "ffx_render_dot_slots": (C.c_size_t, [c_i, c_i]),
+    "ffx_render_filter_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
+    "ffx_render_fwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
+    "ffx_render_bwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd_adjoint": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_apex_prepare": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p]),
     "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),

@@ -11,7 +11,7 @@
 // Three launches on the stream of the re-fit (normally the side stream, off the renders' critical path):
 //   k_bin<false>  a lane per triangle and apex: writes the triangle's APEX RECORD (ffx_common.h TriApex — what k_apex_records did as a
 //                 launch of its own), projects, classifies and counts the tiles it touches (one atomic per tile into `cursors`)
-//   k_bin_scan    a workgroup per grid: the counts into list starts (through LDS), overflow check against the capacity
+//   k_bin_scan    a wave per grid: the counts into list starts (rows of 64 scanned on the DPP network), overflow check against the capacity
 //   k_bin<true>   the same walk again, writing the 64-byte entries at start[tile] + --cursor[tile]: the cursors count back down to
 //                 zero, which is what the next pose's counting pass needs to find (no clearing launch)
 // Triangles that touch up to sixteen tiles loop over them per lane; larger ones (faces next to the apex) and triangles the projection
@@ -66,48 +66,51 @@ __device__ __forceinline__ bool bin_entry_touches(const BinEntry &en, float rx0,
   return ok;
 }
 
-// the scan of one grid's counts (in `cursors`) into list starts, by one workgroup of 256 threads through LDS (coalesced loads and
-// stores; a thread scans a contiguous run of the LDS copy).  The cursors keep the counts (the fill pass counts them down) unless the
-// lists do not fit — then they are cleared here, because no fill pass will run.  s_cnt: nt + 1 words of dynamic LDS.
-__device__ void bin_scan_one(char *base, int nt, uint32_t cap, uint32_t *s_cnt) {
+// the scan of one grid's counts (in `cursors`) into list starts by ONE wave: rows of 64 tiles (coalesced), a row scanned across the lanes on
+// the DPP network, the running total carried in a scalar, eight rows' counts fetched per trip.  One wave and no LDS, because the
+// launch runs beside a render that keeps every CU full: with the counts copied to LDS (16 KB for 64x64 tiles, 64 KB for the colon's
+// 128x128) the workgroup could not be placed until a render had drained (134 us on average inside the bench loop, rocprofv3, against 7
+// alone), and four waves that must start on one CU together still waited 41 us.  The cursors keep the counts (the fill pass counts them
+// down) unless the lists do not fit — then they are cleared here, because no fill pass will run.
+__device__ void bin_scan_one(char *base, int nt, uint32_t cap) {
   uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
   uint32_t *cursors = (uint32_t *)(base + ffx_bin_off_cursors());
-  __shared__ uint32_t s_part[256];
-  for (int i = threadIdx.x; i < nt; i += 256) s_cnt[i] = cursors[i];
-  __syncthreads();
-  const int per = (nt + 255) / 256; // <= 64
-  const int t0 = threadIdx.x * per, t1 = min(t0 + per, nt);
-  uint32_t sum = 0;
-  for (int t = t0; t < t1; ++t) sum += s_cnt[t];
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan of the 256 partial sums
-    const uint32_t v = threadIdx.x >= (unsigned)off ? s_part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    s_part[threadIdx.x] += v;
-    __syncthreads();
+  const int lane = threadIdx.x;
+  const int rows = (nt + 63) >> 6;
+  uint32_t run = 0;
+  auto load = [&](int r) { const int i = r * 64 + lane; return (r < rows && i < nt) ? cursors[i] : 0u; };
+  for (int r8 = 0; r8 < rows; r8 += 8) { // eight rows per trip: their loads are in flight together (one memory round trip per trip, not per row)
+    uint32_t cnt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cnt[u] = load(r8 + u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = (r8 + u) * 64 + lane;
+      const uint32_t c = cnt[u];
+      // inclusive scan across the wave (six DPP adds): Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8: lanes without a source add
+      // 0), then rows 1 and 3 take lane 15 of the row before (row_bcast:15) and rows 2, 3 lane 31 (row_bcast:31)
+      uint32_t incl = c;
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+      incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+      if (i < nt) starts[i] = run + incl - c;
+      run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
   }
-  const uint32_t total = s_part[255];
+  const uint32_t total = run;
   const bool ok = total <= cap;
-  uint32_t run = s_part[threadIdx.x] - sum; // exclusive
-  for (int t = t0; t < t1; ++t) {
-    const uint32_t c = s_cnt[t];
-    s_cnt[t] = run;
-    run += c;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nt; i += 256) {
-    starts[i] = s_cnt[i];
-    if (!ok) cursors[i] = 0u;
-  }
-  if (threadIdx.x == 0) {
+  if (!ok)
+    for (int i = lane; i < nt; i += 64) cursors[i] = 0u;
+  if (lane == 0) {
     starts[nt] = total;
     BinHdr *h = (BinHdr *)base;
     h->total = total;
     h->cap = cap;
     h->ok = ok ? 1u : 0u;
   }
-  __syncthreads();
 }
 
 // apex records of the pre-pass (k_apex_records of ffx_trace.hip, same arithmetic): what to write for apex a
@@ -316,14 +319,13 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
-// a workgroup per grid: its counts into list starts.  (A launch of its own: folded into the counting launch as the job of the workgroup
+// a wave per grid: its counts into list starts.  (A launch of its own: folded into the counting launch as the job of the workgroup
 // that finishes last, it needed an agent-scope release fence in EVERY workgroup — which on this part writes back the whole L2, 7.7 MB of
 // fresh apex records included: the counting launch took 65 us instead of 10.)
-__global__ void __launch_bounds__(256) k_bin_scan(BinBuild bb) {
+__global__ void __launch_bounds__(64) k_bin_scan(BinBuild bb) {
   FFX_SIDE_PRIO();
-  extern __shared__ uint32_t s_dyn_cnt[];
   const int g = blockIdx.x;
-  if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, s_dyn_cnt);
+  if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap);
 }
 
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
@@ -333,12 +335,9 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
   for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
   ba.out = (TriApex *)apex_out; ba.astride = astride; ba.cache_hdr = cache_hdr; ba.cap_stray = cap_stray;
   const dim3 grid(ffx_cdiv(n_tris, BIN_BLOCK), FFX_N_APEX);
-  int max_nt = 0; // dynamic LDS of the counting launch: the largest grid's counts (the scan of the workgroup that finishes last)
-  for (int a = 0; a < FFX_N_APEX; ++a)
-    if (bb.g[a].on && bb.g[a].nx * bb.g[a].ny > max_nt) max_nt = bb.g[a].nx * bb.g[a].ny;
   hipLaunchKernelGGL(k_bin<false>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
-    hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(256), (size_t)4 * (max_nt + 1), s, bb);
+    hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(64), 0, s, bb);
     hipLaunchKernelGGL(k_bin<true>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   }
 }

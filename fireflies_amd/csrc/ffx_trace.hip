@@ -62,6 +62,8 @@ struct ShadeK {
   float mat_h[FFX_MAX_MAT_H];
   // tile bins of the three apexes (ffx_common.h BinsK): the packet kernels try them before the tree walks
   BinsK bins;
+  // reconstruction filter (ffx_scene_desc.rfilter = gaussian; the *_filtered entry points only): g(x) = max(0, exp(rf_alpha x^2) - rf_bias)
+  float rf_alpha, rf_bias;
 };
 // The first kernel argument, read in place.  The scene constants (ShadeK, ~100 dwords + the inline material rows) are the first
 // argument of the render kernels.  Read through the by-value copy the compiler loads them all up front and, out of SGPRs, parks
@@ -2420,10 +2422,135 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
   return (cache_off_arena(n_pix) + sizeof(CacheStray) * cap_stray + 127) & ~(size_t)127;
 }
 
+
+// ---- reconstruction filter that spreads a sample over its 5x5-pixel window (include/ffx.h, ffx_scene_desc.rfilter) -------------------------
+// A wave holds the 64 samples of ONE pixel, one per lane; what the film needs from it are 25 x (r, g, b, weight) sums over those samples —
+// 100 cross-lane reductions (7 instructions each as DPP chains: ~700 at the 4-cycle rate, +65 % on the kernel).  Instead the lanes change
+// roles through LDS: every lane parks its five weights per axis, its radiance and its "I am a sample" flag in 14 rows of 64 floats; then
+// lane l becomes OUTPUT l (window entry l / 4, channel l % 4; two rounds cover the 100) and runs over the 64 samples of the three rows
+// it needs with 16-byte LDS reads — 48 reads, 64 multiplies and 64 fused multiply-adds per round, all in the 2-cycle class, same
+// summation order as the oracle (samples ascending).  The rows alias the wide walk's stack (never live at the same time); the row pitch of
+// 68 floats puts the five rows a round reads into different banks.  Measured (tools/rftime.py, 512^2 x 64 spp): the render kernel 0.386 ->
+// 0.487 ms, as the instruction count says (2 x 128 two-cycle instructions + ~75 for the weights on ~3700 cycles per pixel).
+// Tried and dropped: the same sums on the matrix pipe — v_mfma_f32_16x16x4_f32 with rows = channel (4 of 16 used), columns = window entry,
+// K = samples (lanes ARE the K index: no role change, a fifth of the LDS traffic, bit-identical sums) — 32 instructions x 32 cycles of a
+// pipe whose issue time adds to the VALU's here: 0.545 ms.
+#define FFX_RF_ROW 68
+#define FFX_RF_FLOATS (14 * FFX_RF_ROW)
+__device__ __forceinline__ void rf_weights(float alpha, float bias, float j, float (&w)[5]) {
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float x = ((float)(a - 2) + 0.5f) - j; // centre of window pixel a minus the sample position
+    w[a] = fmaxf(__expf(alpha * (x * x)) - bias, 0.f);
+  }
+}
+// acc[r] += sum over this pass's samples of  gx[a] gy[b] L[ch]  for output o = 64 r + lane = 4 (5 b + a) + ch  (o < 100)
+__device__ __forceinline__ void rf_fold(float *__restrict__ s_rf, int lane, const float (&gx)[5], const float (&gy)[5], float l0, float l1, float l2, float l3,
+                                        float (&acc)[2]) {
+  int lz = lane;
+  asm volatile("" : "+v"(lz)); // (keeps the row addresses out of long-lived registers, as for s_foot)
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    s_rf[a * FFX_RF_ROW + lz] = gx[a];
+    s_rf[(5 + a) * FFX_RF_ROW + lz] = gy[a];
+  }
+  s_rf[10 * FFX_RF_ROW + lz] = l0;
+  s_rf[11 * FFX_RF_ROW + lz] = l1;
+  s_rf[12 * FFX_RF_ROW + lz] = l2;
+  s_rf[13 * FFX_RF_ROW + lz] = l3;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int o = min(r * 64 + lz, 99), n = o >> 2, ch = o & 3;
+    const int b = (n * 13) >> 6, a = n - 5 * b; // n / 5, n % 5 for n < 25
+    const float4 *rx = reinterpret_cast<const float4 *>(s_rf + a * FFX_RF_ROW);
+    const float4 *ry = reinterpret_cast<const float4 *>(s_rf + (5 + b) * FFX_RF_ROW);
+    const float4 *rl = reinterpret_cast<const float4 *>(s_rf + (10 + ch) * FFX_RF_ROW);
+    float t = acc[r];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 X = rx[k], Y = ry[k], L = rl[k];
+      t = __builtin_fmaf(X.x * Y.x, L.x, t);
+      t = __builtin_fmaf(X.y * Y.y, L.y, t);
+      t = __builtin_fmaf(X.z * Y.z, L.z, t);
+      t = __builtin_fmaf(X.w * Y.w, L.w, t);
+    }
+    acc[r] = t;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// a pixel's 25 outgoing sums -> scratch [pixel][25][4]
+__device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix, int lane, const float (&acc)[2]) {
+  float *pp = part + (size_t)pix * 100;
+  pp[lane] = acc[0];
+  if (lane < 36) pp[64 + lane] = acc[1];
+}
+
+// the weights alone (the adjoint's first launch): one wave per pixel, the jitter decides everything
+__global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int n_pix, int spp, uint32_t seed_key, float *__restrict__ part) {
+  __shared__ float s_rf[FFX_RF_FLOATS];
+  const int pix = blockIdx.x, lane = threadIdx.x;
+  if (pix >= n_pix) return;
+  float acc[2] = {0.f, 0.f};
+  for (int pass = 0; pass < (spp + 63) >> 6; ++pass) {
+    const int s = pass * 64 + lane;
+    float jx, jy, gx[5], gy[5];
+    sample_jitter(seed_key, (uint32_t)pix * (uint32_t)spp + (uint32_t)s, jx, jy);
+    rf_weights(alpha, bias, jx, gx);
+    rf_weights(alpha, bias, jy, gy);
+    rf_fold(s_rf, lane, gx, gy, 0.f, 0.f, 0.f, s < spp ? 1.f : 0.f, acc);
+  }
+  rf_store(part, (uint32_t)pix, lane, acc);
+}
+
+// second launch of either direction: a pixel's 25 incoming sums.  Forward: img = (r, g, b) / weight.  Adjoint (gimg != NULL):
+// G = gimg / weight as float4 per pixel.  Window entry n = (a, b) of source pixel (x - (a - 2), y - (b - 2)) is what that pixel's
+// samples sent HERE; summed in window order like the oracle.
+__global__ void __launch_bounds__(256) k_rf_gather(const float4 *__restrict__ part, int W, int H, int fp16, void *__restrict__ img, const float *__restrict__ gimg,
+                                                    float4 *__restrict__ G) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  float r = 0.f, g = 0.f, b = 0.f, w = 0.f;
+#pragma unroll
+  for (int wb = 0; wb < 5; ++wb) {
+#pragma unroll
+    for (int wa = 0; wa < 5; ++wa) {
+      const int qx = x - (wa - 2), qy = y - (wb - 2);
+      if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+      const float4 v = part[((size_t)qy * W + qx) * 25 + (wb * 5 + wa)];
+      r += v.x; g += v.y; b += v.z; w += v.w;
+    }
+  }
+  const size_t pix = (size_t)y * W + x;
+  if (gimg) {
+    const bool ok = w > 0.f;
+    G[pix] = make_float4(ok ? gimg[pix * 3] / w : 0.f, ok ? gimg[pix * 3 + 1] / w : 0.f, ok ? gimg[pix * 3 + 2] / w : 0.f, 0.f);
+    return;
+  }
+  const float v0 = w > 0.f ? r / w : 0.f, v1 = w > 0.f ? g / w : 0.f, v2 = w > 0.f ? b / w : 0.f;
+  if (fp16 & 1) {
+    _Float16 *p = (_Float16 *)img + pix * 3;
+    p[0] = (_Float16)v0; p[1] = (_Float16)v1; p[2] = (_Float16)v2;
+  } else {
+    float *p = (float *)img + pix * 3;
+    p[0] = v0; p[1] = v1; p[2] = v2;
+  }
+}
+
+// lane n < 25: G of window pixel n = (a, b) of pixel (px, py), i.e. pixel (px + a - 2, py + b - 2); zero outside the film and in lanes >= 25
+__device__ __forceinline__ float4 rf_window_g(const float4 *__restrict__ G, int px, int py, int W, int H, int lane, bool live) {
+  const int b = (lane * 13) >> 6, a = lane - 5 * b;
+  const int tx = px + a - 2, ty = py + b - 2;
+  if (!live || lane >= 25 || tx < 0 || tx >= W || ty < 0 || ty >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return G[(size_t)ty * W + tx];
+}
+
 #ifndef FFX_PK_MAT_WAVES
 #define FFX_PK_MAT_WAVES 7 // material rows: 75 VGPRs (72 at this setting without spills; 8 waves spill 4)
 #endif
-template <int R, bool WIDE, int MATM, bool ADJ = false>
+// RF (ffx_render_fwd_filtered): instead of the pixel's mean, the wave leaves the 25 x 4 sums its samples send to its 5x5 window in `cache`
+// (here: the scratch area, [pixel][25][4] floats; no adjoint cache in this mode) — see rf_fold above.
+template <int R, bool WIDE, int MATM, bool ADJ = false, bool RF = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
@@ -2437,8 +2564,10 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // no second pass — the pixel's footprint is scattered into gtex where it is formed instead of being stored for K9, stray samples at
   // once: no cache, no arena that could overflow, no launch behind the render.  `fold`: the footprint bookkeeping runs for either mode.
   // (ADJ is a template parameter: as a run-time mode its three pointers and the epilogue cost the plain forward a dozen scalar spills)
-  const bool fold = ADJ || cache != nullptr;
-  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
+  static_assert(!(RF && ADJ), "the filtered render has its own adjoint (ffx_render_bwd_filtered)");
+  const bool fold = !RF && (ADJ || cache != nullptr);
+  constexpr int WSTACK_N = WIDE ? FFX_WSTACK : 1, RF_N = (FFX_RF_FLOATS * 4 + 7) / 8;
+  __shared__ uint2 s_wstack[RF ? (WSTACK_N > RF_N ? WSTACK_N : RF_N) : WSTACK_N]; // (RF: the filter's rows alias the walk's stack)
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
   __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
   static_assert(R == 1, "the adjoint cache is written one pixel at a time");
@@ -2459,7 +2588,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int passes = (spp + 63) >> 6;
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
-  if (!ADJ && cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
+  if (!ADJ && !RF && cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
   FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
@@ -2485,6 +2614,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       if constexpr (MAT) { if (lz < 32) s_foot_b[lz] = 0.f; }
       __builtin_amdgcn_wave_barrier();
     }
+    float rfacc[2] = {0.f, 0.f}; // RF: this lane's two outputs (window entry, channel), summed over the passes
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -2638,6 +2768,18 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         }
         if constexpr (MAT) { c0 += b0; c1 += b1; c2 += b2; }
         }
+        if constexpr (RF) {
+          // the lane's sample -> its 25 window entries (weights from the jitter, re-derived: two hashes instead of two live registers)
+          float jx, jy, gx[5], gy[5];
+          sample_jitter(seed_key, pix[r] * (uint32_t)spp + (uint32_t)s, jx, jy);
+          rf_weights(ct.rf_alpha, ct.rf_bias, jx, gx);
+          rf_weights(ct.rf_alpha, ct.rf_bias, jy, gy);
+          if (pass > 0) { rfacc[0] = s_acc[r][0][threadIdx.x]; rfacc[1] = s_acc[r][1][threadIdx.x]; }
+          rf_fold(reinterpret_cast<float *>(s_wstack), lane, gx, gy, c0, c1, c2, active[r] ? 1.f : 0.f, rfacc); // (the weight channel: every sample drawn counts)
+          if (pass + 1 < passes) { s_acc[r][0][threadIdx.x] = rfacc[0]; s_acc[r][1][threadIdx.x] = rfacc[1]; }
+          else if (live[r]) rf_store(reinterpret_cast<float *>(cache), pix[r], lane, rfacc);
+          continue;
+        }
         // running sums of a pixel that needs several 64-sample passes are parked in LDS between the passes; the
         // usual single pass never touches it (it had cost 15 LDS operations per pixel)
         if (pass > 0) { c0 += s_acc[r][0][threadIdx.x]; c1 += s_acc[r][1][threadIdx.x]; c2 += s_acc[r][2][threadIdx.x]; }
@@ -2707,7 +2849,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         if (dd != 0.f) atomicAdd(adj_dot + (pix[0] & (FFX_ADJOINT_DOT_SLOTS - 1)), dd);
       }
     }
-    if (!ADJ && cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
+    if (!ADJ && !RF && cache && live[0]) { // the pixel's slot: header always, the footprint only if something was lit
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) {
         CachePix hp;
@@ -2728,7 +2870,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   FFX_TFLUSH();
 }
 
-template <int R, bool WIDE, int MATM>
+// RF (ffx_render_bwd_filtered): `gimg` is then G = gimg / weight as float4 per pixel (k_rf_gather) and a sample's radiance receives
+// sum over its 5x5 window of  w_n G[pixel + n]  — the transpose of the filter — in place of gimg[pixel] / spp.
+template <int R, bool WIDE, int MATM, bool RF = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
@@ -2739,8 +2883,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int tile = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
   const int lane = threadIdx.x & 63;
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy; see kernarg_shade)
-  const float inv_spp = 1.0f / (float)spp;
+  const float inv_spp = RF ? 1.0f : 1.0f / (float)spp; // (RF: the normalisation is the weight inside G)
   const int passes = (spp + 63) >> 6;
+  static_assert(!RF || R == 1, "the filtered adjoint walks one pixel per wave");
   for (int sub = 0; sub < NSUB; ++sub) {
     int px[R], py[R];
     packet_pixels<R>(tile, tiles_x, sub, px, py);
@@ -2752,8 +2897,14 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       live[r] = tile < n_tiles && px[r] < W && py[r] < H;
       pix[r] = live[r] ? (uint32_t)py[r] * (uint32_t)W + (uint32_t)px[r] : 0u;
       g[r][0] = g[r][1] = g[r][2] = 0.f;
+      if constexpr (RF) {
+        // lane n < 25 looks at window pixel n: the pixel is skipped when no pixel of its window carries a gradient
+        const float4 gw = rf_window_g(reinterpret_cast<const float4 *>(gimg), px[r], py[r], W, H, lane, live[r]);
+        live[r] = wballot(gw.x != 0.f || gw.y != 0.f || gw.z != 0.f) != 0ull;
+      } else {
       if (live[r]) { g[r][0] = gimg[(size_t)pix[r] * 3]; g[r][1] = gimg[(size_t)pix[r] * 3 + 1]; g[r][2] = gimg[(size_t)pix[r] * 3 + 2]; }
       live[r] = live[r] && !(g[r][0] == 0.f && g[r][1] == 0.f && g[r][2] == 0.f);
+      }
       any_live |= live[r];
     }
     if (wballot(any_live) == 0ull) continue; // wave-uniform
@@ -2777,6 +2928,24 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       const int tc = ct.tc;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        if constexpr (RF) {
+          // every lane's sample gathers its own gradient through the filter's weights: window pixel n's G sits in lane n (re-read: cached),
+          // broadcast with readlane and weighted per lane — window order, fused multiply-adds, as the oracle
+          const float4 gw = rf_window_g(reinterpret_cast<const float4 *>(gimg), px[r], py[r], W, H, lane, live[r]);
+          float jx, jy, gx[5], gy[5];
+          sample_jitter(seed_key, pix[r] * (uint32_t)spp + (uint32_t)s, jx, jy);
+          rf_weights(ct.rf_alpha, ct.rf_bias, jx, gx);
+          rf_weights(ct.rf_alpha, ct.rf_bias, jy, gy);
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int n = 0; n < 25; ++n) {
+            const float w = gx[n % 5] * gy[n / 5];
+            a0 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.x), n)), a0);
+            a1 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.y), n)), a1);
+            a2 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.z), n)), a2);
+          }
+          g[r][0] = a0; g[r][1] = a1; g[r][2] = a2;
+        }
         if (!st[r].hit || !st[r].has_proj) continue;
         const float *alb = TEX ? st[r].base : mat_table(ct) + (MAT ? FFX_MAT_STRIDE : 3) * st[r].shape;
         size_t o00 = ((size_t)st[r].iy0 * ct.tw + st[r].ix0) * tc, o01 = ((size_t)st[r].iy0 * ct.tw + st[r].ix1) * tc;
@@ -3123,6 +3292,12 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
     c.mat_inline = 1;
     for (int i = 0; i < sd->n_mat_h; ++i) c.mat_h[i] = sd->mat_h[i];
   }
+  if (sd->rfilter == FFX_RFILTER_GAUSSIAN) { // [EXT Mitsuba src/rfilters/gaussian.cpp] radius 4 stddev; the 5x5 window holds radius <= 2
+    const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
+    if (!(sdv <= 0.5f)) return 0;
+    c.rf_alpha = -1.0f / (2.0f * sdv * sdv);
+    c.rf_bias = expf(c.rf_alpha * (4.0f * sdv) * (4.0f * sdv));
+  } else if (sd->rfilter != FFX_RFILTER_BOX) return 0;
   c.n_base_tex = sd->n_base_tex;
   if (c.n_base_tex < 0 || c.n_base_tex > FFX_MAX_BASE_TEX || (c.n_base_tex > 0 && (c.mat_stride != FFX_MAT_STRIDE || !sd->slot_uv))) return 0;
   c.slot_uv = sd->slot_uv;
@@ -3494,13 +3669,17 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                            uint32_t seed, int call_flags, void *img, void *cache, ffx_stream s, const float *adj_gimg = nullptr, float *adj_gtex = nullptr,
-                           float *adj_dot = nullptr) {
+                           float *adj_dot = nullptr, void *rf_scratch = nullptr) {
   const int img_fp16 = call_flags & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT); // what the kernels see; the other bits steer the pre-pass
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
   if (!check_info(info, "render_fwd")) return FFX_ERR_ARG;
+  if ((sd->rfilter != FFX_RFILTER_BOX) != (rf_scratch != nullptr))
+    FFX_FAIL(FFX_ERR_UNSUPPORTED, rf_scratch ? "render_fwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN"
+                                             : "render_fwd: the scene's reconstruction filter is not the box (use ffx_render_fwd_filtered)");
+  if (rf_scratch && (!use_packet() || !use_wide(info))) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_filtered: only the default (wide packet) kernels carry the filter");
   ShadeK c;
-  if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
+  if (!shade_prepare(sd, c)) FFX_FAIL(rf_scratch ? FFX_ERR_UNSUPPORTED : FFX_ERR_ARG, "render_fwd: bad scene description%s", rf_scratch ? " (gaussian filter: stddev <= 0.5)" : "");
   c.mats = shape_albedo;
   const bool mat = c.mat_stride == FFX_MAT_STRIDE;
   if (mat && !c.mat_inline && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd: material rows must be 16-byte aligned");
@@ -3537,6 +3716,19 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
                      arena_off, foot_b_off, nrec, gn, cap_stray, adj_gimg, adj_gtex, adj_dot)
 #define FFX_LAUNCH_FWD(WIDE_, MAT_) do { if (adj_gtex) FFX_LAUNCH_FWD_(WIDE_, MAT_, true); else FFX_LAUNCH_FWD_(WIDE_, MAT_, false); } while (0)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
+    if (rf_scratch) { // the filtered render: the kernel leaves every pixel's 25 x 4 outgoing sums in the scratch area, the gather forms the image
+#define FFX_LAUNCH_RF(MAT_)                                                                                                                               \
+  hipLaunchKernelGGL((k_render_fwd_pk<1, true, MAT_, false, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
+                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16 & 1, img, (char *)rf_scratch, ppw,       \
+                     1.0f / (float)spp, foot_off, arena_off, foot_b_off, nrec, gn, cap_stray, adj_gimg, adj_gtex, adj_dot)
+      if (matm == 2) FFX_LAUNCH_RF(2); else if (matm == 1) FFX_LAUNCH_RF(1); else FFX_LAUNCH_RF(0);
+#undef FFX_LAUNCH_RF
+      FFX_CHECK_LAUNCH("render_fwd_filtered");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 32), ffx_cdiv(c.cam.H, 8)), dim3(256), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
+                         img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
+      FFX_CHECK_LAUNCH("render_fwd_filtered/gather");
+      return FFX_OK;
+    }
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD_(true, 2, false); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_FWD_(false, 2, false); else if (matm == 1) FFX_LAUNCH_FWD(false, 1); else FFX_LAUNCH_FWD(false, 0); }
 #undef FFX_LAUNCH_FWD
@@ -3615,6 +3807,7 @@ size_t ffx_render_dot_slots(int width, int height) {
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
   if (!sd || (!shape_albedo && sd->n_mat_h <= 0) || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (sd->rfilter != FFX_RFILTER_BOX) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
   if (!sd->proj.enabled) {
     if (dot_out) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> is accumulated by the footprint kernel, which a scene without projector does not launch");
     return FFX_OK;
@@ -3663,13 +3856,17 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   return FFX_OK;
 }
 
-int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
-                   const float *gimg, float *gtex, ffx_stream s) {
+static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                           const float *gimg, float *gtex, ffx_stream s, void *rf_scratch) {
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+  if ((sd->rfilter != FFX_RFILTER_BOX) != (rf_scratch != nullptr))
+    FFX_FAIL(FFX_ERR_UNSUPPORTED, rf_scratch ? "render_bwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN"
+                                             : "render_bwd: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
+  if (rf_scratch && (!use_packet() || !use_wide(info))) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_filtered: only the default (wide packet) kernels carry the filter");
   if (!sd->proj.enabled) return FFX_OK;
   if (!check_info(info, "render_bwd")) return FFX_ERR_ARG;
   ShadeK c;
-  if (!shade_prepare(sd, c)) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
+  if (!shade_prepare(sd, c)) FFX_FAIL(rf_scratch ? FFX_ERR_UNSUPPORTED : FFX_ERR_ARG, "render_bwd: bad scene description%s", rf_scratch ? " (gaussian filter: stddev <= 0.5)" : "");
   c.mats = shape_albedo;
   const bool mat = c.mat_stride == FFX_MAT_STRIDE;
   if (mat && !c.mat_inline && ((uintptr_t)shape_albedo & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd: material rows must be 16-byte aligned");
@@ -3695,6 +3892,24 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
                      spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), gimg, gtex, nrec, gn)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1);
+    if (rf_scratch) {
+      // 1. the weight every pixel received (jitter only) -> G = gimg / weight behind the partial sums; 2. the re-trace gathers through the filter
+      const int n_pix = c.cam.W * c.cam.H;
+      float *part = (float *)rf_scratch;
+      float4 *G = (float4 *)(part + (size_t)n_pix * 100);
+      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf_alpha, c.rf_bias, n_pix, spp, seed_key_of(seed), part);
+      FFX_CHECK_LAUNCH("render_bwd_filtered/weights");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 32), ffx_cdiv(c.cam.H, 8)), dim3(256), 0, (hipStream_t)s, (const float4 *)part, c.cam.W, c.cam.H, 0,
+                         (void *)nullptr, gimg, G);
+      FFX_CHECK_LAUNCH("render_bwd_filtered/gather");
+#define FFX_LAUNCH_BWD_RF(MAT_)                                                                                                                          \
+  hipLaunchKernelGGL((k_render_bwd_pk<1, true, MAT_, true>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), (const float *)G, gtex, nrec, gn)
+      if (matm == 2) FFX_LAUNCH_BWD_RF(2); else if (matm == 1) FFX_LAUNCH_BWD_RF(1); else FFX_LAUNCH_BWD_RF(0);
+#undef FFX_LAUNCH_BWD_RF
+      FFX_CHECK_LAUNCH("render_bwd_filtered");
+      return FFX_OK;
+    }
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BWD(true, 2); else if (matm == 1) FFX_LAUNCH_BWD(true, 1); else FFX_LAUNCH_BWD(true, 0); }
     else { if (matm == 2) FFX_LAUNCH_BWD(false, 2); else if (matm == 1) FFX_LAUNCH_BWD(false, 1); else FFX_LAUNCH_BWD(false, 0); }
 #undef FFX_LAUNCH_BWD
@@ -3708,6 +3923,30 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
                      tiles_x, n_tiles, xcd_mode(), gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd");
   return FFX_OK;
+}
+
+int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                   const float *gimg, float *gtex, ffx_stream s) {
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, s, nullptr);
+}
+
+// scratch of the filtered calls: [pixel][25][4] outgoing sums (400 B per pixel) + G = gimg / weight as float4 per pixel (the adjoint)
+size_t ffx_render_filter_bytes(const ffx_scene_desc *sd) {
+  if (!sd || sd->cam.width < 1 || sd->cam.height < 1) return 0;
+  return (size_t)sd->cam.width * sd->cam.height * (25 * 4 + 4) * sizeof(float);
+}
+
+int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                            uint32_t seed, int img_fp16, void *img, void *scratch, ffx_stream s) {
+  if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_filtered: scratch is NULL or not 16-byte aligned");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_APEX_READY), img, nullptr, s, nullptr, nullptr, nullptr,
+                         scratch);
+}
+
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                            const float *gimg, float *gtex, void *scratch, ffx_stream s) {
+  if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd_filtered: scratch is NULL or not 16-byte aligned");
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, s, scratch);
 }
 
 } // extern "C"

@@ -15,7 +15,7 @@ module reads what those scene files contain so that `mi.load_file(path)` keeps w
   <default name value>, $name substitution, <integer|float|string|rgb|boolean name value>
   <integrator>                   read for what it implies: direct illumination at the primary hit is what is rendered
                                  (path / prb / direct with max_depth 2); anything deeper is reported
-  <film> <rfilter>, <sampler>    box filter and independent sampler are what is implemented; others are reported
+  <film> <rfilter>, <sampler>    box and gaussian (the hdrfilm default) filters and the independent sampler are implemented; others are reported
   fov_axis                       x (Mitsuba's default), y, smaller, larger, diagonal: converted to the horizontal angle
 
 Every node or property that is dropped is reported with a warning (once per kind and file); nothing here touches the GPU.
@@ -475,10 +475,17 @@ def load_mitsuba_xml(path):
                     dropped("film.crop", "film crop window ignored: the full film is rendered")
                 rf = _child(film, "rfilter")
                 rtype = rf.get("type") if rf is not None else "gaussian"  # Mitsuba's default film filter
-                if rtype != "box" and not sensors:  # (the camera's film; a projector proxy's film is only a texture size)
-                    dropped("rfilter", f"reconstruction filter {rtype!r}{'' if rf is not None else ' (the hdrfilm default)'}: the BOX filter is used — every sample counts "
-                                       "for its own pixel only; Mitsuba's image would be smoother across pixel edges (equal in the mean).  "
-                                       "Declare <rfilter type=\"box\"/> for the like-for-like case")
+                if not sensors:  # (the camera's film; a projector proxy's film is only a texture size)
+                    if rtype == "gaussian":  # implemented (ffx_render_fwd_filtered): what mi.Scene then renders with
+                        stddev = float(_props(rf).get("stddev", 0.5)) if rf is not None else 0.5
+                        if stddev > 0.5:
+                            dropped("rfilter.stddev", f"gaussian reconstruction filter with stddev {stddev}: its radius does not fit the 5x5-pixel window; 0.5 is used")
+                            stddev = 0.5
+                        notes.setdefault("rfilter_stddev", stddev)
+                    elif rtype != "box":
+                        dropped("rfilter", f"reconstruction filter {rtype!r}: box and gaussian are implemented; the BOX filter is used — every sample counts "
+                                           "for its own pixel only (equal to Mitsuba's image in the mean)")
+                        rtype = "box"
                 notes.setdefault("rfilter", rtype)
             for extra in node:
                 if extra.tag == "sampler":

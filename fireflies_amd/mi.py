@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import functional as Fn
-from . import ops, scene_desc, scenes
+from . import _abi, ops, scene_desc, scenes
 
 _variant = "hip_ad_rgb"
 
@@ -378,6 +378,13 @@ class Scene:
             self._slot_uv = torch.from_numpy(scenes.slot_uv_table(order, tris, tri_shape, data.meshes)).to(self.device).contiguous()
         self.shadows = shadows
         self.tex_color = (0.0, 1.0, 0.0)
+        # the camera film's reconstruction filter: "box" or "gaussian" / ("gaussian", stddev).  A scene file gets what it declares — and
+        # hdrfilm's default, the gaussian, when it declares none, like every scene the reference loads (loaders.load_xml puts it into
+        # data.notes); procedural scenes (scenes.py) default to the box.  Assigning the attribute re-derives the scene description.
+        self._rfilter = None
+        rf = (getattr(data, "notes", None) or {}).get("rfilter")
+        if rf == "gaussian":
+            self._rfilter = ("gaussian", float(data.notes.get("rfilter_stddev", 0.5)))
         self._film_size = {}
         self._params = SceneParameters(self)
         self._build_params()
@@ -604,6 +611,16 @@ class Scene:
         v = self._params[key]
         return v.numpy() if isinstance(v, Transform4f) else np.asarray(v, np.float32).reshape(4, 4)
 
+    @property
+    def rfilter(self):
+        return "box" if self._rfilter is None else self._rfilter
+
+    @rfilter.setter
+    def rfilter(self, value):
+        scene_desc.set_rfilter(_abi.SceneDesc(), value)  # (validates)
+        self._rfilter = None if value in (None, "box") else (value if not isinstance(value, str) else (value, 0.5))
+        self._sd_cache = None
+
     def scene_desc(self, tex_channels=3):
         if self._sd_cache is not None and self._sd_cache[0] == tex_channels:
             return self._sd_cache[1]
@@ -627,7 +644,7 @@ class Scene:
         btex = [(t.data_ptr(), t.shape[1], t.shape[0]) for _, t in self._base_tex] or None
         sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride, base_tex=btex,
                                    slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None,
-                                   host_mats=self._albedo_host if self._mats_in_sd else None)
+                                   host_mats=self._albedo_host if self._mats_in_sd else None, rfilter=self._rfilter)
         self._sd_cache = (tex_channels, sd)
         return sd
 

@@ -199,6 +199,10 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
         a.dot_b_n = int(db.numel())
     if guard is not None:  # an adjoint cache (uint8 tensor): the update is skipped when its header reports dropped samples
         a.guard = _dev(guard, torch.uint8, "guard").value
+    # the struct holds raw addresses: it keeps the tensors alive for as long as it lives itself.  (A temporary passed as grad_out used to be
+    # freed on return — the caching allocator then handed its block to the NEXT small torch.empty, e.g. pattern_bwd_blur's 3-float value
+    # buffer, which the update's gradient store overwrote: an intermittent wrong regulariser value in the test suite, round 4)
+    a._keep = (rays, exp_avg, exp_avg_sq, step, counter, grad_out, dot, guard)
     return a
 
 
@@ -299,6 +303,11 @@ def render_cache_bytes(width, height, spp):
 def render_cache_bytes_sd(sd, spp):
     """the adjoint cache of a render of `sd` (larger with material rows: a second footprint per pixel)"""
     return int(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), int(spp)))
+
+
+def render_filter_bytes(sd):
+    """scratch of ffx_render_{fwd,bwd}_filtered for a render of `sd` (400 + 16 bytes per pixel)"""
+    return int(api().lib.ffx_render_filter_bytes(C.byref(sd)))
 
 
 def render_dot_slots(width, height):
@@ -676,6 +685,16 @@ class DeviceGeometry:
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         blob = self.blob  # (acquire first: the flag below speaks about the blob this call reads)
         flags = int(bool(fp16)) | self._apex_flag(apex_key(sd))
+        if sd.rfilter:  # a reconstruction filter that spreads samples over neighbouring pixels: its own entry point and a scratch area
+            if cache is not None:
+                raise ValueError("the adjoint cache folds box-filtered pixels: a filtered render differentiates through render_bwd (re-traced)")
+            scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device)  # (caching allocator, stream-ordered: renders on two streams never share one)
+            with self._timed("render_fwd"):
+                self._call("ffx_render_fwd_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
+                           _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _dev(scratch, torch.uint8),
+                           _stream(self._didx))
+            self._release()
+            return img
         if cache is not None:
             if cache.numel() < render_cache_bytes_sd(sd, spp):
                 raise ValueError("cache tensor too small")
@@ -701,6 +720,8 @@ class DeviceGeometry:
         -> (img, gtex): the render, and gtex (+)= its adjoint applied to gimg — `out`: accumulate into this [tex_h, tex_w, channels]
         tensor instead of a fresh zeroed one.  dot_out: _abi.ADJOINT_DOT_SLOTS float32 partial sums that <gimg, img> is added to."""
         H, W = sd.cam.height, sd.cam.width
+        if sd.rfilter:
+            raise ValueError("render_fwd_adjoint folds box-filtered pixels: with a reconstruction filter use render_fwd + render_bwd")
         mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device) if img_out is None else img_out
         if tuple(img.shape) != (H, W, 3) or img.dtype != (torch.float16 if fp16 else torch.float32):
@@ -741,6 +762,13 @@ class DeviceGeometry:
         mats_arg = _check_materials(sd, albedo)
         blob = self.blob
         self._apex_flag(apex_key(sd))  # (the call has no flags argument: it always writes its own apex records — which the areas then hold)
+        if sd.rfilter:
+            scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device)
+            with self._timed("render_bwd"):
+                self._call("ffx_render_bwd_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp), int(seed) & 0xFFFFFFFF,
+                           _dev(gimg, name="gimg"), _dev(gtex), _dev(scratch, torch.uint8), _stream(self._didx))
+            self._release()
+            return gtex
         with self._timed("render_bwd"):
             self._call(
                 "ffx_render_bwd", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp),

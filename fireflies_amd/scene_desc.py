@@ -25,14 +25,30 @@ def camera_from_sensor(s, to_world=None):
     return camera_struct(s.to_world if to_world is None else to_world, s.K, s.near, s.far, s.width, s.height)
 
 
+def set_rfilter(sd, rfilter):
+    """the film's reconstruction filter: None / "box", "gaussian" or ("gaussian", stddev) — Mitsuba's `gaussian` is hdrfilm's default
+    (include/ffx.h, ffx_scene_desc.rfilter); rendered by ffx_render_{fwd,bwd}_filtered"""
+    kind, stddev = (rfilter, 0.0) if rfilter is None or isinstance(rfilter, str) else (rfilter[0], float(rfilter[1]))
+    if kind in (None, "box"):
+        sd.rfilter, sd.rfilter_stddev = _abi.RFILTER_BOX, 0.0
+    elif kind == "gaussian":
+        if stddev < 0.0 or stddev > 0.5:
+            raise ValueError(f"gaussian reconstruction filter: stddev {stddev} outside (0, 0.5] (radius 4 stddev must fit the 5x5-pixel window)")
+        sd.rfilter, sd.rfilter_stddev = _abi.RFILTER_GAUSSIAN, stddev
+    else:
+        raise ValueError(f"reconstruction filter {kind!r}: box and gaussian are implemented")
+    return sd
+
+
 def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shadows=True, cam_to_world=None, proj_to_world=None,
-               spot_to_world=None, spot_intensity=None, mat_stride=0, base_tex=None, slot_uv=None, host_mats=None):
+               spot_to_world=None, spot_intensity=None, mat_stride=0, base_tex=None, slot_uv=None, host_mats=None, rfilter=None):
     """ffx_scene_desc for a scenes.SceneData.  `color` is the RGB weight of a 1-channel projector
     texture (the reference packs the laser texture into the green channel,
     examples/vocalfold_scene.py:64-67)."""
     sd = _abi.SceneDesc()
     sd.cam = camera_from_sensor(scene.camera, cam_to_world)
     sd.shadows = int(bool(shadows))
+    set_rfilter(sd, rfilter)
     sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
     sd.mat_stride = int(mat_stride)  # 0 / 3: the material table is [S,3] Lambert albedos; 16: material rows (scenes.material_rows)
     if host_mats is not None:  # the material table travels with the call (kernel arguments): [n_shapes, 3 | 16] host array

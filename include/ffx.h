@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 5
+#define FFX_ABI_VERSION 6
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -512,7 +512,21 @@ typedef struct ffx_scene_desc {
    * a randomisation then enqueues no host-to-device copy at all — like the per-shape transforms of ffx_scene_update_h. */
   int32_t n_mat_h;
   float mat_h[128];
+  /* The film's reconstruction filter (ABI 6).  FFX_RFILTER_BOX: a sample counts for the pixel it was drawn in, weight 1 (what every
+   * call below computes).  FFX_RFILTER_GAUSSIAN: Mitsuba's `gaussian` — the default of `hdrfilm`, which every scene the reference
+   * loads gets because none declares an <rfilter> (examples/vocalfold_scene.py:20-22, main.py:26-29) [EXT Mitsuba 3.5
+   * src/rfilters/gaussian.cpp, src/render/imageblock.cpp put(), src/films/hdrfilm.cpp develop(); not in /root/reference]:
+   *   g(x) = max(0, exp(-x^2 / (2 stddev^2)) - exp(-radius^2 / (2 stddev^2))),  radius = 4 stddev,  stddev default 0.5;
+   *   a sample at film position (x + jx, y + jy) adds  w = g(cx - x - jx) g(cy - y - jy)  times its radiance, and w itself, to every
+   *   pixel whose centre (cx, cy) = (i + 0.5, j + 0.5) is closer than `radius` along both axes;  pixel = sum(w L) / sum(w)
+   *   (0 where no weight arrived).  Samples are drawn inside the film only (no border samples).
+   * Served by ffx_render_fwd_filtered / ffx_render_bwd_filtered only (stddev <= 0.5: a 5x5-pixel window); every other render call
+   * answers FFX_ERR_UNSUPPORTED for rfilter != 0 rather than rendering another filter than the one asked for. */
+  int32_t rfilter;
+  float rfilter_stddev; /* 0: the default, 0.5 */
 } ffx_scene_desc;
+#define FFX_RFILTER_BOX 0
+#define FFX_RFILTER_GAUSSIAN 1
 #define FFX_MAX_MAT_H 128
 
 /* Material rows (mat_stride == FFX_MAT_STRIDE): shape_albedo is then [n_shapes, 16] floats.  Model 1 is the reflection
@@ -628,6 +642,26 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shap
  * it SYNCHRONISES `stream` (a 64-byte device-to-host read).  dropped != 0: fall back to ffx_render_bwd.
  * (The oracle's cache is one record per sample and never drops: {0, 0, 0}.) */
 int ffx_render_cache_status(const void *cache /*[dev]*/, uint32_t *out3 /*[host][3]*/, ffx_stream stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * K8 / K9 through a reconstruction filter that spreads a sample over neighbouring pixels (ffx_scene_desc.rfilter, above).
+ * Forward: the render kernel leaves, per pixel, the 25 x (r, g, b, weight) sums its own samples contribute to the pixels of its
+ * 5x5 window (`scratch`: 400 bytes per pixel), and a second launch gathers each pixel's 25 incoming sums and divides by the weight.
+ * Adjoint: with  G[p] = gimg[p] / weight[p],  a sample's radiance receives  sum_n w_n(sample) G[p + n]  — the filter's transpose —
+ * and is scattered through its bilinear texture taps as in ffx_render_bwd (re-traced: same seed, same samples; gtex ACCUMULATED).
+ * The weights depend on the jitter only, so the adjoint recomputes them (it needs no state of the forward call, only scratch).
+ * scratch: ffx_render_filter_bytes(sd) bytes of device memory, contents irrelevant before and after either call.
+ * ---------------------------------------------------------------------------------------- */
+size_t ffx_render_filter_bytes(const ffx_scene_desc *sd /*[host]*/);
+int ffx_render_fwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                            const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
+                            int img_fp16 /* FFX_RENDER_FP16 | FFX_RENDER_APEX_READY */, void *img /*[dev][H,W,3]*/, void *scratch /*[dev]*/,
+                            ffx_stream stream);
+int ffx_render_bwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                            const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed,
+                            const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, void *scratch /*[dev]*/,
+                            ffx_stream stream);
 
 #ifdef __cplusplus
 }

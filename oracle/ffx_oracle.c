@@ -1503,6 +1503,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h; /* the material table travels with the call */
   if (!bvh || !info || !sd || !shape_albedo || !img || spp < 1) FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
+  if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd: the scene's reconstruction filter is not the box (use ffx_render_fwd_filtered)");
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_fwd: bad scene description");
   c.mats = shape_albedo;
@@ -1630,6 +1631,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   (void)s;
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
   if (!sd->proj.enabled) {
     if (dot_out) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> needs a projector (as in libffx_hip)");
     return FFX_OK;
@@ -1676,6 +1678,7 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   (void)s;
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+  if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
   if (!sd->proj.enabled) return FFX_OK;
   shade_ctx c;
   if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_bwd: bad scene description");
@@ -1710,6 +1713,221 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
         if (st.proj_fac_b != 0.f) {
           if (c.tc == 3) wsum += g[tch] * st.proj_fac_b * inv_spp;
           else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * st.proj_fac_b * inv_spp;
+        }
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b) acc[((size_t)st.iy[a] * c.tw + st.ix[b]) * c.tc + tch] += (double)(wsum * st.wy[a] * st.wx[b]);
+      }
+    }
+  }
+  for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
+  free(acc);
+  return FFX_OK;
+}
+
+/* =========================================================================================
+ * K8 / K9 through a gaussian reconstruction filter (include/ffx.h, ffx_scene_desc.rfilter) [EXT Mitsuba 3.5
+ * src/rfilters/gaussian.cpp eval(): max(0, exp(alpha x^2) - bias), alpha = -1 / (2 stddev^2), bias = exp(alpha radius^2),
+ * radius = 4 stddev; src/render/imageblock.cpp put(): every pixel whose centre lies within `radius` of the sample along both
+ * axes receives weight g(dx) g(dy) times the value, and the weight itself in the film's weight channel;
+ * src/films/hdrfilm.cpp develop(): colour / weight].  Two levels of summation, in the order the HIP path uses: a pixel's own
+ * samples first (per target pixel of its 5x5 window, samples ascending), then each pixel's 25 incoming sums (window row-major).
+ * ========================================================================================= */
+typedef struct { float alpha, bias; } rf_ctx;
+static int rf_prepare(const ffx_scene_desc *sd, rf_ctx *r) {
+  if (sd->rfilter != FFX_RFILTER_GAUSSIAN) return 0;
+  const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
+  if (!(sdv <= 0.5f)) return 0; /* radius 4 stddev <= 2: the 5x5-pixel window */
+  r->alpha = -1.0f / (2.0f * sdv * sdv);
+  r->bias = expf(r->alpha * (4.0f * sdv) * (4.0f * sdv));
+  return 1;
+}
+/* the five weights along one axis of a sample with jitter j in [0, 1): window pixel a (0..4) has its centre at a - 2 + 0.5 - j */
+static inline void rf_weights(const rf_ctx *r, float j, float w[5]) {
+  for (int a = 0; a < 5; ++a) {
+    const float x = ((float)(a - 2) + 0.5f) - j;
+    const float g = expf(r->alpha * (x * x)) - r->bias;
+    w[a] = g > 0.f ? g : 0.f;
+  }
+}
+size_t ffx_render_filter_bytes(const ffx_scene_desc *sd) {
+  if (!sd || sd->cam.width < 1 || sd->cam.height < 1) return 0;
+  return (size_t)sd->cam.width * sd->cam.height * (25 * 4 + 4) * sizeof(float); /* as libffx_hip: outgoing sums + G */
+}
+/* radiance of one shaded sample (the sum the box render accumulates per pixel, above) */
+static inline void sample_radiance(const shade_ctx *c, const float *tex, const sample_terms *st, float out[3]) {
+  out[0] = out[1] = out[2] = 0.f;
+  if (!st->hit) return;
+  const float *alb = st->base;
+  float rgb[3] = {st->spot_rgb[0], st->spot_rgb[1], st->spot_rgb[2]};
+  float rgb_b[3] = {st->spot_rgb_b[0], st->spot_rgb_b[1], st->spot_rgb_b[2]};
+  if (st->has_proj) {
+    for (int ch = 0; ch < 3; ++ch) {
+      int tch = (c->tc == 3) ? ch : 0;
+      float t00 = tex[((size_t)st->iy[0] * c->tw + st->ix[0]) * c->tc + tch], t01 = tex[((size_t)st->iy[0] * c->tw + st->ix[1]) * c->tc + tch];
+      float t10 = tex[((size_t)st->iy[1] * c->tw + st->ix[0]) * c->tc + tch], t11 = tex[((size_t)st->iy[1] * c->tw + st->ix[1]) * c->tc + tch];
+      float tv = st->wy[0] * (st->wx[0] * t00 + st->wx[1] * t01) + st->wy[1] * (st->wx[0] * t10 + st->wx[1] * t11);
+      float col = (c->tc == 3) ? 1.0f : c->p_color[ch];
+      rgb[ch] += tv * col * st->proj_fac;
+      rgb_b[ch] += tv * col * st->proj_fac_b;
+    }
+  }
+  if (c->mat_stride == 3) for (int ch = 0; ch < 3; ++ch) out[ch] = alb[ch] * rgb[ch];
+  else for (int ch = 0; ch < 3; ++ch) out[ch] = alb[ch] * rgb[ch] + rgb_b[ch];
+}
+/* a pixel's 25 incoming sums -> (r, g, b, weight): window entry n = (a, b) of source pixel (x - (a - 2), y - (b - 2)) */
+static inline void rf_gather(const float *part, int W, int H, int x, int y, float out[4]) {
+  out[0] = out[1] = out[2] = out[3] = 0.f;
+  for (int b = 0; b < 5; ++b)
+    for (int a = 0; a < 5; ++a) {
+      const int qx = x - (a - 2), qy = y - (b - 2);
+      if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+      const float *p = part + ((size_t)(qy * W + qx) * 25 + (size_t)(b * 5 + a)) * 4;
+      for (int k = 0; k < 4; ++k) out[k] += p[k];
+    }
+}
+
+int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                            uint32_t seed, int img_fp16, void *img, void *scratch, ffx_stream s) {
+  (void)s;
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
+  if (!bvh || !info || !sd || !shape_albedo || !img || !scratch || spp < 1) FAIL(FFX_ERR_ARG, "render_fwd_filtered: bad argument");
+  if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd_filtered: projector enabled but tex is NULL");
+  rf_ctx rf;
+  if (!rf_prepare(sd, &rf)) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN with stddev <= 0.5");
+  shade_ctx c;
+  if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_fwd_filtered: bad scene description");
+  c.mats = shape_albedo;
+  c.nrec = info->off_nrec ? (const float *)((const char *)bvh + info->off_nrec) : NULL;
+  const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
+  const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
+  const int W = c.cam.W, H = c.cam.H;
+  float *part = (float *)scratch; /* [H*W][25][4] */
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int pix = 0; pix < W * H; ++pix) {
+    const int x = pix % W, y = pix / W;
+    float *pp = part + (size_t)pix * 100;
+    for (int k = 0; k < 100; ++k) pp[k] = 0.f;
+    for (int sidx = 0; sidx < spp; ++sidx) {
+      uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
+      float jx, jy;
+      sample_jitter(seed, idx, &jx, &jy);
+      v3 d;
+      float nt, ft;
+      cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
+      sample_terms st;
+      shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
+      float L[4];
+      sample_radiance(&c, tex, &st, L);
+      L[3] = 1.0f; /* the weight channel: every sample drawn counts, lit or not */
+      float gx[5], gy[5];
+      rf_weights(&rf, jx, gx);
+      rf_weights(&rf, jy, gy);
+      for (int b = 0; b < 5; ++b)
+        for (int a = 0; a < 5; ++a) {
+          const float w = gx[a] * gy[b];
+          for (int k = 0; k < 4; ++k) pp[(b * 5 + a) * 4 + k] = fmaf(w, L[k], pp[(b * 5 + a) * 4 + k]);
+        }
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int pix = 0; pix < W * H; ++pix) {
+    float acc[4];
+    rf_gather(part, W, H, pix % W, pix / W, acc);
+    for (int ch = 0; ch < 3; ++ch) {
+      const float v = acc[3] > 0.f ? acc[ch] / acc[3] : 0.f;
+      if (img_fp16 & 1) ((uint16_t *)img)[(size_t)pix * 3 + ch] = f32_to_f16(v);
+      else ((float *)img)[(size_t)pix * 3 + ch] = v;
+    }
+  }
+  return FFX_OK;
+}
+
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                            const float *gimg, float *gtex, void *scratch, ffx_stream s) {
+  (void)s;
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
+  if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || !scratch || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd_filtered: bad argument");
+  rf_ctx rf;
+  if (!rf_prepare(sd, &rf)) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN with stddev <= 0.5");
+  if (!sd->proj.enabled) return FFX_OK;
+  shade_ctx c;
+  if (!shade_prepare(sd, &c)) FAIL(FFX_ERR_ARG, "render_bwd_filtered: bad scene description");
+  c.mats = shape_albedo;
+  c.nrec = info->off_nrec ? (const float *)((const char *)bvh + info->off_nrec) : NULL;
+  const onode *nodes = (const onode *)((const char *)bvh + info->off_nodes);
+  const orec *recs = (const orec *)((const char *)bvh + info->off_recs);
+  const int W = c.cam.W, H = c.cam.H;
+  /* 1. the weight every pixel received (the jitter alone decides it), then G = gimg / weight */
+  float *part = (float *)scratch; /* [H*W][25] weight sums, then G [H*W][4] behind them */
+  float *G = part + (size_t)W * H * 25;
+  for (int pix = 0; pix < W * H; ++pix) {
+    float *pp = part + (size_t)pix * 25;
+    for (int k = 0; k < 25; ++k) pp[k] = 0.f;
+    for (int sidx = 0; sidx < spp; ++sidx) {
+      float jx, jy, gx[5], gy[5];
+      sample_jitter(seed, (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx, &jx, &jy);
+      rf_weights(&rf, jx, gx);
+      rf_weights(&rf, jy, gy);
+      for (int b = 0; b < 5; ++b)
+        for (int a = 0; a < 5; ++a) pp[b * 5 + a] += gx[a] * gy[b];
+    }
+  }
+  for (int pix = 0; pix < W * H; ++pix) {
+    const int x = pix % W, y = pix / W;
+    float wsum = 0.f;
+    for (int b = 0; b < 5; ++b)
+      for (int a = 0; a < 5; ++a) {
+        const int qx = x - (a - 2), qy = y - (b - 2);
+        if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
+        wsum += part[(size_t)(qy * W + qx) * 25 + (size_t)(b * 5 + a)];
+      }
+    for (int ch = 0; ch < 3; ++ch) G[(size_t)pix * 4 + ch] = wsum > 0.f ? gimg[(size_t)pix * 3 + ch] / wsum : 0.f;
+    G[(size_t)pix * 4 + 3] = 0.f;
+  }
+  /* 2. re-trace: a sample's radiance receives sum_n w_n G[pixel + n]; from there as ffx_render_bwd without the 1 / spp */
+  size_t nt_ = (size_t)c.tw * c.th * c.tc;
+  double *acc = (double *)calloc(nt_, sizeof(double));
+  if (!acc) FAIL(FFX_ERR_NOMEM, "render_bwd_filtered: out of memory");
+  for (int pix = 0; pix < W * H; ++pix) { /* serial on purpose: deterministic double accumulation */
+    const int x = pix % W, y = pix / W;
+    int any = 0;
+    for (int b = 0; b < 5 && !any; ++b)
+      for (int a = 0; a < 5 && !any; ++a) {
+        const int tx = x + (a - 2), ty = y + (b - 2);
+        if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+        const float *gp = G + (size_t)(ty * W + tx) * 4;
+        any = gp[0] != 0.f || gp[1] != 0.f || gp[2] != 0.f;
+      }
+    if (!any) continue;
+    for (int sidx = 0; sidx < spp; ++sidx) {
+      uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
+      float jx, jy;
+      sample_jitter(seed, idx, &jx, &jy);
+      v3 d;
+      float nt, ft;
+      cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
+      sample_terms st;
+      shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
+      if (!st.hit || !st.has_proj) continue;
+      float gx[5], gy[5], g[3] = {0.f, 0.f, 0.f};
+      rf_weights(&rf, jx, gx);
+      rf_weights(&rf, jy, gy);
+      for (int b = 0; b < 5; ++b)
+        for (int a = 0; a < 5; ++a) {
+          const int tx = x + (a - 2), ty = y + (b - 2);
+          if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+          const float w = gx[a] * gy[b];
+          const float *gp = G + (size_t)(ty * W + tx) * 4;
+          for (int ch = 0; ch < 3; ++ch) g[ch] = fmaf(w, gp[ch], g[ch]);
+        }
+      const float *alb = st.base;
+      for (int tch = 0; tch < c.tc; ++tch) {
+        float wsum;
+        if (c.tc == 3) wsum = g[tch] * alb[tch] * st.proj_fac;
+        else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * st.proj_fac;
+        if (st.proj_fac_b != 0.f) {
+          if (c.tc == 3) wsum += g[tch] * st.proj_fac_b;
+          else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * st.proj_fac_b;
         }
         for (int a = 0; a < 2; ++a)
           for (int b = 0; b < 2; ++b) acc[((size_t)st.iy[a] * c.tw + st.ix[b]) * c.tc + tch] += (double)(wsum * st.wy[a] * st.wx[b]);

@@ -319,6 +319,10 @@ class Geometry:
         tex = _f32(tex)
         H, W = sd.cam.height, sd.cam.width
         img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
+        if sd.rfilter:  # a reconstruction filter that spreads samples over neighbouring pixels: its own entry points (include/ffx.h)
+            scratch = np.empty(api().lib.ffx_render_filter_bytes(C.byref(sd)), np.uint8)
+            api().call("ffx_render_fwd_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(scratch), None)
+            return img
         api().call("ffx_render_fwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), None)
         return img
 
@@ -357,5 +361,9 @@ class Geometry:
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         albedo, gimg = _f32(albedo), _f32(gimg)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        if sd.rfilter:
+            scratch = np.empty(api().lib.ffx_render_filter_bytes(C.byref(sd)), np.uint8)
+            api().call("ffx_render_bwd_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, _p(gimg), _p(gtex), _p(scratch), None)
+            return gtex
         api().call("ffx_render_bwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, _p(gimg), _p(gtex), None)
         return gtex

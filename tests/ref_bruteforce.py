@@ -372,7 +372,43 @@ def _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, mats, smooth=None, ve
     return out
 
 
-def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=None, vert_uv=None, base_tex=None):
+def _gaussian(x, stddev):
+    """Mitsuba's `gaussian` reconstruction filter [EXT src/rfilters/gaussian.cpp]: radius 4 stddev, shifted so that it ends at zero"""
+    alpha, r = -1.0 / (2.0 * stddev * stddev), 4.0 * stddev
+    return np.maximum(0.0, np.exp(alpha * x * x) - np.exp(alpha * r * r))
+
+
+def _film_positions(W, H, spp, seed):
+    idx = np.arange(W * H * spp, dtype=np.uint64)
+    pix = idx // spp
+    jx, jy = jitter(seed, idx)
+    return (pix % W).astype(np.int64), (pix // W).astype(np.int64), (pix % W) + jx, (pix // W) + jy  # pixel, film position in pixels
+
+
+def _film_splat(W, H, spp, seed, stddev, values=None, gather=None):
+    """the film of ImageBlock::put [EXT src/render/imageblock.cpp], formed from ABSOLUTE positions (sample position vs pixel centres):
+    values [N,k]: -> (sum w values [H,W,k], sum w [H,W]);  gather [H,W,k]: -> per sample sum_pixels w gather[pixel] (the transpose)"""
+    x, y, fx, fy = _film_positions(W, H, spp, seed)
+    r = int(np.ceil(4.0 * stddev))
+    num = np.zeros((H, W, values.shape[1])) if values is not None else None
+    den = np.zeros((H, W))
+    back = np.zeros((len(x), gather.shape[2])) if gather is not None else None
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            tx, ty = x + dx, y + dy
+            ok = (tx >= 0) & (tx < W) & (ty >= 0) & (ty < H)
+            w = _gaussian((tx + 0.5) - fx, stddev) * _gaussian((ty + 0.5) - fy, stddev)
+            w = np.where(ok, w, 0.0)
+            txc, tyc = np.clip(tx, 0, W - 1), np.clip(ty, 0, H - 1)
+            np.add.at(den, (tyc, txc), w)
+            if num is not None:
+                np.add.at(num, (tyc, txc), w[:, None] * values)
+            if back is not None:
+                back += w[:, None] * gather[tyc, txc]
+    return num, den, back
+
+
+def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=None, vert_uv=None, base_tex=None, gaussian_stddev=None):
     s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth, vert_uv, base_tex)
     W, H = sd.cam.width, sd.cam.height
     rad = s["spot"].copy()
@@ -387,14 +423,26 @@ def render_fwd(verts, tri_idx, tri_shape, sd, albedo, tex, spp, seed, smooth=Non
             tv = w00[:, None] * tex[y0, x0] + w01[:, None] * tex[y0, x1] + w10[:, None] * tex[y1, x0] + w11[:, None] * tex[y1, x1]
             rad += tv * s["pfac"]
     rad = np.where(s["hit"][:, None], rad, 0.0)
+    if gaussian_stddev is not None:  # hdrfilm's default filter: weighted sum over weight [EXT src/films/hdrfilm.cpp develop()]
+        num, den, _ = _film_splat(W, H, spp, seed, gaussian_stddev, values=rad)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(den[..., None] > 0, num / den[..., None], 0.0)
     return rad.reshape(H, W, spp, 3).mean(2)
 
 
-def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg, smooth=None, vert_uv=None, base_tex=None):
+def render_bwd(verts, tri_idx, tri_shape, sd, albedo, spp, seed, gimg, smooth=None, vert_uv=None, base_tex=None, gaussian_stddev=None):
     """d <img, gimg> / d tex for a 1-channel texture"""
     s = _shade_terms(verts, tri_idx, tri_shape, sd, spp, seed, albedo, smooth, vert_uv, base_tex)
-    g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
-    ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) / spp
+    if gaussian_stddev is not None:
+        W, H = sd.cam.width, sd.cam.height
+        _, den, _ = _film_splat(W, H, spp, seed, gaussian_stddev)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            G = np.where(den[..., None] > 0, np.asarray(gimg, np.float64).reshape(H, W, 3) / den[..., None], 0.0)
+        _, _, g = _film_splat(W, H, spp, seed, gaussian_stddev, gather=G)
+        ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1)
+    else:
+        g = np.repeat(np.asarray(gimg, np.float64).reshape(-1, 3), spp, axis=0)
+        ws = (g * s["pfac"] * np.asarray(list(sd.proj.color), np.float64)[None]).sum(1) / spp
     ws = np.where(s["hit"], ws, 0.0)
     gt = np.zeros((sd.proj.tex_h, sd.proj.tex_w))
     (x0, x1, y0, y1), (w00, w01, w10, w11) = s["taps"], s["w"]

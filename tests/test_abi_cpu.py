@@ -92,7 +92,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.Projector) == 4 * (16 + 16 + 1 + 3 + 4)
     assert C.sizeof(_abi.Spot) == 4 * (16 + 3 + 2 + 1)
     # shadows, n_shapes, mat_stride; n_base_tex + 2 x 4 sizes, 4 texture pointers, slot_uv; n_mat_h + 128 inline material floats (+ 4 of padding)
-    assert C.sizeof(_abi.SceneDesc) == C.sizeof(_abi.Camera) + C.sizeof(_abi.Projector) + C.sizeof(_abi.Spot) + 12 + 4 + 32 + 32 + 8 + 4 + 512 + 4
+    assert C.sizeof(_abi.SceneDesc) == C.sizeof(_abi.Camera) + C.sizeof(_abi.Projector) + C.sizeof(_abi.Spot) + 12 + 4 + 32 + 32 + 8 + 4 + 512 + 4 + 4 + 4  # (... n_mat_h, mat_h, rfilter, rfilter_stddev, tail padding)
     # 4 ints, 5 offsets, level_start, 4 ints of the wide overlay (+ 4 bytes of padding to 8), 4 offsets; ABI 4: the refit plan's offset + 2 ints
     assert C.sizeof(_abi.BvhInfo) == 16 + 5 * 8 + 4 * (_abi.FFX_MAX_LEVELS + 1) + 16 + 4 + 4 * 8 + 8 + 8 + 8 + 8 + 16  # (+ off_nrec, off_gn; ABI 5: off_bins, bins_stride)
     assert C.sizeof(_abi.Smooth) == 8 * 4 + 4 + 4 + 8  # four pointers, n_vn (+ padding), one pointer

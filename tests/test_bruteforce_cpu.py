@@ -302,3 +302,60 @@ def test_oracle_render_with_interpolated_normals_agrees_with_bruteforce(oracle):
     go.update(xf, offs)
     smooth_img = go.render_fwd(sd, alb, tex, spp, seed=4)
     assert np.abs(flat - smooth_img).max() > 0.02 * float(flat.max())
+
+
+@pytest.mark.parametrize("which", ["hello_world", "vocalfold"])
+def test_gaussian_reconstruction_filter_oracle_agrees_with_bruteforce(oracle, which):
+    """ffx_scene_desc.rfilter = gaussian (hdrfilm's default, which the reference's scenes get): the oracle's two-level sums
+    (a pixel's own samples per window entry, then the 25 incoming sums) against the brute force's film formed from absolute sample
+    positions and pixel centres — image and texture gradient — plus the properties the filter must have: a constant radiance field
+    stays constant (weights normalised), the adjoint identity holds inside the brute force, and the filtered image differs from
+    the box image (the field is actually read)."""
+    if which == "hello_world":
+        sc, spp, xf, frame = scenes.hello_world(40, 32), 3, None, 0
+    else:
+        sc, spp, frame = scenes.vocalfold(width=24, height=20, tex=32, frames=3, n_fold=12, tube=(12, 16)), 5, 1
+        xf = _xf(len(sc.meshes), 4)
+    pool, tris, shape, off, offs, xf, alb, verts, gidx = _world(sc, frame, xf)
+    go = oracle.Geometry(pool, tris, shape, off)
+    go.update(xf, offs)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    rng = np.random.default_rng(2)
+    tex = rng.random((sc.projector.height, sc.projector.width)).astype(np.float32) if sc.projector is not None else np.zeros((1, 1), np.float32)
+    img_box = go.render_fwd(sd, alb, tex, spp, seed=11)
+    sd.rfilter, sd.rfilter_stddev = _abi.RFILTER_GAUSSIAN, 0.0  # (0: the default, 0.5)
+    img_o = go.render_fwd(sd, alb, tex, spp, seed=11)
+    img_b = bf.render_fwd(verts, gidx, shape, sd, alb, tex, spp, 11, gaussian_stddev=0.5)
+    scale = float(img_b.max())
+    assert scale > 0.01 and float(np.abs(img_o - img_box).max()) > 0.02 * scale
+    err = np.abs(img_o - img_b)
+    # (a sample that flips on an edge now spreads over its 5x5 window: a few more pixels carry a part of it)
+    assert (err > 3e-4 * scale).mean() <= 5e-2, f"{which}: {(err > 3e-4 * scale).mean():.3f} of the pixel channels differ"
+    assert err.max() <= 1.5 * scale / spp
+    assert abs(float(img_o.mean()) - float(img_b.mean())) <= 2e-3 * float(img_b.mean())
+    # a narrower filter too (stddev 0.3: radius 1.2, window entries at distance 2 get no weight)
+    sd.rfilter_stddev = 0.3
+    e3 = np.abs(go.render_fwd(sd, alb, tex, spp, seed=11) - bf.render_fwd(verts, gidx, shape, sd, alb, tex, spp, 11, gaussian_stddev=0.3))
+    assert (e3 > 3e-4 * scale).mean() <= 5e-2 and e3.max() <= 1.5 * scale / spp
+    sd.rfilter_stddev = 0.5
+    # the fp16 film rounds the filtered value once
+    np.testing.assert_array_equal(go.render_fwd(sd, alb, tex, spp, seed=11, fp16=True), img_o.astype(np.float16))
+    if sc.projector is None:
+        return
+    gimg = rng.standard_normal((sc.camera.height, sc.camera.width, 3)).astype(np.float32)
+    gt_o = go.render_bwd(sd, alb, spp, 11, gimg)[..., 0]
+    gt_b = bf.render_bwd(verts, gidx, shape, sd, alb, spp, 11, gimg, gaussian_stddev=0.5)
+    gs = float(np.abs(gt_b).max())
+    assert gs > 0
+    gerr = np.abs(gt_o - gt_b)
+    assert (gerr > 1e-3 * gs).mean() <= 2e-2 and gerr.max() <= 0.5 * gs
+    base = bf.render_fwd(verts, gidx, shape, sd, alb, np.zeros_like(tex), spp, 11, gaussian_stddev=0.5)
+    lhs, rhs = float(((img_b - base) * gimg).sum()), float((tex.astype(np.float64) * gt_b).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1e-12)
+    # ... and in the oracle (float32: looser)
+    base_o = go.render_fwd(sd, alb, np.zeros_like(tex), spp, seed=11).astype(np.float64)
+    lhs_o, rhs_o = float(((img_o - base_o) * gimg).sum()), float((tex.astype(np.float64) * gt_o).sum())
+    assert abs(lhs_o - rhs_o) <= 2e-4 * max(abs(lhs_o), abs(rhs_o))
+    # every other render call refuses the filter instead of rendering a box
+    with pytest.raises(Exception, match="reconstruction filter"):
+        go.render_fwd_cache(sd, alb, tex, spp, seed=11)

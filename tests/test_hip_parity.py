@@ -1071,6 +1071,8 @@ def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, si
         (r_c, m_c, v_c, st_c), (r_e, m_e, v_e, st_e) = fresh(), fresh()
         _, ts_c, to_c, ws_c, _ = ops.pattern_fwd_blur(r_c, KF, sigma, s0, s1, ks, bs, True)
         part = torch.empty(n, device="cuda")
+        # (grad_out as a temporary: ops.adam_args keeps the tensors it takes addresses of alive — a freed one used to be handed to the NEXT small
+        # allocation, the launch's 3-float value buffer, which the update's gradient store then overwrote: val_c[0] came back as a gradient)
         aa = ops.adam_args(r_c, m_c, v_c, st_c, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=torch.empty_like(r_c), dot=(a_d, b_d, part))
         _, _, val_c = ops.pattern_bwd_blur(r_c, KF, sigma, s0, s1, ts_c, to_c, dev(gtex), 0.1, ws_c, ks, bs, loss_div=4.0, adam=aa, scratch=torch.empty_like(ts_c))
         aa = ops.adam_args(r_e, m_e, v_e, st_e, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=torch.empty_like(r_e))
@@ -1497,3 +1499,97 @@ def test_the_in_kernel_update_is_skipped_when_the_adjoint_cache_dropped_samples(
             assert torch.equal(r, dev(rays)) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0 and float(st) == 0.0 and int(counter) == 0
         else:
             assert not torch.equal(r, dev(rays)) and float(st) == 1.0 and bool(torch.isfinite(r).all()) and int(counter) == 0
+
+
+# ------------------------------------------------------------------ reconstruction filter (ffx_scene_desc.rfilter)
+@pytest.mark.parametrize("ch,rows,spp,stddev", [(1, "albedo", 8, 0.5), (3, "albedo", 8, 0.5), (1, "material_rows", 70, 0.5), (1, "albedo", 5, 0.3)])
+def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(oracle, ch, rows, spp, stddev):
+    """hdrfilm's default filter, which every scene the reference loads gets: ffx_render_fwd_filtered / ffx_render_bwd_filtered against the
+    oracle's (itself checked against the float64 brute force, tests/test_bruteforce_cpu.py) — image, fp16 film, texture gradient — for both
+    texture layouts, Lambert and material rows, one and two 64-sample passes per pixel and a narrower filter; every other render entry point
+    refuses the scene instead of rendering a box."""
+    from fireflies_amd import _abi
+
+    sc = scenes.vocalfold(width=72, height=64, tex=96, frames=3, n_fold=24, tube=(24, 32))
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 2))
+    if rows == "material_rows":
+        from tests.test_bruteforce_cpu import material_rows
+
+        alb = material_rows(len(sc.meshes), 5)
+    sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=_abi.MAT_STRIDE if rows == "material_rows" else 0, rfilter=("gaussian", stddev))
+    assert sd.rfilter == _abi.RFILTER_GAUSSIAN
+    tex = _tex(sc, ch)
+    img_d = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=11))
+    img_o = go.render_fwd(sd, alb, host(tex), spp, seed=11)
+    assert img_o.max() > 0.05
+    # (a sample that flips on an edge is spread over its window: the share of touched pixels is up to 25x the box render's)
+    scale, _ = _assert_image_close(img_d, img_o, spp, frac=0.02, what=f"gaussian ch={ch} {rows} spp={spp}")
+    sd_box = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=sd.mat_stride)
+    box = host(gd.render_fwd(sd_box, dev(alb), tex, spp, seed=11))
+    assert np.abs(box - img_d).max() > 0.02 * scale  # the field is read
+    assert abs(float(box.mean()) - float(img_d.mean())) < 0.02 * float(box.mean())  # ... and the filter is normalised
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, spp, seed=11), gd.render_fwd(sd, dev(alb), tex, spp, seed=11))  # no atomics
+    img_h = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=11, fp16=True)).astype(np.float32)
+    np.testing.assert_allclose(img_h, img_d, rtol=1e-3, atol=1e-4 * scale)
+    # ---- adjoint
+    rng = np.random.default_rng(1)
+    gimg = rng.standard_normal((64, 72, 3)).astype(np.float32)
+    gimg[:, :20] = 0.0  # (pixels whose whole window carries no gradient are skipped: the border of this block must still get its share)
+    gt_d = host(gd.render_bwd(sd, dev(alb), spp, 11, dev(gimg)))
+    gt_o = go.render_bwd(sd, alb, spp, 11, gimg)
+    gs = float(np.abs(gt_o).max())
+    assert gs > 0
+    err = np.abs(gt_d - gt_o)
+    assert (err > 1e-3 * gs).mean() <= 2e-3, f"{(err > 1e-3 * gs).mean():.2e}"
+    assert err.max() <= 0.1 * gs
+    # the two directions are transposes of each other on the device itself
+    base = host(gd.render_fwd(sd, dev(alb), torch.zeros_like(tex), spp, seed=11)).astype(np.float64)
+    lhs = float(((img_d - base) * gimg).sum())
+    rhs = float((host(tex).astype(np.float64).reshape(gt_d.shape) * gt_d).sum())
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+    # ---- the box-only entry points refuse
+    cache = torch.empty(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="box"):
+        gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
+    with pytest.raises(ValueError, match="box"):
+        gd.render_fwd_adjoint(sd, dev(alb), tex, spp, 11, dev(gimg))
+    lib, UNSUPPORTED = ops.api(), -3  # FFX_ERR_UNSUPPORTED
+    img_t = torch.empty((64, 72, 3), device="cuda")
+    mats_arg = dev(alb).data_ptr()
+    rc = lib.lib.ffx_render_fwd(gd.blob.data_ptr(), C.byref(gd.info), C.byref(sd), mats_arg, tex.data_ptr(), spp, 11, 0, img_t.data_ptr(), None)
+    assert rc == UNSUPPORTED and "reconstruction filter" in lib.lib.ffx_last_error().decode()
+    rc = lib.lib.ffx_render_bwd(gd.blob.data_ptr(), C.byref(gd.info), C.byref(sd), mats_arg, spp, 11, dev(gimg).data_ptr(), torch.zeros_like(tex).data_ptr(), None)
+    assert rc == UNSUPPORTED
+
+
+def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
+    """mi.Scene.rfilter = "gaussian": mi.render goes through the filtered entry points (also beside the previous render on the scene's second
+    stream), autograd differentiates through the re-traced filtered adjoint, and the optimiser takes its re-trace path."""
+    from fireflies_amd import functional as Fn, mi, workloads
+    from fireflies_amd.optim import PatternOptimizer
+
+    wl = workloads.vocalfold(device="cuda", width=64, height=56, tex=96, grid=6, frames=5, n_fold=20, tube=(20, 24))
+    ms = wl.mi_scene
+    assert ms.rfilter == "box"
+    tex = ms._params["tex.data"]
+    tex = (tex.t if hasattr(tex, "t") else tex).detach().clone()
+    box = mi.render(ms, spp=8, seed=3).torch().clone()
+    ms.rfilter = "gaussian"
+    sd = ms.scene_desc(tex_channels=1 if tex.dim() == 2 else int(tex.shape[-1]))
+    assert sd.rfilter == 1 and not Fn.cache_supported(sd, 8)
+    a = mi.render(ms, spp=8, seed=3).torch().clone()
+    b = mi.render(ms, spp=8, seed=3).torch().clone()  # (the second call runs on the other render stream)
+    assert torch.equal(a, b) and not torch.equal(a, box)
+    t = tex.clone().requires_grad_(True)
+    ms._params["tex.data"] = t
+    img = mi.render(ms, spp=8, seed=3).torch()
+    w = torch.randn_like(img)
+    (img * w).sum().backward()
+    want = ms.geom.render_bwd(sd, ms.materials_arg(sd), 8, 3, w.contiguous())
+    torch.testing.assert_close(t.grad.reshape(want.shape), want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+    ms._params["tex.data"] = tex
+    opt = PatternOptimizer(ms, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=2)
+    before = wl.laser._rays.detach().clone()
+    res = opt.step()
+    assert opt.step_paths["retrace"] == 2 and opt.step_paths["fused"] == 0 and opt.step_paths["cache_k9"] == 0
+    assert np.isfinite(float(res["loss"])) and not torch.equal(before, wl.laser._rays.detach())

@@ -142,7 +142,7 @@ def test_nothing_the_file_asks_for_is_dropped_silently(tmp_path):
     """Every node or property of a scene file that the reader does not honour is reported (round 2 dropped <integrator>,
     <rfilter>, <sampler> and fov_axis without a word): deep integrators, Mitsuba's default gaussian film filter, other
     samplers, unknown top-level nodes and properties, area emitters, textures, spec_trans.  A file that asks only for what
-    is implemented (path with max_depth 2, box filter, independent sampler) loads without any warning."""
+    is implemented (path with max_depth 2, box or gaussian filter, independent sampler) loads without any warning."""
     import warnings
 
     wv, wt = scenes.make_plane(0.0, 1.0, 2, 2)
@@ -164,8 +164,14 @@ def test_nothing_the_file_asks_for_is_dropped_silently(tmp_path):
     assert msgs == [], msgs
     assert sc.notes["integrator"] == {"type": "path", "max_depth": 2} and sc.notes["rfilter"] == "box" and sc.notes["sample_count"] == 64
     # the plain file: Mitsuba's defaults are a gaussian film filter and an unbounded path integrator
-    _, msgs = load(XML)
-    assert any("no <integrator>" in m for m in msgs) and any("reconstruction filter 'gaussian' (the hdrfilm default)" in m for m in msgs)
+    # (the gaussian filter is implemented since round 4: it is selected — notes["rfilter"], which mi.Scene renders with — not reported)
+    sc_plain, msgs = load(XML)
+    assert any("no <integrator>" in m for m in msgs) and not any("reconstruction filter" in m for m in msgs)
+    assert sc_plain.notes["rfilter"] == "gaussian" and sc_plain.notes["rfilter_stddev"] == 0.5
+    sc_g, msgs = load(clean.replace('<rfilter type="box"/>', '<rfilter type="gaussian"><float name="stddev" value="0.4"/></rfilter>'))
+    assert msgs == [] and sc_g.notes["rfilter"] == "gaussian" and sc_g.notes["rfilter_stddev"] == pytest.approx(0.4)
+    _, msgs = load(clean.replace('<rfilter type="box"/>', '<rfilter type="gaussian"><float name="stddev" value="1.0"/></rfilter>'))
+    assert any("stddev 1.0" in m and "5x5" in m for m in msgs)
     # what round 2 swallowed
     noisy = (clean.replace('value="2"/></integrator>', 'value="8"/></integrator>\n<medium type="homogeneous"/>')
              .replace('<rfilter type="box"/>', '<rfilter type="tent"/>')
