@@ -2427,14 +2427,16 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 // A wave holds the 64 samples of ONE pixel, one per lane; what the film needs from it are 25 x (r, g, b, weight) sums over those samples —
 // 100 cross-lane reductions (7 instructions each as DPP chains: ~700 at the 4-cycle rate, +65 % on the kernel).  Instead the lanes change
 // roles through LDS: every lane parks its five weights per axis, its radiance and its "I am a sample" flag in 14 rows of 64 floats; then
-// lane l becomes OUTPUT l (window entry l / 4, channel l % 4; two rounds cover the 100) and runs over the 64 samples of the three rows
-// it needs with 16-byte LDS reads — 48 reads, 64 multiplies and 64 fused multiply-adds per round, all in the 2-cycle class, same
-// summation order as the oracle (samples ascending).  The rows alias the wide walk's stack (never live at the same time); the row pitch of
-// 68 floats puts the five rows a round reads into different banks.  Measured (tools/rftime.py, 512^2 x 64 spp): the render kernel 0.386 ->
-// 0.487 ms, as the instruction count says (2 x 128 two-cycle instructions + ~75 for the weights on ~3700 cycles per pixel).
-// Tried and dropped: the same sums on the matrix pipe — v_mfma_f32_16x16x4_f32 with rows = channel (4 of 16 used), columns = window entry,
-// K = samples (lanes ARE the K index: no role change, a fifth of the LDS traffic, bit-identical sums) — 32 instructions x 32 cycles of a
-// pipe whose issue time adds to the VALU's here: 0.545 ms.
+// lane l becomes window entry l % 32 (25 of them) for the samples of half l / 32 and runs over its 32 samples with 16-byte LDS reads of the
+// six rows it needs (its x weight, its y weight, the four channels): per four samples 6 reads, 4 multiplies and 16 fused multiply-adds,
+// all in the 2-cycle class; the two halves meet in one cross-lane add per channel.  The rows alias the wide walk's stack (never live at the
+// same time); the row pitch of 68 floats puts the rows a read touches into different banks.  The oracle sums in the same order (the two
+// halves of every 64 samples apart, then together).  Measured (tools/rftime.py, 512^2 x 64 spp): see DESIGN 5.1.
+// Tried and dropped: (1) lane = (entry, channel) over all 64 samples in two rounds — twice the LDS reads (96 x 1 KB per pixel: the CU's LDS
+// port, shared by its four SIMDs, was then busy 80 % of the kernel's time) and 256 instead of 160 instructions: the kernel 0.386 -> 0.487 ms;
+// (2) the same sums on the matrix pipe — v_mfma_f32_16x16x4_f32 with rows = channel (4 of 16 used), columns = window entry, K = samples
+// (lanes ARE the K index: no role change, bit-identical k-ordered sums) — 32 instructions x 32 cycles of a pipe whose issue time adds to
+// the VALU's here: 0.545 ms.
 #define FFX_RF_ROW 68
 #define FFX_RF_FLOATS (14 * FFX_RF_ROW)
 __device__ __forceinline__ void rf_weights(float alpha, float bias, float j, float (&w)[5]) {
@@ -2444,9 +2446,9 @@ __device__ __forceinline__ void rf_weights(float alpha, float bias, float j, flo
     w[a] = fmaxf(__expf(alpha * (x * x)) - bias, 0.f);
   }
 }
-// acc[r] += sum over this pass's samples of  gx[a] gy[b] L[ch]  for output o = 64 r + lane = 4 (5 b + a) + ch  (o < 100)
+// acc[ch] of lane l += sum over the samples 32 (l / 32) .. + 31 of this pass of  gx[a] gy[b] L[ch]  for window entry n = 5 b + a = l % 32 (< 25)
 __device__ __forceinline__ void rf_fold(float *__restrict__ s_rf, int lane, const float (&gx)[5], const float (&gy)[5], float l0, float l1, float l2, float l3,
-                                        float (&acc)[2]) {
+                                        float (&acc)[4]) {
   int lz = lane;
   asm volatile("" : "+v"(lz)); // (keeps the row addresses out of long-lived registers, as for s_foot)
 #pragma unroll
@@ -2459,31 +2461,29 @@ __device__ __forceinline__ void rf_fold(float *__restrict__ s_rf, int lane, cons
   s_rf[12 * FFX_RF_ROW + lz] = l2;
   s_rf[13 * FFX_RF_ROW + lz] = l3;
   __builtin_amdgcn_wave_barrier();
+  const int n = min(lz & 31, 24), half = lz >> 5;
+  const int b = (n * 13) >> 6, a = n - 5 * b; // n / 5, n % 5 for n < 25
+  const float4 *rx = reinterpret_cast<const float4 *>(s_rf + a * FFX_RF_ROW) + 8 * half;
+  const float4 *ry = reinterpret_cast<const float4 *>(s_rf + (5 + b) * FFX_RF_ROW) + 8 * half;
+  const float4 *r0 = reinterpret_cast<const float4 *>(s_rf + 10 * FFX_RF_ROW) + 8 * half;
+  float t0 = acc[0], t1 = acc[1], t2 = acc[2], t3 = acc[3];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int o = min(r * 64 + lz, 99), n = o >> 2, ch = o & 3;
-    const int b = (n * 13) >> 6, a = n - 5 * b; // n / 5, n % 5 for n < 25
-    const float4 *rx = reinterpret_cast<const float4 *>(s_rf + a * FFX_RF_ROW);
-    const float4 *ry = reinterpret_cast<const float4 *>(s_rf + (5 + b) * FFX_RF_ROW);
-    const float4 *rl = reinterpret_cast<const float4 *>(s_rf + (10 + ch) * FFX_RF_ROW);
-    float t = acc[r];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float4 X = rx[k], Y = ry[k], L = rl[k];
-      t = __builtin_fmaf(X.x * Y.x, L.x, t);
-      t = __builtin_fmaf(X.y * Y.y, L.y, t);
-      t = __builtin_fmaf(X.z * Y.z, L.z, t);
-      t = __builtin_fmaf(X.w * Y.w, L.w, t);
-    }
-    acc[r] = t;
+  for (int k = 0; k < 8; ++k) {
+    const float4 X = rx[k], Y = ry[k];
+    const float4 L0 = r0[k], L1 = r0[k + FFX_RF_ROW / 4], L2 = r0[k + 2 * (FFX_RF_ROW / 4)], L3 = r0[k + 3 * (FFX_RF_ROW / 4)];
+    const float w0 = X.x * Y.x, w1 = X.y * Y.y, w2 = X.z * Y.z, w3 = X.w * Y.w;
+    t0 = __builtin_fmaf(w0, L0.x, t0); t1 = __builtin_fmaf(w0, L1.x, t1); t2 = __builtin_fmaf(w0, L2.x, t2); t3 = __builtin_fmaf(w0, L3.x, t3);
+    t0 = __builtin_fmaf(w1, L0.y, t0); t1 = __builtin_fmaf(w1, L1.y, t1); t2 = __builtin_fmaf(w1, L2.y, t2); t3 = __builtin_fmaf(w1, L3.y, t3);
+    t0 = __builtin_fmaf(w2, L0.z, t0); t1 = __builtin_fmaf(w2, L1.z, t1); t2 = __builtin_fmaf(w2, L2.z, t2); t3 = __builtin_fmaf(w2, L3.z, t3);
+    t0 = __builtin_fmaf(w3, L0.w, t0); t1 = __builtin_fmaf(w3, L1.w, t1); t2 = __builtin_fmaf(w3, L2.w, t2); t3 = __builtin_fmaf(w3, L3.w, t3);
   }
+  acc[0] = t0; acc[1] = t1; acc[2] = t2; acc[3] = t3;
   __builtin_amdgcn_wave_barrier();
 }
-// a pixel's 25 outgoing sums -> scratch [pixel][25][4]
-__device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix, int lane, const float (&acc)[2]) {
-  float *pp = part + (size_t)pix * 100;
-  pp[lane] = acc[0];
-  if (lane < 36) pp[64 + lane] = acc[1];
+// a pixel's 25 outgoing sums -> scratch [pixel][25][4]: lane n < 25 adds its two halves (samples 0..31 in lanes 0..31, 32..63 in lanes 32..63)
+__device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix, int lane, const float (&acc)[4]) {
+  const float h0 = __shfl_down(acc[0], 32), h1 = __shfl_down(acc[1], 32), h2 = __shfl_down(acc[2], 32), h3 = __shfl_down(acc[3], 32);
+  if (lane < 25) reinterpret_cast<float4 *>(part)[(size_t)pix * 25 + lane] = make_float4(acc[0] + h0, acc[1] + h1, acc[2] + h2, acc[3] + h3);
 }
 
 // the weights alone (the adjoint's first launch): one wave per pixel, the jitter decides everything
@@ -2491,7 +2491,7 @@ __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int 
   __shared__ float s_rf[FFX_RF_FLOATS];
   const int pix = blockIdx.x, lane = threadIdx.x;
   if (pix >= n_pix) return;
-  float acc[2] = {0.f, 0.f};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int pass = 0; pass < (spp + 63) >> 6; ++pass) {
     const int s = pass * 64 + lane;
     float jx, jy, gx[5], gy[5];
@@ -2505,22 +2505,41 @@ __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int 
 
 // second launch of either direction: a pixel's 25 incoming sums.  Forward: img = (r, g, b) / weight.  Adjoint (gimg != NULL):
 // G = gimg / weight as float4 per pixel.  Window entry n = (a, b) of source pixel (x - (a - 2), y - (b - 2)) is what that pixel's
-// samples sent HERE; summed in window order like the oracle.
-__global__ void __launch_bounds__(256) k_rf_gather(const float4 *__restrict__ part, int W, int H, int fp16, void *__restrict__ img, const float *__restrict__ gimg,
-                                                    float4 *__restrict__ G) {
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (x >= W || y >= H) return;
+// samples sent HERE; summed in window order like the oracle.  A wave owns 64 pixels of one film row; for each window row b it stages the
+// 80-byte (b, 0..4) segments of the 68 source records it needs through LDS — five lanes per segment, every byte of the scratch area read
+// once — and lane x then picks entry a from record x + 4 - a.  (Read straight from memory a lane's 25 loads were 400 bytes apart from its
+// neighbours': 0.061 ms for 105 MB, the vector L1 thrashing.)
+#define FFX_RFG_WAVES 4
+__global__ void __launch_bounds__(64 * FFX_RFG_WAVES) k_rf_gather(const float4 *__restrict__ part, int W, int H, int fp16, void *__restrict__ img,
+                                                                   const float *__restrict__ gimg, float4 *__restrict__ G) {
+  __shared__ float4 s_seg[FFX_RFG_WAVES][68 * 5];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * 64, y = blockIdx.y * FFX_RFG_WAVES + wv;
+  if (y >= H) return; // (wave-uniform; the waves of a workgroup never synchronise)
+  float4 *seg = s_seg[wv];
   float r = 0.f, g = 0.f, b = 0.f, w = 0.f;
-#pragma unroll
   for (int wb = 0; wb < 5; ++wb) {
+    const int qy = y - (wb - 2);
+    if (qy < 0 || qy >= H) continue; // (wave-uniform)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = lane + 64 * k; // element (record e / 5, entry e % 5) of the 68 x 5 segment table
+      if (e < 340) {
+        const int rec = e / 5, wa = e - 5 * rec;
+        const int qx = x0 - 2 + rec;
+        seg[e] = (qx >= 0 && qx < W) ? part[((size_t)qy * W + qx) * 25 + (wb * 5 + wa)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int wa = 0; wa < 5; ++wa) {
-      const int qx = x - (wa - 2), qy = y - (wb - 2);
-      if (qx < 0 || qx >= W || qy < 0 || qy >= H) continue;
-      const float4 v = part[((size_t)qy * W + qx) * 25 + (wb * 5 + wa)];
+      const float4 v = seg[(lane + 4 - wa) * 5 + wa];
       r += v.x; g += v.y; b += v.z; w += v.w;
     }
   }
+  const int x = x0 + lane;
+  if (x >= W) return;
   const size_t pix = (size_t)y * W + x;
   if (gimg) {
     const bool ok = w > 0.f;
@@ -2577,7 +2596,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // The per-pixel radiance sums are live across all three walks of every pass but touched once per pass:
   // they are parked in LDS (which these kernels do not otherwise use) instead of holding 3R VGPRs that
   // the allocator would spill to scratch at 8 waves per SIMD.  Each lane only ever reads its own slots.
-  __shared__ float s_acc[R][3][PK_BLOCK];
+  __shared__ float s_acc[R][RF ? 4 : 3][PK_BLOCK];
   // each wave of the workgroup owns its own tile; the waves never synchronise
   // a wave walks `ppw` (1, 2 or 4) of its tile's four pixels; 4 / ppw waves share a tile
   const int wv = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)); // wave-uniform: say so
@@ -2614,7 +2633,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       if constexpr (MAT) { if (lz < 32) s_foot_b[lz] = 0.f; }
       __builtin_amdgcn_wave_barrier();
     }
-    float rfacc[2] = {0.f, 0.f}; // RF: this lane's two outputs (window entry, channel), summed over the passes
+    float rfacc[4] = {0.f, 0.f, 0.f, 0.f}; // RF: this lane's window entry (lane % 32, samples of half lane / 32), four channels, summed over the passes
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -2774,9 +2793,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           sample_jitter(seed_key, pix[r] * (uint32_t)spp + (uint32_t)s, jx, jy);
           rf_weights(ct.rf_alpha, ct.rf_bias, jx, gx);
           rf_weights(ct.rf_alpha, ct.rf_bias, jy, gy);
-          if (pass > 0) { rfacc[0] = s_acc[r][0][threadIdx.x]; rfacc[1] = s_acc[r][1][threadIdx.x]; }
+          if (pass > 0) { rfacc[0] = s_acc[r][0][threadIdx.x]; rfacc[1] = s_acc[r][1][threadIdx.x]; rfacc[2] = s_acc[r][2][threadIdx.x]; rfacc[3] = s_acc[r][3][threadIdx.x]; }
           rf_fold(reinterpret_cast<float *>(s_wstack), lane, gx, gy, c0, c1, c2, active[r] ? 1.f : 0.f, rfacc); // (the weight channel: every sample drawn counts)
-          if (pass + 1 < passes) { s_acc[r][0][threadIdx.x] = rfacc[0]; s_acc[r][1][threadIdx.x] = rfacc[1]; }
+          if (pass + 1 < passes) { s_acc[r][0][threadIdx.x] = rfacc[0]; s_acc[r][1][threadIdx.x] = rfacc[1]; s_acc[r][2][threadIdx.x] = rfacc[2]; s_acc[r][3][threadIdx.x] = rfacc[3]; }
           else if (live[r]) rf_store(reinterpret_cast<float *>(cache), pix[r], lane, rfacc);
           continue;
         }
@@ -3724,7 +3743,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       if (matm == 2) FFX_LAUNCH_RF(2); else if (matm == 1) FFX_LAUNCH_RF(1); else FFX_LAUNCH_RF(0);
 #undef FFX_LAUNCH_RF
       FFX_CHECK_LAUNCH("render_fwd_filtered");
-      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 32), ffx_cdiv(c.cam.H, 8)), dim3(256), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
                          img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
       FFX_CHECK_LAUNCH("render_fwd_filtered/gather");
       return FFX_OK;
@@ -3899,7 +3918,7 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       float4 *G = (float4 *)(part + (size_t)n_pix * 100);
       hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf_alpha, c.rf_bias, n_pix, spp, seed_key_of(seed), part);
       FFX_CHECK_LAUNCH("render_bwd_filtered/weights");
-      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 32), ffx_cdiv(c.cam.H, 8)), dim3(256), 0, (hipStream_t)s, (const float4 *)part, c.cam.W, c.cam.H, 0,
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)part, c.cam.W, c.cam.H, 0,
                          (void *)nullptr, gimg, G);
       FFX_CHECK_LAUNCH("render_bwd_filtered/gather");
 #define FFX_LAUNCH_BWD_RF(MAT_)                                                                                                                          \

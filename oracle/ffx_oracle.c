@@ -1730,7 +1730,8 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
  * radius = 4 stddev; src/render/imageblock.cpp put(): every pixel whose centre lies within `radius` of the sample along both
  * axes receives weight g(dx) g(dy) times the value, and the weight itself in the film's weight channel;
  * src/films/hdrfilm.cpp develop(): colour / weight].  Two levels of summation, in the order the HIP path uses: a pixel's own
- * samples first (per target pixel of its 5x5 window, samples ascending), then each pixel's 25 incoming sums (window row-major).
+ * samples first (per target pixel of its 5x5 window; samples ascending, the two halves of every 64 apart and then together), then each
+ * pixel's 25 incoming sums (window row-major).
  * ========================================================================================= */
 typedef struct { float alpha, bias; } rf_ctx;
 static int rf_prepare(const ffx_scene_desc *sd, rf_ctx *r) {
@@ -1806,7 +1807,8 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   for (int pix = 0; pix < W * H; ++pix) {
     const int x = pix % W, y = pix / W;
     float *pp = part + (size_t)pix * 100;
-    for (int k = 0; k < 100; ++k) pp[k] = 0.f;
+    float half[2][100]; /* the two halves of every 64 samples are summed apart, then together (the lanes of the HIP kernel: rf_fold) */
+    for (int k = 0; k < 100; ++k) half[0][k] = half[1][k] = 0.f;
     for (int sidx = 0; sidx < spp; ++sidx) {
       uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
       float jx, jy;
@@ -1822,12 +1824,14 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
       float gx[5], gy[5];
       rf_weights(&rf, jx, gx);
       rf_weights(&rf, jy, gy);
+      float *hp = half[(sidx & 63) >> 5];
       for (int b = 0; b < 5; ++b)
         for (int a = 0; a < 5; ++a) {
           const float w = gx[a] * gy[b];
-          for (int k = 0; k < 4; ++k) pp[(b * 5 + a) * 4 + k] = fmaf(w, L[k], pp[(b * 5 + a) * 4 + k]);
+          for (int k = 0; k < 4; ++k) hp[(b * 5 + a) * 4 + k] = fmaf(w, L[k], hp[(b * 5 + a) * 4 + k]);
         }
     }
+    for (int k = 0; k < 100; ++k) pp[k] = half[0][k] + half[1][k];
   }
 #pragma omp parallel for schedule(static)
   for (int pix = 0; pix < W * H; ++pix) {
@@ -1862,15 +1866,18 @@ int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   float *G = part + (size_t)W * H * 25;
   for (int pix = 0; pix < W * H; ++pix) {
     float *pp = part + (size_t)pix * 25;
-    for (int k = 0; k < 25; ++k) pp[k] = 0.f;
+    float half[2][25];
+    for (int k = 0; k < 25; ++k) half[0][k] = half[1][k] = 0.f;
     for (int sidx = 0; sidx < spp; ++sidx) {
       float jx, jy, gx[5], gy[5];
       sample_jitter(seed, (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx, &jx, &jy);
       rf_weights(&rf, jx, gx);
       rf_weights(&rf, jy, gy);
+      float *hp = half[(sidx & 63) >> 5];
       for (int b = 0; b < 5; ++b)
-        for (int a = 0; a < 5; ++a) pp[b * 5 + a] += gx[a] * gy[b];
+        for (int a = 0; a < 5; ++a) hp[b * 5 + a] = fmaf(gx[a] * gy[b], 1.0f, hp[b * 5 + a]);
     }
+    for (int k = 0; k < 25; ++k) pp[k] = half[0][k] + half[1][k];
   }
   for (int pix = 0; pix < W * H; ++pix) {
     const int x = pix % W, y = pix / W;

@@ -90,3 +90,4 @@ if os.environ.get("FFX_HP_PROFILE") == "1":
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumtime").print_stats(40)
