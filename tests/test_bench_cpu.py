@@ -46,7 +46,7 @@ def test_operand_form_ceiling_is_consistent(bench):
     """round 3: the share of the add / mul / fma class that carries a scalar source (tools/isa_mix.py, committed) is priced at the
     4-cycle rate — a ceiling between the nominal one and the kernel time recorded in the same profile set"""
     forms = json.load(open(bench._profile_files("isa_operand_forms.json")[-1]))
-    assert "k_render_fwd_pk<1, true, 1" in forms["kernel"]
+    assert "k_render_fwd_pk<1, true, 1, false, false>" in forms["kernel"]
     assert forms["with_scalar_or_constant_source"] == sum(v["with_scalar_source"] for v in forms["per_opcode"].values())
     fr = forms["scalar_source_fraction"]
     assert 0.2 < fr < 0.7
@@ -153,11 +153,11 @@ def test_every_profile_the_bench_line_cites_exists_is_not_empty_and_names_kernel
         stale = sorted({base(k) for k in d if base(k).startswith("k_")} - kernels)
         assert not stale, f"profiles/{name} names kernels that are not in csrc/ any more: {stale}"
     g = json.load(open(os.path.join(ROOT, "profiles", f"{tag}grad_pmc_summary.json")))
-    assert any(k.startswith("k_render_fwd_pk<") and ", true>" in k for k in g), "no counters for the forward + adjoint launch the gradient bracket times"
+    assert any(bench.k8_instance(k)[0] for k in g), "no counters for the forward + adjoint launch the gradient bracket times"
     for want in ("k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached", "k_bin<"):
         assert any(k.startswith(want) for k in g), f"the gradient bracket's PMC summary lacks {want}"
     stats = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()
-    assert "k_render_fwd_pk<1, true, 1, false>" in stats and "k_bin<true>" in stats
+    assert "k_render_fwd_pk<1, true, 1, false, false>" in stats and "k_bin<true>" in stats  # (<R, WIDE, MATM, ADJ, RF>: the plain forward)
     # ... and what the line derives from them resolves to that same set
     t = bench.pmc_traffic("k_render_fwd_pk", "grad", "", adjoint_instance=True)
     assert t is not None and t["source"] == f"{tag}grad_pmc_summary.json"

@@ -80,7 +80,12 @@ tag = sys.argv[1]
 g = json.load(open(f"profiles/{tag}grad_pmc_summary.json"))
 want = ["k_render_fwd_pk<", "k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached"]
 missing = [w for w in want if not any(k.startswith(w) for k in g)]
-if not any(k.startswith("k_render_fwd_pk<") and ", true>" in k for k in g):
+def adjoint_instance(k):  # k_render_fwd_pk<R, WIDE, MATM, ADJ, RF>
+    import re
+    m = re.search(r"k_render_fwd_pk<([^>]*)>", k)
+    a = [t.strip() for t in m.group(1).split(",")] if m else []
+    return len(a) > 3 and a[3] == "true"
+if not any(adjoint_instance(k) for k in g):
     missing.append("k_render_fwd_pk<..., true> (forward + adjoint)")
 if missing:
     print("collect_profiles: the gradient bracket's PMC summary lacks", missing, file=sys.stderr)
