@@ -236,6 +236,10 @@ def valu_issue(kernel_substr, kernel_ms, key=""):
                         # bound of the issue utilisation, this is the upper estimate; the truth lies between them)
                         forms = {"scalar_source_fraction_static": fr, "ceiling_ms_operand_forms": 1e3 * cyc2 / SIMDS / CLOCK_HZ,
                                  "frac_operand_forms": 1e3 * cyc2 / SIMDS / CLOCK_HZ / kernel_ms, "operand_forms_source": "profiles/" + os.path.basename(ff[-1])}
+                        if forms["frac_operand_forms"] > 1.0:
+                            forms["operand_forms_note"] = ("above 1: the share is STATIC (every instruction of the kernel text once); the loops that dominate since the "
+                                                           "tile bins carry fewer scalar-source forms than the text as a whole, so this estimate over-counts — `frac` "
+                                                           "(all fma / mul / add at the 2-cycle rate) is the bound")
                     except Exception:
                         forms = {}
                 return {"valu_wave_instr_per_launch": n, "fp32_fma_mul_add": fast, "transcendental": trans, "other_valu": slow,
