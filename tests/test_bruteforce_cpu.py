@@ -308,9 +308,9 @@ def test_oracle_render_with_interpolated_normals_agrees_with_bruteforce(oracle):
 def test_gaussian_reconstruction_filter_oracle_agrees_with_bruteforce(oracle, which):
     """ffx_scene_desc.rfilter = gaussian (hdrfilm's default, which the reference's scenes get): the oracle's two-level sums
     (a pixel's own samples per window entry, then the 25 incoming sums) against the brute force's film formed from absolute sample
-    positions and pixel centres — image and texture gradient — plus the properties the filter must have: a constant radiance field
-    stays constant (weights normalised), the adjoint identity holds inside the brute force, and the filtered image differs from
-    the box image (the field is actually read)."""
+    positions and pixel centres — image and texture gradient — plus: the means of the two films agree (weights normalised), the adjoint
+    identity holds inside the brute force and in the oracle, the filtered image differs from the box image (the field is actually
+    read), a narrower filter, the fp16 film, and the box-only entry points refuse the scene."""
     if which == "hello_world":
         sc, spp, xf, frame = scenes.hello_world(40, 32), 3, None, 0
     else:

@@ -1593,3 +1593,30 @@ def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
     res = opt.step()
     assert opt.step_paths["retrace"] == 2 and opt.step_paths["fused"] == 0 and opt.step_paths["cache_k9"] == 0
     assert np.isfinite(float(res["loss"])) and not torch.equal(before, wl.laser._rays.detach())
+
+
+def test_per_slot_normal_area_holds_what_the_header_says():
+    """include/ffx.h ffx_bvh_info.off_gn: per leaf slot the unit geometric normal and, in the fourth word, the BITS (shape + 1) | smooth << 30
+    (0: degenerate triangle) — the render kernels take a hit's shape and smooth flag from that word.  The records of the same blob give the
+    expectation (cross product of the two edges, normalised), for a scene with a smooth and a flat shape after a re-fit."""
+    sc = scenes.vocalfold(width=32, height=32, tex=32, frames=3, n_fold=12, tube=(12, 16))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    gd = ops.DeviceGeometry(pool, tris, shape, off, smooth=[True] + [False] * (len(off) - 1))
+    gd.update(_rand_xforms(len(off), 3), off)
+    torch.cuda.synchronize()
+    info, blob = gd.info, gd.blob
+    F = int(info.n_tris)
+    assert int(info.off_gn) > 0
+    recs = blob[int(info.off_recs): int(info.off_recs) + 48 * F].cpu().numpy().view(np.float32).reshape(F, 12)
+    gn = blob[int(info.off_gn): int(info.off_gn) + 16 * F].cpu().numpy()
+    n_dev, word = gn.view(np.float32).reshape(F, 4)[:, :3], gn.view(np.uint32).reshape(F, 4)[:, 3]
+    e1, e2 = recs[:, 3:6].astype(np.float64), recs[:, 6:9].astype(np.float64)
+    shape_of_slot = recs[:, 10].view(np.int32)
+    n = np.cross(e1, e2)
+    ln = np.linalg.norm(n, axis=1)
+    ok = ln > 0
+    assert ok.mean() > 0.99
+    np.testing.assert_allclose(n_dev[ok], (n[ok] / ln[ok, None]), rtol=0, atol=3e-6)
+    assert np.array_equal(word[ok] & 0x3FFFFFFF, (shape_of_slot[ok] + 1).astype(np.uint32))
+    assert np.array_equal((word[ok] >> 30) & 1, (shape_of_slot[ok] == 0).astype(np.uint32))  # shape 0 is the smooth one
+    assert (word[~ok] == 0).all()
