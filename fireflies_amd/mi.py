@@ -104,6 +104,50 @@ class TensorXf(_ArrayBase):
     pass
 
 
+class Vector2f(_ArrayBase):
+    """[N,2] (or two broadcastable components): film positions handed to Sensor.sample_ray (depth.py:60-74)"""
+
+    def __init__(self, x, y=None, device=None):
+        if y is not None:
+            xs = x.t if isinstance(x, _ArrayBase) else torch.as_tensor(x, dtype=torch.float32)
+            ys = y.t if isinstance(y, _ArrayBase) else torch.as_tensor(y, dtype=torch.float32)
+            xs, ys = torch.broadcast_tensors(xs.reshape(-1).float(), ys.reshape(-1).float().to(xs.device))
+            x = torch.stack([xs, ys], -1)
+        super().__init__(x, device)
+        self.t = self.t.reshape(-1, 2)
+
+
+Point2f = Vector2f
+
+
+class Ray3f:
+    """mi.Ray3f(o, d[, maxt]): origins / directions [N,3] (a single origin is broadcast) — depth.py:41"""
+
+    def __init__(self, o, d, maxt=None):
+        ot = o.t if isinstance(o, _ArrayBase) else torch.as_tensor(o, dtype=torch.float32)
+        dt = d.t if isinstance(d, _ArrayBase) else torch.as_tensor(d, dtype=torch.float32)
+        dt = dt.reshape(-1, 3).float()
+        ot = ot.reshape(-1, 3).float().to(dt.device)
+        self.o = ot.expand(dt.shape[0], 3) if ot.shape[0] == 1 else ot
+        self.d = dt
+        self.maxt = maxt  # None or [N]: hits beyond it do not count
+
+
+class SurfaceInteraction3f:
+    """what Scene.ray_intersect returns, as far as the reference reads it (depth.py:41-47,77-84,115-125): the distance `t` along the ray, the
+    hit point `p`, validity, and `shape` — here the shape's index + 1 (0: no shape), which orders like the pointers the reference relabels"""
+
+    def __init__(self, t, shape, prim, ray):
+        self._valid = prim >= 0
+        self.t = Float32(t)
+        self.p = TensorXf(ray.o + t.unsqueeze(-1) * ray.d)
+        self.shape = UInt32((shape + 1).to(torch.int32))
+        self.prim_index = UInt32(prim)
+
+    def is_valid(self):
+        return self._valid
+
+
 class _RenderedXf(TensorXf):
     """The image of a render that was issued on one of the scene's render streams (Scene._render_stream): whoever reads it first makes the
     stream that is current THEN wait for the render — `mi.render(...).torch()`, the reference's idiom, costs one event wait; a loop that
@@ -204,6 +248,13 @@ class Sampler:
     def wavefront_size(self):
         return self._wavefront
 
+    # (the reference draws `sample1` from the sampler and never uses it for a perspective sensor — depth.py:72-74: wavelengths; zeros do)
+    def next_1d(self):
+        return Float32(torch.zeros(max(self._wavefront, 1)))
+
+    def next_2d(self):
+        return Vector2f(torch.zeros((max(self._wavefront, 1), 2)))
+
 
 class Sensor:
     def __init__(self, scene, key):
@@ -234,6 +285,25 @@ class Sensor:
 
     def world_transform(self):
         return self._p("to_world")
+
+    def sample_ray(self, time=0, sample1=None, sample2=None, sample3=None, active=True):
+        """(Ray3f, weights) for film positions sample2 in [0,1)^2 [EXT Mitsuba perspective sensor sample_ray; call sites depth.py:72-74,
+        laser_estimation.py:64]: near_p = sample_to_camera (sx, sy, 0), d = to_world normalize(near_p); the ray starts ON the near plane
+        (o = position + d near / d_l.z) and ends at the far plane (maxt) — so `t` of a hit is what the K7 entry points report."""
+        sc = self._scene
+        pos = sample2.t if isinstance(sample2, _ArrayBase) else torch.as_tensor(sample2, dtype=torch.float32)
+        pos = pos.reshape(-1, 2).to(sc.device, torch.float32)
+        w, h = sc._film_size[self._key]
+        K = perspective_projection((w, h), (w, h), (0, 0), self.x_fov(), self.near_clip(), self.far_clip()).numpy().astype(np.float64)
+        s2c = torch.as_tensor(np.linalg.inv(K), dtype=torch.float32, device=sc.device)
+        tw = torch.as_tensor(sc._mat(self._key + ".to_world"), dtype=torch.float32, device=sc.device)
+        q = torch.cat([pos, torch.zeros_like(pos[:, :1]), torch.ones_like(pos[:, :1])], 1) @ s2c.T
+        near_p = q[:, :3] / q[:, 3:4]
+        dl = near_p / near_p.norm(dim=1, keepdim=True)
+        d = dl @ tw[:3, :3].T
+        near_t, far_t = self.near_clip() / dl[:, 2], self.far_clip() / dl[:, 2]
+        o = tw[:3, 3].unsqueeze(0) + d * near_t.unsqueeze(-1)
+        return Ray3f(o, d, maxt=far_t - near_t), Color3f(torch.ones(3))
 
 
 class _PinnedRing:
@@ -442,6 +512,19 @@ class Scene:
 
     def sensors(self):
         return self._sensors
+
+    def ray_intersect(self, ray, active=True):
+        """scene.ray_intersect(mi.Ray3f(o, d)) (depth.py:41,77,115,157): the closest hit of every ray against the current pose
+        (ffx_trace_rays, K7) — `t`, `p`, `is_valid()`, `shape` (index + 1; 0 without a hit)"""
+        o, d = ray.o.to(self.device).contiguous(), ray.d.to(self.device).contiguous()
+        t, shape, prim = self.geom.trace_rays(o, d)
+        if ray.maxt is not None:
+            far = torch.as_tensor(ray.maxt, dtype=torch.float32, device=self.device).reshape(-1)
+            miss = t > far
+            prim = torch.where(miss, torch.full_like(prim, -1), prim)
+            shape = torch.where(miss, torch.full_like(shape, -1), shape)
+            t = torch.where(miss, torch.zeros_like(t), t)
+        return SurfaceInteraction3f(t, shape, prim, Ray3f(o, d))
 
     def shapes(self):
         return list(self.mesh_names)

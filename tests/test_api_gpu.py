@@ -1086,3 +1086,37 @@ def test_colon_workload_with_the_mucosa_randomisation_of_main_py(oracle):
             scale, _ = assert_image_close(img, ref, 8, frac=2e-3, rel=2e-3 if fp16 else 2e-4, what=f"seed {seed} fp16 {fp16}")
             assert scale > 0.02
     assert np.abs(seen[0] - seen[1]).max() > 0.05  # the draws differ
+
+
+def test_sample_ray_and_ray_intersect_objects_give_the_depth_map():
+    """a script that talks to Mitsuba's objects itself — `sensor.sample_ray(...)`, `scene.ray_intersect(rays)`,
+    `surface_interaction.t / is_valid() / shape` (depth.py:54-125 spelled out by hand) — gets what graphics.depth returns, and
+    `mi.Ray3f(origin, directions)` + `ray_intersect` what cast_laser returns."""
+    from fireflies_amd.graphics import depth
+
+    wl = _small()
+    ms = wl.mi_scene
+    sensor = ms.sensors()[0]
+    w, h = sensor.film().crop_size()
+    spp = 2
+    sampler = sensor.sampler()
+    sampler.seed(0, w * h * spp)
+    idx = torch.arange(w * h * spp) // spp
+    pos = mi.Vector2f((idx % w).float() / w, (idx // w).float() / h)
+    rays, weights = sensor.sample_ray(time=0, sample1=sampler.next_1d(), sample2=pos, sample3=0)
+    si = ms.ray_intersect(rays)
+    t = si.t.torch().clone()
+    t[~si.is_valid()] = 0
+    want = depth.from_camera_non_wrapped(ms, spp=spp)
+    hit = want > 0
+    assert hit.float().mean() > 0.3 and torch.equal(si.is_valid().cpu(), hit.cpu())
+    torch.testing.assert_close(t, want, rtol=2e-5, atol=2e-6)
+    # the relabelled shape ids of get_segmentation_from_camera (depth.py:119-125), from the objects
+    ptr = si.shape.torch().to(torch.int64)
+    ptr = ptr - ptr.min()
+    lab = (ptr.max() - ptr).reshape(h, w, spp)[..., 0]
+    assert torch.equal(lab.cpu(), depth.get_segmentation_from_camera(ms, spp=1).cpu())
+    # laser rays from a common origin
+    o, d = wl.laser.originPerRay(), wl.laser.rays()
+    si2 = ms.ray_intersect(mi.Ray3f(o[0], d))
+    torch.testing.assert_close(si2.p.torch(), depth.cast_laser(ms, laser=wl.laser), rtol=1e-6, atol=1e-6)
