@@ -341,7 +341,7 @@ def cpu_baseline(wl, tex, spp_full, cpu_spp, seed, grad_wl=None):
     per_render = t_upd + (t_r / n) * (spp_full / cpu_spp)
     out = {"value": 1.0 / per_render, "unit": "renders/sec", "cores": cores, "kind": "port",
            "sample": f"{n} renders of the same pose at {cpu_spp} of {spp_full} spp ({t_r:.1f} s measured in total, scaled x{spp_full / cpu_spp:g}) + refit "
-                     f"{t_upd * 1e3:.1f} ms; gcc -O2 scalar oracle (a restatement for checking, not a tuned CPU renderer), OpenMP over pixels on {cores} threads "
+                     f"{t_upd * 1e3:.1f} ms; gcc -O3 -march=x86-64-v3 scalar oracle (a restatement for checking, not a tuned CPU renderer), OpenMP over pixels on {cores} threads "
                      f"(logical CPUs {os.cpu_count()}, affinity {len(os.sched_getaffinity(0))}, cgroup CPU quota {'none' if quota is None else f'{quota:g}'})",
            "mitsuba_scalar_rgb": "unavailable (mitsuba 3.5.0 / drjit 0.4.4 are not installed here or on the GPU box and are not part of /root/reference)"}
     # one thread: a bounded sample (1/16 of the samples per pixel, >= 1), scaled
@@ -410,7 +410,7 @@ def cpu_grad_step(wg, spp_full, cpu_spp, seed, cores):
     per_step = t_pat_f + t_upd + t_r * (spp_full / cpu_spp) + t_pat_b
     return {"value": 1.0 / per_step, "unit": "pattern-gradient steps/sec", "cores": cores, "kind": "port",
             "sample": f"1 step, 1 scene sample: pattern forward {t_pat_f * 1e3:.0f} ms + refit {t_upd * 1e3:.1f} ms + forward-and-adjoint render at {cpu_spp} of {spp_full} spp "
-                      f"{t_r:.1f} s (scaled x{spp_full / cpu_spp:g}) + pattern backward and update {t_pat_b * 1e3:.0f} ms; gcc -O2 scalar oracle, OpenMP on {cores} threads"}
+                      f"{t_r:.1f} s (scaled x{spp_full / cpu_spp:g}) + pattern backward and update {t_pat_b * 1e3:.0f} ms; gcc -O3 -march=x86-64-v3 scalar oracle, OpenMP on {cores} threads"}
 
 
 def launch_ranks(n, argv):
