@@ -13,7 +13,7 @@
  *   fixtures for: for these rows the oracle is "PARITY UNPINNED" against Mitsuba and is
  *   pinned only by analytic known-answer tests (tests/test_oracle_analytic.py).
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; FMAs are written explicitly where
+ * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off -fno-fast-math; FMAs are written explicitly where
  * the documented operation order has one, so the HIP kernels can follow the same order).
  *
  * Each function cites the reference file:line it follows (paths under /root/reference).
