@@ -208,6 +208,7 @@ PROTOTYPES = {
     "ffx_render_dot_slots": (C.c_size_t, [c_i, c_i]),
     "ffx_render_filter_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
     "ffx_render_fwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
+    "ffx_render_fwd_adjoint_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_render_bwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd_adjoint": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_apex_prepare": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p]),

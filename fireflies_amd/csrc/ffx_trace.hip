@@ -2583,8 +2583,10 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // no second pass — the pixel's footprint is scattered into gtex where it is formed instead of being stored for K9, stray samples at
   // once: no cache, no arena that could overflow, no launch behind the render.  `fold`: the footprint bookkeeping runs for either mode.
   // (ADJ is a template parameter: as a run-time mode its three pointers and the epilogue cost the plain forward a dozen scalar spills)
-  static_assert(!(RF && ADJ), "the filtered render has its own adjoint (ffx_render_bwd_filtered)");
-  const bool fold = !RF && (ADJ || cache != nullptr);
+  // RF && ADJ (ffx_render_fwd_adjoint_filtered): adj_gimg is then G = gimg / weight as float4 per pixel (k_rf_gather) and every lit sample
+  // enters the pixel's footprint with ITS OWN gradient — sum over its window of w_n G[pixel + n], times albedo and colour — already applied;
+  // the epilogue scatters the footprint as it is.  1-channel textures only (the host refuses the other).
+  const bool fold = RF ? ADJ : (ADJ || cache != nullptr);
   constexpr int WSTACK_N = WIDE ? FFX_WSTACK : 1, RF_N = (FFX_RF_FLOATS * 4 + 7) / 8;
   __shared__ uint2 s_wstack[RF ? (WSTACK_N > RF_N ? WSTACK_N : RF_N) : WSTACK_N]; // (RF: the filter's rows alias the walk's stack)
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
@@ -2666,14 +2668,38 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             fshape = __builtin_amdgcn_readlane(st[0].shape, wff1(litm));
           }
           const bool in_win = lit && st[0].ix0 >= fox && st[0].ix1 <= fox + 4 && st[0].iy0 >= foy && st[0].iy1 <= foy + 4 && st[0].shape == fshape;
+          float rf_pf = 0.f; // RF && ADJ: proj_fac (and proj_fac_b) of this sample with its filtered gradient, albedo and colour applied
+          if constexpr (RF && ADJ) {
+            const ShadeK &cr = kernarg_shade();
+            const float4 gw = rf_window_g(reinterpret_cast<const float4 *>(adj_gimg), px[0], py[0], W, H, lane, live[0]);
+            float jx, jy, gx[5], gy[5];
+            sample_jitter(seed_key, pix[0] * (uint32_t)spp + (uint32_t)s, jx, jy);
+            rf_weights(cr.rf_alpha, cr.rf_bias, jx, gx);
+            rf_weights(cr.rf_alpha, cr.rf_bias, jy, gy);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int n = 0; n < 25; ++n) {
+              const float w = gx[n % 5] * gy[n / 5];
+              a0 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.x), n)), a0);
+              a1 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.y), n)), a1);
+              a2 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gw.z), n)), a2);
+            }
+            if (lit) { // (the arithmetic of k_render_bwd_pk's scatter, 1-channel texture)
+              const float *alb = mat_table(cr) + MS * st[0].shape;
+              rf_pf = (a0 * alb[0] * cr.p_color[0] + a1 * alb[1] * cr.p_color[1] + a2 * alb[2] * cr.p_color[2]) * st[0].proj_fac;
+              if constexpr (MAT) {
+                if (st[0].proj_fac_b != 0.f) rf_pf += (a0 * cr.p_color[0] + a1 * cr.p_color[1] + a2 * cr.p_color[2]) * st[0].proj_fac_b;
+              }
+            }
+          }
           if (in_win) {
-            const float pf = st[0].proj_fac;
+            const float pf = (RF && ADJ) ? rf_pf : st[0].proj_fac;
             const int bx0 = st[0].ix0 - fox, bx1 = st[0].ix1 - fox, by0 = (st[0].iy0 - foy) * 5, by1 = (st[0].iy1 - foy) * 5;
             atomicAdd(&s_foot[by0 + bx0], pf * st[0].wy0 * st[0].wx0);
             atomicAdd(&s_foot[by0 + bx1], pf * st[0].wy0 * st[0].wx1);
             atomicAdd(&s_foot[by1 + bx0], pf * st[0].wy1 * st[0].wx0);
             atomicAdd(&s_foot[by1 + bx1], pf * st[0].wy1 * st[0].wx1);
-            if constexpr (MAT) {
+            if constexpr (MAT && !(RF && ADJ)) {
               const float pb = st[0].proj_fac_b;
               if (pb != 0.f) {
                 atomicAdd(&s_foot_b[by0 + bx0], pb * st[0].wy0 * st[0].wx0);
@@ -2685,6 +2711,15 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           }
           const wmask straym = wballot(lit && !in_win);
           if (ADJ && straym != 0ull) { // fused adjoint: the four taps of a sample that does not fit the footprint, at once (k9_stray's arithmetic)
+            if constexpr (RF) {
+              if (lit && !in_win && rf_pf != 0.f) {
+                const ShadeK &ca = kernarg_shade();
+                atomicAdd(adj_gtex + (size_t)st[0].iy0 * ca.tw + st[0].ix0, rf_pf * st[0].wy0 * st[0].wx0);
+                atomicAdd(adj_gtex + (size_t)st[0].iy0 * ca.tw + st[0].ix1, rf_pf * st[0].wy0 * st[0].wx1);
+                atomicAdd(adj_gtex + (size_t)st[0].iy1 * ca.tw + st[0].ix0, rf_pf * st[0].wy1 * st[0].wx0);
+                atomicAdd(adj_gtex + (size_t)st[0].iy1 * ca.tw + st[0].ix1, rf_pf * st[0].wy1 * st[0].wx1);
+              }
+            } else
             if (lit && !in_win) {
               const ShadeK &ca = kernarg_shade();
               const float g0 = adj_gimg[(size_t)pix[0] * 3], g1 = adj_gimg[(size_t)pix[0] * 3 + 1], g2 = adj_gimg[(size_t)pix[0] * 3 + 2];
@@ -2834,7 +2869,18 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       }
       FFX_TSTOP(tk, 23);
     }
-    if (ADJ && live[0]) { // fused adjoint: the pixel's footprint x (gimg . albedo . colour) / spp goes straight into gtex (K9's arithmetic)
+    if (ADJ && RF && live[0]) { // filtered fused adjoint: the footprint already carries every sample's own gradient
+      __builtin_amdgcn_wave_barrier();
+      const ShadeK &ca = kernarg_shade();
+      int lw = lane;
+      asm volatile("" : "+v"(lw));
+      if (fox >= 0 && lw < 25) {
+        const float w = s_foot[lw];
+        const int ey = (lw * 13) >> 6, ex = lw - 5 * ey;
+        if (w != 0.f) atomicAdd(adj_gtex + (size_t)(foy + ey) * ca.tw + (fox + ex), w);
+      }
+    }
+    if (ADJ && !RF && live[0]) { // fused adjoint: the pixel's footprint x (gimg . albedo . colour) / spp goes straight into gtex (K9's arithmetic)
       __builtin_amdgcn_wave_barrier();
       const ShadeK &ca = kernarg_shade();
       const float g0 = adj_gimg[(size_t)pix[0] * 3], g1 = adj_gimg[(size_t)pix[0] * 3 + 1], g2 = adj_gimg[(size_t)pix[0] * 3 + 2];
@@ -3735,6 +3781,30 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
                      arena_off, foot_b_off, nrec, gn, cap_stray, adj_gimg, adj_gtex, adj_dot)
 #define FFX_LAUNCH_FWD(WIDE_, MAT_) do { if (adj_gtex) FFX_LAUNCH_FWD_(WIDE_, MAT_, true); else FFX_LAUNCH_FWD_(WIDE_, MAT_, false); } while (0)
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1); // (textured base colours: their own instantiation — the default kernels pay nothing)
+    if (rf_scratch && adj_gtex) { // ... with the adjoint of a loss that is linear in the image folded in (ffx_render_fwd_adjoint_filtered)
+      if (sd->proj.tex_channels != 1 || matm == 2) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint_filtered: 1-channel projector textures without textured base colours (use ffx_render_fwd_filtered + ffx_render_bwd_filtered)");
+      // the weight every pixel will receive (the jitter alone decides it) -> G = gimg / weight behind the partial sums; then the render, whose
+      // footprints take every sample's own gradient from G; then the image
+      const int n_pix = c.cam.W * c.cam.H;
+      float *part = (float *)rf_scratch;
+      float4 *G = (float4 *)(part + (size_t)n_pix * 100);
+      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf_alpha, c.rf_bias, n_pix, spp, seed_key_of(seed), part);
+      FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered/weights");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)part, c.cam.W,
+                         c.cam.H, 0, (void *)nullptr, adj_gimg, G);
+      FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered/gather G");
+#define FFX_LAUNCH_RFA(MAT_)                                                                                                                             \
+  hipLaunchKernelGGL((k_render_fwd_pk<1, true, MAT_, true, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
+                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16, img, (char *)rf_scratch, ppw,          \
+                     1.0f / (float)spp, foot_off, arena_off, foot_b_off, nrec, gn, cap_stray, (const float *)G, adj_gtex, (float *)nullptr)
+      if (matm == 1) FFX_LAUNCH_RFA(1); else FFX_LAUNCH_RFA(0);
+#undef FFX_LAUNCH_RFA
+      FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W,
+                         c.cam.H, img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
+      FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered/gather");
+      return FFX_OK;
+    }
     if (rf_scratch) { // the filtered render: the kernel leaves every pixel's 25 x 4 outgoing sums in the scratch area, the gather forms the image
 #define FFX_LAUNCH_RF(MAT_)                                                                                                                               \
   hipLaunchKernelGGL((k_render_fwd_pk<1, true, MAT_, false, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
@@ -3960,6 +4030,15 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_filtered: scratch is NULL or not 16-byte aligned");
   return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_APEX_READY), img, nullptr, s, nullptr, nullptr, nullptr,
                          scratch);
+}
+
+int ffx_render_fwd_adjoint_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                                    uint32_t seed, int img_fp16, void *img, const float *gimg, float *gtex, void *scratch, ffx_stream s) {
+  if (!gimg || !gtex) FFX_FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: gimg / gtex is NULL");
+  if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: scratch is NULL or not 16-byte aligned");
+  if (sd && !sd->proj.enabled) FFX_FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: the scene has no projector (nothing to differentiate)");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT | FFX_RENDER_APEX_READY), img, nullptr, s, gimg,
+                         gtex, nullptr, scratch);
 }
 
 int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,

@@ -720,8 +720,9 @@ class DeviceGeometry:
         -> (img, gtex): the render, and gtex (+)= its adjoint applied to gimg — `out`: accumulate into this [tex_h, tex_w, channels]
         tensor instead of a fresh zeroed one.  dot_out: _abi.ADJOINT_DOT_SLOTS float32 partial sums that <gimg, img> is added to."""
         H, W = sd.cam.height, sd.cam.width
-        if sd.rfilter:
-            raise ValueError("render_fwd_adjoint folds box-filtered pixels: with a reconstruction filter use render_fwd + render_bwd")
+        if sd.rfilter and (dot_out is not None or sd.proj.tex_channels != 1 or sd.n_base_tex > 0):
+            raise ValueError("render_fwd_adjoint with a reconstruction filter: 1-channel projector textures, no textured base colours, no dot_out "
+                             "(the image forms behind the render launch) — box-filtered pixels are what the general call folds; use render_fwd + render_bwd")
         mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device) if img_out is None else img_out
         if tuple(img.shape) != (H, W, 3) or img.dtype != (torch.float16 if fp16 else torch.float32):
@@ -733,6 +734,13 @@ class DeviceGeometry:
             raise ValueError(f"dot_out must hold {_abi.ADJOINT_DOT_SLOTS} float32 partial sums (the caller zeroes and sums them)")
         blob = self.blob
         flags = int(bool(fp16)) | (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | self._apex_flag(apex_key(sd))
+        if sd.rfilter:  # the filtered film: weights -> G, ONE render launch with the adjoint folded in, gather (ffx_render_fwd_adjoint_filtered)
+            scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device)
+            with self._timed("render_fwd"):
+                self._call("ffx_render_fwd_adjoint_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, _dev(tex, name="tex"), int(spp),
+                           int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _dev(gimg, name="gimg"), _dev(gtex), _dev(scratch, torch.uint8), _stream(self._didx))
+            self._release()
+            return img, gtex
         with self._timed("render_fwd"):
             self._call("ffx_render_fwd_adjoint", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, _dev(tex, name="tex"), int(spp),
                        int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _dev(gimg, name="gimg"), _dev(gtex), _dev(dot_out) if dot_out is not None else None,

@@ -201,8 +201,8 @@ class PatternOptimizer:
         # (one process: the loss value then comes out of the gradient launch, from the step's renders stacked in one buffer; the fused
         # launch's own per-pixel partial sums would cost more than K9 — tools/adjprobe.py, 519 against 510 us per sample.  Several ranks
         # take the same launch; their gradient launch only evaluates the data term, the exchange and the update follow — below.
-        # A filtered film (sd.rfilter) folds no box pixels: forward, then the re-traced filtered adjoint)
-        fused = (linear is not None and int(sd0.n_base_tex) == 0 and not int(sd0.rfilter) and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
+        # A filtered film (sd.rfilter) takes the same route through ffx_render_fwd_adjoint_filtered; with a non-linear loss it re-traces)
+        fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
                  and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
         n_slots = ops.render_dot_slots(cam.width, cam.height)  # (K9's partial sums of the loss; the fused path evaluates it in the gradient launch)
         use_cache = (not fused) and Fn.cache_supported(sd0, self.spp) and not getattr(self, "_cache_overflowed", False)

@@ -658,6 +658,15 @@ int ffx_render_fwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info 
                             const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
                             int img_fp16 /* FFX_RENDER_FP16 | FFX_RENDER_APEX_READY */, void *img /*[dev][H,W,3]*/, void *scratch /*[dev]*/,
                             ffx_stream stream);
+/* Filtered render and its adjoint for a loss that is LINEAR in the image (gimg known before the render), as ffx_render_fwd_adjoint is for
+ * the box film: the weights first (two small launches: G = gimg / weight), then ONE render launch whose per-pixel texture footprints take
+ * every sample's own gradient sum_n w_n G[pixel + n], then the gather of the image.  gtex ACCUMULATED.  1-channel projector textures,
+ * no textured base colours (FFX_ERR_UNSUPPORTED otherwise: ffx_render_fwd_filtered + ffx_render_bwd_filtered serve every case).
+ * Flags: FFX_RENDER_FP16, FFX_RENDER_SPARSE_ADJOINT, FFX_RENDER_APEX_READY.  Same result as that pair up to the order of the float atomics. */
+int ffx_render_fwd_adjoint_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                                    const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
+                                    int img_fp16, void *img /*[dev][H,W,3]*/, const float *gimg /*[dev][H,W,3] fp32*/,
+                                    float *gtex /*[dev][tex_h,tex_w,1]*/, void *scratch /*[dev]*/, ffx_stream stream);
 int ffx_render_bwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
                             const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed,
                             const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, void *scratch /*[dev]*/,

@@ -1847,6 +1847,19 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
 }
 
 int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                            const float *gimg, float *gtex, void *scratch, ffx_stream s);
+/* forward + adjoint of a linear loss in one call (include/ffx.h): here the composition it stands for */
+int ffx_render_fwd_adjoint_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                                    uint32_t seed, int img_fp16, void *img, const float *gimg, float *gtex, void *scratch, ffx_stream s) {
+  if (!gimg || !gtex) FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: gimg / gtex is NULL");
+  if (!sd || !sd->proj.enabled) FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: the scene has no projector (nothing to differentiate)");
+  if (sd->proj.tex_channels != 1 || sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint_filtered: 1-channel projector textures without textured base colours");
+  int rc = ffx_render_fwd_filtered(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, scratch, s);
+  if (rc == FFX_OK) rc = ffx_render_bwd_filtered(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, scratch, s);
+  return rc;
+}
+
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
                             const float *gimg, float *gtex, void *scratch, ffx_stream s) {
   (void)s;
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;

@@ -340,6 +340,11 @@ class Geometry:
         H, W = sd.cam.height, sd.cam.width
         img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        if sd.rfilter:
+            scratch = np.empty(api().lib.ffx_render_filter_bytes(C.byref(sd)), np.uint8)
+            api().call("ffx_render_fwd_adjoint_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(gimg), _p(gtex),
+                       _p(scratch), None)
+            return img, gtex, float((img.astype(np.float64) * gimg.astype(np.float64)).sum())
         dot = np.zeros(4096, np.float32)
         api().call("ffx_render_fwd_adjoint", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(gimg), _p(gtex), _p(dot), None)
         return img, gtex, float(dot.astype(np.float64).sum())

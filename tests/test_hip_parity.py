@@ -1551,8 +1551,23 @@ def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(ora
     cache = torch.empty(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device="cuda")
     with pytest.raises(ValueError, match="box"):
         gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
-    with pytest.raises(ValueError, match="box"):
-        gd.render_fwd_adjoint(sd, dev(alb), tex, spp, 11, dev(gimg))
+    if ch == 1:
+        # forward + adjoint of a loss that is linear in the image in ONE render launch (ffx_render_fwd_adjoint_filtered): the same image, the same
+        # gradient as the pair above (and the oracle's composition), also with the sparse flag where the texture is not zero
+        img_f, gt_f = gd.render_fwd_adjoint(sd, dev(alb), tex, spp, 11, dev(gimg))
+        assert torch.equal(img_f.cpu(), torch.from_numpy(img_d))
+        ef = np.abs(host(gt_f) - gt_o)
+        assert (ef > 1e-3 * gs).mean() <= 2e-3 and ef.max() <= 0.1 * gs
+        np.testing.assert_allclose(host(gt_f), gt_d, rtol=0, atol=2e-4 * gs)  # (the order of the float atomics)
+        _, gt_s = gd.render_fwd_adjoint(sd, dev(alb), tex, spp, 11, dev(gimg), sparse_adjoint=True)
+        nz = host(tex).reshape(gt_d.shape) != 0
+        np.testing.assert_allclose(host(gt_s)[nz], gt_d[nz], rtol=0, atol=2e-4 * gs)
+        img_o2, gt_o2, _ = go.render_fwd_adjoint(sd, alb, host(tex), spp, 11, gimg)
+        np.testing.assert_array_equal(img_o2, img_o)
+        np.testing.assert_allclose(gt_o2, gt_o, rtol=0, atol=1e-6 * gs)
+    else:
+        with pytest.raises(ValueError, match="1-channel"):
+            gd.render_fwd_adjoint(sd, dev(alb), tex, spp, 11, dev(gimg))
     lib, UNSUPPORTED = ops.api(), -3  # FFX_ERR_UNSUPPORTED
     img_t = torch.empty((64, 72, 3), device="cuda")
     mats_arg = dev(alb).data_ptr()
@@ -1564,7 +1579,8 @@ def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(ora
 
 def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
     """mi.Scene.rfilter = "gaussian": mi.render goes through the filtered entry points (also beside the previous render on the scene's second
-    stream), autograd differentiates through the re-traced filtered adjoint, and the optimiser takes its re-trace path."""
+    stream), autograd differentiates through the re-traced filtered adjoint, and the optimiser takes the fused launch for its linear loss and
+    re-traces for a non-linear one."""
     from fireflies_amd import functional as Fn, mi, workloads
     from fireflies_amd.optim import PatternOptimizer
 
@@ -1591,8 +1607,15 @@ def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
     opt = PatternOptimizer(ms, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=2)
     before = wl.laser._rays.detach().clone()
     res = opt.step()
-    assert opt.step_paths["retrace"] == 2 and opt.step_paths["fused"] == 0 and opt.step_paths["cache_k9"] == 0
+    assert opt.step_paths["fused"] == 2 and opt.step_paths["retrace"] == 0 and opt.step_paths["cache_k9"] == 0  # (the coverage loss is linear in the image)
     assert np.isfinite(float(res["loss"])) and not torch.equal(before, wl.laser._rays.detach())
+    # ... and a loss that is not linear in the image re-traces (the footprint cache folds box pixels)
+    from fireflies_amd.optim import image_l1_loss
+
+    opt2 = PatternOptimizer(ms, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=2,
+                            loss_fn=image_l1_loss(a.float()))
+    res2 = opt2.step()
+    assert opt2.step_paths["retrace"] == 2 and np.isfinite(float(res2["loss"]))
 
 
 def test_per_slot_normal_area_holds_what_the_header_says():
