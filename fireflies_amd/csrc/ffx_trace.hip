@@ -1904,6 +1904,27 @@ __device__ __forceinline__ bool bins_primary(const BinsK &bk, const int px, cons
   return true;
 }
 
+// primary rays of a compact block of bw x bh pixels (K7's packets at fewer than 64 samples per pixel: 4x4 pixels at 1 spp ... one pixel):
+// the block is aligned to its own size and at most 4 pixels wide, so it lies inside ONE tile of >= 4 pixels; its rectangle is the block
+__device__ __forceinline__ bool bins_block(const BinsK &bk, const int bx0, const int by0, const int bw, const int bh, const TriApex *__restrict__ recs, const v3 d,
+                                           const float tmin, const float tmax, const wmask active, Hit &h) {
+  if (!bins_ready(bk, 0)) return false;
+  if (active == 0ull) { h.t = -INFINITY; h.prim = -1; h.shape = -1; h.slot = -1; return true; }
+  const float its_x = bk.cam_inv_ts_x, its_y = bk.cam_inv_ts_y; // 1 / tile side: a power of two
+  if ((float)bw * its_x > 1.0f || (float)bh * its_y > 1.0f) return false; // (tiles smaller than the block: FFX_BIN_TILE experiments)
+  const float x0 = (float)bx0 * its_x, y0 = (float)by0 * its_y;
+  const int tx = (int)x0, ty = (int)y0;
+  const float hx = 0.5f * (float)bw * its_x - 0.25f * FFX_BIN_PAD, hy = 0.5f * (float)bh * its_y - 0.25f * FFX_BIN_PAD;
+  const float cx = x0 + hx, cy = y0 + hy;
+  const int stx = __builtin_amdgcn_readfirstlane(tx), sty = __builtin_amdgcn_readfirstlane(ty);
+  const float scx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx))), scy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+  const float shx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hx))), shy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hy)));
+  if (stx >= bk.g[0].nx || sty >= bk.g[0].ny) return false;
+  wmask occ;
+  traverse_bins<false>(bk.base[0], bk.g[0].nx, stx, sty, stx, sty, scx, scy, shx, shy, recs, d, tmin, tmax, active, h, occ);
+  return true;
+}
+
 // four wave-wide reductions of non-negative floats at once — two minima, two maxima — in interleaved DPP chains (wave_reduce3_nn's
 // scheme: the three instructions between a DPP write and the next read of the same register are the wait states the hazard needs)
 __device__ __forceinline__ void wave_reduce_minmax4(uint32_t &mn0, uint32_t &mn1, uint32_t &mx0, uint32_t &mx1) {
@@ -2329,7 +2350,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(FFX_PK1_WAVES, FFX_PK1_WAVES)))
     k_trace_primary_pk(CamK cam, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, WideScene ws, int spp,
                        int jitter, uint32_t seed_key, int bw_log2,
-                       int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out) {
+                       int bh_log2, int blocks_x, int n_blocks, float *__restrict__ t_out, int32_t *__restrict__ shape_out, int32_t *__restrict__ prim_out, BinsK bins) {
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
   // (wave-uniform by construction; readfirstlane tells the compiler, which otherwise carries everything derived from it in VGPRs)
   const int blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -2355,7 +2376,12 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(F
     cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o[0], d[0], nt[0], ft[0]);
     Hit h[1];
     bool fnd[1];
-    traverse_packet_any<false, 1, WIDE>(nodes, arecs, ws, s_wstack, o, d, nt, ft, active, h, fnd);
+    // round 4: the block's candidates from the camera's tile bins (as K8's primary rays) — the tree walk when there are none
+    // (no bins area, a grid that is off or overflowed)
+    bool binned = false;
+    if (bins.g[0].on)
+      binned = bins_block(bins, (blk % blocks_x) << bw_log2, (blk / blocks_x) << bh_log2, 1 << bw_log2, 1 << bh_log2, arecs, d[0], nt[0], ft[0], wballot(active[0]), h[0]);
+    if (!binned) traverse_packet_any<false, 1, WIDE>(nodes, arecs, ws, s_wstack, o, d, nt, ft, active, h, fnd);
     if (active[0]) {
       const bool hit = h[0].prim >= 0;
       t_out[idx] = hit ? (h[0].t - nt[0]) : 0.f;
@@ -3701,18 +3727,26 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
     const int wpb = packet_waves();
     const TriApex *arecs;
     uint32_t astride;
-    if (!launch_apex(bvh, info, cam->to_world, nullptr, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    // the pre-pass of a camera-only scene: apex records and (round 4) the camera's tile bins; with FFX_RENDER_APEX_READY in `jitter` the
+    // camera's area already holds both — a render of this pose from this camera wrote them — and nothing is launched in front of the kernel
+    ffx_scene_desc sdt;
+    memset(&sdt, 0, sizeof sdt);
+    sdt.cam = *cam;
+    if (!launch_apex(bvh, info, cam->to_world, &sdt, &arecs, &astride, (hipStream_t)s, nullptr, 0, jitter & FFX_RENDER_APEX_READY)) return FFX_ERR_ARG;
+    BinsK bk;
+    bins_k(bvh, info, &sdt, bk);
+    const int jit = jitter & 1;
     const WideScene ws = wide_scene(bvh, info);
     if (use_wide(info))
-      hipLaunchKernelGGL(k_trace_primary_pk<true>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jitter,
-                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+      hipLaunchKernelGGL(k_trace_primary_pk<true>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jit,
+                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out, bk);
     else
-      hipLaunchKernelGGL(k_trace_primary_pk<false>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jitter,
-                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out);
+      hipLaunchKernelGGL(k_trace_primary_pk<false>, dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, k, nodes, recs, arecs, ws, spp, jit,
+                         seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, t_out, shape_out, prim_out, bk);
     FFX_CHECK_LAUNCH("trace_primary");
     return FFX_OK;
   }
-  hipLaunchKernelGGL(k_trace_primary, dim3(ffx_cdiv(total, TR_BLOCK)), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, k, nodes, recs, spp, jitter,
+  hipLaunchKernelGGL(k_trace_primary, dim3(ffx_cdiv(total, TR_BLOCK)), dim3(TR_BLOCK), stack_bytes(info), (hipStream_t)s, k, nodes, recs, spp, jitter & 1,
                      seed_key_of(seed), total, t_out, shape_out, prim_out);
   FFX_CHECK_LAUNCH("trace_primary");
   return FFX_OK;

@@ -378,10 +378,15 @@ def apex_key(sd=None, cam=None):
     if sd is not None:
         key += [C.string_at(C.addressof(sd.proj), C.sizeof(sd.proj)) if sd.proj.enabled else None]
         key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg) if sd.spot.enabled else None]  # (not its intensity: randomised per step, no part of the pre-pass)
-        key += [_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N")]
     else:
-        key += [None, None, None]
+        key += [None, None]
+    key += [_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N")]
     return tuple(key)
+
+
+def _camera_part(key):
+    """of an apex_key: what the camera's area (its apex records and tile bins) depends on"""
+    return None if key is None else (key[0], key[3], key[4])
 
 
 def _lane_kernels():
@@ -647,13 +652,25 @@ class DeviceGeometry:
         t = torch.empty(n, dtype=torch.float32, device=self.device)
         shape = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
         prim = torch.empty(n, dtype=torch.int32, device=self.device) if want_ids else None
+        flags = 0
         if not _lane_kernels():
             i = self._cur if self._async else 0
-            self._apex[i] = None  # (it rewrites the camera's area; the emitters' areas keep what they had: claim nothing)
             self._acquire()
-            self._wait_readers(i, _stream_obj(self._didx))
+            so = _stream_obj(self._didx)
+            key = apex_key(cam=cam)
+            if _camera_part(self._apex[i]) == _camera_part(key):
+                # the camera's area already holds this camera's records and tile bins (a render of this pose from it, or an earlier trace):
+                # nothing is rewritten — whatever the areas were claimed to hold, they still do
+                flags = _abi.RENDER_APEX_READY
+                w = self._apex_written[i]
+                if w is not None and w[0] != so.cuda_stream:
+                    so.wait_event(w[1])
+            else:
+                self._apex[i] = key  # (it rewrites the camera's area; the emitters' areas keep what they had, but a render has to re-derive its own)
+                self._wait_readers(i, so)
+                self._apex_writer_pending = True
         self._call(
-            "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(jitter), int(seed) & 0xFFFFFFFF,
+            "ffx_trace_primary", _dev(self.blob, torch.uint8), C.byref(self.info), C.byref(cam), int(spp), int(bool(jitter)) | flags, int(seed) & 0xFFFFFFFF,
             _dev(t), _dev(shape, torch.int32) if want_ids else None, _dev(prim, torch.int32) if want_ids else None, _stream(self._didx),
         )
         self._release()

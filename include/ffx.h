@@ -450,6 +450,9 @@ typedef struct ffx_camera {
   int32_t width, height;
 } ffx_camera;
 
+/* jitter: bit 0 = per-sample jitter on; | FFX_RENDER_APEX_READY (4, defined below): the blob's camera area already holds THIS camera's apex
+ * records and tile bins — a render or trace call of this pose from this camera wrote them (ffx_apex_prepare's promise, camera part) — and
+ * nothing is launched in front of the kernel.  Without it the call writes the camera's records and bins itself. */
 int ffx_trace_primary(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
                       const ffx_camera *cam /*[host]*/, int spp, int jitter, uint32_t seed,
                       float *t_out /*[dev][H*W*spp]*/, int32_t *shape_out /*[dev] or NULL*/,

@@ -1062,6 +1062,7 @@ static inline void cam_ray(const cam_ctx *k, float sx, float sy, v3 *d, float *n
 int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camera *cam, int spp, int jitter, uint32_t seed, float *t_out,
                       int32_t *shape_out, int32_t *prim_out, ffx_stream s) {
   (void)s;
+  jitter &= 1; /* (bit 2: FFX_RENDER_APEX_READY — nothing to prepare here) */
   if (!bvh || !info || !cam || !t_out || spp < 1) FAIL(FFX_ERR_ARG, "trace_primary: bad argument");
   cam_ctx k;
   if (!cam_prepare(cam, &k)) FAIL(FFX_ERR_ARG, "trace_primary: bad camera");
