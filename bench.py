@@ -747,7 +747,8 @@ def main():
                                   else "coverage_loss through the cache + K9")},
             "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if fused_ran else "render_fwd(+cache write)"): k8g_ms,
                                 "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
-            "grad_launches_per_step": "pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if fused_ran
+            "grad_launches_per_step": ("pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if args.rfilter == "box" else
+                                       "pattern_fwd_blur, [rf_weights, rf_gather (G), render_fwd_adjoint_filtered, rf_gather (image)], pattern_bwd<5> (+ re-fit and pre-pass on the side stream)") if fused_ran
             else "pattern_fwd_blur, render_fwd_cache, render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)",
             "grad_step_paths": lin_paths,
             "render_fwd_adjoint_roofline": None if not (fused_ran and k8g_ms) else {
