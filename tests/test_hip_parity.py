@@ -831,10 +831,23 @@ def test_apex_records_written_ahead_and_cache_header_cleared_by_the_caller(oracl
     assert gd._apex[i_cur()] == ops.apex_key(sd2) and not torch.equal(other, ref)
     np.testing.assert_allclose(host(other), go.render_fwd(sd2, alb, host(tex), 9, seed=3), rtol=2e-4, atol=2e-6 * float(ref.max()))
     assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)
-    # a primary trace rewrites the camera's area only: nothing is claimed afterwards
-    gd.trace_primary(scene_desc.camera_from_sensor(sc.camera, cam2), 1, 0, 0)
-    assert gd._apex[i_cur()] is None
-    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)
+    # a primary trace from the camera of the last render finds the camera's records and tile bins in place (FFX_RENDER_APEX_READY in its
+    # `jitter` argument): nothing is rewritten, the claim stays; from ANOTHER camera it rewrites the camera's area and claims that alone
+    cam1 = scene_desc.camera_from_sensor(sc.camera)
+    t_ready = gd.trace_primary(cam1, 2, 1, 5)
+    assert gd._apex[i_cur()] == ops.apex_key(sd)
+    cam2s = scene_desc.camera_from_sensor(sc.camera, cam2)
+    t_other = gd.trace_primary(cam2s, 2, 1, 5)
+    assert gd._apex[i_cur()] == ops.apex_key(cam=cam2s) != ops.apex_key(sd2)
+    t_fresh = gd.trace_primary(cam1, 2, 1, 5)  # (writes the camera's area itself this time)
+    assert gd._apex[i_cur()] == ops.apex_key(cam=cam1)
+    for a_, b_ in zip(t_ready, t_fresh):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(t_other[0], t_fresh[0])
+    t_o = go.trace_primary(cam1, 2, 1, 5)
+    same = (host(t_fresh[2]) == t_o[2])
+    assert same.mean() > 0.998 and np.allclose(host(t_fresh[0])[same], t_o[0][same], rtol=2e-5, atol=2e-6)
+    assert torch.equal(gd.render_fwd(sd, dev(alb), tex, 9, seed=3), ref)  # (a render re-derives its own: the emitters' part is not claimed by a trace)
     # the re-tracing adjoint prepares for itself and leaves its records behind
     gimg = dev(np.random.default_rng(0).standard_normal((44, 52, 3)).astype(np.float32))
     g_ref = gd.render_bwd(sd2, dev(alb), 9, 3, gimg)
