@@ -617,6 +617,21 @@ def test_full_size_parity_with_the_oracle_at_512x512x64(oracle):
             ge = np.abs(host(gtex_f) - gtex_o)
             assert (ge > 1e-3 * gs).mean() <= 1e-3 and ge.max() <= 0.05 * gs, ((ge > 1e-3 * gs).mean(), ge.max() / gs)
             assert float(dot.double().sum()) == pytest.approx(dot_o, rel=1e-4)
+            # ... and the gaussian film at the full size (round 4): ffx_render_fwd_filtered against the oracle's, the fused filtered forward +
+            # adjoint launch against the filtered pair on the device (the oracle's filtered adjoint re-traces 16.8 M samples serially: minutes),
+            # and the two directions as transposes of each other
+            sdg = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16, rfilter="gaussian")
+            img_g = gd.render_fwd(sdg, dev(mats), tex, 64, seed=i)
+            _assert_image_close(host(img_g), go.render_fwd(sdg, mats, host(tex), 64, seed=i), 64, frac=5e-3, what="gaussian film at 512x512x64")
+            gt_g = gd.render_bwd(sdg, dev(mats), 64, i, dev(gimg))
+            img_gf, gt_gf = gd.render_fwd_adjoint(sdg, dev(mats), tex, 64, i, dev(gimg))
+            assert torch.equal(img_gf, img_g)
+            gsg = float(gt_g.abs().max())
+            assert gsg > 0 and float((gt_gf - gt_g).abs().max()) <= 2e-4 * gsg
+            base_g = gd.render_fwd(sdg, dev(mats), torch.zeros_like(tex), 64, seed=i)
+            lhs = float(((img_g - base_g).double() * dev(gimg).double()).sum())
+            rhs = float((tex.double() * gt_g[..., 0].double()).sum())
+            assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs)), (lhs, rhs)
     assert total == 3 * 512 * 512 * 64
     assert lost == 0, f"{lost} rays hit in the oracle and missed on the GPU"
     assert flips <= 2, f"{flips} of {total} rays hit a different primitive"
