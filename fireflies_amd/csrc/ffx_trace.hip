@@ -3477,12 +3477,14 @@ static WideScene wide_scene(const void *bvh, const ffx_bvh_info *info) {
 }
 
 // log2 of the side (in 2x2-pixel tiles) of the square blocks in which tiles are enumerated: FFX_TILE_BLOCK,
-// default 3 = 16x16-pixel blocks (+1 % on both workloads against row-major; the blocked XCD interleave on top of it,
+// default 4 = 32x32-pixel blocks since the tile bins (round 4: 3 / 4 / 5 = 0.4033 / 0.4001 / 0.42 ms for K8 alone, renders/s 2 469 / 2 500,
+// gradient steps/s 2 288 / 2 354, colon 8.39 / 8.31 ms — a block of 16 bin tiles keeps a workgroup round inside fewer tile lists);
+// before them 3 = 16x16-pixel blocks (+1 % on both workloads against row-major; the blocked XCD interleave on top of it,
 // FFX_XCD_REMAP >= 2: B = 64 / 128 / 256 / 512 / 1024 measured +0.5 / +1 / -1 / -2 / -10 % against the round-robin deal)
 static int tile_block_log2() {
   const char *e = getenv("FFX_TILE_BLOCK");
-  int t = e ? atoi(e) : 3;
-  return (t < 0 || t > 8) ? 3 : t;
+  int t = e ? atoi(e) : 4;
+  return (t < 0 || t > 8) ? 4 : t;
 }
 
 // pixels of its 2x2 tile a wave of k_render_fwd_pk walks: FFX_PIXELS_PER_WAVE = 1, 2 (default) or 4.
