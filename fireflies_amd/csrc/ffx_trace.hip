@@ -3494,7 +3494,11 @@ static int tile_block_log2() {
 // per-pixel footprint bookkeeping amortises better: one pixel per wave was 1.5 % slower there); colon: no difference
 static int pixels_per_wave(bool with_cache) {
   const char *e = getenv("FFX_PIXELS_PER_WAVE");
-  const int dflt = with_cache ? 2 : 1;
+  // (round 4, with the tile bins and 32x32-pixel enumeration blocks: two pixels per wave for the plain forward too — 1 / 2 / 4 pixels =
+  // 2 450 / 2 610 / 2 600 renders/s over 100 steps, 2 390 / 2 500 / 2 500 over the driver's 20, K8 alone 0.399 / 0.387 / 0.419 ms; colon
+  // 117.9 / 118.8 / 106.2 renders/s.  Half as many waves to dispatch, and a wave's second pixel finds its tile list in the L1)
+  (void)with_cache;
+  const int dflt = 2;
   int w = e ? atoi(e) : dflt;
   return (w == 1 || w == 2 || w == 4) ? w : dflt;
 }
