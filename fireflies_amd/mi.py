@@ -12,6 +12,7 @@ vocalfold_scene.py:69), `scene.sensors()[i].film().size()/crop_size()/crop_offse
 Everything numeric lives on the HIP device: `params.update()` runs K5+K6 (ffx_scene_update),
 `mi.render` runs K8 (and K9 under autograd when `tex.data` requires grad).
 """
+import ctypes as C
 import math
 import os
 
@@ -22,6 +23,15 @@ from . import functional as Fn
 from . import _abi, ops, scene_desc, scenes
 
 _variant = "hip_ad_rgb"
+
+
+_POSE_KEY, _PLAIN_KEY = object(), object()  # Scene._key_plan markers
+
+# float offsets of the fields scene_desc() patches per step (ffx_scene_desc: camera / projector / spot poses, the spot's intensity)
+_SD_CAM_TW = (_abi.SceneDesc.cam.offset + _abi.Camera.to_world.offset) // 4
+_SD_PROJ_TW = (_abi.SceneDesc.proj.offset + _abi.Projector.to_world.offset) // 4
+_SD_SPOT_TW = (_abi.SceneDesc.spot.offset + _abi.Spot.to_world.offset) // 4
+_SD_SPOT_INT = (_abi.SceneDesc.spot.offset + _abi.Spot.intensity.offset) // 4
 
 
 def set_variant(name: str) -> None:
@@ -187,6 +197,13 @@ class Transform4f:
         if not isinstance(m, torch.Tensor):
             m = torch.as_tensor(np.asarray(m, dtype=np.float32))
         self._m = m.detach().to("cpu", torch.float32).reshape(4, 4).clone()
+
+    @classmethod
+    def _from_rows(cls, rows16):
+        """from 16 host floats (row-major), copied — no tensor conversions (the native randomiser's tables)"""
+        t = cls.__new__(cls)
+        t._m = torch.from_numpy(np.array(rows16, dtype=np.float32).reshape(4, 4))
+        return t
 
     @property
     def matrix(self):
@@ -462,6 +479,9 @@ class Scene:
         if data.projector is not None:
             self._sensors.append(Sensor(self, data.projector.name))
         self._sd_cache = None
+        self._sd_templates = {}  # tex_channels -> (key of what else it depends on, finished description): scene_desc() patches the per-step fields into a copy
+        self._key_plan = {}      # parameter key -> what _apply does for it (worked out the first time the key is seen)
+        self._key_dyn = {}       # parameter key -> is it one of the per-step fields scene_desc() patches?
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -564,10 +584,30 @@ class Scene:
     def _apply(self, dirty):
         geom_dirty = False
         albedo_dirty = False
+        plan = self._key_plan
         for k in dirty:
+            kp = plan.get(k)
+            if kp is not None:
+                # (a key seen before: what it means was worked out then — 19 keys per randomisation went through the string handling below, 25 us)
+                if kp is _POSE_KEY:
+                    geom_dirty = True
+                elif kp is not _PLAIN_KEY:
+                    col, rows, conv, eta_key, warn_st = kp
+                    v = self._params._d[k]
+                    v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
+                    if conv:  # `specular`: the plugin re-derives eta from it
+                        v = scenes.specular_to_eta(v)
+                        self._params._d[eta_key] = Float(v)
+                    if warn_st and v > 0.0:
+                        self._warn_spec_trans(k)
+                    for i in rows:
+                        self._albedo_host[i, col] = v
+                    albedo_dirty = True
+                continue
             base, _, rest = k.partition(".")
             if rest == "__pose__":
                 geom_dirty = True
+                plan[k] = _POSE_KEY
             elif rest == "vertex_positions" and base in self._mesh_index:
                 # generic Mitsuba-style path: the caller transformed the vertices itself
                 v = self._params._d[k]
@@ -603,6 +643,7 @@ class Scene:
                 for i in self._material_meshes[base]:
                     self._albedo_host[i, col] = v
                 albedo_dirty = True
+                plan[k] = (col, tuple(self._material_meshes[base]), name == "specular", base + ".brdf_0.eta", name == "spec_trans")
             elif rest == "brdf_0.base_color.data" and any(n == base for n, _ in self._base_tex):
                 # a new base-colour texture (main.py:147-153 assigns one per iteration, through numpy): any resolution, [h,w,3]
                 v = self._params._d[k]
@@ -619,6 +660,9 @@ class Scene:
                 for i in self._material_meshes[base]:
                     self._albedo_host[i, :3] = c
                 albedo_dirty = True
+            else:
+                if not (rest.startswith("brdf_0.") or rest == "vertex_positions"):
+                    plan[k] = _PLAIN_KEY  # (an emitter / sensor / texture parameter: read when the scene description is formed)
         if albedo_dirty:
             if self._mats_in_sd:
                 self._albedo_stale = True  # the next scene_desc() carries the new rows; the device tensor is refreshed on demand
@@ -626,6 +670,17 @@ class Scene:
                 self._upload_albedo()
         ch = self._sd_cache[0] if self._sd_cache is not None else 3
         self._sd_cache = None
+        kd = self._key_dyn
+        for k in dirty:
+            # (the fields a randomisation writes every step — poses, emitter poses, intensity and cone, material values — are patched into a copy of the
+            # finished description; anything else — a field of view, a clip plane, the projector's scale, a new base-colour texture — rebuilds it)
+            dyn = kd.get(k)
+            if dyn is None:
+                dyn = kd[k] = (k.endswith(".__pose__") or k.endswith(".to_world") or k.endswith(".intensity.value") or k.endswith(".vertex_positions") or k == "tex.data"
+                               or k.endswith(".cutoff_angle") or k.endswith(".beam_width") or (".brdf_0." in k and not k.endswith(".data")))
+            if not dyn:
+                self._sd_templates = {}
+                break
         if geom_dirty:
             # the renders of this pose will come from the camera / emitter positions the parameters hold NOW (every assignment of
             # the update has been applied above): their apex records are written behind the re-fit, on its side stream, and the
@@ -703,10 +758,33 @@ class Scene:
         scene_desc.set_rfilter(_abi.SceneDesc(), value)  # (validates)
         self._rfilter = None if value in (None, "box") else (value if not isinstance(value, str) else (value, 0.5))
         self._sd_cache = None
+        self._sd_templates = {}
 
     def scene_desc(self, tex_channels=3):
         if self._sd_cache is not None and self._sd_cache[0] == tex_channels:
             return self._sd_cache[1]
+        tkey = (self.shadows, tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0)
+        tm = self._sd_templates.get(tex_channels)
+        if tm is not None and tm[0] == tkey:
+            # a copy of the finished description with this step's fields written over it (22 -> 6 us per step): the three poses, the spot's
+            # intensity, the material rows — everything else was read when the template was built and has not been assigned since (_apply)
+            sd = _abi.SceneDesc()
+            C.memmove(C.addressof(sd), C.addressof(tm[1]), C.sizeof(sd))
+            f = np.frombuffer(sd, dtype=np.float32)
+            d, p = self.data, self._params
+            f[_SD_CAM_TW:_SD_CAM_TW + 16] = self._mat(d.camera.name + ".to_world").reshape(-1)
+            if d.projector is not None:
+                f[_SD_PROJ_TW:_SD_PROJ_TW + 16] = self._mat("Projector.to_world").reshape(-1)
+            if d.spot is not None:
+                f[_SD_SPOT_TW:_SD_SPOT_TW + 16] = self._mat(d.spot.name + ".to_world").reshape(-1)
+                inten = p[d.spot.name + ".intensity.value"]
+                f[_SD_SPOT_INT:_SD_SPOT_INT + 3] = inten.t.reshape(-1)[:3].tolist() if isinstance(inten, _ArrayBase) else [float(v) for v in inten]
+                f[_SD_SPOT_INT + 3], f[_SD_SPOT_INT + 4] = float(p[d.spot.name + ".cutoff_angle"]), float(p[d.spot.name + ".beam_width"])
+            if self._mats_in_sd:
+                scene_desc.set_host_materials(sd, self._albedo_host)
+            sd._frozen = True  # (never written again: ops.apex_key may remember its key on it)
+            self._sd_cache = (tex_channels, sd)
+            return sd
         d, p = self.data, self._params
         cam = d.camera
         sensor = scenes.SensorData(cam.name, self._mat(cam.name + ".to_world"), float(p[cam.name + ".x_fov"]), float(p[cam.name + ".near_clip"]),
@@ -728,7 +806,12 @@ class Scene:
         sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride, base_tex=btex,
                                    slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None,
                                    host_mats=self._albedo_host if self._mats_in_sd else None, rfilter=self._rfilter)
+        sd._frozen = True
         self._sd_cache = (tex_channels, sd)
+        if not self._base_tex:  # (base-colour textures are re-assigned per iteration by the dataset loop: their addresses stay out of a template)
+            keep = _abi.SceneDesc()
+            C.memmove(C.addressof(keep), C.addressof(sd), C.sizeof(sd))
+            self._sd_templates[tex_channels] = (tkey, keep)
         return sd
 
     def camera_struct(self, index=0):

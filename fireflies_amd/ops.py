@@ -372,6 +372,10 @@ def apex_key(sd=None, cam=None):
     """what the blob's pre-pass areas must hold for a packet render / trace call (include/ffx.h ffx_apex_prepare): the apex records depend
     on the POSITIONS of the camera and of the enabled emitters, the tile bins (ffx_bvh_info.off_bins) on their whole projections — pose,
     field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
+    if sd is not None:
+        k = getattr(sd, "_apex_key", None)  # (a description is never modified once built: mi.Scene makes a new one per pose — 5 us per call otherwise)
+        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N")):
+            return k[0]
     c = sd.cam if sd is not None else cam
     # (the structs' bytes: ~1 us each — tuples of their 32 floats were 10 us per render call)
     key = [C.string_at(C.addressof(c), C.sizeof(c))]
@@ -380,8 +384,11 @@ def apex_key(sd=None, cam=None):
         key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg) if sd.spot.enabled else None]  # (not its intensity: randomised per step, no part of the pre-pass)
     else:
         key += [None, None]
-    key += [_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N")]
-    return tuple(key)
+    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"))
+    key = tuple(key) + env
+    if sd is not None and getattr(sd, "_frozen", False):  # (only descriptions whose maker promises not to touch them again: mi.Scene.scene_desc)
+        sd._apex_key = (key, env)
+    return key
 
 
 def _camera_part(key):
@@ -462,6 +469,7 @@ class DeviceGeometry:
         # (FFX_SIDE_PRIORITY: -1 = a high-priority queue for the side stream; measured: renders/s unchanged, gradient steps 2 130 -> 1 540 per
         # second — the step's small launches on the main stream then wait behind it.  0 = default)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) if self._async else None
+        self._side_handle = None
         self._upd_done = [None] * n_copies   # event: the refit of blob i has been enqueued up to here (side stream)
         self._apex = [None] * n_copies       # apex_key of what blob i's apex areas hold (None: nothing usable)
         self._apex_written = [None] * n_copies  # (stream handle, event) behind the call whose own pre-pass last wrote blob i's apex areas
@@ -581,21 +589,31 @@ class DeviceGeometry:
         if on_device:
             self._side.wait_stream(main)  # the tables were produced on the caller's stream
             xforms.record_stream(self._side)
-        with torch.cuda.stream(self._side):
-            self._update_into(self._blobs[nxt], xforms, on_device)
-            self._prepare_apex(nxt, apex_sd)
-            ev = self._upd_done[nxt]
-            if ev is None:
-                ev = self._upd_done[nxt] = torch.cuda.Event()
+        ev = self._upd_done[nxt]
+        if ev is None:
+            ev = self._upd_done[nxt] = torch.cuda.Event()
+        if self.timing is None and not on_device:
+            # (the two launch calls take the side stream's handle as an argument: making it the current stream first — a context manager and
+            # two current-stream queries — cost 10 us of the 65 this method took per step; the timed / device-table paths keep that form)
+            sh = self._side_handle
+            if sh is None:
+                sh = self._side_handle = C.c_void_p(self._side.cuda_stream)
+            self._update_into(self._blobs[nxt], xforms, on_device, sh)
+            self._prepare_apex(nxt, apex_sd, sh)
             ev.record(self._side)
+        else:
+            with torch.cuda.stream(self._side):
+                self._update_into(self._blobs[nxt], xforms, on_device)
+                self._prepare_apex(nxt, apex_sd)
+                ev.record(self._side)
         self._cur = nxt
 
-    def _prepare_apex(self, i, sd):
+    def _prepare_apex(self, i, sd, stream=None):
         """(on the stream the re-fit of blob i was enqueued on) the records changed: what the apex areas held is void"""
         self._apex[i] = None
         self._apex_written[i] = None
         if sd is not None and not _lane_kernels():
-            self._call("ffx_apex_prepare", _dev(self._blobs[i], torch.uint8, "blob"), C.byref(self.info), C.byref(sd), _stream(self._didx))
+            self._call("ffx_apex_prepare", _dev(self._blobs[i], torch.uint8, "blob"), C.byref(self.info), C.byref(sd), stream if stream is not None else _stream(self._didx))
             self._apex[i] = apex_key(sd)
 
     def _apex_flag(self, key):
@@ -617,7 +635,7 @@ class DeviceGeometry:
         self._apex[i] = key
         return _abi.RENDER_APEX_READY if ready else 0
 
-    def _update_into(self, blob, xforms, on_device):
+    def _update_into(self, blob, xforms, on_device, stream=None):
         with self._timed("scene_update"):
             if not on_device and self.n_shapes <= 32:
                 xf = xforms.detach().numpy() if isinstance(xforms, torch.Tensor) else np.asarray(xforms)
@@ -632,7 +650,7 @@ class DeviceGeometry:
                 self._call(
                     "ffx_scene_update_h", _dev(blob, torch.uint8, "blob"), C.byref(self.info), _dev(self.src_verts), _dev(self.tris, torch.int32),
                     _dev(self.tri_shape, torch.int32), tabs[2], tabs[0], self.n_shapes, C.byref(self._smooth[0]) if self._smooth is not None else None,
-                    _stream(self._didx),
+                    stream if stream is not None else _stream(self._didx),
                 )
                 return
             if self._vert_off_dev_stale:

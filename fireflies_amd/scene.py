@@ -123,6 +123,7 @@ class _NativePlan:
         plan.ents = (_abi.RandEntity * max(len(rows), 1))(*rows)
         plan.posed, plan.attrs, plan.samplers = posed, attrs, samplers
         plan.mesh_rows = [row_of[id(m)] for m in scene._meshes]
+        plan.row_of = row_of
         plan.gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
         plan.seed1, plan.off1 = (C.c_uint64 * 1)(), (C.c_uint64 * 1)()
         fn = api().lib.ffx_scene_randomize_h
@@ -158,6 +159,7 @@ class Scene:
         self._projector = None
         self._camera = None
         self._lights = []
+        self._native_chain = None  # set while _apply_native pushes a native call's tables (see _write_pose)
         self._curves = []
         self._materials = []
         self._transformables = []
@@ -334,6 +336,12 @@ class Scene:
             p[full] = type(p[full])(value)
 
     def _write_pose(self, ent) -> None:
+        nc = self._native_chain  # (inside _apply_native: the entity's world matrix is a row of the native call's chain table — _world_host()'s product, bit for bit)
+        if nc is not None:
+            i = nc[1].get(id(ent))
+            if i is not None and hasattr(mi.Transform4f, "_from_rows"):
+                self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f._from_rows(nc[0][i])
+                return
         self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f(ent._world_host().tolist())
 
     def update_camera(self) -> None:
@@ -604,12 +612,16 @@ class Scene:
             finally:
                 for m in self._meshes:
                     del m._pending_pick
-        if self._camera is not None:
-            self.update_camera()
-        if self._projector is not None:
-            self.update_projector()
-        self.update_lights()
-        self.update_materials()
+        self._native_chain = (mats[1][k], plan.row_of)
+        try:
+            if self._camera is not None:
+                self.update_camera()
+            if self._projector is not None:
+                self.update_projector()
+            self.update_lights()
+            self.update_materials()
+        finally:
+            self._native_chain = None
         p.update()
 
     def randomize(self) -> None:

@@ -1120,3 +1120,35 @@ def test_sample_ray_and_ray_intersect_objects_give_the_depth_map():
     o, d = wl.laser.originPerRay(), wl.laser.rays()
     si2 = ms.ray_intersect(mi.Ray3f(o[0], d))
     torch.testing.assert_close(si2.p.torch(), depth.cast_laser(ms, laser=wl.laser), rtol=1e-6, atol=1e-6)
+
+
+def test_patched_scene_description_is_the_full_build_byte_for_byte():
+    """mi.Scene.scene_desc() patches the per-step fields (poses, spot intensity, material rows) into a copy of a finished description instead of
+    rebuilding it (host time): over randomisations of both workloads' kinds of parameters the patched struct equals a full build byte for byte;
+    assigning anything else (a field of view, the projector's scale, the filter) drops the template."""
+    import ctypes as C
+
+    for make in (lambda: _small(), lambda: _small(entity_device="cpu")):
+        wl = make()
+        ms = wl.mi_scene
+        for k in range(6):
+            torch.manual_seed(50 + k)
+            random.seed(50 + k)
+            wl.ff_scene.randomize()
+            for ch in (1, 3):
+                ms._sd_cache = None
+                fast = ms.scene_desc(tex_channels=ch)
+                assert k == 0 or ms._sd_templates.get(ch) is not None
+                ms._sd_cache, keep = None, ms._sd_templates
+                ms._sd_templates = {}
+                full = ms.scene_desc(tex_channels=ch)
+                assert fast is not full and C.string_at(C.addressof(fast), C.sizeof(fast)) == C.string_at(C.addressof(full), C.sizeof(full)), (k, ch)
+                ms._sd_templates = keep
+        assert ms._sd_templates
+        cam = ms.data.camera.name
+        wl.params[cam + ".x_fov"] = mi.Float(float(wl.params[cam + ".x_fov"]) * 0.9)
+        wl.params.update()
+        assert not ms._sd_templates  # a static field was assigned: rebuilt on demand
+        a = ms.scene_desc(tex_channels=1)
+        ms.rfilter = "gaussian"
+        assert not ms._sd_templates and ms.scene_desc(tex_channels=1).rfilter == 1 and a.rfilter == 0
