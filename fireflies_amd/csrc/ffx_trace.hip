@@ -3481,10 +3481,14 @@ static WideScene wide_scene(const void *bvh, const ffx_bvh_info *info) {
 // gradient steps/s 2 288 / 2 354, colon 8.39 / 8.31 ms — a block of 16 bin tiles keeps a workgroup round inside fewer tile lists);
 // before them 3 = 16x16-pixel blocks (+1 % on both workloads against row-major; the blocked XCD interleave on top of it,
 // FFX_XCD_REMAP >= 2: B = 64 / 128 / 256 / 512 / 1024 measured +0.5 / +1 / -1 / -2 / -10 % against the round-robin deal)
-static int tile_block_log2() {
+// (films above 512 k pixels — config 5: 1024^2 x 256 spp, 141 MB of tile-list entries per pose — keep the round-3 parameters: the larger block and
+// the second pixel per wave buy them nothing (8.39 / 8.31 ms) and double the kernel's HBM traffic, 168 -> 343 MB of FETCH_SIZE per launch)
+// The kernels that fold footprints (cache / forward + adjoint) take the larger block there too: colon 114.5 -> 126.5 gradient steps/s.
+static int tile_block_log2(long pixels = 0, bool with_cache = false) {
   const char *e = getenv("FFX_TILE_BLOCK");
-  int t = e ? atoi(e) : 4;
-  return (t < 0 || t > 8) ? 4 : t;
+  const int dflt = (pixels > 2L * 512 * 512 && !with_cache) ? 3 : 4;
+  int t = e ? atoi(e) : dflt;
+  return (t < 0 || t > 8) ? dflt : t;
 }
 
 // pixels of its 2x2 tile a wave of k_render_fwd_pk walks: FFX_PIXELS_PER_WAVE = 1, 2 (default) or 4.
@@ -3492,13 +3496,12 @@ static int tile_block_log2() {
 // waves even out the tail of the launch, one pixel per wave pays the wave start-up four times.
 // default: one pixel per wave for the plain forward (finest grain: +1-2 %), two for the cache-writing forward (whose
 // per-pixel footprint bookkeeping amortises better: one pixel per wave was 1.5 % slower there); colon: no difference
-static int pixels_per_wave(bool with_cache) {
+static int pixels_per_wave(bool with_cache, long pixels = 0) {
   const char *e = getenv("FFX_PIXELS_PER_WAVE");
   // (round 4, with the tile bins and 32x32-pixel enumeration blocks: two pixels per wave for the plain forward too — 1 / 2 / 4 pixels =
   // 2 450 / 2 610 / 2 600 renders/s over 100 steps, 2 390 / 2 500 / 2 500 over the driver's 20, K8 alone 0.399 / 0.387 / 0.419 ms; colon
   // 117.9 / 118.8 / 106.2 renders/s.  Half as many waves to dispatch, and a wave's second pixel finds its tile list in the L1)
-  (void)with_cache;
-  const int dflt = 2;
+  const int dflt = (with_cache || pixels <= 2L * 512 * 512) ? 2 : 1;
   int w = e ? atoi(e) : dflt;
   return (w == 1 || w == 2 || w == 4) ? w : dflt;
 }
@@ -3799,12 +3802,12 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (adj_gtex && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
   if ((use_packet() || cache || adj_gtex) && !gn) FFX_FAIL(FFX_ERR_ARG, "render_fwd: blob without per-slot normals (built by another library version?)");
   if (use_packet() || cache || adj_gtex) { // the per-sample cache / the fused adjoint are the packet kernels' 
-    const int tb = tile_block_log2();
+    const int tb = tile_block_log2((long)c.cam.W * c.cam.H, cache != nullptr || adj_gtex != nullptr);
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
     int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb); // whole blocks; tiles outside the image are skipped
     ptx |= tb << 24;
     const int wpb = packet_waves();
-    const int ppw = pixels_per_wave(cache != nullptr || adj_gtex != nullptr);
+    const int ppw = pixels_per_wave(cache != nullptr || adj_gtex != nullptr, (long)c.cam.W * c.cam.H);
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
@@ -4006,7 +4009,7 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   const float4 *gn = info->off_gn ? (const float4 *)((const char *)bvh + info->off_gn) : nullptr;
   if (use_packet() && !gn) FFX_FAIL(FFX_ERR_ARG, "render_bwd: blob without per-slot normals (built by another library version?)");
   if (use_packet()) {
-    const int tb = tile_block_log2();
+    const int tb = tile_block_log2((long)c.cam.W * c.cam.H);
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
     int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb);
     ptx |= tb << 24;
