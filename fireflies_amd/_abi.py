@@ -173,6 +173,7 @@ PROTOTYPES = {
     "ffx_project_rays_bwd": (c_i, [c_p, c_i, PF, c_p, c_p, c_p]),
     "ffx_transform_points": (c_i, [c_p, c_i, PF, c_i, c_p, c_p]),
     "ffx_l1_value_grad": (c_i, [c_p, c_p, C.c_long, C.c_float, c_p, c_p, c_p]),
+    "ffx_l1_value_grad_acc": (c_i, [c_p, c_p, C.c_long, C.c_float, c_p, c_p, c_p, c_p]),
     "ffx_clamp_to_fov": (c_i, [c_p, c_i, PF, PF, C.c_float, C.c_float, c_i, c_p]),
     "ffx_pattern_ws_floats": (C.c_size_t, [c_i, c_i]),
     "ffx_pattern_fwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_p]),

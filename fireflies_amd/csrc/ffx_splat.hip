@@ -159,14 +159,18 @@ __global__ void __launch_bounds__(256) k_l1_partial(const float *__restrict__ a,
   __syncthreads();
   if (threadIdx.x == 0) ws[1 + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
-__global__ void __launch_bounds__(256) k_l1_final(float *__restrict__ ws, int nblocks, float vscale) {
+__global__ void __launch_bounds__(256) k_l1_final(float *__restrict__ ws, int nblocks, float vscale, float *__restrict__ acc_out) {
   __shared__ float s_part[4];
   float acc = (int)threadIdx.x < nblocks ? ws[1 + threadIdx.x] : 0.f;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_down(acc, o, 64);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) ws[0] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * vscale;
+  if (threadIdx.x == 0) {
+    const float v = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * vscale;
+    ws[0] = v;
+    if (acc_out) acc_out[0] += v; // (ffx_l1_value_grad_acc: a step's running loss — launches on one stream are ordered, one thread writes)
+  }
 }
 
 // =================================================================================== K2 dense forward
@@ -1173,10 +1177,13 @@ int ffx_transform_points(const float *pts, int n, const float *M, int mode, floa
 }
 
 int ffx_l1_value_grad(const float *a, const float *b, long n, float weight, float *ws, float *g, ffx_stream s) {
+  return ffx_l1_value_grad_acc(a, b, n, weight, ws, g, nullptr, s);
+}
+int ffx_l1_value_grad_acc(const float *a, const float *b, long n, float weight, float *ws, float *g, float *acc, ffx_stream s) {
   if (!a || !b || !ws || !g || n < 1) FFX_FAIL(FFX_ERR_ARG, "l1_value_grad: bad argument");
   int blocks = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
   hipLaunchKernelGGL(k_l1_partial, dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, n, weight / (float)n, ws, g);
-  hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(256), 0, (hipStream_t)s, ws, blocks, weight / (float)n);
+  hipLaunchKernelGGL(k_l1_final, dim3(1), dim3(256), 0, (hipStream_t)s, ws, blocks, weight / (float)n, acc);
   FFX_CHECK_LAUNCH("l1_value_grad");
   return FFX_OK;
 }

@@ -93,11 +93,15 @@ def transform_points(pts, M, mode=0):
     return out
 
 
-def l1_value_grad(a, b, weight=1.0):
-    """weight * L1Loss(a, b) (a 0-dim view into the workspace) and its gradient with respect to `a`"""
+def l1_value_grad(a, b, weight=1.0, acc=None):
+    """weight * L1Loss(a, b) (a 0-dim view into the workspace) and its gradient with respect to `a`; acc (a float32 tensor): the value is
+    also added to acc[0] by the same launches"""
     ws = torch.empty(257, dtype=torch.float32, device=a.device)
     g = torch.empty_like(a)
-    api().call("ffx_l1_value_grad", _dev(a, name="a"), _dev(b, name="b"), a.numel(), float(weight), _dev(ws), _dev(g), _stream())
+    if acc is not None:
+        api().call("ffx_l1_value_grad_acc", _dev(a, name="a"), _dev(b, name="b"), a.numel(), float(weight), _dev(ws), _dev(g), _dev(acc.reshape(-1), name="acc"), _stream())
+    else:
+        api().call("ffx_l1_value_grad", _dev(a, name="a"), _dev(b, name="b"), a.numel(), float(weight), _dev(ws), _dev(g), _stream())
     return ws[0], g
 
 

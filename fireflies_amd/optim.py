@@ -86,9 +86,15 @@ def image_l1_loss(target):
         return v, g.view(a.shape)
 
     def accumulate(img, acc):
-        v, g = value_and_grad(img)
-        acc.add_(v)
-        return g
+        from . import ops
+
+        a = img if img.dtype == torch.float32 else img.float()
+        if acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() >= 1:
+            _, g = ops.l1_value_grad(a.reshape(-1), tgt.reshape(-1), acc=acc)  # (the value joins the step's running loss inside the reduction launch)
+        else:
+            v, g = ops.l1_value_grad(a.reshape(-1), tgt.reshape(-1))
+            acc.add_(v)
+        return g.view(a.shape)
 
     loss.value_and_grad = value_and_grad
     loss.accumulate_value_and_grad = accumulate

@@ -157,6 +157,10 @@ int ffx_splat_lines_bwd(const float *lines /*[dev][n,2,2]*/, int n, float sigma,
  * ws: [dev][257] floats — [0] the value, [1..256] scratch for the two-pass reduction (fixed order). */
 int ffx_l1_value_grad(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, long n, float weight,
                       float *ws /*[dev][257]*/, float *g /*[dev][n]*/, ffx_stream stream);
+/* ... and acc[0] += ws[0] in the same launches (acc NULL: as above): the running loss of a step's scene samples when the task loss is an
+ * L1 against a target image (optim.image_l1_loss) — one launch less per sample than adding the value afterwards */
+int ffx_l1_value_grad_acc(const float *a /*[dev][n]*/, const float *b /*[dev][n]*/, long n, float weight,
+                          float *ws /*[dev][257]*/, float *g /*[dev][n]*/, float *acc /*[dev][1] or NULL*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * The pattern side of one optimisation step, fused (the loop of rasterization.py:583-607 with the projector in

@@ -164,6 +164,12 @@ int ffx_l1_value_grad(const float *a, const float *b, long n, float weight, floa
   return FFX_OK;
 }
 
+int ffx_l1_value_grad_acc(const float *a, const float *b, long n, float weight, float *ws, float *g, float *acc, ffx_stream s) {
+  const int rc = ffx_l1_value_grad(a, b, n, weight, ws, g, s);
+  if (rc == FFX_OK && acc) acc[0] += ws[0];
+  return rc;
+}
+
 /* Laser.clamp_to_fov + Laser.normalize_rays (fireflies/projection/laser.py:199-206,254-255):
  * project with KF, clamp the screen xy to [lo, hi], un-project with KF_inv, normalise n_normalize times */
 int ffx_clamp_to_fov(float *rays, int n, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {

@@ -449,6 +449,12 @@ def test_l1_value_grad_matches_oracle(oracle):
         vo, go = oracle.l1_value_grad(a, b, 0.1)
         assert abs(float(v) - vo) <= 2e-6 * max(vo, 1e-6)
         np.testing.assert_array_equal(host(g), go)
+        # ffx_l1_value_grad_acc: the same value also joins a running sum inside the reduction launch (a step's loss over its scene samples)
+        acc = torch.full((3,), 2.5, device="cuda")
+        v2, g2 = ops.l1_value_grad(dev(a), dev(b), 0.1, acc=acc[1])
+        v3, _ = ops.l1_value_grad(dev(a), dev(b), 0.1, acc=acc[1])
+        assert float(v2) == float(v) == float(v3) and torch.equal(g2, g)
+        assert host(acc).tolist() == [2.5, float(np.float32(np.float32(2.5) + np.float32(float(v))) + np.float32(float(v))), 2.5]
 
 
 def test_clamp_to_fov_matches_oracle(oracle):
