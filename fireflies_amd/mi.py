@@ -739,9 +739,11 @@ class Scene:
         if not getattr(self, "_warned_spec_trans", False):
             import warnings
 
-            warnings.warn(f"{what}: spec_trans > 0 — the principled BSDF's TRANSMISSION lobe is not evaluated here (both emitters are on the "
-                          "viewer's side of an opaque surface, refraction through the mesh is not traced); spec_trans only scales the diffuse "
-                          "lobe by (1 - spec_trans), as the plugin's reflection side does (DESIGN.md 4.3).  Not reported again for this scene.", stacklevel=5)
+            warnings.warn(f"{what}: spec_trans > 0 — the principled BSDF's TRANSMISSION lobe is not evaluated here; spec_trans only scales the diffuse "
+                          "lobe by (1 - spec_trans).  That is what Mitsuba does for the reference's materials too: they are principled BSDFs nested in "
+                          "`twosided` (`<mat>.brdf_0.*`), which only accepts a BSDF without a transmission component, so the plugin's lobe is switched "
+                          "off at load time (DESIGN.md 8).  A principled BSDF used WITHOUT `twosided` and lit from behind would differ.  "
+                          "Not reported again for this scene.", stacklevel=5)
             self._warned_spec_trans = True
 
     # ------------------------------------------------------------------ render-time blocks

@@ -546,8 +546,9 @@ typedef struct ffx_scene_desc {
  *         + (1-m) sheen Schlick_w(cos_d) lerp(1, base/lum, sheen_tint) cos_o
  * in a frame (s, t, n) with n the geometric normal faced to the viewer (two-sided, as the Blender exporter wraps
  * every material) and (s, t) = Mitsuba's coordinate_system(n) (meshes carry no uv tangents here).  The transmission
- * lobe of spec_trans is not evaluated (the emitters are on the viewer's side of an opaque surface); spec_trans only
- * scales the diffuse lobe, as in the reference.  `eta` is what Mitsuba derives from `specular`:
+ * lobe of spec_trans is not evaluated: the reference's materials are principled BSDFs nested in `twosided` (their keys are
+ * `<mat>.brdf_0.*`, main.py:99-107), which Mitsuba only accepts without a transmission component, so the plugin's lobe is
+ * off for good in those scenes and an assigned spec_trans only scales the diffuse lobe — as here.  `eta` is what Mitsuba derives from `specular`:
  * eta = 2 / (1 - sqrt(0.08 specular)) - 1  (specular 0 -> eta 1: no specular lobe at all, as in Mitsuba).
  * The render stays linear in the texture and affine in base_color, so the adjoint keeps its form. */
 #define FFX_MAT_STRIDE 16
