@@ -116,12 +116,16 @@ __device__ void bin_scan_one(char *base, int nt, uint32_t cap) {
 // apex records of the pre-pass (k_apex_records of ffx_trace.hip, same arithmetic): what to write for apex a
 struct BinApex { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; TriApex *out; uint32_t astride; uint32_t *cache_hdr; uint32_t cap_stray; };
 
-// One wave per workgroup, at most 80 VGPRs: these launches run beside a render whose one-wave workgroups (72 VGPRs, seven per SIMD) refill
-// every slot the moment it frees — a four-wave workgroup of 96-VGPR waves waited for four slots and enough registers on ONE compute unit at
-// the same time and hardly ever found them; a wave that fits the hole one retired render wave leaves is dispatched at once.
+// One wave per workgroup whose registers fit the hole ONE retired render wave leaves: these launches run beside a render whose one-wave
+// workgroups refill every slot the moment it frees.  A four-wave workgroup of 96-VGPR waves waited for four slots and enough registers on ONE
+// compute unit at the same time and hardly ever found them (2 058 -> 2 400 renders/s when it became one wave); and a one-wave workgroup of 80
+// VGPRs beside the Lambert render kernels — eight waves of 64 VGPRs per SIMD — still needed TWO of them to retire together: 141 + 143 us for
+// the two binning launches inside that loop instead of 42 + 77, and the loop's period was this chain's (2 773 -> 3 168 renders/s with the
+// diffuse material).  Hence WPE: 7 waves per SIMD (72 VGPRs, a few spilled) beside the material-row kernels (seven waves of 72), 8 (64 VGPRs)
+// beside the Lambert ones — the launch knows which (ffx_bins_launch `beside_lambert`).
 #define BIN_BLOCK 64
-template <bool FILL>
-__global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb, BinApex ba) {
+template <bool FILL, int WPE = 7>
+__global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_bin(const TriRec *__restrict__ recs, int n_tris, BinBuild bb, BinApex ba) {
   FFX_SIDE_PRIO();
   const int a = blockIdx.y;
   const int k = blockIdx.x * BIN_BLOCK + threadIdx.x;
@@ -329,15 +333,17 @@ __global__ void __launch_bounds__(64) k_bin_scan(BinBuild bb) {
 }
 
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s) {
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert) {
   BinApex ba;
   memset(&ba, 0, sizeof ba);
   for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
   ba.out = (TriApex *)apex_out; ba.astride = astride; ba.cache_hdr = cache_hdr; ba.cap_stray = cap_stray;
   const dim3 grid(ffx_cdiv(n_tris, BIN_BLOCK), FFX_N_APEX);
-  hipLaunchKernelGGL(k_bin<false>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
+  if (beside_lambert) hipLaunchKernelGGL((k_bin<false, 8>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
+  else hipLaunchKernelGGL((k_bin<false, 7>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   if (bb.g[0].on || bb.g[1].on || bb.g[2].on) {
     hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(64), 0, s, bb);
-    hipLaunchKernelGGL(k_bin<true>, grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
+    if (beside_lambert) hipLaunchKernelGGL((k_bin<true, 8>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
+    else hipLaunchKernelGGL((k_bin<true, 7>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   }
 }

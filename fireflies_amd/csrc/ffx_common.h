@@ -181,7 +181,7 @@ struct BinsK {
 // fill); with every grid off it is the apex records alone (one launch)
 struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad[0] of apex 0 */ };
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s);
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0);
 
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };

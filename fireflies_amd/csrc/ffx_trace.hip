@@ -3631,7 +3631,8 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
     if (!bb.arrive) { // no bins area to hold the arrival counter: the plain apex launch
       hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
     } else {
-      ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s);
+      // (the render kernels these launches will run beside: material rows -> seven waves of 72 VGPRs per SIMD, Lambert -> eight of 64)
+      ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s, sd && sd->mat_stride != FFX_MAT_STRIDE);
     }
   } else if (cache)
     hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);

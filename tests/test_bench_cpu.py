@@ -157,7 +157,7 @@ def test_every_profile_the_bench_line_cites_exists_is_not_empty_and_names_kernel
     for want in ("k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached", "k_bin<"):
         assert any(k.startswith(want) for k in g), f"the gradient bracket's PMC summary lacks {want}"
     stats = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()
-    assert "k_render_fwd_pk<1, true, 1, false, false>" in stats and "k_bin<true>" in stats  # (<R, WIDE, MATM, ADJ, RF>: the plain forward)
+    assert "k_render_fwd_pk<1, true, 1, false, false>" in stats and "k_bin<true" in stats  # (<R, WIDE, MATM, ADJ, RF>: the plain forward)
     # ... and what the line derives from them resolves to that same set
     t = bench.pmc_traffic("k_render_fwd_pk", "grad", "", adjoint_instance=True)
     assert t is not None and t["source"] == f"{tag}grad_pmc_summary.json"
