@@ -2535,7 +2535,8 @@ __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int 
 // 80-byte (b, 0..4) segments of the 68 source records it needs through LDS — five lanes per segment, every byte of the scratch area read
 // once — and lane x then picks entry a from record x + 4 - a.  (Read straight from memory a lane's 25 loads were 400 bytes apart from its
 // neighbours': 0.061 ms for 105 MB, the vector L1 thrashing.)
-#define FFX_RFG_WAVES 4
+#define FFX_RFG_WAVES 1 // (one-wave workgroups: the gather of one render runs beside the next render's kernel on the other stream — with four waves and 22 KB of LDS
+                        //  per workgroup it waited for room on one compute unit: 1 742 -> 1 913 filtered renders/s; the waves never cooperated anyway)
 __global__ void __launch_bounds__(64 * FFX_RFG_WAVES) k_rf_gather(const float4 *__restrict__ part, int W, int H, int fp16, void *__restrict__ img,
                                                                    const float *__restrict__ gimg, float4 *__restrict__ G) {
   __shared__ float4 s_seg[FFX_RFG_WAVES][68 * 5];
