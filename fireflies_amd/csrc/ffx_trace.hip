@@ -2653,15 +2653,6 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     // adjoint cache: window origin (wave-uniform) and shape of this pixel's footprint, -1 until a sample is lit
     int fox = -1, foy = -1, fshape = -1;
     float fin0 = 0.f, fin1 = 0.f, fin2 = 0.f; // the pixel's value as stored (ffx_render_fwd_adjoint: <gimg, img>)
-    if (fold) {
-      // (index laundered: the compiler otherwise keeps &s_foot[lane] in a VGPR across the whole kernel — and, at the
-      // 64-VGPR budget, spills it: 256 B of scratch traffic per wave for an address that costs two instructions)
-      int lz = lane;
-      asm volatile("" : "+v"(lz));
-      if (lz < 32) s_foot[lz] = 0.f;
-      if constexpr (MAT) { if (lz < 32) s_foot_b[lz] = 0.f; }
-      __builtin_amdgcn_wave_barrier();
-    }
     float rfacc[4] = {0.f, 0.f, 0.f, 0.f}; // RF: this lane's window entry (lane % 32, samples of half lane / 32), four channels, summed over the passes
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
@@ -2690,6 +2681,14 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         const wmask litm = wballot(lit);
         if (litm != 0ull) {
           if (fox < 0) { // first lit samples of the pixel: the window starts at their smallest tap
+            // (the footprint is cleared HERE, not at the start of every pixel: 96 % of the pixels of a dot pattern's render never get here.
+            // Index laundered: the compiler otherwise keeps &s_foot[lane] in a VGPR across the whole kernel — and, at the 64-VGPR budget,
+            // spills it: 256 B of scratch traffic per wave for an address that costs two instructions)
+            int lz = lane;
+            asm volatile("" : "+v"(lz));
+            if (lz < 32) s_foot[lz] = 0.f;
+            if constexpr (MAT) { if (lz < 32) s_foot_b[lz] = 0.f; }
+            __builtin_amdgcn_wave_barrier();
             fox = (int)wave_reduce_nn<false>(lit ? (uint32_t)st[0].ix0 : 0xffffffffu);
             foy = (int)wave_reduce_nn<false>(lit ? (uint32_t)st[0].iy0 : 0xffffffffu);
             fshape = __builtin_amdgcn_readlane(st[0].shape, wff1(litm));
@@ -2907,7 +2906,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         if (w != 0.f) atomicAdd(adj_gtex + (size_t)(foy + ey) * ca.tw + (fox + ex), w);
       }
     }
-    if (ADJ && !RF && live[0]) { // fused adjoint: the pixel's footprint x (gimg . albedo . colour) / spp goes straight into gtex (K9's arithmetic)
+    if (ADJ && !RF && live[0] && (fox >= 0 || adj_dot)) { // fused adjoint: the pixel's footprint x (gimg . albedo . colour) / spp goes straight into gtex (K9's arithmetic)
       __builtin_amdgcn_wave_barrier();
       const ShadeK &ca = kernarg_shade();
       const float g0 = adj_gimg[(size_t)pix[0] * 3], g1 = adj_gimg[(size_t)pix[0] * 3 + 1], g2 = adj_gimg[(size_t)pix[0] * 3 + 2];
