@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 6
+FFX_ABI_VERSION = 7
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -155,7 +155,7 @@ MAT_STRIDE = 16
 MAT_MODEL, MAT_ROUGHNESS, MAT_ANISOTROPIC, MAT_METALLIC, MAT_SPEC_TRANS, MAT_ETA = 3, 4, 5, 6, 7, 8
 MAT_SPEC_TINT, MAT_SHEEN, MAT_SHEEN_TINT, MAT_FLATNESS, MAT_CLEARCOAT, MAT_CLEARCOAT_GLOSS = 9, 10, 11, 12, 13, 14
 MAT_BASE_TEX = 15
-RENDER_FP16, RENDER_SPARSE_ADJOINT, RENDER_APEX_READY, RENDER_CACHE_ZEROED = 1, 2, 4, 8  # flags in the img_fp16 argument of the render calls
+RENDER_FP16, RENDER_SPARSE_ADJOINT, RENDER_APEX_READY, RENDER_CACHE_ZEROED, RENDER_CACHE_KEEP_DROPPED = 1, 2, 4, 8, 16  # flags in the img_fp16 argument of the render calls
 MAX_BASE_TEX = 4
 RFILTER_BOX, RFILTER_GAUSSIAN = 0, 1
 MAX_MAT_H = 128
@@ -201,7 +201,7 @@ PROTOTYPES = {
     "ffx_trace_primary": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(Camera), c_i, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
     "ffx_trace_rays": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),
-    "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p]),
+    "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_cache_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
@@ -210,7 +210,9 @@ PROTOTYPES = {
     "ffx_render_filter_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
     "ffx_render_fwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_fwd_adjoint_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "ffx_render_bwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_p, c_p, c_p, c_p]),
+    "ffx_render_bwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p]),
+    "ffx_render_fwd_cache_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p]),
+    "ffx_render_bwd_cached_filtered": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_p, c_p, c_p]),
     "ffx_render_fwd_adjoint": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_apex_prepare": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p]),
     "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),

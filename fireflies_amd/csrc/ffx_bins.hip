@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     ra = r4[0]; rb = r4[1]; rc = r4[2];
   }
   if (!FILL) {
-    if (k == 0 && a == 0 && ba.cache_hdr) { ba.cache_hdr[0] = 0u; ba.cache_hdr[1] = ba.cap_stray; ba.cache_hdr[2] = 0u; } // adjoint cache: stray arena empty
+    if (k == 0 && a == 0 && ba.cache_hdr) { // adjoint cache: stray arena empty (top bit of cap_stray: keep the `dropped` count, ffx_common.h)
+      ba.cache_hdr[0] = 0u; ba.cache_hdr[1] = ba.cap_stray & ~FFX_CAP_KEEP_DROPPED;
+      if (!(ba.cap_stray & FFX_CAP_KEEP_DROPPED)) ba.cache_hdr[2] = 0u;
+    }
     if (k < n_tris && ba.out && ba.on[a]) { // the triangle as seen from apex a (ffx_common.h TriApex; the oracle's operation order)
       const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);
       const v3 A = vcross(e2, e1);

@@ -183,6 +183,10 @@ struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
                      uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0);
 
+// top bit of the `cap_stray` argument of the launches that reset an adjoint cache's header (k_bin<false>, k_apex_records, k_cache_reset):
+// FFX_RENDER_CACHE_KEEP_DROPPED — empty the arena, keep the `dropped` count of the step's earlier scene samples
+#define FFX_CAP_KEEP_DROPPED 0x80000000u
+
 // entry of the refit list (leaves-first by node height)
 struct RefitEntry { int32_t node; };
 

@@ -2448,6 +2448,22 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
   return (cache_off_arena(n_pix) + sizeof(CacheStray) * cap_stray + 127) & ~(size_t)127;
 }
 
+// ---- adjoint cache of a FILTERED render (ffx_render_fwd_cache_filtered, include/ffx.h).  A sample spreads over the 25 pixels of its
+// window with weights of its own (the jitter), so a pixel's samples do not fold into one texture footprint as under the box film — its
+// adjoint is a 25 x 25 matrix (window pixel x texel).  Kept instead: one 16-byte record PER SAMPLE of the pixels that have a lit sample
+// {(ubx + 1) | (uby + 1) << 12 | shape << 24, ax, ay, fac} (+ fac_b in a second array with material rows), at the sample's own index —
+// written as one coalesced 1 KB store per wave and pass, nothing to allocate, nothing that can overflow — the dense CachePix array
+// (`lit` = bit mask of the pixel's 64-sample passes that hold a lit sample) and the weight each pixel received (the gather writes it).
+//   [0, 64)                CacheHdr (all zero: nothing is ever dropped)
+//   64 + 8 * pixel         CachePix
+//   rfc_off_wsum           float per pixel
+//   rfc_off_recs           uint4 per sample
+//   rfc_off_facb           float per sample (material rows)
+__host__ __device__ inline size_t rfc_off_wsum(size_t n_pix) { return (64 + 8 * n_pix + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t rfc_off_recs(size_t n_pix) { return (rfc_off_wsum(n_pix) + 4 * n_pix + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t rfc_off_facb(size_t n_pix, size_t spp) { return (rfc_off_recs(n_pix) + 16 * n_pix * spp + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) { return rfc_off_facb(n_pix, spp) + (mat ? ((4 * n_pix * spp + 127) & ~(size_t)127) : 0); }
+
 
 // ---- reconstruction filter that spreads a sample over its 5x5-pixel window (include/ffx.h, ffx_scene_desc.rfilter) -------------------------
 // A wave holds the 64 samples of ONE pixel, one per lane; what the film needs from it are 25 x (r, g, b, weight) sums over those samples —
@@ -2538,7 +2554,7 @@ __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int 
 #define FFX_RFG_WAVES 1 // (one-wave workgroups: the gather of one render runs beside the next render's kernel on the other stream — with four waves and 22 KB of LDS
                         //  per workgroup it waited for room on one compute unit: 1 742 -> 1 913 filtered renders/s; the waves never cooperated anyway)
 __global__ void __launch_bounds__(64 * FFX_RFG_WAVES) k_rf_gather(const float4 *__restrict__ part, int W, int H, int fp16, void *__restrict__ img,
-                                                                   const float *__restrict__ gimg, float4 *__restrict__ G) {
+                                                                   const float *__restrict__ gimg, float4 *__restrict__ G, float *__restrict__ wsum_out = nullptr) {
   __shared__ float4 s_seg[FFX_RFG_WAVES][68 * 5];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int x0 = blockIdx.x * 64, y = blockIdx.y * FFX_RFG_WAVES + wv;
@@ -2574,6 +2590,7 @@ __global__ void __launch_bounds__(64 * FFX_RFG_WAVES) k_rf_gather(const float4 *
     return;
   }
   const float v0 = w > 0.f ? r / w : 0.f, v1 = w > 0.f ? g / w : 0.f, v2 = w > 0.f ? b / w : 0.f;
+  if (wsum_out) wsum_out[pix] = w; // (ffx_render_fwd_cache_filtered: the weight this pixel received, for the cached adjoint's G = gimg / weight)
   if (fp16 & 1) {
     _Float16 *p = (_Float16 *)img + pix * 3;
     p[0] = (_Float16)v0; p[1] = (_Float16)v1; p[2] = (_Float16)v2;
@@ -2596,7 +2613,9 @@ __device__ __forceinline__ float4 rf_window_g(const float4 *__restrict__ G, int 
 #endif
 // RF (ffx_render_fwd_filtered): instead of the pixel's mean, the wave leaves the 25 x 4 sums its samples send to its 5x5 window in `cache`
 // (here: the scratch area, [pixel][25][4] floats; no adjoint cache in this mode) — see rf_fold above.
-template <int R, bool WIDE, int MATM, bool ADJ = false, bool RF = false>
+// RFC (ffx_render_fwd_cache_filtered; RF && !ADJ): additionally the per-sample records of the filtered film's adjoint cache (rfc_off_* above);
+// its base travels in `adj_gtex`, the record areas' offsets (128-byte units) in cache_foot_off / cache_foot_b_off.
+template <int R, bool WIDE, int MATM, bool ADJ = false, bool RF = false, bool RFC = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_fwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
@@ -2619,6 +2638,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
   __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
   static_assert(R == 1, "the adjoint cache is written one pixel at a time");
+  static_assert(!RFC || (RF && !ADJ), "RFC: the filtered forward that writes the per-sample adjoint records");
   FFX_TINIT();
   FFX_TSTART(twave);
   FFX_TSTART(tpro);
@@ -2637,6 +2657,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
   if (!ADJ && !RF && cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
+  if constexpr (RFC) { // (the filtered cache never drops anything: a header of zeros for ffx_render_cache_status / ffx_adam_args.guard)
+    if (wv == 0 && lane < 3) reinterpret_cast<uint32_t *>(adj_gtex)[lane] = 0u;
+  }
   FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
     int px[R], py[R];
@@ -2654,6 +2677,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     int fox = -1, foy = -1, fshape = -1;
     float fin0 = 0.f, fin1 = 0.f, fin2 = 0.f; // the pixel's value as stored (ffx_render_fwd_adjoint: <gimg, img>)
     float rfacc[4] = {0.f, 0.f, 0.f, 0.f}; // RF: this lane's window entry (lane % 32, samples of half lane / 32), four channels, summed over the passes
+    uint32_t rfc_mask = 0u; // RFC: the passes of this pixel that hold a lit sample (wave-uniform)
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -2673,8 +2697,24 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       SampleTerms st[R];
       // (fp16 carries the call's flags: bit 0 fp16 film, bit 1 FFX_RENDER_SPARSE_ADJOINT — then the cache-writing forward may
       // skip dark footprints too: the caller only wants gradients of texels whose value is not zero)
-      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, px[0], py[0], (fold && !(fp16 & 2)) ? nullptr : tex);
+      shade_sample_pk<R, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, px[0], py[0], ((fold || RFC) && !(fp16 & 2)) ? nullptr : tex);
       FFX_TSTOP(tk, 17);
+      if constexpr (RFC) {
+        // ---- the filtered film's adjoint cache: this pass's 64 records, if any of its samples is lit (one 1 KB store per wave)
+        const bool lit = active[0] && st[0].hit && st[0].has_proj;
+        if (wballot(lit) != 0ull) {
+          rfc_mask |= 1u << pass;
+          if (s < spp) {
+            char *rfc = reinterpret_cast<char *>(adj_gtex);
+            const size_t si = (size_t)pix[0] * (size_t)spp + (size_t)s;
+            uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+            if (lit) rec = make_uint4((uint32_t)(st[0].ubx + 1) | ((uint32_t)(st[0].uby + 1) << 12) | ((uint32_t)st[0].shape << 24), __float_as_uint(st[0].wx1),
+                                      __float_as_uint(st[0].wy1), __float_as_uint(st[0].proj_fac));
+            reinterpret_cast<uint4 *>(rfc + ((size_t)cache_foot_off << 7))[si] = rec;
+            if constexpr (MAT) reinterpret_cast<float *>(rfc + ((size_t)cache_foot_b_off << 7))[si] = lit ? st[0].proj_fac_b : 0.f;
+          }
+        }
+      }
       if (fold) {
         // ---- adjoint cache: fold this pass's lit samples into the pixel's footprint
         const bool lit = active[0] && st[0].hit && st[0].has_proj;
@@ -2894,6 +2934,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         }
       }
       FFX_TSTOP(tk, 23);
+    }
+    if constexpr (RFC) { // the pixel's header: which of its passes hold records
+      if (live[0] && lane == 0) {
+        CachePix hp;
+        hp.x0 = 0; hp.y0 = 0; hp.shape = 0; hp.lit = (uint16_t)rfc_mask;
+        reinterpret_cast<CachePix *>(reinterpret_cast<char *>(adj_gtex) + 64)[pix[0]] = hp;
+      }
     }
     if (ADJ && RF && live[0]) { // filtered fused adjoint: the footprint already carries every sample's own gradient
       __builtin_amdgcn_wave_barrier();
@@ -3354,6 +3401,152 @@ __global__ void __launch_bounds__(256)
   k9_stray(cache, n_pix, (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
 }
 
+// K9 of the filtered film's cache (ffx_render_bwd_cached_filtered; rfc_off_* above).  A workgroup of four waves owns a 16x16-pixel block:
+// pass 1, a lane per pixel, reads the dense headers and compacts the (pixel, pass) pairs that hold lit samples into a list — a block
+// without any ends after one round of loads (96 % of a dot pattern's film).  Pass 2: a wave per list entry, lanes on the 64 samples of
+// that pass — the sample's record (one coalesced 1 KB load), its ten filter weights from the jitter (the forward's hash), the pixel's
+// window of G = gimg / weight (lanes 0..24 load a window pixel each, broadcast by v_readlane), the sample's own gradient
+// sum_n w_n G[pixel + n] (the arithmetic and the order of k_render_fwd_pk<.., ADJ, RF>), its four bilinear taps into a 48x48-texel LDS
+// tile anchored at the block's first lit tap (taps outside go to memory directly); the tile is flushed with one global atomic per
+// touched texel.  1-channel textures take the tile; 3-channel ones scatter their twelve atomics per sample directly.
+struct BwdF { int tw, th, tc, spp; float color[3]; float rf_alpha, rf_bias; int W, H; int ms; uint32_t seed_key; size_t off_wsum, off_recs, off_facb;
+              const float *mats; int mat_inline; float mat_h[FFX_MAX_MAT_H]; };
+__device__ __forceinline__ const float *mat_table(const BwdF &k) { return k.mat_inline ? k.mat_h : k.mats; }
+#define K9F_TILE 48
+__global__ void __launch_bounds__(256)
+    k_render_bwd_cached_filtered(BwdF p_by_value, const char *__restrict__ cache, int blocks_x, const float *__restrict__ gimg, float *__restrict__ gtex) {
+  __shared__ float s_tile[K9F_TILE * K9F_TILE];
+  __shared__ int s_n, s_org;
+  __shared__ unsigned short s_list[256 * 16]; // (pixel of the block) | pass << 8 — up to 16 passes (spp <= 1024)
+  const BwdF &p = kernarg_first<BwdF>();
+  const float *albedo = mat_table(p);
+  const int bx = (int)blockIdx.x % blocks_x, by = (int)blockIdx.x / blocks_x;
+  const CachePix *hdrs = reinterpret_cast<const CachePix *>(cache + 64);
+  const float *wsum = reinterpret_cast<const float *>(cache + p.off_wsum);
+  const uint4 *recs = reinterpret_cast<const uint4 *>(cache + p.off_recs);
+  const float *facb = reinterpret_cast<const float *>(cache + p.off_facb);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_n = 0; s_org = -1; }
+  __syncthreads();
+  { // pass 1: one lane per pixel of the block
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = bx * 16 + lx, y = by * 16 + ly;
+    uint32_t mask = 0u;
+    if (x < p.W && y < p.H) mask = hdrs[(long)y * p.W + x].lit;
+    const int cnt = __builtin_popcount(mask);
+    if (cnt != 0) {
+      int k = atomicAdd(&s_n, cnt);
+      while (mask != 0u) {
+        const int ps = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        s_list[k++] = (unsigned short)(threadIdx.x | (ps << 8));
+      }
+    }
+  }
+  __syncthreads();
+  const int n_items = s_n;
+  if (n_items == 0) return; // (uniform: nothing lit in this block)
+  const bool tiled = p.tc == 1;
+  if (tiled) {
+    for (int i = threadIdx.x; i < K9F_TILE * K9F_TILE; i += 256) s_tile[i] = 0.f;
+  }
+  __syncthreads();
+  const bool mat = p.ms != 3;
+  for (int it = wv; it < n_items; it += 4) { // (wave-uniform loop)
+    const int item = (int)s_list[it];
+    const int pl = item & 255, pass = item >> 8;
+    const int px = bx * 16 + (pl & 15), py = by * 16 + (pl >> 4);
+    const long pixel = (long)py * p.W + px;
+    const int s = pass * 64 + lane;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    float fb = 0.f;
+    if (s < p.spp) {
+      rec = recs[(size_t)pixel * (size_t)p.spp + (size_t)s];
+      if (mat) fb = facb[(size_t)pixel * (size_t)p.spp + (size_t)s];
+    }
+    const float fac = __uint_as_float(rec.w);
+    const bool lit = fac != 0.f || fb != 0.f;
+    // the pixel's window of G (lanes 0..24), zero outside the film
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    {
+      const int wb = (lane * 13) >> 6, wa = lane - 5 * wb; // lane / 5, lane % 5 for lane < 25
+      const int tx = px + wa - 2, ty = py + wb - 2;
+      if (lane < 25 && tx >= 0 && tx < p.W && ty >= 0 && ty < p.H) {
+        const long q = (long)ty * p.W + tx;
+        const float w = wsum[q];
+        if (w > 0.f) { g0 = gimg[q * 3] / w; g1 = gimg[q * 3 + 1] / w; g2 = gimg[q * 3 + 2] / w; }
+      }
+    }
+    float jx, jy, gx[5], gy[5];
+    sample_jitter(p.seed_key, (uint32_t)pixel * (uint32_t)p.spp + (uint32_t)s, jx, jy);
+    rf_weights(p.rf_alpha, p.rf_bias, jx, gx);
+    rf_weights(p.rf_alpha, p.rf_bias, jy, gy);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < 25; ++n) {
+      const float w = gx[n % 5] * gy[n / 5];
+      a0 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(g0), n)), a0);
+      a1 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(g1), n)), a1);
+      a2 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(g2), n)), a2);
+    }
+    if (lit) { // (per lane from here on: no cross-lane operation inside)
+      const int ubx = (int)(rec.x & 0xfffu) - 1, uby = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
+      const int x0 = clampi(ubx, 0, p.tw - 1), x1 = clampi(ubx + 1, 0, p.tw - 1), y0 = clampi(uby, 0, p.th - 1), y1 = clampi(uby + 1, 0, p.th - 1);
+      const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
+      const float wx0 = 1.0f - ax, wx1 = ax, wy0 = 1.0f - ay, wy1 = ay;
+      const float *alb = albedo + p.ms * shape;
+      if (tiled) {
+        float pf = (a0 * alb[0] * p.color[0] + a1 * alb[1] * p.color[1] + a2 * alb[2] * p.color[2]) * fac;
+        if (fb != 0.f) pf += (a0 * p.color[0] + a1 * p.color[1] + a2 * p.color[2]) * fb;
+        if (pf != 0.f) {
+          // the tile's origin: the first lit tap any lane of the block gets here with, minus a third of the tile (one word, set once)
+          int org = s_org;
+          if (org < 0) {
+            const int cand = (max(x0 - K9F_TILE / 3, 0)) | (max(y0 - K9F_TILE / 3, 0) << 16);
+            const int prev = atomicCAS(&s_org, -1, cand);
+            org = prev < 0 ? cand : prev;
+          }
+          const int ox = org & 0xffff, oy = org >> 16;
+          const int xs[2] = {x0, x1}, ys[2] = {y0, y1};
+          const float wxs[2] = {wx0, wx1}, wys[2] = {wy0, wy1};
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int lx = xs[b] - ox, ly = ys[a] - oy;
+              const float v = pf * wys[a] * wxs[b];
+              if ((unsigned)lx < (unsigned)K9F_TILE && (unsigned)ly < (unsigned)K9F_TILE) atomicAdd(&s_tile[ly * K9F_TILE + lx], v);
+              else atomicAdd(gtex + (size_t)ys[a] * p.tw + xs[b], v);
+            }
+        }
+      } else {
+        const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3, o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
+        const float aa[3] = {a0, a1, a2};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          float v = aa[ch] * alb[ch] * fac;
+          if (fb != 0.f) v += aa[ch] * fb;
+          if (v != 0.f) {
+            atomicAdd(gtex + o00 + ch, v * wy0 * wx0);
+            atomicAdd(gtex + o01 + ch, v * wy0 * wx1);
+            atomicAdd(gtex + o10 + ch, v * wy1 * wx0);
+            atomicAdd(gtex + o11 + ch, v * wy1 * wx1);
+          }
+        }
+      }
+    }
+  }
+  if (!tiled) return; // (uniform)
+  __syncthreads();
+  const int org = s_org;
+  if (org < 0) return; // (uniform: every lit sample's gradient was zero)
+  const int ox = org & 0xffff, oy = org >> 16;
+  for (int i = threadIdx.x; i < K9F_TILE * K9F_TILE; i += 256) {
+    const float v = s_tile[i];
+    if (v != 0.f) atomicAdd(gtex + (size_t)(oy + i / K9F_TILE) * p.tw + (ox + i % K9F_TILE), v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static int cam_prepare(const ffx_camera *c, CamK &k) {
   if (c->width < 1 || c->height < 1) return 0;
@@ -3432,7 +3625,10 @@ __global__ void __launch_bounds__(256)
     k_apex_records(const TriRec *__restrict__ recs, int n_tris, ApexK ak, TriApex *__restrict__ out, uint32_t astride, uint32_t *__restrict__ cache_hdr,
                    uint32_t cap_stray) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k == 0 && cache_hdr) { cache_hdr[0] = 0u; cache_hdr[1] = cap_stray; cache_hdr[2] = 0u; } // adjoint cache: stray arena empty (CacheHdr)
+  if (k == 0 && cache_hdr) { // adjoint cache: stray arena empty (CacheHdr)
+    cache_hdr[0] = 0u; cache_hdr[1] = cap_stray & ~FFX_CAP_KEEP_DROPPED;
+    if (!(cap_stray & FFX_CAP_KEEP_DROPPED)) cache_hdr[2] = 0u;
+  }
   if (k >= n_tris) return;
   const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
   const float4 a = r4[0], b = r4[1], c = r4[2];
@@ -3589,8 +3785,10 @@ static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
 }
 
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
+// (cap_stray's top bit: FFX_RENDER_CACHE_KEEP_DROPPED — the arena is emptied, the header's `dropped` count stays: ffx_common.h FFX_CAP_KEEP_DROPPED)
 __global__ void k_cache_reset(uint32_t *__restrict__ cache_hdr, uint32_t cap_stray) {
-  cache_hdr[0] = 0u; cache_hdr[1] = cap_stray; cache_hdr[2] = 0u;
+  cache_hdr[0] = 0u; cache_hdr[1] = cap_stray & ~FFX_CAP_KEEP_DROPPED;
+  if (!(cap_stray & FFX_CAP_KEEP_DROPPED)) cache_hdr[2] = 0u;
 }
 // flags: FFX_RENDER_APEX_READY — the areas already hold this call's apexes (ffx_apex_prepare, or an earlier call with the same
 // origins on records that have not changed since): no launch; FFX_RENDER_CACHE_ZEROED — the caller has cleared the cache header.
@@ -3616,6 +3814,7 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
   TriApex *out = (TriApex *)((char *)bvh + ffx_apex_offset(info, 0));
   const TriRec *recs = (const TriRec *)((const char *)bvh + info->off_recs);
   if (flags & FFX_RENDER_CACHE_ZEROED) cache = nullptr;
+  if (flags & FFX_RENDER_CACHE_KEEP_DROPPED) cap_stray |= FFX_CAP_KEEP_DROPPED; // (the reset launches' view of the flag; capacities stay far below 2^31)
   if (!(flags & FFX_RENDER_APEX_READY)) {
     // ONE pre-pass for both: the counting launch of the tile bins writes the apex records too (ffx_bins.hip k_bin<false>), the fill
     // launch follows when a grid is on.  A blob without a bins area (or a primary-visibility call: sd == NULL) gets the apex records alone.
@@ -3626,6 +3825,10 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
       bins_grids(sd, bb.g, ix, iy);
       for (int a = 0; a < FFX_N_APEX; ++a) bb.base[a] = (char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
       bb.cap = (uint32_t)ffx_bin_cap(info->n_tris);
+      if (const char *ce = getenv("FFX_BIN_CAP")) { // (test knob, include/ffx.h: a smaller capacity makes a grid's lists overflow — its packets then walk the tree)
+        const long cv = atol(ce);
+        if (cv >= 0 && (uint64_t)cv < bb.cap) bb.cap = (uint32_t)cv;
+      }
       bb.arrive = (uint32_t *)(bb.base[0] + offsetof(BinHdr, pad));
     }
     if (!bb.arrive) { // no bins area to hold the arrival counter: the plain apex launch
@@ -3778,7 +3981,7 @@ int ffx_trace_rays(const void *bvh, const ffx_bvh_info *info, const float *origi
 
 static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                            uint32_t seed, int call_flags, void *img, void *cache, ffx_stream s, const float *adj_gimg = nullptr, float *adj_gtex = nullptr,
-                           float *adj_dot = nullptr, void *rf_scratch = nullptr) {
+                           float *adj_dot = nullptr, void *rf_scratch = nullptr, void *rf_cache = nullptr) {
   const int img_fp16 = call_flags & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT); // what the kernels see; the other bits steer the pre-pass
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !img || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_fwd: bad argument");
   if (sd->proj.enabled && !tex) FFX_FAIL(FFX_ERR_ARG, "render_fwd: projector enabled but tex is NULL");
@@ -3803,12 +4006,12 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   if (adj_gtex && sd->n_base_tex > 0) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint: textured base colours (the footprint folds one base colour per shape): use ffx_render_bwd");
   if ((use_packet() || cache || adj_gtex) && !gn) FFX_FAIL(FFX_ERR_ARG, "render_fwd: blob without per-slot normals (built by another library version?)");
   if (use_packet() || cache || adj_gtex) { // the per-sample cache / the fused adjoint are the packet kernels' 
-    const int tb = tile_block_log2((long)c.cam.W * c.cam.H, cache != nullptr || adj_gtex != nullptr);
+    const int tb = tile_block_log2((long)c.cam.W * c.cam.H, cache != nullptr || adj_gtex != nullptr || rf_cache != nullptr);
     int ptx = ffx_cdiv(c.cam.W, 2), pty = ffx_cdiv(c.cam.H, 2);
     int pn = (ffx_cdiv(ptx, 1 << tb) * ffx_cdiv(pty, 1 << tb)) << (2 * tb); // whole blocks; tiles outside the image are skipped
     ptx |= tb << 24;
     const int wpb = packet_waves();
-    const int ppw = pixels_per_wave(cache != nullptr || adj_gtex != nullptr, (long)c.cam.W * c.cam.H);
+    const int ppw = pixels_per_wave(cache != nullptr || adj_gtex != nullptr || rf_cache != nullptr, (long)c.cam.W * c.cam.H);
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
@@ -3847,6 +4050,24 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W,
                          c.cam.H, img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
       FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered/gather");
+      return FFX_OK;
+    }
+    if (rf_scratch && rf_cache) { // ... that also stores its adjoint's per-sample records (ffx_render_fwd_cache_filtered; rfc_off_* above)
+      if (matm == 2) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: textured base colours (the records carry one base colour per shape): use ffx_render_bwd_filtered");
+      if (sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: texture larger than 4094^2 or more than 255 shapes");
+      if (spp > 1024) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: more than 1024 samples per pixel (16 passes)");
+      const size_t n_pix = (size_t)c.cam.W * c.cam.H;
+      const uint32_t recs_off = (uint32_t)(rfc_off_recs(n_pix) >> 7), facb_off = (uint32_t)(rfc_off_facb(n_pix, (size_t)spp) >> 7);
+#define FFX_LAUNCH_RFC(MAT_)                                                                                                                              \
+  hipLaunchKernelGGL((k_render_fwd_pk<1, true, MAT_, false, true, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
+                     shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16, img, (char *)rf_scratch, ppw,       \
+                     1.0f / (float)spp, recs_off, arena_off, facb_off, nrec, gn, cap_stray, (const float *)nullptr, (float *)rf_cache, (float *)nullptr)
+      if (matm == 1) FFX_LAUNCH_RFC(1); else FFX_LAUNCH_RFC(0);
+#undef FFX_LAUNCH_RFC
+      FFX_CHECK_LAUNCH("render_fwd_cache_filtered");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
+                         img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr, (float *)((char *)rf_cache + rfc_off_wsum(n_pix)));
+      FFX_CHECK_LAUNCH("render_fwd_cache_filtered/gather");
       return FFX_OK;
     }
     if (rf_scratch) { // the filtered render: the kernel leaves every pixel's 25 x 4 outgoing sums in the scratch area, the gather forms the image
@@ -3890,6 +4111,7 @@ size_t ffx_render_cache_bytes(int width, int height, int spp) {
 
 size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) {
   if (!sd || sd->cam.width < 1 || sd->cam.height < 1 || spp < 1) return 0;
+  if (sd->rfilter != FFX_RFILTER_BOX) return rfc_bytes((size_t)sd->cam.width * sd->cam.height, (size_t)spp, sd->mat_stride == FFX_MAT_STRIDE); // the filtered film's cache
   if (sd->mat_stride != FFX_MAT_STRIDE) return ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp);
   const size_t n_pix = (size_t)sd->cam.width * sd->cam.height;
   return cache_off_foot_b(n_pix, cache_stray_capacity(sd->cam.width, sd->cam.height, spp)) + sizeof(CacheFoot) * n_pix;
@@ -3899,7 +4121,7 @@ int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_sc
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
   if (!cache) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache is NULL");
   if (((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache: cache must be 16-byte aligned");
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 15, img, cache, s);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 31, img, cache, s);
 }
 
 int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
@@ -3989,7 +4211,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   return FFX_OK;
 }
 
-static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                            const float *gimg, float *gtex, ffx_stream s, void *rf_scratch) {
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if ((sd->rfilter != FFX_RFILTER_BOX) != (rf_scratch != nullptr))
@@ -4018,7 +4240,7 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int pgrid = ((ffx_cdiv(pn, wpb) + 7) / 8) * 8;
     const TriApex *arecs;
     uint32_t astride;
-    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s)) return FFX_ERR_ARG;
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, nullptr, 0, flags & FFX_RENDER_APEX_READY)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
     bins_k(bvh, info, sd, c.bins);
 #define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
@@ -4058,9 +4280,9 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
   return FFX_OK;
 }
 
-int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                    const float *gimg, float *gtex, ffx_stream s) {
-  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, s, nullptr);
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s, nullptr);
 }
 
 // scratch of the filtered calls: [pixel][25][4] outgoing sums (400 B per pixel) + G = gimg / weight as float4 per pixel (the adjoint)
@@ -4085,10 +4307,51 @@ int ffx_render_fwd_adjoint_filtered(const void *bvh, const ffx_bvh_info *info, c
                          gtex, nullptr, scratch);
 }
 
-int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                             const float *gimg, float *gtex, void *scratch, ffx_stream s) {
   if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd_filtered: scratch is NULL or not 16-byte aligned");
-  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, s, scratch);
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s, scratch);
+}
+
+int ffx_render_fwd_cache_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                                  uint32_t seed, int img_fp16, void *img, void *cache, void *scratch, ffx_stream s) {
+  if (!cache || ((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache_filtered: cache is NULL or not 16-byte aligned");
+  if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache_filtered: scratch is NULL or not 16-byte aligned");
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT | FFX_RENDER_APEX_READY), img, nullptr, s, nullptr,
+                         nullptr, nullptr, scratch, cache);
+}
+
+int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, uint32_t seed, const float *gimg, float *gtex,
+                                   ffx_stream s) {
+  if (!sd || (!shape_albedo && sd->n_mat_h <= 0) || !cache || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached_filtered: bad argument");
+  if (sd->rfilter != FFX_RFILTER_GAUSSIAN) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: rfilter must be FFX_RFILTER_GAUSSIAN (the box film: ffx_render_bwd_cached)");
+  if (spp > 1024) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: more than 1024 samples per pixel");
+  if (!sd->proj.enabled) return FFX_OK;
+  BwdF p;
+  memset(&p, 0, sizeof p);
+  p.mats = shape_albedo;
+  p.ms = sd->mat_stride ? sd->mat_stride : 3;
+  if (p.ms != 3 && p.ms != FFX_MAT_STRIDE) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached_filtered: bad material stride");
+  if (sd->n_mat_h > 0) {
+    if (sd->n_mat_h > FFX_MAX_MAT_H || sd->n_mat_h != sd->n_shapes * p.ms) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached_filtered: n_mat_h must be n_shapes x stride (<= %d)", FFX_MAX_MAT_H);
+    p.mat_inline = 1;
+    for (int i = 0; i < sd->n_mat_h; ++i) p.mat_h[i] = sd->mat_h[i];
+  }
+  p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
+  p.W = sd->cam.width; p.H = sd->cam.height;
+  if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || p.W < 1 || p.H < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached_filtered: bad scene description");
+  for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];
+  const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
+  if (!(sdv <= 0.5f)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: gaussian filter: stddev <= 0.5");
+  p.rf_alpha = -1.0f / (2.0f * sdv * sdv); // (as shade_prepare)
+  p.rf_bias = expf(p.rf_alpha * (4.0f * sdv) * (4.0f * sdv));
+  p.seed_key = seed_key_of(seed);
+  const size_t n_pix = (size_t)p.W * p.H;
+  p.off_wsum = rfc_off_wsum(n_pix); p.off_recs = rfc_off_recs(n_pix); p.off_facb = rfc_off_facb(n_pix, (size_t)spp);
+  const int blocks_x = ffx_cdiv(p.W, 16), blocks_y = ffx_cdiv(p.H, 16);
+  hipLaunchKernelGGL(k_render_bwd_cached_filtered, dim3(blocks_x * blocks_y), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, blocks_x, gimg, gtex);
+  FFX_CHECK_LAUNCH("render_bwd_cached_filtered");
+  return FFX_OK;
 }
 
 } // extern "C"

@@ -143,10 +143,14 @@ def cache_supported(sd, spp):
     """whether ffx_render_fwd_cache accepts this render (its records pack the texel in 12+12 bits and
     the shape id in 8), the cache fits the FFX_CACHE_LIMIT_GB budget and a pixel's samples can be expected to
     stay inside one 5x5-texel footprint"""
-    if not sd.proj.enabled or sd.rfilter:  # (a filter that spreads samples over neighbouring pixels: the footprint folds box pixels; the adjoint re-traces)
+    if not sd.proj.enabled:
         return False
     if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255 or sd.n_base_tex > 0:  # (textured base colours: one colour per shape in the footprint)
         return False
+    if sd.rfilter:
+        # a filter that spreads samples over neighbouring pixels: ffx_render_fwd_cache_filtered keeps one record per sample of the lit
+        # pixels — no footprint a fine texture could overflow; up to 16 passes of 64 samples per pixel
+        return spp <= 1024 and ops.render_cache_bytes_sd(sd, spp) <= CACHE_LIMIT_BYTES
     if texels_per_pixel(sd) > max_texels_per_pixel():
         return False
     return ops.render_cache_bytes_sd(sd, spp) <= CACHE_LIMIT_BYTES
@@ -183,9 +187,9 @@ class _Render(torch.autograd.Function):
         gtex = None
         if ctx.cache is not None:
             # (one 64-byte read + stream sync per backward of this generic path; the optimiser's explicit step checks lazily)
-            used, cap, dropped = ops.render_cache_status(ctx.cache)
+            used, cap, dropped = (0, 0, 0) if ctx.sd.rfilter else ops.render_cache_status(ctx.cache)  # (the filtered film's cache never drops)
             if dropped == 0:
-                gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g)
+                gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g, seed=ctx.seed if ctx.sd.rfilter else None)
             elif ctx.geom.version != ctx.pose_version:
                 raise CacheOverflowError(
                     f"render backward: the adjoint cache overflowed ({dropped} samples beyond its {cap} single-sample records — a projector "
@@ -206,7 +210,7 @@ class _Render(torch.autograd.Function):
 def render(tex, geom, sd, albedo, spp, seed=0, fp16=False):
     """K8/K9: image [H,W,3], differentiable w.r.t. the projector texture ([h,w] or [h,w,c]).
     When the texture requires grad the forward kernel also stores each pixel's footprint in the texture
-    (128 B per pixel + a small arena: 40 MB at 512x512x64) and the adjoint scatters those footprints; beyond
-    FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
+    (128 B per pixel + a small arena: 40 MB at 512x512x64; under a gaussian film one 16-byte record per sample of the
+    lit pixels) and the adjoint scatters those footprints; beyond FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
     forward and backward)."""
     return _Render.apply(tex, geom, sd, albedo, int(spp), int(seed), bool(fp16))

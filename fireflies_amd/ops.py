@@ -378,7 +378,7 @@ def apex_key(sd=None, cam=None):
     field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
     if sd is not None:
         k = getattr(sd, "_apex_key", None)  # (a description is never modified once built: mi.Scene makes a new one per pose — 5 us per call otherwise)
-        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N")):
+        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP")):
             return k[0]
     c = sd.cam if sd is not None else cam
     # (the structs' bytes: ~1 us each — tuples of their 32 floats were 10 us per render call)
@@ -388,7 +388,7 @@ def apex_key(sd=None, cam=None):
         key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg) if sd.spot.enabled else None]  # (not its intensity: randomised per step, no part of the pre-pass)
     else:
         key += [None, None]
-    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"))
+    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"))
     key = tuple(key) + env
     if sd is not None and getattr(sd, "_frozen", False):  # (only descriptions whose maker promises not to touch them again: mi.Scene.scene_desc)
         sd._apex_key = (key, env)
@@ -397,7 +397,7 @@ def apex_key(sd=None, cam=None):
 
 def _camera_part(key):
     """of an apex_key: what the camera's area (its apex records and tile bins) depends on"""
-    return None if key is None else (key[0], key[3], key[4])
+    return None if key is None else (key[0], key[3], key[4], key[7])  # (camera struct, FFX_BINS, FFX_BIN_TILE, FFX_BIN_CAP)
 
 
 def _lane_kernels():
@@ -713,21 +713,31 @@ class DeviceGeometry:
     def _timed(self, name):
         return _EventPair(self.timing, name)
 
-    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False, cache_zeroed=False):
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False, cache_zeroed=False, keep_dropped=False):
         """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
         footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h).
         sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
         not zero (a pattern optimiser's case), dark footprints are skipped.  cache_zeroed: FFX_RENDER_CACHE_ZEROED — the caller has
-        cleared the first 64 bytes of `cache` on this stream."""
+        cleared the first 64 bytes of `cache` on this stream.  keep_dropped: FFX_RENDER_CACHE_KEEP_DROPPED — the header's count of dropped
+        samples survives this call's reset (the later scene samples of a step that reuses one cache).
+        A filtered film (sd.rfilter) with a cache: ffx_render_fwd_cache_filtered (per-sample records; render_bwd_cached needs the seed)."""
         H, W = sd.cam.height, sd.cam.width
         mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
         blob = self.blob  # (acquire first: the flag below speaks about the blob this call reads)
         flags = int(bool(fp16)) | self._apex_flag(apex_key(sd))
         if sd.rfilter:  # a reconstruction filter that spreads samples over neighbouring pixels: its own entry point and a scratch area
-            if cache is not None:
-                raise ValueError("the adjoint cache folds box-filtered pixels: a filtered render differentiates through render_bwd (re-traced)")
             scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device)  # (caching allocator, stream-ordered: renders on two streams never share one)
+            if cache is not None:  # ... and the per-sample records of its adjoint (ABI 7)
+                if cache.numel() < render_cache_bytes_sd(sd, spp):
+                    raise ValueError("cache tensor too small")
+                flags |= _abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0
+                with self._timed("render_fwd"):
+                    self._call("ffx_render_fwd_cache_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
+                               _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype),
+                               _dev(cache, torch.uint8, "cache"), _dev(scratch, torch.uint8), _stream(self._didx))
+                self._release()
+                return img
             with self._timed("render_fwd"):
                 self._call("ffx_render_fwd_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
                            _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype), _dev(scratch, torch.uint8),
@@ -737,7 +747,7 @@ class DeviceGeometry:
         if cache is not None:
             if cache.numel() < render_cache_bytes_sd(sd, spp):
                 raise ValueError("cache tensor too small")
-            flags |= (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | (_abi.RENDER_CACHE_ZEROED if cache_zeroed else 0)
+            flags |= (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | (_abi.RENDER_CACHE_ZEROED if cache_zeroed else 0) | (_abi.RENDER_CACHE_KEEP_DROPPED if keep_dropped else 0)
             with self._timed("render_fwd"):
                 self._call(
                     "ffx_render_fwd_cache", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
@@ -787,7 +797,7 @@ class DeviceGeometry:
         self._release()
         return img, gtex
 
-    def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None, img=None, dot_out=None):
+    def render_bwd_cached(self, sd, albedo, cache, spp, gimg, out=None, img=None, dot_out=None, seed=None):
         """K9 from the adjoint cache written by render_fwd(..., cache=...): scatters per-pixel footprints, no BVH.
         `out`: accumulate into this [tex_h, tex_w, channels] tensor instead of a fresh zeroed one.
         `img` + `dot_out` (render_dot_slots(W, H) float32 partial sums, one per 8x8-pixel block): the same launch adds
@@ -796,6 +806,15 @@ class DeviceGeometry:
         mats_arg = _check_materials(sd, albedo)
         if (img is None) != (dot_out is None):
             raise ValueError("img and dot_out go together")
+        if sd.rfilter:  # the filtered film's cache: per-sample records, filter weights re-derived from the forward's seed
+            if seed is None or img is not None:
+                raise ValueError("render_bwd_cached of a filtered render needs the forward's seed (and has no <gimg, img> output)")
+            if tuple(gimg.shape) != (sd.cam.height, sd.cam.width, 3):
+                raise ValueError("gimg must be [H, W, 3]")
+            with self._timed("render_bwd_cached"):
+                self._call("ffx_render_bwd_cached_filtered", C.byref(sd), mats_arg, _dev(cache, torch.uint8, "cache"), int(spp), int(seed) & 0xFFFFFFFF,
+                           _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx))
+            return gtex
         if img is not None and (tuple(img.shape) != tuple(gimg.shape) or dot_out.dtype != torch.float32 or dot_out.numel() != render_dot_slots(sd.cam.width, sd.cam.height)):
             raise ValueError("img must have gimg's shape and dot_out must be render_dot_slots(W, H) float32 partial sums (the caller zeroes and sums them)")
         with self._timed("render_bwd_cached"):
@@ -808,18 +827,20 @@ class DeviceGeometry:
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         mats_arg = _check_materials(sd, albedo)
         blob = self.blob
-        self._apex_flag(apex_key(sd))  # (the call has no flags argument: it always writes its own apex records — which the areas then hold)
+        # (ABI 7: the re-tracing adjoints take FFX_RENDER_APEX_READY like the renders.  Before, they always re-ran the pre-pass — and rewrote the
+        # tile bins under the eyes of renders of the same pose on the scene's other render stream)
+        flags = self._apex_flag(apex_key(sd))
         if sd.rfilter:
             scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device)
             with self._timed("render_bwd"):
-                self._call("ffx_render_bwd_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp), int(seed) & 0xFFFFFFFF,
+                self._call("ffx_render_bwd_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp), int(seed) & 0xFFFFFFFF, flags,
                            _dev(gimg, name="gimg"), _dev(gtex), _dev(scratch, torch.uint8), _stream(self._didx))
             self._release()
             return gtex
         with self._timed("render_bwd"):
             self._call(
                 "ffx_render_bwd", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp),
-                int(seed) & 0xFFFFFFFF, _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx),
+                int(seed) & 0xFFFFFFFF, flags, _dev(gimg, name="gimg"), _dev(gtex), _stream(self._didx),
             )
         self._release()
         return gtex

@@ -268,11 +268,13 @@ class PatternOptimizer:
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
             mats = ms.materials_arg(sd)  # (None: the rows are part of sd — no upload, no device tensor)
+            # (the cache is reused by the step's samples one after the other: only the first render of the step may clear the header's count of
+            # dropped samples — the in-kernel Adam guard and _watch_cache read it at the END of the step, FFX_RENDER_CACHE_KEEP_DROPPED)
             img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache,
-                                  cache_zeroed=header_clear)
+                                  cache_zeroed=header_clear, keep_dropped=not header_clear)
             header_clear = False
             self.step_paths["cache_k9" if use_cache else "retrace"] += 1
-            if linear is not None and use_cache:
+            if linear is not None and use_cache and not sd.rfilter:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)
                 continue
@@ -284,7 +286,7 @@ class PatternOptimizer:
                 loss_sum += l
                 gimg = gimg.float().contiguous()
             if use_cache:
-                geom.render_bwd_cached(sd, mats, self._cache, self.spp, gimg, out=gtex)
+                geom.render_bwd_cached(sd, mats, self._cache, self.spp, gimg, out=gtex, seed=seed if sd.rfilter else None)
             else:
                 gtex += geom.render_bwd(sd, mats, self.spp, seed, gimg).reshape(gtex.shape)
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only

@@ -33,6 +33,8 @@
  *       FFX_K7_PPW_LOG2=0..6     cap on log2(pixels per wavefront) of ffx_trace_primary (default 4 at 1 spp, else 3)
  *       FFX_BINS=0               the packet render kernels walk the tree for every packet (default: tile bins first, ffx_bvh_info.off_bins)
  *       FFX_BIN_TILE=4..32       side of a camera tile of the bins in pixels (default 8)
+ *       FFX_BIN_CAP=n            capacity of each grid's entry list, at most the default 2 F + 16384 (a test knob: a grid whose lists do
+ *                                not fit is marked not-ok by the pre-pass and its packets take the tree walks — the overflow path)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
  *     tests/test_hip_parity.py::test_wide_overlay_builders_give_identical_images):
  *       FFX_WIDE_BUILD=area|count|layers   builder of the 64-wide overlay (default area: greedy SAH cut)
@@ -51,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 6
+#define FFX_ABI_VERSION 7
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -571,10 +573,11 @@ int ffx_render_fwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                    const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
                    const float *tex /*[dev][tex_h,tex_w,tex_channels]*/, int spp, uint32_t seed,
                    int img_fp16, void *img /*[dev][H,W,3] fp32 or fp16*/, ffx_stream stream);
-/* gtex is ACCUMULATED into (the caller zeroes it). */
+/* gtex is ACCUMULATED into (the caller zeroes it).  flags (ABI 7): FFX_RENDER_APEX_READY (below) or 0 — without it the call rewrites
+ * the blob's apex records and tile bins in front of its kernel, like a render. */
 int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
                    const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
-                   int spp, uint32_t seed, const float *gimg /*[dev][H,W,3] fp32*/,
+                   int spp, uint32_t seed, int flags, const float *gimg /*[dev][H,W,3] fp32*/,
                    float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -605,6 +608,11 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
 #define FFX_RENDER_CACHE_ZEROED 8    /* img_fp16 bit 3 (ffx_render_fwd_cache): the first 64 bytes of `cache` are zero (cleared by the caller,
                                        stream-ordered before this call — e.g. by the launch that clears its gradient buffer): the call
                                        does not reset the header itself.  The oracle ignores the bit. */
+#define FFX_RENDER_CACHE_KEEP_DROPPED 16 /* img_fp16 bit 4 (ffx_render_fwd_cache, ABI 7): the call resets the arena of single-sample records but
+                                       KEEPS the header's `dropped` count — a step that reuses one cache for several scene samples, one after the
+                                       other, then finds at its end whether ANY of them overflowed (ffx_adam_args.guard, ffx_render_cache_status):
+                                       the first sample of the step clears the word (FFX_RENDER_CACHE_ZEROED or a plain call), the others keep it.
+                                       The oracle ignores the bit (its cache never drops). */
 /* Writes the apex records (the triangles as seen from a fixed ray origin) of sd's camera and enabled emitters into
  * the blob's apex areas — what every packet render does in front of its kernel unless told FFX_RENDER_APEX_READY.  Only
  * sd->cam.to_world, sd->proj.{enabled,to_world} and sd->spot.{enabled,to_world} are read.  No reference counterpart (Mitsuba
@@ -612,7 +620,8 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
 int ffx_apex_prepare(void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/, ffx_stream stream);
 size_t ffx_render_cache_bytes(int width, int height, int spp); /* Lambert scenes (mat_stride 0 / 3) */
 /* the same for any scene: with material rows the cache holds a second footprint per pixel (the part of the BSDF
- * that does not scale with base_color): 67.1 MB at 512x512x64 */
+ * that does not scale with base_color): 67.1 MB at 512x512x64; with sd->rfilter != 0 the size of the filtered film's cache
+ * (ffx_render_fwd_cache_filtered, below) */
 size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd /*[host]*/, int spp);
 int ffx_render_fwd_cache(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/,
                          const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev][n_shapes,3 | FFX_MAT_STRIDE]*/,
@@ -676,9 +685,32 @@ int ffx_render_fwd_adjoint_filtered(const void *bvh /*[dev]*/, const ffx_bvh_inf
                                     int img_fp16, void *img /*[dev][H,W,3]*/, const float *gimg /*[dev][H,W,3] fp32*/,
                                     float *gtex /*[dev][tex_h,tex_w,1]*/, void *scratch /*[dev]*/, ffx_stream stream);
 int ffx_render_bwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
-                            const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed,
+                            const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed, int flags /* FFX_RENDER_APEX_READY or 0 */,
                             const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, void *scratch /*[dev]*/,
                             ffx_stream stream);
+/* Store instead of re-trace for the filtered film (ABI 7): the configuration the reference actually runs — hdrfilm's default gaussian filter
+ * (examples/vocalfold_scene.py:20-22, main.py:26-29) under a loss that is NOT linear in the image (torch.nn.L1Loss,
+ * fireflies/graphics/rasterization.py:579,596-602), whose gradient is only known after the render.
+ * ffx_render_fwd_cache_filtered = ffx_render_fwd_filtered that additionally writes into `cache` (ffx_render_cache_bytes_sd(sd, spp) bytes
+ * for a filtered sd; opaque, read only by the library that wrote it) what the adjoint needs.  A sample spreads over the 25 pixels of its
+ * window with weights of its own, so a pixel's samples do NOT fold into one footprint as under the box film (25 gradients x 25 texels):
+ * libffx_hip keeps, for the pixels that have a lit sample only, one 16-byte record per sample {base texel + shape, the two bilinear
+ * fractions, the factor} (+ 4 bytes with material rows) at the sample's own index — nothing to allocate, nothing that can overflow — plus
+ * a dense array of 8-byte pixel headers (which 64-sample passes of the pixel hold a lit sample) and the weight every pixel received (written by the gather).
+ * 344 MB of address space at 512x512x64 with material rows, ~15 MB of it touched by a dot pattern's render with FFX_RENDER_SPARSE_ADJOINT.
+ * ffx_render_bwd_cached_filtered: gtex += the adjoint applied to gimg — per lit pixel a wave recomputes the samples' filter weights from the
+ * jitter (`seed`: the forward's), forms G = gimg / weight over the pixel's window, gives every lit sample its own gradient
+ * sum_n w_n G[pixel + n] and scatters its four taps through an LDS tile shared by a 16x16-pixel block.  Needs neither the BVH nor the
+ * camera pose (the geometry may be re-fitted in between; shape_albedo must hold the forward's values).  Same result as
+ * ffx_render_bwd_filtered up to the order of the float atomics.  Flags of the forward: FFX_RENDER_FP16, FFX_RENDER_SPARSE_ADJOINT,
+ * FFX_RENDER_APEX_READY.  FFX_ERR_UNSUPPORTED with textured base colours, projector textures above 4094^2 or more than 255 shapes, spp > 1024. */
+int ffx_render_fwd_cache_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                                  const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
+                                  int img_fp16, void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes_sd*/, void *scratch /*[dev] ffx_render_filter_bytes*/,
+                                  ffx_stream stream);
+int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const void *cache /*[dev]*/,
+                                   int spp, uint32_t seed, const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/,
+                                   ffx_stream stream);
 
 #ifdef __cplusplus
 }

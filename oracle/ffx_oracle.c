@@ -1574,7 +1574,12 @@ int ffx_render_fwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
 }
 
 size_t ffx_render_cache_bytes(int width, int height, int spp) { return (size_t)width * height * spp * sizeof(crec); }
-size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) { return sd ? ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp) : 0; }
+size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) {
+  if (!sd) return 0;
+  size_t n = ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp);
+  if (sd->rfilter != FFX_RFILTER_BOX) n += sizeof(float) * (size_t)sd->cam.width * sd->cam.height; /* the weight each pixel received (ffx_render_fwd_cache_filtered) */
+  return n;
+}
 
 int ffx_render_fwd_cache(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
                          uint32_t seed, int img_fp16, void *img, void *cache, ffx_stream s) {
@@ -1680,9 +1685,31 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   return FFX_OK;
 }
 
-int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+/* The adjoints trace in PARALLEL and accumulate SERIALLY: a block of pixels is shaded by all threads into a table of sample_terms,
+ * then one thread adds the block's samples to the double accumulator in sample order — the sums see their operands in the order a
+ * plain serial loop would give them (deterministic for any thread count), at the speed of the forward render. */
+#define BWD_BLOCK_PIX 2048
+static sample_terms *bwd_trace_block(const shade_ctx *c, const onode *nodes, const orec *recs, int pix0, int pix1, int spp, uint32_t seed, sample_terms *tab) {
+  const int W = c->cam.W;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int pix = pix0; pix < pix1; ++pix) {
+    const int x = pix % W, y = pix / W;
+    for (int sidx = 0; sidx < spp; ++sidx) {
+      uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
+      float jx, jy;
+      sample_jitter(seed, idx, &jx, &jy);
+      v3 d;
+      float nt, ft;
+      cam_ray(&c->cam, ((float)x + jx) * c->cam.inv_w, ((float)y + jy) * c->cam.inv_h, &d, &nt, &ft);
+      shade_sample(c, nodes, recs, c->cam.o, d, nt, ft, &tab[(size_t)(pix - pix0) * spp + sidx]);
+    }
+  }
+  return tab;
+}
+
+int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                    const float *gimg, float *gtex, ffx_stream s) {
-  (void)s;
+  (void)s; (void)flags; /* FFX_RENDER_APEX_READY ignored: the apex vectors are formed per test */
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
@@ -1697,37 +1724,35 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   float inv_spp = 1.0f / (float)spp;
   size_t nt_ = (size_t)c.tw * c.th * c.tc;
   double *acc = (double *)calloc(nt_, sizeof(double));
-  /* serial on purpose: deterministic double accumulation */
-  for (int pix = 0; pix < W * H; ++pix) {
-    int x = pix % W, y = pix / W;
-    const float *g = gimg + (size_t)pix * 3;
-    if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
-    for (int sidx = 0; sidx < spp; ++sidx) {
-      uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
-      float jx, jy;
-      sample_jitter(seed, idx, &jx, &jy);
-      v3 d;
-      float nt, ft;
-      cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
-      sample_terms st;
-      shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
-      if (!st.hit || !st.has_proj) continue;
-      const float *alb = st.base;
-      for (int tch = 0; tch < c.tc; ++tch) {
-        float wsum;
-        if (c.tc == 3) wsum = g[tch] * alb[tch] * st.proj_fac * inv_spp;
-        else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * st.proj_fac * inv_spp;
-        if (st.proj_fac_b != 0.f) {
-          if (c.tc == 3) wsum += g[tch] * st.proj_fac_b * inv_spp;
-          else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * st.proj_fac_b * inv_spp;
+  sample_terms *tab = (sample_terms *)malloc(sizeof(sample_terms) * (size_t)BWD_BLOCK_PIX * (size_t)spp);
+  if (!acc || !tab) { free(acc); free(tab); FAIL(FFX_ERR_NOMEM, "render_bwd: out of memory"); }
+  for (int pix0 = 0; pix0 < W * H; pix0 += BWD_BLOCK_PIX) {
+    const int pix1 = pix0 + BWD_BLOCK_PIX < W * H ? pix0 + BWD_BLOCK_PIX : W * H;
+    bwd_trace_block(&c, nodes, recs, pix0, pix1, spp, seed, tab);
+    for (int pix = pix0; pix < pix1; ++pix) { /* serial on purpose: deterministic double accumulation */
+      const float *g = gimg + (size_t)pix * 3;
+      if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
+      for (int sidx = 0; sidx < spp; ++sidx) {
+        const sample_terms *stp = &tab[(size_t)(pix - pix0) * spp + sidx];
+        if (!stp->hit || !stp->has_proj) continue;
+        const float *alb = stp->base;
+        for (int tch = 0; tch < c.tc; ++tch) {
+          float wsum;
+          if (c.tc == 3) wsum = g[tch] * alb[tch] * stp->proj_fac * inv_spp;
+          else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * stp->proj_fac * inv_spp;
+          if (stp->proj_fac_b != 0.f) {
+            if (c.tc == 3) wsum += g[tch] * stp->proj_fac_b * inv_spp;
+            else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * stp->proj_fac_b * inv_spp;
+          }
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) acc[((size_t)stp->iy[a] * c.tw + stp->ix[b]) * c.tc + tch] += (double)(wsum * stp->wy[a] * stp->wx[b]);
         }
-        for (int a = 0; a < 2; ++a)
-          for (int b = 0; b < 2; ++b) acc[((size_t)st.iy[a] * c.tw + st.ix[b]) * c.tc + tch] += (double)(wsum * st.wy[a] * st.wx[b]);
       }
     }
   }
   for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
   free(acc);
+  free(tab);
   return FFX_OK;
 }
 
@@ -1794,9 +1819,9 @@ static inline void rf_gather(const float *part, int W, int H, int x, int y, floa
     }
 }
 
-int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
-                            uint32_t seed, int img_fp16, void *img, void *scratch, ffx_stream s) {
-  (void)s;
+/* cache (ffx_render_fwd_cache_filtered): one crec per sample as in the box render's cache, then the weight each pixel received */
+static int render_fwd_filtered_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                                    uint32_t seed, int img_fp16, void *img, void *scratch, crec *cache) {
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!bvh || !info || !sd || !shape_albedo || !img || !scratch || spp < 1) FAIL(FFX_ERR_ARG, "render_fwd_filtered: bad argument");
   if (sd->proj.enabled && !tex) FAIL(FFX_ERR_ARG, "render_fwd_filtered: projector enabled but tex is NULL");
@@ -1825,6 +1850,14 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
       cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
       sample_terms st;
       shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
+      if (cache) {
+        crec *cr = &cache[idx];
+        cr->w0 = 0; cr->ax = 0.f; cr->ay = 0.f; cr->fac = 0.f; cr->fac_b = 0.f; cr->pad = 0;
+        if (st.hit && st.has_proj) {
+          cr->w0 = (uint32_t)(st.ubx + 1) | ((uint32_t)(st.uby + 1) << 12) | ((uint32_t)st.shape << 24);
+          cr->ax = st.wx[1]; cr->ay = st.wy[1]; cr->fac = st.proj_fac; cr->fac_b = st.proj_fac_b;
+        }
+      }
       float L[4];
       sample_radiance(&c, tex, &st, L);
       L[3] = 1.0f; /* the weight channel: every sample drawn counts, lit or not */
@@ -1849,11 +1882,92 @@ int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
       if (img_fp16 & 1) ((uint16_t *)img)[(size_t)pix * 3 + ch] = f32_to_f16(v);
       else ((float *)img)[(size_t)pix * 3 + ch] = v;
     }
+    if (cache) ((float *)(cache + (size_t)W * H * spp))[pix] = acc[3];
   }
   return FFX_OK;
 }
 
-int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+int ffx_render_fwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                            uint32_t seed, int img_fp16, void *img, void *scratch, ffx_stream s) {
+  (void)s;
+  return render_fwd_filtered_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, scratch, NULL);
+}
+
+/* the filtered render that also stores what its adjoint needs (include/ffx.h): the per-sample records of the box render's cache plus
+ * the weight each pixel received */
+int ffx_render_fwd_cache_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
+                                  uint32_t seed, int img_fp16, void *img, void *cache, void *scratch, ffx_stream s) {
+  (void)s;
+  if (!cache) FAIL(FFX_ERR_ARG, "render_fwd_cache_filtered: cache is NULL");
+  if (sd && sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: textured base colours (use ffx_render_bwd_filtered)");
+  return render_fwd_filtered_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16, img, scratch, (crec *)cache); /* sparse-adjoint bit ignored: full gradient */
+}
+
+/* its adjoint: no tracing — a lit sample's record, its filter weights (from the jitter: the seed) and G = gimg / weight of its window.
+ * Same arithmetic and the same order of the double additions as ffx_render_bwd_filtered (pixels, samples, channels, taps ascending). */
+int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, uint32_t seed, const float *gimg,
+                                   float *gtex, ffx_stream s) {
+  (void)s;
+  if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
+  if (!sd || !shape_albedo || !cache || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd_cached_filtered: bad argument");
+  rf_ctx rf;
+  if (!rf_prepare(sd, &rf)) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: rfilter must be FFX_RFILTER_GAUSSIAN with stddev <= 0.5");
+  if (!sd->proj.enabled) return FFX_OK;
+  const int W = sd->cam.width, H = sd->cam.height, tw = sd->proj.tex_w, th = sd->proj.tex_h, tc = sd->proj.tex_channels;
+  const int ms = sd->mat_stride ? sd->mat_stride : 3;
+  const crec *cr = (const crec *)cache;
+  const float *wsum_pix = (const float *)(cr + (size_t)W * H * spp);
+  float *G = (float *)malloc(sizeof(float) * 4 * (size_t)W * H);
+  size_t nt_ = (size_t)tw * th * tc;
+  double *acc = (double *)calloc(nt_, sizeof(double));
+  if (!G || !acc) { free(G); free(acc); FAIL(FFX_ERR_NOMEM, "render_bwd_cached_filtered: out of memory"); }
+  for (int pix = 0; pix < W * H; ++pix) {
+    const float wsum = wsum_pix[pix];
+    for (int ch = 0; ch < 3; ++ch) G[(size_t)pix * 4 + ch] = wsum > 0.f ? gimg[(size_t)pix * 3 + ch] / wsum : 0.f;
+    G[(size_t)pix * 4 + 3] = 0.f;
+  }
+  for (int pix = 0; pix < W * H; ++pix) {
+    const int x = pix % W, y = pix / W;
+    for (int sidx = 0; sidx < spp; ++sidx) {
+      const uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
+      const crec *r = &cr[idx];
+      if (r->fac == 0.f && r->fac_b == 0.f) continue;
+      float jx, jy, gx[5], gy[5], g[3] = {0.f, 0.f, 0.f};
+      sample_jitter(seed, idx, &jx, &jy);
+      rf_weights(&rf, jx, gx);
+      rf_weights(&rf, jy, gy);
+      for (int b = 0; b < 5; ++b)
+        for (int a = 0; a < 5; ++a) {
+          const int tx = x + (a - 2), ty = y + (b - 2);
+          if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+          const float w = gx[a] * gy[b];
+          const float *gp = G + (size_t)(ty * W + tx) * 4;
+          for (int ch = 0; ch < 3; ++ch) g[ch] = fmaf(w, gp[ch], g[ch]);
+        }
+      int ix0 = (int)(r->w0 & 0xfffu) - 1, iy0 = (int)((r->w0 >> 12) & 0xfffu) - 1, shape = (int)(r->w0 >> 24);
+      int ix[2] = {clampi(ix0, 0, tw - 1), clampi(ix0 + 1, 0, tw - 1)}, iy[2] = {clampi(iy0, 0, th - 1), clampi(iy0 + 1, 0, th - 1)};
+      float wx[2] = {1.0f - r->ax, r->ax}, wy[2] = {1.0f - r->ay, r->ay};
+      const float *alb = shape_albedo + (size_t)ms * shape;
+      for (int tch = 0; tch < tc; ++tch) {
+        float wsum;
+        if (tc == 3) wsum = g[tch] * alb[tch] * r->fac;
+        else wsum = (g[0] * alb[0] * sd->proj.color[0] + g[1] * alb[1] * sd->proj.color[1] + g[2] * alb[2] * sd->proj.color[2]) * r->fac;
+        if (r->fac_b != 0.f) {
+          if (tc == 3) wsum += g[tch] * r->fac_b;
+          else wsum += (g[0] * sd->proj.color[0] + g[1] * sd->proj.color[1] + g[2] * sd->proj.color[2]) * r->fac_b;
+        }
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b) acc[((size_t)iy[a] * tw + ix[b]) * tc + tch] += (double)(wsum * wy[a] * wx[b]);
+      }
+    }
+  }
+  for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
+  free(acc);
+  free(G);
+  return FFX_OK;
+}
+
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                             const float *gimg, float *gtex, void *scratch, ffx_stream s);
 /* forward + adjoint of a linear loss in one call (include/ffx.h): here the composition it stands for */
 int ffx_render_fwd_adjoint_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, const float *tex, int spp,
@@ -1862,13 +1976,13 @@ int ffx_render_fwd_adjoint_filtered(const void *bvh, const ffx_bvh_info *info, c
   if (!sd || !sd->proj.enabled) FAIL(FFX_ERR_ARG, "render_fwd_adjoint_filtered: the scene has no projector (nothing to differentiate)");
   if (sd->proj.tex_channels != 1 || sd->n_base_tex > 0) FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_adjoint_filtered: 1-channel projector textures without textured base colours");
   int rc = ffx_render_fwd_filtered(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & 1, img, scratch, s);
-  if (rc == FFX_OK) rc = ffx_render_bwd_filtered(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, scratch, s);
+  if (rc == FFX_OK) rc = ffx_render_bwd_filtered(bvh, info, sd, shape_albedo, spp, seed, 0, gimg, gtex, scratch, s);
   return rc;
 }
 
-int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                             const float *gimg, float *gtex, void *scratch, ffx_stream s) {
-  (void)s;
+  (void)s; (void)flags;
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
   if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || !scratch || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd_filtered: bad argument");
   rf_ctx rf;
@@ -1884,6 +1998,7 @@ int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   /* 1. the weight every pixel received (the jitter alone decides it), then G = gimg / weight */
   float *part = (float *)scratch; /* [H*W][25] weight sums, then G [H*W][4] behind them */
   float *G = part + (size_t)W * H * 25;
+#pragma omp parallel for schedule(static)
   for (int pix = 0; pix < W * H; ++pix) {
     float *pp = part + (size_t)pix * 25;
     float half[2][25];
@@ -1899,6 +2014,7 @@ int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
     }
     for (int k = 0; k < 25; ++k) pp[k] = half[0][k] + half[1][k];
   }
+#pragma omp parallel for schedule(static)
   for (int pix = 0; pix < W * H; ++pix) {
     const int x = pix % W, y = pix / W;
     float wsum = 0.f;
@@ -1914,55 +2030,57 @@ int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   /* 2. re-trace: a sample's radiance receives sum_n w_n G[pixel + n]; from there as ffx_render_bwd without the 1 / spp */
   size_t nt_ = (size_t)c.tw * c.th * c.tc;
   double *acc = (double *)calloc(nt_, sizeof(double));
-  if (!acc) FAIL(FFX_ERR_NOMEM, "render_bwd_filtered: out of memory");
-  for (int pix = 0; pix < W * H; ++pix) { /* serial on purpose: deterministic double accumulation */
-    const int x = pix % W, y = pix / W;
-    int any = 0;
-    for (int b = 0; b < 5 && !any; ++b)
-      for (int a = 0; a < 5 && !any; ++a) {
-        const int tx = x + (a - 2), ty = y + (b - 2);
-        if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
-        const float *gp = G + (size_t)(ty * W + tx) * 4;
-        any = gp[0] != 0.f || gp[1] != 0.f || gp[2] != 0.f;
-      }
-    if (!any) continue;
-    for (int sidx = 0; sidx < spp; ++sidx) {
-      uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
-      float jx, jy;
-      sample_jitter(seed, idx, &jx, &jy);
-      v3 d;
-      float nt, ft;
-      cam_ray(&c.cam, ((float)x + jx) * c.cam.inv_w, ((float)y + jy) * c.cam.inv_h, &d, &nt, &ft);
-      sample_terms st;
-      shade_sample(&c, nodes, recs, c.cam.o, d, nt, ft, &st);
-      if (!st.hit || !st.has_proj) continue;
-      float gx[5], gy[5], g[3] = {0.f, 0.f, 0.f};
-      rf_weights(&rf, jx, gx);
-      rf_weights(&rf, jy, gy);
-      for (int b = 0; b < 5; ++b)
-        for (int a = 0; a < 5; ++a) {
+  sample_terms *tab = (sample_terms *)malloc(sizeof(sample_terms) * (size_t)BWD_BLOCK_PIX * (size_t)spp);
+  if (!acc || !tab) { free(acc); free(tab); FAIL(FFX_ERR_NOMEM, "render_bwd_filtered: out of memory"); }
+  for (int pix0 = 0; pix0 < W * H; pix0 += BWD_BLOCK_PIX) {
+    const int pix1 = pix0 + BWD_BLOCK_PIX < W * H ? pix0 + BWD_BLOCK_PIX : W * H;
+    bwd_trace_block(&c, nodes, recs, pix0, pix1, spp, seed, tab); /* (parallel; the accumulation below is serial: deterministic double sums) */
+    for (int pix = pix0; pix < pix1; ++pix) {
+      const int x = pix % W, y = pix / W;
+      int any = 0;
+      for (int b = 0; b < 5 && !any; ++b)
+        for (int a = 0; a < 5 && !any; ++a) {
           const int tx = x + (a - 2), ty = y + (b - 2);
           if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
-          const float w = gx[a] * gy[b];
           const float *gp = G + (size_t)(ty * W + tx) * 4;
-          for (int ch = 0; ch < 3; ++ch) g[ch] = fmaf(w, gp[ch], g[ch]);
+          any = gp[0] != 0.f || gp[1] != 0.f || gp[2] != 0.f;
         }
-      const float *alb = st.base;
-      for (int tch = 0; tch < c.tc; ++tch) {
-        float wsum;
-        if (c.tc == 3) wsum = g[tch] * alb[tch] * st.proj_fac;
-        else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * st.proj_fac;
-        if (st.proj_fac_b != 0.f) {
-          if (c.tc == 3) wsum += g[tch] * st.proj_fac_b;
-          else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * st.proj_fac_b;
+      if (!any) continue;
+      for (int sidx = 0; sidx < spp; ++sidx) {
+        const sample_terms *stp = &tab[(size_t)(pix - pix0) * spp + sidx];
+        if (!stp->hit || !stp->has_proj) continue;
+        uint32_t idx = (uint32_t)pix * (uint32_t)spp + (uint32_t)sidx;
+        float jx, jy;
+        sample_jitter(seed, idx, &jx, &jy);
+        float gx[5], gy[5], g[3] = {0.f, 0.f, 0.f};
+        rf_weights(&rf, jx, gx);
+        rf_weights(&rf, jy, gy);
+        for (int b = 0; b < 5; ++b)
+          for (int a = 0; a < 5; ++a) {
+            const int tx = x + (a - 2), ty = y + (b - 2);
+            if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+            const float w = gx[a] * gy[b];
+            const float *gp = G + (size_t)(ty * W + tx) * 4;
+            for (int ch = 0; ch < 3; ++ch) g[ch] = fmaf(w, gp[ch], g[ch]);
+          }
+        const float *alb = stp->base;
+        for (int tch = 0; tch < c.tc; ++tch) {
+          float wsum;
+          if (c.tc == 3) wsum = g[tch] * alb[tch] * stp->proj_fac;
+          else wsum = (g[0] * alb[0] * c.p_color[0] + g[1] * alb[1] * c.p_color[1] + g[2] * alb[2] * c.p_color[2]) * stp->proj_fac;
+          if (stp->proj_fac_b != 0.f) {
+            if (c.tc == 3) wsum += g[tch] * stp->proj_fac_b;
+            else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * stp->proj_fac_b;
+          }
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) acc[((size_t)stp->iy[a] * c.tw + stp->ix[b]) * c.tc + tch] += (double)(wsum * stp->wy[a] * stp->wx[b]);
         }
-        for (int a = 0; a < 2; ++a)
-          for (int b = 0; b < 2; ++b) acc[((size_t)st.iy[a] * c.tw + st.ix[b]) * c.tc + tch] += (double)(wsum * st.wy[a] * st.wx[b]);
       }
     }
   }
   for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
   free(acc);
+  free(tab);
   return FFX_OK;
 }
 

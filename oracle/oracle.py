@@ -331,6 +331,11 @@ class Geometry:
         H, W = sd.cam.height, sd.cam.width
         img = np.empty((H, W, 3), np.float16 if fp16 else np.float32)
         cache = np.zeros(api().lib.ffx_render_cache_bytes_sd(C.byref(sd), spp), np.uint8)
+        if sd.rfilter:  # the filtered film's cache (ffx_render_fwd_cache_filtered): per-sample records + the weight each pixel received
+            scratch = np.empty(api().lib.ffx_render_filter_bytes(C.byref(sd)), np.uint8)
+            api().call("ffx_render_fwd_cache_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(cache),
+                       _p(scratch), None)
+            return img, cache
         api().call("ffx_render_fwd_cache", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), _p(tex), spp, seed, int(fp16), _p(img), _p(cache), None)
         return img, cache
 
@@ -350,10 +355,16 @@ class Geometry:
         return img, gtex, float(dot.astype(np.float64).sum())
 
     @staticmethod
-    def render_bwd_cached(sd, albedo, cache, spp, gimg, img=None):
-        """-> gtex; with `img` (the forward's image, float32 or float16) also <gimg, img>: (gtex, dot)"""
+    def render_bwd_cached(sd, albedo, cache, spp, gimg, img=None, seed=None):
+        """-> gtex; with `img` (the forward's image, float32 or float16) also <gimg, img>: (gtex, dot).  A filtered film's cache
+        (sd.rfilter) needs the forward's `seed` (the filter weights are re-derived from the jitter)."""
         albedo, gimg = _f32(albedo), _f32(gimg)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        if sd.rfilter:
+            if seed is None or img is not None:
+                raise ValueError("filtered cache: pass the forward's seed; no <gimg, img> output")
+            api().call("ffx_render_bwd_cached_filtered", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, seed, _p(gimg), _p(gtex), None)
+            return gtex
         if img is None:
             api().call("ffx_render_bwd_cached", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(gimg), _p(gtex), None, 0, None, None)
             return gtex
@@ -368,7 +379,7 @@ class Geometry:
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
         if sd.rfilter:
             scratch = np.empty(api().lib.ffx_render_filter_bytes(C.byref(sd)), np.uint8)
-            api().call("ffx_render_bwd_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, _p(gimg), _p(gtex), _p(scratch), None)
+            api().call("ffx_render_bwd_filtered", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, 0, _p(gimg), _p(gtex), _p(scratch), None)
             return gtex
-        api().call("ffx_render_bwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, _p(gimg), _p(gtex), None)
+        api().call("ffx_render_bwd", _p(self.blob), C.byref(self.info), C.byref(sd), _p(albedo), spp, seed, 0, _p(gimg), _p(gtex), None)
         return gtex

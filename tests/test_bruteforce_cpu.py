@@ -356,6 +356,17 @@ def test_gaussian_reconstruction_filter_oracle_agrees_with_bruteforce(oracle, wh
     base_o = go.render_fwd(sd, alb, np.zeros_like(tex), spp, seed=11).astype(np.float64)
     lhs_o, rhs_o = float(((img_o - base_o) * gimg).sum()), float((tex.astype(np.float64) * gt_o).sum())
     assert abs(lhs_o - rhs_o) <= 2e-4 * max(abs(lhs_o), abs(rhs_o))
-    # every other render call refuses the filter instead of rendering a box
-    with pytest.raises(Exception, match="reconstruction filter"):
-        go.render_fwd_cache(sd, alb, tex, spp, seed=11)
+    # the filtered film's adjoint cache (ABI 7): the same image, and from its records — no tracing — the re-traced adjoint's gradient
+    # (same arithmetic, same order of the double sums: bit for bit)
+    img_c, cache = go.render_fwd_cache(sd, alb, tex, spp, seed=11)
+    np.testing.assert_array_equal(img_c, img_o)
+    np.testing.assert_array_equal(go.render_bwd_cached(sd, alb, cache, spp, gimg, seed=11)[..., 0], gt_o)
+    assert not np.array_equal(go.render_bwd_cached(sd, alb, cache, spp, gimg, seed=12)[..., 0], gt_o)  # (the weights come from the seed's jitter)
+    # every box-only render call refuses the filter instead of rendering a box
+    import ctypes as C
+
+    a = oracle.api()
+    cbuf, ibuf = np.zeros(a.lib.ffx_render_cache_bytes_sd(C.byref(sd), spp), np.uint8), np.zeros((sc.camera.height, sc.camera.width, 3), np.float32)
+    albc, texc = np.ascontiguousarray(alb, np.float32), np.ascontiguousarray(tex, np.float32)
+    rc = a.lib.ffx_render_fwd_cache(go.blob.ctypes.data, C.byref(go.info), C.byref(sd), albc.ctypes.data, texc.ctypes.data, spp, 11, 0, ibuf.ctypes.data, cbuf.ctypes.data, None)
+    assert rc == -3 and b"reconstruction filter" in a.lib.ffx_last_error()
