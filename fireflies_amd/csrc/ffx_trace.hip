@@ -3401,84 +3401,93 @@ __global__ void __launch_bounds__(256)
   k9_stray(cache, n_pix, (uint32_t)(blockIdx.x - slot_blocks) * 256u + threadIdx.x, p, gimg, albedo, gtex);
 }
 
-// K9 of the filtered film's cache (ffx_render_bwd_cached_filtered; rfc_off_* above).  A workgroup of four waves owns a 16x16-pixel block:
-// pass 1, a lane per pixel, reads the dense headers and compacts the (pixel, pass) pairs that hold lit samples into a list — a block
-// without any ends after one round of loads (96 % of a dot pattern's film).  Pass 2: a wave per list entry, lanes on the 64 samples of
-// that pass — the sample's record (one coalesced 1 KB load), its ten filter weights from the jitter (the forward's hash), the pixel's
-// window of G = gimg / weight (lanes 0..24 load a window pixel each, broadcast by v_readlane), the sample's own gradient
-// sum_n w_n G[pixel + n] (the arithmetic and the order of k_render_fwd_pk<.., ADJ, RF>), its four bilinear taps into a 48x48-texel LDS
-// tile anchored at the block's first lit tap (taps outside go to memory directly); the tile is flushed with one global atomic per
-// touched texel.  1-channel textures take the tile; 3-channel ones scatter their twelve atomics per sample directly.
-struct BwdF { int tw, th, tc, spp; float color[3]; float rf_alpha, rf_bias; int W, H; int ms; uint32_t seed_key; size_t off_wsum, off_recs, off_facb;
+// K9 of the filtered film's cache (ffx_render_bwd_cached_filtered; rfc_off_* above).  An ITEM is one lit 64-sample pass of one pixel: the
+// lanes take its 64 records (one coalesced 1 KB load), their ten filter weights from the jitter (the forward's hash), the pixel's window of
+// G = gimg / weight (lanes 0..24 load a window pixel each, broadcast by v_readlane), the sample's own gradient sum_n w_n G[pixel + n] (the
+// arithmetic and the order of k_render_fwd_pk<.., ADJ, RF>); the wave then sums its samples' taps per texel of the pixel's 5x5 texel window
+// (25 DPP reductions) and 25 lanes add one value each to gtex — no per-sample atomics (samples outside the window: their four taps directly).
+// ~800 VALU instructions per item, and the items of a dot pattern's render sit in ~500 of the film's 4096 8x8-pixel blocks: as ONE workgroup
+// per block (first version: 16x16-pixel blocks, then 8x8, four to sixteen waves, an LDS tile per block) a block's ~64 items ran on ONE compute
+// unit — 0.16 / 0.09 / 0.065 ms with 250 of 256 CUs idle.  Now every block is served by K9F_SUB independent ONE-WAVE workgroups (the
+// dispatcher deals them to different CUs and XCDs): each reads the block's 64 pixel headers itself (512 bytes, L2) and takes every
+// K9F_SUB-th lit item.  A block without lit pixels costs its waves one load.  3-channel textures: twelve direct atomics per sample.
+struct BwdF { int tw, th, tc, spp; float color[3]; float rf_alpha, rf_bias; int W, H; int ms, n_shapes; uint32_t seed_key; size_t off_wsum, off_recs, off_facb;
               const float *mats; int mat_inline; float mat_h[FFX_MAX_MAT_H]; };
 __device__ __forceinline__ const float *mat_table(const BwdF &k) { return k.mat_inline ? k.mat_h : k.mats; }
-#define K9F_TILE 48
-__global__ void __launch_bounds__(256)
+#define K9F_BLOCK 8 // pixels per side of a block
+#ifndef K9F_SUB
+#define K9F_SUB 16 // one-wave workgroups per block (a wave's items are a serial chain of ~1000 instructions each: 4 / 8 / 16 waves per block = 0.102 / 0.055 / 0.035 ms)
+#endif
+__global__ void __launch_bounds__(64)
     k_render_bwd_cached_filtered(BwdF p_by_value, const char *__restrict__ cache, int blocks_x, const float *__restrict__ gimg, float *__restrict__ gtex) {
-  __shared__ float s_tile[K9F_TILE * K9F_TILE];
-  __shared__ int s_n, s_org;
-  __shared__ unsigned short s_list[256 * 16]; // (pixel of the block) | pass << 8 — up to 16 passes (spp <= 1024)
   const BwdF &p = kernarg_first<BwdF>();
   const float *albedo = mat_table(p);
-  const int bx = (int)blockIdx.x % blocks_x, by = (int)blockIdx.x / blocks_x;
+  const int blk = (int)blockIdx.x / K9F_SUB, sub = (int)blockIdx.x % K9F_SUB;
+  const int bx = blk % blocks_x, by = blk / blocks_x;
   const CachePix *hdrs = reinterpret_cast<const CachePix *>(cache + 64);
   const float *wsum = reinterpret_cast<const float *>(cache + p.off_wsum);
   const uint4 *recs = reinterpret_cast<const uint4 *>(cache + p.off_recs);
   const float *facb = reinterpret_cast<const float *>(cache + p.off_facb);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { s_n = 0; s_org = -1; }
-  __syncthreads();
-  { // pass 1: one lane per pixel of the block
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = bx * 16 + lx, y = by * 16 + ly;
-    uint32_t mask = 0u;
+  const int lane = threadIdx.x;
+  uint32_t mask = 0u; // the lane's pixel: its lit passes
+  {
+    const int x = bx * K9F_BLOCK + lane % K9F_BLOCK, y = by * K9F_BLOCK + lane / K9F_BLOCK;
     if (x < p.W && y < p.H) mask = hdrs[(long)y * p.W + x].lit;
-    const int cnt = __builtin_popcount(mask);
-    if (cnt != 0) {
-      int k = atomicAdd(&s_n, cnt);
-      while (mask != 0u) {
-        const int ps = __builtin_ctz(mask);
-        mask &= mask - 1u;
-        s_list[k++] = (unsigned short)(threadIdx.x | (ps << 8));
+  }
+  if (wballot(mask != 0u) == 0ull) return; // (nothing lit in this block: 96 % of a dot pattern's film ends here)
+  const int passes = (p.spp + 63) >> 6;
+  const bool tiled = p.tc == 1, mat = p.ms != 3;
+  // this wave's items: rank r of the block's lit (pass, pixel) pairs in (pass, pixel) order belongs to wave r % K9F_SUB.  State of the walk: the
+  // pass, the lit pixels of that pass not yet visited, the rank of the next one — all wave-uniform
+  int it_pass = 0, it_rank = 0;
+  wmask it_left = wballot((mask & 1u) != 0u);
+  auto next_item = [&](int &pl, int &pass) -> bool { // -> this wave's next item, false when the block is exhausted
+    for (;;) {
+      while (it_left == 0ull) {
+        if (++it_pass >= passes) return false;
+        it_left = wballot(((mask >> it_pass) & 1u) != 0u);
       }
+      const int l = wff1(it_left);
+      it_left &= it_left - 1ull;
+      if ((it_rank++ % K9F_SUB) == sub) { pl = l; pass = it_pass; return true; }
     }
-  }
-  __syncthreads();
-  const int n_items = s_n;
-  if (n_items == 0) return; // (uniform: nothing lit in this block)
-  const bool tiled = p.tc == 1;
-  if (tiled) {
-    for (int i = threadIdx.x; i < K9F_TILE * K9F_TILE; i += 256) s_tile[i] = 0.f;
-  }
-  __syncthreads();
-  const bool mat = p.ms != 3;
-  for (int it = wv; it < n_items; it += 4) { // (wave-uniform loop)
-    const int item = (int)s_list[it];
-    const int pl = item & 255, pass = item >> 8;
-    const int px = bx * 16 + (pl & 15), py = by * 16 + (pl >> 4);
-    const long pixel = (long)py * p.W + px;
+  };
+  // an item's inputs: the lane's record (+ fac_b) and, in lanes 0..24, gimg and the weight of one pixel of the window.  Loaded ONE ITEM AHEAD
+  struct Item { uint4 rec; float fb, q0, q1, q2, qw; int px, py; uint32_t sidx; bool ok; };
+  auto fetch = [&](Item &o) {
+    o.rec = make_uint4(0u, 0u, 0u, 0u); o.fb = 0.f; o.q0 = o.q1 = o.q2 = 0.f; o.qw = 0.f; o.px = o.py = 0; o.sidx = 0u;
+    int pl = 0, pass = 0;
+    o.ok = next_item(pl, pass);
+    if (!o.ok) return;
+    o.px = bx * K9F_BLOCK + pl % K9F_BLOCK; o.py = by * K9F_BLOCK + pl / K9F_BLOCK;
+    const long pixel = (long)o.py * p.W + o.px;
     const int s = pass * 64 + lane;
-    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-    float fb = 0.f;
+    o.sidx = (uint32_t)pixel * (uint32_t)p.spp + (uint32_t)s;
     if (s < p.spp) {
-      rec = recs[(size_t)pixel * (size_t)p.spp + (size_t)s];
-      if (mat) fb = facb[(size_t)pixel * (size_t)p.spp + (size_t)s];
+      o.rec = recs[(size_t)pixel * (size_t)p.spp + (size_t)s];
+      if (mat) o.fb = facb[(size_t)pixel * (size_t)p.spp + (size_t)s];
     }
+    const int wb = (lane * 13) >> 6, wa = lane - 5 * wb; // lane / 5, lane % 5 for lane < 25
+    const int tx = o.px + wa - 2, ty = o.py + wb - 2;
+    if (lane < 25 && tx >= 0 && tx < p.W && ty >= 0 && ty < p.H) {
+      const long q = (long)ty * p.W + tx;
+      o.qw = wsum[q];
+      o.q0 = gimg[q * 3]; o.q1 = gimg[q * 3 + 1]; o.q2 = gimg[q * 3 + 2];
+    }
+  };
+  Item cur, nxt;
+  fetch(cur);
+  while (cur.ok) { // (wave-uniform loop)
+    fetch(nxt);
+    const uint4 rec = cur.rec;
+    const float fb = cur.fb;
     const float fac = __uint_as_float(rec.w);
     const bool lit = fac != 0.f || fb != 0.f;
-    // the pixel's window of G (lanes 0..24), zero outside the film
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    {
-      const int wb = (lane * 13) >> 6, wa = lane - 5 * wb; // lane / 5, lane % 5 for lane < 25
-      const int tx = px + wa - 2, ty = py + wb - 2;
-      if (lane < 25 && tx >= 0 && tx < p.W && ty >= 0 && ty < p.H) {
-        const long q = (long)ty * p.W + tx;
-        const float w = wsum[q];
-        if (w > 0.f) { g0 = gimg[q * 3] / w; g1 = gimg[q * 3 + 1] / w; g2 = gimg[q * 3 + 2] / w; }
-      }
-    }
+    // the pixel's window of G = gimg / weight (lanes 0..24), zero outside the film
+    const bool gok = cur.qw > 0.f;
+    const float g0 = gok ? cur.q0 / cur.qw : 0.f, g1 = gok ? cur.q1 / cur.qw : 0.f, g2 = gok ? cur.q2 / cur.qw : 0.f;
     float jx, jy, gx[5], gy[5];
-    sample_jitter(p.seed_key, (uint32_t)pixel * (uint32_t)p.spp + (uint32_t)s, jx, jy);
+    sample_jitter(p.seed_key, cur.sidx, jx, jy);
     rf_weights(p.rf_alpha, p.rf_bias, jx, gx);
     rf_weights(p.rf_alpha, p.rf_bias, jy, gy);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -3489,61 +3498,67 @@ __global__ void __launch_bounds__(256)
       a1 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(g1), n)), a1);
       a2 = __builtin_fmaf(w, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(g2), n)), a2);
     }
-    if (lit) { // (per lane from here on: no cross-lane operation inside)
-      const int ubx = (int)(rec.x & 0xfffu) - 1, uby = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
-      const int x0 = clampi(ubx, 0, p.tw - 1), x1 = clampi(ubx + 1, 0, p.tw - 1), y0 = clampi(uby, 0, p.th - 1), y1 = clampi(uby + 1, 0, p.th - 1);
-      const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
-      const float wx0 = 1.0f - ax, wx1 = ax, wy0 = 1.0f - ay, wy1 = ay;
-      const float *alb = albedo + p.ms * shape;
-      if (tiled) {
-        float pf = (a0 * alb[0] * p.color[0] + a1 * alb[1] * p.color[1] + a2 * alb[2] * p.color[2]) * fac;
+    const int ubx = (int)(rec.x & 0xfffu) - 1, uby = (int)((rec.x >> 12) & 0xfffu) - 1, shape = (int)(rec.x >> 24);
+    const int x0 = clampi(ubx, 0, p.tw - 1), x1 = clampi(ubx + 1, 0, p.tw - 1), y0 = clampi(uby, 0, p.th - 1), y1 = clampi(uby + 1, 0, p.th - 1);
+    const float ax = __uint_as_float(rec.y), ay = __uint_as_float(rec.z);
+    const float wx0 = 1.0f - ax, wx1 = ax, wy0 = 1.0f - ay, wy1 = ay;
+    const float *alb = albedo + p.ms * (lit ? shape : 0);
+    if (tiled) {
+      float pf = 0.f;
+      if (lit) {
+        pf = (a0 * alb[0] * p.color[0] + a1 * alb[1] * p.color[1] + a2 * alb[2] * p.color[2]) * fac;
         if (fb != 0.f) pf += (a0 * p.color[0] + a1 * p.color[1] + a2 * p.color[2]) * fb;
-        if (pf != 0.f) {
-          // the tile's origin: the first lit tap any lane of the block gets here with, minus a third of the tile (one word, set once)
-          int org = s_org;
-          if (org < 0) {
-            const int cand = (max(x0 - K9F_TILE / 3, 0)) | (max(y0 - K9F_TILE / 3, 0) << 16);
-            const int prev = atomicCAS(&s_org, -1, cand);
-            org = prev < 0 ? cand : prev;
-          }
-          const int ox = org & 0xffff, oy = org >> 16;
-          const int xs[2] = {x0, x1}, ys[2] = {y0, y1};
-          const float wxs[2] = {wx0, wx1}, wys[2] = {wy0, wy1};
+      }
+      const bool on = lit && pf != 0.f;
+      if (wballot(on) != 0ull) { // (wave-uniform)
+        const int fox = (int)wave_reduce_nn<false>(on ? (uint32_t)x0 : 0xffffffffu), foy = (int)wave_reduce_nn<false>(on ? (uint32_t)y0 : 0xffffffffu);
+        const bool in_win = on && x1 - fox <= 4 && y1 - foy <= 4;
+        const int cx0 = x0 - fox, cx1 = x1 - fox, cy0 = y0 - foy, cy1 = y1 - foy;
+        float cw[5], rw[5];
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              const int lx = xs[b] - ox, ly = ys[a] - oy;
-              const float v = pf * wys[a] * wxs[b];
-              if ((unsigned)lx < (unsigned)K9F_TILE && (unsigned)ly < (unsigned)K9F_TILE) atomicAdd(&s_tile[ly * K9F_TILE + lx], v);
-              else atomicAdd(gtex + (size_t)ys[a] * p.tw + xs[b], v);
-            }
+        for (int c = 0; c < 5; ++c) {
+          cw[c] = in_win ? ((cx0 == c ? wx0 : 0.f) + (cx1 == c ? wx1 : 0.f)) : 0.f; // (a clamped border tap may name the same texel twice: both weights count)
+          rw[c] = in_win ? pf * ((cy0 == c ? wy0 : 0.f) + (cy1 == c ? wy1 : 0.f)) : 0.f;
         }
-      } else {
-        const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3, o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
-        const float aa[3] = {a0, a1, a2};
+        float v[27];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float v = aa[ch] * alb[ch] * fac;
-          if (fb != 0.f) v += aa[ch] * fb;
-          if (v != 0.f) {
-            atomicAdd(gtex + o00 + ch, v * wy0 * wx0);
-            atomicAdd(gtex + o01 + ch, v * wy0 * wx1);
-            atomicAdd(gtex + o10 + ch, v * wy1 * wx0);
-            atomicAdd(gtex + o11 + ch, v * wy1 * wx1);
-          }
+        for (int n = 0; n < 25; ++n) v[n] = rw[n / 5] * cw[n % 5];
+        v[25] = v[26] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) asm(FFX_R3_ALL("v_add_f32_dpp") : "+v"(v[3 * k]), "+v"(v[3 * k + 1]), "+v"(v[3 * k + 2])); // (the wave's sums in lane 63)
+        float mine = 0.f;
+#pragma unroll
+        for (int n = 0; n < 25; ++n) {
+          const float sn = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v[n]), 63));
+          if (lane == n) mine = sn;
+        }
+        if (mine != 0.f) { // (lanes 0..24: one texel each)
+          const int ey = (lane * 13) >> 6, ex = lane - 5 * ey;
+          atomicAdd(gtex + (size_t)(foy + ey) * p.tw + (fox + ex), mine);
+        }
+        if (on && !in_win) { // a sample outside its pixel's window (depth discontinuities, grazing surfaces: ~0.1 %): its four taps directly
+          atomicAdd(gtex + (size_t)y0 * p.tw + x0, pf * wy0 * wx0);
+          atomicAdd(gtex + (size_t)y0 * p.tw + x1, pf * wy0 * wx1);
+          atomicAdd(gtex + (size_t)y1 * p.tw + x0, pf * wy1 * wx0);
+          atomicAdd(gtex + (size_t)y1 * p.tw + x1, pf * wy1 * wx1);
+        }
+      }
+    } else if (lit) { // 3-channel textures: twelve direct atomics per sample
+      const size_t o00 = ((size_t)y0 * p.tw + x0) * 3, o01 = ((size_t)y0 * p.tw + x1) * 3, o10 = ((size_t)y1 * p.tw + x0) * 3, o11 = ((size_t)y1 * p.tw + x1) * 3;
+      const float aa[3] = {a0, a1, a2};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float cv = aa[ch] * alb[ch] * fac;
+        if (fb != 0.f) cv += aa[ch] * fb;
+        if (cv != 0.f) {
+          atomicAdd(gtex + o00 + ch, cv * wy0 * wx0);
+          atomicAdd(gtex + o01 + ch, cv * wy0 * wx1);
+          atomicAdd(gtex + o10 + ch, cv * wy1 * wx0);
+          atomicAdd(gtex + o11 + ch, cv * wy1 * wx1);
         }
       }
     }
-  }
-  if (!tiled) return; // (uniform)
-  __syncthreads();
-  const int org = s_org;
-  if (org < 0) return; // (uniform: every lit sample's gradient was zero)
-  const int ox = org & 0xffff, oy = org >> 16;
-  for (int i = threadIdx.x; i < K9F_TILE * K9F_TILE; i += 256) {
-    const float v = s_tile[i];
-    if (v != 0.f) atomicAdd(gtex + (size_t)(oy + i / K9F_TILE) * p.tw + (ox + i % K9F_TILE), v);
+    cur = nxt;
   }
 }
 
@@ -4346,10 +4361,12 @@ int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_
   p.rf_alpha = -1.0f / (2.0f * sdv * sdv); // (as shade_prepare)
   p.rf_bias = expf(p.rf_alpha * (4.0f * sdv) * (4.0f * sdv));
   p.seed_key = seed_key_of(seed);
+  p.n_shapes = sd->n_shapes;
+  if (p.n_shapes < 1 || p.n_shapes > 255) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: 1 .. 255 shapes");
   const size_t n_pix = (size_t)p.W * p.H;
   p.off_wsum = rfc_off_wsum(n_pix); p.off_recs = rfc_off_recs(n_pix); p.off_facb = rfc_off_facb(n_pix, (size_t)spp);
-  const int blocks_x = ffx_cdiv(p.W, 16), blocks_y = ffx_cdiv(p.H, 16);
-  hipLaunchKernelGGL(k_render_bwd_cached_filtered, dim3(blocks_x * blocks_y), dim3(256), 0, (hipStream_t)s, p, (const char *)cache, blocks_x, gimg, gtex);
+  const int blocks_x = ffx_cdiv(p.W, K9F_BLOCK), blocks_y = ffx_cdiv(p.H, K9F_BLOCK);
+  hipLaunchKernelGGL(k_render_bwd_cached_filtered, dim3(blocks_x * blocks_y * K9F_SUB), dim3(64), 0, (hipStream_t)s, p, (const char *)cache, blocks_x, gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd_cached_filtered");
   return FFX_OK;
 }

@@ -713,7 +713,7 @@ class DeviceGeometry:
     def _timed(self, name):
         return _EventPair(self.timing, name)
 
-    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False, cache_zeroed=False, keep_dropped=False):
+    def render_fwd(self, sd, albedo, tex, spp, seed=0, fp16=False, cache=None, sparse_adjoint=False, cache_zeroed=False, keep_dropped=False, img_out=None):
         """K8.  With `cache` (a uint8 tensor of render_cache_bytes(...) bytes) the kernel also stores one
         footprint of every pixel in the projector texture for render_bwd_cached (opaque layout, ffx.h).
         sparse_adjoint (with a cache): FFX_RENDER_SPARSE_ADJOINT — gradients are only wanted at texels whose value is
@@ -723,7 +723,9 @@ class DeviceGeometry:
         A filtered film (sd.rfilter) with a cache: ffx_render_fwd_cache_filtered (per-sample records; render_bwd_cached needs the seed)."""
         H, W = sd.cam.height, sd.cam.width
         mats_arg = _check_materials(sd, albedo)
-        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device)
+        img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device) if img_out is None else img_out
+        if tuple(img.shape) != (H, W, 3) or img.dtype != (torch.float16 if fp16 else torch.float32) or not img.is_contiguous():
+            raise ValueError("img_out must be a contiguous [H, W, 3] tensor of the film's type")
         blob = self.blob  # (acquire first: the flag below speaks about the blob this call reads)
         flags = int(bool(fp16)) | self._apex_flag(apex_key(sd))
         if sd.rfilter:  # a reconstruction filter that spreads samples over neighbouring pixels: its own entry point and a scratch area

@@ -210,6 +210,13 @@ class PatternOptimizer:
         # A filtered film (sd.rfilter) takes the same route through ffx_render_fwd_adjoint_filtered; with a non-linear loss it re-traces)
         fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
                  and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
+        # (round 5) under a gaussian film the fused launch is NOT the fast route: it needs two launches in front of the render (the weights every pixel
+        # will receive, G = gimg / weight) and forms every lit sample's 25-term gradient inside K8 — 0.74 ms per sample against 0.57 for the filtered
+        # forward that stores its per-sample records + the adjoint from them (tools/rfgrad.py).  A linear loss takes that pair too; its value
+        # <gimg, img> still comes out of the gradient launch (the step's renders stacked in one buffer, as for the fused launch).
+        lin_rf = fused and bool(sd0.rfilter) and Fn.cache_supported(sd0, self.spp) and os.environ.get("FFX_FUSED_ADJOINT_FILTERED", "0") != "1"
+        if lin_rf:
+            fused = False
         n_slots = ops.render_dot_slots(cam.width, cam.height)  # (K9's partial sums of the loss; the fused path evaluates it in the gradient launch)
         use_cache = (not fused) and Fn.cache_supported(sd0, self.spp) and not getattr(self, "_cache_overflowed", False)
         nbytes = ops.render_cache_bytes_sd(sd0, self.spp) if use_cache else 0
@@ -268,6 +275,16 @@ class PatternOptimizer:
             # the pattern gradient flows through the splat that produced this texture: texels whose value is exactly zero
             # (no splat within reach, nothing for the blur to spread) have no influence on it — sparse adjoint
             mats = ms.materials_arg(sd)  # (None: the rows are part of sd — no upload, no device tensor)
+            if lin_rf and use_cache:  # linear loss, filtered film: records + their adjoint under the constant gradient; the image joins the step's stack
+                if getattr(self, "_lin_g", None) is None or tuple(self._lin_g.shape) != (cam.height, cam.width, 3):
+                    self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()
+                if getattr(self, "_img_stack", None) is None or tuple(self._img_stack.shape) != (len(seeds), cam.height, cam.width, 3):
+                    self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
+                geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache, sparse_adjoint=True, img_out=self._img_stack[k_sample])
+                geom.render_bwd_cached(sd, mats, self._cache, self.spp, self._lin_g, out=gtex, seed=seed)
+                k_sample += 1
+                self.step_paths["cache_k9"] += 1
+                continue
             # (the cache is reused by the step's samples one after the other: only the first render of the step may clear the header's count of
             # dropped samples — the in-kernel Adam guard and _watch_cache read it at the END of the step, FFX_RENDER_CACHE_KEEP_DROPPED)
             img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache if use_cache else None, sparse_adjoint=use_cache,
@@ -302,7 +319,7 @@ class PatternOptimizer:
         if getattr(self, "_adam_counter", None) is None:
             self._adam_counter = torch.zeros(1, dtype=torch.int32, device=rd.device)
         dot = None
-        if fused and seeds:
+        if (fused or (lin_rf and use_cache)) and seeds:
             if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
                 self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
             dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)

@@ -1793,11 +1793,23 @@ def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
     want = ms.geom.render_bwd(sd, ms.materials_arg(sd), 8, 3, w.contiguous())
     torch.testing.assert_close(t.grad.reshape(want.shape), want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
     ms._params["tex.data"] = tex
-    opt = PatternOptimizer(ms, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=2)
+    # the coverage loss is linear in the image: under the gaussian film the step takes the record-writing forward + the adjoint from the records
+    # (round 5: faster than the fused filtered launch, which FFX_FUSED_ADJOINT_FILTERED=1 still selects) — the same loss, the same update
     before = wl.laser._rays.detach().clone()
-    res = opt.step()
-    assert opt.step_paths["fused"] == 2 and opt.step_paths["retrace"] == 0 and opt.step_paths["cache_k9"] == 0  # (the coverage loss is linear in the image)
-    assert np.isfinite(float(res["loss"])) and not torch.equal(before, wl.laser._rays.detach())
+    lin = {}
+    for fused_env in ("0", "1"):
+        os.environ["FFX_FUSED_ADJOINT_FILTERED"] = fused_env
+        try:
+            wl.laser._rays = before.clone()
+            opt = PatternOptimizer(ms, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21, samples_per_step=2)
+            res = opt.step()
+        finally:
+            os.environ.pop("FFX_FUSED_ADJOINT_FILTERED", None)
+        assert opt.step_paths == ({"fused": 0, "cache_k9": 2, "retrace": 0} if fused_env == "0" else {"fused": 2, "cache_k9": 0, "retrace": 0})
+        assert np.isfinite(float(res["loss"])) and not torch.equal(before, wl.laser._rays.detach())
+        lin[fused_env] = (float(res["loss"]), wl.laser._rays.grad.detach().clone())
+    assert lin["0"][0] == pytest.approx(lin["1"][0], rel=1e-5)
+    assert float((lin["0"][1] - lin["1"][1]).abs().max()) <= 2e-3 * float(lin["1"][1].abs().max())
     # ... and a loss that is not linear in the image — the reference's own L1 (rasterization.py:579) — takes the filtered cache + its adjoint
     # (round 5; it re-traced before), with the same update as the re-tracing step
     from fireflies_amd.optim import image_l1_loss
