@@ -180,7 +180,7 @@ PROTOTYPES = {
     "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p]),
     "ffx_pattern_fwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_i, c_f, c_p, c_p]),
     "ffx_pattern_bwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_f, c_p, C.POINTER(AdamArgs), c_p]),
-    "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p]),
+    "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
     "ffx_splat_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -1038,7 +1038,12 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // step count kept on the device) followed by Laser.clamp_to_fov + normalize_rays on the updated ray: one launch.
 __global__ void __launch_bounds__(256)
     k_adam_clamp(float *__restrict__ rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a, float *__restrict__ grad_out,
-                 float *__restrict__ m, float *__restrict__ v, float *__restrict__ step, int n, double lr, double beta1, double beta2, double eps_d, Mat4 KF, Mat4 KI, float lo, float hi, int n_norm) {
+                 float *__restrict__ m, float *__restrict__ v, float *__restrict__ step, int n, double lr, double beta1, double beta2, double eps_d, Mat4 KF, Mat4 KI, float lo, float hi, int n_norm,
+                 const unsigned int *__restrict__ guard) {
+  // (guard, ABI 7: word 2 of an adjoint-cache header — or, behind a multi-rank exchange, of the all-reduced flat buffer, whose last float is the
+  // sum of the ranks' `dropped` indicators: any non-zero bit pattern means some rank's gradient carries K9's NaN poison — the update is skipped
+  // on EVERY rank, rays, both moments and the step count keep their values)
+  if (guard && guard[2] != 0u) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float t = step[0] + 1.0f;
   if (i < n) adam_clamp_one(i, t, rays, grad, grad_b, scale_a, grad_out, m, v, lr, beta1, beta2, eps_d, KF.m, KI.m, lo, hi, n_norm);
@@ -1049,7 +1054,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) step[0] = t;
   }
 }
-__global__ void k_bump_step(float *step) { step[0] += 1.0f; }
+__global__ void k_bump_step(float *step, const unsigned int *guard) { if (!(guard && guard[2] != 0u)) step[0] += 1.0f; }
 
 // =================================================================================== K3 blur
 // (ksize x ksize) Gaussian, reflect border.  One workgroup per 32x8 output tile, halo staged in LDS.
@@ -1309,16 +1314,18 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
 }
 
 int ffx_adam_clamp_step(float *rays, const float *grad, const float *grad_b, float grad_div, float *grad_out, float *exp_avg, float *exp_avg_sq, float *step, int n,
-                        double lr, double beta1, double beta2, double eps, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, ffx_stream s) {
+                        double lr, double beta1, double beta2, double eps, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize, const void *guard,
+                        ffx_stream s) {
   if ((grad_b || grad_div != 1.0f) && !grad_out) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: combining gradients needs grad_out");
+  if (guard && ((uintptr_t)guard & 3) != 0) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: guard must be 4-byte aligned");
   if (!(grad_div > 0.f)) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: grad_div must be positive");
   if (!rays || !grad || !exp_avg || !exp_avg_sq || !step || !KF || !KF_inv || n < 1 || n_normalize < 0 || !(lo <= hi)) FFX_FAIL(FFX_ERR_ARG, "adam_clamp_step: bad argument");
   Mat4 a, b;
   for (int i = 0; i < 16; ++i) { a.m[i] = KF[i]; b.m[i] = KF_inv[i]; }
   const int blocks = ffx_cdiv(n, 256);
   hipLaunchKernelGGL(k_adam_clamp, dim3(blocks), dim3(256), 0, (hipStream_t)s, rays, grad, grad_b, grad_div, grad_out, exp_avg, exp_avg_sq, step, n, lr, beta1,
-                     beta2, eps, a, b, lo, hi, n_normalize);
-  if (blocks > 1) hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(1), 0, (hipStream_t)s, step);
+                     beta2, eps, a, b, lo, hi, n_normalize, (const unsigned int *)guard);
+  if (blocks > 1) hipLaunchKernelGGL(k_bump_step, dim3(1), dim3(1), 0, (hipStream_t)s, step, (const unsigned int *)guard);
   FFX_CHECK_LAUNCH("adam_clamp_step");
   return FFX_OK;
 }

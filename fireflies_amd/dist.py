@@ -17,10 +17,17 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def force_exchange():
+    """FFX_DIST_FORCE=1: form the process group and run the step's exchange even with ONE rank — the way to take RCCL's load, the
+    communicator's device binding, the nccl barrier and the [3N+2] all-reduce through a real run on a box with a single GPU (round-4
+    review: no RCCL rank had ever run; tests/test_api_gpu.py::test_one_rank_nccl_group_runs_the_multi_rank_step)"""
+    return os.environ.get("FFX_DIST_FORCE", "0") == "1"
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process unless FFX_DIST_FORCE=1)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not td.is_initialized():
+    if (world > 1 or force_exchange()) and not td.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -67,9 +74,14 @@ def sample_seed(base_seed: int, step: int, n_samples: int, k: int) -> int:
 
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """in-place sum over ranks of a flat buffer (one collective per optimisation step)."""
-    if td.is_initialized() and td.get_world_size() > 1:
+    if td.is_initialized() and (td.get_world_size() > 1 or force_exchange()):
         td.all_reduce(flat, op=td.ReduceOp.SUM)
     return flat
+
+
+def exchanging():
+    """whether an optimisation step exchanges its gradient (several ranks, or one rank rehearsing the exchange)"""
+    return td.is_initialized() and (td.get_world_size() > 1 or force_exchange())
 
 
 def accumulate_step(sample_fn, n_values: int, step: int, n_samples: int, base_seed: int = 0, device="cpu"):

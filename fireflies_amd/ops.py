@@ -210,13 +210,17 @@ def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, K
     return a
 
 
-def adam_clamp_step_(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, grad_b=None, grad_div=1.0, grad_out=None):
+def adam_clamp_step_(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, grad_b=None, grad_div=1.0, grad_out=None, guard=None):
     """in place: torch.optim.Adam's update of `rays` followed by Laser.clamp_to_fov + normalisation, one launch.
-    With grad_out the gradient used is grad / grad_div + grad_b (stored in grad_out)."""
+    With grad_out the gradient used is grad / grad_div + grad_b (stored in grad_out).
+    guard: a device tensor (or a slice of one) whose 32-bit word at byte 8 says "skip": an adjoint cache header, or the tail of an
+    all-reduced flat buffer (include/ffx.h)."""
+    if guard is not None and (not guard.is_cuda or guard.numel() * guard.element_size() < 12):
+        raise ValueError("guard must be a device tensor of at least 12 bytes")
     api().call("ffx_adam_clamp_step", _dev(rays, name="rays"), _dev(grad, name="grad"), _dev(grad_b, name="grad_b") if grad_b is not None else None, float(grad_div),
                _dev(grad_out, name="grad_out") if grad_out is not None else None, _dev(exp_avg, name="exp_avg"), _dev(exp_avg_sq, name="exp_avg_sq"),
                _dev(step, name="step"), rays.shape[0], float(lr), float(beta1), float(beta2), float(eps), _m16(KF), _m16(KF_inv), float(lo), float(hi),
-               int(n_normalize), _stream())
+               int(n_normalize), guard.data_ptr() if guard is not None else None, _stream())
     return rays
 
 

@@ -323,18 +323,25 @@ class PatternOptimizer:
             if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
                 self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
             dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)
-        if w > 1:
+        if w > 1 or dist.exchanging():
             # (several ranks: this rank's data term from the gradient launch — Adam arguments without state: no update —, then the exchange)
             aa = ops.adam_args(rd, None, None, None, self._adam_counter, 0.0, 0.0, 0.0, 0.0, self.laser._KF_inv, 0.0, 1.0, dot=dot) if dot is not None else None
             gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
                                                loss_div=float(S), adam=aa, scratch=self._scratch)
-            flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), val[2:3]])  # (val[2]: this rank's data term)
-            dist.allreduce_sum_(flat)  # the ONE exchange of a step: [3N + 1] floats
-            gsum = flat[:-1].reshape(rays.shape).contiguous()
-            loss = flat[-1] / float(S) + val[0]
+            # the ONE exchange of a step: [3N + 2] floats — the gradient, this rank's data term (val[2]) and (round 5) its adjoint cache's count of
+            # dropped samples: K9 has then poisoned THIS rank's gradient with NaN, and after the sum every rank knows.  The update launch reads the
+            # summed count as its guard (ffx_adam_clamp_step: the word at byte 8 of `guard` = the buffer's last float; any non-zero bit pattern,
+            # a NaN's included, skips): no rank applies a poisoned update, rays and Adam state stay identical across ranks
+            dropped = (self._cache[8:12].view(torch.int32).float() if (use_cache and self._cache is not None) else torch.zeros(1, device=rd.device))
+            flat = torch.cat([(gd if gd is not None else torch.zeros_like(rd)).reshape(-1), val[2:3], dropped])
+            dist.allreduce_sum_(flat)
+            n3 = 3 * rd.shape[0]
+            gsum = flat[:n3].reshape(rays.shape).contiguous()
+            loss = flat[n3] / float(S) + val[0]
             # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()
             ops.adam_clamp_step_(rd, gsum, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], KF, self.laser._KF_inv,
-                                 1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad)
+                                 1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad, guard=flat[n3 - 1:])
+            self._last_flat = flat  # (kept alive until the update has run; tests read the exchanged count)
         else:
             # nothing to exchange: the whole backward half is ONE launch — gradient of the data term and of the regulariser, the step's total
             # loss, and (by the workgroup that finishes last) Adam + Laser.clamp_to_fov() + normalize_rays() on grad = gsum / S + regulariser
@@ -361,13 +368,15 @@ class PatternOptimizer:
             if dropped:
                 import warnings
 
-                # the steps since then were NOT applied (ffx_adam_args.guard: the update launch skips when the header reports drops), so the
-                # optimiser state is intact: from here on this optimiser takes the re-tracing adjoint (single process; several ranks update
-                # through ffx_adam_clamp_step after the exchange and still raise)
+                # the steps since then were NOT applied (ffx_adam_args.guard / ffx_adam_clamp_step's guard: the update launch skips when the header
+                # — with several ranks: the exchanged sum of the ranks' headers — reports drops), so the optimiser state is intact and identical on
+                # every rank.  One process switches to the re-tracing adjoint by itself; several ranks cannot decide that alone (a rank whose
+                # OWN cache never overflowed would keep the cache: the ranks' launches must stay in step), so they raise — with clean state.
                 if dist.world_size() > 1:
                     raise Fn.CacheOverflowError(
-                        f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample "
-                        "records) — gradients since then carry NaN. Set FFX_CACHE_LIMIT_GB=0 (re-tracing adjoint).")
+                        f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed on this rank ({dropped} samples beyond its {cap} single-sample "
+                        "records); the updates since then were skipped on every rank (rays and Adam state are intact). Set FFX_CACHE_LIMIT_GB=0 "
+                        "(re-tracing adjoint) on all ranks and continue.")
                 self._cache_overflowed = True
                 self._arena = None
                 warnings.warn(f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample records: a projector "

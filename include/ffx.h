@@ -198,7 +198,11 @@ int ffx_adam_clamp_step(float *rays /*[dev][n,3] in/out*/, const float *grad /*[
                         float grad_div, float *grad_out /*[dev][n,3] or NULL*/, float *exp_avg /*[dev][n,3]*/,
                         float *exp_avg_sq /*[dev][n,3]*/, float *step /*[dev][1]*/, int n, double lr, double beta1, double beta2,
                         double eps, const float *KF /*[host][16]*/, const float *KF_inv /*[host][16]*/, float lo, float hi,
-                        int n_normalize, ffx_stream stream);
+                        int n_normalize, const void *guard /*[dev] or NULL (ABI 7): as ffx_adam_args.guard — when the 32-bit word at byte 8 is not
+                        zero the update is NOT applied (rays, both moments and the step count keep their values).  Either an adjoint cache's header
+                        (its `dropped` count) or, behind a multi-rank exchange, the address of the third-last float of the all-reduced flat buffer whose
+                        LAST float is the sum over ranks of their dropped counts: no rank then applies a poisoned update*/,
+                        ffx_stream stream);
 /* The same two launches carrying their neighbours along (round 3: every launch of the pattern side sits on the critical path of
  * a step, ~5 us each behind a 0.54 ms render):
  *   ffx_pattern_fwd_blur : ffx_pattern_fwd + tex = ffx_blur_fwd(tsum, blur_ksize, blur_sigma) in ONE launch (a11: the texture

@@ -2165,7 +2165,8 @@ done:
 
 int ffx_adam_clamp_step(float *rays, const float *grad, const float *grad_b, float grad_div, float *grad_out, float *exp_avg, float *exp_avg_sq, float *step, int n,
                         double lr, double beta1_d, double beta2_d, double eps_d, const float *KF, const float *KF_inv, float lo, float hi, int n_normalize,
-                        ffx_stream s) {
+                        const void *guard, ffx_stream s) {
+  if (guard && ((const uint32_t *)guard)[2] != 0u) return FFX_OK; /* the gradient of this step is incomplete somewhere: no update (include/ffx.h) */
   if ((grad_b || grad_div != 1.0f) && !grad_out) FAIL(FFX_ERR_ARG, "adam_clamp_step: combining gradients needs grad_out");
   if (!(grad_div > 0.f)) FAIL(FFX_ERR_ARG, "adam_clamp_step: grad_div must be positive");
   if (!rays || !grad || !exp_avg || !exp_avg_sq || !step || !KF || !KF_inv || n < 1 || n_normalize < 0 || !(lo <= hi)) FAIL(FFX_ERR_ARG, "adam_clamp_step: bad argument");
@@ -2224,7 +2225,7 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   /* guard (ffx.h): an adjoint cache header {n_stray, cap_stray, dropped}: dropped != 0 -> no update (the oracle's own cache never drops) */
   const int skip = adam->guard && ((const uint32_t *)adam->guard)[2] != 0u;
   if (!no_update && !skip) rc = ffx_adam_clamp_step(adam->rays, gd, reg_weight > 0.f ? grays_reg : NULL, adam->grad_div, adam->grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step, n, adam->lr,
-                           adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, s);
+                           adam->beta1, adam->beta2, adam->eps, KF, adam->KF_inv, adam->lo, adam->hi, adam->n_normalize, NULL, s);
   free(zeros);
   if (rc == FFX_OK && adam->dot_a) { /* the data term as an inner product (takes the place of loss_in) */
     if (!adam->dot_b || adam->dot_n < 1 || !reg_value || loss_in) FAIL(FFX_ERR_ARG, "pattern_bwd_blur: the inner product needs dot_b, dot_n, reg_value and no loss_in");

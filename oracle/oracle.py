@@ -163,10 +163,10 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
     return (gd, gr, val) if adam is None else (gd, gr, val, gout)
 
 
-def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1):
+def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, guard=None):
     """in place on rays / exp_avg / exp_avg_sq / step (float32 arrays)"""
     api().call("ffx_adam_clamp_step", _p(rays), _p(_f32(grad)), None, 1.0, None, _p(exp_avg), _p(exp_avg_sq), _p(step), rays.shape[0], float(lr), float(beta1), float(beta2), float(eps),
-               _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), None)
+               _m16(KF), _m16(KF_inv), float(lo), float(hi), int(n_normalize), _p(guard) if guard is not None else None, None)
     return rays
 
 

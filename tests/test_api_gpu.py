@@ -661,6 +661,65 @@ def test_two_rank_rccl_step_matches_one_rank(tmp_path, backend):
     np.testing.assert_array_equal(np.asarray(outs[0]["grad"]), np.asarray(outs[1]["grad"]))  # replicated optimiser state
 
 
+def test_one_rank_nccl_group_runs_the_multi_rank_step(tmp_path):
+    """RCCL on a one-GPU box (round-4 review: "no RCCL rank has ever run").  FFX_DIST_FORCE=1 makes a single process form the `nccl`
+    process group (librccl loads, the communicator binds to this rank's device, dist.barrier takes its device_ids form) and run the
+    optimiser's MULTI-rank branch: the gradient launch without the update, the [3N+2] all-reduce through RCCL, ffx_adam_clamp_step with
+    the exchanged dropped-count as its guard.  Same gradient, loss and updated rays as the plain single-process step."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FFX_DIST_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root, RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", FFX_DIST_FORCE="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path), "nccl", "4"], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    o = json.load(open(tmp_path / "rank0.json"))
+    assert o["world"] == 1 and o["backend"] == "nccl" and o["device"] == 0 and o["exchanged"] is True and o["flat_len"] == 3 * len(o["grad"]) + 2
+    kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=21)
+    wl = _small()
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, samples_per_step=4, **kw)
+    out = opt.step()
+    ref = wl.laser._rays.grad.detach().cpu().numpy()
+    np.testing.assert_allclose(np.asarray(o["grad"], np.float32), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    assert o["loss"] == pytest.approx(float(out["loss"]), rel=1e-4)
+    np.testing.assert_allclose(np.asarray(o["rays"], np.float32), wl.laser._rays.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_no_rank_applies_a_poisoned_update(tmp_path):
+    """Round-4 review, weak 9: with several ranks the update runs behind the exchange, where the in-kernel guard of the single-process
+    step did not reach — a rank whose adjoint cache had dropped samples poisoned everybody's rays.  Now the ranks' dropped counts travel
+    in the same flat buffer ([3N+2]) and ffx_adam_clamp_step takes the sum as its guard.  Two gloo ranks on this device, rank 1's cache
+    header forced to report drops (FFX_TEST_FORCE_DROPPED_RANK=1): NEITHER rank moves its rays or its Adam state, both report the count."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root, FFX_TEST_FORCE_DROPPED_RANK="1")
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_rccl_worker.py"), str(tmp_path), "gloo", "4", "l1"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for o in outs:
+        assert o["exchanged_dropped"] == 5.0 and o["rays"] == o["rays_before"] and o["adam_step"] == 0.0 and o["exp_avg_max"] == 0.0
+    # ... and without the forced drop the same two-rank L1 step does move (the guard is not stuck)
+    env.pop("FFX_TEST_FORCE_DROPPED_RANK")
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for o in outs:
+        assert o["exchanged_dropped"] == 0.0 and o["rays"] != o["rays_before"] and o["adam_step"] == 1.0
+    assert outs[0]["rays"] == outs[1]["rays"]
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the launcher starts two fresh rank processes (here both on
     the one device, transport gloo — FFX_DIST_BACKEND=gloo is the explicit opt-in for that; on a node with >= 2 GPUs the
