@@ -202,6 +202,8 @@ PROTOTYPES = {
     "ffx_trace_rays": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p]),
     "ffx_render_fwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p]),
     "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
+    "ffx_render_bwd_det_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
+    "ffx_render_bwd_det": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p]),
     "ffx_render_cache_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),

@@ -3008,13 +3008,28 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   FFX_TFLUSH();
 }
 
+// Deterministic accumulation (ffx_render_bwd_det, include/ffx.h): float atomics make gtex depend on the order in which the samples' taps arrive
+// (reassociation: ~1e-7 relative, different from run to run).  INTEGER additions commute: mode 1 finds the largest |tap value| of the launch
+// (atomicMax on the float's bits — order-independent), the host derives a power-of-two scale from it, mode 2 adds llrint(value * scale) to a
+// 64-bit fixed-point accumulator per texel (global_atomic_add_x2) and k_det_finish converts back — bitwise the same gtex whatever the
+// dispatch order, the number of XCDs or the rank count, at a resolution of 2^-36 of the largest tap (float32 carries 2^-24).
+struct DetK { int mode; float scale; unsigned long long *fix; unsigned int *vmax; };
+__device__ __forceinline__ void det_emit(const DetK &det, float *__restrict__ gtex, size_t t, float v) {
+  if (det.mode == 0) { atomicAdd(gtex + t, v); return; }
+  if (det.mode == 1) { if (v != 0.f) atomicMax(det.vmax, __float_as_uint(fabsf(v))); return; }
+  if (v != 0.f) atomicAdd(det.fix + t, (unsigned long long)__double2ll_rn((double)v * (double)det.scale));
+}
+__global__ void __launch_bounds__(256) k_det_finish(const unsigned long long *__restrict__ fix, float inv_scale, long n, float *__restrict__ gtex) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) gtex[t] += (float)((double)(long long)fix[t] * (double)inv_scale); // (gtex is ACCUMULATED into, as by every adjoint)
+}
 // RF (ffx_render_bwd_filtered): `gimg` is then G = gimg / weight as float4 per pixel (k_rf_gather) and a sample's radiance receives
 // sum over its 5x5 window of  w_n G[pixel + n]  — the transpose of the filter — in place of gimg[pixel] / spp.
 template <int R, bool WIDE, int MATM, bool RF = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 3), MATM ? FFX_PK_MAT_WAVES : (R == 1 ? FFX_PK1_WAVES : 4))))
     k_render_bwd_pk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride,
                     WideScene ws, const float *__restrict__ albedo, int spp, uint32_t seed_key, int tiles_x, int n_tiles, int remap,
-                    const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
+                    const float *__restrict__ gimg, float *__restrict__ gtex, const float4 *__restrict__ nrec, const float4 *__restrict__ gn, DetK det) {
   constexpr int NSUB = 4 / R;
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
@@ -3094,10 +3109,10 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           if constexpr (MAT) {
             if (st[r].proj_fac_b != 0.f) ws += (g[r][0] * ct.p_color[0] + g[r][1] * ct.p_color[1] + g[r][2] * ct.p_color[2]) * st[r].proj_fac_b * inv_spp;
           }
-          atomicAdd(gtex + o00, ws * wy0 * wx0);
-          atomicAdd(gtex + o01, ws * wy0 * wx1);
-          atomicAdd(gtex + o10, ws * wy1 * wx0);
-          atomicAdd(gtex + o11, ws * wy1 * wx1);
+          det_emit(det, gtex, o00, ws * wy0 * wx0);
+          det_emit(det, gtex, o01, ws * wy0 * wx1);
+          det_emit(det, gtex, o10, ws * wy1 * wx0);
+          det_emit(det, gtex, o11, ws * wy1 * wx1);
         } else {
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
@@ -3105,10 +3120,10 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             if constexpr (MAT) {
               if (st[r].proj_fac_b != 0.f) ws += g[r][ch] * st[r].proj_fac_b * inv_spp;
             }
-            atomicAdd(gtex + o00 + ch, ws * wy0 * wx0);
-            atomicAdd(gtex + o01 + ch, ws * wy0 * wx1);
-            atomicAdd(gtex + o10 + ch, ws * wy1 * wx0);
-            atomicAdd(gtex + o11 + ch, ws * wy1 * wx1);
+            det_emit(det, gtex, o00 + ch, ws * wy0 * wx0);
+            det_emit(det, gtex, o01 + ch, ws * wy0 * wx1);
+            det_emit(det, gtex, o10 + ch, ws * wy1 * wx0);
+            det_emit(det, gtex, o11 + ch, ws * wy1 * wx1);
           }
         }
       }
@@ -4227,7 +4242,7 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
 }
 
 static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
-                           const float *gimg, float *gtex, ffx_stream s, void *rf_scratch) {
+                           const float *gimg, float *gtex, ffx_stream s, void *rf_scratch, void *det_ws = nullptr) {
   if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if ((sd->rfilter != FFX_RFILTER_BOX) != (rf_scratch != nullptr))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, rf_scratch ? "render_bwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN"
@@ -4258,10 +4273,10 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, nullptr, 0, flags & FFX_RENDER_APEX_READY)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
     bins_k(bvh, info, sd, c.bins);
-#define FFX_LAUNCH_BWD(WIDE_, MAT_)                                                                                                                      \
-  hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
-                     spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), gimg, gtex, nrec, gn)
+    DetK det;
+    memset(&det, 0, sizeof det);
     const int matm = !mat ? 0 : (c.n_base_tex > 0 ? 2 : 1);
+    const float *gsrc = gimg; // what the kernel gathers from: gimg, or (filtered film) G = gimg / weight as float4 per pixel
     if (rf_scratch) {
       // 1. the weight every pixel received (jitter only) -> G = gimg / weight behind the partial sums; 2. the re-trace gathers through the filter
       const int n_pix = c.cam.W * c.cam.H;
@@ -4272,20 +4287,57 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)part, c.cam.W, c.cam.H, 0,
                          (void *)nullptr, gimg, G);
       FFX_CHECK_LAUNCH("render_bwd_filtered/gather");
-#define FFX_LAUNCH_BWD_RF(MAT_)                                                                                                                          \
-  hipLaunchKernelGGL((k_render_bwd_pk<1, true, MAT_, true>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
-                     spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), (const float *)G, gtex, nrec, gn)
-      if (matm == 2) FFX_LAUNCH_BWD_RF(2); else if (matm == 1) FFX_LAUNCH_BWD_RF(1); else FFX_LAUNCH_BWD_RF(0);
-#undef FFX_LAUNCH_BWD_RF
-      FFX_CHECK_LAUNCH("render_bwd_filtered");
+      gsrc = (const float *)G;
+    }
+    const bool wide = use_wide(info) != 0;
+#define FFX_LAUNCH_BWD(WIDE_, MAT_, RF_)                                                                                                                  \
+  hipLaunchKernelGGL((k_render_bwd_pk<1, WIDE_, MAT_, RF_>), dim3(pgrid), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, shape_albedo, \
+                     spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), gsrc, gtex, nrec, gn, det)
+    auto launch = [&]() {
+      if (rf_scratch) { if (matm == 2) FFX_LAUNCH_BWD(true, 2, true); else if (matm == 1) FFX_LAUNCH_BWD(true, 1, true); else FFX_LAUNCH_BWD(true, 0, true); }
+      else if (wide) { if (matm == 2) FFX_LAUNCH_BWD(true, 2, false); else if (matm == 1) FFX_LAUNCH_BWD(true, 1, false); else FFX_LAUNCH_BWD(true, 0, false); }
+      else { if (matm == 2) FFX_LAUNCH_BWD(false, 2, false); else if (matm == 1) FFX_LAUNCH_BWD(false, 1, false); else FFX_LAUNCH_BWD(false, 0, false); }
+    };
+#undef FFX_LAUNCH_BWD
+    if (det_ws) {
+      // deterministic accumulation (DetK above): the largest tap of the launch -> a power-of-two scale -> 64-bit fixed-point sums -> gtex.  The
+      // scale needs the first pass's result on the host: ONE 4-byte read and a stream synchronisation per call (a debugging / cross-checking mode)
+      const long n_t = (long)c.tw * c.th * c.tc;
+      det.fix = (unsigned long long *)det_ws;
+      det.vmax = (unsigned int *)(det.fix + n_t);
+      if (hipMemsetAsync(det_ws, 0, (size_t)n_t * 8 + 8, (hipStream_t)s) != hipSuccess) FFX_FAIL(FFX_ERR_LAUNCH, "render_bwd_det: clearing the workspace failed");
+      det.mode = 1;
+      launch();
+      FFX_CHECK_LAUNCH("render_bwd_det/max");
+      unsigned int vbits = 0;
+      if (hipMemcpyAsync(&vbits, det.vmax, 4, hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess || hipStreamSynchronize((hipStream_t)s) != hipSuccess)
+        FFX_FAIL(FFX_ERR_LAUNCH, "render_bwd_det: reading the largest tap failed");
+      float vmax;
+      memcpy(&vmax, &vbits, 4);
+      if (!(vmax > 0.f)) return FFX_OK; // nothing lit: gtex unchanged
+      if (!(vmax < 3.0e38f)) { // a non-finite tap: the plain adjoint reports it (NaN / inf in gtex)
+        det.mode = 0;
+        launch();
+        FFX_CHECK_LAUNCH("render_bwd_det/non-finite");
+        return FFX_OK;
+      }
+      int e;
+      frexpf(vmax, &e); // vmax < 2^e
+      // |sum| <= (samples x 4 taps) x vmax < 2^(34 + e) for up to 2^32 samples; 2^(62 - 34 - e) keeps every sum below 2^62
+      const int sh = 62 - 34 - e;
+      det.scale = ldexpf(1.0f, sh > 126 ? 126 : (sh < -126 ? -126 : sh));
+      det.mode = 2;
+      launch();
+      FFX_CHECK_LAUNCH("render_bwd_det/sum");
+      hipLaunchKernelGGL(k_det_finish, dim3(ffx_cdiv(n_t, 256)), dim3(256), 0, (hipStream_t)s, det.fix, 1.0f / det.scale, n_t, gtex);
+      FFX_CHECK_LAUNCH("render_bwd_det/finish");
       return FFX_OK;
     }
-    if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BWD(true, 2); else if (matm == 1) FFX_LAUNCH_BWD(true, 1); else FFX_LAUNCH_BWD(true, 0); }
-    else { if (matm == 2) FFX_LAUNCH_BWD(false, 2); else if (matm == 1) FFX_LAUNCH_BWD(false, 1); else FFX_LAUNCH_BWD(false, 0); }
-#undef FFX_LAUNCH_BWD
-    FFX_CHECK_LAUNCH("render_bwd");
+    launch();
+    FFX_CHECK_LAUNCH(rf_scratch ? "render_bwd_filtered" : "render_bwd");
     return FFX_OK;
   }
+  if (det_ws) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_det: the per-lane kernels (FFX_TRAVERSAL=lane) have no deterministic mode");
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
@@ -4298,6 +4350,21 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
 int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
                    const float *gimg, float *gtex, ffx_stream s) {
   return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s, nullptr);
+}
+
+size_t ffx_render_bwd_det_bytes(const ffx_scene_desc *sd) {
+  if (!sd || sd->proj.tex_w < 1 || sd->proj.tex_h < 1 || (sd->proj.tex_channels != 1 && sd->proj.tex_channels != 3)) return 0;
+  return (size_t)sd->proj.tex_w * sd->proj.tex_h * sd->proj.tex_channels * 8 + 8 + (sd->rfilter != FFX_RFILTER_BOX ? ffx_render_filter_bytes(sd) : 0);
+}
+
+int ffx_render_bwd_det(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
+                       const float *gimg, float *gtex, void *workspace, ffx_stream s) {
+  if (!workspace || ((uintptr_t)workspace & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd_det: workspace is NULL or not 16-byte aligned");
+  if (!sd) FFX_FAIL(FFX_ERR_ARG, "render_bwd_det: bad argument");
+  // workspace: [the filtered film's scratch (16-byte multiple)] [one 64-bit sum per texel and channel] [the largest tap]
+  void *rf = sd->rfilter != FFX_RFILTER_BOX ? workspace : nullptr;
+  void *det = (char *)workspace + (rf ? ffx_render_filter_bytes(sd) : 0);
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s, rf, det);
 }
 
 // scratch of the filtered calls: [pixel][25][4] outgoing sums (400 B per pixel) + G = gimg / weight as float4 per pixel (the adjoint)

@@ -143,7 +143,7 @@ def cache_supported(sd, spp):
     """whether ffx_render_fwd_cache accepts this render (its records pack the texel in 12+12 bits and
     the shape id in 8), the cache fits the FFX_CACHE_LIMIT_GB budget and a pixel's samples can be expected to
     stay inside one 5x5-texel footprint"""
-    if not sd.proj.enabled:
+    if not sd.proj.enabled or ops.deterministic_mode():  # (FFX_DETERMINISTIC=1: every adjoint re-traces with fixed-point accumulation)
         return False
     if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255 or sd.n_base_tex > 0:  # (textured base colours: one colour per shape in the footprint)
         return False

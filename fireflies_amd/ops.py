@@ -404,6 +404,13 @@ def _camera_part(key):
     return None if key is None else (key[0], key[3], key[4], key[7])  # (camera struct, FFX_BINS, FFX_BIN_TILE, FFX_BIN_CAP)
 
 
+def deterministic_mode():
+    """FFX_DETERMINISTIC=1: every texture gradient comes from ffx_render_bwd_det (64-bit fixed-point accumulation: bitwise reproducible, whatever
+    the dispatch order or the number of ranks) instead of the float-atomic adjoints — functional.render's backward and PatternOptimizer.step
+    then re-trace.  A cross-checking / debugging mode: two re-traces and one host synchronisation per adjoint."""
+    return os.environ.get("FFX_DETERMINISTIC", "0") == "1"
+
+
 def _lane_kernels():
     return os.environ.get("FFX_TRAVERSAL") == "lane"  # (the per-lane A/B kernels neither read nor write apex records)
 
@@ -829,10 +836,25 @@ class DeviceGeometry:
                        int(img is not None and img.dtype == torch.float16), _dev(dot_out) if dot_out is not None else None, _stream(self._didx))
         return gtex
 
-    def render_bwd(self, sd, albedo, spp, seed, gimg):
+    def render_bwd(self, sd, albedo, spp, seed, gimg, deterministic=None):
+        """the re-tracing adjoint.  deterministic (default: FFX_DETERMINISTIC=1 in the environment): ffx_render_bwd_det — bitwise
+        reproducible accumulation (64-bit fixed point instead of float atomics; two re-traces and one host synchronisation)."""
         gtex = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), dtype=torch.float32, device=self.device)
         mats_arg = _check_materials(sd, albedo)
         blob = self.blob
+        if deterministic is None:
+            deterministic = deterministic_mode()
+        if deterministic:
+            if _lane_kernels():
+                raise ValueError("the per-lane kernels (FFX_TRAVERSAL=lane) have no deterministic adjoint")
+            flags = self._apex_flag(apex_key(sd))
+            wsb = api().lib.ffx_render_bwd_det_bytes(C.byref(sd))
+            work = torch.empty(wsb, dtype=torch.uint8, device=self.device)
+            with self._timed("render_bwd"):
+                self._call("ffx_render_bwd_det", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp), int(seed) & 0xFFFFFFFF, flags,
+                           _dev(gimg, name="gimg"), _dev(gtex), _dev(work, torch.uint8), _stream(self._didx))
+            self._release()
+            return gtex
         # (ABI 7: the re-tracing adjoints take FFX_RENDER_APEX_READY like the renders.  Before, they always re-ran the pre-pass — and rewrote the
         # tile bins under the eyes of renders of the same pose on the scene's other render stream)
         flags = self._apex_flag(apex_key(sd))

@@ -209,7 +209,7 @@ class PatternOptimizer:
         # take the same launch; their gradient launch only evaluates the data term, the exchange and the update follow — below.
         # A filtered film (sd.rfilter) takes the same route through ffx_render_fwd_adjoint_filtered; with a non-linear loss it re-traces)
         fused = (linear is not None and int(sd0.n_base_tex) == 0 and bool(sd0.proj.enabled) and 1 <= len(self._sample_seeds(self.step_index)) <= 64
-                 and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0")
+                 and os.environ.get("FFX_FUSED_ADJOINT", "1") != "0" and not ops.deterministic_mode())  # (FFX_DETERMINISTIC=1: ffx_render_bwd_det for every sample)
         # (round 5) under a gaussian film the fused launch is NOT the fast route: it needs two launches in front of the render (the weights every pixel
         # will receive, G = gimg / weight) and forms every lit sample's 25-term gradient inside K8 — 0.74 ms per sample against 0.57 for the filtered
         # forward that stores its per-sample records + the adjoint from them (tools/rfgrad.py).  A linear loss takes that pair too; its value

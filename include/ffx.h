@@ -584,6 +584,20 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
                    int spp, uint32_t seed, int flags, const float *gimg /*[dev][H,W,3] fp32*/,
                    float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, ffx_stream stream);
 
+/* The re-tracing adjoint with DETERMINISTIC accumulation (ABI 7; SURVEY 5 "race detection", 7.4 "deterministic mode").  Every other adjoint
+ * accumulates gtex with float atomics: the result depends on the order in which the samples' taps arrive (reassociation, ~1e-7 relative,
+ * different from run to run and with the number of ranks).  This one is bitwise reproducible: pass 1 re-traces and finds the largest
+ * |tap| (an integer atomicMax on the float's bits), the host derives a power-of-two scale from it (ONE 4-byte read + stream
+ * synchronisation), pass 2 re-traces and adds every tap as a 64-bit fixed-point integer — integer additions commute — and a last launch
+ * converts:  gtex[t] += (float)(sum[t] / scale).  Resolution 2^-36 of the largest tap (float32 carries 2^-24 of a value).  Two re-traces:
+ * a cross-check of the atomic paths at any size (tests/test_hip_parity.py) and a debugging aid, not the fast path.  Box and gaussian film.
+ * workspace: ffx_render_bwd_det_bytes(sd) bytes of device memory, 16-byte aligned, contents irrelevant. */
+size_t ffx_render_bwd_det_bytes(const ffx_scene_desc *sd /*[host]*/);
+int ffx_render_bwd_det(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                       const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed, int flags /* FFX_RENDER_APEX_READY or 0 */,
+                       const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, void *workspace /*[dev]*/,
+                       ffx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * K8 + K9 with an adjoint cache (store instead of re-trace).
  * ffx_render_fwd_cache = ffx_render_fwd that additionally writes what the adjoint needs into `cache`, an opaque

@@ -2084,6 +2084,18 @@ int ffx_render_bwd_filtered(const void *bvh, const ffx_bvh_info *info, const ffx
   return FFX_OK;
 }
 
+/* the deterministic adjoint (include/ffx.h): the oracle's adjoints accumulate in double, serially, in sample order — they ARE deterministic */
+size_t ffx_render_bwd_det_bytes(const ffx_scene_desc *sd) {
+  if (!sd || sd->proj.tex_w < 1 || sd->proj.tex_h < 1 || (sd->proj.tex_channels != 1 && sd->proj.tex_channels != 3)) return 0;
+  return (size_t)sd->proj.tex_w * sd->proj.tex_h * sd->proj.tex_channels * 8 + 8 + (sd->rfilter != FFX_RFILTER_BOX ? ffx_render_filter_bytes(sd) : 0);
+}
+int ffx_render_bwd_det(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
+                       const float *gimg, float *gtex, void *workspace, ffx_stream s) {
+  if (!workspace || !sd) FAIL(FFX_ERR_ARG, "render_bwd_det: bad argument");
+  if (sd->rfilter != FFX_RFILTER_BOX) return ffx_render_bwd_filtered(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, workspace, s);
+  return ffx_render_bwd(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s);
+}
+
 /* =========================================================================================
  * The pattern side of one optimisation step as ONE call each way (include/ffx.h): restated by composing the entry
  * points above — which each follow the reference line by line — so that the fused HIP kernels are checked against

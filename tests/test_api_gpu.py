@@ -720,6 +720,30 @@ def test_no_rank_applies_a_poisoned_update(tmp_path):
     assert outs[0]["rays"] == outs[1]["rays"]
 
 
+def test_deterministic_mode_makes_an_optimisation_run_bitwise_reproducible(monkeypatch):
+    """FFX_DETERMINISTIC=1: every texture gradient of PatternOptimizer.step comes from ffx_render_bwd_det, the rest of the
+    step has no atomics (fp64 partial sums in a fixed order) — two runs from the same state end in bitwise the same rays, loss and Adam
+    state; the default (float-atomic) run agrees to rounding."""
+    kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=31, samples_per_step=3)
+
+    def run():
+        wl = _small()
+        opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, **kw)
+        losses = [float(opt.step()["loss"]) for _ in range(3)]
+        return wl.laser._rays.detach().clone(), losses, dict(opt.step_paths), opt.opt.state[wl.laser._rays]["exp_avg_sq"].clone()
+
+    monkeypatch.setenv("FFX_DETERMINISTIC", "1")
+    r1, l1, p1, v1 = run()
+    r2, l2, p2, v2 = run()
+    assert p1 == {"fused": 0, "cache_k9": 0, "retrace": 9} == p2
+    assert torch.equal(r1, r2) and l1 == l2 and torch.equal(v1, v2)
+    monkeypatch.delenv("FFX_DETERMINISTIC")
+    r3, l3, p3, _ = run()
+    assert p3["fused"] == 9
+    torch.testing.assert_close(r3, r1, rtol=1e-4, atol=1e-5)
+    assert l3 == pytest.approx(l1, rel=1e-4)
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the launcher starts two fresh rank processes (here both on
     the one device, transport gloo — FFX_DIST_BACKEND=gloo is the explicit opt-in for that; on a node with >= 2 GPUs the

@@ -1830,6 +1830,59 @@ def test_gaussian_filter_through_the_python_api_and_autograd(oracle):
     assert gmax > 0 and float((runs["32"][1] - runs["0"][1]).abs().max()) <= 2e-3 * gmax
 
 
+def test_deterministic_adjoint_is_bitwise_reproducible_and_cross_checks_the_atomic_paths(oracle, monkeypatch):
+    """ffx_render_bwd_det (ABI 7; SURVEY 5 "race detection", 7.4 "deterministic mode"): the re-tracing adjoint with 64-bit fixed-point
+    accumulation instead of float atomics.  At the BASELINE size (512x512x64, material rows): two runs are bitwise equal — also under another
+    workgroup-to-XCD mapping and another tile enumeration, i.e. whatever order the taps arrive in — and the float-atomic adjoints (re-traced,
+    cached K9, forward + adjoint in one launch) agree with it within 1e-3 of the gradient's scale on all but 1e-3 of the texels; the same
+    for the gaussian film.  At a small size it meets the oracle's (serial, double precision) sums to float rounding."""
+    for k in ("FFX_XCD_REMAP", "FFX_TILE_BLOCK", "FFX_DETERMINISTIC"):
+        monkeypatch.delenv(k, raising=False)
+    from tests.test_bruteforce_cpu import material_rows
+
+    sc = scenes.vocalfold()
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    gd = ops.DeviceGeometry(pool, tris, shape, off)
+    gd.update(_rand_xforms(2, 6), off + np.array([0, 9 * stride[1]], np.int32))
+    mats = material_rows(2, 3, anisotropic=0.0)
+    tex = _tex(sc)
+    rng = np.random.default_rng(8)
+    gimg = dev(np.where(rng.random((512, 512, 3)) < 0.5, -1.0, 1.0).astype(np.float32) / (512 * 512 * 3))
+    for rf in ("box", "gaussian"):
+        sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16, rfilter=rf)
+        g_det = gd.render_bwd(sd, dev(mats), 64, 5, gimg, deterministic=True)
+        assert torch.equal(g_det, gd.render_bwd(sd, dev(mats), 64, 5, gimg, deterministic=True))
+        monkeypatch.setenv("FFX_XCD_REMAP", "1")  # one image band per XCD: a completely different arrival order
+        monkeypatch.setenv("FFX_TILE_BLOCK", "2")
+        assert torch.equal(g_det, gd.render_bwd(sd, dev(mats), 64, 5, gimg, deterministic=True)), rf
+        monkeypatch.delenv("FFX_XCD_REMAP")
+        monkeypatch.delenv("FFX_TILE_BLOCK")
+        gs = float(g_det.abs().max())
+        assert gs > 0 and bool(torch.isfinite(g_det).all())
+        g_atomic = gd.render_bwd(sd, dev(mats), 64, 5, gimg, deterministic=False)
+        cache = torch.zeros(ops.render_cache_bytes_sd(sd, 64), dtype=torch.uint8, device="cuda")
+        gd.render_fwd(sd, dev(mats), tex, 64, seed=5, cache=cache)
+        g_cached = gd.render_bwd_cached(sd, dev(mats), cache, 64, gimg, seed=5 if rf == "gaussian" else None)
+        del cache
+        _, g_fused = gd.render_fwd_adjoint(sd, dev(mats), tex, 64, 5, gimg)
+        for what, g in (("re-traced", g_atomic), ("cached", g_cached), ("fused", g_fused)):
+            err = (g - g_det).abs()
+            assert float((err > 1e-3 * gs).float().mean()) <= 1e-3 and float(err.max()) <= 0.05 * gs, (rf, what, float(err.max()) / gs)
+    # small: against the oracle, 1- and 3-channel textures, a Lambert table
+    sc2 = scenes.vocalfold(width=52, height=44, tex=80, frames=3, n_fold=20, tube=(20, 24))
+    go, gd2, alb2 = _pair(oracle, sc2, frame=2, xforms=_rand_xforms(2, 5))
+    g2 = rng.standard_normal((44, 52, 3)).astype(np.float32)
+    for ch in (1, 3):
+        sd2 = scene_desc.scene_desc(sc2, tex_channels=ch, shadows=True)
+        a = host(gd2.render_bwd(sd2, dev(alb2), 9, 3, dev(g2), deterministic=True))
+        b = go.render_bwd(sd2, alb2, 9, 3, g2)
+        sb = float(np.abs(b).max())
+        assert sb > 0 and (np.abs(a - b) > 1e-4 * sb).mean() <= 1e-3 and np.abs(a - b).max() <= 0.1 * sb
+    # nothing lit: gtex stays as it is
+    sd0 = scene_desc.scene_desc(sc2, tex_channels=1, shadows=True)
+    assert float(gd2.render_bwd(sd0, dev(alb2), 9, 3, torch.zeros(44, 52, 3, device="cuda"), deterministic=True).abs().max()) == 0.0
+
+
 def test_per_slot_normal_area_holds_what_the_header_says():
     """include/ffx.h ffx_bvh_info.off_gn: per leaf slot the unit geometric normal and, in the fourth word, the BITS (shape + 1) | smooth << 30
     (0: degenerate triangle) — the render kernels take a hit's shape and smooth flag from that word.  The records of the same blob give the
