@@ -2481,6 +2481,7 @@ __host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) 
 // the VALU's here: 0.545 ms.
 #define FFX_RF_ROW 68
 #define FFX_RF_FLOATS (14 * FFX_RF_ROW)
+static_assert(FFX_RF_ROW % 4 == 0, "rf_fold reads the rows as float4: the row pitch must keep them 16-byte aligned");
 __device__ __forceinline__ void rf_weights(float alpha, float bias, float j, float (&w)[5]) {
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
@@ -2530,7 +2531,7 @@ __device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix,
 
 // the weights alone (the adjoint's first launch): one wave per pixel, the jitter decides everything
 __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int n_pix, int spp, uint32_t seed_key, float *__restrict__ part) {
-  __shared__ float s_rf[FFX_RF_FLOATS];
+  __shared__ __attribute__((aligned(16))) float s_rf[FFX_RF_FLOATS]; // (rf_fold reads it in 16-byte units)
   const int pix = blockIdx.x, lane = threadIdx.x;
   if (pix >= n_pix) return;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2634,7 +2635,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // the epilogue scatters the footprint as it is.  1-channel textures only (the host refuses the other).
   const bool fold = RF ? ADJ : (ADJ || cache != nullptr);
   constexpr int WSTACK_N = WIDE ? FFX_WSTACK : 1, RF_N = (FFX_RF_FLOATS * 4 + 7) / 8;
-  __shared__ uint2 s_wstack[RF ? (WSTACK_N > RF_N ? WSTACK_N : RF_N) : WSTACK_N]; // (RF: the filter's rows alias the walk's stack)
+  __shared__ __attribute__((aligned(16))) uint2 s_wstack[RF ? (WSTACK_N > RF_N ? WSTACK_N : RF_N) : WSTACK_N]; // (RF: the filter's rows alias the walk's stack and are read in 16-byte units)
   __shared__ float s_foot[32]; // the pixel's 5x5 texture footprint (adjoint cache)
   __shared__ float s_foot_b[MAT ? 32 : 1]; // material rows: the footprint of the base_color-independent part
   static_assert(R == 1, "the adjoint cache is written one pixel at a time");

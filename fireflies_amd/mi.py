@@ -47,6 +47,14 @@ def variant() -> str:
 
 # ----------------------------------------------------------------------------- value wrappers
 class Float(float):
+    """a scalar — or, given an array (mi.Float(pos % w), depth.py:65-66), the float array of it"""
+
+    def __new__(cls, v=0.0):
+        if isinstance(v, (_ArrayBase, torch.Tensor, np.ndarray, list, tuple)):
+            t = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v)
+            return Float32(t.to(torch.float32))
+        return float.__new__(cls, v)
+
     def torch(self):
         return torch.tensor([float(self)])
 
@@ -73,6 +81,60 @@ class _ArrayBase:
 
     def __iter__(self):
         return iter(self.t)
+
+    # The reference's own call sites compute with Mitsuba's arrays (graphics/depth.py:61-69,84: `pos * scale`, `idx % w`, `idx // w`,
+    # `result[~si.is_valid()] = 0`): element-wise arithmetic and masked assignment on the wrapped tensor, the result in the operand's type
+    def _wrap(self, t):
+        cls = type(self)
+        if isinstance(getattr(cls, "t", None), property):  # (a lazily resolved image, _RenderedXf: its arithmetic yields a plain tensor wrapper)
+            cls = TensorXf
+        out = object.__new__(cls)
+        out.t = t
+        return out
+
+    @staticmethod
+    def _raw(o):
+        return o.t if isinstance(o, _ArrayBase) else o
+
+    def __setitem__(self, i, v):
+        self.t[self._raw(i)] = self._raw(v)
+
+    def __mul__(self, o):
+        return self._wrap(self.t * self._raw(o))
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return self._wrap(self.t + self._raw(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._wrap(self.t - self._raw(o))
+
+    def __rsub__(self, o):
+        return self._wrap(self._raw(o) - self.t)
+
+    def __truediv__(self, o):
+        return self._wrap(self.t / self._raw(o))
+
+    def __mod__(self, o):
+        return self._wrap(self.t % self._raw(o))
+
+    def __floordiv__(self, o):
+        return self._wrap(torch.div(self.t, self._raw(o), rounding_mode="floor"))
+
+    def __neg__(self):
+        return self._wrap(-self.t)
+
+    def __invert__(self):
+        return self._wrap(~self.t)
+
+    def __and__(self, o):
+        return self._wrap(self.t & self._raw(o))
+
+    def __or__(self, o):
+        return self._wrap(self.t | self._raw(o))
 
     @property
     def shape(self):

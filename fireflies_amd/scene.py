@@ -687,13 +687,16 @@ class Scene:
                 _seed_generators(int(seeds[-1]))
                 plan.gen.set_offset(4 * plan.n_draws)
                 config = sbase.mutation_count()
+                drawn_versions = plan.version_key  # (_native_plan has just checked it against the bound tensors)
                 if keep is not None:
                     torch.cuda.set_rng_state(keep[0], torch.device(self._device))
                     torch.set_rng_state(keep[1])
                     _random.setstate(keep[2])
 
                 def native_appliers():
-                    if sbase.mutation_count() != config:
+                    # (an in-place edit of a sampler's bound tensor — through a handle get_min() / get_max() gave out earlier — does not move the
+                    # configuration counter: the tensors' own version counters do, round-4 advisor)
+                    if sbase.mutation_count() != config or plan.versions() != drawn_versions:
                         raise StaleDrawError("the sampler configuration changed after these scene samples were drawn")
                     return [(lambda k=k: self._apply_native(plan, out[0], out[1], k, all_picks[k])) for k in range(len(seeds))]
 

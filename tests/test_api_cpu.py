@@ -595,3 +595,32 @@ def test_native_scene_randomiser_is_the_python_mirror_bit_for_bit(oracle):
                 np.testing.assert_array_equal(mats[1, s, e].reshape(4, 4), w)
                 np.testing.assert_array_equal(mats[2, s, e].reshape(4, 4), fma_mm(w, unc))  # Scene.update_meshes
     assert Mesh is not None
+
+
+def test_mitsuba_array_shims_carry_the_arithmetic_of_depth_py():
+    """Round-4 advisor: the reference's own call sites compute with Mitsuba's arrays before and after the entry points the shims serve —
+    fireflies/graphics/depth.py:61-69 (`pos //= spp`, `pos % w`, `pos // w`, `mi.Float(...)` of an array, `mi.Vector2f(x, y)`, `pos * scale`)
+    and :84 (`result[~si.is_valid()] = 0`).  The same statements on fireflies_amd.mi's wrappers, against numpy."""
+    import numpy as np
+    import torch
+
+    from fireflies_amd import mi
+
+    W, H, spp = 7, 5, 3
+    total = W * H * spp
+    pos = mi.UInt32(torch.arange(total, dtype=torch.int32))
+    pos //= spp
+    scale = mi.Vector2f(1.0 / W, 1.0 / H)
+    p2 = mi.Vector2f(mi.Float(pos % int(W)), mi.Float(pos // int(W)))
+    got = (p2 * scale).numpy()
+    idx = np.arange(total) // spp
+    want = np.stack([(idx % W) / W, (idx // W) / H], -1).astype(np.float32)
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    assert isinstance(p2 * scale, mi.Vector2f) and isinstance(mi.Float(pos % int(W)), mi.Float32) and isinstance(mi.Float(2.5), float)
+    # masked assignment with a negated validity mask
+    result = mi.Float32(torch.arange(6, dtype=torch.float32) + 1.0)
+    valid = torch.tensor([True, False, True, True, False, True])
+    result[~valid] = 0
+    assert result.numpy().tolist() == [1.0, 0.0, 3.0, 4.0, 0.0, 6.0]
+    m = mi.UInt32(torch.tensor([1, 0, 3], dtype=torch.int32))
+    assert ((m + 1) * 2 - 1).numpy().tolist() == [3, 1, 7] and (2 * m).numpy().tolist() == [2, 0, 6] and (-mi.Float32([1.0, -2.0])).numpy().tolist() == [-1.0, 2.0]

@@ -720,6 +720,31 @@ def test_no_rank_applies_a_poisoned_update(tmp_path):
     assert outs[0]["rays"] == outs[1]["rays"]
 
 
+def test_samples_drawn_ahead_are_refused_after_an_in_place_edit_of_a_sampler_bound():
+    """Round-4 advisor: scene samples drawn ahead (Scene.randomize_batch(seeds, lazy=True), what PatternOptimizer does for the next step) are
+    stale not only when a sampler is re-configured (the configuration counter moves) but also when one of its BOUND TENSORS is edited in
+    place through a handle get_max() gave out earlier (only the tensor's version counter moves): applying them raises StaleDrawError instead
+    of posing the scene under bounds that no longer hold; drawing again takes the new bounds."""
+    from fireflies_amd.scene import StaleDrawError
+
+    wl = _small()
+    sc = wl.ff_scene
+    plan = sc._native_plan()
+    if plan is None:
+        pytest.skip("the native randomiser does not serve this scene configuration")
+    seeds = [5, 6]
+    lazy = sc.randomize_batch(seeds, lazy=True)
+    assert len(lazy()) == 2  # untouched bounds: the samples drawn ahead are good
+    lazy = sc.randomize_batch(seeds, lazy=True)
+    handle = plan.samplers[0].get_max()
+    handle.add_(0.125)  # (no accessor of the sampler is called: only the tensor's version moves)
+    with pytest.raises(StaleDrawError):
+        lazy()
+    fresh = sc.randomize_batch(seeds)  # the new bounds compile into a new plan
+    assert len(fresh) == 2
+    fresh[0]()
+
+
 def test_deterministic_mode_makes_an_optimisation_run_bitwise_reproducible(monkeypatch):
     """FFX_DETERMINISTIC=1: every texture gradient of PatternOptimizer.step comes from ffx_render_bwd_det, the rest of the
     step has no atomics (fp64 partial sums in a fixed order) — two runs from the same state end in bitwise the same rays, loss and Adam
