@@ -114,7 +114,8 @@ __device__ void bin_scan_one(char *base, int nt, uint32_t cap) {
 }
 
 // apex records of the pre-pass (k_apex_records of ffx_trace.hip, same arithmetic): what to write for apex a
-struct BinApex { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; TriApex *out; uint32_t astride; uint32_t *cache_hdr; uint32_t cap_stray; };
+struct BinApex { float o[FFX_N_APEX][3]; int on[FFX_N_APEX]; TriApex *out; uint32_t astride; uint32_t *cache_hdr; uint32_t cap_stray;
+                 uint32_t *gnw; int clear_on; }; // gnw: the per-slot normals as words (word 4 k + 3: shape / smooth / clear bits); clear_on: k_bin_clear will run
 
 // One wave per workgroup whose registers fit the hole ONE retired render wave leaves: these launches run beside a render whose one-wave
 // workgroups refill every slot the moment it frees.  A four-wave workgroup of 96-VGPR waves waited for four slots and enough registers on ONE
@@ -153,6 +154,16 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
   }
   const bool grid_on = bb.g[a].on != 0 && bb.base[a] != nullptr;
+  if (!FILL && a >= 1 && ba.gnw && k < n_tris) {
+    // the emitter's "clear" bit of this triangle (ffx_common.h FFX_GN_CLEAR_BIT): set here for every triangle when the proof will run,
+    // taken back by k_bin_clear where it fails; cleared otherwise (a blob whose pre-pass ran before with other emitter positions).  A
+    // degenerate triangle's word stays 0 — that IS its flag.
+    uint32_t *w = ba.gnw + 4 * (size_t)k + 3;
+    if ((*w & FFX_GN_SHAPE_MASK) != 0u) {
+      if (grid_on && ba.clear_on && ba.on[a]) atomicOr(w, FFX_GN_CLEAR_BIT(a));
+      else atomicAnd(w, ~FFX_GN_CLEAR_BIT(a));
+    }
+  }
   char *base = bb.base[a];
   uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
   uint32_t *cursors = (uint32_t *)(base + ffx_bin_off_cursors());
@@ -335,12 +346,90 @@ __global__ void __launch_bounds__(64) k_bin_scan(BinBuild bb) {
   if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap);
 }
 
+// ---- "clear" triangles (ffx_common.h FFX_GN_CLEAR_BIT): the proof that nothing can shadow a triangle from an emitter.
+// Shadow segments run from the emitter E to Po = P + off n_k, P on triangle k, n_k its unit normal on the viewer's side — which is E's
+// side for every sample E lights — off = (1 + max|P|) 8.9e-5 >= 8.9e-5; hits at t >= 1 - 8.9e-4 do not count.  Triangle j cannot
+// intersect the counted part of ANY such segment if
+//   (H0) its projection from E is apart from k's (padded boxes in the grid: a segment is a POINT of E's image plane), or
+//   (H1) all of j lies behind k's plane or within 2e-5 above it: the counted part of the segment stays >= 8.9e-5 (1 - 8.9e-4) above, or
+//   (H2) j faces E, the two E-side normals agree (cos >= 0.5) and all of k lies in front of j's plane or within 2e-5 behind it: then
+//        Po (lifted by >= 8.9e-5 x 0.5) and E are both strictly in front of j's plane, and so is the whole segment.
+// The tolerances shrink by the rounding of the plane evaluations (3e-7 of the coordinates' magnitude: scenes beyond ~60 units lose them and
+// keep the strict tests).  Two triangles whose projections overlap share a tile of E's grid, so testing k against the entries of its
+// tiles is complete.  Unsafe projections (a vertex behind / beside the apex) have infinite boxes: H0 never holds for them, H1 / H2 are 3-D.
+// A wave per (tile, chunk of 64 entries k): lanes on k, the tile's entries j one after the other (uniform: scalar loads).
+#define CLEAR_SPLIT 4
+template <int WPE>
+__global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_bin_clear(const TriRec *__restrict__ recs, BinBuild bb, BinApex ba) {
+  FFX_SIDE_PRIO();
+  const int a = 1 + (int)blockIdx.y;
+  if (!bb.g[a].on || !bb.base[a] || !ba.on[a] || !ba.gnw) return;
+  const char *base = bb.base[a];
+  if (((const BinHdr *)base)->ok == 0u) return; // (lists incomplete: the render kernels do not look at the bits then, bins_ready)
+  const int tile = (int)blockIdx.x / CLEAR_SPLIT, part = (int)blockIdx.x % CLEAR_SPLIT;
+  if (tile >= bb.g[a].nx * bb.g[a].ny) return;
+  const uint32_t *starts = (const uint32_t *)(base + ffx_bin_off_starts());
+  const uint32_t beg = starts[tile], n = starts[tile + 1] - beg;
+  if (n < 2u) return; // alone in its tile
+  const char *ents = base + ffx_bin_off_entries() + ((size_t)beg << 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const v3 E = V3(ba.o[a][0], ba.o[a][1], ba.o[a][2]);
+  const uint32_t bit = FFX_GN_CLEAR_BIT(a);
+  for (uint32_t k0 = (uint32_t)part * 64u; k0 < n; k0 += 64u * CLEAR_SPLIT) {
+    const uint32_t ki = k0 + lane;
+    const bool valid = ki < n;
+    const float4 *ek = reinterpret_cast<const float4 *>(ents + ((size_t)(valid ? ki : n - 1u) << 6));
+    const float4 bbk = ek[0];
+    const int slot_k = __float_as_int(ek[3].y);
+    const float4 *rk = reinterpret_cast<const float4 *>(recs + slot_k);
+    const float4 ra = rk[0], rb = rk[1], rc = rk[2];
+    const v3 k0v = V3(ra.x, ra.y, ra.z), ke1 = V3(ra.w, rb.x, rb.y), ke2 = V3(rb.z, rb.w, rc.x);
+    const v3 k1v = V3(k0v.x + ke1.x, k0v.y + ke1.y, k0v.z + ke1.z), k2v = V3(k0v.x + ke2.x, k0v.y + ke2.y, k0v.z + ke2.z);
+    v3 nk = vcross(ke1, ke2);
+    const float sk = vdot(nk, vsub(E, k0v));
+    if (sk < 0.f) nk = V3(-nk.x, -nk.y, -nk.z); // towards the emitter
+    const float lenk = sqrtf(vdot(nk, nk));
+    const float Mk = fmaxf(fmaxf(fmaxf(fabsf(k0v.x), fabsf(k0v.y)), fabsf(k0v.z)), fmaxf(fmaxf(fabsf(ke1.x) + fabsf(ke2.x), fabsf(ke1.y) + fabsf(ke2.y)), fabsf(ke1.z) + fabsf(ke2.z)));
+    // (already refuted in another tile, edge-on to the emitter, or degenerate: nothing to prove)
+    bool open = valid && (ba.gnw[4 * (size_t)slot_k + 3] & bit) != 0u;
+    // (the emitter must stand clearly off k's plane — 1e-4: above the tolerances — or the segment's first part is no higher than j may be)
+    bool unclear = open && !(lenk > 0.f && fabsf(sk) > 1e-4f * lenk);
+    open = open && !unclear;
+    for (uint32_t j = 0; j < n && __ballot(open) != 0ull; ++j) { // (uniform)
+      const float4 *ej = reinterpret_cast<const float4 *>(ents + ((size_t)j << 6));
+      const float4 bbj = ej[0];
+      const int slot_j = __float_as_int(ej[3].y);
+      const bool other = open && slot_j != slot_k;
+      const bool apart = bbk.x > bbj.z || bbk.z < bbj.x || bbk.y > bbj.w || bbk.w < bbj.y; // (H0; an unsafe entry's infinite box is never apart)
+      if (__ballot(other && !apart) == 0ull) continue;
+      const float4 *rj = reinterpret_cast<const float4 *>(recs + slot_j);
+      const float4 qa = rj[0], qb = rj[1], qc = rj[2];
+      const v3 j0v = V3(qa.x, qa.y, qa.z), je1 = V3(qa.w, qb.x, qb.y), je2 = V3(qb.z, qb.w, qc.x);
+      const v3 j1v = V3(j0v.x + je1.x, j0v.y + je1.y, j0v.z + je1.z), j2v = V3(j0v.x + je2.x, j0v.y + je2.y, j0v.z + je2.z);
+      const float Mj = fmaxf(fmaxf(fmaxf(fabsf(j0v.x), fabsf(j0v.y)), fabsf(j0v.z)), fmaxf(fmaxf(fabsf(je1.x) + fabsf(je2.x), fabsf(je1.y) + fabsf(je2.y)), fabsf(je1.z) + fabsf(je2.z)));
+      const float tol = 2e-5f - 3e-7f * (Mk + Mj); // world units; <= 0 for large coordinates: the strict tests remain
+      // H1: j behind k's plane
+      const float tk = tol * lenk;
+      const bool h1 = vdot(nk, vsub(j0v, k0v)) <= tk && vdot(nk, vsub(j1v, k0v)) <= tk && vdot(nk, vsub(j2v, k0v)) <= tk;
+      // H2: j faces the emitter, normals agree, k in front of j's plane
+      v3 nj = vcross(je1, je2);
+      const float sj = vdot(nj, vsub(E, j0v));
+      if (sj < 0.f) nj = V3(-nj.x, -nj.y, -nj.z);
+      const float lenj = sqrtf(vdot(nj, nj)), tj = -tol * lenj;
+      const bool h2 = fabsf(sj) > 1e-5f * lenj && vdot(nk, nj) >= 0.5f * lenk * lenj && vdot(nj, vsub(k0v, j0v)) >= tj && vdot(nj, vsub(k1v, j0v)) >= tj && vdot(nj, vsub(k2v, j0v)) >= tj;
+      if (other && !apart && !h1 && !h2) { unclear = true; open = false; }
+    }
+    if (valid && unclear) atomicAnd(ba.gnw + 4 * (size_t)slot_k + 3, ~bit);
+  }
+}
+
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert) {
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert, uint32_t *gn_words, int clear_on) {
   BinApex ba;
   memset(&ba, 0, sizeof ba);
   for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
   ba.out = (TriApex *)apex_out; ba.astride = astride; ba.cache_hdr = cache_hdr; ba.cap_stray = cap_stray;
+  ba.gnw = gn_words; ba.clear_on = clear_on;
   const dim3 grid(ffx_cdiv(n_tris, BIN_BLOCK), FFX_N_APEX);
   if (beside_lambert) hipLaunchKernelGGL((k_bin<false, 8>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
   else hipLaunchKernelGGL((k_bin<false, 7>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
@@ -348,5 +437,12 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
     hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(64), 0, s, bb);
     if (beside_lambert) hipLaunchKernelGGL((k_bin<true, 8>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
     else hipLaunchKernelGGL((k_bin<true, 7>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
+    if (gn_words && clear_on && ((bb.g[1].on && apex_on[1]) || (bb.g[2].on && apex_on[2]))) { // the emitters' grids: which triangles nothing can shadow
+      int nt = 0;
+      for (int a = 1; a < FFX_N_APEX; ++a) if (bb.g[a].on && apex_on[a]) nt = nt > bb.g[a].nx * bb.g[a].ny ? nt : bb.g[a].nx * bb.g[a].ny;
+      const dim3 cgrid(nt * CLEAR_SPLIT, FFX_N_APEX - 1);
+      if (beside_lambert) hipLaunchKernelGGL((k_bin_clear<8>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);
+      else hipLaunchKernelGGL((k_bin_clear<7>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);
+    }
   }
 }

@@ -176,12 +176,22 @@ struct BinsK {
   const char *base[3]; // per apex: BinHdr, list starts, cursors, entries
   BinGrid g[3];
   float cam_inv_ts_x, cam_inv_ts_y; // camera pixels -> tile units
+  int clear_on;                     // the emitters' "nothing can shadow this triangle" bits of the per-slot normals are valid (FFX_GN_CLEAR_BIT)
 };
+// Round 5: "clear" triangles.  The spot's any-hit stage was a quarter of the render kernel (K8 0.400 -> 0.302 ms without it, tools/k8ab.py) for an
+// emitter next to the camera that hardly anything shadows.  The pre-pass (k_bin_clear, ffx_bins.hip) proves per triangle k and emitter E that
+// NO other triangle can intersect a shadow segment from E to a lifted point of k — every triangle j listed in a tile of E's grid with k is
+// (H0) apart from k in E's image plane, or (H1) wholly behind k's plane, or (H2) front-facing to E with k wholly in front of ITS plane (the
+// concave neighbours of a tube seen from inside) — and leaves bit 27 + a (a = 1 projector, 2 spot) of the fourth word of the triangle's
+// per-slot normal (ffx_bvh_info.off_gn) set.  A packet all of whose samples that need emitter a lie on such triangles skips the walk.
+#define FFX_GN_SHAPE_MASK 0x0fffffff
+#define FFX_GN_SMOOTH_BIT 0x40000000
+#define FFX_GN_CLEAR_BIT(a) (1u << (27 + (a)))
 // the pre-pass of a packet render on `s` (ffx_bins.hip): apex records + the bins of the enabled grids — three launches (count, scan,
 // fill); with every grid off it is the apex records alone (one launch)
 struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad[0] of apex 0 */ };
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0);
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0, uint32_t *gn_words = nullptr, int clear_on = 0);
 
 // top bit of the `cap_stray` argument of the launches that reset an adjoint cache's header (k_bin<false>, k_apex_records, k_cache_reset):
 // FFX_RENDER_CACHE_KEEP_DROPPED — empty the arena, keep the `dropped` count of the step's earlier scene samples

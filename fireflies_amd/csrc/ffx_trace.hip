@@ -2037,6 +2037,9 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
   FFX_TSTOP(tp, 22);
   const ShadeK &c = kernarg_shade(); // phase: light terms at the hit point
   ShadePre pre[R];
+  int cbits[R]; // the hit triangle's flag word (per-slot normal, word 3): the emitters' "clear" bits (ffx_common.h FFX_GN_CLEAR_BIT)
+#pragma unroll
+  for (int r = 0; r < R; ++r) cbits[r] = 0;
   bool any_p = false, any_s = false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -2065,10 +2068,11 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       // word: the record itself is only touched by samples that interpolate normals or look up a base-colour texture
       const float4 gq = gn[h[r].slot];
       const int gbits = __float_as_int(gq.w); // 0: degenerate triangle; else (shape + 1) | smooth << 30
-      st[r].shape = (gbits & 0x3fffffff) - 1;
+      st[r].shape = (gbits & FFX_GN_SHAPE_MASK) - 1;
+      cbits[r] = gbits;
       q.P = V3(fmaf(h[r].t, d[r].x, o[r].x), fmaf(h[r].t, d[r].y, o[r].y), fmaf(h[r].t, d[r].z, o[r].z));
       v3 ng = V3(gq.x, gq.y, gq.z);
-      q.ok = gbits != 0;
+      q.ok = (gbits & FFX_GN_SHAPE_MASK) != 0;
       if (!q.ok) st[r].shape = 0;
       if (q.ok) {
         if (vdot(ng, d[r]) > 0.f) ng = V3(-ng.x, -ng.y, -ng.z);
@@ -2077,7 +2081,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
         float off = (1.0f + pmax) * RAY_EPS;
         q.Po = V3(fmaf(off, ng.x, q.P.x), fmaf(off, ng.y, q.P.y), fmaf(off, ng.z, q.P.z));
         ns = ng;
-        smooth = (gbits & 0x40000000) != 0;
+        smooth = (gbits & FFX_GN_SMOOTH_BIT) != 0;
         if (wballot(smooth) != 0ull) { // (wave-uniform: scenes without flagged records never enter)
           const float4 ra = r4[0], rb = r4[1], rc = r4[2];
           const v3 ni = interpolated_normal<true>(nrec, smooth ? h[r].slot : 0, ra, rb, rc, o[r], d[r], ng);
@@ -2178,7 +2182,17 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 #pragma unroll
   for (int r = 0; r < R; ++r) occ_p[r] = occ_s[r] = false;
   FFX_TSTOP(tp, 18);
-  if (c.shadows && wballot(any_p) != 0ull) {
+  // (round 5) a packet all of whose samples that need an emitter lie on triangles NOTHING can shadow from it (k_bin_clear's proof, the bit in
+  // the per-slot normal's flag word; valid while that emitter's lists are: bins_ready) skips that emitter's any-hit stage altogether
+  bool walk_p = c.shadows && wballot(any_p) != 0ull, walk_s = c.shadows && wballot(any_s) != 0ull;
+  if constexpr (R == 1) {
+    const BinsK &bkc = kernarg_shade().bins;
+    if (bkc.clear_on) {
+      if (walk_p && wballot(pre[0].need_p && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(1))) == 0ull && bins_ready(bkc, 1)) { walk_p = false; FFX_STAT(38); }
+      if (walk_s && wballot(pre[0].need_s && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(2))) == 0ull && bins_ready(bkc, 2)) { walk_s = false; FFX_STAT(39); }
+    }
+  }
+  if (walk_p) {
     const v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
     v3 so[R], sdir[R];
     float s0[R], s1[R];
@@ -2213,7 +2227,11 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
 #endif
   }
   FFX_TSTOP(tp, 19);
-  if (c.shadows && wballot(any_s) != 0ull) {
+#ifdef FFX_EXP_NO_SPOT_SHADOW // timing experiment: what the spot's any-hit stage costs (every spot sample counts as unoccluded)
+  if (false) {
+#else
+  if (walk_s) {
+#endif
     const v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
     v3 so[R], sdir[R];
     float s0[R], s1[R];
@@ -3807,12 +3825,19 @@ static void bins_grids(const ffx_scene_desc *sd, BinGrid (&g)[FFX_N_APEX], float
     }
   }
 }
+// FFX_SHADOW_CLEAR=0: the render kernels walk every shadow packet (A/B and the tests' reference for the skip; the pre-pass then leaves the
+// bits cleared).  A pure function of (sd, info, environment), like the grids: ffx_apex_prepare and the renders behind it agree.
+static int clear_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
+  const char *e = getenv("FFX_SHADOW_CLEAR");
+  return sd && sd->shadows && info->off_gn != 0 && bins_enabled() && !(e && strcmp(e, "0") == 0);
+}
 // the kernels' view of the bins of `sd` in the blob (grids as bins_grids gives them; built by launch_apex / ffx_apex_prepare)
 static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, BinsK &bk) {
   memset(&bk, 0, sizeof bk);
   if (!info->off_bins || !info->bins_stride) return;
   bins_grids(sd, bk.g, bk.cam_inv_ts_x, bk.cam_inv_ts_y);
   for (int a = 0; a < FFX_N_APEX; ++a) bk.base[a] = (const char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
+  bk.clear_on = clear_enabled(sd, info);
 }
 
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
@@ -3866,7 +3891,8 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
       hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
     } else {
       // (the render kernels these launches will run beside: material rows -> seven waves of 72 VGPRs per SIMD, Lambert -> eight of 64)
-      ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s, sd && sd->mat_stride != FFX_MAT_STRIDE);
+      ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s, sd && sd->mat_stride != FFX_MAT_STRIDE,
+                      info->off_gn ? (uint32_t *)((char *)bvh + info->off_gn) : nullptr, clear_enabled(sd, info));
     }
   } else if (cache)
     hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);

@@ -382,17 +382,18 @@ def apex_key(sd=None, cam=None):
     field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
     if sd is not None:
         k = getattr(sd, "_apex_key", None)  # (a description is never modified once built: mi.Scene makes a new one per pose — 5 us per call otherwise)
-        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP")):
+        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR")):
             return k[0]
     c = sd.cam if sd is not None else cam
     # (the structs' bytes: ~1 us each — tuples of their 32 floats were 10 us per render call)
     key = [C.string_at(C.addressof(c), C.sizeof(c))]
     if sd is not None:
         key += [C.string_at(C.addressof(sd.proj), C.sizeof(sd.proj)) if sd.proj.enabled else None]
-        key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg) if sd.spot.enabled else None]  # (not its intensity: randomised per step, no part of the pre-pass)
+        # (not the spot's intensity: randomised per step, no part of the pre-pass; `shadows`: the pre-pass proves the "clear" triangles only for a scene that traces shadow rays)
+        key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg, int(sd.shadows)) if sd.spot.enabled else (None, int(sd.shadows))]
     else:
         key += [None, None]
-    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"))
+    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"))
     key = tuple(key) + env
     if sd is not None and getattr(sd, "_frozen", False):  # (only descriptions whose maker promises not to touch them again: mi.Scene.scene_desc)
         sd._apex_key = (key, env)

@@ -814,6 +814,61 @@ def test_tile_bins_that_overflow_or_cannot_be_built_fall_back_to_the_tree_walks(
     assert gw > 0 and (np.abs(g_w - g_wo) > 1e-3 * gw).mean() <= 1e-3
 
 
+def _clear_fraction(gd, a):
+    """share of the non-degenerate triangles whose flag word carries emitter a's "clear" bit (ffx_common.h FFX_GN_CLEAR_BIT: 1 projector, 2 spot)"""
+    torch.cuda.synchronize()
+    info, blob = gd.info, gd.blob
+    F = int(info.n_tris)
+    w = blob[int(info.off_gn): int(info.off_gn) + 16 * F].cpu().numpy().view(np.uint32).reshape(F, 4)[:, 3]
+    ok = (w & 0x0FFFFFFF) != 0
+    return float(((w[ok] >> (27 + a)) & 1).mean())
+
+
+@pytest.mark.parametrize("which", ["vocalfold", "vocalfold_rows", "hello", "colon"])
+def test_shadow_walks_skipped_for_clear_triangles_leave_the_image_as_it_is(oracle, which, monkeypatch):
+    """Round 5: the pre-pass proves, per triangle and emitter, that NOTHING can intersect a shadow segment ending on it (k_bin_clear: every
+    triangle sharing a tile of the emitter's grid with it is apart in the emitter's image plane, behind its plane, or a front-facing
+    neighbour whose plane it lies in front of) and a packet whose samples all lie on such triangles skips that emitter's any-hit stage —
+    a quarter of the render kernel for the spot.  The proof is exact, so the image must not change by a bit: with and without the skip
+    (FFX_SHADOW_CLEAR=0), on the smooth tube and folds (concave: H2), on a cube standing on a plane (convex edges, a concave crease, a
+    cast shadow), on the colon; the texture gradient agrees to the order of the atomics; and the oracle's image is met."""
+    for k in ("FFX_SHADOW_CLEAR", "FFX_BINS"):
+        monkeypatch.delenv(k, raising=False)
+    from tests.test_bruteforce_cpu import material_rows
+
+    if which == "hello":
+        sc, spp = scenes.hello_world(96, 80), 16
+    elif which == "colon":
+        sc, spp = scenes.colon(width=96, height=96, tex=128, n_around=48, n_along=160), 16
+    else:
+        sc, spp = scenes.vocalfold(width=96, height=80, tex=96, frames=3, n_fold=24, tube=(24, 32)), 16
+    S = len(sc.meshes)
+    xf = _rand_xforms(S, 12) if which != "hello" else None
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=xf)
+    rows = which == "vocalfold_rows"
+    mats = material_rows(S, 4) if rows else alb
+    has_proj = sc.projector is not None
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=16 if rows else 0)
+    tex = _tex(sc, 1) if has_proj else None
+    img_on = gd.render_fwd(sd, dev(mats), tex, spp, seed=9)
+    frac_spot = _clear_fraction(gd, 2)
+    assert 0.05 < frac_spot <= 1.0, frac_spot  # the proof succeeds somewhere ...
+    if which == "hello":
+        assert frac_spot < 1.0  # ... and fails where it must: the ground under the cube is shadowed
+    g_on = gd.render_bwd(sd, dev(mats), spp, 9, torch.ones_like(img_on) / img_on.numel()) if has_proj else None
+    monkeypatch.setenv("FFX_SHADOW_CLEAR", "0")
+    pose = gd._vert_off_host.copy()
+    gd.update(xf if xf is not None else np.tile(np.eye(4, dtype=np.float32), (S, 1, 1)), pose)
+    img_off = gd.render_fwd(sd, dev(mats), tex, spp, seed=9)
+    assert _clear_fraction(gd, 2) == 0.0 and _clear_fraction(gd, 1) == 0.0
+    assert torch.equal(img_on, img_off), f"{which}: {int((img_on != img_off).sum())} pixel channels differ, worst {float((img_on - img_off).abs().max()):.3g}"
+    if has_proj:
+        g_off = gd.render_bwd(sd, dev(mats), spp, 9, torch.ones_like(img_on) / img_on.numel())
+        assert float((g_on - g_off).abs().max()) <= 1e-4 * float(g_off.abs().max())
+    img_o = go.render_fwd(sd, mats, host(tex) if has_proj else np.zeros((1, 1), np.float32), spp, seed=9)
+    _assert_image_close(host(img_on), img_o, spp, frac=1e-3 if which == "hello" else 2e-4, what=which)
+
+
 @pytest.mark.parametrize("ch,k9_block", [(1, "16"), (1, "8"), (3, "16")])
 def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch, k9_block, monkeypatch):
     """store-instead-of-retrace: the forward also writes, per pixel, the footprint of its samples in the
