@@ -154,13 +154,13 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
   }
   const bool grid_on = bb.g[a].on != 0 && bb.base[a] != nullptr;
-  if (!FILL && a >= 1 && ba.gnw && k < n_tris) {
+  if (!FILL && a >= 1 && ba.gnw && ba.clear_on && k < n_tris) { // (clear_on == 0: the render kernels do not look at the bits)
     // the emitter's "clear" bit of this triangle (ffx_common.h FFX_GN_CLEAR_BIT): set here for every triangle when the proof will run,
     // taken back by k_bin_clear where it fails; cleared otherwise (a blob whose pre-pass ran before with other emitter positions).  A
     // degenerate triangle's word stays 0 — that IS its flag.
     uint32_t *w = ba.gnw + 4 * (size_t)k + 3;
     if ((*w & FFX_GN_SHAPE_MASK) != 0u) {
-      if (grid_on && ba.clear_on && ba.on[a]) atomicOr(w, FFX_GN_CLEAR_BIT(a));
+      if (grid_on && ((ba.clear_on >> (a - 1)) & 1) && ba.on[a]) atomicOr(w, FFX_GN_CLEAR_BIT(a));
       else atomicAnd(w, ~FFX_GN_CLEAR_BIT(a));
     }
   }
@@ -358,12 +358,35 @@ __global__ void __launch_bounds__(64) k_bin_scan(BinBuild bb) {
 // keep the strict tests).  Two triangles whose projections overlap share a tile of E's grid, so testing k against the entries of its
 // tiles is complete.  Unsafe projections (a vertex behind / beside the apex) have infinite boxes: H0 never holds for them, H1 / H2 are 3-D.
 // A wave per (tile, chunk of 64 entries k): lanes on k, the tile's entries j one after the other (uniform: scalar loads).
+// The entries j are walked 64 at a time: every lane loads ONE of them and derives its plane (normal towards the emitter, its length, the
+// facing test, the coordinate magnitude) — one memory round trip per 64 entries — and the inner loop broadcasts entry after entry with
+// v_readlane.  (First version: entry j and its record fetched inside the loop, two dependent loads per iteration: 357 us beside a render
+// for 9 M instructions' worth of work, the loop's period.)
 #define CLEAR_SPLIT 4
+struct ClearTri { v3 a, b, c, n; float len, s, M; float4 bb; int slot; };
+__device__ __forceinline__ ClearTri clear_load(const char *__restrict__ ents, const TriRec *__restrict__ recs, uint32_t i, v3 E) {
+  ClearTri t;
+  const float4 *e4 = reinterpret_cast<const float4 *>(ents + ((size_t)i << 6));
+  t.bb = e4[0];
+  t.slot = __float_as_int(e4[3].y);
+  const float4 *r4 = reinterpret_cast<const float4 *>(recs + t.slot);
+  const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+  const v3 e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);
+  t.a = V3(ra.x, ra.y, ra.z);
+  t.b = V3(t.a.x + e1.x, t.a.y + e1.y, t.a.z + e1.z);
+  t.c = V3(t.a.x + e2.x, t.a.y + e2.y, t.a.z + e2.z);
+  t.n = vcross(e1, e2);
+  t.s = vdot(t.n, vsub(E, t.a));
+  if (t.s < 0.f) { t.n = V3(-t.n.x, -t.n.y, -t.n.z); t.s = -t.s; } // towards the emitter
+  t.len = sqrtf(vdot(t.n, t.n));
+  t.M = fmaxf(fmaxf(fmaxf(fabsf(t.a.x), fabsf(t.a.y)), fabsf(t.a.z)), fmaxf(fmaxf(fabsf(e1.x) + fabsf(e2.x), fabsf(e1.y) + fabsf(e2.y)), fabsf(e1.z) + fabsf(e2.z)));
+  return t;
+}
 template <int WPE>
 __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_bin_clear(const TriRec *__restrict__ recs, BinBuild bb, BinApex ba) {
   FFX_SIDE_PRIO();
   const int a = 1 + (int)blockIdx.y;
-  if (!bb.g[a].on || !bb.base[a] || !ba.on[a] || !ba.gnw) return;
+  if (!bb.g[a].on || !bb.base[a] || !ba.on[a] || !ba.gnw || !((ba.clear_on >> (a - 1)) & 1)) return;
   const char *base = bb.base[a];
   if (((const BinHdr *)base)->ok == 0u) return; // (lists incomplete: the render kernels do not look at the bits then, bins_ready)
   const int tile = (int)blockIdx.x / CLEAR_SPLIT, part = (int)blockIdx.x % CLEAR_SPLIT;
@@ -375,51 +398,40 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
   const uint32_t lane = threadIdx.x & 63u;
   const v3 E = V3(ba.o[a][0], ba.o[a][1], ba.o[a][2]);
   const uint32_t bit = FFX_GN_CLEAR_BIT(a);
+  auto bc = [](float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); };
   for (uint32_t k0 = (uint32_t)part * 64u; k0 < n; k0 += 64u * CLEAR_SPLIT) {
     const uint32_t ki = k0 + lane;
     const bool valid = ki < n;
-    const float4 *ek = reinterpret_cast<const float4 *>(ents + ((size_t)(valid ? ki : n - 1u) << 6));
-    const float4 bbk = ek[0];
-    const int slot_k = __float_as_int(ek[3].y);
-    const float4 *rk = reinterpret_cast<const float4 *>(recs + slot_k);
-    const float4 ra = rk[0], rb = rk[1], rc = rk[2];
-    const v3 k0v = V3(ra.x, ra.y, ra.z), ke1 = V3(ra.w, rb.x, rb.y), ke2 = V3(rb.z, rb.w, rc.x);
-    const v3 k1v = V3(k0v.x + ke1.x, k0v.y + ke1.y, k0v.z + ke1.z), k2v = V3(k0v.x + ke2.x, k0v.y + ke2.y, k0v.z + ke2.z);
-    v3 nk = vcross(ke1, ke2);
-    const float sk = vdot(nk, vsub(E, k0v));
-    if (sk < 0.f) nk = V3(-nk.x, -nk.y, -nk.z); // towards the emitter
-    const float lenk = sqrtf(vdot(nk, nk));
-    const float Mk = fmaxf(fmaxf(fmaxf(fabsf(k0v.x), fabsf(k0v.y)), fabsf(k0v.z)), fmaxf(fmaxf(fabsf(ke1.x) + fabsf(ke2.x), fabsf(ke1.y) + fabsf(ke2.y)), fabsf(ke1.z) + fabsf(ke2.z)));
-    // (already refuted in another tile, edge-on to the emitter, or degenerate: nothing to prove)
-    bool open = valid && (ba.gnw[4 * (size_t)slot_k + 3] & bit) != 0u;
-    // (the emitter must stand clearly off k's plane — 1e-4: above the tolerances — or the segment's first part is no higher than j may be)
-    bool unclear = open && !(lenk > 0.f && fabsf(sk) > 1e-4f * lenk);
+    const ClearTri K = clear_load(ents, recs, valid ? ki : n - 1u, E);
+    // (already refuted in another tile: nothing to prove.  The emitter must stand clearly off k's plane — 1e-4: above the tolerances — or the
+    // first part of a segment is no higher above it than j may be)
+    bool open = valid && (ba.gnw[4 * (size_t)K.slot + 3] & bit) != 0u;
+    bool unclear = open && !(K.len > 0.f && K.s > 1e-4f * K.len);
     open = open && !unclear;
-    for (uint32_t j = 0; j < n && __ballot(open) != 0ull; ++j) { // (uniform)
-      const float4 *ej = reinterpret_cast<const float4 *>(ents + ((size_t)j << 6));
-      const float4 bbj = ej[0];
-      const int slot_j = __float_as_int(ej[3].y);
-      const bool other = open && slot_j != slot_k;
-      const bool apart = bbk.x > bbj.z || bbk.z < bbj.x || bbk.y > bbj.w || bbk.w < bbj.y; // (H0; an unsafe entry's infinite box is never apart)
-      if (__ballot(other && !apart) == 0ull) continue;
-      const float4 *rj = reinterpret_cast<const float4 *>(recs + slot_j);
-      const float4 qa = rj[0], qb = rj[1], qc = rj[2];
-      const v3 j0v = V3(qa.x, qa.y, qa.z), je1 = V3(qa.w, qb.x, qb.y), je2 = V3(qb.z, qb.w, qc.x);
-      const v3 j1v = V3(j0v.x + je1.x, j0v.y + je1.y, j0v.z + je1.z), j2v = V3(j0v.x + je2.x, j0v.y + je2.y, j0v.z + je2.z);
-      const float Mj = fmaxf(fmaxf(fmaxf(fabsf(j0v.x), fabsf(j0v.y)), fabsf(j0v.z)), fmaxf(fmaxf(fabsf(je1.x) + fabsf(je2.x), fabsf(je1.y) + fabsf(je2.y)), fabsf(je1.z) + fabsf(je2.z)));
-      const float tol = 2e-5f - 3e-7f * (Mk + Mj); // world units; <= 0 for large coordinates: the strict tests remain
-      // H1: j behind k's plane
-      const float tk = tol * lenk;
-      const bool h1 = vdot(nk, vsub(j0v, k0v)) <= tk && vdot(nk, vsub(j1v, k0v)) <= tk && vdot(nk, vsub(j2v, k0v)) <= tk;
-      // H2: j faces the emitter, normals agree, k in front of j's plane
-      v3 nj = vcross(je1, je2);
-      const float sj = vdot(nj, vsub(E, j0v));
-      if (sj < 0.f) nj = V3(-nj.x, -nj.y, -nj.z);
-      const float lenj = sqrtf(vdot(nj, nj)), tj = -tol * lenj;
-      const bool h2 = fabsf(sj) > 1e-5f * lenj && vdot(nk, nj) >= 0.5f * lenk * lenj && vdot(nj, vsub(k0v, j0v)) >= tj && vdot(nj, vsub(k1v, j0v)) >= tj && vdot(nj, vsub(k2v, j0v)) >= tj;
-      if (other && !apart && !h1 && !h2) { unclear = true; open = false; }
+    for (uint32_t j0 = 0; j0 < n && __ballot(open) != 0ull; j0 += 64u) { // (uniform)
+      const uint32_t m = min(64u, n - j0);
+      const ClearTri J = clear_load(ents, recs, j0 + lane < n ? j0 + lane : n - 1u, E); // this lane's entry of the chunk
+      for (uint32_t t = 0; t < m && __ballot(open) != 0ull; ++t) { // (uniform) entry j0 + t, broadcast
+        const int slot_j = __builtin_amdgcn_readlane(J.slot, (int)t);
+        const float bx0 = bc(J.bb.x, t), by0 = bc(J.bb.y, t), bx1 = bc(J.bb.z, t), by1 = bc(J.bb.w, t);
+        const bool other = open && slot_j != K.slot;
+        const bool apart = K.bb.x > bx1 || K.bb.z < bx0 || K.bb.y > by1 || K.bb.w < by0; // (H0; an unsafe entry's infinite box is never apart)
+        if (__ballot(other && !apart) == 0ull) continue;
+        const v3 ja = V3(bc(J.a.x, t), bc(J.a.y, t), bc(J.a.z, t)), jb = V3(bc(J.b.x, t), bc(J.b.y, t), bc(J.b.z, t)), jc = V3(bc(J.c.x, t), bc(J.c.y, t), bc(J.c.z, t));
+        const v3 nj = V3(bc(J.n.x, t), bc(J.n.y, t), bc(J.n.z, t));
+        const float lenj = bc(J.len, t), sj = bc(J.s, t), Mj = bc(J.M, t);
+        const float tol = 2e-5f - 3e-7f * (K.M + Mj); // world units; <= 0 for large coordinates: the strict tests remain
+        // H1: j behind k's plane
+        // (differences first: a neighbour's vertex minus k's is exact in float, Sterbenz — the products then carry no cancellation)
+        const float tk = tol * K.len;
+        const bool h1 = vdot(K.n, vsub(ja, K.a)) <= tk && vdot(K.n, vsub(jb, K.a)) <= tk && vdot(K.n, vsub(jc, K.a)) <= tk;
+        // H2: j faces the emitter, the emitter-side normals agree, k in front of j's plane
+        const float tj = -tol * lenj;
+        const bool h2 = sj > 1e-5f * lenj && vdot(K.n, nj) >= 0.5f * K.len * lenj && vdot(nj, vsub(K.a, ja)) >= tj && vdot(nj, vsub(K.b, ja)) >= tj && vdot(nj, vsub(K.c, ja)) >= tj;
+        if (other && !apart && !h1 && !h2) { unclear = true; open = false; }
+      }
     }
-    if (valid && unclear) atomicAnd(ba.gnw + 4 * (size_t)slot_k + 3, ~bit);
+    if (valid && unclear) atomicAnd(ba.gnw + 4 * (size_t)K.slot + 3, ~bit);
   }
 }
 
@@ -437,9 +449,9 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
     hipLaunchKernelGGL(k_bin_scan, dim3(FFX_N_APEX), dim3(64), 0, s, bb);
     if (beside_lambert) hipLaunchKernelGGL((k_bin<true, 8>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
     else hipLaunchKernelGGL((k_bin<true, 7>), grid, dim3(BIN_BLOCK), 0, s, recs, n_tris, bb, ba);
-    if (gn_words && clear_on && ((bb.g[1].on && apex_on[1]) || (bb.g[2].on && apex_on[2]))) { // the emitters' grids: which triangles nothing can shadow
+    if (gn_words && clear_on && (((clear_on & 1) && bb.g[1].on && apex_on[1]) || ((clear_on & 2) && bb.g[2].on && apex_on[2]))) { // the emitters' grids: which triangles nothing can shadow
       int nt = 0;
-      for (int a = 1; a < FFX_N_APEX; ++a) if (bb.g[a].on && apex_on[a]) nt = nt > bb.g[a].nx * bb.g[a].ny ? nt : bb.g[a].nx * bb.g[a].ny;
+      for (int a = 1; a < FFX_N_APEX; ++a) if (((clear_on >> (a - 1)) & 1) && bb.g[a].on && apex_on[a]) nt = nt > bb.g[a].nx * bb.g[a].ny ? nt : bb.g[a].nx * bb.g[a].ny;
       const dim3 cgrid(nt * CLEAR_SPLIT, FFX_N_APEX - 1);
       if (beside_lambert) hipLaunchKernelGGL((k_bin_clear<8>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);
       else hipLaunchKernelGGL((k_bin_clear<7>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);

@@ -2188,8 +2188,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
   if constexpr (R == 1) {
     const BinsK &bkc = kernarg_shade().bins;
     if (bkc.clear_on) {
-      if (walk_p && wballot(pre[0].need_p && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(1))) == 0ull && bins_ready(bkc, 1)) { walk_p = false; FFX_STAT(38); }
-      if (walk_s && wballot(pre[0].need_s && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(2))) == 0ull && bins_ready(bkc, 2)) { walk_s = false; FFX_STAT(39); }
+      if ((bkc.clear_on & 1) && walk_p && wballot(pre[0].need_p && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(1))) == 0ull && bins_ready(bkc, 1)) { walk_p = false; FFX_STAT(38); }
+      if ((bkc.clear_on & 2) && walk_s && wballot(pre[0].need_s && !((uint32_t)cbits[0] & FFX_GN_CLEAR_BIT(2))) == 0ull && bins_ready(bkc, 2)) { walk_s = false; FFX_STAT(39); }
     }
   }
   if (walk_p) {
@@ -3827,9 +3827,18 @@ static void bins_grids(const ffx_scene_desc *sd, BinGrid (&g)[FFX_N_APEX], float
 }
 // FFX_SHADOW_CLEAR=0: the render kernels walk every shadow packet (A/B and the tests' reference for the skip; the pre-pass then leaves the
 // bits cleared).  A pure function of (sd, info, environment), like the grids: ffx_apex_prepare and the renders behind it agree.
+// -> a mask over the emitters: bit 0 projector, bit 1 spot.  DEFAULT 0 (off) — a measured negative result, kept as an opt-in because it is
+// exact and tested: without the spot's any-hit stage K8 runs 0.400 -> 0.302 ms (-DFFX_EXP_NO_SPOT_SHADOW), but the proof only succeeds for
+// 22 - 36 % of the vocal fold's triangles (a smooth surface is half saddle: there a triangle's vertex neighbours straddle its plane and it
+// theirs — neither H1 nor H2 — and the margin between the lift of a shadow ray's end point, 8.9e-5 (1 + |P|), and the ignored tail of the
+// ray, 8.9e-4 |d|, is too small to settle them by distance), so ~20 % of the pixels skip the stage: K8 0.400 -> 0.381 ms (tools/k8ab.py),
+// while the pairwise proof adds ~10 M instructions to the pre-pass on the side stream, 280 us elapsed beside a render (rocprofv3): the loop
+// fell from 2 400 to 1 810 renders/s (spot only; 1 580 with the projector's 68-entry tiles too).  FFX_SHADOW_CLEAR=2 / 3 switches it on.
 static int clear_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
   const char *e = getenv("FFX_SHADOW_CLEAR");
-  return sd && sd->shadows && info->off_gn != 0 && bins_enabled() && !(e && strcmp(e, "0") == 0);
+  if (!(sd && sd->shadows && info->off_gn != 0 && bins_enabled())) return 0;
+  const int m = e ? atoi(e) : 0;
+  return (m < 0 || m > 3) ? 0 : m;
 }
 // the kernels' view of the bins of `sd` in the blob (grids as bins_grids gives them; built by launch_apex / ffx_apex_prepare)
 static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, BinsK &bk) {

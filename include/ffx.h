@@ -33,6 +33,10 @@
  *       FFX_K7_PPW_LOG2=0..6     cap on log2(pixels per wavefront) of ffx_trace_primary (default 4 at 1 spp, else 3)
  *       FFX_BINS=0               the packet render kernels walk the tree for every packet (default: tile bins first, ffx_bvh_info.off_bins)
  *       FFX_BIN_TILE=4..32       side of a camera tile of the bins in pixels (default 8)
+ *       FFX_SHADOW_CLEAR=1|2|3   (off by default) the pre-pass also proves per triangle that nothing can shadow it from the projector (1) / the
+ *                                spot (2) and marks it in its per-slot normal's flag word (ffx_bvh_info.off_gn); a pixel whose samples all
+ *                                lie on such triangles skips that emitter's shadow stage — exact, tested, but the proof costs the loop more
+ *                                than the skip gains on the default workload (fireflies_amd/csrc/ffx_trace.hip clear_enabled)
  *       FFX_BIN_CAP=n            capacity of each grid's entry list, at most the default 2 F + 16384 (a test knob: a grid whose lists do
  *                                not fit is marked not-ok by the pre-pass and its packets take the tree walks — the overflow path)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
@@ -378,7 +382,8 @@ typedef struct ffx_bvh_info {
   uint64_t off_gn;    /* (n_tris + 4) x 16 B: per leaf slot the unit geometric normal {nx, ny, nz, bits}, written by ffx_scene_update with
                          IEEE cross / sqrt / divide in the oracle's order; the packet render kernels read it instead of re-deriving it
                          per sample.  The fourth word is NOT a float: raw bits 0 for a degenerate triangle (the normal is then
-                         {0,0,0}), else (shape + 1) | smooth << 30 (smooth: the record is flagged by ffx_smooth) — the kernels take
+                         {0,0,0}), else (shape + 1) | smooth << 30 (smooth: the record is flagged by ffx_smooth; bits 28 / 29: scratch of the
+                         render calls' pre-pass under FFX_SHADOW_CLEAR — "nothing can shadow this triangle from the projector / spot") — the kernels take
                          the hit's shape id and smooth flag from it, so a blob written to any other encoding renders with a wrong
                          material row.  0 in the oracle's blob (it has no such area). */
   /* tile bins (ABI 5, DESIGN.md 5.1 "round 4"): for each of the three ray origins of a render (camera, projector, spot) a

@@ -826,7 +826,8 @@ def _clear_fraction(gd, a):
 
 @pytest.mark.parametrize("which", ["vocalfold", "vocalfold_rows", "hello", "colon"])
 def test_shadow_walks_skipped_for_clear_triangles_leave_the_image_as_it_is(oracle, which, monkeypatch):
-    """Round 5: the pre-pass proves, per triangle and emitter, that NOTHING can intersect a shadow segment ending on it (k_bin_clear: every
+    """Round 5 (an opt-in, FFX_SHADOW_CLEAR=1|2|3; off by default: it did not pay in the loop, ffx_trace.hip clear_enabled): the pre-pass
+    proves, per triangle and emitter, that NOTHING can intersect a shadow segment ending on it (k_bin_clear: every
     triangle sharing a tile of the emitter's grid with it is apart in the emitter's image plane, behind its plane, or a front-facing
     neighbour whose plane it lies in front of) and a packet whose samples all lie on such triangles skips that emitter's any-hit stage —
     a quarter of the render kernel for the spot.  The proof is exact, so the image must not change by a bit: with and without the skip
@@ -834,6 +835,7 @@ def test_shadow_walks_skipped_for_clear_triangles_leave_the_image_as_it_is(oracl
     cast shadow), on the colon; the texture gradient agrees to the order of the atomics; and the oracle's image is met."""
     for k in ("FFX_SHADOW_CLEAR", "FFX_BINS"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("FFX_SHADOW_CLEAR", "3")  # both emitters (the default proves the spot only: the projector's stage is 3 % of the kernel)
     from tests.test_bruteforce_cpu import material_rows
 
     if which == "hello":
