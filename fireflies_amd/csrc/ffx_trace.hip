@@ -3731,7 +3731,11 @@ static WideScene wide_scene(const void *bvh, const ffx_bvh_info *info) {
 // The kernels that fold footprints (cache / forward + adjoint) take the larger block there too: colon 114.5 -> 126.5 gradient steps/s.
 static int tile_block_log2(long pixels = 0, bool with_cache = false) {
   const char *e = getenv("FFX_TILE_BLOCK");
-  const int dflt = (pixels > 2L * 512 * 512 && !with_cache) ? 3 : 4;
+  // (round 5, tools/trafficsweep.sh: 64x64-pixel blocks with 1024 workgroups per XCD and round — half a block, 32 camera tiles, on one L2 — read
+  // 45 MB per launch instead of 67 at the same speed (2 530 vs 2 527 - 2 558 renders/s); the floor is 40 MB: the tile lists are 16.6 MB of
+  // 64-byte entries that a render reads once, and the counter correction doubles them.  Coarser deals — one block or more per XCD — reach
+  // the floor but lose 14 % to load imbalance)
+  const int dflt = (pixels > 2L * 512 * 512) ? (with_cache ? 4 : 3) : 5;
   int t = e ? atoi(e) : dflt;
   return (t < 0 || t > 8) ? dflt : t;
 }
@@ -3916,7 +3920,7 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
 // FETCH_SIZE per launch; the vocal fold at 512x512 loses 1 % at 256)
 static int xcd_mode(long pixels = 0) {
   const char *e = getenv("FFX_XCD_REMAP");
-  int m = e ? atoi(e) : (pixels > 2L * 512 * 512 ? 256 : 128);
+  int m = e ? atoi(e) : (pixels > 2L * 512 * 512 ? 256 : 1024);
   return m < 0 ? 0 : m;
 }
 
