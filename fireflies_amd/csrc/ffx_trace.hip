@@ -39,6 +39,12 @@ struct CamK {
   float iw_u;
 };
 
+#define FFX_MAT_PRE 12 // floats per pre-row: eta, 1/eta^2, a2, 1/a2, metallic, c_sw, c_fd, brdf, 2 roughness, lobe flags (bits), roughness^2, tint term
+#define FFX_PRE_ANISO 1u
+#define FFX_PRE_TINT 2u
+#define FFX_PRE_CLEARCOAT 4u
+#define FFX_PRE_FLAT 8u
+#define FFX_PRE_SHEEN 16u
 struct ShadeK {
   CamK cam;
   int proj_on, spot_on, shadows;
@@ -60,6 +66,10 @@ struct ShadeK {
   // the material table as a kernel argument (ffx_scene_desc.mat_h): the kernels then read the rows from their own kernarg segment
   int mat_inline;
   float mat_h[FFX_MAX_MAT_H];
+  // per-row constants of the inline material rows (round 5; shade_prepare -> mat_pre_row): what every BSDF evaluation of a row re-derived from its
+  // parameters — alpha^2 and its reciprocal, 1 / eta^2, the Fresnel mix's coefficients, the diffuse weight, which optional lobes are on
+  int mat_pre_on;
+  float mat_pre[8 * FFX_MAT_PRE];
   // tile bins of the three apexes (ffx_common.h BinsK): the packet kernels try them before the tree walks
   BinsK bins;
   // reconstruction filter (ffx_scene_desc.rfilter = gaussian; the *_filtered entry points only): g(x) = max(0, exp(rf_alpha x^2) - rf_bias)
@@ -508,6 +518,114 @@ __device__ __forceinline__ void material_terms(const float *__restrict__ m, cons
   }
   const float sheen = m[FFX_MAT_SHEEN];
   if (sheen > 0.f && 1.0f - metallic > 0.f) {
+    const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
+    const float lum = TEX ? 0.212671f * b0 + 0.715160f * b1 + 0.072169f * b2 : 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2], sheen_tint = m[FFX_MAT_SHEEN_TINT];
+    if (lum > 0.f) { a += bdiv(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
+    else b += sv;
+  }
+  A = a * FFX_PI_F;
+  B = b * FFX_PI_F;
+}
+
+// ---- the same two functions on a row whose constants the host has derived once (ShadeK.mat_pre, FFX_MAT_PRE floats per row): no squares, clamps
+// and reciprocals of parameters per evaluation, one flag word instead of five parameter loads and compares.  The arithmetic of the lobes is
+// material_terms', with the host's IEEE values where that one forms hardware seeds (a last-bit difference, inside the parity tolerance).
+__device__ __forceinline__ void material_geometry_p(const float *__restrict__ m, const float *__restrict__ p, v3 n, v3 wv, v3 wl, MatGeo &g) {
+  g.cos_i = vdot(n, wv);
+  g.cos_o = vdot(n, wl);
+  v3 wh = V3(wv.x + wl.x, wv.y + wl.y, wv.z + wl.z);
+  const float ihl = __builtin_amdgcn_rsqf(vdot(wh, wh));
+  wh = V3(wh.x * ihl, wh.y * ihl, wh.z * ihl);
+  g.ci_h = vdot(wv, wh);
+  g.co_h = vdot(wl, wh);
+  g.ch = vdot(n, wh);
+  if (__float_as_uint(p[9]) & FFX_PRE_ANISO) { // calc_dist_params + the shading frame coordinate_system(n): as material_geometry
+    const float r2 = p[10], aniso = m[FFX_MAT_ANISOTROPIC];
+    const float aspect = bsqrt(1.0f - 0.9f * aniso);
+    const float ax = fmaxf(0.001f, bdiv(r2, aspect)), ay = fmaxf(0.001f, r2 * aspect);
+    const float sg = copysignf(1.0f, n.z), ca = -brcp(sg + n.z), cb = n.x * n.y * ca;
+    const v3 fs = V3(sg * (sqrf(n.x) * ca) + 1.0f, sg * cb, -sg * n.x), ft = V3(cb, fmaf(n.y, n.y * ca, sg), -n.y);
+    const float hx = vdot(wh, fs), hy = vdot(wh, ft);
+    g.s2 = sqrf(hx) + sqrf(hy);
+    g.tmp = sqrf(bdiv(hx, ax)) + sqrf(bdiv(hy, ay)) + sqrf(g.ch);
+    g.xy_i = sqrf(ax * vdot(wv, fs)) + sqrf(ay * vdot(wv, ft));
+    g.xy_o = sqrf(ax * vdot(wl, fs)) + sqrf(ay * vdot(wl, ft));
+    g.axay = ax * ay;
+  } else {
+    const float a2 = p[2];
+    const v3 cx = vcross(n, wh);
+    g.s2 = vdot(cx, cx);
+    g.tmp = fmaf(g.s2, p[3], sqrf(g.ch));
+    g.xy_i = a2 * fmaxf(1.0f - sqrf(g.cos_i), 0.f);
+    g.xy_o = a2 * fmaxf(1.0f - sqrf(g.cos_o), 0.f);
+    g.axay = a2;
+  }
+}
+template <bool TEX = false>
+__device__ __forceinline__ void material_terms_p(const float *__restrict__ m, const float *__restrict__ p, const MatGeo &g, float &A, float &B, float b0 = 0.f, float b1 = 0.f,
+                                                 float b2 = 0.f) {
+  const float cos_i = g.cos_i, cos_o = g.cos_o, ch = g.ch, ci_h = g.ci_h, co_h = g.co_h;
+  A = 0.f; B = 0.f;
+  if (!(cos_i > 0.f && cos_o > 0.f)) return;
+  const bool facing = ci_h > 0.f && co_h > 0.f;
+  float a = 0.f, b = 0.f;
+  const float eta = p[0];
+  const uint32_t flags = __float_as_uint(p[9]);
+  const float ct2 = 1.0f - (1.0f - ci_h * ci_h) * p[1];
+  const float ct = ct2 > 0.f ? bsqrt(ct2) : 0.f;
+  const float sw = schlick_weight(eta > 1.0f ? fabsf(ci_h) : ct);
+  float F_d;
+  {
+    const float c = fabsf(ci_h);
+    const float ds = c + eta * ct, dp = ct + eta * c, ir = brcp(ds * dp);
+    const float a_s = (c - eta * ct) * dp * ir, a_p = (ct - eta * c) * ds * ir;
+    F_d = 0.5f * (a_s * a_s + a_p * a_p);
+    if (eta == 1.0f) F_d = 0.f;
+    else if (c == 0.f) F_d = 1.f;
+  }
+  const float metallic = p[4];
+  if (facing && F_d > 0.f) { // main specular reflection lobe
+    const float dden = FFX_PI_F * g.axay * sqrf(g.tmp);
+    const float s_i = bsqrt(sqrf(cos_i) + g.xy_i), s_o = bsqrt(sqrf(cos_o) + g.xy_o);
+    float common = bdiv(cos_o, dden * ((cos_i + s_i) * (cos_o + s_o)));
+    if (!(ch > 1e-20f * dden)) common = 0.f;
+    float Fa = metallic * (1.0f - sw), Fb = fmaf(p[5], sw, p[6] * F_d); // (metallic + m1 spec_tint) sw + m1 (1 - spec_tint) F_d
+    if (flags & FFX_PRE_TINT) {
+      const float lum = TEX ? 0.212671f * b0 + 0.715160f * b1 + 0.072169f * b2 : 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2];
+      const float t = p[11] * (1.0f - sw);
+      if (lum > 0.f) Fa += bdiv(t, lum);
+      else Fb += t;
+    }
+    a += Fa * common;
+    b += Fb * common;
+  }
+  if ((flags & FFX_PRE_CLEARCOAT) && facing) {
+    const float cc = m[FFX_MAT_CLEARCOAT];
+    const float Fcc = sw + (1.0f - sw) * 0.04f;
+    const float alpha = 0.1f + (0.001f - 0.1f) * m[FFX_MAT_CLEARCOAT_GLOSS], a2 = sqrf(alpha), c2 = sqrf(ch);
+    float Dcc = bdiv(a2 - 1.0f, FFX_PI_F * logf(a2) * (g.s2 + a2 * c2));
+    if (!(Dcc * ch > 1e-20f)) Dcc = 0.f;
+    const float Gcc = ggx1_cc(cos_i, ci_h) * ggx1_cc(cos_o, co_h);
+    b += cc * 0.25f * Fcc * Dcc * Gcc * cos_o;
+  }
+  const float brdf = p[7];
+  if (brdf > 0.f) { // diffuse + retro-reflection (+ fake subsurface)
+    const float Fo = schlick_weight(cos_o), Fi = schlick_weight(cos_i);
+    const float f_diff = (1.0f - 0.5f * Fi) * (1.0f - 0.5f * Fo);
+    const float Rr = p[8] * sqrf(co_h);
+    const float f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0f));
+    float dterm = f_diff + f_retro;
+    if (flags & FFX_PRE_FLAT) {
+      const float flat = m[FFX_MAT_FLATNESS];
+      const float Fss90 = Rr * 0.5f;
+      const float Fss = (1.0f + (Fss90 - 1.0f) * Fo) * (1.0f + (Fss90 - 1.0f) * Fi);
+      const float f_ss = 1.25f * (Fss * (brcp(cos_o + cos_i) - 0.5f) + 0.5f);
+      dterm = dterm + (f_ss - dterm) * flat;
+    }
+    a += brdf * cos_o * 0.3183098861837907f * dterm;
+  }
+  if (flags & FFX_PRE_SHEEN) {
+    const float sheen = m[FFX_MAT_SHEEN];
     const float sv = sheen * (1.0f - metallic) * schlick_weight(fabsf(co_h)) * cos_o;
     const float lum = TEX ? 0.212671f * b0 + 0.715160f * b1 + 0.072169f * b2 : 0.212671f * m[0] + 0.715160f * m[1] + 0.072169f * m[2], sheen_tint = m[FFX_MAT_SHEEN_TINT];
     if (lum > 0.f) { a += bdiv(sv * sheen_tint, lum); b += sv * (1.0f - sheen_tint); }
@@ -2277,6 +2395,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       if (lit_p || lit_s) {
         const float *mrow = mat_table(c2) + (size_t)FFX_MAT_STRIDE * st[r].shape;
         const bool mat_on = mrow[FFX_MAT_MODEL] != 0.f;
+        // (wave-uniform: the rows travel with the call and the host derived their constants — FFX_MAT_PRE=0 in the environment keeps the on-the-fly form)
+        const float *prow = c2.mat_pre_on ? c2.mat_pre + FFX_MAT_PRE * st[r].shape : nullptr;
         const v3 wv = V3(-d[r].x, -d[r].y, -d[r].z);
         if constexpr (TEX) { // base colour of this sample: the row's, or its texture at the hit (only lit samples need one)
           st[r].base[0] = mrow[0]; st[r].base[1] = mrow[1]; st[r].base[2] = mrow[2];
@@ -2296,8 +2416,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           float bA = vdot(q.ng, wi), bB = 0.f;
           if (mat_on) {
             MatGeo g;
-            material_geometry(mrow, q.ng, wv, wi, g);
-            material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]);
+            if (prow) { material_geometry_p(mrow, prow, q.ng, wv, wi, g); material_terms_p<TEX>(mrow, prow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]); }
+            else { material_geometry(mrow, q.ng, wv, wi, g); material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]); }
           }
           q.pfac_b = q.pfac * bB;
           q.pfac = q.pfac * bA;
@@ -2309,8 +2429,8 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           float bA = vdot(q.ng, wi), bB = 0.f;
           if (mat_on) {
             MatGeo g;
-            material_geometry(mrow, q.ng, wv, wi, g);
-            material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]);
+            if (prow) { material_geometry_p(mrow, prow, q.ng, wv, wi, g); material_terms_p<TEX>(mrow, prow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]); }
+            else { material_geometry(mrow, q.ng, wv, wi, g); material_terms<TEX>(mrow, g, bA, bB, st[r].base[0], st[r].base[1], st[r].base[2]); }
           }
           q.sfac_b = q.sfac * bB;
           q.sfac = q.sfac * bA;
@@ -3624,6 +3744,26 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
     if (sd->n_mat_h > FFX_MAX_MAT_H || sd->n_mat_h != sd->n_shapes * c.mat_stride) return 0;
     c.mat_inline = 1;
     for (int i = 0; i < sd->n_mat_h; ++i) c.mat_h[i] = sd->mat_h[i];
+    const char *pe = getenv("FFX_MAT_PRE");
+    if (c.mat_stride == FFX_MAT_STRIDE && sd->n_shapes <= 8 && !(pe && strcmp(pe, "0") == 0)) { // per-row constants of the principled rows (ShadeK.mat_pre)
+      c.mat_pre_on = 1;
+      for (int k = 0; k < sd->n_shapes; ++k) {
+        const float *m = sd->mat_h + k * FFX_MAT_STRIDE;
+        float *p = c.mat_pre + k * FFX_MAT_PRE;
+        const float eta = m[FFX_MAT_ETA], r2 = m[FFX_MAT_ROUGHNESS] * m[FFX_MAT_ROUGHNESS], a = r2 > 0.001f ? r2 : 0.001f, a2 = a * a;
+        const float metallic = m[FFX_MAT_METALLIC], m1 = 1.0f - metallic, tint = m[FFX_MAT_SPEC_TINT];
+        const float r0 = (eta - 1.0f) / (eta + 1.0f);
+        uint32_t flags = 0;
+        if (m[FFX_MAT_ANISOTROPIC] != 0.f) flags |= FFX_PRE_ANISO;
+        if (tint != 0.f) flags |= FFX_PRE_TINT;
+        if (m[FFX_MAT_CLEARCOAT] > 0.f) flags |= FFX_PRE_CLEARCOAT;
+        if (m[FFX_MAT_FLATNESS] > 0.f) flags |= FFX_PRE_FLAT;
+        if (m[FFX_MAT_SHEEN] > 0.f && m1 > 0.f) flags |= FFX_PRE_SHEEN;
+        p[0] = eta; p[1] = 1.0f / (eta * eta); p[2] = a2; p[3] = 1.0f / a2;
+        p[4] = metallic; p[5] = metallic + m1 * tint; p[6] = m1 * (1.0f - tint); p[7] = m1 * (1.0f - m[FFX_MAT_SPEC_TRANS]);
+        p[8] = 2.0f * m[FFX_MAT_ROUGHNESS]; memcpy(&p[9], &flags, 4); p[10] = r2; p[11] = m1 * tint * r0 * r0;
+      }
+    }
   }
   if (sd->rfilter == FFX_RFILTER_GAUSSIAN) { // [EXT Mitsuba src/rfilters/gaussian.cpp] radius 4 stddev; the 5x5 window holds radius <= 2
     const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
