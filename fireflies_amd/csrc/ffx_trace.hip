@@ -39,6 +39,12 @@ struct CamK {
   float iw_u;
 };
 
+// the gaussian reconstruction filter's constants (ffx_scene_desc.rfilter): g(x) = max(0, exp(alpha x^2) - bias).  A sample needs the five weights
+// of its window along each axis, at x0 + a, a = 0..4: instead of five exponentials, exp(alpha (x + 1)^2) = exp(alpha x^2) exp(2 alpha x) exp(alpha)
+// — two exponentials and eight multiplies with k[n] = exp(alpha (2 n + 1)) from the host (round 5; `rec`: |alpha| <= 8, i.e. stddev >= 0.25:
+// the factor exp(2 alpha x0) stays inside float's range — narrower filters keep the five exponentials).  Every kernel that forms weights
+// calls rf_weights, so forward, adjoint and cache agree bit for bit; the oracle's five expf differ in the last bits (1e-6 of a weight).
+struct RfC { float alpha, bias, aL, aL2, k[4]; int rec; };
 #define FFX_MAT_PRE 12 // floats per pre-row: eta, 1/eta^2, a2, 1/a2, metallic, c_sw, c_fd, brdf, 2 roughness, lobe flags (bits), roughness^2, tint term
 #define FFX_PRE_ANISO 1u
 #define FFX_PRE_TINT 2u
@@ -73,7 +79,7 @@ struct ShadeK {
   // tile bins of the three apexes (ffx_common.h BinsK): the packet kernels try them before the tree walks
   BinsK bins;
   // reconstruction filter (ffx_scene_desc.rfilter = gaussian; the *_filtered entry points only): g(x) = max(0, exp(rf_alpha x^2) - rf_bias)
-  float rf_alpha, rf_bias;
+  RfC rf;
 };
 // The first kernel argument, read in place.  The scene constants (ShadeK, ~100 dwords + the inline material rows) are the first
 // argument of the render kernels.  Read through the by-value copy the compiler loads them all up front and, out of SGPRs, parks
@@ -2620,12 +2626,28 @@ __host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) 
 #define FFX_RF_ROW 68
 #define FFX_RF_FLOATS (14 * FFX_RF_ROW)
 static_assert(FFX_RF_ROW % 4 == 0, "rf_fold reads the rows as float4: the row pitch must keep them 16-byte aligned");
-__device__ __forceinline__ void rf_weights(float alpha, float bias, float j, float (&w)[5]) {
+__device__ __forceinline__ void rf_weights(const RfC &c, float j, float (&w)[5]) {
+  if (c.rec) { // (wave-uniform)
+    const float x0 = -1.5f - j; // centre of window pixel 0 minus the sample position; pixel a: x0 + a
+    const float e0 = __builtin_amdgcn_exp2f(c.aL * (x0 * x0)), r = __builtin_amdgcn_exp2f(c.aL2 * x0);
+    const float e1 = e0 * r * c.k[0], e2 = e1 * r * c.k[1], e3 = e2 * r * c.k[2], e4 = e3 * r * c.k[3];
+    w[0] = fmaxf(e0 - c.bias, 0.f); w[1] = fmaxf(e1 - c.bias, 0.f); w[2] = fmaxf(e2 - c.bias, 0.f); w[3] = fmaxf(e3 - c.bias, 0.f); w[4] = fmaxf(e4 - c.bias, 0.f);
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
-    const float x = ((float)(a - 2) + 0.5f) - j; // centre of window pixel a minus the sample position
-    w[a] = fmaxf(__expf(alpha * (x * x)) - bias, 0.f);
+    const float x = ((float)(a - 2) + 0.5f) - j;
+    w[a] = fmaxf(__expf(c.alpha * (x * x)) - c.bias, 0.f);
   }
+}
+static void rf_constants(float stddev, RfC &c) { // [EXT Mitsuba src/rfilters/gaussian.cpp] radius 4 stddev
+  c.alpha = -1.0f / (2.0f * stddev * stddev);
+  c.bias = expf(c.alpha * (4.0f * stddev) * (4.0f * stddev));
+  c.aL = c.alpha * 1.4426950408889634f;
+  c.aL2 = 2.0f * c.aL;
+  for (int n = 0; n < 4; ++n) c.k[n] = (float)exp((double)c.alpha * (2 * n + 1));
+  const char *e = getenv("FFX_RF_RECURRENCE");
+  c.rec = (c.alpha >= -8.0f && !(e && strcmp(e, "0") == 0)) ? 1 : 0;
 }
 // acc[ch] of lane l += sum over the samples 32 (l / 32) .. + 31 of this pass of  gx[a] gy[b] L[ch]  for window entry n = 5 b + a = l % 32 (< 25)
 __device__ __forceinline__ void rf_fold(float *__restrict__ s_rf, int lane, const float (&gx)[5], const float (&gy)[5], float l0, float l1, float l2, float l3,
@@ -2668,7 +2690,7 @@ __device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix,
 }
 
 // the weights alone (the adjoint's first launch): one wave per pixel, the jitter decides everything
-__global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int n_pix, int spp, uint32_t seed_key, float *__restrict__ part) {
+__global__ void __launch_bounds__(64) k_rf_weights(RfC rfc, int n_pix, int spp, uint32_t seed_key, float *__restrict__ part) {
   __shared__ __attribute__((aligned(16))) float s_rf[FFX_RF_FLOATS]; // (rf_fold reads it in 16-byte units)
   const int pix = blockIdx.x, lane = threadIdx.x;
   if (pix >= n_pix) return;
@@ -2677,8 +2699,8 @@ __global__ void __launch_bounds__(64) k_rf_weights(float alpha, float bias, int 
     const int s = pass * 64 + lane;
     float jx, jy, gx[5], gy[5];
     sample_jitter(seed_key, (uint32_t)pix * (uint32_t)spp + (uint32_t)s, jx, jy);
-    rf_weights(alpha, bias, jx, gx);
-    rf_weights(alpha, bias, jy, gy);
+    rf_weights(rfc, jx, gx);
+    rf_weights(rfc, jy, gy);
     rf_fold(s_rf, lane, gx, gy, 0.f, 0.f, 0.f, s < spp ? 1.f : 0.f, acc);
   }
   rf_store(part, (uint32_t)pix, lane, acc);
@@ -2879,8 +2901,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
             const float4 gw = rf_window_g(reinterpret_cast<const float4 *>(adj_gimg), px[0], py[0], W, H, lane, live[0]);
             float jx, jy, gx[5], gy[5];
             sample_jitter(seed_key, pix[0] * (uint32_t)spp + (uint32_t)s, jx, jy);
-            rf_weights(cr.rf_alpha, cr.rf_bias, jx, gx);
-            rf_weights(cr.rf_alpha, cr.rf_bias, jy, gy);
+            rf_weights(cr.rf, jx, gx);
+            rf_weights(cr.rf, jy, gy);
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int n = 0; n < 25; ++n) {
@@ -3029,10 +3051,12 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         }
         if constexpr (RF) {
           // the lane's sample -> its 25 window entries (weights from the jitter, re-derived: two hashes instead of two live registers)
+          // (re-derived: two hashes instead of two live registers — parking the jitter in LDS instead was tried in round 5: the film's fold keeps
+          // the CU's LDS port busy as it is, filtered render 0.531 -> 0.559 ms)
           float jx, jy, gx[5], gy[5];
           sample_jitter(seed_key, pix[r] * (uint32_t)spp + (uint32_t)s, jx, jy);
-          rf_weights(ct.rf_alpha, ct.rf_bias, jx, gx);
-          rf_weights(ct.rf_alpha, ct.rf_bias, jy, gy);
+          rf_weights(ct.rf, jx, gx);
+          rf_weights(ct.rf, jy, gy);
           if (pass > 0) { rfacc[0] = s_acc[r][0][threadIdx.x]; rfacc[1] = s_acc[r][1][threadIdx.x]; rfacc[2] = s_acc[r][2][threadIdx.x]; rfacc[3] = s_acc[r][3][threadIdx.x]; }
           rf_fold(reinterpret_cast<float *>(s_wstack), lane, gx, gy, c0, c1, c2, active[r] ? 1.f : 0.f, rfacc); // (the weight channel: every sample drawn counts)
           if (pass + 1 < passes) { s_acc[r][0][threadIdx.x] = rfacc[0]; s_acc[r][1][threadIdx.x] = rfacc[1]; s_acc[r][2][threadIdx.x] = rfacc[2]; s_acc[r][3][threadIdx.x] = rfacc[3]; }
@@ -3226,8 +3250,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
           const float4 gw = rf_window_g(reinterpret_cast<const float4 *>(gimg), px[r], py[r], W, H, lane, live[r]);
           float jx, jy, gx[5], gy[5];
           sample_jitter(seed_key, pix[r] * (uint32_t)spp + (uint32_t)s, jx, jy);
-          rf_weights(ct.rf_alpha, ct.rf_bias, jx, gx);
-          rf_weights(ct.rf_alpha, ct.rf_bias, jy, gy);
+          rf_weights(ct.rf, jx, gx);
+          rf_weights(ct.rf, jy, gy);
           float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
           for (int n = 0; n < 25; ++n) {
@@ -3565,7 +3589,7 @@ __global__ void __launch_bounds__(256)
 // unit — 0.16 / 0.09 / 0.065 ms with 250 of 256 CUs idle.  Now every block is served by K9F_SUB independent ONE-WAVE workgroups (the
 // dispatcher deals them to different CUs and XCDs): each reads the block's 64 pixel headers itself (512 bytes, L2) and takes every
 // K9F_SUB-th lit item.  A block without lit pixels costs its waves one load.  3-channel textures: twelve direct atomics per sample.
-struct BwdF { int tw, th, tc, spp; float color[3]; float rf_alpha, rf_bias; int W, H; int ms, n_shapes; uint32_t seed_key; size_t off_wsum, off_recs, off_facb;
+struct BwdF { int tw, th, tc, spp; float color[3]; RfC rf; int W, H; int ms, n_shapes; uint32_t seed_key; size_t off_wsum, off_recs, off_facb;
               const float *mats; int mat_inline; float mat_h[FFX_MAX_MAT_H]; };
 __device__ __forceinline__ const float *mat_table(const BwdF &k) { return k.mat_inline ? k.mat_h : k.mats; }
 #define K9F_BLOCK 8 // pixels per side of a block
@@ -3642,8 +3666,8 @@ __global__ void __launch_bounds__(64)
     const float g0 = gok ? cur.q0 / cur.qw : 0.f, g1 = gok ? cur.q1 / cur.qw : 0.f, g2 = gok ? cur.q2 / cur.qw : 0.f;
     float jx, jy, gx[5], gy[5];
     sample_jitter(p.seed_key, cur.sidx, jx, jy);
-    rf_weights(p.rf_alpha, p.rf_bias, jx, gx);
-    rf_weights(p.rf_alpha, p.rf_bias, jy, gy);
+    rf_weights(p.rf, jx, gx);
+    rf_weights(p.rf, jy, gy);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int n = 0; n < 25; ++n) {
@@ -3768,8 +3792,7 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   if (sd->rfilter == FFX_RFILTER_GAUSSIAN) { // [EXT Mitsuba src/rfilters/gaussian.cpp] radius 4 stddev; the 5x5 window holds radius <= 2
     const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
     if (!(sdv <= 0.5f)) return 0;
-    c.rf_alpha = -1.0f / (2.0f * sdv * sdv);
-    c.rf_bias = expf(c.rf_alpha * (4.0f * sdv) * (4.0f * sdv));
+    rf_constants(sdv, c.rf);
   } else if (sd->rfilter != FFX_RFILTER_BOX) return 0;
   c.n_base_tex = sd->n_base_tex;
   if (c.n_base_tex < 0 || c.n_base_tex > FFX_MAX_BASE_TEX || (c.n_base_tex > 0 && (c.mat_stride != FFX_MAT_STRIDE || !sd->slot_uv))) return 0;
@@ -4245,7 +4268,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       const int n_pix = c.cam.W * c.cam.H;
       float *part = (float *)rf_scratch;
       float4 *G = (float4 *)(part + (size_t)n_pix * 100);
-      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf_alpha, c.rf_bias, n_pix, spp, seed_key_of(seed), part);
+      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf, n_pix, spp, seed_key_of(seed), part);
       FFX_CHECK_LAUNCH("render_fwd_adjoint_filtered/weights");
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)part, c.cam.W,
                          c.cam.H, 0, (void *)nullptr, adj_gimg, G);
@@ -4462,7 +4485,7 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       const int n_pix = c.cam.W * c.cam.H;
       float *part = (float *)rf_scratch;
       float4 *G = (float4 *)(part + (size_t)n_pix * 100);
-      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf_alpha, c.rf_bias, n_pix, spp, seed_key_of(seed), part);
+      hipLaunchKernelGGL(k_rf_weights, dim3(n_pix), dim3(64), 0, (hipStream_t)s, c.rf, n_pix, spp, seed_key_of(seed), part);
       FFX_CHECK_LAUNCH("render_bwd_filtered/weights");
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)part, c.cam.W, c.cam.H, 0,
                          (void *)nullptr, gimg, G);
@@ -4605,8 +4628,7 @@ int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];
   const float sdv = sd->rfilter_stddev > 0.f ? sd->rfilter_stddev : 0.5f;
   if (!(sdv <= 0.5f)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: gaussian filter: stddev <= 0.5");
-  p.rf_alpha = -1.0f / (2.0f * sdv * sdv); // (as shade_prepare)
-  p.rf_bias = expf(p.rf_alpha * (4.0f * sdv) * (4.0f * sdv));
+  rf_constants(sdv, p.rf); // (as shade_prepare)
   p.seed_key = seed_key_of(seed);
   p.n_shapes = sd->n_shapes;
   if (p.n_shapes < 1 || p.n_shapes > 255) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: 1 .. 255 shapes");

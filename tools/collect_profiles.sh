@@ -15,13 +15,20 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the profiled runs time and count the bracket's own launches only: no clock-settle launches (the same kernel on ONE pose, cheaper than
 # the average random pose: they would pull the per-kernel averages down) and no preflight renders (bench.py: FFX_BENCH_SETTLE / _PREFLIGHT)
-export FFX_BENCH_SETTLE=0 FFX_BENCH_PREFLIGHT=0 FFX_BENCH_EXTRA_BRACKETS=0
+# ... and no gaussian-film brackets (round 5: bench.py's default line carries them; here they get a pass of their own, r<N>gauss_*)
+export FFX_BENCH_SETTLE=0 FFX_BENCH_PREFLIGHT=0 FFX_BENCH_EXTRA_BRACKETS=0 FFX_BENCH_GAUSSIAN=0
 B="--steps 20 --warmup 3 --no-cpu-baseline $X"
 (cd $R && rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py $B > $OUT/bench_under_rocprof.json 2> $OUT/stats.log)
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-grad-steps $X > /dev/null 2>&1)
   (cd $R && rocprofv3 --pmc $c --kernel-trace -d $OUT/gpmc_$c -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-render-steps $X > /dev/null 2>&1)
 done
+if [ -z "$X" ]; then  # the gaussian film's kernels (k_render_fwd_pk<..., RF[, RFC]>, k_rf_gather, k_render_bwd_cached_filtered): kernel stats + the line
+  (cd $R && rocprofv3 --kernel-trace --stats -d $OUT/gstats -o s --output-format csv -- python3 bench.py $B --rfilter gaussian > $OUT/gauss_bench_under_rocprof.json 2> $OUT/gstats.log)
+  G=$(find $OUT/gstats -name "*kernel_stats.csv" | head -1)
+  [ -n "$G" ] && cp "$G" $R/profiles/${TAG}gauss_kernel_stats.csv
+  tail -1 $OUT/gauss_bench_under_rocprof.json > $R/profiles/${TAG}gauss_bench_under_rocprof.json
+fi
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_CYCLES SQ_WAVES" \
            "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_INST_CYCLES_VALU" \

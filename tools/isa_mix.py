@@ -24,7 +24,7 @@ FAST = ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_sub
 
 
 def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else "k_render_fwd_pk<1, true, 1, false, false>"  # (one pixel per packet, 64-wide walk, material rows, plain forward)
+    want = sys.argv[1] if len(sys.argv) > 1 else "k_render_fwd_pk<1, true, 1, false, false, false>"  # (one pixel per packet, 64-wide walk, material rows, plain forward)
     src = os.path.join(ROOT, "fireflies_amd", "csrc", "ffx_trace.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "t.s")

@@ -57,12 +57,13 @@ def main():
         v = tot[k] / npx
         acc += v
         print(f"  {name:78s} {v:8.1f}  {100 * v / whole:5.1f} %")
-        if k in (22, 20):
+        if k in (22, 20):  # the sub-phases of the TREE walks: only printed when a packet walked the tree (with the tile bins hardly any does)
             base = 0 if k == 22 else 8
             sub = tot[base:base + 5]
             lab = "closest-hit walks" if k == 22 else "any-hit walks (both emitters)"
             for j in (4, 0, 1, 2, 3):
-                print(f"      {lab}: {WALK[j]:40s} {sub[j] / npx:8.1f}  {100 * sub[j] / npx / whole:5.1f} %")
+                if sub[j] > 0:
+                    print(f"      {lab} (tree fallback): {WALK[j]:40s} {sub[j] / npx:8.1f}  {100 * sub[j] / npx / whole:5.1f} %")
     print(f"  {'(sum of the phases)':78s} {acc:8.1f}  {100 * acc / whole:5.1f} %")
 
 
