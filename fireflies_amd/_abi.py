@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 7
+FFX_ABI_VERSION = 8
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -94,6 +94,25 @@ class RandEntity(C.Structure):
     """ffx_rand_entity: how one entity's matrices follow from its draws"""
     _fields_ = [("kind", C.c_int32), ("parent", C.c_int32), ("draw_t", C.c_int32), ("draw_r", C.c_int32), ("draw_s", C.c_int32), ("pad", C.c_int32 * 3),
                 ("world", C.c_float * 16), ("centroid", C.c_float * 3), ("pad2", C.c_float)]
+
+
+class StepOp(C.Structure):
+    """ffx_step_op: one compiled key write of a scene sample (include/ffx.h ffx_scene_step_h)"""
+    _fields_ = [("kind", C.c_int32), ("src", C.c_int32), ("comp", C.c_int32), ("dst", C.c_int32), ("conv", C.c_int32), ("mode", C.c_int32), ("pad", C.c_int32 * 2)]
+
+
+STEP_POSE_SD, STEP_VALUE_SD, STEP_VALUE_MAT, STEP_MESH = 0, 1, 2, 3
+
+
+class StepPlan(C.Structure):
+    _fields_ = [("ops", C.POINTER(StepOp)), ("n_ops", C.c_int32), ("n_shapes", C.c_int32), ("n_draws", C.c_int32), ("n_ents", C.c_int32),
+                ("frame_base", C.POINTER(C.c_int32)), ("frame_stride", C.POINTER(C.c_int32)), ("n_frames", C.POINTER(C.c_int32)),
+                ("n_mat_floats", C.c_int32), ("pad", C.c_int32)]
+
+
+class StepGeom(C.Structure):
+    """ffx_step_geom: the blob a scene sample is re-fitted into and the static device tables of the re-fit"""
+    _fields_ = [("bvh", C.c_void_p), ("info", C.POINTER(BvhInfo)), ("src_verts", C.c_void_p), ("tris", C.c_void_p), ("tri_shape", C.c_void_p), ("smooth", C.POINTER(Smooth))]
 
 
 class Camera(C.Structure):
@@ -217,6 +236,7 @@ PROTOTYPES = {
     "ffx_render_bwd_cached_filtered": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_p, c_p, c_p]),
     "ffx_render_fwd_adjoint": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p, c_p]),
     "ffx_apex_prepare": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p]),
+    "ffx_scene_step_h": (c_i, [C.POINTER(StepPlan), c_p, c_p, c_p, c_p, C.POINTER(SceneDesc), C.POINTER(SceneDesc), c_p, c_p, c_p, C.POINTER(StepGeom), c_i, c_p]),
     "ffx_render_cache_status": (c_i, [c_p, C.POINTER(C.c_uint32), c_p]),
 }
 

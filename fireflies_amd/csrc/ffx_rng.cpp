@@ -12,6 +12,8 @@
 // have consumed, so every later consumer of the generator sees the same stream as in the reference program.
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <time.h>
 
 #include "../../include/ffx.h"
 #include "ffx_common.h"
@@ -165,4 +167,85 @@ extern "C" int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const
     }
   }
   return FFX_OK;
+}
+
+// ---- one scene sample from the randomiser's tables to the device (include/ffx.h ffx_scene_step_h, ABI 8): the native params.update().
+// The reference pushes a randomisation key by key through Mitsuba's parameter map (fireflies/scene.py:243-342) and lets
+// params.update() (scene.py:384) rebuild; here the key writes are compiled into `ops` once and a sample is: copy the template
+// description, run the ops over the drawn values and chain matrices, copy the material rows, enqueue the re-fit and the pre-pass.
+extern "C" int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, const float *chain, const float *chain_unc, const int32_t *frames,
+                                const ffx_scene_desc *tmpl, ffx_scene_desc *sd_out, float *mat_rows, float *xform, int32_t *vert_off,
+                                const ffx_step_geom *geom, int prepare_apex, ffx_stream stream) {
+  if (!plan || !tmpl || !sd_out || !xform || !vert_off || plan->n_ops < 0 || (plan->n_ops > 0 && !plan->ops) || plan->n_shapes < 1 ||
+      plan->n_shapes > FFX_MAX_SHAPES_H || plan->n_draws < 0 || plan->n_ents < 0 || (plan->n_draws > 0 && !values) ||
+      (plan->n_ents > 0 && (!chain || !chain_unc)))
+    FFX_FAIL(FFX_ERR_ARG, "scene_step_h: bad argument");
+  if (plan->n_mat_floats < 0 || plan->n_mat_floats > FFX_MAX_MAT_H || (plan->n_mat_floats > 0 && !mat_rows))
+    FFX_FAIL(FFX_ERR_ARG, "scene_step_h: material table of %d floats (at most %d, and then mat_rows must be given)", plan->n_mat_floats, FFX_MAX_MAT_H);
+  if (tmpl->n_mat_h > 0 && tmpl->n_mat_h != plan->n_mat_floats)
+    FFX_FAIL(FFX_ERR_ARG, "scene_step_h: the template carries %d material floats, the plan %d", tmpl->n_mat_h, plan->n_mat_floats);
+  const int sd_words = (int)(sizeof(ffx_scene_desc) / sizeof(float));
+  // every op checked before anything is written: a refused call leaves the caller's tables as they were
+  for (int i = 0; i < plan->n_ops; ++i) {
+    const ffx_step_op &o = plan->ops[i];
+    bool ok = false;
+    switch (o.kind) {
+      case FFX_STEP_POSE_SD: ok = o.src >= 0 && o.src < plan->n_ents && o.dst >= 0 && o.dst + 16 <= sd_words; break;
+      case FFX_STEP_VALUE_SD: ok = o.src >= 0 && o.src < plan->n_draws && o.comp >= 0 && o.comp < 4 && o.dst >= 0 && o.dst < sd_words; break;
+      case FFX_STEP_VALUE_MAT: ok = o.src >= 0 && o.src < plan->n_draws && o.comp >= 0 && o.comp < 4 && o.dst >= 0 && o.dst < plan->n_mat_floats && (o.conv == 0 || o.conv == 1); break;
+      case FFX_STEP_MESH: ok = o.src >= 0 && o.src < plan->n_ents && o.dst >= 0 && o.dst < plan->n_shapes && (o.mode == 0 || o.mode == 1); break;
+      default: break;
+    }
+    if (!ok) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: op %d (kind %d, src %d, comp %d, dst %d) out of range", i, o.kind, o.src, o.comp, o.dst);
+  }
+  if (frames) {
+    if (!plan->frame_base || !plan->frame_stride || !plan->n_frames) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: frames without the frame tables");
+    for (int s = 0; s < plan->n_shapes; ++s)
+      if (frames[s] >= plan->n_frames[s]) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: shape %d: frame %d out of range [0, %d)", s, frames[s], plan->n_frames[s]);
+  }
+  if (sd_out != tmpl) *sd_out = *tmpl;
+  float *sdw = reinterpret_cast<float *>(sd_out);
+  for (int i = 0; i < plan->n_ops; ++i) {
+    const ffx_step_op &o = plan->ops[i];
+    switch (o.kind) {
+      case FFX_STEP_POSE_SD:
+        for (int j = 0; j < 16; ++j) sdw[o.dst + j] = chain[16 * o.src + j];
+        break;
+      case FFX_STEP_VALUE_SD: sdw[o.dst] = values[4 * o.src + o.comp]; break;
+      case FFX_STEP_VALUE_MAT: {
+        const float v = values[4 * o.src + o.comp];
+        // (conv 1, [EXT Mitsuba principled.cpp parameters_changed]: in double, rounded to float once — the Python expression's bits)
+        mat_rows[o.dst] = o.conv ? (float)(2.0 / (1.0 - sqrt(0.08 * (double)v)) - 1.0) : v;
+        break;
+      }
+      default: { // FFX_STEP_MESH
+        const float *m = (o.mode ? chain : chain_unc) + 16 * o.src;
+        for (int j = 0; j < 16; ++j) xform[16 * o.dst + j] = m[j];
+      }
+    }
+  }
+  if (tmpl->n_mat_h > 0)
+    for (int j = 0; j < plan->n_mat_floats; ++j) sd_out->mat_h[j] = mat_rows[j];
+  if (frames)
+    for (int s = 0; s < plan->n_shapes; ++s)
+      if (frames[s] >= 0) vert_off[s] = plan->frame_base[s] + frames[s] * plan->frame_stride[s];
+  if (!geom) return FFX_OK;
+  if (!geom->bvh || !geom->info || !geom->src_verts || !geom->tris || !geom->tri_shape) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: incomplete geometry block");
+#ifdef FFX_STEP_TIMING
+  struct timespec t0, t1, t2;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+#endif
+  const int rc = ffx_scene_update_h(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth, stream);
+  if (rc != FFX_OK || !prepare_apex) return rc;
+#ifdef FFX_STEP_TIMING
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  const int rc2 = ffx_apex_prepare(geom->bvh, geom->info, sd_out, stream);
+  clock_gettime(CLOCK_MONOTONIC, &t2);
+  static double a = 0, b = 0; static int n = 0;
+  a += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3; b += (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3;
+  if (++n % 200 == 0) { fprintf(stderr, "step_h: update_h %.1f us, apex_prepare %.1f us (mean of 200)\n", a / 200, b / 200); a = b = 0; }
+  return rc2;
+#else
+  return ffx_apex_prepare(geom->bvh, geom->info, sd_out, stream);
+#endif
 }

@@ -143,7 +143,42 @@ class _Pending:
         return self.batch._values(None)
 
 
+class _Lazy:
+    """an attribute of an entity that a natively pushed scene sample (fireflies_amd/scene.py Scene._push_native) fills in on first use: the sample
+    went to the device in one call, and what it means for the entities — matrices, last draws, attribute values — is derived only if somebody asks.
+    A write counts as a use (the pending values are put in place first, so that they cannot overwrite it afterwards)."""
+
+    def __init__(self, name):
+        self.name, self.slot = name, "_lz" + name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        d = obj.__dict__
+        owner = d.get("_lazy_owner")
+        if owner is not None and owner._lazy is not None:
+            owner._materialise()
+        try:
+            return d[self.slot]
+        except KeyError:
+            raise AttributeError(self.name) from None
+
+    def __set__(self, obj, value):
+        d = obj.__dict__
+        owner = d.get("_lazy_owner")
+        if owner is not None and owner._lazy is not None:
+            owner._materialise()
+        d[self.slot] = value
+
+
 class Transformable:
+    _randomized_world = _Lazy("_randomized_world")
+    _last_draw = _Lazy("_last_draw")
+    _host_float_attributes = _Lazy("_host_float_attributes")
+    _host_vec3_attributes = _Lazy("_host_vec3_attributes")
+    _randomized_float_attributes = _Lazy("_randomized_float_attributes")
+    _randomized_vec3_attributes = _Lazy("_randomized_vec3_attributes")
+
     def __init__(self, name: str, device=torch.device("cuda")):
         self._device = device
         self._name = name

@@ -406,6 +406,11 @@ class _PinnedRing:
         self.events[k] = ev
 
 
+class _StepPlan:
+    """a compiled scene-sample push (Scene.compile_step): the ctypes tables of ffx_scene_step_h and what keeps them alive"""
+    ptrs = None
+
+
 class SceneParameters:
     """dict-like parameter view with Mitsuba-style keys and `.update()` (fireflies/scene.py:94,121,
     135,249,257,384).  Assignments only record the new value; `update()` pushes everything that
@@ -415,11 +420,14 @@ class SceneParameters:
         self._scene = scene
         self._d = {}
         self._dirty = set()
+        self._pending = None  # a callable: values of a natively pushed scene sample not yet written into the map (fireflies_amd/scene.py Scene._materialise)
 
     def keys(self):
         return self._d.keys()
 
     def items(self):
+        if self._pending is not None:
+            self._pending()
         return self._d.items()
 
     def __contains__(self, k):
@@ -432,11 +440,15 @@ class SceneParameters:
         return len(self._d)
 
     def __getitem__(self, k):
+        if self._pending is not None and k != "tex.data":  # (no scene sample writes the texture: mi.render's own lookup leaves the sample pending)
+            self._pending()
         return self._d[k]
 
     def __setitem__(self, k, v):
         if k not in self._d:
             raise KeyError(f"unknown scene parameter {k!r}")
+        if self._pending is not None and k != "tex.data":
+            self._pending()  # (the sample's own values first: they must not overwrite this assignment later)
         self._d[k] = v
         self._dirty.add(k)
         if k == "tex.data":
@@ -457,6 +469,8 @@ class SceneParameters:
         self._dirty.add(name + ".__pose__")
 
     def update(self):
+        if self._pending is not None:
+            self._pending()
         self._scene._apply(self._dirty)
         self._dirty = set()
 
@@ -515,6 +529,8 @@ class Scene:
         # render streams, "caller_stream" = the plain forward on the caller's stream (a texture written in place since its assignment,
         # device material tables, base-colour textures, FFX_RENDER_STREAMS=1), "autograd" = through functional.render (tex.data requires grad)
         self.render_paths = {"two_stream": 0, "caller_stream": 0, "autograd": 0}
+        # which way each geometry push went: "native" = one ffx_scene_step_h call for the whole sample (step_native), "python" = params.update()
+        self.update_paths = {"native": 0, "python": 0}
         self._tex_src = self._tex_ready = self._tex_private = None
         self._tex_ver = -1
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
@@ -647,84 +663,94 @@ class Scene:
         geom_dirty = False
         albedo_dirty = False
         plan = self._key_plan
-        for k in dirty:
-            kp = plan.get(k)
-            if kp is not None:
-                # (a key seen before: what it means was worked out then — 19 keys per randomisation went through the string handling below, 25 us)
-                if kp is _POSE_KEY:
+        # (`specular` last: Mitsuba's principled plugin re-derives eta from it whenever it is among the updated keys [EXT principled.cpp
+        # parameters_changed], so it overrides an `eta` assigned in the same update — and the result must not depend on the order a set is walked in)
+        late = []
+        for keys in (dirty, late):
+            for k in keys:
+                kp = plan.get(k)
+                if kp is not None:
+                    # (a key seen before: what it means was worked out then — 19 keys per randomisation went through the string handling below, 25 us)
+                    if kp is _POSE_KEY:
+                        geom_dirty = True
+                    elif kp is not _PLAIN_KEY:
+                        col, rows, conv, eta_key, warn_st = kp
+                        if conv and keys is dirty:
+                            late.append(k)
+                            continue
+                        v = self._params._d[k]
+                        v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
+                        if conv:  # `specular`: the plugin re-derives eta from it
+                            v = scenes.specular_to_eta(v)
+                            self._params._d[eta_key] = Float(v)
+                        if warn_st and v > 0.0:
+                            self._warn_spec_trans(k)
+                        for i in rows:
+                            self._albedo_host[i, col] = v
+                        albedo_dirty = True
+                    continue
+                base, _, rest = k.partition(".")
+                if rest == "__pose__":
                     geom_dirty = True
-                elif kp is not _PLAIN_KEY:
-                    col, rows, conv, eta_key, warn_st = kp
+                    plan[k] = _POSE_KEY
+                elif rest == "vertex_positions" and base in self._mesh_index:
+                    # generic Mitsuba-style path: the caller transformed the vertices itself
+                    v = self._params._d[k]
+                    v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v)
+                    self._set_pose(base, torch.eye(4), None, v)
+                    geom_dirty = True
+                elif rest.startswith("brdf_0.") and rest not in ("brdf_0.base_color.value", "brdf_0.base_color.data") and base in self._material_meshes:
+                    # principled-BSDF parameters (specular, roughness, clearcoat, ...; the reference randomises them:
+                    # main.py:97-107, examples/vocalfold_scene.py:93)
+                    name = rest[len("brdf_0."):]
+                    name = name[:-len(".value")] if name.endswith(".value") else name
+                    if name == "specular" and keys is dirty:
+                        late.append(k)
+                        continue
+                    if not self._material_principled.get(base, False):
+                        # a diffuse material has no such parameters in Mitsuba; accepted so that the scripts run — say so once
+                        if not getattr(self, "_warned_bsdf", False):
+                            import warnings
+
+                            warnings.warn(f"{k}: material {base!r} is diffuse — principled-BSDF parameters do not affect it "
+                                          "(declare it principled: scenes.MeshData(bsdf={...}) or <bsdf type=\"principled\">); "
+                                          "further assignments of such parameters are not reported", stacklevel=4)
+                            self._warned_bsdf = True
+                        continue
                     v = self._params._d[k]
                     v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
-                    if conv:  # `specular`: the plugin re-derives eta from it
-                        v = scenes.specular_to_eta(v)
-                        self._params._d[eta_key] = Float(v)
-                    if warn_st and v > 0.0:
+                    if name == "specular":  # the plugin re-derives eta from it (principled.cpp parameters_changed)
+                        col, v = scenes.MAT_COLUMN["eta"], scenes.specular_to_eta(v)
+                        self._params._d[base + ".brdf_0.eta"] = Float(v)
+                    elif name in scenes.MAT_COLUMN and name != "model":
+                        col = scenes.MAT_COLUMN[name]
+                    else:
+                        raise KeyError(f"{k}: not a parameter of the principled BSDF")
+                    if name == "spec_trans" and v > 0.0:
                         self._warn_spec_trans(k)
-                    for i in rows:
+                    for i in self._material_meshes[base]:
                         self._albedo_host[i, col] = v
                     albedo_dirty = True
-                continue
-            base, _, rest = k.partition(".")
-            if rest == "__pose__":
-                geom_dirty = True
-                plan[k] = _POSE_KEY
-            elif rest == "vertex_positions" and base in self._mesh_index:
-                # generic Mitsuba-style path: the caller transformed the vertices itself
-                v = self._params._d[k]
-                v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v)
-                self._set_pose(base, torch.eye(4), None, v)
-                geom_dirty = True
-            elif rest.startswith("brdf_0.") and rest not in ("brdf_0.base_color.value", "brdf_0.base_color.data") and base in self._material_meshes:
-                # principled-BSDF parameters (specular, roughness, clearcoat, ...; the reference randomises them:
-                # main.py:97-107, examples/vocalfold_scene.py:93)
-                name = rest[len("brdf_0."):]
-                name = name[:-len(".value")] if name.endswith(".value") else name
-                if not self._material_principled.get(base, False):
-                    # a diffuse material has no such parameters in Mitsuba; accepted so that the scripts run — say so once
-                    if not getattr(self, "_warned_bsdf", False):
-                        import warnings
-
-                        warnings.warn(f"{k}: material {base!r} is diffuse — principled-BSDF parameters do not affect it "
-                                      "(declare it principled: scenes.MeshData(bsdf={...}) or <bsdf type=\"principled\">); "
-                                      "further assignments of such parameters are not reported", stacklevel=4)
-                        self._warned_bsdf = True
-                    continue
-                v = self._params._d[k]
-                v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
-                if name == "specular":  # the plugin re-derives eta from it (principled.cpp parameters_changed)
-                    col, v = scenes.MAT_COLUMN["eta"], scenes.specular_to_eta(v)
-                    self._params._d[base + ".brdf_0.eta"] = Float(v)
-                elif name in scenes.MAT_COLUMN and name != "model":
-                    col = scenes.MAT_COLUMN[name]
+                    plan[k] = (col, tuple(self._material_meshes[base]), name == "specular", base + ".brdf_0.eta", name == "spec_trans")
+                elif rest == "brdf_0.base_color.data" and any(n == base for n, _ in self._base_tex):
+                    # a new base-colour texture (main.py:147-153 assigns one per iteration, through numpy): any resolution, [h,w,3]
+                    v = self._params._d[k]
+                    v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(np.asarray(v, np.float32))
+                    if v.dim() != 3 or v.shape[-1] != 3:
+                        raise ValueError(f"{k}: expected a [height, width, 3] texture, got {tuple(v.shape)}")
+                    v = v.detach().to(self.device, torch.float32).contiguous()
+                    self._base_tex = [(n, v if n == base else t) for n, t in self._base_tex]
+                    self._params._d[k] = TensorXf(v)
+                elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
+                    c = self._params._d[k]
+                    c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]
+                    c = c.detach().cpu().numpy()
+                    for i in self._material_meshes[base]:
+                        self._albedo_host[i, :3] = c
+                    albedo_dirty = True
                 else:
-                    raise KeyError(f"{k}: not a parameter of the principled BSDF")
-                if name == "spec_trans" and v > 0.0:
-                    self._warn_spec_trans(k)
-                for i in self._material_meshes[base]:
-                    self._albedo_host[i, col] = v
-                albedo_dirty = True
-                plan[k] = (col, tuple(self._material_meshes[base]), name == "specular", base + ".brdf_0.eta", name == "spec_trans")
-            elif rest == "brdf_0.base_color.data" and any(n == base for n, _ in self._base_tex):
-                # a new base-colour texture (main.py:147-153 assigns one per iteration, through numpy): any resolution, [h,w,3]
-                v = self._params._d[k]
-                v = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(np.asarray(v, np.float32))
-                if v.dim() != 3 or v.shape[-1] != 3:
-                    raise ValueError(f"{k}: expected a [height, width, 3] texture, got {tuple(v.shape)}")
-                v = v.detach().to(self.device, torch.float32).contiguous()
-                self._base_tex = [(n, v if n == base else t) for n, t in self._base_tex]
-                self._params._d[k] = TensorXf(v)
-            elif rest == "brdf_0.base_color.value" and base in self._material_meshes:
-                c = self._params._d[k]
-                c = (c.t if isinstance(c, _ArrayBase) else torch.as_tensor(c, dtype=torch.float32)).reshape(-1)[:3]
-                c = c.detach().cpu().numpy()
-                for i in self._material_meshes[base]:
-                    self._albedo_host[i, :3] = c
-                albedo_dirty = True
-            else:
-                if not (rest.startswith("brdf_0.") or rest == "vertex_positions"):
-                    plan[k] = _PLAIN_KEY  # (an emitter / sensor / texture parameter: read when the scene description is formed)
+                    if not (rest.startswith("brdf_0.") or rest == "vertex_positions"):
+                        plan[k] = _PLAIN_KEY  # (an emitter / sensor / texture parameter: read when the scene description is formed)
         if albedo_dirty:
             if self._mats_in_sd:
                 self._albedo_stale = True  # the next scene_desc() carries the new rows; the device tensor is refreshed on demand
@@ -747,7 +773,134 @@ class Scene:
             # the renders of this pose will come from the camera / emitter positions the parameters hold NOW (every assignment of
             # the update has been applied above): their apex records are written behind the re-fit, on its side stream, and the
             # render launches without a pre-pass (ops.DeviceGeometry.update; the description is built here instead of in render())
+            self.update_paths["python"] += 1
             self.geom.update(self._xforms, self._offs, apex_sd=self.scene_desc(tex_channels=ch) if self._apex_ahead else None)
+
+    # ------------------------------------------------------------------ the native params.update() (include/ffx.h ffx_scene_step_h)
+    # A scene sample drawn by the native randomiser (ffx_scene_randomize_h) reaches the device in ONE call: its key writes — poses into
+    # the description's to_world blocks, the spot's attributes, material attributes into the material rows, mesh poses into the transform
+    # table — are compiled once into a table of ops, from what _apply / scene_desc() LEARNED about each key when the Python path pushed a
+    # sample (`_key_plan`, `_key_dyn`): the native path can only do what the Python path was seen doing, and anything it was not — a key
+    # that rebuilds the description, caller-supplied vertices, a device material table — keeps the Python path (fireflies_amd/scene.py).
+    def compile_step(self, poses, values, meshes, n_draws, n_ents):
+        """poses: [(entity row, parameter key)], values: [(draw row, values per draw, repeat, parameter key)], meshes: [(entity row, mesh
+        name)] — the writes of Scene._apply_native.  -> the compiled plan, or None (not compilable, or not yet: a key never pushed before)"""
+        g = self.geom
+        if not (self._apex_ahead and g._async and g.n_shapes <= 32 and self.device.type == "cuda") or ops._lane_kernels():
+            return None
+        d, stride = self.data, self._mat_stride
+        sd_pose = {d.camera.name + ".to_world": _SD_CAM_TW}
+        if d.projector is not None:
+            sd_pose["Projector.to_world"] = _SD_PROJ_TW
+        spot = d.spot.name if d.spot is not None else None
+        if spot is not None:
+            sd_pose[spot + ".to_world"] = _SD_SPOT_TW
+        out, eta, late, warn = [], [], [], []
+        for row, key in poses:
+            if self._key_dyn.get(key) is not True:
+                return None
+            dst = sd_pose.get(key)
+            if dst is not None:  # (any other entity's pose is no part of the description)
+                out.append((_abi.STEP_POSE_SD, row, 0, dst, 0, 0))
+        for drow, n, rep, key in values:
+            if self._key_dyn.get(key) is not True:
+                return None
+            comp = (lambda j: j) if (rep == 1 and n == 3) else (lambda j: 0)
+            kp = self._key_plan.get(key)
+            if kp is None:
+                base, _, rest = key.partition(".")
+                if rest == "brdf_0.base_color.value" and base in self._material_meshes and (n == 3 or rep == 3):
+                    for i in self._material_meshes[base]:
+                        out += [(_abi.STEP_VALUE_MAT, drow, comp(j), i * stride + j, 0, 0) for j in range(3)]
+                    continue
+                return None
+            if kp is _POSE_KEY:
+                return None
+            if kp is _PLAIN_KEY:
+                if spot is not None and key == spot + ".intensity.value":
+                    if not (n == 3 or rep == 3):
+                        return None
+                    out += [(_abi.STEP_VALUE_SD, drow, comp(j), _SD_SPOT_INT + j, 0, 0) for j in range(3)]
+                elif spot is not None and key in (spot + ".cutoff_angle", spot + ".beam_width"):
+                    if n != 1 or rep != 1:
+                        return None
+                    out.append((_abi.STEP_VALUE_SD, drow, 0, _SD_SPOT_INT + (3 if key.endswith("cutoff_angle") else 4), 0, 0))
+                continue  # (anything else that is plain and per-step is no part of the description)
+            col, rows, conv, eta_key, warn_st = kp
+            if warn_st:
+                warn.append((key, drow))  # (a value > 0 is reported once per scene: step_native looks)
+            (late if conv else out).extend((_abi.STEP_VALUE_MAT, drow, 0, i * stride + col, 1 if conv else 0, 0) for i in rows)
+            if conv:
+                eta.append((eta_key, drow))
+        out += late  # (`specular` -> eta after everything else, as in _apply)
+        has_mat = any(o[0] == _abi.STEP_VALUE_MAT for o in out)
+        if has_mat and not self._mats_in_sd:
+            return None  # (a material table on the device is uploaded by the Python path)
+        for row, name in meshes:
+            out.append((_abi.STEP_MESH, row, 0, self._mesh_index[name], 0, 0))
+        sp = _StepPlan()
+        sp.ops = (_abi.StepOp * max(len(out), 1))()
+        for o, t in zip(sp.ops, out):
+            o.kind, o.src, o.comp, o.dst, o.conv, o.mode = t
+        S = g.n_shapes
+        sp.tabs = [np.ascontiguousarray(a, np.int32) for a in (self._base_off, self._stride, self._n_frames)]
+        sp.plan = _abi.StepPlan()
+        sp.plan.ops, sp.plan.n_ops, sp.plan.n_shapes, sp.plan.n_draws, sp.plan.n_ents = sp.ops, len(out), S, int(n_draws), int(n_ents)
+        sp.plan.frame_base, sp.plan.frame_stride, sp.plan.n_frames = (t.ctypes.data_as(C.POINTER(C.c_int32)) for t in sp.tabs)
+        sp.plan.n_mat_floats = int(self._albedo_host.size) if self._mats_in_sd else 0
+        sp.frames = (C.c_int32 * S)(*([-1] * S))
+        sp.mesh_shapes = [self._mesh_index[name] for _, name in meshes]
+        sp.eta, sp.has_mat, sp.warn = eta, has_mat, warn
+        sp.geoms = []
+        for b in g._blobs:
+            gs = _abi.StepGeom()
+            gs.bvh, gs.info = b.data_ptr(), C.pointer(g.info)
+            gs.src_verts, gs.tris, gs.tri_shape = g.src_verts.data_ptr(), g.tris.data_ptr(), g.tri_shape.data_ptr()
+            gs.smooth = C.pointer(g._smooth[0]) if g._smooth is not None else None
+            sp.geoms.append(gs)
+        sp.pool = g.src_verts  # (the tensors whose addresses the blocks hold)
+        sp.fn = ops.api().lib.ffx_scene_step_h
+        return sp
+
+    def step_native(self, sp, values, chain, unc, frames):
+        """one scene sample through ffx_scene_step_h.  values [n_draws,4], chain / unc [n_ents,16]: rows of the native randomiser's tables (float32,
+        contiguous); frames: per posed mesh of the plan the pool frame of this sample.  False: not this time (the caller takes the Python path)"""
+        p = self._params
+        if p._dirty and not (len(p._dirty) == 1 and "tex.data" in p._dirty):
+            return False  # (assignments of the caller's own are pending: params.update() applies them in its order)
+        ch = self._sd_cache[0] if self._sd_cache is not None else 3
+        tm = self._sd_templates.get(ch)
+        if tm is None or tm[0] != (self.shadows, tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0):
+            return False
+        g = self.geom
+        if g.timing is not None or g.src_verts is not sp.pool:
+            return False
+        fr = sp.frames
+        for s, f in zip(sp.mesh_shapes, frames):
+            fr[s] = f
+        sd = _abi.SceneDesc()
+        sd._frozen = True  # (never written again once the call has filled it in: ops.apex_key may remember its key on it)
+        ptrs = sp.ptrs
+        if ptrs is None or ptrs[3] is not self._albedo_host:  # (host tables only ever written in place: their addresses are taken once)
+            ptrs = sp.ptrs = (self._xforms.data_ptr(), self._offs.ctypes.data, self._albedo_host.ctypes.data if sp.plan.n_mat_floats else None, self._albedo_host)
+
+        def launch(i, stream):
+            rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, tm[1], sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], 1, stream)
+            if rc != 0:
+                ops.api().check(rc, "ffx_scene_step_h")
+            return sd
+
+        g.update_native(launch, self._offs)
+        self.update_paths["native"] += 1
+        if sp.warn and not getattr(self, "_warned_spec_trans", False):
+            for key, drow in sp.warn:
+                if values[drow, 0] > 0.0:
+                    self._warn_spec_trans(key)
+        p._dirty = set()
+        if sp.has_mat:
+            self._albedo_stale = True
+        self._sd_cache = (ch, sd)
+        return True
 
     def _note_texture(self, v):
         """`params["tex.data"] = v`: from here on the texture is this tensor as the current stream leaves it — what a render stream waits for"""

@@ -624,6 +624,30 @@ class DeviceGeometry:
                 ev.record(self._side)
         self._cur = nxt
 
+    def update_native(self, launch, vert_off):
+        """update() for a caller whose ONE native call enqueues the re-fit and the pre-pass (mi.Scene.step_native -> ffx_scene_step_h):
+        the same blob rotation and ordering.  launch(blob index, side stream handle) -> the scene description whose apex records and
+        tile bins the blob then holds; vert_off: the frame offsets [S] the call used (host int32, already checked by it)."""
+        self.version += 1
+        nxt = (self._cur + 1) % len(self._blobs)
+        self._wait_readers(nxt, self._side)
+        if self._pool_written is not None:
+            self._side.wait_event(self._pool_written)
+        ev = self._upd_done[nxt]
+        if ev is None:
+            ev = self._upd_done[nxt] = torch.cuda.Event()
+        sh = self._side_handle
+        if sh is None:
+            sh = self._side_handle = C.c_void_p(self._side.cuda_stream)
+        self._apex[nxt] = None
+        self._apex_written[nxt] = None
+        sd = launch(nxt, sh)
+        np.copyto(self._vert_off_host, vert_off)
+        self._vert_off_dev_stale = True
+        self._apex[nxt] = apex_key(sd)
+        ev.record(self._side)
+        self._cur = nxt
+
     def _prepare_apex(self, i, sd, stream=None):
         """(on the stream the re-fit of blob i was enqueued on) the records changed: what the apex areas held is void"""
         self._apex[i] = None

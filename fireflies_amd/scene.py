@@ -17,6 +17,7 @@ from typing import List
 import torch
 
 from . import emitter, entity, material, mi, ops, sampling
+from . import scenes as _scenes
 
 
 def _seed_generators(seed: int) -> None:
@@ -160,6 +161,8 @@ class Scene:
         self._camera = None
         self._lights = []
         self._native_chain = None  # set while _apply_native pushes a native call's tables (see _write_pose)
+        self._pushed_natively = False  # set while _materialise tells the parameter map what the device already has
+        self._lazy = None  # the natively pushed scene sample whose values the entities and the parameter map have not been told yet (_materialise)
         self._curves = []
         self._materials = []
         self._transformables = []
@@ -328,19 +331,24 @@ class Scene:
     def _write_attributes(self, ent) -> None:
         p = self._mitsuba_params
         # host copies made by the entity's _compose (one transfer per randomisation, not one sync per attribute)
+        # (behind a native push — _apply_native — the values are only recorded: the device already has them)
+        put = p._d.__setitem__ if self._pushed_natively else p.__setitem__
         for key, value in ent._host_float_attributes.items():
             full = ent.name() + "." + key
-            p[full] = type(p[full])(value)
+            put(full, type(p[full])(value))
         for key, value in ent._host_vec3_attributes.items():
             full = ent.name() + "." + key
-            p[full] = type(p[full])(value)
+            put(full, type(p[full])(value))
 
     def _write_pose(self, ent) -> None:
         nc = self._native_chain  # (inside _apply_native: the entity's world matrix is a row of the native call's chain table — _world_host()'s product, bit for bit)
         if nc is not None:
             i = nc[1].get(id(ent))
             if i is not None and hasattr(mi.Transform4f, "_from_rows"):
-                self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f._from_rows(nc[0][i])
+                if self._pushed_natively:
+                    self._mitsuba_params._d[ent.name() + ".to_world"] = mi.Transform4f._from_rows(nc[0][i])
+                else:
+                    self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f._from_rows(nc[0][i])
                 return
         self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f(ent._world_host().tolist())
 
@@ -578,15 +586,10 @@ class Scene:
 
     def _apply_native(self, plan, vals, mats, k, picks) -> None:
         """phase 2 + push for sample k of a native call: entity state from the tables, parameter writes, ONE device pass"""
-        v = vals[k].tolist()
-        loc = mats[0][k]
-        for i, e, dt, dr in plan.posed:
-            e._randomized_world = torch.from_numpy(loc[i].reshape(4, 4))
-            e._last_draw = (v[dt][:3], v[dr][:3])
-        for e, fl, v3 in plan.attrs:
-            e._host_float_attributes = {key: v[d][0] for key, d in fl}
-            e._host_vec3_attributes = {key: (v[d][:3] if rep == 1 else [v[d][0]] * 3) for key, d, rep in v3}
-            e._randomized_float_attributes = e._randomized_vec3_attributes = None
+        if self._push_native(plan, vals, mats, k, picks):
+            return
+        self._materialise()  # (a pending sample first: this one then writes over it key by key)
+        self._entity_state(plan, vals, mats, k)
         p = self._mitsuba_params
         if hasattr(p, "set_mesh_pose_np"):  # our parameter object: poses straight from the tables
             chain, unc = mats[1][k], mats[2][k]
@@ -623,6 +626,107 @@ class Scene:
         finally:
             self._native_chain = None
         p.update()
+
+    # ---- the native params.update() (include/ffx.h ffx_scene_step_h; mi.Scene.compile_step / step_native): the sample's tables go to the
+    # device in ONE call — description, transform table, re-fit and pre-pass launches — and the parameter map is only told the values
+    # afterwards (a script may read them back; nothing is pushed twice).  The reference writes key after key and lets Mitsuba's
+    # params.update() find out what changed (fireflies/scene.py:243-342,384).  Compiled from what the Python path below was SEEN to do
+    # with each key, hence available from the second sample of a configuration on; FFX_NATIVE_UPDATE=0 keeps the Python path.
+    def _step_plan(self, plan):
+        import os
+
+        sp = getattr(plan, "step", None)
+        if sp is not None or getattr(plan, "step_tries", 0) >= 4:
+            return sp
+        p = self._mitsuba_params
+        ms = getattr(p, "_scene", None)
+        if ms is None or not hasattr(ms, "compile_step") or os.environ.get("FFX_NATIVE_UPDATE", "1") == "0" or not getattr(self, "native_update", True):
+            plan.step_tries = 4
+            return None
+        plan.step_tries = getattr(plan, "step_tries", 0) + 1
+        keys = p.keys()
+        pushed = [e for e in ([self._camera, self._projector] + list(self._lights)) if e is not None and e.randomizable()]
+        poses = [(plan.row_of[id(e)], e.name() + ".to_world") for e in pushed if id(e) in plan.row_of and e.name() + ".to_world" in keys]
+        writers = {id(e) for e in pushed + [m for m in self._materials if m.randomizable()]}
+        values = []
+        for e, fl, v3 in plan.attrs:
+            if id(e) not in writers:
+                continue
+            values += [(d, int(plan.draws[d].n), 1, e.name() + "." + key) for key, d in fl]
+            values += [(d, int(plan.draws[d].n), rep, e.name() + "." + key) for key, d, rep in v3]
+        if any(full not in keys for _, _, _, full in values):
+            plan.step_tries = 4  # (the Python path raises KeyError for it: let it)
+            return None
+        meshes = [(i, m.name()) for m, i in zip(self._meshes, plan.mesh_rows) if m.randomizable()]
+        plan.step = ms.compile_step(poses, values, meshes, plan.n_draws, plan.n_ents)
+        if plan.step is not None:
+            for e in self._draw_order():
+                e.__dict__["_lazy_owner"] = self  # (entity.base._Lazy: whom to ask for a pending sample's values)
+        return plan.step
+
+    def _push_native(self, plan, vals, mats, k, picks) -> bool:
+        sp = self._step_plan(plan)
+        if sp is None:
+            return False
+        frames = []
+        for m, pick in zip(self._meshes, picks):
+            if not m.randomizable():
+                continue
+            if pick is None:
+                frames.append(0)
+                continue
+            pool = getattr(m, "_pool_frames", None)
+            if pick[0] == "func" or pool is None:
+                return False  # (vertices the caller supplies travel through the vertex pool: the Python path)
+            frames.append(pool[pick[1]][0] + pick[2])
+        p = self._mitsuba_params
+        lz = self._lazy
+        if lz is not None and lz[0] is not plan:
+            self._materialise()  # (another configuration's sample: its entities need not be this one's)
+        if not p._scene.step_native(sp, vals[k], mats[1][k], mats[2][k], frames):
+            return False
+        # what the sample means for the parameter map and the entities is worked out when somebody looks (_materialise): the device has it all
+        self._lazy = (plan, vals, mats, k, sp)
+        p._pending = self._materialise
+        return True
+
+    def _materialise(self) -> None:
+        """the pending natively pushed sample -> entity state and parameter map (not dirty: nothing is pushed twice)"""
+        lz = self._lazy
+        if lz is None:
+            return
+        plan, vals, mats, k, sp = lz
+        p = self._mitsuba_params
+        self._lazy = None
+        p._pending = None
+        v = self._entity_state(plan, vals, mats, k)
+        self._native_chain = (mats[1][k], plan.row_of)
+        self._pushed_natively = True
+        try:
+            if self._camera is not None:
+                self.update_camera()
+            if self._projector is not None:
+                self.update_projector()
+            self.update_lights()
+            self.update_materials()
+        finally:
+            self._native_chain = None
+            self._pushed_natively = False
+        for eta_key, drow in sp.eta:
+            p._d[eta_key] = mi.Float(_scenes.specular_to_eta(v[drow][0]))
+
+    @staticmethod
+    def _entity_state(plan, vals, mats, k):
+        v = vals[k].tolist()
+        loc = mats[0][k]
+        for i, e, dt, dr in plan.posed:
+            e._randomized_world = torch.from_numpy(loc[i].reshape(4, 4))
+            e._last_draw = (v[dt][:3], v[dr][:3])
+        for e, fl, v3 in plan.attrs:
+            e._host_float_attributes = {key: v[d][0] for key, d in fl}
+            e._host_vec3_attributes = {key: (v[d][:3] if rep == 1 else [v[d][0]] * 3) for key, d, rep in v3}
+            e._randomized_float_attributes = e._randomized_vec3_attributes = None
+        return v
 
     def randomize(self) -> None:
         plan = self._native_plan()

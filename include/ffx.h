@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 7
+#define FFX_ABI_VERSION 8
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -641,6 +641,57 @@ int ffx_render_bwd_det(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[ho
  * sd->cam.to_world, sd->proj.{enabled,to_world} and sd->spot.{enabled,to_world} are read.  No reference counterpart (Mitsuba
  * builds its acceleration structure inside params.update(), /root/reference/fireflies/scene.py:384). */
 int ffx_apex_prepare(void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One scene sample pushed to the device in ONE call (ABI 8): the native params.update().
+ * Replaces, for a sample drawn by ffx_scene_randomize_h, what the reference does between the draws and the render
+ * (fireflies/scene.py:243-342: update_meshes, update_camera, update_projector, update_lights, update_materials write the
+ * randomised poses and attributes into Mitsuba's parameter map one key at a time; scene.py:384: params.update() pushes them and
+ * rebuilds the acceleration structure): the randomiser's output tables go straight into the scene description of the next renders,
+ * the per-shape transform table and the re-fit + pre-pass launches — no parameter map in between.
+ * `ops` is the compiled form of those key writes (the caller works it out once per sampler configuration):
+ *   FFX_STEP_POSE_SD    chain[src] (16 floats)                    -> sd float word `dst` .. dst + 15 (a to_world block)
+ *   FFX_STEP_VALUE_SD   values[src][comp]                         -> sd float word `dst`   (spot intensity / cutoff / beam width)
+ *   FFX_STEP_VALUE_MAT  values[src][comp], conv 1: eta = 2 / (1 - sqrt(0.08 v)) - 1 in double, Mitsuba's specular -> eta
+ *                                                                 -> mat_rows[dst]        (row x stride + column of the material table)
+ *   FFX_STEP_MESH       mode 0: chain_uncentred[src], mode 1: chain[src] -> xform[dst]     (shape dst's transform)
+ * in the order given (a later op overwrites an earlier one, as a later key write would).  `frames`: per shape the animation frame
+ * of this sample (vert_off[shape] = frame_base + frame x frame_stride, checked against n_frames) or -1: vert_off stays.
+ * sd_out = *tmpl with the ops applied and, when tmpl->n_mat_h > 0, the whole of mat_rows copied into mat_h (the caller's table
+ * stays the one source of the rows).  Then, unless geom == NULL (description and tables only — also the form the CPU tests call):
+ * ffx_scene_update_h(geom..., vert_off, xform) and ffx_apex_prepare(geom->bvh, sd_out) on `stream`. */
+#define FFX_STEP_POSE_SD 0
+#define FFX_STEP_VALUE_SD 1
+#define FFX_STEP_VALUE_MAT 2
+#define FFX_STEP_MESH 3
+typedef struct ffx_step_op {
+  int32_t kind, src, comp, dst;
+  int32_t conv, mode, pad[2];
+} ffx_step_op;
+typedef struct ffx_step_plan {
+  const ffx_step_op *ops; /* [host][n_ops] */
+  int32_t n_ops, n_shapes;
+  int32_t n_draws, n_ents;           /* rows of values / chain / chain_uncentred (bounds of the ops' src) */
+  const int32_t *frame_base;         /* [host][n_shapes] pool offset of each shape's frame 0 */
+  const int32_t *frame_stride;       /* [host][n_shapes] vertices per frame */
+  const int32_t *n_frames;           /* [host][n_shapes] */
+  int32_t n_mat_floats;              /* floats of mat_rows (n_shapes x stride), 0: no material table on the host */
+  int32_t pad;
+} ffx_step_plan;
+typedef struct ffx_step_geom {
+  void *bvh;                  /* [dev] the blob this sample is re-fitted into */
+  const ffx_bvh_info *info;   /* [host] */
+  const float *src_verts;     /* [dev] */
+  const int32_t *tris;        /* [dev] */
+  const int32_t *tri_shape;   /* [dev] */
+  const ffx_smooth *smooth;   /* [host] or NULL */
+} ffx_step_geom;
+int ffx_scene_step_h(const ffx_step_plan *plan /*[host]*/, const float *values /*[host][n_draws,4]*/, const float *chain /*[host][n_ents,16]*/,
+                     const float *chain_uncentred /*[host][n_ents,16]*/, const int32_t *frames /*[host][n_shapes] or NULL*/,
+                     const ffx_scene_desc *tmpl /*[host]*/, ffx_scene_desc *sd_out /*[host]*/, float *mat_rows /*[host] in/out, or NULL*/,
+                     float *xform /*[host][n_shapes,16] in/out*/, int32_t *vert_off /*[host][n_shapes] in/out*/,
+                     const ffx_step_geom *geom /*[host] or NULL*/, int prepare_apex, ffx_stream stream);
+
 size_t ffx_render_cache_bytes(int width, int height, int spp); /* Lambert scenes (mat_stride 0 / 3) */
 /* the same for any scene: with material rows the cache holds a second footprint per pixel (the part of the BSDF
  * that does not scale with base_color): 67.1 MB at 512x512x64; with sd->rfilter != 0 the size of the filtered film's cache

@@ -2249,3 +2249,76 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   }
   return rc;
 }
+
+/* One scene sample pushed in one call (include/ffx.h ffx_scene_step_h, ABI 8), restated key write by key write:
+ *   fireflies/scene.py:243-251  update_meshes: a posed mesh's vertices = chain x un-centring applied to its frame (here: the shape's transform row and
+ *                               the frame's pool offset, the vertices are transformed by the update below)
+ *   fireflies/scene.py:253-262  update_camera / update_projector: `<name>.to_world` = the entity's world()
+ *   fireflies/scene.py:264-322  update_lights: `to_world` and the float / vec3 attributes of every randomisable light
+ *   fireflies/scene.py:324-342  update_materials: the float / vec3 attributes of every randomisable material
+ *   fireflies/scene.py:384      params.update(): here the re-fit (ffx_scene_update_h) and the apex pre-pass (a no-op in this library)
+ * The description is built in a local copy and handed over only when every op has been applied. */
+static int step_src_ok(const ffx_step_plan *p, const ffx_step_op *o) {
+  const int from_ents = o->kind == FFX_STEP_POSE_SD || o->kind == FFX_STEP_MESH;
+  return o->src >= 0 && o->src < (from_ents ? p->n_ents : p->n_draws) && (from_ents || (o->comp >= 0 && o->comp <= 3));
+}
+int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, const float *chain, const float *chain_uncentred, const int32_t *frames,
+                     const ffx_scene_desc *tmpl, ffx_scene_desc *sd_out, float *mat_rows, float *xform, int32_t *vert_off,
+                     const ffx_step_geom *geom, int prepare_apex, ffx_stream stream) {
+  if (!plan || !tmpl || !sd_out || !xform || !vert_off) FAIL(FFX_ERR_ARG, "scene_step_h: bad argument");
+  if (plan->n_ops < 0 || (plan->n_ops && !plan->ops) || plan->n_shapes < 1 || plan->n_shapes > FFX_MAX_SHAPES_H || plan->n_draws < 0 || plan->n_ents < 0)
+    FAIL(FFX_ERR_ARG, "scene_step_h: bad argument");
+  if ((plan->n_draws && !values) || (plan->n_ents && (!chain || !chain_uncentred))) FAIL(FFX_ERR_ARG, "scene_step_h: bad argument");
+  if (plan->n_mat_floats < 0 || plan->n_mat_floats > FFX_MAX_MAT_H || (plan->n_mat_floats && !mat_rows))
+    FAIL(FFX_ERR_ARG, "scene_step_h: material table of %d floats (at most %d, and then mat_rows must be given)", plan->n_mat_floats, FFX_MAX_MAT_H);
+  if (tmpl->n_mat_h > 0 && tmpl->n_mat_h != plan->n_mat_floats)
+    FAIL(FFX_ERR_ARG, "scene_step_h: the template carries %d material floats, the plan %d", tmpl->n_mat_h, plan->n_mat_floats);
+  const int words = (int)(sizeof(ffx_scene_desc) / 4);
+  for (int i = 0; i < plan->n_ops; ++i) {
+    const ffx_step_op *o = &plan->ops[i];
+    int span = 0, limit = 0;
+    if (o->kind == FFX_STEP_POSE_SD) { span = 16; limit = words; }
+    else if (o->kind == FFX_STEP_VALUE_SD) { span = 1; limit = words; }
+    else if (o->kind == FFX_STEP_VALUE_MAT) { span = 1; limit = plan->n_mat_floats; }
+    else if (o->kind == FFX_STEP_MESH) { span = 1; limit = plan->n_shapes; }
+    const int flags_ok = (o->kind != FFX_STEP_VALUE_MAT || o->conv == 0 || o->conv == 1) && (o->kind != FFX_STEP_MESH || o->mode == 0 || o->mode == 1);
+    if (!span || !step_src_ok(plan, o) || o->dst < 0 || o->dst + span > limit || !flags_ok)
+      FAIL(FFX_ERR_ARG, "scene_step_h: op %d (kind %d, src %d, comp %d, dst %d) out of range", i, o->kind, o->src, o->comp, o->dst);
+  }
+  if (frames) {
+    if (!plan->frame_base || !plan->frame_stride || !plan->n_frames) FAIL(FFX_ERR_ARG, "scene_step_h: frames without the frame tables");
+    for (int s = 0; s < plan->n_shapes; ++s)
+      if (frames[s] >= plan->n_frames[s]) FAIL(FFX_ERR_ARG, "scene_step_h: shape %d: frame %d out of range [0, %d)", s, frames[s], plan->n_frames[s]);
+  }
+  ffx_scene_desc sd = *tmpl;
+  float w[sizeof(ffx_scene_desc) / 4];
+  memcpy(w, &sd, sizeof sd);
+  for (int i = 0; i < plan->n_ops; ++i) {
+    const ffx_step_op *o = &plan->ops[i];
+    if (o->kind == FFX_STEP_POSE_SD) {
+      memcpy(w + o->dst, chain + 16 * (size_t)o->src, 16 * sizeof(float)); /* `<name>.to_world` = world() */
+    } else if (o->kind == FFX_STEP_VALUE_SD) {
+      w[o->dst] = values[4 * (size_t)o->src + o->comp];
+    } else if (o->kind == FFX_STEP_VALUE_MAT) {
+      float v = values[4 * (size_t)o->src + o->comp];
+      if (o->conv) { /* Mitsuba's principled plugin re-derives eta from `specular` [EXT principled.cpp parameters_changed] */
+        double root = sqrt(0.08 * (double)v);
+        v = (float)(2.0 / (1.0 - root) - 1.0);
+      }
+      mat_rows[o->dst] = v;
+    } else {
+      memcpy(xform + 16 * (size_t)o->dst, (o->mode ? chain : chain_uncentred) + 16 * (size_t)o->src, 16 * sizeof(float));
+    }
+  }
+  memcpy(&sd, w, sizeof sd);
+  if (tmpl->n_mat_h > 0) memcpy(sd.mat_h, mat_rows, sizeof(float) * (size_t)plan->n_mat_floats);
+  *sd_out = sd;
+  if (frames)
+    for (int s = 0; s < plan->n_shapes; ++s)
+      if (frames[s] >= 0) vert_off[s] = plan->frame_base[s] + frames[s] * plan->frame_stride[s];
+  if (!geom) return FFX_OK;
+  if (!geom->bvh || !geom->info || !geom->src_verts || !geom->tris || !geom->tri_shape) FAIL(FFX_ERR_ARG, "scene_step_h: incomplete geometry block");
+  int rc = ffx_scene_update_h(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth, stream);
+  if (rc != FFX_OK || !prepare_apex) return rc;
+  return ffx_apex_prepare(geom->bvh, geom->info, &sd, stream);
+}

@@ -597,6 +597,107 @@ def test_native_scene_randomiser_is_the_python_mirror_bit_for_bit(oracle):
     assert Mesh is not None
 
 
+def test_native_params_update_writes_what_the_key_writes_write(oracle):
+    """include/ffx.h ffx_scene_step_h (ABI 8) without a device (geom NULL: description and tables only): product library and oracle against the
+    key writes spelled out in numpy — to_world blocks from the chain rows, spot attributes, material cells with Mitsuba's specular -> eta in
+    double, mesh transforms from the un-centred chain, frame offsets — on random op tables; later ops overwrite earlier ones; a refused
+    call (op out of range, frame out of range, material table missing) leaves every table as it was."""
+    import ctypes as C
+
+    from fireflies_amd import _abi, _lib
+
+    rng = np.random.default_rng(11)
+    words = C.sizeof(_abi.SceneDesc) // 4
+    libs = {"hip": _lib.api().lib, "oracle": oracle.api().lib}
+    for name, lib in libs.items():
+        fn = lib.ffx_scene_step_h
+        fn.restype, fn.argtypes = _abi.PROTOTYPES["ffx_scene_step_h"]
+
+    def run(lib, plan, vals, chain, unc, frames, tmpl, mat, xf, off):
+        sd = _abi.SceneDesc()
+        mat, xf, off = mat.copy(), xf.copy(), off.copy()
+        rc = lib.ffx_scene_step_h(plan, vals.ctypes.data, chain.ctypes.data, unc.ctypes.data, frames, tmpl, sd, mat.ctypes.data if mat.size else None,
+                                  xf.ctypes.data, off.ctypes.data, None, 1, None)
+        return rc, np.frombuffer(C.string_at(C.addressof(sd), C.sizeof(sd)), np.uint8).copy(), mat, xf, off
+
+    for trial in range(30):
+        S, nd, ne = int(rng.integers(1, 6)), int(rng.integers(1, 9)), int(rng.integers(1, 7))
+        stride = 16 if trial % 2 else 3
+        n_mat = S * stride
+        vals = rng.uniform(0.01, 0.9, (nd, 4)).astype(np.float32)
+        chain, unc = rng.standard_normal((ne, 16)).astype(np.float32), rng.standard_normal((ne, 16)).astype(np.float32)
+        tmpl = _abi.SceneDesc()
+        C.memmove(C.addressof(tmpl), rng.integers(0, 255, C.sizeof(tmpl), dtype=np.uint8).tobytes(), C.sizeof(tmpl))
+        tmpl.n_mat_h = n_mat if trial % 3 else 0
+        mat = rng.uniform(0, 1, n_mat).astype(np.float32)
+        xf, off = rng.standard_normal((S, 16)).astype(np.float32), rng.integers(0, 1000, S).astype(np.int32)
+        base, fstride, nfr = (rng.integers(0, 1000, S).astype(np.int32), rng.integers(1, 50, S).astype(np.int32), rng.integers(1, 9, S).astype(np.int32))
+        ops = []
+        for _ in range(int(rng.integers(0, 14))):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                ops.append((0, int(rng.integers(0, ne)), 0, int(rng.integers(0, words - 16 + 1)), 0, 0))
+            elif kind == 1:
+                ops.append((1, int(rng.integers(0, nd)), int(rng.integers(0, 4)), int(rng.integers(0, words)), 0, 0))
+            elif kind == 2:
+                ops.append((2, int(rng.integers(0, nd)), int(rng.integers(0, 4)), int(rng.integers(0, n_mat)), int(rng.integers(0, 2)), 0))
+            else:
+                ops.append((3, int(rng.integers(0, ne)), 0, int(rng.integers(0, S)), 0, int(rng.integers(0, 2))))
+        oarr = (_abi.StepOp * max(len(ops), 1))()
+        for o, t in zip(oarr, ops):
+            o.kind, o.src, o.comp, o.dst, o.conv, o.mode = t
+        plan = _abi.StepPlan()
+        plan.ops, plan.n_ops, plan.n_shapes, plan.n_draws, plan.n_ents = oarr, len(ops), S, nd, ne
+        plan.frame_base, plan.frame_stride, plan.n_frames = (a.ctypes.data_as(C.POINTER(C.c_int32)) for a in (base, fstride, nfr))
+        plan.n_mat_floats = n_mat
+        fr = np.array([int(rng.integers(-1, nfr[s_])) for s_ in range(S)], np.int32)
+        frames = (C.c_int32 * S)(*[int(v) for v in fr])
+        # the key writes, spelled out
+        w = np.frombuffer(C.string_at(C.addressof(tmpl), C.sizeof(tmpl)), np.uint8).copy().view(np.float32)
+        want_mat, want_xf, want_off = mat.copy(), xf.copy(), off.copy()
+        for kind, src, comp, dst, conv, mode in ops:
+            if kind == 0:
+                w[dst:dst + 16] = chain[src]
+            elif kind == 1:
+                w[dst] = vals[src, comp]
+            elif kind == 2:
+                v = float(vals[src, comp])
+                want_mat[dst] = np.float32(2.0 / (1.0 - float(np.sqrt(0.08 * v))) - 1.0) if conv else vals[src, comp]
+            else:
+                want_xf[dst] = (chain if mode else unc)[src]
+        want_sd = w.view(np.uint8).copy()
+        if tmpl.n_mat_h > 0:
+            o0 = _abi.SceneDesc.mat_h.offset
+            want_sd[o0:o0 + 4 * n_mat] = want_mat.view(np.uint8)
+        for s_ in range(S):
+            if fr[s_] >= 0:
+                want_off[s_] = base[s_] + fr[s_] * fstride[s_]
+        for name, lib in libs.items():
+            rc, sd, m2, x2, o2 = run(lib, plan, vals, chain, unc, frames, tmpl, mat, xf, off)
+            assert rc == 0, (name, trial)
+            np.testing.assert_array_equal(sd, want_sd, err_msg=name)
+            np.testing.assert_array_equal(m2.view(np.uint32), want_mat.view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(x2.view(np.uint32), want_xf.view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(o2, want_off, err_msg=name)
+        # refusals: nothing is written
+        bad_frames = (C.c_int32 * S)(*[int(nfr[0])] + [-1] * (S - 1))
+        bad_op = (_abi.StepOp * (len(ops) + 1))()
+        for o, t in zip(bad_op, ops + [(0, ne, 0, 0, 0, 0)]):
+            o.kind, o.src, o.comp, o.dst, o.conv, o.mode = t
+        plan_bad = _abi.StepPlan()
+        C.memmove(C.addressof(plan_bad), C.addressof(plan), C.sizeof(plan))
+        plan_bad.ops, plan_bad.n_ops = bad_op, len(ops) + 1
+        for name, lib in libs.items():
+            for pl, frs in ((plan, bad_frames), (plan_bad, frames)):
+                rc, _sd, m2, x2, o2 = run(lib, pl, vals, chain, unc, frs, tmpl, mat, xf, off)
+                assert rc == -1, (name, trial)
+                np.testing.assert_array_equal(m2, mat)
+                np.testing.assert_array_equal(x2, xf)
+                np.testing.assert_array_equal(o2, off)
+            sd = _abi.SceneDesc()
+            assert lib.ffx_scene_step_h(plan, vals.ctypes.data, chain.ctypes.data, unc.ctypes.data, frames, tmpl, sd, None, xf.ctypes.data, off.ctypes.data, None, 1, None) == -1
+
+
 def test_mitsuba_array_shims_carry_the_arithmetic_of_depth_py():
     """Round-4 advisor: the reference's own call sites compute with Mitsuba's arrays before and after the entry points the shims serve —
     fireflies/graphics/depth.py:61-69 (`pos //= spp`, `pos % w`, `pos // w`, `mi.Float(...)` of an array, `mi.Vector2f(x, y)`, `pos * scale`)

@@ -1230,6 +1230,97 @@ def test_sample_ray_and_ray_intersect_objects_give_the_depth_map():
     torch.testing.assert_close(si2.p.torch(), depth.cast_laser(ms, laser=wl.laser), rtol=1e-6, atol=1e-6)
 
 
+def test_native_params_update_pushes_the_sample_the_python_path_pushes():
+    """ffx_scene_step_h behind Scene.randomize() (ABI 8, the native params.update()): two scenes of the same configuration, one kept on the Python
+    path (FFX_NATIVE_UPDATE=0), over seeded randomisations with animation picks — the same scene description byte for byte, the same transform
+    table, frame offsets and material rows, the same values in the parameter map and on the entities, the same re-fitted blob (everything the
+    re-fit writes) and the same image; single samples and the samples of a batch; and the native path really is the one that ran."""
+    import ctypes as C
+
+    def make(native):
+        wl = _small()
+        wl.ff_scene.native_update = native  # (FFX_NATIVE_UPDATE=0 for one scene)
+        with torch.no_grad():
+            wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
+        torch.manual_seed(7)
+        random.seed(7)
+        wl.ff_scene.randomize()  # (the Python path teaches the plan what each key means)
+        wl.ff_scene.randomize()
+        return wl
+
+    a, b = make(False), make(True)
+    ma, mb = a.mi_scene, b.mi_scene
+
+    def same_state(tag):
+        sa, sb = ma.scene_desc(tex_channels=1), mb.scene_desc(tex_channels=1)
+        assert C.string_at(C.addressof(sa), C.sizeof(sa)) == C.string_at(C.addressof(sb), C.sizeof(sb)), tag
+        assert torch.equal(ma._xforms, mb._xforms) and np.array_equal(ma._offs, mb._offs) and np.array_equal(ma._albedo_host, mb._albedo_host), tag
+        assert np.array_equal(ma.geom._vert_off_host, mb.geom._vert_off_host), tag
+        for k in a.params.keys():
+            va, vb = a.params[k], b.params[k]
+            if isinstance(va, float):
+                assert float(va) == float(vb), (tag, k)
+            elif isinstance(va, mi.Transform4f):
+                assert np.array_equal(va.numpy(), vb.numpy()), (tag, k)
+            elif isinstance(va, mi._ArrayBase) and k != "tex.data":
+                assert torch.equal(va.t.cpu(), vb.t.cpu()), (tag, k)
+        for ea, eb in zip(a.ff_scene._draw_order(), b.ff_scene._draw_order()):
+            assert torch.equal(ea.world(), eb.world()), tag
+            assert ea._host_float_attributes == eb._host_float_attributes and ea._host_vec3_attributes == eb._host_vec3_attributes, tag
+        static = int(ma.geom.info.off_bins)
+        torch.cuda.synchronize()
+        assert torch.equal(ma.geom.blob[:static], mb.geom.blob[:static]), tag
+        ia, ib = mi.render(ma, spp=4, seed=3).torch(), mi.render(mb, spp=4, seed=3).torch()
+        assert torch.equal(ia, ib) and float(ia.sum()) > 0, tag
+
+    for k in range(8):
+        for wl in (a, b):
+            torch.manual_seed(90 + k)
+            random.seed(90 + k)
+            wl.ff_scene.randomize()
+        # what the sample means for the entities and the parameter map is worked out on first use ...
+        assert b.ff_scene._lazy is not None and b.params._pending is not None and a.ff_scene._lazy is None
+        if k == 3:  # ... and an assignment of the caller's own right behind the sample is not overwritten by it
+            key = ma.data.spot.name + ".intensity.value"
+            for wl in (a, b):
+                wl.params[key] = mi.Color3f(torch.tensor([2.0, 3.0, 4.0]))
+                wl.params.update()
+            assert b.ff_scene._lazy is None and b.params[key].t.tolist() == [2.0, 3.0, 4.0]
+        if k == 5:  # ... nor is an entity's own randomisation
+            for wl in (a, b):
+                torch.manual_seed(1234)
+                wl.ff_scene._lights[0].randomize()
+            assert b.ff_scene._lazy is None
+        same_state(k)
+        assert b.ff_scene._lazy is None
+    assert ma.update_paths["native"] == 0 and mb.update_paths["native"] >= 8, (ma.update_paths, mb.update_paths)
+    # the samples of a batch, applied one after the other
+    seeds = [300 + i for i in range(5)]
+    n0 = mb.update_paths["native"]
+    for fa, fb in zip(a.ff_scene.randomize_batch(seeds), b.ff_scene.randomize_batch(seeds)):
+        fa()
+        fb()
+        same_state("batch")
+    assert mb.update_paths["native"] == n0 + 5
+    # an assignment of the caller's own between two samples is applied by params.update() in its order: that sample takes the Python path
+    cam = mb.data.camera.name
+    for wl in (a, b):
+        wl.params[cam + ".x_fov"] = mi.Float(float(wl.params[cam + ".x_fov"]) * 0.95)
+        torch.manual_seed(5)
+        random.seed(5)
+        wl.ff_scene.randomize()
+    assert mb.update_paths["native"] == n0 + 5
+    same_state("after a static key")
+    for wl in (a, b):  # ... and the template is rebuilt, the next samples go native again
+        for k in range(3):
+            torch.manual_seed(700 + k)
+            random.seed(700 + k)
+            wl.ff_scene.randomize()
+            mi.render(wl.mi_scene, spp=1)
+    assert mb.update_paths["native"] >= n0 + 6
+    same_state("native again")
+
+
 def test_patched_scene_description_is_the_full_build_byte_for_byte():
     """mi.Scene.scene_desc() patches the per-step fields (poses, spot intensity, material rows) into a copy of a finished description instead of
     rebuilding it (host time): over randomisations of both workloads' kinds of parameters the patched struct equals a full build byte for byte;

@@ -1,13 +1,14 @@
 #!/bin/bash
 # K8's speed (bench loop, 60 steps) and HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/k8once.py) per launch
 # configuration: bash tools/trafficsweep.sh "name|ENV=1 ENV2=x" ...   -> one line per configuration (corrected = 2 x FETCH + WRITE, KB -> MB)
+# TRAFFIC_CMD = the program the counter passes run (default: four renders of the vocal fold); K8SWEEP_ARGS = the speed leg's bench arguments
 R=$(pwd); OUT=$R/gpurun_out/trafficsweep; rm -rf $OUT; mkdir -p $OUT
 export FFX_BENCH_GAUSSIAN=0 FFX_BENCH_EXTRA_BRACKETS=0
 for spec in "$@"; do
   name=${spec%%|*}; envs=${spec#*|}
   line=$(cd $R && env $envs bash tools/k8sweep.sh "$name|$envs")
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && export TMPDIR=/tmp && cd $R && env $envs rocprofv3 --pmc $c --kernel-trace -d $OUT/${name}_$c -o p --output-format csv -- python3 tools/k8once.py 4 > /dev/null 2>&1)
+    (cd /tmp && export TMPDIR=/tmp && cd $R && env $envs rocprofv3 --pmc $c --kernel-trace -d $OUT/${name}_$c -o p --output-format csv -- ${TRAFFIC_CMD:-python3 tools/k8once.py 4} > /dev/null 2>&1)
   done
   python - "$OUT/${name}" "$line" <<'PY'
 import csv, glob, sys
