@@ -780,6 +780,7 @@ def main():
                                        "pattern_fwd_blur, [rf_weights, rf_gather (G), render_fwd_adjoint_filtered, rf_gather (image)], pattern_bwd<5> (+ re-fit and pre-pass on the side stream)") if fused_ran
             else "pattern_fwd_blur, render_fwd_cache, render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)",
             "grad_step_paths": lin_paths,
+            "grad_update_paths": dict(wg.mi_scene.update_paths),  # (scene samples pushed by ffx_scene_step_h / by the Python path, up to the end of this bracket)
             "render_fwd_adjoint_roofline": None if not (fused_ran and k8g_ms) else {
                 "kernel": "k_render_fwd_pk<1, wide, material rows, true> (ffx_render_fwd_adjoint: K8 with the adjoint folded in)", "bound": "hbm",
                 "achieved": bytes_fused / (k8g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_fused / (k8g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -937,7 +938,7 @@ def main():
             if args.workload == "vocalfold" else
             (f"BASELINE configs[4]: procedural colon scene, {bytes_['F']} triangles, {args.grid**2}-point projector, {W}x{H}, {args.spp} spp, "
              f"{'fp16' if args.fp16 else 'fp32'} radiance buffer"),
-            "step": "ff_scene.randomize() + params.update() [K5+K6] + mi.render(...).torch() [K8; the image is consumed on the caller's stream, as the reference's loop "
+            "step": "ff_scene.randomize() [draws + chains: ffx_scene_randomize_h; push: ffx_scene_step_h = params.update(), K5+K6 and the pre-pass] + mi.render(...).torch() [K8; the image is consumed on the caller's stream, as the reference's loop "
                     "does]; texture built once before the loop",
             "preflight": preflight or None,
             "clock_settle": {"renders_before_each_bracket": SETTLE_RENDERS,
@@ -951,6 +952,9 @@ def main():
             "primary_rays_per_sec": world * args.steps * W * H * args.spp / t_render,
             "parallelism": f"dp{world}: independent scene samples per rank, no collective in the render loop",
             "render_paths": dict(wl.mi_scene.render_paths),
+            # how the scene samples reached the device: "native" = one ffx_scene_step_h call each (ABI 8, the native params.update()), "python" = key writes + params.update()
+            "update_paths": dict(wl.mi_scene.update_paths),
+            "update_fallbacks": dict(wl.mi_scene.update_fallbacks),
         },
         "roofline": {
             "kernel": "k_render_fwd_pk<1, wide, %s, false> (ffx_render_fwd, K8)" % ("material rows" if args.material == "principled" else "albedo"),

@@ -531,6 +531,7 @@ class Scene:
         self.render_paths = {"two_stream": 0, "caller_stream": 0, "autograd": 0}
         # which way each geometry push went: "native" = one ffx_scene_step_h call for the whole sample (step_native), "python" = params.update()
         self.update_paths = {"native": 0, "python": 0}
+        self.update_fallbacks = {}  # why a sample of a compiled configuration took the Python path after all (reason -> count)
         self._tex_src = self._tex_ready = self._tex_private = None
         self._tex_ver = -1
         # texture-valued base colours (`<mat>.brdf_0.base_color.data`): device tensors [h,w,3] + the texture coordinates of every
@@ -865,15 +866,17 @@ class Scene:
     def step_native(self, sp, values, chain, unc, frames):
         """one scene sample through ffx_scene_step_h.  values [n_draws,4], chain / unc [n_ents,16]: rows of the native randomiser's tables (float32,
         contiguous); frames: per posed mesh of the plan the pool frame of this sample.  False: not this time (the caller takes the Python path)"""
-        p = self._params
+        p, fb = self._params, self.update_fallbacks
         if p._dirty and not (len(p._dirty) == 1 and "tex.data" in p._dirty):
-            return False  # (assignments of the caller's own are pending: params.update() applies them in its order)
+            fb["caller's own assignments pending"] = fb.get("caller's own assignments pending", 0) + 1
+            return False  # (params.update() applies them in its order)
         ch = self._sd_cache[0] if self._sd_cache is not None else 3
         tm = self._sd_templates.get(ch)
         if tm is None or tm[0] != (self.shadows, tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0):
+            fb["no description template yet"] = fb.get("no description template yet", 0) + 1
             return False
         g = self.geom
-        if g.timing is not None or g.src_verts is not sp.pool:
+        if g.src_verts is not sp.pool:
             return False
         fr = sp.frames
         for s, f in zip(sp.mesh_shapes, frames):
@@ -884,8 +887,8 @@ class Scene:
         if ptrs is None or ptrs[3] is not self._albedo_host:  # (host tables only ever written in place: their addresses are taken once)
             ptrs = sp.ptrs = (self._xforms.data_ptr(), self._offs.ctypes.data, self._albedo_host.ctypes.data if sp.plan.n_mat_floats else None, self._albedo_host)
 
-        def launch(i, stream):
-            rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, tm[1], sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], 1, stream)
+        def launch(i, stream, prepare):
+            rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, tm[1], sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], prepare, stream)
             if rc != 0:
                 ops.api().check(rc, "ffx_scene_step_h")
             return sd

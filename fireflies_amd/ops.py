@@ -626,7 +626,7 @@ class DeviceGeometry:
 
     def update_native(self, launch, vert_off):
         """update() for a caller whose ONE native call enqueues the re-fit and the pre-pass (mi.Scene.step_native -> ffx_scene_step_h):
-        the same blob rotation and ordering.  launch(blob index, side stream handle) -> the scene description whose apex records and
+        the same blob rotation and ordering.  launch(blob index, side stream handle, with the pre-pass?) -> the scene description whose apex records and
         tile bins the blob then holds; vert_off: the frame offsets [S] the call used (host int32, already checked by it)."""
         self.version += 1
         nxt = (self._cur + 1) % len(self._blobs)
@@ -641,10 +641,18 @@ class DeviceGeometry:
             sh = self._side_handle = C.c_void_p(self._side.cuda_stream)
         self._apex[nxt] = None
         self._apex_written[nxt] = None
-        sd = launch(nxt, sh)
+        if self.timing is None:
+            sd = launch(nxt, sh, 1)
+            self._apex[nxt] = apex_key(sd)
+        else:  # (bench.py's per-launch event pairs: around the re-fit alone, as on the Python path; the pre-pass as a call of its own behind them)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(self._side)
+            sd = launch(nxt, sh, 0)
+            b.record(self._side)
+            self.timing.append(("scene_update", a, b))
+            self._prepare_apex(nxt, sd, sh)
         np.copyto(self._vert_off_host, vert_off)
         self._vert_off_dev_stale = True
-        self._apex[nxt] = apex_key(sd)
         ev.record(self._side)
         self._cur = nxt
 

@@ -677,7 +677,9 @@ class Scene:
                 continue
             pool = getattr(m, "_pool_frames", None)
             if pick[0] == "func" or pool is None:
-                return False  # (vertices the caller supplies travel through the vertex pool: the Python path)
+                fb = self._mitsuba_params._scene.update_fallbacks
+                fb["caller-supplied vertices"] = fb.get("caller-supplied vertices", 0) + 1
+                return False  # (they travel through the vertex pool: the Python path)
             frames.append(pool[pick[1]][0] + pick[2])
         p = self._mitsuba_params
         lz = self._lazy
