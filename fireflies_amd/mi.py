@@ -876,8 +876,8 @@ class Scene:
             fb["no description template yet"] = fb.get("no description template yet", 0) + 1
             return False
         g = self.geom
-        if g.src_verts is not sp.pool:
-            return False
+        if g.src_verts is not sp.pool or (g.device.index is not None and torch._C._cuda_getDevice() != g.device.index):
+            return False  # (a scene on another device than the current one: DeviceGeometry._call switches for the Python path's launches)
         fr = sp.frames
         for s, f in zip(sp.mesh_shapes, frames):
             fr[s] = f
