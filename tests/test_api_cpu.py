@@ -696,6 +696,34 @@ def test_native_params_update_writes_what_the_key_writes_write(oracle):
                 np.testing.assert_array_equal(o2, off)
             sd = _abi.SceneDesc()
             assert lib.ffx_scene_step_h(plan, vals.ctypes.data, chain.ctypes.data, unc.ctypes.data, frames, tmpl, sd, None, xf.ctypes.data, off.ctypes.data, None, 1, None) == -1
+    # ... and with a geometry block the call IS the re-fit (the oracle's, on host memory): two shapes, three frames each, against Geometry.update
+    V, S = 5, 2
+    pool = rng.standard_normal((S * 3 * V, 3)).astype(np.float32)
+    tris = np.array([[0, 1, 2], [2, 3, 4], [0, 2, 4], [1, 3, 4]], np.int32)
+    tri_shape = np.array([0, 0, 1, 1], np.int32)
+    off0 = np.array([0, 3 * V], np.int32)
+    ga, gb = oracle.Geometry(pool, tris, tri_shape, off0), oracle.Geometry(pool, tris, tri_shape, off0)
+    chain, unc = rng.standard_normal((3, 16)).astype(np.float32), rng.standard_normal((3, 16)).astype(np.float32)
+    for m in (chain, unc):
+        m.reshape(3, 4, 4)[:, 3] = (0, 0, 0, 1)
+    oarr = (_abi.StepOp * 2)()
+    for o, t in zip(oarr, [(3, 2, 0, 0, 0, 0), (3, 1, 0, 1, 0, 1)]):
+        o.kind, o.src, o.comp, o.dst, o.conv, o.mode = t
+    base, fstride, nfr = off0.copy(), np.full(S, V, np.int32), np.full(S, 3, np.int32)
+    plan = _abi.StepPlan()
+    plan.ops, plan.n_ops, plan.n_shapes, plan.n_draws, plan.n_ents = oarr, 2, S, 0, 3
+    plan.frame_base, plan.frame_stride, plan.n_frames = (a.ctypes.data_as(C.POINTER(C.c_int32)) for a in (base, fstride, nfr))
+    geom = _abi.StepGeom()
+    geom.bvh, geom.info = ga.blob.ctypes.data, C.pointer(ga.info)
+    geom.src_verts, geom.tris, geom.tri_shape = ga.src_verts.ctypes.data, ga.tris.ctypes.data, ga.tri_shape.ctypes.data
+    xf, off = np.tile(np.eye(4, dtype=np.float32).reshape(-1), (S, 1)), off0.copy()
+    tmpl, sd = _abi.SceneDesc(), _abi.SceneDesc()
+    assert libs["oracle"].ffx_scene_step_h(plan, None, chain.ctypes.data, unc.ctypes.data, (C.c_int32 * S)(2, 1), tmpl, sd, None, xf.ctypes.data, off.ctypes.data, geom, 1, None) == 0
+    np.testing.assert_array_equal(off, [2 * V, 3 * V + V])
+    gb.update(np.stack([unc[2], chain[1]]).reshape(S, 4, 4), vert_off=off)
+    np.testing.assert_array_equal(ga.blob, gb.blob)
+    geom.tris = None
+    assert libs["oracle"].ffx_scene_step_h(plan, None, chain.ctypes.data, unc.ctypes.data, None, tmpl, sd, None, xf.ctypes.data, off.ctypes.data, geom, 1, None) == -1
 
 
 def test_mitsuba_array_shims_carry_the_arithmetic_of_depth_py():
