@@ -1319,6 +1319,20 @@ def test_native_params_update_pushes_the_sample_the_python_path_pushes():
             mi.render(wl.mi_scene, spp=1)
     assert mb.update_paths["native"] >= n0 + 6
     same_state("native again")
+    # eval mode draws through the samplers' own sequences (the Python path) right behind a natively pushed sample that nobody has looked at
+    for wl in (a, b):
+        torch.manual_seed(11)
+        random.seed(11)
+        wl.ff_scene.randomize()
+        wl.ff_scene.eval()
+        wl.ff_scene.randomize()
+    n1 = mb.update_paths["native"]
+    same_state("eval mode")
+    for wl in (a, b):
+        wl.ff_scene.randomize()
+        wl.ff_scene.train()
+    assert mb.update_paths["native"] == n1
+    same_state("eval mode, second sample")
 
 
 def test_patched_scene_description_is_the_full_build_byte_for_byte():
