@@ -14,6 +14,9 @@ import torch
 from .. import ops
 
 
+_GRIDS = {}  # (height, width, device) -> pixel coordinates along x and along y (ApplySilhouette)
+
+
 def _to_device(image):
     if isinstance(image, np.ndarray):
         return torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).cuda(), True
@@ -100,8 +103,12 @@ class ApplySilhouette(BasePostProcessingFunction):
         cc_y = random.randint(200, 300)
         radius = random.randint(170, 230)
         h, w = t.shape[-2], t.shape[-1]
-        yy, xx = torch.meshgrid(torch.arange(h, device=t.device), torch.arange(w, device=t.device), indexing="ij")
-        mask = (((xx - cc_x) ** 2 + (yy - cc_y) ** 2) <= radius * radius).float().contiguous()
+        # (x - cc_x)^2 + (y - cc_y)^2 <= radius^2 on the pixel grid: the two squares along their own axis, then one broadcast sum — the pixel
+        # coordinates are small integers, exact in float32 (the reference draws the disc with cv2.circle on the host)
+        g = _GRIDS.get((h, w, t.device))
+        if g is None:
+            g = _GRIDS[(h, w, t.device)] = (torch.arange(w, device=t.device, dtype=torch.float32), torch.arange(h, device=t.device, dtype=torch.float32).unsqueeze(1))
+        mask = (((g[1] - cc_y).square_() + (g[0] - cc_x).square_()) <= float(radius * radius)).float()
         mask = ops.blur_fwd(mask, 11, 5.0)
         return _back(t * mask, was_np)
 

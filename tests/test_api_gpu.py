@@ -1272,6 +1272,11 @@ def test_native_params_update_pushes_the_sample_the_python_path_pushes():
         assert torch.equal(ma.geom.blob[:static], mb.geom.blob[:static]), tag
         ia, ib = mi.render(ma, spp=4, seed=3).torch(), mi.render(mb, spp=4, seed=3).torch()
         assert torch.equal(ia, ib) and float(ia.sum()) > 0, tag
+        for m in (ma, mb):  # the camera block depth.py's queries take from the finished description is the one built from the sensor's parameters
+            for _ in range(2):
+                fast, slow = m.camera_struct(0), m._camera_struct_slow(0)
+                assert C.string_at(C.addressof(fast), C.sizeof(fast)) == C.string_at(C.addressof(slow), C.sizeof(slow)), tag
+        assert mb._cam_check[1] is True
 
     for k in range(8):
         for wl in (a, b):

@@ -41,7 +41,22 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(n):
     keep = sample(10 + i)
+t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+print(f"host issued the {n} samples in {1e3 * t_issue / n:.3f} ms each; the device finished {1e3 * (dt - t_issue):.2f} ms after the last was issued")
 print(f"dataset path: {n / dt:.1f} samples/s ({1e3 * dt / n:.3f} ms per sample: render {spp} spp + post-processing + segmentation + depth, 512x512), "
       f"outputs {tuple(keep[0].shape)} {tuple(keep[1].shape)} {tuple(keep[2].shape)}")
+
+if os.environ.get("FFX_DS_PROFILE") == "1":  # where the host's time per sample goes (cProfile, 200 samples at 1 spp so that the device is not the limit)
+    import cProfile
+    import pstats
+
+    spp = 1
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(200):
+        sample(i)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
