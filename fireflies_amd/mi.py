@@ -717,6 +717,7 @@ class Scene:
                                           "(declare it principled: scenes.MeshData(bsdf={...}) or <bsdf type=\"principled\">); "
                                           "further assignments of such parameters are not reported", stacklevel=4)
                             self._warned_bsdf = True
+                        plan[k] = _PLAIN_KEY  # (no part of anything the device sees)
                         continue
                     v = self._params._d[k]
                     v = float(v) if isinstance(v, float) else float((v.t if isinstance(v, _ArrayBase) else torch.as_tensor(v, dtype=torch.float32)).reshape(-1)[0])
