@@ -12,8 +12,6 @@
 // have consumed, so every later consumer of the generator sees the same stream as in the reference program.
 #include <math.h>
 #include <stdint.h>
-#include <stdio.h>
-#include <time.h>
 
 #include "../../include/ffx.h"
 #include "ffx_common.h"
@@ -231,21 +229,7 @@ extern "C" int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, 
       if (frames[s] >= 0) vert_off[s] = plan->frame_base[s] + frames[s] * plan->frame_stride[s];
   if (!geom) return FFX_OK;
   if (!geom->bvh || !geom->info || !geom->src_verts || !geom->tris || !geom->tri_shape) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: incomplete geometry block");
-#ifdef FFX_STEP_TIMING
-  struct timespec t0, t1, t2;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
-#endif
   const int rc = ffx_scene_update_h(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth, stream);
   if (rc != FFX_OK || !prepare_apex) return rc;
-#ifdef FFX_STEP_TIMING
-  clock_gettime(CLOCK_MONOTONIC, &t1);
-  const int rc2 = ffx_apex_prepare(geom->bvh, geom->info, sd_out, stream);
-  clock_gettime(CLOCK_MONOTONIC, &t2);
-  static double a = 0, b = 0; static int n = 0;
-  a += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3; b += (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3;
-  if (++n % 200 == 0) { fprintf(stderr, "step_h: update_h %.1f us, apex_prepare %.1f us (mean of 200)\n", a / 200, b / 200); a = b = 0; }
-  return rc2;
-#else
   return ffx_apex_prepare(geom->bvh, geom->info, sd_out, stream);
-#endif
 }
