@@ -213,6 +213,9 @@ PROTOTYPES = {
     "ffx_scene_randomize_h": (c_i, [c_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(RandDraw), c_i, C.POINTER(RandEntity), c_i, c_p, c_p, c_p, c_p]),
     "ffx_blur_fwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "ffx_blur_bwd": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "ffx_rgb_to_gray": (c_i, [c_p, c_i, C.c_size_t, c_f, c_f, c_f, c_p, c_p]),
+    "ffx_silhouette_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "ffx_noise_clamp": (c_i, [c_p, c_p, C.c_size_t, c_f, c_f, c_f, c_f, c_p, c_p]),
     "ffx_bvh_blob_bytes": (C.c_size_t, [c_i]),
     "ffx_bvh_build_host": (c_i, [c_p, c_i, c_p, c_i, c_p, C.c_size_t, C.POINTER(BvhInfo)]),
     "ffx_scene_update": (c_i, [c_p, C.POINTER(BvhInfo), c_p, c_p, c_p, c_p, c_p, c_i, C.POINTER(Smooth), c_p]),

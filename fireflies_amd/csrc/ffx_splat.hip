@@ -1078,6 +1078,47 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_blur_fwd(const float *__restric
   }
   out[(size_t)y * w + x] = acc;
 }
+// ---- dataset path (include/ffx.h: ffx_silhouette_fwd, ffx_noise_clamp, ffx_rgb_to_gray): one launch per post-processing step
+// the image times the blurred disc: k_blur_fwd with the mask evaluated where it stages its tile (the mask is never stored)
+__global__ void __launch_bounds__(SPLAT_BLOCK) k_silhouette_fwd(const float *__restrict__ img, int h, int w, int cx, int cy, int r2, BlurW bw, float *__restrict__ out) {
+  __shared__ float tile[(TILE_H + 14) * (TILE_W + 14)];
+  const int r = bw.ksize / 2, tw = TILE_W + 2 * r, th = TILE_H + 2 * r;
+  const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+  for (int t = threadIdx.x; t < tw * th; t += SPLAT_BLOCK) {
+    const int yy = reflect_idx(y0 + t / tw - r, h) - cy, xx = reflect_idx(x0 + t % tw - r, w) - cx;
+    tile[t] = (xx * xx + yy * yy <= r2) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % TILE_W, ly = threadIdx.x / TILE_W;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= w || y >= h) return;
+  float acc = 0.f;
+  for (int ky = 0; ky < bw.ksize; ++ky) {
+    float row = 0.f;
+    for (int kx = 0; kx < bw.ksize; ++kx) row = fmaf(bw.w[kx], tile[(ly + ky) * tw + lx + kx], row);
+    acc = fmaf(bw.w[ky], row, acc);
+  }
+  out[(size_t)y * w + x] = img[(size_t)y * w + x] * acc;
+}
+__global__ void __launch_bounds__(256) k_noise_clamp(const float *__restrict__ img, const float *__restrict__ noise, size_t n, float mean, float sd, float lo, float hi,
+                                                     float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float nz = noise[i] * sd;
+    const float v = img[i] + (nz + mean);
+    out[i] = (v != v) ? v : fminf(fmaxf(v, lo), hi);
+  }
+}
+template <bool F16>
+__global__ void __launch_bounds__(256) k_rgb_to_gray(const void *__restrict__ img, size_t n, float wr, float wg, float wb, float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float r, g, b;
+    if (F16) { const _Float16 *p = (const _Float16 *)img + 3 * i; r = (float)p[0]; g = (float)p[1]; b = (float)p[2]; }
+    else { const float *p = (const float *)img + 3 * i; r = p[0]; g = p[1]; b = p[2]; }
+    const float a = r * wr, c = g * wg, d = b * wb;
+    out[i] = (a + c) + d;
+  }
+}
+
 // K3^T (blur_bwd_texel above).  One workgroup per 32x8 tile.  Whatever a pixel of the tile reads lies in the tile's halo
 // [y0 - r, y0 + TILE_H + r) x [x0 - r, x0 + TILE_W + r) clipped to the image (the reflected candidates of a border pixel read the
 // first / last r rows, which are in the halo of the border tiles): staged through LDS like the forward blur, zero outside the
@@ -1425,6 +1466,32 @@ int ffx_splat_bwd(const float *pts, int n, float sigma, int reduce, int half_win
   return FFX_OK;
 }
 
+int ffx_silhouette_fwd(const float *img, int h, int w, int cx, int cy, int radius, int ksize, float sg, float *out, ffx_stream s) {
+  BlurW bw;
+  if (!img || !out || h <= 0 || w <= 0 || h > 32768 || w > 32768 || radius < 0 || radius > 32768 || cx < -32768 || cx > 65536 || cy < -32768 || cy > 65536 ||
+      !blur_weights(ksize, sg, bw))
+    FFX_FAIL(FFX_ERR_ARG, "silhouette_fwd: bad argument");
+  dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H);
+  hipLaunchKernelGGL(k_silhouette_fwd, grid, dim3(SPLAT_BLOCK), 0, (hipStream_t)s, img, h, w, cx, cy, radius * radius, bw, out);
+  FFX_CHECK_LAUNCH("silhouette_fwd");
+  return FFX_OK;
+}
+int ffx_noise_clamp(const float *img, const float *noise, size_t n, float mean, float sd, float lo, float hi, float *out, ffx_stream s) {
+  if (!img || !noise || !out || n == 0) FFX_FAIL(FFX_ERR_ARG, "noise_clamp: bad argument");
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_noise_clamp, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)s, img, noise, n, mean, sd, lo, hi, out);
+  FFX_CHECK_LAUNCH("noise_clamp");
+  return FFX_OK;
+}
+int ffx_rgb_to_gray(const void *img, int img_fp16, size_t n, float wr, float wg, float wb, float *out, ffx_stream s) {
+  if (!img || !out || n == 0) FFX_FAIL(FFX_ERR_ARG, "rgb_to_gray: bad argument");
+  const size_t blocks = (n + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096));
+  if (img_fp16 & 1) hipLaunchKernelGGL(k_rgb_to_gray<true>, grid, dim3(256), 0, (hipStream_t)s, img, n, wr, wg, wb, out);
+  else hipLaunchKernelGGL(k_rgb_to_gray<false>, grid, dim3(256), 0, (hipStream_t)s, img, n, wr, wg, wb, out);
+  FFX_CHECK_LAUNCH("rgb_to_gray");
+  return FFX_OK;
+}
 int ffx_blur_fwd(const float *in, int h, int w, int ksize, float sg, float *out, ffx_stream s) {
   BlurW bw;
   if (!in || !out || h <= 0 || w <= 0 || !blur_weights(ksize, sg, bw)) FFX_FAIL(FFX_ERR_ARG, "blur_fwd: bad argument");

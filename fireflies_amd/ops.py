@@ -298,6 +298,32 @@ def blur_fwd(img, ksize=5, sigma=3.0):
     return out
 
 
+def silhouette(img, cx, cy, radius, ksize=11, sigma=5.0):
+    """img [H,W] times the blurred filled circle of apply_silhouette.py — ffx_silhouette_fwd: blur_fwd(mask) * img bit for bit, one launch, no mask tensor"""
+    if img.dim() != 2:
+        raise ValueError("silhouette expects [H,W]")
+    out = torch.empty_like(img)
+    api().call("ffx_silhouette_fwd", _dev(img, name="img"), img.shape[0], img.shape[1], int(cx), int(cy), int(radius), int(ksize), float(sigma), _dev(out), _stream())
+    return out
+
+
+def noise_clamp(img, noise, mean, std, lo=0.0, hi=1.0):
+    """clamp(img + (noise * std + mean), lo, hi) in one launch (ffx_noise_clamp); the result takes the noise tensor's place"""
+    if img.shape != noise.shape:
+        raise ValueError("noise must have the image's shape")
+    api().call("ffx_noise_clamp", _dev(img, name="img"), _dev(noise, name="noise"), img.numel(), float(mean), float(std), float(lo), float(hi), _dev(noise), _stream())
+    return noise
+
+
+def rgb_to_gray(img, weights=(0.299, 0.587, 0.114)):
+    """[..., 3] float32 / float16 -> [...] float32: (r wr + g wg) + b wb (ffx_rgb_to_gray; cv2.COLOR_RGB2GRAY's weights by default)"""
+    if img.shape[-1] != 3 or img.dtype not in (torch.float32, torch.float16):
+        raise ValueError("rgb_to_gray expects a [..., 3] float32 or float16 image")
+    out = torch.empty(img.shape[:-1], dtype=torch.float32, device=img.device)
+    api().call("ffx_rgb_to_gray", _dev(img, img.dtype, "img"), int(img.dtype == torch.float16), out.numel(), float(weights[0]), float(weights[1]), float(weights[2]), _dev(out), _stream())
+    return out
+
+
 def blur_bwd(g, ksize=5, sigma=3.0):
     out = torch.empty_like(g)
     api().call("ffx_blur_bwd", _dev(g, name="g"), g.shape[0], g.shape[1], ksize, float(sigma), _dev(out), _stream())

@@ -14,9 +14,6 @@ import torch
 from .. import ops
 
 
-_GRIDS = {}  # (height, width, device) -> pixel coordinates along x and along y (ApplySilhouette)
-
-
 def _to_device(image):
     if isinstance(image, np.ndarray):
         return torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).cuda(), True
@@ -85,8 +82,8 @@ class WhiteNoise(BasePostProcessingFunction):
             shape = tuple(t.shape)
             noise = np.random.normal(np.ones(shape) * self._mean, np.ones(shape) * self._std)  # float64, the reference's call
             out = (t.double() + torch.from_numpy(noise).to(t.device)).to(t.dtype)  # `image += noise`: one rounding to the image type
-        else:
-            out = t + (torch.randn_like(t) * self._std + self._mean)
+        else:  # (one launch behind the draw: ffx_noise_clamp — t + (n std + mean), clipped, every operation rounded as the torch expression rounds it)
+            return _back(ops.noise_clamp(t, torch.randn_like(t), self._mean, self._std, 0.0, 1.0), was_np)
         return _back(torch.clamp(out, 0, 1), was_np)
 
 
@@ -102,15 +99,18 @@ class ApplySilhouette(BasePostProcessingFunction):
         cc_x = random.randint(100, 200)
         cc_y = random.randint(200, 300)
         radius = random.randint(170, 230)
-        h, w = t.shape[-2], t.shape[-1]
-        # (x - cc_x)^2 + (y - cc_y)^2 <= radius^2 on the pixel grid: the two squares along their own axis, then one broadcast sum — the pixel
-        # coordinates are small integers, exact in float32 (the reference draws the disc with cv2.circle on the host)
-        g = _GRIDS.get((h, w, t.device))
-        if g is None:
-            g = _GRIDS[(h, w, t.device)] = (torch.arange(w, device=t.device, dtype=torch.float32), torch.arange(h, device=t.device, dtype=torch.float32).unsqueeze(1))
-        mask = (((g[1] - cc_y).square_() + (g[0] - cc_x).square_()) <= float(radius * radius)).float()
-        mask = ops.blur_fwd(mask, 11, 5.0)
-        return _back(t * mask, was_np)
+        # the filled circle, its 11 x 11 sigma-5 blur and the product in ONE launch (ffx_silhouette_fwd: ops.blur_fwd(mask) * t bit for bit; as torch
+        # expressions — two coordinate grids, the disc test, the blur, the product — it was nine launches of the dataset loop's ~25 per sample)
+        return _back(ops.silhouette(t, cc_x, cc_y, radius, 11, 5.0), was_np)
 
 
-__all__ = ["BasePostProcessingFunction", "PostProcessor", "GaussianBlur", "WhiteNoise", "ApplySilhouette"]
+def rgb_to_gray(image):
+    """main.py:157 `cv2.cvtColor(render, cv2.COLOR_RGB2GRAY)` for an image that stays on the device: [H,W,3] -> [H,W], (r 0.299 + g 0.587) + b 0.114
+    in float32 (one launch, ffx_rgb_to_gray); a numpy image is converted on the host with the same expression."""
+    if isinstance(image, np.ndarray):
+        im = image.astype(np.float32, copy=False)
+        return (im[..., 0] * np.float32(0.299) + im[..., 1] * np.float32(0.587)) + im[..., 2] * np.float32(0.114)
+    return ops.rgb_to_gray(image.contiguous())
+
+
+__all__ = ["BasePostProcessingFunction", "PostProcessor", "GaussianBlur", "WhiteNoise", "ApplySilhouette", "rgb_to_gray"]

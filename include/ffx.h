@@ -334,6 +334,25 @@ int ffx_blur_bwd(const float *gout /*[dev][h,w]*/, int h, int w, int ksize, floa
                  float *gin /*[dev][h,w]*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dataset path: the post-processing steps of main.py:138-160 as single launches on device images (ABI 8).
+ * The reference copies every render to the host and runs cv2 / kornia / numpy there; as torch expressions on the device the same
+ * steps are ~25 small dependent launches per sample, which then set the pace of the loop (tools/datasetbench.py).
+ *   ffx_rgb_to_gray     main.py:157 cv2.cvtColor(render, cv2.COLOR_RGB2GRAY):  out = (r wr + g wg) + b wb, every operation rounded to float32
+ *   ffx_silhouette_fwd  fireflies/postprocessing/apply_silhouette.py:10-40: the image times a blurred filled circle (the endoscope's vignette).
+ *                       disc(x, y) = 1 where (x - cx)^2 + (y - cy)^2 <= radius^2, else 0 (integer arithmetic); out = img * K3(disc) with
+ *                       ffx_blur_fwd's arithmetic (ksize x ksize, reflect border) — bit for bit ffx_blur_fwd of the stored mask times the
+ *                       image, without the mask ever existing.  out may be img.
+ *   ffx_noise_clamp     fireflies/postprocessing/white_noise.py:5-20 with the noise drawn on the device: out = clamp(img + (noise std + mean),
+ *                       lo, hi), NaN kept (torch.clamp's rule); every operation rounded to float32.  out may be img or noise.
+ * ---------------------------------------------------------------------------------------- */
+int ffx_rgb_to_gray(const void *img /*[dev][n_pixels,3] float32, or float16 with img_fp16*/, int img_fp16, size_t n_pixels,
+                    float wr, float wg, float wb, float *out /*[dev][n_pixels]*/, ffx_stream stream);
+int ffx_silhouette_fwd(const float *img /*[dev][h,w]*/, int h, int w, int cx, int cy, int radius, int ksize, float blur_sigma,
+                       float *out /*[dev][h,w]*/, ffx_stream stream);
+int ffx_noise_clamp(const float *img /*[dev][n]*/, const float *noise /*[dev][n]*/, size_t n, float mean, float std, float lo, float hi,
+                    float *out /*[dev][n]*/, ffx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * K5 + K6  per-randomisation geometry update.
  * Replaces Mesh.get_randomized_vertices (fireflies/entity/mesh.py:158-165) +
  * Scene.update_meshes (fireflies/scene.py:243-251) + the acceleration-structure rebuild

@@ -665,6 +665,52 @@ int ffx_blur_fwd(const float *in, int h, int w, int ksize, float sg, float *out,
     }
   return FFX_OK;
 }
+static inline float f16_to_f32(uint16_t h);
+/* dataset path (include/ffx.h): the three post-processing steps, each written out the long way.
+ *   fireflies/postprocessing/apply_silhouette.py:10-40  mask = filled circle; mask = blur(mask, 11x11, sigma 5); image * mask
+ *   fireflies/postprocessing/white_noise.py:5-20        image + normal(mean, std), clipped to [0, 1]
+ *   main.py:157                                         cv2.cvtColor(render, cv2.COLOR_RGB2GRAY) */
+int ffx_silhouette_fwd(const float *img, int h, int w, int cx, int cy, int radius, int ksize, float sg, float *out, ffx_stream s) {
+  if (!img || !out || h <= 0 || w <= 0 || h > 32768 || w > 32768 || radius < 0 || radius > 32768 || cx < -32768 || cx > 65536 || cy < -32768 || cy > 65536)
+    FAIL(FFX_ERR_ARG, "silhouette_fwd: bad argument");
+  float *mask = (float *)malloc(sizeof(float) * (size_t)h * w), *soft = (float *)malloc(sizeof(float) * (size_t)h * w);
+  if (!mask || !soft) { free(mask); free(soft); FAIL(FFX_ERR_NOMEM, "silhouette_fwd: out of memory"); }
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      long dx = x - cx, dy = y - cy;
+      mask[(size_t)y * w + x] = (dx * dx + dy * dy <= (long)radius * radius) ? 1.0f : 0.0f;
+    }
+  int rc = ffx_blur_fwd(mask, h, w, ksize, sg, soft, s);
+  if (rc == FFX_OK)
+    for (size_t i = 0; i < (size_t)h * w; ++i) out[i] = img[i] * soft[i];
+  free(mask);
+  free(soft);
+  return rc;
+}
+int ffx_noise_clamp(const float *img, const float *noise, size_t n, float mean, float sd, float lo, float hi, float *out, ffx_stream s) {
+  (void)s;
+  if (!img || !noise || !out || n == 0) FAIL(FFX_ERR_ARG, "noise_clamp: bad argument");
+  for (size_t i = 0; i < n; ++i) {
+    volatile float scaled = noise[i] * sd; /* (one rounding per operation, whatever the compiler would like to contract) */
+    volatile float shifted = scaled + mean;
+    float v = img[i] + shifted;
+    if (v == v) { v = v < lo ? lo : v; v = v > hi ? hi : v; }
+    out[i] = v;
+  }
+  return FFX_OK;
+}
+int ffx_rgb_to_gray(const void *img, int img_fp16, size_t n, float wr, float wg, float wb, float *out, ffx_stream s) {
+  (void)s;
+  if (!img || !out || n == 0) FAIL(FFX_ERR_ARG, "rgb_to_gray: bad argument");
+  for (size_t i = 0; i < n; ++i) {
+    float c[3];
+    for (int k = 0; k < 3; ++k) c[k] = (img_fp16 & 1) ? f16_to_f32(((const uint16_t *)img)[3 * i + k]) : ((const float *)img)[3 * i + k];
+    volatile float a = c[0] * wr, b = c[1] * wg, d = c[2] * wb;
+    volatile float ab = a + b;
+    out[i] = ab + d;
+  }
+  return FFX_OK;
+}
 int ffx_blur_bwd(const float *gout, int h, int w, int ksize, float sg, float *gin, ffx_stream s) {
   (void)s;
   if (!gout || !gin || h <= 0 || w <= 0 || ksize < 1 || ksize > 15 || !(ksize & 1) || !(sg > 0)) FAIL(FFX_ERR_ARG, "blur_bwd: bad argument");

@@ -185,6 +185,62 @@ def test_k2_depth_and_lines(oracle):
 
 
 # ------------------------------------------------------------------ K3
+def test_dataset_path_steps_in_single_launches(oracle):
+    """include/ffx.h ffx_silhouette_fwd / ffx_noise_clamp / ffx_rgb_to_gray (ABI 8): each against the oracle's long form (mask -> its K3
+    blur -> product; the clipped sum; the weighted sum) and against the torch expressions they replace in fireflies_amd.postprocessing — bit for bit,
+    which is what lets the dataset loop swap ~20 small launches per sample for three; discs that leave the image, reflect borders, ragged tile edges,
+    NaN kept by the clamp, the fp16 film."""
+    from fireflies_amd import _abi
+
+    olib = oracle.api().lib
+    for name in ("ffx_silhouette_fwd", "ffx_noise_clamp", "ffx_rgb_to_gray"):
+        getattr(olib, name).restype, getattr(olib, name).argtypes = _abi.PROTOTYPES[name]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for (h, w, cx, cy, r, ks, sg) in ((512, 512, 150, 250, 200, 11, 5.0), (37, 53, 5, 30, 12, 11, 5.0), (64, 40, -20, 10, 45, 7, 2.0), (9, 70, 60, 4, 0, 15, 4.0),
+                                      (33, 33, 16, 16, 400, 3, 1.0)):
+        img = torch.rand((h, w), generator=g)
+        d = img.to("cuda")
+        got = ops.silhouette(d, cx, cy, r, ks, sg)
+        want = np.empty((h, w), np.float32)
+        assert olib.ffx_silhouette_fwd(img.numpy().ctypes.data, h, w, cx, cy, r, ks, sg, want.ctypes.data, None) == 0
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32), err_msg=str((h, w, cx, cy, r)))
+        yy, xx = torch.meshgrid(torch.arange(h, device="cuda"), torch.arange(w, device="cuda"), indexing="ij")
+        mask = (((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).float().contiguous()
+        assert torch.equal(got, d * ops.blur_fwd(mask, ks, sg))  # (the torch form it replaces)
+        assert torch.equal(ops.silhouette(d, cx, cy, r, ks, sg), got)
+    with pytest.raises(Exception):
+        ops.silhouette(torch.rand((8, 8), device="cuda"), 1, 1, 2, 4, 1.0)  # even kernel size
+    for n, mean, sd in ((512 * 512, 0.0, 0.05), (1000, 0.1, 0.02), (77, -0.05, 0.2)):
+        img, nz = torch.rand(n, generator=g), torch.randn(n, generator=g)
+        img[3], nz[5] = float("nan"), float("inf")
+        want = np.empty(n, np.float32)
+        assert olib.ffx_noise_clamp(img.numpy().ctypes.data, nz.numpy().ctypes.data, n, mean, sd, 0.0, 1.0, want.ctypes.data, None) == 0
+        di, dn = img.to("cuda"), nz.to("cuda")
+        torch_form = torch.clamp(di + (dn * sd + mean), 0, 1)
+        got = ops.noise_clamp(di, dn.clone(), mean, sd)
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert torch.equal(got.view(torch.int32), torch_form.view(torch.int32)) and bool(torch.isnan(got[3])) and float(got[5]) == 1.0
+    for n in (512 * 512, 129):
+        rgb = torch.rand((n, 3), generator=g) * 3.0
+        for dt in (torch.float32, torch.float16):
+            src = rgb.to(dt)
+            want = np.empty(n, np.float32)
+            assert olib.ffx_rgb_to_gray(src.numpy().ctypes.data, int(dt == torch.float16), n, 0.299, 0.587, 0.114, want.ctypes.data, None) == 0
+            dsrc = src.to("cuda")
+            got = ops.rgb_to_gray(dsrc)
+            np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+            f = dsrc.float()
+            assert torch.equal(got, f[..., 0] * 0.299 + f[..., 1] * 0.587 + f[..., 2] * 0.114)
+    # the relabelling of depth.py:119-125 in one reduction (graphics.depth._labels): ids -= min; ids = max - ids
+    from fireflies_amd.graphics import depth
+
+    ids = torch.randint(-1, 5, (4096,), generator=g).to(torch.int32).to("cuda")
+    ptr = ids.to(torch.int64) + 1
+    ptr = ptr - ptr.min()
+    assert torch.equal(depth._labels(ids), ptr.max() - ptr)
+    assert torch.equal(depth._labels(torch.full((7,), -1, dtype=torch.int32, device="cuda")), torch.zeros(7, dtype=torch.int64, device="cuda"))
+
+
 def test_k3_blur(oracle):
     rng = np.random.default_rng(0)
     for shape in ((500, 500), (37, 61), (6, 7), (3, 4)):

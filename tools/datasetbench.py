@@ -28,7 +28,7 @@ random.seed(0)
 def sample(i):
     wl.ff_scene.randomize()
     img = mi.render(wl.mi_scene, spp=spp, seed=i).torch()
-    grey = img[..., 0] * 0.299 + img[..., 1] * 0.587 + img[..., 2] * 0.114  # cv2.COLOR_RGB2GRAY weights
+    grey = pp.rgb_to_gray(img)  # cv2.COLOR_RGB2GRAY's weights, one launch (as a torch expression: five)
     out = chain.post_process(grey)
     seg = ff.graphics.depth.get_segmentation_from_camera(wl.mi_scene)
     depth = ff.graphics.depth.from_camera_non_wrapped(wl.mi_scene, spp=1)
