@@ -2132,13 +2132,18 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
                                                 uint32_t astride, const WideScene &ws, uint2 *__restrict__ stack, const bool (&active)[R], const v3 (&o)[R],
                                                 const v3 (&d)[R], const float (&nt)[R], const float (&ft)[R], SampleTerms (&st)[R],
                                                 const float4 *__restrict__ nrec, const float4 *__restrict__ gn, const int px, const int py,
-                                                const float *__restrict__ tex_probe = nullptr) {
+                                                const float *__restrict__ tex_probe = nullptr, const int blk_w = 1, const int blk_h = 1) {
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   Hit h[R];
   bool fnd[R];
   FFX_TSTART(tp);
   bool binned = false;
-  if constexpr (R == 1) binned = bins_primary(kernarg_shade().bins, px, py, arecs, d[0], nt[0], ft[0], wballot(active[0]), h[0]);
+  // (blk_w x blk_h > 1: the packet's primary rays belong to a compact block of pixels whose first is (px, py) — k_render_fwd_blk, renders at
+  // fewer than 64 samples per pixel; the default arguments are constants of every other caller)
+  if constexpr (R == 1) {
+    if (blk_w * blk_h == 1) binned = bins_primary(kernarg_shade().bins, px, py, arecs, d[0], nt[0], ft[0], wballot(active[0]), h[0]);
+    else binned = bins_block(kernarg_shade().bins, px, py, blk_w, blk_h, arecs, d[0], nt[0], ft[0], wballot(active[0]), h[0]);
+  }
   if (!binned) {
     if constexpr (R == 1) FFX_STAT(36);
     traverse_packet_any<false, R, WIDE>(nodes, arecs, ws, stack, o, d, nt, ft, active, h, fnd); // apex 0: the camera
@@ -3171,6 +3176,114 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   FFX_TFLUSH();
 }
 
+// ---- K8 at fewer than 64 samples per pixel (round 5): the plain forward, box film.  k_render_fwd_pk gives every pixel a wave of its own
+// whatever the sample count — at 1 spp one lane of 64 works and the launch costs what it costs at 64 (0.37 ms at 512^2: the dataset loop of
+// main.py:138-160 draws its spp from 1..100).  Here a wave owns a compact block of bw x bh pixels with spp_w sample slots each, as
+// k_trace_primary_pk does (same layout, same caps: thinner packets mean fewer exact tests per walk and enough waves to fill the GPU); the
+// block's primary rays take the block's rectangle to the camera's tile bins (bins_block), shadow packets their samples' bounding box as always.
+// Shading is shade_sample_pk's, per sample; a pixel's sum runs over its own spp_w lanes (xor butterfly inside the group).  No adjoint cache,
+// no fused adjoint, no reconstruction filter: those keep a pixel per wave.
+template <bool WIDE, int MATM>
+__global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : FFX_PK1_WAVES, MATM ? FFX_PK_MAT_WAVES : FFX_PK1_WAVES)))
+    k_render_fwd_blk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride, WideScene ws,
+                     const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int bw_log2, int bh_log2, int blocks_x, int n_blocks,
+                     int fp16, void *__restrict__ img, float inv_spp_arg, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
+  constexpr bool MAT = MATM != 0, TEX = MATM == 2;
+  constexpr int MS = MAT ? FFX_MAT_STRIDE : 3;
+  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
+  const int blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (blk >= n_blocks) return; // whole wave
+  const int lane = threadIdx.x & 63;
+  const int ppw_log2 = bw_log2 + bh_log2;
+  const int spp_w = 64 >> ppw_log2;      // sample slots per pixel (>= spp: the host chooses the block so)
+  const int pl = lane >> (6 - ppw_log2); // pixel of the block
+  const int sl = lane & (spp_w - 1);     // sample slot
+  const int bx0 = (blk % blocks_x) << bw_log2, by0 = (blk / blocks_x) << bh_log2;
+  const int x = bx0 + (pl & ((1 << bw_log2) - 1)), y = by0 + (pl >> bw_log2);
+  const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
+  const bool in_img = x < W && y < H;
+  const uint32_t pix = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+  const bool active[1] = {in_img && sl < spp};
+  v3 o[1], d[1];
+  float nt[1], ft[1];
+  {
+    const CamK &cam = kernarg_shade().cam;
+    float jx, jy;
+    sample_jitter(seed_key, pix * (uint32_t)spp + (uint32_t)sl, jx, jy);
+    cam_ray(cam, ((float)x + jx) * cam.inv_w, ((float)y + jy) * cam.inv_h, o[0], d[0], nt[0], ft[0]);
+  }
+  SampleTerms st[1];
+  shade_sample_pk<1, WIDE, MATM>(nodes, recs, arecs, astride, ws, s_wstack, active, o, d, nt, ft, st, nrec, gn, bx0, by0, tex, 1 << bw_log2, 1 << bh_log2);
+  const ShadeK &ct = kernarg_shade(); // texture gather and the sample's colour: k_render_fwd_pk's arithmetic
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  if (st[0].hit) {
+    float r0 = st[0].spot[0], r1 = st[0].spot[1], r2 = st[0].spot[2];
+    float b0 = st[0].spot_b[0], b1 = st[0].spot_b[1], b2 = st[0].spot_b[2]; // (MAT only: dead otherwise)
+    if (st[0].has_proj) {
+      const int tc = ct.tc;
+      const size_t o00 = ((size_t)st[0].iy0 * ct.tw + st[0].ix0) * tc, o01 = ((size_t)st[0].iy0 * ct.tw + st[0].ix1) * tc;
+      const size_t o10 = ((size_t)st[0].iy1 * ct.tw + st[0].ix0) * tc, o11 = ((size_t)st[0].iy1 * ct.tw + st[0].ix1) * tc;
+      const float wx0 = st[0].wx0, wx1 = st[0].wx1, wy0 = st[0].wy0, wy1 = st[0].wy1, pf = st[0].proj_fac, pb = st[0].proj_fac_b;
+      if (tc == 1) {
+        const float tv = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
+        r0 += tv * ct.p_color[0] * pf;
+        r1 += tv * ct.p_color[1] * pf;
+        r2 += tv * ct.p_color[2] * pf;
+        if constexpr (MAT) {
+          b0 += tv * ct.p_color[0] * pb;
+          b1 += tv * ct.p_color[1] * pb;
+          b2 += tv * ct.p_color[2] * pb;
+        }
+      } else {
+        const float tv0 = wy0 * (wx0 * tex[o00] + wx1 * tex[o01]) + wy1 * (wx0 * tex[o10] + wx1 * tex[o11]);
+        const float tv1 = wy0 * (wx0 * tex[o00 + 1] + wx1 * tex[o01 + 1]) + wy1 * (wx0 * tex[o10 + 1] + wx1 * tex[o11 + 1]);
+        const float tv2 = wy0 * (wx0 * tex[o00 + 2] + wx1 * tex[o01 + 2]) + wy1 * (wx0 * tex[o10 + 2] + wx1 * tex[o11 + 2]);
+        r0 += tv0 * 1.0f * pf;
+        r1 += tv1 * 1.0f * pf;
+        r2 += tv2 * 1.0f * pf;
+        if constexpr (MAT) {
+          b0 += tv0 * 1.0f * pb;
+          b1 += tv1 * 1.0f * pb;
+          b2 += tv2 * 1.0f * pb;
+        }
+      }
+    }
+    if constexpr (TEX) {
+      c0 = st[0].base[0] * r0;
+      c1 = st[0].base[1] * r1;
+      c2 = st[0].base[2] * r2;
+    } else {
+      const float *alb = mat_table(ct) + MS * st[0].shape;
+      c0 = alb[0] * r0;
+      c1 = alb[1] * r1;
+      c2 = alb[2] * r2;
+    }
+    if constexpr (MAT) { c0 += b0; c1 += b1; c2 += b2; }
+  }
+  // the pixel's samples sit in spp_w neighbouring lanes: a butterfly inside the group, nearest partners first — the tree of k_render_fwd_pk's DPP
+  // chain (pairs, quads, half rows, rows, rows of rows; its lanes beyond the sample count add zeros), so the two kernels store the same bits
+  for (int m = 1; m < spp_w; m <<= 1) {
+    c0 += __shfl_xor(c0, m, 64);
+    c1 += __shfl_xor(c1, m, 64);
+    c2 += __shfl_xor(c2, m, 64);
+  }
+  if (in_img && sl == 0) {
+    const size_t o3 = (size_t)pix * 3;
+    if (fp16 & 1) {
+      _Float16 *p = (_Float16 *)img;
+      p[o3] = (_Float16)(c0 * inv_spp_arg);
+      p[o3 + 1] = (_Float16)(c1 * inv_spp_arg);
+      p[o3 + 2] = (_Float16)(c2 * inv_spp_arg);
+    } else {
+      float *p = (float *)img;
+      p[o3] = c0 * inv_spp_arg;
+      p[o3 + 1] = c1 * inv_spp_arg;
+      p[o3 + 2] = c2 * inv_spp_arg;
+    }
+  }
+}
+
+
 // Deterministic accumulation (ffx_render_bwd_det, include/ffx.h): float atomics make gtex depend on the order in which the samples' taps arrive
 // (reassociation: ~1e-7 relative, different from run to run).  INTEGER additions commute: mode 1 finds the largest |tap value| of the launch
 // (atomicMax on the float's bits — order-independent), the host derives a power-of-two scale from it, mode 2 adds llrint(value * scale) to a
@@ -3920,6 +4033,11 @@ static int pixels_per_wave(bool with_cache, long pixels = 0) {
 
 // experiment knob: dynamic LDS bytes per workgroup of the packet kernels (unused by the kernel; it only
 // lowers occupancy so that latency- and throughput-bound behaviour can be told apart)
+// renders below 33 samples per pixel take k_render_fwd_blk (several pixels per wave); FFX_RENDER_BLOCKS=0: a pixel per wave whatever the count
+static bool lowspp_blocks() {
+  const char *e = getenv("FFX_RENDER_BLOCKS");
+  return !(e && strcmp(e, "0") == 0);
+}
 static size_t dummy_lds() {
   const char *e = getenv("FFX_DUMMY_LDS");
   return e ? (size_t)atol(e) : 0;
@@ -4165,7 +4283,8 @@ int ffx_trace_primary(const void *bvh, const ffx_bvh_info *info, const ffx_camer
       // 1 / 2 / 4 spp 0.118 / 0.105 / 0.095 ms with full waves, 0.071 / 0.056 / 0.057 ms capped; >= 8 spp unchanged.
       // FFX_K7_PPW_LOG2 overrides the cap (experiment knob).
       static const int env_cap = getenv("FFX_K7_PPW_LOG2") ? atoi(getenv("FFX_K7_PPW_LOG2")) : -1;
-      const int cap = env_cap >= 0 ? env_cap : (spp == 1 ? 4 : 3);
+      // (tools/lowspp.py, 512^2: 4 / 8 / 16 / 32 / 64 pixels per wave at 1 spp = 0.174 / 0.160 / 0.169 / 0.192 / 0.239 ms; at 4 spp 0.193 / 0.175 / 0.185)
+      const int cap = env_cap >= 0 ? env_cap : 3;
       if (ppw_log2 > cap) ppw_log2 = cap;
     }
     const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
@@ -4314,6 +4433,27 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
                          img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
       FFX_CHECK_LAUNCH("render_fwd_filtered/gather");
+      return FFX_OK;
+    }
+    if (!cache && !adj_gtex && spp <= 32 && lowspp_blocks()) {
+      // fewer than 64 samples per pixel: several pixels per wave (k_render_fwd_blk).  Sample slots per pixel = the next power of two >= spp; the
+      // block never exceeds 8 pixels (K7's reason, ffx_trace_primary: thinner packets, fewer exact tests per walk, more waves)
+      int slots = 1;
+      while (slots < spp) slots <<= 1;
+      int ppw_log2 = 0;
+      while ((slots << (ppw_log2 + 1)) <= 64) ++ppw_log2;
+      static const int env_cap = getenv("FFX_RENDER_BLK_LOG2") ? atoi(getenv("FFX_RENDER_BLK_LOG2")) : -1; // (experiment knob: pixels per wave, log2)
+      const int cap = env_cap >= 0 ? env_cap : (spp == 1 ? 4 : 3);
+      if (ppw_log2 > cap) ppw_log2 = cap;
+      const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
+      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(c.cam.H, 1 << bh_log2);
+#define FFX_LAUNCH_BLK(WIDE_, MAT_)                                                                                                                     \
+  hipLaunchKernelGGL((k_render_fwd_blk<WIDE_, MAT_>), dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
+                     shape_albedo, tex, spp, seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, img_fp16, img, 1.0f / (float)spp, nrec, gn)
+      if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_BLK(true, 2); else if (matm == 1) FFX_LAUNCH_BLK(true, 1); else FFX_LAUNCH_BLK(true, 0); }
+      else { if (matm == 2) FFX_LAUNCH_BLK(false, 2); else if (matm == 1) FFX_LAUNCH_BLK(false, 1); else FFX_LAUNCH_BLK(false, 0); }
+#undef FFX_LAUNCH_BLK
+      FFX_CHECK_LAUNCH("render_fwd (pixel blocks)");
       return FFX_OK;
     }
     if (use_wide(info)) { if (matm == 2) FFX_LAUNCH_FWD_(true, 2, false); else if (matm == 1) FFX_LAUNCH_FWD(true, 1); else FFX_LAUNCH_FWD(true, 0); }

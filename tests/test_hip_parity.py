@@ -185,6 +185,38 @@ def test_k2_depth_and_lines(oracle):
 
 
 # ------------------------------------------------------------------ K3
+def test_renders_below_64_spp_pack_several_pixels_into_a_wave(oracle, monkeypatch):
+    """k_render_fwd_blk (round 5): below 33 samples per pixel ffx_render_fwd gives a wave a compact block of pixels instead of one (K7's layout):
+    sample counts from 1 to 32 — powers of two and not — on a film whose sides are no multiple of any block, fp32 and fp16, Lambert and material
+    rows, with and without shadow rays and tile bins: against the oracle within the radiance bounds, and bit for bit the image of the
+    pixel-per-wave kernel (FFX_RENDER_BLOCKS=0: the same samples, the same summation tree)."""
+    for k in ("FFX_TRAVERSAL", "FFX_WIDE", "FFX_BINS", "FFX_RENDER_BLOCKS"):
+        monkeypatch.delenv(k, raising=False)
+    for principled in (False, True):
+        sc = scenes.vocalfold(width=45, height=37, tex=64, frames=3, n_fold=20, tube=(20, 24), principled=principled)
+        go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 8))
+        tex = _tex(sc, 1)
+        for shadows in (True, False):
+            sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=shadows)
+            for spp in ((1, 2, 3, 4, 7, 8, 16, 24, 32) if shadows else (1, 5, 32)):
+                want = go.render_fwd(sd, alb, host(tex), spp, seed=21)
+                for env in ({}, {"FFX_BINS": "0"}, {"FFX_WIDE": "0", "FFX_BINS": "0"}):
+                    for k, v in env.items():
+                        monkeypatch.setenv(k, v)
+                    got = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=21))
+                    monkeypatch.setenv("FFX_RENDER_BLOCKS", "0")
+                    one = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=21))
+                    monkeypatch.delenv("FFX_RENDER_BLOCKS")
+                    for k in env:
+                        monkeypatch.delenv(k)
+                    scale, _ = _assert_image_close(got, want, spp, frac=1e-3, what=f"pixel blocks, {spp} spp, {env}, principled {principled}")
+                    assert scale > 0.02
+                    np.testing.assert_array_equal(got.view(np.uint32), one.view(np.uint32), err_msg=f"{spp} spp {env}")  # (the same summation tree)
+                if spp in (1, 7, 32):
+                    h16 = host(gd.render_fwd(sd, dev(alb), tex, spp, seed=21, fp16=True).float())
+                    np.testing.assert_allclose(h16, got, rtol=2e-3, atol=1e-4 * scale)
+
+
 def test_dataset_path_steps_in_single_launches(oracle):
     """include/ffx.h ffx_silhouette_fwd / ffx_noise_clamp / ffx_rgb_to_gray (ABI 8): each against the oracle's long form (mask -> its K3
     blur -> product; the clipped sum; the weighted sum) and against the torch expressions they replace in fireflies_amd.postprocessing — bit for bit,
