@@ -596,16 +596,18 @@ def main():
 
     events = []
 
-    # Per-launch HIP event pairs (on the launch streams) are recorded for every 8th step of a timed bracket, at most
-    # TIMED_STEPS of them (two in a 20-step bracket), and resolved right after it.  Every pair costs two marker packets around the kernel, which
+    # Per-launch HIP event pairs (on the launch streams) are recorded for every 16th step of a timed bracket, at most
+    # TIMED_STEPS of them (one in a 20-step bracket), and resolved right after it.  Every pair costs two marker packets around the kernel, which
     # keep the next step's refit from overlapping it: with all 20 steps of a short bracket instrumented the bracket
     # itself ran 8 % slower; and hundreds of unresolved timing events slow every later launch of the process down
     # (measured: the gradient bracket ran at half speed after 600 of them).
     TIMED_STEPS = int(os.environ.get("FFX_BENCH_TIMED_STEPS", "8"))
 
-    def _timed(i, first, steps=None):  # steps 4, 12, 20, ... of a bracket (not its first step, which starts on an idle GPU)
-        off = 4 if (steps is None or steps > 4) else 0  # (a bracket of fewer than five steps: its first)
-        return i >= first + off and (i - first - off) % 8 == 0 and (i - first - off) // 8 < TIMED_STEPS
+    def _timed(i, first, steps=None):  # steps 8, 24, 40, ... of a bracket (not its first steps, which start on an idle GPU)
+        # (every 16th since round 5 — ONE step of the driver's 20: the marker packets of a timed step cost the bracket ~0.1 ms, more the further the host
+        # runs ahead of the device, and the roofline takes its per-launch time from the drained launches of kernel_alone_ms, not from these)
+        off = 8 if (steps is None or steps > 8) else 0  # (a bracket of fewer than nine steps: its first)
+        return i >= first + off and (i - first - off) % 16 == 0 and (i - first - off) // 16 < TIMED_STEPS
 
     w_render = 0 if args.no_render_steps else args.warmup
     n_render = args.steps if not args.no_render_steps else 1
