@@ -62,7 +62,7 @@ def main():
             sub = tot[base:base + 5]
             lab = "closest-hit walks" if k == 22 else "any-hit walks (both emitters)"
             for j in (4, 0, 1, 2, 3):
-                if sub[j] > 0:
+                if 100 * sub[j] / npx / whole >= 0.05:  # (the handful of packets that fall back to the tree would print a row of zeros)
                     print(f"      {lab} (tree fallback): {WALK[j]:40s} {sub[j] / npx:8.1f}  {100 * sub[j] / npx / whole:5.1f} %")
     print(f"  {'(sum of the phases)':78s} {acc:8.1f}  {100 * acc / whole:5.1f} %")
 
