@@ -10,7 +10,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fireflies_amd import mi, ops, scene as ffscene, scene_desc, workloads  # noqa: E402
+from fireflies_amd import mi, scene_desc, workloads  # noqa: E402
 
 SPP = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 # "small": the same entities, samplers and parameter keys over a 64x56 film and ~2 k triangles — the host's work per step is the same, the device's
@@ -76,10 +76,6 @@ print(f"{1e6 * tot / N:7.1f} us per step (wrapped loop, {SPP} spp); geometry pus
 for k, v in acc.items():
     print(f"{k:70s} {1e-3 * v / N:7.1f} us  ({cnt[k] / N:.0f} calls)")
 # ... and the loop as a script runs it (no wrappers)
-for k in list(acc):
-    pass
-import importlib  # noqa: E402
-
 wl2 = workloads.vocalfold(device="cuda", entity_device="cuda", **KW)
 with torch.no_grad():
     wl2.params["tex.data"] = workloads.build_texture(wl2).contiguous()
