@@ -6,7 +6,6 @@ offset), miss value 0 and the label rule follow depth.py:54-84,119-125; the jitt
 """
 import torch
 
-from .. import ops  # noqa: F401 (kept importable as depth.ops: scripts written against round 1 reach the launch wrappers through it)
 from ..utils import math as ffmath
 
 
