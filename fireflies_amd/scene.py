@@ -685,6 +685,8 @@ class Scene:
         lz = self._lazy
         if lz is not None and lz[0] is not plan:
             self._materialise()  # (another configuration's sample: its entities need not be this one's)
+        if p._pending is not None and lz is None:
+            p._pending()  # (a sample pushed through ANOTHER Scene object over the same parameter map: told to the map before this one replaces it)
         if not p._scene.step_native(sp, vals[k], mats[1][k], mats[2][k], frames):
             return False
         # what the sample means for the parameter map and the entities is worked out when somebody looks (_materialise): the device has it all
