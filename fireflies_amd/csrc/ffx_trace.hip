@@ -2694,6 +2694,52 @@ __device__ __forceinline__ void rf_store(float *__restrict__ part, uint32_t pix,
   if (lane < 25) reinterpret_cast<float4 *>(part)[(size_t)pix * 25 + lane] = make_float4(acc[0] + h0, acc[1] + h1, acc[2] + h2, acc[3] + h3);
 }
 
+// rf_fold + rf_store for a wave that holds SEVERAL pixels (k_render_fwd_blk<..., RF>: 2^ppw_log2 pixels x spp_w = 64 >> ppw_log2 sample slots, pixel q in
+// lanes [q spp_w, (q + 1) spp_w)): the same 14 rows of 64 floats; then work item (pixel q, window entry n) runs over ITS pixel's slots in order — the
+// fma chain rf_fold runs over a half's 32 samples, where the slots beyond the sample count add exact zeros and the second half is empty: the same bits
+// as the pixel-per-wave kernel's sums.  50 items per round (two pixels x 25 entries), 2^ppw_log2 / 2 rounds: 160 multiply-adds per lane as in rf_fold,
+// for 2^ppw_log2 pixels instead of one.
+__device__ __forceinline__ void rf_fold_blk(float *__restrict__ s_rf, int lane, const float (&gx)[5], const float (&gy)[5], float l0, float l1, float l2, float l3,
+                                            int ppw_log2, int bw_log2, int bx0, int by0, int W, int H, float *__restrict__ part) {
+  int lz = lane;
+  asm volatile("" : "+v"(lz));
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    s_rf[a * FFX_RF_ROW + lz] = gx[a];
+    s_rf[(5 + a) * FFX_RF_ROW + lz] = gy[a];
+  }
+  s_rf[10 * FFX_RF_ROW + lz] = l0;
+  s_rf[11 * FFX_RF_ROW + lz] = l1;
+  s_rf[12 * FFX_RF_ROW + lz] = l2;
+  s_rf[13 * FFX_RF_ROW + lz] = l3;
+  __builtin_amdgcn_wave_barrier();
+  const int spp_w = 64 >> ppw_log2, groups = spp_w >> 2; // float4 groups of a pixel's slots (spp_w >= 8: the block never exceeds 8 pixels)
+  const int item = lz < 50 ? lz : 49, ql = item >= 25 ? 1 : 0, n = item - 25 * ql;
+  const int b = (n * 13) >> 6, a = n - 5 * b; // n / 5, n % 5 for n < 25
+  const int n_pix = 1 << ppw_log2;
+  for (int q0 = 0; q0 < n_pix; q0 += 2) {
+    const int q = q0 + ql; // (a block of one pixel does not get here: the host sends >= 2 pixels per wave, or the pixel-per-wave kernel)
+    const float4 *rx = reinterpret_cast<const float4 *>(s_rf + a * FFX_RF_ROW) + q * groups;
+    const float4 *ry = reinterpret_cast<const float4 *>(s_rf + (5 + b) * FFX_RF_ROW) + q * groups;
+    const float4 *r0 = reinterpret_cast<const float4 *>(s_rf + 10 * FFX_RF_ROW) + q * groups;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int k = 0; k < groups; ++k) {
+      const float4 X = rx[k], Y = ry[k];
+      const float4 L0 = r0[k], L1 = r0[k + FFX_RF_ROW / 4], L2 = r0[k + 2 * (FFX_RF_ROW / 4)], L3 = r0[k + 3 * (FFX_RF_ROW / 4)];
+      const float w0 = X.x * Y.x, w1 = X.y * Y.y, w2 = X.z * Y.z, w3 = X.w * Y.w;
+      t0 = __builtin_fmaf(w0, L0.x, t0); t1 = __builtin_fmaf(w0, L1.x, t1); t2 = __builtin_fmaf(w0, L2.x, t2); t3 = __builtin_fmaf(w0, L3.x, t3);
+      t0 = __builtin_fmaf(w1, L0.y, t0); t1 = __builtin_fmaf(w1, L1.y, t1); t2 = __builtin_fmaf(w1, L2.y, t2); t3 = __builtin_fmaf(w1, L3.y, t3);
+      t0 = __builtin_fmaf(w2, L0.z, t0); t1 = __builtin_fmaf(w2, L1.z, t1); t2 = __builtin_fmaf(w2, L2.z, t2); t3 = __builtin_fmaf(w2, L3.z, t3);
+      t0 = __builtin_fmaf(w3, L0.w, t0); t1 = __builtin_fmaf(w3, L1.w, t1); t2 = __builtin_fmaf(w3, L2.w, t2); t3 = __builtin_fmaf(w3, L3.w, t3);
+    }
+    const int x = bx0 + (q & ((1 << bw_log2) - 1)), y = by0 + (q >> bw_log2);
+    // (rf_store adds the second half's sums — here an empty half: + 0.f keeps the bits and turns a -0.f into the +0.f the other kernel stores)
+    if (lz < 50 && q < n_pix && x < W && y < H)
+      reinterpret_cast<float4 *>(part)[((size_t)y * W + x) * 25 + n] = make_float4(t0 + 0.f, t1 + 0.f, t2 + 0.f, t3 + 0.f);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // the weights alone (the adjoint's first launch): one wave per pixel, the jitter decides everything
 __global__ void __launch_bounds__(64) k_rf_weights(RfC rfc, int n_pix, int spp, uint32_t seed_key, float *__restrict__ part) {
   __shared__ __attribute__((aligned(16))) float s_rf[FFX_RF_FLOATS]; // (rf_fold reads it in 16-byte units)
@@ -3183,14 +3229,17 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // block's primary rays take the block's rectangle to the camera's tile bins (bins_block), shadow packets their samples' bounding box as always.
 // Shading is shade_sample_pk's, per sample; a pixel's sum runs over its own spp_w lanes (xor butterfly inside the group).  No adjoint cache,
 // no fused adjoint, no reconstruction filter: those keep a pixel per wave.
-template <bool WIDE, int MATM>
+// RF (ffx_render_fwd_filtered below 33 spp): instead of the pixels' means the wave leaves every pixel's 25 x 4 outgoing sums in the scratch area
+// (`img`: [pixel][25][4] floats), as k_render_fwd_pk<..., RF> does — rf_fold_blk below.
+template <bool WIDE, int MATM, bool RF = false>
 __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(MATM ? FFX_PK_MAT_WAVES : FFX_PK1_WAVES, MATM ? FFX_PK_MAT_WAVES : FFX_PK1_WAVES)))
     k_render_fwd_blk(ShadeK c, const BvhNode *__restrict__ nodes, const TriRec *__restrict__ recs, const TriApex *__restrict__ arecs, uint32_t astride, WideScene ws,
                      const float *__restrict__ albedo, const float *__restrict__ tex, int spp, uint32_t seed_key, int bw_log2, int bh_log2, int blocks_x, int n_blocks,
                      int fp16, void *__restrict__ img, float inv_spp_arg, const float4 *__restrict__ nrec, const float4 *__restrict__ gn) {
   constexpr bool MAT = MATM != 0, TEX = MATM == 2;
   constexpr int MS = MAT ? FFX_MAT_STRIDE : 3;
-  __shared__ uint2 s_wstack[WIDE ? FFX_WSTACK : 1];
+  constexpr int WSTACK_N = WIDE ? FFX_WSTACK : 1, RF_N = (FFX_RF_FLOATS * 4 + 7) / 8;
+  __shared__ __attribute__((aligned(16))) uint2 s_wstack[RF ? (WSTACK_N > RF_N ? WSTACK_N : RF_N) : WSTACK_N]; // (RF: the filter's rows alias the walk's stack)
   const int blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (blk >= n_blocks) return; // whole wave
   const int lane = threadIdx.x & 63;
@@ -3259,6 +3308,14 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       c2 = alb[2] * r2;
     }
     if constexpr (MAT) { c0 += b0; c1 += b1; c2 += b2; }
+  }
+  if constexpr (RF) {
+    float jx, jy, gx[5], gy[5];
+    sample_jitter(seed_key, pix * (uint32_t)spp + (uint32_t)sl, jx, jy);
+    rf_weights(ct.rf, jx, gx);
+    rf_weights(ct.rf, jy, gy);
+    rf_fold_blk(reinterpret_cast<float *>(s_wstack), lane, gx, gy, c0, c1, c2, active[0] ? 1.f : 0.f, ppw_log2, bw_log2, bx0, by0, W, H, reinterpret_cast<float *>(img));
+    return;
   }
   // the pixel's samples sit in spp_w neighbouring lanes: a butterfly inside the group, nearest partners first — the tree of k_render_fwd_pk's DPP
   // chain (pairs, quads, half rows, rows, rows of rows; its lanes beyond the sample count add zeros), so the two kernels store the same bits
@@ -4420,6 +4477,24 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
                          img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr, (float *)((char *)rf_cache + rfc_off_wsum(n_pix)));
       FFX_CHECK_LAUNCH("render_fwd_cache_filtered/gather");
+      return FFX_OK;
+    }
+    if (rf_scratch && spp <= 32 && lowspp_blocks()) { // ... below 33 samples per pixel: several pixels per wave, the same scratch contents (k_render_fwd_blk<..., RF>)
+      int slots = 8; // (at least 8 sample slots per pixel: rf_fold_blk reads them in groups of four, two pixels per round)
+      while (slots < spp) slots <<= 1;
+      int ppw_log2 = 0;
+      while ((slots << (ppw_log2 + 1)) <= 64) ++ppw_log2; // 8 / 4 / 2 pixels per wave at <= 8 / 16 / 32 spp
+      const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
+      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(c.cam.H, 1 << bh_log2);
+#define FFX_LAUNCH_BLKF(MAT_)                                                                                                                            \
+  hipLaunchKernelGGL((k_render_fwd_blk<true, MAT_, true>), dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
+                     shape_albedo, tex, spp, seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, img_fp16 & 1, rf_scratch, 1.0f / (float)spp, nrec, gn)
+      if (matm == 2) FFX_LAUNCH_BLKF(2); else if (matm == 1) FFX_LAUNCH_BLKF(1); else FFX_LAUNCH_BLKF(0);
+#undef FFX_LAUNCH_BLKF
+      FFX_CHECK_LAUNCH("render_fwd_filtered (pixel blocks)");
+      hipLaunchKernelGGL(k_rf_gather, dim3(ffx_cdiv(c.cam.W, 64), ffx_cdiv(c.cam.H, FFX_RFG_WAVES)), dim3(64 * FFX_RFG_WAVES), 0, (hipStream_t)s, (const float4 *)rf_scratch, c.cam.W, c.cam.H,
+                         img_fp16 & 1, img, (const float *)nullptr, (float4 *)nullptr);
+      FFX_CHECK_LAUNCH("render_fwd_filtered/gather");
       return FFX_OK;
     }
     if (rf_scratch) { // the filtered render: the kernel leaves every pixel's 25 x 4 outgoing sums in the scratch area, the gather forms the image

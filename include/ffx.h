@@ -39,9 +39,9 @@
  *                                than the skip gains on the default workload (fireflies_amd/csrc/ffx_trace.hip clear_enabled)
  *       FFX_BIN_CAP=n            capacity of each grid's entry list, at most the default 2 F + 16384 (a test knob: a grid whose lists do
  *                                not fit is marked not-ok by the pre-pass and its packets take the tree walks — the overflow path)
- *       FFX_RENDER_BLOCKS=0      ffx_render_fwd below 33 samples per pixel: a pixel per wave whatever the count, as at 64 (default: compact
- *                                blocks of up to 8 pixels per wave, k_render_fwd_blk — the same image bit for bit, 1.5 - 2.2x faster;
- *                                FFX_RENDER_BLK_LOG2=n: at most 2^n pixels per wave, an experiment knob)
+ *       FFX_RENDER_BLOCKS=0      ffx_render_fwd / ffx_render_fwd_filtered below 33 samples per pixel: a pixel per wave whatever the count, as
+ *                                at 64 (default: compact blocks of up to 8 pixels per wave, k_render_fwd_blk — the same image bit for bit,
+ *                                1.5 - 2.3x faster; FFX_RENDER_BLK_LOG2=n: at most 2^n pixels per wave of the box film, an experiment knob)
  *     ffx_bvh_build_host additionally reads, once per build (host side; the renders do not depend on them —
  *     tests/test_hip_parity.py::test_wide_overlay_builders_give_identical_images):
  *       FFX_WIDE_BUILD=area|count|layers   builder of the 64-wide overlay (default area: greedy SAH cut)

@@ -217,6 +217,33 @@ def test_renders_below_64_spp_pack_several_pixels_into_a_wave(oracle, monkeypatc
                     np.testing.assert_allclose(h16, got, rtol=2e-3, atol=1e-4 * scale)
 
 
+def test_filtered_renders_below_33_spp_pack_several_pixels_into_a_wave(oracle, monkeypatch):
+    """k_render_fwd_blk<..., RF> (round 5): the gaussian film — the film of every scene the reference loads, whose examples render at 10 and 12 spp
+    (examples/01_hello_world.py:29, 06_animation.py:51) — below 33 samples per pixel: 8 / 4 / 2 pixels per wave whose 25 x 4 outgoing sums are formed by
+    rf_fold_blk; against the oracle, and bit for bit the image of the pixel-per-wave kernel (FFX_RENDER_BLOCKS=0: the same fma chains), on a film whose
+    sides are no multiple of a block, Lambert and material rows, 1- and 3-channel textures, fp16."""
+    from fireflies_amd import _abi
+    from tests.test_bruteforce_cpu import material_rows
+
+    monkeypatch.delenv("FFX_RENDER_BLOCKS", raising=False)
+    sc = scenes.vocalfold(width=53, height=42, tex=96, frames=3, n_fold=24, tube=(24, 32))
+    go, gd, alb = _pair(oracle, sc, frame=1, xforms=_rand_xforms(2, 2))
+    for ch, rows, stddev in ((1, alb, 0.5), (3, alb, 0.5), (1, material_rows(len(sc.meshes), 5), 0.5), (1, alb, 0.3)):
+        sd = scene_desc.scene_desc(sc, tex_channels=ch, shadows=True, mat_stride=_abi.MAT_STRIDE if rows.shape[1] == _abi.MAT_STRIDE else 0, rfilter=("gaussian", stddev))
+        tex = _tex(sc, ch)
+        for spp in (1, 3, 8, 10, 12, 16, 27, 32):
+            got = gd.render_fwd(sd, dev(rows), tex, spp, seed=11)
+            monkeypatch.setenv("FFX_RENDER_BLOCKS", "0")
+            one = gd.render_fwd(sd, dev(rows), tex, spp, seed=11)
+            monkeypatch.delenv("FFX_RENDER_BLOCKS")
+            assert torch.equal(got.view(torch.int32), one.view(torch.int32)), (ch, rows.shape, spp)
+            if spp in (1, 10, 32):
+                want = go.render_fwd(sd, rows, host(tex), spp, seed=11)
+                scale, _ = _assert_image_close(host(got), want, spp, frac=0.02, what=f"filtered pixel blocks ch={ch} spp={spp}")
+                h16 = host(gd.render_fwd(sd, dev(rows), tex, spp, seed=11, fp16=True)).astype(np.float32)
+                np.testing.assert_allclose(h16, host(got), rtol=1e-3, atol=1e-4 * scale)
+
+
 def test_dataset_path_steps_in_single_launches(oracle):
     """include/ffx.h ffx_silhouette_fwd / ffx_noise_clamp / ffx_rgb_to_gray (ABI 8): each against the oracle's long form (mask -> its K3
     blur -> product; the clipped sum; the weighted sum) and against the torch expressions they replace in fireflies_amd.postprocessing — bit for bit,

@@ -47,6 +47,27 @@ for pose in range(4):
         r = rows.setdefault(spp, [0.0, 0.0])
         r[0] += t_blk / 4
         r[1] += t_one / 4
-print("spp   pixel blocks   pixel per wave   (ms, mean of 4 poses)")
+print("box film:\nspp   pixel blocks   pixel per wave   (ms, mean of 4 poses)")
+for spp, (a, b) in rows.items():
+    print(f"{spp:3d}   {a:10.4f}   {b:12.4f}   x{b / a:5.2f}")
+# the gaussian film (the filtered render: kernel + gather), the film of every scene the reference loads
+ms.rfilter = "gaussian"
+rows = {}
+for pose in range(4):
+    torch.manual_seed(pose)
+    random.seed(pose)
+    wl.ff_scene.randomize()
+    sd = ms.scene_desc(tex_channels=1)
+    mats = ms.materials_arg(sd)
+    for spp in (1, 4, 8, 10, 12, 16, 32, 64):
+        os.environ.pop("FFX_RENDER_BLOCKS", None)
+        t_blk = timed(lambda: geom.render_fwd(sd, mats, tex3, spp, 7))
+        os.environ["FFX_RENDER_BLOCKS"] = "0"
+        t_one = timed(lambda: geom.render_fwd(sd, mats, tex3, spp, 7))
+        os.environ.pop("FFX_RENDER_BLOCKS", None)
+        r = rows.setdefault(spp, [0.0, 0.0])
+        r[0] += t_blk / 4
+        r[1] += t_one / 4
+print("gaussian film (kernel + gather):\nspp   pixel blocks   pixel per wave")
 for spp, (a, b) in rows.items():
     print(f"{spp:3d}   {a:10.4f}   {b:12.4f}   x{b / a:5.2f}")
