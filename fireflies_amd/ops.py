@@ -505,13 +505,15 @@ class DeviceGeometry:
         self._async = self.device.type == "cuda" and os.environ.get("FFX_ASYNC_UPDATE", "1") != "0"
         # (FFX_BLOB_COPIES >= 2: measured 2 / 3 / 4 copies = 2 050 / 2 043 / 2 038 renders/s — a longer window for the side stream's work buys
         # nothing: the GPU is busy either way, the re-fit and the pre-pass cost what they cost)
-        n_copies = max(2, int(os.environ.get("FFX_BLOB_COPIES", "2"))) if self._async else 1
+        # (round 5: four copies, of which renders at 33 samples per pixel and more use two — see _ring)
+        n_copies = max(2, int(os.environ.get("FFX_BLOB_COPIES", "4"))) if self._async else 1
         self._blobs = [b0] + [b0.clone() for _ in range(n_copies - 1)]
         self._cur = 0
         # (FFX_SIDE_PRIORITY: -1 = a high-priority queue for the side stream; measured: renders/s unchanged, gradient steps 2 130 -> 1 540 per
         # second — the step's small launches on the main stream then wait behind it.  0 = default)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) if self._async else None
         self._side_handle = None
+        self._last_spp = 64  # samples per pixel of the last render call (how deep update() lets the poses run ahead: _ring)
         self._upd_done = [None] * n_copies   # event: the refit of blob i has been enqueued up to here (side stream)
         self._apex = [None] * n_copies       # apex_key of what blob i's apex areas hold (None: nothing usable)
         self._apex_written = [None] * n_copies  # (stream handle, event) behind the call whose own pre-pass last wrote blob i's apex areas
@@ -568,6 +570,14 @@ class DeviceGeometry:
                 self._apex_written[self._cur if self._async else 0] = (so.cuda_stream, ev)
                 self._apex_writer_pending = False
 
+    def _ring(self):
+        """how many of the blob copies the next update() rotates through.  A render at 64 spp (0.39 ms) hides the whole side chain of the next pose
+        (re-fit -> count -> scan -> fill, ~0.18 ms beside it) behind itself with two copies — more only cost (2 050 / 2 043 / 2 038 renders/s with 2 / 3 / 4).
+        Below 33 spp the render is as short as the chain, and with two copies the chain of pose i + 2 has to wait for the render of pose i: 5 435 /
+        5 735 / 6 002 renders/s at 1 spp, 5 107 / 5 384 / 5 602 at 10 spp with 2 / 3 / 4 copies."""
+        n = len(self._blobs)
+        return n if self._last_spp <= 32 else min(n, 2)
+
     def _wait_readers(self, i, stream_obj):
         """`stream_obj` is about to WRITE into blob i (a re-fit, an apex pre-pass): every reader on another stream must be done"""
         for handle, ev in self._last_use[i].items():
@@ -623,7 +633,7 @@ class DeviceGeometry:
             self._update_into(self._blobs[0], xforms, on_device)
             self._prepare_apex(0, apex_sd)
             return
-        nxt = (self._cur + 1) % len(self._blobs)
+        nxt = (self._cur + 1) % self._ring()
         main = _stream_obj(self._didx)
         self._wait_readers(nxt, self._side)  # its readers must be done before it is overwritten
         if self._pool_written is not None:
@@ -655,7 +665,7 @@ class DeviceGeometry:
         the same blob rotation and ordering.  launch(blob index, side stream handle, with the pre-pass?) -> the scene description whose apex records and
         tile bins the blob then holds; vert_off: the frame offsets [S] the call used (host int32, already checked by it)."""
         self.version += 1
-        nxt = (self._cur + 1) % len(self._blobs)
+        nxt = (self._cur + 1) % self._ring()
         self._wait_readers(nxt, self._side)
         if self._pool_written is not None:
             self._side.wait_event(self._pool_written)
@@ -792,6 +802,7 @@ class DeviceGeometry:
         samples survives this call's reset (the later scene samples of a step that reuses one cache).
         A filtered film (sd.rfilter) with a cache: ffx_render_fwd_cache_filtered (per-sample records; render_bwd_cached needs the seed)."""
         H, W = sd.cam.height, sd.cam.width
+        self._last_spp = spp
         mats_arg = _check_materials(sd, albedo)
         img = torch.empty((H, W, 3), dtype=torch.float16 if fp16 else torch.float32, device=self.device) if img_out is None else img_out
         if tuple(img.shape) != (H, W, 3) or img.dtype != (torch.float16 if fp16 else torch.float32) or not img.is_contiguous():

@@ -510,18 +510,27 @@ def test_k5k6_async_double_buffered_update_matches_synchronous(monkeypatch):
         poses.append((_rand_xforms(2, 100 + i), offs))
     monkeypatch.setenv("FFX_ASYNC_UPDATE", "1")
     ga = ops.DeviceGeometry(pool, tris, shape, off)
-    assert ga._async and len(ga._blobs) == 2
-    outs = []
-    for xf, offs in poses:  # no synchronisation anywhere in this loop
-        ga.update(xf, offs)
-        outs.append(ga.trace_primary(cam, 4, 1, seed=9))
+    assert ga._async and len(ga._blobs) == 4
+    runs = []
+    for last_spp, ring in ((64, 2), (8, 4)):  # (the ring of blob copies update() rotates through: two behind renders at 33 spp and more, all four below)
+        ga._last_spp = last_spp
+        assert ga._ring() == ring
+        outs, used = [], set()
+        for xf, offs in poses:  # no synchronisation anywhere in this loop
+            ga.update(xf, offs)
+            used.add(ga._cur)
+            outs.append(ga.trace_primary(cam, 4, 1, seed=9))
+        assert len(used) == ring
+        runs.append(outs)
     monkeypatch.setenv("FFX_ASYNC_UPDATE", "0")
     gs = ops.DeviceGeometry(pool, tris, shape, off)
     assert not gs._async
-    for (xf, offs), (t, s_, p) in zip(poses, outs):
+    for i, (xf, offs) in enumerate(poses):
         gs.update(xf, offs)
         t2, s2, p2 = gs.trace_primary(cam, 4, 1, seed=9)
-        assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
+        for outs in runs:
+            t, s_, p = outs[i]
+            assert torch.equal(t, t2) and torch.equal(s_, s2) and torch.equal(p, p2)
 
 
 def test_async_update_with_caller_supplied_vertices(monkeypatch):
