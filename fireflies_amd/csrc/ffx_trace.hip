@@ -3247,7 +3247,13 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   const int spp_w = 64 >> ppw_log2;      // sample slots per pixel (>= spp: the host chooses the block so)
   const int pl = lane >> (6 - ppw_log2); // pixel of the block
   const int sl = lane & (spp_w - 1);     // sample slot
-  const int bx0 = (blk % blocks_x) << bw_log2, by0 = (blk / blocks_x) << bh_log2;
+  // blocks are enumerated in patches of 8 x 8 blocks (row-major inside a patch, patches row-major over the film: n_blocks counts whole patches), so that
+  // the waves the dispatcher starts together work on neighbouring tiles' lists
+  const int patches_x = (blocks_x + 7) >> 3, patch = blk >> 6, within = blk & 63;
+  const int pby = patch / patches_x, pbx = patch - pby * patches_x;
+  const int bxi = (pbx << 3) + (within & 7), byi = (pby << 3) + (within >> 3);
+  const int bx0 = bxi << bw_log2, by0 = byi << bh_log2;
+  if (bx0 >= c.cam.W || by0 >= c.cam.H) return; // (a patch that overhangs the film)
   const int x = bx0 + (pl & ((1 << bw_log2) - 1)), y = by0 + (pl >> bw_log2);
   const int W = c.cam.W, H = c.cam.H; // (the only direct use of the by-value copy)
   const bool in_img = x < W && y < H;
@@ -4485,7 +4491,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       int ppw_log2 = 0;
       while ((slots << (ppw_log2 + 1)) <= 64) ++ppw_log2; // 8 / 4 / 2 pixels per wave at <= 8 / 16 / 32 spp
       const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
-      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(c.cam.H, 1 << bh_log2);
+      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = 64 * ffx_cdiv(blocks_x, 8) * ffx_cdiv(ffx_cdiv(c.cam.H, 1 << bh_log2), 8); // (whole 8 x 8 patches)
 #define FFX_LAUNCH_BLKF(MAT_)                                                                                                                            \
   hipLaunchKernelGGL((k_render_fwd_blk<true, MAT_, true>), dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
                      shape_albedo, tex, spp, seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, img_fp16 & 1, rf_scratch, 1.0f / (float)spp, nrec, gn)
@@ -4521,7 +4527,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       const int cap = env_cap >= 0 ? env_cap : (spp == 1 ? 4 : 3);
       if (ppw_log2 > cap) ppw_log2 = cap;
       const int bw_log2 = (ppw_log2 + 1) / 2, bh_log2 = ppw_log2 / 2;
-      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = blocks_x * ffx_cdiv(c.cam.H, 1 << bh_log2);
+      const int blocks_x = ffx_cdiv(c.cam.W, 1 << bw_log2), n_blocks = 64 * ffx_cdiv(blocks_x, 8) * ffx_cdiv(ffx_cdiv(c.cam.H, 1 << bh_log2), 8); // (whole 8 x 8 patches)
 #define FFX_LAUNCH_BLK(WIDE_, MAT_)                                                                                                                     \
   hipLaunchKernelGGL((k_render_fwd_blk<WIDE_, MAT_>), dim3(ffx_cdiv(n_blocks, wpb)), dim3(64 * wpb), 0, (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
                      shape_albedo, tex, spp, seed_key_of(seed), bw_log2, bh_log2, blocks_x, n_blocks, img_fp16, img, 1.0f / (float)spp, nrec, gn)
