@@ -350,6 +350,9 @@ class Scene:
                 else:
                     self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f._from_rows(nc[0][i])
                 return
+        if self._pushed_natively:  # (told, not assigned: the device has it)
+            self._mitsuba_params._d[ent.name() + ".to_world"] = mi.Transform4f(ent._world_host().tolist())
+            return
         self._mitsuba_params[ent.name() + ".to_world"] = mi.Transform4f(ent._world_host().tolist())
 
     def update_camera(self) -> None:
