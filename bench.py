@@ -902,6 +902,29 @@ def main():
             finally:
                 wg.mi_scene.rfilter = "box"
 
+    # ------------------------------------------------------------------ the sample counts of the reference's own scripts
+    # examples/01..06 render at 10 and 12 spp, main.py:144 draws its spp from 1..100, all through hdrfilm's gaussian film: below 33 spp the renders pack
+    # several pixels into a wave (k_render_fwd_blk, round 5).  Two short brackets of the same randomise + render + read-back step, informational beside
+    # the headline (FFX_BENCH_LOWSPP=0: off): 16 spp with the box film, 10 spp with the gaussian film.
+    lowspp = {}
+    if args.rfilter == "box" and args.spp > 32 and not args.no_render_steps and os.environ.get("FFX_BENCH_LOWSPP", "1") != "0" and os.environ.get("FFX_BENCH_EXTRA_BRACKETS", "1") != "0":
+        def step_at(spp_):
+            def f(i):
+                wl.ff_scene.randomize()
+                return mi.render(wl.mi_scene, spp=spp_, seed=base_seed + i * world + rank, fp16=args.fp16).torch()
+            return f
+
+        t16 = _bracket(step_at(16), args.steps, args.warmup, dev)
+        wl.mi_scene.rfilter = "gaussian"
+        try:
+            t10 = _bracket(step_at(10), args.steps, args.warmup, dev)
+        finally:
+            wl.mi_scene.rfilter = "box"
+        lowspp = {"value_16spp": world * args.steps / t16, "ms_per_step_16spp": 1e3 * t16 / args.steps,
+                  "value_10spp_gaussian": world * args.steps / t10, "ms_per_step_10spp_gaussian": 1e3 * t10 / args.steps,
+                  "lowspp_config": "the headline's step at 16 spp (box film) and at 10 spp with the gaussian film (the reference's examples/01_hello_world.py:29); "
+                                   "below 33 spp a wave renders a compact block of pixels (k_render_fwd_blk), the same image bit for bit as a pixel per wave"}
+
     if rank != 0:
         return
     # the dominant kernel's time: the SIXTEEN launches timed behind the bracket (each between HIP events on its launch stream); the
@@ -992,6 +1015,7 @@ def main():
         rccl["renders_per_sec_per_rank"] = [args.steps / t for t in per_rank_t]
     out.update(grad)
     out.update(gauss)
+    out.update(lowspp)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, tex, args.spp, args.cpu_spp, seed=base_seed, grad_wl=wg if not args.no_grad_steps else None)
     else:
