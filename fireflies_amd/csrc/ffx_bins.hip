@@ -72,7 +72,7 @@ __device__ __forceinline__ bool bin_entry_touches(const BinEntry &en, float rx0,
 // 128x128) the workgroup could not be placed until a render had drained (134 us on average inside the bench loop, rocprofv3, against 7
 // alone), and four waves that must start on one CU together still waited 41 us.  The cursors keep the counts (the fill pass counts them
 // down) unless the lists do not fit — then they are cleared here, because no fill pass will run.
-__device__ void bin_scan_one(char *base, int nt, uint32_t cap) {
+__device__ void bin_scan_one(char *base, int nt, uint32_t cap, bool env) {
   uint32_t *starts = (uint32_t *)(base + ffx_bin_off_starts());
   uint32_t *cursors = (uint32_t *)(base + ffx_bin_off_cursors());
   const int lane = threadIdx.x;
@@ -110,6 +110,7 @@ __device__ void bin_scan_one(char *base, int nt, uint32_t cap) {
     h->total = total;
     h->cap = cap;
     h->ok = ok ? 1u : 0u;
+    h->env = env ? 1u : 0u;
   }
 }
 
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
 __global__ void __launch_bounds__(64) k_bin_scan(BinBuild bb) {
   FFX_SIDE_PRIO();
   const int g = blockIdx.x;
-  if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap);
+  if (bb.g[g].on && bb.base[g]) bin_scan_one(bb.base[g], bb.g[g].nx * bb.g[g].ny, bb.cap, g >= 1 && ((bb.env_mask >> (g - 1)) & 1));
 }
 
 // ---- "clear" triangles (ffx_common.h FFX_GN_CLEAR_BIT): the proof that nothing can shadow a triangle from an emitter.
@@ -435,8 +436,110 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+// ---- the ENVELOPE of an emitter's grid (ffx_common.h FFX_ENV_SUB; round 6).  The spot's any-hit stage is a quarter of the render kernel for an
+// emitter next to the camera that hardly anything shadows, and a per-triangle proof (k_bin_clear) settles a third of the
+// triangles at best: the neighbours of a triangle on a curved surface do come within the shadow ray's ignored tail of it.  What CAN be stated
+// cheaply is where the front of everything a tile lists lies.  Seen from the emitter E a triangle's plane is affine in 1 / depth:
+//     1 / t_j(d) = d . n_j,  n_j = A_j / T_j  (the apex record's own numbers),      d = Z Minv (x, y, 1)   =>   1 / (t_j Z) = m_j . (x, y, 1)
+// for the ray towards tile-space point (x, y).  A wave per tile, its 64 lanes on the 8 x 8 VERTICES of the tile's 7 x 7 cells; the tile's
+// entries one after the other (lanes on the entries first: 64 planes per trip into LDS, then broadcast reads): a vertex keeps the largest
+// plane value of the entries whose padded box touches one of the cells around it.  Over a cell each of those planes lies below the bilinear
+// patch of the cell's four vertex values (affine functions are reproduced by bilinear interpolation, whose weights are non-negative), and
+//     c0 + ax (x - X0) + ay (y - Y0),   ax, ay the patch's mean slopes,  c0 = max over the corners of (corner - slopes)
+// lies above the patch (their difference is bilinear: extremal at the corners).  In world space that plane is N . d <= 1 with
+//     N = kap (ax (M0 - X0 M2) + ay (M1 - Y0 M2) + c0 M2),   kap = (1 - 10 eps)(1 + 6e-5):
+// a shadow direction d = Po - E with N . d <= 1 has kap / t_j <= 1 for every listed triangle that can contain its image point — t_j beyond
+// the counted part of the ray with 6e-5 to spare for the roundings here (few 1e-6: everything is formed in tile-LOCAL coordinates) and of the
+// exact test's own det (2.4e-7 |d||A_j| / |d . A_j|: an entry steeper than 1 : 40 against the rays of a vertex poisons it, +inf).
+// Poisoned cells hold NaN (the render's `<= 1` fails), cells nothing touches hold 0 (nothing to hit: always proven).
+// (First version: lanes on the CELLS, four corner values each — 24 VALU per entry instead of 10, 100 us beside a render; the launch sits in
+// the chain the next render waits for.)
+struct EnvArgs { const TriApex *arecs; uint32_t astride; int n_first; /* workgroups of emitter 1 (0: its envelope is off) */ };
+template <int WPE>
+__global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_bin_env(BinBuild bb, EnvBuild eb, EnvArgs ea) {
+  FFX_SIDE_PRIO();
+  // (one launch for both emitters: the projector's tiles first, then the spot's)
+  const int n1 = ea.n_first;
+  const int a = (int)blockIdx.x < n1 ? 1 : 2;
+  const int tile = (int)blockIdx.x - (a == 1 ? 0 : n1);
+  const int nx = bb.g[a].nx;
+  const char *base = bb.base[a];
+  if (((const BinHdr *)base)->ok == 0u) return; // (lists incomplete: this pose's packets walk the tree and never look here, bins_ready)
+  const uint32_t *starts = (const uint32_t *)(base + ffx_bin_off_starts());
+  const uint32_t beg = starts[tile], n = starts[tile + 1] - beg;
+  const int lane = threadIdx.x & 63;
+  const int ty = tile / nx, tx = tile - ty * nx;
+  const int vx = lane & 7, vy = lane >> 3; // this lane's vertex; cell (vx, vy) for vx, vy < FFX_ENV_SUB
+  float4 *env = reinterpret_cast<float4 *>(bb.base[a] + eb.env_off) + ((size_t)(ty * FFX_ENV_SUB + vy) * (size_t)(nx * FFX_ENV_SUB)) + (size_t)(tx * FFX_ENV_SUB + vx);
+  const bool cell = vx < FFX_ENV_SUB && vy < FFX_ENV_SUB;
+  if (n == 0u) { // (outside the scene as the emitter sees it: nothing listed, nothing to hit)
+    if (cell) *env = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float4 *ents = reinterpret_cast<const float4 *>(base + ffx_bin_off_entries()) + 4 * (size_t)beg;
+  const char *rbase = reinterpret_cast<const char *>(ea.arecs) + (size_t)a * ea.astride;
+  const float h = 1.0f / FFX_ENV_SUB, pe = 1.0f / 4096.0f; // (cells a little wider than they are: the render's cell index comes from a rounded quotient)
+  const float lx = (float)vx * h, ly = (float)vy * h;       // the vertex, tile-local
+  const float bx0 = (float)tx + lx - h - pe, bx1 = (float)tx + lx + h + pe, by0 = (float)ty + ly - h - pe, by1 = (float)ty + ly + h + pe; // the cells around it
+  const float *Mi = eb.Minv[a];
+  // direction through the tile's origin and the two tile-space axes:  Minv (x, y, 1) = u0 + (x - tx) ux + (y - ty) uy
+  const v3 ux = V3(Mi[0], Mi[3], Mi[6]), uy = V3(Mi[1], Mi[4], Mi[7]);
+  const v3 u0 = V3(fmaf(Mi[0], (float)tx, fmaf(Mi[1], (float)ty, Mi[2])), fmaf(Mi[3], (float)tx, fmaf(Mi[4], (float)ty, Mi[5])), fmaf(Mi[6], (float)tx, fmaf(Mi[7], (float)ty, Mi[8])));
+  __shared__ __attribute__((aligned(16))) float4 s_bb[BIN_BLOCK];
+  __shared__ __attribute__((aligned(16))) float4 s_pl[BIN_BLOCK];
+  float w = -INFINITY;
+  for (uint32_t j0 = 0; j0 < n; j0 += 64u) { // (uniform)
+    const uint32_t i = j0 + (uint32_t)lane;
+    float4 bbv = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY), pl = make_float4(0.f, 0.f, 0.f, 0.f); // (beyond the list: touches nothing)
+    if (i < n) {
+      bbv = ents[4 * (size_t)i];
+      const int slot = __float_as_int(ents[4 * (size_t)i + 3].y);
+      const float4 *r4 = reinterpret_cast<const float4 *>(rbase + (size_t)slot * 48u);
+      const float4 rA = r4[0];
+      const float T = r4[2].y;
+      const float iT = 1.0f / T;
+      const v3 nj = V3(rA.x * iT, rA.y * iT, rA.z * iT);
+      pl = make_float4(vdot(nj, ux), vdot(nj, uy), vdot(nj, u0), sqrtf(vdot(nj, nj)) * eb.graz[a]);
+    }
+    if (j0 != 0u) __syncthreads(); // (one wave: orders this trip's writes behind the last trip's reads)
+    s_bb[lane] = bbv;
+    s_pl[lane] = pl;
+    __syncthreads();
+    const uint32_t m = min(64u, n - j0);
+#pragma unroll 4
+    for (uint32_t t = 0; t < m; ++t) { // (uniform: broadcast reads)
+      const float4 b = s_bb[t], p = s_pl[t];
+      asm volatile("" ::"v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w)); // (both rows read up front: no lazy, branchy re-reads)
+      const bool ov = (b.x <= bx1) & (b.z >= bx0) & (b.y <= by1) & (b.w >= by0); // (an unsafe entry's infinite box: every vertex)
+      const float pv = fmaf(p.x, lx, fmaf(p.y, ly, p.z));
+      const float q = pv >= p.w ? pv : INFINITY; // edge-on against this vertex's ray, behind the emitter there, or T = 0 (NaN): poison
+      w = ov ? fmaxf(w, q) : w;
+    }
+  }
+  // the cell's four vertices: this lane's, and those of the lanes 1, 8 and 9 further
+  const float w00 = w, w10 = __shfl_down(w, 1, 64), w01 = __shfl_down(w, 8, 64), w11 = __shfl_down(w, 9, 64);
+  if (!cell) return;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f); // a vertex nothing is near: nothing listed touches the cell
+  if (w00 != -INFINITY && w10 != -INFINITY && w01 != -INFINITY && w11 != -INFINITY) {
+    const float ih = (float)FFX_ENV_SUB;
+    const float ax = 0.5f * ((w10 - w00) + (w11 - w01)) * ih, ay = 0.5f * ((w01 - w00) + (w11 - w10)) * ih;
+    float c0 = fmaxf(fmaxf(w00, w10 - ax * h), fmaxf(w01 - ay * h, w11 - (ax + ay) * h));
+    c0 += 2e-6f * (fabsf(c0) + (fabsf(ax) + fabsf(ay)) * h);
+    const float gx0 = (float)tx + lx, gy0 = (float)ty + ly;
+    const float *M = bb.g[a].M;
+    const v3 m2 = V3(M[6], M[7], M[8]);
+    const v3 mx = V3(fmaf(-gx0, m2.x, M[0]), fmaf(-gx0, m2.y, M[1]), fmaf(-gx0, m2.z, M[2]));
+    const v3 my = V3(fmaf(-gy0, m2.x, M[3]), fmaf(-gy0, m2.y, M[4]), fmaf(-gy0, m2.z, M[5]));
+    const v3 N = V3(fmaf(ax, mx.x, fmaf(ay, my.x, c0 * m2.x)), fmaf(ax, mx.y, fmaf(ay, my.y, c0 * m2.y)), fmaf(ax, mx.z, fmaf(ay, my.z, c0 * m2.z)));
+    out = make_float4(N.x * eb.kap, N.y * eb.kap, N.z * eb.kap, 0.f);
+    const bool fin = fabsf(out.x) < 3.0e38f && fabsf(out.y) < 3.0e38f && fabsf(out.z) < 3.0e38f; // (false for NaN, and for a poisoned vertex: inf - inf)
+    if (!fin) out = make_float4(NAN, NAN, NAN, 0.f);
+  }
+  *env = out;
+}
+
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert, uint32_t *gn_words, int clear_on) {
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert, uint32_t *gn_words, int clear_on, const EnvBuild *env) {
   BinApex ba;
   memset(&ba, 0, sizeof ba);
   for (int a = 0; a < FFX_N_APEX; ++a) { ba.on[a] = apex_on[a]; ba.o[a][0] = apex_o[a][0]; ba.o[a][1] = apex_o[a][1]; ba.o[a][2] = apex_o[a][2]; }
@@ -455,6 +558,17 @@ void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const v
       const dim3 cgrid(nt * CLEAR_SPLIT, FFX_N_APEX - 1);
       if (beside_lambert) hipLaunchKernelGGL((k_bin_clear<8>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);
       else hipLaunchKernelGGL((k_bin_clear<7>), cgrid, dim3(BIN_BLOCK), 0, s, recs, bb, ba);
+    }
+    if (env && apex_out) { // the emitters' envelopes (ffx_common.h FFX_ENV_SUB): a wave per tile
+      int nt[FFX_N_APEX] = {0, 0, 0};
+      for (int a = 1; a < FFX_N_APEX; ++a) if (env->on[a] && bb.g[a].on && bb.base[a] && apex_on[a]) nt[a] = bb.g[a].nx * bb.g[a].ny;
+      if (nt[1] + nt[2] > 0) {
+        EnvArgs ea;
+        ea.arecs = (const TriApex *)apex_out; ea.astride = astride; ea.n_first = nt[1];
+        const dim3 egrid(nt[1] + nt[2]);
+        if (beside_lambert) hipLaunchKernelGGL((k_bin_env<8>), egrid, dim3(BIN_BLOCK), 0, s, bb, *env, ea);
+        else hipLaunchKernelGGL((k_bin_env<7>), egrid, dim3(BIN_BLOCK), 0, s, bb, *env, ea);
+      }
     }
   }
 }

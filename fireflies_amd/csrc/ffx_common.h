@@ -164,19 +164,32 @@ struct __attribute__((aligned(16))) BinEntry {
 static_assert(sizeof(BinEntry) == 64, "bin entry must be 64 bytes");
 // tile coordinates of a world point p seen from the apex o: (M[0..2] . (p - o)) / Z, (M[3..5] . (p - o)) / Z with Z = M[6..8] . (p - o) > 0
 struct BinGrid { float M[9]; float o[3]; int32_t nx, ny, on; };
-struct BinHdr { uint32_t ok, total, cap, pad[13]; };
+struct BinHdr { uint32_t ok, total, cap, pad0 /* apex 0: the fill pass's arrival counter (BinBuild.arrive) */, env /* this pose's pre-pass wrote the grid's envelope */, pad[11]; };
 static_assert(sizeof(BinHdr) == 64, "bin header must be 64 bytes");
 __host__ __device__ static inline uint64_t ffx_bin_cap(int n_tris) { return (uint64_t)2 * (uint64_t)n_tris + FFX_BIN_MAX_TILES; } // (a few screen-filling triangles fit)
 __host__ __device__ static inline uint64_t ffx_bin_off_starts() { return 64; }
 __host__ __device__ static inline uint64_t ffx_bin_off_cursors() { return 64 + 4 * (uint64_t)(FFX_BIN_MAX_TILES + 16); }
 __host__ __device__ static inline uint64_t ffx_bin_off_entries() { return (ffx_bin_off_cursors() + 4 * (uint64_t)FFX_BIN_MAX_TILES + 63) & ~(uint64_t)63; }
-__host__ __device__ static inline uint64_t ffx_bin_stride(int n_tris) { return (ffx_bin_off_entries() + 64 * (ffx_bin_cap(n_tris) + 64) + 63) & ~(uint64_t)63; }
+// Round 6: the ENVELOPE of an emitter's grid (k_bin_env, ffx_bins.hip; read by bins_shadow, ffx_trace.hip).  Every tile is cut into
+// FFX_ENV_SUB x FFX_ENV_SUB cells (7: their 8 x 8 vertices are the 64 lanes of the wave that builds them) and every cell gets ONE plane through the emitter's space, N . (X - E) = 1, that lies in front of every
+// triangle the tile lists over that cell (conservative: the cell's corner maxima of the triangles' own planes in 1 / depth, where planes are
+// affine, then a plane above the bilinear patch of the four corners), pulled a little further forward than the ignored tail of a shadow ray
+// (N carries the factor (1 - 10 eps)(1 + 6e-5)).  A shadow segment E -> Po with N . (Po - E) <= 1 ends in front of that plane: every
+// triangle that could be hit at the segment's image point has its plane at ray parameter t >= (1 - 10 eps)(1 + 2e-5), which the exact test
+// rejects — the packet skips the emitter's any-hit stage.  float4 per cell {N, 0}: N = 0 for a cell no listed triangle touches (nothing to
+// hit), NaN where no proof is offered (a listed triangle seen edge-on, whose 1 / depth is ill-conditioned).  One row-major array over the
+// grid's fine cells, [ny * SUB][nx * SUB], at the end of the apex's bins area.
+#define FFX_ENV_SUB 7
+__host__ __device__ static inline uint64_t ffx_bin_off_env(int n_tris) { return (ffx_bin_off_entries() + 64 * (ffx_bin_cap(n_tris) + 64) + 63) & ~(uint64_t)63; }
+__host__ __device__ static inline uint64_t ffx_bin_stride(int n_tris) { return ffx_bin_off_env(n_tris) + 16 * (uint64_t)FFX_BIN_MAX_TILES * FFX_ENV_SUB * FFX_ENV_SUB; }
 // what the render kernels need of the bins (part of their first kernel argument)
 struct BinsK {
   const char *base[3]; // per apex: BinHdr, list starts, cursors, entries
   BinGrid g[3];
   float cam_inv_ts_x, cam_inv_ts_y; // camera pixels -> tile units
   int clear_on;                     // the emitters' "nothing can shadow this triangle" bits of the per-slot normals are valid (FFX_GN_CLEAR_BIT)
+  int env_on;                       // mask over the emitters (bit 0 projector, bit 1 spot): the pre-pass built that grid's envelope
+  uint32_t env_off;                 // ffx_bin_off_env(n_tris): the envelope's offset inside an apex's bins area
 };
 // Round 5: "clear" triangles.  The spot's any-hit stage was a quarter of the render kernel (K8 0.400 -> 0.302 ms without it, tools/k8ab.py) for an
 // emitter next to the camera that hardly anything shadows.  The pre-pass (k_bin_clear, ffx_bins.hip) proves per triangle k and emitter E that
@@ -189,9 +202,14 @@ struct BinsK {
 #define FFX_GN_CLEAR_BIT(a) (1u << (27 + (a)))
 // the pre-pass of a packet render on `s` (ffx_bins.hip): apex records + the bins of the enabled grids — three launches (count, scan,
 // fill); with every grid off it is the apex records alone (one launch)
-struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad[0] of apex 0 */ };
+struct BinBuild { BinGrid g[3]; char *base[3]; uint32_t cap; uint32_t *arrive; /* [dev] one word, zero between builds: BinHdr.pad0 of apex 0 */
+                  int env_mask; /* bit a - 1: k_bin_env will run for emitter a (k_bin_scan notes it in the grid's header) */ };
+// the envelope launch's constants: Minv = inverse of BinGrid.M (direction of a tile-space point: d = Minv (x, y, 1) Z), graz = (largest |Minv (x, y, 1)|
+// over the grid) / 40 — a listed triangle whose plane is steeper than 1 : 40 against a cell's rays poisons the cell —, kap = (1 - 10 eps)(1 + 6e-5)
+struct EnvBuild { float Minv[FFX_N_APEX][9]; float graz[FFX_N_APEX]; int on[FFX_N_APEX]; uint32_t env_off; float kap; };
 void ffx_bins_launch(const TriRec *recs, int n_tris, const BinBuild &bb, const void *apex_out, const float (*apex_o)[3], const int *apex_on, uint32_t astride,
-                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0, uint32_t *gn_words = nullptr, int clear_on = 0);
+                     uint32_t *cache_hdr, uint32_t cap_stray, hipStream_t s, int beside_lambert = 0, uint32_t *gn_words = nullptr, int clear_on = 0,
+                     const EnvBuild *env = nullptr);
 
 // top bit of the `cap_stray` argument of the launches that reset an adjoint cache's header (k_bin<false>, k_apex_records, k_cache_reset):
 // FFX_RENDER_CACHE_KEEP_DROPPED — empty the arena, keep the `dropped` count of the step's earlier scene samples

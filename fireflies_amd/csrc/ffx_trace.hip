@@ -2081,6 +2081,18 @@ __device__ __forceinline__ bool bins_shadow(const BinsK &bk, const int a, const 
   // inside the grid (NaN fails): everything else is the tree's business
   const wmask inside = m_gt(Z, 0.f) & m_ge(fx, 0.f) & m_ge(fy, 0.f) & m_lt(fx, gx) & m_lt(fy, gy);
   if ((active & ~inside) != 0ull) return false;
+  // (round 6) the grid's ENVELOPE (ffx_common.h FFX_ENV_SUB, k_bin_env): the cell of each sample's image point holds a plane N . (X - E) = 1 in
+  // front of every triangle the tile lists over that cell, pulled forward past the ignored tail of a shadow ray.  N . sdir <= 1: the segment
+  // ends in front of it, no listed triangle can be hit within the counted part — and only listed triangles can be hit at all.  A packet all of
+  // whose samples pass skips the stage (most do: the emitter stands next to the camera); NaN cells (no proof offered) fail the comparison.
+  if (((bk.env_on >> (a - 1)) & 1) && reinterpret_cast<const BinHdr *>(bk.base[a])->env != 0u) { // (the header: THIS pose's pre-pass built it)
+    const int nxf = bk.g[a].nx * FFX_ENV_SUB;
+    const uint32_t last = (uint32_t)(nxf * bk.g[a].ny * FFX_ENV_SUB) - 1u;
+    const uint32_t ci = (uint32_t)((int)(fy * (float)FFX_ENV_SUB) * nxf + (int)(fx * (float)FFX_ENV_SUB));
+    const float4 Nc = reinterpret_cast<const float4 *>(bk.base[a] + bk.env_off)[ci < last ? ci : last]; // (lanes that are not active may hold anything)
+    const float v = fmaf(Nc.x, sdir.x, fmaf(Nc.y, sdir.y, Nc.z * sdir.z));
+    if ((active & ~m_le(v, 1.0f)) == 0ull) { occluded = 0ull; FFX_STAT(a == 1 ? 37 : 47); return true; }
+  }
   uint32_t mnx = msel(active, __float_as_uint(fx), 0x7f800000u), mny = msel(active, __float_as_uint(fy), 0x7f800000u);
   uint32_t mxx = msel(active, __float_as_uint(fx), 0u), mxy = msel(active, __float_as_uint(fy), 0u);
   wave_reduce_minmax4(mnx, mny, mxx, mxy);
@@ -4188,6 +4200,44 @@ static int clear_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
   const int m = e ? atoi(e) : 0;
   return (m < 0 || m > 3) ? 0 : m;
 }
+// FFX_ENVELOPE=0: no envelopes (every shadow packet runs its any-hit stage: the A/B baseline and the tests' reference).  -> a mask over the
+// emitters (bit 0 projector, bit 1 spot).  A pure function of (sd, info, environment), like the grids: the pre-pass and the renders behind it agree.
+static int env_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
+  const char *e = getenv("FFX_ENVELOPE");
+  if (!(sd && sd->shadows && bins_enabled() && info->off_bins)) return 0;
+  if (sd->shadows & FFX_SHADOWS_PLAIN) return 0; // (the caller's hint: this pose's renders are short — the envelope launch would only lengthen the pre-pass chain)
+  if (info->bins_stride < ffx_bin_stride(info->n_tris) || ffx_bin_off_env(info->n_tris) >= (1ull << 32)) return 0; // (a blob of another library version)
+  const int m = e ? atoi(e) : 3;
+  return (m < 0 || m > 3) ? 0 : m;
+}
+// the envelope launch's constants for the grids g (ffx_common.h EnvBuild); an emitter whose grid is off or not invertible drops out of the mask
+static int env_build(const BinGrid (&g)[FFX_N_APEX], int mask, int n_tris, EnvBuild &eb) {
+  memset(&eb, 0, sizeof eb);
+  eb.env_off = (uint32_t)ffx_bin_off_env(n_tris);
+  eb.kap = (float)((1.0 - (double)SHADOW_EPS) * (1.0 + 6e-5));
+  int out = 0;
+  for (int a = 1; a < FFX_N_APEX; ++a) {
+    if (!((mask >> (a - 1)) & 1) || !g[a].on) continue;
+    const float *M = g[a].M;
+    const double m[9] = {M[0], M[1], M[2], M[3], M[4], M[5], M[6], M[7], M[8]};
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (!(fabs(det) > 1e-30)) continue;
+    const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                           (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                           (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+    double umax = 0.0; // |Minv (x, y, 1)| is convex in (x, y): its maximum over the grid sits at a corner
+    for (int c = 0; c < 4; ++c) {
+      const double x = (c & 1) ? g[a].nx : 0.0, y = (c & 2) ? g[a].ny : 0.0;
+      const double ux = inv[0] * x + inv[1] * y + inv[2], uy = inv[3] * x + inv[4] * y + inv[5], uz = inv[6] * x + inv[7] * y + inv[8];
+      umax = fmax(umax, sqrt(ux * ux + uy * uy + uz * uz));
+    }
+    for (int k = 0; k < 9; ++k) eb.Minv[a][k] = (float)inv[k];
+    eb.graz[a] = (float)(umax * 1.001 / 40.0);
+    eb.on[a] = 1;
+    out |= 1 << (a - 1);
+  }
+  return out;
+}
 // the kernels' view of the bins of `sd` in the blob (grids as bins_grids gives them; built by launch_apex / ffx_apex_prepare)
 static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, BinsK &bk) {
   memset(&bk, 0, sizeof bk);
@@ -4195,6 +4245,9 @@ static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
   bins_grids(sd, bk.g, bk.cam_inv_ts_x, bk.cam_inv_ts_y);
   for (int a = 0; a < FFX_N_APEX; ++a) bk.base[a] = (const char *)bvh + info->off_bins + (uint64_t)a * info->bins_stride;
   bk.clear_on = clear_enabled(sd, info);
+  EnvBuild eb;
+  bk.env_on = env_build(bk.g, env_enabled(sd, info), info->n_tris, eb);
+  bk.env_off = eb.env_off;
 }
 
 // fills the blob's apex areas for the camera (and the enabled emitters of sd, if given) on stream s
@@ -4242,14 +4295,17 @@ static int launch_apex(const void *bvh, const ffx_bvh_info *info, const float *c
         const long cv = atol(ce);
         if (cv >= 0 && (uint64_t)cv < bb.cap) bb.cap = (uint32_t)cv;
       }
-      bb.arrive = (uint32_t *)(bb.base[0] + offsetof(BinHdr, pad));
+      bb.arrive = (uint32_t *)(bb.base[0] + offsetof(BinHdr, pad0));
     }
     if (!bb.arrive) { // no bins area to hold the arrival counter: the plain apex launch
       hipLaunchKernelGGL(k_apex_records, dim3(ffx_cdiv(info->n_tris, 256)), dim3(256), 0, s, recs, info->n_tris, ak, out, (uint32_t)stride, (uint32_t *)cache, cap_stray);
     } else {
       // (the render kernels these launches will run beside: material rows -> seven waves of 72 VGPRs per SIMD, Lambert -> eight of 64)
+      EnvBuild eb;
+      const int env_mask = env_build(bb.g, env_enabled(sd, info), info->n_tris, eb);
+      bb.env_mask = env_mask;
       ffx_bins_launch(recs, info->n_tris, bb, out, ak.o, ak.on, (uint32_t)stride, (uint32_t *)cache, cap_stray, s, sd && sd->mat_stride != FFX_MAT_STRIDE,
-                      info->off_gn ? (uint32_t *)((char *)bvh + info->off_gn) : nullptr, clear_enabled(sd, info));
+                      info->off_gn ? (uint32_t *)((char *)bvh + info->off_gn) : nullptr, clear_enabled(sd, info), env_mask ? &eb : nullptr);
     }
   } else if (cache)
     hipLaunchKernelGGL(k_cache_reset, dim3(1), dim3(1), 0, s, (uint32_t *)cache, cap_stray);

@@ -543,6 +543,7 @@ class Scene:
             order = self.geom._blobs[0][int(info.off_order): int(info.off_order) + 4 * int(info.n_tris)].cpu().numpy().view(np.int32)
             self._slot_uv = torch.from_numpy(scenes.slot_uv_table(order, tris, tri_shape, data.meshes)).to(self.device).contiguous()
         self.shadows = shadows
+        self._low_spp = False  # (note_spp)
         self.tex_color = (0.0, 1.0, 0.0)
         # the camera film's reconstruction filter: "box" or "gaussian" / ("gaussian", stddev).  A scene file gets what it declares — and
         # hdrfilm's default, the gaussian, when it declares none, like every scene the reference loads (loaders.load_xml puts it into
@@ -873,7 +874,7 @@ class Scene:
             return False  # (params.update() applies them in its order)
         ch = self._sd_cache[0] if self._sd_cache is not None else 3
         tm = self._sd_templates.get(ch)
-        if tm is None or tm[0] != (self.shadows, tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0):
+        if tm is None or tm[0] != (self._shadows_word(), tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0):
             fb["no description template yet"] = fb.get("no description template yet", 0) + 1
             return False
         g = self.geom
@@ -981,10 +982,24 @@ class Scene:
         self._sd_cache = None
         self._sd_templates = {}
 
+    def _shadows_word(self):
+        """include/ffx.h ffx_scene_desc.shadows: on / off, plus the hint that this scene's renders are short (note_spp)"""
+        return 0 if not self.shadows else (3 if self._low_spp else 1)
+
+    def note_spp(self, spp):
+        """called by whoever renders this scene with `spp` samples per pixel: below 33 the pre-pass of the NEXT poses leaves the emitters' envelopes
+        out (FFX_SHADOWS_PLAIN: a short render waits for the pre-pass chain, which the envelope launch lengthens; a long one hides it and runs
+        15 % faster with them).  A change of regime drops the finished descriptions — the first render after it prepares its own pose."""
+        low = int(spp) < 33
+        if low != self._low_spp:
+            self._low_spp = low
+            self._sd_cache = None
+            self._sd_templates = {}
+
     def scene_desc(self, tex_channels=3):
         if self._sd_cache is not None and self._sd_cache[0] == tex_channels:
             return self._sd_cache[1]
-        tkey = (self.shadows, tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0)
+        tkey = (self._shadows_word(), tuple(self.tex_color), self._mat_stride, self._mats_in_sd, self._rfilter, self._slot_uv.data_ptr() if self._slot_uv is not None else 0)
         tm = self._sd_templates.get(tex_channels)
         if tm is not None and tm[0] == tkey:
             # a copy of the finished description with this step's fields written over it (22 -> 6 us per step): the three poses, the spot's
@@ -1024,7 +1039,7 @@ class Scene:
                                    float(p[s.name + ".beam_width"]))
         tmp = scenes.SceneData(d.meshes, sensor, proj, spot, float(p["Projector.scale"]) if proj is not None else 1.0)
         btex = [(t.data_ptr(), t.shape[1], t.shape[0]) for _, t in self._base_tex] or None
-        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self.shadows, mat_stride=self._mat_stride, base_tex=btex,
+        sd = scene_desc.scene_desc(tmp, tex_channels=tex_channels, color=self.tex_color, shadows=self._shadows_word(), mat_stride=self._mat_stride, base_tex=btex,
                                    slot_uv=self._slot_uv.data_ptr() if self._slot_uv is not None else None,
                                    host_mats=self._albedo_host if self._mats_in_sd else None, rfilter=self._rfilter)
         sd._frozen = True
@@ -1095,6 +1110,7 @@ def render(scene: Scene, params: SceneParameters = None, spp: int = 16, seed: in
         if tex.device != scene.device:
             tex = tex.to(scene.device)  # the reference uploads through numpy (vocalfold_scene.py:69)
         ch = 1 if tex.dim() == 2 else int(tex.shape[-1])
+    scene.note_spp(spp)
     sd = scene.scene_desc(tex_channels=ch)
     if tex is None:
         tex = torch.zeros((1, 1, 1), device=scene.device)

@@ -408,7 +408,7 @@ def apex_key(sd=None, cam=None):
     field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
     if sd is not None:
         k = getattr(sd, "_apex_key", None)  # (a description is never modified once built: mi.Scene makes a new one per pose — 5 us per call otherwise)
-        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR")):
+        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"), _ENV_GET("FFX_ENVELOPE")):
             return k[0]
     c = sd.cam if sd is not None else cam
     # (the structs' bytes: ~1 us each — tuples of their 32 floats were 10 us per render call)
@@ -419,7 +419,7 @@ def apex_key(sd=None, cam=None):
         key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg, int(sd.shadows)) if sd.spot.enabled else (None, int(sd.shadows))]
     else:
         key += [None, None]
-    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"))
+    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"), _ENV_GET("FFX_ENVELOPE"))
     key = tuple(key) + env
     if sd is not None and getattr(sd, "_frozen", False):  # (only descriptions whose maker promises not to touch them again: mi.Scene.scene_desc)
         sd._apex_key = (key, env)
@@ -512,7 +512,14 @@ class DeviceGeometry:
         # (FFX_SIDE_PRIORITY: -1 = a high-priority queue for the side stream; measured: renders/s unchanged, gradient steps 2 130 -> 1 540 per
         # second — the step's small launches on the main stream then wait behind it.  0 = default)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) if self._async else None
-        self._side_handle = None
+        # (round 6) one side stream PER BLOB COPY: the chains of consecutive poses — re-fit -> count -> scan -> fill [-> envelopes], five or six
+        # dependent launches of mostly latency — then overlap each other instead of queueing on one stream (each writes its own copy; what they
+        # share is read-only: the vertex pool, the topology tables).  A loop whose render is shorter than a chain was paced by the chain (renders
+        # below 33 spp, the diffuse material at 64).  FFX_SIDE_STREAMS=1: the one stream of rounds 1-5 (the A/B baseline; set below for a
+        # geometry with interpolated shading normals, whose update shares the vertex-normal scratch between poses).
+        n_side = max(1, min(n_copies, int(os.environ.get("FFX_SIDE_STREAMS", str(n_copies))))) if self._async else 0
+        self._sides = [self._side] + [torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) for _ in range(n_side - 1)] if self._async else []
+        self._side_handles = {}
         self._last_spp = 64  # samples per pixel of the last render call (how deep update() lets the poses run ahead: _ring)
         self._upd_done = [None] * n_copies   # event: the refit of blob i has been enqueued up to here (side stream)
         self._apex = [None] * n_copies       # apex_key of what blob i's apex areas hold (None: nothing usable)
@@ -544,7 +551,10 @@ class DeviceGeometry:
             self._smooth = (sm, keep)
         self.smooth = [bool(f) for f in smooth] if smooth is not None else [False] * S
         if self._async:  # blob copies / uploads above were enqueued on the caller's stream
-            self._side.wait_stream(_stream_obj(self._didx))
+            if self._smooth is not None:
+                self._sides = self._sides[:1]
+            for s_ in self._sides:
+                s_.wait_stream(_stream_obj(self._didx))
         self.update(torch.eye(4, dtype=torch.float32).repeat(S, 1, 1) if build_xforms is None else torch.from_numpy(np.asarray(build_xforms, np.float32)))
 
     @property
@@ -576,6 +586,8 @@ class DeviceGeometry:
         Below 33 spp the render is as short as the chain, and with two copies the chain of pose i + 2 has to wait for the render of pose i: 5 435 /
         5 735 / 6 002 renders/s at 1 spp, 5 107 / 5 384 / 5 602 at 10 spp with 2 / 3 / 4 copies."""
         n = len(self._blobs)
+        if len(self._sides) > 1:  # (round 6: a side stream per copy — the chains of up to n - 1 poses ahead overlap each other and the renders)
+            return n if self._last_spp <= 32 else min(n, max(2, int(os.environ.get("FFX_RING_LONG", "3"))))
         return n if self._last_spp <= 32 else min(n, 2)
 
     def _wait_readers(self, i, stream_obj):
@@ -635,30 +647,39 @@ class DeviceGeometry:
             return
         nxt = (self._cur + 1) % self._ring()
         main = _stream_obj(self._didx)
-        self._wait_readers(nxt, self._side)  # its readers must be done before it is overwritten
+        side = self._side_of(nxt)
+        self._wait_readers(nxt, side)  # its readers must be done before it is overwritten
         if self._pool_written is not None:
-            self._side.wait_event(self._pool_written)  # caller-supplied vertices must have landed in the pool
+            side.wait_event(self._pool_written)  # caller-supplied vertices must have landed in the pool
         if on_device:
-            self._side.wait_stream(main)  # the tables were produced on the caller's stream
-            xforms.record_stream(self._side)
+            side.wait_stream(main)  # the tables were produced on the caller's stream
+            xforms.record_stream(side)
         ev = self._upd_done[nxt]
         if ev is None:
             ev = self._upd_done[nxt] = torch.cuda.Event()
         if self.timing is None and not on_device:
             # (the two launch calls take the side stream's handle as an argument: making it the current stream first — a context manager and
             # two current-stream queries — cost 10 us of the 65 this method took per step; the timed / device-table paths keep that form)
-            sh = self._side_handle
-            if sh is None:
-                sh = self._side_handle = C.c_void_p(self._side.cuda_stream)
+            sh = self._side_handle_of(side)
             self._update_into(self._blobs[nxt], xforms, on_device, sh)
             self._prepare_apex(nxt, apex_sd, sh)
-            ev.record(self._side)
+            ev.record(side)
         else:
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(side):
                 self._update_into(self._blobs[nxt], xforms, on_device)
                 self._prepare_apex(nxt, apex_sd)
-                ev.record(self._side)
+                ev.record(side)
         self._cur = nxt
+
+    def _side_of(self, i):
+        """the side stream that re-fits blob copy i (one per copy: the poses' chains overlap; a copy is always written from the same stream)"""
+        return self._sides[i % len(self._sides)]
+
+    def _side_handle_of(self, side):
+        h = self._side_handles.get(side.cuda_stream)
+        if h is None:
+            h = self._side_handles[side.cuda_stream] = C.c_void_p(side.cuda_stream)
+        return h
 
     def update_native(self, launch, vert_off):
         """update() for a caller whose ONE native call enqueues the re-fit and the pre-pass (mi.Scene.step_native -> ffx_scene_step_h):
@@ -666,15 +687,14 @@ class DeviceGeometry:
         tile bins the blob then holds; vert_off: the frame offsets [S] the call used (host int32, already checked by it)."""
         self.version += 1
         nxt = (self._cur + 1) % self._ring()
-        self._wait_readers(nxt, self._side)
+        side = self._side_of(nxt)
+        self._wait_readers(nxt, side)
         if self._pool_written is not None:
-            self._side.wait_event(self._pool_written)
+            side.wait_event(self._pool_written)
         ev = self._upd_done[nxt]
         if ev is None:
             ev = self._upd_done[nxt] = torch.cuda.Event()
-        sh = self._side_handle
-        if sh is None:
-            sh = self._side_handle = C.c_void_p(self._side.cuda_stream)
+        sh = self._side_handle_of(side)
         self._apex[nxt] = None
         self._apex_written[nxt] = None
         if self.timing is None:
@@ -682,14 +702,14 @@ class DeviceGeometry:
             self._apex[nxt] = apex_key(sd)
         else:  # (bench.py's per-launch event pairs: around the re-fit alone, as on the Python path; the pre-pass as a call of its own behind them)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(self._side)
+            a.record(side)
             sd = launch(nxt, sh, 0)
-            b.record(self._side)
+            b.record(side)
             self.timing.append(("scene_update", a, b))
             self._prepare_apex(nxt, sd, sh)
         np.copyto(self._vert_off_host, vert_off)
         self._vert_off_dev_stale = True
-        ev.record(self._side)
+        ev.record(side)
         self._cur = nxt
 
     def _prepare_apex(self, i, sd, stream=None):

@@ -107,6 +107,7 @@ class PatternOptimizer:
                  base_seed=0, loss_fn=coverage_loss, blur=(5, 3.0)):
         self.mi_scene, self.ff_scene, self.laser = mi_scene, ff_scene, laser
         self.sigma, self.tex_size, self.spp = float(sigma), (int(tex_size[0]), int(tex_size[1])), int(spp)
+        mi_scene.note_spp(self.spp)  # (the pre-pass of the poses to come: with or without the emitters' envelopes, mi.Scene.note_spp)
         self.reg_weight, self.samples_per_step, self.base_seed = float(reg_weight), int(samples_per_step), int(base_seed)
         self.loss_fn, self.blur = loss_fn, blur
         laser._rays = laser._rays.detach().clone().requires_grad_(True)

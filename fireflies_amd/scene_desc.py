@@ -47,7 +47,7 @@ def scene_desc(scene, n_shapes=None, tex_channels=1, color=(0.0, 1.0, 0.0), shad
     examples/vocalfold_scene.py:64-67)."""
     sd = _abi.SceneDesc()
     sd.cam = camera_from_sensor(scene.camera, cam_to_world)
-    sd.shadows = int(bool(shadows))
+    sd.shadows = int(shadows) if isinstance(shadows, int) and not isinstance(shadows, bool) else int(bool(shadows))  # (an int: include/ffx.h FFX_SHADOWS_* bits)
     set_rfilter(sd, rfilter)
     sd.n_shapes = int(n_shapes if n_shapes is not None else len(scene.meshes))
     sd.mat_stride = int(mat_stride)  # 0 / 3: the material table is [S,3] Lambert albedos; 16: material rows (scenes.material_rows)

@@ -1,0 +1,113 @@
+"""(CPU, numpy) prototype of a per-triangle "nothing can shadow it" proof by PLANE ORDER over the overlap of the projections:
+triangle j cannot occlude a segment that ends on k if, over the overlap of their (padded) boxes in the emitter's image plane, plane j lies
+behind plane k x (1 - tail).   python tools/clearproto.py [n_tiles] [spp] [seed]"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from fireflies_amd import scenes  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tools.envproto import pose, W, H, RAY_EPS, SHADOW_EPS  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+SPP = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+KAPPA = (1.0 / (1.0 - SHADOW_EPS)) * (1 - 2e-5)
+
+
+def main():
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    data = scenes.vocalfold(width=W, height=H)
+    tri = pose(data, rng)
+    F = tri.shape[0]
+    E = data.spot.to_world[:3, 3].astype(np.float64)
+    w2l = np.linalg.inv(data.spot.to_world.astype(np.float64))
+    tanc = np.tan(np.deg2rad(data.spot.cutoff_angle + 1.0))
+    M = np.stack([0.5 * N * (w2l[0, :3] / tanc + w2l[2, :3]), 0.5 * N * (w2l[1, :3] / tanc + w2l[2, :3]), w2l[2, :3]])
+    Minv = np.linalg.inv(M)
+    rel = tri - E
+    pz = rel @ M[2]
+    px, py = (rel @ M[0]) / pz, (rel @ M[1]) / pz
+    safe = (pz > 0).all(1)
+    nn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    den = (nn * rel[:, 0]).sum(1)
+    nj = nn / den[:, None]
+    mj = nj @ Minv
+    PAD = 1 / 256
+    # the lifted end point's image: within LIFT tiles of its triangle's projection (off <= (1 + 8) eps, over the nearest depth, times the tile scale)
+    LIFT = 0.012 * N / 80
+    bx0, bx1, by0, by1 = px.min(1) - PAD, px.max(1) + PAD, py.min(1) - PAD, py.max(1) + PAD
+    tiles = {}
+    for j in range(F):
+        if not safe[j] or bx1[j] < 0 or by1[j] < 0 or bx0[j] >= N or by0[j] >= N:
+            continue
+        for ty in range(max(0, int(np.floor(by0[j] - LIFT))), min(N - 1, int(np.floor(by1[j] + LIFT))) + 1):
+            for tx in range(max(0, int(np.floor(bx0[j] - LIFT))), min(N - 1, int(np.floor(bx1[j] + LIFT))) + 1):
+                tiles.setdefault((ty, tx), []).append(j)
+    clear = np.ones(F, bool)
+    npairs = 0
+    reasons = np.zeros(3, int)
+    for (ty, tx), lst in tiles.items():
+        idx = np.asarray(lst)
+        n = idx.size
+        npairs += n * n
+        # k rows, j columns
+        kx0, kx1, ky0, ky1 = bx0[idx] - LIFT, bx1[idx] + LIFT, by0[idx] - LIFT, by1[idx] + LIFT
+        ox0 = np.maximum(kx0[:, None], bx0[idx][None, :]); ox1 = np.minimum(kx1[:, None], bx1[idx][None, :])
+        oy0 = np.maximum(ky0[:, None], by0[idx][None, :]); oy1 = np.minimum(ky1[:, None], by1[idx][None, :])
+        overlap = (ox0 <= ox1) & (oy0 <= oy1) & (idx[:, None] != idx[None, :])
+        mk, mjj = mj[idx][:, None, :], mj[idx][None, :, :]
+        dcoef = mjj - KAPPA * mk  # [k, j, 3]
+        worst = dcoef[..., 2] + np.maximum(dcoef[..., 0] * ox0, dcoef[..., 0] * ox1) + np.maximum(dcoef[..., 1] * oy0, dcoef[..., 1] * oy1)
+        wk_min = mk[..., 2] + np.minimum(mk[..., 0] * ox0, mk[..., 0] * ox1) + np.minimum(mk[..., 1] * oy0, mk[..., 1] * oy1)
+        behind = (worst <= 0) & (wk_min > 0)
+        failp = overlap & ~behind
+        clear[idx[failp.any(1)]] = False
+    print(f"grid {N}: {len(tiles)} tiles, {npairs} ordered pairs; clear triangles {clear.sum()} / {F} = {clear.mean():.3f}")
+    for m, (a, b) in zip(data.meshes, [(0, data.meshes[0].tris.shape[0]), (data.meshes[0].tris.shape[0], F)]):
+        print(f"  {m.name}: {clear[a:b].mean():.3f}")
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    go = orc.Geometry(verts, np.arange(3 * F, dtype=np.int32).reshape(F, 3), np.zeros(F, np.int32), np.zeros(1, np.int32))
+    K = scenes.perspective_projection(W, H, data.camera.fov_x, data.camera.near, data.camera.far).astype(np.float64)
+    Ki = np.linalg.inv(K)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ok_pix = np.ones((H, W), bool)
+    need_pix = np.zeros((H, W), bool)
+    C = data.camera.to_world[:3, 3].astype(np.float64)
+    R = data.camera.to_world[:3, :3].astype(np.float64)
+    n_s = n_ok = 0
+    for s in range(SPP):
+        jx, jy = rng.random((H, W)), rng.random((H, W))
+        sx, sy = (xx + jx) / W, (yy + jy) / H
+        npnt = np.stack([sx, sy, np.zeros_like(sx), np.ones_like(sx)], -1) @ Ki.T
+        dl = npnt[..., :3] / npnt[..., 3:]
+        dl /= np.linalg.norm(dl, axis=-1, keepdims=True)
+        d = dl @ R.T
+        o = np.broadcast_to(C, d.shape)
+        t, sh, prim = go.trace_rays(o.reshape(-1, 3), d.reshape(-1, 3))
+        hit = (prim >= 0).reshape(H, W)
+        t = t.reshape(H, W).astype(np.float64)
+        P = C + t[..., None] * d
+        pr = np.maximum(prim.reshape(H, W), 0)
+        ng = nn[pr] / np.linalg.norm(nn[pr], axis=-1, keepdims=True)
+        flip = (ng * d).sum(-1) > 0
+        ng[flip] *= -1
+        sd = P - E
+        cos_s = (ng * (-sd)).sum(-1)
+        ll = sd @ w2l[:3, :3].T
+        cos_t = ll[..., 2] / np.linalg.norm(ll, axis=-1)
+        need = hit & (cos_s > 0) & (cos_t > np.cos(np.deg2rad(data.spot.cutoff_angle)))
+        proven = clear[pr]
+        n_s += int(need.sum()); n_ok += int((need & proven).sum())
+        ok_pix &= ~need | proven
+        need_pix |= need
+    print(f"samples that need the spot: {n_s}, on clear triangles {n_ok} = {n_ok / max(n_s, 1):.3f}")
+    print(f"pixels with such samples: {int(need_pix.sum())}, all {SPP} samples clear: {int((need_pix & ok_pix).sum())} = {(need_pix & ok_pix).sum() / max(need_pix.sum(), 1):.3f}")
+    blk = (need_pix & ~ok_pix).reshape(16, 32, 16, 32).mean((1, 3))
+    print("share of unproven pixels per 32x32 block:")
+    for r in blk:
+        print(" ".join(f"{int(99 * v):2d}" for v in r))
+
+
+if __name__ == "__main__":
+    main()
