@@ -110,7 +110,7 @@ __device__ void bin_scan_one(char *base, int nt, uint32_t cap, bool env) {
     h->total = total;
     h->cap = cap;
     h->ok = ok ? 1u : 0u;
-    h->env = env ? 1u : 0u;
+    h->env = env && ok ? 1u : 0u; // (k_bin_env leaves a grid whose lists do not fit alone)
   }
 }
 
@@ -506,7 +506,6 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     s_pl[lane] = pl;
     __syncthreads();
     const uint32_t m = min(64u, n - j0);
-#pragma unroll 4
     for (uint32_t t = 0; t < m; ++t) { // (uniform: broadcast reads)
       const float4 b = s_bb[t], p = s_pl[t];
       asm volatile("" ::"v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w)); // (both rows read up front: no lazy, branchy re-reads)

@@ -62,6 +62,7 @@ struct ShadeK {
   float s_w2l[12];
   float s_pos[3], s_int[3];
   float cos_cut, cos_beam, cutoff, inv_trans;
+  int s_rigid; // the 3x3 part of s_w2l is a rotation (orthonormal rows to 2e-6): the packet kernels take the cosine to the spot's axis from its third row alone
   int mat_stride;    // floats per row of the material table: 3 (Lambert albedo) or FFX_MAT_STRIDE
   const float *mats; // the material table (the render calls' shape_albedo)
   // texture-valued base colours (ffx_scene_desc.base_tex): rows select one with FFX_MAT_BASE_TEX
@@ -334,6 +335,12 @@ __device__ __forceinline__ float sqrt_nr(float x) {
   return x > 0.f ? s1 : s; // sqrt(0) = 0 (rsq(0) = inf would give NaN)
 }
 #endif
+// 1 / sqrt(x) of a squared emitter distance (x > 0): the hardware seed plus one Newton step — five instructions where rcp_nr(sqrt_nr(x)) took ten
+// (two transcendental seeds, two refinements), the same value to the last bit or two
+__device__ __forceinline__ float rsqrt_nr(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  return fmaf(0.5f * y, fmaf(-(x * y), y, 1.0f), y);
+}
 
 // Shading normal of a hit on a record flagged by ffx_smooth (include/ffx.h): the three vertex normals stored next to the
 // record, interpolated with Moller-Trumbore's barycentrics of the hit (P = v0 + u e1 + v e2, recomputed here from the record:
@@ -2254,7 +2261,7 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
           v3 ppos = V3(c.p_pos[0], c.p_pos[1], c.p_pos[2]);
           v3 wi = vsub(ppos, q.P);
           float d2 = vdot(wi, wi);
-          const float idist = rcp_nr(sqrt_nr(d2));
+          const float idist = rsqrt_nr(d2);
           wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
           float cos_s = vdot(ns, wi);
           float cos_p = -vdot(V3(c.p_axis[0], c.p_axis[1], c.p_axis[2]), wi);
@@ -2282,15 +2289,20 @@ __device__ __forceinline__ void shade_sample_pk(const BvhNode *__restrict__ node
       v3 spos = V3(c.s_pos[0], c.s_pos[1], c.s_pos[2]);
       v3 wi = vsub(spos, q.P);
       float d2 = vdot(wi, wi);
-      const float idist = rcp_nr(sqrt_nr(d2));
+      const float idist = rsqrt_nr(d2);
       wi = V3(wi.x * idist, wi.y * idist, wi.z * idist);
       float cos_s = vdot(ns, wi);
       bool front = cos_s > 0.f;
       if (any_smooth) front = front && (!smooth || vdot(q.ng, wi) > 0.f);
       if (front) {
-        v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
-        float ln = sqrt_nr(vdot(ll, ll));
-        float cos_t = div_nr(ll.z, ln);
+        float cos_t;
+        if (c.s_rigid) { // (the spot's world-to-local is a rotation — the usual case: |ll| = |wi| = 1, and ll.z is one row of it)
+          cos_t = -fmaf(c.s_w2l[8], wi.x, fmaf(c.s_w2l[9], wi.y, c.s_w2l[10] * wi.z));
+        } else {
+          v3 ll = xf_dir(c.s_w2l, V3(-wi.x, -wi.y, -wi.z));
+          float ln = sqrt_nr(vdot(ll, ll));
+          cos_t = div_nr(ll.z, ln);
+        }
         float fall = 0.f;
         if (cos_t >= c.cos_beam) fall = 1.f;
         else if (cos_t > c.cos_cut) fall = (c.cutoff - acosf(cos_t)) * c.inv_trans;
@@ -4004,6 +4016,16 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   if (c.spot_on) {
     if (!ffx_inv4(sd->spot.to_world, inv)) return 0;
     for (int i = 0; i < 12; ++i) c.s_w2l[i] = inv[i];
+    {
+      double worst = 0.0;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double d = 0.0;
+          for (int k = 0; k < 3; ++k) d += (double)inv[4 * i + k] * (double)inv[4 * j + k];
+          worst = fmax(worst, fabs(d - (i == j ? 1.0 : 0.0)));
+        }
+      c.s_rigid = worst < 2e-6 ? 1 : 0;
+    }
     c.s_pos[0] = sd->spot.to_world[3]; c.s_pos[1] = sd->spot.to_world[7]; c.s_pos[2] = sd->spot.to_world[11];
     for (int i = 0; i < 3; ++i) c.s_int[i] = sd->spot.intensity[i];
     const float deg = 0.017453292519943295f;

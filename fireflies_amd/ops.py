@@ -512,12 +512,12 @@ class DeviceGeometry:
         # (FFX_SIDE_PRIORITY: -1 = a high-priority queue for the side stream; measured: renders/s unchanged, gradient steps 2 130 -> 1 540 per
         # second — the step's small launches on the main stream then wait behind it.  0 = default)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) if self._async else None
-        # (round 6) one side stream PER BLOB COPY: the chains of consecutive poses — re-fit -> count -> scan -> fill [-> envelopes], five or six
-        # dependent launches of mostly latency — then overlap each other instead of queueing on one stream (each writes its own copy; what they
-        # share is read-only: the vertex pool, the topology tables).  A loop whose render is shorter than a chain was paced by the chain (renders
-        # below 33 spp, the diffuse material at 64).  FFX_SIDE_STREAMS=1: the one stream of rounds 1-5 (the A/B baseline; set below for a
-        # geometry with interpolated shading normals, whose update shares the vertex-normal scratch between poses).
-        n_side = max(1, min(n_copies, int(os.environ.get("FFX_SIDE_STREAMS", str(n_copies))))) if self._async else 0
+        # (round 6, a measured negative result kept as a knob) FFX_SIDE_STREAMS=n: a side stream per blob copy, so that the chains of consecutive
+        # poses — re-fit -> count -> scan -> fill [-> envelopes], five or six dependent launches of mostly latency — overlap each other instead of
+        # queueing on one stream (each writes its own copy; what they share is read-only).  With 4 streams the loops LOSE a quarter (principled
+        # 64 spp 2 890 -> 2 208 renders/s, diffuse 3 406 -> 2 506, 16 spp 5 516 -> 3 849): more side work in flight only takes issue slots and
+        # dispatch turns from the render that the chain then waits for.  Default 1: the one stream of rounds 1-5.
+        n_side = max(1, min(n_copies, int(os.environ.get("FFX_SIDE_STREAMS", "1")))) if self._async else 0
         self._sides = [self._side] + [torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) for _ in range(n_side - 1)] if self._async else []
         self._side_handles = {}
         self._last_spp = 64  # samples per pixel of the last render call (how deep update() lets the poses run ahead: _ring)
@@ -586,7 +586,7 @@ class DeviceGeometry:
         Below 33 spp the render is as short as the chain, and with two copies the chain of pose i + 2 has to wait for the render of pose i: 5 435 /
         5 735 / 6 002 renders/s at 1 spp, 5 107 / 5 384 / 5 602 at 10 spp with 2 / 3 / 4 copies."""
         n = len(self._blobs)
-        if len(self._sides) > 1:  # (round 6: a side stream per copy — the chains of up to n - 1 poses ahead overlap each other and the renders)
+        if len(self._sides) > 1:  # (FFX_SIDE_STREAMS > 1: the chains of up to n - 1 poses ahead may overlap each other and the renders)
             return n if self._last_spp <= 32 else min(n, max(2, int(os.environ.get("FFX_RING_LONG", "3"))))
         return n if self._last_spp <= 32 else min(n, 2)
 

@@ -37,6 +37,11 @@
  *                                spot (2) and marks it in its per-slot normal's flag word (ffx_bvh_info.off_gn); a pixel whose samples all
  *                                lie on such triangles skips that emitter's shadow stage — exact, tested, but the proof costs the loop more
  *                                than the skip gains on the default workload (fireflies_amd/csrc/ffx_trace.hip clear_enabled)
+ *       FFX_ENVELOPE=0|1|2|3     (round 6; default 3) the emitters whose tile grid also gets an ENVELOPE from the pre-pass — bit 0 projector, bit 1
+ *                                spot: per cell of the grid (7 x 7 per tile) one plane in front of every triangle the tile lists there; a shadow
+ *                                packet whose segments all end in front of their cells' planes skips that emitter's any-hit stage (exact: the
+ *                                image is the same bit for bit; 87 % of the vocal fold's shadow packets, K8 0.39 -> 0.34 ms).  0: none (the A/B
+ *                                baseline).  A caller's hint in ffx_scene_desc.shadows (FFX_SHADOWS_PLAIN) leaves them out per pose.
  *       FFX_BIN_CAP=n            capacity of each grid's entry list, at most the default 2 F + 16384 (a test knob: a grid whose lists do
  *                                not fit is marked not-ok by the pre-pass and its packets take the tree walks — the overflow path)
  *       FFX_RENDER_BLOCKS=0      ffx_render_fwd / ffx_render_fwd_filtered below 33 samples per pixel: a pixel per wave whatever the count, as
@@ -48,7 +53,7 @@
  *       FFX_WIDE_CLUSTER=4..64, FFX_WIDE_COST_EXP=x   experiment knobs of that builder (largest cluster; priority area * count^x)
  *     The Python host layer reads FFX_LIB (alternative BUILD of this library), FFX_ASYNC_UPDATE=0 (single BVH blob,
  *     refit on the caller's stream), FFX_CACHE_LIMIT_GB (adjoint cache budget), FFX_HOST_PHILOX=0 (sampler draws on the
- *     device instead of ffx_torch_rand_h) and then FFX_PREDRAW=0; bench.py reads FFX_DIST_BACKEND and FFX_BENCH_TIMED_STEPS.
+ *     device instead of ffx_torch_rand_h) and then FFX_PREDRAW=0, FFX_SIDE_STREAMS=n (a side stream per BVH blob copy: a measured loss, default 1); bench.py reads FFX_DIST_BACKEND and FFX_BENCH_TIMED_STEPS.
  */
 #ifndef FFX_H
 #define FFX_H
@@ -416,7 +421,8 @@ typedef struct ffx_bvh_info {
    * ray / triangle test on the survivors only — no tree walk.  Packets the bins cannot serve (outside a grid, more than four tiles,
    * an overflowed or disabled grid) take the tree walks as before; results are identical either way.
    * Layout: FFX_N_APEX areas of bins_stride bytes from off_bins: a 64-byte header {ok, entries, capacity}, (tiles + 1) uint32 list
-   * starts, `tiles` uint32 fill cursors, then the entries.  0 in the oracle's blob. */
+   * starts, `tiles` uint32 fill cursors, the entries, then (round 6) the grid's envelope: 16 bytes per cell, 49 cells per tile (fireflies_amd/csrc/ffx_common.h
+   * FFX_ENV_SUB; header word 4: this pose's pre-pass wrote it).  0 in the oracle's blob. */
   uint64_t off_bins;
   uint64_t bins_stride;
 } ffx_bvh_info;
