@@ -925,6 +925,56 @@ def main():
                   "lowspp_config": "the headline's step at 16 spp (box film) and at 10 spp with the gaussian film (the reference's examples/01_hello_world.py:29); "
                                    "below 33 spp a wave renders a compact block of pixels (k_render_fwd_blk), the same image bit for bit as a pixel per wave"}
 
+    # ------------------------------------------------------------------ BASELINE configs[3] and [4], driver-timed beside the headline (round-5 review, item 5)
+    # Two short informational brackets (FFX_BENCH_CONFIGS34=0: off; only behind the default workload, one rank): configs[3] — 32 scene samples per
+    # gradient step (the step of examples/11_..., `--grad-samples 32`) — and configs[4] — the colon at 1024 x 1024 x 256 spp with an fp16 film and a
+    # 1024-point pattern (`--workload colon --res 1024 --spp 256 --grid 32 --fp16`), with its own roofline from the committed r*colon_* passes.
+    cfg34 = {}
+    default_line = (args.workload == "vocalfold" and args.rfilter == "box" and args.res == 512 and args.spp == 64 and args.material == "principled" and not args.fp16
+                    and not args.no_shadows and args.grad_samples == 0)
+    if default_line and world == 1 and os.environ.get("FFX_BENCH_CONFIGS34", "1") != "0" and os.environ.get("FFX_BENCH_EXTRA_BRACKETS", "1") != "0":
+        if not args.no_grad_steps:
+            opt32 = PatternOptimizer(wg.mi_scene, wg.ff_scene, wg.laser, sigma=wg.sigma, tex_size=wg.tex_size, spp=args.spp, samples_per_step=32, base_seed=19)
+            t32 = _bracket(lambda i: opt32.step(), 3, 1, dev, None, settle_grad)
+            cfg34.update({"grad_samples_per_sec_s32": 32 * 3 / t32, "grad_ms_per_step_s32": 1e3 * t32 / 3,
+                          "grad_s32_config": {"what": "BASELINE configs[3]: 32 randomised scene samples per gradient step (one rank: all 32 here; N ranks take 32 / N each and "
+                                                      "exchange [3N+2] floats), 3 timed steps after 1", "step_paths": dict(opt32.step_paths)}})
+        if not args.no_render_steps:
+            t_set = time.perf_counter()
+            wc = workloads.colon(device=dev, width=1024, height=1024, tex=1024, grid=32, entity_device=args.entity_device)
+            with torch.no_grad():
+                wc.params["tex.data"] = workloads.build_texture(wc).contiguous()
+            t_set = time.perf_counter() - t_set
+
+            def colon_step(i):
+                wc.ff_scene.randomize()
+                return mi.render(wc.mi_scene, spp=256, seed=base_seed + i, fp16=True).torch()
+
+            tc = _bracket(colon_step, 5, 2, dev)
+            cev = []
+            wc.mi_scene.geom.timing = cev
+            for i in range(3):  # the kernel alone: device drained between the launches (as kernel_alone_ms above)
+                colon_step(7 + i)
+                torch.cuda.synchronize()
+            wc.mi_scene.geom.timing = None
+            kc_ms, kc_n = _kernel_ms(cev, "render_fwd")
+            bc = algorithmic_bytes(wc, 1024, 1024, fp16=True)
+            trc = pmc_traffic("k_render_fwd_pk", "r", "colon")
+            cfg34.update({"value_colon": 5 / tc, "ms_per_step_colon": 1e3 * tc / 5, "colon_setup_s": t_set,
+                          "colon_config": f"BASELINE configs[4]: procedural colon scene, {bc['F']} triangles, 1024-point projector, 1024x1024, 256 spp, fp16 radiance buffer; "
+                                          "5 timed steps after 2 (randomise + params.update() + mi.render(...).torch())",
+                          "colon_primary_rays_per_sec": 5 * 1024 * 1024 * 256 / tc,
+                          "colon_roofline": None if not kc_ms else {
+                              "kernel": "k_render_fwd_pk<1, wide, material rows, false> (ffx_render_fwd, K8) on configs[4]", "bound": "hbm",
+                              "achieved": bc["render_fwd"] / (kc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": bc["render_fwd"] / (kc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": None if trc is None else trc["bytes"], "traffic_ratio": None if trc is None else trc["bytes"] / bc["render_fwd"],
+                              "traffic_source": None if trc is None else f"profiles/{trc['source']}",
+                              "algorithmic_bytes_per_launch": bc["render_fwd"], "avg_kernel_ms": kc_ms, "kernel_alone_ms": kc_ms, "launches_timed": kc_n,
+                              "valu_issue": valu_issue("k_render_fwd_pk", kc_ms, "colon")}})
+            del wc
+            torch.cuda.empty_cache()
+
     if rank != 0:
         return
     # the dominant kernel's time: the SIXTEEN launches timed behind the bracket (each between HIP events on its launch stream); the
@@ -1016,11 +1066,12 @@ def main():
     out.update(grad)
     out.update(gauss)
     out.update(lowspp)
+    out.update(cfg34)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, tex, args.spp, args.cpu_spp, seed=base_seed, grad_wl=wg if not args.no_grad_steps else None)
     else:
         out["cpu_baseline"] = None
-    out["evidence"] = cited_profiles(pkey)
+    out["evidence"] = cited_profiles(pkey) + ([f for f in cited_profiles("colon") if "colon" in f] if "colon_roofline" in cfg34 else [])
     print(json.dumps(out))
 
 

@@ -1100,8 +1100,8 @@ __global__ void __launch_bounds__(SPLAT_BLOCK) k_silhouette_fwd(const float *__r
   }
   out[(size_t)y * w + x] = img[(size_t)y * w + x] * acc;
 }
-__global__ void __launch_bounds__(256) k_noise_clamp(const float *__restrict__ img, const float *__restrict__ noise, size_t n, float mean, float sd, float lo, float hi,
-                                                     float *__restrict__ out) {
+// (noise and out may be the SAME array — ops.noise_clamp writes the result over the noise it drew: no __restrict__ on either)
+__global__ void __launch_bounds__(256) k_noise_clamp(const float *__restrict__ img, const float *noise, size_t n, float mean, float sd, float lo, float hi, float *out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float nz = noise[i] * sd;
     const float v = img[i] + (nz + mean);

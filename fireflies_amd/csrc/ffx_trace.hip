@@ -3375,7 +3375,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // (reassociation: ~1e-7 relative, different from run to run).  INTEGER additions commute: mode 1 finds the largest |tap value| of the launch
 // (atomicMax on the float's bits — order-independent), the host derives a power-of-two scale from it, mode 2 adds llrint(value * scale) to a
 // 64-bit fixed-point accumulator per texel (global_atomic_add_x2) and k_det_finish converts back — bitwise the same gtex whatever the
-// dispatch order, the number of XCDs or the rank count, at a resolution of 2^-36 of the largest tap (float32 carries 2^-24).
+// dispatch order, the number of XCDs or the rank count, at a resolution of 2^-(62 - b) of the largest tap, b = bits of the launch's tap count: 2^-36 at 512 x 512 x 64 spp (float32 carries 2^-24).
 struct DetK { int mode; float scale; unsigned long long *fix; unsigned int *vmax; };
 __device__ __forceinline__ void det_emit(const DetK &det, float *__restrict__ gtex, size_t t, float v) {
   if (det.mode == 0) { atomicAdd(gtex + t, v); return; }
@@ -4825,8 +4825,11 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       }
       int e;
       frexpf(vmax, &e); // vmax < 2^e
-      // |sum| <= (samples x 4 taps) x vmax < 2^(34 + e) for up to 2^32 samples; 2^(62 - 34 - e) keeps every sum below 2^62
-      const int sh = 62 - 34 - e;
+      // |sum| <= (samples x 4 taps) x vmax < 2^(b + e) with b = bits of this launch's tap count; 2^(62 - b - e) keeps every sum below 2^62 and one
+      // unit at 2^-(62 - b) of the largest tap: 2^-36 at 512 x 512 x 64 spp (a fixed b = 34 — room for 2^32 samples — had left 2^-28, round-5 advisor)
+      int b = 2; // (4 taps per sample)
+      for (unsigned long long ns = (unsigned long long)c.cam.W * (unsigned long long)c.cam.H * (unsigned long long)(spp > 0 ? spp : 1); ns > 0; ns >>= 1) ++b;
+      const int sh = 62 - b - e;
       det.scale = ldexpf(1.0f, sh > 126 ? 126 : (sh < -126 ? -126 : sh));
       det.mode = 2;
       launch();

@@ -50,6 +50,8 @@ class Float(float):
     """a scalar — or, given an array (mi.Float(pos % w), depth.py:65-66), the float array of it"""
 
     def __new__(cls, v=0.0):
+        if isinstance(v, (torch.Tensor, np.ndarray)) and v.ndim == 0:
+            return float.__new__(cls, float(v))  # (a 0-dim tensor is a scalar: mi.Float(torch.tensor(0.5)) stays usable as float(...))
         if isinstance(v, (_ArrayBase, torch.Tensor, np.ndarray, list, tuple)):
             t = v.t if isinstance(v, _ArrayBase) else torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v)
             return Float32(t.to(torch.float32))
@@ -69,6 +71,11 @@ class _ArrayBase:
 
     def torch(self):
         return self.t
+
+    def __float__(self):
+        if self.t.numel() != 1:
+            raise TypeError(f"only a single-element array converts to a float (shape {tuple(self.t.shape)})")
+        return float(self.t.reshape(-1)[0])
 
     def numpy(self):
         return self.t.detach().cpu().numpy()
@@ -772,6 +779,14 @@ class Scene:
             if not dyn:
                 self._sd_templates = {}
                 break
+        else:
+            # the templates themselves keep up with assignments of the description's per-step fields — a pose of the camera, the projector or the
+            # spot, the spot's intensity or cone: the native push (step_native) starts from a template and only writes the fields ITS plan has ops
+            # for, i.e. those of randomised entities; a caller who moves a fixed camera between samples would have rendered every natively pushed
+            # sample from the old pose (round-5 advisor; the Python path reads the map every time)
+            if self._sd_templates and any(k.endswith(".to_world") or k.endswith(".intensity.value") or k.endswith(".cutoff_angle") or k.endswith(".beam_width") for k in dirty):
+                for _, keep in self._sd_templates.values():
+                    self._patch_sd(keep)
         if geom_dirty:
             # the renders of this pose will come from the camera / emitter positions the parameters hold NOW (every assignment of
             # the update has been applied above): their apex records are written behind the re-fit, on its side stream, and the
@@ -889,8 +904,14 @@ class Scene:
         if ptrs is None or ptrs[3] is not self._albedo_host:  # (host tables only ever written in place: their addresses are taken once)
             ptrs = sp.ptrs = (self._xforms.data_ptr(), self._offs.ctypes.data, self._albedo_host.ctypes.data if sp.plan.n_mat_floats else None, self._albedo_host)
 
+        # what the sample's description starts from: the LAST finished description when there is one — every field this plan has no op for then keeps
+        # the value the scene was last pushed with, as on the Python path, where such a field is read from the parameter map (a second Scene over the
+        # same map randomises other entities than the first: started from the template, its samples carried the spot intensity of the day the
+        # template was built — found by the round-6 action fuzz) —, else the template
+        base = self._sd_cache[1] if self._sd_cache is not None else tm[1]
+
         def launch(i, stream, prepare):
-            rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, tm[1], sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], prepare, stream)
+            rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, base, sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], prepare, stream)
             if rc != 0:
                 ops.api().check(rc, "ffx_scene_step_h")
             return sd
@@ -996,6 +1017,19 @@ class Scene:
             self._sd_cache = None
             self._sd_templates = {}
 
+    def _patch_sd(self, sd):
+        """the per-step fields of a finished description from the parameter map as it is NOW: the three poses, the spot's intensity and cone"""
+        f = np.frombuffer(sd, dtype=np.float32)
+        d, p = self.data, self._params
+        f[_SD_CAM_TW:_SD_CAM_TW + 16] = self._mat(d.camera.name + ".to_world").reshape(-1)
+        if d.projector is not None:
+            f[_SD_PROJ_TW:_SD_PROJ_TW + 16] = self._mat("Projector.to_world").reshape(-1)
+        if d.spot is not None:
+            f[_SD_SPOT_TW:_SD_SPOT_TW + 16] = self._mat(d.spot.name + ".to_world").reshape(-1)
+            inten = p[d.spot.name + ".intensity.value"]
+            f[_SD_SPOT_INT:_SD_SPOT_INT + 3] = inten.t.reshape(-1)[:3].tolist() if isinstance(inten, _ArrayBase) else [float(v) for v in inten]
+            f[_SD_SPOT_INT + 3], f[_SD_SPOT_INT + 4] = float(p[d.spot.name + ".cutoff_angle"]), float(p[d.spot.name + ".beam_width"])
+
     def scene_desc(self, tex_channels=3):
         if self._sd_cache is not None and self._sd_cache[0] == tex_channels:
             return self._sd_cache[1]
@@ -1006,16 +1040,7 @@ class Scene:
             # intensity, the material rows — everything else was read when the template was built and has not been assigned since (_apply)
             sd = _abi.SceneDesc()
             C.memmove(C.addressof(sd), C.addressof(tm[1]), C.sizeof(sd))
-            f = np.frombuffer(sd, dtype=np.float32)
-            d, p = self.data, self._params
-            f[_SD_CAM_TW:_SD_CAM_TW + 16] = self._mat(d.camera.name + ".to_world").reshape(-1)
-            if d.projector is not None:
-                f[_SD_PROJ_TW:_SD_PROJ_TW + 16] = self._mat("Projector.to_world").reshape(-1)
-            if d.spot is not None:
-                f[_SD_SPOT_TW:_SD_SPOT_TW + 16] = self._mat(d.spot.name + ".to_world").reshape(-1)
-                inten = p[d.spot.name + ".intensity.value"]
-                f[_SD_SPOT_INT:_SD_SPOT_INT + 3] = inten.t.reshape(-1)[:3].tolist() if isinstance(inten, _ArrayBase) else [float(v) for v in inten]
-                f[_SD_SPOT_INT + 3], f[_SD_SPOT_INT + 4] = float(p[d.spot.name + ".cutoff_angle"]), float(p[d.spot.name + ".beam_width"])
+            self._patch_sd(sd)
             if self._mats_in_sd:
                 scene_desc.set_host_materials(sd, self._albedo_host)
             sd._frozen = True  # (never written again: ops.apex_key may remember its key on it)

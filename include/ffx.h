@@ -627,7 +627,7 @@ int ffx_render_bwd(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*
  * different from run to run and with the number of ranks).  This one is bitwise reproducible: pass 1 re-traces and finds the largest
  * |tap| (an integer atomicMax on the float's bits), the host derives a power-of-two scale from it (ONE 4-byte read + stream
  * synchronisation), pass 2 re-traces and adds every tap as a 64-bit fixed-point integer — integer additions commute — and a last launch
- * converts:  gtex[t] += (float)(sum[t] / scale).  Resolution 2^-36 of the largest tap (float32 carries 2^-24 of a value).  Two re-traces:
+ * converts:  gtex[t] += (float)(sum[t] / scale).  Resolution 2^-(62 - b) of the largest tap, b = bits of (pixels x spp x 4 taps): 2^-36 at 512 x 512 x 64 spp (float32 carries 2^-24 of a value).  Two re-traces:
  * a cross-check of the atomic paths at any size (tests/test_hip_parity.py) and a debugging aid, not the fast path.  Box and gaussian film.
  * workspace: ffx_render_bwd_det_bytes(sd) bytes of device memory, 16-byte aligned, contents irrelevant. */
 size_t ffx_render_bwd_det_bytes(const ffx_scene_desc *sd /*[host]*/);

@@ -1230,52 +1230,197 @@ def test_sample_ray_and_ray_intersect_objects_give_the_depth_map():
     torch.testing.assert_close(si2.p.torch(), depth.cast_laser(ms, laser=wl.laser), rtol=1e-6, atol=1e-6)
 
 
+def _native_pair():
+    """two scenes of the same configuration, the first kept on the Python path (native_update = False: FFX_NATIVE_UPDATE=0 for one scene), both
+    past the two Python-path samples that teach the plan what each key means"""
+    def make(native):
+        wl = _small()
+        wl.ff_scene.native_update = native
+        with torch.no_grad():
+            wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
+        torch.manual_seed(7)
+        random.seed(7)
+        wl.ff_scene.randomize()
+        wl.ff_scene.randomize()
+        return wl
+
+    return make(False), make(True)
+
+
+def _same_device_state(a, b, tag, spp=4, lit=True):
+    """what the DEVICE holds, without asking the parameter map or the entities anything (a pending natively pushed sample stays pending): the scene
+    description byte for byte, the tables, the re-fitted blob, the image"""
+    import ctypes as C
+
+    ma, mb = a.mi_scene, b.mi_scene
+    sa, sb = ma.scene_desc(tex_channels=1), mb.scene_desc(tex_channels=1)
+    assert C.string_at(C.addressof(sa), C.sizeof(sa)) == C.string_at(C.addressof(sb), C.sizeof(sb)), tag
+    assert torch.equal(ma._xforms, mb._xforms) and np.array_equal(ma._offs, mb._offs) and np.array_equal(ma._albedo_host, mb._albedo_host), tag
+    assert np.array_equal(ma.geom._vert_off_host, mb.geom._vert_off_host), tag
+    static = int(ma.geom.info.off_bins)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.geom.blob[:static], mb.geom.blob[:static]), tag
+    ia, ib = mi.render(ma, spp=spp, seed=3).torch(), mi.render(mb, spp=spp, seed=3).torch()
+    assert torch.equal(ia, ib) and (float(ia.sum()) > 0 or not lit), tag
+
+
+def _same_native_state(a, b, tag, lit=True):
+    """... and what a script can read back: every value of the parameter map, every entity's world matrix and attributes, the camera block"""
+    import ctypes as C
+
+    ma, mb = a.mi_scene, b.mi_scene
+    _same_device_state(a, b, tag, lit=lit)
+    for k in a.params.keys():
+        va, vb = a.params[k], b.params[k]
+        if isinstance(va, float):
+            assert float(va) == float(vb), (tag, k)
+        elif isinstance(va, mi.Transform4f):
+            assert np.array_equal(va.numpy(), vb.numpy()), (tag, k)
+        elif isinstance(va, mi._ArrayBase) and k != "tex.data":
+            assert torch.equal(va.t.cpu(), vb.t.cpu()), (tag, k)
+    for ea, eb in zip(a.ff_scene._draw_order(), b.ff_scene._draw_order()):
+        assert torch.equal(ea.world(), eb.world()), tag
+        assert ea._host_float_attributes == eb._host_float_attributes and ea._host_vec3_attributes == eb._host_vec3_attributes, tag
+    for wl in (a, b):  # the camera block depth.py's queries take from the finished description is the one built from the sensor's parameters
+        if wl.params._dirty:
+            continue  # (an assignment params.update() has not seen yet: the description is the scene as pushed, the map already holds the new value)
+        m = wl.mi_scene
+        for _ in range(2):
+            fast, slow = m.camera_struct(0), m._camera_struct_slow(0)
+            assert C.string_at(C.addressof(fast), C.sizeof(fast)) == C.string_at(C.addressof(slow), C.sizeof(slow)), tag
+
+
+def test_native_update_sees_a_fixed_camera_moved_between_samples():
+    """Round-5 advisor: the native push starts every sample's description from a template and only writes the fields its plan has ops for — those
+    of RANDOMISED entities.  A caller who assigns a pose of an entity that is not randomised (this workload's camera) between two samples used to
+    render every later natively pushed sample with the template's old value, while the Python path read the new one from the map.  The
+    templates now keep up with such assignments (mi.Scene._apply): both paths push the same sample, and it is the moved camera's."""
+    a, b = _native_pair()
+    cam = b.mi_scene.data.camera.name
+    for k in range(2):
+        for wl in (a, b):
+            torch.manual_seed(40 + k)
+            random.seed(40 + k)
+            wl.ff_scene.randomize()
+    assert b.mi_scene.update_paths["native"] >= 2
+    _same_native_state(a, b, "before")
+    img0 = mi.render(b.mi_scene, spp=4, seed=3).torch().clone()
+    for wl in (a, b):  # the camera is no randomised entity of this workload: its pose is the caller's to assign
+        m = wl.params[cam + ".to_world"].numpy().reshape(4, 4).copy()
+        m[0, 3] += 0.07
+        m[1, 3] -= 0.05
+        wl.params[cam + ".to_world"] = mi.Transform4f(m)
+        wl.params.update()
+    n0 = b.mi_scene.update_paths["native"]
+    for k in range(3):
+        for wl in (a, b):
+            torch.manual_seed(50 + k)
+            random.seed(50 + k)
+            wl.ff_scene.randomize()
+        _same_device_state(a, b, f"moved camera, sample {k}")
+        sd = b.mi_scene.scene_desc(tex_channels=1)
+        assert abs(sd.cam.to_world[3] - (float(a.mi_scene.data.camera.to_world[0, 3]) + 0.07)) < 1e-6
+    # (the sample right behind a caller's own params.update() takes the Python path — nothing says yet how many channels the next render's
+    # texture has —, the two after it are pushed natively: from the templates the assignment was written into)
+    assert b.mi_scene.update_paths["native"] >= n0 + 2, (b.mi_scene.update_paths, b.mi_scene.update_fallbacks)
+    _same_native_state(a, b, "after")
+    assert not torch.equal(mi.render(b.mi_scene, spp=4, seed=3).torch(), img0)
+
+
+def test_lazy_native_update_under_random_action_sequences():
+    """Round-5 review, item 8: the lazy native update (a natively pushed sample is told to the entities and the parameter map only when somebody
+    looks) against the key-by-key path over SEEDED RANDOM action sequences — randomise, batches, reads and writes of parameters (per-step keys,
+    keys of fixed entities, keys that rebuild the description), entity reads, train / eval, in-place edits of sampler bounds, a second Scene over
+    the same parameter map, renders — on two scenes of the same configuration (native_update on / off).  After EVERY action the device state
+    must agree byte for byte (description, tables, blob, image — asked without materialising a pending sample), and after a random subset
+    everything a script can read back.  FFX_FUZZ_SEQUENCES (default 200) sequences of 30 actions; a sequence that fails names its seed."""
+    import os
+
+    a, b = _native_pair()
+    cam, spot = b.mi_scene.data.camera.name, b.mi_scene.data.spot.name
+    cam0 = a.params[cam + ".to_world"].numpy().reshape(4, 4).copy()
+    fov0 = float(a.params[cam + ".x_fov"])
+    second = {}
+
+    def act(wl, kind, r, tag):
+        ffs, p = wl.ff_scene, wl.params
+        if kind == 0 or kind == 1:  # a sample (twice as likely as anything else)
+            torch.manual_seed(r)
+            random.seed(r)
+            ffs.randomize()
+        elif kind == 2:  # a batch, its samples applied one after the other (not all of them)
+            for i, f in enumerate(ffs.randomize_batch([r + i for i in range(3)])):
+                if i < 2:
+                    f()
+        elif kind == 3:  # read a parameter (tells a pending sample to the map)
+            keys = sorted(k for k in p.keys() if k != "tex.data")
+            v = p[keys[r % len(keys)]]
+            _ = float(v) if isinstance(v, float) else v
+        elif kind == 4:  # write a per-step key of a RANDOMISED entity right behind a sample
+            p[spot + ".intensity.value"] = mi.Color3f(torch.tensor([1.0 + (r % 7), 2.0, 3.0]))
+            p.update()
+        elif kind == 5:  # move the FIXED camera / change the fixed cone (template fields no plan op writes)
+            m = cam0.copy()
+            m[0, 3] += 0.01 * (r % 9)
+            p[cam + ".to_world"] = mi.Transform4f(m)
+            p[spot + ".beam_width"] = mi.Float(25.0 + (r % 5))
+            if r % 2:
+                p.update()
+        elif kind == 6:  # a key that rebuilds the description (the next sample takes the Python path)
+            p[cam + ".x_fov"] = mi.Float(fov0 * (0.97 + 0.01 * (r % 6)))
+            if r % 2:
+                p.update()
+        elif kind == 7:  # read an entity
+            ents = list(ffs._draw_order())
+            ents[r % len(ents)].world()
+        elif kind == 8:
+            (ffs.eval if r % 2 else ffs.train)()
+        elif kind == 9:  # an in-place edit of a sampler's bound through the live tensor the accessor hands out
+            mesh = ffs.mesh("mesh-Larynx")
+            smp = list(mesh._all_samplers())
+            t = smp[r % len(smp)].get_max()
+            t.mul_(1.0 + 0.01 * ((r % 5) - 2))
+        elif kind == 10:  # a render (asks the parameter map nothing)
+            mi.render(wl.mi_scene, spp=1 + (r % 3), seed=r).torch()
+        elif kind == 11:  # a second Scene object over the same parameter map pushes a sample of its own
+            s2 = second.get(id(wl))
+            if s2 is None:
+                s2 = second[id(wl)] = ff.Scene(p, device=DEV)
+                s2.native_update = getattr(ffs, "native_update", True)
+                s2.mesh("mesh-Larynx").rotate_y(-0.05, 0.05)
+                s2.train()
+            torch.manual_seed(r)
+            random.seed(r)
+            s2.randomize()
+
+    n_seq = int(os.environ.get("FFX_FUZZ_SEQUENCES", "200"))
+    for seq in range(n_seq):
+        rng = random.Random(9000 + seq)
+        for wl in (a, b):
+            wl.ff_scene.train()
+        for step in range(30):
+            kind, r = rng.randrange(12), rng.randrange(1 << 20)
+            tag = f"sequence {9000 + seq}, action {step} (kind {kind}, r {r})"
+            state = random.getstate()
+            for wl in (a, b):
+                random.setstate(state)
+                act(wl, kind, r, tag)
+            _same_device_state(a, b, tag, spp=2, lit=False)  # (a random walk of bounds and poses may well leave the scene dark)
+            if rng.random() < 0.3:
+                _same_native_state(a, b, tag + " [read back]", lit=False)
+    assert b.mi_scene.update_paths["native"] > 4 * n_seq and a.mi_scene.update_paths["native"] == 0, (a.mi_scene.update_paths, b.mi_scene.update_paths)
+
+
 def test_native_params_update_pushes_the_sample_the_python_path_pushes():
     """ffx_scene_step_h behind Scene.randomize() (ABI 8, the native params.update()): two scenes of the same configuration, one kept on the Python
     path (FFX_NATIVE_UPDATE=0), over seeded randomisations with animation picks — the same scene description byte for byte, the same transform
     table, frame offsets and material rows, the same values in the parameter map and on the entities, the same re-fitted blob (everything the
     re-fit writes) and the same image; single samples and the samples of a batch; and the native path really is the one that ran."""
-    import ctypes as C
-
-    def make(native):
-        wl = _small()
-        wl.ff_scene.native_update = native  # (FFX_NATIVE_UPDATE=0 for one scene)
-        with torch.no_grad():
-            wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
-        torch.manual_seed(7)
-        random.seed(7)
-        wl.ff_scene.randomize()  # (the Python path teaches the plan what each key means)
-        wl.ff_scene.randomize()
-        return wl
-
-    a, b = make(False), make(True)
+    a, b = _native_pair()
     ma, mb = a.mi_scene, b.mi_scene
 
     def same_state(tag):
-        sa, sb = ma.scene_desc(tex_channels=1), mb.scene_desc(tex_channels=1)
-        assert C.string_at(C.addressof(sa), C.sizeof(sa)) == C.string_at(C.addressof(sb), C.sizeof(sb)), tag
-        assert torch.equal(ma._xforms, mb._xforms) and np.array_equal(ma._offs, mb._offs) and np.array_equal(ma._albedo_host, mb._albedo_host), tag
-        assert np.array_equal(ma.geom._vert_off_host, mb.geom._vert_off_host), tag
-        for k in a.params.keys():
-            va, vb = a.params[k], b.params[k]
-            if isinstance(va, float):
-                assert float(va) == float(vb), (tag, k)
-            elif isinstance(va, mi.Transform4f):
-                assert np.array_equal(va.numpy(), vb.numpy()), (tag, k)
-            elif isinstance(va, mi._ArrayBase) and k != "tex.data":
-                assert torch.equal(va.t.cpu(), vb.t.cpu()), (tag, k)
-        for ea, eb in zip(a.ff_scene._draw_order(), b.ff_scene._draw_order()):
-            assert torch.equal(ea.world(), eb.world()), tag
-            assert ea._host_float_attributes == eb._host_float_attributes and ea._host_vec3_attributes == eb._host_vec3_attributes, tag
-        static = int(ma.geom.info.off_bins)
-        torch.cuda.synchronize()
-        assert torch.equal(ma.geom.blob[:static], mb.geom.blob[:static]), tag
-        ia, ib = mi.render(ma, spp=4, seed=3).torch(), mi.render(mb, spp=4, seed=3).torch()
-        assert torch.equal(ia, ib) and float(ia.sum()) > 0, tag
-        for m in (ma, mb):  # the camera block depth.py's queries take from the finished description is the one built from the sensor's parameters
-            for _ in range(2):
-                fast, slow = m.camera_struct(0), m._camera_struct_slow(0)
-                assert C.string_at(C.addressof(fast), C.sizeof(fast)) == C.string_at(C.addressof(slow), C.sizeof(slow)), tag
+        _same_native_state(a, b, tag)
         assert mb._cam_check[1] is True
 
     for k in range(8):

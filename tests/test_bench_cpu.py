@@ -188,3 +188,26 @@ def test_committed_bench_line_is_consistent_with_itself(bench):
     assert vi["kernel_ms"] == r["kernel_alone_ms"] and 0.5 < vi["frac"] <= 1.0
     tag = os.path.basename(f).split("_")[0]
     assert f"{tag}_sq_instruction_mix.json" in vi["source"] and f"{tag}_issue_rates.txt" in vi["source"], vi["source"]  # (the line cites its own round's files)
+
+
+def test_committed_driver_line_carries_configs_3_and_4(bench):
+    """Round-5 review, item 5: BASELINE configs[3] (32 scene samples per gradient step) and configs[4] (the colon at 1024 x 1024 x 256 spp, fp16 film)
+    are timed inside the DEFAULT bench line — what the driver runs — as informational brackets, the colon with a roofline of its own from the
+    committed r<N>colon_* passes.  On the newest committed driver-style line (profiles/r<N>_bench_line.json, written by tools/collect_profiles.sh):
+    the keys are there, the colon's fraction is its algorithmic bytes over its own kernel time over 8 TB/s, and its traffic is the committed figure."""
+    ff = bench._profile_files("bench_line.json")
+    if not ff:
+        pytest.skip("no committed profiles/r<N>_bench_line.json yet")
+    d = json.load(open(ff[-1]))
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["grad_samples_per_sec_s32"] > 0 and d["grad_s32_config"]["step_paths"]
+    assert d["grad_samples_per_sec_s32"] >= 0.9 * d["grad_steps_per_sec"]  # (32 samples amortise the pattern side: at least the one-sample step's pace)
+    assert d["value_colon"] > 0 and d["ms_per_step_colon"] == pytest.approx(1e3 / d["value_colon"], rel=1e-9)
+    r = d["colon_roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-12)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9, rel=1e-9)
+    assert r["kernel_alone_ms"] <= 1.05 * d["ms_per_step_colon"]
+    tr = bench.pmc_traffic("k_render_fwd_pk", "r", "colon")
+    if tr is not None and r["traffic"] is not None and os.path.basename(tr["source"]) == os.path.basename(r["traffic_source"]):
+        assert r["traffic"] == pytest.approx(tr["bytes"], rel=1e-12) and r["traffic_ratio"] == pytest.approx(tr["bytes"] / r["algorithmic_bytes_per_launch"], rel=1e-12)
+    assert any("colon" in f for f in d["evidence"])

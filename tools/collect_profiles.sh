@@ -48,6 +48,11 @@ python tools/microbench.py > profiles/${TAG}_microbench.json 2> $OUT/microbench.
 # issue-rate microbenchmark (instruction counts are fixed by the inline-asm bodies; `grep -c` on the .s confirms)
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o /tmp/issue_rates issue_rates.hip 2> $OUT/issue_rates_build.log && /tmp/issue_rates > $R/profiles/${TAG}_issue_rates.txt 2>&1)
 fi
+if [ -z "$X" ]; then
+# the line as the driver runs it (no profiler, every informational bracket: gaussian film, low spp, configs[3] and [4]): what BENCH_r<N>.json will look like
+(unset FFX_BENCH_SETTLE FFX_BENCH_PREFLIGHT FFX_BENCH_EXTRA_BRACKETS FFX_BENCH_GAUSSIAN; python bench.py --steps 20 --warmup 5 2> $OUT/bench_line.log | tail -1 > $OUT/bench_line.json) \
+  && [ -s $OUT/bench_line.json ] && mv $OUT/bench_line.json profiles/${TAG}_bench_line.json
+fi
 # where K8's wave time goes (shader-clock stamps; needs the -DFFX_TIMERS build of the CURRENT sources: tools/build_variant_lib.sh timers -DFFX_TIMERS,
 # before gpurun — a stale variant library fails to load (missing symbols) and used to leave an empty file behind)
 FAILED=""
