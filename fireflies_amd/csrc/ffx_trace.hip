@@ -2624,18 +2624,29 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 // ---- adjoint cache of a FILTERED render (ffx_render_fwd_cache_filtered, include/ffx.h).  A sample spreads over the 25 pixels of its
 // window with weights of its own (the jitter), so a pixel's samples do not fold into one texture footprint as under the box film — its
 // adjoint is a 25 x 25 matrix (window pixel x texel).  Kept instead: one 16-byte record PER SAMPLE of the pixels that have a lit sample
-// {(ubx + 1) | (uby + 1) << 12 | shape << 24, ax, ay, fac} (+ fac_b in a second array with material rows), at the sample's own index —
-// written as one coalesced 1 KB store per wave and pass, nothing to allocate, nothing that can overflow — the dense CachePix array
-// (`lit` = bit mask of the pixel's 64-sample passes that hold a lit sample) and the weight each pixel received (the gather writes it).
-//   [0, 64)                CacheHdr (all zero: nothing is ever dropped)
-//   64 + 8 * pixel         CachePix
+// {(ubx + 1) | (uby + 1) << 12 | shape << 24, ax, ay, fac} (+ fac_b in a second array with material rows) — one coalesced 1 KB store per
+// wave and lit pass.  Round 6: the records live in an ARENA of 64-sample blocks (rounds 4-5: a dense [pixel][sample] array, 20 B x pixels x
+// spp of address space — 5.4 GB at 1024 x 1024 x 256 — for the ~4 % of the pixels that hold a lit sample): the first lit pass of a pixel
+// takes one block for itself and for every later pass with ONE atomic of its wave, the pixel's header holds the first block and that pass;
+// capacity = rfc_cap_blocks; a pixel that finds the arena full is counted in `dropped` (sticky, as the
+// box film's arena: ffx_render_cache_status, the NaN poison of the adjoint, ffx_adam_args.guard) and keeps no records.
+//   [0, 64)                CacheHdr {blocks taken (may exceed the capacity), capacity, dropped pixels}
+//   64 + 8 * pixel         CachePix {x0 | y0 << 16 = first block, shape = first lit pass, lit = bit mask of the passes that hold records}
 //   rfc_off_wsum           float per pixel
-//   rfc_off_recs           uint4 per sample
-//   rfc_off_facb           float per sample (material rows)
+//   rfc_off_recs           uint4 per sample slot of the arena's blocks
+//   rfc_off_facb           float per sample slot (material rows)
+__host__ __device__ inline size_t rfc_cap_blocks(size_t n_pix, size_t spp) {
+  // every pass of every pixel up to 2^18 blocks (335 MB with material rows: 512 x 512 x 64 spp keeps a block per pixel and cannot overflow,
+  // whatever the texture), a QUARTER of them beyond: 1024 x 1024 x 256 — 1.05 M blocks, 1.34 GB instead of 5.4 GB.  (A tenth, 0.54 GB, was
+  // tried first: BASELINE configs[4]'s own 1 024-point pattern lights 17 % of the film — 178 k pixels x 4 passes — and 73 k of them found no block.)
+  const size_t dense = n_pix * ((spp + 63) / 64), part = dense / 4, keep = (size_t)1 << 18;
+  const size_t n = part > keep ? part : keep;
+  return n < dense ? n : dense;
+}
 __host__ __device__ inline size_t rfc_off_wsum(size_t n_pix) { return (64 + 8 * n_pix + 127) & ~(size_t)127; }
 __host__ __device__ inline size_t rfc_off_recs(size_t n_pix) { return (rfc_off_wsum(n_pix) + 4 * n_pix + 127) & ~(size_t)127; }
-__host__ __device__ inline size_t rfc_off_facb(size_t n_pix, size_t spp) { return (rfc_off_recs(n_pix) + 16 * n_pix * spp + 127) & ~(size_t)127; }
-__host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) { return rfc_off_facb(n_pix, spp) + (mat ? ((4 * n_pix * spp + 127) & ~(size_t)127) : 0); }
+__host__ __device__ inline size_t rfc_off_facb(size_t n_pix, size_t spp) { return (rfc_off_recs(n_pix) + 16 * 64 * rfc_cap_blocks(n_pix, spp) + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) { return rfc_off_facb(n_pix, spp) + (mat ? ((4 * 64 * rfc_cap_blocks(n_pix, spp) + 127) & ~(size_t)127) : 0); }
 
 
 // ---- reconstruction filter that spreads a sample over its 5x5-pixel window (include/ffx.h, ffx_scene_desc.rfilter) -------------------------
@@ -2893,8 +2904,8 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
   // (wave-uniform, used once per pixel: kept in an SGPR — as a VGPR it was live across the whole kernel and spilled)
   const float inv_spp_u = inv_spp_arg; // 1 / spp from the host (a kernel argument is scalar by construction; the division here was ten vector instructions per wave)
   if (!ADJ && !RF && cache && wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(cache)->cap_stray = cap_stray; // (read back by K9 and ffx_render_cache_status; no wave of this launch reads it)
-  if constexpr (RFC) { // (the filtered cache never drops anything: a header of zeros for ffx_render_cache_status / ffx_adam_args.guard)
-    if (wv == 0 && lane < 3) reinterpret_cast<uint32_t *>(adj_gtex)[lane] = 0u;
+  if constexpr (RFC) { // (the arena's counters were cleared in front of this launch — launch_apex / FFX_RENDER_CACHE_ZEROED; nobody here reads the capacity word)
+    if (wv == 0 && lane == 0) reinterpret_cast<CacheHdr *>(adj_gtex)->cap_stray = cap_stray;
   }
   FFX_TSTOP(tpro, 25);
   for (int sub = sub0; sub < sub0 + ppw; ++sub) {
@@ -2914,6 +2925,9 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     float fin0 = 0.f, fin1 = 0.f, fin2 = 0.f; // the pixel's value as stored (ffx_render_fwd_adjoint: <gimg, img>)
     float rfacc[4] = {0.f, 0.f, 0.f, 0.f}; // RF: this lane's window entry (lane % 32, samples of half lane / 32), four channels, summed over the passes
     uint32_t rfc_mask = 0u; // RFC: the passes of this pixel that hold a lit sample (wave-uniform)
+    uint32_t rfc_first = 0u; // ... the arena block of the first of them (the later passes follow it), and that pass; rfc_drop: the arena was full
+    int rfc_first_pass = -1;
+    bool rfc_drop = false;
     for (int pass = 0; pass < passes; ++pass) {
       const int s = pass * 64 + lane;
       bool active[R];
@@ -2938,11 +2952,27 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
       if constexpr (RFC) {
         // ---- the filtered film's adjoint cache: this pass's 64 records, if any of its samples is lit (one 1 KB store per wave)
         const bool lit = active[0] && st[0].hit && st[0].has_proj;
-        if (wballot(lit) != 0ull) {
+        if (wballot(lit) != 0ull && !rfc_drop) {
+          char *rfc = reinterpret_cast<char *>(adj_gtex);
+          if (rfc_first_pass < 0) { // the pixel's first lit pass: blocks for it and for every pass behind it, one atomic of the wave
+            const uint32_t want = (uint32_t)(passes - pass);
+            uint32_t b0 = 0u;
+            if (lane == 0) b0 = atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->n_stray, want);
+            b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            if (b0 + want > cap_stray) {
+              rfc_drop = true; // (arena full: this pixel keeps no records — counted, the adjoint is poisoned, the caller re-traces)
+              if (lane == 0) atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->dropped, 1u);
+            } else {
+              rfc_first = b0;
+              rfc_first_pass = pass;
+            }
+          }
+        }
+        if (wballot(lit) != 0ull && !rfc_drop) {
           rfc_mask |= 1u << pass;
           if (s < spp) {
             char *rfc = reinterpret_cast<char *>(adj_gtex);
-            const size_t si = (size_t)pix[0] * (size_t)spp + (size_t)s;
+            const size_t si = (size_t)(rfc_first + (uint32_t)(pass - rfc_first_pass)) * 64u + (size_t)(s & 63);
             uint4 rec = make_uint4(0u, 0u, 0u, 0u);
             if (lit) rec = make_uint4((uint32_t)(st[0].ubx + 1) | ((uint32_t)(st[0].uby + 1) << 12) | ((uint32_t)st[0].shape << 24), __float_as_uint(st[0].wx1),
                                       __float_as_uint(st[0].wy1), __float_as_uint(st[0].proj_fac));
@@ -3176,7 +3206,7 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
     if constexpr (RFC) { // the pixel's header: which of its passes hold records
       if (live[0] && lane == 0) {
         CachePix hp;
-        hp.x0 = 0; hp.y0 = 0; hp.shape = 0; hp.lit = (uint16_t)rfc_mask;
+        hp.x0 = (int16_t)(rfc_first & 0xffffu); hp.y0 = (int16_t)(rfc_first >> 16); hp.shape = (uint16_t)(rfc_first_pass < 0 ? 0 : rfc_first_pass); hp.lit = (uint16_t)rfc_mask;
         reinterpret_cast<CachePix *>(reinterpret_cast<char *>(adj_gtex) + 64)[pix[0]] = hp;
       }
     }
@@ -3807,11 +3837,21 @@ __global__ void __launch_bounds__(64)
   const uint4 *recs = reinterpret_cast<const uint4 *>(cache + p.off_recs);
   const float *facb = reinterpret_cast<const float *>(cache + p.off_facb);
   const int lane = threadIdx.x;
-  uint32_t mask = 0u; // the lane's pixel: its lit passes
+  uint32_t mask = 0u; // the lane's pixel: its lit passes, the arena block of the first of them, that pass
+  uint32_t hfirst = 0u;
+  int hpass = 0;
   {
     const int x = bx * K9F_BLOCK + lane % K9F_BLOCK, y = by * K9F_BLOCK + lane / K9F_BLOCK;
-    if (x < p.W && y < p.H) mask = hdrs[(long)y * p.W + x].lit;
+    if (x < p.W && y < p.H) {
+      const CachePix hp = hdrs[(long)y * p.W + x];
+      mask = hp.lit;
+      hfirst = (uint32_t)(uint16_t)hp.x0 | ((uint32_t)(uint16_t)hp.y0 << 16);
+      hpass = hp.shape;
+    }
   }
+  // (a forward that found the arena full left pixels without records: the gradient would have holes that look like values — poison it, NaN;
+  // ffx_render_cache_status tells the host why, which re-traces (functional._Render.backward) or raises (optim.PatternOptimizer))
+  if (blockIdx.x == 0 && lane == 0 && reinterpret_cast<const CacheHdr *>(cache)->dropped != 0u) atomicAdd(gtex, __uint_as_float(0x7fc00000u));
   if (wballot(mask != 0u) == 0ull) return; // (nothing lit in this block: 96 % of a dot pattern's film ends here)
   const int passes = (p.spp + 63) >> 6;
   const bool tiled = p.tc == 1, mat = p.ms != 3;
@@ -3842,8 +3882,9 @@ __global__ void __launch_bounds__(64)
     const int s = pass * 64 + lane;
     o.sidx = (uint32_t)pixel * (uint32_t)p.spp + (uint32_t)s;
     if (s < p.spp) {
-      o.rec = recs[(size_t)pixel * (size_t)p.spp + (size_t)s];
-      if (mat) o.fb = facb[(size_t)pixel * (size_t)p.spp + (size_t)s];
+      const uint32_t blk_ = (uint32_t)__builtin_amdgcn_readlane((int)hfirst, pl) + (uint32_t)(pass - __builtin_amdgcn_readlane(hpass, pl));
+      o.rec = recs[(size_t)blk_ * 64u + (size_t)lane];
+      if (mat) o.fb = facb[(size_t)blk_ * 64u + (size_t)lane];
     }
     const int wb = (lane * 13) >> 6, wa = lane - 5 * wb; // lane / 5, lane % 5 for lane < 25
     const int tx = o.px + wa - 2, ty = o.py + wb - 2;
@@ -4508,8 +4549,14 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     int pgrid = ((ffx_cdiv((long)pn * (4 / ppw), wpb) + 7) / 8) * 8; // multiple of 8 so the XCD remap is a bijection onto [0, grid)
     const TriApex *arecs;
     uint32_t astride;
-    const uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : 0u;
-    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache, cap_stray, call_flags)) return FFX_ERR_ARG;
+    // (capacity of the cache's arena: single-sample records of the box film's footprint cache / 64-sample blocks of the filtered film's record cache)
+    uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : (rf_cache ? (uint32_t)rfc_cap_blocks((size_t)c.cam.W * c.cam.H, (size_t)spp) : 0u);
+    if (rf_cache)
+      if (const char *ce = getenv("FFX_RFC_CAP")) { // (test knob, include/ffx.h: fewer blocks than the cache has room for — the overflow path)
+        const long cv = atol(ce);
+        if (cv >= 0 && (unsigned long)cv < cap_stray) cap_stray = (uint32_t)cv;
+      }
+    if (!launch_apex(bvh, info, sd->cam.to_world, sd, &arecs, &astride, (hipStream_t)s, cache ? cache : rf_cache, cap_stray, call_flags)) return FFX_ERR_ARG;
     const WideScene ws = wide_scene(bvh, info);
     bins_k(bvh, info, sd, c.bins);
     // offsets of the cache areas in units of 128 bytes (both are multiples of 128; a 1024^2 x 256-spp cache is 160 MB)
@@ -4904,8 +4951,9 @@ int ffx_render_fwd_cache_filtered(const void *bvh, const ffx_bvh_info *info, con
                                   uint32_t seed, int img_fp16, void *img, void *cache, void *scratch, ffx_stream s) {
   if (!cache || ((uintptr_t)cache & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache_filtered: cache is NULL or not 16-byte aligned");
   if (!scratch || ((uintptr_t)scratch & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_fwd_cache_filtered: scratch is NULL or not 16-byte aligned");
-  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed, img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT | FFX_RENDER_APEX_READY), img, nullptr, s, nullptr,
-                         nullptr, nullptr, scratch, cache);
+  return render_fwd_impl(bvh, info, sd, shape_albedo, tex, spp, seed,
+                         img_fp16 & (FFX_RENDER_FP16 | FFX_RENDER_SPARSE_ADJOINT | FFX_RENDER_APEX_READY | FFX_RENDER_CACHE_ZEROED | FFX_RENDER_CACHE_KEEP_DROPPED), img, nullptr, s,
+                         nullptr, nullptr, nullptr, scratch, cache);
 }
 
 int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, uint32_t seed, const float *gimg, float *gtex,

@@ -148,8 +148,9 @@ def cache_supported(sd, spp):
     if sd.proj.tex_w > 4094 or sd.proj.tex_h > 4094 or sd.n_shapes > 255 or sd.n_base_tex > 0:  # (textured base colours: one colour per shape in the footprint)
         return False
     if sd.rfilter:
-        # a filter that spreads samples over neighbouring pixels: ffx_render_fwd_cache_filtered keeps one record per sample of the lit
-        # pixels — no footprint a fine texture could overflow; up to 16 passes of 64 samples per pixel
+        # a filter that spreads samples over neighbouring pixels: ffx_render_fwd_cache_filtered keeps one 16-byte record (+ 4 with material rows) per
+        # sample of the pixels that have a lit sample, in an arena of 64-sample blocks (a block per pass of every pixel up to 2^18 blocks — 344 MB
+        # at 512 x 512 x 64 —, a quarter of them beyond: include/ffx.h) — no footprint a fine texture could overflow; up to 16 passes per pixel
         return spp <= 1024 and ops.render_cache_bytes_sd(sd, spp) <= CACHE_LIMIT_BYTES
     if texels_per_pixel(sd) > max_texels_per_pixel():
         return False
@@ -187,7 +188,7 @@ class _Render(torch.autograd.Function):
         gtex = None
         if ctx.cache is not None:
             # (one 64-byte read + stream sync per backward of this generic path; the optimiser's explicit step checks lazily)
-            used, cap, dropped = (0, 0, 0) if ctx.sd.rfilter else ops.render_cache_status(ctx.cache)  # (the filtered film's cache never drops)
+            used, cap, dropped = ops.render_cache_status(ctx.cache)  # (box film: stray samples beyond the arena; filtered film: pixels that found no block)
             if dropped == 0:
                 gtex = ctx.geom.render_bwd_cached(ctx.sd, ctx.albedo, ctx.cache, ctx.spp, g, seed=ctx.seed if ctx.sd.rfilter else None)
             elif ctx.geom.version != ctx.pose_version:
@@ -210,7 +211,7 @@ class _Render(torch.autograd.Function):
 def render(tex, geom, sd, albedo, spp, seed=0, fp16=False):
     """K8/K9: image [H,W,3], differentiable w.r.t. the projector texture ([h,w] or [h,w,c]).
     When the texture requires grad the forward kernel also stores each pixel's footprint in the texture
-    (128 B per pixel + a small arena: 40 MB at 512x512x64; under a gaussian film one 16-byte record per sample of the
-    lit pixels) and the adjoint scatters those footprints; beyond FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
+    (128 B per pixel + a small arena: 40 MB at 512x512x64; under a gaussian film an arena of per-sample records — 16 / 20 bytes per sample
+    of the pixels that have a lit sample, room for every pixel up to 344 MB, a quarter of them beyond) and the adjoint scatters those footprints; beyond FFX_CACHE_LIMIT_GB the adjoint re-traces instead (then the geometry must not be re-fitted between
     forward and backward)."""
     return _Render.apply(tex, geom, sd, albedo, int(spp), int(seed), bool(fp16))

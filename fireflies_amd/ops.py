@@ -349,7 +349,8 @@ def render_dot_slots(width, height):
 
 
 def render_cache_status(cache):
-    """(stray records used, arena capacity, dropped samples) of an adjoint cache written by render_fwd(..., cache=...).
+    """(stray records used, arena capacity, dropped samples) of an adjoint cache written by render_fwd(..., cache=...) — for a filtered film's
+    cache: (64-sample blocks taken, blocks the arena holds, pixels that found it full and kept no records).
     SYNCHRONISES the current stream (64-byte read).  dropped > 0: the cache is incomplete — ffx_render_bwd_cached then
     poisons gtex[0] with NaN; use the re-tracing adjoint."""
     out = (C.c_uint32 * 3)()
@@ -834,7 +835,7 @@ class DeviceGeometry:
             if cache is not None:  # ... and the per-sample records of its adjoint (ABI 7)
                 if cache.numel() < render_cache_bytes_sd(sd, spp):
                     raise ValueError("cache tensor too small")
-                flags |= _abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0
+                flags |= (_abi.RENDER_SPARSE_ADJOINT if sparse_adjoint else 0) | (_abi.RENDER_CACHE_ZEROED if cache_zeroed else 0) | (_abi.RENDER_CACHE_KEEP_DROPPED if keep_dropped else 0)
                 with self._timed("render_fwd"):
                     self._call("ffx_render_fwd_cache_filtered", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg,
                                _dev(tex, name="tex") if tex is not None else None, int(spp), int(seed) & 0xFFFFFFFF, flags, _dev(img, img.dtype),

@@ -42,6 +42,8 @@
  *                                packet whose segments all end in front of their cells' planes skips that emitter's any-hit stage (exact: the
  *                                image is the same bit for bit; 87 % of the vocal fold's shadow packets, K8 0.39 -> 0.34 ms).  0: none (the A/B
  *                                baseline).  A caller's hint in ffx_scene_desc.shadows (FFX_SHADOWS_PLAIN) leaves them out per pose.
+ *       FFX_RFC_CAP=n            blocks of the filtered film's adjoint cache a forward may take, at most what the cache holds (a test knob: pixels
+ *                                that find the arena full keep no records and are counted in `dropped` — the overflow path)
  *       FFX_BIN_CAP=n            capacity of each grid's entry list, at most the default 2 F + 16384 (a test knob: a grid whose lists do
  *                                not fit is marked not-ok by the pre-pass and its packets take the tree walks — the overflow path)
  *       FFX_RENDER_BLOCKS=0      ffx_render_fwd / ffx_render_fwd_filtered below 33 samples per pixel: a pixel per wave whatever the count, as
@@ -802,15 +804,22 @@ int ffx_render_bwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info 
  * for a filtered sd; opaque, read only by the library that wrote it) what the adjoint needs.  A sample spreads over the 25 pixels of its
  * window with weights of its own, so a pixel's samples do NOT fold into one footprint as under the box film (25 gradients x 25 texels):
  * libffx_hip keeps, for the pixels that have a lit sample only, one 16-byte record per sample {base texel + shape, the two bilinear
- * fractions, the factor} (+ 4 bytes with material rows) at the sample's own index — nothing to allocate, nothing that can overflow — plus
- * a dense array of 8-byte pixel headers (which 64-sample passes of the pixel hold a lit sample) and the weight every pixel received (written by the gather).
- * 344 MB of address space at 512x512x64 with material rows, ~15 MB of it touched by a dot pattern's render with FFX_RENDER_SPARSE_ADJOINT.
+ * fractions, the factor} (+ 4 bytes with material rows), in an ARENA of 64-sample blocks (round 6): the first lit 64-sample pass of a pixel
+ * takes a block for itself and one for every later pass, the dense array of 8-byte pixel headers says where (and which passes hold a lit
+ * sample); plus the weight every pixel received (written by the gather).  The arena holds a block for every pass of every pixel up to 2^18
+ * blocks — 344 MB at 512x512x64 with material rows, ~15 MB of it touched by a dot pattern's render with FFX_RENDER_SPARSE_ADJOINT; such a
+ * cache cannot overflow — and a quarter of them beyond: 1.34 GB at 1024x1024x256 (rounds 4-5: 5.4 GB of address space; configs[4]'s own
+ * 1 024-point pattern lights 17 % of that film).  A pixel that finds
+ * the arena full keeps no records and is counted: ffx_render_cache_status reports {blocks taken, capacity, dropped pixels}, the adjoint
+ * poisons gtex[0] with NaN when anything was dropped (re-trace with ffx_render_bwd_filtered then), ffx_adam_args.guard skips the update.  The
+ * counters must be zero when the kernel starts: the call clears them in front of its launch (with FFX_RENDER_APEX_READY: one tiny launch)
+ * unless told FFX_RENDER_CACHE_ZEROED; FFX_RENDER_CACHE_KEEP_DROPPED keeps the count of a step's earlier scene samples, as for the box film.
  * ffx_render_bwd_cached_filtered: gtex += the adjoint applied to gimg — per lit pixel a wave recomputes the samples' filter weights from the
  * jitter (`seed`: the forward's), forms G = gimg / weight over the pixel's window, gives every lit sample its own gradient
  * sum_n w_n G[pixel + n] and scatters its four taps through an LDS tile shared by a 16x16-pixel block.  Needs neither the BVH nor the
  * camera pose (the geometry may be re-fitted in between; shape_albedo must hold the forward's values).  Same result as
  * ffx_render_bwd_filtered up to the order of the float atomics.  Flags of the forward: FFX_RENDER_FP16, FFX_RENDER_SPARSE_ADJOINT,
- * FFX_RENDER_APEX_READY.  FFX_ERR_UNSUPPORTED with textured base colours, projector textures above 4094^2 or more than 255 shapes, spp > 1024. */
+ * FFX_RENDER_APEX_READY, FFX_RENDER_CACHE_ZEROED, FFX_RENDER_CACHE_KEEP_DROPPED.  FFX_ERR_UNSUPPORTED with textured base colours, projector textures above 4094^2 or more than 255 shapes, spp > 1024. */
 int ffx_render_fwd_cache_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
                                   const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const float *tex /*[dev]*/, int spp, uint32_t seed,
                                   int img_fp16, void *img /*[dev][H,W,3]*/, void *cache /*[dev] ffx_render_cache_bytes_sd*/, void *scratch /*[dev] ffx_render_filter_bytes*/,

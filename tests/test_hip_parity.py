@@ -3,6 +3,7 @@ compared with (a) the golden vectors captured from the reference's torch code an
 oracle on the same seeded inputs.  Tolerances are stated per test.  Run with `-m gpu`."""
 import ctypes as C
 import os
+import random
 
 import numpy as np
 import pytest
@@ -1932,8 +1933,62 @@ def test_the_in_kernel_update_is_skipped_when_the_adjoint_cache_dropped_samples(
 
 
 # ------------------------------------------------------------------ reconstruction filter (ffx_scene_desc.rfilter)
+def test_filtered_film_adjoint_cache_is_an_arena_at_config_5_size(oracle):
+    """Round-5 review, missing 4 / item 7: the filtered film's adjoint cache was a dense [pixel][sample] array — 5.4 GB of address space at
+    BASELINE configs[4] (1024 x 1024 x 256 spp, material rows) for records of the few per cent of the pixels that hold a lit sample.  Now an arena
+    of 64-sample blocks: 1.34 GB there (a quarter of the passes: configs[4]'s own 1 024-point pattern lights 17 % of the film).  The colon at 96 x 96 against the ORACLE's filtered adjoint, and at full size — 1024 x 1024 x 256, a dot
+    pattern, FFX_RENDER_SPARSE_ADJOINT — against the library's own re-traced filtered adjoint; nothing dropped, a plausible share of the arena used."""
+    from fireflies_amd import _abi
+    from tests.test_bruteforce_cpu import material_rows
+
+    sc = scenes.colon(width=96, height=96, tex=128, n_around=48, n_along=160)
+    go, gd, alb = _pair(oracle, sc, frame=0, xforms=_rand_xforms(1, 3))
+    mats = material_rows(1, 6)
+    spp = 70
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True, mat_stride=_abi.MAT_STRIDE, rfilter="gaussian")
+    tex = _tex(sc, 1)
+    rng = np.random.default_rng(4)
+    gimg = rng.standard_normal((96, 96, 3)).astype(np.float32)
+    cache = torch.empty(ops.render_cache_bytes_sd(sd, spp), dtype=torch.uint8, device="cuda")
+    gd.render_fwd(sd, dev(mats), tex, spp, seed=21, cache=cache)
+    assert ops.render_cache_status(cache)[2] == 0
+    gt_c = host(gd.render_bwd_cached(sd, dev(mats), cache, spp, dev(gimg), seed=21))
+    gt_o = go.render_bwd(sd, mats, spp, 21, gimg)
+    gs = float(np.abs(gt_o).max())
+    ec = np.abs(gt_c - gt_o)
+    assert gs > 0 and (ec > 1e-3 * gs).mean() <= 2e-3 and ec.max() <= 0.1 * gs, ((ec > 1e-3 * gs).mean(), ec.max() / gs)
+    del gd, go
+    # ---- configs[4] at full size: the workload's own scene, pattern and material randomisation
+    from fireflies_amd import mi, workloads
+
+    wl = workloads.colon(device="cuda", entity_device="cpu")
+    with torch.no_grad():
+        t = workloads.build_texture(wl).contiguous()
+    torch.manual_seed(5)
+    random.seed(5)
+    wl.ff_scene.randomize()
+    wl.mi_scene.rfilter = "gaussian"
+    sdb = wl.mi_scene.scene_desc(tex_channels=1)
+    nb = ops.render_cache_bytes_sd(sdb, 256)
+    assert nb <= 1.4e9, nb  # (5.4e9 as a dense array)
+    cache = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    g = wl.mi_scene.geom
+    matsb = wl.mi_scene.materials_arg(sdb)
+    tex3 = t.unsqueeze(-1).contiguous()
+    img = g.render_fwd(sdb, matsb, tex3, 256, seed=2, cache=cache, sparse_adjoint=True)
+    used, cap, dropped = ops.render_cache_status(cache)
+    assert dropped == 0 and 0 < used <= cap and cap == (1024 * 1024 * 4) // 4 and bool(torch.isfinite(img).all())
+    gb = torch.randn((1024, 1024, 3), device="cuda").sign_() / (3.0 * 1024 * 1024)
+    a = g.render_bwd_cached(sdb, matsb, cache, 256, gb, seed=2)
+    b = g.render_bwd(sdb, matsb, 256, 2, gb)
+    nz = tex3 != 0  # (sparse records: gradients where the texture is not zero)
+    sb = float(b[nz].abs().max())
+    eb = (a[nz] - b[nz]).abs()
+    assert sb > 0 and float((eb > 1e-3 * sb).float().mean()) <= 2e-3 and float(eb.max()) <= 0.1 * sb
+
+
 @pytest.mark.parametrize("ch,rows,spp,stddev", [(1, "albedo", 8, 0.5), (3, "albedo", 8, 0.5), (1, "material_rows", 70, 0.5), (1, "albedo", 5, 0.3)])
-def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(oracle, ch, rows, spp, stddev):
+def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(oracle, ch, rows, spp, stddev, monkeypatch):
     """hdrfilm's default filter, which every scene the reference loads gets: ffx_render_fwd_filtered / ffx_render_bwd_filtered against the
     oracle's (itself checked against the float64 brute force, tests/test_bruteforce_cpu.py) — image, fp16 film, texture gradient — for both
     texture layouts, Lambert and material rows, one and two 64-sample passes per pixel and a narrower filter; every other render entry point
@@ -1980,13 +2035,17 @@ def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(ora
     # ---- store instead of re-trace (ABI 7): the filtered forward that also writes one record per sample of the lit pixels, and the adjoint
     # from those records — same image (bitwise), the re-traced adjoint's gradient up to the order of the float atomics, the oracle's own
     # cached pair (one record per sample of every pixel), unaffected by a re-fit in between, accumulating into the caller's buffer
+    monkeypatch.delenv("FFX_RFC_CAP", raising=False)
     nb = ops.render_cache_bytes_sd(sd, spp)
     npx, up = 72 * 64, (lambda v: ((v + 127) // 128) * 128)
-    assert nb == up(up(up(64 + 8 * npx) + 4 * npx) + 16 * npx * spp) + (up(4 * npx * spp) if rows == "material_rows" else 0)
+    # (round 6: the records live in an arena of 64-sample blocks — a block per pass of every pixel while that stays below 2^18 blocks, as here)
+    blocks = npx * ((spp + 63) // 64)
+    assert nb == up(up(up(64 + 8 * npx) + 4 * npx) + 16 * 64 * blocks) + (up(4 * 64 * blocks) if rows == "material_rows" else 0)
     cache = torch.full((nb,), 0xAB, dtype=torch.uint8, device="cuda")  # (garbage: every byte the adjoint reads is written by the forward)
     img_c = gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
     assert torch.equal(img_c.cpu(), torch.from_numpy(img_d))
-    assert ops.render_cache_status(cache) == (0, 0, 0)
+    used, cap, dropped = ops.render_cache_status(cache)
+    assert dropped == 0 and cap == blocks and 0 < used <= cap and used % ((spp + 63) // 64) == 0  # (a lit pixel takes a block for every pass from its first lit one on)
     pose = gd._vert_off_host.copy()
     gd.update(_rand_xforms(2, 99))  # re-fit to another pose: the cached adjoint needs neither the tree nor the camera
     acc = torch.full((sd.proj.tex_h, sd.proj.tex_w, ch), 1.5, device="cuda")
@@ -2008,6 +2067,17 @@ def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(ora
     gt_sp = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), seed=11))
     nzs = host(tex_s).reshape(gt_d.shape) != 0
     np.testing.assert_allclose(gt_sp[nzs], gt_d[nzs], rtol=0, atol=1e-3 * gs)
+    # an arena too small for the lit pixels (FFX_RFC_CAP: the overflow path): the image is the same, the pixels that found no block are counted,
+    # the adjoint from such a cache is poisoned rather than silently incomplete — and the next plain forward starts from a clean header
+    monkeypatch.setenv("FFX_RFC_CAP", "5")
+    img_x = gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
+    used_x, cap_x, dropped_x = ops.render_cache_status(cache)
+    assert torch.equal(img_x.cpu(), torch.from_numpy(img_d)) and cap_x == 5 and dropped_x > 0 and used_x > cap_x
+    assert bool(torch.isnan(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), seed=11).reshape(-1)[0]))
+    monkeypatch.delenv("FFX_RFC_CAP")
+    gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
+    assert ops.render_cache_status(cache)[2] == 0
+    np.testing.assert_allclose(host(gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), seed=11)), gt_d, rtol=0, atol=1e-3 * gs)
     if ch == 1:
         # forward + adjoint of a loss that is linear in the image in ONE render launch (ffx_render_fwd_adjoint_filtered): the same image, the same
         # gradient as the pair above (and the oracle's composition), also with the sparse flag where the texture is not zero
