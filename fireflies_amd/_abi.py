@@ -7,7 +7,7 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 8
+FFX_ABI_VERSION = 9
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -226,6 +226,9 @@ PROTOTYPES = {
     "ffx_render_bwd": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_det_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
     "ffx_render_bwd_det": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p, c_p]),
+    "ffx_render_bwd_det_part": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_i, C.c_uint32, c_i, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "ffx_det_scale_log2": (c_i, [C.c_uint32, C.c_uint64]),
+    "ffx_det_finish": (c_i, [c_p, c_i, C.c_size_t, c_p, c_p]),
     "ffx_render_cache_bytes": (C.c_size_t, [c_i, c_i, c_i]),
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),

@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <limits.h>
+
 #include "ffx_common.h"
 
 #define TR_BLOCK 256
@@ -3407,6 +3409,22 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // 64-bit fixed-point accumulator per texel (global_atomic_add_x2) and k_det_finish converts back — bitwise the same gtex whatever the
 // dispatch order, the number of XCDs or the rank count, at a resolution of 2^-(62 - b) of the largest tap, b = bits of the launch's tap count: 2^-36 at 512 x 512 x 64 spp (float32 carries 2^-24).
 struct DetK { int mode; float scale; unsigned long long *fix; unsigned int *vmax; };
+// one of the two passes alone (ffx_render_bwd_det_part, ABI 9): part 1 = the largest tap into *vmax (atomicMax: accumulates over calls), part 2 = the
+// fixed-point sums at the caller's scale 2^scale_log2 into fix[] (accumulate over calls — over the scene samples of a step, over ranks)
+struct DetPart { int part; int scale_log2; unsigned long long *fix; unsigned int *vmax; };
+// the scale of a deterministic accumulation: vmax < 2^e, |sum| <= n_taps x vmax < 2^(b + e) with b = bits of the tap count; 2^(62 - b - e) keeps
+// every sum below 2^62 and one unit at 2^-(62 - b) of the largest tap.  INT_MIN: nothing lit (vmax = 0) or a non-finite tap
+static int det_scale_log2(uint32_t vmax_bits, unsigned long long n_taps) {
+  float vmax;
+  memcpy(&vmax, &vmax_bits, 4);
+  if (!(vmax > 0.f) || !(vmax < 3.0e38f)) return INT_MIN;
+  int e;
+  frexpf(vmax, &e);
+  int b = 0;
+  for (unsigned long long ns = n_taps > 0 ? n_taps : 1; ns > 0; ns >>= 1) ++b;
+  const int sh = 62 - b - e;
+  return sh > 126 ? 126 : (sh < -126 ? -126 : sh);
+}
 __device__ __forceinline__ void det_emit(const DetK &det, float *__restrict__ gtex, size_t t, float v) {
   if (det.mode == 0) { atomicAdd(gtex + t, v); return; }
   if (det.mode == 1) { if (v != 0.f) atomicMax(det.vmax, __float_as_uint(fabsf(v))); return; }
@@ -4791,8 +4809,8 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
 }
 
 static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
-                           const float *gimg, float *gtex, ffx_stream s, void *rf_scratch, void *det_ws = nullptr) {
-  if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || !gtex || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+                           const float *gimg, float *gtex, ffx_stream s, void *rf_scratch, void *det_ws = nullptr, const DetPart *det_part = nullptr) {
+  if (!bvh || !info || !sd || (!shape_albedo && sd->n_mat_h <= 0) || !gimg || (!gtex && !det_part) || spp < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if ((sd->rfilter != FFX_RFILTER_BOX) != (rf_scratch != nullptr))
     FFX_FAIL(FFX_ERR_UNSUPPORTED, rf_scratch ? "render_bwd_filtered: rfilter must be FFX_RFILTER_GAUSSIAN"
                                              : "render_bwd: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
@@ -4848,6 +4866,15 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       else { if (matm == 2) FFX_LAUNCH_BWD(false, 2, false); else if (matm == 1) FFX_LAUNCH_BWD(false, 1, false); else FFX_LAUNCH_BWD(false, 0, false); }
     };
 #undef FFX_LAUNCH_BWD
+    if (det_part) { // one pass of the deterministic accumulation alone: the caller owns the accumulators and the scale (ffx_render_bwd_det_part)
+      det.mode = det_part->part;
+      det.vmax = det_part->vmax;
+      det.fix = det_part->fix;
+      det.scale = ldexpf(1.0f, det_part->scale_log2);
+      launch();
+      FFX_CHECK_LAUNCH(det_part->part == 1 ? "render_bwd_det_part/max" : "render_bwd_det_part/sum");
+      return FFX_OK;
+    }
     if (det_ws) {
       // deterministic accumulation (DetK above): the largest tap of the launch -> a power-of-two scale -> 64-bit fixed-point sums -> gtex.  The
       // scale needs the first pass's result on the host: ONE 4-byte read and a stream synchronisation per call (a debugging / cross-checking mode)
@@ -4870,14 +4897,10 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
         FFX_CHECK_LAUNCH("render_bwd_det/non-finite");
         return FFX_OK;
       }
-      int e;
-      frexpf(vmax, &e); // vmax < 2^e
-      // |sum| <= (samples x 4 taps) x vmax < 2^(b + e) with b = bits of this launch's tap count; 2^(62 - b - e) keeps every sum below 2^62 and one
-      // unit at 2^-(62 - b) of the largest tap: 2^-36 at 512 x 512 x 64 spp (a fixed b = 34 — room for 2^32 samples — had left 2^-28, round-5 advisor)
-      int b = 2; // (4 taps per sample)
-      for (unsigned long long ns = (unsigned long long)c.cam.W * (unsigned long long)c.cam.H * (unsigned long long)(spp > 0 ? spp : 1); ns > 0; ns >>= 1) ++b;
-      const int sh = 62 - b - e;
-      det.scale = ldexpf(1.0f, sh > 126 ? 126 : (sh < -126 ? -126 : sh));
+      // (b = bits of this launch's tap count — 4 taps per sample: 2^-36 of the largest tap at 512 x 512 x 64 spp; a fixed b = 34 — room for 2^32
+      // samples — had left 2^-28, round-5 advisor)
+      const int sh = det_scale_log2(vbits, 4ull * (unsigned long long)c.cam.W * (unsigned long long)c.cam.H * (unsigned long long)(spp > 0 ? spp : 1));
+      det.scale = ldexpf(1.0f, sh);
       det.mode = 2;
       launch();
       FFX_CHECK_LAUNCH("render_bwd_det/sum");
@@ -4889,7 +4912,7 @@ static int render_bwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     FFX_CHECK_LAUNCH(rf_scratch ? "render_bwd_filtered" : "render_bwd");
     return FFX_OK;
   }
-  if (det_ws) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_det: the per-lane kernels (FFX_TRAVERSAL=lane) have no deterministic mode");
+  if (det_ws || det_part) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_det: the per-lane kernels (FFX_TRAVERSAL=lane) have no deterministic mode");
   int tiles_x = ffx_cdiv(c.cam.W, 8), tiles_y = ffx_cdiv(c.cam.H, 8);
   int n_tiles = tiles_x * tiles_y;
   int grid = ((n_tiles + 7) / 8) * 8;
@@ -4917,6 +4940,29 @@ int ffx_render_bwd_det(const void *bvh, const ffx_bvh_info *info, const ffx_scen
   void *rf = sd->rfilter != FFX_RFILTER_BOX ? workspace : nullptr;
   void *det = (char *)workspace + (rf ? ffx_render_filter_bytes(sd) : 0);
   return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s, rf, det);
+}
+
+int ffx_render_bwd_det_part(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
+                            const float *gimg, int part, int scale_log2, void *acc, void *workspace, ffx_stream s) {
+  if (!sd || !acc || (part != 1 && part != 2) || ((uintptr_t)acc & (part == 1 ? 3 : 7)) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd_det_part: bad argument");
+  if (scale_log2 < -126 || scale_log2 > 126) FFX_FAIL(FFX_ERR_ARG, "render_bwd_det_part: scale_log2 out of range");
+  void *rf = nullptr;
+  if (sd->rfilter != FFX_RFILTER_BOX) {
+    if (!workspace || ((uintptr_t)workspace & 15) != 0) FFX_FAIL(FFX_ERR_ARG, "render_bwd_det_part: a filtered film needs its scratch (ffx_render_filter_bytes), 16-byte aligned");
+    rf = workspace;
+  }
+  DetPart dp;
+  dp.part = part; dp.scale_log2 = scale_log2;
+  dp.vmax = part == 1 ? (unsigned int *)acc : nullptr;
+  dp.fix = part == 2 ? (unsigned long long *)acc : nullptr;
+  return render_bwd_impl(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, nullptr, s, rf, nullptr, &dp);
+}
+int ffx_det_scale_log2(uint32_t vmax_bits, uint64_t n_taps) { return det_scale_log2(vmax_bits, (unsigned long long)n_taps); }
+int ffx_det_finish(const void *acc, int scale_log2, size_t n, float *gtex, ffx_stream s) {
+  if (!acc || !gtex || n == 0 || scale_log2 < -126 || scale_log2 > 126) FFX_FAIL(FFX_ERR_ARG, "det_finish: bad argument");
+  hipLaunchKernelGGL(k_det_finish, dim3(ffx_cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)s, (const unsigned long long *)acc, ldexpf(1.0f, -scale_log2), (long)n, gtex);
+  FFX_CHECK_LAUNCH("det_finish");
+  return FFX_OK;
 }
 
 // scratch of the filtered calls: [pixel][25][4] outgoing sums (400 B per pixel) + G = gimg / weight as float4 per pixel (the adjoint)

@@ -79,6 +79,13 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def allreduce_max_(flat: torch.Tensor) -> torch.Tensor:
+    """in-place maximum over ranks (integers: the bits of non-negative floats order as they do)"""
+    if td.is_initialized() and (td.get_world_size() > 1 or force_exchange()):
+        td.all_reduce(flat, op=td.ReduceOp.MAX)
+    return flat
+
+
 def exchanging():
     """whether an optimisation step exchanges its gradient (several ranks, or one rank rehearsing the exchange)"""
     return td.is_initialized() and (td.get_world_size() > 1 or force_exchange())

@@ -439,6 +439,21 @@ def deterministic_mode():
     return os.environ.get("FFX_DETERMINISTIC", "0") == "1"
 
 
+def det_scale_log2(vmax_bits: int, n_taps: int):
+    """the power-of-two scale of a deterministic accumulation whose largest |tap| has the float bits `vmax_bits`, over `n_taps` taps in all
+    (include/ffx.h ffx_det_scale_log2) — None: nothing lit, or a non-finite tap"""
+    sh = int(api().lib.ffx_det_scale_log2(C.c_uint32(int(vmax_bits) & 0xFFFFFFFF), C.c_uint64(int(n_taps))))
+    return None if sh < -126 else sh
+
+
+def det_finish_(acc: torch.Tensor, scale_log2: int, gtex: torch.Tensor):
+    """gtex += acc * 2^-scale_log2 (acc: int64 fixed-point sums, one per texel and channel)"""
+    if acc.dtype != torch.int64 or not acc.is_contiguous() or gtex.dtype != torch.float32 or not gtex.is_contiguous() or acc.numel() != gtex.numel():
+        raise ValueError("det_finish_: int64 sums and a float32 gradient of the same size, both contiguous")
+    api().call("ffx_det_finish", C.c_void_p(acc.data_ptr()), int(scale_log2), acc.numel(), C.c_void_p(gtex.data_ptr()), _stream())
+    return gtex
+
+
 def _lane_kernels():
     return os.environ.get("FFX_TRAVERSAL") == "lane"  # (the per-lane A/B kernels neither read nor write apex records)
 
@@ -926,6 +941,26 @@ class DeviceGeometry:
                        _dev(gimg, name="gimg"), _dev(gtex), _dev(img, img.dtype, "img") if img is not None else None,
                        int(img is not None and img.dtype == torch.float16), _dev(dot_out) if dot_out is not None else None, _stream(self._didx))
         return gtex
+
+    def render_bwd_det_part(self, sd, albedo, spp, seed, gimg, part, acc, scale_log2=0):
+        """ONE pass of the deterministic re-tracing adjoint (ffx_render_bwd_det_part): part 1 — the largest |tap| of this render into the int32
+        word `acc` (the float's bits; maximum over calls); part 2 — every tap as a 64-bit fixed-point integer at 2^scale_log2 into the int64
+        tensor `acc` [tex_h, tex_w, channels] (sum over calls).  The caller clears `acc`, reduces it over samples and ranks, and converts
+        (det_scale_log2, det_finish_): sums that come out bitwise equal whatever the order or the number of ranks."""
+        if _lane_kernels():
+            raise ValueError("the per-lane kernels (FFX_TRAVERSAL=lane) have no deterministic adjoint")
+        want = torch.int32 if part == 1 else torch.int64
+        if acc.dtype != want or not acc.is_contiguous() or (part == 2 and acc.numel() != sd.proj.tex_h * sd.proj.tex_w * sd.proj.tex_channels):
+            raise ValueError("render_bwd_det_part: acc must be one int32 word (part 1) / an int64 tensor of the texture's size (part 2)")
+        mats_arg = _check_materials(sd, albedo)
+        blob = self.blob
+        flags = self._apex_flag(apex_key(sd))
+        scratch = torch.empty(render_filter_bytes(sd), dtype=torch.uint8, device=self.device) if sd.rfilter else None
+        with self._timed("render_bwd"):
+            self._call("ffx_render_bwd_det_part", _dev(blob, torch.uint8), C.byref(self.info), C.byref(sd), mats_arg, int(spp), int(seed) & 0xFFFFFFFF, flags,
+                       _dev(gimg, name="gimg"), int(part), int(scale_log2), C.c_void_p(acc.data_ptr()), _dev(scratch, torch.uint8) if scratch is not None else None,
+                       _stream(self._didx))
+        self._release()
 
     def render_bwd(self, sd, albedo, spp, seed, gimg, deterministic=None):
         """the re-tracing adjoint.  deterministic (default: FFX_DETERMINISTIC=1 in the environment): ffx_render_bwd_det — bitwise

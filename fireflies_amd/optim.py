@@ -259,6 +259,47 @@ class PatternOptimizer:
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
         k_sample = 0
+        det = ops.deterministic_mode() and bool(sd0.proj.enabled)
+        if det:
+            # FFX_DETERMINISTIC=1 (round 6): a step whose result does not depend on the number of ranks, BIT FOR BIT.  Every sample's texture gradient
+            # is re-traced twice (ffx_render_bwd_det_part): first for the largest tap — maximum over this rank's samples, then over the ranks —, from
+            # which every rank derives the SAME power-of-two scale; then as 64-bit fixed-point sums into one buffer per rank, summed over the ranks
+            # as integers.  Integer sums are the same in any order and any grouping, the per-sample seeds do not depend on the world size
+            # (dist.sample_seed), and from the summed gradient on every rank runs the same launches on the same bits: pattern, Adam state and loss
+            # of a 1-, 2-, 4- or 8-rank run are equal.  (The float exchange of the default mode agrees to ~1e-7, not to the bit.)
+            vmax = torch.zeros(1, dtype=torch.int32, device=rd.device)
+            lossv = torch.zeros(max(S, 1), dtype=torch.float32, device=rd.device)  # one slot per sample of the STEP: each rank fills its own
+            mine = dist.sample_ids(S, r, w)
+            kept = []
+            for kg, seed, apply_sample in zip(mine, seeds, appliers):
+                apply_sample()
+                sd = ms.scene_desc(tex_channels=1)
+                mats = ms.materials_arg(sd)
+                img = geom.render_fwd(sd, mats, tex3, self.spp, seed, False)
+                if fast_loss is not None:
+                    gimg = fast_loss(img, lossv[kg])
+                else:
+                    with torch.enable_grad():
+                        l, gimg = self._loss_and_grad(img)
+                    lossv[kg] += l
+                    gimg = gimg.float().contiguous()
+                geom.render_bwd_det_part(sd, mats, self.spp, seed, gimg, 1, vmax)
+                kept.append((seed, apply_sample, gimg))
+                self.step_paths["retrace"] += 1
+            dist.allreduce_max_(vmax)
+            dist.allreduce_sum_(lossv)  # (x + 0 is x: the slots arrive as their owners wrote them)
+            sh = ops.det_scale_log2(int(vmax.item()), 4 * cam.width * cam.height * self.spp * max(S, 1))
+            fix = torch.zeros(tex3.shape, dtype=torch.int64, device=rd.device)
+            if sh is not None:
+                for seed, apply_sample, gimg in kept:
+                    apply_sample()  # (the pose again: the second re-trace of this sample)
+                    sd = ms.scene_desc(tex_channels=1)
+                    geom.render_bwd_det_part(sd, ms.materials_arg(sd), self.spp, seed, gimg, 2, fix, scale_log2=sh)
+            dist.allreduce_sum_(fix)
+            if sh is not None:
+                ops.det_finish_(fix, sh, gtex)
+            loss_sum += lossv.double().sum().float()  # (the same S floats in the same order on every rank, whatever the world size)
+            seeds_run, seeds = seeds, []  # (the sample loop below has nothing left to do)
         for seed, apply_sample in zip(seeds, appliers):
             apply_sample()  # host 4x4 algebra + K5/K6 on the side stream
             sd = ms.scene_desc(tex_channels=1)
@@ -310,7 +351,9 @@ class PatternOptimizer:
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
         # K3^T is applied inside the gradient launch, over the points' footprints only (ffx_pattern_bwd_blur: the gradient of the separate
         # transpose blur + ffx_pattern_bwd, bit for bit)
-        g2 = gtex.reshape(tex.shape) if seeds else None
+        if det:
+            seeds = seeds_run
+        g2 = gtex.reshape(tex.shape) if (seeds or det) else None
         bk, bs = (self.blur[0], self.blur[1]) if self.blur else (0, 1.0)
         reg_w = self.reg_weight if want_reg else 0.0
         st, g = self._adam_state(rays)
@@ -324,7 +367,7 @@ class PatternOptimizer:
             if getattr(self, "_dot_part", None) is None or self._dot_part.numel() < rd.shape[0]:
                 self._dot_part = torch.empty(rd.shape[0], dtype=torch.float32, device=rd.device)
             dot = (self._img_stack, self._lin_g, self._dot_part)  # <gimg, img_k> summed over the step's renders (gimg repeated)
-        if w > 1 or dist.exchanging():
+        if (w > 1 or dist.exchanging()) and not det:  # (det: the texture gradient has been exchanged — as integers; every rank holds the step's sum)
             # (several ranks: this rank's data term from the gradient launch — Adam arguments without state: no update —, then the exchange)
             aa = ops.adam_args(rd, None, None, None, self._adam_counter, 0.0, 0.0, 0.0, 0.0, self.laser._KF_inv, 0.0, 1.0, dot=dot) if dot is not None else None
             gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,

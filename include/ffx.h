@@ -67,7 +67,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 8
+#define FFX_ABI_VERSION 9
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -637,6 +637,21 @@ int ffx_render_bwd_det(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[ho
                        const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed, int flags /* FFX_RENDER_APEX_READY or 0 */,
                        const float *gimg /*[dev][H,W,3] fp32*/, float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, void *workspace /*[dev]*/,
                        ffx_stream stream);
+
+/* The two passes of the deterministic accumulation on their own (ABI 9), for sums that run over SEVERAL calls — the scene samples of an optimisation
+ * step, the ranks of a multi-GPU step (the reference has no such exchange; fireflies/graphics/rasterization.py:583-607 is its serial
+ * loop): integer sums are the same whatever the order and the grouping, so a step's texture gradient — and with it the pattern, the Adam state,
+ * the whole run — comes out BITWISE equal on 1, 2, 4 or 8 ranks.  part 1: the largest |tap| of this render into *acc (one uint32 word, the
+ * float's bits, atomicMax: clear it once, call per sample, MAX-reduce the word over the ranks).  ffx_det_scale_log2(bits, taps) -> the power of
+ * two for `taps` = 4 x pixels x spp x ALL samples of all ranks (INT_MIN: nothing lit, or a non-finite tap).  part 2: acc = int64 [tex_h x tex_w x
+ * channels], every tap added as llrint(value x 2^scale_log2) (clear once, call per sample, SUM-reduce over the ranks as integers).
+ * ffx_det_finish: gtex[t] += (float)(acc[t] x 2^-scale_log2).  workspace: the filtered film's scratch (ffx_render_filter_bytes(sd)) or NULL. */
+int ffx_render_bwd_det_part(const void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, const ffx_scene_desc *sd /*[host]*/,
+                            const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, int spp, uint32_t seed, int flags /* FFX_RENDER_APEX_READY or 0 */,
+                            const float *gimg /*[dev][H,W,3] fp32*/, int part /* 1 | 2 */, int scale_log2 /* part 2 */, void *acc /*[dev]*/,
+                            void *workspace /*[dev] or NULL*/, ffx_stream stream);
+int ffx_det_scale_log2(uint32_t vmax_bits, uint64_t n_taps); /* host arithmetic only */
+int ffx_det_finish(const void *acc /*[dev] int64 [n]*/, int scale_log2, size_t n, float *gtex /*[dev][n], accumulated into*/, ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8 + K9 with an adjoint cache (store instead of re-trace).

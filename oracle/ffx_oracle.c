@@ -20,6 +20,7 @@
  */
 #include "../include/ffx.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1753,11 +1754,12 @@ static sample_terms *bwd_trace_block(const shade_ctx *c, const onode *nodes, con
   return tab;
 }
 
-int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
-                   const float *gimg, float *gtex, ffx_stream s) {
-  (void)s; (void)flags; /* FFX_RENDER_APEX_READY ignored: the apex vectors are formed per test */
+/* part 0: the adjoint as specified (double sums, serial, added to gtex); part 1 / 2: the passes of ffx_render_bwd_det_part on the same taps —
+ * the largest |tap| into *(uint32_t *)accp (the float's bits), every tap as llrint(value x 2^sh) into (int64_t *)accp */
+static int render_bwd_box(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed,
+                          const float *gimg, float *gtex, int part, int sh, void *accp) {
   if (sd && sd->n_mat_h > 0) shape_albedo = sd->mat_h;
-  if (!bvh || !info || !sd || !shape_albedo || !gimg || !gtex || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
+  if (!bvh || !info || !sd || !shape_albedo || !gimg || (!gtex && part == 0) || spp < 1) FAIL(FFX_ERR_ARG, "render_bwd: bad argument");
   if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
   if (!sd->proj.enabled) return FFX_OK;
   shade_ctx c;
@@ -1791,15 +1793,32 @@ int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
             else wsum += (g[0] * c.p_color[0] + g[1] * c.p_color[1] + g[2] * c.p_color[2]) * stp->proj_fac_b * inv_spp;
           }
           for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b) acc[((size_t)stp->iy[a] * c.tw + stp->ix[b]) * c.tc + tch] += (double)(wsum * stp->wy[a] * stp->wx[b]);
+            for (int b = 0; b < 2; ++b) {
+              const float v = wsum * stp->wy[a] * stp->wx[b];
+              const size_t t = ((size_t)stp->iy[a] * c.tw + stp->ix[b]) * c.tc + tch;
+              if (part == 0) acc[t] += (double)v;
+              else if (v != 0.f) {
+                if (part == 1) {
+                  const float av = fabsf(v);
+                  uint32_t bits;
+                  memcpy(&bits, &av, 4);
+                  if (bits > *(uint32_t *)accp) *(uint32_t *)accp = bits;
+                } else ((int64_t *)accp)[t] += (int64_t)llrint((double)v * ldexp(1.0, sh));
+              }
+            }
         }
       }
     }
   }
-  for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
+  if (part == 0) for (size_t t = 0; t < nt_; ++t) gtex[t] += (float)acc[t];
   free(acc);
   free(tab);
   return FFX_OK;
+}
+int ffx_render_bwd(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
+                   const float *gimg, float *gtex, ffx_stream s) {
+  (void)s; (void)flags; /* FFX_RENDER_APEX_READY ignored: the apex vectors are formed per test */
+  return render_bwd_box(bvh, info, sd, shape_albedo, spp, seed, gimg, gtex, 0, 0, NULL);
 }
 
 /* =========================================================================================
@@ -2140,6 +2159,34 @@ int ffx_render_bwd_det(const void *bvh, const ffx_bvh_info *info, const ffx_scen
   if (!workspace || !sd) FAIL(FFX_ERR_ARG, "render_bwd_det: bad argument");
   if (sd->rfilter != FFX_RFILTER_BOX) return ffx_render_bwd_filtered(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, workspace, s);
   return ffx_render_bwd(bvh, info, sd, shape_albedo, spp, seed, flags, gimg, gtex, s);
+}
+
+/* the two passes on their own (ABI 9, include/ffx.h): the box film's taps as the adjoint above forms them.  (The filtered film: not restated here —
+ * the HIP library's passes for it are checked against its own one-call form.) */
+int ffx_render_bwd_det_part(const void *bvh, const ffx_bvh_info *info, const ffx_scene_desc *sd, const float *shape_albedo, int spp, uint32_t seed, int flags,
+                            const float *gimg, int part, int scale_log2, void *acc, void *workspace, ffx_stream s) {
+  (void)flags; (void)workspace; (void)s;
+  if (!sd || !acc || (part != 1 && part != 2) || scale_log2 < -126 || scale_log2 > 126) FAIL(FFX_ERR_ARG, "render_bwd_det_part: bad argument");
+  if (sd->rfilter != FFX_RFILTER_BOX) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_det_part: the oracle restates the box film's passes only");
+  if (!sd->proj.enabled) return FFX_OK;
+  return render_bwd_box(bvh, info, sd, shape_albedo, spp, seed, gimg, NULL, part, scale_log2, acc);
+}
+int ffx_det_scale_log2(uint32_t vmax_bits, uint64_t n_taps) {
+  float vmax;
+  memcpy(&vmax, &vmax_bits, 4);
+  if (!(vmax > 0.f) || !(vmax < 3.0e38f)) return INT_MIN;
+  int e, b = 0;
+  frexpf(vmax, &e);
+  for (uint64_t ns = n_taps > 0 ? n_taps : 1; ns > 0; ns >>= 1) ++b;
+  const int sh = 62 - b - e;
+  return sh > 126 ? 126 : (sh < -126 ? -126 : sh);
+}
+int ffx_det_finish(const void *acc, int scale_log2, size_t n, float *gtex, ffx_stream s) {
+  (void)s;
+  if (!acc || !gtex || n == 0 || scale_log2 < -126 || scale_log2 > 126) FAIL(FFX_ERR_ARG, "det_finish: bad argument");
+  const float inv = ldexpf(1.0f, -scale_log2);
+  for (size_t t = 0; t < n; ++t) gtex[t] += (float)((double)((const int64_t *)acc)[t] * (double)inv);
+  return FFX_OK;
 }
 
 /* =========================================================================================

@@ -1,7 +1,7 @@
 """worker of tests/test_api_gpu.py::test_two_rank_rccl_step_matches_one_rank (and of the one-rank nccl / poisoned-update tests) — launched by
 torch.distributed.run (or directly, with RANK / WORLD_SIZE in the environment), one process per GPU; writes its result to <outdir>/rank<r>.json.
 
-    _rccl_worker.py <outdir> [nccl|gloo] [samples per step] [coverage|l1]
+    _rccl_worker.py <outdir> [nccl|gloo] [samples per step] [coverage|l1] [steps]
 """
 import json
 import os
@@ -47,19 +47,21 @@ def main():
             return r
 
         ops.pattern_fwd_blur = planted
-    res = opt.step()
+    for _ in range(int(sys.argv[5]) if len(sys.argv) > 5 else 1):
+        res = opt.step()
     import torch.distributed as td
 
     st = opt.opt.state[wl.laser._rays]
     flat = getattr(opt, "_last_flat", None)
     with open(os.path.join(out, f"rank{rank}.json"), "w") as f:
-        json.dump({"world": td.get_world_size(), "backend": td.get_backend(), "device": dev, "grad": wl.laser._rays.grad.detach().cpu().tolist(),
+        json.dump({"world": dist.world_size(), "backend": td.get_backend() if td.is_initialized() else "none", "device": dev, "grad": wl.laser._rays.grad.detach().cpu().tolist(),
                    "loss": float(res["loss"]), "rays": wl.laser._rays.detach().cpu().tolist(), "rays_before": rays_before,
                    "exchanged": flat is not None, "flat_len": int(flat.numel()) if flat is not None else 0,
                    "exchanged_dropped": float(flat[-1]) if flat is not None else None,
                    "adam_step": float(st["step"]) if len(st) else 0.0, "exp_avg_max": float(st["exp_avg"].abs().max()) if len(st) else 0.0}, f)
     dist.barrier()
-    td.destroy_process_group()
+    if td.is_initialized():  # (one rank without FFX_DIST_FORCE: no group was formed)
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":
