@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (k == 0 && a == 0 && ba.cache_hdr) { // adjoint cache: stray arena empty (top bit of cap_stray: keep the `dropped` count, ffx_common.h)
       ba.cache_hdr[0] = 0u; ba.cache_hdr[1] = ba.cap_stray & ~FFX_CAP_KEEP_DROPPED;
       if (!(ba.cap_stray & FFX_CAP_KEEP_DROPPED)) ba.cache_hdr[2] = 0u;
+      for (int i = 4; i < 12; ++i) ba.cache_hdr[i] = 0u; // (the filtered film's cache: its arena's eight counters, CacheHdr.pad[1..8])
     }
     if (k < n_tris && ba.out && ba.on[a]) { // the triangle as seen from apex a (ffx_common.h TriApex; the oracle's operation order)
       const v3 v0 = V3(ra.x, ra.y, ra.z), e1 = V3(ra.w, rb.x, rb.y), e2 = V3(rb.z, rb.w, rc.x);

@@ -2629,10 +2629,12 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 // {(ubx + 1) | (uby + 1) << 12 | shape << 24, ax, ay, fac} (+ fac_b in a second array with material rows) — one coalesced 1 KB store per
 // wave and lit pass.  Round 6: the records live in an ARENA of 64-sample blocks (rounds 4-5: a dense [pixel][sample] array, 20 B x pixels x
 // spp of address space — 5.4 GB at 1024 x 1024 x 256 — for the ~4 % of the pixels that hold a lit sample): the first lit pass of a pixel
-// takes one block for itself and for every later pass with ONE atomic of its wave, the pixel's header holds the first block and that pass;
+// takes one block for itself and for every later pass with ONE atomic of its wave (on one of eight counters — sub-arenas —, neighbouring
+// pixels on different ones; an arena with a block for every pass of every pixel hands each pixel its own, without atomics), the pixel's
+// header holds the first block and that pass;
 // capacity = rfc_cap_blocks; a pixel that finds the arena full is counted in `dropped` (sticky, as the
 // box film's arena: ffx_render_cache_status, the NaN poison of the adjoint, ffx_adam_args.guard) and keeps no records.
-//   [0, 64)                CacheHdr {blocks taken (may exceed the capacity), capacity, dropped pixels}
+//   [0, 64)                CacheHdr {-, capacity, dropped pixels, -, blocks taken from each of the eight sub-arenas (may exceed their share)}
 //   64 + 8 * pixel         CachePix {x0 | y0 << 16 = first block, shape = first lit pass, lit = bit mask of the passes that hold records}
 //   rfc_off_wsum           float per pixel
 //   rfc_off_recs           uint4 per sample slot of the arena's blocks
@@ -2956,17 +2958,28 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
         const bool lit = active[0] && st[0].hit && st[0].has_proj;
         if (wballot(lit) != 0ull && !rfc_drop) {
           char *rfc = reinterpret_cast<char *>(adj_gtex);
-          if (rfc_first_pass < 0) { // the pixel's first lit pass: blocks for it and for every pass behind it, one atomic of the wave
+          if (rfc_first_pass < 0) { // the pixel's first lit pass: blocks for it and for every pass behind it
             const uint32_t want = (uint32_t)(passes - pass);
-            uint32_t b0 = 0u;
-            if (lane == 0) b0 = atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->n_stray, want);
-            b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-            if (b0 + want > cap_stray) {
-              rfc_drop = true; // (arena full: this pixel keeps no records — counted, the adjoint is poisoned, the caller re-traces)
-              if (lane == 0) atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->dropped, 1u);
-            } else {
-              rfc_first = b0;
+            if (cap_stray >= (uint32_t)W * (uint32_t)H * (uint32_t)passes) {
+              // the arena holds a block for every pass of every pixel (up to 2^18 blocks: 512 x 512 x 64 spp): the pixel's own — nothing to take,
+              // nothing that can run out
+              rfc_first = pix[0] * (uint32_t)passes + (uint32_t)pass;
               rfc_first_pass = pass;
+            } else {
+              // one atomic of the wave — on ONE of eight counters, picked so that neighbouring pixels take different ones: the lit pixels of a
+              // laser dot are rendered together, and same-address atomics from eight XCDs serialise at ~90 ns each (one counter: 178 k of them
+              // on configs[4], twice the kernel's own time; at 512 x 512 x 64 the filtered gradient step lost 8 %)
+              const uint32_t sub = ((uint32_t)px[0] + 3u * (uint32_t)py[0]) & 7u, sub_cap = cap_stray >> 3;
+              uint32_t b0 = 0u;
+              if (lane == 0) b0 = atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->pad[1 + sub], want);
+              b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+              if (b0 + want > sub_cap) {
+                rfc_drop = true; // (sub-arena full: this pixel keeps no records — counted, the adjoint is poisoned, the caller re-traces)
+                if (lane == 0) atomicAdd(&reinterpret_cast<CacheHdr *>(rfc)->dropped, 1u);
+              } else {
+                rfc_first = sub * sub_cap + b0;
+                rfc_first_pass = pass;
+              }
             }
           }
         }
@@ -4109,6 +4122,7 @@ __global__ void __launch_bounds__(256)
   if (k == 0 && cache_hdr) { // adjoint cache: stray arena empty (CacheHdr)
     cache_hdr[0] = 0u; cache_hdr[1] = cap_stray & ~FFX_CAP_KEEP_DROPPED;
     if (!(cap_stray & FFX_CAP_KEEP_DROPPED)) cache_hdr[2] = 0u;
+    for (int i = 4; i < 12; ++i) cache_hdr[i] = 0u; // (the filtered film's cache: its arena's eight counters)
   }
   if (k >= n_tris) return;
   const float4 *r4 = reinterpret_cast<const float4 *>(recs + k);
@@ -4336,6 +4350,7 @@ static void bins_k(const void *bvh, const ffx_bvh_info *info, const ffx_scene_de
 __global__ void k_cache_reset(uint32_t *__restrict__ cache_hdr, uint32_t cap_stray) {
   cache_hdr[0] = 0u; cache_hdr[1] = cap_stray & ~FFX_CAP_KEEP_DROPPED;
   if (!(cap_stray & FFX_CAP_KEEP_DROPPED)) cache_hdr[2] = 0u;
+  for (int i = 4; i < 12; ++i) cache_hdr[i] = 0u; // (the filtered film's cache: its arena's eight counters)
 }
 // flags: FFX_RENDER_APEX_READY — the areas already hold this call's apexes (ffx_apex_prepare, or an earlier call with the same
 // origins on records that have not changed since): no launch; FFX_RENDER_CACHE_ZEROED — the caller has cleared the cache header.
@@ -4727,6 +4742,7 @@ int ffx_render_cache_status(const void *cache, uint32_t *out3, ffx_stream s) {
   if (hipMemcpyAsync(&h, cache, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess || hipStreamSynchronize((hipStream_t)s) != hipSuccess)
     FFX_FAIL(FFX_ERR_LAUNCH, "render_cache_status: reading the cache header failed");
   out3[0] = h.n_stray; out3[1] = h.cap_stray; out3[2] = h.dropped;
+  for (int i = 1; i <= 8; ++i) out3[0] += h.pad[i]; // (a filtered film's cache counts its blocks in eight sub-arenas; zero in a box film's)
   return FFX_OK;
 }
 

@@ -825,7 +825,8 @@ int ffx_render_bwd_filtered(const void *bvh /*[dev]*/, const ffx_bvh_info *info 
  * blocks — 344 MB at 512x512x64 with material rows, ~15 MB of it touched by a dot pattern's render with FFX_RENDER_SPARSE_ADJOINT; such a
  * cache cannot overflow — and a quarter of them beyond: 1.34 GB at 1024x1024x256 (rounds 4-5: 5.4 GB of address space; configs[4]'s own
  * 1 024-point pattern lights 17 % of that film).  A pixel that finds
- * the arena full keeps no records and is counted: ffx_render_cache_status reports {blocks taken, capacity, dropped pixels}, the adjoint
+ * the arena full keeps no records and is counted: ffx_render_cache_status reports {blocks taken from the arena's counters — 0 while it holds
+ * a block for every pass of every pixel: each pixel then has its own —, capacity, dropped pixels}, the adjoint
  * poisons gtex[0] with NaN when anything was dropped (re-trace with ffx_render_bwd_filtered then), ffx_adam_args.guard skips the update.  The
  * counters must be zero when the kernel starts: the call clears them in front of its launch (with FFX_RENDER_APEX_READY: one tiny launch)
  * unless told FFX_RENDER_CACHE_ZEROED; FFX_RENDER_CACHE_KEEP_DROPPED keeps the count of a step's earlier scene samples, as for the box film.

@@ -2044,8 +2044,8 @@ def test_gaussian_reconstruction_filter_forward_and_adjoint_match_the_oracle(ora
     cache = torch.full((nb,), 0xAB, dtype=torch.uint8, device="cuda")  # (garbage: every byte the adjoint reads is written by the forward)
     img_c = gd.render_fwd(sd, dev(alb), tex, spp, seed=11, cache=cache)
     assert torch.equal(img_c.cpu(), torch.from_numpy(img_d))
-    used, cap, dropped = ops.render_cache_status(cache)
-    assert dropped == 0 and cap == blocks and 0 < used <= cap and used % ((spp + 63) // 64) == 0  # (a lit pixel takes a block for every pass from its first lit one on)
+    # (an arena that holds a block for every pass of every pixel hands each pixel its own: nothing is taken from a counter, nothing can run out)
+    assert ops.render_cache_status(cache) == (0, blocks, 0)
     pose = gd._vert_off_host.copy()
     gd.update(_rand_xforms(2, 99))  # re-fit to another pose: the cached adjoint needs neither the tree nor the camera
     acc = torch.full((sd.proj.tex_h, sd.proj.tex_w, ch), 1.5, device="cuda")
