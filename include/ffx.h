@@ -540,8 +540,9 @@ typedef struct ffx_scene_desc {
   ffx_spot spot;
   int32_t shadows;    /* != 0: trace shadow rays toward both emitters.  Bit 1 (FFX_SHADOWS_PLAIN, round 6) is a HINT of the caller to the pre-pass
                          (ffx_apex_prepare / ffx_scene_step_h): the renders of this pose are short (fewer than ~33 samples per pixel) — the emitters'
-                         envelopes (DESIGN.md 5.1 "round 6"), which let most shadow packets skip their any-hit stage, are then not built: one launch
-                         less in the chain a short render waits for.  Images do not depend on it. */
+                         envelopes (DESIGN.md 5.1 "round 6"), which let most shadow packets skip their any-hit stage, are then not built, and the spot's
+                         tile grid is coarser (1.2 instead of 2 tiles per degree of cutoff): a shorter chain for a short render to wait for.
+                         Images do not depend on it. */
   int32_t n_shapes;   /* rows of shape_albedo */
   int32_t mat_stride; /* floats per row of shape_albedo: 0 or 3 = Lambert albedo only, FFX_MAT_STRIDE = material rows (below) */
   /* Texture-valued base colours (Mitsuba: `<mat>.brdf_0.base_color.data`, which the reference's dataset loop re-assigns every
