@@ -909,6 +909,11 @@ class Scene:
         # same map randomises other entities than the first: started from the template, its samples carried the spot intensity of the day the
         # template was built — found by the round-6 action fuzz) —, else the template
         base = self._sd_cache[1] if self._sd_cache is not None else tm[1]
+        if base.shadows != tm[1].shadows:  # (note_spp changed the regime since that description was made: the new sample carries the new word)
+            nb = _abi.SceneDesc()
+            C.memmove(C.addressof(nb), C.addressof(base), C.sizeof(nb))
+            nb.shadows = tm[1].shadows
+            base = nb
 
         def launch(i, stream, prepare):
             rc = sp.fn(sp.plan, values.ctypes.data, chain.ctypes.data, unc.ctypes.data, fr, base, sd, ptrs[2], ptrs[0], ptrs[1], sp.geoms[i], prepare, stream)
@@ -1009,13 +1014,17 @@ class Scene:
 
     def note_spp(self, spp):
         """called by whoever renders this scene with `spp` samples per pixel: below 33 the pre-pass of the NEXT poses leaves the emitters' envelopes
-        out (FFX_SHADOWS_PLAIN: a short render waits for the pre-pass chain, which the envelope launch lengthens; a long one hides it and runs
-        15 % faster with them).  A change of regime drops the finished descriptions — the first render after it prepares its own pose."""
+        out and bins the spot on a coarser grid (FFX_SHADOWS_PLAIN: a short render waits for the pre-pass chain; a long one hides it and runs
+        15 % faster with the envelopes).  Only poses pushed from now on are affected: the finished description of the current pose — the one its
+        pre-pass was run with — stays as it is, the templates take the new word (a loop that draws its sample count per render, main.py:145,
+        changes regime every few samples: nothing is rebuilt, a pose is merely prepared with the hint of the render before it)."""
         low = int(spp) < 33
         if low != self._low_spp:
             self._low_spp = low
-            self._sd_cache = None
-            self._sd_templates = {}
+            w = self._shadows_word()
+            for ch, (tkey, keep) in list(self._sd_templates.items()):
+                keep.shadows = w
+                self._sd_templates[ch] = ((w,) + tuple(tkey[1:]), keep)
 
     def _patch_sd(self, sd):
         """the per-step fields of a finished description from the parameter map as it is NOW: the three poses, the spot's intensity and cone"""
