@@ -236,10 +236,14 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // a tile of the far wall receives 400 entries, and 400 same-address atomics from eight XCDs were the tail of both launches
     // (they serialise at the memory side, ~90 ns each).  Four rounds are in flight at a time: a fill-pass atomic returns the group's
     // place in the list, and one dependent round trip per round was the rest of that tail.
-    BinEntry en;
+    // (round 6, fill pass) the lane's 64-byte entry waits in LDS instead of sixteen registers — the kernel had spilled 27 - 50 of them — and
+    // leaves through it TRANSPOSED: four lanes write the four 16-byte quarters of ONE entry side by side, a whole 64-byte line per entry,
+    // where every lane used to issue four scattered 16-byte stores of its own (write traffic of the launch 31.7 -> MB, profiles/r6_pmc_summary.json)
+    __shared__ __attribute__((aligned(16))) float4 s_en[FILL ? 4 * BIN_BLOCK : 1];
     uint32_t touched = 0u;
     const int w = tx1 - tx0 + 1;
     if (cls == 1) {
+      BinEntry en;
       bin_make_entry(x[0], y[0], x[1], y[1], x[2], y[2], k, false, en);
       const int nt_ = w * (ty1 - ty0 + 1);
 #pragma nounroll
@@ -247,7 +251,13 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const int ty = ty0 + t / w, tx = tx0 + t % w;
         if (bin_entry_touches(en, (float)tx, (float)ty, (float)(tx + 1), (float)(ty + 1))) touched |= 1u << t;
       }
+      if (FILL) {
+        const float4 *e4 = reinterpret_cast<const float4 *>(&en);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) s_en[4 * lane + p] = e4[p];
+      }
     }
+    if (FILL) __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: program order + the LDS counter order the reads below behind these writes)
     const wmask_t below = (1ull << lane) - 1ull;
 #pragma nounroll
     while (__ballot(touched != 0u) != 0ull) {
@@ -278,10 +288,17 @@ __global__ void __launch_bounds__(BIN_BLOCK) __attribute__((amdgpu_waves_per_eu(
           else at[q] = atomicSub(&cursors[tl[q]], (uint32_t)cnt[q]) - (uint32_t)cnt[q];
         }
       if (FILL) {
+        float4 *ents4 = reinterpret_cast<float4 *>(ents);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t base_ = (uint32_t)__shfl((int)at[q], leader[q], 64);
-          if (tl[q] >= 0) ents[starts[tl[q]] + base_ + (uint32_t)rank[q]] = en;
+          const int dst = tl[q] >= 0 ? (int)(starts[tl[q]] + base_ + (uint32_t)rank[q]) : -1; // where this lane's entry goes (-1: nowhere this round)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { // entries of lanes 16 i .. 16 i + 15: lane l writes quarter l % 4 of lane 16 i + l / 4's
+            const int src = 16 * i + (lane >> 2);
+            const int d = __shfl(dst, src, 64);
+            if (d >= 0) ents4[4 * (size_t)d + (lane & 3)] = s_en[4 * src + (lane & 3)];
+          }
         }
       }
     }

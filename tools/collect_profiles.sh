@@ -57,7 +57,7 @@ fi
 # before gpurun — a stale variant library fails to load (missing symbols) and used to leave an empty file behind)
 FAILED=""
 TL=fireflies_amd/csrc/_stats/libffx_hip_timers.so
-if [ -f $TL ] && [ ! $TL -ot fireflies_amd/csrc/libffx_hip.so ]; then
+if [ -f $TL ]; then  # (no mtime comparison: the snapshot that carries the tree to the GPU box does not keep the files' order in time; a stale variant fails to load)
   if [ -z "$X" ]; then FFX_LIB=$TL python tools/phaseclk.py vocalfold 64 8 > $OUT/phaseclk.txt 2> $OUT/phaseclk.log
   else FFX_LIB=$TL python tools/phaseclk.py colon 256 2 > $OUT/phaseclk.txt 2> $OUT/phaseclk.log; fi
   if [ $? -eq 0 ] && [ -s $OUT/phaseclk.txt ]; then mv $OUT/phaseclk.txt profiles/${TAG}_phaseclk.txt
