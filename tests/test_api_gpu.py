@@ -1362,6 +1362,40 @@ def test_native_update_sees_a_fixed_camera_moved_between_samples():
     assert not torch.equal(mi.render(b.mi_scene, spp=4, seed=3).torch(), img0)
 
 
+def test_short_render_hint_follows_the_sample_count_and_never_changes_an_image(monkeypatch):
+    """Round 6: `mi.render(scene, spp)` tells the scene how long its renders are (`Scene.note_spp`); poses pushed AFTER a render below 33 samples
+    per pixel carry `ffx_scene_desc.shadows = 3` (FFX_SHADOWS_PLAIN: no envelope launch, a coarser spot grid — a short render waits for the
+    pre-pass chain), poses pushed after a long one carry 1 again; the pose that is current when the regime changes keeps the description its
+    pre-pass ran with, and nothing is rebuilt (the native push keeps going).  Whatever the hint, every image is the one a scene without
+    envelopes renders (FFX_ENVELOPE=0), bit for bit."""
+    seq = [64, 64, 8, 8, 16, 64, 40, 4, 64]
+
+    def run(env):
+        if env is None:
+            monkeypatch.delenv("FFX_ENVELOPE", raising=False)
+        else:
+            monkeypatch.setenv("FFX_ENVELOPE", env)
+        wl = _small()
+        with torch.no_grad():
+            wl.params["tex.data"] = workloads.build_texture(wl).contiguous()
+        imgs, words = [], []
+        for i, spp in enumerate(seq):
+            torch.manual_seed(600 + i)
+            random.seed(600 + i)
+            wl.ff_scene.randomize()
+            words.append(int(wl.mi_scene.scene_desc(tex_channels=1).shadows))
+            imgs.append(mi.render(wl.mi_scene, spp=spp, seed=i).torch().clone())
+        return wl, imgs, words
+
+    wl, imgs, words = run(None)
+    want = [1] + [3 if s < 33 else 1 for s in seq[:-1]]  # a pose is prepared with the hint of the render before it
+    assert words == want, (words, want)
+    assert wl.mi_scene.update_paths["native"] >= len(seq) - 3, (wl.mi_scene.update_paths, wl.mi_scene.update_fallbacks)
+    _, ref, _ = run("0")
+    for i, (a, b) in enumerate(zip(imgs, ref)):
+        assert torch.equal(a, b) and float(a.sum()) > 0, f"render {i} ({seq[i]} spp)"
+
+
 def test_lazy_native_update_under_random_action_sequences():
     """Round-5 review, item 8: the lazy native update (a natively pushed sample is told to the entities and the parameter map only when somebody
     looks) against the key-by-key path over SEEDED RANDOM action sequences — randomise, batches, reads and writes of parameters (per-step keys,
