@@ -46,7 +46,6 @@ def main():
                 tiles.setdefault((ty, tx), []).append(j)
     clear = np.ones(F, bool)
     npairs = 0
-    reasons = np.zeros(3, int)
     for (ty, tx), lst in tiles.items():
         idx = np.asarray(lst)
         n = idx.size

@@ -60,18 +60,17 @@ def main():
     wl.mi_scene._sd_cache = None
     st = stats48()
     if st is not None:
-        for cache_like in (False,):
-            mi.render(wl.mi_scene, spp=spp, seed=1).torch()
-            torch.cuda.synchronize()
-            stats48()
-            mi.render(wl.mi_scene, spp=spp, seed=1).torch()
-            torch.cuda.synchronize()
-            st = stats48()
-            # 40: any-hit walks served by the bins' exact stage; 37 / 47: projector / spot packets the envelope settled; 44 / 45: fall-backs to the tree
-            print(f"shadow packets: envelope settled projector {st[37]}, spot {st[47]}; exact any-hit stages {st[40]} (chunk steps {st[41] / max(st[40], 1):.2f}, "
-                  f"candidates {st[42] / max(st[40], 1):.2f}); tree fall-backs projector {st[44]}, spot {st[45]}")
-            tot = st[37] + st[47] + st[40] + st[44] + st[45]
-            print(f"share of shadow packets settled by the envelope: {(st[37] + st[47]) / max(tot, 1):.3f}")
+        mi.render(wl.mi_scene, spp=spp, seed=1).torch()
+        torch.cuda.synchronize()
+        stats48()
+        mi.render(wl.mi_scene, spp=spp, seed=1).torch()
+        torch.cuda.synchronize()
+        st = stats48()
+        # 40: any-hit walks served by the bins' exact stage; 37 / 47: projector / spot packets the envelope settled; 44 / 45: fall-backs to the tree
+        print(f"shadow packets: envelope settled projector {st[37]}, spot {st[47]}; exact any-hit stages {st[40]} (chunk steps {st[41] / max(st[40], 1):.2f}, "
+              f"candidates {st[42] / max(st[40], 1):.2f}); tree fall-backs projector {st[44]}, spot {st[45]}")
+        tot = st[37] + st[47] + st[40] + st[44] + st[45]
+        print(f"share of shadow packets settled by the envelope: {(st[37] + st[47]) / max(tot, 1):.3f}")
 
 
 if __name__ == "__main__":
