@@ -1450,7 +1450,7 @@ def test_lazy_native_update_under_random_action_sequences():
             t = smp[r % len(smp)].get_max()
             t.mul_(1.0 + 0.01 * ((r % 5) - 2))
         elif kind == 10:  # a render (asks the parameter map nothing)
-            mi.render(wl.mi_scene, spp=1 + (r % 3), seed=r).torch()
+            mi.render(wl.mi_scene, spp=(1, 2, 3, 40, 70)[r % 5], seed=r).torch()  # (short and long renders: the scene's short-render hint changes sides, Scene.note_spp)
         elif kind == 11:  # a second Scene object over the same parameter map pushes a sample of its own
             s2 = second.get(id(wl))
             if s2 is None:
