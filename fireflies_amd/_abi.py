@@ -7,7 +7,9 @@ shared library (oracle/oracle.py) — both libraries implement the same header.
 import ctypes as C
 
 FFX_MAX_LEVELS = 96
-FFX_ABI_VERSION = 9
+FFX_ABI_VERSION = 10
+PATTERN_SYNC_BYTES = 35840  # FFX_PATTERN_SYNC_BYTES
+FFX_ERR_UNSUPPORTED = -3
 REDUCE_SUM = 0
 REDUCE_SOFTOR = 1
 
@@ -199,6 +201,10 @@ PROTOTYPES = {
     "ffx_pattern_bwd": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p]),
     "ffx_pattern_fwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_long, c_i, c_f, c_p, c_p]),
     "ffx_pattern_bwd_blur": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_f, c_p, C.POINTER(AdamArgs), c_p]),
+    # rays, n, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight, ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, ksize, blur_sigma, adam,
+    # pts, zero, n_zero, tex, rays_kept, check_kept, sync, epoch, stream
+    "ffx_pattern_step": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_f, C.POINTER(AdamArgs),
+                               c_p, c_p, C.c_long, c_p, c_p, c_i, c_p, C.c_uint32, c_p]),
     "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
@@ -281,3 +287,10 @@ class Api:
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(*args), name)
+
+    def call_rc(self, name, *args, allow=()):
+        """like call, but the return codes in `allow` are handed back instead of raised (an entry point that may decline a shape)"""
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0 and rc not in allow:
+            self.check(rc, name)
+        return rc

@@ -562,12 +562,13 @@ __device__ __forceinline__ float blur_bwd_texel(const float *__restrict__ win, i
 
 // Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the step count t kept
 // on the device) followed by Laser.clamp_to_fov + normalize_rays on the updated ray i
-__device__ __forceinline__ void adam_clamp_one(int i, float t, float *__restrict__ rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
+// (pw1, pw2: beta1^t, beta2^t)
+__device__ __forceinline__ void adam_clamp_one(int i, float t, double pw1, double pw2, float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
                                                float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
                                                const float *K, const float *I, float lo, float hi, int n_norm) {
   // the scalars as torch forms them: in double from the Python floats, rounded to float where they meet the tensors
   const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
-  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  const double bc1 = 1.0 - pw1, bc2 = 1.0 - pw2;
   const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
   float r[3];
 #pragma unroll
@@ -606,6 +607,12 @@ __device__ __forceinline__ void adam_clamp_one(int i, float t, float *__restrict
   rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
 }
 
+__device__ __forceinline__ void adam_clamp_one(int i, float t, float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
+                                               float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
+                                               const float *K, const float *I, float lo, float hi, int n_norm) {
+  adam_clamp_one(i, t, pow(beta1, (double)t), pow(beta2, (double)t), rays, grad, grad_b, scale_a, grad_out, m, v, lr, beta1, beta2, eps_d, K, I, lo, hi, n_norm);
+}
+
 // =================================================================================== fused pattern side of an optimisation step
 // The pattern has 64..1024 points and the texture 500^2 texels: every kernel of the pattern side is launch-bound,
 // and as separate entry points one gradient step issued ~30 of them (~0.11 ms next to a 0.75 ms render).  Three
@@ -613,7 +620,7 @@ __device__ __forceinline__ void adam_clamp_one(int i, float t, float *__restrict
 //   k_pattern_fwd   K1 + K2(sum) + K2(softor) (+ the partial sums of the overlap regulariser L1(softor, sum))
 //   k_pattern_bwd   K2-bwd of the data term, of the regulariser's softor and sum terms, and K1-bwd of both
 //   k_adam_clamp    Adam + Laser.clamp_to_fov + normalize_rays
-__device__ __forceinline__ void project_xy(const float *__restrict__ rays, int k, const float *K, float &p0, float &p1) {
+__device__ __forceinline__ void project_xy(const float *rays, int k, const float *K, float &p0, float &p1) {
   const float x = rays[3 * k], y = rays[3 * k + 1], z = rays[3 * k + 2];
   const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
   const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
@@ -701,11 +708,12 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // there.  Every value is formed as the separate launches form it (same candidate order per texel: points that cannot reach a
 // texel add an exact 0; same thread-to-texel mapping for the regulariser's partial sums and for the blur), so tsum, tsor, ws
 // and tex are bitwise those of ffx_pattern_fwd + ffx_blur_fwd; one launch (~5 us on the critical path of a step) less.
+// (the tile (bx, by) of a grid nbx tiles wide: the body of k_pattern_fwd_blur, shared with k_pattern_step — `rays` carries no __restrict__: in
+// k_pattern_step the same launch has written it)
 template <int R>
-__global__ void __launch_bounds__(SPLAT_BLOCK)
-    k_pattern_fwd_blur(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, int want_softor, float *__restrict__ pts,
-                       float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws, float *__restrict__ zero, long n_zero, BlurW bw,
-                       float *__restrict__ tex) {
+__device__ __forceinline__ void pattern_fwd_blur_tile(int bx, int by, int nbx, const float *rays, int n, const Mat4 &KF, float sigma, int size0, int size1, int want_softor,
+                                                      float *__restrict__ pts, float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws, const BlurW &bw,
+                                                      float *__restrict__ tex) {
   constexpr int HW = TILE_W + 2 * R, HH = TILE_H + 2 * R, NT = (HW * HH + SPLAT_BLOCK - 1) / SPLAT_BLOCK;
   __shared__ float c_p0[CAND_MAX], c_p1[CAND_MAX];
   __shared__ int c_count;
@@ -713,13 +721,9 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   __shared__ float s_t[HW * HH];                 // tsum over the haloed tile (the blur's input tile)
   __shared__ float s_o[TILE_W * TILE_H];         // tsor of the tile itself
   const int tid = threadIdx.x;
-  if (zero) {
-    const long stride = (long)gridDim.x * gridDim.y * SPLAT_BLOCK;
-    for (long t = ((long)blockIdx.y * gridDim.x + blockIdx.x) * SPLAT_BLOCK + tid; t < n_zero; t += stride) zero[t] = 0.f;
-  }
-  const int j0 = blockIdx.x * TILE_W, i0 = blockIdx.y * TILE_H;
+  const int j0 = bx * TILE_W, i0 = by * TILE_H;
   const float inv_sigma = 1.0f / sigma;
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  const bool first = bx == 0 && by == 0;
   // the texels of this thread: haloed-tile elements tid, tid + 256, ... at their reflected image positions
   float fj[NT], fi[NT], acc_s[NT], acc_p[NT];
 #pragma unroll
@@ -807,8 +811,19 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     for (int o = 32; o >= 1; o >>= 1) l1 += __shfl_down(l1, o, 64);
     if ((tid & 63) == 0) s_part[tid >> 6] = l1;
     __syncthreads();
-    if (tid == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (tid == 0) ws[by * nbx + bx] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
+}
+template <int R>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_fwd_blur(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, int want_softor, float *__restrict__ pts,
+                       float *__restrict__ tsum, float *__restrict__ tsor, float *__restrict__ ws, float *__restrict__ zero, long n_zero, BlurW bw,
+                       float *__restrict__ tex) {
+  if (zero) {
+    const long stride = (long)gridDim.x * gridDim.y * SPLAT_BLOCK;
+    for (long t = ((long)blockIdx.y * gridDim.x + blockIdx.x) * SPLAT_BLOCK + threadIdx.x; t < n_zero; t += stride) zero[t] = 0.f;
+  }
+  pattern_fwd_blur_tile<R>(blockIdx.x, blockIdx.y, gridDim.x, rays, n, KF, sigma, size0, size1, want_softor, pts, tsum, tsor, ws, bw, tex);
 }
 
 // one workgroup per point over its non-zero footprint, like k_splat_bwd.  Data term: upstream gts on the SUM
@@ -821,17 +836,17 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
 // and `adam` (if it names rays): the workgroup that finishes last applies ffx_adam_clamp_step's update to every point.
 struct AdamK { float *rays, *m, *v, *step, *grad_out; unsigned int *counter; double lr, beta1, beta2, eps; Mat4 KI; float lo, hi, grad_div; int n_norm;
                const float *dot_a, *dot_b; long dot_n; float *dot_partial; long dot_b_n; int no_update; const unsigned int *guard; };
+// (point k of n: the gradient part of k_pattern_bwd — shared with k_pattern_step, where `rays` is written later in the same launch: no
+// __restrict__ on it.  s_win: the launch's dynamic LDS, KS >= 0: gts over the footprint + halo)
 template <int KS>
-__global__ void __launch_bounds__(SPLAT_BLOCK)
-    k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
-                  const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
-                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n, float loss_div,
-                  BlurW bw, AdamK adam) {
-  extern __shared__ float s_win[]; // KS >= 0: gts over the footprint + halo
+__device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays, int n, const Mat4 &KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
+                                                  const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
+                                                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value,
+                                                  const float *__restrict__ loss_in, int loss_in_n, float loss_div, const BlurW &bw, float *s_win) {
   __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
   __shared__ int nb_count;
   __shared__ double red[4][SPLAT_BLOCK / 64];
-  const int k = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const float inv_sigma = 1.0f / sigma;
   float p0, p1;
   project_xy(rays, k, KF.m, p0, p1);
@@ -881,7 +896,20 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   }
   if (alive) {
     const int rw = hi0 - lo0, rh = hi1 - lo1;
+    // (the regulariser's two texture values of the NEXT round are asked for at the top of this one: a round used to begin with a dependent
+    // pair of global loads — three rounds, three latencies in a 7 us workgroup; the arithmetic and its order are untouched)
+    float n_so = 0.f, n_su = 0.f;
+    if (reg && tid < rw * rh) {
+      const size_t Tn = (size_t)(lo1 + tid / rw) * size0 + (lo0 + tid % rw);
+      n_so = tsor[Tn]; n_su = tsum[Tn];
+    }
     for (int t = tid; t < rw * rh; t += SPLAT_BLOCK) {
+      const float c_so = n_so, c_su = n_su;
+      if (reg && t + SPLAT_BLOCK < rw * rh) {
+        const int tn = t + SPLAT_BLOCK;
+        const size_t Tn = (size_t)(lo1 + tn / rw) * size0 + (lo0 + tn % rw);
+        n_so = tsor[Tn]; n_su = tsum[Tn];
+      }
       const int j = lo0 + t % rw, i = lo1 + t / rw;
       float d, yd, xd;
       const float v = splat_val((float)j, (float)i, p0s, p1s, sigma, inv_sigma, d, yd, xd);
@@ -896,7 +924,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
         a1 += (double)(w * (cf * xd));
       }
       if (reg) {
-        const float df = tsor[T] - tsum[T];
+        const float df = c_so - c_su;
         const float gd = df > 0.f ? gscale : (df < 0.f ? -gscale : 0.f);
         if (gd != 0.f) {
           float prod = 1.f;
@@ -976,9 +1004,13 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
       }
     }
   }
-  if (adam.rays && adam.dot_a) { // this workgroup's slice of <dot_a, dot_b> (the data term of a loss that is linear in the image)
+}
+// slice k of n_slices of <dot_a, dot_b> (the data term of a loss that is linear in the image) -> dot_partial[k]
+__device__ __forceinline__ void pattern_dot_slice(const int k, const int n_slices, const AdamK &adam) {
+  const int tid = threadIdx.x;
+  {
     __shared__ double s_dot[SPLAT_BLOCK / 64];
-    const long per = ((adam.dot_n + gridDim.x - 1) / gridDim.x + 3) & ~3L; // (slices of whole float4s)
+    const long per = ((adam.dot_n + n_slices - 1) / n_slices + 3) & ~3L; // (slices of whole float4s)
     const long lo_i = min(adam.dot_n, per * k), hi_i = min(adam.dot_n, lo_i + per); // (workgroups past the end: an empty slice)
     double acc = 0.0;
     const long bn = adam.dot_b_n; // period of b (a whole number of float4s for the vector path: a quad of a never straddles two periods)
@@ -997,6 +1029,32 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
     __syncthreads();
     if (tid == 0) adam.dot_partial[k] = (float)((s_dot[0] + s_dot[1]) + (s_dot[2] + s_dot[3]));
   }
+}
+// the step's data term from the slices, in slice order -> reg_value[1] (total loss: data term / loss_div + regulariser), reg_value[2]
+__device__ __forceinline__ void pattern_dot_total(const int n_slices, const AdamK &adam, float *reg_value, float loss_div) {
+  __shared__ double s_tot[SPLAT_BLOCK / 64];
+  const int tid = threadIdx.x;
+  double tot = 0.0;
+  for (int i = tid; i < n_slices; i += SPLAT_BLOCK) tot += (double)adam.dot_partial[i];
+  tot = wave_sum(tot);
+  if ((tid & 63) == 0) s_tot[tid >> 6] = tot;
+  __syncthreads();
+  if (tid == 0) {
+    const float ls = (float)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]));
+    reg_value[1] = ls / loss_div + reg_value[0]; // (reg_value[0]: written by point 0's workgroup before it arrived at the counter)
+    reg_value[2] = ls;
+  }
+}
+template <int KS>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_bwd(const float *__restrict__ rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
+                  const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
+                  float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n, float loss_div,
+                  BlurW bw, AdamK adam) {
+  extern __shared__ float s_win[]; // KS >= 0: gts over the footprint + halo
+  const int k = blockIdx.x, tid = threadIdx.x;
+  pattern_bwd_point<KS>(k, rays, n, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, n_ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, bw, s_win);
+  if (adam.rays && adam.dot_a) pattern_dot_slice(k, (int)gridDim.x, adam);
   if (adam.rays) { // the update rides along: whoever finishes last sees every point's gradient (agent-scope fence + counter)
     __shared__ int s_last;
     __syncthreads();
@@ -1015,22 +1073,138 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
         for (int i = tid; i < n; i += SPLAT_BLOCK)
           adam_clamp_one(i, t, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
                          adam.lo, adam.hi, adam.n_norm);
-      if (adam.dot_a && reg_value) { // the data term: the slices in workgroup order
-        __shared__ double s_tot[SPLAT_BLOCK / 64];
-        double tot = 0.0;
-        for (int i = tid; i < (int)gridDim.x; i += SPLAT_BLOCK) tot += (double)adam.dot_partial[i];
-        tot = wave_sum(tot);
-        if ((tid & 63) == 0) s_tot[tid >> 6] = tot;
-        __syncthreads();
-        if (tid == 0) {
-          const float ls = (float)((s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]));
-          reg_value[1] = ls / loss_div + reg_value[0]; // (reg_value[0]: written by workgroup 0 before it arrived at the counter)
-          reg_value[2] = ls;
-        }
-      }
+      if (adam.dot_a && reg_value) pattern_dot_total((int)gridDim.x, adam, reg_value, loss_div); // the data term: the slices in workgroup order
       __syncthreads();
       if (tid == 0) { if (!skip) adam.step[0] = t; *adam.counter = 0u; } // (the counter is ready for the next launch)
     }
+  }
+}
+
+// ------------------------------------------------------------------------------- the pattern side of a step as ONE launch
+// k_pattern_step (ffx_pattern_step, round 6): k_pattern_bwd<KS> of step s — gradient, Adam, clamp_to_fov, the step's loss — AND
+// k_pattern_fwd_blur<2> of step s + 1 (K1 + K2 + K3 on the updated pattern, the accumulator cleared) in one launch: the launch boundary between
+// them (a drained GPU behind a 17 us kernel of 64 workgroups) and the serial tail of the gradient launch (every workgroup's slice of the data
+// term behind its own point, two double-precision pow() in front of the update) leave the critical path between two renders.
+//
+//   workgroups 0 .. n-1     the gradient of point blockIdx.x (pattern_bwd_point); the one that arrives last applies the update to all points, copies
+//                           the guard's header (the same launch clears it below) and publishes `go` = this launch's epoch.  They wait for nobody.
+//   workgroups n .. G-1     helpers: slices of the data term's inner product while the gradient runs, then WAIT for `go`, then a forward tile each
+//                           and the clearing of `zero`.
+// What same-address device-scope atomics cost on this part decides the shape (measured here: ~27 ns each, one after the other — they execute where
+// the eight XCDs meet): a ticket per workgroup to deal the roles in start order took 29 us for 1072 workgroups, a "who leaves last" counter another 29,
+// a thousand helpers polling ONE flag kept the flag's line busy for longer than the wait.  Hence: roles by blockIdx (workgroups are dispatched in
+// index order, per XCD as well: a helper only ever waits for workgroups dispatched before it; the wait is BOUNDED all the same — a helper that has
+// polled for ~0.2 s raises `timeout` and leaves its tile undone, the host raises: never a hang), no exit counter (the flags carry the launch's epoch
+// instead of being re-armed; the counters are re-armed by the workgroup that completes them), 64 copies of the flag on lines of their own, and a
+// poll that is a read-modify-write (a plain load is answered by the XCD's own L2, possibly with the line from before: 130 us until it happened to be
+// evicted; an acquire per poll invalidates that L2 at the polling rate: the gradient then misses on every load, 340 us).
+#define PAT_GO_COPIES 64
+struct PatSync {
+  unsigned int pad0[4], stale, timeout, pad1[2]; double pw_t, pw_b1, pw_b2, pw1, pw2; unsigned int hdr[16]; unsigned int pad2[256 - 34]; // bytes 0..1023
+  unsigned int arrived, pad3[255];
+  unsigned int fin, pad4[255];
+  struct { unsigned int v, pad[127]; } go[PAT_GO_COPIES];
+};
+static_assert(sizeof(PatSync) == FFX_PATTERN_SYNC_BYTES && offsetof(PatSync, stale) == 16 && offsetof(PatSync, timeout) == 20 && offsetof(PatSync, hdr) == 72,
+              "ffx.h: FFX_PATTERN_SYNC_BYTES and the documented offsets");
+struct FwdK { float *pts, *tsum, *tsor, *ws, *zero, *tex, *kept_new; const float *kept_old; long n_zero; int want_softor, nbx, nby, check_kept, pow_cache; unsigned int epoch; };
+// the data term is complete when its slices AND the regulariser's value (point 0's workgroup) are: whoever of the slice helpers and the updating
+// workgroup gets here last adds the slices up
+__device__ __forceinline__ void pattern_step_fin(PatSync *sy, unsigned int participants, int n, const AdamK &adam, float *reg_value, float loss_div) {
+  __shared__ int s_fin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_fin = atomicAdd(&sy->fin, 1u) == participants - 1u;
+  }
+  __syncthreads();
+  if (s_fin) {
+    __threadfence();
+    pattern_dot_total(n, adam, reg_value, loss_div);
+    if (threadIdx.x == 0) sy->fin = 0u;
+  }
+}
+template <int KS>
+__global__ void __launch_bounds__(SPLAT_BLOCK)
+    k_pattern_step(float *rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts, float reg_weight, const float *ws,
+                   int n_ws, float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value, const float *__restrict__ loss_in, int loss_in_n,
+                   float loss_div, BlurW bw, AdamK adam, FwdK fw, PatSync *sy) {
+  extern __shared__ float s_win[];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const unsigned int G = gridDim.x, H = G - (unsigned int)n;                          // H helpers
+  const unsigned int dot_helpers = adam.dot_a ? (H < (unsigned int)n ? H : (unsigned int)n) : 0u; // the first of them take the data term's n slices
+  if (blockIdx.x < (unsigned int)n) {
+    const int k = (int)blockIdx.x;
+    if (fw.check_kept && tid < 3) { // the texture this step rendered with was made from rays_kept: has anybody edited the pattern since?
+      if (__float_as_uint(rays[3 * k + tid]) != __float_as_uint(fw.kept_old[3 * k + tid])) atomicOr(&sy->stale, 1u);
+    }
+    pattern_bwd_point<KS>(k, rays, n, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, n_ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, bw, s_win);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      s_flag = atomicAdd(&sy->arrived, 1u) == (unsigned int)n - 1u;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    // ---- every point's gradient is in memory: the update
+    __threadfence();
+    const bool skip = adam.no_update || (adam.guard && adam.guard[2] != 0u);
+    const float t = skip ? 0.f : adam.step[0] + 1.0f;
+    if (adam.guard && tid < 16) sy->hdr[tid] = adam.guard[tid]; // (what _watch_cache reads: the forward part below clears the header itself)
+    if (!skip) {
+      // beta^t: the running products of the last launch when they belong to step t - 1 and to these betas (one multiply instead of two
+      // double-precision pow() in this workgroup's serial tail); pow() otherwise
+      double p1, p2;
+      if (fw.pow_cache && sy->pw_t == (double)t - 1.0 && sy->pw_b1 == adam.beta1 && sy->pw_b2 == adam.beta2 && t > 1.0f) { p1 = sy->pw1 * adam.beta1; p2 = sy->pw2 * adam.beta2; }
+      else { p1 = pow(adam.beta1, (double)t); p2 = pow(adam.beta2, (double)t); }
+      for (int i = tid; i < n; i += SPLAT_BLOCK)
+        adam_clamp_one(i, t, p1, p2, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
+                       adam.lo, adam.hi, adam.n_norm);
+      __syncthreads();
+      if (tid == 0) { sy->pw_t = (double)t; sy->pw_b1 = adam.beta1; sy->pw_b2 = adam.beta2; sy->pw1 = p1; sy->pw2 = p2; adam.step[0] = t; }
+    }
+    // The pattern the texture is made from goes to the half of rays_kept that NO workgroup of this launch has read: the helpers take it from there with
+    // plain loads and WITHOUT an acquire fence — their XCD's L2 cannot hold that half (it does hold `rays` as they were: the gradient's workgroups
+    // read them).  A fence per helper wave — 4 000 at the same moment, each a write-back + invalidate of a whole L2 — was 60 us of an 80 us launch.
+    // (every thread copies the rays it has written itself)
+    for (int i = tid; i < n; i += SPLAT_BLOCK) {
+      fw.kept_new[3 * i] = rays[3 * i]; fw.kept_new[3 * i + 1] = rays[3 * i + 1]; fw.kept_new[3 * i + 2] = rays[3 * i + 2];
+    }
+    __syncthreads();
+    if (tid < PAT_GO_COPIES) {
+      if (tid == 0) sy->arrived = 0u; // (re-armed for the next launch: nobody else touches it any more)
+      __threadfence();
+      __hip_atomic_exchange(&sy->go[tid].v, fw.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (dot_helpers && reg_value) pattern_step_fin(sy, dot_helpers + 1u, n, adam, reg_value, loss_div);
+    return;
+  }
+  const unsigned int h = blockIdx.x - (unsigned int)n; // helper h of H
+  if (h < dot_helpers) {
+    for (unsigned int sl = h; sl < (unsigned int)n; sl += H) { pattern_dot_slice((int)sl, n, adam); __syncthreads(); }
+    if (reg_value) pattern_step_fin(sy, dot_helpers + 1u, n, adam, reg_value, loss_div);
+  }
+  if (tid == 0) {
+    unsigned int *flag = &sy->go[h % PAT_GO_COPIES].v;
+    if (h >= dot_helpers) __builtin_amdgcn_s_sleep(100); // (nothing to do meanwhile: the gradient takes 7 us at least, this is 2.7)
+    int ok = 1;
+    for (unsigned int polls = 0; __hip_atomic_fetch_add(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fw.epoch; ++polls) {
+      if (polls > 600000u) { ok = 0; atomicOr(&sy->timeout, 1u); break; } // (~0.2 s: see above)
+      __builtin_amdgcn_s_sleep(8);
+    }
+    s_flag = ok;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  asm volatile("" ::: "memory"); // (no fence: see kept_new above; the loads below are issued behind the poll that saw the flag)
+  if (fw.zero)
+    for (long t = (long)h * SPLAT_BLOCK + tid; t < fw.n_zero; t += (long)H * SPLAT_BLOCK) fw.zero[t] = 0.f;
+  const unsigned int n_tiles = (unsigned int)(fw.nbx * fw.nby);
+  for (unsigned int tile = h; tile < n_tiles; tile += H) {
+    pattern_fwd_blur_tile<2>((int)(tile % (unsigned int)fw.nbx), (int)(tile / (unsigned int)fw.nbx), fw.nbx, fw.kept_new, n, KF, sigma, size0, size1, fw.want_softor, fw.pts, fw.tsum,
+                             fw.tsor, fw.ws, bw, fw.tex);
+    __syncthreads();
   }
 }
 
@@ -1351,6 +1525,62 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   else FFX_LAUNCH_PB(0, lds);
 #undef FFX_LAUNCH_PB
   FFX_CHECK_LAUNCH("pattern_bwd_blur");
+  return FFX_OK;
+}
+
+int ffx_pattern_step(float *rays, int n, const float *KF, float sigma, int size0, int size1, float *tsum, float *tsor, const float *gtex, float reg_weight, float *ws,
+                     float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div, int blur_ksize, float blur_sigma,
+                     const ffx_adam_args *adam, float *pts, float *zero, long n_zero, float *tex, float *rays_kept, int check_kept, void *sync, uint32_t epoch, ffx_stream s) {
+  if (!rays || !KF || n < 1 || size0 <= 0 || size1 <= 0 || !(sigma > 0.f) || !tsum || !pts || !tex || !sync || !reg_value || (gtex && !grays_data) ||
+      (reg_weight > 0.f && (!tsor || !ws || !grays_reg)) || (loss_in && loss_in_n < 1) || (zero && n_zero < 1) || !rays_kept || ((uintptr_t)sync & 7) != 0 || epoch == 0u)
+    FFX_FAIL(FFX_ERR_ARG, "pattern_step: bad argument");
+  if (n > 65535) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_step: more than 65535 points");
+  if (blur_ksize != 5) FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_step: blur_ksize must be 5 (other sizes: ffx_pattern_bwd_blur + ffx_pattern_fwd_blur)");
+  BlurW bw;
+  if (!blur_weights(blur_ksize, blur_sigma, bw)) FFX_FAIL(FFX_ERR_ARG, "pattern_step: blur sigma must be positive");
+  if (!adam || !adam->exp_avg || !adam->exp_avg_sq || !adam->step || adam->rays != rays || !(adam->grad_div > 0.f) || adam->n_normalize < 0 || !(adam->lo <= adam->hi))
+    FFX_FAIL(FFX_ERR_ARG, "pattern_step: needs Adam arguments with state, for the rays of the call");
+  if ((grays_reg || adam->grad_div != 1.0f) && !adam->grad_out) FFX_FAIL(FFX_ERR_ARG, "pattern_step: combining gradients needs grad_out");
+  if (adam->guard && ((uintptr_t)adam->guard & 3) != 0) FFX_FAIL(FFX_ERR_ARG, "pattern_step: guard must be 4-byte aligned");
+  AdamK ak;
+  memset(&ak, 0, sizeof ak);
+  ak.guard = (const unsigned int *)adam->guard;
+  ak.rays = adam->rays; ak.m = adam->exp_avg; ak.v = adam->exp_avg_sq; ak.step = adam->step; ak.grad_out = adam->grad_out;
+  ak.lr = adam->lr; ak.beta1 = adam->beta1; ak.beta2 = adam->beta2; ak.eps = adam->eps;
+  for (int i = 0; i < 16; ++i) ak.KI.m[i] = adam->KF_inv[i];
+  ak.lo = adam->lo; ak.hi = adam->hi; ak.grad_div = adam->grad_div; ak.n_norm = adam->n_normalize;
+  if (adam->dot_a) {
+    if (!adam->dot_b || adam->dot_n < 1 || !adam->dot_partial) FFX_FAIL(FFX_ERR_ARG, "pattern_step: the inner product needs dot_b, dot_n and dot_partial");
+    if (loss_in) FFX_FAIL(FFX_ERR_ARG, "pattern_step: the data term comes either as partial sums (loss_in) or as an inner product (dot_a), not both");
+    if (adam->dot_b_n < 0 || adam->dot_b_n > adam->dot_n) FFX_FAIL(FFX_ERR_ARG, "pattern_step: dot_b_n must be 0 or a period <= dot_n");
+    ak.dot_a = adam->dot_a; ak.dot_b = adam->dot_b; ak.dot_n = (long)adam->dot_n; ak.dot_partial = adam->dot_partial;
+    ak.dot_b_n = adam->dot_b_n > 0 ? (long)adam->dot_b_n : (long)adam->dot_n;
+  }
+  const int r = blur_ksize / 2;
+  const int wmax = 2 * (int)ceilf(sqrtf(FFX_QCUT * sigma) + 1.0f) + 4 + 2 * r;
+  const size_t lds = (size_t)wmax * wmax * sizeof(float);
+  if (gtex && !(lds <= 24 * 1024 && size0 > 2 * r + 2 && size1 > 2 * r + 2))
+    FFX_FAIL(FFX_ERR_UNSUPPORTED, "pattern_step: this footprint / image size takes the separate launches (ffx_pattern_bwd_blur + ffx_pattern_fwd_blur)");
+  Mat4 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = KF[i];
+  FwdK fw;
+  memset(&fw, 0, sizeof fw);
+  fw.want_softor = tsor && ws ? 1 : 0; // (the next step's regulariser outputs whenever the caller keeps buffers for them)
+  fw.pts = pts; fw.tsum = tsum; fw.tsor = fw.want_softor ? tsor : nullptr; fw.ws = fw.want_softor ? ws : nullptr; fw.zero = zero; fw.n_zero = zero ? n_zero : 0L; fw.tex = tex;
+  fw.kept_new = rays_kept + (size_t)(epoch & 1u) * 3 * (size_t)n; fw.kept_old = rays_kept + (size_t)((epoch & 1u) ^ 1u) * 3 * (size_t)n; fw.check_kept = check_kept ? 1 : 0;
+  fw.nbx = ffx_cdiv(size0, TILE_W); fw.nby = ffx_cdiv(size1, TILE_H);
+  static const int pow_cache = [] { const char *e = getenv("FFX_ADAM_POW_CACHE"); return e ? atoi(e) : 1; }();
+  fw.pow_cache = pow_cache;
+  fw.epoch = epoch;
+  // one helper per forward tile up to 1024 (5 workgroups of this kernel fit a CU by LDS: 1280 at a time; beyond that helpers take several tiles
+  // each); the gradient's n workgroups in front
+  const long tiles = (long)fw.nbx * fw.nby;
+  const int helpers = (int)(tiles < 1024 ? tiles : 1024);
+  const float *gd_in = gtex;
+  hipLaunchKernelGGL(k_pattern_step<5>, dim3(n + helpers), dim3(SPLAT_BLOCK), gtex ? lds : 0, (hipStream_t)s, rays, n, m, sigma, size0, size1, tsum, tsor, gd_in, reg_weight, ws,
+                     ws ? (int)ffx_pattern_ws_floats(size0, size1) : 0, gtex ? grays_data : nullptr, reg_weight > 0.f ? grays_reg : nullptr, reg_value, loss_in, loss_in ? loss_in_n : 0,
+                     loss_div > 0.f ? loss_div : 1.0f, bw, ak, fw, (PatSync *)sync);
+  FFX_CHECK_LAUNCH("pattern_step");
   return FFX_OK;
 }
 

@@ -181,6 +181,41 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
     return gd, gr, val
 
 
+_pattern_epochs = {}
+
+
+def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, blur_sigma, adam, zero, sync, rays_kept=None, check_kept=False, loss_in=None, loss_div=1.0):
+    """The pattern side of a step as ONE launch (ffx_pattern_step): pattern_bwd_blur(..., adam) on `bufs` = (pts, tsum, tsor, ws, tex) of THIS step,
+    then — behind the update, in the same launch — pattern_fwd_blur of the NEXT step into the same five tensors, `zero` cleared.
+    -> (grays_data, grays_reg, [3] loss values), or None when the library declines the shape (FFX_ERR_UNSUPPORTED: the caller issues the two launches).
+    `sync`: uint8 tensor of _abi.PATTERN_SYNC_BYTES, zero before the first call."""
+    pts, tsum, tsor, ws, tex = bufs
+    n = rays.shape[0]
+    gd = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if gtex is not None else None
+    gr = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if reg_weight > 0 else None
+    val = torch.empty(3, dtype=torch.float32, device=rays.device)
+    if sync.numel() < _abi.PATTERN_SYNC_BYTES or sync.dtype != torch.uint8:
+        raise ValueError("pattern_step: sync must be a uint8 tensor of PATTERN_SYNC_BYTES")
+    # the launch's epoch: a count of the launches on this sync buffer (kept here, by the buffer's address and allocation: a new tensor starts at 1)
+    if rays_kept is None or rays_kept.numel() != 6 * n:
+        raise ValueError("pattern_step: rays_kept must be a float32 tensor [2, n, 3]")
+    key = (sync.data_ptr(), id(sync.untyped_storage()), rays_kept.data_ptr())
+    epoch = _pattern_epochs.get(key, 0) % 0xFFFFFFF0 + 1
+    if len(_pattern_epochs) > 256 and key not in _pattern_epochs:
+        _pattern_epochs.clear()
+    rc = api().call_rc("ffx_pattern_step", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), _dev(tsum, name="tsum"),
+                       _dev(tsor, name="tsor") if tsor is not None else None, _dev(gtex, name="gtex") if gtex is not None else None, float(reg_weight),
+                       _dev(ws, name="ws") if ws is not None else None, _dev(gd) if gd is not None else None, _dev(gr) if gr is not None else None, _dev(val),
+                       _dev(loss_in, name="loss_in") if loss_in is not None else None, int(loss_in.numel()) if loss_in is not None else 0, float(loss_div),
+                       int(ksize), float(blur_sigma), C.byref(adam), _dev(pts, name="pts"), _dev(zero, name="zero") if zero is not None else None,
+                       int(zero.numel()) if zero is not None else 0, _dev(tex, name="tex"), _dev(rays_kept, name="rays_kept"),
+                       int(bool(check_kept)), _dev(sync, torch.uint8, "sync"), epoch, _stream(), allow=(_abi.FFX_ERR_UNSUPPORTED,))
+    if rc != 0:
+        return None
+    _pattern_epochs[key] = epoch
+    return gd, gr, val
+
+
 def adam_args(rays, exp_avg, exp_avg_sq, step, counter, lr, beta1, beta2, eps, KF_inv, lo, hi, n_normalize=1, grad_div=1.0, grad_out=None, dot=None, guard=None):
     """ffx_adam_args for pattern_bwd_blur (the tensors must outlive the launch; `counter`: one zeroed int32 / uint32 device word).
     dot = (a, b, partial): the launch also evaluates <a, b> (two float32 tensors of equal size: the render and the constant gradient of a loss

@@ -226,10 +226,19 @@ class PatternOptimizer:
             self._arena = torch.empty(acc_bytes + max(nbytes, 64), dtype=torch.uint8, device=rd.device)
             self._acc = self._arena[: acc_bytes + 64].view(torch.float32)  # what the pattern launch clears: accumulator + cache header
             self._cache = self._arena[acc_bytes:] if use_cache else None
+        # (round 6) the texture of this step may already be there: the previous step's pattern launch (ffx_pattern_step) went on, behind its
+        # update, to K1 + K2 + K3 of the updated pattern and cleared the accumulator — if the pattern, the buffers and the settings are still
+        # the ones it saw (_premade_key; the launch itself checks the pattern's bits against what it kept: `stale`, read by _watch_cache)
+        pre, self._premade = getattr(self, "_premade", None), None
+        used_premade = False
         if self.blur:  # K1 + K2 + K3 in one launch (the blur rides on the splat's tiles)
             if buf is not None and len(buf) != 5:
                 buf = None
-            pts, tsum, tsor, ws, tex = self._pat_buf = ops.pattern_fwd_blur(rd, KF, self.sigma, s0, s1, self.blur[0], self.blur[1], want_softor=want_reg, out=buf, zero=self._acc)
+            if pre is not None and buf is not None and pre == self._premade_key(rays, KF, want_reg, buf):
+                pts, tsum, tsor, ws, tex = buf
+                used_premade = True
+            else:
+                pts, tsum, tsor, ws, tex = self._pat_buf = ops.pattern_fwd_blur(rd, KF, self.sigma, s0, s1, self.blur[0], self.blur[1], want_softor=want_reg, out=buf, zero=self._acc)
         else:
             if buf is not None and len(buf) != 4:
                 buf = None
@@ -393,13 +402,43 @@ class PatternOptimizer:
             # poisoned the gradient with NaN; rays and the Adam state stay intact and _watch_cache switches this optimiser to the re-tracing adjoint)
             aa = ops.adam_args(rd, st["exp_avg"], st["exp_avg_sq"], st["step"], self._adam_counter, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.laser._KF_inv,
                                1 - 0.95, 0.95, 2, grad_div=float(S), grad_out=grad, dot=dot, guard=self._cache if use_cache else None)
-            gd, gr, val = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
-                                               loss_div=float(S), adam=aa, scratch=self._scratch)
+            res = None
+            self._merged_last = False
+            if self.blur and bk == 5 and g2 is not None and os.environ.get("FFX_PATTERN_STEP", "1") != "0":
+                # ... and (round 6) the NEXT step's K1 + K2 + K3 behind the update, in the same launch (ffx_pattern_step): between two renders of a
+                # one-sample step there is ONE launch.  The library declines footprints that do not fit its LDS window: the two launches then
+                if getattr(self, "_pat_sync", None) is None:
+                    self._pat_sync = torch.zeros(_abi.PATTERN_SYNC_BYTES, dtype=torch.uint8, device=rd.device)
+                if getattr(self, "_rays_kept", None) is None or tuple(self._rays_kept.shape[1:]) != tuple(rd.shape):
+                    self._rays_kept = torch.empty((2,) + tuple(rd.shape), dtype=torch.float32, device=rd.device)
+                    used_premade = False  # (nothing kept to compare with)
+                res = ops.pattern_step(rd, KF, self.sigma, s0, s1, self._pat_buf, g2, reg_w, bk, bs, aa, self._acc, self._pat_sync, rays_kept=self._rays_kept,
+                                       check_kept=used_premade, loss_in=None if dot is not None else loss_slots, loss_div=float(S))
+                if res is not None:
+                    self._premade = self._premade_key(rays, KF, want_reg, self._pat_buf)
+                    self._merged_last = True
+            if res is None:
+                res = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
+                                           loss_div=float(S), adam=aa, scratch=self._scratch)
+            gd, gr, val = res
             loss = val[1]
         rays.grad = grad
         self.step_index += 1
         self._watch_cache()
         return {"loss": loss}
+
+    def _premade_key(self, rays, KF, want_reg, buf):
+        """what must be unchanged for the texture made by the previous step's pattern launch to be THIS step's texture: the pattern tensor (storage and
+        torch's version counter: in-place edits through torch bump it; the native update does not), the laser's own edit count, the accumulator the launch
+        cleared, the five texture buffers, and every setting of K1-K3.  (Edits torch cannot see — `rays.data` written in place — are caught on the device:
+        ffx_pattern_step compares the pattern's bits with the ones it kept and raises `stale`, which _watch_cache turns into an error.)"""
+        return (rays.data_ptr(), rays._version, tuple(rays.shape), getattr(self.laser, "_edits", 0), self._acc.data_ptr(), self._acc.numel(),
+                tuple(b.data_ptr() if b is not None else 0 for b in buf), float(self.sigma), tuple(self.tex_size), tuple(self.blur) if self.blur else None, bool(want_reg),
+                KF.tobytes() if hasattr(KF, "tobytes") else tuple(float(v) for v in torch.as_tensor(KF).reshape(-1).tolist()))
+
+    def invalidate_texture(self):
+        """forget the texture the last step made ahead for the next one (call after editing the pattern behind torch's back, e.g. through `rays.data`)"""
+        self._premade = None
 
     def _watch_cache(self, every=32):
         """The adjoint cache is lossy once its arena of single-sample records is full (include/ffx.h
@@ -407,8 +446,19 @@ class PatternOptimizer:
         copied to pinned host memory behind the step's kernels and inspected once it has landed — the host never waits."""
         w = getattr(self, "_watch", None)
         if w is not None and w[1].query():
-            used, cap, dropped = (int(v) for v in w[0][:3].tolist())
+            words = w[0].tolist()
             self._watch = None
+            if w[3]:  # (behind ffx_pattern_step: its sync words — `stale` in word 4, the header as the step left it in words 18..33)
+                if words[5]:
+                    raise RuntimeError(f"PatternOptimizer: a pattern launch around step {w[2]} gave up waiting for its own update (ffx_pattern_step's `timeout`): "
+                                       "the texture of the step after it is incomplete.  Set FFX_PATTERN_STEP=0 and report this.")
+                if words[4]:
+                    raise RuntimeError(
+                        f"PatternOptimizer: the pattern was edited in place between two steps in a way torch does not record (around step {w[2]}: e.g. through "
+                        "`laser._rays.data`), and the step after the edit rendered with the texture of the unedited pattern.  Call invalidate_texture() after "
+                        "such an edit (or set FFX_PATTERN_STEP=0).")
+                words = words[18:34]
+            used, cap, dropped = words[:3] if w[4] else (0, 0, 0)
             if dropped:
                 import warnings
 
@@ -426,14 +476,18 @@ class PatternOptimizer:
                 warnings.warn(f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample records: a projector "
                               "texture much finer than the camera's pixels, or grazing views).  The updates of the affected steps were skipped; this optimiser "
                               "now uses the re-tracing adjoint (ffx_render_bwd).", stacklevel=3)
-        if getattr(self, "_watch", None) is None and self._cache is not None and (self.step_index - 1) % every == 0:
+        merged = getattr(self, "_merged_last", False)
+        if getattr(self, "_watch", None) is None and (self._cache is not None or merged) and (self.step_index - 1) % every == 0:
             pin = getattr(self, "_watch_pin", None)
             if pin is None:
-                pin = self._watch_pin = torch.empty(16, dtype=torch.int32, pin_memory=True)
-            pin.copy_(self._cache[:64].view(torch.int32), non_blocking=True)
+                pin = self._watch_pin = torch.empty(64, dtype=torch.int32, pin_memory=True)
+            if merged:  # (the launch has cleared the cache's header for the next step; it kept a copy)
+                pin.copy_(self._pat_sync[:256].view(torch.int32), non_blocking=True)
+            else:
+                pin[:16].copy_(self._cache[:64].view(torch.int32), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._watch = (pin, ev, self.step_index - 1)
+            self._watch = (pin, ev, self.step_index - 1, merged, self._cache is not None)
 
     # ------------------------------------------------------------------ the same step through autograd
     def step_autograd(self):

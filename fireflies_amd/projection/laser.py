@@ -145,6 +145,7 @@ class Laser(camera.Camera):
         normalize_rays() that the training loops call right after (laser.py:254-255)."""
         if self._rays.is_cuda and self._rays.is_contiguous():
             ops.clamp_to_fov_(self._rays.detach(), self._KF, self._KF_inv, 1 - clamp_val, clamp_val, 2 if then_normalize else 1)
+            self._edits = getattr(self, "_edits", 0) + 1  # (a native in-place edit: torch's version counter does not see it — optim.PatternOptimizer._premade_key)
             return
         ndc = ops.project_rays_fwd(self._rays.detach().contiguous(), self._KF)
         ndc[:, 0:2] = torch.clamp(ndc[:, 0:2], 1 - clamp_val, clamp_val)

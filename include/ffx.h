@@ -67,7 +67,7 @@
 extern "C" {
 #endif
 
-#define FFX_ABI_VERSION 9
+#define FFX_ABI_VERSION 10
 #define FFX_MAX_LEVELS 96
 
 typedef void *ffx_stream; /* hipStream_t */
@@ -272,6 +272,43 @@ int ffx_pattern_bwd_blur(const float *rays /*[dev][n,3]*/, int n, const float *K
                          const float *loss_in /*[dev][loss_in_n] or NULL*/, int loss_in_n, float loss_div, int blur_ksize,
                          float blur_sigma, float *gts_scratch /*[dev][size1,size0] or NULL*/, const ffx_adam_args *adam /*[host] or NULL*/,
                          ffx_stream stream);
+
+/* The pattern side of an optimisation step as ONE launch (ABI 10): ffx_pattern_bwd_blur(..., adam) of step s — K3^T, K2-bwd, K1-bwd, the
+ * step's loss, torch.optim.Adam.step(), Laser.clamp_to_fov() + normalize_rays() — followed, inside the same launch, by ffx_pattern_fwd_blur of
+ * step s + 1 on the UPDATED rays: pts, tsum, tsor, ws, tex are overwritten with the next step's texture and `zero` (the next step's accumulator,
+ * normally gtex itself + the loss slots + the adjoint cache's header) is cleared — after the gradient has been taken from it.
+ * Replaces, for a step of fireflies' optimisation loop (main.py:97-107: loss.backward(); optim.step(); laser.clamp_to_fov();
+ * laser.normalize_rays(); and the next iteration's laser.generateTexture(sigma, size) + blur, fireflies/projection/laser.py:199-206,254-255,
+ * fireflies/graphics/rasterization.py:583-607), the launches between two renders by one.
+ * Every value is formed exactly as the two separate entry points form it (the same device functions); the bias corrections' beta^t are kept
+ * as running products between launches (one multiply per step; pow() when the step count or the betas are not the last launch's).
+ * Inside the launch the first n workgroups take the points' gradients (the last of them to arrive applies the update), the others slices of the
+ * data term's inner product, then — once the update is published — a forward tile each.  A waiting workgroup only waits for workgroups with a
+ * smaller index, which the hardware dispatches before it and which wait for nothing; the wait is bounded all the same: after ~0.2 s a helper
+ * sets the `timeout` word and leaves (the texture is then incomplete: the caller must treat a non-zero word as a failed call).
+ *   tsor, ws        : both given: the next step's soft-or texture and the regulariser's partial sums are written too (whatever reg_weight is).
+ *   adam            : required, with state (exp_avg, exp_avg_sq, step); adam->counter is not used.
+ *   blur_ksize      : 5 (the reference's kernel); a footprint that does not fit the workgroup's LDS: FFX_ERR_UNSUPPORTED (the caller then issues
+ *                     the two launches).
+ *   sync            : FFX_PATTERN_SYNC_BYTES device bytes (counters and flags on lines of their own), 8-byte aligned, zero before the first call;
+ *                     the launch leaves its counters zero and its flags at `epoch`.  Word 5 (`timeout`): above.  Bytes 72..135: a
+ *                     copy of the 64-byte header behind adam->guard as this step left it (the launch clears the header itself when `zero` covers
+ *                     it); word 4 (`stale`): set when check_kept found the rays changed (below).
+ *   epoch           : the previous call's on this sync buffer and these rays_kept + 1 (1 for the first): what the launch's flags are set to, and
+ *                     its parity says which half of rays_kept is written.
+ *   rays_kept       : [dev][2][n,3]: half (epoch & 1) receives the rays the new texture is made from (the forward part reads them from there);
+ *                     with check_kept != 0 the launch first compares the incoming rays with the OTHER half, the previous call's — a caller that
+ *                     skipped its own forward launch because the previous ffx_pattern_step had made the texture asks for the proof that nobody
+ *                     edited the pattern in between; a mismatch sets sync's `stale` word (sticky).
+ * ---------------------------------------------------------------------------------------- */
+#define FFX_PATTERN_SYNC_BYTES 35840
+int ffx_pattern_step(float *rays /*[dev][n,3] in/out*/, int n, const float *KF /*[host][16]*/, float sigma, int size0, int size1,
+                     float *tsum /*[dev] in: step s, out: step s + 1*/, float *tsor /*[dev] or NULL*/, const float *gtex /*[dev][size1,size0] or NULL*/,
+                     float reg_weight, float *ws /*[dev] or NULL*/, float *grays_data /*[dev][n,3] or NULL*/, float *grays_reg /*[dev][n,3] or NULL*/,
+                     float *reg_value /*[dev][3]*/, const float *loss_in /*[dev][loss_in_n] or NULL*/, int loss_in_n, float loss_div, int blur_ksize,
+                     float blur_sigma, const ffx_adam_args *adam /*[host]*/, float *pts /*[dev][n,2]*/, float *zero /*[dev][n_zero] or NULL*/, long n_zero,
+                     float *tex /*[dev][size1,size0]*/, float *rays_kept /*[dev][2][n,3]*/, int check_kept, void *sync /*[dev]*/, uint32_t epoch,
+                     ffx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * f1  sampler draws of a scene randomisation, on the host.

@@ -2343,6 +2343,29 @@ int ffx_pattern_bwd_blur(const float *rays, int n, const float *KF, float sigma,
   return rc;
 }
 
+/* the pattern side of a step in one call (include/ffx.h ffx_pattern_step, ABI 10): the composition it stands for —
+ *   main.py:97-107                                      loss.backward(); optim.step(); laser.clamp_to_fov(); laser.normalize_rays()   [ffx_pattern_bwd_blur with adam]
+ *   fireflies/projection/laser.py:254-255, rasterization.py:583-607   the next iteration's generateTexture + blur on the updated rays    [ffx_pattern_fwd_blur]
+ * with the accumulator cleared in between and the guard's header copied to the sync words first.  The comparison with rays_kept and the
+ * `stale` word as the header describes them; the sync counters have no meaning here and stay zero. */
+int ffx_pattern_step(float *rays, int n, const float *KF, float sigma, int size0, int size1, float *tsum, float *tsor, const float *gtex, float reg_weight, float *ws,
+                     float *grays_data, float *grays_reg, float *reg_value, const float *loss_in, int loss_in_n, float loss_div, int blur_ksize, float blur_sigma,
+                     const ffx_adam_args *adam, float *pts, float *zero, long n_zero, float *tex, float *rays_kept, int check_kept, void *sync, uint32_t epoch, ffx_stream s) {
+  if (!rays || !sync || !adam || !adam->exp_avg || !adam->exp_avg_sq || !adam->step || !pts || !tex || !reg_value || !rays_kept || epoch == 0u)
+    FAIL(FFX_ERR_ARG, "pattern_step: bad argument");
+  float *kept_new = rays_kept + (size_t)(epoch & 1u) * 3 * (size_t)n;
+  const float *kept_old = rays_kept + (size_t)((epoch & 1u) ^ 1u) * 3 * (size_t)n;
+  if (blur_ksize != 5) FAIL(FFX_ERR_UNSUPPORTED, "pattern_step: blur_ksize must be 5");
+  uint32_t *sw = (uint32_t *)sync;
+  if (check_kept && memcmp(rays, kept_old, sizeof(float) * 3 * (size_t)n) != 0) sw[4] |= 1u;
+  if (adam->guard) memcpy(sw + 18, adam->guard, 64);
+  int rc = ffx_pattern_bwd_blur(rays, n, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight, ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, blur_ksize,
+                                blur_sigma, NULL, adam, s);
+  if (rc != FFX_OK) return rc;
+  memcpy(kept_new, rays, sizeof(float) * 3 * (size_t)n);
+  return ffx_pattern_fwd_blur(rays, n, KF, sigma, size0, size1, tsor && ws ? 1 : 0, pts, tsum, tsor, ws, zero, n_zero, blur_ksize, blur_sigma, tex, s);
+}
+
 /* One scene sample pushed in one call (include/ffx.h ffx_scene_step_h, ABI 8), restated key write by key write:
  *   fireflies/scene.py:243-251  update_meshes: a posed mesh's vertices = chain x un-centring applied to its frame (here: the shape's transform row and
  *                               the frame's pool offset, the vertices are transformed by the update below)

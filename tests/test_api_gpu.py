@@ -769,6 +769,84 @@ def test_deterministic_mode_makes_an_optimisation_run_bitwise_reproducible(monke
     assert l3 == pytest.approx(l1, rel=1e-4)
 
 
+def test_one_pattern_launch_between_two_renders(monkeypatch):
+    """Round-5 review, item 6: behind a step's renders the gradient launch goes on to the NEXT step's K1 + K2 + K3 (ffx_pattern_step), so that the next
+    step() issues no pattern launch of its own — bit for bit the run that issues the two launches (FFX_PATTERN_STEP=0; compared under FFX_DETERMINISTIC=1,
+    where a run has no float atomics), for the linear loss and for an L1 loss; the fused / cached paths (float atomics in K8 / K9) to rounding.  The texture
+    made ahead is only used while the pattern is what the launch left: an in-place edit through torch between two steps (version counter), the laser's own
+    clamp_to_fov (edit count) and a changed sigma each bring the forward launch back for that step — same results as the two-launch run; an edit torch
+    cannot see (`rays.data`) is caught ON THE DEVICE by the next launch and reported by the optimiser's watch."""
+    from fireflies_amd import ops
+    from fireflies_amd.optim import image_l1_loss
+
+    calls = {"fwd": 0, "step": 0}
+    real_fwd, real_step = ops.pattern_fwd_blur, ops.pattern_step
+
+    def counting_fwd(*a, **k):
+        calls["fwd"] += 1
+        return real_fwd(*a, **k)
+
+    def counting_step(*a, **k):
+        calls["step"] += 1
+        return real_step(*a, **k)
+
+    monkeypatch.setattr(ops, "pattern_fwd_blur", counting_fwd)
+    monkeypatch.setattr(ops, "pattern_step", counting_step)
+
+    def run(merged, loss_kind, edits=False, steps=6):
+        monkeypatch.setenv("FFX_PATTERN_STEP", "1" if merged else "0")
+        calls["fwd"] = calls["step"] = 0
+        wl = _small()
+        kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=41, samples_per_step=2)
+        if loss_kind == "l1":
+            with torch.no_grad():
+                kw["loss_fn"] = image_l1_loss(mi.render(wl.mi_scene, spp=4, seed=99).torch().clone())
+        opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, **kw)
+        losses = []
+        for k in range(steps):
+            losses.append(float(opt.step()["loss"]))
+            if edits and k == 1:
+                with torch.no_grad():
+                    wl.laser._rays.mul_(1.01)  # (torch sees it)
+            if edits and k == 2:
+                wl.laser.clamp_to_fov(0.9, then_normalize=True)  # (a native in-place edit: the laser counts it)
+            if edits and k == 3:
+                opt.sigma = 8.0
+        st = opt.opt.state[wl.laser._rays]
+        return wl.laser._rays.detach().clone(), losses, st["exp_avg"].clone(), st["exp_avg_sq"].clone(), float(st["step"]), dict(calls), opt
+
+    monkeypatch.setenv("FFX_DETERMINISTIC", "1")
+    for loss_kind in ("linear", "l1"):
+        for edits in (False, True):
+            r1, l1, m1, v1, s1, c1, _ = run(True, loss_kind, edits)
+            r0, l0, m0, v0, s0, c0, _ = run(False, loss_kind, edits)
+            assert c0 == {"fwd": 6, "step": 0} and c1 == {"fwd": 4 if edits else 1, "step": 6}, (c0, c1)
+            assert torch.equal(r1, r0) and l1 == l0 and torch.equal(m1, m0) and torch.equal(v1, v0) and s1 == s0 == 6.0, (loss_kind, edits)
+    monkeypatch.delenv("FFX_DETERMINISTIC")
+    for loss_kind in ("linear", "l1"):  # the fused launch / the cache + K9: the same run up to the order of their float atomics
+        r1, l1, _, _, s1, c1, o1 = run(True, loss_kind)
+        r0, l0, _, _, s0, c0, _ = run(False, loss_kind)
+        assert c1 == {"fwd": 1, "step": 6} and s1 == s0 == 6.0 and o1.step_paths["fused" if loss_kind == "linear" else "cache_k9"] == 12
+        torch.testing.assert_close(r1, r0, rtol=1e-4, atol=1e-5)
+        assert l1 == pytest.approx(l0, rel=1e-4, abs=1e-7)
+    # an edit behind torch's back: the texture made ahead is stale, the next launch notices, the watch raises
+    *_, opt = run(True, "linear", steps=2)
+    with torch.no_grad():
+        opt.laser._rays.data[0, 0] += 1e-3
+    with pytest.raises(RuntimeError, match="edited in place"):
+        for _ in range(40):  # (the watch looks every 32 steps and never waits for the GPU)
+            opt.step()
+            torch.cuda.synchronize()
+    # ... unless the caller says so
+    *_, opt = run(True, "linear", steps=2)
+    with torch.no_grad():
+        opt.laser._rays.data[0, 0] += 1e-3
+    opt.invalidate_texture()
+    for _ in range(40):
+        opt.step()
+        torch.cuda.synchronize()
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the launcher starts two fresh rank processes (here both on
     the one device, transport gloo — FFX_DIST_BACKEND=gloo is the explicit opt-in for that; on a node with >= 2 GPUs the

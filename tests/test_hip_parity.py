@@ -1533,6 +1533,122 @@ def test_pattern_launches_that_carry_the_blur_and_the_update_along(oracle, n, si
         ops.pattern_fwd_blur(dev(rays), KF, sigma, s0, s1, 4, bs, True)
 
 
+@pytest.mark.parametrize("n,size,sigma", [(64, (500, 500), 10.0), (64, (96, 80), 10.0), (300, (250, 120), 6.0), (9, (40, 24), 4.0), (1500, (1024, 1024), 10.0)])
+def test_the_pattern_side_of_a_step_as_one_launch(oracle, n, size, sigma):
+    """ffx_pattern_step (round 6): ffx_pattern_bwd_blur(..., adam) of one step and ffx_pattern_fwd_blur of the next in ONE launch — workgroups take
+    their roles by ticket, helpers wait for the update, then splat and blur the updated pattern and clear the accumulator the gradient was read from.
+    Five consecutive steps (so that the sync words are re-armed by the launch itself and the running products beta^t take over from pow()) against
+    the two separate launches, BIT FOR BIT: gradient, loss values, rays, both moments, step count, the combined gradient, and the next step's
+    pts / tsum / tsor / ws / tex; the cleared range exactly the range asked for; the data term as partial sums and as an inner product; a guard that
+    skips the update (the copy of its header in the sync words, the header itself cleared); the kept pattern and the `stale` word; and the first
+    step's gradient against the oracle.  Sizes: the bench's, a small image, more points than a workgroup has threads, a tiny image, and more points +
+    tiles than the GPU holds workgroups at a time (1500 + 1024 workgroups of which helpers take four tiles each)."""
+    rng = np.random.default_rng(n + size[0])
+    s0, s1 = size
+    g2 = load_golden("g2_projection.npz")
+    KF = (g2["K"] @ FLIP_Y).astype(np.float32)
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    ndc = (rng.random((n, 3)) * np.array([1.0, 1.0, 0.0]) + np.array([0.0, 0.0, -1.0])).astype(np.float32)
+    rays = oracle.transform_points(ndc, KFi)
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    ks, bs = 5, 3.0
+    T = s0 * s1
+
+    def fresh():
+        r = dev(rays).clone()
+        return r, torch.zeros_like(r), torch.zeros_like(r), torch.zeros((), device="cuda")
+
+    for variant in ("slots", "dot", "guard"):
+        (r_a, m_a, v_a, st_a), (r_b, m_b, v_b, st_b) = fresh(), fresh()
+        counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+        sync = torch.zeros(35840, dtype=torch.uint8, device="cuda")
+        kept = torch.zeros((2,) + tuple(r_b.shape), device="cuda")
+        # the accumulator as optim.PatternOptimizer lays it out: gtex, loss slots, a 64-byte header behind them — plus a canary on either side
+        n_slots = 37
+        acc_a = torch.zeros(1 + T + n_slots + 16 + 1, device="cuda")
+        acc_b = torch.zeros_like(acc_a)
+        n_dot = 3 * 41 * 29
+        a_d, b_d = dev(rng.standard_normal(n_dot).astype(np.float32)), dev(rng.standard_normal(n_dot).astype(np.float32))
+        part_a, part_b = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+        buf_a = ops.pattern_fwd_blur(r_a, KF, sigma, s0, s1, ks, bs, True)
+        buf_b = ops.pattern_fwd_blur(r_b, KF, sigma, s0, s1, ks, bs, True)
+        for k in range(5):
+            gtex_k = (rng.standard_normal((s1, s0)) * (k + 1)).astype(np.float32)
+            gtex_k[rng.random((s1, s0)) < 0.3] = 0.0
+            li = rng.standard_normal(n_slots).astype(np.float32)
+            hdr = np.zeros(16, np.int32)
+            if variant == "guard":
+                d = 7 if k in (1, 3) else 0  # (steps 1 and 3 are NOT applied)
+                hdr[0], hdr[1], hdr[2] = 4096 + d, 4096, d
+            w = 0.1 if k != 2 else 0.0
+            for acc in (acc_a, acc_b):
+                acc.fill_(0.0)
+                acc[0], acc[-1] = 7.0, 7.0
+                acc[1:1 + T] = dev(gtex_k).reshape(-1)
+                acc[1 + T:1 + T + n_slots] = dev(li)
+                acc[1 + T + n_slots:-1].view(torch.int32).copy_(torch.from_numpy(hdr).cuda())
+            gt_a, sl_a, hd_a = acc_a[1:1 + T].view(s1, s0), acc_a[1 + T:1 + T + n_slots], acc_a[1 + T + n_slots:-1].view(torch.uint8)
+            gt_b, sl_b, hd_b = acc_b[1:1 + T].view(s1, s0), acc_b[1 + T:1 + T + n_slots], acc_b[1 + T + n_slots:-1].view(torch.uint8)
+            g_a, g_b = torch.empty_like(r_a), torch.empty_like(r_b)
+            dot_a = (a_d, b_d, part_a) if variant == "dot" else None
+            dot_b = (a_d, b_d, part_b) if variant == "dot" else None
+            # ---- the two launches
+            aa = ops.adam_args(r_a, m_a, v_a, st_a, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_a, dot=dot_a,
+                               guard=hd_a if variant == "guard" else None)
+            gd_a, gr_a, val_a = ops.pattern_bwd_blur(r_a, KF, sigma, s0, s1, buf_a[1], buf_a[2], gt_a, w, buf_a[3], ks, bs, loss_in=None if dot_a else sl_a, loss_div=4.0,
+                                                     adam=aa, scratch=torch.empty_like(buf_a[1]))
+            if k == 0 and variant == "slots":
+                gd_o, gr_o, val_o = oracle.pattern_bwd_blur(rays.copy(), KF, sigma, s0, s1, host(buf_a[1]), host(buf_a[2]), gtex_k, w, host(buf_a[3]), ks, bs, loss_in=li, loss_div=4.0)
+            buf_a = ops.pattern_fwd_blur(r_a, KF, sigma, s0, s1, ks, bs, True, out=buf_a, zero=acc_a[1:-1])
+            # ---- the one launch
+            ab = ops.adam_args(r_b, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_b, dot=dot_b,
+                               guard=hd_b if variant == "guard" else None)
+            res = ops.pattern_step(r_b, KF, sigma, s0, s1, buf_b, gt_b, w, ks, bs, ab, acc_b[1:-1], sync, rays_kept=kept, check_kept=k > 0,
+                                   loss_in=None if dot_b else sl_b, loss_div=4.0)
+            assert res is not None
+            gd_b, gr_b, val_b = res
+            what = f"{variant} step {k}"
+            assert torch.equal(gd_a, gd_b) and (gr_a is None) == (gr_b is None) and (gr_a is None or torch.equal(gr_a, gr_b)), what
+            assert torch.equal(val_a, val_b), (what, val_a, val_b)
+            applied = not (variant == "guard" and k in (1, 3))
+            if applied:
+                assert torch.equal(g_a, g_b), what
+            assert torch.equal(r_a, r_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b) and float(st_a) == float(st_b), what
+            for x, y, nm in zip(buf_a, buf_b, ("pts", "tsum", "tsor", "ws", "tex")):
+                assert torch.equal(x, y), (what, nm)
+            assert torch.equal(acc_a, acc_b) and float(acc_b[0]) == 7.0 and float(acc_b[-1]) == 7.0 and float(acc_b[1:-1].abs().max()) == 0.0, what
+            assert torch.equal(kept[(k + 1) & 1], r_b), what  # (launch k + 1 of this sync buffer: its parity's half)
+            sw = sync.view(torch.int32).cpu().numpy()
+            flags = sw[768::128]
+            assert (sw[:8] == 0).all() and sw[256] == 0 and sw[512] == 0 and len(flags) == 64 and flags[0] != 0 and (flags == flags[0]).all(), (what, sw[:8], flags)
+            # (nothing stale, no time-out; the counters re-armed; the 64 flags at this launch's epoch)
+            if variant == "guard":
+                assert (sw[18:34] == hdr).all(), what
+            if k == 0 and variant == "slots":
+                np.testing.assert_allclose(host(gd_b), gd_o, rtol=3e-4, atol=3e-5 * max(np.abs(gd_o).max(), 1e-20))
+                np.testing.assert_allclose(host(val_b), val_o, rtol=2e-5, atol=2e-5)
+        steps = 3.0 if variant == "guard" else 5.0
+        assert float(st_b) == steps
+        if variant == "slots":
+            # an edit behind torch's back between two steps: the launch that was told the texture is the kept pattern's finds out
+            r_b[0, 0] += 1e-3
+            acc_b.fill_(0.0)
+            ab = ops.adam_args(r_b, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=torch.empty_like(r_b))
+            assert ops.pattern_step(r_b, KF, sigma, s0, s1, buf_b, acc_b[1:1 + T].view(s1, s0), 0.1, ks, bs, ab, acc_b[1:-1], sync, rays_kept=kept, check_kept=True,
+                                    loss_in=acc_b[1 + T:1 + T + n_slots], loss_div=4.0) is not None
+            assert int(sync.view(torch.int32)[4]) == 1
+    # declined shapes: a footprint beyond the launch's LDS window, another kernel size
+    r, m, v, st = fresh()
+    aa = ops.adam_args(r, m, v, st, torch.zeros(1, dtype=torch.int32, device="cuda"), 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_out=torch.empty_like(r))
+    bufs = ops.pattern_fwd_blur(r, KF, 400.0, s0, s1, 5, bs, True)
+    z = torch.zeros(T + 16, device="cuda")
+    sy = torch.zeros(35840, dtype=torch.uint8, device="cuda")
+    kp = torch.zeros((2,) + tuple(r.shape), device="cuda")
+    assert ops.pattern_step(r, KF, 400.0, s0, s1, bufs, z[:T].view(s1, s0), 0.1, 5, bs, aa, z, sy, rays_kept=kp) is None
+    assert ops.pattern_step(r, KF, sigma, s0, s1, bufs, z[:T].view(s1, s0), 0.1, 3, bs, aa, z, sy, rays_kept=kp) is None
+    assert torch.equal(r, dev(rays)) and float(st) == 0.0 and int(sy.view(torch.int32).abs().sum()) == 0  # (declined: nothing launched)
+
+
 def test_dpp_three_chain_reduction_against_shuffle_reference(tmp_path):
     """the interleaved DPP / row_bcast wave reduction that make_widepk uses for the packet bounds
     (ffx_trace.hip: wave_reduce3_nn), compiled as the stand-alone checker tools/ubench/reduce3_check.hip and compared
