@@ -778,9 +778,9 @@ def main():
                                   else "coverage_loss through the cache + K9")},
             "grad_kernels_ms": {("render_fwd(+adjoint in the same launch: ffx_render_fwd_adjoint)" if fused_ran else "render_fwd(+cache write)"): k8g_ms,
                                 "render_bwd_cached": k9c_ms, "render_bwd(retrace)": k9_ms},
-            "grad_launches_per_step": ("pattern_fwd_blur, render_fwd_adjoint, pattern_bwd<5> (+ re-fit and apex records on the side stream)" if args.rfilter == "box" else
-                                       "pattern_fwd_blur, [rf_weights, rf_gather (G), render_fwd_adjoint_filtered, rf_gather (image)], pattern_bwd<5> (+ re-fit and pre-pass on the side stream)") if fused_ran
-            else "pattern_fwd_blur, render_fwd_cache, render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)",
+            "grad_launches_per_step": ("render_fwd_adjoint, pattern_step<5> [gradient + Adam + clamp, then the next step's splat + blur] (+ re-fit and apex records on the side stream)" if args.rfilter == "box" else
+                                       "[rf_weights, rf_gather (G), render_fwd_adjoint_filtered, rf_gather (image)], pattern_step<5> (+ re-fit and pre-pass on the side stream)") if fused_ran
+            else "render_fwd_cache, render_bwd_cached, pattern_step<5> (+ re-fit and apex records on the side stream)",
             "grad_step_paths": lin_paths,
             "grad_update_paths": dict(wg.mi_scene.update_paths),  # (scene samples pushed by ffx_scene_step_h / by the Python path, up to the end of this bracket)
             "render_fwd_adjoint_roofline": None if not (fused_ran and k8g_ms) else {
@@ -823,7 +823,7 @@ def main():
                 "grad_ms_per_step_nonlinear": 1e3 * t_grad2 / args.steps,
                 "grad_nonlinear_config": {"loss": "torch.nn.L1Loss()(img, target) against a fixed target render (optim.image_l1_loss): its gradient depends on the image",
                                           "step_paths": dict(opt2.step_paths),
-                                          "launches_per_step": "pattern_fwd_blur, render_fwd_cache, l1_value_grad (+ add), render_bwd_cached, pattern_bwd<5> (+ re-fit and apex records on the side stream)"},
+                                          "launches_per_step": "render_fwd_cache, l1_value_grad (+ add), render_bwd_cached, pattern_step<5> (+ re-fit and apex records on the side stream)"},
                 "grad_nonlinear_kernels_ms": {"render_fwd(+cache write)": k8g2_ms, "render_bwd_cached": k9c2_ms, "render_bwd(retrace)": k9r2_ms},
                 "render_bwd_cached_roofline": None if k9c2_ms is None else {
                     "kernel": "k_render_bwd_cached_tiled16 (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",
@@ -896,8 +896,8 @@ def main():
                     gauss.update({"grad_steps_per_sec_gaussian_nonlinear": args.steps / t_gg2, "grad_ms_per_step_gaussian_nonlinear": 1e3 * t_gg2 / args.steps,
                                   "grad_gaussian_nonlinear_config": {
                                       "loss": "torch.nn.L1Loss()(img, target) on the gaussian film (optim.image_l1_loss)", "step_paths": dict(optg2.step_paths),
-                                      "launches_per_step": "pattern_fwd_blur, render_fwd_cache_filtered [K8 + per-sample records, rf_gather], l1_value_grad, render_bwd_cached_filtered, "
-                                                           "pattern_bwd<5> (+ re-fit and pre-pass on the side stream)",
+                                      "launches_per_step": "render_fwd_cache_filtered [K8 + per-sample records, rf_gather], l1_value_grad, render_bwd_cached_filtered, "
+                                                           "pattern_step<5> (+ re-fit and pre-pass on the side stream)",
                                       "kernels_ms": {"render_fwd_cache_filtered (K8 + gather)": k8f_ms, "render_bwd_cached_filtered": k9f_ms, "render_bwd_filtered(retrace)": k9fr_ms}}})
             finally:
                 wg.mi_scene.rfilter = "box"

@@ -562,10 +562,23 @@ __device__ __forceinline__ float blur_bwd_texel(const float *__restrict__ win, i
 
 // Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the step count t kept
 // on the device) followed by Laser.clamp_to_fov + normalize_rays on the updated ray i
-// (pw1, pw2: beta1^t, beta2^t)
-__device__ __forceinline__ void adam_clamp_one(int i, float t, double pw1, double pw2, float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
-                                               float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
-                                               const float *K, const float *I, float lo, float hi, int n_norm) {
+// (pw1, pw2: beta1^t, beta2^t.  The operands of ray i come in an AdamIn, loaded by adam_load — k_pattern_step asks for them before it knows whether
+// the update is applied; `kept`: a second place the updated ray is written to, or NULL)
+struct AdamIn { float g[3], gb[3], m[3], v[3], r[3]; };
+__device__ __forceinline__ void adam_load(int i, const float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, const float *__restrict__ m,
+                                          const float *__restrict__ v, AdamIn &in) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    in.g[c] = grad ? grad[3 * i + c] : 0.f;
+    in.gb[c] = grad_b ? grad_b[3 * i + c] : 0.f;
+    in.m[c] = m[3 * i + c];
+    in.v[c] = v[3 * i + c];
+    in.r[c] = rays[3 * i + c];
+  }
+}
+__device__ __forceinline__ void adam_clamp_core(int i, float t, double pw1, double pw2, const AdamIn &in, float *rays, bool have_grad_b, float scale_a,
+                                                float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
+                                                const float *K, const float *I, float lo, float hi, int n_norm, float *kept) {
   // the scalars as torch forms them: in double from the Python floats, rounded to float where they meet the tensors
   const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2), eps = (float)eps_d;
   const double bc1 = 1.0 - pw1, bc2 = 1.0 - pw2;
@@ -573,19 +586,19 @@ __device__ __forceinline__ void adam_clamp_one(int i, float t, double pw1, doubl
   float r[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float g = grad ? grad[3 * i + c] : 0.f;
+    float g = in.g[c];
     if (grad_out) { // g = grad / S + grad_b, rounded like the two torch ops it replaces; kept as the parameter's .grad
       if (scale_a != 1.0f) g = g / scale_a;
-      if (grad_b) g = g + grad_b[3 * i + c];
+      if (have_grad_b) g = g + in.gb[c];
       grad_out[3 * i + c] = g;
     }
-    float mm = m[3 * i + c], vv = v[3 * i + c];
+    float mm = in.m[c], vv = in.v[c];
     mm = mm + omb1 * (g - mm);
     vv = b2 * vv + omb2 * g * g;
     m[3 * i + c] = mm;
     v[3 * i + c] = vv;
     const float denom = sqrtf(vv) / bc2s + eps;
-    r[c] = rays[3 * i + c] - step_size * mm / denom;
+    r[c] = in.r[c] - step_size * mm / denom;
   }
   float x = r[0], y = r[1], z = r[2];
   const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
@@ -605,8 +618,15 @@ __device__ __forceinline__ void adam_clamp_one(int i, float t, double pw1, doubl
     x /= nrm; y /= nrm; z /= nrm;
   }
   rays[3 * i] = x; rays[3 * i + 1] = y; rays[3 * i + 2] = z;
+  if (kept) { kept[3 * i] = x; kept[3 * i + 1] = y; kept[3 * i + 2] = z; }
 }
-
+__device__ __forceinline__ void adam_clamp_one(int i, float t, double pw1, double pw2, float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
+                                               float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
+                                               const float *K, const float *I, float lo, float hi, int n_norm) {
+  AdamIn in;
+  adam_load(i, rays, grad, grad_b, m, v, in);
+  adam_clamp_core(i, t, pw1, pw2, in, rays, grad_b != nullptr, scale_a, grad_out, m, v, lr, beta1, beta2, eps_d, K, I, lo, hi, n_norm, nullptr);
+}
 __device__ __forceinline__ void adam_clamp_one(int i, float t, float *rays, const float *__restrict__ grad, const float *__restrict__ grad_b, float scale_a,
                                                float *__restrict__ grad_out, float *__restrict__ m, float *__restrict__ v, double lr, double beta1, double beta2, double eps_d,
                                                const float *K, const float *I, float lo, float hi, int n_norm) {
@@ -620,6 +640,13 @@ __device__ __forceinline__ void adam_clamp_one(int i, float t, float *rays, cons
 //   k_pattern_fwd   K1 + K2(sum) + K2(softor) (+ the partial sums of the overlap regulariser L1(softor, sum))
 //   k_pattern_bwd   K2-bwd of the data term, of the regulariser's softor and sum terms, and K1-bwd of both
 //   k_adam_clamp    Adam + Laser.clamp_to_fov + normalize_rays
+__device__ __forceinline__ void project_xyz(const float x, const float y, const float z, const float *K, float &p0, float &p1) {
+  const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
+  const float q1 = K[4] * x + K[5] * y + K[6] * z + K[7];
+  const float q3 = K[12] * x + K[13] * y + K[14] * z + K[15];
+  p0 = q0 / q3;
+  p1 = q1 / q3;
+}
 __device__ __forceinline__ void project_xy(const float *rays, int k, const float *K, float &p0, float &p1) {
   const float x = rays[3 * k], y = rays[3 * k + 1], z = rays[3 * k + 2];
   const float q0 = K[0] * x + K[1] * y + K[2] * z + K[3];
@@ -842,21 +869,53 @@ template <int KS>
 __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays, int n, const Mat4 &KF, float sigma, int size0, int size1, const float *__restrict__ tsum,
                                                   const float *__restrict__ tsor, const float *__restrict__ gts, float reg_weight, const float *__restrict__ ws, int n_ws,
                                                   float *__restrict__ grays_data, float *__restrict__ grays_reg, float *__restrict__ reg_value,
-                                                  const float *__restrict__ loss_in, int loss_in_n, float loss_div, const BlurW &bw, float *s_win) {
+                                                  const float *__restrict__ loss_in, int loss_in_n, float loss_div, const BlurW &bw, float *s_win,
+                                                  unsigned long long *stamps = nullptr) {
+#ifdef FFX_PATSTAMP
+#define PB_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
+#else
+#define PB_STAMP(slot) do { } while (0)
+#endif
   __shared__ float nb_p0[NEIGH_MAX], nb_p1[NEIGH_MAX];
   __shared__ int nb_count;
   __shared__ double red[4][SPLAT_BLOCK / 64];
   const int tid = threadIdx.x;
   const float inv_sigma = 1.0f / sigma;
+  const bool reg = reg_weight > 0.f && tsor != nullptr;
+  const bool use_list = reg && n <= NEIGH_MAX;
+  // (round 6: the loads of this workgroup's dependent chain are asked for as early as their addresses are known — this point's ray together with
+  // the first 64 candidate neighbours' rays here, the regulariser's first texture values together with the window of gts below: four memory
+  // latencies in a row were most of a 6 us workgroup.  Same arithmetic in the same order.)
   float p0, p1;
-  project_xy(rays, k, KF.m, p0, p1);
+  const float kx = rays[3 * k], ky = rays[3 * k + 1], kz = rays[3 * k + 2];
+  float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+  if (use_list && tid < 64 && tid < n) { c_x = rays[3 * tid]; c_y = rays[3 * tid + 1]; c_z = rays[3 * tid + 2]; }
+  project_xyz(kx, ky, kz, KF.m, p0, p1);
   const float p0s = p0 * (float)size0, p1s = p1 * (float)size1;
   const float R = sqrtf(FFX_QCUT * sigma) + 1.0f;
   const int lo0 = max(0, (int)floorf(p0s - R)), hi0 = min(size0, (int)ceilf(p0s + R) + 1);
   const int lo1 = max(0, (int)floorf(p1s - R)), hi1 = min(size1, (int)ceilf(p1s + R) + 1);
   const bool alive = hi0 > lo0 && hi1 > lo1;
-  const bool reg = reg_weight > 0.f && tsor != nullptr;
-  const bool use_list = reg && n <= NEIGH_MAX;
+  float n_so = 0.f, n_su = 0.f; // the regulariser's texture values of the first round of the texel loop
+  if (alive && reg && tid < (hi0 - lo0) * (hi1 - lo1)) {
+    const size_t Tn = (size_t)(lo1 + tid / (hi0 - lo0)) * size0 + (lo0 + tid % (hi0 - lo0));
+    n_so = tsor[Tn]; n_su = tsum[Tn];
+  }
+  // the window of gts (KS >= 0: footprint + halo, for K3^T) is staged by waves 1..3 WHILE wave 0 compacts the neighbour list (round 6: one barrier
+  // and one memory latency instead of two of each); without a list all four waves stage
+  const int br = KS >= 0 ? (KS ? KS : bw.ksize) / 2 : 0;
+  const int ww = hi0 - lo0 + 2 * br; // row length of the staged window
+  if constexpr (KS >= 0) {
+    if (alive && gts) {
+      const int wh = hi1 - lo1 + 2 * br;
+      const int first = use_list ? 64 : 0;
+      if (tid >= first)
+        for (int t = tid - first; t < ww * wh; t += SPLAT_BLOCK - first) {
+          const int gy = lo1 - br + t / ww, gx = lo0 - br + t % ww;
+          s_win[t] = (gy >= 0 && gy < size1 && gx >= 0 && gx < size0) ? gts[(size_t)gy * size0 + gx] : 0.f;
+        }
+    }
+  }
   if (use_list) {
     if (tid < 64) {
       int count = 0;
@@ -866,7 +925,8 @@ __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays
         float q0 = 0.f, q1 = 0.f;
         if (m < n && m != k) {
           float a, b;
-          project_xy(rays, m, KF.m, a, b);
+          if (base == 0) project_xyz(c_x, c_y, c_z, KF.m, a, b);
+          else project_xy(rays, m, KF.m, a, b);
           q0 = a * (float)size0;
           q1 = b * (float)size1;
           keep = fabsf(q0 - p0s) <= 2.f * R + 2.f && fabsf(q1 - p1s) <= 2.f * R + 2.f;
@@ -878,31 +938,14 @@ __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays
       }
       if (tid == 0) nb_count = count;
     }
-    __syncthreads();
   }
+  if (use_list || KS >= 0) __syncthreads();
+  PB_STAMP(10);
   const float gscale = reg_weight / ((float)size0 * (float)size1);
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-  const int br = KS >= 0 ? (KS ? KS : bw.ksize) / 2 : 0;
-  const int ww = hi0 - lo0 + 2 * br; // row length of the staged window
-  if constexpr (KS >= 0) {
-    if (alive && gts) {
-      const int wh = hi1 - lo1 + 2 * br;
-      for (int t = tid; t < ww * wh; t += SPLAT_BLOCK) {
-        const int gy = lo1 - br + t / ww, gx = lo0 - br + t % ww;
-        s_win[t] = (gy >= 0 && gy < size1 && gx >= 0 && gx < size0) ? gts[(size_t)gy * size0 + gx] : 0.f;
-      }
-    }
-    __syncthreads();
-  }
   if (alive) {
     const int rw = hi0 - lo0, rh = hi1 - lo1;
-    // (the regulariser's two texture values of the NEXT round are asked for at the top of this one: a round used to begin with a dependent
-    // pair of global loads — three rounds, three latencies in a 7 us workgroup; the arithmetic and its order are untouched)
-    float n_so = 0.f, n_su = 0.f;
-    if (reg && tid < rw * rh) {
-      const size_t Tn = (size_t)(lo1 + tid / rw) * size0 + (lo0 + tid % rw);
-      n_so = tsor[Tn]; n_su = tsum[Tn];
-    }
+    // (the regulariser's two texture values of the NEXT round are asked for at the top of this one — the first round's: above)
     for (int t = tid; t < rw * rh; t += SPLAT_BLOCK) {
       const float c_so = n_so, c_su = n_su;
       if (reg && t + SPLAT_BLOCK < rw * rh) {
@@ -948,6 +991,7 @@ __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays
       }
     }
   }
+  PB_STAMP(11);
   a0 = wave_sum(a0); a1 = wave_sum(a1); b0 = wave_sum(b0); b1 = wave_sum(b1);
   if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; red[2][tid >> 6] = b0; red[3][tid >> 6] = b1; }
   __syncthreads();
@@ -957,7 +1001,7 @@ __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays
     for (int c = 0; c < 4; ++c)
       for (int w = 0; w < SPLAT_BLOCK / 64; ++w) sres[c] += red[c][w];
     // K1-bwd (k_project_bwd) with gpts = (g0, g1, 0)
-    const float x = rays[3 * k], y = rays[3 * k + 1], z = rays[3 * k + 2];
+    const float x = kx, y = ky, z = kz;
     const float *K = KF.m;
     float q[4];
 #pragma unroll
@@ -981,6 +1025,7 @@ __device__ __forceinline__ void pattern_bwd_point(const int k, const float *rays
       for (int c = 0; c < 3; ++c) out[3 * k + c] = gq[0] * K[c] + gq[1] * K[4 + c] + gq[2] * K[8 + c] + gq[3] * K[12 + c];
     }
   }
+  PB_STAMP(12);
   if (k == 0 && reg_value) { // value of the regulariser from the forward's per-tile partial sums (fixed order)
     float acc = 0.f;
     if (reg && ws) // (no regulariser: the forward wrote no partial sums and ws may be NULL)
@@ -1124,6 +1169,12 @@ __device__ __forceinline__ void pattern_step_fin(PatSync *sy, unsigned int parti
     if (threadIdx.x == 0) sy->fin = 0u;
   }
 }
+// -DFFX_PATSTAMP (tools/patstamp.py): s_memrealtime (100 MHz) at the launch's milestones, into the unused words of the sync block's first KB
+#ifdef FFX_PATSTAMP
+#define PAT_STAMP(slot) do { if (threadIdx.x == 0) ((unsigned long long *)sy->pad2)[slot] = wall_clock64(); } while (0)
+#else
+#define PAT_STAMP(slot) do { } while (0)
+#endif
 template <int KS>
 __global__ void __launch_bounds__(SPLAT_BLOCK)
     k_pattern_step(float *rays, int n, Mat4 KF, float sigma, int size0, int size1, const float *tsum, const float *tsor, const float *gts, float reg_weight, const float *ws,
@@ -1136,51 +1187,68 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   const unsigned int dot_helpers = adam.dot_a ? (H < (unsigned int)n ? H : (unsigned int)n) : 0u; // the first of them take the data term's n slices
   if (blockIdx.x < (unsigned int)n) {
     const int k = (int)blockIdx.x;
+    if (k == 0) PAT_STAMP(1);
     if (fw.check_kept && tid < 3) { // the texture this step rendered with was made from rays_kept: has anybody edited the pattern since?
       if (__float_as_uint(rays[3 * k + tid]) != __float_as_uint(fw.kept_old[3 * k + tid])) atomicOr(&sy->stale, 1u);
     }
+#ifdef FFX_PATSTAMP
+    pattern_bwd_point<KS>(k, rays, n, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, n_ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, bw, s_win,
+                          k == 1 ? (unsigned long long *)sy->pad2 : nullptr);
+#else
     pattern_bwd_point<KS>(k, rays, n, KF, sigma, size0, size1, tsum, tsor, gts, reg_weight, ws, n_ws, grays_data, grays_reg, reg_value, loss_in, loss_in_n, loss_div, bw, s_win);
+#endif
     __syncthreads();
+    if (k == 1) PAT_STAMP(13);
     if (tid == 0) {
       __threadfence();
+      if (k == 1) PAT_STAMP(14);
       s_flag = atomicAdd(&sy->arrived, 1u) == (unsigned int)n - 1u;
+      if (k == 1) PAT_STAMP(15);
     }
     __syncthreads();
     if (!s_flag) return;
     // ---- every point's gradient is in memory: the update
+    PAT_STAMP(2);
     __threadfence();
+    PAT_STAMP(3);
+    // (the first round's operands are asked for together with the words that decide whether the update is applied: one memory latency, not two)
+    AdamIn in0;
+    if (tid < n && !adam.no_update) adam_load(tid, adam.rays, grays_data, grays_reg, adam.m, adam.v, in0);
     const bool skip = adam.no_update || (adam.guard && adam.guard[2] != 0u);
     const float t = skip ? 0.f : adam.step[0] + 1.0f;
     if (adam.guard && tid < 16) sy->hdr[tid] = adam.guard[tid]; // (what _watch_cache reads: the forward part below clears the header itself)
+    // The pattern the texture is made from goes to the half of rays_kept that NO workgroup of this launch has read: the helpers take it from there with
+    // plain loads and WITHOUT an acquire fence — their XCD's L2 cannot hold that half (it does hold `rays` as they were: the gradient's workgroups
+    // read them).  A fence per helper wave — 4 000 at the same moment, each a write-back + invalidate of a whole L2 — was 60 us of an 80 us launch.
     if (!skip) {
       // beta^t: the running products of the last launch when they belong to step t - 1 and to these betas (one multiply instead of two
       // double-precision pow() in this workgroup's serial tail); pow() otherwise
       double p1, p2;
       if (fw.pow_cache && sy->pw_t == (double)t - 1.0 && sy->pw_b1 == adam.beta1 && sy->pw_b2 == adam.beta2 && t > 1.0f) { p1 = sy->pw1 * adam.beta1; p2 = sy->pw2 * adam.beta2; }
       else { p1 = pow(adam.beta1, (double)t); p2 = pow(adam.beta2, (double)t); }
-      for (int i = tid; i < n; i += SPLAT_BLOCK)
-        adam_clamp_one(i, t, p1, p2, adam.rays, grays_data, grays_reg, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
-                       adam.lo, adam.hi, adam.n_norm);
-      __syncthreads();
+      for (int i = tid; i < n; i += SPLAT_BLOCK) {
+        AdamIn in = in0;
+        if (i != tid) adam_load(i, adam.rays, grays_data, grays_reg, adam.m, adam.v, in);
+        adam_clamp_core(i, t, p1, p2, in, adam.rays, grays_reg != nullptr, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
+                        adam.lo, adam.hi, adam.n_norm, fw.kept_new);
+      }
       if (tid == 0) { sy->pw_t = (double)t; sy->pw_b1 = adam.beta1; sy->pw_b2 = adam.beta2; sy->pw1 = p1; sy->pw2 = p2; adam.step[0] = t; }
+    } else {
+      for (int i = tid; i < 3 * n; i += SPLAT_BLOCK) fw.kept_new[i] = rays[i]; // (the pattern as it was)
     }
-    // The pattern the texture is made from goes to the half of rays_kept that NO workgroup of this launch has read: the helpers take it from there with
-    // plain loads and WITHOUT an acquire fence — their XCD's L2 cannot hold that half (it does hold `rays` as they were: the gradient's workgroups
-    // read them).  A fence per helper wave — 4 000 at the same moment, each a write-back + invalidate of a whole L2 — was 60 us of an 80 us launch.
-    // (every thread copies the rays it has written itself)
-    for (int i = tid; i < n; i += SPLAT_BLOCK) {
-      fw.kept_new[3 * i] = rays[3 * i]; fw.kept_new[3 * i + 1] = rays[3 * i + 1]; fw.kept_new[3 * i + 2] = rays[3 * i + 2];
-    }
+    PAT_STAMP(4);
     __syncthreads();
     if (tid < PAT_GO_COPIES) {
       if (tid == 0) sy->arrived = 0u; // (re-armed for the next launch: nobody else touches it any more)
       __threadfence();
       __hip_atomic_exchange(&sy->go[tid].v, fw.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PAT_STAMP(5);
     if (dot_helpers && reg_value) pattern_step_fin(sy, dot_helpers + 1u, n, adam, reg_value, loss_div);
     return;
   }
   const unsigned int h = blockIdx.x - (unsigned int)n; // helper h of H
+  if (h == H - 1u) PAT_STAMP(6);
   if (h < dot_helpers) {
     for (unsigned int sl = h; sl < (unsigned int)n; sl += H) { pattern_dot_slice((int)sl, n, adam); __syncthreads(); }
     if (reg_value) pattern_step_fin(sy, dot_helpers + 1u, n, adam, reg_value, loss_div);
@@ -1198,6 +1266,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
   __syncthreads();
   if (!s_flag) return;
   asm volatile("" ::: "memory"); // (no fence: see kept_new above; the loads below are issued behind the poll that saw the flag)
+  if (h == H - 1u) PAT_STAMP(7);
   if (fw.zero)
     for (long t = (long)h * SPLAT_BLOCK + tid; t < fw.n_zero; t += (long)H * SPLAT_BLOCK) fw.zero[t] = 0.f;
   const unsigned int n_tiles = (unsigned int)(fw.nbx * fw.nby);
@@ -1206,6 +1275,7 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
                              fw.tsor, fw.ws, bw, fw.tex);
     __syncthreads();
   }
+  if (h == H - 1u) PAT_STAMP(8);
 }
 
 // Adam (the arithmetic of torch.optim.Adam's fused kernel: lerp of the first moment, bias corrections from the

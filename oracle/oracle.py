@@ -156,11 +156,42 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
             part = np.zeros(n, np.float32)
             aa.dot_a, aa.dot_b, aa.dot_n, aa.dot_partial = da.ctypes.data, db.ctypes.data, int(da.size), part.ctypes.data
             aa.dot_b_n = int(db.size)
+        if adam.get("guard") is not None:  # an adjoint cache's header (uint8 array): dropped != 0 -> the update is not applied
+            aa.guard = adam["guard"].ctypes.data
     api().call("ffx_pattern_bwd_blur", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(_f32(tsum)), _p(_f32(tsor)) if tsor is not None else None,
                _p(gtex) if gtex is not None else None, float(reg_weight), _p(_f32(ws)) if ws is not None else None, _p(gd), _p(gr), _p(val),
                _p(li) if li is not None else None, 0 if li is None else int(li.size), float(loss_div), int(ksize), float(blur_sigma), None,
                C.byref(aa) if aa is not None else None, None)
     return (gd, gr, val) if adam is None else (gd, gr, val, gout)
+
+
+def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, blur_sigma, adam, zero, sync, rays_kept, epoch, check_kept=False, loss_in=None, loss_div=1.0):
+    """ffx_pattern_step: pattern_bwd_blur(..., adam) on bufs = (pts, tsum, tsor, ws, tex) of this step, then pattern_fwd_blur of the next into the same arrays (in place, as rays,
+    adam's state, zero, sync [uint8, FFX_PATTERN_SYNC_BYTES] and rays_kept [2, n, 3] are) -> (grays_data, grays_reg, [3] values, grad_out)"""
+    import ctypes as C
+
+    from fireflies_amd import _abi
+
+    pts, tsum, tsor, ws, tex = bufs
+    assert rays.dtype == np.float32 and rays.flags.c_contiguous and sync.dtype == np.uint8 and sync.size >= _abi.PATTERN_SYNC_BYTES
+    n = rays.shape[0]
+    gd, gr, val, gout = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(3, np.float32), np.zeros((n, 3), np.float32)
+    li = None if loss_in is None else _f32(loss_in).reshape(-1)
+    aa = _abi.AdamArgs()
+    aa.rays = rays.ctypes.data
+    aa.exp_avg, aa.exp_avg_sq, aa.step = adam["exp_avg"].ctypes.data, adam["exp_avg_sq"].ctypes.data, adam["step"].ctypes.data
+    aa.grad_out = gout.ctypes.data
+    aa.lr, aa.beta1, aa.beta2, aa.eps = float(adam["lr"]), float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"])
+    aa.KF_inv = _m16(adam["KF_inv"])
+    aa.lo, aa.hi, aa.grad_div, aa.n_normalize = float(adam["lo"]), float(adam["hi"]), float(adam.get("grad_div", 1.0)), int(adam.get("n_normalize", 1))
+    guard = adam.get("guard")
+    if guard is not None:
+        aa.guard = guard.ctypes.data
+    api().call("ffx_pattern_step", _p(rays), n, _m16(KF), float(sigma), size0, size1, _p(tsum), _p(tsor) if tsor is not None else None, _p(gtex) if gtex is not None else None,
+               float(reg_weight), _p(ws) if ws is not None else None, _p(gd), _p(gr), _p(val), _p(li) if li is not None else None, 0 if li is None else int(li.size), float(loss_div),
+               int(ksize), float(blur_sigma), C.byref(aa), _p(pts), _p(zero) if zero is not None else None, 0 if zero is None else int(zero.size), _p(tex), _p(rays_kept),
+               int(bool(check_kept)), sync.ctypes.data, int(epoch), None)
+    return gd, gr, val, gout
 
 
 def adam_clamp_step(rays, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, KF, KF_inv, lo, hi, n_normalize=1, guard=None):

@@ -455,6 +455,52 @@ def test_round3_entry_points_are_the_compositions_they_replace(oracle):
     assert float(val3[2]) == float(val2[2])
 
 
+def test_pattern_step_is_the_composition_it_replaces(oracle):
+    """ffx_pattern_step (include/ffx.h, round 6) as the oracle implements it: pattern_bwd_blur with the update, then pattern_fwd_blur of the updated
+    pattern into the same buffers, the accumulator cleared, the guard's header copied to the sync words, the kept pattern in the half of rays_kept
+    the epoch names and the comparison with the other half — bit for bit the separate calls, over three steps."""
+    from fireflies_amd import _abi
+
+    sc = scenes.vocalfold(width=40, height=32, tex=48, frames=2, n_fold=12, tube=(16, 16))
+    K = sc.projector.K.astype(np.float64)
+    KF = (K @ np.diag([1.0, -1.0, 1.0, 1.0])).astype(np.float32)
+    KFi = np.linalg.inv(KF.astype(np.float64)).astype(np.float32)
+    rng = np.random.default_rng(5)
+    ndc = (rng.random((12, 3)) * [0.9, 0.9, 0.0] + [0.05, 0.05, 0.5]).astype(np.float32)
+    rays = oracle.transform_points(ndc, KFi)
+    rays = (rays / np.linalg.norm(rays, axis=1, keepdims=True)).astype(np.float32)
+    s0 = s1 = 48
+    r_a, m_a, v_a, st_a = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    r_b, m_b, v_b, st_b = rays.copy(), np.zeros_like(rays), np.zeros_like(rays), np.zeros(1, np.float32)
+    buf_a = oracle.pattern_fwd_blur(r_a, KF, 10.0, s0, s1, 5, 3.0, True)
+    buf_b = tuple(x.copy() for x in buf_a)
+    sync = np.zeros(_abi.PATTERN_SYNC_BYTES, np.uint8)
+    kept = np.zeros((2, 12, 3), np.float32)
+    for k in range(3):
+        acc = np.zeros(s0 * s1 + 5 + 16, np.float32)
+        acc[:s0 * s1] = rng.standard_normal(s0 * s1).astype(np.float32)
+        acc[s0 * s1:s0 * s1 + 5] = rng.standard_normal(5).astype(np.float32)
+        hdr = np.array([4096 + (3 if k == 1 else 0), 4096, 3 if k == 1 else 0] + [0] * 13, np.int32)  # (step 1 is not applied)
+        acc[s0 * s1 + 5:].view(np.int32)[:] = hdr
+        acc_b = acc.copy()
+        ad = lambda m, v, st, g: dict(exp_avg=m, exp_avg_sq=v, step=st, lr=5e-3, beta1=0.9, beta2=0.999, eps=1e-8, KF_inv=KFi, lo=0.05, hi=0.95, grad_div=2.0, n_normalize=2, guard=g)  # noqa: E731
+        gd, gr, val, g_a = oracle.pattern_bwd_blur(r_a, KF, 10.0, s0, s1, buf_a[1], buf_a[2], acc[:s0 * s1].reshape(s1, s0), 0.1, buf_a[3], 5, 3.0,
+                                                   loss_in=acc[s0 * s1:s0 * s1 + 5], loss_div=2.0, adam=ad(m_a, v_a, st_a, acc[s0 * s1 + 5:].view(np.uint8)))
+        buf_a = oracle.pattern_fwd_blur(r_a, KF, 10.0, s0, s1, 5, 3.0, True)
+        gd2, gr2, val2, g_b = oracle.pattern_step(r_b, KF, 10.0, s0, s1, buf_b, acc_b[:s0 * s1].reshape(s1, s0), 0.1, 5, 3.0, ad(m_b, v_b, st_b, acc_b[s0 * s1 + 5:].view(np.uint8)),
+                                                  acc_b, sync, kept, epoch=k + 1, check_kept=k > 0, loss_in=acc_b[s0 * s1:s0 * s1 + 5], loss_div=2.0)
+        for a, b in ((gd, gd2), (gr, gr2), (val, val2), (r_a, r_b), (m_a, m_b), (v_a, v_b), (st_a, st_b)) + tuple(zip(buf_a, buf_b)):
+            np.testing.assert_array_equal(a, b)
+        if k != 1:
+            np.testing.assert_array_equal(g_a, g_b)
+        assert not acc_b.any() and (sync.view(np.int32)[18:34] == hdr).all() and sync.view(np.int32)[4] == 0
+        np.testing.assert_array_equal(kept[(k + 1) & 1], r_b)
+    assert st_b[0] == 2.0
+    r_b[0, 0] += 1e-3  # an edit between two steps: the next call is told to compare
+    oracle.pattern_step(r_b, KF, 10.0, s0, s1, buf_b, np.zeros((s1, s0), np.float32), 0.1, 5, 3.0, ad(m_b, v_b, st_b, None), None, sync, kept, epoch=4, check_kept=True)
+    assert sync.view(np.int32)[4] == 1
+
+
 def test_l1_value_grad(oracle):
     """weight * L1Loss(a, b) (rasterization.py:579,589-600) and its gradient with respect to a"""
     rng = np.random.default_rng(2)

@@ -1,3 +1,5 @@
+"""patparse.py (CPU) — splits the kernel trace of `rocprofv3 --kernel-trace --output-format csv -d gpurun_out/patprof -- python3 tools/patbench.py 100` into the variants
+patbench.py runs one after the other (110 launches each): median / min / max kernel duration per variant."""
 import csv, glob, statistics
 f = glob.glob('gpurun_out/patprof/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
