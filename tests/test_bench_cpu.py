@@ -154,7 +154,7 @@ def test_every_profile_the_bench_line_cites_exists_is_not_empty_and_names_kernel
         assert not stale, f"profiles/{name} names kernels that are not in csrc/ any more: {stale}"
     g = json.load(open(os.path.join(ROOT, "profiles", f"{tag}grad_pmc_summary.json")))
     assert any(bench.k8_instance(k)[0] for k in g), "no counters for the forward + adjoint launch the gradient bracket times"
-    for want in ("k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached", "k_bin<"):
+    for want in ("k_pattern_step<5>", "k_render_bwd_cached", "k_bin<"):  # (round 6: the pattern side of a step is one launch)
         assert any(k.startswith(want) for k in g), f"the gradient bracket's PMC summary lacks {want}"
     stats = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()
     assert "k_render_fwd_pk<1, true, 1, false, false" in stats and "k_bin<true" in stats  # (<R, WIDE, MATM, ADJ, RF[, RFC]>: the plain forward)

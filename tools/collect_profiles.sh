@@ -90,7 +90,7 @@ python - "$TAG" <<'PYEOF' || FAILED="$FAILED kernel-names"
 import json, sys
 tag = sys.argv[1]
 g = json.load(open(f"profiles/{tag}grad_pmc_summary.json"))
-want = ["k_render_fwd_pk<", "k_pattern_fwd_blur<2>", "k_pattern_bwd<5>", "k_render_bwd_cached"]
+want = ["k_render_fwd_pk<", "k_pattern_step<5>", "k_render_bwd_cached"]  # (round 6: the pattern side of a step is ONE launch)
 missing = [w for w in want if not any(k.startswith(w) for k in g)]
 def adjoint_instance(k):  # k_render_fwd_pk<R, WIDE, MATM, ADJ, RF>
     import re

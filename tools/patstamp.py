@@ -29,6 +29,8 @@ def main():
              "(unused)", "point 1: list + window staged", "point 1: texel loop done", "point 1: gradient stored", "point 1: (k = 0 extras)", "point 1: fence done", "point 1: arrived"]
     print(f"{len(rows)} launches; us after point 0's workgroup started (median / min / max)")
     for i, nm in enumerate(names):
+        if nm == "(unused)":
+            continue
         col = [r[i] for r in rows]
         print(f"  [{i + 1}] {nm:26s} {statistics.median(col):7.2f} {min(col):7.2f} {max(col):7.2f}")
 
