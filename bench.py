@@ -823,7 +823,7 @@ def main():
                 "grad_ms_per_step_nonlinear": 1e3 * t_grad2 / args.steps,
                 "grad_nonlinear_config": {"loss": "torch.nn.L1Loss()(img, target) against a fixed target render (optim.image_l1_loss): its gradient depends on the image",
                                           "step_paths": dict(opt2.step_paths),
-                                          "launches_per_step": "render_fwd_cache, l1_value_grad (+ add), render_bwd_cached, pattern_step<5> (+ re-fit and apex records on the side stream)"},
+                                          "launches_per_step": "render_fwd_cache, render_bwd_cached_l1 [the L1 loss's value and gradient formed inside K9], pattern_step<5> (+ re-fit and apex records on the side stream)"},
                 "grad_nonlinear_kernels_ms": {"render_fwd(+cache write)": k8g2_ms, "render_bwd_cached": k9c2_ms, "render_bwd(retrace)": k9r2_ms},
                 "render_bwd_cached_roofline": None if k9c2_ms is None else {
                     "kernel": "k_render_bwd_cached_tiled16 (scatters the per-pixel texture footprints written by K8)", "bound": "hbm",

@@ -239,6 +239,7 @@ PROTOTYPES = {
     "ffx_render_cache_bytes_sd": (C.c_size_t, [C.POINTER(SceneDesc), c_i]),
     "ffx_render_fwd_cache": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),
     "ffx_render_bwd_cached": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "ffx_render_bwd_cached_l1": (c_i, [C.POINTER(SceneDesc), c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_p]),  # sd, mats, cache, spp, img, target, weight, gtex, slots, stream
     "ffx_render_dot_slots": (C.c_size_t, [c_i, c_i]),
     "ffx_render_filter_bytes": (C.c_size_t, [C.POINTER(SceneDesc)]),
     "ffx_render_fwd_filtered": (c_i, [c_p, C.POINTER(BvhInfo), C.POINTER(SceneDesc), c_p, c_p, c_i, C.c_uint32, c_i, c_p, c_p, c_p]),

@@ -3561,8 +3561,23 @@ __global__ void __launch_bounds__(PK_BLOCK) __attribute__((amdgpu_waves_per_eu(M
 // pixel slots): one lane per stray sample record, four taps each.
 struct BwdP { int tw, th, tc, spp; float color[3]; float inv_spp; int W, H; int ms; size_t off_foot_b; // ms: floats per material row (3 / FFX_MAT_STRIDE)
               const void *img; int img_fp16; float *dot_out; int dot_slots; // optional: sum(dot_out[0 .. dot_slots)) += <gimg, img> (the value of a linear loss whose gradient gimg is)
+              const float *l1_tgt; float l1_gs, l1_vs; // optional (ffx_render_bwd_cached_l1): gimg = the gradient of l1_vs * sum |img - l1_tgt|, formed per pixel
               const float *mats; int mat_inline; float mat_h[FFX_MAX_MAT_H]; }; // the material table: the caller's device array or (ffx_scene_desc.mat_h) this kernel argument
 __device__ __forceinline__ const float *mat_table(const BwdP &k) { return k.mat_inline ? k.mat_h : k.mats; }
+// the loss gradient at a pixel: the caller's gimg, or (l1_tgt) the L1 loss's own — sign(img - target) * weight / n, the arithmetic of k_l1_partial
+// (ffx_l1_value_grad) — with the pixel's |img - target| for the loss value
+__device__ __forceinline__ void k9_g(const BwdP &p, const float *__restrict__ gimg, long pixel, float &g0, float &g1, float &g2, float *absum = nullptr) {
+  if (p.l1_tgt) {
+    const float *q = (const float *)p.img + pixel * 3, *t = p.l1_tgt + pixel * 3;
+    const float d0 = q[0] - t[0], d1 = q[1] - t[1], d2 = q[2] - t[2];
+    g0 = d0 > 0.f ? p.l1_gs : (d0 < 0.f ? -p.l1_gs : 0.f);
+    g1 = d1 > 0.f ? p.l1_gs : (d1 < 0.f ? -p.l1_gs : 0.f);
+    g2 = d2 > 0.f ? p.l1_gs : (d2 < 0.f ? -p.l1_gs : 0.f);
+    if (absum) *absum = (fabsf(d0) + fabsf(d1)) + fabsf(d2);
+    return;
+  }
+  g0 = gimg[pixel * 3]; g1 = gimg[pixel * 3 + 1]; g2 = gimg[pixel * 3 + 2];
+}
 __device__ __forceinline__ float k9_pixel_dot(const BwdP &p, long pixel, const float *__restrict__ gimg) {
   const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
   if (p.img_fp16) {
@@ -3585,7 +3600,8 @@ __device__ __forceinline__ void k9_stray(const char *__restrict__ cache, long n_
   if (i >= n) return;
   const CacheStray rec = reinterpret_cast<const CacheStray *>(cache + cache_off_arena((size_t)n_pix))[i];
   const long pixel = rec.pix;
-  const float g0 = gimg[pixel * 3], g1 = gimg[pixel * 3 + 1], g2 = gimg[pixel * 3 + 2];
+  float g0, g1, g2;
+  k9_g(p, gimg, pixel, g0, g1, g2);
   const int ix0 = (int)(rec.xy_shape & 0xfffu) - 1, iy0 = (int)((rec.xy_shape >> 12) & 0xfffu) - 1, shape = (int)(rec.xy_shape >> 24);
   const int x0 = clampi(ix0, 0, p.tw - 1), x1 = clampi(ix0 + 1, 0, p.tw - 1), y0 = clampi(iy0, 0, p.th - 1), y1 = clampi(iy0 + 1, 0, p.th - 1);
   const float wx0 = 1.0f - rec.ax, wx1 = rec.ax, wy0 = 1.0f - rec.ay, wy1 = rec.ay;
@@ -3727,8 +3743,12 @@ __global__ void __launch_bounds__(256)
     hp.lit = 0;
     if (in) hp = hdrs[pixel];
     const bool lit = in && hp.lit;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (in && (p.dot_out || lit)) { g0 = gimg[pixel * 3]; g1 = gimg[pixel * 3 + 1]; g2 = gimg[pixel * 3 + 2]; }
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, l1_abs = 0.f;
+    if (in && (p.dot_out || lit)) k9_g(p, gimg, pixel, g0, g1, g2, &l1_abs);
+    if (p.l1_tgt) { // the L1 loss's value: this wave's 4 rows of |img - target|, one add into the block's own slot (summed by the gradient launch)
+      const float d = wave_sum64(l1_abs);
+      if ((threadIdx.x & 63) == 0 && d != 0.f) atomicAdd(p.dot_out + (int)blockIdx.x % p.dot_slots, d * p.l1_vs);
+    }
     const wmask lm = wballot(lit);
     if (lm != 0ull) { // (per wave) origin of the tile and the wave's share of the list
       int base = 0;
@@ -3745,7 +3765,7 @@ __global__ void __launch_bounds__(256)
         s_wsb[k] = (g0 * p.color[0] + g1 * p.color[1] + g2 * p.color[2]) * p.inv_spp;
       }
     }
-    if (p.dot_out) { // <gimg, img> of this wave's 4 rows: one add into the block's own slot (ffx_render_dot_slots)
+    if (p.dot_out && !p.l1_tgt) { // <gimg, img> of this wave's 4 rows: one add into the block's own slot (ffx_render_dot_slots)
       float d = 0.f;
       if (in) {
         if (p.img_fp16) { const _Float16 *q = (const _Float16 *)p.img + pixel * 3; d = g0 * (float)q[0] + g1 * (float)q[1] + g2 * (float)q[2]; }
@@ -4775,9 +4795,25 @@ size_t ffx_render_dot_slots(int width, int height) {
   return b < 256 ? b : 256;
 }
 
+static int render_bwd_cached_impl(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
+                                  int img_fp16, float *dot_out, const float *l1_target, float l1_weight, ffx_stream s);
 int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
                           int img_fp16, float *dot_out, ffx_stream s) {
-  if (!sd || (!shape_albedo && sd->n_mat_h <= 0) || !cache || !gimg || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  if (!gimg) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
+  return render_bwd_cached_impl(sd, shape_albedo, cache, spp, gimg, gtex, img, img_fp16, dot_out, nullptr, 0.f, s);
+}
+// K9 under an L1 loss against a target image (include/ffx.h): the loss launch (ffx_l1_value_grad) and its gradient image are folded into the scatter
+int ffx_render_bwd_cached_l1(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *img, const float *target, float weight,
+                             float *gtex, float *loss_slots, ffx_stream s) {
+  if (!img || !target || !loss_slots) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached_l1: bad argument");
+  if (sd && (!sd->proj.enabled || sd->proj.tex_channels != 1)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_l1: a projector with a one-channel texture (else ffx_l1_value_grad + ffx_render_bwd_cached)");
+  const char *k9e = getenv("FFX_K9_BLOCK");
+  if (k9e && atoi(k9e) == 8) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_l1: only the 16x16-block kernel carries the loss");
+  return render_bwd_cached_impl(sd, shape_albedo, cache, spp, nullptr, gtex, img, 0, loss_slots, target, weight, s);
+}
+static int render_bwd_cached_impl(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *gimg, float *gtex, const void *img,
+                                  int img_fp16, float *dot_out, const float *l1_target, float l1_weight, ffx_stream s) {
+  if (!sd || (!shape_albedo && sd->n_mat_h <= 0) || !cache || (!gimg && !l1_target) || !gtex || spp < 1 || (dot_out && !img)) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad argument");
   if (sd->rfilter != FFX_RFILTER_BOX) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: the scene's reconstruction filter is not the box (use ffx_render_bwd_filtered)");
   if (!sd->proj.enabled) {
     if (dot_out) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached: <gimg, img> is accumulated by the footprint kernel, which a scene without projector does not launch");
@@ -4794,6 +4830,10 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   }
   p.img = dot_out ? img : nullptr; p.img_fp16 = img_fp16 & 1; p.dot_out = dot_out;
   p.dot_slots = (int)ffx_render_dot_slots(sd->cam.width, sd->cam.height);
+  if (l1_target) { // (sign(img - target) * weight / n per element; value weight / n * sum |img - target|: ffx_l1_value_grad's)
+    const float n_el = 3.0f * (float)sd->cam.width * (float)sd->cam.height;
+    p.l1_tgt = l1_target; p.l1_gs = l1_weight / n_el; p.l1_vs = l1_weight / n_el;
+  }
   p.tw = sd->proj.tex_w; p.th = sd->proj.tex_h; p.tc = sd->proj.tex_channels; p.spp = spp;
   if (p.tw < 1 || p.th < 1 || (p.tc != 1 && p.tc != 3) || sd->cam.width < 1 || sd->cam.height < 1) FFX_FAIL(FFX_ERR_ARG, "render_bwd_cached: bad scene description");
   for (int i = 0; i < 3; ++i) p.color[i] = sd->proj.color[i];

@@ -977,6 +977,20 @@ class DeviceGeometry:
                        int(img is not None and img.dtype == torch.float16), _dev(dot_out) if dot_out is not None else None, _stream(self._didx))
         return gtex
 
+    def render_bwd_cached_l1(self, sd, albedo, cache, spp, img, target, weight, out, loss_slots):
+        """K9 under weight * L1Loss(img, target) (ffx_render_bwd_cached_l1): the loss's gradient image is formed inside the scatter launch and the loss value
+        goes to `loss_slots` (render_dot_slots(W, H) float32 partial sums) — no loss launch, no gradient image.  -> `out`, or None when the library
+        declines the case (FFX_ERR_UNSUPPORTED: the caller takes ffx_l1_value_grad + render_bwd_cached)."""
+        if sd.rfilter or img.dtype != torch.float32 or target.dtype != torch.float32 or tuple(img.shape) != (sd.cam.height, sd.cam.width, 3) or tuple(target.shape) != tuple(img.shape):
+            return None
+        if loss_slots.dtype != torch.float32 or loss_slots.numel() != render_dot_slots(sd.cam.width, sd.cam.height):
+            raise ValueError("loss_slots must be render_dot_slots(W, H) float32 partial sums")
+        mats_arg = _check_materials(sd, albedo)
+        with self._timed("render_bwd_cached"):
+            rc = api().call_rc("ffx_render_bwd_cached_l1", C.byref(sd), mats_arg, _dev(cache, torch.uint8, "cache"), int(spp), _dev(img, name="img"), _dev(target, name="target"),
+                               float(weight), _dev(out), _dev(loss_slots), _stream(self._didx), allow=(_abi.FFX_ERR_UNSUPPORTED,))
+        return out if rc == 0 else None
+
     def render_bwd_det_part(self, sd, albedo, spp, seed, gimg, part, acc, scale_log2=0):
         """ONE pass of the deterministic re-tracing adjoint (ffx_render_bwd_det_part): part 1 — the largest |tap| of this render into the int32
         word `acc` (the float's bits; maximum over calls); part 2 — every tap as a 64-bit fixed-point integer at 2^scale_log2 into the int64

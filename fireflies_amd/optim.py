@@ -99,6 +99,7 @@ def image_l1_loss(target):
     loss.value_and_grad = value_and_grad
     loss.accumulate_value_and_grad = accumulate
     loss.target = tgt
+    loss.l1_target = (tgt, 1.0)  # (target, weight): PatternOptimizer folds value and gradient into K9 (ffx_render_bwd_cached_l1)
     return loss
 
 
@@ -331,7 +332,10 @@ class PatternOptimizer:
                     self._lin_g = linear(torch.empty((cam.height, cam.width, 3), device=tex.device)).float().contiguous()
                 if getattr(self, "_img_stack", None) is None or tuple(self._img_stack.shape) != (len(seeds), cam.height, cam.width, 3):
                     self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
-                geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache, sparse_adjoint=True, img_out=self._img_stack[k_sample])
+                # (the pattern launch has cleared the cache's header: the step's first render has nothing to reset — no k_cache_reset launch in front of it)
+                geom.render_fwd(sd, mats, tex3, self.spp, seed, False, cache=self._cache, sparse_adjoint=True, img_out=self._img_stack[k_sample],
+                                cache_zeroed=header_clear, keep_dropped=not header_clear)
+                header_clear = False
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, self._lin_g, out=gtex, seed=seed)
                 k_sample += 1
                 self.step_paths["cache_k9"] += 1
@@ -346,6 +350,12 @@ class PatternOptimizer:
                 # loss(img) = <gimg, img>: K9 adds it to loss_sum while it scatters the footprints (no reduction launch)
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, linear(img), out=gtex, img=img, dot_out=loss_slots)
                 continue
+            l1t = getattr(self.loss_fn, "l1_target", None)
+            if l1t is not None and use_cache and not sd.rfilter and os.environ.get("FFX_K9_L1", "1") != "0":
+                # the reference's own loss, L1 against a target image: K9 forms sign(img - target) / n per pixel itself and adds the loss value to the step's
+                # slots — no loss launches (two), no gradient image (ffx_render_bwd_cached_l1; declined cases take the general route below)
+                if geom.render_bwd_cached_l1(sd, mats, self._cache, self.spp, img, l1t[0], l1t[1], gtex, loss_slots) is not None:
+                    continue
             if fast_loss is not None:
                 gimg = fast_loss(img, loss_sum)
             else:

@@ -814,6 +814,15 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd /*[host]*/, const float *shap
                           const void *cache /*[dev]*/, int spp, const float *gimg /*[dev][H,W,3] fp32*/,
                           float *gtex /*[dev][tex_h,tex_w,tex_channels]*/, const void *img /*[dev][H,W,3] or NULL*/, int img_fp16,
                           float *dot_out /*[dev][ffx_render_dot_slots] or NULL*/, ffx_stream stream);
+/* K9 under the reference's own loss (ABI 10): loss = weight * torch.nn.L1Loss()(img, target) (fireflies/graphics/rasterization.py:579,596-602) and its
+ * backward through the render, in the scatter launch itself.  Per pixel the launch forms gimg = sign(img - target) * weight / (3 W H) — the arithmetic of
+ * ffx_l1_value_grad — instead of reading it, and adds weight / (3 W H) * sum |img - target| of every 16x16-pixel block to loss_slots[block mod
+ * ffx_render_dot_slots] (the caller zeroes them and sums them, e.g. ffx_pattern_bwd_blur's loss_in): ffx_l1_value_grad (two launches, a [H,W,3]
+ * gradient image written and read back) + ffx_render_bwd_cached in ONE launch.  gtex as ffx_render_bwd_cached's up to the order of the float atomics,
+ * the loss value up to the order of its partial sums.  fp32 image, projector with a one-channel texture; FFX_ERR_UNSUPPORTED otherwise. */
+int ffx_render_bwd_cached_l1(const ffx_scene_desc *sd /*[host]*/, const float *shape_albedo /*[dev] or NULL with sd->mat_h*/, const void *cache /*[dev]*/,
+                             int spp, const float *img /*[dev][H,W,3] fp32*/, const float *target /*[dev][H,W,3] fp32*/, float weight,
+                             float *gtex /*[dev][tex_h,tex_w,1]*/, float *loss_slots /*[dev][ffx_render_dot_slots]*/, ffx_stream stream);
 /* The cache is lossy when its arena of single-sample records fills up (a projector texture much finer than the camera's
  * pixel footprint, grazing views: most samples then miss their pixel's 5x5 window).  Samples beyond the arena are counted
  * in `dropped` and ffx_render_bwd_cached then poisons gtex[0] with NaN instead of returning a gradient with silent holes.

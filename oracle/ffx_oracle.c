@@ -1732,6 +1732,23 @@ int ffx_render_bwd_cached(const ffx_scene_desc *sd, const float *shape_albedo, c
   return FFX_OK;
 }
 
+/* K9 under weight * L1Loss(img, target) (include/ffx.h ffx_render_bwd_cached_l1, ABI 10): the composition it stands for —
+ *   fireflies/graphics/rasterization.py:579,596-602   loss = L1Loss()(img, target); loss.backward()    [ffx_l1_value_grad: value and sign(img - target) w / n]
+ *   ... through the render's adjoint                                                                    [ffx_render_bwd_cached]
+ * the loss value added to loss_slots[0] (the caller sums the slots). */
+int ffx_render_bwd_cached_l1(const ffx_scene_desc *sd, const float *shape_albedo, const void *cache, int spp, const float *img, const float *target, float weight,
+                             float *gtex, float *loss_slots, ffx_stream s) {
+  if (!sd || !img || !target || !loss_slots) FAIL(FFX_ERR_ARG, "render_bwd_cached_l1: bad argument");
+  if (!sd->proj.enabled || sd->proj.tex_channels != 1) FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_l1: a projector with a one-channel texture");
+  const long n = 3L * sd->cam.width * sd->cam.height;
+  float *g = (float *)malloc(sizeof(float) * (size_t)n), v = 0.f;
+  int rc = ffx_l1_value_grad(img, target, n, weight, &v, g, s);
+  if (rc == FFX_OK) rc = ffx_render_bwd_cached(sd, shape_albedo, cache, spp, g, gtex, NULL, 0, NULL, s);
+  if (rc == FFX_OK) loss_slots[0] += v;
+  free(g);
+  return rc;
+}
+
 /* The adjoints trace in PARALLEL and accumulate SERIALLY: a block of pixels is shaded by all threads into a table of sample_terms,
  * then one thread adds the block's samples to the double accumulator in sample order — the sums see their operands in the order a
  * plain serial loop would give them (deterministic for any thread count), at the speed of the forward render. */

@@ -405,6 +405,15 @@ class Geometry:
                    _p(dot), None)
         return gtex, float(dot[0])
 
+    @staticmethod
+    def render_bwd_cached_l1(sd, albedo, cache, spp, img, target, weight):
+        """ffx_render_bwd_cached_l1 -> (gtex, weight * L1Loss(img, target))"""
+        albedo, img, target = _f32(albedo), _f32(img), _f32(target)
+        gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)
+        slots = np.zeros(int(api().lib.ffx_render_dot_slots(sd.cam.width, sd.cam.height)), np.float32)
+        api().call("ffx_render_bwd_cached_l1", C.byref(sd), _p(albedo), _p(np.ascontiguousarray(cache)), spp, _p(img), _p(target), float(weight), _p(gtex), _p(slots), None)
+        return gtex, float(slots.sum())
+
     def render_bwd(self, sd, albedo, spp, seed, gimg):
         albedo, gimg = _f32(albedo), _f32(gimg)
         gtex = np.zeros((sd.proj.tex_h, sd.proj.tex_w, sd.proj.tex_channels), np.float32)

@@ -829,6 +829,13 @@ def test_one_pattern_launch_between_two_renders(monkeypatch):
         assert c1 == {"fwd": 1, "step": 6} and s1 == s0 == 6.0 and o1.step_paths["fused" if loss_kind == "linear" else "cache_k9"] == 12
         torch.testing.assert_close(r1, r0, rtol=1e-4, atol=1e-5)
         assert l1 == pytest.approx(l0, rel=1e-4, abs=1e-7)
+        if loss_kind == "l1":  # ... and the L1 loss folded into K9 (ffx_render_bwd_cached_l1, the default) against the loss launch + K9
+            monkeypatch.setenv("FFX_K9_L1", "0")
+            r2, l2, _, _, s2, _, o2 = run(True, loss_kind)
+            monkeypatch.delenv("FFX_K9_L1")
+            assert s2 == 6.0 and o2.step_paths["cache_k9"] == 12
+            torch.testing.assert_close(r1, r2, rtol=1e-4, atol=1e-5)
+            assert l1 == pytest.approx(l2, rel=1e-4, abs=1e-7)
     # an edit behind torch's back: the texture made ahead is stale, the next launch notices, the watch raises
     *_, opt = run(True, "linear", steps=2)
     with torch.no_grad():

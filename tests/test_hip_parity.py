@@ -1140,6 +1140,28 @@ def test_k9_cached_adjoint_matches_retrace_and_oracle(oracle, ch, k9_block, monk
             gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img_c)
         with pytest.raises(ValueError):
             gd.render_bwd_cached(sd, dev(alb), cache, spp, dev(gimg), img=img16, dot_out=torch.zeros(1, device="cuda"))
+        # K9 under the reference's own loss, L1 against a target image (ffx_render_bwd_cached_l1, round 6): the scatter launch forms the loss's
+        # gradient per pixel and emits the loss value into the slots — against ffx_l1_value_grad + ffx_render_bwd_cached and the oracle's composition
+        # (the stray records replay the same per-pixel gradient)
+        tgt = (host(img_c) + rng.standard_normal(host(img_c).shape).astype(np.float32) * 0.05).astype(np.float32)
+        eq = rng.random(tgt.shape) < 0.1
+        tgt[eq] = host(img_c)[eq]  # (exact ties: gradient 0)
+        v_sep, g_sep = ops.l1_value_grad(img_c.reshape(-1), dev(tgt).reshape(-1), weight=0.7)
+        gt_sep = host(gd.render_bwd_cached(sd, dev(alb), cache, spp, g_sep.view(img_c.shape)))
+        slots = torch.zeros(n_slots, device="cuda")
+        gt_l1 = torch.zeros((sd.proj.tex_h, sd.proj.tex_w, ch), device="cuda")
+        res = gd.render_bwd_cached_l1(sd, dev(alb), cache, spp, img_c, dev(tgt), 0.7, gt_l1, slots)
+        if ch == 1 and k9_block == "16":
+            assert res is gt_l1
+            assert np.abs(host(gt_l1) - gt_sep).max() <= 1e-4 * max(float(np.abs(gt_sep).max()), 1e-20)  # (float atomics: order only)
+            assert float(slots.double().sum()) == pytest.approx(float(v_sep), rel=5e-6)
+            gt_o, v_o = go.render_bwd_cached_l1(sd, alb, cache_o, spp, host(img_c), tgt, 0.7)
+            err = np.abs(host(gt_l1) - gt_o)
+            sc_o = float(np.abs(gt_o).max())
+            assert (err > 1e-3 * sc_o).mean() <= 1e-3 and err.max() <= 0.1 * sc_o
+            assert v_o == pytest.approx(float(v_sep), rel=1e-5)
+        else:  # (three-channel textures and the 8x8-block kernel: declined, nothing written)
+            assert res is None and float(gt_l1.abs().max()) == 0.0 and float(slots.abs().max()) == 0.0
         scale = float(np.abs(g_oracle).max())
         assert scale > 0
         for a, b in ((g_cached, g_retrace), (g_cached, g_oracle), (g_oracle, go.render_bwd(sd, alb, spp, 3, gimg))):

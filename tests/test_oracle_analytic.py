@@ -501,6 +501,24 @@ def test_pattern_step_is_the_composition_it_replaces(oracle):
     assert sync.view(np.int32)[4] == 1
 
 
+def test_k9_under_the_l1_loss_is_the_composition_it_replaces(oracle):
+    """ffx_render_bwd_cached_l1 (include/ffx.h, round 6) as the oracle implements it: ffx_l1_value_grad's gradient through ffx_render_bwd_cached, the
+    loss value in the slots — bit for bit the separate calls."""
+    sc = scenes.vocalfold(width=40, height=32, tex=48, frames=2, n_fold=12, tube=(16, 16))
+    pool, tris, shape, off, stride, nfr, alb = scenes.flatten(sc)
+    g = oracle.Geometry(pool, tris, shape, off)
+    sd = scene_desc.scene_desc(sc, tex_channels=1, shadows=True)
+    rng = np.random.default_rng(7)
+    tex = rng.random((48, 48, 1)).astype(np.float32)
+    img, cache = g.render_fwd_cache(sd, alb, tex, 4, seed=2)
+    tgt = (img + rng.standard_normal(img.shape).astype(np.float32) * 0.05).astype(np.float32)
+    v, gi = oracle.l1_value_grad(img.reshape(-1), tgt.reshape(-1), 0.5)
+    gtex_a = g.render_bwd_cached(sd, alb, cache, 4, gi.reshape(img.shape))
+    gtex_b, v_b = g.render_bwd_cached_l1(sd, alb, cache, 4, img, tgt, 0.5)
+    np.testing.assert_array_equal(gtex_a, gtex_b)
+    assert v_b == float(v) and float(np.abs(gtex_b).max()) > 0
+
+
 def test_l1_value_grad(oracle):
     """weight * L1Loss(a, b) (rasterization.py:579,589-600) and its gradient with respect to a"""
     rng = np.random.default_rng(2)
