@@ -184,11 +184,13 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
 _pattern_epochs = {}
 
 
-def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, blur_sigma, adam, zero, sync, rays_kept=None, check_kept=False, loss_in=None, loss_div=1.0):
+def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, blur_sigma, adam, zero, sync, rays_kept=None, check_kept=False, loss_in=None, loss_div=1.0,
+                 epoch=None):
     """The pattern side of a step as ONE launch (ffx_pattern_step): pattern_bwd_blur(..., adam) on `bufs` = (pts, tsum, tsor, ws, tex) of THIS step,
     then — behind the update, in the same launch — pattern_fwd_blur of the NEXT step into the same five tensors, `zero` cleared.
     -> (grays_data, grays_reg, [3] loss values), or None when the library declines the shape (FFX_ERR_UNSUPPORTED: the caller issues the two launches).
-    `sync`: uint8 tensor of _abi.PATTERN_SYNC_BYTES, zero before the first call."""
+    `sync`: uint8 tensor of _abi.PATTERN_SYNC_BYTES, zero before the first call; rays_kept: float32 [2, n, 3]; epoch: 1, 2, 3, ... per launch on this pair of
+    buffers (None: counted here)."""
     pts, tsum, tsor, ws, tex = bufs
     n = rays.shape[0]
     gd = torch.empty((n, 3), dtype=torch.float32, device=rays.device) if gtex is not None else None
@@ -196,13 +198,16 @@ def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, b
     val = torch.empty(3, dtype=torch.float32, device=rays.device)
     if sync.numel() < _abi.PATTERN_SYNC_BYTES or sync.dtype != torch.uint8:
         raise ValueError("pattern_step: sync must be a uint8 tensor of PATTERN_SYNC_BYTES")
-    # the launch's epoch: a count of the launches on this sync buffer (kept here, by the buffer's address and allocation: a new tensor starts at 1)
     if rays_kept is None or rays_kept.numel() != 6 * n:
         raise ValueError("pattern_step: rays_kept must be a float32 tensor [2, n, 3]")
-    key = (sync.data_ptr(), id(sync.untyped_storage()), rays_kept.data_ptr())
-    epoch = _pattern_epochs.get(key, 0) % 0xFFFFFFF0 + 1
-    if len(_pattern_epochs) > 256 and key not in _pattern_epochs:
-        _pattern_epochs.clear()
+    # the launch's epoch: the caller's count of the launches on this (sync, rays_kept) pair — or, for callers that keep none, a count kept here by the
+    # buffers' addresses (a pair that was zeroed and is used again under the same addresses continues the old count: any value but the flags' works)
+    key = None
+    if epoch is None:
+        key = (sync.data_ptr(), rays_kept.data_ptr())
+        epoch = _pattern_epochs.get(key, 0) % 0xFFFFFFF0 + 1
+        if len(_pattern_epochs) > 256 and key not in _pattern_epochs:
+            _pattern_epochs.clear()
     rc = api().call_rc("ffx_pattern_step", _dev(rays, name="rays"), n, _m16(KF), float(sigma), int(size0), int(size1), _dev(tsum, name="tsum"),
                        _dev(tsor, name="tsor") if tsor is not None else None, _dev(gtex, name="gtex") if gtex is not None else None, float(reg_weight),
                        _dev(ws, name="ws") if ws is not None else None, _dev(gd) if gd is not None else None, _dev(gr) if gr is not None else None, _dev(val),
@@ -212,7 +217,8 @@ def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, b
                        int(bool(check_kept)), _dev(sync, torch.uint8, "sync"), epoch, _stream(), allow=(_abi.FFX_ERR_UNSUPPORTED,))
     if rc != 0:
         return None
-    _pattern_epochs[key] = epoch
+    if key is not None:
+        _pattern_epochs[key] = epoch
     return gd, gr, val
 
 

@@ -417,14 +417,18 @@ class PatternOptimizer:
             if self.blur and bk == 5 and g2 is not None and os.environ.get("FFX_PATTERN_STEP", "1") != "0":
                 # ... and (round 6) the NEXT step's K1 + K2 + K3 behind the update, in the same launch (ffx_pattern_step): between two renders of a
                 # one-sample step there is ONE launch.  The library declines footprints that do not fit its LDS window: the two launches then
-                if getattr(self, "_pat_sync", None) is None:
-                    self._pat_sync = torch.zeros(_abi.PATTERN_SYNC_BYTES, dtype=torch.uint8, device=rd.device)
                 if getattr(self, "_rays_kept", None) is None or tuple(self._rays_kept.shape[1:]) != tuple(rd.shape):
+                    # (the sync words, the kept pattern and the count of launches on them belong together: flags that still hold an old epoch must
+                    # never meet a count that starts again)
+                    self._pat_sync = torch.zeros(_abi.PATTERN_SYNC_BYTES, dtype=torch.uint8, device=rd.device)
                     self._rays_kept = torch.empty((2,) + tuple(rd.shape), dtype=torch.float32, device=rd.device)
+                    self._pat_epoch = 0
                     used_premade = False  # (nothing kept to compare with)
                 res = ops.pattern_step(rd, KF, self.sigma, s0, s1, self._pat_buf, g2, reg_w, bk, bs, aa, self._acc, self._pat_sync, rays_kept=self._rays_kept,
-                                       check_kept=used_premade, loss_in=None if dot is not None else loss_slots, loss_div=float(S))
+                                       check_kept=used_premade, loss_in=None if dot is not None else loss_slots, loss_div=float(S),
+                                       epoch=self._pat_epoch % 0xFFFFFFF0 + 1)
                 if res is not None:
+                    self._pat_epoch += 1
                     self._premade = self._premade_key(rays, KF, want_reg, self._pat_buf)
                     self._merged_last = True
             if res is None:
