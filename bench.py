@@ -876,6 +876,12 @@ def main():
                         for k in range(2):
                             mats = ms.materials_arg(sd)
                             geom_g.render_fwd(sd, mats, tex3, args.spp, 55 + k, False, cache=cache)
+                            used, cap, dropped = ops.render_cache_status(cache)
+                            if dropped:  # (the arena of 64-sample blocks is a quarter of the dense size beyond 2^18 blocks: a pose that lights more of the film
+                                # overflows it — counted, the adjoint poisoned, PatternOptimizer re-traces from then on: nothing to compare here)
+                                preflight["gradient_gaussian_nonlinear"] = {"checked": f"the adjoint cache's arena overflowed on this pose ({dropped} blocks beyond {cap}): "
+                                                                                       "the optimiser takes the re-tracing adjoint (ffx_render_bwd_filtered)", "adjoints": 0}
+                                return
                             a = geom_g.render_bwd_cached(sd, mats, cache, args.spp, gimg, seed=55 + k)
                             b = geom_g.render_bwd(sd, mats, args.spp, 55 + k, gimg)
                             worst = max(worst, _adjoint_close(a, b, "filtered film: cached adjoint vs re-traced adjoint"))
