@@ -2639,18 +2639,20 @@ __host__ __device__ inline size_t cache_off_foot_b(size_t n_pix, size_t cap_stra
 //   rfc_off_wsum           float per pixel
 //   rfc_off_recs           uint4 per sample slot of the arena's blocks
 //   rfc_off_facb           float per sample slot (material rows)
-__host__ __device__ inline size_t rfc_cap_blocks(size_t n_pix, size_t spp) {
+__host__ __device__ inline size_t rfc_cap_blocks(size_t n_pix, size_t spp, bool all = false) {
   // every pass of every pixel up to 2^18 blocks (335 MB with material rows: 512 x 512 x 64 spp keeps a block per pixel and cannot overflow,
   // whatever the texture), a QUARTER of them beyond: 1024 x 1024 x 256 — 1.05 M blocks, 1.34 GB instead of 5.4 GB.  (A tenth, 0.54 GB, was
   // tried first: BASELINE configs[4]'s own 1 024-point pattern lights 17 % of the film — 178 k pixels x 4 passes — and 73 k of them found no block.)
+  // `all` (ffx_scene_desc.shadows & FFX_SHADOWS_CACHE_DENSE: the caller's answer to an overflow): a block for every pass of every pixel
   const size_t dense = n_pix * ((spp + 63) / 64), part = dense / 4, keep = (size_t)1 << 18;
   const size_t n = part > keep ? part : keep;
-  return n < dense ? n : dense;
+  return (all || n >= dense) ? dense : n;
 }
 __host__ __device__ inline size_t rfc_off_wsum(size_t n_pix) { return (64 + 8 * n_pix + 127) & ~(size_t)127; }
 __host__ __device__ inline size_t rfc_off_recs(size_t n_pix) { return (rfc_off_wsum(n_pix) + 4 * n_pix + 127) & ~(size_t)127; }
-__host__ __device__ inline size_t rfc_off_facb(size_t n_pix, size_t spp) { return (rfc_off_recs(n_pix) + 16 * 64 * rfc_cap_blocks(n_pix, spp) + 127) & ~(size_t)127; }
-__host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat) { return rfc_off_facb(n_pix, spp) + (mat ? ((4 * 64 * rfc_cap_blocks(n_pix, spp) + 127) & ~(size_t)127) : 0); }
+__host__ __device__ inline size_t rfc_off_facb(size_t n_pix, size_t spp, bool all) { return (rfc_off_recs(n_pix) + 16 * 64 * rfc_cap_blocks(n_pix, spp, all) + 127) & ~(size_t)127; }
+__host__ __device__ inline size_t rfc_bytes(size_t n_pix, size_t spp, bool mat, bool all) { return rfc_off_facb(n_pix, spp, all) + (mat ? ((4 * 64 * rfc_cap_blocks(n_pix, spp, all) + 127) & ~(size_t)127) : 0); }
+static inline bool rfc_all(const ffx_scene_desc *sd) { return (sd->shadows & FFX_SHADOWS_CACHE_DENSE) != 0; }
 
 
 // ---- reconstruction filter that spreads a sample over its 5x5-pixel window (include/ffx.h, ffx_scene_desc.rfilter) -------------------------
@@ -4053,7 +4055,7 @@ static int shade_prepare(const ffx_scene_desc *sd, ShadeK &c) {
   if (!cam_prepare(&sd->cam, c.cam)) return 0;
   c.proj_on = sd->proj.enabled;
   c.spot_on = sd->spot.enabled;
-  c.shadows = sd->shadows;
+  c.shadows = sd->shadows & FFX_SHADOWS_ON; // (the word's other bits are hints to the pre-pass and the caches)
   c.mat_stride = sd->mat_stride ? sd->mat_stride : 3;
   if (c.mat_stride != 3 && c.mat_stride != FFX_MAT_STRIDE) return 0;
   if (sd->n_mat_h > 0) { // the material table travels with the call (ffx_scene_desc.mat_h)
@@ -4314,7 +4316,7 @@ static void bins_grids(const ffx_scene_desc *sd, BinGrid (&g)[FFX_N_APEX], float
 // fell from 2 400 to 1 810 renders/s (spot only; 1 580 with the projector's 68-entry tiles too).  FFX_SHADOW_CLEAR=2 / 3 switches it on.
 static int clear_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
   const char *e = getenv("FFX_SHADOW_CLEAR");
-  if (!(sd && sd->shadows && info->off_gn != 0 && bins_enabled())) return 0;
+  if (!(sd && (sd->shadows & FFX_SHADOWS_ON) && info->off_gn != 0 && bins_enabled())) return 0;
   const int m = e ? atoi(e) : 0;
   return (m < 0 || m > 3) ? 0 : m;
 }
@@ -4322,7 +4324,7 @@ static int clear_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
 // emitters (bit 0 projector, bit 1 spot).  A pure function of (sd, info, environment), like the grids: the pre-pass and the renders behind it agree.
 static int env_enabled(const ffx_scene_desc *sd, const ffx_bvh_info *info) {
   const char *e = getenv("FFX_ENVELOPE");
-  if (!(sd && sd->shadows && bins_enabled() && info->off_bins)) return 0;
+  if (!(sd && (sd->shadows & FFX_SHADOWS_ON) && bins_enabled() && info->off_bins)) return 0;
   if (sd->shadows & FFX_SHADOWS_PLAIN) return 0; // (the caller's hint: this pose's renders are short — the envelope launch would only lengthen the pre-pass chain)
   if (info->bins_stride < ffx_bin_stride(info->n_tris) || ffx_bin_off_env(info->n_tris) >= (1ull << 32)) return 0; // (a blob of another library version)
   const int m = e ? atoi(e) : 3;
@@ -4606,7 +4608,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
     const TriApex *arecs;
     uint32_t astride;
     // (capacity of the cache's arena: single-sample records of the box film's footprint cache / 64-sample blocks of the filtered film's record cache)
-    uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : (rf_cache ? (uint32_t)rfc_cap_blocks((size_t)c.cam.W * c.cam.H, (size_t)spp) : 0u);
+    uint32_t cap_stray = cache ? (uint32_t)cache_stray_capacity(c.cam.W, c.cam.H, spp) : (rf_cache ? (uint32_t)rfc_cap_blocks((size_t)c.cam.W * c.cam.H, (size_t)spp, rfc_all(sd)) : 0u);
     if (rf_cache)
       if (const char *ce = getenv("FFX_RFC_CAP")) { // (test knob, include/ffx.h: fewer blocks than the cache has room for — the overflow path)
         const long cv = atol(ce);
@@ -4653,7 +4655,7 @@ static int render_fwd_impl(const void *bvh, const ffx_bvh_info *info, const ffx_
       if (sd->proj.enabled && (sd->proj.tex_w > 4094 || sd->proj.tex_h > 4094 || sd->n_shapes > 255)) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: texture larger than 4094^2 or more than 255 shapes");
       if (spp > 1024) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_fwd_cache_filtered: more than 1024 samples per pixel (16 passes)");
       const size_t n_pix = (size_t)c.cam.W * c.cam.H;
-      const uint32_t recs_off = (uint32_t)(rfc_off_recs(n_pix) >> 7), facb_off = (uint32_t)(rfc_off_facb(n_pix, (size_t)spp) >> 7);
+      const uint32_t recs_off = (uint32_t)(rfc_off_recs(n_pix) >> 7), facb_off = (uint32_t)(rfc_off_facb(n_pix, (size_t)spp, rfc_all(sd)) >> 7);
 #define FFX_LAUNCH_RFC(MAT_)                                                                                                                              \
   hipLaunchKernelGGL((k_render_fwd_pk<1, true, MAT_, false, true, true>), dim3(pgrid), dim3(64 * wpb), dummy_lds(), (hipStream_t)s, c, nodes, recs, arecs, astride, ws, \
                      shape_albedo, tex, spp, seed_key_of(seed), ptx, pn, xcd_mode((long)c.cam.W * c.cam.H), img_fp16, img, (char *)rf_scratch, ppw,       \
@@ -4746,7 +4748,7 @@ size_t ffx_render_cache_bytes(int width, int height, int spp) {
 
 size_t ffx_render_cache_bytes_sd(const ffx_scene_desc *sd, int spp) {
   if (!sd || sd->cam.width < 1 || sd->cam.height < 1 || spp < 1) return 0;
-  if (sd->rfilter != FFX_RFILTER_BOX) return rfc_bytes((size_t)sd->cam.width * sd->cam.height, (size_t)spp, sd->mat_stride == FFX_MAT_STRIDE); // the filtered film's cache
+  if (sd->rfilter != FFX_RFILTER_BOX) return rfc_bytes((size_t)sd->cam.width * sd->cam.height, (size_t)spp, sd->mat_stride == FFX_MAT_STRIDE, rfc_all(sd)); // the filtered film's cache
   if (sd->mat_stride != FFX_MAT_STRIDE) return ffx_render_cache_bytes(sd->cam.width, sd->cam.height, spp);
   const size_t n_pix = (size_t)sd->cam.width * sd->cam.height;
   return cache_off_foot_b(n_pix, cache_stray_capacity(sd->cam.width, sd->cam.height, spp)) + sizeof(CacheFoot) * n_pix;
@@ -5088,7 +5090,7 @@ int ffx_render_bwd_cached_filtered(const ffx_scene_desc *sd, const float *shape_
   p.n_shapes = sd->n_shapes;
   if (p.n_shapes < 1 || p.n_shapes > 255) FFX_FAIL(FFX_ERR_UNSUPPORTED, "render_bwd_cached_filtered: 1 .. 255 shapes");
   const size_t n_pix = (size_t)p.W * p.H;
-  p.off_wsum = rfc_off_wsum(n_pix); p.off_recs = rfc_off_recs(n_pix); p.off_facb = rfc_off_facb(n_pix, (size_t)spp);
+  p.off_wsum = rfc_off_wsum(n_pix); p.off_recs = rfc_off_recs(n_pix); p.off_facb = rfc_off_facb(n_pix, (size_t)spp, rfc_all(sd));
   const int blocks_x = ffx_cdiv(p.W, K9F_BLOCK), blocks_y = ffx_cdiv(p.H, K9F_BLOCK);
   hipLaunchKernelGGL(k_render_bwd_cached_filtered, dim3(blocks_x * blocks_y * K9F_SUB), dim3(64), 0, (hipStream_t)s, p, (const char *)cache, blocks_x, gimg, gtex);
   FFX_CHECK_LAUNCH("render_bwd_cached_filtered");

@@ -1010,7 +1010,21 @@ class Scene:
 
     def _shadows_word(self):
         """include/ffx.h ffx_scene_desc.shadows: on / off, plus the hint that this scene's renders are short (note_spp)"""
-        return 0 if not self.shadows else (3 if self._low_spp else 1)
+        return (0 if not self.shadows else (3 if self._low_spp else 1)) | (4 if getattr(self, "_cache_dense", False) else 0)
+
+    def set_cache_dense(self, dense=True):
+        """FFX_SHADOWS_CACHE_DENSE for the descriptions to come: the filtered film's adjoint cache with a block for every pass of every pixel (it cannot
+        overflow) instead of the arena's share — PatternOptimizer's answer to an overflow.  Like note_spp: templates and the finished description take
+        the new word, nothing is rebuilt."""
+        dense = bool(dense)
+        if dense != getattr(self, "_cache_dense", False):
+            self._cache_dense = dense
+            bit = 4 if dense else 0
+            for ch, (tkey, keep) in list(self._sd_templates.items()):
+                keep.shadows = (int(keep.shadows) & ~4) | bit
+                self._sd_templates[ch] = ((int(keep.shadows),) + tuple(tkey[1:]), keep)
+            if self._sd_cache is not None:  # (only this bit: the finished description keeps the pre-pass hint it was prepared with)
+                self._sd_cache[1].shadows = (int(self._sd_cache[1].shadows) & ~4) | bit
 
     def note_spp(self, spp):
         """called by whoever renders this scene with `spp` samples per pixel: below 33 the pre-pass of the NEXT poses leaves the emitters' envelopes

@@ -438,7 +438,7 @@ class PatternOptimizer:
             loss = val[1]
         rays.grad = grad
         self.step_index += 1
-        self._watch_cache()
+        self._watch_cache(every=1 if self.step_index <= 4 else 32)  # (an arena that is too small shows in the first steps)
         return {"loss": loss}
 
     def _premade_key(self, rays, KF, want_reg, buf):
@@ -485,6 +485,15 @@ class PatternOptimizer:
                         f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed on this rank ({dropped} samples beyond its {cap} single-sample "
                         "records); the updates since then were skipped on every rank (rays and Adam state are intact). Set FFX_CACHE_LIMIT_GB=0 "
                         "(re-tracing adjoint) on all ranks and continue.")
+                if getattr(self.mi_scene, "_rfilter", None) is not None and not getattr(self.mi_scene, "_cache_dense", False):
+                    # the filtered film's cache: an arena with a share of the blocks (a quarter beyond 2^18) — a pattern that lights more of the film than
+                    # that gets the dense layout (FFX_SHADOWS_CACHE_DENSE: cannot overflow) instead of the re-tracing adjoint
+                    self.mi_scene.set_cache_dense(True)
+                    self._arena = None
+                    self._premade = None  # (the accumulator moves with the arena)
+                    warnings.warn(f"PatternOptimizer: the filtered film's adjoint cache of step {w[2]} overflowed ({dropped} blocks beyond its {cap}); the updates of the "
+                                  "affected steps were skipped; from now on the cache keeps a block for every pass of every pixel.", stacklevel=3)
+                    return
                 self._cache_overflowed = True
                 self._arena = None
                 warnings.warn(f"PatternOptimizer: the adjoint cache of step {w[2]} overflowed ({dropped} samples beyond its {cap} single-sample records: a projector "

@@ -575,7 +575,7 @@ typedef struct ffx_scene_desc {
   ffx_camera cam;
   ffx_projector proj;
   ffx_spot spot;
-  int32_t shadows;    /* != 0: trace shadow rays toward both emitters.  Bit 1 (FFX_SHADOWS_PLAIN, round 6) is a HINT of the caller to the pre-pass
+  int32_t shadows;    /* bit 0 (FFX_SHADOWS_ON): trace shadow rays toward both emitters.  Bit 2: FFX_SHADOWS_CACHE_DENSE, below.  Bit 1 (FFX_SHADOWS_PLAIN, round 6) is a HINT of the caller to the pre-pass
                          (ffx_apex_prepare / ffx_scene_step_h): the renders of this pose are short (fewer than ~33 samples per pixel) — the emitters'
                          envelopes (DESIGN.md 5.1 "round 6"), which let most shadow packets skip their any-hit stage, are then not built, and the spot's
                          tile grid is coarser (1.2 instead of 2 tiles per degree of cutoff): a shorter chain for a short render to wait for.
@@ -616,6 +616,9 @@ typedef struct ffx_scene_desc {
 } ffx_scene_desc;
 #define FFX_SHADOWS_ON 1
 #define FFX_SHADOWS_PLAIN 2
+#define FFX_SHADOWS_CACHE_DENSE 4 /* shadows bit 2 (ABI 10) — not about shadows: the filtered film's adjoint cache (ffx_render_fwd_cache_filtered) gets a block for
+                                   * every pass of every pixel instead of the arena's share (a quarter beyond 2^18 blocks): ffx_render_cache_bytes_sd answers
+                                   * the dense size (5.4 GB at 1024 x 1024 x 256), the cache cannot overflow.  A caller's answer to `dropped` != 0. */
 #define FFX_RFILTER_BOX 0
 #define FFX_RFILTER_GAUSSIAN 1
 #define FFX_MAX_MAT_H 128

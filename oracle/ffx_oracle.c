@@ -1183,7 +1183,7 @@ static int shade_prepare(const ffx_scene_desc *sd, shade_ctx *c) {
   if (!cam_prepare(&sd->cam, &c->cam)) return 0;
   c->proj_on = sd->proj.enabled;
   c->spot_on = sd->spot.enabled;
-  c->shadows = sd->shadows;
+  c->shadows = sd->shadows & FFX_SHADOWS_ON; /* (the other bits: hints to the HIP library's pre-pass and caches) */
   c->mats = NULL;
   c->mat_stride = sd->mat_stride ? sd->mat_stride : 3;
   if (c->mat_stride != 3 && c->mat_stride != FFX_MAT_STRIDE) return 0;

@@ -854,6 +854,51 @@ def test_one_pattern_launch_between_two_renders(monkeypatch):
         torch.cuda.synchronize()
 
 
+def test_filtered_cache_overflow_grows_to_the_dense_layout_before_it_re_traces(monkeypatch):
+    """The filtered film's adjoint cache is an arena with a share of the blocks; a pattern that lights more of the film than that overflows it (config 5
+    does, on its denser poses).  The optimiser's answer, in this order: the updates of the affected steps are skipped (rays and Adam state intact), the scene
+    gets FFX_SHADOWS_CACHE_DENSE — a block for every pass of every pixel, the size ffx_render_cache_bytes_sd then answers —, and only if THAT overflows
+    too (here: the test knob FFX_RFC_CAP keeps the capacity at two blocks whatever the layout) the re-tracing adjoint.  The watch looks at every one of
+    the first steps, so the switch happens within a few."""
+    import warnings
+
+    from fireflies_amd import ops
+    from fireflies_amd.optim import image_l1_loss
+
+    wl = _small()
+    wl.mi_scene.rfilter = "gaussian"
+    with torch.no_grad():
+        target = mi.render(wl.mi_scene, spp=4, seed=99).torch().clone()
+    opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=43, loss_fn=image_l1_loss(target))
+    sd = wl.mi_scene.scene_desc(tex_channels=1)
+    share = ops.render_cache_bytes_sd(sd, 4)
+    rays0 = wl.laser._rays.detach().clone()
+    monkeypatch.setenv("FFX_RFC_CAP", "2")
+    seen = []
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for k in range(12):
+            opt.step()
+            torch.cuda.synchronize()
+            seen.append((bool(getattr(wl.mi_scene, "_cache_dense", False)), bool(getattr(opt, "_cache_overflowed", False)), torch.equal(wl.laser._rays.detach(), rays0)))
+    msgs = [str(r.message) for r in rec if "adjoint cache" in str(r.message)]
+    assert any("a block for every pass" in m for m in msgs) and any("re-tracing adjoint" in m for m in msgs), msgs
+    first_dense = next(i for i, v in enumerate(seen) if v[0])
+    first_retrace = next(i for i, v in enumerate(seen) if v[1])
+    assert first_dense < first_retrace <= 8, seen
+    assert all(v[2] for v in seen[:first_retrace]), seen  # no update was applied while the gradient was incomplete
+    assert not seen[-1][2] and opt.step_paths["retrace"] > 0  # ... and the run goes on, re-tracing
+    # the dense layout's size: what the description now asks for (the small film keeps a block per pass either way: equal here, larger beyond 2^18 blocks)
+    assert ops.render_cache_bytes_sd(wl.mi_scene.scene_desc(tex_channels=1), 4) >= share and int(wl.mi_scene.scene_desc(tex_channels=1).shadows) & 4
+    monkeypatch.delenv("FFX_RFC_CAP")
+    # without the knob the dense layout holds: a second optimiser on the same scene keeps its cache
+    opt2 = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=44, loss_fn=image_l1_loss(target))
+    for _ in range(6):
+        opt2.step()
+        torch.cuda.synchronize()
+    assert not getattr(opt2, "_cache_overflowed", False) and opt2.step_paths["cache_k9"] == 6
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the launcher starts two fresh rank processes (here both on
     the one device, transport gloo — FFX_DIST_BACKEND=gloo is the explicit opt-in for that; on a node with >= 2 GPUs the

@@ -2123,6 +2123,19 @@ def test_filtered_film_adjoint_cache_is_an_arena_at_config_5_size(oracle):
     sb = float(b[nz].abs().max())
     eb = (a[nz] - b[nz]).abs()
     assert sb > 0 and float((eb > 1e-3 * sb).float().mean()) <= 2e-3 and float(eb.max()) <= 0.1 * sb
+    # the caller's answer to an overflow (the bench's loop reaches poses on which this pattern lights 26 % of the block-passes): the DENSE layout,
+    # FFX_SHADOWS_CACHE_DENSE in the description — a block for every pass of every pixel, handed out without atomics; same records, same gradient
+    del cache
+    wl.mi_scene.set_cache_dense(True)
+    sdd = wl.mi_scene.scene_desc(tex_channels=1)
+    nd = ops.render_cache_bytes_sd(sdd, 256)
+    assert int(sdd.shadows) & 4 and 5.0e9 <= nd <= 5.6e9, (int(sdd.shadows), nd)
+    cache = torch.empty(nd, dtype=torch.uint8, device="cuda")
+    img_d = g.render_fwd(sdd, matsb, tex3, 256, seed=2, cache=cache, sparse_adjoint=True)
+    assert torch.equal(img_d, img) and ops.render_cache_status(cache) == (0, 1024 * 1024 * 4, 0)
+    a_d = g.render_bwd_cached(sdd, matsb, cache, 256, gb, seed=2)
+    ed = (a_d[nz] - b[nz]).abs()
+    assert float((ed > 1e-3 * sb).float().mean()) <= 2e-3 and float(ed.max()) <= 0.1 * sb
 
 
 @pytest.mark.parametrize("ch,rows,spp,stddev", [(1, "albedo", 8, 0.5), (3, "albedo", 8, 0.5), (1, "material_rows", 70, 0.5), (1, "albedo", 5, 0.3)])
