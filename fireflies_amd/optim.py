@@ -269,6 +269,7 @@ class PatternOptimizer:
             self._ahead = ((self.step_index + 1, tuple(nxt)), self.ff_scene.randomize_batch(nxt, lazy=True))
         fast_loss = getattr(self.loss_fn, "accumulate_value_and_grad", None)
         k_sample = 0
+        used_rs = []
         det = ops.deterministic_mode() and bool(sd0.proj.enabled)
         if det:
             # FFX_DETERMINISTIC=1 (round 6): a step whose result does not depend on the number of ranks, BIT FOR BIT.  Every sample's texture gradient
@@ -320,7 +321,22 @@ class PatternOptimizer:
                 # a quarter of a million atomics per render, 27 us, and only used when a step has several samples)
                 if getattr(self, "_img_stack", None) is None or tuple(self._img_stack.shape) != (len(seeds), cam.height, cam.width, 3):
                     self._img_stack = torch.empty((len(seeds), cam.height, cam.width, 3), dtype=torch.float32, device=tex.device)
-                geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
+                # (round 6) a step of SEVERAL samples: their fused launches are independent of each other — each adds its adjoint to gtex with atomics and
+                # writes its own image of the stack — and take the scene's two render streams in turn, as consecutive mi.render calls do: the tail of one
+                # launch runs beside the head of the next (FFX_STEP_STREAMS=1: one after the other on the caller's stream)
+                rs_list = getattr(ms, "_render_streams", None)
+                if len(seeds) > 1 and rs_list is not None and os.environ.get("FFX_STEP_STREAMS", "2") != "1":
+                    if k_sample == 0:
+                        step_ready = torch.cuda.Event()
+                        step_ready.record()  # (the texture, the cleared accumulator, the constant gradient: everything issued on the caller's stream so far)
+                    rs = rs_list[k_sample & 1]
+                    if rs not in used_rs:
+                        rs.wait_event(step_ready)
+                        used_rs.append(rs)
+                    with torch.cuda.stream(rs):
+                        geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
+                else:
+                    geom.render_fwd_adjoint(sd, ms.materials_arg(sd), tex3, self.spp, seed, self._lin_g, out=gtex, sparse_adjoint=True, img_out=self._img_stack[k_sample])
                 k_sample += 1
                 self.step_paths["fused"] += 1
                 continue
@@ -367,6 +383,8 @@ class PatternOptimizer:
                 geom.render_bwd_cached(sd, mats, self._cache, self.spp, gimg, out=gtex, seed=seed if sd.rfilter else None)
             else:
                 gtex += geom.render_bwd(sd, mats, self.spp, seed, gimg).reshape(gtex.shape)
+        for rs in used_rs:  # (the step's renders on the render streams: the gradient launch waits for them)
+            torch.cuda.current_stream().wait_stream(rs)
         # back through K3^T, K2-bwd, K1-bwd for this rank's share; the regulariser depends on the pattern only
         # K3^T is applied inside the gradient launch, over the points' footprints only (ffx_pattern_bwd_blur: the gradient of the separate
         # transpose blur + ffx_pattern_bwd, bit for bit)
