@@ -529,7 +529,7 @@ class Scene:
         # the re-fit of its blob); the image is handed out as _RenderedXf.
         self._render_streams = None
         if self.device.type == "cuda" and os.environ.get("FFX_RENDER_STREAMS", "2") != "1":
-            self._render_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            self._render_streams = list(ops.shared_streams(self.device, "render", 2))  # (the process's pair on this device: ops.shared_streams)
             self._render_done = [[torch.cuda.Event() for _ in range(4)] for _ in range(2)]
         self._render_turn = 0
         # which path each mi.render of this scene took (bench.py prints it): "two_stream" = beside the previous render on the scene's

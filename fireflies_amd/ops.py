@@ -184,6 +184,19 @@ def pattern_bwd_blur(rays, KF, sigma, size0, size1, tsum, tsor, gtex, reg_weight
 _pattern_epochs = {}
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_streams(device, role, n, priority=0):
+    """the process's n streams of `role` on `device` (created on first use): every scene / geometry of the device takes the same ones"""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), role, int(priority))
+    got = _SHARED_STREAMS.setdefault(key, [])
+    while len(got) < n:
+        got.append(torch.cuda.Stream(dev, priority=int(priority)))
+    return got[:n]
+
+
 def pattern_step(rays, KF, sigma, size0, size1, bufs, gtex, reg_weight, ksize, blur_sigma, adam, zero, sync, rays_kept=None, check_kept=False, loss_in=None, loss_div=1.0,
                  epoch=None):
     """The pattern side of a step as ONE launch (ffx_pattern_step): pattern_bwd_blur(..., adam) on `bufs` = (pts, tsum, tsor, ws, tex) of THIS step,
@@ -568,7 +581,10 @@ class DeviceGeometry:
         self._cur = 0
         # (FFX_SIDE_PRIORITY: -1 = a high-priority queue for the side stream; measured: renders/s unchanged, gradient steps 2 130 -> 1 540 per
         # second — the step's small launches on the main stream then wait behind it.  0 = default)
-        self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("FFX_SIDE_PRIORITY", "0"))) if self._async else None
+        # (round 6: ONE side stream — and one pair of render streams, shared_streams below — per device and process, not per geometry: the streams of a
+        # scene that was used a moment ago keep their hardware queues, and a second scene's own streams then share what is left — its consecutive renders
+        # lost their overlap: configs[4] behind a two-stream bracket of the vocal fold, 125 -> 118 renders/s, K8 alone unchanged)
+        self._side = shared_streams(self.device, "side", 1, int(os.environ.get("FFX_SIDE_PRIORITY", "0")))[0] if self._async else None
         # (round 6, a measured negative result kept as a knob) FFX_SIDE_STREAMS=n: a side stream per blob copy, so that the chains of consecutive
         # poses — re-fit -> count -> scan -> fill [-> envelopes], five or six dependent launches of mostly latency — overlap each other instead of
         # queueing on one stream (each writes its own copy; what they share is read-only).  With 4 streams the loops LOSE a quarter (principled
