@@ -854,6 +854,29 @@ def test_one_pattern_launch_between_two_renders(monkeypatch):
         torch.cuda.synchronize()
 
 
+def test_multi_sample_steps_on_two_render_streams_and_streams_shared_by_scenes(monkeypatch):
+    """Round 6: a step of several scene samples issues its fused render launches in turn on the scene's two render streams (the gradient launch waits
+    for both) — the same run as on the caller's stream alone (FFX_STEP_STREAMS=1) up to the order of the float atomics; and every scene of a device
+    takes the process's ONE side stream and ONE pair of render streams (a second scene's own streams used to share hardware queues with the first's)."""
+    from fireflies_amd import ops
+
+    def run(streams):
+        monkeypatch.setenv("FFX_STEP_STREAMS", streams)
+        wl = _small()
+        opt = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, base_seed=47, samples_per_step=5)
+        losses = [float(opt.step()["loss"]) for _ in range(4)]
+        return wl, opt, losses, wl.laser._rays.detach().clone()
+
+    wl2, opt2, l2, r2 = run("2")
+    wl1, opt1, l1, r1 = run("1")
+    assert opt2.step_paths["fused"] == opt1.step_paths["fused"] == 20
+    torch.testing.assert_close(r2, r1, rtol=1e-4, atol=1e-5)
+    assert l2 == pytest.approx(l1, rel=1e-4, abs=1e-7)
+    a, b = wl1.mi_scene, wl2.mi_scene
+    assert a is not b and a._render_streams is not None and all(x is y for x, y in zip(a._render_streams, b._render_streams))
+    assert a.geom._side is b.geom._side and a.geom._side is ops.shared_streams(a.geom.device, "side", 1)[0]
+
+
 def test_filtered_cache_overflow_grows_to_the_dense_layout_before_it_re_traces(monkeypatch):
     """The filtered film's adjoint cache is an arena with a share of the blocks; a pattern that lights more of the film than that overflows it (config 5
     does, on its denser poses).  The optimiser's answer, in this order: the updates of the affected steps are skipped (rays and Adam state intact), the scene
