@@ -1232,6 +1232,9 @@ __global__ void __launch_bounds__(SPLAT_BLOCK)
         adam_clamp_core(i, t, p1, p2, in, adam.rays, grays_reg != nullptr, adam.grad_div, adam.grad_out, adam.m, adam.v, adam.lr, adam.beta1, adam.beta2, adam.eps, KF.m, adam.KI.m,
                         adam.lo, adam.hi, adam.n_norm, fw.kept_new);
       }
+      // (the step count and the running products are written BEHIND the barrier below: every wave of this workgroup reads them above — a wave that
+      // read them late would take the next step's count)
+      __syncthreads();
       if (tid == 0) { sy->pw_t = (double)t; sy->pw_b1 = adam.beta1; sy->pw_b2 = adam.beta2; sy->pw1 = p1; sy->pw2 = p2; adam.step[0] = t; }
     } else {
       for (int i = tid; i < 3 * n; i += SPLAT_BLOCK) fw.kept_new[i] = rays[i]; // (the pattern as it was)
