@@ -422,6 +422,7 @@ class PatternOptimizer:
             # grad = gsum / S (+ regulariser, identical on every rank); Adam; Laser.clamp_to_fov() + normalize_rays()
             ops.adam_clamp_step_(rd, gsum, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], KF, self.laser._KF_inv,
                                  1 - 0.95, 0.95, 2, grad_b=gr, grad_div=float(S), grad_out=grad, guard=flat[n3 - 1:])
+            self.laser._edits = getattr(self.laser, "_edits", 0) + 1
             self._last_flat = flat  # (kept alive until the update has run; tests read the exchanged count)
         else:
             # nothing to exchange: the whole backward half is ONE launch — gradient of the data term and of the regulariser, the step's total
@@ -447,11 +448,13 @@ class PatternOptimizer:
                                        epoch=self._pat_epoch % 0xFFFFFFF0 + 1)
                 if res is not None:
                     self._pat_epoch += 1
+                    self.laser._edits = getattr(self.laser, "_edits", 0) + 1  # (this update, counted before the key is taken: ANOTHER optimiser's is not in it)
                     self._premade = self._premade_key(rays, KF, want_reg, self._pat_buf)
                     self._merged_last = True
             if res is None:
                 res = ops.pattern_bwd_blur(rd, KF, self.sigma, s0, s1, tsum, tsor, g2, reg_w, ws, bk, bs, loss_in=None if dot is not None else loss_slots,
                                            loss_div=float(S), adam=aa, scratch=self._scratch)
+                self.laser._edits = getattr(self.laser, "_edits", 0) + 1  # (a native update of the pattern: torch's version counter does not see it)
             gd, gr, val = res
             loss = val[1]
         rays.grad = grad

@@ -836,6 +836,25 @@ def test_one_pattern_launch_between_two_renders(monkeypatch):
             assert s2 == 6.0 and o2.step_paths["cache_k9"] == 12
             torch.testing.assert_close(r1, r2, rtol=1e-4, atol=1e-5)
             assert l1 == pytest.approx(l2, rel=1e-4, abs=1e-7)
+    # two optimisers taking turns on ONE laser: each one's update is a native edit the other's key sees (the laser's edit count) — same run as with
+    # the two launches
+    def duet(merged):
+        monkeypatch.setenv("FFX_PATTERN_STEP", "1" if merged else "0")
+        wl = _small()
+        kw = dict(sigma=10.0, tex_size=(96, 96), spp=4, lr=5e-3, reg_weight=0.1, samples_per_step=1)
+        oa = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, base_seed=51, **kw)
+        ob = PatternOptimizer(wl.mi_scene, wl.ff_scene, wl.laser, base_seed=52, **kw)
+        assert oa.laser is ob.laser  # (one pattern tensor — the second constructor's — and an Adam state per optimiser)
+        out = []
+        for k in range(6):
+            out.append(float((oa if k % 2 == 0 else ob).step()["loss"]))
+        return wl.laser._rays.detach().clone(), out
+
+    monkeypatch.setenv("FFX_DETERMINISTIC", "1")
+    rd1, ld1 = duet(True)
+    rd0, ld0 = duet(False)
+    monkeypatch.delenv("FFX_DETERMINISTIC")
+    assert torch.equal(rd1, rd0) and ld1 == ld0
     # an edit behind torch's back: the texture made ahead is stale, the next launch notices, the watch raises
     *_, opt = run(True, "linear", steps=2)
     with torch.no_grad():
