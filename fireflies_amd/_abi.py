@@ -205,6 +205,7 @@ PROTOTYPES = {
     # pts, zero, n_zero, tex, rays_kept, check_kept, sync, epoch, stream
     "ffx_pattern_step": (c_i, [c_p, c_i, PF, c_f, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_f, C.POINTER(AdamArgs),
                                c_p, c_p, C.c_long, c_p, c_p, c_i, c_p, C.c_uint32, c_p]),
+    "ffx_scene_refit_top": (c_i, [c_p, C.POINTER(BvhInfo), c_p]),
     "ffx_adam_clamp_step": (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, PF, PF, c_f, c_f, c_i, c_p, c_p]),
     "ffx_splat_dense_fwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p]),
     "ffx_splat_dense_bwd": (c_i, [c_p, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),

@@ -171,6 +171,8 @@ extern "C" int ffx_scene_randomize_h(int n_samples, const uint64_t *seeds, const
 // The reference pushes a randomisation key by key through Mitsuba's parameter map (fireflies/scene.py:243-342) and lets
 // params.update() (scene.py:384) rebuild; here the key writes are compiled into `ops` once and a sample is: copy the template
 // description, run the ops over the drawn values and chain matrices, copy the material rows, enqueue the re-fit and the pre-pass.
+int ffx_scene_update_h_top(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape, const int32_t *vert_off,
+                           const float *xform, int n_shapes, const ffx_smooth *smooth, int top, ffx_stream s); // ffx_scene.hip
 extern "C" int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, const float *chain, const float *chain_unc, const int32_t *frames,
                                 const ffx_scene_desc *tmpl, ffx_scene_desc *sd_out, float *mat_rows, float *xform, int32_t *vert_off,
                                 const ffx_step_geom *geom, int prepare_apex, ffx_stream stream) {
@@ -229,7 +231,9 @@ extern "C" int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, 
       if (frames[s] >= 0) vert_off[s] = plan->frame_base[s] + frames[s] * plan->frame_stride[s];
   if (!geom) return FFX_OK;
   if (!geom->bvh || !geom->info || !geom->src_verts || !geom->tris || !geom->tri_shape) FFX_FAIL(FFX_ERR_ARG, "scene_step_h: incomplete geometry block");
-  const int rc = ffx_scene_update_h(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth, stream);
-  if (rc != FFX_OK || !prepare_apex) return rc;
+  // prepare_apex: bit 0 — the pre-pass behind the re-fit; bit 1 (FFX_STEP_DEFER_TOP) — the re-fit leaves the top of the tree to ffx_scene_refit_top
+  const int rc = ffx_scene_update_h_top(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth,
+                                        (prepare_apex & 2) ? 1 : 0, stream);
+  if (rc != FFX_OK || !(prepare_apex & 1)) return rc;
   return ffx_apex_prepare(geom->bvh, geom->info, sd_out, stream);
 }

@@ -425,8 +425,28 @@ static int refit_fused_enabled() {
   return !(e && strcmp(e, "levels") == 0);
 }
 
+// top: 0 = the whole update; 1 = everything but the top of the tree (the treelets' records, boxes and nodes: all the pre-pass reads) — the caller owes
+// ffx_scene_refit_top before anything walks the tree; 2 = the top alone.  (1 and 2 only with the fused kernel's two-launch form, the default; every
+// other configuration does the whole update at 0 and 1 and nothing at 2: the top is then already in place.)
 static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
-                             const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s, bool host_tab) {
+                             const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s, bool host_tab, int top = 0) {
+  if (top == 2) {
+    if (!bvh || !info) FFX_FAIL(FFX_ERR_ARG, "scene_refit_top: bad argument");
+#if FFX_WIDE_F32
+    if (refit_fused_enabled() && refit_split_enabled() && info->off_plan != 0 && info->n_treelets > 0 && info->off_tq != 0) {
+      char *b = (char *)bvh;
+      SmoothTab sm0;
+      memset(&sm0, 0, sizeof sm0);
+      ShapeTabH tab0;
+      hipLaunchKernelGGL(k_scene_update_fused<true>, dim3(1), dim3(FUSED_BLOCK), 0, (hipStream_t)s, (BvhNode *)(b + info->off_nodes), (TriRec *)(b + info->off_recs),
+                         (const int32_t *)(b + info->off_order), (WideChild *)(b + info->off_tq), (WideChild *)(b + info->off_wnodes), (const int32_t *)(b + info->off_wsrc),
+                         (int32_t *)(b + info->off_plan), info->n_treelets, info->plan_ints - 1, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                         (const int32_t *)nullptr, (const float *)nullptr, 1, tab0, sm0, 2);
+      FFX_CHECK_LAUNCH("scene_refit_top");
+    }
+#endif
+    return FFX_OK;
+  }
   if (!bvh || !info || !src_verts || !tris || !tri_shape || !vert_off || !xform || n_shapes < 1) FFX_FAIL(FFX_ERR_ARG, "scene_update: bad argument");
   if (host_tab && n_shapes > FFX_MAX_SHAPES_H) FFX_FAIL(FFX_ERR_UNSUPPORTED, "scene_update_h: more than %d shapes", FFX_MAX_SHAPES_H);
   if (info->n_tris < 1 || info->n_nodes < 1 || info->n_levels < 1 || info->n_levels > FFX_MAX_LEVELS)
@@ -477,7 +497,7 @@ static int scene_update_impl(void *bvh, const ffx_bvh_info *info, const float *s
     const int32_t *wsrc = (const int32_t *)(base + info->off_wsrc);
     int32_t *plan = (int32_t *)(base + info->off_plan);
     const int split = refit_split_enabled();
-    for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+    for (int pass = 0; pass < (split ? (top == 1 ? 1 : 2) : 1); ++pass) {
       const int mode = split ? pass + 1 : 0;
       const dim3 grid(mode == 2 ? 1 : info->n_treelets);
       if (host_tab)
@@ -534,6 +554,14 @@ extern "C" int ffx_scene_update(void *bvh, const ffx_bvh_info *info, const float
   return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s, false);
 }
 
+// (ffx_rng.cpp, ffx_scene_step_h: the whole update, or — top = 1 — without the top of the tree; not part of the C ABI)
+int ffx_scene_update_h_top(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape, const int32_t *vert_off,
+                           const float *xform, int n_shapes, const ffx_smooth *smooth, int top, ffx_stream s) {
+  return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s, true, top);
+}
+extern "C" int ffx_scene_refit_top(void *bvh, const ffx_bvh_info *info, ffx_stream s) {
+  return scene_update_impl(bvh, info, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, s, true, 2);
+}
 extern "C" int ffx_scene_update_h(void *bvh, const ffx_bvh_info *info, const float *src_verts, const int32_t *tris, const int32_t *tri_shape,
                                   const int32_t *vert_off, const float *xform, int n_shapes, const ffx_smooth *smooth, ffx_stream s) {
   return scene_update_impl(bvh, info, src_verts, tris, tri_shape, vert_off, xform, n_shapes, smooth, s, true);

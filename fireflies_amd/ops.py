@@ -595,6 +595,12 @@ class DeviceGeometry:
         self._side_handles = {}
         self._last_spp = 64  # samples per pixel of the last render call (how deep update() lets the poses run ahead: _ring)
         self._upd_done = [None] * n_copies   # event: the refit of blob i has been enqueued up to here (side stream)
+        self._top = [None] * n_copies        # the top of blob i's tree: None = in place; True = owed (FFX_STEP_DEFER_TOP); a stream handle = launched there (_top_ev)
+        self._top_ev = [None] * n_copies
+        # (measured, 100-step render loops of the vocal fold: 1 / 4 / 8 spp +11 / +17 / +16 % with the top deferred, 10 / 12 / 16 spp -4 / -2 / -4 %, 64 spp
+        # unchanged — a render of a few samples waits for the chain, a longer one for the GPU, where the extra launch in front of it only costs: deferred
+        # while the last render had at most FFX_DEFER_TOP samples per pixel, default 8; 0: never)
+        self._defer_top_spp = int(os.environ.get("FFX_DEFER_TOP", "8"))
         self._apex = [None] * n_copies       # apex_key of what blob i's apex areas hold (None: nothing usable)
         self._apex_written = [None] * n_copies  # (stream handle, event) behind the call whose own pre-pass last wrote blob i's apex areas
         self._apex_writer_pending = False
@@ -640,6 +646,24 @@ class DeviceGeometry:
         ev = self._upd_done[self._cur] if self._async else None
         if ev is not None:
             _stream_obj(self._didx).wait_event(ev)
+        if self._async:
+            # (round 6) a natively pushed pose leaves the TOP of its tree to the first call that walks it (FFX_STEP_DEFER_TOP: the chain a short render
+            # waits for is one dependent launch shorter; the top — one workgroup — runs here, on the reader's own stream, beside the previous render).
+            # A second reader on another stream waits for that launch.
+            i = self._cur
+            tp = self._top[i]
+            if tp is True:
+                so = _stream_obj(self._didx)
+                self._call("ffx_scene_refit_top", _dev(self._blobs[i], torch.uint8, "blob"), C.byref(self.info), _stream(self._didx))
+                e = self._top_ev[i]
+                if e is None:
+                    e = self._top_ev[i] = torch.cuda.Event()
+                e.record(so)
+                self._top[i] = so.cuda_stream
+            elif tp is not None:
+                so = _stream_obj(self._didx)
+                if tp != so.cuda_stream:
+                    so.wait_event(self._top_ev[i])
 
     def _release(self):
         if self.device.type == "cuda":
@@ -730,6 +754,7 @@ class DeviceGeometry:
         ev = self._upd_done[nxt]
         if ev is None:
             ev = self._upd_done[nxt] = torch.cuda.Event()
+        self._top[nxt] = None  # (this path re-fits the whole tree)
         if self.timing is None and not on_device:
             # (the two launch calls take the side stream's handle as an argument: making it the current stream first — a context manager and
             # two current-stream queries — cost 10 us of the 65 this method took per step; the timed / device-table paths keep that form)
@@ -770,8 +795,12 @@ class DeviceGeometry:
         sh = self._side_handle_of(side)
         self._apex[nxt] = None
         self._apex_written[nxt] = None
+        self._top[nxt] = None
         if self.timing is None:
-            sd = launch(nxt, sh, 1)
+            defer = self._last_spp <= self._defer_top_spp
+            sd = launch(nxt, sh, 3 if defer else 1)  # (bit 1: FFX_STEP_DEFER_TOP — _acquire launches the top in front of the first reader)
+            if defer:
+                self._top[nxt] = True
             self._apex[nxt] = apex_key(sd)
         else:  # (bench.py's per-launch event pairs: around the re-fit alone, as on the Python path; the pre-pass as a call of its own behind them)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -785,7 +785,15 @@ int ffx_scene_step_h(const ffx_step_plan *plan /*[host]*/, const float *values /
                      const float *chain_uncentred /*[host][n_ents,16]*/, const int32_t *frames /*[host][n_shapes] or NULL*/,
                      const ffx_scene_desc *tmpl /*[host]*/, ffx_scene_desc *sd_out /*[host]*/, float *mat_rows /*[host] in/out, or NULL*/,
                      float *xform /*[host][n_shapes,16] in/out*/, int32_t *vert_off /*[host][n_shapes] in/out*/,
-                     const ffx_step_geom *geom /*[host] or NULL*/, int prepare_apex, ffx_stream stream);
+                     const ffx_step_geom *geom /*[host] or NULL*/, int prepare_apex /*bit 0: the pre-pass behind the re-fit; bit 1: FFX_STEP_DEFER_TOP*/,
+                     ffx_stream stream);
+/* FFX_STEP_DEFER_TOP (ABI 10): the re-fit stops below the top of the tree — the treelets' records, boxes and nodes, which is all the pre-pass reads — and
+ * the caller owes ffx_scene_refit_top(bvh, info, stream) on a stream ordered behind this call before anything WALKS the tree of that blob (a render, a
+ * trace, a re-tracing adjoint).  The chain of dependent launches a short render waits for — re-fit, re-fit of the top, count, scan, fill — is one launch
+ * shorter; the top (one workgroup, ~10 us of latency) runs on the render's own stream, beside the previous render.  Same tree, bit for bit.  (Only the
+ * default two-launch re-fit has a top of its own: with FFX_REFIT=fused / levels the flag changes nothing and ffx_scene_refit_top launches nothing.) */
+#define FFX_STEP_DEFER_TOP 2
+int ffx_scene_refit_top(void *bvh /*[dev]*/, const ffx_bvh_info *info /*[host]*/, ffx_stream stream);
 
 size_t ffx_render_cache_bytes(int width, int height, int spp); /* Lambert scenes (mat_stride 0 / 3) */
 /* the same for any scene: with material rows the cache holds a second footprint per pixel (the part of the BSDF

@@ -2452,6 +2452,11 @@ int ffx_scene_step_h(const ffx_step_plan *plan, const float *values, const float
   if (!geom) return FFX_OK;
   if (!geom->bvh || !geom->info || !geom->src_verts || !geom->tris || !geom->tri_shape) FAIL(FFX_ERR_ARG, "scene_step_h: incomplete geometry block");
   int rc = ffx_scene_update_h(geom->bvh, geom->info, geom->src_verts, geom->tris, geom->tri_shape, vert_off, xform, plan->n_shapes, geom->smooth, stream);
-  if (rc != FFX_OK || !prepare_apex) return rc;
+  if (rc != FFX_OK || !(prepare_apex & 1)) return rc; /* (bit 1, FFX_STEP_DEFER_TOP: this library's update has no separate top) */
   return ffx_apex_prepare(geom->bvh, geom->info, &sd, stream);
+}
+int ffx_scene_refit_top(void *bvh, const ffx_bvh_info *info, ffx_stream stream) {
+  (void)stream;
+  if (!bvh || !info) FAIL(FFX_ERR_ARG, "scene_refit_top: bad argument");
+  return FFX_OK; /* (the whole tree was re-fitted by the update) */
 }

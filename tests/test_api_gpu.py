@@ -896,6 +896,43 @@ def test_multi_sample_steps_on_two_render_streams_and_streams_shared_by_scenes(m
     assert a.geom._side is b.geom._side and a.geom._side is ops.shared_streams(a.geom.device, "side", 1)[0]
 
 
+def test_the_top_of_the_tree_is_refitted_in_front_of_the_first_reader_when_renders_are_short(monkeypatch):
+    """FFX_STEP_DEFER_TOP (round 6): while the renders have at most 8 samples per pixel a natively pushed pose leaves the top of its tree to the first call
+    that walks it — the chain a short render waits for is one dependent launch shorter (1 / 4 / 8 spp: +11 / +17 / +16 % renders/s) — and that call's
+    stream launches ffx_scene_refit_top itself; a reader on another stream waits for that launch.  Same images and depth maps as with the whole re-fit in
+    the chain (FFX_DEFER_TOP=0), bit for bit; at 64 spp nothing is deferred."""
+    from fireflies_amd import ops
+
+    calls = {"top": 0}
+    real = ops.DeviceGeometry._call
+
+    def counting(self, name, *a):
+        if name == "ffx_scene_refit_top":
+            calls["top"] += 1
+        return real(self, name, *a)
+
+    monkeypatch.setattr(ops.DeviceGeometry, "_call", counting)
+
+    def run(defer):
+        monkeypatch.setenv("FFX_DEFER_TOP", defer)
+        calls["top"] = 0
+        wl = _small()
+        torch.manual_seed(3)
+        random.seed(3)
+        out = []
+        for k, spp in enumerate((4, 4, 1, 8, 4, 64, 64, 4, 4)):
+            wl.ff_scene.randomize()
+            if k == 4:  # a depth map first (the caller's stream), then the render (a render stream): two readers of one pose on two streams
+                out.append(ff.graphics.depth.from_camera(wl.mi_scene, spp=1).clone())
+            out.append(mi.render(wl.mi_scene, spp=spp, seed=100 + k).torch().clone())
+        return out, calls["top"], dict(wl.mi_scene.update_paths)
+
+    a, n_a, paths = run("8")
+    b, n_b, _ = run("0")
+    assert paths["native"] >= 8 and n_b == 0 and 4 <= n_a <= 7, (paths, n_a, n_b)  # (poses pushed behind a 64-spp render are not deferred)
+    assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_filtered_cache_overflow_grows_to_the_dense_layout_before_it_re_traces(monkeypatch):
     """The filtered film's adjoint cache is an arena with a share of the blocks; a pattern that lights more of the film than that overflows it (config 5
     does, on its denser poses).  The optimiser's answer, in this order: the updates of the affected steps are skipped (rays and Adam state intact), the scene
