@@ -454,7 +454,20 @@ class _EventPair:
         return False
 
 
-_ENV_GET = os.environ.get
+# the pre-pass knobs are read per call (a test flips them mid-process) — straight from os.environ's own dict where it has one (posix: bytes -> bytes;
+# os.environ.get's encode + KeyError path was 0.6 us a look-up, fourteen of them per loop step: a tenth of the host's time at 4 spp)
+_ENV_DATA = getattr(os.environ, "_data", None)
+_ENV_NAMES = ("FFX_BINS", "FFX_BIN_TILE", "FFX_BIN_TILE_PROJ", "FFX_BIN_SPOT_N", "FFX_BIN_CAP", "FFX_SHADOW_CLEAR", "FFX_ENVELOPE")
+if isinstance(_ENV_DATA, dict) and os.name == "posix":
+    _ENV_KEYS = tuple(n.encode() for n in _ENV_NAMES)
+
+    def _apex_env():
+        g = _ENV_DATA.get
+        return tuple(g(k) for k in _ENV_KEYS)
+else:
+    def _apex_env():
+        g = os.environ.get
+        return tuple(g(n) for n in _ENV_NAMES)
 
 
 def apex_key(sd=None, cam=None):
@@ -463,7 +476,7 @@ def apex_key(sd=None, cam=None):
     field of view, film / texture size, the spot's cone — as the exact floats the library reads"""
     if sd is not None:
         k = getattr(sd, "_apex_key", None)  # (a description is never modified once built: mi.Scene makes a new one per pose — 5 us per call otherwise)
-        if k is not None and k[1] == (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"), _ENV_GET("FFX_ENVELOPE")):
+        if k is not None and k[1] == _apex_env():
             return k[0]
     c = sd.cam if sd is not None else cam
     # (the structs' bytes: ~1 us each — tuples of their 32 floats were 10 us per render call)
@@ -474,7 +487,7 @@ def apex_key(sd=None, cam=None):
         key += [(C.string_at(C.addressof(sd.spot), 64), sd.spot.cutoff_deg, int(sd.shadows)) if sd.spot.enabled else (None, int(sd.shadows))]
     else:
         key += [None, None]
-    env = (_ENV_GET("FFX_BINS"), _ENV_GET("FFX_BIN_TILE"), _ENV_GET("FFX_BIN_TILE_PROJ"), _ENV_GET("FFX_BIN_SPOT_N"), _ENV_GET("FFX_BIN_CAP"), _ENV_GET("FFX_SHADOW_CLEAR"), _ENV_GET("FFX_ENVELOPE"))
+    env = _apex_env()
     key = tuple(key) + env
     if sd is not None and getattr(sd, "_frozen", False):  # (only descriptions whose maker promises not to touch them again: mi.Scene.scene_desc)
         sd._apex_key = (key, env)
