@@ -58,7 +58,8 @@
  *     device instead of ffx_torch_rand_h) and then FFX_PREDRAW=0, FFX_SIDE_STREAMS=n (a side stream per BVH blob copy: a measured loss, default 1),
  *     FFX_PATTERN_STEP=0 (the optimiser's step with ffx_pattern_bwd_blur + ffx_pattern_fwd_blur instead of ffx_pattern_step), FFX_K9_L1=0 (ffx_l1_value_grad +
  *     ffx_render_bwd_cached instead of ffx_render_bwd_cached_l1), FFX_STEP_STREAMS=1 (the fused renders of a multi-sample step one after the other on the
- *     caller's stream instead of in turn on the scene's two render streams); ffx_pattern_step itself reads FFX_ADAM_POW_CACHE=0 (pow() every step);
+ *     caller's stream instead of in turn on the scene's two render streams), FFX_DEFER_TOP=n (FFX_STEP_DEFER_TOP while the last render had at most n samples
+ *     per pixel; default 8, 0: never); ffx_pattern_step itself reads FFX_ADAM_POW_CACHE=0 (pow() every step);
  *     bench.py reads FFX_DIST_BACKEND and FFX_BENCH_TIMED_STEPS.
  */
 #ifndef FFX_H
