@@ -1626,7 +1626,7 @@ def test_the_pattern_side_of_a_step_as_one_launch(oracle, n, size, sigma):
             ab = ops.adam_args(r_b, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=g_b, dot=dot_b,
                                guard=hd_b if variant == "guard" else None)
             res = ops.pattern_step(r_b, KF, sigma, s0, s1, buf_b, gt_b, w, ks, bs, ab, acc_b[1:-1], sync, rays_kept=kept, check_kept=k > 0,
-                                   loss_in=None if dot_b else sl_b, loss_div=4.0)
+                                   loss_in=None if dot_b else sl_b, loss_div=4.0, epoch=k + 1)
             assert res is not None
             gd_b, gr_b, val_b = res
             what = f"{variant} step {k}"
@@ -1642,7 +1642,7 @@ def test_the_pattern_side_of_a_step_as_one_launch(oracle, n, size, sigma):
             assert torch.equal(kept[(k + 1) & 1], r_b), what  # (launch k + 1 of this sync buffer: its parity's half)
             sw = sync.view(torch.int32).cpu().numpy()
             flags = sw[768::128]
-            assert (sw[:8] == 0).all() and sw[256] == 0 and sw[512] == 0 and len(flags) == 64 and flags[0] != 0 and (flags == flags[0]).all(), (what, sw[:8], flags)
+            assert (sw[:8] == 0).all() and sw[256] == 0 and sw[512] == 0 and len(flags) == 64 and (flags == k + 1).all(), (what, sw[:8], flags)
             # (nothing stale, no time-out; the counters re-armed; the 64 flags at this launch's epoch)
             if variant == "guard":
                 assert (sw[18:34] == hdr).all(), what
@@ -1657,7 +1657,7 @@ def test_the_pattern_side_of_a_step_as_one_launch(oracle, n, size, sigma):
             acc_b.fill_(0.0)
             ab = ops.adam_args(r_b, m_b, v_b, st_b, counter, 5e-3, 0.9, 0.999, 1e-8, KFi, 0.05, 0.95, 2, grad_div=4.0, grad_out=torch.empty_like(r_b))
             assert ops.pattern_step(r_b, KF, sigma, s0, s1, buf_b, acc_b[1:1 + T].view(s1, s0), 0.1, ks, bs, ab, acc_b[1:-1], sync, rays_kept=kept, check_kept=True,
-                                    loss_in=acc_b[1 + T:1 + T + n_slots], loss_div=4.0) is not None
+                                    loss_in=acc_b[1 + T:1 + T + n_slots], loss_div=4.0, epoch=6) is not None
             assert int(sync.view(torch.int32)[4]) == 1
     # declined shapes: a footprint beyond the launch's LDS window, another kernel size
     r, m, v, st = fresh()
