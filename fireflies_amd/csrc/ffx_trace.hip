@@ -2102,6 +2102,9 @@ __device__ __forceinline__ bool bins_shadow(const BinsK &bk, const int a, const 
     const float v = fmaf(Nc.x, sdir.x, fmaf(Nc.y, sdir.y, Nc.z * sdir.z));
     if ((active & ~m_le(v, 1.0f)) == 0ull) { occluded = 0ull; FFX_STAT(a == 1 ? 37 : 47); return true; }
   }
+#ifdef FFX_EXP_NO_SPOT_WALK // timing experiment: what the any-hit stage of the packets the envelope does NOT settle costs (they count as unoccluded)
+  if (a == 2) { occluded = 0ull; return true; }
+#endif
   uint32_t mnx = msel(active, __float_as_uint(fx), 0x7f800000u), mny = msel(active, __float_as_uint(fy), 0x7f800000u);
   uint32_t mxx = msel(active, __float_as_uint(fx), 0u), mxy = msel(active, __float_as_uint(fy), 0u);
   wave_reduce_minmax4(mnx, mny, mxx, mxy);
