@@ -2087,8 +2087,9 @@ __device__ __forceinline__ bool bins_shadow(const BinsK &bk, const int a, const 
   const float iz = __builtin_amdgcn_rcpf(Z);
   const float fx = fmaf(M[0], sdir.x, fmaf(M[1], sdir.y, M[2] * sdir.z)) * iz, fy = fmaf(M[3], sdir.x, fmaf(M[4], sdir.y, M[5] * sdir.z)) * iz;
   const float gx = (float)bk.g[a].nx, gy = (float)bk.g[a].ny;
-  // inside the grid (NaN fails): everything else is the tree's business
-  const wmask inside = m_gt(Z, 0.f) & m_ge(fx, 0.f) & m_ge(fy, 0.f) & m_lt(fx, gx) & m_lt(fy, gy);
+  // inside the grid (NaN fails): everything else is the tree's business.  0 <= f < g as ONE unsigned comparison of the floats' bits: non-negative floats
+  // order like their bits, negative ones (and NaN) have larger bits than any grid size (-0.0 counts as outside: the tree gives the same answer)
+  const wmask inside = m_gt(Z, 0.f) & m_ult(__float_as_uint(fx), __float_as_uint(gx)) & m_ult(__float_as_uint(fy), __float_as_uint(gy));
   if ((active & ~inside) != 0ull) return false;
   // (round 6) the grid's ENVELOPE (ffx_common.h FFX_ENV_SUB, k_bin_env): the cell of each sample's image point holds a plane N . (X - E) = 1 in
   // front of every triangle the tile lists over that cell, pulled forward past the ignored tail of a shadow ray.  N . sdir <= 1: the segment
